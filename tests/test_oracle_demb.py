@@ -1,0 +1,294 @@
+"""CPU tests that pin the path-A oracle (oracle/demb_oracle.c + oracle/oracle.py)
+against the reference's own fixtures and invariants:
+
+* hash / digest / empty digest: golden vectors generated from the reference's
+  Python copy of the hash (tests/golden/gen_demb_golden.py);
+* segmented unique: the invariants of corelib/dynamicemb/test/test_unique_op.py:81-150;
+* table insert / lookup / evict: the invariants of
+  test/unit_tests/table_operation/test_table_operation.py (round trip, bucket
+  rule, eviction takes the lowest score, LOCKED protection inside one call);
+* 11-key fixture of test_batched_dynamic_embedding_tables_v2.py:1517-1522 with
+  the DEBUG initializer closed form of test/unit_tests/debug.py:157-224.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_hash_golden():
+    g = json.load(open(os.path.join(GOLD, "demb_hash_golden.json")))
+    for r in g["rows"]:
+        k = int(r["key"])
+        assert orc.fmix64(k) == int(r["fmix64"])
+        assert orc.digest(k) == r["digest"]
+        assert orc.hash64(k) == int(r["fmix64"]) & 0x7FFFFFFFFFFFFFFF
+    assert orc.empty_digest() == g["empty_digest"]
+
+
+def test_reserved_keys_invalid():
+    t = orc.OracleTable([256])
+    bad = np.array([orc.EMPTY_KEY, orc.RECLAIM_KEY, orc.LOCKED_KEY, 0xFFFFFFFFFFFFFFFC], dtype=np.uint64)
+    idx, res, _ = t.insert(bad, np.zeros(4, np.int64), np.ones(4, np.uint64))
+    assert (idx == -1).all() and (res == orc.RES_ILLEGAL).all()
+    _, f, i = t.lookup(bad, np.zeros(4, np.int64))
+    assert not f.any() and (i == -1).all()
+
+
+def _rand_keys(rng, n, hi=1 << 40):
+    return rng.choice(hi, size=n, replace=False).astype(np.int64)
+
+
+def test_unique_invariants():
+    rng = np.random.default_rng(0)
+    T = 3
+    lens = [1000, 0, 2500]
+    keys = np.concatenate([rng.integers(0, 300, size=n) for n in lens]).astype(np.int64)
+    seg = np.concatenate([[0], np.cumsum(lens)])
+    uk, oi, to, fr = orc.segmented_unique(keys, seg, count_freq=True)
+    # test_unique_op.py:81-105
+    assert (uk.view(np.int64)[oi] == keys).all()
+    assert (np.diff(to) >= 0).all() and to[-1] == uk.size
+    for t in range(T):
+        a = keys[seg[t]:seg[t + 1]]
+        assert to[t + 1] - to[t] == np.unique(a).size
+        # first-occurrence order (this build's deterministic choice)
+        _, first = np.unique(a, return_index=True)
+        assert (uk.view(np.int64)[to[t]:to[t + 1]] == a[np.sort(first)]).all()
+    assert fr.sum() == keys.size
+    # same key in two tables -> two uniques (test_unique_op.py:110-150)
+    uk2, _, to2, _ = orc.segmented_unique(np.array([5, 5, 5], np.int64), np.array([0, 2, 3]))
+    assert uk2.size == 2 and list(to2) == [0, 1, 2]
+    # weighted frequencies
+    _, oi3, _, fr3 = orc.segmented_unique(np.array([7, 9, 7], np.int64), np.array([0, 3]),
+                                          in_freq=np.array([2, 3, 4]), count_freq=True)
+    assert list(fr3) == [6, 3] and list(oi3) == [0, 1, 0]
+
+
+def test_insert_lookup_roundtrip_and_bucket_rule():
+    rng = np.random.default_rng(1)
+    C = 128
+    t = orc.OracleTable([4096, 1024], bucket_capacity=C)
+    keys = _rand_keys(rng, 3000)
+    tids = (rng.random(3000) < 0.25).astype(np.int64)
+    scores = rng.integers(1, 1 << 30, size=3000).astype(np.uint64)
+    idx, res, so = t.insert(keys, tids, scores, orc.POLICY_ASSIGN)
+    assert (res == orc.RES_INSERT).all() or ((res == orc.RES_INSERT) | (res == orc.RES_EVICT)).all()
+    so2, found, idx2 = t.lookup(keys, tids)
+    ok = idx >= 0
+    assert found[ok].all() and (idx2[ok] == idx[ok]).all()
+    assert (so2[ok].astype(np.uint64) == scores[ok]).all()
+    # bucket rule kernels.cuh:107-125: slot // C == (hash % table_cap) // C
+    for k, tid, i in zip(keys[:200], tids[:200], idx[:200]):
+        cap = t.per_table_capacity[tid]
+        assert i // C == (orc.hash64(int(k)) % cap) // C
+    # key <-> slot bijection per table
+    for tid in (0, 1):
+        s = idx[(tids == tid) & ok]
+        assert np.unique(s).size == s.size
+    assert t.bucket_sizes.sum() == (res == orc.RES_INSERT).sum()
+    # unknown keys are not found
+    _, f3, i3 = t.lookup(keys + (1 << 41), tids)
+    assert not f3.any() and (i3 == -1).all()
+
+
+def test_eviction_takes_lowest_score_and_locks_protect_new_entries():
+    C = 16
+    t = orc.OracleTable([C], bucket_capacity=C)  # one bucket
+    keys = np.arange(100, 100 + C, dtype=np.int64)
+    scores = np.arange(10, 10 + C, dtype=np.uint64)
+    idx, res, _ = t.insert(keys, np.zeros(C, np.int64), scores, orc.POLICY_ASSIGN)
+    assert (res == orc.RES_INSERT).all() and sorted(idx) == list(range(C))
+    # one more key evicts the min score (key 100, score 10)
+    idx2, res2, _, ev = t.insert(np.array([999], np.int64), np.zeros(1, np.int64),
+                                 np.array([50], np.uint64), orc.POLICY_ASSIGN, evict_out=True)
+    assert res2[0] == orc.RES_EVICT and ev[0][0] == 100 and ev[2][0] == 10 and ev[1][0] == idx2[0]
+    assert idx2[0] == idx[0]
+    _, f, _ = t.lookup(np.array([100, 999], np.int64), np.zeros(2, np.int64))
+    assert list(f) == [False, True]
+    # a full batch of C+1 new keys in ONE call: C succeed by evicting, the last is BUSY
+    newk = np.arange(5000, 5000 + C + 1, dtype=np.int64)
+    idx3, res3, _, ev3 = t.insert(newk, np.zeros(C + 1, np.int64), np.full(C + 1, 7, np.uint64),
+                                  orc.POLICY_ASSIGN, evict_out=True)
+    assert (res3[:C] == orc.RES_EVICT).all() and res3[C] == orc.RES_BUSY and idx3[C] == -1
+    assert ev3[1][-1] == -(C + 1) and ev3[0][-1] == newk[C]
+    # pinned slots (ref counter > 0) are never evicted
+    t.counter[:] = 1
+    _, res4, _ = t.insert(np.array([31337], np.int64), np.zeros(1, np.int64), np.array([1], np.uint64),
+                          orc.POLICY_ASSIGN)
+    assert res4[0] == orc.RES_BUSY
+
+
+def test_erase_and_reclaim():
+    C = 16
+    t = orc.OracleTable([C], bucket_capacity=C)
+    keys = np.arange(1, C + 1, dtype=np.int64)
+    idx, _, _ = t.insert(keys, np.zeros(C, np.int64), np.full(C, 5, np.uint64), orc.POLICY_ASSIGN)
+    e = t.erase(keys[:3], np.zeros(3, np.int64))
+    assert (e == idx[:3]).all() and t.bucket_sizes[0] == C - 3
+    _, f, _ = t.lookup(keys, np.zeros(C, np.int64))
+    assert list(f[:3]) == [False] * 3 and f[3:].all()
+    # tombstone has score 0 -> reused first, lowest slot first (types.cuh:398-512)
+    i2, r2, _ = t.insert(np.array([77], np.int64), np.zeros(1, np.int64), np.array([9], np.uint64),
+                         orc.POLICY_ASSIGN)
+    assert r2[0] == orc.RES_RECLAIM and i2[0] == min(idx[:3]) and t.bucket_sizes[0] == C - 2
+
+
+def test_policies():
+    t = orc.OracleTable([256])
+    k = np.array([42], np.int64)
+    z = np.zeros(1, np.int64)
+    t.insert(k, z, np.array([5], np.uint64), orc.POLICY_ASSIGN)
+    so, f, _ = t.lookup(k, z, np.array([3], np.uint64), orc.POLICY_ACCUMULATE)
+    assert f[0] and so[0] == 8
+    so, _, _ = t.lookup(k, z)  # CONST returns the stored score
+    assert so[0] == 8
+    so, _, _ = t.lookup(k, z, None, orc.POLICY_GLOBAL_TIMER, timer=123456)
+    assert so[0] == 123456
+    t2 = orc.OracleTable([256], num_scores=2)
+    t2.insert(k, z, np.array([2], np.uint64), orc.POLICY_LRU_LFU, timer=1000)
+    so, _, _ = t2.lookup(k, z, np.array([3], np.uint64), orc.POLICY_LRU_LFU, timer=2000)
+    assert so[0] == 5
+    _, _, sc = t2._view()
+    assert 2000 in sc[..., 0] and 5 in sc[..., 1]
+
+
+def test_deterministic_insert_is_order_independent():
+    rng = np.random.default_rng(3)
+    keys = _rand_keys(rng, 5000)
+    tids = np.zeros(5000, np.int64)
+    sc = rng.integers(1, 1000, size=5000).astype(np.uint64)
+    a = orc.OracleTable([2048], bucket_capacity=128)
+    b = orc.OracleTable([2048], bucket_capacity=128)
+    ia = a.insert_deterministic(keys, tids, sc, orc.POLICY_ASSIGN)
+    p = rng.permutation(5000)
+    ib = b.insert_deterministic(keys[p], tids, sc[p], orc.POLICY_ASSIGN)
+    assert (ia[p] == ib).all()
+    assert (a.storage == b.storage).all()
+    assert a.bucket_sizes.sum() == 2048  # overfull table: 5000 keys into 2048 slots
+
+
+def test_eleven_key_fixture_debug_closed_form():
+    """test_batched_dynamic_embedding_tables_v2.py:1517-1522 key stream; DEBUG initializer
+    (row = key % 100000) => pooled SUM = sum of keys of the bag (debug.py:157-180)."""
+    indices = np.array([0, 1, 12, 64, 8, 12, 15, 2, 7, 105, 0], np.int64)
+    offsets = np.array([0, 2, 3, 5, 6, 8, 10, 10, 11], np.int64)
+    feature_offsets = np.array([0, 2, 3, 4], np.int64)  # feature_table_map = [0,0,1,2]
+    B, D = 2, 8
+    rng_ = orc.get_table_range(offsets, feature_offsets, B)
+    assert list(rng_) == [0, 6, 10, 11]
+    uk, rev, to, _ = orc.segmented_unique(indices, rng_)
+    assert list(to) == [0, 5, 9, 10]
+    tids = orc.expand_table_ids(to, uk.size)
+    assert list(tids) == [0] * 5 + [1] * 4 + [2]
+    t = orc.OracleTable([2048] * 3)
+    slots = t.insert_deterministic(uk, tids, np.ones(uk.size, np.uint64), orc.POLICY_ASSIGN)
+    assert (slots >= 0).all()
+    unique_embs = orc.debug_init(uk, D)
+    out = orc.gather_pooled(unique_embs, rev, offsets, B, combiner=0)
+    exp = np.zeros((B, 4 * D), np.float32)
+    for i in range(8):
+        f, b = divmod(i, B)
+        exp[b, f * D:(f + 1) * D] = float(indices[offsets[i]:offsets[i + 1]].sum())
+    assert (out == exp).all()
+    assert (orc.gather_pooled_fast(unique_embs, rev, offsets, B, 0) == exp).all()
+    mean = orc.gather_pooled(unique_embs, rev, offsets, B, combiner=1)
+    assert mean[0, 0] == 0.5 and mean[1, 3 * D] == 0.0 and mean[0, 3 * D] == 0.0
+    seq = orc.gather_sequence(unique_embs, rev)
+    assert (seq[:, 0] == indices % 100000).all()
+
+
+def test_reduce_grads_matches_dense_autograd():
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(5)
+    B, F, D, Nu = 6, 3, 8, 20
+    lens = rng.integers(0, 4, size=F * B)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    rev = rng.integers(0, Nu, size=int(offsets[-1])).astype(np.int64)
+    w = torch.randn(Nu, D, dtype=torch.float64, requires_grad=True)
+    for combiner in (0, 1):
+        g = rng.standard_normal((B, F * D)).astype(np.float32)
+        ug = orc.reduce_grads(rev, g, Nu, B, offsets, None, combiner)
+        ugf = orc.reduce_grads_pooled_fast(rev, g, Nu, B, offsets, combiner)
+        # dense autograd of the same pooled forward
+        out = torch.zeros(B, F * D, dtype=torch.float64)
+        rows = []
+        for i in range(F * B):
+            f, b = divmod(i, B)
+            s = w[rev[offsets[i]:offsets[i + 1]]].sum(0)
+            if combiner == 1 and lens[i] > 0:
+                s = s / float(lens[i])
+            rows.append((b, f, s))
+        loss = sum((s * torch.from_numpy(g[b, f * D:(f + 1) * D].astype(np.float64))).sum() for b, f, s in rows)
+        (gw,) = torch.autograd.grad(loss, w)
+        np.testing.assert_allclose(ug, gw.numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(ugf, gw.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_optimizers_match_torch_optim():
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(7)
+    N, D = 16, 8
+    w0 = rng.standard_normal((N, D)).astype(np.float32)
+    gs = [rng.standard_normal((N, D)).astype(np.float32) for _ in range(4)]
+
+    def run_torch(opt_ctor):
+        p = torch.nn.Parameter(torch.from_numpy(w0.copy()))
+        o = opt_ctor([p])
+        for g in gs:
+            p.grad = torch.from_numpy(g.copy())
+            o.step()
+        return p.detach().numpy()
+
+    rows = w0.copy()
+    for g in gs:
+        orc.sgd_update(rows, g, D, 0.3)
+    np.testing.assert_allclose(rows, run_torch(lambda p: torch.optim.SGD(p, lr=0.3)), rtol=1e-6, atol=1e-6)
+
+    rows = np.concatenate([w0.copy(), np.zeros((N, 2 * D), np.float32)], 1)
+    for it, g in enumerate(gs, 1):
+        orc.adam_update(rows, g, D, 0.01, 0.9, 0.999, 1e-8, 0.0, it)
+    # the reference's Adam divides by (sqrt(vhat)+eps) like torch.optim.Adam
+    np.testing.assert_allclose(rows[:, :D], run_torch(lambda p: torch.optim.Adam(p, lr=0.01, eps=1e-8)),
+                               rtol=2e-5, atol=2e-6)
+
+    rows = np.concatenate([w0.copy(), np.zeros((N, D), np.float32)], 1)
+    for g in gs:
+        orc.adagrad_update(rows, g, D, 0.1, 1e-10)
+    np.testing.assert_allclose(rows[:, :D], run_torch(lambda p: torch.optim.Adagrad(p, lr=0.1, eps=1e-10)),
+                               rtol=1e-5, atol=1e-6)
+
+    rows = np.concatenate([w0.copy(), np.zeros((N, 4), np.float32)], 1)
+    for g in gs:
+        orc.rowwise_adagrad_update(rows, g, D, 0.1, 1e-8)
+    G = np.zeros(N, np.float32)
+    w = w0.copy()
+    for g in gs:
+        G += (g * g).mean(1)
+        w -= 0.1 * g / (np.sqrt(G)[:, None] + 1e-8)
+    np.testing.assert_allclose(rows[:, :D], w, rtol=1e-5, atol=1e-6)
+
+
+def test_block_bucketize_routing():
+    rng = np.random.default_rng(11)
+    W, F, B = 4, 2, 3
+    lens = rng.integers(0, 5, size=F * B)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    idx = rng.integers(0, 1000, size=int(offsets[-1])).astype(np.int64)
+    for dist in (1, 2, 0):
+        nl, no, ni, perm = orc.block_bucketize(offsets, idx, W, B, [250, 250], dist)
+        assert nl.sum() == idx.size and no[-1] == idx.size
+        assert sorted(perm) == list(range(idx.size))
+        for j, k in enumerate(idx):
+            p = int(np.searchsorted(no, perm[j], side="right") - 1) // (F * B)
+            if dist == 1:
+                assert p == k % W and ni[perm[j]] == k
+            elif dist == 2:
+                assert p == orc.fmix64(int(k)) % W and ni[perm[j]] == k
+            else:
+                assert p == k // 250 and ni[perm[j]] == k % 250
