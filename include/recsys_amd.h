@@ -1,0 +1,198 @@
+/*
+ * recsys_amd.h -- C ABI of librecsys_amd.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary for the two hot paths of NVIDIA/recsys-examples:
+ *   A. DynamicEmb lookup  -- replaces the pybind11 module `dynamicemb_extensions`
+ *      (corelib/dynamicemb/src/module_bind.cu:33-44); every entry point below cites the
+ *      reference function it stands in for.
+ *   B. HSTU jagged attention -- replaces `hstu_attn_2_cuda.varlen_fwd / varlen_bwd`
+ *      (corelib/hstu/csrc/hstu_attn/hstu_api.cpp:335-725) / `torch.ops.fbgemm.hstu_varlen_{fwd,bwd}_*`.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers (unless a parameter says "host"), sizes, a hipStream_t.
+ *     No torch types.  The caller owns every buffer; nothing is allocated or freed here.
+ *   - every function returns 0 on success, MI355_EINVAL (-1) for a rejected argument,
+ *     MI355_ELAUNCH (-2) for a HIP launch error; mi355_last_error() holds the message
+ *     (thread local).  Per-key failure is DATA (index -1, InsertResult), never an error code,
+ *     as in the reference (src/check.h:40-60; kernels.cuh).
+ *   - everything is asynchronous on `stream`; no entry point synchronises the host.
+ *   - `n_dev` / `nu_dev` (nullable): the element count may live on the device; kernels are
+ *     launched for the upper bound `n` and use min(n, *n_dev).  This removes the host syncs
+ *     the reference API bakes in (h_num_missing, num_evicted.item(), ...).
+ *   - keys are 64-bit (int64 or uint64 bit patterns), indices/offsets int64, as in the reference.
+ *   - dtype codes: 0 = float32, 1 = bfloat16, 2 = float16.
+ *   - scratch comes from the caller: mi355_*_workspace_bytes() gives the size.
+ *
+ * Reference paths are relative to /root/reference/corelib/dynamicemb/ unless noted.
+ */
+#ifndef RECSYS_AMD_H_
+#define RECSYS_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t;
+
+#define MI355_OK 0
+#define MI355_EINVAL (-1)
+#define MI355_ELAUNCH (-2)
+
+/* ScorePolicy: src/table_operation/score.cuh:30-43 (pybind enum table.cu:186-192) */
+enum { MI355_POLICY_CONST = 0, MI355_POLICY_ASSIGN = 1, MI355_POLICY_ACCUMULATE = 2,
+       MI355_POLICY_GLOBAL_TIMER = 3, MI355_POLICY_LRU_LFU = 4 };
+/* InsertResult: src/table_operation/types.cuh:52-61 */
+enum { MI355_RES_INSERT = 0, MI355_RES_RECLAIM = 1, MI355_RES_ASSIGN = 2, MI355_RES_EVICT = 3,
+       MI355_RES_DUPLICATED = 4, MI355_RES_BUSY = 5, MI355_RES_ILLEGAL = 6, MI355_RES_INIT = 7 };
+
+const char* mi355_last_error(void);
+int mi355_abi_version(void);
+
+/* ------------------------------------------------------------------ scored hash table ---- */
+
+/* LinearBucketTable._init_table, scored_hashtable.py:476-495 (keys = Empty, scores = 0,
+ * digests = empty digest).  storage: num_buckets * C * (9 + 8*num_scores) bytes. */
+int mi355_table_init(void* storage, int64_t num_buckets, int64_t bucket_capacity, int64_t num_scores,
+                     hipStream_t stream);
+
+/* table_lookup, src/table_operation/lookup.cu:151-191 + table_lookup_kernel kernels.cuh:81-187.
+ * founds: uint8 (bool), indices: table-relative slot or -1, score_out as the reference.
+ * timer_override != 0 replaces the device clock for GLOBAL_TIMER / LRU_LFU (test hook). */
+int mi355_table_lookup(void* storage, const int64_t* table_bucket_offsets, int64_t bucket_capacity,
+                       int64_t num_scores, int64_t n, const int64_t* n_dev, const void* keys,
+                       const int64_t* table_ids, const void* score_in, int policy, uint64_t timer_override,
+                       int64_t* score_out, uint8_t* founds, int64_t* indices, hipStream_t stream);
+
+/* table_insert / table_insert_and_evict (+ table_unlock_kernel), src/table_operation/insert.cu:36-45,
+ * insert_and_evict.cu:81-93, kernels.cuh:189-585.  Keys must be unique (scored_hashtable.py:148).
+ * num_evicted == NULL -> plain insert; otherwise the evicted (key, index, score, table_id) streams are
+ * compacted (arbitrary order) and *num_evicted (device int64) counts them.
+ * skip (nullable uint8[n]): keys with skip[i] != 0 are ignored (indices[i] untouched). */
+int mi355_table_insert(void* storage, const int64_t* table_bucket_offsets, int64_t bucket_capacity,
+                       int64_t num_scores, int32_t* bucket_sizes, int32_t* counter, int64_t n,
+                       const int64_t* n_dev, const void* keys, const int64_t* table_ids, const void* score_in,
+                       int policy, uint64_t timer_override, const uint8_t* skip, int64_t* indices,
+                       uint8_t* results, int64_t* score_out, int64_t* num_evicted, void* evicted_keys,
+                       int64_t* evicted_indices, int64_t* evicted_scores, int64_t* evicted_table_ids,
+                       hipStream_t stream);
+
+/* table_erase, src/table_operation/erase.cu + table_erase_kernel kernels.cuh:587-652 */
+int mi355_table_erase(void* storage, const int64_t* table_bucket_offsets, int64_t bucket_capacity,
+                      int64_t num_scores, int32_t* bucket_sizes, int64_t n, const void* keys,
+                      const int64_t* table_ids, int64_t* indices, hipStream_t stream);
+
+/* table_update_counter_with_layout, insert_and_evict.cu:27-58,397-430 (main-table region) */
+int mi355_table_update_counter(int32_t* counter, int64_t counter_numel, const int64_t* slot_indices, int64_t n,
+                               const int64_t* n_dev, int32_t delta, const int64_t* table_ids,
+                               const int64_t* table_bucket_offsets, int64_t bucket_capacity, hipStream_t stream);
+
+/* device_timestamp, src/torch_utils.cu:22-40,150 */
+int mi355_device_timestamp(int64_t* out, hipStream_t stream);
+
+/* ------------------------------------------------------------------------ index ops ---- */
+
+/* segmented_unique_cuda, src/unique_op.cu:484-714.  Outputs sized n; table_offsets[T] is the number
+ * of uniques (device).  Unique order = first occurrence inside each table (deterministic). */
+int64_t mi355_segmented_unique_workspace_bytes(int64_t n);
+int mi355_segmented_unique(const void* keys, int64_t n, const int64_t* segmented_range, int64_t num_tables,
+                           const int64_t* input_frequencies, int count_freq, void* unique_keys,
+                           int64_t* output_indices, int64_t* table_offsets, int64_t* freq, void* workspace,
+                           int64_t workspace_bytes, hipStream_t stream);
+
+/* expand_table_ids_cuda, src/unique_op.cu:719-750 */
+int mi355_expand_table_ids(const int64_t* offsets, int64_t num_tables, int64_t n, const int64_t* n_dev,
+                           int64_t* table_ids, hipStream_t stream);
+
+/* get_table_range, src/index_calculation.cu:77-127: range[t] = offsets[feature_offsets[t] * B] with
+ * B = feature_x_batch / feature_offsets[T] computed on the device (feature_x_batch = len(offsets) - 1) */
+int mi355_get_table_range(const int64_t* offsets, const int64_t* feature_offsets, int64_t num_tables,
+                          int64_t feature_x_batch, int64_t* table_range, hipStream_t stream);
+
+/* flagged_compact, src/index_calculation.cu:129-232 -- order preserving; the count stays on the
+ * device in *count_out (the reference syncs the host here).  Arrays are 8-byte words. */
+int64_t mi355_flagged_compact_workspace_bytes(int64_t n);
+int mi355_flagged_compact(const uint8_t* flags, int64_t n, const int64_t* n_dev, int64_t* count_out,
+                          int64_t* out_index, int num_arrays, const void* const* inputs, void* const* outputs,
+                          void* workspace, int64_t workspace_bytes, hipStream_t stream);
+
+/* Groups the keys of a batch by unique row (counting sort keyed by the reverse index): stands in for
+ * generate_gather_ids_pooled_kernel + cub::DeviceRadixSort of reduce_grads, dynamic_emb_op.cu:140-263.
+ * ptr: int32[max_unique+1], csr_src: int32[n] = bag id f*B+b (offsets != NULL) or key position. */
+int64_t mi355_group_by_unique_workspace_bytes(int64_t n, int64_t max_unique);
+int mi355_group_by_unique(const int64_t* reverse_indices, int64_t n, const int64_t* offsets, int64_t num_bags,
+                          int64_t max_unique, const int64_t* nu_dev, int32_t* ptr, int32_t* csr_src,
+                          void* workspace, int64_t workspace_bytes, hipStream_t stream);
+
+/* block_bucketize_sparse_features, src/sparse_block_bucketize_features.cu:220-350,366-830:
+ * dist_type per feature 0 continuous / 1 roundrobin / 2 hash_roundrobin; offsets has num_bags+1 entries
+ * (feature-major F*B bags); new_lengths [W*num_bags], new_offsets [W*num_bags+1]. */
+int mi355_block_bucketize(int64_t world_size, int64_t num_bags, int64_t batch_size, const int64_t* offsets,
+                          const void* indices, const int64_t* block_sizes, const int32_t* dist_type_per_feature,
+                          const float* weights, int64_t* new_lengths, int64_t* new_offsets, void* new_indices,
+                          float* new_weights, int64_t* unbucketize_permute, hipStream_t stream);
+
+/* ------------------------------------------------------------------------ value ops ---- */
+
+/* gather_embedding_pooled, src/dynamic_emb_op.cu:106-133 (kernels lookup_kernel.cuh:859-998).
+ * Source: dense [*, src_stride] (reference form) or table rows through row_addr[u] (fused form;
+ * address 0 = missing row = zeros).  offsets feature-major [num_bags+1]; combiner 0 sum / 1 mean;
+ * D_offsets (int32[F+1]) NULL for uniform dim.  aligned16: rows, dims and column offsets allow
+ * 4-element vector access. */
+int mi355_gather_pooled(const void* src, int64_t src_stride, const int64_t* row_addr, int src_dtype,
+                        const int64_t* reverse_indices, const int64_t* offsets, int64_t num_bags,
+                        int64_t batch_size, int combiner, int64_t dim, const int32_t* D_offsets, int64_t total_D,
+                        void* dst, int dst_dtype, int aligned16, hipStream_t stream);
+
+/* gather_embedding, src/dynamic_emb_op.cu:79-104 (index NULL = identity) */
+int mi355_gather_rows(const void* src, int64_t src_stride, const int64_t* row_addr, int src_dtype,
+                      const int64_t* index, int64_t n, const int64_t* n_dev, int64_t dim, void* dst,
+                      int64_t dst_stride, int dst_dtype, int aligned16, hipStream_t stream);
+
+/* load_from_flat_table_{contiguous,emb,value} (is_load=1) / store_to_flat_table_{contiguous,value}
+ * (is_load=0), src/dynamic_emb_op.cu:294-684.  region 0/1/2 as NumRegions there. */
+int mi355_flat_table_copy(int is_load, int region, int64_t n, const int64_t* n_dev, void* dense,
+                          int64_t dense_dim, int64_t dense_stride, int dtype, const int64_t* indices,
+                          const int64_t* table_ids, int64_t scalar_table_id, const int64_t* table_ptrs,
+                          const int64_t* table_value_dims, const int64_t* table_emb_dims, int64_t max_emb_dim,
+                          hipStream_t stream);
+
+/* row_addr[u] = table_ptrs[tid] + slot * value_dim * elem_bytes (0 for slot < 0): the address form of
+ * the (table_ptrs, table_ids, indices) triple every flat-table kernel of the reference takes. */
+int mi355_row_addresses(int64_t n, const int64_t* n_dev, const int64_t* slots, const int64_t* table_ids,
+                        const int64_t* table_ptrs, const int64_t* table_value_dims, int elem_bytes,
+                        int64_t* row_addr, hipStream_t stream);
+
+/* {uniform,normal,truncated_normal,const,debug}_init, src/initializer.cu:64-212.  mode 0..4. */
+int mi355_init_rows(int mode, float p0, float p1, float p2, float p3, uint64_t seed, float state_init,
+                    int64_t n, const int64_t* n_dev, const void* keys, const int64_t* sel,
+                    const int64_t* row_addr, void* dense, int64_t dense_stride, int dtype, int64_t emb_dim,
+                    int64_t value_dim, const uint8_t* results, const uint8_t* skip, hipStream_t stream);
+
+/* ------------------------------------------------------------------------- backward ---- */
+
+/* reduce_grads (opt_kind 0, src/dynamic_emb_op.cu:159-285) and reduce_grads fused with
+ * {sgd,adam,adagrad,rowwise_adagrad}_update_for_flat_table (opt_kind 1..4, src/optimizer.cu:77-240)
+ * over the CSR of mi355_group_by_unique.  combiner -1 sequence / 0 sum / 1 mean. */
+int64_t mi355_backward_workspace_bytes(int64_t num_keys, int64_t dim);
+int mi355_backward_fused(const int32_t* ptr, const int32_t* csr_src, int64_t num_keys, int64_t max_unique,
+                         const int64_t* nu_dev, const void* grads, int64_t grad_stride, int grad_dtype,
+                         const int64_t* offsets, const int32_t* D_offsets, int64_t batch_size, int64_t dim,
+                         int combiner, const int64_t* row_addr, int weight_dtype, int opt_kind, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int64_t iter_num,
+                         int64_t state_offset, int round_grad, void* out, int64_t out_stride, int aligned16,
+                         void* workspace, int64_t workspace_bytes, hipStream_t stream);
+
+/* {sgd,adam,adagrad,rowwise_adagrad}_update_for_flat_table (row_addr) / ..._for_padded_buffer
+ * (dense_rows), src/optimizer.cu:77-476, on dense unique gradients. */
+int mi355_optimizer_update(int opt_kind, const void* grads, int64_t grad_stride, int grad_dtype, int64_t n,
+                           const int64_t* n_dev, const int64_t* row_addr, void* dense_rows, int64_t dense_stride,
+                           int weight_dtype, int64_t dim, int64_t state_offset, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, int64_t iter_num, int aligned16,
+                           hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECSYS_AMD_H_ */

@@ -1,0 +1,626 @@
+// Index plumbing of the DynamicEmb lookup path for gfx950: segmented unique (dedup),
+// table-id expansion, table ranges, order-preserving stream compaction, the block-aggregated
+// counting sort that groups the keys of a batch by unique row (CSR for the backward pass) and
+// the row-wise key -> rank bucketize that precedes the all-to-all.
+//
+// Replaces (reference, corelib/dynamicemb/src/): segmented_unique_cuda + expand_table_ids_cuda
+// (unique_op.cu:209-750), get_table_range / flagged_compact (index_calculation.cu:77-232),
+// generate_gather_ids + cub radix sort of reduce_grads (dynamic_emb_op.cu:140-263),
+// block_bucketize_sparse_features (sparse_block_bucketize_features.cu:220-350).
+//
+// MI355X design notes
+//  * Dedup is a per-table open-addressing set of int32 input positions in HBM (2 slots per
+//    key).  The representative of a key is made the MINIMUM input position with atomicMin, so
+//    the unique order is first-occurrence order: deterministic, unlike the schedule-dependent
+//    order of the reference.  Hot (Zipf) keys cost no atomic traffic: a lane only issues the
+//    atomicMin when its position is below the value it just read (values only decrease).
+//  * unique ids come from an exclusive scan of the "is first occurrence" flags (block scan with
+//    wave64 shuffles + one small partial pass), so no counts cross to the host.
+//  * grouping keys by unique row uses LDS-privatised counters: each 1024-key tile counts its
+//    rows in an LDS hash table and issues ONE global atomic per distinct row per tile, so the
+//    hottest row of a Zipf stream costs (#tiles) atomics instead of (#occurrences).
+#include "common.h"
+
+namespace mi355 {
+
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 4;
+constexpr int kScanTile = kScanThreads * kScanItems;  // 1024
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int o = __shfl_up(v, off, 64);
+    if (lane_id() >= off) v += o;
+  }
+  return v;
+}
+
+// exclusive scan of one int per thread across a 256-thread block; returns the block total in `total`
+__device__ __forceinline__ int block_excl_scan(int v, int& total) {
+  __shared__ int s_w[kScanThreads / 64 + 1];
+  const int w = threadIdx.x >> 6;
+  int incl = wave_incl_scan(v);
+  if (lane_id() == 63) s_w[w] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < kScanThreads / 64; ++k) {
+    int x = s_w[k];
+    if (k < w) base += x;
+    tot += x;
+  }
+  __syncthreads();
+  total = tot;
+  return base + incl - v;
+}
+
+__device__ __forceinline__ int upper_bound_i64(const int64_t* __restrict__ a, int n, int64_t x) {
+  int lo = 0, hi = n;  // first index with a[idx] > x
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (a[mid] <= x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+// segmented unique
+// ---------------------------------------------------------------------------------------------
+struct UniqWs {
+  int* slots;    // [2n]   open-addressing set, value = representative input position, -1 empty
+  int* rep;      // [n]    slot of key i, then representative (min position) of key i
+  int* uid_of;   // [n]    unique id of position i (valid where rep[i] == i)
+  int* partial;  // [nb+1] per-tile counts of first occurrences, then exclusive offsets
+  int* total;    // [1]
+};
+
+__global__ void __launch_bounds__(256)
+uniq_insert_kernel(const uint64_t* __restrict__ keys, int64_t n, const int64_t* __restrict__ seg, int T, UniqWs ws) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t key = keys[i];
+    const int t = upper_bound_i64(seg, T + 1, i) - 1;
+    const int64_t lo = seg[t], len = seg[t + 1] - lo;
+    const uint64_t range = 2ull * (uint64_t)len;
+    const int64_t base = 2 * lo;
+    uint64_t h = fmix64(key);
+    int64_t off = (int64_t)((((h >> 32) ^ (h & 0xffffffffull)) * range) >> 32);
+    int64_t pos = base + off;
+    const int me = (int)i;
+    while (true) {
+      int cur = ws.slots[pos];
+      if (cur == -1) {
+        int old = atomicCAS(&ws.slots[pos], -1, me);
+        if (old == -1) break;
+        cur = old;
+      }
+      if (keys[cur] == key) {
+        if (me < cur) atomicMin(&ws.slots[pos], me);
+        break;
+      }
+      ++off;
+      if ((uint64_t)off == range) off = 0;
+      pos = base + off;
+    }
+    ws.rep[i] = (int)pos;
+  }
+}
+
+// rep[i] <- slots[rep[i]]; count first occurrences per 1024-tile
+__global__ void __launch_bounds__(kScanThreads)
+uniq_flag_kernel(int64_t n, UniqWs ws) {
+  const int64_t tile0 = (int64_t)blockIdx.x * kScanTile;
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    int64_t i = tile0 + threadIdx.x * kScanItems + k;
+    if (i < n) {
+      int r = ws.slots[ws.rep[i]];
+      ws.rep[i] = r;
+      c += (r == (int)i);
+    }
+  }
+  int tot;
+  block_excl_scan(c, tot);
+  if (threadIdx.x == 0) ws.partial[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of `partial[0..nb)` in place, total -> *total
+__global__ void __launch_bounds__(kScanThreads) scan_partials_kernel(int* partial, int64_t nb, int* total) {
+  __shared__ int s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int64_t b0 = 0; b0 < nb; b0 += kScanThreads) {
+    int64_t b = b0 + threadIdx.x;
+    int v = b < nb ? partial[b] : 0;
+    int tot;
+    int ex = block_excl_scan(v, tot);
+    int carry = s_carry;
+    if (b < nb) partial[b] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry = carry + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = s_carry;
+}
+
+template <bool kFreq>
+__global__ void __launch_bounds__(kScanThreads)
+uniq_emit_kernel(const uint64_t* __restrict__ keys, int64_t n, const int64_t* __restrict__ seg, int T, UniqWs ws,
+                 uint64_t* __restrict__ unique_keys, int64_t* __restrict__ table_offsets, int64_t* __restrict__ freq) {
+  const int64_t tile0 = (int64_t)blockIdx.x * kScanTile;
+  int f[kScanItems];
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    int64_t i = tile0 + threadIdx.x * kScanItems + k;
+    f[k] = (i < n) && (ws.rep[i] == (int)i);
+    c += f[k];
+  }
+  int tot;
+  int ex = block_excl_scan(c, tot) + ws.partial[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    int64_t i = tile0 + threadIdx.x * kScanItems + k;
+    if (i < n) {
+      // table boundaries: every table t with seg[t] == i starts at the exclusive count here
+      int t = upper_bound_i64(seg, T + 1, i) - 1;
+      while (t >= 0 && seg[t] == i) { table_offsets[t] = ex; --t; }
+      if (f[k]) {
+        unique_keys[ex] = keys[i];
+        ws.uid_of[i] = ex;
+        if (kFreq) freq[ex] = 0;
+        ++ex;
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t total = *ws.total;
+    for (int t = T; t >= 0 && seg[t] >= n; --t) table_offsets[t] = total;
+  }
+}
+
+template <bool kFreq>
+__global__ void __launch_bounds__(256)
+uniq_finish_kernel(int64_t n, UniqWs ws, const int64_t* __restrict__ in_freq, int64_t* __restrict__ output_indices,
+                   int64_t* __restrict__ freq) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int u = ws.uid_of[ws.rep[i]];
+    output_indices[i] = u;
+    if (kFreq) atomicAdd((unsigned long long*)&freq[u], (unsigned long long)(in_freq ? in_freq[i] : 1));
+  }
+}
+
+__global__ void zero_offsets_kernel(int64_t* p, int64_t n) {
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
+}
+
+// expand_table_ids_kernel (unique_op.cu:471-480): table_ids[i] = upper_bound(offsets, i) - 1
+__global__ void __launch_bounds__(256)
+expand_table_ids_kernel(const int64_t* __restrict__ offsets, int T, int64_t n, const int64_t* __restrict__ n_dev,
+                        int64_t* __restrict__ table_ids) {
+  if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    table_ids[i] = upper_bound_i64(offsets, T + 1, i) - 1;
+}
+
+// get_table_range_kernel (index_calculation.cu:78-91)
+__global__ void get_table_range_kernel(const int64_t* __restrict__ offsets, const int64_t* __restrict__ feature_offsets,
+                                       int T, int64_t feature_x_batch, int64_t* __restrict__ range) {
+  const int64_t nfeat = feature_offsets[T];
+  const int64_t B = nfeat > 0 ? feature_x_batch / nfeat : 0;
+  for (int t = threadIdx.x; t <= T; t += blockDim.x) range[t] = offsets[feature_offsets[t] * B];
+}
+
+// ---------------------------------------------------------------------------------------------
+// order-preserving compaction (flagged_compact, index_calculation.cu:129-232) without the host
+// sync on the count: count stays in `*count_out` on the device.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kScanThreads)
+compact_count_kernel(const uint8_t* __restrict__ flags, int64_t n, const int64_t* __restrict__ n_dev, int* partial) {
+  if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
+  const int64_t tile0 = (int64_t)blockIdx.x * kScanTile;
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    int64_t i = tile0 + threadIdx.x * kScanItems + k;
+    c += (i < n) && flags[i];
+  }
+  int tot;
+  block_excl_scan(c, tot);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+struct CompactArrays {
+  const int64_t* in[6];
+  int64_t* out[6];
+  int num;
+};
+
+__global__ void __launch_bounds__(kScanThreads)
+compact_emit_kernel(const uint8_t* __restrict__ flags, int64_t n, const int64_t* __restrict__ n_dev,
+                    const int* __restrict__ partial, const int* __restrict__ total, int64_t* __restrict__ count_out,
+                    int64_t* __restrict__ out_index, CompactArrays arrs) {
+  if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
+  const int64_t tile0 = (int64_t)blockIdx.x * kScanTile;
+  int f[kScanItems];
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    int64_t i = tile0 + threadIdx.x * kScanItems + k;
+    f[k] = (i < n) && flags[i];
+    c += f[k];
+  }
+  int tot;
+  int ex = block_excl_scan(c, tot) + partial[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    int64_t i = tile0 + threadIdx.x * kScanItems + k;
+    if (f[k]) {
+      if (out_index) out_index[ex] = i;
+      for (int a = 0; a < arrs.num; ++a) arrs.out[a][ex] = arrs.in[a][i];
+      ++ex;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = *total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// group the keys of a pooled / sequence batch by unique row: histogram + exclusive scan + scatter
+// (a counting sort keyed by the reverse index).  csr_src[p] = source grad row of the p-th entry:
+// pooled: slot f*B+b -> b*F+f is NOT used here; we store the BAG id (f*B+b) and let the consumer
+// derive (b, f); sequence: the key position j.
+// ---------------------------------------------------------------------------------------------
+constexpr int kHistTile = 1024;  // keys per block
+constexpr int kHistSlots = 2048; // LDS hash slots
+
+struct LdsEntry { int u; int cnt; int base; };
+
+__device__ __forceinline__ int lds_find_or_add(LdsEntry* tab, int u) {
+  int h = (int)(((uint32_t)u * 2654435761u) >> 21) & (kHistSlots - 1);
+  while (true) {
+    int cur = atomicCAS(&tab[h].u, -1, u);
+    if (cur == -1 || cur == u) return h;
+    h = (h + 1) & (kHistSlots - 1);
+  }
+}
+
+// pass 1: cnt[u] += occurrences (one global atomic per distinct row per tile)
+__global__ void __launch_bounds__(256)
+csr_hist_kernel(const int64_t* __restrict__ rev, int64_t n, int* __restrict__ cnt) {
+  __shared__ LdsEntry tab[kHistSlots];
+  for (int s = threadIdx.x; s < kHistSlots; s += blockDim.x) { tab[s].u = -1; tab[s].cnt = 0; }
+  __syncthreads();
+  const int64_t tile0 = (int64_t)blockIdx.x * kHistTile;
+  for (int k = threadIdx.x; k < kHistTile; k += blockDim.x) {
+    int64_t j = tile0 + k;
+    if (j < n) { int h = lds_find_or_add(tab, (int)rev[j]); atomicAdd(&tab[h].cnt, 1); }
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < kHistSlots; s += blockDim.x)
+    if (tab[s].u >= 0) atomicAdd(&cnt[tab[s].u], tab[s].cnt);
+}
+
+// exclusive scan of cnt[0..nu) -> ptr[0..nu], nu read from the device
+__global__ void __launch_bounds__(kScanThreads)
+scan_reduce_kernel(const int* __restrict__ in, int64_t n, const int64_t* __restrict__ n_dev, int* partial) {
+  if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
+  const int64_t tile0 = (int64_t)blockIdx.x * kScanTile;
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    int64_t i = tile0 + threadIdx.x * kScanItems + k;
+    if (i < n) c += in[i];
+  }
+  int tot;
+  block_excl_scan(c, tot);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(kScanThreads)
+scan_down_kernel(const int* __restrict__ in, int64_t n, const int64_t* __restrict__ n_dev, const int* __restrict__ partial,
+                 const int* __restrict__ total, int* __restrict__ out) {
+  if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
+  const int64_t tile0 = (int64_t)blockIdx.x * kScanTile;
+  int v[kScanItems];
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    int64_t i = tile0 + threadIdx.x * kScanItems + k;
+    v[k] = i < n ? in[i] : 0;
+    c += v[k];
+  }
+  int tot;
+  int ex = block_excl_scan(c, tot) + partial[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    int64_t i = tile0 + threadIdx.x * kScanItems + k;
+    if (i < n) { out[i] = ex; ex += v[k]; }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
+}
+
+// pass 2: scatter.  src id of key j: pooled -> bag id (found by walking the bag offsets), sequence -> j.
+__global__ void __launch_bounds__(256)
+csr_fill_kernel(const int64_t* __restrict__ rev, int64_t n, const int64_t* __restrict__ offsets, int64_t num_bags,
+                const int* __restrict__ ptr, int* __restrict__ cursor, int* __restrict__ csr_src) {
+  __shared__ LdsEntry tab[kHistSlots];
+  for (int s = threadIdx.x; s < kHistSlots; s += blockDim.x) { tab[s].u = -1; tab[s].cnt = 0; }
+  __syncthreads();
+  const int64_t tile0 = (int64_t)blockIdx.x * kHistTile;
+  int hh[kHistTile / 256], rk[kHistTile / 256];
+#pragma unroll
+  for (int q = 0; q < kHistTile / 256; ++q) {
+    int64_t j = tile0 + q * 256 + threadIdx.x;
+    hh[q] = -1;
+    if (j < n) { hh[q] = lds_find_or_add(tab, (int)rev[j]); rk[q] = atomicAdd(&tab[hh[q]].cnt, 1); }
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < kHistSlots; s += blockDim.x)
+    if (tab[s].u >= 0) tab[s].base = ptr[tab[s].u] + atomicAdd(&cursor[tab[s].u], tab[s].cnt);
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kHistTile / 256; ++q) {
+    int64_t j = tile0 + q * 256 + threadIdx.x;
+    if (hh[q] >= 0) {
+      int src;
+      if (offsets) {
+        // bag of key j: last bag with offsets[bag] <= j
+        int lo = 0, hi = (int)num_bags;  // first idx with offsets[idx] > j
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (offsets[mid] <= j) lo = mid + 1; else hi = mid; }
+        src = lo - 1;
+      } else src = (int)j;
+      csr_src[tab[hh[q]].base + rk[q]] = src;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// row-wise key -> rank routing before the key all-to-all (sparse_block_bucketize_features.cu:220-350)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void route(uint64_t idx, int dist, uint64_t blk, uint64_t W, uint64_t& p, uint64_t& nw) {
+  if (dist == 1) { p = idx % W; nw = idx; }
+  else if (dist == 2) { p = fmix64(idx) % W; nw = idx; }
+  else if (idx < blk * W) { p = idx / blk; nw = idx % blk; }
+  else { p = idx % W; nw = idx / W; }
+}
+
+// one wave per bag (HSTU bags are whole sequences: few bags, thousands of keys each): lane r owns
+// the counter of destination rank r; ranks of a 64-key chunk are tallied with one ballot per rank.
+__global__ void __launch_bounds__(256)
+bucketize_count_kernel(int64_t FB, int64_t B, int W, const int64_t* __restrict__ offsets, const uint64_t* __restrict__ indices,
+                       const int64_t* __restrict__ block_sizes, const int* __restrict__ dist_type, int64_t* __restrict__ new_lengths) {
+  const int lane = lane_id();
+  for (int64_t bag = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); bag < FB; bag += (int64_t)gridDim.x * (blockDim.x / 64)) {
+    const int64_t f = bag / B;
+    const int dist = dist_type ? dist_type[f] : 0;
+    const uint64_t blk = (uint64_t)block_sizes[f];
+    const int64_t lo = offsets[bag], hi = offsets[bag + 1];
+    for (int p0 = 0; p0 < W; p0 += 64) {
+      int64_t mycnt = 0;
+      for (int64_t j0 = lo; j0 < hi; j0 += 64) {
+        const int64_t j = j0 + lane;
+        uint64_t p = ~0ull, nw;
+        if (j < hi) route(indices[j], dist, blk, (uint64_t)W, p, nw);
+        const int nr = W - p0 < 64 ? W - p0 : 64;
+        for (int r = 0; r < nr; ++r) {
+          int c = __popcll(__ballot(p == (uint64_t)(p0 + r)));
+          if (lane == r) mycnt += c;
+        }
+      }
+      if (p0 + lane < W) new_lengths[(int64_t)(p0 + lane) * FB + bag] = mycnt;
+    }
+  }
+}
+
+// one wave per bag; order of keys inside a (rank, bag) segment = order inside the bag, as the
+// reference's one-thread-per-bag kernel2 produces.
+__global__ void __launch_bounds__(256)
+bucketize_scatter_kernel(int64_t FB, int64_t B, int W, const int64_t* __restrict__ offsets, const uint64_t* __restrict__ indices,
+                         const int64_t* __restrict__ block_sizes, const int* __restrict__ dist_type,
+                         const int64_t* __restrict__ new_offsets, uint64_t* __restrict__ new_indices,
+                         int64_t* __restrict__ unbucketize_permute, const float* __restrict__ weights,
+                         float* __restrict__ new_weights) {
+  const int lane = lane_id();
+  for (int64_t bag = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); bag < FB; bag += (int64_t)gridDim.x * (blockDim.x / 64)) {
+    const int64_t f = bag / B;
+    const int dist = dist_type ? dist_type[f] : 0;
+    const uint64_t blk = (uint64_t)block_sizes[f];
+    const int64_t lo = offsets[bag], hi = offsets[bag + 1];
+    for (int p0 = 0; p0 < W; p0 += 64) {
+      int64_t cursor = p0 + lane < W ? new_offsets[(int64_t)(p0 + lane) * FB + bag] : 0;  // lane r: write head of rank p0+r
+      const int nr = W - p0 < 64 ? W - p0 : 64;
+      for (int64_t j0 = lo; j0 < hi; j0 += 64) {
+        const int64_t j = j0 + lane;
+        uint64_t p = ~0ull, nw = 0;
+        if (j < hi) route(indices[j], dist, blk, (uint64_t)W, p, nw);
+        int64_t dst = -1;
+        for (int r = 0; r < nr; ++r) {
+          const uint64_t m = __ballot(p == (uint64_t)(p0 + r));
+          const uint32_t clo = __shfl((int)(uint32_t)cursor, r, 64), chi = __shfl((int)(uint32_t)((uint64_t)cursor >> 32), r, 64);
+          const int64_t head = (int64_t)(((uint64_t)chi << 32) | clo);
+          if (p == (uint64_t)(p0 + r)) dst = head + __popcll(m & ((1ull << lane) - 1));
+          if (lane == r) cursor += __popcll(m);
+        }
+        if (dst >= 0) {
+          new_indices[dst] = nw;
+          if (unbucketize_permute) unbucketize_permute[j] = dst;
+          if (weights) new_weights[dst] = weights[j];
+        }
+      }
+    }
+  }
+}
+
+// exclusive scan of int64 lengths -> offsets (single block; W*F*B is small relative to the keys)
+__global__ void __launch_bounds__(1024) scan_i64_kernel(const int64_t* __restrict__ in, int64_t n, int64_t* __restrict__ out) {
+  __shared__ int64_t s_w[17];
+  __shared__ int64_t s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const int w = threadIdx.x >> 6, lane = lane_id();
+  for (int64_t b0 = 0; b0 < n; b0 += 1024) {
+    int64_t i = b0 + threadIdx.x;
+    int64_t v = i < n ? in[i] : 0, incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      int lo = __shfl_up((int)(uint32_t)incl, off, 64), hi = __shfl_up((int)(uint32_t)((uint64_t)incl >> 32), off, 64);
+      int64_t o = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    int64_t base = s_carry, tot = 0;
+    for (int k = 0; k < 16; ++k) { if (k < w) base += s_w[k]; tot += s_w[k]; }
+    if (i < n) out[i] = base + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[n] = s_carry;
+}
+
+}  // namespace mi355
+
+using namespace mi355;
+
+static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+extern "C" {
+
+int64_t mi355_segmented_unique_workspace_bytes(int64_t n) {
+  int64_t nb = ceil_div(n > 0 ? n : 1, kScanTile);
+  return align_up(8 * n, 256) + 2 * align_up(4 * n, 256) + align_up(4 * (nb + 1), 256) + 256;
+}
+
+int mi355_segmented_unique(const void* keys, int64_t n, const int64_t* segmented_range, int64_t num_tables,
+                           const int64_t* input_frequencies, int count_freq, void* unique_keys,
+                           int64_t* output_indices, int64_t* table_offsets, int64_t* freq, void* workspace,
+                           int64_t workspace_bytes, hipStream_t stream) {
+  MI355_CHECK_ARG(num_tables > 0, "num_tables must be positive");
+  MI355_CHECK_ARG(n < 0x7fffffffLL / 2, "num_keys must be < 2^30");
+  MI355_CHECK_ARG(!count_freq || freq, "freq output required when counting frequencies");
+  if (n == 0) {
+    hipLaunchKernelGGL(zero_offsets_kernel, dim3(1), dim3(64), 0, stream, table_offsets, num_tables + 1);
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+  }
+  MI355_CHECK_ARG(workspace && workspace_bytes >= mi355_segmented_unique_workspace_bytes(n), "workspace too small");
+  const int64_t nb = ceil_div(n, kScanTile);
+  uint8_t* w = (uint8_t*)workspace;
+  UniqWs ws;
+  ws.slots = (int*)w; w += align_up(8 * n, 256);
+  ws.rep = (int*)w; w += align_up(4 * n, 256);
+  ws.uid_of = (int*)w; w += align_up(4 * n, 256);
+  ws.partial = (int*)w; w += align_up(4 * (nb + 1), 256);
+  ws.total = (int*)w;
+  if (hipMemsetAsync(ws.slots, 0xFF, 8 * n, stream) != hipSuccess) { mi355_set_error("memset failed"); return MI355_ELAUNCH; }
+  const uint64_t* k = (const uint64_t*)keys;
+  const int T = (int)num_tables;
+  hipLaunchKernelGGL(uniq_insert_kernel, dim3(grid_for(n, 256, 256 * 32)), dim3(256), 0, stream, k, n, segmented_range, T, ws);
+  hipLaunchKernelGGL(uniq_flag_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, n, ws);
+  hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, stream, ws.partial, nb, ws.total);
+  if (count_freq) {
+    hipLaunchKernelGGL(uniq_emit_kernel<true>, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, k, n, segmented_range, T, ws,
+                       (uint64_t*)unique_keys, table_offsets, freq);
+    hipLaunchKernelGGL(uniq_finish_kernel<true>, dim3(grid_for(n, 256, 256 * 32)), dim3(256), 0, stream, n, ws, input_frequencies,
+                       output_indices, freq);
+  } else {
+    hipLaunchKernelGGL(uniq_emit_kernel<false>, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, k, n, segmented_range, T, ws,
+                       (uint64_t*)unique_keys, table_offsets, freq);
+    hipLaunchKernelGGL(uniq_finish_kernel<false>, dim3(grid_for(n, 256, 256 * 32)), dim3(256), 0, stream, n, ws, input_frequencies,
+                       output_indices, freq);
+  }
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int mi355_expand_table_ids(const int64_t* offsets, int64_t num_tables, int64_t n, const int64_t* n_dev,
+                           int64_t* table_ids, hipStream_t stream) {
+  if (n == 0) return MI355_OK;
+  hipLaunchKernelGGL(expand_table_ids_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, offsets, (int)num_tables, n, n_dev, table_ids);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int mi355_get_table_range(const int64_t* offsets, const int64_t* feature_offsets, int64_t num_tables, int64_t feature_x_batch,
+                          int64_t* table_range, hipStream_t stream) {
+  hipLaunchKernelGGL(get_table_range_kernel, dim3(1), dim3(128), 0, stream, offsets, feature_offsets, (int)num_tables, feature_x_batch, table_range);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int64_t mi355_flagged_compact_workspace_bytes(int64_t n) {
+  return align_up(4 * (ceil_div(n > 0 ? n : 1, kScanTile) + 1), 256) + 256;
+}
+
+// out_index / inputs are int64 arrays (keys, table ids, scores are all 8-byte words on this path)
+int mi355_flagged_compact(const uint8_t* flags, int64_t n, const int64_t* n_dev, int64_t* count_out, int64_t* out_index,
+                          int num_arrays, const void* const* inputs, void* const* outputs, void* workspace,
+                          int64_t workspace_bytes, hipStream_t stream) {
+  MI355_CHECK_ARG(num_arrays >= 0 && num_arrays <= 6, "at most 6 arrays");
+  if (n == 0) {
+    hipLaunchKernelGGL(zero_offsets_kernel, dim3(1), dim3(64), 0, stream, count_out, (int64_t)1);
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+  }
+  MI355_CHECK_ARG(workspace && workspace_bytes >= mi355_flagged_compact_workspace_bytes(n), "workspace too small");
+  const int64_t nb = ceil_div(n, kScanTile);
+  int* partial = (int*)workspace;
+  int* total = (int*)((uint8_t*)workspace + align_up(4 * (nb + 1), 256));
+  CompactArrays arrs;
+  arrs.num = num_arrays;
+  for (int a = 0; a < num_arrays; ++a) { arrs.in[a] = (const int64_t*)inputs[a]; arrs.out[a] = (int64_t*)outputs[a]; }
+  hipLaunchKernelGGL(compact_count_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, flags, n, n_dev, partial);
+  hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, stream, partial, nb, total);
+  hipLaunchKernelGGL(compact_emit_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, flags, n, n_dev, partial, total,
+                     count_out, out_index, arrs);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+// CSR of the batch keyed by unique row.  cnt/cursor: int32[max_unique] scratch, ptr: int32[max_unique+1],
+// csr_src: int32[n].  num_unique may live on the device (nu_dev).
+int64_t mi355_group_by_unique_workspace_bytes(int64_t n, int64_t max_unique) {
+  return 2 * align_up(4 * (max_unique + 1), 256) + align_up(4 * (ceil_div(max_unique + 1, kScanTile) + 1), 256) + 256;
+}
+
+int mi355_group_by_unique(const int64_t* reverse_indices, int64_t n, const int64_t* offsets, int64_t num_bags,
+                          int64_t max_unique, const int64_t* nu_dev, int32_t* ptr, int32_t* csr_src, void* workspace,
+                          int64_t workspace_bytes, hipStream_t stream) {
+  MI355_CHECK_ARG(n < 0x7fffffffLL, "too many keys");
+  MI355_CHECK_ARG(workspace && workspace_bytes >= mi355_group_by_unique_workspace_bytes(n, max_unique), "workspace too small");
+  uint8_t* w = (uint8_t*)workspace;
+  int* cnt = (int*)w; w += align_up(4 * (max_unique + 1), 256);
+  int* cursor = (int*)w; w += align_up(4 * (max_unique + 1), 256);
+  const int64_t nbu = ceil_div(max_unique + 1, kScanTile);
+  int* partial = (int*)w; w += align_up(4 * (nbu + 1), 256);
+  int* total = (int*)w;
+  if (hipMemsetAsync(cnt, 0, 2 * align_up(4 * (max_unique + 1), 256), stream) != hipSuccess) { mi355_set_error("memset failed"); return MI355_ELAUNCH; }
+  if (n > 0) hipLaunchKernelGGL(csr_hist_kernel, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, reverse_indices, n, cnt);
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, cnt, max_unique, nu_dev, partial);
+  hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, stream, partial, nbu, total);
+  hipLaunchKernelGGL(scan_down_kernel, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, cnt, max_unique, nu_dev, partial, total, ptr);
+  if (n > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, reverse_indices, n, offsets,
+                                num_bags, ptr, cursor, csr_src);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int mi355_block_bucketize(int64_t world_size, int64_t num_bags, int64_t batch_size, const int64_t* offsets,
+                          const void* indices, const int64_t* block_sizes, const int32_t* dist_type_per_feature,
+                          const float* weights, int64_t* new_lengths, int64_t* new_offsets, void* new_indices,
+                          float* new_weights, int64_t* unbucketize_permute, hipStream_t stream) {
+  MI355_CHECK_ARG(world_size >= 1 && world_size <= 4096, "bad world size");
+  if (num_bags == 0) return MI355_OK;
+  const int W = (int)world_size;
+  hipLaunchKernelGGL(bucketize_count_kernel, dim3(grid_for(num_bags, 4)), dim3(256), 0, stream, num_bags, batch_size, W, offsets,
+                     (const uint64_t*)indices, block_sizes, dist_type_per_feature, new_lengths);
+  hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, stream, new_lengths, world_size * num_bags, new_offsets);
+  hipLaunchKernelGGL(bucketize_scatter_kernel, dim3(grid_for(num_bags, 4)), dim3(256), 0, stream, num_bags, batch_size, W, offsets,
+                     (const uint64_t*)indices, block_sizes, dist_type_per_feature, new_offsets, (uint64_t*)new_indices,
+                     unbucketize_permute, weights, new_weights);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,553 @@
+// Scored hash table ("LinearBucketTable") kernels for gfx950.
+//
+// Replaces (reference, corelib/dynamicemb/src/table_operation/): table_lookup_kernel
+// (kernels.cuh:81-187), table_insert_kernel / table_insert_and_evict_kernel /
+// table_unlock_kernel (kernels.cuh:189-585), table_erase_kernel (:587-652),
+// update_counter_with_layout_kernel (insert_and_evict.cu:27-58), the probe/reduce of
+// types.cuh:308-512 and the score policies of score.cuh:30-99.
+//
+// MI355X design (not a translation of the one-thread-per-key CUDA kernels):
+//  * a bucket's digest array is C bytes = ONE 128-B line at the default C = 128, so an
+//    8-lane group owns one key: every lane pulls 16 digests with one dwordx4 load and the
+//    whole bucket is matched in a single step (no serial 16-slot probe chain), a wave64
+//    resolves 8 keys at a time; candidate key words are then fetched only by the lanes
+//    whose digests matched.
+//  * the min-score eviction scan is the same 8 lanes striding the bucket's score words as
+//    coalesced 16-B pairs, followed by a 3-step xor-shuffle arg-min; no LDS staging or
+//    cp.async-style double buffer is needed because the group reads a full line per step.
+//  * slot lock = 64-bit CAS on the key word at agent scope (sc1), exactly one lane per
+//    group issues it; evicted-stream compaction is a wave-wide ballot + mbcnt prefix and
+//    ONE atomic per wave.
+//  * all counts can stay on the device (`n_dev`), so the pipeline never syncs the host.
+#include "common.h"
+
+namespace mi355 {
+
+constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
+constexpr uint64_t kLockedKey = 0xFFFFFFFFFFFFFFFDull;
+constexpr uint64_t kReclaimKey = 0xFFFFFFFFFFFFFFFEull;
+constexpr uint64_t kReserveMask = 0xFFFFFFFFFFFFFFFCull;
+
+enum Policy : int { kConst = 0, kAssign = 1, kAccumulate = 2, kGlobalTimer = 3, kLruLfu = 4 };
+enum Result : uint8_t { kInsert = 0, kReclaim = 1, kAssigned = 2, kEvict = 3, kDuplicated = 4,
+                        kBusy = 5, kIllegal = 6, kInit = 7 };
+
+constexpr int G = 8;  // lanes per key
+
+struct Table {
+  uint8_t* storage;
+  int64_t C;       // slots per bucket, multiple of 16
+  int64_t ns;      // score words per slot
+  int64_t stride;  // bytes per bucket = (9 + 8 ns) C
+  __device__ __forceinline__ uint64_t* keys(int64_t b) const { return (uint64_t*)(storage + b * stride); }
+  __device__ __forceinline__ uint8_t* dig(int64_t b) const { return storage + b * stride + 8 * C; }
+  __device__ __forceinline__ uint64_t* scores(int64_t b) const { return (uint64_t*)(storage + b * stride + 9 * C); }
+};
+
+__device__ __forceinline__ bool is_valid(uint64_t k) { return (k & kReserveMask) != kReserveMask; }
+__device__ __forceinline__ uint8_t digest_of(int64_t h) { return (uint8_t)(h >> 32); }
+
+// 16-bit mask of the bytes of v equal to d (exact zero-byte detection, no false positives)
+__device__ __forceinline__ uint32_t eq_mask16(uint4 v, uint32_t d) {
+  const uint32_t s = d * 0x01010101u;
+  uint32_t w[4] = {v.x ^ s, v.y ^ s, v.z ^ s, v.w ^ s};
+  uint32_t m = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t x = w[i];
+    uint32_t t = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);  // 0x80 where byte == 0
+    uint32_t nib = (((t >> 7) * 0x00204081u) >> 21) & 0xFu;
+    m |= nib << (4 * i);
+  }
+  return m;
+}
+
+__device__ __forceinline__ uint4 load_dig16(const uint8_t* p, bool fresh) {
+  if (!fresh) return *reinterpret_cast<const uint4*>(p);
+  const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+  uint4 r;
+  r.x = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  r.y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  r.z = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  r.w = __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return r;
+}
+
+// value of `v` held by lane `src` of this lane's 8-lane group
+template <typename T>
+__device__ __forceinline__ T group_bcast(T v, int src_in_group) {
+  int src = (lane_id() & ~(G - 1)) | src_in_group;
+  if constexpr (sizeof(T) == 8) {
+    uint64_t u = (uint64_t)v;
+    uint32_t lo = __shfl((int)(uint32_t)u, src, 64), hi = __shfl((int)(uint32_t)(u >> 32), src, 64);
+    return (T)(((uint64_t)hi << 32) | lo);
+  } else {
+    return (T)__shfl((int)v, src, 64);
+  }
+}
+// 8-bit mask of the group's lanes with pred set (control flow must be group-uniform)
+__device__ __forceinline__ uint32_t group_ballot(bool pred) {
+  uint64_t b = __ballot(pred);
+  return (uint32_t)(b >> (lane_id() & ~(G - 1))) & 0xFFu;
+}
+
+struct Located {
+  int64_t hash, bkt_begin, bucket;
+  bool ok;
+};
+// bucket choice (kernels.cuh:107-125)
+__device__ __forceinline__ Located locate(uint64_t key, int64_t tid, const int64_t* __restrict__ tbo, int64_t C) {
+  Located r{0, 0, 0, false};
+  if (!is_valid(key)) return r;
+  r.hash = (int64_t)(fmix64(key) & 0x7FFFFFFFFFFFFFFFull);
+  r.bkt_begin = tbo[tid];
+  int64_t cap = (tbo[tid + 1] - r.bkt_begin) * C;
+  if (cap <= 0) return r;
+  uint64_t local = (uint64_t)r.hash % (uint64_t)cap;
+  r.bucket = r.bkt_begin + (int64_t)(local / (uint64_t)C);
+  r.ok = true;
+  return r;
+}
+
+// Group-cooperative probe of one bucket (types.cuh:308-396 semantics: first slot in probe
+// order -- 16-aligned start, wrap around -- that holds `key`; if none, the first Empty slot).
+// Returns via reference: found_slot (>=0 or -1), empty_slot (>=0 or -1).  All 8 lanes of the
+// group call with the same arguments; results are group-uniform.
+__device__ __forceinline__ void group_probe(const Table& t, int64_t b, uint64_t key, int64_t hash, bool fresh,
+                                            bool want_empty, int& found_slot, int& empty_slot) {
+  const int g = lane_id() & (G - 1);
+  const int C = (int)t.C;
+  const uint32_t d = digest_of(hash);
+  const uint32_t ed = digest_of((int64_t)(fmix64(kEmptyKey) & 0x7FFFFFFFFFFFFFFFull));
+  const int start = (int)(((C & (C - 1)) == 0 ? ((uint64_t)hash & (uint64_t)(C - 1)) : ((uint64_t)hash % (uint64_t)C))) & ~15;
+  const uint8_t* dg = t.dig(b);
+  const uint64_t* ks = t.keys(b);
+  found_slot = -1;
+  empty_slot = -1;
+  for (int chunk = 0; chunk < C; chunk += 16 * G) {
+    const int rank0 = chunk + g * 16;
+    const bool in = rank0 < C;
+    int p0 = start + rank0;
+    if (p0 >= C) p0 -= C;
+    int my_found = -1, my_empty = -1;
+    if (in) {
+      uint4 dv = load_dig16(dg + p0, fresh);
+      uint32_t m = eq_mask16(dv, d);
+      while (m) {
+        int bit = __ffs(m) - 1;
+        m &= m - 1;
+        uint64_t k = fresh ? ald64(ks + p0 + bit) : ks[p0 + bit];
+        if (k == key) { my_found = p0 + bit; break; }
+      }
+      if (want_empty && my_found < 0) {
+        uint32_t me = eq_mask16(dv, ed);
+        while (me) {
+          int bit = __ffs(me) - 1;
+          me &= me - 1;
+          uint64_t k = fresh ? ald64(ks + p0 + bit) : ks[p0 + bit];
+          if (k == kEmptyKey) { my_empty = p0 + bit; break; }
+        }
+      }
+    }
+    uint32_t fm = group_ballot(my_found >= 0);
+    if (fm) { found_slot = group_bcast(my_found, __ffs(fm) - 1); return; }
+    if (want_empty && empty_slot < 0) {
+      uint32_t em = group_ballot(my_empty >= 0);
+      if (em) empty_slot = group_bcast(my_empty, __ffs(em) - 1);  // lowest lane == lowest probe rank
+    }
+    // a key can never sit behind an Empty slot in probe order (slots never return to Empty),
+    // so once an Empty slot is known the key is absent
+    if (want_empty && empty_slot >= 0) return;
+  }
+}
+
+__device__ __forceinline__ uint64_t policy_get(int policy, const uint64_t* score_in, int64_t i, uint64_t timer) {
+  if (policy == kConst) return 0;
+  if (policy == kGlobalTimer) return timer;
+  return score_in[i];
+}
+// score.cuh:72-96; s = first score word of the slot
+__device__ __forceinline__ uint64_t policy_update(int policy, uint64_t* s, uint64_t score, uint64_t timer) {
+  switch (policy) {
+    case kConst: return ald64(s);
+    case kAccumulate: score += ald64(s); ast64(s, score); return score;
+    case kLruLfu: ast64(s, timer); score += ald64(s + 1); ast64(s + 1, score); return score;
+    default: ast64(s, score); return score;
+  }
+}
+
+__global__ void __launch_bounds__(256) table_init_kernel(Table t, int64_t num_buckets) {
+  const uint8_t ed = digest_of((int64_t)(fmix64(kEmptyKey) & 0x7FFFFFFFFFFFFFFFull));
+  const int64_t total = num_buckets * t.C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t b = i / t.C, s = i % t.C;
+    t.keys(b)[s] = kEmptyKey;
+    t.dig(b)[s] = ed;
+    for (int64_t k = 0; k < t.ns; ++k) t.scores(b)[s * t.ns + k] = 0;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+table_lookup_kernel(Table t, const int64_t* __restrict__ tbo, int64_t n, const int64_t* __restrict__ n_dev,
+                    const uint64_t* __restrict__ keys, const int64_t* __restrict__ table_ids,
+                    const uint64_t* __restrict__ score_in, int policy, uint64_t timer_override,
+                    int64_t* __restrict__ score_out, uint8_t* __restrict__ founds, int64_t* __restrict__ indices) {
+  if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
+  const int g = lane_id() & (G - 1);
+  const int64_t gpb = blockDim.x / G;
+  const uint64_t timer = timer_override ? timer_override : device_clock();
+  for (int64_t base = (int64_t)blockIdx.x * gpb; base < n; base += (int64_t)gridDim.x * gpb) {
+    const int64_t i = base + threadIdx.x / G;
+    const bool act = i < n;
+    uint64_t key = act ? keys[i] : kEmptyKey;
+    int64_t tid = act ? (table_ids ? table_ids[i] : 0) : 0;
+    uint64_t score = act ? policy_get(policy, score_in, i, timer) : 0;
+    Located L = locate(key, tid, tbo, t.C);
+    int found_slot = -1, empty_slot = -1;
+    if (L.ok) group_probe(t, L.bucket, key, L.hash, false, false, found_slot, empty_slot);
+    if (act && g == 0) {
+      bool found = found_slot >= 0;
+      int64_t index = -1;
+      if (found) {
+        uint64_t* sc = t.scores(L.bucket) + (int64_t)found_slot * t.ns;
+        if (policy == kConst) {
+          score = sc[t.ns - 1];
+        } else {
+          uint64_t* kp = t.keys(L.bucket) + found_slot;
+          uint64_t exp = key;
+          if (cas64(kp, exp, kLockedKey)) {
+            score = policy_update(policy, sc, score, timer);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ast64(kp, key);
+          } else {
+            found = false;  // concurrent writer owns the slot (kernels.cuh:142-145)
+            score = 0;
+          }
+        }
+        if (found) index = (L.bucket - L.bkt_begin) * t.C + found_slot;
+      }
+      score_out[i] = (int64_t)score;
+      founds[i] = found ? 1 : 0;
+      indices[i] = index;
+    }
+  }
+}
+
+// group arg-min over (score, slot): smaller score wins, ties -> lower slot
+__device__ __forceinline__ void group_argmin(uint64_t& s, int& slot, uint64_t& k) {
+#pragma unroll
+  for (int off = 1; off < G; off <<= 1) {
+    int src = lane_id() ^ off;
+    uint32_t lo = __shfl((int)(uint32_t)s, src, 64), hi = __shfl((int)(uint32_t)(s >> 32), src, 64);
+    uint64_t os = ((uint64_t)hi << 32) | lo;
+    int oslot = __shfl(slot, src, 64);
+    uint32_t klo = __shfl((int)(uint32_t)k, src, 64), khi = __shfl((int)(uint32_t)(k >> 32), src, 64);
+    uint64_t ok = ((uint64_t)khi << 32) | klo;
+    bool take = (oslot >= 0) && (slot < 0 || os < s || (os == s && oslot < slot));
+    if (take) { s = os; slot = oslot; k = ok; }
+  }
+}
+
+// insert / insert_and_evict (kernels.cuh:189-567).  `skip` (optional): keys with skip[i] != 0 are
+// left alone (their `indices[i]` stays as the caller set it) -- lets "lookup then insert the
+// missing ones" run without a host-side compaction.
+__global__ void __launch_bounds__(256)
+table_insert_kernel(Table t, const int64_t* __restrict__ tbo, int32_t* __restrict__ bucket_sizes,
+                    int32_t* __restrict__ counter, int64_t n, const int64_t* __restrict__ n_dev,
+                    const uint64_t* __restrict__ keys, const int64_t* __restrict__ table_ids,
+                    const uint64_t* __restrict__ score_in, int policy, uint64_t timer_override,
+                    const uint8_t* __restrict__ skip, int64_t* __restrict__ indices,
+                    uint8_t* __restrict__ results, int64_t* __restrict__ score_out,
+                    unsigned long long* __restrict__ num_evicted, uint64_t* __restrict__ ev_keys,
+                    int64_t* __restrict__ ev_indices, int64_t* __restrict__ ev_scores,
+                    int64_t* __restrict__ ev_table_ids) {
+  if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
+  const int g = lane_id() & (G - 1);
+  const int64_t gpb = blockDim.x / G;
+  const uint64_t timer = timer_override ? timer_override : device_clock();
+  const int C = (int)t.C;
+  for (int64_t base = (int64_t)blockIdx.x * gpb; base < n; base += (int64_t)gridDim.x * gpb) {
+    const int64_t i = base + threadIdx.x / G;
+    const bool act = i < n && !(skip && skip[i]);
+    uint64_t key = act ? keys[i] : kEmptyKey;
+    int64_t tid = act ? (table_ids ? table_ids[i] : 0) : 0;
+    uint64_t score = act ? policy_get(policy, score_in, i, timer) : 0;
+    Located L = locate(key, tid, tbo, t.C);
+    int res = act ? (L.ok ? kInit : kIllegal) : kIllegal;
+    int slot = -1;
+    uint64_t ev_key = 0, ev_score = 0;
+
+    if (L.ok) {
+      uint64_t* ks = t.keys(L.bucket);
+      // ---- existing key / first Empty slot (insert_probe, kernels.cuh:189-224) ----
+      bool fresh = false;
+      while (true) {
+        int found_slot, empty_slot;
+        group_probe(t, L.bucket, key, L.hash, fresh, true, found_slot, empty_slot);
+        int ok = 0;  // 0 exhausted, 1 assigned, 2 inserted, 3 retry, 4 lost the lock on an existing key
+        if (found_slot >= 0) {
+          if (g == 0) { uint64_t e = key; ok = cas64(ks + found_slot, e, kLockedKey) ? 1 : 4; }
+          ok = group_bcast(ok, 0);
+          slot = found_slot;
+        } else if (empty_slot >= 0) {
+          if (g == 0) {
+            uint64_t e = kEmptyKey;
+            if (cas64(ks + empty_slot, e, kLockedKey)) {
+              t.dig(L.bucket)[empty_slot] = digest_of(L.hash);
+              atomicAdd(&bucket_sizes[L.bucket], 1);
+              ok = 2;
+            } else ok = 3;
+          }
+          ok = group_bcast(ok, 0);
+          slot = empty_slot;
+        }
+        if (ok == 1) { res = kAssigned; break; }
+        if (ok == 2) { res = kInsert; break; }
+        if (ok == 3) { fresh = true; continue; }
+        break;  // exhausted or lock lost -> eviction path with res == kInit
+      }
+      // ---- bucket full: evict the minimum score (insert(), kernels.cuh:226-287) ----
+      while (res == kInit) {
+        uint64_t best = ~0ull, bkey = 0;
+        int bslot = -1;
+        const uint64_t* sc = t.scores(L.bucket);
+        const int32_t* cnt = counter ? counter + L.bucket * t.C : nullptr;
+        for (int s0 = 2 * g; s0 < C; s0 += 2 * G) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int s = s0 + u;
+            uint64_t v = ald64(sc + (int64_t)s * t.ns + (t.ns - 1));
+            if (v < best) {
+              uint64_t k = ald64(ks + s);
+              if (k == kLockedKey || k == kEmptyKey) continue;
+              if (cnt && __hip_atomic_load(cnt + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;
+              best = v; bslot = s; bkey = k;
+            }
+          }
+        }
+        group_argmin(best, bslot, bkey);
+        if (bslot < 0) { res = kBusy; ev_key = key; ev_score = score; break; }
+        int ok = 0;  // 0 retry, 1 reclaim, 2 evict
+        if (g == 0) {
+          uint64_t e = bkey;
+          if (cas64(ks + bslot, e, kLockedKey)) {
+            bool good = true;
+            if (bkey != kReclaimKey && cnt &&
+                __hip_atomic_load(cnt + bslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0)
+              good = false;
+            if (good && ald64(sc + (int64_t)bslot * t.ns + (t.ns - 1)) != best) good = false;
+            if (!good) {
+              ast64(ks + bslot, bkey);
+            } else {
+              t.dig(L.bucket)[bslot] = digest_of(L.hash);
+              if (bkey == kReclaimKey) { atomicAdd(&bucket_sizes[L.bucket], 1); ok = 1; }
+              else {
+                for (int64_t w = 0; w < t.ns; ++w) ast64((uint64_t*)sc + (int64_t)bslot * t.ns + w, 0);
+                ok = 2;
+              }
+            }
+          }
+        }
+        ok = group_bcast(ok, 0);
+        if (ok == 1) { res = kReclaim; slot = bslot; }
+        else if (ok == 2) { res = kEvict; slot = bslot; ev_key = bkey; ev_score = best; }
+      }
+    }
+
+    int64_t index = -1;
+    if (act && g == 0 && res <= kEvict) {
+      score = policy_update(policy, t.scores(L.bucket) + (int64_t)slot * t.ns, score, timer);
+      index = (L.bucket - L.bkt_begin) * t.C + slot;
+    }
+    // ---- evicted-stream compaction: one ballot + one atomic per wave (kernels.cuh:522-556) ----
+    if (num_evicted) {
+      const bool ev = act && g == 0 && (res == kEvict || res == kBusy);
+      const uint64_t vote = __ballot(ev);
+      if (vote) {
+        const int lane = lane_id();
+        const int leader = __ffsll((unsigned long long)vote) - 1;
+        unsigned long long off = 0;
+        if (lane == leader) off = atomicAdd(num_evicted, (unsigned long long)__popcll(vote));
+        uint32_t lo = __shfl((int)(uint32_t)off, leader, 64), hi = __shfl((int)(uint32_t)(off >> 32), leader, 64);
+        off = ((unsigned long long)hi << 32) | lo;
+        if (ev) {
+          int64_t o = (int64_t)off + __popcll(vote & ((1ull << lane) - 1));
+          ev_keys[o] = ev_key;
+          ev_scores[o] = (int64_t)ev_score;
+          ev_indices[o] = res == kEvict ? index : -(i + 1);
+          ev_table_ids[o] = tid;
+        }
+      }
+    }
+    if (act && g == 0) {
+      indices[i] = index;
+      if (results) results[i] = (uint8_t)res;
+      if (score_out) score_out[i] = (int64_t)score;
+    }
+  }
+}
+
+// table_unlock_kernel (kernels.cuh:569-585): publish the real key into every slot taken above.
+__global__ void __launch_bounds__(256)
+table_unlock_kernel(Table t, const int64_t* __restrict__ tbo, int64_t n, const int64_t* __restrict__ n_dev,
+                    const uint64_t* __restrict__ keys, const int64_t* __restrict__ table_ids,
+                    const uint8_t* __restrict__ skip, const int64_t* __restrict__ indices) {
+  if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (skip && skip[i]) continue;
+    int64_t idx = indices[i];
+    if (idx < 0) continue;
+    int64_t tid = table_ids ? table_ids[i] : 0;
+    int64_t b = tbo[tid] + idx / t.C;
+    ast64(t.keys(b) + idx % t.C, keys[i]);
+  }
+}
+
+// table_erase_kernel (kernels.cuh:587-652)
+__global__ void __launch_bounds__(256)
+table_erase_kernel(Table t, const int64_t* __restrict__ tbo, int32_t* __restrict__ bucket_sizes, int64_t n,
+                   const uint64_t* __restrict__ keys, const int64_t* __restrict__ table_ids,
+                   int64_t* __restrict__ indices) {
+  const int g = lane_id() & (G - 1);
+  const int64_t gpb = blockDim.x / G;
+  const uint8_t ed = digest_of((int64_t)(fmix64(kEmptyKey) & 0x7FFFFFFFFFFFFFFFull));
+  for (int64_t base = (int64_t)blockIdx.x * gpb; base < n; base += (int64_t)gridDim.x * gpb) {
+    const int64_t i = base + threadIdx.x / G;
+    const bool act = i < n;
+    uint64_t key = act ? keys[i] : kEmptyKey;
+    int64_t tid = act ? (table_ids ? table_ids[i] : 0) : 0;
+    Located L = locate(key, tid, tbo, t.C);
+    int found_slot = -1, empty_slot = -1;
+    if (L.ok) group_probe(t, L.bucket, key, L.hash, false, false, found_slot, empty_slot);
+    if (act && g == 0) {
+      int64_t index = -1;
+      if (found_slot >= 0) {
+        uint64_t* kp = t.keys(L.bucket) + found_slot;
+        uint64_t e = key;
+        if (cas64(kp, e, kLockedKey)) {
+          ast64(t.scores(L.bucket) + (int64_t)found_slot * t.ns, 0);
+          t.dig(L.bucket)[found_slot] = ed;
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          ast64(kp, kReclaimKey);
+          atomicSub(&bucket_sizes[L.bucket], 1);
+          index = (L.bucket - L.bkt_begin) * t.C + found_slot;
+        }
+      }
+      if (indices) indices[i] = index;
+    }
+  }
+}
+
+// update_counter_with_layout_kernel (insert_and_evict.cu:27-58), main table part: non-atomic +=
+// (the caller guarantees unique (table, slot) pairs, scored_hashtable.py:680-684).
+__global__ void __launch_bounds__(256)
+update_counter_kernel(int32_t* __restrict__ counter, int64_t total, const int64_t* __restrict__ slots, int64_t n,
+                      const int64_t* __restrict__ n_dev, int32_t delta, const int64_t* __restrict__ table_ids,
+                      const int64_t* __restrict__ tbo, int64_t C) {
+  if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t s = slots[i];
+    if (s < 0) continue;
+    int64_t flat = (table_ids && tbo) ? tbo[table_ids[i]] * C + s : s;
+    if (flat >= 0 && flat < total) counter[flat] += delta;
+  }
+}
+
+__global__ void device_timestamp_kernel(int64_t* out) { *out = (int64_t)device_clock(); }
+
+}  // namespace mi355
+
+using namespace mi355;
+
+static Table make_table(void* storage, int64_t C, int64_t ns) {
+  Table t;
+  t.storage = (uint8_t*)storage; t.C = C; t.ns = ns; t.stride = (9 + 8 * ns) * C;
+  return t;
+}
+
+extern "C" {
+
+int mi355_table_init(void* storage, int64_t num_buckets, int64_t C, int64_t num_scores, hipStream_t stream) {
+  MI355_CHECK_ARG(C > 0 && C % 16 == 0, "bucket capacity must be a positive multiple of 16");
+  MI355_CHECK_ARG(num_scores >= 1 && num_scores <= 2, "num_scores must be 1 or 2");
+  if (num_buckets == 0) return MI355_OK;
+  Table t = make_table(storage, C, num_scores);
+  hipLaunchKernelGGL(table_init_kernel, dim3(grid_for(num_buckets * C, 256)), dim3(256), 0, stream, t, num_buckets);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int mi355_table_lookup(void* storage, const int64_t* table_bucket_offsets, int64_t C, int64_t num_scores, int64_t n,
+                       const int64_t* n_dev, const void* keys, const int64_t* table_ids, const void* score_in,
+                       int policy, uint64_t timer_override, int64_t* score_out, uint8_t* founds, int64_t* indices,
+                       hipStream_t stream) {
+  MI355_CHECK_ARG(C > 0 && C % 16 == 0, "bucket capacity must be a positive multiple of 16");
+  MI355_CHECK_ARG(policy >= kConst && policy <= kLruLfu, "bad score policy");
+  MI355_CHECK_ARG(policy == kConst || policy == kGlobalTimer || score_in, "score_in required by this policy");
+  MI355_CHECK_ARG(policy != kLruLfu || num_scores == 2, "LRU_LFU needs num_scores == 2");
+  if (n == 0) return MI355_OK;
+  Table t = make_table(storage, C, num_scores);
+  hipLaunchKernelGGL(table_lookup_kernel, dim3(grid_for(n, 256 / G)), dim3(256), 0, stream, t, table_bucket_offsets, n,
+                     n_dev, (const uint64_t*)keys, table_ids, (const uint64_t*)score_in, policy, timer_override,
+                     score_out, founds, indices);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int mi355_table_insert(void* storage, const int64_t* table_bucket_offsets, int64_t C, int64_t num_scores,
+                       int32_t* bucket_sizes, int32_t* counter, int64_t n, const int64_t* n_dev, const void* keys,
+                       const int64_t* table_ids, const void* score_in, int policy, uint64_t timer_override,
+                       const uint8_t* skip, int64_t* indices, uint8_t* results, int64_t* score_out,
+                       int64_t* num_evicted, void* evicted_keys, int64_t* evicted_indices, int64_t* evicted_scores,
+                       int64_t* evicted_table_ids, hipStream_t stream) {
+  MI355_CHECK_ARG(C > 0 && C % 16 == 0, "bucket capacity must be a positive multiple of 16");
+  MI355_CHECK_ARG(policy >= kConst && policy <= kLruLfu, "bad score policy");
+  MI355_CHECK_ARG(policy == kConst || policy == kGlobalTimer || score_in, "score_in required by this policy");
+  MI355_CHECK_ARG(policy != kLruLfu || num_scores == 2, "LRU_LFU needs num_scores == 2");
+  MI355_CHECK_ARG(!num_evicted || (evicted_keys && evicted_indices && evicted_scores && evicted_table_ids),
+                  "evicted output buffers required with num_evicted");
+  if (num_evicted) {
+    if (hipMemsetAsync(num_evicted, 0, sizeof(int64_t), stream) != hipSuccess) { mi355_set_error("memset failed"); return MI355_ELAUNCH; }
+  }
+  if (n == 0) return MI355_OK;
+  Table t = make_table(storage, C, num_scores);
+  hipLaunchKernelGGL(table_insert_kernel, dim3(grid_for(n, 256 / G)), dim3(256), 0, stream, t, table_bucket_offsets,
+                     bucket_sizes, counter, n, n_dev, (const uint64_t*)keys, table_ids, (const uint64_t*)score_in,
+                     policy, timer_override, skip, indices, results, score_out, (unsigned long long*)num_evicted,
+                     (uint64_t*)evicted_keys, evicted_indices, evicted_scores, evicted_table_ids);
+  MI355_LAUNCH_CHECK();
+  hipLaunchKernelGGL(table_unlock_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, t, table_bucket_offsets, n, n_dev,
+                     (const uint64_t*)keys, table_ids, skip, indices);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int mi355_table_erase(void* storage, const int64_t* table_bucket_offsets, int64_t C, int64_t num_scores,
+                      int32_t* bucket_sizes, int64_t n, const void* keys, const int64_t* table_ids, int64_t* indices,
+                      hipStream_t stream) {
+  MI355_CHECK_ARG(C > 0 && C % 16 == 0, "bucket capacity must be a positive multiple of 16");
+  if (n == 0) return MI355_OK;
+  Table t = make_table(storage, C, num_scores);
+  hipLaunchKernelGGL(table_erase_kernel, dim3(grid_for(n, 256 / G)), dim3(256), 0, stream, t, table_bucket_offsets,
+                     bucket_sizes, n, (const uint64_t*)keys, table_ids, indices);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int mi355_table_update_counter(int32_t* counter, int64_t counter_numel, const int64_t* slot_indices, int64_t n,
+                               const int64_t* n_dev, int32_t delta, const int64_t* table_ids,
+                               const int64_t* table_bucket_offsets, int64_t C, hipStream_t stream) {
+  if (n == 0) return MI355_OK;
+  hipLaunchKernelGGL(update_counter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, counter, counter_numel,
+                     slot_indices, n, n_dev, delta, table_ids, table_bucket_offsets, C);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int mi355_device_timestamp(int64_t* out, hipStream_t stream) {
+  hipLaunchKernelGGL(device_timestamp_kernel, dim3(1), dim3(1), 0, stream, out);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,145 @@
+"""ctypes loader of librecsys_amd.so (the C ABI of include/recsys_amd.h).
+
+PyTorch is plumbing only: tensors provide device memory and the current HIP stream; every
+compute call goes through the C ABI with raw pointers.  There is NO CPU or eager fallback: if
+the library is missing, or a call is made without a GPU, this raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librecsys_amd.so")
+
+c_i64 = ctypes.c_int64
+c_u64 = ctypes.c_uint64
+c_int = ctypes.c_int
+c_f = ctypes.c_float
+c_p = ctypes.c_void_p
+
+DT_F32, DT_BF16, DT_F16 = 0, 1, 2
+_DT = {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.float16: DT_F16}
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+_SIGS = {
+    "mi355_table_init": [c_p, c_i64, c_i64, c_i64, c_p],
+    "mi355_table_lookup": [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_int, c_u64, c_p, c_p, c_p, c_p],
+    "mi355_table_insert": [c_p, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_int, c_u64, c_p, c_p, c_p,
+                           c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "mi355_table_erase": [c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p],
+    "mi355_table_update_counter": [c_p, c_i64, c_p, c_i64, c_p, ctypes.c_int32, c_p, c_p, c_i64, c_p],
+    "mi355_device_timestamp": [c_p, c_p],
+    "mi355_segmented_unique": [c_p, c_i64, c_p, c_i64, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_i64, c_p],
+    "mi355_expand_table_ids": [c_p, c_i64, c_i64, c_p, c_p, c_p],
+    "mi355_get_table_range": [c_p, c_p, c_i64, c_i64, c_p, c_p],
+    "mi355_flagged_compact": [c_p, c_i64, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_i64, c_p],
+    "mi355_group_by_unique": [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p],
+    "mi355_block_bucketize": [c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "mi355_gather_pooled": [c_p, c_i64, c_p, c_int, c_p, c_p, c_i64, c_i64, c_int, c_i64, c_p, c_i64, c_p, c_int,
+                            c_int, c_p],
+    "mi355_gather_rows": [c_p, c_i64, c_p, c_int, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_int, c_int, c_p],
+    "mi355_flat_table_copy": [c_int, c_int, c_i64, c_p, c_p, c_i64, c_i64, c_int, c_p, c_p, c_i64, c_p, c_p, c_p,
+                              c_i64, c_p],
+    "mi355_row_addresses": [c_i64, c_p, c_p, c_p, c_p, c_p, c_int, c_p, c_p],
+    "mi355_init_rows": [c_int, c_f, c_f, c_f, c_f, c_u64, c_f, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_i64,
+                        c_i64, c_p, c_p, c_p],
+    "mi355_backward_fused": [c_p, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_int, c_p, c_p, c_i64, c_i64, c_int, c_p,
+                             c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_int, c_p, c_i64, c_int, c_p,
+                             c_i64, c_p],
+    "mi355_optimizer_update": [c_int, c_p, c_i64, c_int, c_i64, c_p, c_p, c_p, c_i64, c_int, c_i64, c_i64, c_f, c_f,
+                               c_f, c_f, c_f, c_i64, c_int, c_p],
+    "mi355_segmented_unique_workspace_bytes": [c_i64],
+    "mi355_flagged_compact_workspace_bytes": [c_i64],
+    "mi355_group_by_unique_workspace_bytes": [c_i64, c_i64],
+    "mi355_backward_workspace_bytes": [c_i64, c_i64],
+    "mi355_abi_version": [],
+    "mi355_last_error": [],
+}
+_RESTYPES = {
+    "mi355_segmented_unique_workspace_bytes": c_i64,
+    "mi355_flagged_compact_workspace_bytes": c_i64,
+    "mi355_group_by_unique_workspace_bytes": c_i64,
+    "mi355_backward_workspace_bytes": c_i64,
+    "mi355_last_error": ctypes.c_char_p,
+}
+_OPTIONAL_SIGS = {}  # filled by optional modules (e.g. hstu) before first load
+
+
+def register_signatures(sigs, restypes=None):
+    _OPTIONAL_SIGS.update(sigs)
+    if restypes:
+        _RESTYPES.update(restypes)
+    if _lib is not None:
+        _bind(_lib, sigs)
+
+
+def _bind(lib, sigs):
+    for name, args in sigs.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.argtypes = args
+        fn.restype = _RESTYPES.get(name, c_int)
+
+
+def exported_symbols():
+    return sorted(list(_SIGS) + list(_OPTIONAL_SIGS))
+
+
+def lib():
+    """Loads the HIP library.  Raises NativeError if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} not found: build it with `python recsys-examples_amd/build.py` "
+                "(or __graft_entry__.build()); this package has no CPU/eager fallback"
+            )
+        l = ctypes.CDLL(LIB_PATH)
+        _bind(l, _SIGS)
+        _bind(l, _OPTIONAL_SIGS)
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().mi355_last_error()
+        raise NativeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def dt(t_or_dtype) -> int:
+    d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    try:
+        return _DT[d]
+    except KeyError:
+        raise NativeError(f"unsupported dtype {d}")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Raw device pointer of a tensor (None -> NULL).  Refuses CPU tensors: the kernels only run
+    on the GPU and there is deliberately no host implementation behind this ABI."""
+    if t is None:
+        return c_p(0)
+    if not t.is_cuda:
+        raise NativeError("librecsys_amd expects GPU tensors (no CPU fallback exists)")
+    return c_p(t.data_ptr())
+
+
+def stream() -> ctypes.c_void_p:
+    return c_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_contiguous(*ts):
+    for t in ts:
+        if t is not None and not t.is_contiguous():
+            raise NativeError("tensor must be contiguous")

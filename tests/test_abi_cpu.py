@@ -1,0 +1,65 @@
+"""CPU checks of the drop-in boundary: librecsys_amd.so loads without a GPU, exports every symbol
+include/recsys_amd.h declares, rejects bad arguments with an error code + message, and the
+Python shims refuse CPU tensors (there is no CPU fallback behind the ABI)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    names = set()
+    for fn in os.listdir(os.path.join(ROOT, "include")):
+        if fn.endswith(".h"):
+            src = open(os.path.join(ROOT, "include", fn)).read()
+            names |= set(re.findall(r"\b(mi355_\w+)\s*\(", src))
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol():
+    import mi355_native as N
+
+    lib = N.lib()
+    decl = _declared()
+    assert len(decl) >= 25
+    for name in decl:
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+    assert lib.mi355_abi_version() >= 1
+    # and the python binding table covers the header
+    assert set(decl) <= set(N.exported_symbols()) | {"mi355_set_error"}
+
+
+def test_bad_arguments_are_error_codes_not_crashes():
+    import mi355_native as N
+
+    lib = N.lib()
+    rc = lib.mi355_table_init(None, 4, 100, 1, None)  # capacity not a multiple of 16
+    assert rc == -1 and b"multiple of 16" in lib.mi355_last_error()
+    rc = lib.mi355_table_lookup(None, None, 128, 1, 0, None, None, None, None, 9, 0, None, None, None, None)
+    assert rc == -1 and b"policy" in lib.mi355_last_error()
+    rc = lib.mi355_segmented_unique(None, 10, None, 0, None, 0, None, None, None, None, None, 0, None)
+    assert rc == -1
+    assert lib.mi355_segmented_unique_workspace_bytes(1000) > 16 * 1000
+
+
+def test_shims_refuse_cpu_tensors():
+    import dynamicemb_extensions as ext
+    import mi355_native as N
+
+    with pytest.raises(N.NativeError):
+        ext.table_init(torch.zeros(17 * 16, dtype=torch.uint8), 16, 1)
+
+
+def test_table_partition_views_cpu():
+    import dynamicemb_extensions as ext
+
+    C, nb = 16, 3
+    st = torch.arange(17 * C * nb, dtype=torch.int64).to(torch.uint8)
+    keys, dig, sc = ext.table_partition(st, [torch.int64, torch.uint8, torch.uint64], C, nb)
+    assert keys.shape == (nb, C) and dig.shape == (nb, C) and sc.shape == (nb, C)
+    assert dig[1, 2].item() == st[17 * C + 8 * C + 2].item()
+    assert keys.stride() == (17 * C // 8, 1)
