@@ -498,12 +498,12 @@ int mi355_segmented_unique(const void* keys, int64_t n, const int64_t* segmented
                            int64_t workspace_bytes, hipStream_t stream) {
   MI355_CHECK_ARG(num_tables > 0, "num_tables must be positive");
   MI355_CHECK_ARG(n < 0x7fffffffLL / 2, "num_keys must be < 2^30");
-  MI355_CHECK_ARG(!count_freq || freq, "freq output required when counting frequencies");
   if (n == 0) {
     hipLaunchKernelGGL(zero_offsets_kernel, dim3(1), dim3(64), 0, stream, table_offsets, num_tables + 1);
     MI355_LAUNCH_CHECK();
     return MI355_OK;
   }
+  MI355_CHECK_ARG(!count_freq || freq, "freq output required when counting frequencies");
   MI355_CHECK_ARG(workspace && workspace_bytes >= mi355_segmented_unique_workspace_bytes(n), "workspace too small");
   const int64_t nb = ceil_div(n, kScanTile);
   uint8_t* w = (uint8_t*)workspace;

@@ -342,6 +342,21 @@ def _tol(dtype):
     return dict(rtol=1e-3, atol=1e-3) if dtype != torch.float32 else dict(rtol=1e-5, atol=1e-5)
 
 
+def assert_close_lowp(got, exp, dtype, rtol=1e-3):
+    """Tolerance for 16-bit outputs (north_star: 1e-3 relative on bf16 values): the fp32 sums of both
+    sides agree to `rtol`; after the final rounding a value that sits on a rounding boundary may land on
+    the neighbouring 16-bit number, so one unit in the last place of the output type is allowed on top."""
+    got = np.asarray(got, np.float32)
+    exp = np.asarray(exp, np.float32)
+    if dtype == torch.float32:
+        np.testing.assert_allclose(got, exp, rtol=1e-5, atol=1e-5)
+        return
+    mant = 8 if dtype == torch.bfloat16 else 11
+    ulp = np.exp2(np.floor(np.log2(np.maximum(np.abs(exp), 1e-30))) - (mant - 1)).astype(np.float32)
+    bad = np.abs(got - exp) > rtol * np.abs(exp) + ulp + 1e-6
+    assert not bad.any(), f"{bad.sum()} of {bad.size} beyond 1e-3 rel + 1 ulp; worst {np.abs(got - exp).max()}"
+
+
 _NP = {torch.float32: "f32", torch.bfloat16: "bf16", torch.float16: "f16"}
 
 
@@ -362,7 +377,7 @@ def test_gather_pooled(D, sdt, ddt, combiner):
     exp = orc.gather_pooled(src, rev, offsets, B, combiner, out_dtype=_NP[ddt])
     out = torch.empty(B, F * D, dtype=ddt, device=DEV)
     e.gather_embedding_pooled(T(src, sdt), out, T(rev), T(offsets), combiner, F * D, B)
-    np.testing.assert_allclose(out.float().cpu().numpy(), exp, **_tol(ddt))
+    assert_close_lowp(out.float().cpu().numpy(), exp, ddt)
 
 
 def test_gather_pooled_mixed_dims_and_row_addr():
@@ -396,7 +411,7 @@ def test_gather_pooled_mixed_dims_and_row_addr():
     exp2 = orc.gather_pooled(uniq, rev2, off2, B, 1, out_dtype="bf16")
     out2 = torch.empty(B, F2 * D, dtype=torch.bfloat16, device=DEV)
     e.gather_embedding_pooled(None, out2, T(rev2), T(off2), 1, F2 * D, B, max_D=D, row_addr=addr, src_dtype=torch.float32)
-    np.testing.assert_allclose(out2.float().cpu().numpy(), exp2, rtol=1e-3, atol=1e-3)
+    assert_close_lowp(out2.float().cpu().numpy(), exp2, torch.bfloat16)
 
 
 @pytest.mark.parametrize("D", [8, 7, 128, 300])
@@ -533,8 +548,9 @@ def test_backward_fused_optimizers(opt, D, wdt, gdt):
     kinds = {"sgd": (1, 0), "adam": (2, 2 * D), "adagrad": (3, D), "rowwise_adagrad": (4, 16 // (4 if wdt == torch.float32 else 2))}
     kind, nstate = kinds[opt]
     vdim = D + nstate
-    table0 = orc.round_to(rng.standard_normal((cap, vdim)).astype(np.float32) * 0.1, _NP[wdt])
+    table0 = rng.standard_normal((cap, vdim)).astype(np.float32) * 0.1
     table0[:, D:] = 0.0 if opt != "adagrad" else 0.1
+    table0 = orc.round_to(table0, _NP[wdt])
     table = T(table0, wdt).contiguous()
     slots = rng.choice(cap, size=Nu, replace=False).astype(np.int64)
     slots[5] = -1  # failed insert: skipped
