@@ -1,0 +1,269 @@
+#!/usr/bin/env python
+"""bench.py -- DynamicEmb lookup+pool forward/backward on MI355X (BASELINE.json configs[1], "C2").
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one synthetic batch that is already resident in HBM:
+forward (dedup -> hash lookup -> [insert + init of unseen keys: none in steady state] -> fused
+gather+pool straight from the table rows -> bf16 [B, 128]) and backward (group keys by unique row
+-> reduce the bf16 gradients -> SGD in place on the fp32 table rows).
+
+Workload (SURVEY 8(d) "C2"): 1 table x 10,000,000 rows x 128-D fp32, SGD; B = 65,536 bags, bag
+length randint(1, 11) (reference harness convention), keys Zipf(0.99) over 10 M ranks mapped through
+a fixed permutation (seed 1234); every timed batch is different; all touched keys are pre-inserted
+(steady state).  N > 1: row-wise model-parallel shards, one process per GPU, keys all-to-all out /
+pooled partial sums back; weak scaling (per-GPU batch fixed).
+
+Prints ONE JSON line (rank 0).  `value` = lookups (keys) per second of the whole job.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "recsys-examples_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--alpha", type=float, default=0.99)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def zipf_batches(rows, alpha, batch, n_batches, device, seed=1234):
+    """Key stream of the reference's dataset_generator.zipf() recipe (benchmark/dataset_generator.py:75-103):
+    p_r ~ r^-alpha over ranks 1..rows, sampled with replacement, rank -> key by a fixed permutation."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    w = torch.arange(1, rows + 1, device=device, dtype=torch.float64).pow_(-alpha)
+    cdf = torch.cumsum(w, 0)
+    cdf /= cdf[-1].clone()
+    perm = torch.randperm(rows, device=device, generator=g)
+    out = []
+    for _ in range(n_batches):
+        lens = torch.randint(1, 11, (batch,), device=device, generator=g)
+        offsets = torch.zeros(batch + 1, dtype=torch.int64, device=device)
+        offsets[1:] = torch.cumsum(lens, 0)
+        nt = int(offsets[-1].item())
+        u = torch.rand(nt, device=device, dtype=torch.float64, generator=g)
+        ranks = torch.searchsorted(cdf, u).clamp_(max=rows - 1)
+        out.append((perm[ranks].contiguous(), offsets))
+    return out
+
+
+def build_module(rows, dim, device):
+    from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
+    from dynamicemb.dynamicemb_config import (DynamicEmbInitializerArgs, DynamicEmbInitializerMode,
+                                              DynamicEmbPoolingMode, DynamicEmbScoreStrategy, DynamicEmbTableOptions,
+                                              EmbOptimType)
+
+    opt = DynamicEmbTableOptions(dim=dim, max_capacity=rows, embedding_dtype=torch.float32, index_type=torch.int64,
+                                 score_strategy=DynamicEmbScoreStrategy.TIMESTAMP,
+                                 initializer_args=DynamicEmbInitializerArgs(mode=DynamicEmbInitializerMode.UNIFORM,
+                                                                            lower=-0.01, upper=0.01))
+    return BatchedDynamicEmbeddingTablesV2([opt], feature_table_map=[0], pooling_mode=DynamicEmbPoolingMode.SUM,
+                                           output_dtype=torch.bfloat16, optimizer=EmbOptimType.SGD, learning_rate=0.1,
+                                           device=device)
+
+
+def cpu_baseline(args, batches_cpu):
+    """The path an unsharded TorchRec CPU EmbeddingBagCollection executes: nn.EmbeddingBag(mode='sum',
+    include_last_offset=True) forward + sparse-gradient SGD, timed on this host on a bounded sample."""
+    torch.set_num_threads(os.cpu_count() or 1)
+    t0 = time.time()
+    emb = torch.nn.EmbeddingBag(args.rows, args.dim, mode="sum", include_last_offset=True, sparse=True)
+    with torch.no_grad():
+        emb.weight.uniform_(-0.01, 0.01)
+    setup = time.time() - t0
+    keys_done, spent, iters = 0, 0.0, 0
+    for keys, offsets in batches_cpu:
+        g = torch.ones(offsets.numel() - 1, args.dim)
+        t = time.time()
+        out = emb(keys, offsets)
+        out.backward(g)
+        with torch.no_grad():
+            emb.weight.add_(emb.weight.grad, alpha=-0.1)
+        emb.weight.grad = None
+        dt_ = time.time() - t
+        if iters > 0:  # first iteration is warm-up
+            spent += dt_
+            keys_done += keys.numel()
+        iters += 1
+        if spent > args.cpu_seconds:
+            break
+    val = keys_done / spent if spent > 0 else 0.0
+    return {"value": val, "unit": "lookups/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{iters - 1} batches of {args.batch} bags ({keys_done} keys) fwd+bwd+sparse SGD through "
+                      f"torch.nn.EmbeddingBag(mode=sum) on a {args.rows}x{args.dim} fp32 host table; "
+                      f"os.cpu_count()={os.cpu_count()}, table init {setup:.1f}s not timed"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    import dynamicemb_extensions as ext
+
+    n_batches = args.steps + args.warmup
+    batches = zipf_batches(args.rows, args.alpha, args.batch, n_batches, device, seed=1234 + rank)
+
+    if world == 1:
+        module = build_module(args.rows, args.dim, device)
+        module.train()
+
+        def fwd(keys, offsets):
+            return module._forward_impl(keys, offsets, train=True)
+
+        def bwd(st, grad):
+            module._backward_impl(st, grad)
+    else:
+        from dynamicemb.sharded import ShardedPooledLookup
+
+        sharded = ShardedPooledLookup(args.rows, args.dim, device, world, rank)
+
+        def fwd(keys, offsets):
+            return sharded.forward(keys, offsets)
+
+        def bwd(st, grad):
+            sharded.backward(st, grad)
+
+    grad = (torch.randn(args.batch, args.dim, device=device) * 0.01).to(torch.bfloat16)
+
+    # steady state: every key of every batch is already in the table
+    with torch.no_grad():
+        for keys, offsets in batches:
+            fwd(keys, offsets)
+    torch.cuda.synchronize()
+
+    def step(i):
+        keys, offsets = batches[i]
+        out, st = fwd(keys, offsets)
+        bwd(st, grad)
+        return out, st
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_batches):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    keys_local = sum(batches[i][0].numel() for i in range(args.warmup, n_batches))
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        k = torch.tensor([keys_local], device=device, dtype=torch.float64)
+        dist.all_reduce(k, op=dist.ReduceOp.SUM)
+        keys_total = float(k.item())
+    else:
+        keys_total = float(keys_local)
+
+    result = {
+        "metric": "embedding lookups/sec (DynamicEmb lookup+pool fwd+bwd, steady state)",
+        "value": keys_total / elapsed,
+        "unit": "lookups/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32 table rows, f32 accumulate, bf16 pooled output / gradients",
+        "data": "synthetic",
+        "config": {"workload": f"C2: DynamicEmb 1 table x {args.rows} rows x {args.dim}-D fp32, Zipf-{args.alpha} keys, "
+                               f"batch {args.batch} bags x randint(1,11) keys, SUM pooling, SGD, lookup+pool fwd/bwd",
+                   "keys_per_step": keys_total / args.steps / world, "parallelism": f"row-wise mp{world}" if world > 1 else "1 GPU"},
+    }
+
+    if rank == 0 and world == 1 and not args.no_kernel_timing:
+        # ---- dominant kernels, timed live with HIP events on the launch stream (torch's current stream) ----
+        nu_list, fwd_ms, bwd_ms = [], [], []
+        D, e, o = args.dim, 4, 2
+        for i in range(args.warmup, n_batches):
+            keys, offsets = batches[i]
+            out, st = fwd(keys, offsets)
+            nu = int(st.uoff[-1].item())
+            nt = keys.numel()
+            nu_list.append((nt, nu))
+            out2 = torch.empty_like(out)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+            ext.gather_embedding_pooled(None, out2, st.rev, offsets, 0, D, args.batch, max_D=D, row_addr=st.row_addr,
+                                        src_dtype=torch.float32)
+            ev[1].record()
+            ptr_t, csr = ext.group_by_unique(st.rev, nt, offsets, nu_dev=st.uoff[-1:])
+            ev[2].record()
+            ext.backward_fused(ptr_t, csr, nt, nt, grad, args.batch, D, 0, offsets, None, st.row_addr, torch.float32, 1,
+                               lr=0.1, nu_dev=st.uoff[-1:])
+            ev[3].record()
+            torch.cuda.synchronize()
+            fwd_ms.append(ev[0].elapsed_time(ev[1]))
+            bwd_ms.append(ev[2].elapsed_time(ev[3]))
+        nt_avg = float(np.mean([a for a, _ in nu_list]))
+        nu_avg = float(np.mean([b for _, b in nu_list]))
+        FB = args.batch
+        fwd_bytes = 8 * nt_avg + 8 * (FB + 1) + 8 * nu_avg + nu_avg * D * e + FB * D * o
+        bwd_bytes = 4 * nt_avg + 4 * (nu_avg + 1) + 8 * nu_avg + FB * D * o + 2 * nu_avg * D * e
+        f_ms, b_ms = float(np.median(fwd_ms)), float(np.median(bwd_ms))
+        kern = {
+            "gather_pooled_vec_kernel": {"ms": f_ms, "algorithmic_bytes": fwd_bytes, "GB/s": fwd_bytes / f_ms / 1e6},
+            "bwd_rows_kernel(+bwd_hot_kernel)": {"ms": b_ms, "algorithmic_bytes": bwd_bytes, "GB/s": bwd_bytes / b_ms / 1e6},
+        }
+        dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
+        result["roofline"] = {"bound": "hbm", "kernel": dom[0], "achieved": dom[1]["GB/s"], "peak": HBM_PEAK_GBPS,
+                              "unit": "GB/s", "frac": dom[1]["GB/s"] / HBM_PEAK_GBPS, "traffic": None,
+                              "kernels": kern, "keys_per_launch": nt_avg, "unique_rows_per_launch": nu_avg}
+        step_bytes = (8 * nt_avg + 8 * (FB + 1) + 16 * nu_avg + nu_avg * D * e + FB * D * o) + \
+                     (8 * nt_avg + FB * D * o + 2 * nu_avg * D * e)
+        result["step_algorithmic_GBps"] = step_bytes / (elapsed / args.steps) / 1e9
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # keys index host rows directly (the permuted keys are already in [0, rows))
+        bc = [(k.cpu(), o.cpu()) for k, o in batches[: min(len(batches), 8)]]
+        result["cpu_baseline"] = cpu_baseline(args, bc)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -168,7 +168,8 @@ int mi355_row_addresses(int64_t n, const int64_t* n_dev, const int64_t* slots, c
 int mi355_init_rows(int mode, float p0, float p1, float p2, float p3, uint64_t seed, float state_init,
                     int64_t n, const int64_t* n_dev, const void* keys, const int64_t* sel,
                     const int64_t* row_addr, void* dense, int64_t dense_stride, int dtype, int64_t emb_dim,
-                    int64_t value_dim, const uint8_t* results, const uint8_t* skip, hipStream_t stream);
+                    int64_t value_dim, const uint8_t* results, const uint8_t* skip, const int64_t* table_ids,
+                    const int64_t* table_emb_dims, const int64_t* table_value_dims, hipStream_t stream);
 
 /* ------------------------------------------------------------------------- backward ---- */
 
@@ -191,6 +192,39 @@ int mi355_optimizer_update(int opt_kind, const void* grads, int64_t grad_stride,
                            int weight_dtype, int64_t dim, int64_t state_offset, float lr, float beta1,
                            float beta2, float eps, float weight_decay, int64_t iter_num, int aligned16,
                            hipStream_t stream);
+
+/* ------------------------------------------------------------------ fused pipelines ---- */
+
+/* One-call forward of BatchedDynamicEmbeddingTablesV2 with HBM-only storage:
+ * dynamicemb_prefetch (_prefetch_hbm_direct_path) + DynamicEmbeddingFunction.forward, or
+ * dynamicemb_eval_forward when train == 0 (dynamicemb/batched_dynamicemb_function.py:559-932,1042-1191).
+ * No host sync; persisted arrays feed mi355_demb_backward. */
+int64_t mi355_demb_forward_workspace_bytes(int64_t num_keys, int64_t num_tables);
+int mi355_demb_forward(void* storage, const int64_t* table_bucket_offsets, int64_t bucket_capacity,
+                       int64_t num_scores, int32_t* bucket_sizes, int32_t* counter, int64_t counter_numel,
+                       const int64_t* table_ptrs, const int64_t* table_value_dims, const int64_t* table_emb_dims,
+                       int value_dtype, int64_t emb_dim, int64_t value_dim, const void* keys, int64_t num_keys,
+                       const int64_t* offsets, int64_t num_bags, int64_t batch_size, const int64_t* feature_offsets,
+                       int64_t num_tables, int train, int find_policy, const void* find_scores, int insert_policy,
+                       const void* insert_scores, uint64_t timer_override, int pin, int init_mode, float p0,
+                       float p1, float p2, float p3, uint64_t seed, float state_init, int combiner,
+                       const int32_t* D_offsets, int64_t total_D, void* out, int out_dtype, int aligned16,
+                       int64_t* reverse_indices, int64_t* unique_offsets, int64_t* table_ids, int64_t* slots,
+                       int64_t* row_addr, int64_t* freq, void* workspace, int64_t workspace_bytes,
+                       hipStream_t stream);
+
+/* One-call backward: DynamicEmbeddingFunction.backward (batched_dynamicemb_function.py:1193-1300):
+ * reduce_grads + optimizer.fused_update_for_flat_table + decrement_counter. */
+int64_t mi355_demb_backward_workspace_bytes(int64_t num_keys, int64_t dim);
+int mi355_demb_backward(const int64_t* reverse_indices, int64_t num_keys, const int64_t* unique_offsets,
+                        int64_t num_tables, const int64_t* offsets, int64_t num_bags, int64_t batch_size,
+                        const void* grads, int64_t grad_stride, int grad_dtype, const int32_t* D_offsets,
+                        int64_t dim, int combiner, const int64_t* row_addr, int value_dtype, int opt_kind, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, int64_t iter_num,
+                        int64_t state_offset, int round_grad, int aligned16, int32_t* counter,
+                        int64_t counter_numel, const int64_t* slots, const int64_t* table_ids,
+                        const int64_t* table_bucket_offsets, int64_t bucket_capacity, int unpin, void* workspace,
+                        int64_t workspace_bytes, hipStream_t stream);
 
 #ifdef __cplusplus
 }

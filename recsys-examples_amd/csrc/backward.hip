@@ -32,7 +32,8 @@ struct OptArgs {
   int kind;
   float lr, beta1, beta2, eps, weight_decay;
   float bias1, bias2;   // 1 - beta^t (Adam), computed on the host
-  int state_offset;     // elements from the row start to the first optimizer state (emb_dim, or max_emb_dim)
+  int state_offset;     // elements from the row start to the first optimizer state (emb_dim, or max_emb_dim);
+                        // < 0: the row's own embedding dim (flat tables with per-table dims)
   // kOptStore: write the reduced gradient to a dense tensor
   void* out; int64_t out_stride;
 };
@@ -131,8 +132,10 @@ __device__ __forceinline__ float group_sum(float v, int lpr_log2) {
 // (element W*(c + k*LPR) + w).  Called by ALL 64 lanes (row-wise AdaGrad needs a group reduction);
 // only row group 0 (sub == 0) touches memory.
 template <int WDT, int GDT, int NCOL, bool kVec>
-__device__ __forceinline__ void apply_sink(const OptArgs& o, int64_t u, void* row, int D, int lpr_log2, bool round_grad,
+__device__ __forceinline__ void apply_sink(const OptArgs& o_in, int64_t u, void* row, int D, int lpr_log2, bool round_grad,
                                            float (&g)[NCOL][4]) {
+  OptArgs o = o_in;
+  if (o.state_offset < 0) o.state_offset = D;
   const int lane = lane_id();
   const int LPR = 1 << lpr_log2;
   const int sub = lane >> lpr_log2, c = lane & (LPR - 1);
@@ -241,7 +244,12 @@ __global__ void __launch_bounds__(256) bwd_rows_kernel(BwdArgs a, OptArgs o, int
     float g[NCOL][4];
     reduce_entries<GDT, NCOL, kVec>(a, lo, hi, lpr_log2, g);
     if (cnt == 0 && o.kind != kOptStore) continue;  // unique without occurrences: nothing to apply
-    apply_sink<WDT, GDT, NCOL, kVec>(o, u, row, a.D, lpr_log2, a.round_grad != 0, g);
+    int Drow = a.D;  // mixed dims: every occurrence of a row belongs to the same table, hence the same width
+    if (a.D_offsets && a.combiner >= 0 && cnt > 0 && o.kind != kOptStore) {
+      const int f = a.csr_src[lo] / a.B;
+      Drow = a.D_offsets[f + 1] - a.D_offsets[f];
+    }
+    apply_sink<WDT, GDT, NCOL, kVec>(o, u, row, Drow, lpr_log2, a.round_grad != 0, g);
   }
 }
 
@@ -297,7 +305,12 @@ __global__ void __launch_bounds__(256) bwd_hot_kernel(BwdArgs a, OptArgs o, int 
                          : 0.f;
         }
       void* row = o.kind == kOptStore ? nullptr : reinterpret_cast<void*>(a.row_addr[u]);
-      apply_sink<WDT, GDT, NCOL, kVec>(o, u, row, a.D, lpr_log2, a.round_grad != 0, gg);
+      int Drow = a.D;
+      if (a.D_offsets && a.combiner >= 0 && o.kind != kOptStore) {
+        const int f = a.csr_src[a.ptr[u]] / a.B;
+        Drow = a.D_offsets[f + 1] - a.D_offsets[f];
+      }
+      apply_sink<WDT, GDT, NCOL, kVec>(o, u, row, Drow, lpr_log2, a.round_grad != 0, gg);
     }
     __syncthreads();
   }

@@ -1,0 +1,137 @@
+// Sync-free forward / backward pipelines of the DynamicEmb lookup: the whole per-step sequence
+// of BatchedDynamicEmbeddingTablesV2 (HBM-only storage) launched from ONE C call, with every
+// intermediate count kept on the device.
+//
+// Restates the orchestration of (reference, corelib/dynamicemb/dynamicemb/):
+//   dynamicemb_prefetch + _prefetch_hbm_direct_path   batched_dynamicemb_function.py:559-833
+//   DynamicEmbeddingFunction.forward / backward        batched_dynamicemb_function.py:1042-1300
+//   dynamicemb_eval_forward                            batched_dynamicemb_function.py:836-932
+// The reference needs 2-4 host syncs per step (segmented_unique sizes, flagged_compact counts);
+// here the step is a fixed launch sequence (hipGraph capturable).
+#include "common.h"
+#include "../../include/recsys_amd.h"
+
+extern "C" {
+
+// Scratch layout helper: byte offsets of the per-step arrays inside one workspace.
+static inline int64_t al(int64_t x) { return (x + 255) / 256 * 256; }
+
+int64_t mi355_demb_forward_workspace_bytes(int64_t num_keys, int64_t num_tables) {
+  return al(8 * (num_tables + 1)) /*table_range*/ + al(8 * num_keys) /*unique_keys*/ + al(num_keys) /*founds*/ +
+         al(num_keys) /*results*/ + mi355_segmented_unique_workspace_bytes(num_keys) + 256;
+}
+
+// Forward of one batch.
+//  keys [num_keys] grouped by feature-major bags, offsets [num_bags+1], feature_offsets [T+1] (device).
+//  Persisted outputs (caller-allocated, consumed by the backward): reverse_indices [num_keys] i64,
+//  unique_offsets [T+1] i64 (unique_offsets[T] = number of uniques), table_ids [num_keys] i64,
+//  slots [num_keys] i64, row_addr [num_keys] i64.
+//  train != 0: missing keys are inserted (insert_policy / insert_scores) and their rows initialised in
+//  place; train == 0: missing keys contribute zeros (eval, key_value_table.py:2915-2949).
+//  pooling: combiner 0 sum / 1 mean -> out [batch_size, total_D]; combiner -1 sequence -> out [num_keys, dim].
+int mi355_demb_forward(
+    /* table */ void* storage, const int64_t* table_bucket_offsets, int64_t bucket_capacity, int64_t num_scores,
+    int32_t* bucket_sizes, int32_t* counter, int64_t counter_numel,
+    /* values */ const int64_t* table_ptrs, const int64_t* table_value_dims, const int64_t* table_emb_dims,
+    int value_dtype, int64_t emb_dim,
+    int64_t value_dim,
+    /* batch */ const void* keys, int64_t num_keys, const int64_t* offsets, int64_t num_bags, int64_t batch_size,
+    const int64_t* feature_offsets, int64_t num_tables,
+    /* policies */ int train, int find_policy, const void* find_scores, int insert_policy, const void* insert_scores,
+    uint64_t timer_override, int pin,
+    /* initializer */ int init_mode, float p0, float p1, float p2, float p3, uint64_t seed, float state_init,
+    /* output */ int combiner, const int32_t* D_offsets, int64_t total_D, void* out, int out_dtype, int aligned16,
+    /* persisted */ int64_t* reverse_indices, int64_t* unique_offsets, int64_t* table_ids, int64_t* slots,
+    int64_t* row_addr, int64_t* freq /* nullable: per-unique occurrence counts (LFU scores) */,
+    /* scratch */ void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  MI355_CHECK_ARG(workspace && workspace_bytes >= mi355_demb_forward_workspace_bytes(num_keys, num_tables),
+                  "workspace too small");
+  if (num_keys == 0 && combiner < 0) return MI355_OK;
+  uint8_t* w = (uint8_t*)workspace;
+  int64_t* table_range = (int64_t*)w; w += al(8 * (num_tables + 1));
+  void* unique_keys = w; w += al(8 * num_keys);
+  uint8_t* founds = w; w += al(num_keys);
+  uint8_t* results = w; w += al(num_keys);
+  void* uws = w;
+  const int64_t uws_bytes = mi355_segmented_unique_workspace_bytes(num_keys);
+  const int64_t* nu_dev = unique_offsets + num_tables;
+  int rc;
+#define STEP(call) do { rc = (call); if (rc != MI355_OK) return rc; } while (0)
+  STEP(mi355_get_table_range(offsets, feature_offsets, num_tables, num_bags, table_range, stream));
+  STEP(mi355_segmented_unique(keys, num_keys, table_range, num_tables, nullptr, freq ? 1 : 0, unique_keys, reverse_indices,
+                              unique_offsets, freq, uws, uws_bytes, stream));
+  if (!find_scores) find_scores = freq;      // LFU: scores are the occurrence counts of this batch
+  if (!insert_scores) insert_scores = freq;
+  if (num_keys > 0) {
+    STEP(mi355_expand_table_ids(unique_offsets, num_tables, num_keys, nu_dev, table_ids, stream));
+    STEP(mi355_table_lookup(storage, table_bucket_offsets, bucket_capacity, num_scores, num_keys, nu_dev, unique_keys,
+                            table_ids, find_scores, find_policy, timer_override, nullptr, founds, slots, stream));
+    if (train) {
+      STEP(mi355_table_insert(storage, table_bucket_offsets, bucket_capacity, num_scores, bucket_sizes, counter,
+                              num_keys, nu_dev, unique_keys, table_ids, insert_scores, insert_policy, timer_override,
+                              founds, slots, results, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream));
+    }
+    STEP(mi355_row_addresses(num_keys, nu_dev, slots, table_ids, table_ptrs, table_value_dims,
+                             value_dtype == 0 ? 4 : 2, row_addr, stream));
+    if (train) {
+      STEP(mi355_init_rows(init_mode, p0, p1, p2, p3, seed, state_init, num_keys, nu_dev, unique_keys, nullptr,
+                           row_addr, nullptr, 0, value_dtype, emb_dim, value_dim, results, founds, table_ids, table_emb_dims,
+                           table_value_dims, stream));
+      if (pin)
+        STEP(mi355_table_update_counter(counter, counter_numel, slots, num_keys, nu_dev, 1, table_ids,
+                                        table_bucket_offsets, bucket_capacity, stream));
+    }
+  }
+  if (combiner >= 0) {
+    STEP(mi355_gather_pooled(nullptr, 0, row_addr, value_dtype, reverse_indices, offsets, num_bags, batch_size,
+                             combiner, emb_dim, D_offsets, total_D, out, out_dtype, aligned16, stream));
+  } else {
+    STEP(mi355_gather_rows(nullptr, 0, row_addr, value_dtype, reverse_indices, num_keys, nullptr, emb_dim, out,
+                           emb_dim, out_dtype, aligned16, stream));
+  }
+#undef STEP
+  return MI355_OK;
+}
+
+int64_t mi355_demb_backward_workspace_bytes(int64_t num_keys, int64_t dim) {
+  return al(4 * (num_keys + 1)) /*ptr*/ + al(4 * (num_keys > 0 ? num_keys : 1)) /*csr*/ +
+         mi355_group_by_unique_workspace_bytes(num_keys, num_keys) + mi355_backward_workspace_bytes(num_keys, dim) + 256;
+}
+
+// Backward of one batch: group keys by unique row, reduce the gradients, apply the optimizer in place,
+// release the pins taken by the forward.
+int mi355_demb_backward(
+    const int64_t* reverse_indices, int64_t num_keys, const int64_t* unique_offsets, int64_t num_tables,
+    const int64_t* offsets, int64_t num_bags, int64_t batch_size, const void* grads, int64_t grad_stride, int grad_dtype,
+    const int32_t* D_offsets, int64_t dim, int combiner, const int64_t* row_addr, int value_dtype, int opt_kind,
+    float lr, float beta1, float beta2, float eps, float weight_decay, int64_t iter_num, int64_t state_offset,
+    int round_grad, int aligned16,
+    /* unpin */ int32_t* counter, int64_t counter_numel, const int64_t* slots, const int64_t* table_ids,
+    const int64_t* table_bucket_offsets, int64_t bucket_capacity, int unpin,
+    void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  MI355_CHECK_ARG(workspace && workspace_bytes >= mi355_demb_backward_workspace_bytes(num_keys, dim), "workspace too small");
+  if (num_keys == 0) return MI355_OK;
+  uint8_t* w = (uint8_t*)workspace;
+  int32_t* ptr = (int32_t*)w; w += al(4 * (num_keys + 1));
+  int32_t* csr = (int32_t*)w; w += al(4 * num_keys);
+  void* gws = w;
+  const int64_t gws_bytes = mi355_group_by_unique_workspace_bytes(num_keys, num_keys);
+  w += gws_bytes;
+  void* bws = w;
+  const int64_t bws_bytes = mi355_backward_workspace_bytes(num_keys, dim);
+  const int64_t* nu_dev = unique_offsets + num_tables;
+  int rc;
+  rc = mi355_group_by_unique(reverse_indices, num_keys, combiner >= 0 ? offsets : nullptr, num_bags, num_keys, nu_dev, ptr,
+                             csr, gws, gws_bytes, stream);
+  if (rc != MI355_OK) return rc;
+  rc = mi355_backward_fused(ptr, csr, num_keys, num_keys, nu_dev, grads, grad_stride, grad_dtype, offsets, D_offsets,
+                            batch_size, dim, combiner, row_addr, value_dtype, opt_kind, lr, beta1, beta2, eps, weight_decay,
+                            iter_num, state_offset, round_grad, nullptr, 0, aligned16, bws, bws_bytes, stream);
+  if (rc != MI355_OK) return rc;
+  if (unpin)
+    rc = mi355_table_update_counter(counter, counter_numel, slots, num_keys, nu_dev, -1, table_ids, table_bucket_offsets,
+                                    bucket_capacity, stream);
+  return rc;
+}
+
+}  // extern "C"

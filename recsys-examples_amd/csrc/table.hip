@@ -226,7 +226,7 @@ table_lookup_kernel(Table t, const int64_t* __restrict__ tbo, int64_t n, const i
         }
         if (found) index = (L.bucket - L.bkt_begin) * t.C + found_slot;
       }
-      score_out[i] = (int64_t)score;
+      if (score_out) score_out[i] = (int64_t)score;
       founds[i] = found ? 1 : 0;
       indices[i] = index;
     }

@@ -268,7 +268,9 @@ template <int DT>
 __global__ void __launch_bounds__(256)
 init_rows_kernel(InitArgs a, int64_t n, const int64_t* __restrict__ n_dev, const uint64_t* __restrict__ keys,
                  const int64_t* __restrict__ sel, const int64_t* __restrict__ row_addr, void* dense, int64_t dense_stride,
-                 int emb_dim, int value_dim, const uint8_t* __restrict__ results, const uint8_t* __restrict__ skip) {
+                 int emb_dim, int value_dim, const uint8_t* __restrict__ results, const uint8_t* __restrict__ skip,
+                 const int64_t* __restrict__ table_ids, const int64_t* __restrict__ table_emb_dims,
+                 const int64_t* __restrict__ table_value_dims) {
   if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
   const int lane = lane_id();
   const int64_t wpb = blockDim.x >> 6;
@@ -280,8 +282,10 @@ init_rows_kernel(InitArgs a, int64_t n, const int64_t* __restrict__ n_dev, const
                         : (void*)(reinterpret_cast<typename Elem<DT>::T*>(dense) + i * dense_stride);
     if (!rp) continue;
     const uint64_t key = keys[i];
-    for (int e = lane; e < value_dim; e += 64)
-      st1<DT>(rp, e, e < emb_dim ? init_value(a, key, (uint32_t)e) : a.state_init);
+    int ed = emb_dim, vd = value_dim;
+    if (table_ids && table_emb_dims) { const int64_t t = table_ids[i]; ed = (int)table_emb_dims[t]; vd = (int)table_value_dims[t]; }
+    for (int e = lane; e < vd; e += 64)
+      st1<DT>(rp, e, e < ed ? init_value(a, key, (uint32_t)e) : a.state_init);
   }
 }
 
@@ -393,7 +397,8 @@ int mi355_row_addresses(int64_t n, const int64_t* n_dev, const int64_t* slots, c
 int mi355_init_rows(int mode, float p0, float p1, float p2, float p3, uint64_t seed, float state_init, int64_t n,
                     const int64_t* n_dev, const void* keys, const int64_t* sel, const int64_t* row_addr, void* dense,
                     int64_t dense_stride, int dtype, int64_t emb_dim, int64_t value_dim, const uint8_t* results,
-                    const uint8_t* skip, hipStream_t stream) {
+                    const uint8_t* skip, const int64_t* table_ids, const int64_t* table_emb_dims,
+                    const int64_t* table_value_dims, hipStream_t stream) {
   MI355_CHECK_ARG(mode >= 0 && mode <= 4, "bad initializer mode");
   MI355_CHECK_ARG(row_addr || dense, "row_addr or dense required");
   if (n == 0) return MI355_OK;
@@ -401,7 +406,8 @@ int mi355_init_rows(int mode, float p0, float p1, float p2, float p3, uint64_t s
   const int grid = grid_for(n, 4, 1 << 20);
   return MI355_DISPATCH_DTYPE(dtype, DT, [&] {
     hipLaunchKernelGGL((init_rows_kernel<DT>), dim3(grid), dim3(256), 0, stream, a, n, n_dev, (const uint64_t*)keys, sel, row_addr,
-                       dense, dense_stride, (int)emb_dim, (int)value_dim, results, skip);
+                       dense, dense_stride, (int)emb_dim, (int)value_dim, results, skip, table_ids, table_emb_dims,
+                       table_value_dims);
     MI355_LAUNCH_CHECK();
     return MI355_OK;
   });

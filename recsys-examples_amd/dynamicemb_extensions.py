@@ -462,7 +462,7 @@ def _init(mode, buffer, indices, keys, p, ctx=None):
     check(lib().mi355_init_rows(mode, c_f(p[0]), c_f(p[1]), c_f(p[2]), c_f(p[3]), c_u64(seed), c_f(0.0), n, None,
                                 ptr(keys if keys is not None else torch.arange(buffer.size(0), device=buffer.device)),
                                 ptr(indices), None, ptr(buffer), buffer.stride(0), dt(buffer), buffer.size(1),
-                                buffer.size(1), None, None, stream()), "init_rows")
+                                buffer.size(1), None, None, None, None, None, stream()), "init_rows")
 
 
 def uniform_init(buffer, indices, curand_ctx, lower, upper, keys=None):
@@ -607,10 +607,11 @@ def rowwise_adagrad_update_for_padded_buffer(grads, values, table_ids, table_emb
 
 
 def init_rows(mode, params, seed, state_init, keys, row_addr, dtype, emb_dim, value_dim, results=None, skip=None,
-              n_dev=None):
+              n_dev=None, table_ids=None, table_emb_dims=None, table_value_dims=None):
     """first-touch initialisation of table rows IN PLACE (fuses initializer + store_to_flat of
     batched_dynamicemb_function.py:648-676)."""
     p = list(params) + [0.0] * (4 - len(params))
     check(lib().mi355_init_rows(int(mode), c_f(p[0]), c_f(p[1]), c_f(p[2]), c_f(p[3]), c_u64(seed), c_f(state_init),
                                 keys.numel(), ptr(n_dev), ptr(keys), None, ptr(row_addr), None, 0, dt(dtype), emb_dim,
-                                value_dim, ptr(_u8(results)), ptr(_u8(skip)), stream()), "init_rows")
+                                value_dim, ptr(_u8(results)), ptr(_u8(skip)), ptr(table_ids), ptr(table_emb_dims),
+                                ptr(table_value_dims), stream()), "init_rows")

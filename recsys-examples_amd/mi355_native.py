@@ -53,7 +53,20 @@ _SIGS = {
                               c_i64, c_p],
     "mi355_row_addresses": [c_i64, c_p, c_p, c_p, c_p, c_p, c_int, c_p, c_p],
     "mi355_init_rows": [c_int, c_f, c_f, c_f, c_f, c_u64, c_f, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_i64,
-                        c_i64, c_p, c_p, c_p],
+                        c_i64, c_p, c_p, c_p, c_p, c_p, c_p],
+    "mi355_demb_forward": [c_p, c_p, c_i64, c_i64, c_p, c_p, c_i64,  # table
+                           c_p, c_p, c_p, c_int, c_i64, c_i64,  # values
+                           c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i64,  # batch
+                           c_int, c_int, c_p, c_int, c_p, c_u64, c_int,  # policies
+                           c_int, c_f, c_f, c_f, c_f, c_u64, c_f,  # initializer
+                           c_int, c_p, c_i64, c_p, c_int, c_int,  # output
+                           c_p, c_p, c_p, c_p, c_p, c_p,  # persisted (+ freq)
+                           c_p, c_i64, c_p],
+    "mi355_demb_backward": [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_int, c_p, c_i64, c_int, c_p,
+                            c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_int, c_int, c_p, c_i64, c_p, c_p,
+                            c_p, c_i64, c_int, c_p, c_i64, c_p],
+    "mi355_demb_forward_workspace_bytes": [c_i64, c_i64],
+    "mi355_demb_backward_workspace_bytes": [c_i64, c_i64],
     "mi355_backward_fused": [c_p, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_int, c_p, c_p, c_i64, c_i64, c_int, c_p,
                              c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_int, c_p, c_i64, c_int, c_p,
                              c_i64, c_p],
@@ -71,6 +84,8 @@ _RESTYPES = {
     "mi355_flagged_compact_workspace_bytes": c_i64,
     "mi355_group_by_unique_workspace_bytes": c_i64,
     "mi355_backward_workspace_bytes": c_i64,
+    "mi355_demb_forward_workspace_bytes": c_i64,
+    "mi355_demb_backward_workspace_bytes": c_i64,
     "mi355_last_error": ctypes.c_char_p,
 }
 _OPTIONAL_SIGS = {}  # filled by optional modules (e.g. hstu) before first load
