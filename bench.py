@@ -228,10 +228,10 @@ def main():
             ext.gather_embedding_pooled(None, out2, st.rev, offsets, 0, D, args.batch, max_D=D, row_addr=st.row_addr,
                                         src_dtype=torch.float32)
             ev[1].record()
-            ptr_t, csr = ext.group_by_unique(st.rev, nt, offsets, nu_dev=st.uoff[-1:])
+            ptr_t, csr, hot = ext.group_by_unique(st.rev, nt, offsets, nu_dev=st.uoff[-1:], dim=D)
             ev[2].record()
             ext.backward_fused(ptr_t, csr, nt, nt, grad, args.batch, D, 0, offsets, None, st.row_addr, torch.float32, 1,
-                               lr=0.1, nu_dev=st.uoff[-1:])
+                               lr=0.1, nu_dev=st.uoff[-1:], hot=hot)
             ev[3].record()
             torch.cuda.synchronize()
             fwd_ms.append(ev[0].elapsed_time(ev[1]))

@@ -121,9 +121,13 @@ int mi355_flagged_compact(const uint8_t* flags, int64_t n, const int64_t* n_dev,
  * generate_gather_ids_pooled_kernel + cub::DeviceRadixSort of reduce_grads, dynamic_emb_op.cu:140-263.
  * ptr: int32[max_unique+1], csr_src: int32[n] = bag id f*B+b (offsets != NULL) or key position. */
 int64_t mi355_group_by_unique_workspace_bytes(int64_t n, int64_t max_unique);
+int64_t mi355_hot_rows_workspace_bytes(int64_t num_keys, int64_t dim);
+/* hot_workspace (nullable, mi355_hot_rows_workspace_bytes(n, dim) bytes): receives the task list of the
+ * rows with more than 16 occurrences; hand the SAME buffer to mi355_backward_fused as `workspace`. */
 int mi355_group_by_unique(const int64_t* reverse_indices, int64_t n, const int64_t* offsets, int64_t num_bags,
                           int64_t max_unique, const int64_t* nu_dev, int32_t* ptr, int32_t* csr_src,
-                          void* workspace, int64_t workspace_bytes, hipStream_t stream);
+                          void* workspace, int64_t workspace_bytes, void* hot_workspace,
+                          int64_t hot_workspace_bytes, int64_t dim, hipStream_t stream);
 
 /* block_bucketize_sparse_features, src/sparse_block_bucketize_features.cu:220-350,366-830:
  * dist_type per feature 0 continuous / 1 roundrobin / 2 hash_roundrobin; offsets has num_bags+1 entries
@@ -141,7 +145,7 @@ int mi355_block_bucketize(int64_t world_size, int64_t num_bags, int64_t batch_si
  * D_offsets (int32[F+1]) NULL for uniform dim.  aligned16: rows, dims and column offsets allow
  * 4-element vector access. */
 int mi355_gather_pooled(const void* src, int64_t src_stride, const int64_t* row_addr, int src_dtype,
-                        const int64_t* reverse_indices, const int64_t* offsets, int64_t num_bags,
+                        const int64_t* reverse_indices, int64_t num_keys, const int64_t* offsets, int64_t num_bags,
                         int64_t batch_size, int combiner, int64_t dim, const int32_t* D_offsets, int64_t total_D,
                         void* dst, int dst_dtype, int aligned16, hipStream_t stream);
 

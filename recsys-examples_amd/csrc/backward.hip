@@ -9,22 +9,21 @@
 // MI355X design
 //  * Input is the CSR produced by mi355_group_by_unique (keys of the batch grouped by unique row),
 //    NOT a radix-sorted (reverse_idx, gather_id) pair stream.
-//  * One wave64 per unique row: LPR = D/4 lanes cover a gradient row, 64/LPR rows are summed per
-//    wave step, bag loop unrolled 4x, fp32 accumulation.  The finished sum goes straight into a
-//    "sink": either the dense unique_grads tensor (reference op `reduce_grads`) or the optimizer,
-//    which reads-modifies-writes the table row in place -- the [Nu, D] gradient tensor never
-//    touches HBM in the fused path.
-//  * Zipf-hot rows (more than kHot occurrences) would serialise one wave for hundreds of
-//    microseconds.  They are cut into 256-entry chunks; each chunk is summed by one block and
-//    added to a per-hot-row fp32 accumulator with agent-scope atomics, a ticket counter elects the
-//    last chunk, which applies the sink after an agent-scope acquire (release/acquire pattern of
-//    the CDNA hand-off recipe).
+//  * One LPR-lane group (LPR = D/4: half a wave at D = 128) per unique row; 4 CSR entries per round,
+//    every load of a round unconditional (padding entries read a zero row) so the round is three
+//    back-to-back batches of independent loads, fp32 accumulation in CSR order.  The finished sum goes
+//    straight into a "sink": either the dense unique_grads tensor (reference op `reduce_grads`) or
+//    the optimizer, which reads-modifies-writes the table row in place -- the [Nu, D] gradient
+//    tensor never touches HBM in the fused path.
+//  * Zipf-hot rows (more than kHot occurrences) would serialise one lane group for hundreds of
+//    microseconds.  The CSR builder cuts them into kChunk-entry tasks (hot.h); the FIRST blocks of
+//    the same launch take the tasks (one wave each, so the long work starts first), add their partial
+//    sums to a per-hot-row fp32 accumulator with agent-scope atomics, and a ticket counter elects the
+//    last task, which applies the sink after an agent-scope acquire (CDNA hand-off recipe).
 #include "common.h"
+#include "hot.h"
 
 namespace mi355 {
-
-constexpr int kHot = 256;       // rows with more occurrences than this take the chunked path
-constexpr int kChunk = 256;     // occurrences per hot chunk (one block)
 
 enum Opt : int { kOptStore = 0, kOptSgd = 1, kOptAdam = 2, kOptAdagrad = 3, kOptRowwiseAdagrad = 4 };
 
@@ -51,75 +50,118 @@ struct BwdArgs {
   const int64_t* nu_dev;    // number of uniques on the device (nullable)
   int round_grad;           // round the reduced gradient to the grad dtype first (what the reference's
                             // unique_grads tensor does, batched_dynamicemb_function.py:1242)
-  // hot-row machinery
-  int* n_hot; int* n_tasks; int* hot_u; int* hot_done; int* hot_nchunks; int* task_h; int* task_c; float* hot_acc;
-  int max_hot, max_tasks;
+  int n_entries;            // number of CSR entries (= num_keys)
+  HotList hot;              // hot-row task list built by mi355_group_by_unique (hot.n_tasks == nullptr: none)
+  int hot_blocks;           // leading blocks of the launch that serve the hot tasks
 };
 
-__device__ __forceinline__ void add4s(float4& a, const float4& b, float s) {
-  a.x += b.x * s; a.y += b.y * s; a.z += b.z * s; a.w += b.w * s;
-}
+__device__ __attribute__((aligned(16))) float g_zero_grad[1024];  // see g_zero_row in value_ops.hip
 
-// gradient row of one CSR entry
-template <int GDT>
-__device__ __forceinline__ void grad_src(const BwdArgs& a, int src, const void*& base, int64_t& off, int& Df, float& scale) {
-  scale = 1.f;
-  if (a.combiner < 0) { base = a.grads; off = (int64_t)src * a.grad_stride; Df = a.D; return; }
-  const int f = src / a.B, b = src % a.B;
-  int d0;
-  if (a.D_offsets) { d0 = a.D_offsets[f]; Df = a.D_offsets[f + 1] - d0; } else { d0 = f * a.D; Df = a.D; }
-  if (a.combiner == 1) {
-    const int64_t L = a.offsets[src + 1] - a.offsets[src];
-    if (L > 0) scale = 1.0f / (float)L;
-  }
-  base = a.grads; off = (int64_t)b * a.grad_stride + d0;
-}
+typedef const __attribute__((address_space(1))) char* gptr_t;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
-// sum of the gradient rows of CSR entries [lo, hi) -> acc (all R row groups folded, every lane of a
-// column group holds the full sum).  kVec: 4 elements per lane; else 1 element per lane per column.
-template <int GDT, int NCOL, bool kVec>
-__device__ __forceinline__ void reduce_entries(const BwdArgs& a, int lo, int hi, int lpr_log2, float (&acc)[NCOL][4]) {
-  const int lane = lane_id();
-  const int LPR = 1 << lpr_log2, R = 64 >> lpr_log2;
-  const int sub = lane >> lpr_log2, c = lane & (LPR - 1);
-  constexpr int W = kVec ? 4 : 1;
-#pragma unroll
-  for (int k = 0; k < NCOL; ++k)
-#pragma unroll
-    for (int w = 0; w < 4; ++w) acc[k][w] = 0.f;
-  for (int p0 = lo + sub; p0 < hi; p0 += 4 * R) {
-    const void* base[4]; int64_t off[4]; int Df[4]; float sc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int p = p0 + q * R;
-      base[q] = nullptr; off[q] = 0; Df[q] = 0; sc[q] = 0.f;
-      if (p < hi) grad_src<GDT>(a, a.csr_src[p], base[q], off[q], Df[q], sc[q]);
+template <int DT>
+__device__ __forceinline__ void ldNg(gptr_t p, bool vec, float (&o)[4]) {
+  if (vec) {
+    if constexpr (DT == kF32) {
+      const f32x4_t t = *reinterpret_cast<const __attribute__((address_space(1))) f32x4_t*>(p);
+      o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+    } else {
+      const u32x2_t r = *reinterpret_cast<const __attribute__((address_space(1))) u32x2_t*>(p);
+      if constexpr (DT == kBF16) {
+        o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
+        o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
+      } else {
+        o[0] = f16_to_f32((uint16_t)(r.x & 0xffff)); o[1] = f16_to_f32((uint16_t)(r.x >> 16));
+        o[2] = f16_to_f32((uint16_t)(r.y & 0xffff)); o[3] = f16_to_f32((uint16_t)(r.y >> 16));
+      }
     }
-    float4 v[4][NCOL];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int k = 0; k < NCOL; ++k) {
-        const int e = W * (c + k * LPR);
-        v[q][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (base[q] && e < Df[q]) {
-          if (kVec) v[q][k] = ld4<GDT>(base[q], off[q] + e);
-          else v[q][k].x = ld1<GDT>(base[q], off[q] + e);
-        }
-      }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int k = 0; k < NCOL; ++k) {
-        acc[k][0] += v[q][k].x * sc[q];
-        if (kVec) { acc[k][1] += v[q][k].y * sc[q]; acc[k][2] += v[q][k].z * sc[q]; acc[k][3] += v[q][k].w * sc[q]; }
-      }
+  } else {
+    if constexpr (DT == kF32) o[0] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(p);
+    else {
+      const uint16_t h = *reinterpret_cast<const __attribute__((address_space(1))) uint16_t*>(p);
+      o[0] = DT == kBF16 ? bf16_to_f32(h) : f16_to_f32(h);
+    }
+    o[1] = o[2] = o[3] = 0.f;
   }
-  for (int o = LPR; o < 64; o <<= 1)
+}
+
+// Sums of the gradient rows of NB CSR ranges [lo[b], hi[b]) by ONE lane group, RPR entries of every
+// range per round; every lane owns the columns W*(c + k*LPR) .. +W-1 of the rows.  Branch free (see the
+// kernel comment in value_ops.hip): an empty or exhausted range keeps reading a zero row.
+template <int GDT, int NCOL, bool kVec, int NB, int RPR>
+__device__ __forceinline__ void reduce_multi(const BwdArgs& a, const int (&lo)[NB], const int (&hi)[NB], int lpr_log2,
+                                             float (&acc)[NB][NCOL][4]) {
+  const int LPR = 1 << lpr_log2;
+  const int c = lane_id() & (LPR - 1);
+  constexpr int W = kVec ? 4 : 1;
+  constexpr int EB = GDT == kF32 ? 4 : 2;
+  const gptr_t zero = (gptr_t)(uintptr_t)g_zero_grad;
+  int maxcnt = 0;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
 #pragma unroll
     for (int k = 0; k < NCOL; ++k)
 #pragma unroll
-      for (int w = 0; w < W; ++w) acc[k][w] += __shfl_xor(acc[k][w], o, 64);
+      for (int w = 0; w < 4; ++w) acc[b][k][w] = 0.f;
+    maxcnt = hi[b] - lo[b] > maxcnt ? hi[b] - lo[b] : maxcnt;
+  }
+  for (int r = 0; r < maxcnt; r += RPR) {
+    int src[NB][RPR];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int q = 0; q < RPR; ++q) {
+        int p = lo[b] + r + q;
+        p = p < hi[b] ? p : hi[b] - 1;
+        p = p < lo[b] ? lo[b] : p;
+        p = p < a.n_entries ? p : a.n_entries - 1;
+        src[b][q] = a.csr_src[p];
+      }
+    uintptr_t base[NB][RPR]; int Df[NB][RPR]; float sc[NB][RPR];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int q = 0; q < RPR; ++q) {
+        const bool ok = lo[b] + r + q < hi[b];
+        Df[b][q] = a.D; sc[b][q] = 1.f;
+        int64_t off;
+        const int sv = src[b][q];
+        if (a.combiner < 0) {
+          off = (int64_t)sv * a.grad_stride;
+        } else {
+          const int f = sv / a.B, bb = sv - f * a.B;
+          int d0 = f * a.D;
+          if (a.D_offsets) { d0 = a.D_offsets[f]; Df[b][q] = a.D_offsets[f + 1] - d0; }
+          if (a.combiner == 1) {
+            const int64_t L = a.offsets[sv + 1] - a.offsets[sv];
+            sc[b][q] = L > 0 ? 1.0f / (float)L : 1.f;
+          }
+          off = (int64_t)bb * a.grad_stride + d0;
+        }
+        base[b][q] = ok ? (uintptr_t)a.grads + (uintptr_t)(off * EB) : 0;
+      }
+    float v[NB][RPR][NCOL][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int q = 0; q < RPR; ++q)
+#pragma unroll
+        for (int k = 0; k < NCOL; ++k) {
+          const int e = W * (c + k * LPR);
+          const gptr_t p = (base[b][q] != 0 && e < Df[b][q]) ? (gptr_t)(base[b][q] + (uintptr_t)(e * EB)) : zero;
+          ldNg<GDT>(p, kVec, v[b][q][k]);
+        }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int q = 0; q < RPR; ++q)
+#pragma unroll
+        for (int k = 0; k < NCOL; ++k)
+#pragma unroll
+          for (int w = 0; w < W; ++w) acc[b][k][w] += v[b][q][k][w] * sc[b][q];
+  }
 }
 
 // sum over the LPR lanes of a column group (every lane gets the total)
@@ -129,16 +171,17 @@ __device__ __forceinline__ float group_sum(float v, int lpr_log2) {
 }
 
 // Apply the sink to one row.  g holds the full reduced gradient of the row in the column layout
-// (element W*(c + k*LPR) + w).  Called by ALL 64 lanes (row-wise AdaGrad needs a group reduction);
-// only row group 0 (sub == 0) touches memory.
+// (element W*(c + k*LPR) + w).  Called by whole waves (row-wise AdaGrad needs a lane-group reduction);
+// lane groups with `active` == false run the shuffles but touch no memory.
 template <int WDT, int GDT, int NCOL, bool kVec>
 __device__ __forceinline__ void apply_sink(const OptArgs& o_in, int64_t u, void* row, int D, int lpr_log2, bool round_grad,
-                                           float (&g)[NCOL][4]) {
+                                           float (&g)[NCOL][4], bool active) {
   OptArgs o = o_in;
   if (o.state_offset < 0) o.state_offset = D;
   const int lane = lane_id();
   const int LPR = 1 << lpr_log2;
-  const int sub = lane >> lpr_log2, c = lane & (LPR - 1);
+  const int c = lane & (LPR - 1);
+  const int sub = active ? 0 : 1;  // inactive lane groups run the shuffles but touch no memory
   constexpr int W = kVec ? 4 : 1;
   if (round_grad) {
 #pragma unroll
@@ -218,101 +261,178 @@ __device__ __forceinline__ void apply_sink(const OptArgs& o_in, int64_t u, void*
 }
 
 template <int WDT, int GDT, int NCOL, bool kVec>
-__global__ void __launch_bounds__(256) bwd_rows_kernel(BwdArgs a, OptArgs o, int lpr_log2) {
+__global__ void __launch_bounds__(256) bwd_kernel(BwdArgs a, OptArgs o, int lpr_log2) {
+  const int lane = lane_id();
+  const int LPR = 1 << lpr_log2, NSUB = 64 >> lpr_log2;
+  const int sub = lane >> lpr_log2, c = lane & (LPR - 1);
+  const int wpb = blockDim.x >> 6;
+  constexpr int W = kVec ? 4 : 1;
+  if ((int)blockIdx.x < a.hot_blocks) {
+    // ------------------------------------------------ hot tasks: one BLOCK per chunk of CSR entries
+    // The chunk is split over the block's 4*NSUB lane groups (<= 16 entries each at the default chunk of
+    // 128), folded inside the wave with shuffles and across the 4 waves through LDS.  A row that fits one
+    // chunk is finished right here; longer rows add one partial per chunk into the row's fp32 accumulator
+    // (agent-scope atomics: ~0.1-0.2 us each when thousands hit one address, hence block-sized chunks)
+    // and the chunk that draws the last ticket applies the sink.
+    extern __shared__ __attribute__((aligned(16))) float s_part[];  // [4 waves][D]
+    const int wv = threadIdx.x >> 6;
+    int ntasks = *a.hot.n_tasks;
+    ntasks = ntasks < a.hot.max_tasks ? ntasks : a.hot.max_tasks;
+    for (int task = blockIdx.x; task < ntasks; task += a.hot_blocks) {
+      const int u = a.hot.task_u[task], h = a.hot.task_h[task];
+      const int lo = a.hot.task_lo[task], hi = a.hot.task_hi[task];
+      const int ngroups = wpb * NSUB;
+      const int per = (hi - lo + ngroups - 1) / ngroups;
+      int slo = lo + (wv * NSUB + sub) * per, shi = slo + per;
+      shi = shi < hi ? shi : hi;
+      float g1[1][NCOL][4];
+      {
+        const int l1[1] = {slo < shi ? slo : 0}, h1[1] = {slo < shi ? shi : 0};
+        reduce_multi<GDT, NCOL, kVec, 1, 4>(a, l1, h1, lpr_log2, g1);
+      }
+      float (&g)[NCOL][4] = g1[0];
+      for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+        for (int k = 0; k < NCOL; ++k)
+#pragma unroll
+          for (int w = 0; w < W; ++w) g[k][w] += __shfl_xor(g[k][w], off, 64);
+      if (sub == 0) {
+#pragma unroll
+        for (int k = 0; k < NCOL; ++k)
+#pragma unroll
+          for (int w = 0; w < W; ++w) { const int e = W * (c + k * LPR) + w; if (e < a.D) s_part[wv * a.D + e] = g[k][w]; }
+      }
+      __syncthreads();
+      if (wv == 0) {
+        int Drow = a.D;
+        if (a.D_offsets && a.combiner >= 0) { const int f = a.csr_src[lo] / a.B; Drow = a.D_offsets[f + 1] - a.D_offsets[f]; }
+        float gg[NCOL][4];
+#pragma unroll
+        for (int k = 0; k < NCOL; ++k)
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            const int e = W * (c + k * LPR) + w;
+            gg[k][w] = (w < W && e < a.D) ? s_part[e] + s_part[a.D + e] + s_part[2 * a.D + e] + s_part[3 * a.D + e] : 0.f;
+          }
+        const int nch = a.hot.hot_nchunks[h];
+        int last = 1;
+        if (nch > 1) {
+          if (sub == 0) {
+#pragma unroll
+            for (int k = 0; k < NCOL; ++k)
+#pragma unroll
+              for (int w = 0; w < W; ++w) {
+                const int e = W * (c + k * LPR) + w;
+                if (e < Drow)
+                  __hip_atomic_fetch_add(&a.hot.hot_acc[(int64_t)h * a.hot.dim + e], gg[k][w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+          }
+          // The accumulator is only ever touched with agent-scope atomics (performed at the coherence
+          // point), so no release/acquire fence is needed -- a release fence would write back the XCD's
+          // whole dirty L2 (the table rows other waves are updating) once per task.  Drain this wave's
+          // atomics (vmcnt counts them), then take a ticket; the last ticket owns the row.
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          last = 0;
+          if (lane == 0) {
+            const int t = __hip_atomic_fetch_add(&a.hot.hot_done[h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (t == nch - 1);
+          }
+          last = __shfl(last, 0, 64);
+          if (last) {
+#pragma unroll
+            for (int k = 0; k < NCOL; ++k)
+#pragma unroll
+              for (int w = 0; w < 4; ++w) {
+                const int e = W * (c + k * LPR) + w;
+                gg[k][w] = (w < W && e < Drow)
+                               ? __hip_atomic_load(&a.hot.hot_acc[(int64_t)h * a.hot.dim + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                               : 0.f;
+              }
+          }
+        }
+        if (last) {
+          void* row = o.kind == kOptStore ? nullptr : reinterpret_cast<void*>(a.row_addr[u]);
+          apply_sink<WDT, GDT, NCOL, kVec>(o, u, row, Drow, lpr_log2, a.round_grad != 0, gg, sub == 0);
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  // ---------------------------------------------------- regular rows: NB unique rows per lane group
+  // Most rows of a batch occur once or twice, so one row per lane group would leave a wave with ~1.5 KB
+  // in flight per ~5 us dependent chain (ptr -> CSR entry -> gradient row).  Each lane group therefore
+  // takes NB consecutive unique rows and walks their entries in lock step, RPR entries of each per round;
+  // the table rows themselves are fetched up front (SGD) since their address only needs row_addr[u].
+  constexpr int NB = NCOL == 1 ? 4 : (NCOL == 2 ? 2 : 1);
+  constexpr int RPR = 2;
   int64_t nu = a.max_unique;
   if (a.nu_dev) { int64_t m = *a.nu_dev; nu = m < nu ? m : nu; }
-  const int lane = lane_id();
-  const int64_t wpb = blockDim.x >> 6;
-  for (int64_t u = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); u < nu; u += (int64_t)gridDim.x * wpb) {
-    const int lo = a.ptr[u], hi = a.ptr[u + 1];
-    const int cnt = hi - lo;
-    void* row = o.kind == kOptStore ? nullptr : reinterpret_cast<void*>(a.row_addr[u]);
-    if (cnt > kHot && a.n_hot) {
-      // register the hot row and its chunks; the chunk kernel finishes it
-      const int nchunks = (cnt + kChunk - 1) / kChunk;
-      int h = 0, t0 = 0;
-      if (lane == 0) { h = atomicAdd(a.n_hot, 1); t0 = atomicAdd(a.n_tasks, nchunks); }
-      h = __shfl(h, 0, 64); t0 = __shfl(t0, 0, 64);
-      if (h < a.max_hot && t0 + nchunks <= a.max_tasks) {
-        if (lane == 0) { a.hot_u[h] = (int)u; a.hot_done[h] = 0; a.hot_nchunks[h] = nchunks; }
-        for (int e = lane; e < a.D; e += 64) a.hot_acc[(int64_t)h * a.D + e] = 0.f;
-        for (int cc = lane; cc < nchunks; cc += 64) { a.task_h[t0 + cc] = h; a.task_c[t0 + cc] = cc; }
+  const int64_t sg = ((int64_t)(blockIdx.x - a.hot_blocks) * wpb + (threadIdx.x >> 6)) * NSUB + sub;
+  const int64_t total_sg = (int64_t)(gridDim.x - a.hot_blocks) * wpb * NSUB;
+  const int64_t rounds = (nu + total_sg * NB - 1) / (total_sg * NB);
+  for (int64_t it = 0; it < rounds; ++it) {   // wave-uniform trip count (apply_sink shuffles inside)
+    const int64_t u0 = (it * total_sg + sg) * NB;
+    int lo[NB], hi[NB];
+    bool work[NB], have[NB], hotrow[NB];
+    uintptr_t rowp[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int64_t u = u0 + b;
+      have[b] = u < nu;
+      const int64_t uc = have[b] ? u : (nu > 0 ? nu - 1 : 0);
+      const int l = a.ptr[uc], h = a.ptr[uc + 1];
+      hotrow[b] = a.hot.n_tasks != nullptr && (h - l) > a.hot.khot;
+      work[b] = have[b] && h > l && !hotrow[b];
+      lo[b] = work[b] ? l : 0;
+      hi[b] = work[b] ? h : 0;
+      rowp[b] = (work[b] && o.kind != kOptStore) ? (uintptr_t)a.row_addr[uc] : 0;
+    }
+    const bool pre = kVec && o.kind == kOptSgd && a.D_offsets == nullptr;
+    float wpre[NB][NCOL][4];
+    if (pre) {
+      constexpr int WB = WDT == kF32 ? 4 : 2;
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int k = 0; k < NCOL; ++k) {
+          const int e = 4 * (c + k * LPR);
+          const gptr_t p = (rowp[b] != 0 && e < a.D) ? (gptr_t)(rowp[b] + (uintptr_t)(e * WB)) : (gptr_t)(uintptr_t)g_zero_grad;
+          ldNg<WDT>(p, true, wpre[b][k]);
+        }
+    }
+    float g[NB][NCOL][4];
+    reduce_multi<GDT, NCOL, kVec, NB, RPR>(a, lo, hi, lpr_log2, g);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (pre) {
+        if (rowp[b] != 0) {
+#pragma unroll
+          for (int k = 0; k < NCOL; ++k) {
+            const int e = 4 * (c + k * LPR);
+            if (e < a.D) {
+              float r4[4];
+#pragma unroll
+              for (int w = 0; w < 4; ++w) {
+                const float gr = a.round_grad ? Elem<GDT>::rnd(g[b][k][w]) : g[b][k][w];
+                r4[w] = wpre[b][k][w] - gr * o.lr;
+              }
+              st4<WDT>(reinterpret_cast<void*>(rowp[b]), e, make_float4(r4[0], r4[1], r4[2], r4[3]));
+            }
+          }
+        }
         continue;
       }
-      // (cannot happen with the documented workspace sizes) fall through to the serial path
-    }
-    float g[NCOL][4];
-    reduce_entries<GDT, NCOL, kVec>(a, lo, hi, lpr_log2, g);
-    if (cnt == 0 && o.kind != kOptStore) continue;  // unique without occurrences: nothing to apply
-    int Drow = a.D;  // mixed dims: every occurrence of a row belongs to the same table, hence the same width
-    if (a.D_offsets && a.combiner >= 0 && cnt > 0 && o.kind != kOptStore) {
-      const int f = a.csr_src[lo] / a.B;
-      Drow = a.D_offsets[f + 1] - a.D_offsets[f];
-    }
-    apply_sink<WDT, GDT, NCOL, kVec>(o, u, row, Drow, lpr_log2, a.round_grad != 0, g);
-  }
-}
-
-template <int WDT, int GDT, int NCOL, bool kVec>
-__global__ void __launch_bounds__(256) bwd_hot_kernel(BwdArgs a, OptArgs o, int lpr_log2) {
-  extern __shared__ __attribute__((aligned(16))) float s_part[];  // [4 waves][D]
-  __shared__ int s_last;
-  const int ntasks = *a.n_tasks < a.max_tasks ? *a.n_tasks : a.max_tasks;
-  const int lane = lane_id(), wv = threadIdx.x >> 6;
-  const int LPR = 1 << lpr_log2;
-  const int sub = lane >> lpr_log2, c = lane & (LPR - 1);
-  constexpr int W = kVec ? 4 : 1;
-  for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
-    const int h = a.task_h[task], cc = a.task_c[task];
-    const int u = a.hot_u[h];
-    const int lo = a.ptr[u] + cc * kChunk;
-    int hi = lo + kChunk; if (hi > a.ptr[u + 1]) hi = a.ptr[u + 1];
-    const int per = (hi - lo + 3) / 4;
-    int wlo = lo + wv * per, whi = wlo + per; if (whi > hi) whi = hi; if (wlo > hi) wlo = hi;
-    float g[NCOL][4];
-    reduce_entries<GDT, NCOL, kVec>(a, wlo, whi, lpr_log2, g);
-    if (sub == 0) {
-#pragma unroll
-      for (int k = 0; k < NCOL; ++k)
-#pragma unroll
-        for (int w = 0; w < W; ++w) { const int e = W * (c + k * LPR) + w; if (e < a.D) s_part[wv * a.D + e] = g[k][w]; }
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < a.D; e += blockDim.x) {
-      float s = s_part[e] + s_part[a.D + e] + s_part[2 * a.D + e] + s_part[3 * a.D + e];
-      __hip_atomic_fetch_add(&a.hot_acc[(int64_t)h * a.D + e], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // publish: drain this block's atomics, then take a ticket (CDNA hand-off recipe, counter form)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      int t = __hip_atomic_fetch_add(&a.hot_done[h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = (t == a.hot_nchunks[h] - 1);
-      if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    if (s_last && wv == 0) {
-      float gg[NCOL][4];
-#pragma unroll
-      for (int k = 0; k < NCOL; ++k)
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          const int e = W * (c + k * LPR) + w;
-          gg[k][w] = (w < W && e < a.D)
-                         ? __hip_atomic_load(&a.hot_acc[(int64_t)h * a.D + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                         : 0.f;
-        }
-      void* row = o.kind == kOptStore ? nullptr : reinterpret_cast<void*>(a.row_addr[u]);
       int Drow = a.D;
-      if (a.D_offsets && a.combiner >= 0 && o.kind != kOptStore) {
-        const int f = a.csr_src[a.ptr[u]] / a.B;
+      if (work[b] && a.D_offsets && a.combiner >= 0 && o.kind != kOptStore) {
+        const int f = a.csr_src[lo[b]] / a.B;
         Drow = a.D_offsets[f + 1] - a.D_offsets[f];
       }
-      apply_sink<WDT, GDT, NCOL, kVec>(o, u, row, Drow, lpr_log2, a.round_grad != 0, gg);
+      // rows without occurrences: the reference's reduce_grads leaves them unwritten; store zeros
+      const bool act = work[b] || (have[b] && !hotrow[b] && o.kind == kOptStore);
+      apply_sink<WDT, GDT, NCOL, kVec>(o, have[b] ? u0 + b : 0, reinterpret_cast<void*>(rowp[b]), Drow, lpr_log2,
+                                       a.round_grad != 0, g[b], act);
     }
-    __syncthreads();
   }
 }
 
@@ -341,7 +461,7 @@ opt_rows_kernel(OptArgs o, const void* grads, int64_t grad_stride, int64_t n, co
         else g[k][0] = ld1<GDT>(grads, u * grad_stride + e);
       }
     }
-    apply_sink<WDT, GDT, NCOL, kVec>(o, u, row, D, lpr_log2, false, g);
+    apply_sink<WDT, GDT, NCOL, kVec>(o, u, row, D, lpr_log2, false, g, (lane >> lpr_log2) == 0);
   }
 }
 
@@ -357,28 +477,17 @@ static int lpr_log2_for(int D, bool vec) {
   return l;
 }
 
-struct HotWs { int max_hot, max_tasks; int64_t bytes; };
-static HotWs hot_ws(int64_t n, int64_t D) {
-  HotWs w;
-  w.max_hot = (int)(n / kHot + 1);
-  w.max_tasks = (int)(n / kChunk + w.max_hot + 1);
-  w.bytes = 256 + 3 * align_up(4LL * w.max_hot, 256) + 2 * align_up(4LL * w.max_tasks, 256) + align_up(4LL * w.max_hot * D, 256);
-  return w;
-}
-
 template <int WDT, int GDT>
 static int launch_bwd(BwdArgs a, OptArgs o, bool vec, hipStream_t stream) {
   const int l = lpr_log2_for(a.D, vec);
   const int per = vec ? 4 : 1;
   const int ncol = (a.D + (per << l) - 1) / (per << l);
-  const int grid = grid_for(a.max_unique, 4, 1 << 20);
-  const int hgrid = a.n_hot ? (a.max_tasks < 4096 ? a.max_tasks : 4096) : 0;
-  const size_t smem = 4 * (size_t)a.D * sizeof(float);
-#define MI355_BWD_LAUNCH(NC, V)                                                                                         \
-  do {                                                                                                                  \
-    hipLaunchKernelGGL((bwd_rows_kernel<WDT, GDT, NC, V>), dim3(grid), dim3(256), 0, stream, a, o, l);                   \
-    if (hgrid) hipLaunchKernelGGL((bwd_hot_kernel<WDT, GDT, NC, V>), dim3(hgrid), dim3(256), smem, stream, a, o, l);     \
-  } while (0)
+  const int nsub = 64 >> l;
+  a.hot_blocks = a.hot.n_tasks ? (a.hot.max_tasks < 2048 ? a.hot.max_tasks : 2048) : 0;
+  const size_t smem = a.hot.n_tasks ? 4 * (size_t)a.D * sizeof(float) : 0;
+  const int nb = ncol <= 1 ? 4 : (ncol <= 2 ? 2 : 1);
+  const int grid = a.hot_blocks + grid_for(a.max_unique, 4 * nsub * nb, 1 << 20);
+#define MI355_BWD_LAUNCH(NC, V) hipLaunchKernelGGL((bwd_kernel<WDT, GDT, NC, V>), dim3(grid), dim3(256), smem, stream, a, o, l)
   if (vec) {
     if (ncol <= 1) MI355_BWD_LAUNCH(1, true); else if (ncol <= 2) MI355_BWD_LAUNCH(2, true); else MI355_BWD_LAUNCH(4, true);
   } else {
@@ -413,7 +522,7 @@ static int launch_opt(OptArgs o, const void* grads, int64_t grad_stride, int64_t
 
 extern "C" {
 
-int64_t mi355_backward_workspace_bytes(int64_t num_keys, int64_t dim) { return hot_ws(num_keys, dim).bytes; }
+int64_t mi355_backward_workspace_bytes(int64_t num_keys, int64_t dim) { return hot_bytes(num_keys, dim); }
 
 // Fused backward over the CSR of mi355_group_by_unique.
 //   opt_kind 0: store the reduced gradients to `out` [max_unique, out_stride] in the grad dtype (reduce_grads)
@@ -434,20 +543,10 @@ int mi355_backward_fused(const int32_t* ptr, const int32_t* csr_src, int64_t num
   BwdArgs a{};
   a.ptr = ptr; a.csr_src = csr_src; a.grads = grads; a.grad_stride = grad_stride; a.offsets = offsets; a.D_offsets = D_offsets;
   a.B = (int)batch_size; a.D = (int)dim; a.combiner = combiner; a.row_addr = row_addr; a.max_unique = max_unique;
-  a.nu_dev = nu_dev; a.round_grad = round_grad;
-  if (workspace) {
-    HotWs hw = hot_ws(num_keys, dim);
-    MI355_CHECK_ARG(workspace_bytes >= hw.bytes, "workspace too small");
-    uint8_t* w = (uint8_t*)workspace;
-    a.n_hot = (int*)w; a.n_tasks = (int*)(w + 8); w += 256;
-    a.hot_u = (int*)w; w += align_up(4LL * hw.max_hot, 256);
-    a.hot_done = (int*)w; w += align_up(4LL * hw.max_hot, 256);
-    a.hot_nchunks = (int*)w; w += align_up(4LL * hw.max_hot, 256);
-    a.task_h = (int*)w; w += align_up(4LL * hw.max_tasks, 256);
-    a.task_c = (int*)w; w += align_up(4LL * hw.max_tasks, 256);
-    a.hot_acc = (float*)w;
-    a.max_hot = hw.max_hot; a.max_tasks = hw.max_tasks;
-    if (hipMemsetAsync(workspace, 0, 256, stream) != hipSuccess) { mi355_set_error("memset failed"); return MI355_ELAUNCH; }
+  a.nu_dev = nu_dev; a.round_grad = round_grad; a.n_entries = (int)num_keys;
+  if (workspace) {  // the hot-row task list filled by mi355_group_by_unique(..., hot_workspace = workspace, dim)
+    MI355_CHECK_ARG(workspace_bytes >= hot_bytes(num_keys, dim), "workspace too small");
+    a.hot = hot_carve(workspace, num_keys, dim);
   }
   OptArgs o{};
   o.kind = opt_kind; o.lr = lr; o.beta1 = beta1; o.beta2 = beta2; o.eps = eps; o.weight_decay = weight_decay;

@@ -20,6 +20,7 @@
 //    rows in an LDS hash table and issues ONE global atomic per distinct row per tile, so the
 //    hottest row of a Zipf stream costs (#tiles) atomics instead of (#occurrences).
 #include "common.h"
+#include "hot.h"
 
 namespace mi355 {
 
@@ -75,34 +76,84 @@ struct UniqWs {
   int* total;    // [1]
 };
 
+// One 1024-key tile per block.  Keys are first de-duplicated INSIDE the tile in an LDS hash set (block
+// representative = smallest position), then only the tile representatives touch the global set.  Under a
+// Zipf stream this turns (#occurrences) same-address CAS/atomicMin operations on a hot key -- which
+// serialise at ~12 ns each in the L2 atomic unit -- into at most (#tiles).
+constexpr int kUniqTile = 1024;
+constexpr int kUniqLds = 2048;
+
 __global__ void __launch_bounds__(256)
 uniq_insert_kernel(const uint64_t* __restrict__ keys, int64_t n, const int64_t* __restrict__ seg, int T, UniqWs ws) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const uint64_t key = keys[i];
-    const int t = upper_bound_i64(seg, T + 1, i) - 1;
-    const int64_t lo = seg[t], len = seg[t + 1] - lo;
-    const uint64_t range = 2ull * (uint64_t)len;
-    const int64_t base = 2 * lo;
-    uint64_t h = fmix64(key);
-    int64_t off = (int64_t)((((h >> 32) ^ (h & 0xffffffffull)) * range) >> 32);
-    int64_t pos = base + off;
-    const int me = (int)i;
-    while (true) {
-      int cur = ws.slots[pos];
-      if (cur == -1) {
-        int old = atomicCAS(&ws.slots[pos], -1, me);
-        if (old == -1) break;
-        cur = old;
+  __shared__ uint64_t s_key[kUniqTile];
+  __shared__ int s_tab[kUniqLds];   // tile-local position of the representative, -1 empty
+  __shared__ int s_pos[kUniqLds];   // global slot of that representative
+  __shared__ int s_t[kUniqTile];    // table of each key of the tile
+  const int64_t tile0 = (int64_t)blockIdx.x * kUniqTile;
+  for (int s = threadIdx.x; s < kUniqLds; s += blockDim.x) s_tab[s] = -1;
+  int hh[kUniqTile / 256];
+#pragma unroll
+  for (int q = 0; q < kUniqTile / 256; ++q) {
+    const int li = q * 256 + threadIdx.x;
+    const int64_t i = tile0 + li;
+    if (i < n) { s_key[li] = keys[i]; s_t[li] = upper_bound_i64(seg, T + 1, i) - 1; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kUniqTile / 256; ++q) {
+    const int li = q * 256 + threadIdx.x;
+    hh[q] = -1;
+    if (tile0 + li < n) {
+      const uint64_t key = s_key[li];
+      const int t = s_t[li];
+      int h = (int)(fmix64(key + 0x9E3779B97F4A7C15ull * (uint64_t)t) >> 40) & (kUniqLds - 1);
+      while (true) {
+        int cur = atomicCAS(&s_tab[h], -1, li);
+        if (cur == -1) break;
+        if (s_key[cur] == key && s_t[cur] == t) { atomicMin(&s_tab[h], li); break; }
+        h = (h + 1) & (kUniqLds - 1);
       }
-      if (keys[cur] == key) {
-        if (me < cur) atomicMin(&ws.slots[pos], me);
-        break;
-      }
-      ++off;
-      if ((uint64_t)off == range) off = 0;
-      pos = base + off;
+      hh[q] = h;
     }
-    ws.rep[i] = (int)pos;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kUniqTile / 256; ++q) {
+    const int li = q * 256 + threadIdx.x;
+    if (hh[q] >= 0 && s_tab[hh[q]] == li) {  // tile representative: insert into the global per-table set
+      const int64_t i = tile0 + li;
+      const uint64_t key = s_key[li];
+      const int t = s_t[li];
+      const int64_t lo = seg[t], len = seg[t + 1] - lo;
+      const uint64_t range = 2ull * (uint64_t)len;
+      const int64_t base = 2 * lo;
+      const uint64_t h = fmix64(key);
+      int64_t off = (int64_t)((((h >> 32) ^ (h & 0xffffffffull)) * range) >> 32);
+      int64_t pos = base + off;
+      const int me = (int)i;
+      while (true) {
+        int cur = ws.slots[pos];
+        if (cur == -1) {
+          int old = atomicCAS(&ws.slots[pos], -1, me);
+          if (old == -1) break;
+          cur = old;
+        }
+        if (keys[cur] == key) {
+          if (me < cur) atomicMin(&ws.slots[pos], me);
+          break;
+        }
+        ++off;
+        if ((uint64_t)off == range) off = 0;
+        pos = base + off;
+      }
+      s_pos[hh[q]] = (int)pos;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kUniqTile / 256; ++q) {
+    const int li = q * 256 + threadIdx.x;
+    if (hh[q] >= 0) ws.rep[tile0 + li] = s_pos[hh[q]];
   }
 }
 
@@ -318,7 +369,7 @@ scan_reduce_kernel(const int* __restrict__ in, int64_t n, const int64_t* __restr
 }
 __global__ void __launch_bounds__(kScanThreads)
 scan_down_kernel(const int* __restrict__ in, int64_t n, const int64_t* __restrict__ n_dev, const int* __restrict__ partial,
-                 const int* __restrict__ total, int* __restrict__ out) {
+                 const int* __restrict__ total, int* __restrict__ out, HotList hot, bool build_hot) {
   if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
   const int64_t tile0 = (int64_t)blockIdx.x * kScanTile;
   int v[kScanItems];
@@ -331,22 +382,119 @@ scan_down_kernel(const int* __restrict__ in, int64_t n, const int64_t* __restric
   }
   int tot;
   int ex = block_excl_scan(c, tot) + partial[blockIdx.x];
+  // hot rows of this tile: ids and task ranges are reserved with ONE atomic pair per block
+  int nh_local = 0, nt_local = 0;
+  if (build_hot) {
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+      if (v[k] > hot.khot) { ++nh_local; nt_local += (v[k] + hot.kchunk - 1) / hot.kchunk; }
+  }
+  __shared__ int s_hbase[2];
+  int h_ex = 0, t_ex = 0;
+  if (build_hot) {
+    int th, tt;
+    h_ex = block_excl_scan(nh_local, th);
+    t_ex = block_excl_scan(nt_local, tt);
+    if (threadIdx.x == 0) {
+      s_hbase[0] = th ? atomicAdd(hot.n_hot, th) : 0;
+      s_hbase[1] = tt ? atomicAdd(hot.n_tasks, tt) : 0;
+    }
+    __syncthreads();
+    h_ex += s_hbase[0];
+    t_ex += s_hbase[1];
+  }
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
     int64_t i = tile0 + threadIdx.x * kScanItems + k;
-    if (i < n) { out[i] = ex; ex += v[k]; }
+    if (i < n) {
+      out[i] = ex;
+      if (build_hot && v[k] > hot.khot) {
+        const int nch = (v[k] + hot.kchunk - 1) / hot.kchunk;
+        const int h = h_ex++, t0 = t_ex;
+        t_ex += nch;
+        if (h < hot.max_hot && t0 + nch <= hot.max_tasks) {  // tasks are written out by csr_fill_kernel
+          hot.hot_done[h] = 0;
+          hot.hot_nchunks[h] = nch;
+          hot.hot_u[h] = (int)i;
+          hot.hot_lo[h] = ex;
+          hot.hot_cnt[h] = v[k];
+          hot.hot_t0[h] = t0;
+        }
+      }
+      ex += v[k];
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
 }
 
-// pass 2: scatter.  src id of key j: pooled -> bag id (found by walking the bag offsets), sequence -> j.
+// pass 2: scatter.  src id of key j: pooled -> bag id, sequence -> j.  The bag of every key of the tile is
+// resolved in LDS: two binary searches per TILE (first / last key), the heads of the bags that start
+// inside the tile are marked, an inclusive max-scan spreads them -- instead of a 16-step global binary
+// search per key.
 __global__ void __launch_bounds__(256)
 csr_fill_kernel(const int64_t* __restrict__ rev, int64_t n, const int64_t* __restrict__ offsets, int64_t num_bags,
-                const int* __restrict__ ptr, int* __restrict__ cursor, int* __restrict__ csr_src) {
+                const int* __restrict__ ptr, int* __restrict__ cursor, int* __restrict__ csr_src, HotList hot, bool build_hot) {
   __shared__ LdsEntry tab[kHistSlots];
+  if (build_hot) {
+    // expand the hot rows registered by scan_down_kernel into wave tasks and clear their accumulators
+    // (one wave per hot row, riding on this launch)
+    int nh = *hot.n_hot;
+    nh = nh < hot.max_hot ? nh : hot.max_hot;
+    for (int h = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); h < nh; h += gridDim.x * (blockDim.x >> 6)) {
+      const int nch = hot.hot_nchunks[h], t0 = hot.hot_t0[h], lo = hot.hot_lo[h], cnt = hot.hot_cnt[h], u = hot.hot_u[h];
+      if (t0 + nch > hot.max_tasks) continue;
+      for (int cc = lane_id(); cc < nch; cc += 64) {
+        hot.task_u[t0 + cc] = u;
+        hot.task_h[t0 + cc] = h;
+        hot.task_lo[t0 + cc] = lo + cc * hot.kchunk;
+        const int hi = lo + (cc + 1) * hot.kchunk;
+        hot.task_hi[t0 + cc] = hi < lo + cnt ? hi : lo + cnt;
+      }
+      for (int e = lane_id(); e < hot.dim; e += 64) hot.hot_acc[(int64_t)h * hot.dim + e] = 0.f;
+    }
+  }
+  __shared__ int s_bag[kHistTile];
+  __shared__ int s_range[2];
+  __shared__ int s_wmax[4];
   for (int s = threadIdx.x; s < kHistSlots; s += blockDim.x) { tab[s].u = -1; tab[s].cnt = 0; }
-  __syncthreads();
   const int64_t tile0 = (int64_t)blockIdx.x * kHistTile;
+  const int64_t tile_end = tile0 + kHistTile < n ? tile0 + kHistTile : n;
+  if (offsets) {
+    for (int k = threadIdx.x; k < kHistTile; k += blockDim.x) s_bag[k] = -1;
+    if (threadIdx.x == 0 || threadIdx.x == 64) {
+      const int64_t key = threadIdx.x == 0 ? tile0 : tile_end - 1;
+      int lo = 0, hi = (int)num_bags;  // first idx with offsets[idx] > key
+      while (lo < hi) { int mid = (lo + hi) >> 1; if (offsets[mid] <= key) lo = mid + 1; else hi = mid; }
+      s_range[threadIdx.x == 0 ? 0 : 1] = lo - 1;
+    }
+  }
+  __syncthreads();
+  if (offsets) {
+    const int b_lo = s_range[0], b_hi = s_range[1];
+    for (int b = b_lo + threadIdx.x; b <= b_hi; b += blockDim.x) {
+      const int64_t o0 = offsets[b], o1 = offsets[b + 1];
+      if (o1 > o0) { const int64_t p = o0 > tile0 ? o0 - tile0 : 0; if (p < kHistTile) s_bag[p] = b; }
+    }
+    __syncthreads();
+    // inclusive max-scan over the tile positions (4 consecutive positions per thread)
+    int v[4];
+    int m = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = s_bag[threadIdx.x * 4 + k]; m = v[k] > m ? v[k] : m; v[k] = m; }
+    int incl = m;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { int o = __shfl_up(incl, off, 64); if (lane_id() >= off) incl = o > incl ? o : incl; }
+    if (lane_id() == 63) s_wmax[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int base = -1;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base = s_wmax[w] > base ? s_wmax[w] : base;
+    int prev = __shfl_up(incl, 1, 64);
+    if (lane_id() == 0) prev = -1;
+    prev = prev > base ? prev : base;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_bag[threadIdx.x * 4 + k] = v[k] > prev ? v[k] : prev;
+  }
+  __syncthreads();
   int hh[kHistTile / 256], rk[kHistTile / 256];
 #pragma unroll
   for (int q = 0; q < kHistTile / 256; ++q) {
@@ -361,16 +509,7 @@ csr_fill_kernel(const int64_t* __restrict__ rev, int64_t n, const int64_t* __res
 #pragma unroll
   for (int q = 0; q < kHistTile / 256; ++q) {
     int64_t j = tile0 + q * 256 + threadIdx.x;
-    if (hh[q] >= 0) {
-      int src;
-      if (offsets) {
-        // bag of key j: last bag with offsets[bag] <= j
-        int lo = 0, hi = (int)num_bags;  // first idx with offsets[idx] > j
-        while (lo < hi) { int mid = (lo + hi) >> 1; if (offsets[mid] <= j) lo = mid + 1; else hi = mid; }
-        src = lo - 1;
-      } else src = (int)j;
-      csr_src[tab[hh[q]].base + rk[q]] = src;
-    }
+    if (hh[q] >= 0) csr_src[tab[hh[q]].base + rk[q]] = offsets ? s_bag[q * 256 + threadIdx.x] : (int)j;
   }
 }
 
@@ -516,7 +655,7 @@ int mi355_segmented_unique(const void* keys, int64_t n, const int64_t* segmented
   if (hipMemsetAsync(ws.slots, 0xFF, 8 * n, stream) != hipSuccess) { mi355_set_error("memset failed"); return MI355_ELAUNCH; }
   const uint64_t* k = (const uint64_t*)keys;
   const int T = (int)num_tables;
-  hipLaunchKernelGGL(uniq_insert_kernel, dim3(grid_for(n, 256, 256 * 32)), dim3(256), 0, stream, k, n, segmented_range, T, ws);
+  hipLaunchKernelGGL(uniq_insert_kernel, dim3((unsigned)ceil_div(n, kUniqTile)), dim3(256), 0, stream, k, n, segmented_range, T, ws);
   hipLaunchKernelGGL(uniq_flag_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, n, ws);
   hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, stream, ws.partial, nb, ws.total);
   if (count_freq) {
@@ -583,25 +722,34 @@ int mi355_flagged_compact(const uint8_t* flags, int64_t n, const int64_t* n_dev,
 int64_t mi355_group_by_unique_workspace_bytes(int64_t n, int64_t max_unique) {
   return 2 * align_up(4 * (max_unique + 1), 256) + align_up(4 * (ceil_div(max_unique + 1, kScanTile) + 1), 256) + 256;
 }
+int64_t mi355_hot_rows_workspace_bytes(int64_t num_keys, int64_t dim) { return hot_bytes(num_keys, dim); }
 
 int mi355_group_by_unique(const int64_t* reverse_indices, int64_t n, const int64_t* offsets, int64_t num_bags,
                           int64_t max_unique, const int64_t* nu_dev, int32_t* ptr, int32_t* csr_src, void* workspace,
-                          int64_t workspace_bytes, hipStream_t stream) {
+                          int64_t workspace_bytes, void* hot_workspace, int64_t hot_workspace_bytes, int64_t dim,
+                          hipStream_t stream) {
   MI355_CHECK_ARG(n < 0x7fffffffLL, "too many keys");
   MI355_CHECK_ARG(workspace && workspace_bytes >= mi355_group_by_unique_workspace_bytes(n, max_unique), "workspace too small");
+  MI355_CHECK_ARG(!hot_workspace || hot_workspace_bytes >= hot_bytes(n, dim), "hot workspace too small");
   uint8_t* w = (uint8_t*)workspace;
   int* cnt = (int*)w; w += align_up(4 * (max_unique + 1), 256);
   int* cursor = (int*)w; w += align_up(4 * (max_unique + 1), 256);
   const int64_t nbu = ceil_div(max_unique + 1, kScanTile);
   int* partial = (int*)w; w += align_up(4 * (nbu + 1), 256);
   int* total = (int*)w;
+  HotList hot{};
+  if (hot_workspace) {
+    hot = hot_carve(hot_workspace, n, dim);
+    if (hipMemsetAsync(hot_workspace, 0, 256, stream) != hipSuccess) { mi355_set_error("memset failed"); return MI355_ELAUNCH; }
+  }
   if (hipMemsetAsync(cnt, 0, 2 * align_up(4 * (max_unique + 1), 256), stream) != hipSuccess) { mi355_set_error("memset failed"); return MI355_ELAUNCH; }
   if (n > 0) hipLaunchKernelGGL(csr_hist_kernel, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, reverse_indices, n, cnt);
   hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, cnt, max_unique, nu_dev, partial);
   hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, stream, partial, nbu, total);
-  hipLaunchKernelGGL(scan_down_kernel, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, cnt, max_unique, nu_dev, partial, total, ptr);
+  hipLaunchKernelGGL(scan_down_kernel, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, cnt, max_unique, nu_dev, partial, total, ptr,
+                     hot, hot_workspace != nullptr);
   if (n > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, reverse_indices, n, offsets,
-                                num_bags, ptr, cursor, csr_src);
+                                num_bags, ptr, cursor, csr_src, hot, hot_workspace != nullptr);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }

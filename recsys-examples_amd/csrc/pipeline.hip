@@ -83,7 +83,7 @@ int mi355_demb_forward(
     }
   }
   if (combiner >= 0) {
-    STEP(mi355_gather_pooled(nullptr, 0, row_addr, value_dtype, reverse_indices, offsets, num_bags, batch_size,
+    STEP(mi355_gather_pooled(nullptr, 0, row_addr, value_dtype, reverse_indices, num_keys, offsets, num_bags, batch_size,
                              combiner, emb_dim, D_offsets, total_D, out, out_dtype, aligned16, stream));
   } else {
     STEP(mi355_gather_rows(nullptr, 0, row_addr, value_dtype, reverse_indices, num_keys, nullptr, emb_dim, out,
@@ -122,7 +122,7 @@ int mi355_demb_backward(
   const int64_t* nu_dev = unique_offsets + num_tables;
   int rc;
   rc = mi355_group_by_unique(reverse_indices, num_keys, combiner >= 0 ? offsets : nullptr, num_bags, num_keys, nu_dev, ptr,
-                             csr, gws, gws_bytes, stream);
+                             csr, gws, gws_bytes, bws, bws_bytes, dim, stream);
   if (rc != MI355_OK) return rc;
   rc = mi355_backward_fused(ptr, csr, num_keys, num_keys, nu_dev, grads, grad_stride, grad_dtype, offsets, D_offsets,
                             batch_size, dim, combiner, row_addr, value_dtype, opt_kind, lr, beta1, beta2, eps, weight_decay,

@@ -19,6 +19,7 @@
 //    xor-shuffles; fp32 accumulation, one rounding at the store.
 //  * HBM-bound: no LDS, no MFMA.  Occupancy (small VGPR count) supplies the latency hiding.
 #include "common.h"
+#include <stdlib.h>
 
 namespace mi355 {
 
@@ -31,6 +32,7 @@ struct PoolArgs {
   const int32_t* D_offsets;    // [F+1] or nullptr (uniform D)
   void* dst;                   // [B, total_D]
   int64_t FB;
+  int64_t n;                   // number of keys (= offsets[FB])
   int B;
   int D;                       // uniform dim, or max_D when D_offsets != nullptr
   int total_D;
@@ -46,61 +48,136 @@ __device__ __forceinline__ const void* src_row(const PoolArgs& a, int64_t u) {
 __device__ __forceinline__ void add4(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 
 // vectorised: D_f % 4 == 0, rows 16-B (fp32) / 8-B (16-bit) aligned.  NCOL = ceil(D / (4*LPR)).
-template <int SDT, int DDT, int NCOL>
+//
+// The kernel is LATENCY bound, not issue bound: a bag is a chain of dependent loads
+// (offsets -> reverse index -> row address -> row) of ~1.5 us per hop under load, so the number of
+// independent chains in flight decides the bandwidth.  Each LPR-lane group therefore owns NB whole
+// bags at a time (64/LPR groups per wave -> NB*64/LPR bags per wave) and walks them in lock step,
+// four rows per bag per round; all index loads of a round are issued before the row loads, all row
+// loads before the adds.  A bag never leaves its lane group, so there is no cross-lane reduction and
+// the fp32 sum runs in bag order (bit-identical to a sequential sum).
+// 4 KiB of zeros every lane may read: padding rows, missing rows (address 0) and lanes beyond a
+// row's width load from here, so EVERY load of a round is unconditional -- hipcc otherwise wraps each
+// predicated load in its own exec-masked branch with an s_waitcnt vmcnt(0), which serialises the
+// whole round into one long dependent chain (measured: 3x slower).
+__device__ __attribute__((aligned(16))) float g_zero_row[1024];
+
+typedef const __attribute__((address_space(1))) char* gptr_t;   // explicit GLOBAL pointers: keeps the
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) u32x2_t* gptr2_t;  // row loads global_load, not flat_load
+typedef const __attribute__((address_space(1))) f32x4_t* gptr4_t;
+
+template <int DT>
+__device__ __forceinline__ float4 ld4g(gptr_t p) {
+  if constexpr (DT == kF32) {
+    const f32x4_t t = *reinterpret_cast<gptr4_t>(p);
+    return make_float4(t.x, t.y, t.z, t.w);
+  } else {
+    const u32x2_t r = *reinterpret_cast<gptr2_t>(p);
+    float4 o;
+    if constexpr (DT == kBF16) {
+      o.x = __uint_as_float(r.x << 16); o.y = __uint_as_float(r.x & 0xffff0000u);
+      o.z = __uint_as_float(r.y << 16); o.w = __uint_as_float(r.y & 0xffff0000u);
+    } else {
+      o.x = f16_to_f32((uint16_t)(r.x & 0xffff)); o.y = f16_to_f32((uint16_t)(r.x >> 16));
+      o.z = f16_to_f32((uint16_t)(r.y & 0xffff)); o.w = f16_to_f32((uint16_t)(r.y >> 16));
+    }
+    return o;
+  }
+}
+
+template <int SDT, int DDT, int NCOL, int NB, bool kAddr, int RPR = 4>
 __global__ void __launch_bounds__(256) gather_pooled_vec_kernel(PoolArgs a, int lpr_log2) {
   const int lane = lane_id();
   const int LPR = 1 << lpr_log2;
-  const int R = 64 >> lpr_log2;         // rows in flight per wave instruction
+  const int NSUB = 64 >> lpr_log2;
   const int sub = lane >> lpr_log2;
   const int c = lane & (LPR - 1);
   const int64_t wpb = blockDim.x >> 6;
-  for (int64_t bag = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); bag < a.FB; bag += (int64_t)gridDim.x * wpb) {
-    const int f = (int)(bag / a.B), b = (int)(bag % a.B);
-    int d0, Df;
-    if (a.D_offsets) { d0 = a.D_offsets[f]; Df = a.D_offsets[f + 1] - d0; } else { d0 = f * a.D; Df = a.D; }
-    const int64_t lo = a.offsets[bag], hi = a.offsets[bag + 1];
-    float4 acc[NCOL];
+  const int64_t sg = ((int64_t)blockIdx.x * wpb + (threadIdx.x >> 6)) * NSUB + sub;
+  const int64_t total_sg = (int64_t)gridDim.x * wpb * NSUB;
+  const gptr_t zero = (gptr_t)(uintptr_t)g_zero_row;
+  constexpr int EB = SDT == kF32 ? 4 : 2;
+  for (int64_t bag0 = sg * NB; bag0 < a.FB; bag0 += total_sg * NB) {
+    int64_t lo[NB], hi[NB];
+    int Dfb[NB];
 #pragma unroll
-    for (int k = 0; k < NCOL; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int64_t j0 = lo + sub; j0 < hi; j0 += 4 * R) {
-      const void* rp[4];
+    for (int b = 0; b < NB; ++b) {
+      const int64_t bag = bag0 + b < a.FB ? bag0 + b : a.FB - 1;
+      lo[b] = a.offsets[bag];
+      hi[b] = bag0 + b < a.FB ? a.offsets[bag + 1] : lo[b];
+      Dfb[b] = a.D;
+      if (a.D_offsets) { const int f = (int)(bag / a.B); Dfb[b] = a.D_offsets[f + 1] - a.D_offsets[f]; }
+    }
+    float4 acc[NB][NCOL];
+    int64_t maxlen = 0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int64_t j = j0 + (int64_t)q * R;
-        rp[q] = j < hi ? src_row<SDT>(a, a.rev[j]) : nullptr;
-      }
-      float4 v[4][NCOL];
+    for (int b = 0; b < NB; ++b) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int k = 0; k < NCOL; ++k) acc[b][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      maxlen = hi[b] - lo[b] > maxlen ? hi[b] - lo[b] : maxlen;
+    }
+    for (int64_t r = 0; r < maxlen; r += RPR) {
+      // hop 1: reverse indices (clamped to the bag's last key: the duplicate is masked below)
+      int64_t u[NB][RPR];
 #pragma unroll
-        for (int k = 0; k < NCOL; ++k) {
-          const int e = 4 * (c + k * LPR);
-          v[q][k] = (rp[q] && e < Df) ? ld4<SDT>(rp[q], e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int q = 0; q < RPR; ++q) {
+          int64_t j = lo[b] + r + q;
+          j = j < hi[b] ? j : hi[b] - 1;
+          j = j < lo[b] ? lo[b] : j;           // empty bag: any in-range key (a.n > 0 here)
+          j = j < a.n ? j : a.n - 1;
+          u[b][q] = a.rev[j];
         }
+      // hop 2: row addresses
+      uintptr_t rp[NB][RPR];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int k = 0; k < NCOL; ++k) add4(acc[k], v[q][k]);
+        for (int q = 0; q < RPR; ++q) {
+          uintptr_t p;
+          if constexpr (kAddr) p = (uintptr_t)a.row_addr[u[b][q]];
+          else p = (uintptr_t)a.src + (uintptr_t)(u[b][q] * a.src_stride * EB);
+          rp[b][q] = (lo[b] + r + q < hi[b]) ? p : 0;
+        }
+      // hop 3: rows
+      float4 v[NB][RPR][NCOL];
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int q = 0; q < RPR; ++q)
+#pragma unroll
+          for (int k = 0; k < NCOL; ++k) {
+            const int e = 4 * (c + k * LPR);
+            const gptr_t p = (rp[b][q] != 0 && e < Dfb[b]) ? (gptr_t)(rp[b][q] + (uintptr_t)(e * EB)) : zero;
+            v[b][q][k] = ld4g<SDT>(p);
+          }
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int q = 0; q < RPR; ++q)
+#pragma unroll
+          for (int k = 0; k < NCOL; ++k) add4(acc[b][k], v[b][q][k]);
     }
-    // fold the R row groups
-    for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
-      for (int k = 0; k < NCOL; ++k) {
-        acc[k].x += __shfl_xor(acc[k].x, off, 64); acc[k].y += __shfl_xor(acc[k].y, off, 64);
-        acc[k].z += __shfl_xor(acc[k].z, off, 64); acc[k].w += __shfl_xor(acc[k].w, off, 64);
-      }
-    }
-    if (sub == 0) {
-      const int64_t L = hi - lo;
+    for (int b = 0; b < NB; ++b) {
+      const int64_t bag = bag0 + b;
+      if (bag >= a.FB) continue;
+      const int f = (int)(bag / a.B), bb = (int)(bag % a.B);
+      int d0, Df;
+      if (a.D_offsets) { d0 = a.D_offsets[f]; Df = a.D_offsets[f + 1] - d0; } else { d0 = f * a.D; Df = a.D; }
+      const int64_t L = hi[b] - lo[b];
       if (a.combiner == 1 && L > 0) {
         const float fl = (float)L;
 #pragma unroll
-        for (int k = 0; k < NCOL; ++k) { acc[k].x /= fl; acc[k].y /= fl; acc[k].z /= fl; acc[k].w /= fl; }
+        for (int k = 0; k < NCOL; ++k) { acc[b][k].x /= fl; acc[b][k].y /= fl; acc[b][k].z /= fl; acc[b][k].w /= fl; }
       }
 #pragma unroll
       for (int k = 0; k < NCOL; ++k) {
         const int e = 4 * (c + k * LPR);
-        if (e < Df) st4<DDT>(a.dst, (int64_t)b * a.total_D + d0 + e, acc[k]);
+        if (e < Df) st4<DDT>(a.dst, (int64_t)bb * a.total_D + d0 + e, acc[b][k]);
       }
     }
   }
@@ -274,18 +351,33 @@ init_rows_kernel(InitArgs a, int64_t n, const int64_t* __restrict__ n_dev, const
   if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
   const int lane = lane_id();
   const int64_t wpb = blockDim.x >> 6;
-  for (int64_t q = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); q < n; q += (int64_t)gridDim.x * wpb) {
-    const int64_t i = sel ? sel[q] : q;
-    if (skip && skip[i]) continue;
-    if (results) { uint8_t r = results[i]; if (!(r == 0 || r == 1 || r == 3)) continue; }
-    void* rp = row_addr ? reinterpret_cast<void*>(row_addr[i])
-                        : (void*)(reinterpret_cast<typename Elem<DT>::T*>(dense) + i * dense_stride);
-    if (!rp) continue;
-    const uint64_t key = keys[i];
-    int ed = emb_dim, vd = value_dim;
-    if (table_ids && table_emb_dims) { const int64_t t = table_ids[i]; ed = (int)table_emb_dims[t]; vd = (int)table_value_dims[t]; }
-    for (int e = lane; e < vd; e += 64)
-      st1<DT>(rp, e, e < ed ? init_value(a, key, (uint32_t)e) : a.state_init);
+  // each wave owns 64 candidate rows: one lane per row tests the flags, then the whole wave
+  // initialises the rows that need it, one after the other with coalesced stores.  In steady state
+  // (nothing new) this is a single flag read per row.
+  for (int64_t q0 = ((int64_t)blockIdx.x * wpb + (threadIdx.x >> 6)) * 64; q0 < n; q0 += (int64_t)gridDim.x * wpb * 64) {
+    const int64_t q = q0 + lane;
+    bool need = q < n;
+    int64_t i = 0;
+    if (need) {
+      i = sel ? sel[q] : q;
+      if (skip && skip[i]) need = false;
+      if (need && results) { uint8_t r = results[i]; need = (r == 0 || r == 1 || r == 3); }
+    }
+    uint64_t todo = __ballot(need);
+    while (todo) {
+      const int src = __ffsll((unsigned long long)todo) - 1;
+      todo &= todo - 1;
+      const uint32_t ilo = __shfl((int)(uint32_t)i, src, 64), ihi = __shfl((int)(uint32_t)((uint64_t)i >> 32), src, 64);
+      const int64_t ii = (int64_t)(((uint64_t)ihi << 32) | ilo);
+      void* rp = row_addr ? reinterpret_cast<void*>(row_addr[ii])
+                          : (void*)(reinterpret_cast<typename Elem<DT>::T*>(dense) + ii * dense_stride);
+      if (!rp) continue;
+      const uint64_t key = keys[ii];
+      int ed = emb_dim, vd = value_dim;
+      if (table_ids && table_emb_dims) { const int64_t t = table_ids[ii]; ed = (int)table_emb_dims[t]; vd = (int)table_value_dims[t]; }
+      for (int e = lane; e < vd; e += 64)
+        st1<DT>(rp, e, e < ed ? init_value(a, key, (uint32_t)e) : a.state_init);
+    }
   }
 }
 
@@ -301,15 +393,46 @@ static int lpr_log2_for(int D) {
 
 template <int SDT, int DDT>
 static int launch_pooled(PoolArgs a, bool vec, hipStream_t stream) {
-  const int grid = grid_for(a.FB, 4, 1 << 20);
   if (!vec) {
+    const int grid = grid_for(a.FB, 4, 1 << 20);
     hipLaunchKernelGGL((gather_pooled_scalar_kernel<SDT, DDT>), dim3(grid), dim3(256), 0, stream, a);
   } else {
     const int l = lpr_log2_for(a.D);
     const int ncol = (a.D + (4 << l) - 1) / (4 << l);
-    if (ncol <= 1) hipLaunchKernelGGL((gather_pooled_vec_kernel<SDT, DDT, 1>), dim3(grid), dim3(256), 0, stream, a, l);
-    else if (ncol <= 2) hipLaunchKernelGGL((gather_pooled_vec_kernel<SDT, DDT, 2>), dim3(grid), dim3(256), 0, stream, a, l);
-    else hipLaunchKernelGGL((gather_pooled_vec_kernel<SDT, DDT, 4>), dim3(grid), dim3(256), 0, stream, a, l);
+    const int nsub = 64 >> l;
+    // bags per block = 4 waves x nsub groups x NB
+    if (ncol <= 1) {
+      static const int variant = getenv("MI355_POOL_VARIANT") ? atoi(getenv("MI355_POOL_VARIANT")) : 0;
+#define MI355_POOL_V(NBV, RPRV)                                                                                          \
+  do {                                                                                                                   \
+    if (a.row_addr) hipLaunchKernelGGL((gather_pooled_vec_kernel<SDT, DDT, 1, NBV, true, RPRV>), dim3(grid_for(a.FB, 4 * nsub * NBV, 1 << 20)), dim3(256), 0, stream, a, l); \
+    else hipLaunchKernelGGL((gather_pooled_vec_kernel<SDT, DDT, 1, NBV, false, RPRV>), dim3(grid_for(a.FB, 4 * nsub * NBV, 1 << 20)), dim3(256), 0, stream, a, l); \
+  } while (0)
+      if (SDT == kF32 && DDT == kBF16) {
+        switch (variant) {
+          case 1: MI355_POOL_V(1, 4); break;
+          case 2: MI355_POOL_V(4, 2); break;
+          case 3: MI355_POOL_V(4, 4); break;
+          case 4: MI355_POOL_V(2, 2); break;
+          case 5: MI355_POOL_V(1, 8); break;
+          case 6: MI355_POOL_V(8, 1); break;
+          case 7: MI355_POOL_V(4, 1); break;
+          case 8: MI355_POOL_V(2, 4); break;
+          default: MI355_POOL_V(1, 4); break;  // measured best on C2 (rocprofv3: 36-38 us vs 40-51 us)
+        }
+      } else {
+        MI355_POOL_V(1, 4);
+      }
+#undef MI355_POOL_V
+    } else if (ncol <= 2) {
+      constexpr int NB = 2;
+      if (a.row_addr) hipLaunchKernelGGL((gather_pooled_vec_kernel<SDT, DDT, 2, NB, true>), dim3(grid_for(a.FB, 4 * nsub * NB, 1 << 20)), dim3(256), 0, stream, a, l);
+      else hipLaunchKernelGGL((gather_pooled_vec_kernel<SDT, DDT, 2, NB, false>), dim3(grid_for(a.FB, 4 * nsub * NB, 1 << 20)), dim3(256), 0, stream, a, l);
+    } else {
+      constexpr int NB = 1;
+      if (a.row_addr) hipLaunchKernelGGL((gather_pooled_vec_kernel<SDT, DDT, 4, NB, true>), dim3(grid_for(a.FB, 4 * nsub * NB, 1 << 20)), dim3(256), 0, stream, a, l);
+      else hipLaunchKernelGGL((gather_pooled_vec_kernel<SDT, DDT, 4, NB, false>), dim3(grid_for(a.FB, 4 * nsub * NB, 1 << 20)), dim3(256), 0, stream, a, l);
+    }
   }
   MI355_LAUNCH_CHECK();
   return MI355_OK;
@@ -320,7 +443,7 @@ extern "C" {
 // gather_embedding_pooled (dynamic_emb_op.cu:106-133).  Source is EITHER the dense unique-row
 // tensor `src` (reference form) OR the table rows themselves through `row_addr` (fused form).
 int mi355_gather_pooled(const void* src, int64_t src_stride, const int64_t* row_addr, int src_dtype,
-                        const int64_t* reverse_indices, const int64_t* offsets, int64_t num_bags, int64_t batch_size,
+                        const int64_t* reverse_indices, int64_t num_keys, const int64_t* offsets, int64_t num_bags, int64_t batch_size,
                         int combiner, int64_t dim, const int32_t* D_offsets, int64_t total_D, void* dst, int dst_dtype,
                         int aligned16, hipStream_t stream) {
   MI355_CHECK_ARG(src || row_addr, "src or row_addr required");
@@ -330,8 +453,14 @@ int mi355_gather_pooled(const void* src, int64_t src_stride, const int64_t* row_
   if (num_bags == 0) return MI355_OK;
   PoolArgs a;
   a.src = src; a.src_stride = src_stride; a.row_addr = row_addr; a.rev = reverse_indices; a.offsets = offsets;
-  a.D_offsets = D_offsets; a.dst = dst; a.FB = num_bags; a.B = (int)batch_size; a.D = (int)dim;
+  a.D_offsets = D_offsets; a.dst = dst; a.FB = num_bags; a.n = num_keys; a.B = (int)batch_size; a.D = (int)dim;
   a.total_D = (int)total_D; a.combiner = combiner;
+  if (num_keys == 0) {  // every bag is empty: the pooled output is all zeros
+    if (hipMemsetAsync(dst, 0, (size_t)batch_size * total_D * dtype_bytes(dst_dtype), stream) != hipSuccess) {
+      mi355_set_error("memset failed"); return MI355_ELAUNCH;
+    }
+    return MI355_OK;
+  }
   const bool vec = aligned16 != 0;
   return MI355_DISPATCH_DTYPE(src_dtype, S, [&] {
     return MI355_DISPATCH_DTYPE(dst_dtype, Dd, [&] { return launch_pooled<S, Dd>(a, vec, stream); });
@@ -403,7 +532,7 @@ int mi355_init_rows(int mode, float p0, float p1, float p2, float p3, uint64_t s
   MI355_CHECK_ARG(row_addr || dense, "row_addr or dense required");
   if (n == 0) return MI355_OK;
   InitArgs a{mode, p0, p1, p2, p3, seed, state_init};
-  const int grid = grid_for(n, 4, 1 << 20);
+  const int grid = grid_for(n, 4 * 64, 1 << 20);
   return MI355_DISPATCH_DTYPE(dtype, DT, [&] {
     hipLaunchKernelGGL((init_rows_kernel<DT>), dim3(grid), dim3(256), 0, stream, a, n, n_dev, (const uint64_t*)keys, sel, row_addr,
                        dense, dense_stride, (int)emb_dim, (int)value_dim, results, skip, table_ids, table_emb_dims,

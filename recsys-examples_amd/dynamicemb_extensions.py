@@ -387,7 +387,7 @@ def gather_embedding_pooled(input, output, index, offsets, combiner, total_D, ba
         al = al and bool((D_offsets % 4 == 0).all().item()) if D_offsets.numel() < 4096 else al
     if input is not None:
         al = al and input.data_ptr() % 16 == 0
-    check(lib().mi355_gather_pooled(ptr(input), stride, ptr(row_addr), sdt, ptr(index), ptr(offsets), num_bags,
+    check(lib().mi355_gather_pooled(ptr(input), stride, ptr(row_addr), sdt, ptr(index), index.numel(), ptr(offsets), num_bags,
                                     batch_size, int(combiner), dim, ptr(D_offsets), total_D, ptr(output), dt(output),
                                     int(al), stream()), "gather_embedding_pooled")
 
@@ -486,40 +486,44 @@ def debug_init(buffer, indices, keys):
 
 
 # --------------------------------------------------------------------------------- backward ----
-def group_by_unique(reverse_indices, num_unique_max, offsets=None, nu_dev=None):
-    """CSR (ptr int32[Nu+1], csr_src int32[Nt]) of the batch keyed by unique row."""
+def group_by_unique(reverse_indices, num_unique_max, offsets=None, nu_dev=None, dim=0):
+    """CSR (ptr int32[Nu+1], csr_src int32[Nt]) of the batch keyed by unique row, plus (dim > 0) the
+    hot-row task list consumed by backward_fused."""
     n = reverse_indices.numel()
     dev = reverse_indices.device
     ptr_t = torch.empty(num_unique_max + 1, dtype=torch.int32, device=dev)
     csr = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     ws = _workspace(lib().mi355_group_by_unique_workspace_bytes(n, num_unique_max), dev)
+    hot = _workspace(lib().mi355_hot_rows_workspace_bytes(n, dim), dev) if dim > 0 else None
     nb = offsets.numel() - 1 if offsets is not None else 0
     check(lib().mi355_group_by_unique(ptr(reverse_indices), n, ptr(offsets), nb, num_unique_max, ptr(nu_dev),
-                                      ptr(ptr_t), ptr(csr), ptr(ws), ws.numel(), stream()), "group_by_unique")
+                                      ptr(ptr_t), ptr(csr), ptr(ws), ws.numel(), ptr(hot),
+                                      hot.numel() if hot is not None else 0, dim, stream()), "group_by_unique")
+    if dim > 0:
+        return ptr_t, csr, hot
     return ptr_t, csr
 
 
 def backward_fused(ptr_t, csr, num_keys, num_unique_max, grads, batch_size, dim, combiner, offsets=None,
                    D_offsets=None, row_addr=None, weight_dtype=torch.float32, opt_kind=0, lr=0.0, beta1=0.9,
                    beta2=0.999, eps=1e-8, weight_decay=0.0, iter_num=1, state_offset=None, round_grad=True, out=None,
-                   nu_dev=None, use_hot_path=True):
-    dev = grads.device
-    ws = _workspace(lib().mi355_backward_workspace_bytes(num_keys, dim), dev) if use_hot_path else None
+                   nu_dev=None, hot=None):
+    """`hot`: the hot-row task list from group_by_unique(..., dim=dim); None = every row on the serial path."""
     gs = grads.stride(0)
     al = _aligned(dim, gs) and grads.data_ptr() % 16 == 0
     if D_offsets is not None:
         al = al and bool((D_offsets % 4 == 0).all().item())
     if out is not None:
         al = al and out.stride(0) % 4 == 0
-    so = dim if state_offset is None else state_offset
-    if opt_kind != 0:
+    so = -1 if state_offset is None else state_offset
+    if opt_kind != 0 and state_offset is not None:
         al = al and so % 4 == 0
     check(lib().mi355_backward_fused(ptr(ptr_t), ptr(csr), num_keys, num_unique_max, ptr(nu_dev), ptr(grads), gs,
                                      dt(grads), ptr(offsets), ptr(D_offsets), batch_size, dim, combiner,
                                      ptr(row_addr), dt(weight_dtype), opt_kind, c_f(lr), c_f(beta1), c_f(beta2),
                                      c_f(eps), c_f(weight_decay), iter_num, so, int(round_grad), ptr(out),
-                                     out.stride(0) if out is not None else 0, int(al), ptr(ws),
-                                     ws.numel() if ws is not None else 0, stream()), "backward_fused")
+                                     out.stride(0) if out is not None else 0, int(al), ptr(hot),
+                                     hot.numel() if hot is not None else 0, stream()), "backward_fused")
 
 
 def reduce_grads(reverse_indices, grads, num_unique, batch_size, out_dim, offsets=None, D_offsets=None, combiner=-1,
@@ -530,10 +534,10 @@ def reduce_grads(reverse_indices, grads, num_unique, batch_size, out_dim, offset
     if n == 0 or batch_size == 0 or num_unique == 0:
         return unique_grads
     pooled = offsets is not None
-    ptr_t, csr = group_by_unique(reverse_indices, num_unique, offsets if pooled else None)
+    ptr_t, csr, hot = group_by_unique(reverse_indices, num_unique, offsets if pooled else None, dim=out_dim)
     backward_fused(ptr_t, csr, n, num_unique, grads.contiguous(), batch_size, out_dim,
                    combiner if pooled else -1, offsets if pooled else None, D_offsets if pooled else None,
-                   opt_kind=0, out=unique_grads, round_grad=False)
+                   opt_kind=0, out=unique_grads, round_grad=False, hot=hot)
     return unique_grads
 
 

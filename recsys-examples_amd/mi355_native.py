@@ -44,9 +44,10 @@ _SIGS = {
     "mi355_expand_table_ids": [c_p, c_i64, c_i64, c_p, c_p, c_p],
     "mi355_get_table_range": [c_p, c_p, c_i64, c_i64, c_p, c_p],
     "mi355_flagged_compact": [c_p, c_i64, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_i64, c_p],
-    "mi355_group_by_unique": [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p],
+    "mi355_group_by_unique": [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_p],
+    "mi355_hot_rows_workspace_bytes": [c_i64, c_i64],
     "mi355_block_bucketize": [c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
-    "mi355_gather_pooled": [c_p, c_i64, c_p, c_int, c_p, c_p, c_i64, c_i64, c_int, c_i64, c_p, c_i64, c_p, c_int,
+    "mi355_gather_pooled": [c_p, c_i64, c_p, c_int, c_p, c_i64, c_p, c_i64, c_i64, c_int, c_i64, c_p, c_i64, c_p, c_int,
                             c_int, c_p],
     "mi355_gather_rows": [c_p, c_i64, c_p, c_int, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_int, c_int, c_p],
     "mi355_flat_table_copy": [c_int, c_int, c_i64, c_p, c_p, c_i64, c_i64, c_int, c_p, c_p, c_i64, c_p, c_p, c_p,
@@ -84,6 +85,7 @@ _RESTYPES = {
     "mi355_flagged_compact_workspace_bytes": c_i64,
     "mi355_group_by_unique_workspace_bytes": c_i64,
     "mi355_backward_workspace_bytes": c_i64,
+    "mi355_hot_rows_workspace_bytes": c_i64,
     "mi355_demb_forward_workspace_bytes": c_i64,
     "mi355_demb_backward_workspace_bytes": c_i64,
     "mi355_last_error": ctypes.c_char_p,

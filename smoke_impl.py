@@ -38,8 +38,8 @@ def run():
     assert (out.cpu().numpy() == exp).all(), "pooled output mismatch"
     # backward: SGD in place, closed form w -= lr * sum(grad rows)
     g = torch.ones(B, 4 * D, device=dev)
-    ptr_t, csr = ext.group_by_unique(rev, nu, t(offsets))
-    ext.backward_fused(ptr_t, csr, indices.size, nu, g, B, D, 0, t(offsets), None, addr, torch.float32, 1, lr=0.5)
+    ptr_t, csr, hot = ext.group_by_unique(rev, nu, t(offsets), dim=D)
+    ext.backward_fused(ptr_t, csr, indices.size, nu, g, B, D, 0, t(offsets), None, addr, torch.float32, 1, lr=0.5, hot=hot)
     out2 = torch.empty(B, 4 * D, device=dev)
     ext.gather_embedding_pooled(None, out2, rev, t(offsets), 0, 4 * D, B, max_D=D, row_addr=addr, src_dtype=torch.float32)
     cnt = np.bincount(orev, minlength=nu).astype(np.float32)

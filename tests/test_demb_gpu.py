@@ -573,9 +573,9 @@ def test_backward_fused_optimizers(opt, D, wdt, gdt):
         else:
             orc.rowwise_adagrad_update(rows, ug[ok], D, hp["lr"], hp["eps"])
         ref[slots[ok]] = orc.round_to(rows, _NP[wdt])
-        ptr_t, csr = e.group_by_unique(T(rev), Nu, T(offsets))
+        ptr_t, csr, hot = e.group_by_unique(T(rev), Nu, T(offsets), dim=D)
         e.backward_fused(ptr_t, csr, rev.size, Nu, T(g, gdt), B, D, 1, T(offsets), None, addr, wdt, kind, iter_num=it,
-                         state_offset=D, **hp)
+                         state_offset=D, hot=hot, **hp)
     got = table.float().cpu().numpy()
     tol = dict(rtol=2e-2, atol=2e-2) if (wdt != torch.float32 or gdt != torch.float32) else dict(rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(got, ref, **tol)

@@ -1,0 +1,21 @@
+"""Runs only the C2 (Zipf) pattern of the fused gather+pool kernel a few times (for rocprofv3 --pmc)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "recsys-examples_amd")); sys.path.insert(0, ROOT)
+import torch
+import dynamicemb_extensions as ext
+dev = torch.device("cuda"); rows, D, B = 10_000_000, 128, 65536
+table = torch.empty(rows, D, device=dev).uniform_(-1, 1)
+g = torch.Generator(device=dev); g.manual_seed(0)
+lens = torch.randint(1, 11, (B,), device=dev, generator=g)
+off = torch.zeros(B + 1, dtype=torch.int64, device=dev); off[1:] = torch.cumsum(lens, 0); nt = int(off[-1])
+w = torch.arange(1, rows + 1, device=dev, dtype=torch.float64).pow_(-0.99); cdf = torch.cumsum(w, 0); cdf /= cdf[-1].clone()
+perm = torch.randperm(rows, device=dev, generator=g)
+keys = perm[torch.searchsorted(cdf, torch.rand(nt, device=dev, dtype=torch.float64, generator=g)).clamp_(max=rows - 1)]
+uk, rev = torch.unique(keys, return_inverse=True); rev = rev.contiguous()
+addr = table.data_ptr() + uk * (D * 4)
+out = torch.empty(B, D, dtype=torch.bfloat16, device=dev)
+print("nt", nt, "nu", uk.numel())
+for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
+    ext.gather_embedding_pooled(None, out, rev, off, 0, D, B, max_D=D, row_addr=addr, src_dtype=torch.float32)
+torch.cuda.synchronize()
