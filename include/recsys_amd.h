@@ -230,6 +230,33 @@ int mi355_demb_backward(const int64_t* reverse_indices, int64_t num_keys, const 
                         const int64_t* table_bucket_offsets, int64_t bucket_capacity, int unpin, void* workspace,
                         int64_t workspace_bytes, hipStream_t stream);
 
+/* ---------------------------------------------------------------- HSTU jagged attention ---- */
+
+/* hstu_varlen_fwd (corelib/hstu/csrc/hstu_attn/hstu_api.cpp:335-523; torch.ops.fbgemm.hstu_varlen_fwd_80,
+ * examples/hstu/ops/fused_hstu_op.py:318-337): out = M * SiLU(alpha q k^T) v / scaling_seqlen per jagged
+ * sequence.  q, k, v, out: bf16 [total, H, d], element strides between tokens / heads given explicitly
+ * (last dim contiguous); cu_seqlens int32 [batch+1] (shared by q and k); num_contexts / num_targets
+ * int32 [batch] or NULL; causal = window (-1, 0), else full (-1, -1); head_dim in {32, 64, 128, 256}. */
+int mi355_hstu_attn_fwd(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride,
+                        int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride,
+                        int64_t k_head_stride, int64_t v_head_stride, int64_t o_head_stride,
+                        const int32_t* cu_seqlens, int64_t batch, int64_t num_heads, int64_t head_dim,
+                        int64_t max_seqlen, const int32_t* num_contexts, const int32_t* num_targets,
+                        int64_t target_group_size, int causal, float alpha, float scaling_seqlen,
+                        hipStream_t stream);
+
+/* hstu_varlen_bwd (hstu_api.cpp:525-719; hstu_varlen_bwd_80, fused_hstu_op.py:682-706): dq, dk, dv
+ * contiguous bf16 [total, H, d].  Deterministic (two passes, no atomics): `deterministic` of the
+ * reference is always on. */
+int64_t mi355_hstu_attn_bwd_workspace_bytes(int64_t total_tokens, int64_t num_heads, int64_t head_dim);
+int mi355_hstu_attn_bwd(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
+                        int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t do_row_stride,
+                        int64_t q_head_stride, int64_t k_head_stride, int64_t v_head_stride,
+                        int64_t do_head_stride, const int32_t* cu_seqlens, int64_t batch, int64_t num_heads,
+                        int64_t head_dim, int64_t max_seqlen, const int32_t* num_contexts,
+                        const int32_t* num_targets, int64_t target_group_size, int causal, float alpha,
+                        float scaling_seqlen, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,6 @@
+"""Drop-in for the `hstu` package of the reference (pip `fbgemm_gpu_hstu`, built from the un-vendored
+third_party/FBGEMM submodule): `hstu_attn_varlen_func` with the positional order the example pins
+(examples/hstu/modules/hstu_attention.py:296-314, test/hstu_attn/test_hstu_attn_smoke.py:105-121), on top of
+the gfx950 MFMA kernels (mi355_hstu_attn_fwd / mi355_hstu_attn_bwd).
+"""
+from .hstu_attn_interface import HstuAttnVarlenFunc, hstu_attn_varlen_func, hstu_varlen_bwd, hstu_varlen_fwd  # noqa: F401

@@ -1,0 +1,119 @@
+"""autograd wrapper of the HSTU jagged attention kernels (MI355X).
+
+Mirrors `HstuAttnVarlenFunc` / `hstu_attn_varlen_func` of the reference
+(corelib/hstu/hstu_attn/hstu_attn_interface.py:23-279 legacy signature; new positional order of
+examples/hstu/modules/hstu_attention.py:296-314): same argument meaning, same input checks
+(bf16/fp16-class inputs, int32 cu_seqlens / num_contexts / num_targets, head_dim in {32, 64, 128, 256},
+contextual / target masks require causal -- hstu_api.cpp:359-430).
+Not supported this round (raise): rab / drab, paged kv_cache, seqused_*, local windows, fp16 (bf16 only).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+import mi355_native as N
+from mi355_native import c_f, c_i64, c_int, c_p, check, lib, ptr, stream
+
+N.register_signatures({
+    "mi355_hstu_attn_fwd": [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_i64,
+                            c_i64, c_i64, c_p, c_p, c_i64, c_int, c_f, c_f, c_p],
+    "mi355_hstu_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p,
+                            c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_int, c_f, c_f, c_p, c_i64, c_p],
+    "mi355_hstu_attn_bwd_workspace_bytes": [c_i64, c_i64, c_i64],
+}, {"mi355_hstu_attn_bwd_workspace_bytes": c_i64})
+
+
+def _check_inputs(q, k, v, cu_q, cu_k, num_contexts, num_targets, window_size, rab, kv_cache, seqused_q, seqused_k):
+    if rab is not None or kv_cache is not None:
+        raise NotImplementedError("rab / paged kv_cache are 'next' rows (DESIGN.md)")
+    if seqused_q is not None or seqused_k is not None:
+        raise NotImplementedError("seqused_q / seqused_k are not supported")
+    if q.dtype != torch.bfloat16 or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise RuntimeError("hstu_attn only supports bf16 q/k/v in this build")
+    if q.dim() != 3 or k.shape != q.shape or v.shape != q.shape:
+        raise RuntimeError("q, k, v must be (total, nheads, head_dim) with equal shapes")
+    if q.stride(-1) != 1 or k.stride(-1) != 1 or v.stride(-1) != 1:
+        raise RuntimeError("q, k, v must have a contiguous last dimension")
+    if cu_q.dtype != torch.int32 or cu_k.dtype != torch.int32:
+        raise RuntimeError("cu_seqlens must be int32")
+    if cu_q.data_ptr() != cu_k.data_ptr() and not torch.equal(cu_q, cu_k):
+        raise NotImplementedError("cu_seqlens_q != cu_seqlens_k (delta-q / kv cache) is a 'next' row")
+    for t, name in ((num_contexts, "num_contexts"), (num_targets, "num_targets")):
+        if t is not None and t.dtype != torch.int32:
+            raise RuntimeError(f"{name} must be int32")
+    wl, wr = window_size
+    if wl != -1 or wr not in (-1, 0):
+        raise NotImplementedError("local attention windows are not supported; use (-1, 0) causal or (-1, -1) full")
+    causal = wr == 0
+    if not causal and (num_contexts is not None or num_targets is not None):
+        raise RuntimeError("contextual / target masks require causal attention")
+    if q.shape[-1] not in (32, 64, 128, 256):
+        raise RuntimeError("head_dim must be one of 32, 64, 128, 256")
+    return causal
+
+
+def hstu_varlen_fwd(q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_contexts, num_targets, target_group_size,
+                    causal, alpha):
+    """Raw forward (stands in for torch.ops.fbgemm.hstu_varlen_fwd_80 / hstu_attn_2_cuda.varlen_fwd)."""
+    T, H, D = q.shape
+    out = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
+    B = cu_seqlens.numel() - 1
+    check(lib().mi355_hstu_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
+                                    q.stride(1), k.stride(1), v.stride(1), out.stride(1), ptr(cu_seqlens), B, H, D,
+                                    int(max_seqlen), ptr(num_contexts), ptr(num_targets), int(target_group_size), int(causal),
+                                    c_f(alpha), c_f(float(scaling_seqlen)), stream()), "hstu_attn_fwd")
+    return out
+
+
+def hstu_varlen_bwd(dout, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_contexts, num_targets, target_group_size,
+                    causal, alpha):
+    """Raw backward (stands in for hstu_varlen_bwd_80 / varlen_bwd): returns (dq, dk, dv)."""
+    T, H, D = q.shape
+    dout = dout.contiguous() if dout.stride(-1) != 1 else dout
+    dq = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
+    dk = torch.empty_like(dq)
+    dv = torch.empty_like(dq)
+    B = cu_seqlens.numel() - 1
+    wsb = lib().mi355_hstu_attn_bwd_workspace_bytes(T, H, D)
+    ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=q.device)
+    check(lib().mi355_hstu_attn_bwd(ptr(dout), ptr(q), ptr(k), ptr(v), ptr(dq), ptr(dk), ptr(dv), q.stride(0), k.stride(0),
+                                    v.stride(0), dout.stride(0), q.stride(1), k.stride(1), v.stride(1), dout.stride(1),
+                                    ptr(cu_seqlens), B, H, D, int(max_seqlen), ptr(num_contexts), ptr(num_targets),
+                                    int(target_group_size), int(causal), c_f(alpha), c_f(float(scaling_seqlen)), ptr(ws),
+                                    ws.numel(), stream()), "hstu_attn_bwd")
+    return dq, dk, dv
+
+
+class HstuAttnVarlenFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_contexts, num_targets, target_group_size, causal,
+                alpha):
+        out = hstu_varlen_fwd(q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_contexts, num_targets, target_group_size,
+                              causal, alpha)
+        ctx.save_for_backward(q, k, v, cu_seqlens, num_contexts, num_targets)
+        ctx.meta = (max_seqlen, scaling_seqlen, target_group_size, causal, alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, cu, nc, nt = ctx.saved_tensors
+        max_seqlen, scaling, g, causal, alpha = ctx.meta
+        dq, dk, dv = hstu_varlen_bwd(dout, q, k, v, cu, max_seqlen, scaling, nc, nt, g, causal, alpha)
+        return dq, dk, dv, None, None, None, None, None, None, None, None
+
+
+def hstu_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, seqused_q, seqused_k, max_seqlen_q, max_seqlen_k,
+                          scaling_seqlen, num_contexts, num_targets, target_group_size=1, window_size=(-1, -1), alpha=1.0,
+                          rab=None, has_drab=False, kv_cache=None, page_offsets=None, page_ids=None, last_page_lens=None,
+                          func=None, quant_mode=-1):
+    """out (total_q, nheads, head_dim) = HSTU attention over the jagged batch described by cu_seqlens."""
+    causal = _check_inputs(q, k, v, cu_seqlens_q, cu_seqlens_k, num_contexts, num_targets, window_size, rab, kv_cache,
+                           seqused_q, seqused_k)
+    if max_seqlen_q > max_seqlen_k:
+        raise RuntimeError("max_seqlen_q must be <= max_seqlen_k")
+    if scaling_seqlen is None or scaling_seqlen == -1:
+        scaling_seqlen = max_seqlen_q
+    return HstuAttnVarlenFunc.apply(q, k, v, cu_seqlens_q, int(max_seqlen_k), scaling_seqlen, num_contexts, num_targets,
+                                    int(target_group_size), causal, float(alpha))

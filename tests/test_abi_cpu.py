@@ -22,6 +22,7 @@ def _declared():
 
 def test_library_exports_every_declared_symbol():
     import mi355_native as N
+    import hstu  # noqa: F401  (registers the attention entry points in the binding table)
 
     lib = N.lib()
     decl = _declared()
