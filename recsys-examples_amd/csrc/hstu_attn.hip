@@ -70,6 +70,40 @@ __device__ __forceinline__ float silu_f(float x) {
   return x * __frcp_rn(1.0f + __expf(-x));
 }
 
+// Row-side mask state of one query (causal case).  M(i, j) of the reference collapses to
+//   j <= jmax  and  (j < hlen  or  j >= jlo)
+// with jmax = i (history / target rows) or hlen-1 (contextual rows: they see the whole history), and
+// jlo = first key of the row's target group (0 for non-target rows).  Non causal: j < L.
+struct RowMask { int jmax, jlo, hlen; };
+__device__ __forceinline__ RowMask row_mask(int i, const SeqInfo& s, int causal, int group) {
+  RowMask m;
+  m.hlen = s.hlen;
+  if (!causal) { m.jmax = s.L - 1; m.jlo = 0; m.hlen = s.L; return m; }
+  m.jmax = (s.has_ctx && i < s.c) ? s.hlen - 1 : i;
+  if (m.jmax > s.L - 1) m.jmax = s.L - 1;
+  m.jlo = (s.has_tgt && i >= s.hlen) ? s.hlen + ((i - s.hlen) / group) * group : 0;
+  return m;
+}
+__device__ __forceinline__ bool key_ok(int j, const RowMask& m) { return (j <= m.jmax) & ((j < m.hlen) | (j >= m.jlo)); }
+
+// SiLU(alpha * acc) * inv_scale from the raw accumulator: 4 plain VALU + 2 transcendental ops
+__device__ __forceinline__ float silu_scaled(float acc, float neg_alpha_log2e, float alpha_inv_scale) {
+  const float t = __builtin_amdgcn_exp2f(acc * neg_alpha_log2e);
+  return acc * alpha_inv_scale * __builtin_amdgcn_rcpf(1.0f + t);
+}
+
+// rows [row0, row0+NR) of a [*, H, D] tensor -> LDS [NR][D+8] row-major (zeros beyond nvalid)
+template <int D, int NR>
+__device__ __forceinline__ void stage_rows(uint16_t* dst, const uint16_t* src, int64_t row_stride, int row0, int nvalid) {
+  constexpr int NCH = NR * D / 8;
+#pragma unroll
+  for (int ch = threadIdx.x; ch < NCH; ch += 256) {
+    const int r = ch / (D / 8), dc = ch % (D / 8);
+    uint4 t = make_uint4(0, 0, 0, 0);
+    if (row0 + r < nvalid) t = *reinterpret_cast<const uint4*>(src + (int64_t)(row0 + r) * row_stride + 8 * dc);
+    *reinterpret_cast<uint4*>(dst + r * (D + 8) + 8 * dc) = t;
+  }
+}
 template <int D>
 __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
   constexpr int KS = D + 8;    // padded K row (elements)
@@ -77,6 +111,8 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   uint16_t* Ks = smem;                 // [kBN][KS]
   uint16_t* Vt = smem + kBN * KS;      // [D][VS], key positions permuted inside every 16-group
+  constexpr bool QLDS = D >= 256;      // large head dim: Q fragments live in LDS to free 64 VGPRs for prefetching
+  uint16_t* Qs = Vt + D * VS;          // [kBM][KS] (QLDS only)
 
   const int b = blockIdx.z, h = blockIdx.y;
   SeqInfo s;
@@ -111,8 +147,10 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
   }
 
   // ---- Q fragments (B operand of GEMM 1): lane = (query l31, k half hi), 8 consecutive d per 16-slice
-  bf16x8_t qf[D / 16];
-  {
+  bf16x8_t qf[QLDS ? 1 : D / 16];
+  if constexpr (QLDS) {
+    stage_rows<D, kBM>(Qs, a.q + (int64_t)s.start * a.q_row + (int64_t)h * a.q_head, a.q_row, m0, s.L);
+  } else {
     const uint16_t* qp = a.q + (int64_t)(s.start + (qi < s.L ? qi : 0)) * a.q_row + (int64_t)h * a.q_head + 8 * hi;
 #pragma unroll
     for (int sl = 0; sl < D / 16; ++sl) {
@@ -128,37 +166,57 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_o[dt][r] = 0.f;
 
-  for (int n0 = 0; n0 < n_end; n0 += kBN) {
-    __syncthreads();
-    // ---- stage K tile: [64 keys][D] row-major, 16-B chunks
-    constexpr int KCH = kBN * D / 8;
+  const float nal2e = -a.alpha * 1.44269504088896f, ais = a.alpha * a.inv_scale;
+  const RowMask rm = row_mask(qi, s, a.causal, a.group);
+  // ---- software-pipelined staging (issue-early / write-late): the K / V tile of step n+1 is fetched
+  // into registers while step n computes; it is written to LDS (V transposed) after the barrier.
+  constexpr int KCH = kBN * D / 8;            // 16-B chunks of the K tile
+  constexpr int KPT = (KCH + 255) / 256;      // per thread
+  constexpr int VCH = (kBN / 4) * (D / 8);    // (4 keys x 8 d) blocks of the V tile
+  constexpr int VPT = (VCH + 255) / 256;
+  uint4 kreg[KPT], vreg[VPT][4];
+  const uint16_t* kbase = a.k + (int64_t)s.start * a.k_row + (int64_t)h * a.k_head;
+  const uint16_t* vbase = a.v + (int64_t)s.start * a.v_row + (int64_t)h * a.v_head;
+  auto fetch = [&](int n0) {
 #pragma unroll
-    for (int ch = threadIdx.x; ch < KCH; ch += 256) {
+    for (int i = 0; i < KPT; ++i) {
+      const int ch = threadIdx.x + 256 * i;
       const int key = ch / (D / 8), dc = ch % (D / 8);
-      uint4 t = make_uint4(0, 0, 0, 0);
-      if (n0 + key < s.L)
-        t = *reinterpret_cast<const uint4*>(a.k + (int64_t)(s.start + n0 + key) * a.k_row + (int64_t)h * a.k_head + 8 * dc);
-      *reinterpret_cast<uint4*>(Ks + key * KS + 8 * dc) = t;
+      // rows past the sequence end are clamped to its last row: their P is masked to 0, so any finite data do
+      const int row = n0 + key < s.L ? n0 + key : s.L - 1;
+      if (KCH % 256 == 0 || ch < KCH) kreg[i] = *reinterpret_cast<const uint4*>(kbase + (int64_t)row * a.k_row + 8 * dc);
     }
-    // ---- stage V tile transposed: each lane takes 4 consecutive keys x 8 d, writes 8 x (4 keys) b64
-    constexpr int VCH = (kBN / 4) * (D / 8);
 #pragma unroll
-    for (int ch = threadIdx.x; ch < VCH; ch += 256) {
+    for (int i = 0; i < VPT; ++i) {
+      const int ch = threadIdx.x + 256 * i;
       const int kgpos = ch % (kBN / 4), dc = ch / (kBN / 4);
       const int g16 = kgpos >> 2, pg = kgpos & 3;
       const int ak = pg == 1 ? 2 : (pg == 2 ? 1 : pg);  // position group -> actual key group
       const int key0 = 16 * g16 + 4 * ak;
-      uint4 r[4];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        r[kk] = make_uint4(0, 0, 0, 0);
-        if (n0 + key0 + kk < s.L)
-          r[kk] = *reinterpret_cast<const uint4*>(a.v + (int64_t)(s.start + n0 + key0 + kk) * a.v_row + (int64_t)h * a.v_head + 8 * dc);
+        const int row = n0 + key0 + kk < s.L ? n0 + key0 + kk : s.L - 1;
+        if (VCH % 256 == 0 || ch < VCH) vreg[i][kk] = *reinterpret_cast<const uint4*>(vbase + (int64_t)row * a.v_row + 8 * dc);
       }
-      const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&r[0]);
-      const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&r[1]);
-      const uint32_t* w2 = reinterpret_cast<const uint32_t*>(&r[2]);
-      const uint32_t* w3 = reinterpret_cast<const uint32_t*>(&r[3]);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int ch = threadIdx.x + 256 * i;
+      const int key = ch / (D / 8), dc = ch % (D / 8);
+      if (KCH % 256 == 0 || ch < KCH) *reinterpret_cast<uint4*>(Ks + key * KS + 8 * dc) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int ch = threadIdx.x + 256 * i;
+      if (VCH % 256 != 0 && ch >= VCH) continue;
+      const int kgpos = ch % (kBN / 4), dc = ch / (kBN / 4);
+      const int g16 = kgpos >> 2, pg = kgpos & 3;
+      const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&vreg[i][0]);
+      const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&vreg[i][1]);
+      const uint32_t* w2 = reinterpret_cast<const uint32_t*>(&vreg[i][2]);
+      const uint32_t* w3 = reinterpret_cast<const uint32_t*>(&vreg[i][3]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
@@ -168,51 +226,97 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
         *reinterpret_cast<uint2*>(Vt + (8 * dc + e) * VS + 16 * g16 + 4 * pg) = o;
       }
     }
+  };
+
+  if (n_end > 0) fetch(0);
+  for (int n0 = 0; n0 < n_end; n0 += kBN) {
     __syncthreads();
+    commit();
+    __syncthreads();
+    if (n0 + kBN < n_end) fetch(n0 + kBN);
     if (!wave_live || n0 >= w_end) continue;
 
-    // ---- GEMM 1: S^T[64 keys x 32 q] = K Q^T, two 32-key tiles
+    // ---- GEMM 1: S^T[64 keys x 32 q] = K Q^T, two 32-key tiles.  Operand fragments are fetched from LDS
+    // in batches of 8 ahead of the 8 MFMAs that consume them (hipcc otherwise emits read-wait-mfma triples).
     f32x16_t acc_s[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc_s[t][r] = 0.f;
 #pragma unroll
-    for (int sl = 0; sl < D / 16; ++sl) {
+    for (int sl0 = 0; sl0 < D / 16; sl0 += 4) {
+      bf16x8_t kfr[4][2], qfr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (sl0 + u >= D / 16) continue;
+        if constexpr (QLDS) qfr[u] = *reinterpret_cast<const bf16x8_t*>(Qs + (32 * wv + l31) * KS + 16 * (sl0 + u) + 8 * hi);
+        else qfr[u] = qf[sl0 + u];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          kfr[u][t] = *reinterpret_cast<const bf16x8_t*>(Ks + (32 * t + l31) * KS + 16 * (sl0 + u) + 8 * hi);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          if (sl0 + u < D / 16)
+            acc_s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[u][t], qfr[u], acc_s[t], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, QLDS ? 12 : 8, 0);  // the DS reads of this batch first,
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);               // then its 8 MFMAs
+    }
+    // ---- P^T = mask * SiLU(alpha S^T) / scaling, packed straight into the B operand of GEMM 2.
+    // Tiles strictly below the diagonal of every row of the wave need no per-element mask.
+    const bool full = a.causal && (n0 + kBN - 1 <= qrow0) && (!s.has_ctx || qrow0 >= s.c) && (!s.has_tgt || n0 + kBN - 1 < s.hlen);
+    bf16x8_t pf[4];
+    if (full) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (32 * t + l31) * KS + 16 * sl + 8 * hi);
-        acc_s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[sl], acc_s[t], 0, 0, 0);
+        uint32_t pk[8];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2)
+          pk[r >> 1] = pack_bf16(silu_scaled(acc_s[t][r], nal2e, ais), silu_scaled(acc_s[t][r + 1], nal2e, ais));
+        uint4 lo4 = make_uint4(pk[0], pk[1], pk[2], pk[3]), hi4 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        pf[2 * t] = *reinterpret_cast<bf16x8_t*>(&lo4);
+        pf[2 * t + 1] = *reinterpret_cast<bf16x8_t*>(&hi4);
       }
-    }
-    // ---- P^T = mask * SiLU(alpha S^T) / scaling, packed straight into the B operand of GEMM 2
-    bf16x8_t pf[4];
+    } else {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      uint32_t pk[8];
+      for (int t = 0; t < 2; ++t) {
+        uint32_t pk[8];
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        float p2[2];
+        for (int r = 0; r < 16; r += 2) {
+          float p2[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int rr = r + u;
-          const int key = n0 + 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
-          const float x = acc_s[t][rr] * a.alpha;
-          p2[u] = attn_allowed(qi, key, s, a.causal, a.group) ? silu_f(x) * a.inv_scale : 0.f;
+          for (int u = 0; u < 2; ++u) {
+            const int rr = r + u;
+            const int key = n0 + 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+            const float pv = silu_scaled(acc_s[t][rr], nal2e, ais);
+            p2[u] = key_ok(key, rm) ? pv : 0.f;
+          }
+          pk[r >> 1] = pack_bf16(p2[0], p2[1]);
         }
-        pk[r >> 1] = pack_bf16(p2[0], p2[1]);
+        uint4 lo4 = make_uint4(pk[0], pk[1], pk[2], pk[3]), hi4 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        pf[2 * t] = *reinterpret_cast<bf16x8_t*>(&lo4);
+        pf[2 * t + 1] = *reinterpret_cast<bf16x8_t*>(&hi4);
       }
-      uint4 lo4 = make_uint4(pk[0], pk[1], pk[2], pk[3]), hi4 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-      pf[2 * t] = *reinterpret_cast<bf16x8_t*>(&lo4);
-      pf[2 * t + 1] = *reinterpret_cast<bf16x8_t*>(&hi4);
     }
-    // ---- GEMM 2: O^T[D x 32 q] += V^T[D x 64 keys] P^T
+    // ---- GEMM 2: O^T[D x 32 q] += V^T[D x 64 keys] P^T: key slice outer, so consecutive MFMAs hit
+    // independent accumulators; fragments again fetched in batches
+    constexpr int NDT = D / 32;
+    constexpr int DB = NDT < 8 ? NDT : 8;
 #pragma unroll
-    for (int dt = 0; dt < D / 32; ++dt) {
+    for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vt + (32 * dt + l31) * VS + 16 * ks + 8 * hi);
-        acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], acc_o[dt], 0, 0, 0);
+      for (int dt0 = 0; dt0 < NDT; dt0 += DB) {
+        bf16x8_t vfr[DB];
+#pragma unroll
+        for (int u = 0; u < DB; ++u)
+          vfr[u] = *reinterpret_cast<const bf16x8_t*>(Vt + (32 * (dt0 + u) + l31) * VS + 16 * ks + 8 * hi);
+#pragma unroll
+        for (int u = 0; u < DB; ++u)
+          acc_o[dt0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[u], pf[ks], acc_o[dt0 + u], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, DB, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, DB, 0);
       }
     }
   }
@@ -246,18 +350,6 @@ __device__ __forceinline__ float dsilu_f(float x) {
   return sg * (1.0f + x * (1.0f - sg));
 }
 
-// rows [row0, row0+NR) of a [*, H, D] tensor -> LDS [NR][D+8] row-major (zeros beyond nvalid)
-template <int D, int NR>
-__device__ __forceinline__ void stage_rows(uint16_t* dst, const uint16_t* src, int64_t row_stride, int row0, int nvalid) {
-  constexpr int NCH = NR * D / 8;
-#pragma unroll
-  for (int ch = threadIdx.x; ch < NCH; ch += 256) {
-    const int r = ch / (D / 8), dc = ch % (D / 8);
-    uint4 t = make_uint4(0, 0, 0, 0);
-    if (row0 + r < nvalid) t = *reinterpret_cast<const uint4*>(src + (int64_t)(row0 + r) * row_stride + 8 * dc);
-    *reinterpret_cast<uint4*>(dst + r * (D + 8) + 8 * dc) = t;
-  }
-}
 // same rows transposed -> LDS [D][NR+8], row positions permuted inside every 16-group ({0-3,8-11,4-7,12-15})
 template <int D, int NR>
 __device__ __forceinline__ void stage_transposed(uint16_t* dst, const uint16_t* src, int64_t row_stride, int row0, int nvalid) {
@@ -567,7 +659,7 @@ static int launch_bwd(const BwdAttnArgs& g, int B, int max_seqlen, hipStream_t s
 
 template <int D>
 static int launch_fwd(const AttnArgs& a, int B, int max_seqlen, hipStream_t stream) {
-  const size_t smem = (size_t)(kBN * (D + 8) + D * (kBN + 8)) * sizeof(uint16_t);
+  const size_t smem = (size_t)(kBN * (D + 8) + D * (kBN + 8) + (D >= 256 ? kBM * (D + 8) : 0)) * sizeof(uint16_t);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
