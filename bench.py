@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="run the row-wise sharded path even at N=1 (debug)")
+    ap.add_argument("--shard-mode", default="auto", choices=["auto", "rows", "partial"])
     return ap.parse_args()
 
 
@@ -125,10 +127,13 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded_path = world > 1 or args.force_sharded
+    if sharded_path:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
@@ -137,7 +142,7 @@ def main():
     n_batches = args.steps + args.warmup
     batches = zipf_batches(args.rows, args.alpha, args.batch, n_batches, device, seed=1234 + rank)
 
-    if world == 1:
+    if not sharded_path:
         module = build_module(args.rows, args.dim, device)
         module.train()
 
@@ -149,7 +154,8 @@ def main():
     else:
         from dynamicemb.sharded import ShardedPooledLookup
 
-        sharded = ShardedPooledLookup(args.rows, args.dim, device, world, rank)
+        sharded = ShardedPooledLookup(args.rows, args.dim, device, world, rank, mode=args.shard_mode,
+                                      keys_per_step=int(args.batch * 5.5), batch=args.batch)
 
         def fwd(keys, offsets):
             return sharded.forward(keys, offsets)
@@ -173,14 +179,14 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    if world > 1:
+    if sharded_path:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.warmup, n_batches):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded_path:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     keys_local = sum(batches[i][0].numel() for i in range(args.warmup, n_batches))
@@ -212,7 +218,7 @@ def main():
                    "keys_per_step": keys_total / args.steps / world, "parallelism": f"row-wise mp{world}" if world > 1 else "1 GPU"},
     }
 
-    if rank == 0 and world == 1 and not args.no_kernel_timing:
+    if rank == 0 and not sharded_path and not args.no_kernel_timing:
         # ---- dominant kernels, timed live with HIP events on the launch stream (torch's current stream) ----
         nu_list, fwd_ms, bwd_ms = [], [], []
         D, e, o = args.dim, 4, 2
@@ -261,7 +267,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if sharded_path:
         dist.destroy_process_group()
 
 

@@ -137,7 +137,24 @@ int mi355_block_bucketize(int64_t world_size, int64_t num_bags, int64_t batch_si
                           const float* weights, int64_t* new_lengths, int64_t* new_offsets, void* new_indices,
                           float* new_weights, int64_t* unbucketize_permute, hipStream_t stream);
 
+/* Bag re-ordering of a received key stream, (source rank, feature, batch) -> (feature, source rank, batch):
+ * the recat / permute_2D_sparse_data step of TorchRec's KJTAllToAll (third party), call site
+ * dynamicemb/input_dist.py:239-285.  Offsets are exclusive scans of the respective lengths. */
+int mi355_permute_lengths(int64_t num_sources, int64_t num_features, int64_t batch_size, const int64_t* in_lengths,
+                          int64_t* out_lengths, hipStream_t stream);
+/* elem_bytes: bytes per element of the permuted stream (8 for keys, D*sizeof(T) for embedding rows);
+ * num_elements: length of the stream (host value, picks the short-bag or long-bag kernel). */
+int mi355_permute_bags(int64_t num_sources, int64_t num_features, int64_t batch_size, int64_t elem_bytes,
+                       int64_t num_elements, const int64_t* in_offsets, const int64_t* out_offsets, const void* in_keys,
+                       void* out_keys, hipStream_t stream);
+
 /* ------------------------------------------------------------------------ value ops ---- */
+
+/* out[r] = sum_c in[c][r] (fp32 partial pooled sums of the W shards -> output dtype): the local half of the
+ * pooled output dist (TorchRec RwPooledEmbeddingSharding reduce-scatter, planner/rw_sharding.py:191-261). */
+int mi355_sum_chunks(const float* in, int64_t chunks, int64_t numel_per_chunk, void* out, int out_dtype,
+                     hipStream_t stream);
+
 
 /* gather_embedding_pooled, src/dynamic_emb_op.cu:106-133 (kernels lookup_kernel.cuh:859-998).
  * Source: dense [*, src_stride] (reference form) or table rows through row_addr[u] (fused form;
@@ -179,7 +196,9 @@ int mi355_init_rows(int mode, float p0, float p1, float p2, float p3, uint64_t s
 
 /* reduce_grads (opt_kind 0, src/dynamic_emb_op.cu:159-285) and reduce_grads fused with
  * {sgd,adam,adagrad,rowwise_adagrad}_update_for_flat_table (opt_kind 1..4, src/optimizer.cu:77-240)
- * over the CSR of mi355_group_by_unique.  combiner -1 sequence / 0 sum / 1 mean. */
+ * over the CSR of mi355_group_by_unique.  combiner -1 sequence / 0 sum / 1 mean.
+ * opt_kind 0 writes the reduced gradients to `out` [max_unique, out_stride] and `weight_dtype` is then the dtype
+ * of `out` (the reference returns the grad dtype; fp32 keeps the sums exact for the sharded backward). */
 int64_t mi355_backward_workspace_bytes(int64_t num_keys, int64_t dim);
 int mi355_backward_fused(const int32_t* ptr, const int32_t* csr_src, int64_t num_keys, int64_t max_unique,
                          const int64_t* nu_dev, const void* grads, int64_t grad_stride, int grad_dtype,

@@ -195,8 +195,8 @@ __device__ __forceinline__ void apply_sink(const OptArgs& o_in, int64_t u, void*
     for (int k = 0; k < NCOL; ++k) {
       const int e = W * (c + k * LPR);
       if (e < D) {
-        if (kVec) st4<GDT>(o.out, u * o.out_stride + e, make_float4(g[k][0], g[k][1], g[k][2], g[k][3]));
-        else st1<GDT>(o.out, u * o.out_stride + e, g[k][0]);
+        if (kVec) st4<WDT>(o.out, u * o.out_stride + e, make_float4(g[k][0], g[k][1], g[k][2], g[k][3]));
+        else st1<WDT>(o.out, u * o.out_stride + e, g[k][0]);
       }
     }
     return;
@@ -525,7 +525,8 @@ extern "C" {
 int64_t mi355_backward_workspace_bytes(int64_t num_keys, int64_t dim) { return hot_bytes(num_keys, dim); }
 
 // Fused backward over the CSR of mi355_group_by_unique.
-//   opt_kind 0: store the reduced gradients to `out` [max_unique, out_stride] in the grad dtype (reduce_grads)
+//   opt_kind 0: store the reduced gradients to `out` [max_unique, out_stride]; `weight_dtype` is then the dtype
+//               of `out` (reduce_grads uses the grad dtype; the sharded backward keeps fp32)
 //   opt_kind 1..4: SGD / Adam / AdaGrad / row-wise AdaGrad applied in place on the table rows `row_addr`
 int mi355_backward_fused(const int32_t* ptr, const int32_t* csr_src, int64_t num_keys, int64_t max_unique,
                          const int64_t* nu_dev, const void* grads, int64_t grad_stride, int grad_dtype,

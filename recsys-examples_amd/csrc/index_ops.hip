@@ -590,6 +590,47 @@ bucketize_scatter_kernel(int64_t FB, int64_t B, int W, const int64_t* __restrict
   }
 }
 
+// Re-order the bags of a received key stream from (source rank, feature, batch) to (feature, source rank,
+// batch) order -- what TorchRec's KJTAllToAll does with permute_2D_sparse_data after the key all-to-all
+// (third-party; call site corelib/dynamicemb/dynamicemb/input_dist.py:239-285).  One wave per output bag.
+__global__ void __launch_bounds__(256)
+permute_bags_kernel(int64_t S, int64_t F, int64_t B, int64_t W8, const int64_t* __restrict__ in_offsets,
+                    const int64_t* __restrict__ out_offsets, const uint64_t* __restrict__ in_keys,
+                    uint64_t* __restrict__ out_keys) {
+  const int lane = lane_id();
+  const int64_t nb = S * F * B;
+  for (int64_t o = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); o < nb; o += (int64_t)gridDim.x * (blockDim.x >> 6)) {
+    const int64_t f = o / (S * B), s = (o / B) % S, b = o % B;
+    const int64_t i = s * (F * B) + f * B + b;
+    const int64_t src = in_offsets[i] * W8, len = (in_offsets[i + 1] - in_offsets[i]) * W8, dst = out_offsets[o] * W8;
+    for (int64_t k = lane; k < len; k += 64) out_keys[dst + k] = in_keys[src + k];
+  }
+}
+// Same permutation for long bags (a few bags of many rows: the dedup'd exchange of sharded.py): blockIdx.y
+// walks the bags, the blocks of one grid row share a bag.
+__global__ void __launch_bounds__(256)
+permute_long_bags_kernel(int64_t S, int64_t F, int64_t B, int64_t W8, const int64_t* __restrict__ in_offsets,
+                         const int64_t* __restrict__ out_offsets, const uint64_t* __restrict__ in_keys,
+                         uint64_t* __restrict__ out_keys) {
+  const int64_t nb = S * F * B;
+  for (int64_t o = blockIdx.y; o < nb; o += gridDim.y) {
+    const int64_t f = o / (S * B), s = (o / B) % S, b = o % B;
+    const int64_t i = s * (F * B) + f * B + b;
+    const int64_t src = in_offsets[i] * W8, len = (in_offsets[i + 1] - in_offsets[i]) * W8, dst = out_offsets[o] * W8;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < len; k += (int64_t)gridDim.x * 256)
+      out_keys[dst + k] = in_keys[src + k];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+permute_lengths_kernel(int64_t S, int64_t F, int64_t B, const int64_t* __restrict__ in_lengths, int64_t* __restrict__ out_lengths) {
+  const int64_t nb = S * F * B;
+  for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < nb; o += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t f = o / (S * B), s = (o / B) % S, b = o % B;
+    out_lengths[o] = in_lengths[s * (F * B) + f * B + b];
+  }
+}
+
 // exclusive scan of int64 lengths -> offsets (single block; W*F*B is small relative to the keys)
 __global__ void __launch_bounds__(1024) scan_i64_kernel(const int64_t* __restrict__ in, int64_t n, int64_t* __restrict__ out) {
   __shared__ int64_t s_w[17];
@@ -750,6 +791,38 @@ int mi355_group_by_unique(const int64_t* reverse_indices, int64_t n, const int64
                      hot, hot_workspace != nullptr);
   if (n > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, reverse_indices, n, offsets,
                                 num_bags, ptr, cursor, csr_src, hot, hot_workspace != nullptr);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int mi355_permute_lengths(int64_t num_sources, int64_t num_features, int64_t batch_size, const int64_t* in_lengths,
+                          int64_t* out_lengths, hipStream_t stream) {
+  const int64_t nb = num_sources * num_features * batch_size;
+  if (nb == 0) return MI355_OK;
+  hipLaunchKernelGGL(permute_lengths_kernel, dim3(grid_for(nb, 256)), dim3(256), 0, stream, num_sources, num_features, batch_size,
+                     in_lengths, out_lengths);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int mi355_permute_bags(int64_t num_sources, int64_t num_features, int64_t batch_size, int64_t elem_bytes,
+                       int64_t num_elements, const int64_t* in_offsets, const int64_t* out_offsets, const void* in_keys,
+                       void* out_keys, hipStream_t stream) {
+  const int64_t nb = num_sources * num_features * batch_size;
+  MI355_CHECK_ARG(elem_bytes > 0 && elem_bytes % 8 == 0, "element size must be a multiple of 8 bytes");
+  if (nb == 0 || num_elements == 0) return MI355_OK;
+  const int64_t words_per_bag = num_elements * (elem_bytes / 8) / nb;
+  if (words_per_bag > 512) {
+    const int64_t gx = std::min<int64_t>((words_per_bag + 1023) / 1024, 256);
+    const int64_t gy = std::min<int64_t>(nb, 65535);
+    hipLaunchKernelGGL(permute_long_bags_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, stream, num_sources,
+                       num_features, batch_size, elem_bytes / 8, in_offsets, out_offsets, (const uint64_t*)in_keys,
+                       (uint64_t*)out_keys);
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+  }
+  hipLaunchKernelGGL(permute_bags_kernel, dim3(grid_for(nb, 4, 1 << 16)), dim3(256), 0, stream, num_sources, num_features, batch_size,
+                     elem_bytes / 8, in_offsets, out_offsets, (const uint64_t*)in_keys, (uint64_t*)out_keys);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }

@@ -381,6 +381,19 @@ init_rows_kernel(InitArgs a, int64_t n, const int64_t* __restrict__ n_dev, const
   }
 }
 
+// out[r, :] = sum_c in[c, r, :] (fp32 in, any out dtype): local reduction of the partial pooled sums that
+// arrive from the W shards (the reduce half of the pooled output dist: TorchRec reduce-scatter in the
+// reference, all-to-all + this sum here because xGMI is a point-to-point mesh).
+template <int DDT>
+__global__ void __launch_bounds__(256)
+sum_chunks_kernel(const float* __restrict__ in, int64_t chunks, int64_t n, void* out) {
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t c = 0; c < chunks; ++c) add4(acc, *reinterpret_cast<const float4*>(in + c * n + i));
+    st4<DDT>(out, i, acc);
+  }
+}
+
 }  // namespace mi355
 
 using namespace mi355;
@@ -506,6 +519,17 @@ int mi355_flat_table_copy(int is_load, int region, int64_t n, const int64_t* n_d
     else
       hipLaunchKernelGGL((flat_table_copy_kernel<DT, false>), dim3(grid), dim3(256), 0, stream, region, n, n_dev, dense, dense_dim,
                          dense_stride, indices, table_ids, scalar_table_id, table_ptrs, table_value_dims, table_emb_dims, max_emb_dim);
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+  });
+}
+
+int mi355_sum_chunks(const float* in, int64_t chunks, int64_t numel_per_chunk, void* out, int out_dtype, hipStream_t stream) {
+  MI355_CHECK_ARG(numel_per_chunk % 4 == 0, "chunk size must be a multiple of 4 elements");
+  if (numel_per_chunk == 0) return MI355_OK;
+  return MI355_DISPATCH_DTYPE(out_dtype, Dd, [&] {
+    hipLaunchKernelGGL((sum_chunks_kernel<Dd>), dim3(grid_for(numel_per_chunk, 1024)), dim3(256), 0, stream, in, chunks,
+                       numel_per_chunk, out);
     MI355_LAUNCH_CHECK();
     return MI355_OK;
   });

@@ -1,0 +1,180 @@
+"""Row-wise input dist: key -> owning rank bucketize, then the all-to-all(v) of lengths and keys.
+
+Mirror of the reference's `dynamicemb/input_dist.py` (bucketize_kjt_before_all2all :80-173,
+RwSparseFeaturesDist :199-285) plus the piece of TorchRec it calls (KJTAllToAll: lengths all-to-all,
+values all-to-all-v, recat to feature-major -- third party, not under /root/reference; its contract is
+restated from the call site and from SURVEY.md 8(e)).
+
+There is no TorchRec here, so a jagged batch is the plain pair (lengths [F*B] feature-major, values).
+The collectives are `torch.distributed` (RCCL on the GPU, gloo in the CPU tests).  All compute around
+them (bucketize, bag permutation) goes through an `ops` backend: `HipOps` (the C ABI) in production;
+the CPU tests inject a numpy backend built on oracle/ -- this module itself never touches oracle/.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+DIST_TYPES = {"continuous": 0, "roundrobin": 1, "hash_roundrobin": 2}
+
+
+class HipOps:
+    """Compute backend of the sharded path: every method is one or two C-ABI launches."""
+
+    def bucketize(self, lengths, values, block_sizes, world, sequence, dist_types):
+        import dynamicemb_extensions as ext
+
+        nl, nv, _, _, perm = ext.block_bucketize_sparse_features(
+            lengths, values, bucketize_pos=False, sequence=sequence, block_sizes=block_sizes, my_size=world,
+            dist_type_per_feature=dist_types)
+        return nl, nv, perm
+
+    def permute_lengths(self, S, F, B, lengths):
+        from mi355_native import check, lib, ptr, stream
+
+        if S == 1 or F == 1:
+            return lengths  # (s, f, b) and (f, s, b) are the same order
+        out = torch.empty_like(lengths)
+        check(lib().mi355_permute_lengths(S, F, B, ptr(lengths), ptr(out), stream()), "permute_lengths")
+        return out
+
+    def permute_bags(self, S, F, B, in_offsets, out_offsets, data):
+        from mi355_native import check, lib, ptr, stream
+
+        if S == 1 or F == 1:
+            return data
+        out = torch.empty_like(data)
+        eb = data.element_size() * (data.size(1) if data.dim() == 2 else 1)
+        check(lib().mi355_permute_bags(S, F, B, eb, data.size(0), ptr(in_offsets), ptr(out_offsets), ptr(data), ptr(out),
+                                       stream()), "permute_bags")
+        return out
+
+    def sum_chunks(self, x, out_dtype):
+        from mi355_native import check, dt, lib, ptr, stream
+
+        out = torch.empty(x.shape[1:], dtype=out_dtype, device=x.device)
+        check(lib().mi355_sum_chunks(ptr(x), x.size(0), out.numel(), ptr(out), dt(out_dtype), stream()), "sum_chunks")
+        return out
+
+    def gather_rows(self, src, index):
+        import dynamicemb_extensions as ext
+
+        out = torch.empty(index.numel(), src.size(1), dtype=src.dtype, device=src.device)
+        if index.numel():
+            ext.gather_embedding(src, out, index)
+        return out
+
+    # ---- local dedup / pooling around the exchange (rows-back pooled mode, sharded.py) ----
+    def unique(self, keys, offsets, feature_offsets):
+        """-> (unique_keys [Nt] (first Nu valid), reverse [Nt], unique_offsets [T+1]) per-table dedup."""
+        import dynamicemb_extensions as ext
+
+        T = feature_offsets.numel() - 1
+        rng = ext.get_table_range(offsets, feature_offsets)
+        _, ukeys, rev, uoff, _ = ext.segmented_unique_cuda(keys, rng, T)
+        return ukeys, rev, uoff
+
+    def pool(self, rows, reverse, offsets, batch_size, combiner, total_D, D_offsets, max_D, out_dtype):
+        import dynamicemb_extensions as ext
+
+        out = torch.empty(batch_size, total_D, dtype=out_dtype, device=rows.device)
+        ext.gather_embedding_pooled(rows, out, reverse, offsets, combiner, total_D, batch_size, D_offsets=D_offsets,
+                                    max_D=max_D)
+        return out
+
+    def reduce_grads(self, reverse, grads, num_unique, batch_size, dim, offsets, D_offsets, combiner):
+        import dynamicemb_extensions as ext
+
+        return ext.reduce_grads(reverse, grads, num_unique, batch_size, dim, offsets=offsets, D_offsets=D_offsets,
+                                combiner=combiner, out_dtype=torch.float32)
+
+
+def exclusive_offsets(lengths: torch.Tensor) -> torch.Tensor:
+    off = torch.zeros(lengths.numel() + 1, dtype=torch.int64, device=lengths.device)
+    torch.cumsum(lengths, 0, out=off[1:])
+    return off
+
+
+@dataclass
+class ShardedKeys:
+    """What a rank holds after the input dist: the keys it owns, for the GLOBAL batch."""
+    lengths: torch.Tensor          # [F * W * B] feature-major, batch index = src_rank * B + b
+    offsets: torch.Tensor          # [F * W * B + 1]
+    values: torch.Tensor           # [n_recv]
+    recv_offsets: torch.Tensor     # [W * F * B + 1] offsets of the stream as received, (src, f, b) order
+    send_splits: List[int]         # keys sent to each rank
+    recv_splits: List[int]         # keys received from each rank
+    unbucketize_permute: Optional[torch.Tensor]  # [n_local] (sequence mode)
+    batch_size: int                # local B
+    num_features: int
+
+
+def bucketize_before_all2all(lengths, values, num_buckets, block_sizes, output_permute=False,
+                             dist_type_per_feature: Optional[Sequence[str]] = None, ops=None):
+    """bucketize_kjt_before_all2all (input_dist.py:80-173): -> (new_lengths [W*F*B], new_values, permute)."""
+    ops = ops or HipOps()
+    F = block_sizes.numel()
+    if dist_type_per_feature is None:
+        dist_type_per_feature = ["continuous"] * F
+    codes = []
+    for d in dist_type_per_feature:
+        if d not in DIST_TYPES:
+            raise ValueError("Not support dist type of ", d)
+        codes.append(DIST_TYPES[d])
+    dist_t = torch.tensor(codes, dtype=torch.int32, device=values.device)
+    return ops.bucketize(lengths.view(-1), values, block_sizes.to(values.device), num_buckets, output_permute, dist_t)
+
+
+class RwSparseFeaturesDist:
+    """RwSparseFeaturesDist (input_dist.py:199-285) + KJTAllToAll, for equal local batch sizes."""
+
+    def __init__(self, pg, num_features: int, feature_hash_sizes: List[int], device=None, is_sequence: bool = False,
+                 dist_type_per_feature: Optional[Sequence[str]] = None, ops=None):
+        self._pg = pg
+        self._world_size = dist.get_world_size(pg)
+        self._num_features = num_features
+        self._block_sizes = torch.tensor([(h + self._world_size - 1) // self._world_size for h in feature_hash_sizes],
+                                         dtype=torch.int64, device=device)
+        self._is_sequence = is_sequence
+        self._dist_type_per_feature = list(dist_type_per_feature) if dist_type_per_feature is not None \
+            else ["roundrobin"] * num_features
+        self._ops = ops or HipOps()
+        self.unbucketize_permute_tensor = None
+
+    def forward(self, lengths: torch.Tensor, values: torch.Tensor, collapse_batch: bool = False) -> ShardedKeys:
+        """collapse_batch: the batch dimension is only a local chunking of per-feature key lists (it may differ
+        between ranks); the exchange then carries one bag per (rank, feature)."""
+        W, F, ops = self._world_size, self._num_features, self._ops
+        lengths = lengths.view(-1).to(torch.int64)
+        assert lengths.numel() % F == 0
+        B = lengths.numel() // F
+        new_lengths, new_values, perm = bucketize_before_all2all(
+            lengths, values, W, self._block_sizes, self._is_sequence, self._dist_type_per_feature, ops)
+        self.unbucketize_permute_tensor = perm
+        new_lengths = new_lengths.to(torch.int64)
+        if collapse_batch:
+            new_lengths = new_lengths.view(W * F, B).sum(1)
+            B = 1
+        # lengths all-to-all: equal splits of F*B per peer
+        recv_lengths = torch.empty_like(new_lengths)
+        dist.all_to_all_single(recv_lengths, new_lengths, group=self._pg)
+        # key counts per peer (the one host read of the step, as in KJTAllToAll)
+        splits = torch.stack([new_lengths.view(W, F * B).sum(1), recv_lengths.view(W, F * B).sum(1)]).cpu()
+        send_splits, recv_splits = splits[0].tolist(), splits[1].tolist()
+        n_send = sum(send_splits)  # == values.numel() unless the caller passed a padded key buffer
+        new_values = new_values[:n_send]
+        if perm is not None:
+            perm = perm[:n_send]
+        recv_values = torch.empty(sum(recv_splits), dtype=new_values.dtype, device=new_values.device)
+        dist.all_to_all_single(recv_values, new_values, recv_splits, send_splits, group=self._pg)
+        # recat (src, f, b) -> (f, src, b)
+        recv_offsets = exclusive_offsets(recv_lengths)
+        fm_lengths = ops.permute_lengths(W, F, B, recv_lengths)
+        fm_offsets = exclusive_offsets(fm_lengths)
+        fm_values = ops.permute_bags(W, F, B, recv_offsets, fm_offsets, recv_values)
+        return ShardedKeys(fm_lengths, fm_offsets, fm_values, recv_offsets, send_splits, recv_splits, perm, B, F)
+
+    __call__ = forward

@@ -1,0 +1,214 @@
+"""Row-wise (model-parallel) sharded DynamicEmb lookup: one process per GPU, one exchange each way.
+
+Mirror of what TorchRec's RwPooledEmbeddingSharding / RwSequenceEmbeddingSharding do around the
+reference's compute kernel (planner/rw_sharding.py:85-158 sequence, :191-261 pooled; output dists are
+third-party TorchRec, restated from SURVEY.md 8(e)):
+
+  input dist   bucketize -> all-to-all lengths -> all-to-all-v keys -> recat         (input_dist.py)
+  lookup       the full single-GPU path on the received keys (BatchedDynamicEmbeddingTablesV2)
+  output dist  pooled:   partial sums for the GLOBAL batch [W*B, total_D] fp32 -> all-to-all of the W
+                         [B, total_D] blocks + one local sum kernel.  The reference uses a ring
+                         reduce-scatter; on MI355X every GPU pair owns an xGMI link, so the all-to-all
+                         moves (W-1)/W of the data over 7 links in parallel where a ring is bound by one.
+               sequence: all-to-all-v of rows back + unbucketize_permute gather
+  backward     pooled: all-gather of output grads; sequence: all-to-all-v of row grads; then the local
+               fused backward (reduce + optimizer) on each shard.  No cross-GPU atomics anywhere: the
+               hash tables are per-rank and independent.
+
+The local lookup and all element work are injected (`local`, `ops`) so the routing/collective logic runs
+unchanged over gloo on CPU in the tests, with an oracle-backed local lookup injected by the test.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from .input_dist import HipOps, RwSparseFeaturesDist, ShardedKeys
+
+
+@dataclass
+class _ShardedCtx:
+    keys: ShardedKeys
+    local_ctx: object
+    n_local: int
+
+
+class RowWiseShardedLookup:
+    """`local` must provide
+         forward(values, offsets, train) -> (out, ctx)   out: pooled [W*B, total_D] fp32 or rows [n, D]
+         backward(ctx, grads) -> None
+       (BatchedDynamicEmbeddingTablesV2._forward_impl/_backward_impl have exactly this shape)."""
+
+    def __init__(self, local, num_features: int, feature_hash_sizes: List[int], pooled: bool, pg=None,
+                 device=None, out_dtype=torch.float32, dist_type_per_feature: Optional[Sequence[str]] = None,
+                 ops=None):
+        self.pg = pg if pg is not None else dist.group.WORLD
+        self.world = dist.get_world_size(self.pg)
+        self.rank = dist.get_rank(self.pg)
+        self.local = local
+        self.pooled = pooled
+        self.out_dtype = out_dtype
+        self.ops = ops or HipOps()
+        self.input_dist = RwSparseFeaturesDist(self.pg, num_features, feature_hash_sizes, device,
+                                               is_sequence=not pooled, dist_type_per_feature=dist_type_per_feature,
+                                               ops=self.ops)
+
+    # ------------------------------------------------------------------------------ forward
+    def forward(self, values: torch.Tensor, offsets: torch.Tensor, train: bool = True, collapse_batch: bool = False):
+        lengths = offsets[1:] - offsets[:-1]
+        sk = self.input_dist(lengths, values, collapse_batch)
+        out_local, lctx = self.local.forward(sk.values, sk.offsets, train)
+        W, B = self.world, sk.batch_size
+        if self.pooled:
+            # out_local [W*B, total_D] fp32: block p belongs to rank p's samples
+            assert out_local.dtype == torch.float32 and out_local.size(0) == W * B
+            recv = torch.empty_like(out_local)
+            dist.all_to_all_single(recv, out_local.contiguous(), group=self.pg)
+            out = self.ops.sum_chunks(recv.view(W, B * out_local.size(1)), self.out_dtype).view(B, out_local.size(1))
+        else:
+            D = out_local.size(1)
+            # rows come out in (f, src, b) order; send them back in the order they arrived: (src, f, b)
+            rows_sfb = self.ops.permute_bags(sk.num_features, W, B, sk.offsets, sk.recv_offsets, out_local.contiguous())
+            back = torch.empty(sum(sk.send_splits), D, dtype=out_local.dtype, device=out_local.device)
+            dist.all_to_all_single(back, rows_sfb, [s for s in sk.send_splits], [r for r in sk.recv_splits],
+                                   group=self.pg)
+            out = self.ops.gather_rows(back, sk.unbucketize_permute)
+            if out.dtype != self.out_dtype:
+                out = out.to(self.out_dtype)
+        return out, _ShardedCtx(sk, lctx, sum(sk.send_splits))
+
+    # ------------------------------------------------------------------------------ backward
+    def backward(self, ctx: _ShardedCtx, grads: torch.Tensor) -> None:
+        sk, W, B = ctx.keys, self.world, ctx.keys.batch_size
+        grads = grads.contiguous()
+        if self.pooled:
+            g_all = torch.empty(W * grads.size(0), grads.size(1), dtype=grads.dtype, device=grads.device)
+            dist.all_gather_into_tensor(g_all, grads, group=self.pg)
+        else:
+            n = ctx.n_local
+            perm = sk.unbucketize_permute
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(n, dtype=perm.dtype, device=perm.device)
+            g_send = self.ops.gather_rows(grads, inv)  # bucketized order
+            g_recv = torch.empty(sum(sk.recv_splits), grads.size(1), dtype=grads.dtype, device=grads.device)
+            dist.all_to_all_single(g_recv, g_send, [r for r in sk.recv_splits], [s for s in sk.send_splits],
+                                   group=self.pg)
+            g_all = self.ops.permute_bags(W, sk.num_features, B, sk.recv_offsets, sk.offsets, g_recv)
+        self.local.backward(ctx.local_ctx, g_all)
+
+
+class RowWiseShardedPooledRows:
+    """Pooled lookup that exchanges ROWS, not partial sums: dedup locally, run the sequence exchange on the
+    unique keys, pool locally from the returned rows.  Per rank and step it moves Nu_local*D elements each way
+    where the partial-sum dist moves W*B*total_D -- smaller whenever bags are short relative to W (C2 at W=8:
+    162 K rows vs 524 K), and the pooled result is bit-identical to the single-GPU one (same fp32 rows summed in
+    the same bag order).  The reference offers the same idea for sequence embeddings (`use_index_dedup`,
+    shard/embedding.py:183-275); for pooled EBC it always reduce-scatters.
+
+    The unique keys of table t are cut into pseudo-bags of `chunk` keys so that the bag-oriented bucketize /
+    recat machinery (wave per bag) sees many small bags instead of T huge ones."""
+
+    def __init__(self, local_seq, feature_table_map: List[int], table_hash_sizes: List[int], dims: List[int],
+                 combiner: int = 0, pg=None, device=None, out_dtype=torch.float32,
+                 dist_type_per_table: Optional[Sequence[str]] = None, ops=None, chunk: int = 64):
+        T = len(table_hash_sizes)
+        assert all(d == dims[0] for d in dims), "rows-back pooled mode needs one embedding dim (use the partial-sum dist)"
+        self.dim = dims[0]
+        self.F = len(feature_table_map)
+        self.T = T
+        self.combiner = combiner
+        self.chunk = chunk
+        self.out_dtype = out_dtype
+        self.ops = ops or HipOps()
+        tof, old = [], -1
+        for i, t in enumerate(feature_table_map):
+            assert t >= old, "features must be grouped by table"
+            if t != old:
+                tof.append(i)
+                old = t
+        tof.append(self.F)
+        self.feature_offsets = torch.tensor(tof, dtype=torch.int64, device=device)
+        self.inner = RowWiseShardedLookup(local_seq, T, table_hash_sizes, pooled=False, pg=pg, device=device,
+                                          out_dtype=torch.float32, dist_type_per_feature=dist_type_per_table,
+                                          ops=self.ops)
+        self.world, self.rank = self.inner.world, self.inner.rank
+
+    def forward(self, values: torch.Tensor, offsets: torch.Tensor, train: bool = True):
+        B = (offsets.numel() - 1) // self.F
+        ukeys, rev, uoff = self.ops.unique(values, offsets, self.feature_offsets)
+        nchunk = max(1, (values.numel() + self.chunk - 1) // self.chunk)
+        counts = (uoff[1:] - uoff[:-1]).view(self.T, 1)
+        steps = torch.arange(nchunk, dtype=torch.int64, device=values.device).view(1, nchunk) * self.chunk
+        lengths = (counts - steps).clamp_(0, self.chunk).view(-1)
+        u_offsets = torch.zeros(lengths.numel() + 1, dtype=torch.int64, device=values.device)
+        torch.cumsum(lengths, 0, out=u_offsets[1:])
+        rows, ictx = self.inner.forward(ukeys, u_offsets, train, collapse_batch=True)  # [Nu, D] fp32
+        out = self.ops.pool(rows, rev, offsets, B, self.combiner, self.F * self.dim, None, self.dim, self.out_dtype)
+        return out, (ictx, rev, offsets, B, rows.size(0))
+
+    def backward(self, ctx, grads: torch.Tensor) -> None:
+        ictx, rev, offsets, B, nu = ctx
+        ug = self.ops.reduce_grads(rev, grads.contiguous(), nu, B, self.dim, offsets, None, self.combiner)
+        self.inner.backward(ictx, ug)
+
+
+class _ModuleLocal:
+    """Adapter: BatchedDynamicEmbeddingTablesV2 as the `local` of RowWiseShardedLookup."""
+
+    def __init__(self, module):
+        self.module = module
+
+    def forward(self, values, offsets, train):
+        return self.module._forward_impl(values, offsets, train=train)
+
+    def backward(self, ctx, grads):
+        self.module._backward_impl(ctx, grads)
+
+
+def shard_capacity(rows: int, world: int, bucket_capacity: int = 128) -> int:
+    """Per-rank table capacity: ceil(N / W) aligned up to the bucket capacity."""
+    per = (rows + world - 1) // world
+    return (per + bucket_capacity - 1) // bucket_capacity * bucket_capacity
+
+
+class ShardedPooledLookup:
+    """bench.py's N>1 path: one `rows` x `dim` table, row-wise sharded over the world, SUM pooling, SGD.
+    Every rank holds ceil(rows/W) rows in its own HBM.  mode: "partial" = the reference's dist (partial sums
+    for the global batch), "rows" = dedup + row exchange + local pooling, "auto" = whichever moves less."""
+
+    def __init__(self, rows: int, dim: int, device, world: int, rank: int, lr: float = 0.1,
+                 out_dtype=torch.bfloat16, dist_type: str = "roundrobin", mode: str = "auto",
+                 keys_per_step: Optional[int] = None, batch: Optional[int] = None):
+        from .batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
+        from .dynamicemb_config import (DynamicEmbInitializerArgs, DynamicEmbInitializerMode, DynamicEmbPoolingMode,
+                                        DynamicEmbScoreStrategy, DynamicEmbTableOptions, EmbOptimType)
+
+        opt = DynamicEmbTableOptions(
+            dim=dim, max_capacity=shard_capacity(rows, world), index_type=torch.int64, embedding_dtype=torch.float32,
+            score_strategy=DynamicEmbScoreStrategy.TIMESTAMP,
+            initializer_args=DynamicEmbInitializerArgs(mode=DynamicEmbInitializerMode.UNIFORM, lower=-0.01, upper=0.01))
+        if mode == "auto":
+            # rows-back moves ~Nu ~ 0.5 Nt rows, partial sums move W*B rows (both D wide)
+            mode = "rows" if (keys_per_step and batch and 0.5 * keys_per_step < world * batch) else "partial"
+        self.mode = mode
+        module = BatchedDynamicEmbeddingTablesV2(
+            [opt], pooling_mode=DynamicEmbPoolingMode.SUM if mode == "partial" else DynamicEmbPoolingMode.NONE,
+            output_dtype=torch.float32, device=device, optimizer=EmbOptimType.SGD, learning_rate=lr)
+        module.train()
+        self.module = module
+        if mode == "partial":
+            self.impl = RowWiseShardedLookup(_ModuleLocal(module), 1, [rows], pooled=True, device=device,
+                                             out_dtype=out_dtype, dist_type_per_feature=[dist_type])
+        else:
+            self.impl = RowWiseShardedPooledRows(_ModuleLocal(module), [0], [rows], [dim], combiner=0, device=device,
+                                                 out_dtype=out_dtype, dist_type_per_table=[dist_type])
+        assert self.impl.world == world and self.impl.rank == rank
+
+    def forward(self, values, offsets, train: bool = True):
+        return self.impl.forward(values, offsets, train)
+
+    def backward(self, ctx, grads):
+        self.impl.backward(ctx, grads)

@@ -527,9 +527,11 @@ def backward_fused(ptr_t, csr, num_keys, num_unique_max, grads, batch_size, dim,
 
 
 def reduce_grads(reverse_indices, grads, num_unique, batch_size, out_dim, offsets=None, D_offsets=None, combiner=-1,
-                 total_D=0):
-    """reduce_grads (dynamic_emb_op.cu:159-285) -> unique_grads [num_unique, out_dim] in the grad dtype."""
-    unique_grads = torch.empty(num_unique, out_dim, dtype=grads.dtype, device=grads.device)
+                 total_D=0, out_dtype=None):
+    """reduce_grads (dynamic_emb_op.cu:159-285) -> unique_grads [num_unique, out_dim] in the grad dtype
+    (`out_dtype`, an extension, keeps the fp32 sums -- used by the sharded backward)."""
+    out_dtype = out_dtype or grads.dtype
+    unique_grads = torch.empty(num_unique, out_dim, dtype=out_dtype, device=grads.device)
     n = reverse_indices.numel()
     if n == 0 or batch_size == 0 or num_unique == 0:
         return unique_grads
@@ -537,7 +539,7 @@ def reduce_grads(reverse_indices, grads, num_unique, batch_size, out_dim, offset
     ptr_t, csr, hot = group_by_unique(reverse_indices, num_unique, offsets if pooled else None, dim=out_dim)
     backward_fused(ptr_t, csr, n, num_unique, grads.contiguous(), batch_size, out_dim,
                    combiner if pooled else -1, offsets if pooled else None, D_offsets if pooled else None,
-                   opt_kind=0, out=unique_grads, round_grad=False, hot=hot)
+                   weight_dtype=out_dtype, opt_kind=0, out=unique_grads, round_grad=False, hot=hot)
     return unique_grads
 
 

@@ -46,6 +46,9 @@ _SIGS = {
     "mi355_flagged_compact": [c_p, c_i64, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_i64, c_p],
     "mi355_group_by_unique": [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_p],
     "mi355_hot_rows_workspace_bytes": [c_i64, c_i64],
+    "mi355_permute_lengths": [c_i64, c_i64, c_i64, c_p, c_p, c_p],
+    "mi355_permute_bags": [c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p],
+    "mi355_sum_chunks": [c_p, c_i64, c_i64, c_p, c_int, c_p],
     "mi355_block_bucketize": [c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "mi355_gather_pooled": [c_p, c_i64, c_p, c_int, c_p, c_i64, c_p, c_i64, c_i64, c_int, c_i64, c_p, c_i64, c_p, c_int,
                             c_int, c_p],

@@ -1,0 +1,297 @@
+"""World-size-2 (and 3) gloo tests of the row-wise sharded lookup's routing / collective logic on CPU.
+
+The product code under test is dynamicemb/input_dist.py + dynamicemb/sharded.py (bucketize -> all-to-all
+lengths/keys -> recat -> local lookup -> output dist, and the backward).  There is no GPU here, so the
+element work is injected: a numpy `ops` backend built on the oracle's block_bucketize, and a dict-backed
+local table.  Expected results come from ONE process doing the global batch on one dict table.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (os.path.join(ROOT, "recsys-examples_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+D = 8
+LR = 0.5
+
+
+def init_row(key: int, table: int = 0) -> np.ndarray:
+    return ((np.arange(D, dtype=np.float32) + 1.0 + table) * np.float32((key % 97) + 1) * np.float32(0.01)).astype(np.float32)
+
+
+class NumpyOps:
+    """CPU stand-in for HipOps (tests only): same contracts, oracle/numpy inside."""
+
+    def bucketize(self, lengths, values, block_sizes, world, sequence, dist_types):
+        from oracle import oracle as orc
+
+        ln = lengths.numpy().astype(np.int64)
+        off = np.zeros(ln.size + 1, np.int64)
+        off[1:] = np.cumsum(ln)
+        F = block_sizes.numel()
+        B = ln.size // F
+        dts = set(dist_types.tolist())
+        assert len(dts) == 1
+        nl, _, ni, perm = orc.block_bucketize(off, values.numpy(), world, B, block_sizes.numpy(), dts.pop())
+        return (torch.from_numpy(nl), torch.from_numpy(ni.astype(np.int64)),
+                torch.from_numpy(perm) if sequence else None)
+
+    def permute_lengths(self, S, F, B, lengths):
+        return lengths.view(S, F, B).permute(1, 0, 2).contiguous().view(-1)
+
+    def permute_bags(self, S, F, B, in_offsets, out_offsets, data):
+        out = torch.empty_like(data)
+        io, oo = in_offsets.tolist(), out_offsets.tolist()
+        for f in range(F):
+            for s in range(S):
+                for b in range(B):
+                    i = s * F * B + f * B + b
+                    o = f * S * B + s * B + b
+                    n = io[i + 1] - io[i]
+                    assert oo[o + 1] - oo[o] == n
+                    out[oo[o]:oo[o] + n] = data[io[i]:io[i] + n]
+        return out
+
+    def sum_chunks(self, x, out_dtype):
+        return x.sum(0).to(out_dtype)
+
+    def gather_rows(self, src, index):
+        return src[index]
+
+    def unique(self, keys, offsets, feature_offsets):
+        from oracle import oracle as orc
+
+        rng = orc.get_table_range(offsets.numpy(), feature_offsets.numpy())
+        uk, rev, uoff, _ = orc.segmented_unique(keys.numpy(), rng)
+        padded = np.full(keys.numel(), -7, np.int64)  # padded like the device buffer: only [:Nu] is valid
+        padded[:uk.size] = uk.astype(np.int64)
+        return torch.from_numpy(padded), torch.from_numpy(rev), torch.from_numpy(uoff)
+
+    def pool(self, rows, reverse, offsets, batch_size, combiner, total_D, D_offsets, max_D, out_dtype):
+        from oracle import oracle as orc
+
+        out = orc.gather_pooled(rows.numpy(), reverse.numpy(), offsets.numpy(), batch_size, combiner)
+        return torch.from_numpy(out).to(out_dtype)
+
+    def reduce_grads(self, reverse, grads, num_unique, batch_size, dim, offsets, D_offsets, combiner):
+        from oracle import oracle as orc
+
+        return torch.from_numpy(orc.reduce_grads(reverse.numpy(), grads.numpy(), num_unique, batch_size,
+                                                 offsets.numpy(), None, combiner))
+
+
+class DictLocal:
+    """A dict-backed embedding shard, one table per feature: rows[(table, key)], insert-on-miss with init_row,
+    SUM pooling or sequence rows, SGD."""
+
+    def __init__(self, num_features, pooled, key_offset=0):
+        # "continuous" routing re-bases keys to the shard (new_idx = idx - rank*block); the other modes send
+        # the key unchanged (sparse_block_bucketize_features.cu:330-341)
+        self.key_offset = key_offset
+        self.rows = {}
+        self.F = num_features
+        self.pooled = pooled
+
+    def _tagged(self, values, off):
+        nb = len(off) - 1
+        B = nb // self.F
+        keys = []
+        for bag in range(nb):
+            t = bag // B if B else 0
+            keys += [(t, k + self.key_offset) for k in values[off[bag]:off[bag + 1]]]
+        return keys, B
+
+    def forward(self, values, offsets, train):
+        off = offsets.tolist()
+        keys, B = self._tagged(values.tolist(), off)
+        for tk in keys:
+            if tk not in self.rows:
+                self.rows[tk] = init_row(tk[1], tk[0])
+        if self.pooled:
+            out = np.zeros((B, self.F * D), np.float32)
+            for f in range(self.F):
+                for b in range(B):
+                    bag = f * B + b
+                    for j in range(off[bag], off[bag + 1]):
+                        out[b, f * D:(f + 1) * D] += self.rows[keys[j]]
+        else:
+            out = np.stack([self.rows[k] for k in keys]) if keys else np.zeros((0, D), np.float32)
+        return torch.from_numpy(out), (keys, off, B)
+
+    def backward(self, ctx, grads):
+        keys, off, B = ctx
+        g = grads.float().numpy()
+        acc = {}
+        if self.pooled:
+            for f in range(self.F):
+                for b in range(B):
+                    bag = f * B + b
+                    for j in range(off[bag], off[bag + 1]):
+                        acc[keys[j]] = acc.get(keys[j], 0) + g[b, f * D:(f + 1) * D]
+        else:
+            for j, k in enumerate(keys):
+                acc[k] = acc.get(k, 0) + g[j]
+        for k, v in acc.items():
+            self.rows[k] = (self.rows[k] - np.float32(LR) * v).astype(np.float32)
+
+
+def make_batch(rank, F, B, seed, max_len=5, key_space=200):
+    rng = np.random.default_rng(seed * 100 + rank)
+    lens = rng.integers(0, max_len + 1, F * B)
+    if rank == 0:
+        lens[0] = 0  # an empty bag
+    off = np.zeros(F * B + 1, np.int64)
+    off[1:] = np.cumsum(lens)
+    keys = rng.integers(0, key_space, off[-1]).astype(np.int64)
+    return torch.from_numpy(keys), torch.from_numpy(off)
+
+
+def grads_for(rank, shape, seed):
+    rng = np.random.default_rng(seed * 7 + rank + 1000)
+    return torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, W, port, F, B, pooled, dist_type, steps, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    try:
+        from dynamicemb.sharded import RowWiseShardedLookup, RowWiseShardedPooledRows
+
+        blk = (200 + W - 1) // W
+        koff = rank * blk if dist_type == "continuous" else 0
+        if pooled == "rows":
+            # two features share table 0, the third has its own: T = 2 when F == 3, else one table per feature
+            ftm = [0, 0, 1] if F == 3 else list(range(F))
+            T = max(ftm) + 1
+            local = DictLocal(T, False, key_offset=koff)
+            sh = RowWiseShardedPooledRows(local, ftm, [200] * T, [D] * T, combiner=0, device="cpu",
+                                          out_dtype=torch.float32, dist_type_per_table=[dist_type] * T, ops=NumpyOps(),
+                                          chunk=4)
+        else:
+            local = DictLocal(F, pooled, key_offset=koff)
+            sh = RowWiseShardedLookup(local, F, [200] * F, pooled=pooled, device="cpu", out_dtype=torch.float32,
+                                      dist_type_per_feature=[dist_type] * F, ops=NumpyOps())
+        outs = []
+        for step in range(steps):
+            keys, off = make_batch(rank, F, B, step)
+            out, ctx = sh.forward(keys, off, True)
+            outs.append(out.numpy().copy())
+            sh.backward(ctx, grads_for(rank, tuple(out.shape), step))
+        q.put((rank, outs, dict(local.rows)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _ftm(F, pooled):
+    return ([0, 0, 1] if F == 3 else list(range(F))) if pooled == "rows" else list(range(F))
+
+
+def _expected(W, F, B, pooled, steps):
+    """One process, one set of tables, the global batch (rank r's samples are batch rows r*B..(r+1)*B)."""
+    ftm = _ftm(F, pooled)
+    rows = {}
+    outs = [[] for _ in range(W)]
+    for step in range(steps):
+        batches = [make_batch(r, F, B, step) for r in range(W)]
+        tagged = []
+        for r in range(W):
+            keys, off = batches[r][0].tolist(), batches[r][1].tolist()
+            tk = []
+            for bag in range(F * B):
+                tk += [(ftm[bag // B], k) for k in keys[off[bag]:off[bag + 1]]]
+            tagged.append(tk)
+            for x in tk:
+                rows.setdefault(x, init_row(x[1], x[0]))
+        acc = {}
+        for r in range(W):
+            keys, off = tagged[r], batches[r][1].tolist()
+            if pooled:
+                out = np.zeros((B, F * D), np.float32)
+                for f in range(F):
+                    for b in range(B):
+                        for j in range(off[f * B + b], off[f * B + b + 1]):
+                            out[b, f * D:(f + 1) * D] += rows[keys[j]]
+            else:
+                out = np.stack([rows[k] for k in keys]) if keys else np.zeros((0, D), np.float32)
+            outs[r].append(out)
+            g = grads_for(r, out.shape, step).numpy()
+            if pooled:
+                for f in range(F):
+                    for b in range(B):
+                        for j in range(off[f * B + b], off[f * B + b + 1]):
+                            acc[keys[j]] = acc.get(keys[j], 0) + g[b, f * D:(f + 1) * D]
+            else:
+                for j, k in enumerate(keys):
+                    acc[k] = acc.get(k, 0) + g[j]
+        for k, v in acc.items():
+            rows[k] = (rows[k] - np.float32(LR) * v).astype(np.float32)
+    return outs, rows
+
+
+def _owner(key, W, dist_type):
+    if dist_type == "roundrobin":
+        return key % W
+    if dist_type == "continuous":
+        return key // ((200 + W - 1) // W)
+    from oracle import oracle as orc
+
+    return orc.fmix64(key) % W
+
+
+@pytest.mark.parametrize("W,F,B,pooled,dist_type", [
+    (2, 2, 5, True, "roundrobin"),
+    (2, 3, 4, False, "roundrobin"),
+    (2, 1, 6, True, "hash_roundrobin"),
+    (2, 2, 3, False, "continuous"),
+    (3, 2, 4, True, "roundrobin"),
+    (2, 3, 6, "rows", "roundrobin"),
+    (2, 2, 5, "rows", "hash_roundrobin"),
+    (3, 3, 4, "rows", "continuous"),
+])
+def test_rowwise_sharded_matches_single_process(W, F, B, pooled, dist_type):
+    steps = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, W, port, F, B, pooled, dist_type, steps, q)) for r in range(W)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(W):
+        rank, outs, rows = q.get(timeout=120)
+        got[rank] = (outs, rows)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp_outs, exp_rows = _expected(W, F, B, pooled, steps)
+    seen = {}
+    for r in range(W):
+        outs, rows = got[r]
+        for step in range(steps):
+            np.testing.assert_allclose(outs[step], exp_outs[r][step], rtol=1e-5, atol=1e-6,
+                                       err_msg=f"rank {r} step {step}")
+        for k, v in rows.items():
+            assert _owner(k[1], W, dist_type) == r, f"key {k} landed on rank {r}"
+            assert k not in seen
+            seen[k] = v
+    assert set(seen) == set(exp_rows)
+    for k in exp_rows:
+        np.testing.assert_allclose(seen[k], exp_rows[k], rtol=1e-5, atol=1e-6)
