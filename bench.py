@@ -46,6 +46,12 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-hstu", action="store_true")
+    ap.add_argument("--hstu-batch", type=int, default=32)
+    ap.add_argument("--hstu-seqlen", type=int, default=512)
+    ap.add_argument("--hstu-heads", type=int, default=4)
+    ap.add_argument("--hstu-dim", type=int, default=256)
+    ap.add_argument("--hstu-reps", type=int, default=20)
     ap.add_argument("--force-sharded", action="store_true", help="run the row-wise sharded path even at N=1 (debug)")
     ap.add_argument("--shard-mode", default="auto", choices=["auto", "rows", "partial"])
     return ap.parse_args()
@@ -117,6 +123,61 @@ def cpu_baseline(args, batches_cpu):
             "sample": f"{iters - 1} batches of {args.batch} bags ({keys_done} keys) fwd+bwd+sparse SGD through "
                       f"torch.nn.EmbeddingBag(mode=sum) on a {args.rows}x{args.dim} fp32 host table; "
                       f"os.cpu_count()={os.cpu_count()}, table init {setup:.1f}s not timed"}
+
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+def hstu_flops(lengths, heads, dim, causal=True):
+    """The reference's FLOP model (examples/commons/utils/perf.py:697-740) without contexts/targets:
+    4*H*L^2*d for the two GEMMs, halved by causality; bwd = 2.5 x fwd (hstu_attn_kernel_benchmark.py:343-352)."""
+    fl = 0.0
+    for L in lengths:
+        fl += 4.0 * heads * L * L * dim - (2.0 * heads * L * L * dim if causal else 0.0)
+    return fl
+
+
+def hstu_section(args, device, world, dist=None):
+    """Path B on the C3 attention shape (B=32, L=512, H=4, d=256, bf16, causal): fwd + bwd kernels timed with
+    HIP events on the launch stream.  Replicas only under N > 1 (attention is per-sequence data parallel)."""
+    from hstu import hstu_varlen_bwd, hstu_varlen_fwd
+
+    Bq, L, H, d = args.hstu_batch, args.hstu_seqlen, args.hstu_heads, args.hstu_dim
+    T = Bq * L
+    cu = torch.arange(0, T + 1, L, dtype=torch.int32, device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(7)
+    q, k, v, do = (torch.empty(T, H, d, device=device).uniform_(-1, 1, generator=g).bfloat16() for _ in range(4))
+    alpha = 1.0 / d ** 0.5
+
+    def timeit(fn, reps):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    tf = timeit(lambda: hstu_varlen_fwd(q, k, v, cu, L, L, None, None, 1, True, alpha), args.hstu_reps)
+    tb = timeit(lambda: hstu_varlen_bwd(do, q, k, v, cu, L, L, None, None, 1, True, alpha), args.hstu_reps)
+    if dist is not None:
+        t = torch.tensor([tf, tb], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tf, tb = float(t[0]), float(t[1])
+    fl = hstu_flops([L] * Bq, H, d)
+    tot = (fl + 2.5 * fl) / (tf + tb) / 1e9
+    return {"metric": "HSTU seq-tokens/sec (hstu_attn_varlen fwd+bwd kernels)", "value": world * T / (tf + tb) * 1e3,
+            "unit": "tokens/s", "fwd_ms": tf, "bwd_ms": tb, "fwd_TFLOPs": fl / tf / 1e9, "bwd_TFLOPs": 2.5 * fl / tb / 1e9,
+            "dtype": "bf16 operands, f32 accumulate", "scaling": "replicas only",
+            "roofline": {"bound": "mfma", "achieved": tot, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tot / MFMA_BF16_PEAK_TFLOPS},
+            "config": {"workload": f"C3 attention: batch {Bq} x L {L} (dense lengths), H {H}, d {d}, causal, alpha 1/sqrt(d)"}}
 
 
 def main():
@@ -259,6 +320,11 @@ def main():
         step_bytes = (8 * nt_avg + 8 * (FB + 1) + 16 * nu_avg + nu_avg * D * e + FB * D * o) + \
                      (8 * nt_avg + FB * D * o + 2 * nu_avg * D * e)
         result["step_algorithmic_GBps"] = step_bytes / (elapsed / args.steps) / 1e9
+
+    if not args.no_hstu:
+        h = hstu_section(args, device, world, dist if sharded_path else None)
+        if rank == 0:
+            result["hstu"] = h
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # keys index host rows directly (the permuted keys are already in [0, rows))

@@ -83,6 +83,31 @@ int mi355_table_erase(void* storage, const int64_t* table_bucket_offsets, int64_
                       int64_t num_scores, int32_t* bucket_sizes, int64_t n, const void* keys,
                       const int64_t* table_ids, int64_t* indices, hipStream_t stream);
 
+/* table_export_batch, src/table_operation/export_batch.cu:22-124 (kernel kernels.cuh:655-705): the valid slots of
+ * [offset, offset+batch) whose score[score_index] >= threshold (has_threshold) -> compacted (keys, scores,
+ * indices = slot - table_begin), *counter = how many.  Output is in slot order (the reference: atomic order). */
+int64_t mi355_table_export_batch_workspace_bytes(int64_t batch);
+int mi355_table_export_batch(const void* storage, int64_t num_buckets, int64_t bucket_capacity, int64_t num_scores,
+                             int64_t batch, int64_t offset, int has_threshold, uint64_t threshold,
+                             int64_t table_begin, int64_t score_index, int64_t* counter, void* keys,
+                             int64_t* scores, int64_t* indices, void* workspace, int64_t workspace_bytes,
+                             hipStream_t stream);
+
+/* table_count_matched, src/table_operation/count_matched.cu:23-93: number of valid slots in [begin, end)
+ * (negative = whole table) with score[score_index] >= threshold (unsigned compare) -> *num_matched. */
+int mi355_table_count_matched(const void* storage, int64_t num_buckets, int64_t bucket_capacity, int64_t num_scores,
+                              uint64_t threshold, int64_t begin, int64_t end, int64_t score_index,
+                              int64_t* num_matched, hipStream_t stream);
+
+/* table_{copy,gather,scatter}_score_blocks, src/table_operation/insert.cu:155-254 (kernels.cuh:839-910):
+ * mode 0 copy src[src_slots]->dst[dst_slots], 1 gather src[src_slots]->dense [n, num_scores], 2 scatter
+ * dense->dst[dst_slots]; slots are table-relative, *_bkt_begin the table's first bucket; slot < 0 skipped
+ * (gather writes zeros). */
+int mi355_table_score_blocks(int mode, const void* src_storage, int64_t src_bucket_capacity, int64_t src_bkt_begin,
+                             void* dst_storage, int64_t dst_bucket_capacity, int64_t dst_bkt_begin,
+                             int64_t num_scores, int64_t n, const int64_t* src_slots, const int64_t* dst_slots,
+                             int64_t* dense, hipStream_t stream);
+
 /* table_update_counter_with_layout, insert_and_evict.cu:27-58,397-430 (main-table region) */
 int mi355_table_update_counter(int32_t* counter, int64_t counter_numel, const int64_t* slot_indices, int64_t n,
                                const int64_t* n_dev, int32_t delta, const int64_t* table_ids,
@@ -136,6 +161,16 @@ int mi355_block_bucketize(int64_t world_size, int64_t num_bags, int64_t batch_si
                           const void* indices, const int64_t* block_sizes, const int32_t* dist_type_per_feature,
                           const float* weights, int64_t* new_lengths, int64_t* new_offsets, void* new_indices,
                           float* new_weights, int64_t* unbucketize_permute, hipStream_t stream);
+
+/* compute_dedup_lengths_cuda, src/unique_op.cu:753-789 (kernel lookup_kernel.cuh:1049-1090): lengths/offsets that
+ * spread each table's unique keys evenly over its (feature, batch) bags.  new_offsets has new_lengths_size+1. */
+int mi355_compute_dedup_lengths(const int64_t* unique_offsets, const int64_t* table_offsets_in_feature,
+                                int64_t num_tables, int64_t local_batch_size, int64_t new_lengths_size,
+                                int64_t* new_lengths, int64_t* new_offsets, hipStream_t stream);
+
+/* segmented_sum_cuda, src/index_calculation.cu:38-75: int32 data, int64 offsets [S+1] -> int64 sums [S]. */
+int mi355_segmented_sum(const int32_t* data, const int64_t* offsets, int64_t num_segments, int64_t* out,
+                        hipStream_t stream);
 
 /* Bag re-ordering of a received key stream, (source rank, feature, batch) -> (feature, source rank, batch):
  * the recat / permute_2D_sparse_data step of TorchRec's KJTAllToAll (third party), call site

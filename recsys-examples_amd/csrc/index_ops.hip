@@ -590,6 +590,42 @@ bucketize_scatter_kernel(int64_t FB, int64_t B, int W, const int64_t* __restrict
   }
 }
 
+// compute_dedup_lengths (get_new_length_and_offsets_kernel, lookup_kernel.cuh:1049-1090): spread the Nu_t unique keys
+// of table t evenly over its (features of t) x local_batch pseudo-bags; first `remainder` bags get one more.
+__global__ void __launch_bounds__(256)
+dedup_lengths_kernel(const int64_t* __restrict__ unique_offsets, const int64_t* __restrict__ table_offsets_in_feature,
+                     int num_tables, int64_t n, int64_t local_batch, int64_t* __restrict__ new_lengths,
+                     int64_t* __restrict__ new_offsets) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t feature = i / local_batch;
+  int t = 0;
+  while (t + 1 < num_tables && table_offsets_in_feature[t + 1] <= feature) ++t;  // upper_bound - 1
+  const int64_t f0 = table_offsets_in_feature[t];
+  const int64_t buckets = (table_offsets_in_feature[t + 1] - f0) * local_batch;
+  const int64_t bid = i - f0 * local_batch;
+  const uint64_t nu = (uint64_t)(unique_offsets[t + 1] - unique_offsets[t]);
+  const uint64_t base = nu / (uint64_t)buckets, rem = nu % (uint64_t)buckets;
+  const uint64_t len = base + ((uint64_t)bid < rem ? 1 : 0);
+  const uint64_t off = (uint64_t)unique_offsets[t] + (uint64_t)bid * base + ((uint64_t)bid < rem ? (uint64_t)bid : rem);
+  new_lengths[i] = (int64_t)len;
+  new_offsets[i] = (int64_t)off;
+  if (i == n - 1) new_offsets[n] = (int64_t)(off + base);  // as the reference writes it (== off + len: the last bag never has the +1)
+}
+
+// segmented_sum_cuda (index_calculation.cu:38-75): out[s] = sum(int32 data[offsets[s] .. offsets[s+1])) as int64
+__global__ void __launch_bounds__(256)
+segmented_sum_kernel(const int32_t* __restrict__ data, const int64_t* __restrict__ offsets, int64_t* __restrict__ out) {
+  __shared__ int64_t part[4];
+  const int64_t b = offsets[blockIdx.x], e = offsets[blockIdx.x + 1];
+  int64_t acc = 0;
+  for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) acc += data[i];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane_id() == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
 // Re-order the bags of a received key stream from (source rank, feature, batch) to (feature, source rank,
 // batch) order -- what TorchRec's KJTAllToAll does with permute_2D_sparse_data after the key all-to-all
 // (third-party; call site corelib/dynamicemb/dynamicemb/input_dist.py:239-285).  One wave per output bag.
@@ -791,6 +827,25 @@ int mi355_group_by_unique(const int64_t* reverse_indices, int64_t n, const int64
                      hot, hot_workspace != nullptr);
   if (n > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, reverse_indices, n, offsets,
                                 num_bags, ptr, cursor, csr_src, hot, hot_workspace != nullptr);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int mi355_compute_dedup_lengths(const int64_t* unique_offsets, const int64_t* table_offsets_in_feature, int64_t num_tables,
+                                int64_t local_batch_size, int64_t new_lengths_size, int64_t* new_lengths,
+                                int64_t* new_offsets, hipStream_t stream) {
+  MI355_CHECK_ARG(local_batch_size > 0 || new_lengths_size == 0, "local_batch_size must be positive");
+  if (new_lengths_size == 0) return MI355_OK;
+  hipLaunchKernelGGL(dedup_lengths_kernel, dim3((unsigned)ceil_div(new_lengths_size, 256)), dim3(256), 0, stream,
+                     unique_offsets, table_offsets_in_feature, (int)num_tables, new_lengths_size, local_batch_size,
+                     new_lengths, new_offsets);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int mi355_segmented_sum(const int32_t* data, const int64_t* offsets, int64_t num_segments, int64_t* out, hipStream_t stream) {
+  MI355_CHECK_ARG(num_segments > 0, "offsets size must be at least 2 (num_segments >= 1)");
+  hipLaunchKernelGGL(segmented_sum_kernel, dim3((unsigned)num_segments), dim3(256), 0, stream, data, offsets, out);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }

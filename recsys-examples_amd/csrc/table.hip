@@ -20,6 +20,7 @@
 //    ONE atomic per wave.
 //  * all counts can stay on the device (`n_dev`), so the pipeline never syncs the host.
 #include "common.h"
+#include "../../include/recsys_amd.h"
 
 namespace mi355 {
 
@@ -455,6 +456,64 @@ update_counter_kernel(int32_t* __restrict__ counter, int64_t total, const int64_
 
 __global__ void device_timestamp_kernel(int64_t* out) { *out = (int64_t)device_clock(); }
 
+// ---- table scan: export / count (table_export_batch_kernel kernels.cuh:655-705, EvalAndCount :59-79) ----
+// One thread per slot of [begin, end): flag = valid key && (no threshold || score[score_index] >= threshold).
+// The dense (flag, key, score, index) arrays are then compacted in slot order (mi355_flagged_compact), so the
+// export order is deterministic; the reference's is atomicAdd order.
+__global__ void __launch_bounds__(256)
+table_scan_kernel(Table t, int64_t begin, int64_t end, int64_t table_begin, int has_thr, uint64_t thr, int64_t score_index,
+                  uint8_t* __restrict__ flags, uint64_t* __restrict__ keys, uint64_t* __restrict__ scores,
+                  int64_t* __restrict__ indices) {
+  for (int64_t i = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < end; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / t.C, it = i % t.C;
+    const uint64_t k = t.keys(b)[it];
+    const uint64_t sc = t.scores(b)[it * t.ns + score_index];
+    const bool m = is_valid(k) && (!has_thr || sc >= thr);
+    const int64_t o = i - begin;
+    flags[o] = m ? 1 : 0;
+    keys[o] = k;
+    scores[o] = sc;
+    indices[o] = i - table_begin;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+table_count_kernel(Table t, int64_t begin, int64_t end, uint64_t thr, int64_t score_index, unsigned long long* counter) {
+  int cnt = 0;
+  for (int64_t i = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < end; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / t.C, it = i % t.C;
+    cnt += (is_valid(t.keys(b)[it]) && t.scores(b)[it * t.ns + score_index] >= thr) ? 1 : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if (lane_id() == 0 && cnt) atomicAdd(counter, (unsigned long long)cnt);
+}
+
+// copy / gather / scatter of whole score blocks (kernels.cuh:839-910); slots are table-relative flat indices
+__global__ void __launch_bounds__(256)
+score_blocks_kernel(int mode, Table src, int64_t src_bkt_begin, Table dst, int64_t dst_bkt_begin, int64_t n,
+                    const int64_t* __restrict__ src_slots, const int64_t* __restrict__ dst_slots, uint64_t* dense) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t ns = dst.ns;
+  if (mode == 0) {  // copy src[src_slots[i]] -> dst[dst_slots[i]]
+    const int64_t ss = src_slots[i], ds = dst_slots[i];
+    if (ss < 0 || ds < 0) return;
+    const uint64_t* sp = src.scores(src_bkt_begin + ss / src.C) + (ss % src.C) * src.ns;
+    uint64_t* dp = dst.scores(dst_bkt_begin + ds / dst.C) + (ds % dst.C) * dst.ns;
+    for (int64_t k = 0; k < ns; ++k) dp[k] = sp[k];
+  } else if (mode == 1) {  // gather -> dense [n, ns]
+    const int64_t sl = src_slots[i];
+    if (sl < 0) { for (int64_t k = 0; k < ns; ++k) dense[i * ns + k] = 0; return; }
+    const uint64_t* sp = src.scores(src_bkt_begin + sl / src.C) + (sl % src.C) * src.ns;
+    for (int64_t k = 0; k < ns; ++k) dense[i * ns + k] = sp[k];
+  } else {  // scatter dense [n, ns] -> dst
+    const int64_t sl = dst_slots[i];
+    if (sl < 0) return;
+    uint64_t* dp = dst.scores(dst_bkt_begin + sl / dst.C) + (sl % dst.C) * dst.ns;
+    for (int64_t k = 0; k < ns; ++k) dp[k] = dense[i * ns + k];
+  }
+}
+
 }  // namespace mi355
 
 using namespace mi355;
@@ -540,6 +599,66 @@ int mi355_table_update_counter(int32_t* counter, int64_t counter_numel, const in
   if (n == 0) return MI355_OK;
   hipLaunchKernelGGL(update_counter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, counter, counter_numel,
                      slot_indices, n, n_dev, delta, table_ids, table_bucket_offsets, C);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int64_t mi355_table_export_batch_workspace_bytes(int64_t batch) {
+  const int64_t a = (batch + 255) / 256 * 256;
+  return a + 3 * 8 * a + 8 * a + mi355_flagged_compact_workspace_bytes(batch) + 256;
+}
+
+int mi355_table_export_batch(const void* storage, int64_t num_buckets, int64_t C, int64_t num_scores, int64_t batch,
+                             int64_t offset, int has_threshold, uint64_t threshold, int64_t table_begin,
+                             int64_t score_index, int64_t* counter, void* keys, int64_t* scores, int64_t* indices,
+                             void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  MI355_CHECK_ARG(C > 0 && C % 16 == 0, "bucket capacity must be a positive multiple of 16");
+  MI355_CHECK_ARG(score_index >= 0 && score_index < num_scores, "score_index out of range");
+  MI355_CHECK_ARG(offset >= 0 && offset + batch <= num_buckets * C, "Offset and batch size overflow.");
+  MI355_CHECK_ARG(workspace_bytes >= mi355_table_export_batch_workspace_bytes(batch), "workspace too small");
+  if (batch == 0) return MI355_OK;
+  const int64_t a = (batch + 255) / 256 * 256;
+  uint8_t* w = (uint8_t*)workspace;
+  uint8_t* flags = w; w += a;
+  uint64_t* k_tmp = (uint64_t*)w; w += 8 * a;
+  uint64_t* s_tmp = (uint64_t*)w; w += 8 * a;
+  int64_t* i_tmp = (int64_t*)w; w += 8 * a;
+  int64_t* pos = (int64_t*)w; w += 8 * a;
+  Table t = make_table(const_cast<void*>(storage), C, num_scores);
+  hipLaunchKernelGGL(table_scan_kernel, dim3(grid_for(batch, 256)), dim3(256), 0, stream, t, offset, offset + batch,
+                     table_begin, has_threshold, threshold, score_index, flags, k_tmp, s_tmp, i_tmp);
+  MI355_LAUNCH_CHECK();
+  const void* ins[3] = {k_tmp, s_tmp, i_tmp};
+  void* outs[3] = {keys, scores, indices};
+  return mi355_flagged_compact(flags, batch, nullptr, counter, pos, 3, ins, outs, w,
+                               mi355_flagged_compact_workspace_bytes(batch), stream);
+}
+
+int mi355_table_count_matched(const void* storage, int64_t num_buckets, int64_t C, int64_t num_scores, uint64_t threshold,
+                              int64_t begin, int64_t end, int64_t score_index, int64_t* num_matched, hipStream_t stream) {
+  MI355_CHECK_ARG(C > 0 && C % 16 == 0, "bucket capacity must be a positive multiple of 16");
+  MI355_CHECK_ARG(score_index >= 0 && score_index < num_scores, "score_index out of range");
+  if (begin < 0) begin = 0;
+  if (end < 0) end = num_buckets * C;
+  if (hipMemsetAsync(num_matched, 0, 8, stream) != hipSuccess) { mi355_set_error("hipMemsetAsync failed"); return MI355_ELAUNCH; }
+  if (end - begin <= 0) return MI355_OK;
+  MI355_CHECK_ARG(end <= num_buckets * C, "range exceeds the table");
+  Table t = make_table(const_cast<void*>(storage), C, num_scores);
+  hipLaunchKernelGGL(table_count_kernel, dim3(grid_for(end - begin, 256, 2048)), dim3(256), 0, stream, t, begin, end,
+                     threshold, score_index, (unsigned long long*)num_matched);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int mi355_table_score_blocks(int mode, const void* src_storage, int64_t src_C, int64_t src_bkt_begin, void* dst_storage,
+                             int64_t dst_C, int64_t dst_bkt_begin, int64_t num_scores, int64_t n, const int64_t* src_slots,
+                             const int64_t* dst_slots, int64_t* dense, hipStream_t stream) {
+  MI355_CHECK_ARG(mode >= 0 && mode <= 2, "mode must be 0 copy / 1 gather / 2 scatter");
+  if (n == 0) return MI355_OK;
+  Table s = make_table(const_cast<void*>(src_storage ? src_storage : dst_storage), src_C > 0 ? src_C : dst_C, num_scores);
+  Table d = make_table(dst_storage ? dst_storage : const_cast<void*>(src_storage), dst_C > 0 ? dst_C : src_C, num_scores);
+  hipLaunchKernelGGL(score_blocks_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, mode, s, src_bkt_begin, d,
+                     dst_bkt_begin, n, src_slots, dst_slots, (uint64_t*)dense);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }

@@ -187,6 +187,76 @@ def table_update_counter_with_layout(counter, slot_indices, delta, table_bucket_
                                            stream()), "table_update_counter")
 
 
+def _num_buckets(table_storage, bucket_capacity, num_scores):
+    return table_storage.numel() * table_storage.element_size() // (bucket_capacity * (9 + 8 * num_scores))
+
+
+def table_export_batch(table_storage, bucket_capacity, batch, offset, key_dtype=torch.int64, threshold=None,
+                       table_begin=0, num_scores=1, score_index=0):
+    """table_export_batch (export_batch.cu:88-124) -> (counter i64[1], keys[batch], scores i64[batch], indices i64[batch]);
+    the first `counter` entries are valid.  Slot order (deterministic); the reference's order is atomic order."""
+    dev = table_storage.device
+    counter = torch.zeros(1, dtype=torch.int64, device=dev)
+    keys = torch.empty(batch, dtype=key_dtype, device=dev)
+    score = torch.empty(batch, dtype=torch.int64, device=dev)
+    indices = torch.empty(batch, dtype=torch.int64, device=dev)
+    if batch == 0:
+        return counter, keys, score, indices
+    if keys.element_size() != 8:
+        raise RuntimeError("only 64-bit keys are supported")
+    nb = _num_buckets(table_storage, bucket_capacity, num_scores)
+    if offset + batch > nb * bucket_capacity:
+        raise ValueError("Offset and batch size overflow.")
+    ws = _workspace(lib().mi355_table_export_batch_workspace_bytes(batch), dev)
+    thr = 0 if threshold is None else int(threshold) & 0xFFFFFFFFFFFFFFFF
+    check(lib().mi355_table_export_batch(ptr(table_storage), nb, bucket_capacity, num_scores, batch, offset,
+                                         int(threshold is not None), c_u64(thr), table_begin, score_index, ptr(counter),
+                                         ptr(keys), ptr(score), ptr(indices), ptr(ws), ws.numel(), stream()),
+          "table_export_batch")
+    return counter, keys, score, indices
+
+
+def table_count_matched(table_storage, key_dtype, bucket_capacity, threshold, begin=-1, end=-1, num_scores=1,
+                        score_index=0):
+    """table_count_matched (count_matched.cu:77-93) -> i64[1] on the device."""
+    out = torch.zeros(1, dtype=torch.int64, device=table_storage.device)
+    nb = _num_buckets(table_storage, bucket_capacity, num_scores)
+    check(lib().mi355_table_count_matched(ptr(table_storage), nb, bucket_capacity, num_scores,
+                                          c_u64(int(threshold) & 0xFFFFFFFFFFFFFFFF), begin, end, score_index, ptr(out),
+                                          stream()), "table_count_matched")
+    return out
+
+
+def table_copy_score_blocks(src_storage, src_bucket_capacity, dst_storage, dst_bucket_capacity, num_scores,
+                            src_bkt_begin, dst_bkt_begin, src_slots, dst_slots, key_dtype=torch.int64):
+    n = src_slots.size(0)
+    if n == 0:
+        return
+    check(lib().mi355_table_score_blocks(0, ptr(src_storage), src_bucket_capacity, src_bkt_begin, ptr(dst_storage),
+                                         dst_bucket_capacity, dst_bkt_begin, num_scores, n, ptr(src_slots.contiguous()),
+                                         ptr(dst_slots.contiguous()), None, stream()), "table_copy_score_blocks")
+
+
+def table_gather_score_blocks(table_storage, bucket_capacity, num_scores, bkt_begin, slots, key_dtype=torch.int64):
+    n = slots.size(0)
+    out = torch.empty(n, num_scores, dtype=torch.int64, device=table_storage.device)
+    if n:
+        check(lib().mi355_table_score_blocks(1, ptr(table_storage), bucket_capacity, bkt_begin, None, 0, 0, num_scores, n,
+                                             ptr(slots.contiguous()), None, ptr(out), stream()),
+              "table_gather_score_blocks")
+    return out
+
+
+def table_scatter_score_blocks(table_storage, bucket_capacity, num_scores, bkt_begin, slots, values,
+                               key_dtype=torch.int64):
+    n = slots.size(0)
+    if n == 0:
+        return
+    vals = values.contiguous()
+    check(lib().mi355_table_score_blocks(2, None, 0, 0, ptr(table_storage), bucket_capacity, bkt_begin, num_scores, n, None,
+                                         ptr(slots.contiguous()), ptr(vals), stream()), "table_scatter_score_blocks")
+
+
 def device_timestamp() -> int:
     """device_timestamp (torch_utils.cu:150): device clock ticks (host sync, as the reference)."""
     t = torch.empty(1, dtype=torch.int64, device="cuda")
@@ -289,6 +359,37 @@ def expand_table_ids_cuda(offsets, num_elements=0, n_dev=None):
     return out
 
 
+def compute_dedup_lengths_cuda(unique_offsets, table_offsets_in_feature, num_tables, local_batch_size, new_lengths_size):
+    """compute_dedup_lengths_cuda (unique_op.cu:753-789) -> (new_lengths i64[n], new_offsets i64[n+1])."""
+    if not unique_offsets.is_cuda:
+        raise RuntimeError("unique_offsets must be on CUDA device")
+    if not table_offsets_in_feature.is_cuda:
+        raise RuntimeError("table_offsets_in_feature must be on CUDA device")
+    dev = unique_offsets.device
+    if new_lengths_size == 0:
+        return torch.empty(0, dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
+    nl = torch.empty(new_lengths_size, dtype=torch.int64, device=dev)
+    no = torch.empty(new_lengths_size + 1, dtype=torch.int64, device=dev)
+    check(lib().mi355_compute_dedup_lengths(ptr(unique_offsets), ptr(table_offsets_in_feature), num_tables,
+                                            local_batch_size, new_lengths_size, ptr(nl), ptr(no), stream()),
+          "compute_dedup_lengths")
+    return nl, no
+
+
+def segmented_sum_cuda(data, offsets):
+    """segmented_sum_cuda (index_calculation.cu:38-75): int32 data, int64 offsets -> int64 [num_segments]."""
+    if offsets.dtype != torch.int64:
+        raise RuntimeError("offsets must be int64")
+    if data.dtype != torch.int32:
+        raise RuntimeError("data must be int32")
+    ns = offsets.size(0) - 1
+    if ns <= 0:
+        raise RuntimeError("offsets size must be at least 2 (num_segments >= 1)")
+    out = torch.empty(ns, dtype=torch.int64, device=data.device)
+    check(lib().mi355_segmented_sum(ptr(data.contiguous()), ptr(offsets), ns, ptr(out), stream()), "segmented_sum")
+    return out
+
+
 def get_table_range(offsets, feature_offsets):
     """get_table_range (index_calculation.cu:93-127): range[t] = offsets[feature_offsets[t] * B]."""
     if not offsets.is_cuda:
@@ -302,11 +403,11 @@ def get_table_range(offsets, feature_offsets):
     return out
 
 
-def flagged_compact(flags: torch.Tensor, tensors: List[Optional[torch.Tensor]]):
+def flagged_compact(flags: torch.Tensor, inputs: List[Optional[torch.Tensor]]):
     """flagged_compact (index_calculation.cu:129-232) -> (count:int, indices, [tensors]).
     The reference returns the count as a host int (one sync); so does this wrapper.  The sync-free
     form is `flagged_compact_async` below."""
-    cnt, idx, outs = flagged_compact_async(flags, tensors)
+    cnt, idx, outs = flagged_compact_async(flags, inputs)
     c = int(cnt.item())
     return c, idx[:c], [None if o is None else o[:c] for o in outs]
 
@@ -331,8 +432,8 @@ def flagged_compact_async(flags, tensors, n_dev=None):
     return cnt, idx, [None if t is None else next(it) for t in tensors]
 
 
-def block_bucketize_sparse_features(lengths, indices, bucketize_pos, sequence, block_sizes, my_size, weights=None,
-                                    dist_type_per_feature=None, batch_size_per_feature=None, max_B=-1,
+def block_bucketize_sparse_features(lengths, indices, bucketize_pos, sequence, dist_type_per_feature=None,
+                                    block_sizes=None, my_size=None, weights=None, batch_size_per_feature=None, max_B=-1,
                                     block_bucketize_pos=None):
     """block_bucketize_sparse_features (sparse_block_bucketize_features.cu:366-830) ->
     (new_lengths, new_indices, new_weights, new_pos, unbucketize_permute)."""
@@ -465,16 +566,16 @@ def _init(mode, buffer, indices, keys, p, ctx=None):
                                 buffer.size(1), None, None, None, None, None, stream()), "init_rows")
 
 
-def uniform_init(buffer, indices, curand_ctx, lower, upper, keys=None):
-    _init(0, buffer, indices, keys, (lower, upper, 0, 0), curand_ctx)
+def uniform_init(buffer, indices, curand_state_context, lower, upper, keys=None):
+    _init(0, buffer, indices, keys, (lower, upper, 0, 0), curand_state_context)
 
 
-def normal_init(buffer, indices, curand_ctx, mean, std_dev, keys=None):
-    _init(1, buffer, indices, keys, (mean, std_dev, 0, 0), curand_ctx)
+def normal_init(buffer, indices, curand_state_context, mean, std_dev, keys=None):
+    _init(1, buffer, indices, keys, (mean, std_dev, 0, 0), curand_state_context)
 
 
-def truncated_normal_init(buffer, indices, curand_ctx, mean, std_dev, lower, upper, keys=None):
-    _init(2, buffer, indices, keys, (mean, std_dev, lower, upper), curand_ctx)
+def truncated_normal_init(buffer, indices, curand_state_context, mean, std_dev, lower, upper, keys=None):
+    _init(2, buffer, indices, keys, (mean, std_dev, lower, upper), curand_state_context)
 
 
 def const_init(buffer, indices, value):
@@ -557,29 +658,44 @@ def _opt_flat(kind, grads, indices, table_ptrs, table_ids, table_value_dims, tab
           "optimizer_update")
 
 
+_DT_FROM_ENUM = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}
+
+
+def _table_dtype(d):
+    """table_dtype arrives as a DynamicEmbDataType value from the reference's optimizer.py (torch_to_dyn_emb(..).value)
+    or as a torch dtype."""
+    if isinstance(d, torch.dtype):
+        return d
+    return _DT_FROM_ENUM[int(d)]
+
+
+# Positional orders are the pybind ones of src/optimizer.cu:415-447 (the reference calls them positionally).
 def sgd_update_for_flat_table(grads, indices, table_ptrs, table_ids, table_value_dims, table_emb_dims, max_emb_dim,
-                              all_dims_vec4, lr, weight_dtype=torch.float32):
+                              all_dims_vec4, lr, table_dtype=torch.float32):
     _opt_flat(1, grads, indices, table_ptrs, table_ids, table_value_dims, table_emb_dims, max_emb_dim, dict(lr=lr),
-              weight_dtype)
+              _table_dtype(table_dtype))
 
 
-def adam_update_for_flat_table(grads, indices, table_ptrs, table_ids, table_value_dims, table_emb_dims, max_emb_dim,
-                               all_dims_vec4, lr, beta1, beta2, eps, weight_decay, iter_num,
-                               weight_dtype=torch.float32):
+def adam_update_for_flat_table(grads, indices, table_ptrs, table_ids, table_value_dims, table_emb_dims, lr, beta1, beta2,
+                               eps, weight_decay, iter_num, max_emb_dim, all_dims_vec4, table_dtype=torch.float32):
     _opt_flat(2, grads, indices, table_ptrs, table_ids, table_value_dims, table_emb_dims, max_emb_dim,
-              dict(lr=lr, beta1=beta1, beta2=beta2, eps=eps, weight_decay=weight_decay, iter_num=iter_num), weight_dtype)
+              dict(lr=lr, beta1=beta1, beta2=beta2, eps=eps, weight_decay=weight_decay, iter_num=iter_num),
+              _table_dtype(table_dtype))
 
 
-def adagrad_update_for_flat_table(grads, indices, table_ptrs, table_ids, table_value_dims, table_emb_dims,
-                                  max_emb_dim, all_dims_vec4, lr, eps, weight_dtype=torch.float32):
+def adagrad_update_for_flat_table(grads, indices, table_ptrs, table_ids, table_value_dims, table_emb_dims, lr, eps,
+                                  max_emb_dim, all_dims_vec4, table_dtype=torch.float32):
     _opt_flat(3, grads, indices, table_ptrs, table_ids, table_value_dims, table_emb_dims, max_emb_dim,
-              dict(lr=lr, eps=eps), weight_dtype)
+              dict(lr=lr, eps=eps), _table_dtype(table_dtype))
 
 
-def rowwise_adagrad_update_for_flat_table(grads, indices, table_ptrs, table_ids, table_value_dims, table_emb_dims,
-                                          max_emb_dim, all_dims_vec4, lr, eps, weight_dtype=torch.float32):
+def rowwise_adagrad_for_flat_table(grads, indices, table_ptrs, table_ids, table_value_dims, table_emb_dims, lr, eps,
+                                   max_emb_dim, all_dims_vec4, table_dtype=torch.float32):
     _opt_flat(4, grads, indices, table_ptrs, table_ids, table_value_dims, table_emb_dims, max_emb_dim,
-              dict(lr=lr, eps=eps), weight_dtype)
+              dict(lr=lr, eps=eps), _table_dtype(table_dtype))
+
+
+rowwise_adagrad_update_for_flat_table = rowwise_adagrad_for_flat_table
 
 
 def _opt_padded(kind, grads, values, emb_dim, state_offset, hp):
@@ -592,24 +708,27 @@ def _opt_padded(kind, grads, values, emb_dim, state_offset, hp):
                                        int(hp.get("iter_num", 1)), int(al), stream()), "optimizer_update_padded")
 
 
-def sgd_update_for_padded_buffer(grads, values, table_ids, table_emb_dims, max_emb_dim, value_dim, all_dims_vec4, lr):
-    _opt_padded(1, grads, values, max_emb_dim, max_emb_dim, dict(lr=lr))
+def sgd_update_for_padded_buffer(grads, values, table_ids, table_emb_dims, emb_dim, value_dim, all_dims_vec4, lr):
+    _opt_padded(1, grads, values, emb_dim, emb_dim, dict(lr=lr))
 
 
-def adam_update_for_padded_buffer(grads, values, table_ids, table_emb_dims, max_emb_dim, value_dim, all_dims_vec4,
+def adam_update_for_padded_buffer(grads, values, table_ids, table_emb_dims, emb_dim, value_dim, all_dims_vec4,
                                   lr, beta1, beta2, eps, weight_decay, iter_num):
-    _opt_padded(2, grads, values, max_emb_dim, max_emb_dim,
+    _opt_padded(2, grads, values, emb_dim, emb_dim,
                 dict(lr=lr, beta1=beta1, beta2=beta2, eps=eps, weight_decay=weight_decay, iter_num=iter_num))
 
 
-def adagrad_update_for_padded_buffer(grads, values, table_ids, table_emb_dims, max_emb_dim, value_dim, all_dims_vec4,
+def adagrad_update_for_padded_buffer(grads, values, table_ids, table_emb_dims, emb_dim, value_dim, all_dims_vec4,
                                      lr, eps):
-    _opt_padded(3, grads, values, max_emb_dim, max_emb_dim, dict(lr=lr, eps=eps))
+    _opt_padded(3, grads, values, emb_dim, emb_dim, dict(lr=lr, eps=eps))
 
 
-def rowwise_adagrad_update_for_padded_buffer(grads, values, table_ids, table_emb_dims, max_emb_dim, value_dim,
-                                             all_dims_vec4, lr, eps):
-    _opt_padded(4, grads, values, max_emb_dim, max_emb_dim, dict(lr=lr, eps=eps))
+def rowwise_adagrad_for_padded_buffer(grads, values, table_ids, table_emb_dims, emb_dim, value_dim, all_dims_vec4,
+                                      lr, eps):
+    _opt_padded(4, grads, values, emb_dim, emb_dim, dict(lr=lr, eps=eps))
+
+
+rowwise_adagrad_update_for_padded_buffer = rowwise_adagrad_for_padded_buffer
 
 
 def init_rows(mode, params, seed, state_init, keys, row_addr, dtype, emb_dim, value_dim, results=None, skip=None,

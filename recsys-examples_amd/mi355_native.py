@@ -40,6 +40,13 @@ _SIGS = {
     "mi355_table_erase": [c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p],
     "mi355_table_update_counter": [c_p, c_i64, c_p, c_i64, c_p, ctypes.c_int32, c_p, c_p, c_i64, c_p],
     "mi355_device_timestamp": [c_p, c_p],
+    "mi355_table_export_batch": [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_u64, c_i64, c_i64, c_p, c_p, c_p, c_p,
+                                 c_p, c_i64, c_p],
+    "mi355_table_export_batch_workspace_bytes": [c_i64],
+    "mi355_table_count_matched": [c_p, c_i64, c_i64, c_i64, c_u64, c_i64, c_i64, c_i64, c_p, c_p],
+    "mi355_table_score_blocks": [c_int, c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p],
+    "mi355_compute_dedup_lengths": [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p],
+    "mi355_segmented_sum": [c_p, c_p, c_i64, c_p, c_p],
     "mi355_segmented_unique": [c_p, c_i64, c_p, c_i64, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_i64, c_p],
     "mi355_expand_table_ids": [c_p, c_i64, c_i64, c_p, c_p, c_p],
     "mi355_get_table_range": [c_p, c_p, c_i64, c_i64, c_p, c_p],
@@ -85,6 +92,7 @@ _SIGS = {
 }
 _RESTYPES = {
     "mi355_segmented_unique_workspace_bytes": c_i64,
+    "mi355_table_export_batch_workspace_bytes": c_i64,
     "mi355_flagged_compact_workspace_bytes": c_i64,
     "mi355_group_by_unique_workspace_bytes": c_i64,
     "mi355_backward_workspace_bytes": c_i64,

@@ -319,8 +319,8 @@ def test_block_bucketize_exact(W):
     for dist in ([1, 1, 1], [2, 2, 2], [0, 0, 0], [0, 1, 2]):
         nl, no, ni, perm = None, None, None, None
         # the oracle takes one dist type per call: run per feature and stitch by comparing per-feature
-        gl, gi, _, _, gperm = e.block_bucketize_sparse_features(T(lens.astype(np.int64)), T(idx), False, True, T(blk), W,
-                                                                 dist_type_per_feature=T(np.array(dist, np.int32)))
+        gl, gi, _, _, gperm = e.block_bucketize_sparse_features(T(lens.astype(np.int64)), T(idx), False, True,
+                                                                 T(np.array(dist, np.int32)), T(blk), W)
         gl = gl.cpu().numpy(); gi = gi.cpu().numpy(); gperm = gperm.cpu().numpy()
         assert gl.sum() == idx.size and sorted(gperm.tolist()) == list(range(idx.size))
         go = np.concatenate([[0], np.cumsum(gl)])
@@ -603,13 +603,14 @@ def test_optimizer_update_ops_dense_grads():
             e.sgd_update_for_flat_table(T(g), T(idx), tptr, tid, tv, te, D, True, 0.1)
             orc.sgd_update(rows, g, D, 0.1)
         elif kind == 2:
-            e.adam_update_for_flat_table(T(g), T(idx), tptr, tid, tv, te, D, True, 0.01, 0.9, 0.999, 1e-8, 0.0, 3)
+            e.adam_update_for_flat_table(T(g), T(idx), tptr, tid, tv, te, 0.01, 0.9, 0.999, 1e-8, 0.0, 3, D, True,
+                                         e.DynamicEmbDataType.Float32.value)
             orc.adam_update(rows, g, D, 0.01, 0.9, 0.999, 1e-8, 0.0, 3)
         elif kind == 3:
-            e.adagrad_update_for_flat_table(T(g), T(idx), tptr, tid, tv, te, D, True, 0.1, 1e-8)
+            e.adagrad_update_for_flat_table(T(g), T(idx), tptr, tid, tv, te, 0.1, 1e-8, D, True)
             orc.adagrad_update(rows, g, D, 0.1, 1e-8)
         else:
-            e.rowwise_adagrad_update_for_flat_table(T(g), T(idx), tptr, tid, tv, te, D, True, 0.1, 1e-8)
+            e.rowwise_adagrad_for_flat_table(T(g), T(idx), tptr, tid, tv, te, 0.1, 1e-8, D, True)
             orc.rowwise_adagrad_update(rows, g, D, 0.1, 1e-8)
         np.testing.assert_allclose(table.cpu().numpy()[idx], rows, rtol=1e-5, atol=1e-6)
         # padded buffer variant: states start at max_emb_dim
@@ -625,6 +626,115 @@ def test_optimizer_update_ops_dense_grads():
         elif kind == 3:
             e.adagrad_update_for_padded_buffer(T(g), buf, tid, te, D, vdim, True, 0.1, 1e-8); orc.adagrad_update(rows, g, D, 0.1, 1e-8)
         else:
-            e.rowwise_adagrad_update_for_padded_buffer(T(g), buf, tid, te, D, vdim, True, 0.1, 1e-8)
+            e.rowwise_adagrad_for_padded_buffer(T(g), buf, tid, te, D, vdim, True, 0.1, 1e-8)
             orc.rowwise_adagrad_update(rows, g, D, 0.1, 1e-8)
         np.testing.assert_allclose(buf.cpu().numpy(), rows, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ export / count / score blocks / dedup lengths
+def _filled_table(ns=1, caps=(2048, 1024), n_keys=1500, seed=3):
+    rng = np.random.default_rng(seed)
+    tb = orc.OracleTable(list(caps), 128, ns)
+    T_ = len(caps)
+    keys = rng.choice(2**40, size=n_keys, replace=False).astype(np.uint64)
+    tids = rng.integers(0, T_, n_keys).astype(np.int64)
+    scores = rng.integers(1, 1000, n_keys).astype(np.uint64)
+    tb.insert(keys, tids, scores, orc.POLICY_ASSIGN)
+    storage = torch.from_numpy(tb.storage.copy()).to(DEV)
+    return tb, storage
+
+
+@pytest.mark.parametrize("ns", [1, 2])
+@pytest.mark.parametrize("threshold", [None, 500])
+def test_table_export_batch_and_count(ns, threshold):
+    e = ext()
+    tb, storage = _filled_table(ns)
+    C = 128
+    keys_v, _, scores_v = tb._view()
+    flat_k = keys_v.reshape(-1)
+    flat_s = scores_v.reshape(-1, ns)
+    total = flat_k.size
+    valid = (flat_k & np.uint64(0xFFFFFFFFFFFFFFFC)) != np.uint64(0xFFFFFFFFFFFFFFFC)
+    for (offset, batch, table_begin, sidx) in [(0, total, 0, 0), (128 * 3, 128 * 7 + 5, 128 * 2, ns - 1), (total - 64, 64, 0, 0)]:
+        sel = np.zeros(total, bool)
+        sel[offset:offset + batch] = True
+        m = valid & sel
+        if threshold is not None:
+            m &= flat_s[:, sidx] >= np.uint64(threshold)
+        exp_idx = np.nonzero(m)[0]
+        cnt, k, s, i = e.table_export_batch(storage, C, batch, offset, torch.int64, threshold, table_begin, ns, sidx)
+        c = int(cnt.item())
+        assert c == exp_idx.size
+        np.testing.assert_array_equal(i[:c].cpu().numpy(), exp_idx - table_begin)  # slot order
+        np.testing.assert_array_equal(k[:c].cpu().numpy().view(np.uint64), flat_k[exp_idx])
+        np.testing.assert_array_equal(s[:c].cpu().numpy().view(np.uint64), flat_s[exp_idx, sidx])
+        if threshold is not None:
+            n = e.table_count_matched(storage, torch.int64, C, threshold, offset, offset + batch, ns, sidx)
+            assert int(n.item()) == exp_idx.size
+    n_all = e.table_count_matched(storage, torch.int64, C, 0, -1, -1, ns, 0)
+    assert int(n_all.item()) == int(valid.sum())
+    with pytest.raises(Exception):
+        e.table_export_batch(storage, C, 128, total - 64, torch.int64, None, 0, ns)
+
+
+def test_table_score_blocks():
+    e = ext()
+    ns = 2
+    tb, storage = _filled_table(ns, caps=(1024, 2048))
+    C = 128
+    _, _, scores_v = tb._view()
+    rng = np.random.default_rng(9)
+    bkt_begin = 1024 // C  # table 1
+    n = 300
+    slots = rng.integers(0, 2048, n).astype(np.int64)
+    slots[::17] = -1
+    got = e.table_gather_score_blocks(storage, C, ns, bkt_begin, T(slots)).cpu().numpy().view(np.uint64)
+    flat = scores_v.reshape(-1, ns)
+    exp = np.where((slots >= 0)[:, None], flat[np.maximum(slots, 0) + bkt_begin * C], 0)
+    np.testing.assert_array_equal(got, exp)
+    # scatter new values to unique slots, read back
+    uslots = rng.choice(2048, size=200, replace=False).astype(np.int64)
+    vals = rng.integers(0, 2**62, (200, ns)).astype(np.int64)
+    e.table_scatter_score_blocks(storage, C, ns, bkt_begin, T(uslots), T(vals))
+    back = e.table_gather_score_blocks(storage, C, ns, bkt_begin, T(uslots)).cpu().numpy()
+    np.testing.assert_array_equal(back, vals)
+    # copy table1[uslots] -> a fresh table with bucket capacity 64, slots permuted
+    dst = torch.zeros(4096 // 64 * 64 * (9 + 8 * ns), dtype=torch.uint8, device=DEV)
+    dslots = rng.choice(4096, size=200, replace=False).astype(np.int64)
+    e.table_copy_score_blocks(storage, C, dst, 64, ns, bkt_begin, 0, T(uslots), T(dslots))
+    back2 = e.table_gather_score_blocks(dst, 64, ns, 0, T(dslots)).cpu().numpy()
+    np.testing.assert_array_equal(back2, vals)
+
+
+@pytest.mark.parametrize("tof,B", [([0, 1], 4), ([0, 2, 3], 5), ([0, 1, 4, 6], 3)])
+def test_compute_dedup_lengths_and_segmented_sum(tof, B):
+    e = ext()
+    rng = np.random.default_rng(len(tof) + B)
+    T_ = len(tof) - 1
+    F = tof[-1]
+    nu = rng.integers(0, 50, T_)
+    nu[0] = 0 if T_ > 1 else 7
+    uoff = np.concatenate([[0], np.cumsum(nu)]).astype(np.int64)
+    nl, no = e.compute_dedup_lengths_cuda(T(uoff), T(np.array(tof, np.int64)), T_, B, F * B)
+    nl, no = nl.cpu().numpy(), no.cpu().numpy()
+    # restatement of lookup_kernel.cuh:1049-1090
+    exp_l, exp_o = [], []
+    for i in range(F * B):
+        f = i // B
+        t = max(tt for tt in range(T_) if tof[tt] <= f)
+        buckets = (tof[t + 1] - tof[t]) * B
+        bid = i - tof[t] * B
+        base, rem = divmod(int(nu[t]), buckets)
+        exp_l.append(base + (1 if bid < rem else 0))
+        exp_o.append(int(uoff[t]) + bid * base + min(bid, rem))
+    np.testing.assert_array_equal(nl, exp_l)
+    np.testing.assert_array_equal(no[:-1], exp_o)
+    assert no[-1] == uoff[-1] and nl.sum() == uoff[-1]
+    for t in range(T_):  # every table's keys are covered contiguously by its own bags
+        assert nl[tof[t] * B:tof[t + 1] * B].sum() == nu[t]
+    empty_l, empty_o = e.compute_dedup_lengths_cuda(T(uoff), T(np.array(tof, np.int64)), T_, B, 0)
+    assert empty_l.numel() == 0 and empty_o.tolist() == [0]
+    data = rng.integers(0, 128, 5000).astype(np.int32)
+    offs = np.sort(np.concatenate([[0, 5000], rng.integers(0, 5000, 6)])).astype(np.int64)
+    got = e.segmented_sum_cuda(T(data), T(offs)).cpu().numpy()
+    np.testing.assert_array_equal(got, [int(data[a:b].sum()) for a, b in zip(offs[:-1], offs[1:])])
