@@ -23,11 +23,13 @@
 //    row block can reach are skipped (causal / contextual / target rules), the mask itself is applied
 //    per element on the fp32 accumulator together with alpha, SiLU and 1/scaling_seqlen.
 #include "common.h"
+#include <stdlib.h>
 
 namespace mi355 {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;   // first-class 16-B value (HIP's uint4 struct arrays end up in scratch)
 
 constexpr int kBM = 128;  // query rows per workgroup (32 per wave)
 constexpr int kBN = 64;   // keys per tile
@@ -69,6 +71,34 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 __device__ __forceinline__ float silu_f(float x) {
   return x * __frcp_rn(1.0f + __expf(-x));
 }
+
+// MFMA wrappers.  The builtin (not inline asm) is deliberate: with asm MFMAs the hazard recogniser cannot see the
+// instruction, and every variant tried (AGPR "+a" accumulators, VGPR "+v" accumulators, padded with s_nop, with a
+// memory clobber) produced timing-dependent wrong sums on gfx950 although the same structure with builtins is
+// bit-stable.  What the asm forms were meant to achieve -- keeping the long-lived output accumulators in AGPRs -- is
+// done with pin_agpr() below, which costs no instructions.
+__device__ __forceinline__ void mfma_a(f32x16_t& c, const bf16x8_t& a, const bf16x8_t& b) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void mfma_v(f32x16_t& c, const bf16x8_t& a, const bf16x8_t& b) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void mfma_v0(f32x16_t& c, const bf16x8_t& a, const bf16x8_t& b) {  // c = a b
+  f32x16_t z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, z, 0, 0, 0);
+}
+__device__ __forceinline__ void mfma_fence() {}
+// keeps a long-lived accumulator resident in AGPRs at this program point (the allocator otherwise splits its live
+// range and parks it in VGPRs across the high-pressure staging code, paying a full copy in and out every iteration)
+template <int N>
+__device__ __forceinline__ void pin_agpr(f32x16_t (&c)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+a"(c[i]));
+}
+template <int N> __device__ __forceinline__ void fence_v(f32x16_t (&)[N]) {}   // builtins: the compiler inserts the waits
+template <int N> __device__ __forceinline__ void fence_a(f32x16_t (&c)[N]) { pin_agpr(c); }
 
 // Row-side mask state of one query (causal case).  M(i, j) of the reference collapses to
 //   j <= jmax  and  (j < hlen  or  j >= jlo)
@@ -174,7 +204,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
   constexpr int KPT = (KCH + 255) / 256;      // per thread
   constexpr int VCH = (kBN / 4) * (D / 8);    // (4 keys x 8 d) blocks of the V tile
   constexpr int VPT = (VCH + 255) / 256;
-  uint4 kreg[KPT], vreg[VPT][4];
+  u32x4_t kreg[KPT], vreg[VPT][4];
   const uint16_t* kbase = a.k + (int64_t)s.start * a.k_row + (int64_t)h * a.k_head;
   const uint16_t* vbase = a.v + (int64_t)s.start * a.v_row + (int64_t)h * a.v_head;
   auto fetch = [&](int n0) {
@@ -184,7 +214,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
       const int key = ch / (D / 8), dc = ch % (D / 8);
       // rows past the sequence end are clamped to its last row: their P is masked to 0, so any finite data do
       const int row = n0 + key < s.L ? n0 + key : s.L - 1;
-      if (KCH % 256 == 0 || ch < KCH) kreg[i] = *reinterpret_cast<const uint4*>(kbase + (int64_t)row * a.k_row + 8 * dc);
+      if (KCH % 256 == 0 || ch < KCH) kreg[i] = *reinterpret_cast<const u32x4_t*>(kbase + (int64_t)row * a.k_row + 8 * dc);
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
@@ -196,7 +226,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int row = n0 + key0 + kk < s.L ? n0 + key0 + kk : s.L - 1;
-        if (VCH % 256 == 0 || ch < VCH) vreg[i][kk] = *reinterpret_cast<const uint4*>(vbase + (int64_t)row * a.v_row + 8 * dc);
+        if (VCH % 256 == 0 || ch < VCH) vreg[i][kk] = *reinterpret_cast<const u32x4_t*>(vbase + (int64_t)row * a.v_row + 8 * dc);
       }
     }
   };
@@ -205,7 +235,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
     for (int i = 0; i < KPT; ++i) {
       const int ch = threadIdx.x + 256 * i;
       const int key = ch / (D / 8), dc = ch % (D / 8);
-      if (KCH % 256 == 0 || ch < KCH) *reinterpret_cast<uint4*>(Ks + key * KS + 8 * dc) = kreg[i];
+      if (KCH % 256 == 0 || ch < KCH) *reinterpret_cast<u32x4_t*>(Ks + key * KS + 8 * dc) = kreg[i];
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
@@ -213,10 +243,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
       if (VCH % 256 != 0 && ch >= VCH) continue;
       const int kgpos = ch % (kBN / 4), dc = ch / (kBN / 4);
       const int g16 = kgpos >> 2, pg = kgpos & 3;
-      const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&vreg[i][0]);
-      const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&vreg[i][1]);
-      const uint32_t* w2 = reinterpret_cast<const uint32_t*>(&vreg[i][2]);
-      const uint32_t* w3 = reinterpret_cast<const uint32_t*>(&vreg[i][3]);
+      const u32x4_t w0 = vreg[i][0], w1 = vreg[i][1], w2 = vreg[i][2], w3 = vreg[i][3];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
@@ -230,40 +257,52 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
 
   if (n_end > 0) fetch(0);
   for (int n0 = 0; n0 < n_end; n0 += kBN) {
+    pin_agpr(acc_o);
     __syncthreads();
     commit();
+    pin_agpr(acc_o);
     __syncthreads();
     if (n0 + kBN < n_end) fetch(n0 + kBN);
+    pin_agpr(acc_o);
     if (!wave_live || n0 >= w_end) continue;
 
     // ---- GEMM 1: S^T[64 keys x 32 q] = K Q^T, two 32-key tiles.  Operand fragments are fetched from LDS
     // in batches of 8 ahead of the 8 MFMAs that consume them (hipcc otherwise emits read-wait-mfma triples).
     f32x16_t acc_s[2];
+    {
+      // fragment batches are double-buffered: the LDS reads of batch n+1 are in flight while the 8 MFMAs of batch n
+      // issue (one wave per SIMD at d = 256: nothing else hides the LDS latency)
+      constexpr int SLB = D / 16 < 4 ? D / 16 : 4;   // 16-wide d slices per batch
+      constexpr int NBAT = (D / 16) / SLB;
+      bf16x8_t kfr[2][SLB][2], qfr[2][SLB];
+      auto load_b = [&](int bi, int buf) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+        for (int u = 0; u < SLB; ++u) {
+          const int sl = SLB * bi + u;
+          if constexpr (QLDS) qfr[buf][u] = *reinterpret_cast<const bf16x8_t*>(Qs + (32 * wv + l31) * KS + 16 * sl + 8 * hi);
+          else qfr[buf][u] = qf[sl];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc_s[t][r] = 0.f;
+          for (int t = 0; t < 2; ++t)
+            kfr[buf][u][t] = *reinterpret_cast<const bf16x8_t*>(Ks + (32 * t + l31) * KS + 16 * sl + 8 * hi);
+        }
+      };
+      load_b(0, 0);
 #pragma unroll
-    for (int sl0 = 0; sl0 < D / 16; sl0 += 4) {
-      bf16x8_t kfr[4][2], qfr[4];
+      for (int bi = 0; bi < NBAT; ++bi) {
+        if (bi + 1 < NBAT) load_b(bi + 1, (bi + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (sl0 + u >= D / 16) continue;
-        if constexpr (QLDS) qfr[u] = *reinterpret_cast<const bf16x8_t*>(Qs + (32 * wv + l31) * KS + 16 * (sl0 + u) + 8 * hi);
-        else qfr[u] = qf[sl0 + u];
+        for (int u = 0; u < SLB; ++u)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-          kfr[u][t] = *reinterpret_cast<const bf16x8_t*>(Ks + (32 * t + l31) * KS + 16 * (sl0 + u) + 8 * hi);
+          for (int t = 0; t < 2; ++t) {
+            if (bi == 0 && u == 0) mfma_v0(acc_s[t], kfr[bi & 1][u][t], qfr[bi & 1][u]);
+            else mfma_v(acc_s[t], kfr[bi & 1][u][t], qfr[bi & 1][u]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-          if (sl0 + u < D / 16)
-            acc_s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[u][t], qfr[u], acc_s[t], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, QLDS ? 12 : 8, 0);  // the DS reads of this batch first,
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);               // then its 8 MFMAs
     }
+    fence_v(acc_s);
+    pin_agpr(acc_o);
     // ---- P^T = mask * SiLU(alpha S^T) / scaling, packed straight into the B operand of GEMM 2.
     // Tiles strictly below the diagonal of every row of the wave need no per-element mask.
     const bool full = a.causal && (n0 + kBN - 1 <= qrow0) && (!s.has_ctx || qrow0 >= s.c) && (!s.has_tgt || n0 + kBN - 1 < s.hlen);
@@ -304,22 +343,29 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
     // independent accumulators; fragments again fetched in batches
     constexpr int NDT = D / 32;
     constexpr int DB = NDT < 8 ? NDT : 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-      for (int dt0 = 0; dt0 < NDT; dt0 += DB) {
-        bf16x8_t vfr[DB];
-#pragma unroll
-        for (int u = 0; u < DB; ++u)
-          vfr[u] = *reinterpret_cast<const bf16x8_t*>(Vt + (32 * (dt0 + u) + l31) * VS + 16 * ks + 8 * hi);
+    pin_agpr(acc_o);
+    {
+      constexpr int NBAT2 = 4 * (NDT / DB);
+      bf16x8_t vfr[2][DB];
+      auto load_v = [&](int bi, int buf) {
+        const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
 #pragma unroll
         for (int u = 0; u < DB; ++u)
-          acc_o[dt0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[u], pf[ks], acc_o[dt0 + u], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, DB, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, DB, 0);
+          vfr[buf][u] = *reinterpret_cast<const bf16x8_t*>(Vt + (32 * (dt0 + u) + l31) * VS + 16 * ks + 8 * hi);
+      };
+      load_v(0, 0);
+#pragma unroll
+      for (int bi = 0; bi < NBAT2; ++bi) {
+        if (bi + 1 < NBAT2) load_v(bi + 1, (bi + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
+#pragma unroll
+        for (int u = 0; u < DB; ++u) mfma_a(acc_o[dt0 + u], vfr[bi & 1][u], pf[ks]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
+  fence_a(acc_o);
 
   // ---- epilogue: O^T accumulator -> out[token][head][d] (bf16), 4 consecutive d per store
   if (qi < s.L) {
@@ -350,34 +396,92 @@ __device__ __forceinline__ float dsilu_f(float x) {
   return sg * (1.0f + x * (1.0f - sg));
 }
 
-// same rows transposed -> LDS [D][NR+8], row positions permuted inside every 16-group ({0-3,8-11,4-7,12-15})
+// ---- register-prefetched tile staging (issue the global loads of tile n+1 before the MFMAs of tile n, write them
+// to LDS after the barrier).  Rows past the sequence end are read clamped and zeroed with selects: no branches.
+// RowTile: rows [row0, row0+NR) -> LDS [NR][D+8] row-major.
 template <int D, int NR>
-__device__ __forceinline__ void stage_transposed(uint16_t* dst, const uint16_t* src, int64_t row_stride, int row0, int nvalid) {
-  constexpr int NCH = (NR / 4) * (D / 8);
+struct RowTile {
+  static constexpr int NCH = NR * D / 8, PT = (NCH + 255) / 256;
+  u32x4_t r[PT];
+  __device__ __forceinline__ void fetch(const uint16_t* src, int64_t row_stride, int row0, int L) {
 #pragma unroll
-  for (int ch = threadIdx.x; ch < NCH; ch += 256) {
-    const int gpos = ch % (NR / 4), dc = ch / (NR / 4);
-    const int g16 = gpos >> 2, pg = gpos & 3;
-    const int ak = pg == 1 ? 2 : (pg == 2 ? 1 : pg);
-    const int r0 = 16 * g16 + 4 * ak;
-    uint4 r[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      r[kk] = make_uint4(0, 0, 0, 0);
-      if (row0 + r0 + kk < nvalid) r[kk] = *reinterpret_cast<const uint4*>(src + (int64_t)(row0 + r0 + kk) * row_stride + 8 * dc);
+    for (int i = 0; i < PT; ++i) {
+      const int ch = threadIdx.x + 256 * i;
+      const int row = row0 + ch / (D / 8), dc = ch % (D / 8);
+      r[i] = *reinterpret_cast<const u32x4_t*>(src + (int64_t)(row < L ? row : L - 1) * row_stride + 8 * (NCH % 256 == 0 || ch < NCH ? dc : 0));
     }
-    const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&r[0]);
-    const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&r[1]);
-    const uint32_t* w2 = reinterpret_cast<const uint32_t*>(&r[2]);
-    const uint32_t* w3 = reinterpret_cast<const uint32_t*>(&r[3]);
+  }
+  // row0 / L of the tile being written: rows past the sequence end become zeros here, not at fetch time, so that
+  // nothing waits on the loads until the tile is needed
+  __device__ __forceinline__ void commit(uint16_t* dst, int row0, int L) const {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
-      uint2 o;
-      o.x = __builtin_amdgcn_perm(w1[e >> 1], w0[e >> 1], sel);
-      o.y = __builtin_amdgcn_perm(w3[e >> 1], w2[e >> 1], sel);
-      *reinterpret_cast<uint2*>(dst + (8 * dc + e) * (NR + 8) + 16 * g16 + 4 * pg) = o;
+    for (int i = 0; i < PT; ++i) {
+      const int ch = threadIdx.x + 256 * i;
+      const u32x4_t z = {0u, 0u, 0u, 0u};
+      const u32x4_t v = (row0 + ch / (D / 8) < L) ? r[i] : z;
+      if (NCH % 256 == 0 || ch < NCH) *reinterpret_cast<u32x4_t*>(dst + (ch / (D / 8)) * (D + 8) + 8 * (ch % (D / 8))) = v;
     }
+  }
+};
+// TransTile: the same rows transposed -> LDS [D][NR+8], row positions permuted inside every 16-group
+// ({0-3,8-11,4-7,12-15}) so that an MFMA accumulator's register order is directly the k order of the next GEMM.
+template <int D, int NR>
+struct TransTile {
+  static constexpr int NCH = (NR / 4) * (D / 8), PT = (NCH + 255) / 256;
+  u32x4_t r[PT][4];
+  __device__ __forceinline__ void fetch(const uint16_t* src, int64_t row_stride, int row0, int L) {
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int ch = (threadIdx.x + 256 * i) % NCH;   // threads past NCH repeat a block (their writes are skipped)
+      const int gpos = ch % (NR / 4), dc = ch / (NR / 4);
+      const int g16 = gpos >> 2, pg = gpos & 3;
+      const int ak = pg == 1 ? 2 : (pg == 2 ? 1 : pg);
+      const int r0 = row0 + 16 * g16 + 4 * ak;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int row = r0 + kk;
+        r[i][kk] = *reinterpret_cast<const u32x4_t*>(src + (int64_t)(row < L ? row : L - 1) * row_stride + 8 * dc);
+      }
+    }
+  }
+  __device__ __forceinline__ void commit(uint16_t* dst, int row0, int L) const {
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int ch = threadIdx.x + 256 * i;
+      if (NCH % 256 != 0 && ch >= NCH) continue;
+      const int gpos = ch % (NR / 4), dc = ch / (NR / 4);
+      const int g16 = gpos >> 2, pg = gpos & 3;
+      const int ak = pg == 1 ? 2 : (pg == 2 ? 1 : pg);
+      const int r0 = row0 + 16 * g16 + 4 * ak;
+      const u32x4_t z = {0u, 0u, 0u, 0u};
+      const u32x4_t w0 = r0 + 0 < L ? r[i][0] : z, w1 = r0 + 1 < L ? r[i][1] : z, w2 = r0 + 2 < L ? r[i][2] : z,
+                    w3 = r0 + 3 < L ? r[i][3] : z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
+        uint2 o;
+        o.x = __builtin_amdgcn_perm(w1[e >> 1], w0[e >> 1], sel);
+        o.y = __builtin_amdgcn_perm(w3[e >> 1], w2[e >> 1], sel);
+        *reinterpret_cast<uint2*>(dst + (8 * dc + e) * (NR + 8) + 16 * g16 + 4 * pg) = o;
+      }
+    }
+  }
+};
+struct NoTile {
+  __device__ __forceinline__ void fetch(const uint16_t*, int64_t, int, int) {}
+  __device__ __forceinline__ void commit(uint16_t*, int, int) const {}
+};
+template <bool C, typename A, typename B> struct SelT { typedef A type; };
+template <typename A, typename B> struct SelT<false, A, B> { typedef B type; };
+
+// B-operand fragments of the wave's own 32 rows (lane = row l31, 8 consecutive d per 16-slice); clamped rows
+template <int D>
+__device__ __forceinline__ void load_own_frags(bf16x8_t (&f)[D / 16], const uint16_t* base, int64_t row_stride, int row, int L, int hi) {
+  const uint16_t* p = base + (int64_t)(row < L ? row : L - 1) * row_stride + 8 * hi;
+#pragma unroll
+  for (int sl = 0; sl < D / 16; ++sl) {
+    const u32x4_t t = *reinterpret_cast<const u32x4_t*>(p + 16 * sl);
+    f[sl] = __builtin_bit_cast(bf16x8_t, t);
   }
 }
 
@@ -387,16 +491,21 @@ struct BwdAttnArgs {
   uint16_t* dq; uint16_t* dk; uint16_t* dv;   // contiguous [T, H, D]
 };
 
-// pass A: one workgroup = 128 keys (32 per wave) of one (sequence, head); loops over query tiles of BQ rows
-template <int D, int BQ>
+// pass A: one workgroup = 128 keys (32 per wave) of one (sequence, head); loops over query tiles of BQ rows.
+// MODE 0: dV and dK together (d <= 64).  Larger d: the two output accumulators plus the S / dP accumulators and the
+// K / V fragments exceed the register file of one wave, so the pass is split: MODE 1 = dV only (S -> P -> dV),
+// MODE 2 = dK only (S, dP -> dS -> dK).  Loop structure as in the forward: register-prefetched tiles, explicit
+// AGPR output accumulators, double-buffered LDS fragment batches, branch-free mask.
+template <int D, int BQ, int MODE>
 __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
   const AttnArgs& a = g.f;
-  constexpr int RS = D + 8, TS = BQ + 8;
+  constexpr bool kDV = MODE != 2, kDK = MODE != 1;
+  constexpr int RS = D + 8, TS = BQ + 8, NT = BQ / 32;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-  uint16_t* Qs = smem;               // [BQ][RS]
-  uint16_t* dOs = Qs + BQ * RS;      // [BQ][RS]
-  uint16_t* Qt = dOs + BQ * RS;      // [D][TS]
-  uint16_t* dOt = Qt + D * TS;       // [D][TS]
+  uint16_t* Qs = smem;                              // [BQ][RS]   (S)
+  uint16_t* dOs = Qs + BQ * RS;                     // [BQ][RS]   (dP; kDK only)
+  uint16_t* Qt = dOs + (kDK ? BQ * RS : 0);         // [D][TS]    (dK; kDK only)
+  uint16_t* dOt = Qt + (kDK ? D * TS : 0);          // [D][TS]    (dV; kDV only)
 
   const int b = blockIdx.z, h = blockIdx.y;
   SeqInfo s;
@@ -412,64 +521,114 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
   const int key0 = n0 + 32 * wv;
   const int kj = key0 + l31;
   const bool wave_live = key0 < s.L;
-
-  // K / V fragments of the wave's 32 keys (B operands: lane = key, 8 consecutive d per 16-slice)
-  bf16x8_t kf[D / 16], vf[D / 16];
-  {
-    const int64_t tok = s.start + (kj < s.L ? kj : 0);
-    const uint16_t* kp = a.k + tok * a.k_row + (int64_t)h * a.k_head + 8 * hi;
-    const uint16_t* vp = a.v + tok * a.v_row + (int64_t)h * a.v_head + 8 * hi;
-#pragma unroll
-    for (int sl = 0; sl < D / 16; ++sl) {
-      uint4 t0 = make_uint4(0, 0, 0, 0), t1 = make_uint4(0, 0, 0, 0);
-      if (kj < s.L) { t0 = *reinterpret_cast<const uint4*>(kp + 16 * sl); t1 = *reinterpret_cast<const uint4*>(vp + 16 * sl); }
-      kf[sl] = *reinterpret_cast<bf16x8_t*>(&t0);
-      vf[sl] = *reinterpret_cast<bf16x8_t*>(&t1);
-    }
-  }
-  f32x16_t acc_dv[D / 32], acc_dk[D / 32];
-#pragma unroll
-  for (int dt = 0; dt < D / 32; ++dt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc_dv[dt][r] = 0.f; acc_dk[dt][r] = 0.f; }
+  const bool plain = !s.has_ctx && !s.has_tgt;   // block-uniform: mask is kj <= qi (causal) or kj < L
 
   const uint16_t* qbase = a.q + (int64_t)s.start * a.q_row + (int64_t)h * a.q_head;
   const uint16_t* dobase = g.dout + (int64_t)s.start * g.do_row + (int64_t)h * g.do_head;
-  const int blk_last_key = n0 + kBM - 1 < s.L - 1 ? n0 + kBM - 1 : s.L - 1;
-  for (int i0 = 0; i0 < s.L; i0 += BQ) {
-    // does any row of this query tile see any key of the block?
-    const int i1 = i0 + BQ - 1 < s.L - 1 ? i0 + BQ - 1 : s.L - 1;
-    bool reach = true;
-    if (a.causal) reach = (i1 >= n0) || (s.has_ctx && i0 < s.c && n0 < s.hlen);
-    if (!reach) continue;   // block-uniform
+  // K / V fragments of the wave's 32 keys.  Keys beyond the sequence read a clamped row: kj < L is part of the mask.
+  bf16x8_t kf[D / 16], vf[kDK ? D / 16 : 1];
+  load_own_frags<D>(kf, a.k + (int64_t)s.start * a.k_row + (int64_t)h * a.k_head, a.k_row, kj, s.L, hi);
+  if constexpr (kDK) load_own_frags<D>(vf, a.v + (int64_t)s.start * a.v_row + (int64_t)h * a.v_head, a.v_row, kj, s.L, hi);
+
+  f32x16_t acc_dv[kDV ? D / 32 : 1], acc_dk[kDK ? D / 32 : 1];
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (kDV) acc_dv[dt][r] = 0.f;
+      if (kDK) acc_dk[dt][r] = 0.f;
+    }
+
+  const float neg_alpha_log2e = -a.alpha * 1.4426950408889634f;
+  const float c_p = a.alpha * a.inv_scale;   // P  = acc * c_p * sigmoid
+  const float c_ds = a.alpha * a.inv_scale;  // dS = dP * c_ds * sigmoid * (1 + x (1 - sigmoid))
+  // query tiles that can see this key block: the tiles holding contextual rows (they see all history keys), then
+  // from the tile containing row n0 on (causal); everything (non causal)
+  int jump = 0, c_end = 0;
+  if (a.causal) {
+    jump = (n0 / BQ) * BQ;
+    if (s.has_ctx && s.c > 0 && n0 < s.hlen) c_end = ((s.c + BQ - 1) / BQ) * BQ;
+  }
+  auto advance = [&](int i) { i += BQ; return (i >= c_end && i < jump) ? jump : i; };
+  int i0 = c_end > 0 ? 0 : jump;
+
+  typename SelT<true, RowTile<D, BQ>, NoTile>::type q_rows;
+  typename SelT<kDK, RowTile<D, BQ>, NoTile>::type do_rows;
+  typename SelT<kDK, TransTile<D, BQ>, NoTile>::type q_tr;
+  typename SelT<kDV, TransTile<D, BQ>, NoTile>::type do_tr;
+  auto fetch_all = [&](int i) {
+    q_rows.fetch(qbase, a.q_row, i, s.L);
+    do_rows.fetch(dobase, g.do_row, i, s.L);
+    q_tr.fetch(qbase, a.q_row, i, s.L);
+    do_tr.fetch(dobase, g.do_row, i, s.L);
+  };
+  // small head dims run several waves per SIMD, which hides the staging latency better than holding a tile in
+  // registers does (the prefetch registers would halve the occupancy); d = 256 runs one wave per SIMD and prefetches
+  constexpr bool kPre = D >= 256;
+  if (kPre && i0 < s.L) fetch_all(i0);
+  for (; i0 < s.L; i0 = advance(i0)) {
+    if (kDV) pin_agpr(acc_dv);
+    if (kDK) pin_agpr(acc_dk);
     __syncthreads();
-    stage_rows<D, BQ>(Qs, qbase, a.q_row, i0, s.L);
-    stage_rows<D, BQ>(dOs, dobase, g.do_row, i0, s.L);
-    stage_transposed<D, BQ>(Qt, qbase, a.q_row, i0, s.L);
-    stage_transposed<D, BQ>(dOt, dobase, g.do_row, i0, s.L);
+    if (!kPre) fetch_all(i0);
+    q_rows.commit(Qs, i0, s.L);
+    do_rows.commit(dOs, i0, s.L);
+    q_tr.commit(Qt, i0, s.L);
+    do_tr.commit(dOt, i0, s.L);
+    if (kDV) pin_agpr(acc_dv);
+    if (kDK) pin_agpr(acc_dk);
     __syncthreads();
+    if (kPre) {
+      const int nx = advance(i0);
+      if (nx < s.L) fetch_all(nx);
+    }
+    if (kDV) pin_agpr(acc_dv);
+    if (kDK) pin_agpr(acc_dk);
     if (!wave_live) continue;
-    (void)blk_last_key;
     // GEMM 1 / 2: S[q x keys] = Q K^T, dP[q x keys] = dO V^T (A from LDS rows, B = register fragments)
-    f32x16_t acc_s[BQ / 32], acc_p[BQ / 32];
+    f32x16_t acc_s[NT], acc_p[kDK ? NT : 1];
+    {
+      constexpr int SLB = (kDK ? 4 : 8) / NT < D / 16 ? (kDK ? 4 : 8) / NT : D / 16;   // slices per batch (~8 MFMAs)
+      constexpr int NBAT = (D / 16) / SLB;
+      bf16x8_t qa[2][SLB][NT], da[2][kDK ? SLB : 1][NT];
+      auto load_b = [&](int bi, int buf) {
 #pragma unroll
-    for (int t = 0; t < BQ / 32; ++t)
+        for (int u = 0; u < SLB; ++u)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc_s[t][r] = 0.f; acc_p[t][r] = 0.f; }
+          for (int t = 0; t < NT; ++t) {
+            const int off = (32 * t + l31) * RS + 16 * (SLB * bi + u) + 8 * hi;
+            qa[buf][u][t] = *reinterpret_cast<const bf16x8_t*>(Qs + off);
+            if (kDK) da[buf][u][t] = *reinterpret_cast<const bf16x8_t*>(dOs + off);
+          }
+      };
+      load_b(0, 0);
 #pragma unroll
-    for (int sl = 0; sl < D / 16; ++sl) {
+      for (int bi = 0; bi < NBAT; ++bi) {
+        if (bi + 1 < NBAT) load_b(bi + 1, (bi + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < BQ / 32; ++t) {
-        const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(Qs + (32 * t + l31) * RS + 16 * sl + 8 * hi);
-        const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(dOs + (32 * t + l31) * RS + 16 * sl + 8 * hi);
-        acc_s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[sl], acc_s[t], 0, 0, 0);
-        acc_p[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[sl], acc_p[t], 0, 0, 0);
+        for (int u = 0; u < SLB; ++u)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int sl = SLB * bi + u;
+            if (sl == 0) mfma_v0(acc_s[t], qa[bi & 1][u][t], kf[sl]);
+            else mfma_v(acc_s[t], qa[bi & 1][u][t], kf[sl]);
+            if (kDK) {
+              if (sl == 0) mfma_v0(acc_p[t], da[bi & 1][u][t], vf[sl]);
+              else mfma_v(acc_p[t], da[bi & 1][u][t], vf[sl]);
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    fence_v(acc_s);
+    if (kDK) fence_v(acc_p);
+    if (kDV) pin_agpr(acc_dv);
+    if (kDK) pin_agpr(acc_dk);
     // P and dS packed as B operands (k = query rows held in the registers, lane = key)
-    bf16x8_t pf[BQ / 16], sf[BQ / 16];
+    bf16x8_t pf[kDV ? BQ / 16 : 1], sf[kDK ? BQ / 16 : 1];
 #pragma unroll
-    for (int t = 0; t < BQ / 32; ++t) {
+    for (int t = 0; t < NT; ++t) {
       uint32_t pk[8], sk[8];
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
@@ -478,31 +637,67 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
         for (int u = 0; u < 2; ++u) {
           const int rr = r + u;
           const int qi = i0 + 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
-          const float x = acc_s[t][rr] * a.alpha;
-          const bool ok = attn_allowed(qi, kj, s, a.causal, a.group);
-          p2[u] = ok ? silu_f(x) * a.inv_scale : 0.f;
-          s2[u] = ok ? acc_p[t][rr] * dsilu_f(x) * (a.inv_scale * a.alpha) : 0.f;
+          bool ok;
+          if (plain) {
+            ok = a.causal ? (kj <= qi) : (kj < s.L);
+          } else {
+            const RowMask m = row_mask(qi, s, a.causal, a.group);
+            ok = key_ok(kj, m);
+          }
+          const float acc = acc_s[t][rr];
+          const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc * neg_alpha_log2e));
+          if (kDV) p2[u] = ok ? acc * c_p * sg : 0.f;
+          if (kDK) {
+            const float x = acc * a.alpha;
+            s2[u] = ok ? acc_p[t][rr] * c_ds * sg * (1.0f + x * (1.0f - sg)) : 0.f;
+          }
         }
-        pk[r >> 1] = pack_bf16(p2[0], p2[1]);
-        sk[r >> 1] = pack_bf16(s2[0], s2[1]);
+        if (kDV) pk[r >> 1] = pack_bf16(p2[0], p2[1]);
+        if (kDK) sk[r >> 1] = pack_bf16(s2[0], s2[1]);
       }
-      uint4 x0 = make_uint4(pk[0], pk[1], pk[2], pk[3]), x1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-      uint4 y0 = make_uint4(sk[0], sk[1], sk[2], sk[3]), y1 = make_uint4(sk[4], sk[5], sk[6], sk[7]);
-      pf[2 * t] = *reinterpret_cast<bf16x8_t*>(&x0); pf[2 * t + 1] = *reinterpret_cast<bf16x8_t*>(&x1);
-      sf[2 * t] = *reinterpret_cast<bf16x8_t*>(&y0); sf[2 * t + 1] = *reinterpret_cast<bf16x8_t*>(&y1);
+      if (kDV) {
+        const u32x4_t x0 = {pk[0], pk[1], pk[2], pk[3]}, x1 = {pk[4], pk[5], pk[6], pk[7]};
+        pf[2 * t] = __builtin_bit_cast(bf16x8_t, x0); pf[2 * t + 1] = __builtin_bit_cast(bf16x8_t, x1);
+      }
+      if (kDK) {
+        const u32x4_t y0 = {sk[0], sk[1], sk[2], sk[3]}, y1 = {sk[4], sk[5], sk[6], sk[7]};
+        sf[2 * t] = __builtin_bit_cast(bf16x8_t, y0); sf[2 * t + 1] = __builtin_bit_cast(bf16x8_t, y1);
+      }
     }
+    if (kDV) pin_agpr(acc_dv);
+    if (kDK) pin_agpr(acc_dk);
     // GEMM 3 / 4: dV^T[D x keys] += dO^T P, dK^T[D x keys] += Q^T dS
+    {
+      constexpr int NDT = D / 32;
+      constexpr int DB = (MODE == 0 ? 4 : 8) < NDT ? (MODE == 0 ? 4 : 8) : NDT;   // d tiles per batch (~8 MFMAs)
+      constexpr int NBAT2 = (BQ / 16) * (NDT / DB);
+      bf16x8_t fa[2][kDV ? DB : 1], fb[2][kDK ? DB : 1];
+      auto load_t = [&](int bi, int buf) {
+        const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
 #pragma unroll
-    for (int dt = 0; dt < D / 32; ++dt) {
+        for (int u = 0; u < DB; ++u) {
+          const int off = (32 * (dt0 + u) + l31) * TS + 16 * ks + 8 * hi;
+          if (kDV) fa[buf][u] = *reinterpret_cast<const bf16x8_t*>(dOt + off);
+          if (kDK) fb[buf][u] = *reinterpret_cast<const bf16x8_t*>(Qt + off);
+        }
+      };
+      load_t(0, 0);
 #pragma unroll
-      for (int ks = 0; ks < BQ / 16; ++ks) {
-        const bf16x8_t dot = *reinterpret_cast<const bf16x8_t*>(dOt + (32 * dt + l31) * TS + 16 * ks + 8 * hi);
-        const bf16x8_t qt = *reinterpret_cast<const bf16x8_t*>(Qt + (32 * dt + l31) * TS + 16 * ks + 8 * hi);
-        acc_dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pf[ks], acc_dv[dt], 0, 0, 0);
-        acc_dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, sf[ks], acc_dk[dt], 0, 0, 0);
+      for (int bi = 0; bi < NBAT2; ++bi) {
+        if (bi + 1 < NBAT2) load_t(bi + 1, (bi + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
+#pragma unroll
+        for (int u = 0; u < DB; ++u) {
+          if (kDV) mfma_a(acc_dv[dt0 + u], fa[bi & 1][u], pf[ks]);
+          if (kDK) mfma_a(acc_dk[dt0 + u], fb[bi & 1][u], sf[ks]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
+  if (kDV) fence_a(acc_dv);
+  if (kDK) fence_a(acc_dk);
   if (kj < s.L) {
     uint16_t* dvp = g.dv + ((int64_t)(s.start + kj) * a.H + h) * D;
     uint16_t* dkp = g.dk + ((int64_t)(s.start + kj) * a.H + h) * D;
@@ -511,12 +706,16 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         uint2 o;
-        o.x = pack_bf16(acc_dv[dt][4 * g4 + 0], acc_dv[dt][4 * g4 + 1]);
-        o.y = pack_bf16(acc_dv[dt][4 * g4 + 2], acc_dv[dt][4 * g4 + 3]);
-        *reinterpret_cast<uint2*>(dvp + 32 * dt + 8 * g4 + 4 * hi) = o;
-        o.x = pack_bf16(acc_dk[dt][4 * g4 + 0], acc_dk[dt][4 * g4 + 1]);
-        o.y = pack_bf16(acc_dk[dt][4 * g4 + 2], acc_dk[dt][4 * g4 + 3]);
-        *reinterpret_cast<uint2*>(dkp + 32 * dt + 8 * g4 + 4 * hi) = o;
+        if (kDV) {
+          o.x = pack_bf16(acc_dv[dt][4 * g4 + 0], acc_dv[dt][4 * g4 + 1]);
+          o.y = pack_bf16(acc_dv[dt][4 * g4 + 2], acc_dv[dt][4 * g4 + 3]);
+          *reinterpret_cast<uint2*>(dvp + 32 * dt + 8 * g4 + 4 * hi) = o;
+        }
+        if (kDK) {
+          o.x = pack_bf16(acc_dk[dt][4 * g4 + 0], acc_dk[dt][4 * g4 + 1]);
+          o.y = pack_bf16(acc_dk[dt][4 * g4 + 2], acc_dk[dt][4 * g4 + 3]);
+          *reinterpret_cast<uint2*>(dkp + 32 * dt + 8 * g4 + 4 * hi) = o;
+        }
       }
   }
 }
@@ -525,7 +724,7 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
 template <int D, int BK>
 __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
   const AttnArgs& a = g.f;
-  constexpr int RS = D + 8, TS = BK + 8;
+  constexpr int RS = D + 8, TS = BK + 8, NT = BK / 32;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   uint16_t* Ks = smem;               // [BK][RS]
   uint16_t* Vs = Ks + BK * RS;       // [BK][RS]
@@ -553,19 +752,13 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
   int w_end = s.L;
   if (a.causal) { w_end = w_last + 1; if (s.has_ctx && qrow0 < s.c && s.hlen > w_end) w_end = s.hlen; }
 
+  // Q / dO fragments of the wave's 32 queries; rows beyond the sequence read a clamped row and are never stored
   bf16x8_t qf[D / 16], dof[D / 16];
-  {
-    const int64_t tok = s.start + (qi < s.L ? qi : 0);
-    const uint16_t* qp = a.q + tok * a.q_row + (int64_t)h * a.q_head + 8 * hi;
-    const uint16_t* dp = g.dout + tok * g.do_row + (int64_t)h * g.do_head + 8 * hi;
-#pragma unroll
-    for (int sl = 0; sl < D / 16; ++sl) {
-      uint4 t0 = make_uint4(0, 0, 0, 0), t1 = make_uint4(0, 0, 0, 0);
-      if (qi < s.L) { t0 = *reinterpret_cast<const uint4*>(qp + 16 * sl); t1 = *reinterpret_cast<const uint4*>(dp + 16 * sl); }
-      qf[sl] = *reinterpret_cast<bf16x8_t*>(&t0);
-      dof[sl] = *reinterpret_cast<bf16x8_t*>(&t1);
-    }
-  }
+  load_own_frags<D>(qf, a.q + (int64_t)s.start * a.q_row + (int64_t)h * a.q_head, a.q_row, qi, s.L, hi);
+  load_own_frags<D>(dof, g.dout + (int64_t)s.start * g.do_row + (int64_t)h * g.do_head, g.do_row, qi, s.L, hi);
+  const RowMask rm = row_mask(qi < s.L ? qi : s.L - 1, s, a.causal, a.group);
+  const float neg_alpha_log2e = -a.alpha * 1.4426950408889634f;
+  const float c_ds = a.alpha * a.inv_scale;
   f32x16_t acc_dq[D / 32];
 #pragma unroll
   for (int dt = 0; dt < D / 32; ++dt)
@@ -574,31 +767,64 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
 
   const uint16_t* kbase = a.k + (int64_t)s.start * a.k_row + (int64_t)h * a.k_head;
   const uint16_t* vbase = a.v + (int64_t)s.start * a.v_row + (int64_t)h * a.v_head;
+  RowTile<D, BK> k_rows, v_rows;
+  TransTile<D, BK> k_tr;
+  auto fetch_all = [&](int n) {
+    k_rows.fetch(kbase, a.k_row, n, s.L);
+    v_rows.fetch(vbase, a.v_row, n, s.L);
+    k_tr.fetch(kbase, a.k_row, n, s.L);
+  };
+  constexpr bool kPre = D >= 256;
+  if (kPre && n_end > 0) fetch_all(0);
   for (int n0 = 0; n0 < n_end; n0 += BK) {
+    pin_agpr(acc_dq);
     __syncthreads();
-    stage_rows<D, BK>(Ks, kbase, a.k_row, n0, s.L);
-    stage_rows<D, BK>(Vs, vbase, a.v_row, n0, s.L);
-    stage_transposed<D, BK>(Kt, kbase, a.k_row, n0, s.L);
+    if (!kPre) fetch_all(n0);
+    k_rows.commit(Ks, n0, s.L);
+    v_rows.commit(Vs, n0, s.L);
+    k_tr.commit(Kt, n0, s.L);
+    pin_agpr(acc_dq);
     __syncthreads();
+    if (kPre && n0 + BK < n_end) fetch_all(n0 + BK);
+    pin_agpr(acc_dq);
     if (!wave_live || n0 >= w_end) continue;
-    f32x16_t acc_s[BK / 32], acc_p[BK / 32];
+    f32x16_t acc_s[NT], acc_p[NT];   // S^T, dP^T [keys x q]
+    {
+      constexpr int SLB = 4 / NT < D / 16 ? 4 / NT : D / 16;
+      constexpr int NBAT = (D / 16) / SLB;
+      bf16x8_t ka[2][SLB][NT], va[2][SLB][NT];
+      auto load_b = [&](int bi, int buf) {
 #pragma unroll
-    for (int t = 0; t < BK / 32; ++t)
+        for (int u = 0; u < SLB; ++u)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc_s[t][r] = 0.f; acc_p[t][r] = 0.f; }
+          for (int t = 0; t < NT; ++t) {
+            const int off = (32 * t + l31) * RS + 16 * (SLB * bi + u) + 8 * hi;
+            ka[buf][u][t] = *reinterpret_cast<const bf16x8_t*>(Ks + off);
+            va[buf][u][t] = *reinterpret_cast<const bf16x8_t*>(Vs + off);
+          }
+      };
+      load_b(0, 0);
 #pragma unroll
-    for (int sl = 0; sl < D / 16; ++sl) {
+      for (int bi = 0; bi < NBAT; ++bi) {
+        if (bi + 1 < NBAT) load_b(bi + 1, (bi + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < BK / 32; ++t) {
-        const bf16x8_t ka = *reinterpret_cast<const bf16x8_t*>(Ks + (32 * t + l31) * RS + 16 * sl + 8 * hi);
-        const bf16x8_t va = *reinterpret_cast<const bf16x8_t*>(Vs + (32 * t + l31) * RS + 16 * sl + 8 * hi);
-        acc_s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[sl], acc_s[t], 0, 0, 0);    // S^T[keys x q]
-        acc_p[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[sl], acc_p[t], 0, 0, 0);   // dP^T[keys x q]
+        for (int u = 0; u < SLB; ++u)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int sl = SLB * bi + u;
+            if (sl == 0) { mfma_v0(acc_s[t], ka[bi & 1][u][t], qf[sl]); mfma_v0(acc_p[t], va[bi & 1][u][t], dof[sl]); }
+            else { mfma_v(acc_s[t], ka[bi & 1][u][t], qf[sl]); mfma_v(acc_p[t], va[bi & 1][u][t], dof[sl]); }
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    fence_v(acc_s);
+    fence_v(acc_p);
+    pin_agpr(acc_dq);
     bf16x8_t sf[BK / 16];
 #pragma unroll
-    for (int t = 0; t < BK / 32; ++t) {
+    for (int t = 0; t < NT; ++t) {
       uint32_t sk[8];
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
@@ -607,23 +833,41 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
         for (int u = 0; u < 2; ++u) {
           const int rr = r + u;
           const int key = n0 + 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
-          const float x = acc_s[t][rr] * a.alpha;
-          s2[u] = attn_allowed(qi, key, s, a.causal, a.group) ? acc_p[t][rr] * dsilu_f(x) * (a.inv_scale * a.alpha) : 0.f;
+          const float acc = acc_s[t][rr];
+          const float x = acc * a.alpha;
+          const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc * neg_alpha_log2e));
+          s2[u] = key_ok(key, rm) ? acc_p[t][rr] * c_ds * sg * (1.0f + x * (1.0f - sg)) : 0.f;
         }
         sk[r >> 1] = pack_bf16(s2[0], s2[1]);
       }
-      uint4 y0 = make_uint4(sk[0], sk[1], sk[2], sk[3]), y1 = make_uint4(sk[4], sk[5], sk[6], sk[7]);
-      sf[2 * t] = *reinterpret_cast<bf16x8_t*>(&y0); sf[2 * t + 1] = *reinterpret_cast<bf16x8_t*>(&y1);
+      const u32x4_t y0 = {sk[0], sk[1], sk[2], sk[3]}, y1 = {sk[4], sk[5], sk[6], sk[7]};
+      sf[2 * t] = __builtin_bit_cast(bf16x8_t, y0); sf[2 * t + 1] = __builtin_bit_cast(bf16x8_t, y1);
     }
+    pin_agpr(acc_dq);
+    {
+      constexpr int NDT = D / 32;
+      constexpr int DB = 8 < NDT ? 8 : NDT;
+      constexpr int NBAT2 = (BK / 16) * (NDT / DB);
+      bf16x8_t fk[2][DB];
+      auto load_t = [&](int bi, int buf) {
+        const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
 #pragma unroll
-    for (int dt = 0; dt < D / 32; ++dt) {
+        for (int u = 0; u < DB; ++u)
+          fk[buf][u] = *reinterpret_cast<const bf16x8_t*>(Kt + (32 * (dt0 + u) + l31) * TS + 16 * ks + 8 * hi);
+      };
+      load_t(0, 0);
 #pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        const bf16x8_t kt = *reinterpret_cast<const bf16x8_t*>(Kt + (32 * dt + l31) * TS + 16 * ks + 8 * hi);
-        acc_dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, sf[ks], acc_dq[dt], 0, 0, 0);  // dQ^T[D x q]
+      for (int bi = 0; bi < NBAT2; ++bi) {
+        if (bi + 1 < NBAT2) load_t(bi + 1, (bi + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
+#pragma unroll
+        for (int u = 0; u < DB; ++u) mfma_a(acc_dq[dt0 + u], fk[bi & 1][u], sf[ks]);   // dQ^T[D x q]
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
+  fence_a(acc_dq);
   if (qi < s.L) {
     uint16_t* dqp = g.dq + ((int64_t)(s.start + qi) * a.H + h) * D;
 #pragma unroll
@@ -638,20 +882,34 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
   }
 }
 
+template <int D, int BQ, int MODE>
+static void launch_bwd_kv(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
+  constexpr bool kDV = MODE != 2, kDK = MODE != 1;
+  const size_t smem = (size_t)(BQ * (D + 8) + (kDK ? BQ * (D + 8) + D * (BQ + 8) : 0) + (kDV ? D * (BQ + 8) : 0)) * sizeof(uint16_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_kv_kernel<D, BQ, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((hstu_bwd_kv_kernel<D, BQ, MODE>), grid, dim3(256), smem, stream, g);
+}
+
 template <int D>
 static int launch_bwd(const BwdAttnArgs& g, int B, int max_seqlen, hipStream_t stream) {
-  constexpr int BQ = D >= 256 ? 32 : 64;
-  constexpr int BK = 64;
-  const size_t smem_kv = (size_t)(2 * BQ * (D + 8) + 2 * D * (BQ + 8)) * sizeof(uint16_t);
+  constexpr int BK = D >= 256 ? 32 : 64;
   const size_t smem_q = (size_t)(2 * BK * (D + 8) + D * (BK + 8)) * sizeof(uint16_t);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_kv_kernel<D, BQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_kv);
     hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_q_kernel<D, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_q);
     attr_set = true;
   }
   dim3 grid((max_seqlen + kBM - 1) / kBM, g.f.H, B);
-  hipLaunchKernelGGL((hstu_bwd_kv_kernel<D, BQ>), grid, dim3(256), smem_kv, stream, g);
+  if constexpr (D >= 128) {
+    launch_bwd_kv<D, 64, 1>(g, grid, stream);
+    launch_bwd_kv<D, 32, 2>(g, grid, stream);
+  } else {
+    launch_bwd_kv<D, 64, 0>(g, grid, stream);
+  }
   hipLaunchKernelGGL((hstu_bwd_q_kernel<D, BK>), grid, dim3(256), smem_q, stream, g);
   MI355_LAUNCH_CHECK();
   return MI355_OK;

@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librecsys_amd.so")
+LIB_PATH = os.environ.get("MI355_LIB", os.path.join(_HERE, "lib", "librecsys_amd.so"))
 
 c_i64 = ctypes.c_int64
 c_u64 = ctypes.c_uint64
