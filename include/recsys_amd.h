@@ -125,6 +125,13 @@ int mi355_segmented_unique(const void* keys, int64_t n, const int64_t* segmented
                            const int64_t* input_frequencies, int count_freq, void* unique_keys,
                            int64_t* output_indices, int64_t* table_offsets, int64_t* freq, void* workspace,
                            int64_t workspace_bytes, hipStream_t stream);
+/* Same, and (both nullable) csr_cnt int32[n]: occurrences of unique key u in the batch; csr_rank int32[n]: position of
+ * occurrence i inside the list of its unique key (a permutation of 0..cnt-1 per key, order unspecified).  They let
+ * mi355_group_by_unique_csr build the backward's CSR with a scan and a scatter -- no histogram pass, no atomics. */
+int mi355_segmented_unique_csr(const void* keys, int64_t n, const int64_t* segmented_range, int64_t num_tables,
+                               const int64_t* input_frequencies, int count_freq, void* unique_keys,
+                               int64_t* output_indices, int64_t* table_offsets, int64_t* freq, int32_t* csr_cnt,
+                               int32_t* csr_rank, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* expand_table_ids_cuda, src/unique_op.cu:719-750 */
 int mi355_expand_table_ids(const int64_t* offsets, int64_t num_tables, int64_t n, const int64_t* n_dev,
@@ -153,6 +160,11 @@ int mi355_group_by_unique(const int64_t* reverse_indices, int64_t n, const int64
                           int64_t max_unique, const int64_t* nu_dev, int32_t* ptr, int32_t* csr_src,
                           void* workspace, int64_t workspace_bytes, void* hot_workspace,
                           int64_t hot_workspace_bytes, int64_t dim, hipStream_t stream);
+int64_t mi355_group_by_unique_csr_workspace_bytes(int64_t max_unique);
+int mi355_group_by_unique_csr(const int32_t* csr_cnt, const int32_t* csr_rank, const int64_t* reverse_indices, int64_t n,
+                              const int64_t* offsets, int64_t num_bags, int64_t max_unique, const int64_t* nu_dev,
+                              int32_t* ptr, int32_t* csr_src, void* workspace, int64_t workspace_bytes,
+                              void* hot_workspace, int64_t hot_workspace_bytes, int64_t dim, hipStream_t stream);
 
 /* block_bucketize_sparse_features, src/sparse_block_bucketize_features.cu:220-350,366-830:
  * dist_type per feature 0 continuous / 1 roundrobin / 2 hash_roundrobin; offsets has num_bags+1 entries
@@ -268,8 +280,8 @@ int mi355_demb_forward(void* storage, const int64_t* table_bucket_offsets, int64
                        float p1, float p2, float p3, uint64_t seed, float state_init, int combiner,
                        const int32_t* D_offsets, int64_t total_D, void* out, int out_dtype, int aligned16,
                        int64_t* reverse_indices, int64_t* unique_offsets, int64_t* table_ids, int64_t* slots,
-                       int64_t* row_addr, int64_t* freq, void* workspace, int64_t workspace_bytes,
-                       hipStream_t stream);
+                       int64_t* row_addr, int64_t* freq, int32_t* csr_cnt /* nullable */,
+                       int32_t* csr_rank /* nullable */, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* One-call backward: DynamicEmbeddingFunction.backward (batched_dynamicemb_function.py:1193-1300):
  * reduce_grads + optimizer.fused_update_for_flat_table + decrement_counter. */
@@ -281,8 +293,9 @@ int mi355_demb_backward(const int64_t* reverse_indices, int64_t num_keys, const 
                         float beta1, float beta2, float eps, float weight_decay, int64_t iter_num,
                         int64_t state_offset, int round_grad, int aligned16, int32_t* counter,
                         int64_t counter_numel, const int64_t* slots, const int64_t* table_ids,
-                        const int64_t* table_bucket_offsets, int64_t bucket_capacity, int unpin, void* workspace,
-                        int64_t workspace_bytes, hipStream_t stream);
+                        const int64_t* table_bucket_offsets, int64_t bucket_capacity, int unpin,
+                        const int32_t* csr_cnt, const int32_t* csr_rank /* from the forward, or both NULL */,
+                        void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* ---------------------------------------------------------------- HSTU jagged attention ---- */
 

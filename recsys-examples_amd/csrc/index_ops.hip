@@ -21,6 +21,7 @@
 //    hottest row of a Zipf stream costs (#tiles) atomics instead of (#occurrences).
 #include "common.h"
 #include "hot.h"
+#include "../../include/recsys_amd.h"
 
 namespace mi355 {
 
@@ -69,9 +70,9 @@ __device__ __forceinline__ int upper_bound_i64(const int64_t* __restrict__ a, in
 // segmented unique
 // ---------------------------------------------------------------------------------------------
 struct UniqWs {
-  int* slots;    // [2n]   open-addressing set, value = representative input position, -1 empty
-  int* rep;      // [n]    slot of key i, then representative (min position) of key i
-  int* uid_of;   // [n]    unique id of position i (valid where rep[i] == i)
+  int* slots;    // [2n]   open-addressing set, value = representative (smallest) input position, -1 empty
+  int* gcnt;     // [2n]   per slot: occurrences - 1 (starts at -1, same fill byte as slots); later the unique id
+  int* rep;      // [n]    slot of key i
   int* partial;  // [nb+1] per-tile counts of first occurrences, then exclusive offsets
   int* total;    // [1]
 };
@@ -84,14 +85,17 @@ constexpr int kUniqTile = 1024;
 constexpr int kUniqLds = 2048;
 
 __global__ void __launch_bounds__(256)
-uniq_insert_kernel(const uint64_t* __restrict__ keys, int64_t n, const int64_t* __restrict__ seg, int T, UniqWs ws) {
+uniq_insert_kernel(const uint64_t* __restrict__ keys, int64_t n, const int64_t* __restrict__ seg, int T, UniqWs ws,
+                   int* __restrict__ csr_rank) {
   __shared__ uint64_t s_key[kUniqTile];
   __shared__ int s_tab[kUniqLds];   // tile-local position of the representative, -1 empty
   __shared__ int s_pos[kUniqLds];   // global slot of that representative
+  __shared__ int s_cnt[kUniqLds];   // occurrences of the key inside the tile
+  __shared__ int s_base[kUniqLds];  // occurrences of the key in the tiles that got to the global counter first
   __shared__ int s_t[kUniqTile];    // table of each key of the tile
   const int64_t tile0 = (int64_t)blockIdx.x * kUniqTile;
-  for (int s = threadIdx.x; s < kUniqLds; s += blockDim.x) s_tab[s] = -1;
-  int hh[kUniqTile / 256];
+  for (int s = threadIdx.x; s < kUniqLds; s += blockDim.x) { s_tab[s] = -1; s_cnt[s] = 0; }
+  int hh[kUniqTile / 256], rk[kUniqTile / 256];
 #pragma unroll
   for (int q = 0; q < kUniqTile / 256; ++q) {
     const int li = q * 256 + threadIdx.x;
@@ -114,6 +118,7 @@ uniq_insert_kernel(const uint64_t* __restrict__ keys, int64_t n, const int64_t* 
         h = (h + 1) & (kUniqLds - 1);
       }
       hh[q] = h;
+      rk[q] = atomicAdd(&s_cnt[h], 1);   // rank of this occurrence inside the tile (arbitrary but unique)
     }
   }
   __syncthreads();
@@ -147,17 +152,23 @@ uniq_insert_kernel(const uint64_t* __restrict__ keys, int64_t n, const int64_t* 
         pos = base + off;
       }
       s_pos[hh[q]] = (int)pos;
+      // one counter update per distinct key per tile; the value before it places this tile's occurrences in
+      // the key's list (counter starts at -1: see UniqWs::gcnt)
+      s_base[hh[q]] = atomicAdd(&ws.gcnt[pos], s_cnt[hh[q]]) + 1;
     }
   }
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < kUniqTile / 256; ++q) {
     const int li = q * 256 + threadIdx.x;
-    if (hh[q] >= 0) ws.rep[tile0 + li] = s_pos[hh[q]];
+    if (hh[q] >= 0) {
+      ws.rep[tile0 + li] = s_pos[hh[q]];
+      if (csr_rank) csr_rank[tile0 + li] = s_base[hh[q]] + rk[q];
+    }
   }
 }
 
-// rep[i] <- slots[rep[i]]; count first occurrences per 1024-tile
+// count first occurrences (slots[rep[i]] == i) per 1024-tile
 __global__ void __launch_bounds__(kScanThreads)
 uniq_flag_kernel(int64_t n, UniqWs ws) {
   const int64_t tile0 = (int64_t)blockIdx.x * kScanTile;
@@ -166,9 +177,7 @@ uniq_flag_kernel(int64_t n, UniqWs ws) {
   for (int k = 0; k < kScanItems; ++k) {
     int64_t i = tile0 + threadIdx.x * kScanItems + k;
     if (i < n) {
-      int r = ws.slots[ws.rep[i]];
-      ws.rep[i] = r;
-      c += (r == (int)i);
+      c += (ws.slots[ws.rep[i]] == (int)i);
     }
   }
   int tot;
@@ -177,7 +186,7 @@ uniq_flag_kernel(int64_t n, UniqWs ws) {
 }
 
 // single block: exclusive scan of `partial[0..nb)` in place, total -> *total
-__global__ void __launch_bounds__(kScanThreads) scan_partials_kernel(int* partial, int64_t nb, int* total) {
+__device__ __forceinline__ void scan_partials_body(int* partial, int64_t nb, int* total) {
   __shared__ int s_carry;
   if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
@@ -194,18 +203,27 @@ __global__ void __launch_bounds__(kScanThreads) scan_partials_kernel(int* partia
   }
   if (threadIdx.x == 0) *total = s_carry;
 }
+__global__ void __launch_bounds__(kScanThreads) scan_partials_kernel(int* partial, int64_t nb, int* total) {
+  scan_partials_body(partial, nb, total);
+}
+// same, and clears the two counters of a hot-row list on the way (saves a memset launch)
+__global__ void __launch_bounds__(kScanThreads) scan_partials_clear_kernel(int* partial, int64_t nb, int* total, int* c0, int* c1) {
+  if (threadIdx.x == 0) { *c0 = 0; *c1 = 0; }
+  scan_partials_body(partial, nb, total);
+}
 
 template <bool kFreq>
 __global__ void __launch_bounds__(kScanThreads)
 uniq_emit_kernel(const uint64_t* __restrict__ keys, int64_t n, const int64_t* __restrict__ seg, int T, UniqWs ws,
-                 uint64_t* __restrict__ unique_keys, int64_t* __restrict__ table_offsets, int64_t* __restrict__ freq) {
+                 uint64_t* __restrict__ unique_keys, int64_t* __restrict__ table_offsets, int64_t* __restrict__ freq,
+                 const int64_t* __restrict__ in_freq, int* __restrict__ csr_cnt) {
   const int64_t tile0 = (int64_t)blockIdx.x * kScanTile;
   int f[kScanItems];
   int c = 0;
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
     int64_t i = tile0 + threadIdx.x * kScanItems + k;
-    f[k] = (i < n) && (ws.rep[i] == (int)i);
+    f[k] = (i < n) && (ws.slots[ws.rep[i]] == (int)i);
     c += f[k];
   }
   int tot;
@@ -219,8 +237,11 @@ uniq_emit_kernel(const uint64_t* __restrict__ keys, int64_t n, const int64_t* __
       while (t >= 0 && seg[t] == i) { table_offsets[t] = ex; --t; }
       if (f[k]) {
         unique_keys[ex] = keys[i];
-        ws.uid_of[i] = ex;
-        if (kFreq) freq[ex] = 0;
+        const int slot = ws.rep[i];
+        const int occ = ws.gcnt[slot] + 1;   // only this thread reads the slot's counter: it may now hold the id
+        ws.gcnt[slot] = ex;
+        if (csr_cnt) csr_cnt[ex] = occ;
+        if (kFreq) freq[ex] = in_freq ? 0 : occ;
         ++ex;
       }
     }
@@ -236,9 +257,9 @@ __global__ void __launch_bounds__(256)
 uniq_finish_kernel(int64_t n, UniqWs ws, const int64_t* __restrict__ in_freq, int64_t* __restrict__ output_indices,
                    int64_t* __restrict__ freq) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int u = ws.uid_of[ws.rep[i]];
+    const int u = ws.gcnt[ws.rep[i]];
     output_indices[i] = u;
-    if (kFreq) atomicAdd((unsigned long long*)&freq[u], (unsigned long long)(in_freq ? in_freq[i] : 1));
+    if (kFreq && in_freq) atomicAdd((unsigned long long*)&freq[u], (unsigned long long)in_freq[i]);
   }
 }
 
@@ -513,6 +534,73 @@ csr_fill_kernel(const int64_t* __restrict__ rev, int64_t n, const int64_t* __res
   }
 }
 
+// pass 2 when the forward already ranked every occurrence inside its unique row (mi355_segmented_unique_csr):
+// csr_src[ptr[rev[j]] + rank[j]] = src id of key j.  No atomics, no LDS hash; the bag resolution and the hot-row task
+// expansion are those of csr_fill_kernel.
+__global__ void __launch_bounds__(256)
+csr_scatter_kernel(const int64_t* __restrict__ rev, const int* __restrict__ rank, int64_t n, const int64_t* __restrict__ offsets,
+                   int64_t num_bags, const int* __restrict__ ptr, int* __restrict__ csr_src, HotList hot, bool build_hot) {
+  if (build_hot) {
+    int nh = *hot.n_hot;
+    nh = nh < hot.max_hot ? nh : hot.max_hot;
+    for (int h = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); h < nh; h += gridDim.x * (blockDim.x >> 6)) {
+      const int nch = hot.hot_nchunks[h], t0 = hot.hot_t0[h], lo = hot.hot_lo[h], cnt = hot.hot_cnt[h], u = hot.hot_u[h];
+      if (t0 + nch > hot.max_tasks) continue;
+      for (int cc = lane_id(); cc < nch; cc += 64) {
+        hot.task_u[t0 + cc] = u;
+        hot.task_h[t0 + cc] = h;
+        hot.task_lo[t0 + cc] = lo + cc * hot.kchunk;
+        const int hi = lo + (cc + 1) * hot.kchunk;
+        hot.task_hi[t0 + cc] = hi < lo + cnt ? hi : lo + cnt;
+      }
+      for (int e = lane_id(); e < hot.dim; e += 64) hot.hot_acc[(int64_t)h * hot.dim + e] = 0.f;
+    }
+  }
+  __shared__ int s_bag[kHistTile];
+  __shared__ int s_range[2];
+  __shared__ int s_wmax[4];
+  const int64_t tile0 = (int64_t)blockIdx.x * kHistTile;
+  const int64_t tile_end = tile0 + kHistTile < n ? tile0 + kHistTile : n;
+  if (offsets) {
+    for (int k = threadIdx.x; k < kHistTile; k += blockDim.x) s_bag[k] = -1;
+    if (threadIdx.x == 0 || threadIdx.x == 64) {
+      const int64_t key = threadIdx.x == 0 ? tile0 : tile_end - 1;
+      int lo = 0, hi = (int)num_bags;  // first idx with offsets[idx] > key
+      while (lo < hi) { int mid = (lo + hi) >> 1; if (offsets[mid] <= key) lo = mid + 1; else hi = mid; }
+      s_range[threadIdx.x == 0 ? 0 : 1] = lo - 1;
+    }
+    __syncthreads();
+    const int b_lo = s_range[0], b_hi = s_range[1];
+    for (int b = b_lo + threadIdx.x; b <= b_hi; b += blockDim.x) {
+      const int64_t o0 = offsets[b], o1 = offsets[b + 1];
+      if (o1 > o0) { const int64_t p = o0 > tile0 ? o0 - tile0 : 0; if (p < kHistTile) s_bag[p] = b; }
+    }
+    __syncthreads();
+    int v[4];
+    int m = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = s_bag[threadIdx.x * 4 + k]; m = v[k] > m ? v[k] : m; v[k] = m; }
+    int incl = m;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { int o = __shfl_up(incl, off, 64); if (lane_id() >= off) incl = o > incl ? o : incl; }
+    if (lane_id() == 63) s_wmax[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int base = -1;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base = s_wmax[w] > base ? s_wmax[w] : base;
+    int prev = __shfl_up(incl, 1, 64);
+    if (lane_id() == 0) prev = -1;
+    prev = prev > base ? prev : base;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_bag[threadIdx.x * 4 + k] = v[k] > prev ? v[k] : prev;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < kHistTile / 256; ++q) {
+    const int64_t j = tile0 + q * 256 + threadIdx.x;
+    if (j < n) csr_src[ptr[rev[j]] + rank[j]] = offsets ? s_bag[q * 256 + threadIdx.x] : (int)j;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // row-wise key -> rank routing before the key all-to-all (sparse_block_bucketize_features.cu:220-350)
 // ---------------------------------------------------------------------------------------------
@@ -705,13 +793,21 @@ extern "C" {
 
 int64_t mi355_segmented_unique_workspace_bytes(int64_t n) {
   int64_t nb = ceil_div(n > 0 ? n : 1, kScanTile);
-  return align_up(8 * n, 256) + 2 * align_up(4 * n, 256) + align_up(4 * (nb + 1), 256) + 256;
+  return 2 * align_up(8 * n, 256) + align_up(4 * n, 256) + align_up(4 * (nb + 1), 256) + 256;
 }
 
 int mi355_segmented_unique(const void* keys, int64_t n, const int64_t* segmented_range, int64_t num_tables,
                            const int64_t* input_frequencies, int count_freq, void* unique_keys,
                            int64_t* output_indices, int64_t* table_offsets, int64_t* freq, void* workspace,
                            int64_t workspace_bytes, hipStream_t stream) {
+  return mi355_segmented_unique_csr(keys, n, segmented_range, num_tables, input_frequencies, count_freq, unique_keys,
+                                    output_indices, table_offsets, freq, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+int mi355_segmented_unique_csr(const void* keys, int64_t n, const int64_t* segmented_range, int64_t num_tables,
+                               const int64_t* input_frequencies, int count_freq, void* unique_keys,
+                               int64_t* output_indices, int64_t* table_offsets, int64_t* freq, int32_t* csr_cnt,
+                               int32_t* csr_rank, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   MI355_CHECK_ARG(num_tables > 0, "num_tables must be positive");
   MI355_CHECK_ARG(n < 0x7fffffffLL / 2, "num_keys must be < 2^30");
   if (n == 0) {
@@ -725,24 +821,26 @@ int mi355_segmented_unique(const void* keys, int64_t n, const int64_t* segmented
   uint8_t* w = (uint8_t*)workspace;
   UniqWs ws;
   ws.slots = (int*)w; w += align_up(8 * n, 256);
+  ws.gcnt = (int*)w; w += align_up(8 * n, 256);
   ws.rep = (int*)w; w += align_up(4 * n, 256);
-  ws.uid_of = (int*)w; w += align_up(4 * n, 256);
   ws.partial = (int*)w; w += align_up(4 * (nb + 1), 256);
   ws.total = (int*)w;
-  if (hipMemsetAsync(ws.slots, 0xFF, 8 * n, stream) != hipSuccess) { mi355_set_error("memset failed"); return MI355_ELAUNCH; }
+  // slots and counters are adjacent and share the fill byte: one memset
+  if (hipMemsetAsync(ws.slots, 0xFF, 2 * align_up(8 * n, 256), stream) != hipSuccess) { mi355_set_error("memset failed"); return MI355_ELAUNCH; }
   const uint64_t* k = (const uint64_t*)keys;
   const int T = (int)num_tables;
-  hipLaunchKernelGGL(uniq_insert_kernel, dim3((unsigned)ceil_div(n, kUniqTile)), dim3(256), 0, stream, k, n, segmented_range, T, ws);
+  hipLaunchKernelGGL(uniq_insert_kernel, dim3((unsigned)ceil_div(n, kUniqTile)), dim3(256), 0, stream, k, n, segmented_range, T, ws,
+                     csr_rank);
   hipLaunchKernelGGL(uniq_flag_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, n, ws);
   hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, stream, ws.partial, nb, ws.total);
   if (count_freq) {
     hipLaunchKernelGGL(uniq_emit_kernel<true>, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, k, n, segmented_range, T, ws,
-                       (uint64_t*)unique_keys, table_offsets, freq);
+                       (uint64_t*)unique_keys, table_offsets, freq, input_frequencies, csr_cnt);
     hipLaunchKernelGGL(uniq_finish_kernel<true>, dim3(grid_for(n, 256, 256 * 32)), dim3(256), 0, stream, n, ws, input_frequencies,
                        output_indices, freq);
   } else {
     hipLaunchKernelGGL(uniq_emit_kernel<false>, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, k, n, segmented_range, T, ws,
-                       (uint64_t*)unique_keys, table_offsets, freq);
+                       (uint64_t*)unique_keys, table_offsets, freq, input_frequencies, csr_cnt);
     hipLaunchKernelGGL(uniq_finish_kernel<false>, dim3(grid_for(n, 256, 256 * 32)), dim3(256), 0, stream, n, ws, input_frequencies,
                        output_indices, freq);
   }
@@ -827,6 +925,38 @@ int mi355_group_by_unique(const int64_t* reverse_indices, int64_t n, const int64
                      hot, hot_workspace != nullptr);
   if (n > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, reverse_indices, n, offsets,
                                 num_bags, ptr, cursor, csr_src, hot, hot_workspace != nullptr);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+// CSR from the counts / ranks produced by mi355_segmented_unique_csr: scan + scatter, no atomics.
+int64_t mi355_group_by_unique_csr_workspace_bytes(int64_t max_unique) {
+  return align_up(4 * (ceil_div(max_unique + 1, kScanTile) + 1), 256) + 256;
+}
+int mi355_group_by_unique_csr(const int32_t* csr_cnt, const int32_t* csr_rank, const int64_t* reverse_indices, int64_t n,
+                              const int64_t* offsets, int64_t num_bags, int64_t max_unique, const int64_t* nu_dev,
+                              int32_t* ptr, int32_t* csr_src, void* workspace, int64_t workspace_bytes,
+                              void* hot_workspace, int64_t hot_workspace_bytes, int64_t dim, hipStream_t stream) {
+  MI355_CHECK_ARG(n < 0x7fffffffLL && max_unique < 0x7fffffffLL, "n must be < 2^31");
+  MI355_CHECK_ARG(workspace && workspace_bytes >= mi355_group_by_unique_csr_workspace_bytes(max_unique), "workspace too small");
+  MI355_CHECK_ARG(csr_cnt && csr_rank, "counts and ranks required");
+  const int64_t nbu = ceil_div(max_unique + 1, kScanTile);
+  int* partial = (int*)workspace;
+  int* total = (int*)((uint8_t*)workspace + align_up(4 * (nbu + 1), 256));
+  HotList hot{};
+  if (hot_workspace) {
+    MI355_CHECK_ARG(hot_workspace_bytes >= hot_bytes(n, dim), "hot workspace too small");
+    hot = hot_carve(hot_workspace, n, dim);
+  }
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, csr_cnt, max_unique, nu_dev, partial);
+  if (hot_workspace)
+    hipLaunchKernelGGL(scan_partials_clear_kernel, dim3(1), dim3(kScanThreads), 0, stream, partial, nbu, total, hot.n_hot, hot.n_tasks);
+  else
+    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, stream, partial, nbu, total);
+  hipLaunchKernelGGL(scan_down_kernel, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, csr_cnt, max_unique, nu_dev, partial, total, ptr,
+                     hot, hot_workspace != nullptr);
+  if (n > 0) hipLaunchKernelGGL(csr_scatter_kernel, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, reverse_indices, csr_rank, n,
+                                offsets, num_bags, ptr, csr_src, hot, hot_workspace != nullptr);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }

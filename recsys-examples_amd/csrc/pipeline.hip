@@ -43,6 +43,7 @@ int mi355_demb_forward(
     /* output */ int combiner, const int32_t* D_offsets, int64_t total_D, void* out, int out_dtype, int aligned16,
     /* persisted */ int64_t* reverse_indices, int64_t* unique_offsets, int64_t* table_ids, int64_t* slots,
     int64_t* row_addr, int64_t* freq /* nullable: per-unique occurrence counts (LFU scores) */,
+    int32_t* csr_cnt, int32_t* csr_rank /* nullable: CSR ingredients for mi355_demb_backward */,
     /* scratch */ void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   MI355_CHECK_ARG(workspace && workspace_bytes >= mi355_demb_forward_workspace_bytes(num_keys, num_tables),
                   "workspace too small");
@@ -58,8 +59,8 @@ int mi355_demb_forward(
   int rc;
 #define STEP(call) do { rc = (call); if (rc != MI355_OK) return rc; } while (0)
   STEP(mi355_get_table_range(offsets, feature_offsets, num_tables, num_bags, table_range, stream));
-  STEP(mi355_segmented_unique(keys, num_keys, table_range, num_tables, nullptr, freq ? 1 : 0, unique_keys, reverse_indices,
-                              unique_offsets, freq, uws, uws_bytes, stream));
+  STEP(mi355_segmented_unique_csr(keys, num_keys, table_range, num_tables, nullptr, freq ? 1 : 0, unique_keys, reverse_indices,
+                                  unique_offsets, freq, csr_cnt, csr_rank, uws, uws_bytes, stream));
   if (!find_scores) find_scores = freq;      // LFU: scores are the occurrence counts of this batch
   if (!insert_scores) insert_scores = freq;
   if (num_keys > 0) {
@@ -108,6 +109,7 @@ int mi355_demb_backward(
     int round_grad, int aligned16,
     /* unpin */ int32_t* counter, int64_t counter_numel, const int64_t* slots, const int64_t* table_ids,
     const int64_t* table_bucket_offsets, int64_t bucket_capacity, int unpin,
+    /* CSR ingredients persisted by the forward (both or neither) */ const int32_t* csr_cnt, const int32_t* csr_rank,
     void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   MI355_CHECK_ARG(workspace && workspace_bytes >= mi355_demb_backward_workspace_bytes(num_keys, dim), "workspace too small");
   if (num_keys == 0) return MI355_OK;
@@ -121,8 +123,12 @@ int mi355_demb_backward(
   const int64_t bws_bytes = mi355_backward_workspace_bytes(num_keys, dim);
   const int64_t* nu_dev = unique_offsets + num_tables;
   int rc;
-  rc = mi355_group_by_unique(reverse_indices, num_keys, combiner >= 0 ? offsets : nullptr, num_bags, num_keys, nu_dev, ptr,
-                             csr, gws, gws_bytes, bws, bws_bytes, dim, stream);
+  if (csr_cnt && csr_rank)
+    rc = mi355_group_by_unique_csr(csr_cnt, csr_rank, reverse_indices, num_keys, combiner >= 0 ? offsets : nullptr, num_bags,
+                                   num_keys, nu_dev, ptr, csr, gws, gws_bytes, bws, bws_bytes, dim, stream);
+  else
+    rc = mi355_group_by_unique(reverse_indices, num_keys, combiner >= 0 ? offsets : nullptr, num_bags, num_keys, nu_dev, ptr,
+                               csr, gws, gws_bytes, bws, bws_bytes, dim, stream);
   if (rc != MI355_OK) return rc;
   rc = mi355_backward_fused(ptr, csr, num_keys, num_keys, nu_dev, grads, grad_stride, grad_dtype, offsets, D_offsets,
                             batch_size, dim, combiner, row_addr, value_dtype, opt_kind, lr, beta1, beta2, eps, weight_decay,

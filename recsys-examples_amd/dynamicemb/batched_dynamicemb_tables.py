@@ -37,7 +37,8 @@ _OPT_KIND = {"SGD": 1, "EXACT_SGD": 1, "ADAM": 2, "EXACT_ADAGRAD": 3, "EXACT_ROW
 class _StepCtx:
     """What one forward leaves for its backward (the reference's PrefetchState + autograd ctx)."""
 
-    __slots__ = ("rev", "uoff", "tids", "slots", "row_addr", "offsets", "num_keys", "batch_size", "num_bags")
+    __slots__ = ("rev", "uoff", "tids", "slots", "row_addr", "offsets", "num_keys", "batch_size", "num_bags", "csr_cnt",
+                 "csr_rank")
 
 
 class _LookupFunction(torch.autograd.Function):
@@ -209,6 +210,9 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         st.tids = torch.empty(n, dtype=torch.int64, device=dev)
         st.slots = torch.empty(n, dtype=torch.int64, device=dev)
         st.row_addr = torch.empty(n, dtype=torch.int64, device=dev)
+        # CSR ingredients for the backward (occurrences per unique row, rank of every key inside its row's list)
+        st.csr_cnt = torch.empty(n, dtype=torch.int32, device=dev) if train else None
+        st.csr_rank = torch.empty(n, dtype=torch.int32, device=dev) if train else None
         st.offsets, st.num_keys, st.batch_size, st.num_bags = offsets, n, B, num_bags
         if pooled:
             out = torch.empty(B, self.total_D, dtype=self.output_dtype, device=dev)
@@ -233,7 +237,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             mode, c_f(p[0]), c_f(p[1]), c_f(p[2]), c_f(p[3]), c_u64(self._seed), c_f(state_init),
             combiner, ptr(self.D_offsets_t), self.total_D, ptr(out), dt(out), int(al),
             ptr(st.rev), ptr(st.uoff), ptr(st.tids), ptr(st.slots), ptr(st.row_addr), ptr(freq),
-            ptr(ws), ws.numel(), stream()), "demb_forward")
+            ptr(st.csr_cnt), ptr(st.csr_rank), ptr(ws), ws.numel(), stream()), "demb_forward")
         if train:
             self._step += 1
             if self._dynamicemb_options[0].safe_check_mode != DynamicEmbCheckMode.IGNORE:
@@ -266,7 +270,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             dt(self.embedding_dtype), self._opt_kind, c_f(self.learning_rate), c_f(self.beta1), c_f(self.beta2),
             c_f(self.eps), c_f(self.weight_decay), self._iter_num, -1, 1, int(al),
             ptr(tb._ref_counter), tb._ref_counter.numel(), ptr(st.slots), ptr(st.tids), ptr(tb.table_bucket_offsets_),
-            tb.bucket_capacity_, int(self._pin), ptr(ws), ws.numel(), stream()), "demb_backward")
+            tb.bucket_capacity_, int(self._pin), ptr(st.csr_cnt), ptr(st.csr_rank), ptr(ws), ws.numel(), stream()),
+            "demb_backward")
 
     def forward(self, indices: torch.Tensor, offsets: torch.Tensor, per_sample_weights=None,
                 feature_requires_grad=None, batch_size_per_feature_per_rank=None, total_unique_indices=None):

@@ -352,6 +352,40 @@ def segmented_unique_cuda(keys, segmented_range, num_tables, input_frequencies=N
     return table_offsets[num_tables:], unique_keys, out_idx, table_offsets, freq
 
 
+def segmented_unique_csr(keys, segmented_range, num_tables):
+    """segmented_unique_cuda plus the CSR ingredients of the backward (extension): ->
+    (unique_keys[N], output_indices i64[N], table_offsets i64[T+1], csr_cnt i32[N], csr_rank i32[N])."""
+    n = keys.numel()
+    dev = keys.device
+    unique_keys = torch.empty_like(keys)
+    out_idx = torch.empty(n, dtype=torch.int64, device=dev)
+    table_offsets = torch.empty(num_tables + 1, dtype=torch.int64, device=dev)
+    cnt = torch.empty(n, dtype=torch.int32, device=dev)
+    rank = torch.empty(n, dtype=torch.int32, device=dev)
+    ws = _workspace(lib().mi355_segmented_unique_workspace_bytes(n), dev)
+    check(lib().mi355_segmented_unique_csr(ptr(keys), n, ptr(segmented_range), num_tables, None, 0, ptr(unique_keys),
+                                           ptr(out_idx), ptr(table_offsets), None, ptr(cnt), ptr(rank), ptr(ws), ws.numel(),
+                                           stream()), "segmented_unique_csr")
+    return unique_keys, out_idx, table_offsets, cnt, rank
+
+
+def group_by_unique_csr(csr_cnt, csr_rank, reverse_indices, num_unique_max, offsets=None, nu_dev=None, dim=0):
+    """group_by_unique from the forward's counts / ranks: scan + scatter (no histogram, no atomics)."""
+    n = reverse_indices.numel()
+    dev = reverse_indices.device
+    ptr_t = torch.empty(num_unique_max + 1, dtype=torch.int32, device=dev)
+    csr = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    ws = _workspace(lib().mi355_group_by_unique_csr_workspace_bytes(num_unique_max), dev)
+    hot = _workspace(lib().mi355_hot_rows_workspace_bytes(n, dim), dev) if dim > 0 else None
+    nb = offsets.numel() - 1 if offsets is not None else 0
+    check(lib().mi355_group_by_unique_csr(ptr(csr_cnt), ptr(csr_rank), ptr(reverse_indices), n, ptr(offsets), nb,
+                                          num_unique_max, ptr(nu_dev), ptr(ptr_t), ptr(csr), ptr(ws), ws.numel(), ptr(hot),
+                                          hot.numel() if hot is not None else 0, dim, stream()), "group_by_unique_csr")
+    if dim > 0:
+        return ptr_t, csr, hot
+    return ptr_t, csr
+
+
 def expand_table_ids_cuda(offsets, num_elements=0, n_dev=None):
     out = torch.empty(num_elements, dtype=torch.int64, device=offsets.device)
     check(lib().mi355_expand_table_ids(ptr(offsets), offsets.numel() - 1, num_elements, ptr(n_dev), ptr(out), stream()),

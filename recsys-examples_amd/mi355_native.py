@@ -48,6 +48,9 @@ _SIGS = {
     "mi355_compute_dedup_lengths": [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p],
     "mi355_segmented_sum": [c_p, c_p, c_i64, c_p, c_p],
     "mi355_segmented_unique": [c_p, c_i64, c_p, c_i64, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_i64, c_p],
+    "mi355_segmented_unique_csr": [c_p, c_i64, c_p, c_i64, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p],
+    "mi355_group_by_unique_csr": [c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_p],
+    "mi355_group_by_unique_csr_workspace_bytes": [c_i64],
     "mi355_expand_table_ids": [c_p, c_i64, c_i64, c_p, c_p, c_p],
     "mi355_get_table_range": [c_p, c_p, c_i64, c_i64, c_p, c_p],
     "mi355_flagged_compact": [c_p, c_i64, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_i64, c_p],
@@ -71,11 +74,11 @@ _SIGS = {
                            c_int, c_int, c_p, c_int, c_p, c_u64, c_int,  # policies
                            c_int, c_f, c_f, c_f, c_f, c_u64, c_f,  # initializer
                            c_int, c_p, c_i64, c_p, c_int, c_int,  # output
-                           c_p, c_p, c_p, c_p, c_p, c_p,  # persisted (+ freq)
+                           c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,  # persisted (+ freq, csr_cnt, csr_rank)
                            c_p, c_i64, c_p],
     "mi355_demb_backward": [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_int, c_p, c_i64, c_int, c_p,
                             c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_int, c_int, c_p, c_i64, c_p, c_p,
-                            c_p, c_i64, c_int, c_p, c_i64, c_p],
+                            c_p, c_i64, c_int, c_p, c_p, c_p, c_i64, c_p],
     "mi355_demb_forward_workspace_bytes": [c_i64, c_i64],
     "mi355_demb_backward_workspace_bytes": [c_i64, c_i64],
     "mi355_backward_fused": [c_p, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_int, c_p, c_p, c_i64, c_i64, c_int, c_p,
@@ -92,6 +95,7 @@ _SIGS = {
 }
 _RESTYPES = {
     "mi355_segmented_unique_workspace_bytes": c_i64,
+    "mi355_group_by_unique_csr_workspace_bytes": c_i64,
     "mi355_table_export_batch_workspace_bytes": c_i64,
     "mi355_flagged_compact_workspace_bytes": c_i64,
     "mi355_group_by_unique_workspace_bytes": c_i64,

@@ -738,3 +738,44 @@ def test_compute_dedup_lengths_and_segmented_sum(tof, B):
     offs = np.sort(np.concatenate([[0, 5000], rng.integers(0, 5000, 6)])).astype(np.int64)
     got = e.segmented_sum_cuda(T(data), T(offs)).cpu().numpy()
     np.testing.assert_array_equal(got, [int(data[a:b].sum()) for a, b in zip(offs[:-1], offs[1:])])
+
+
+@pytest.mark.parametrize("n,T,zipf", [(1, 1, False), (5000, 1, True), (40000, 3, True), (3000, 2, False)])
+def test_segmented_unique_csr_and_group_by(n, T, zipf):
+    """counts / ranks emitted by the forward dedup, and the CSR built from them, against the plain counting sort"""
+    e = ext()
+    TT = globals()['T']
+    rng = np.random.default_rng(n + T)
+    keys = (rng.zipf(1.2, n) % 5000 if zipf else rng.integers(0, 2000, n)).astype(np.int64)
+    cuts = np.sort(rng.integers(0, n + 1, T - 1)) if T > 1 else np.zeros(0, np.int64)
+    seg = np.concatenate([[0], cuts, [n]]).astype(np.int64)
+    uk, rev, uoff, cnt, rank = e.segmented_unique_csr(TT(keys), TT(seg), len(seg) - 1)
+    uk_o, rev_o, uoff_o, _ = orc.segmented_unique(keys, seg)
+    nu = int(uoff_o[-1])
+    rev_n, cnt_n, rank_n = rev.cpu().numpy(), cnt.cpu().numpy()[:nu], rank.cpu().numpy()
+    np.testing.assert_array_equal(rev_n, rev_o)
+    np.testing.assert_array_equal(uk.cpu().numpy()[:nu].view(np.uint64), uk_o)
+    np.testing.assert_array_equal(cnt_n, np.bincount(rev_o, minlength=nu))
+    order = np.lexsort((rank_n, rev_n))
+    starts = np.concatenate([[0], np.cumsum(cnt_n)])
+    # ranks of every unique row are a permutation of 0..cnt-1
+    np.testing.assert_array_equal(rank_n[order], np.concatenate([np.arange(c) for c in cnt_n]) if nu else np.zeros(0))
+    # CSR from counts/ranks == CSR from the counting sort, row by row as sets (sequence mode: src = key position)
+    p1, c1 = e.group_by_unique_csr(cnt, rank, rev, n, nu_dev=uoff[-1:])
+    p0, c0 = e.group_by_unique(rev, n, nu_dev=uoff[-1:])
+    p1, c1, p0, c0 = (x.cpu().numpy() for x in (p1, c1, p0, c0))
+    np.testing.assert_array_equal(p1[:nu + 1], starts)
+    np.testing.assert_array_equal(p0[:nu + 1], starts)
+    for u in range(0, nu, max(1, nu // 200)):
+        a, b = starts[u], starts[u + 1]
+        assert sorted(c1[a:b].tolist()) == sorted(c0[a:b].tolist()) == np.nonzero(rev_o == u)[0].tolist()
+    # pooled mode: src = bag id
+    B = max(1, n // 7)
+    lens = rng.multinomial(n, np.ones(B) / B)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    p2, c2 = e.group_by_unique_csr(cnt, rank, rev, n, offsets=TT(offs), nu_dev=uoff[-1:])
+    c2 = c2.cpu().numpy()
+    bag_of = np.repeat(np.arange(B), lens)
+    for u in range(0, nu, max(1, nu // 200)):
+        a, b = starts[u], starts[u + 1]
+        assert sorted(c2[a:b].tolist()) == sorted(bag_of[rev_o == u].tolist())

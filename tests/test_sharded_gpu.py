@@ -108,6 +108,7 @@ def test_pooled_rows_mode_one_rank_matches_unsharded(one_rank_group):
 
     F, B, dim = 3, 64, 16
     rng = np.random.default_rng(11)
+    torch.manual_seed(11)
     ref = _module(True, F, dim, torch.bfloat16)
     loc = _module(False, F, dim, torch.float32)
     sh = RowWiseShardedPooledRows(_ModuleLocal(loc), list(range(F)), [1000] * F, [dim] * F, combiner=0,
@@ -134,8 +135,9 @@ def test_pooled_rows_mode_one_rank_matches_unsharded(one_rank_group):
             f2, r2 = loc.lookup_rows(probe, t)
             assert torch.equal(f1, f2)
             # the single-GPU path rounds the reduced gradient to the grad dtype (bf16) once, like the reference's
-            # reduce_grads; the two-stage path keeps fp32 -> compare within one bf16 ulp of lr*|g|
-            torch.testing.assert_close(r1, r2, rtol=1e-2, atol=1e-3)
+            # reduce_grads; the two-stage path keeps fp32 -> compare within one bf16 ulp of lr*|sum g| (hot keys
+            # collect ~100 gradients of magnitude 0.1: |sum| up to ~2, ulp 2^-7, lr 0.25 -> 4e-3)
+            torch.testing.assert_close(r1, r2, rtol=1e-2, atol=5e-3)
 
 
 @pytest.mark.parametrize("pooled", [True, False])
@@ -146,6 +148,7 @@ def test_sharded_lookup_one_rank_matches_unsharded(one_rank_group, pooled):
 
     F, B, dim = 3, 17, 16
     rng = np.random.default_rng(5)
+    torch.manual_seed(5)
     ref = _module(pooled, F, dim, torch.float32)
     loc = _module(pooled, F, dim, torch.float32)
     sh = RowWiseShardedLookup(_ModuleLocal(loc), F, [1000] * F, pooled=pooled, device=torch.device("cuda", 0),
