@@ -22,6 +22,7 @@
 #include "common.h"
 #include "hot.h"
 #include "../../include/recsys_amd.h"
+#include "internal.h"
 
 namespace mi355 {
 
@@ -76,6 +77,20 @@ struct UniqWs {
   int* partial;  // [nb+1] per-tile counts of first occurrences, then exclusive offsets
   int* total;    // [1]
 };
+
+// Clears the scratch set / counters (0xFF bytes) and, when asked, derives the table ranges from the bag offsets
+// (get_table_range_kernel's job) in the same launch.
+__global__ void __launch_bounds__(256)
+uniq_prepare_kernel(uint4* __restrict__ fill, int64_t n16, const int64_t* __restrict__ offsets,
+                    const int64_t* __restrict__ feature_offsets, int T, int64_t feature_x_batch, int64_t* __restrict__ range) {
+  const uint4 ff = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) fill[i] = ff;
+  if (blockIdx.x == 0 && range) {
+    const int64_t nfeat = feature_offsets[T];
+    const int64_t B = nfeat > 0 ? feature_x_batch / nfeat : 0;
+    for (int t = threadIdx.x; t <= T; t += blockDim.x) range[t] = offsets[feature_offsets[t] * B];
+  }
+}
 
 // One 1024-key tile per block.  Keys are first de-duplicated INSIDE the tile in an LDS hash set (block
 // representative = smallest position), then only the tile representatives touch the global set.  Under a
@@ -255,8 +270,10 @@ uniq_emit_kernel(const uint64_t* __restrict__ keys, int64_t n, const int64_t* __
 template <bool kFreq>
 __global__ void __launch_bounds__(256)
 uniq_finish_kernel(int64_t n, UniqWs ws, const int64_t* __restrict__ in_freq, int64_t* __restrict__ output_indices,
-                   int64_t* __restrict__ freq) {
+                   int64_t* __restrict__ freq, const int64_t* __restrict__ table_offsets, int T, int64_t* __restrict__ table_ids) {
+  const int64_t nu = table_ids ? *ws.total : 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < nu) table_ids[i] = upper_bound_i64(table_offsets, T + 1, i) - 1;   // fused expand_table_ids
     const int u = ws.gcnt[ws.rep[i]];
     output_indices[i] = u;
     if (kFreq && in_freq) atomicAdd((unsigned long long*)&freq[u], (unsigned long long)in_freq[i]);
@@ -808,8 +825,20 @@ int mi355_segmented_unique_csr(const void* keys, int64_t n, const int64_t* segme
                                const int64_t* input_frequencies, int count_freq, void* unique_keys,
                                int64_t* output_indices, int64_t* table_offsets, int64_t* freq, int32_t* csr_cnt,
                                int32_t* csr_rank, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  return mi355i_segmented_unique(keys, n, segmented_range, num_tables, input_frequencies, count_freq, unique_keys,
+                                 output_indices, table_offsets, freq, csr_cnt, csr_rank, nullptr, nullptr, 0, nullptr, nullptr,
+                                 workspace, workspace_bytes, stream);
+}
+
+int mi355i_segmented_unique(const void* keys, int64_t n, const int64_t* segmented_range, int64_t num_tables,
+                            const int64_t* input_frequencies, int count_freq, void* unique_keys,
+                            int64_t* output_indices, int64_t* table_offsets, int64_t* freq, int32_t* csr_cnt,
+                            int32_t* csr_rank, const int64_t* offsets, const int64_t* feature_offsets,
+                            int64_t feature_x_batch, int64_t* table_range_out, int64_t* table_ids_out, void* workspace,
+                            int64_t workspace_bytes, hipStream_t stream) {
   MI355_CHECK_ARG(num_tables > 0, "num_tables must be positive");
   MI355_CHECK_ARG(n < 0x7fffffffLL / 2, "num_keys must be < 2^30");
+  MI355_CHECK_ARG(segmented_range || (offsets && feature_offsets && table_range_out), "table ranges or bag offsets required");
   if (n == 0) {
     hipLaunchKernelGGL(zero_offsets_kernel, dim3(1), dim3(64), 0, stream, table_offsets, num_tables + 1);
     MI355_LAUNCH_CHECK();
@@ -825,10 +854,13 @@ int mi355_segmented_unique_csr(const void* keys, int64_t n, const int64_t* segme
   ws.rep = (int*)w; w += align_up(4 * n, 256);
   ws.partial = (int*)w; w += align_up(4 * (nb + 1), 256);
   ws.total = (int*)w;
-  // slots and counters are adjacent and share the fill byte: one memset
-  if (hipMemsetAsync(ws.slots, 0xFF, 2 * align_up(8 * n, 256), stream) != hipSuccess) { mi355_set_error("memset failed"); return MI355_ELAUNCH; }
-  const uint64_t* k = (const uint64_t*)keys;
   const int T = (int)num_tables;
+  // slots and counters are adjacent and share the fill byte: one fill (plus the table ranges when they are derived here)
+  const int64_t n16 = 2 * align_up(8 * n, 256) / 16;
+  hipLaunchKernelGGL(uniq_prepare_kernel, dim3(grid_for(n16, 256, 2048)), dim3(256), 0, stream, (uint4*)ws.slots, n16, offsets,
+                     feature_offsets, T, feature_x_batch, segmented_range ? (int64_t*)nullptr : table_range_out);
+  if (!segmented_range) segmented_range = table_range_out;
+  const uint64_t* k = (const uint64_t*)keys;
   hipLaunchKernelGGL(uniq_insert_kernel, dim3((unsigned)ceil_div(n, kUniqTile)), dim3(256), 0, stream, k, n, segmented_range, T, ws,
                      csr_rank);
   hipLaunchKernelGGL(uniq_flag_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, n, ws);
@@ -837,12 +869,12 @@ int mi355_segmented_unique_csr(const void* keys, int64_t n, const int64_t* segme
     hipLaunchKernelGGL(uniq_emit_kernel<true>, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, k, n, segmented_range, T, ws,
                        (uint64_t*)unique_keys, table_offsets, freq, input_frequencies, csr_cnt);
     hipLaunchKernelGGL(uniq_finish_kernel<true>, dim3(grid_for(n, 256, 256 * 32)), dim3(256), 0, stream, n, ws, input_frequencies,
-                       output_indices, freq);
+                       output_indices, freq, table_offsets, T, table_ids_out);
   } else {
     hipLaunchKernelGGL(uniq_emit_kernel<false>, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, k, n, segmented_range, T, ws,
                        (uint64_t*)unique_keys, table_offsets, freq, input_frequencies, csr_cnt);
     hipLaunchKernelGGL(uniq_finish_kernel<false>, dim3(grid_for(n, 256, 256 * 32)), dim3(256), 0, stream, n, ws, input_frequencies,
-                       output_indices, freq);
+                       output_indices, freq, table_offsets, T, table_ids_out);
   }
   MI355_LAUNCH_CHECK();
   return MI355_OK;

@@ -1,0 +1,29 @@
+// Entry points shared between the translation units of librecsys_amd.so but not part of the public C ABI: the
+// fused variants used by the one-call pipelines (pipeline.hip).  A launch on this GPU costs ~5 us even when the
+// kernel does next to nothing, and the DynamicEmb step is a chain of ~25 dependent launches, so the pipelines fold
+// the plumbing kernels into their neighbours.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+extern "C" {
+
+// mi355_segmented_unique_csr with two optional fusions:
+//  * segmented_range == NULL: the table ranges are derived from (offsets, feature_offsets, feature_x_batch) by the
+//    same kernel that clears the scratch set (replaces mi355_get_table_range + a memset); they are left in
+//    table_range_out [num_tables+1];
+//  * table_ids_out != NULL: table id of every unique key (replaces mi355_expand_table_ids).
+int mi355i_segmented_unique(const void* keys, int64_t n, const int64_t* segmented_range, int64_t num_tables,
+                            const int64_t* input_frequencies, int count_freq, void* unique_keys,
+                            int64_t* output_indices, int64_t* table_offsets, int64_t* freq, int32_t* csr_cnt,
+                            int32_t* csr_rank, const int64_t* offsets, const int64_t* feature_offsets,
+                            int64_t feature_x_batch, int64_t* table_range_out, int64_t* table_ids_out, void* workspace,
+                            int64_t workspace_bytes, hipStream_t stream);
+
+// mi355_table_insert whose unlock pass also produces the row address of every key (replaces mi355_row_addresses)
+int mi355i_table_insert(void* storage, const int64_t* table_bucket_offsets, int64_t C, int64_t num_scores,
+                        int32_t* bucket_sizes, int32_t* counter, int64_t n, const int64_t* n_dev, const void* keys,
+                        const int64_t* table_ids, const void* score_in, int policy, uint64_t timer_override,
+                        const uint8_t* skip, int64_t* indices, uint8_t* results, const int64_t* table_ptrs,
+                        const int64_t* table_value_dims, int elem_bytes, int64_t* row_addr_out, hipStream_t stream);
+}

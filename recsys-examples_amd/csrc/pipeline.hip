@@ -10,6 +10,7 @@
 // here the step is a fixed launch sequence (hipGraph capturable).
 #include "common.h"
 #include "../../include/recsys_amd.h"
+#include "internal.h"
 
 extern "C" {
 
@@ -58,29 +59,30 @@ int mi355_demb_forward(
   const int64_t* nu_dev = unique_offsets + num_tables;
   int rc;
 #define STEP(call) do { rc = (call); if (rc != MI355_OK) return rc; } while (0)
-  STEP(mi355_get_table_range(offsets, feature_offsets, num_tables, num_bags, table_range, stream));
-  STEP(mi355_segmented_unique_csr(keys, num_keys, table_range, num_tables, nullptr, freq ? 1 : 0, unique_keys, reverse_indices,
-                                  unique_offsets, freq, csr_cnt, csr_rank, uws, uws_bytes, stream));
+  // table ranges, dedup, table ids of the unique keys: one call, no separate range / memset / expand launches
+  STEP(mi355i_segmented_unique(keys, num_keys, nullptr, num_tables, nullptr, freq ? 1 : 0, unique_keys, reverse_indices,
+                               unique_offsets, freq, csr_cnt, csr_rank, offsets, feature_offsets, num_bags, table_range,
+                               table_ids, uws, uws_bytes, stream));
   if (!find_scores) find_scores = freq;      // LFU: scores are the occurrence counts of this batch
   if (!insert_scores) insert_scores = freq;
   if (num_keys > 0) {
-    STEP(mi355_expand_table_ids(unique_offsets, num_tables, num_keys, nu_dev, table_ids, stream));
     STEP(mi355_table_lookup(storage, table_bucket_offsets, bucket_capacity, num_scores, num_keys, nu_dev, unique_keys,
                             table_ids, find_scores, find_policy, timer_override, nullptr, founds, slots, stream));
     if (train) {
-      STEP(mi355_table_insert(storage, table_bucket_offsets, bucket_capacity, num_scores, bucket_sizes, counter,
-                              num_keys, nu_dev, unique_keys, table_ids, insert_scores, insert_policy, timer_override,
-                              founds, slots, results, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream));
-    }
-    STEP(mi355_row_addresses(num_keys, nu_dev, slots, table_ids, table_ptrs, table_value_dims,
-                             value_dtype == 0 ? 4 : 2, row_addr, stream));
-    if (train) {
+      // insert + unlock; the unlock pass also writes the row address of every unique key
+      STEP(mi355i_table_insert(storage, table_bucket_offsets, bucket_capacity, num_scores, bucket_sizes, counter,
+                               num_keys, nu_dev, unique_keys, table_ids, insert_scores, insert_policy, timer_override,
+                               founds, slots, results, table_ptrs, table_value_dims, value_dtype == 0 ? 4 : 2, row_addr,
+                               stream));
       STEP(mi355_init_rows(init_mode, p0, p1, p2, p3, seed, state_init, num_keys, nu_dev, unique_keys, nullptr,
                            row_addr, nullptr, 0, value_dtype, emb_dim, value_dim, results, founds, table_ids, table_emb_dims,
                            table_value_dims, stream));
       if (pin)
         STEP(mi355_table_update_counter(counter, counter_numel, slots, num_keys, nu_dev, 1, table_ids,
                                         table_bucket_offsets, bucket_capacity, stream));
+    } else {
+      STEP(mi355_row_addresses(num_keys, nu_dev, slots, table_ids, table_ptrs, table_value_dims,
+                               value_dtype == 0 ? 4 : 2, row_addr, stream));
     }
   }
   if (combiner >= 0) {

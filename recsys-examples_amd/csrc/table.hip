@@ -21,6 +21,7 @@
 //  * all counts can stay on the device (`n_dev`), so the pipeline never syncs the host.
 #include "common.h"
 #include "../../include/recsys_amd.h"
+#include "internal.h"
 
 namespace mi355 {
 
@@ -392,13 +393,17 @@ table_insert_kernel(Table t, const int64_t* __restrict__ tbo, int32_t* __restric
 __global__ void __launch_bounds__(256)
 table_unlock_kernel(Table t, const int64_t* __restrict__ tbo, int64_t n, const int64_t* __restrict__ n_dev,
                     const uint64_t* __restrict__ keys, const int64_t* __restrict__ table_ids,
-                    const uint8_t* __restrict__ skip, const int64_t* __restrict__ indices) {
+                    const uint8_t* __restrict__ skip, const int64_t* __restrict__ indices,
+                    const int64_t* __restrict__ table_ptrs, const int64_t* __restrict__ table_value_dims, int elem_bytes,
+                    int64_t* __restrict__ row_addr) {
   if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t idx = indices[i];
+    const int64_t tid = table_ids ? table_ids[i] : 0;
+    // fused mi355_row_addresses: every key (found earlier or placed now) gets the address of its row
+    if (row_addr) row_addr[i] = idx < 0 ? 0 : table_ptrs[tid] + idx * table_value_dims[tid] * elem_bytes;
     if (skip && skip[i]) continue;
-    int64_t idx = indices[i];
     if (idx < 0) continue;
-    int64_t tid = table_ids ? table_ids[i] : 0;
     int64_t b = tbo[tid] + idx / t.C;
     ast64(t.keys(b) + idx % t.C, keys[i]);
   }
@@ -576,7 +581,30 @@ int mi355_table_insert(void* storage, const int64_t* table_bucket_offsets, int64
                      (uint64_t*)evicted_keys, evicted_indices, evicted_scores, evicted_table_ids);
   MI355_LAUNCH_CHECK();
   hipLaunchKernelGGL(table_unlock_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, t, table_bucket_offsets, n, n_dev,
-                     (const uint64_t*)keys, table_ids, skip, indices);
+                     (const uint64_t*)keys, table_ids, skip, indices, (const int64_t*)nullptr, (const int64_t*)nullptr, 0,
+                     (int64_t*)nullptr);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int mi355i_table_insert(void* storage, const int64_t* table_bucket_offsets, int64_t C, int64_t num_scores,
+                        int32_t* bucket_sizes, int32_t* counter, int64_t n, const int64_t* n_dev, const void* keys,
+                        const int64_t* table_ids, const void* score_in, int policy, uint64_t timer_override,
+                        const uint8_t* skip, int64_t* indices, uint8_t* results, const int64_t* table_ptrs,
+                        const int64_t* table_value_dims, int elem_bytes, int64_t* row_addr_out, hipStream_t stream) {
+  MI355_CHECK_ARG(C > 0 && C % 16 == 0, "bucket capacity must be a positive multiple of 16");
+  MI355_CHECK_ARG(policy >= kConst && policy <= kLruLfu, "bad score policy");
+  MI355_CHECK_ARG(policy == kConst || policy == kGlobalTimer || score_in, "score_in required by this policy");
+  MI355_CHECK_ARG(policy != kLruLfu || num_scores == 2, "LRU_LFU needs num_scores == 2");
+  if (n == 0) return MI355_OK;
+  Table t = make_table(storage, C, num_scores);
+  hipLaunchKernelGGL(table_insert_kernel, dim3(grid_for(n, 256 / G)), dim3(256), 0, stream, t, table_bucket_offsets,
+                     bucket_sizes, counter, n, n_dev, (const uint64_t*)keys, table_ids, (const uint64_t*)score_in,
+                     policy, timer_override, skip, indices, results, (int64_t*)nullptr, (unsigned long long*)nullptr,
+                     (uint64_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr);
+  MI355_LAUNCH_CHECK();
+  hipLaunchKernelGGL(table_unlock_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, t, table_bucket_offsets, n, n_dev,
+                     (const uint64_t*)keys, table_ids, skip, indices, table_ptrs, table_value_dims, elem_bytes, row_addr_out);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }
