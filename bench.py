@@ -314,8 +314,17 @@ def main():
             "bwd_rows_kernel(+bwd_hot_kernel)": {"ms": b_ms, "algorithmic_bytes": bwd_bytes, "GB/s": bwd_bytes / b_ms / 1e6},
         }
         dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
+        # HBM traffic of the dominant kernel per launch from the committed PMC passes (counters cannot be read from
+        # inside this process): 2*FETCH_SIZE + WRITE_SIZE, see profiles/r01_pmc_traffic.json
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            key = "bwd_kernel" if dom[0].startswith("bwd") else "gather_pooled_vec_kernel"
+            traffic = pmc[key]["traffic_bytes"]
+        except Exception:
+            pass
         result["roofline"] = {"bound": "hbm", "kernel": dom[0], "achieved": dom[1]["GB/s"], "peak": HBM_PEAK_GBPS,
-                              "unit": "GB/s", "frac": dom[1]["GB/s"] / HBM_PEAK_GBPS, "traffic": None,
+                              "unit": "GB/s", "frac": dom[1]["GB/s"] / HBM_PEAK_GBPS, "traffic": traffic,
                               "kernels": kern, "keys_per_launch": nt_avg, "unique_rows_per_launch": nu_avg}
         step_bytes = (8 * nt_avg + 8 * (FB + 1) + 16 * nu_avg + nu_avg * D * e + FB * D * o) + \
                      (8 * nt_avg + FB * D * o + 2 * nu_avg * D * e)
