@@ -65,14 +65,14 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                  learning_rate: float = 0.01, eps: float = 1.0e-8, initial_accumulator_value: float = 0.0,
                  momentum: float = 0.9, weight_decay: float = 0.0, weight_decay_mode=None, eta: float = 0.001,
                  beta1: float = 0.9, beta2: float = 0.999, counter_based_regularization=None,
-                 cowclip_regularization=None, *args, **kwargs) -> None:
+                 cowclip_regularization=None, storage_mode: Optional[str] = None, *args, **kwargs) -> None:
         super().__init__()
         assert len(table_options) >= 1
         opt0 = table_options[0]
         for o in table_options:
             assert opt0 == o, "All tables must match in grouped keys."
             if o.caching or o.external_storage is not None or o.admit_strategy is not None:
-                raise NotImplementedError("cache / external storage / admission are 'next' rows (DESIGN.md)")
+                raise NotImplementedError("cache-with-promotion / external storage / admission are 'next' rows (DESIGN.md)")
         self._dynamicemb_options = table_options
         self._table_names = table_names or [f"t{i}" for i in range(len(table_options))]
         self.pooling_mode = pooling_mode
@@ -135,11 +135,45 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         self._policy = pol
 
         caps = [o.max_capacity for o in table_options]
-        self.table = LinearBucketTable(caps, [ScoreSpec("score", pol)], key_type=torch.int64,
-                                       bucket_capacity=opt0.bucket_capacity, device=self.device_)
-        # flat value tables [capacity_t, value_dim_t] resident in HBM
-        self.values = [torch.zeros(c, v, dtype=self.embedding_dtype, device=self.device_)
-                       for c, v in zip(self.table.per_table_capacity_, self.value_dims)]
+        # ---- storage tiers (batched_dynamicemb_tables.py:637-787, key_value_table.py:1522-2403) -------------------
+        #  hbm    : hash table + rows in HBM (DynamicEmbStorage on device)
+        #  host   : hash table + rows in pinned host memory, driven by the same kernels over the host link
+        #  hybrid : HBM tier limited to `local_hbm_for_values` bytes + host tier (HybridStorage): a key lives in exactly
+        #           one tier, new keys enter the HBM tier, what it evicts spills to the host tier.  The gather / backward
+        #           kernels take row ADDRESSES, so rows of both tiers are mixed freely in one launch -- nothing is staged.
+        # Deviation: `local_hbm_for_values == 0` means "no limit" here (288 GB of HBM per GPU); the reference reads 0
+        # as host-only.  `storage_mode="host"` selects that explicitly.
+        elem = torch.empty((), dtype=self.embedding_dtype).element_size()
+        row_bytes = [v * elem for v in self.value_dims]
+        total_bytes = sum(c * b for c, b in zip(caps, row_bytes))
+        if storage_mode is None:
+            storage_mode = "hybrid" if 0 < opt0.local_hbm_for_values < total_bytes else "hbm"
+        assert storage_mode in ("hbm", "host", "hybrid")
+        self.storage_mode = storage_mode
+        C = opt0.bucket_capacity
+
+        def _values(capacities, host):
+            if host:
+                return [torch.zeros(c, v, dtype=self.embedding_dtype).pin_memory() for c, v in zip(capacities, self.value_dims)]
+            return [torch.zeros(c, v, dtype=self.embedding_dtype, device=self.device_) for c, v in zip(capacities, self.value_dims)]
+
+        if storage_mode == "hybrid":
+            share = [opt0.local_hbm_for_values * (c * b) // max(total_bytes, 1) for c, b in zip(caps, row_bytes)]
+            hbm_caps = [max(C, (sh // b) // C * C) for sh, b in zip(share, row_bytes)]
+            self.table = LinearBucketTable(hbm_caps, [ScoreSpec("score", pol)], key_type=torch.int64, bucket_capacity=C,
+                                           device=self.device_)
+            self.table_host = LinearBucketTable(caps, [ScoreSpec("score", pol)], key_type=torch.int64, bucket_capacity=C,
+                                                device=self.device_, host=True)
+            self.values = _values(self.table.per_table_capacity_, False)
+            self.values_host = _values(self.table_host.per_table_capacity_, True)
+            self.table_ptrs_host = torch.tensor([v.data_ptr() for v in self.values_host], dtype=torch.int64, device=self.device_)
+        else:
+            host = storage_mode == "host"
+            self.table = LinearBucketTable(caps, [ScoreSpec("score", pol)], key_type=torch.int64, bucket_capacity=C,
+                                           device=self.device_, host=host)
+            self.table_host = None
+            # flat value tables [capacity_t, value_dim_t]
+            self.values = _values(self.table.per_table_capacity_, host)
         self.table_ptrs = torch.tensor([v.data_ptr() for v in self.values], dtype=torch.int64, device=self.device_)
         self.table_value_dims = torch.tensor(self.value_dims, dtype=torch.int64, device=self.device_)
         self.table_emb_dims = torch.tensor(self.dims, dtype=torch.int64, device=self.device_)
@@ -198,6 +232,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         offsets = offsets.to(torch.int64).contiguous()
         if indices.dtype != torch.int64:
             indices = indices.to(torch.int64)
+        if self.storage_mode == "hybrid":
+            return self._forward_hybrid(indices, offsets, train)
         n = indices.numel()
         num_bags = offsets.numel() - 1
         B = num_bags // self.feature_num
@@ -244,6 +280,106 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                 self._safe_check(st)
         return out, st
 
+    # ---------------------------------------------------------------------------------- hybrid tiers
+    def _forward_hybrid(self, indices: torch.Tensor, offsets: torch.Tensor, train: bool):
+        """HybridStorage forward (key_value_table.py:2107-2403, _prefetch path of batched_dynamicemb_function.py:298-556):
+        find in the HBM tier, then the host tier; unseen keys enter the HBM tier, its evictions spill (key, score, row)
+        to the host tier, keys the HBM tier cannot take go to the host tier directly.  Orchestrated from Python over the
+        per-op C ABI (it needs the miss counts on the host, as the reference does); the result is one row address per
+        unique key, after which gather and backward are the same launches as for HBM-only storage."""
+        from .scored_hashtable import ScoreArg
+
+        n = indices.numel()
+        num_bags = offsets.numel() - 1
+        B = num_bags // self.feature_num
+        pooled = self.pooling_mode != DynamicEmbPoolingMode.NONE
+        dev, T = self.device_, self.num_tables
+        eb = torch.empty((), dtype=self.embedding_dtype).element_size()
+        st = _StepCtx()
+        st.offsets, st.num_keys, st.batch_size, st.num_bags = offsets, n, B, num_bags
+        st.tids = st.slots = None
+        if pooled:
+            out = torch.empty(B, self.total_D, dtype=self.output_dtype, device=dev)
+            combiner = 0 if self.pooling_mode == DynamicEmbPoolingMode.SUM else 1
+        else:
+            out = torch.empty(n, self.dims[0], dtype=self.output_dtype, device=dev)
+            combiner = -1
+        rng = ext.get_table_range(offsets, self.feature_offsets)
+        ukeys, st.rev, st.uoff, st.csr_cnt, st.csr_rank = ext.segmented_unique_csr(indices, rng, T)
+        nu = int(st.uoff[-1].item())
+        st.row_addr = torch.zeros(max(n, 1), dtype=torch.int64, device=dev)
+        if nu > 0:
+            uk = ukeys[:nu].contiguous()
+            tids = ext.expand_table_ids_cuda(st.uoff, nu)
+            fp, fs, ip, isc, need_freq = self._scores(nu)
+            if need_freq:
+                fs = isc = st.csr_cnt[:nu].to(torch.int64)
+            find = ScoreArg("score", None if fs is None else fs[:nu], fp)
+            ins = ScoreArg("score", None if isc is None else isc[:nu], ip)
+            addr = st.row_addr[:nu]
+            _, f0, s0 = self.table.lookup(uk, tids, find)
+            hit0 = f0.nonzero().squeeze(1)
+            if hit0.numel():
+                addr[hit0] = ext.row_addresses(s0[hit0], tids[hit0], self.table_ptrs, self.table_value_dims, eb)
+            miss = (~f0).nonzero().squeeze(1)
+            if miss.numel():
+                k1, t1 = uk[miss].contiguous(), tids[miss].contiguous()
+                find1 = ScoreArg("score", None if find.value is None else find.value[miss].contiguous(), fp)
+                _, f1, s1 = self.table_host.lookup(k1, t1, find1)
+                hit1 = f1.nonzero().squeeze(1)
+                if hit1.numel():
+                    addr[miss[hit1]] = ext.row_addresses(s1[hit1], t1[hit1], self.table_ptrs_host, self.table_value_dims, eb)
+                new = miss[(~f1).nonzero().squeeze(1)]
+                if train and new.numel():
+                    kn, tn = uk[new].contiguous(), tids[new].contiguous()
+                    insn = ScoreArg("score", None if ins.value is None else ins.value[new].contiguous(), ip)
+                    # rows found in the HBM tier for THIS batch must not be evicted by this batch's inserts
+                    if hit0.numel():
+                        self.table.increment_counter(s0[hit0].contiguous(), tids[hit0].contiguous())
+                    idxn, h, ek, ei, es, et = self.table.insert_and_evict(kn, tn, insn)
+                    if hit0.numel():
+                        self.table.decrement_counter(s0[hit0].contiguous(), tids[hit0].contiguous())
+                    if h:
+                        ev = (ei >= 0).nonzero().squeeze(1)   # real evictions (negative entries mark refused inputs)
+                        if ev.numel():
+                            e_k, e_s, e_sc, e_t = ek[ev].contiguous(), ei[ev].contiguous(), es[ev].contiguous(), et[ev].contiguous()
+                            dst = self.table_host.insert(e_k, e_t, ScoreArg("score", e_sc, ext.ScorePolicy.ASSIGN))
+                            ok = (dst >= 0).nonzero().squeeze(1)
+                            if ok.numel():   # move the evicted rows (embedding + optimizer state) before they are overwritten
+                                buf = torch.empty(ok.numel(), max(self.value_dims), dtype=self.embedding_dtype, device=dev)
+                                ext.load_from_flat_table_value(self.table_ptrs, e_s[ok].contiguous(), e_t[ok].contiguous(), buf,
+                                                               self.table_value_dims, self.table_emb_dims, self.max_D, True)
+                                ext.store_to_flat_table_value(self.table_ptrs_host, dst[ok].contiguous(), e_t[ok].contiguous(), buf,
+                                                              self.table_value_dims, self.table_emb_dims, self.max_D, True)
+                    okn = (idxn >= 0).nonzero().squeeze(1)
+                    if okn.numel():
+                        addr[new[okn]] = ext.row_addresses(idxn[okn].contiguous(), tn[okn].contiguous(), self.table_ptrs,
+                                                           self.table_value_dims, eb)
+                    bad = (idxn < 0).nonzero().squeeze(1)
+                    if bad.numel():   # the HBM tier refused them (bucket full of pinned rows): they live in the host tier
+                        insb = ScoreArg("score", None if insn.value is None else insn.value[bad].contiguous(), ip)
+                        sh = self.table_host.insert(kn[bad].contiguous(), tn[bad].contiguous(), insb)
+                        okb = (sh >= 0).nonzero().squeeze(1)
+                        if okb.numel():
+                            addr[new[bad[okb]]] = ext.row_addresses(sh[okb].contiguous(), tn[bad[okb]].contiguous(),
+                                                                    self.table_ptrs_host, self.table_value_dims, eb)
+                    mode, p = self._init_params()
+                    a_new = addr[new].contiguous()
+                    ext.init_rows(mode, p, self._seed, self.initial_accumulator_value, kn, a_new, self.embedding_dtype,
+                                  self.max_D, max(self.value_dims), skip=(a_new == 0), table_ids=tn,
+                                  table_emb_dims=self.table_emb_dims, table_value_dims=self.table_value_dims)
+        al = all(d % 4 == 0 for d in self.dims) and all(v % 4 == 0 for v in self.value_dims)
+        if pooled:
+            check(lib().mi355_gather_pooled(None, 0, ptr(st.row_addr), dt(self.embedding_dtype), ptr(st.rev), n, ptr(offsets),
+                                            num_bags, B, combiner, self.max_D, ptr(self.D_offsets_t), self.total_D, ptr(out),
+                                            dt(out), int(al), stream()), "gather_pooled")
+        elif n:
+            check(lib().mi355_gather_rows(None, 0, ptr(st.row_addr), dt(self.embedding_dtype), ptr(st.rev), n, None, self.max_D,
+                                          ptr(out), out.stride(0), dt(out), int(al), stream()), "gather_rows")
+        if train:
+            self._step += 1
+        return out, st
+
     def _safe_check(self, st):
         nu = int(st.uoff[-1].item())
         failed = int((st.slots[:nu] < 0).sum().item())
@@ -283,15 +419,26 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         return out
 
     # ---------------------------------------------------------------------------------- inspection
+    def _tiers(self):
+        t = [(self.table, self.values)]
+        if self.table_host is not None:
+            t.append((self.table_host, self.values_host))
+        return t
+
     def size(self, table_id: Optional[int] = None):
-        return self.table.size(table_id)
+        return sum(int(tb.size(table_id)) for tb, _ in self._tiers())
 
     def lookup_rows(self, keys: torch.Tensor, table_id: int = 0):
-        """(found, rows [n, value_dim]) of `keys` -- test / debugging helper (CONST lookup)."""
+        """(found, rows [n, value_dim]) of `keys` over all storage tiers -- test / debugging helper (CONST lookup)."""
         from .scored_hashtable import ScoreArg
 
         tids = torch.full_like(keys, table_id)
-        _, found, idx = self.table.lookup(keys, tids, ScoreArg("score", None, ext.ScorePolicy.CONST))
-        rows = self.values[table_id][idx.clamp(min=0)]
-        rows[~found] = 0
+        found = torch.zeros(keys.numel(), dtype=torch.bool, device=keys.device)
+        rows = torch.zeros(keys.numel(), self.value_dims[table_id], dtype=self.embedding_dtype, device=keys.device)
+        for tb, vals in self._tiers():
+            _, f, idx = tb.lookup(keys, tids, ScoreArg("score", None, ext.ScorePolicy.CONST))
+            v = vals[table_id]
+            r = v[idx.clamp(min=0).to(v.device)].to(keys.device)
+            rows[f] = r[f]
+            found |= f
         return found, rows

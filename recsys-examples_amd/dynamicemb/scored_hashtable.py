@@ -69,7 +69,11 @@ class ScoredHashTable(abc.ABC):
 
 class LinearBucketTable(ScoredHashTable):
     def __init__(self, capacity: List[int], score_specs: List[ScoreSpec], key_type: torch.dtype = torch.int64,
-                 bucket_capacity: Optional[int] = None, device: torch.device = None, enable_overflow: bool = False):
+                 bucket_capacity: Optional[int] = None, device: torch.device = None, enable_overflow: bool = False,
+                 host: bool = False):
+        """host=True keeps the table (keys / digests / scores, bucket sizes, pin counters) in pinned host memory, which
+        the GPU kernels address directly (the host tier of the reference's HybridStorage / host-only storage,
+        key_value_table.py:2107-2403; the reference stages through HostVMMTensor)."""
         if enable_overflow:
             raise NotImplementedError("overflow buckets (cache tables) are a 'next' row; see DESIGN.md")
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -97,9 +101,15 @@ class LinearBucketTable(ScoredHashTable):
         self.table_bucket_offsets_ = torch.tensor(offs, dtype=torch.int64, device=self.device)
         self.table_bucket_offsets_cpu_ = torch.tensor(offs, dtype=torch.int64)
         self.storage_bytes_ = (9 + 8 * self.num_scores_) * C * self.num_buckets_
-        self.table_storage_ = torch.empty(self.storage_bytes_, dtype=torch.uint8, device=self.device)
-        self.bucket_sizes = torch.zeros(self.num_buckets_, dtype=torch.int32, device=self.device)
-        self._ref_counter = torch.zeros(self.capacity_, dtype=torch.int32, device=self.device)
+        self.host_ = host
+        if host:
+            self.table_storage_ = torch.empty(self.storage_bytes_, dtype=torch.uint8, pin_memory=True)
+            self.bucket_sizes = torch.zeros(self.num_buckets_, dtype=torch.int32).pin_memory()
+            self._ref_counter = torch.zeros(self.capacity_, dtype=torch.int32).pin_memory()
+        else:
+            self.table_storage_ = torch.empty(self.storage_bytes_, dtype=torch.uint8, device=self.device)
+            self.bucket_sizes = torch.zeros(self.num_buckets_, dtype=torch.int32, device=self.device)
+            self._ref_counter = torch.zeros(self.capacity_, dtype=torch.int32, device=self.device)
         self.enable_overflow_ = False
         self.reset()
 

@@ -187,6 +187,11 @@ def table_update_counter_with_layout(counter, slot_indices, delta, table_bucket_
                                            stream()), "table_update_counter")
 
 
+def _gpu(t: torch.Tensor):
+    """device for the outputs of an op on `t`: a pinned host table is driven from the current GPU"""
+    return t.device if t.is_cuda else torch.device("cuda", torch.cuda.current_device())
+
+
 def _num_buckets(table_storage, bucket_capacity, num_scores):
     return table_storage.numel() * table_storage.element_size() // (bucket_capacity * (9 + 8 * num_scores))
 
@@ -195,7 +200,7 @@ def table_export_batch(table_storage, bucket_capacity, batch, offset, key_dtype=
                        table_begin=0, num_scores=1, score_index=0):
     """table_export_batch (export_batch.cu:88-124) -> (counter i64[1], keys[batch], scores i64[batch], indices i64[batch]);
     the first `counter` entries are valid.  Slot order (deterministic); the reference's order is atomic order."""
-    dev = table_storage.device
+    dev = _gpu(table_storage)
     counter = torch.zeros(1, dtype=torch.int64, device=dev)
     keys = torch.empty(batch, dtype=key_dtype, device=dev)
     score = torch.empty(batch, dtype=torch.int64, device=dev)
@@ -219,7 +224,7 @@ def table_export_batch(table_storage, bucket_capacity, batch, offset, key_dtype=
 def table_count_matched(table_storage, key_dtype, bucket_capacity, threshold, begin=-1, end=-1, num_scores=1,
                         score_index=0):
     """table_count_matched (count_matched.cu:77-93) -> i64[1] on the device."""
-    out = torch.zeros(1, dtype=torch.int64, device=table_storage.device)
+    out = torch.zeros(1, dtype=torch.int64, device=_gpu(table_storage))
     nb = _num_buckets(table_storage, bucket_capacity, num_scores)
     check(lib().mi355_table_count_matched(ptr(table_storage), nb, bucket_capacity, num_scores,
                                           c_u64(int(threshold) & 0xFFFFFFFFFFFFFFFF), begin, end, score_index, ptr(out),
@@ -239,7 +244,7 @@ def table_copy_score_blocks(src_storage, src_bucket_capacity, dst_storage, dst_b
 
 def table_gather_score_blocks(table_storage, bucket_capacity, num_scores, bkt_begin, slots, key_dtype=torch.int64):
     n = slots.size(0)
-    out = torch.empty(n, num_scores, dtype=torch.int64, device=table_storage.device)
+    out = torch.empty(n, num_scores, dtype=torch.int64, device=_gpu(table_storage))
     if n:
         check(lib().mi355_table_score_blocks(1, ptr(table_storage), bucket_capacity, bkt_begin, None, 0, 0, num_scores, n,
                                              ptr(slots.contiguous()), None, ptr(out), stream()),

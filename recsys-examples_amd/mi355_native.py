@@ -158,12 +158,14 @@ def dt(t_or_dtype) -> int:
 
 
 def ptr(t: Optional[torch.Tensor]):
-    """Raw device pointer of a tensor (None -> NULL).  Refuses CPU tensors: the kernels only run
+    """Raw device pointer of a tensor (None -> NULL).  Refuses pageable CPU tensors: the kernels only run
     on the GPU and there is deliberately no host implementation behind this ABI."""
     if t is None:
         return c_p(0)
-    if not t.is_cuda:
+    if not t.is_cuda and not t.is_pinned():
         raise NativeError("librecsys_amd expects GPU tensors (no CPU fallback exists)")
+    # pinned host tensors are device-visible at the same address (hipHostMalloc, unified addressing): the host
+    # tier of the embedding storage is read and written by the same kernels, over the host link
     return c_p(t.data_ptr())
 
 

@@ -239,3 +239,68 @@ def test_bf16_output_matches_fp32_within_1e3():
     # same seed + counter based initialiser => identical rows in both modules
     assert torch.allclose(a, b, rtol=8e-3, atol=1e-3)  # bf16 has 8 bits of mantissa: half-ulp = 3.9e-3
     assert torch.allclose(a, b.bfloat16().float())       # i.e. exactly the rounded fp32 result
+
+
+# ---------------------------------------------------------------------------------------- storage tiers
+@pytest.mark.parametrize("mode", ["host", "hybrid"])
+@pytest.mark.parametrize("pooling", ["SUM", "NONE"])
+@pytest.mark.parametrize("optimizer", ["SGD", "ADAM"])
+def test_storage_tiers_are_transparent(mode, pooling, optimizer):
+    """Host-only storage and the hybrid HBM + host tiers must be invisible in the results: same outputs and same rows
+    as the HBM-only module on the same key stream, including while the (tiny) HBM tier keeps evicting into the host
+    tier (reference: test_batched_dynamic_embedding_tables_v2.py hybrid / host-only parametrisations :862-1318)."""
+    from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
+    from dynamicemb.dynamicemb_config import (DynamicEmbInitializerArgs, DynamicEmbInitializerMode, DynamicEmbPoolingMode,
+                                              DynamicEmbScoreStrategy, DynamicEmbTableOptions, EmbOptimType)
+
+    torch.manual_seed(3)
+    rng = np.random.default_rng(3)
+    dims, F, B = [8, 8], 2, 24
+    opt_t = EmbOptimType.SGD if optimizer == "SGD" else EmbOptimType.ADAM
+    pm = DynamicEmbPoolingMode.SUM if pooling == "SUM" else DynamicEmbPoolingMode.NONE
+
+    def make(storage_mode, local_hbm=0):
+        opts = [DynamicEmbTableOptions(dim=d, max_capacity=4096, index_type=torch.int64, embedding_dtype=torch.float32,
+                                       score_strategy=DynamicEmbScoreStrategy.STEP, local_hbm_for_values=local_hbm,
+                                       initializer_args=DynamicEmbInitializerArgs(mode=DynamicEmbInitializerMode.DEBUG))
+                for d in dims]
+        m = BatchedDynamicEmbeddingTablesV2(opts, pooling_mode=pm, output_dtype=torch.float32, optimizer=opt_t,
+                                            learning_rate=0.05, device=torch.device("cuda", 0), storage_mode=storage_mode)
+        m.train()
+        return m
+
+    ref = make("hbm")
+    # hybrid: room for 128 rows per table in HBM (one bucket), everything else spills to the host tier
+    row_bytes = 4 * (dims[0] * (3 if optimizer == "ADAM" else 1))
+    dut = make(mode, local_hbm=2 * 128 * row_bytes if mode == "hybrid" else 0)
+    assert dut.storage_mode == mode
+    seen = set()
+    for step in range(8):
+        lens = rng.integers(0, 5, F * B)
+        off = np.zeros(F * B + 1, np.int64)
+        off[1:] = np.cumsum(lens)
+        keys_np = rng.integers(0, 600, off[-1]).astype(np.int64)
+        seen.update(keys_np.tolist())
+        keys = torch.from_numpy(keys_np).cuda()
+        off_t = torch.from_numpy(off).cuda()
+        o_ref, st = ref._forward_impl(keys, off_t, train=True)
+        o_dut, st2 = dut._forward_impl(keys, off_t, train=True)
+        torch.testing.assert_close(o_dut, o_ref, rtol=1e-6, atol=1e-6)
+        g = torch.randn_like(o_ref)
+        ref._backward_impl(st, g)
+        dut._backward_impl(st2, g)
+        if step % 3 == 2:   # eval lookups in between (unknown keys -> zeros, no inserts)
+            ek = torch.from_numpy(rng.integers(0, 1200, 40).astype(np.int64)).cuda()
+            eo = torch.arange(0, 41, dtype=torch.int64, device="cuda")[: (40 // F) * F + 1]
+            e1, _ = ref._forward_impl(ek[: eo.numel() - 1], eo, train=False)
+            e2, _ = dut._forward_impl(ek[: eo.numel() - 1], eo, train=False)
+            torch.testing.assert_close(e2, e1, rtol=1e-6, atol=1e-6)
+    probe = torch.arange(0, 600, device="cuda", dtype=torch.int64)
+    for t in range(len(dims)):
+        f1, r1 = ref.lookup_rows(probe, t)
+        f2, r2 = dut.lookup_rows(probe, t)
+        assert torch.equal(f1, f2)
+        torch.testing.assert_close(r2, r1, rtol=1e-5, atol=1e-6)
+    if mode == "hybrid":
+        assert int(dut.table_host.size()) > 0, "the HBM tier never spilled: the test does not exercise eviction"
+        assert dut.size() == ref.size()
