@@ -312,6 +312,35 @@ int mi355_hstu_attn_fwd(const void* q, const void* k, const void* v, void* out, 
                         int64_t target_group_size, int causal, float alpha, float scaling_seqlen,
                         hipStream_t stream);
 
+/* Inference forward of the same op: the queries may be the LAST tokens of a longer key sequence (cu_seqlens_k;
+ * the reference's delta-q) and the history keys / values may live in a paged cache [num_pages, 2, page_size, H, d]
+ * addressed through (page_offsets [batch+1], page_ids, last_page_lens [batch]) -- hstu_attn_varlen_func(...,
+ * kv_cache=, page_offsets=, page_ids=, last_page_lens=) of examples/hstu/modules/paged_hstu_infer_layer.py:492-514,
+ * kernel hstu_fwd.h Paged_KV paths :104-131,516-545,785; reference statement _hstu_paged_kv_attention,
+ * examples/hstu/test/test_paged_hstu_attn_kernel.py:179-256.  With a cache, k / v hold [new history | candidates]
+ * per sequence and only their candidate rows are read (the history, new tokens included, is in the cache);
+ * cu_seqlens_k[b+1]-cu_seqlens_k[b] = cached length + num_targets[b].  NULL cu_seqlens_k / kv_cache = training call. */
+int mi355_hstu_attn_fwd_kv(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride,
+                           int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride,
+                           int64_t k_head_stride, int64_t v_head_stride, int64_t o_head_stride,
+                           const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int64_t batch, int64_t num_heads,
+                           int64_t head_dim, int64_t max_seqlen_q, const int32_t* num_contexts,
+                           const int32_t* num_targets, int64_t target_group_size, int causal, float alpha,
+                           float scaling_seqlen, const void* kv_cache, const int32_t* page_offsets,
+                           const int32_t* page_ids, const int32_t* last_page_lens, int64_t page_size,
+                           hipStream_t stream);
+
+/* append_kvcache (torch.ops.paged_kvcache_ops.append_kvcache, examples/commons/ops/cuda_ops/csrc/
+ * paged_kvcache_ops_kernel.cu:106-140, call site paged_hstu_infer_layer.py:350-364): new-history token i (i < *nnz_dev,
+ * or < max_nnz when max_nnz > 0) of sequence batch_indices[i] is written at position positions[i] of that user's
+ * cache (page kv_indices[kv_indptr[batch] + pos / page_size], slot pos % page_size; NHD layout); its source row in
+ * append_key / append_value is i + seqlen_offsets[batch].  nnz_upper bounds the launch when the count is on the device. */
+int mi355_append_kvcache(void* kv_cache, const int32_t* kv_indices, const int32_t* kv_indptr, int64_t num_heads,
+                         int64_t head_dim, int64_t page_size, const void* append_key, const void* append_value,
+                         int64_t k_row_stride, int64_t v_row_stride, int64_t k_head_stride, int64_t v_head_stride,
+                         const int32_t* batch_indices, const int32_t* positions, const int32_t* seqlen_offsets,
+                         const int32_t* nnz_dev, int64_t max_nnz, int64_t nnz_upper, hipStream_t stream);
+
 /* hstu_varlen_bwd (hstu_api.cpp:525-719; hstu_varlen_bwd_80, fused_hstu_op.py:682-706): dq, dk, dv
  * contiguous bf16 [total, H, d].  Deterministic (two passes, no atomics): `deterministic` of the
  * reference is always on. */

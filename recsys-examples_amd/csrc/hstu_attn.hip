@@ -23,6 +23,7 @@
 //    row block can reach are skipped (causal / contextual / target rules), the mask itself is applied
 //    per element on the fp32 accumulator together with alpha, SiLU and 1/scaling_seqlen.
 #include "common.h"
+#include "../../include/recsys_amd.h"
 #include <stdlib.h>
 
 namespace mi355 {
@@ -44,6 +45,13 @@ struct AttnArgs {
   const int* num_targets;   // [B] or nullptr
   int H, causal, group;
   float alpha, inv_scale;
+  // ---- inference extensions (forward only; NULL / 0 for training) ----
+  const int* cu_seqlens_k;     // [B+1] key offsets when the keys are longer than the queries (delta-q); NULL = same as q
+  const uint16_t* kv_cache;    // paged KV [num_pages, 2, page_size, H, d] (hstu_fwd.h Paged_KV paths :104-131,516-545)
+  const int* page_offsets;     // [B+1] into page_ids
+  const int* page_ids;         // page of every (sequence, page slot)
+  const int* last_page_lens;   // [B] valid tokens of the last page
+  int page_size;
 };
 
 struct SeqInfo { int start, L, c, hlen; bool has_ctx, has_tgt; };
@@ -147,45 +155,59 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
   const int b = blockIdx.z, h = blockIdx.y;
   SeqInfo s;
   s.start = a.cu_seqlens[b];
-  s.L = a.cu_seqlens[b + 1] - s.start;
-  const int nblk = (s.L + kBM - 1) / kBM;
-  if ((int)blockIdx.x >= nblk) return;
+  const int Lq = a.cu_seqlens[b + 1] - s.start;
+  // keys: the same tokens (training), a longer key sequence (delta-q: the queries are its LAST Lq positions), or the
+  // user's paged cache followed by the candidate tokens of k / v
+  const int kstart = a.cu_seqlens_k ? a.cu_seqlens_k[b] : s.start;
+  s.L = a.cu_seqlens_k ? a.cu_seqlens_k[b + 1] - kstart : Lq;
+  const int dq = s.L - Lq;   // absolute position of query row r is dq + r
+  const int nblk = (Lq + kBM - 1) / kBM;
+  if ((int)blockIdx.x >= nblk || dq < 0) return;
   const int m0 = (nblk - 1 - (int)blockIdx.x) * kBM;  // heaviest (latest) row blocks first
   s.has_ctx = a.num_contexts != nullptr;
   s.has_tgt = a.num_targets != nullptr;
   s.c = s.has_ctx ? a.num_contexts[b] : 0;
-  s.hlen = s.L - (s.has_tgt ? a.num_targets[b] : 0);
+  const int ntgt = s.has_tgt ? a.num_targets[b] : 0;
+  s.hlen = s.L - ntgt;
+  const bool paged = a.kv_cache != nullptr;
+  int cachelen = 0, pg0 = 0;
+  if (paged) {
+    pg0 = a.page_offsets[b];
+    cachelen = (a.page_offsets[b + 1] - pg0 - 1) * a.page_size + a.last_page_lens[b];
+    if (cachelen < 0) cachelen = 0;
+  }
 
   const int lane = lane_id(), wv = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
-  const int qrow0 = m0 + 32 * wv;
-  const int qi = qrow0 + l31;
-  const bool wave_live = qrow0 < s.L;
+  const int qrow0 = m0 + 32 * wv;          // local (query tensor) row
+  const int qloc = qrow0 + l31;
+  const int qi = dq + qloc;                // absolute position
+  const bool wave_live = qrow0 < Lq;
 
-  // keys this row block can reach
-  int last_row = m0 + kBM - 1 < s.L - 1 ? m0 + kBM - 1 : s.L - 1;
+  // keys this row block can reach (absolute positions)
+  int last_row = dq + (m0 + kBM - 1 < Lq - 1 ? m0 + kBM - 1 : Lq - 1);
   int n_end = s.L;
   if (a.causal) {
     n_end = last_row + 1;
-    if (s.has_ctx && m0 < s.c && s.hlen > n_end) n_end = s.hlen;
+    if (s.has_ctx && dq + m0 < s.c && s.hlen > n_end) n_end = s.hlen;
   }
   // the wave's own reach (skips MFMA work on tiles past it)
-  int w_last = qrow0 + 31 < s.L - 1 ? qrow0 + 31 : s.L - 1;
+  int w_last = dq + (qrow0 + 31 < Lq - 1 ? qrow0 + 31 : Lq - 1);
   int w_end = s.L;
   if (a.causal) {
     w_end = w_last + 1;
-    if (s.has_ctx && qrow0 < s.c && s.hlen > w_end) w_end = s.hlen;
+    if (s.has_ctx && dq + qrow0 < s.c && s.hlen > w_end) w_end = s.hlen;
   }
 
   // ---- Q fragments (B operand of GEMM 1): lane = (query l31, k half hi), 8 consecutive d per 16-slice
   bf16x8_t qf[QLDS ? 1 : D / 16];
   if constexpr (QLDS) {
-    stage_rows<D, kBM>(Qs, a.q + (int64_t)s.start * a.q_row + (int64_t)h * a.q_head, a.q_row, m0, s.L);
+    stage_rows<D, kBM>(Qs, a.q + (int64_t)s.start * a.q_row + (int64_t)h * a.q_head, a.q_row, m0, Lq);
   } else {
-    const uint16_t* qp = a.q + (int64_t)(s.start + (qi < s.L ? qi : 0)) * a.q_row + (int64_t)h * a.q_head + 8 * hi;
+    const uint16_t* qp = a.q + (int64_t)(s.start + (qloc < Lq ? qloc : 0)) * a.q_row + (int64_t)h * a.q_head + 8 * hi;
 #pragma unroll
     for (int sl = 0; sl < D / 16; ++sl) {
       uint4 t = make_uint4(0, 0, 0, 0);
-      if (qi < s.L) t = *reinterpret_cast<const uint4*>(qp + 16 * sl);
+      if (qloc < Lq) t = *reinterpret_cast<const uint4*>(qp + 16 * sl);
       qf[sl] = *reinterpret_cast<bf16x8_t*>(&t);
     }
   }
@@ -197,7 +219,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) acc_o[dt][r] = 0.f;
 
   const float nal2e = -a.alpha * 1.44269504088896f, ais = a.alpha * a.inv_scale;
-  const RowMask rm = row_mask(qi, s, a.causal, a.group);
+  const RowMask rm = row_mask(qi < s.L ? qi : s.L - 1, s, a.causal, a.group);
   // ---- software-pipelined staging (issue-early / write-late): the K / V tile of step n+1 is fetched
   // into registers while step n computes; it is written to LDS (V transposed) after the barrier.
   constexpr int KCH = kBN * D / 8;            // 16-B chunks of the K tile
@@ -205,8 +227,20 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
   constexpr int VCH = (kBN / 4) * (D / 8);    // (4 keys x 8 d) blocks of the V tile
   constexpr int VPT = (VCH + 255) / 256;
   u32x4_t kreg[KPT], vreg[VPT][4];
-  const uint16_t* kbase = a.k + (int64_t)s.start * a.k_row + (int64_t)h * a.k_head;
-  const uint16_t* vbase = a.v + (int64_t)s.start * a.v_row + (int64_t)h * a.v_head;
+  // key j of the sequence: cached token (page table walk) or a token of k / v.  With a cache, k / v hold
+  // [new history | candidates] per sequence and only the candidates are read from them (the history is in the cache).
+  const int64_t tok0 = paged ? (int64_t)s.start + (Lq - ntgt) - cachelen : (int64_t)kstart;
+  const uint16_t* kbase = a.k + (int64_t)h * a.k_head;
+  const uint16_t* vbase = a.v + (int64_t)h * a.v_head;
+  const int64_t pg_slot = (int64_t)a.H * D, pg_kv = (int64_t)a.page_size * pg_slot;
+  auto kv_row = [&](int j, int which) -> const uint16_t* {
+    const uint16_t* direct = (which ? vbase : kbase) + (tok0 + j) * (which ? a.v_row : a.k_row);
+    if (!paged) return direct;
+    const int jc = j < cachelen ? j : 0;
+    const int page = a.page_ids[pg0 + jc / a.page_size];
+    const uint16_t* cached = a.kv_cache + ((int64_t)page * 2 + which) * pg_kv + (int64_t)(jc % a.page_size) * pg_slot + (int64_t)h * D;
+    return j < cachelen ? cached : direct;
+  };
   auto fetch = [&](int n0) {
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
@@ -214,7 +248,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
       const int key = ch / (D / 8), dc = ch % (D / 8);
       // rows past the sequence end are clamped to its last row: their P is masked to 0, so any finite data do
       const int row = n0 + key < s.L ? n0 + key : s.L - 1;
-      if (KCH % 256 == 0 || ch < KCH) kreg[i] = *reinterpret_cast<const u32x4_t*>(kbase + (int64_t)row * a.k_row + 8 * dc);
+      if (KCH % 256 == 0 || ch < KCH) kreg[i] = *reinterpret_cast<const u32x4_t*>(kv_row(row, 0) + 8 * dc);
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
@@ -226,7 +260,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int row = n0 + key0 + kk < s.L ? n0 + key0 + kk : s.L - 1;
-        if (VCH % 256 == 0 || ch < VCH) vreg[i][kk] = *reinterpret_cast<const u32x4_t*>(vbase + (int64_t)row * a.v_row + 8 * dc);
+        if (VCH % 256 == 0 || ch < VCH) vreg[i][kk] = *reinterpret_cast<const u32x4_t*>(kv_row(row, 1) + 8 * dc);
       }
     }
   };
@@ -305,7 +339,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
     pin_agpr(acc_o);
     // ---- P^T = mask * SiLU(alpha S^T) / scaling, packed straight into the B operand of GEMM 2.
     // Tiles strictly below the diagonal of every row of the wave need no per-element mask.
-    const bool full = a.causal && (n0 + kBN - 1 <= qrow0) && (!s.has_ctx || qrow0 >= s.c) && (!s.has_tgt || n0 + kBN - 1 < s.hlen);
+    const bool full = a.causal && (n0 + kBN - 1 <= dq + qrow0) && (!s.has_ctx || dq + qrow0 >= s.c) && (!s.has_tgt || n0 + kBN - 1 < s.hlen);
     bf16x8_t pf[4];
     if (full) {
 #pragma unroll
@@ -368,8 +402,8 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
   fence_a(acc_o);
 
   // ---- epilogue: O^T accumulator -> out[token][head][d] (bf16), 4 consecutive d per store
-  if (qi < s.L) {
-    uint16_t* op = a.out + (int64_t)(s.start + qi) * a.o_row + (int64_t)h * a.o_head;
+  if (qloc < Lq) {
+    uint16_t* op = a.out + (int64_t)(s.start + qloc) * a.o_row + (int64_t)h * a.o_head;
 #pragma unroll
     for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
@@ -944,6 +978,23 @@ int mi355_hstu_attn_fwd(const void* q, const void* k, const void* v, void* out, 
                         int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen,
                         const int32_t* num_contexts, const int32_t* num_targets, int64_t target_group_size, int causal,
                         float alpha, float scaling_seqlen, hipStream_t stream) {
+  return mi355_hstu_attn_fwd_kv(q, k, v, out, q_row_stride, k_row_stride, v_row_stride, o_row_stride, q_head_stride,
+                                k_head_stride, v_head_stride, o_head_stride, cu_seqlens, nullptr, batch, num_heads, head_dim,
+                                max_seqlen, num_contexts, num_targets, target_group_size, causal, alpha, scaling_seqlen,
+                                nullptr, nullptr, nullptr, nullptr, 0, stream);
+}
+
+// Inference forward: queries may be the tail of a longer key sequence (cu_seqlens_k, "delta-q") and the keys / values
+// of the history may live in a paged cache [num_pages, 2, page_size, H, d] (hstu_attn_varlen_func kv_cache /
+// page_offsets / page_ids / last_page_lens, hstu_attn_interface.py; kernel hstu_fwd.h Paged_KV paths :104-131,516-545).
+int mi355_hstu_attn_fwd_kv(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride,
+                           int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride,
+                           int64_t k_head_stride, int64_t v_head_stride, int64_t o_head_stride, const int32_t* cu_seqlens_q,
+                           const int32_t* cu_seqlens_k, int64_t batch, int64_t num_heads, int64_t head_dim,
+                           int64_t max_seqlen_q, const int32_t* num_contexts, const int32_t* num_targets,
+                           int64_t target_group_size, int causal, float alpha, float scaling_seqlen, const void* kv_cache,
+                           const int32_t* page_offsets, const int32_t* page_ids, const int32_t* last_page_lens,
+                           int64_t page_size, hipStream_t stream) {
   MI355_CHECK_ARG(head_dim == 32 || head_dim == 64 || head_dim == 128 || head_dim == 256,
                   "head_dim must be one of 32, 64, 128, 256 (hstu_api.cpp:391)");
   MI355_CHECK_ARG(target_group_size >= 1, "target_group_size must be >= 1");
@@ -952,20 +1003,71 @@ int mi355_hstu_attn_fwd(const void* q, const void* k, const void* v, void* out, 
   MI355_CHECK_ARG(q_row_stride % 8 == 0 && k_row_stride % 8 == 0 && v_row_stride % 8 == 0 && o_row_stride % 4 == 0 &&
                       q_head_stride % 8 == 0 && k_head_stride % 8 == 0 && v_head_stride % 8 == 0 && o_head_stride % 4 == 0,
                   "q/k/v strides must be multiples of 8 elements (16-byte rows)");
-  if (batch == 0 || max_seqlen == 0) return MI355_OK;
-  AttnArgs a;
+  MI355_CHECK_ARG(!kv_cache || (cu_seqlens_k && page_offsets && page_ids && last_page_lens && page_size > 0),
+                  "a paged cache needs cu_seqlens_k, page_offsets, page_ids, last_page_lens and page_size");
+  if (batch == 0 || max_seqlen_q == 0) return MI355_OK;
+  AttnArgs a{};
   a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v; a.out = (uint16_t*)out;
   a.q_row = q_row_stride; a.k_row = k_row_stride; a.v_row = v_row_stride; a.o_row = o_row_stride;
   a.q_head = q_head_stride; a.k_head = k_head_stride; a.v_head = v_head_stride; a.o_head = o_head_stride;
-  a.cu_seqlens = cu_seqlens; a.num_contexts = num_contexts; a.num_targets = num_targets;
+  a.cu_seqlens = cu_seqlens_q; a.num_contexts = num_contexts; a.num_targets = num_targets;
   a.H = (int)num_heads; a.causal = causal; a.group = (int)target_group_size;
   a.alpha = alpha; a.inv_scale = 1.0f / scaling_seqlen;
+  a.cu_seqlens_k = cu_seqlens_k; a.kv_cache = (const uint16_t*)kv_cache; a.page_offsets = page_offsets; a.page_ids = page_ids;
+  a.last_page_lens = last_page_lens; a.page_size = (int)page_size;
   switch (head_dim) {
-    case 32: return launch_fwd<32>(a, (int)batch, (int)max_seqlen, stream);
-    case 64: return launch_fwd<64>(a, (int)batch, (int)max_seqlen, stream);
-    case 128: return launch_fwd<128>(a, (int)batch, (int)max_seqlen, stream);
-    default: return launch_fwd<256>(a, (int)batch, (int)max_seqlen, stream);
+    case 32: return launch_fwd<32>(a, (int)batch, (int)max_seqlen_q, stream);
+    case 64: return launch_fwd<64>(a, (int)batch, (int)max_seqlen_q, stream);
+    case 128: return launch_fwd<128>(a, (int)batch, (int)max_seqlen_q, stream);
+    default: return launch_fwd<256>(a, (int)batch, (int)max_seqlen_q, stream);
   }
+}
+
+// append_kvcache (examples/commons/ops/cuda_ops/csrc/paged_kvcache_ops_kernel.cu:106-140): token i of the new history
+// (i < *nnz) of sequence batch_indices[i] goes to position positions[i] of that user's paged cache, NHD layout
+// [num_pages, 2, page_size, H, d]; its source row in append_key / append_value is i + seqlen_offsets[batch] (the
+// tensors hold [new history | candidates] per sequence; seqlen_offsets = candidate offsets).
+namespace mi355 {
+__global__ void __launch_bounds__(256)
+append_kvcache_kernel(uint16_t* __restrict__ cache, const int* __restrict__ kv_indices, const int* __restrict__ kv_indptr,
+                      int H, int D, int page_size, const uint16_t* __restrict__ key, const uint16_t* __restrict__ value,
+                      int64_t k_row, int64_t v_row, int64_t k_head, int64_t v_head, const int* __restrict__ batch_indices,
+                      const int* __restrict__ positions, const int* __restrict__ offsets, const int* __restrict__ nnz_dev,
+                      int nnz_max) {
+  int nnz = nnz_dev ? *nnz_dev : nnz_max;
+  if (nnz_max > 0 && nnz > nnz_max) nnz = nnz_max;
+  const int chunks = H * D / 8;   // 16-byte chunks per token
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < (int64_t)nnz * chunks; w += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(w / chunks), c = (int)(w % chunks);
+    const int hh = (c * 8) / D, dd = (c * 8) % D;
+    const int bidx = batch_indices[i], pos = positions[i];
+    const int page = kv_indices[kv_indptr[bidx] + pos / page_size];
+    const int64_t src = (int64_t)i + offsets[bidx];
+    const int64_t dst = (((int64_t)page * 2) * page_size + pos % page_size) * H * D + (int64_t)hh * D + dd;
+    *reinterpret_cast<uint4*>(cache + dst) = *reinterpret_cast<const uint4*>(key + src * k_row + (int64_t)hh * k_head + dd);
+    *reinterpret_cast<uint4*>(cache + dst + (int64_t)page_size * H * D) =
+        *reinterpret_cast<const uint4*>(value + src * v_row + (int64_t)hh * v_head + dd);
+  }
+}
+}  // namespace mi355
+
+int mi355_append_kvcache(void* kv_cache, const int32_t* kv_indices, const int32_t* kv_indptr, int64_t num_heads,
+                         int64_t head_dim, int64_t page_size, const void* append_key, const void* append_value,
+                         int64_t k_row_stride, int64_t v_row_stride, int64_t k_head_stride, int64_t v_head_stride,
+                         const int32_t* batch_indices, const int32_t* positions, const int32_t* seqlen_offsets,
+                         const int32_t* nnz_dev, int64_t max_nnz, int64_t nnz_upper, hipStream_t stream) {
+  MI355_CHECK_ARG(head_dim % 8 == 0 && k_row_stride % 8 == 0 && v_row_stride % 8 == 0 && k_head_stride % 8 == 0 &&
+                      v_head_stride % 8 == 0, "head_dim and strides must be multiples of 8 elements");
+  MI355_CHECK_ARG(page_size > 0, "page_size must be positive");
+  MI355_CHECK_ARG(nnz_dev || max_nnz > 0, "nnz (device) or max_nnz required");
+  const int64_t upper = max_nnz > 0 ? max_nnz : nnz_upper;
+  if (upper == 0) return MI355_OK;
+  hipLaunchKernelGGL(append_kvcache_kernel, dim3(grid_for(upper * num_heads * head_dim / 8, 256)), dim3(256), 0, stream,
+                     (uint16_t*)kv_cache, kv_indices, kv_indptr, (int)num_heads, (int)head_dim, (int)page_size,
+                     (const uint16_t*)append_key, (const uint16_t*)append_value, k_row_stride, v_row_stride, k_head_stride,
+                     v_head_stride, batch_indices, positions, seqlen_offsets, nnz_dev, (int)max_nnz);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
 }
 
 int64_t mi355_hstu_attn_bwd_workspace_bytes(int64_t total_tokens, int64_t num_heads, int64_t head_dim) {
@@ -990,7 +1092,7 @@ int mi355_hstu_attn_bwd(const void* dout, const void* q, const void* k, const vo
                       q_head_stride % 8 == 0 && k_head_stride % 8 == 0 && v_head_stride % 8 == 0 && do_head_stride % 8 == 0,
                   "q/k/v/dout strides must be multiples of 8 elements (16-byte rows)");
   if (batch == 0 || max_seqlen == 0) return MI355_OK;
-  BwdAttnArgs g;
+  BwdAttnArgs g{};
   AttnArgs& a = g.f;
   a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v; a.out = nullptr;
   a.q_row = q_row_stride; a.k_row = k_row_stride; a.v_row = v_row_stride; a.o_row = 0;

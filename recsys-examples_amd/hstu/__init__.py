@@ -3,4 +3,5 @@ third_party/FBGEMM submodule): `hstu_attn_varlen_func` with the positional order
 (examples/hstu/modules/hstu_attention.py:296-314, test/hstu_attn/test_hstu_attn_smoke.py:105-121), on top of
 the gfx950 MFMA kernels (mi355_hstu_attn_fwd / mi355_hstu_attn_bwd).
 """
-from .hstu_attn_interface import HstuAttnVarlenFunc, hstu_attn_varlen_func, hstu_varlen_bwd, hstu_varlen_fwd  # noqa: F401
+from .hstu_attn_interface import (HstuAttnVarlenFunc, append_kvcache, hstu_attn_varlen_func, hstu_varlen_bwd,  # noqa: F401
+                                  hstu_varlen_fwd, hstu_varlen_fwd_kv)

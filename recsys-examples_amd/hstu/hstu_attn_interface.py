@@ -5,7 +5,9 @@ Mirrors `HstuAttnVarlenFunc` / `hstu_attn_varlen_func` of the reference
 examples/hstu/modules/hstu_attention.py:296-314): same argument meaning, same input checks
 (bf16/fp16-class inputs, int32 cu_seqlens / num_contexts / num_targets, head_dim in {32, 64, 128, 256},
 contextual / target masks require causal -- hstu_api.cpp:359-430).
-Not supported this round (raise): rab / drab, paged kv_cache, seqused_*, local windows, fp16 (bf16 only).
+Inference extensions (forward only): cu_seqlens_k longer than cu_seqlens_q (delta-q) and the paged KV cache
+(kv_cache / page_offsets / page_ids / last_page_lens).
+Not supported this round (raise): rab / drab, seqused_*, local windows, fp16 (bf16 only).
 """
 from __future__ import annotations
 
@@ -22,24 +24,26 @@ N.register_signatures({
     "mi355_hstu_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p,
                             c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_int, c_f, c_f, c_p, c_i64, c_p],
     "mi355_hstu_attn_bwd_workspace_bytes": [c_i64, c_i64, c_i64],
+    "mi355_hstu_attn_fwd_kv": [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64,
+                               c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_int, c_f, c_f, c_p, c_p, c_p, c_p, c_i64, c_p],
+    "mi355_append_kvcache": [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p,
+                             c_i64, c_i64, c_p],
 }, {"mi355_hstu_attn_bwd_workspace_bytes": c_i64})
 
 
 def _check_inputs(q, k, v, cu_q, cu_k, num_contexts, num_targets, window_size, rab, kv_cache, seqused_q, seqused_k):
-    if rab is not None or kv_cache is not None:
-        raise NotImplementedError("rab / paged kv_cache are 'next' rows (DESIGN.md)")
+    if rab is not None:
+        raise NotImplementedError("rab / drab is a 'next' row (DESIGN.md)")
     if seqused_q is not None or seqused_k is not None:
         raise NotImplementedError("seqused_q / seqused_k are not supported")
     if q.dtype != torch.bfloat16 or k.dtype != q.dtype or v.dtype != q.dtype:
         raise RuntimeError("hstu_attn only supports bf16 q/k/v in this build")
-    if q.dim() != 3 or k.shape != q.shape or v.shape != q.shape:
-        raise RuntimeError("q, k, v must be (total, nheads, head_dim) with equal shapes")
+    if q.dim() != 3 or k.dim() != 3 or k.shape[1:] != q.shape[1:] or v.shape != k.shape:
+        raise RuntimeError("q, k, v must be (total, nheads, head_dim); k and v of equal shape")
     if q.stride(-1) != 1 or k.stride(-1) != 1 or v.stride(-1) != 1:
         raise RuntimeError("q, k, v must have a contiguous last dimension")
     if cu_q.dtype != torch.int32 or cu_k.dtype != torch.int32:
         raise RuntimeError("cu_seqlens must be int32")
-    if cu_q.data_ptr() != cu_k.data_ptr() and not torch.equal(cu_q, cu_k):
-        raise NotImplementedError("cu_seqlens_q != cu_seqlens_k (delta-q / kv cache) is a 'next' row")
     for t, name in ((num_contexts, "num_contexts"), (num_targets, "num_targets")):
         if t is not None and t.dtype != torch.int32:
             raise RuntimeError(f"{name} must be int32")
@@ -65,6 +69,47 @@ def hstu_varlen_fwd(q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_context
                                     int(max_seqlen), ptr(num_contexts), ptr(num_targets), int(target_group_size), int(causal),
                                     c_f(alpha), c_f(float(scaling_seqlen)), stream()), "hstu_attn_fwd")
     return out
+
+
+def hstu_varlen_fwd_kv(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, scaling_seqlen, num_contexts, num_targets,
+                       target_group_size, causal, alpha, kv_cache=None, page_offsets=None, page_ids=None,
+                       last_page_lens=None):
+    """Inference forward: delta-q (cu_seqlens_k) and / or paged KV cache [num_pages, 2, page_size, H, d]."""
+    T, H, D = q.shape
+    out = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
+    B = cu_seqlens_q.numel() - 1
+    page_size = 0
+    if kv_cache is not None:
+        if kv_cache.dim() != 5 or kv_cache.size(1) != 2 or kv_cache.size(3) != H or kv_cache.size(4) != D:
+            raise RuntimeError("kv_cache must be [num_pages, 2, page_size, nheads, head_dim]")
+        if not kv_cache.is_contiguous() or kv_cache.dtype != q.dtype:
+            raise RuntimeError("kv_cache must be contiguous and of the dtype of q")
+        for t, name in ((page_offsets, "page_offsets"), (page_ids, "page_ids"), (last_page_lens, "last_page_lens")):
+            if t is None or t.dtype != torch.int32:
+                raise RuntimeError(f"{name} must be an int32 tensor")
+        page_size = kv_cache.size(2)
+    check(lib().mi355_hstu_attn_fwd_kv(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
+                                       q.stride(1), k.stride(1), v.stride(1), out.stride(1), ptr(cu_seqlens_q),
+                                       ptr(cu_seqlens_k), B, H, D, int(max_seqlen_q), ptr(num_contexts), ptr(num_targets),
+                                       int(target_group_size), int(causal), c_f(alpha), c_f(float(scaling_seqlen)),
+                                       ptr(kv_cache), ptr(page_offsets), ptr(page_ids), ptr(last_page_lens), page_size,
+                                       stream()), "hstu_attn_fwd_kv")
+    return out
+
+
+def append_kvcache(append_key, append_value, batch_indices, positions, seqlen_offsets, nnz_cuda, max_nnz, kv_cache_table,
+                   kv_indices, kv_indptr, kv_last_page_len, kv_layout=0):
+    """torch.ops.paged_kvcache_ops.append_kvcache (paged_kvcache_ops_cuda.cpp:332): writes the new-history tokens of
+    append_key / append_value into the paged cache (NHD layout) and returns the table."""
+    if kv_layout != 0:
+        raise NotImplementedError("only the NHD layout is supported")
+    H, D = append_key.shape[1], append_key.shape[2]
+    check(lib().mi355_append_kvcache(ptr(kv_cache_table), ptr(kv_indices), ptr(kv_indptr), H, D, kv_cache_table.size(2),
+                                     ptr(append_key), ptr(append_value), append_key.stride(0), append_value.stride(0),
+                                     append_key.stride(1), append_value.stride(1), ptr(batch_indices), ptr(positions),
+                                     ptr(seqlen_offsets), ptr(nnz_cuda), int(max_nnz), batch_indices.numel(), stream()),
+          "append_kvcache")
+    return kv_cache_table
 
 
 def hstu_varlen_bwd(dout, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_contexts, num_targets, target_group_size,
@@ -115,5 +160,14 @@ def hstu_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, seqused_q, sequse
         raise RuntimeError("max_seqlen_q must be <= max_seqlen_k")
     if scaling_seqlen is None or scaling_seqlen == -1:
         scaling_seqlen = max_seqlen_q
+    same = cu_seqlens_q.data_ptr() == cu_seqlens_k.data_ptr() or (
+        cu_seqlens_q.shape == cu_seqlens_k.shape and bool(torch.equal(cu_seqlens_q, cu_seqlens_k)))
+    if kv_cache is not None or not same:
+        # inference: keys longer than the queries and / or history keys in the paged cache; no backward
+        if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+            raise NotImplementedError("delta-q / paged-KV attention is forward only (as in the reference's inference path)")
+        return hstu_varlen_fwd_kv(q, k, v, cu_seqlens_q, cu_seqlens_k, int(max_seqlen_q), scaling_seqlen, num_contexts,
+                                  num_targets, int(target_group_size), causal, float(alpha), kv_cache, page_offsets,
+                                  page_ids, last_page_lens)
     return HstuAttnVarlenFunc.apply(q, k, v, cu_seqlens_q, int(max_seqlen_k), scaling_seqlen, num_contexts, num_targets,
                                     int(target_group_size), causal, float(alpha))

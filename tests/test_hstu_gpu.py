@@ -118,3 +118,119 @@ def test_rejects_unsupported():
         hstu_attn_varlen_func(q, q, q, cu, cu, None, None, 4, 4, 4, None, nt, window_size=(-1, -1))  # targets need causal
     with pytest.raises(RuntimeError):
         hstu_attn_varlen_func(q.float(), q.float(), q.float(), cu, cu, None, None, 4, 4, 4, None, None)
+
+
+# ---------------------------------------------------------------------------------------- inference: delta-q / paged KV
+def _paged_case(name):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "hstu_paged_golden.npz"))
+    return {k[len(name) + 1:]: g[k] for k in g.files if k.startswith(name + "_")}
+
+
+@pytest.mark.parametrize("name", ["warm", "cold"])
+def test_paged_kv_forward_matches_reference_golden(name):
+    """hstu_attn_varlen_func(..., kv_cache=, page_offsets=, page_ids=, last_page_lens=) vs the reference's own
+    _hstu_paged_kv_attention on the committed fixtures (bf16-representable inputs).  Same criterion as the other
+    kernel-vs-reference checks of this file: max abs error within 6e-3 of the output scale (P is rounded to bf16
+    before the second GEMM, exactly as in the reference kernel)."""
+    from hstu import hstu_attn_varlen_func
+
+    c = _paged_case(name)
+    dev = "cuda"
+    t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(dev) if dt is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+    q, k, v, cache = (t(c[x], torch.bfloat16) for x in ("q", "k", "v", "cache"))
+    out = hstu_attn_varlen_func(q, k, v, t(c["q_off"]), t(c["k_off"]), None, None, 48, 48, float(c["scaling"]), None,
+                                t(c["num_cand"]), target_group_size=1, window_size=(-1, 0), alpha=float(c["alpha"]),
+                                kv_cache=cache, page_offsets=t(c["page_off"]), page_ids=t(c["page_ids"]),
+                                last_page_lens=t(c["last_len"]))
+    got = out.float().cpu().numpy()
+    want = c["out"]
+    err = np.abs(got - want).max()
+    assert err <= 6e-3 * np.abs(want).max() + 1e-6, err
+
+
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+def test_delta_q_and_paged_random_vs_oracle(d):
+    """random jagged batch: (a) delta-q without a cache (keys longer than queries), (b) the same keys served from a
+    paged cache built with append_kvcache; both against the CPU oracle"""
+    from hstu import append_kvcache, hstu_attn_varlen_func
+
+    rng = np.random.default_rng(d)
+    B, H, P = 5, 2, 16
+    new_hist = rng.integers(1, 70, B)
+    num_cand = rng.integers(1, 9, B)
+    old = rng.integers(0, 120, B)
+    old[0] = 0
+    qlen = new_hist + num_cand
+    cachelen = old + new_hist
+    klen = cachelen + num_cand
+    q_off = np.concatenate([[0], np.cumsum(qlen)]).astype(np.int32)
+    k_off = np.concatenate([[0], np.cumsum(klen)]).astype(np.int32)
+    T, Tk = int(q_off[-1]), int(k_off[-1])
+    mk = lambda n: torch.empty(n, H, d, device=DEV).uniform_(-1, 1).bfloat16()
+    q, k_new, v_new = mk(T), mk(T), mk(T)            # q / k / v of the request: [new history | candidates] per sequence
+    k_old, v_old = mk(int(old.sum())), mk(int(old.sum()))
+    o_off = np.concatenate([[0], np.cumsum(old)])
+    # full key sequences for the cache-less delta-q call and the oracle: old history, new history, candidates
+    kf, vf = [], []
+    for b in range(B):
+        kf += [k_old[o_off[b]:o_off[b + 1]], k_new[q_off[b]:q_off[b + 1]]]
+        vf += [v_old[o_off[b]:o_off[b + 1]], v_new[q_off[b]:q_off[b + 1]]]
+    k_full, v_full = torch.cat(kf), torch.cat(vf)
+    alpha, scaling = 1.0 / d ** 0.5, 200.0
+    tgt = torch.from_numpy(num_cand.astype(np.int32)).to(DEV)
+    cuq, cuk = torch.from_numpy(q_off).to(DEV), torch.from_numpy(k_off).to(DEV)
+    ref = ho.hstu_attn_fwd_delta_q(q.float().cpu().numpy(), k_full.float().cpu().numpy(), v_full.float().cpu().numpy(), q_off,
+                                   k_off, alpha, scaling, True, num_cand)
+    out_a = hstu_attn_varlen_func(q, k_full, v_full, cuq, cuk, None, None, int(qlen.max()), int(klen.max()), scaling, None, tgt,
+                                  window_size=(-1, 0), alpha=alpha)
+    err = np.abs(out_a.float().cpu().numpy() - ref).max()
+    assert err <= 6e-3 * np.abs(ref).max() + 1e-6, err
+    # (b) paged: old history written page by page, new history appended with append_kvcache
+    npages = int(((cachelen + P - 1) // P).sum())
+    cache = torch.zeros(npages + 3, 2, P, H, d, dtype=torch.bfloat16, device=DEV)
+    perm = rng.permutation(npages + 3)[:npages]
+    page_ids, page_off, last = [], [0], []
+    cursor = 0
+    for b in range(B):
+        n = int((cachelen[b] + P - 1) // P)
+        pages = perm[cursor:cursor + n]
+        cursor += n
+        page_ids += pages.tolist()
+        page_off.append(len(page_ids))
+        last.append(int(cachelen[b] - (n - 1) * P))
+        for j in range(int(old[b])):
+            cache[pages[j // P], 0, j % P] = k_old[o_off[b] + j]
+            cache[pages[j // P], 1, j % P] = v_old[o_off[b] + j]
+    ti = lambda a: torch.tensor(a, dtype=torch.int32, device=DEV)
+    batch_idx = np.repeat(np.arange(B), new_hist)
+    positions = np.concatenate([old[b] + np.arange(new_hist[b]) for b in range(B)])
+    cand_off = np.concatenate([[0], np.cumsum(num_cand)])
+    nnz = ti([int(new_hist.sum())])
+    append_kvcache(k_new, v_new, ti(batch_idx), ti(positions), ti(cand_off), nnz, 0, cache, ti(page_ids), ti(page_off), ti(last), 0)
+    kc, vc, koff = ho.gather_paged_kv(k_new.float().cpu().numpy(), v_new.float().cpu().numpy(), q_off, num_cand,
+                                      cache.float().cpu().numpy(), page_off, page_ids, last)
+    np.testing.assert_array_equal(kc, k_full.float().cpu().numpy())   # append_kvcache put every token where the walk finds it
+    np.testing.assert_array_equal(vc, v_full.float().cpu().numpy())
+    out_b = hstu_attn_varlen_func(q, k_new, v_new, cuq, cuk, None, None, int(qlen.max()), int(klen.max()), scaling, None, tgt,
+                                  window_size=(-1, 0), alpha=alpha, kv_cache=cache, page_offsets=ti(page_off),
+                                  page_ids=ti(page_ids), last_page_lens=ti(last))
+    assert torch.equal(out_a, out_b)   # same keys, same order of operations -> bit-identical
+
+
+def test_paged_kvcache_ops_registration():
+    """torch.ops.paged_kvcache_ops.append_kvcache exists with the reference's schema and writes the cache"""
+    import paged_kvcache_ops  # noqa: F401
+
+    H, d, P = 2, 32, 8
+    key = torch.randn(10, H, d, device=DEV).bfloat16()
+    val = torch.randn(10, H, d, device=DEV).bfloat16()
+    cache = torch.zeros(4, 2, P, H, d, device=DEV, dtype=torch.bfloat16)
+    ti = lambda a: torch.tensor(a, dtype=torch.int32, device=DEV)
+    # one sequence: 6 new-history tokens (positions 3..8 of its cache) + 4 candidates; pages [2, 0]
+    out = torch.ops.paged_kvcache_ops.append_kvcache(key, val, ti([0] * 6), ti(list(range(3, 9))), ti([0, 4]), ti([6]), 0, cache,
+                                                     ti([2, 0]), ti([0, 2]), ti([1]), 0)
+    assert out.data_ptr() == cache.data_ptr()
+    for i, pos in enumerate(range(3, 9)):
+        page = [2, 0][pos // P]
+        assert torch.equal(cache[page, 0, pos % P], key[i]) and torch.equal(cache[page, 1, pos % P], val[i])
+    assert float(cache[1].abs().sum()) == 0 and float(cache[3].abs().sum()) == 0
