@@ -262,6 +262,64 @@ def table_scatter_score_blocks(table_storage, bucket_capacity, num_scores, bkt_b
                                          ptr(slots.contiguous()), ptr(vals), stream()), "table_scatter_score_blocks")
 
 
+class _GrowableTensor:
+    """VMMTensor / HostVMMTensor of the reference (src/vmm_tensor.cu:555-585): a 1-D buffer whose logical size can be
+    extended in place (`extend`), `data()` returning the current logical view.  The reference reserves virtual address
+    space and maps physical pages on demand; here the buffer over-allocates geometrically and re-allocates + copies
+    when the slack is used up (callers re-read `data()` after `extend`, extendable_tensor.py:120-130), which on a
+    288 GB device is the simpler trade.  Host flavour = pinned memory, directly addressable by the kernels."""
+
+    _PAGE = 2 << 20
+
+    def __init__(self, numel: int, dtype: torch.dtype, device: int, host: bool):
+        if numel <= 0:
+            raise ValueError("numel must be positive")
+        self._dtype, self._device, self._host = dtype, device, host
+        self._logical = int(numel)
+        self._buf = self._alloc(self._round(numel))
+
+    def _round(self, numel):
+        eb = torch.empty((), dtype=self._dtype).element_size()
+        return (numel * eb + self._PAGE - 1) // self._PAGE * self._PAGE // eb
+
+    def _alloc(self, numel):
+        if self._host:
+            return torch.empty(numel, dtype=self._dtype, pin_memory=True)
+        return torch.empty(numel, dtype=self._dtype, device=torch.device("cuda", self._device))
+
+    def extend(self, new_total_logical_numel: int) -> None:
+        n = int(new_total_logical_numel)
+        if n <= self._logical:
+            return
+        if n > self._buf.numel():
+            new = self._alloc(self._round(max(n, 2 * self._buf.numel())))
+            new[: self._logical].copy_(self._buf[: self._logical])
+            self._buf = new
+        self._logical = n
+
+    def data(self) -> torch.Tensor:
+        return self._buf[: self._logical]
+
+    def logical_numel(self) -> int:
+        return self._logical
+
+    def allocated_numel(self) -> int:
+        return self._buf.numel()
+
+    def allocated_bytes(self) -> int:
+        return self._buf.numel() * self._buf.element_size()
+
+
+class VMMTensor(_GrowableTensor):
+    def __init__(self, numel: int, dtype: torch.dtype, device: int):
+        super().__init__(numel, dtype, device, host=False)
+
+
+class HostVMMTensor(_GrowableTensor):
+    def __init__(self, numel: int, dtype: torch.dtype, device: int):
+        super().__init__(numel, dtype, device, host=True)
+
+
 def device_timestamp() -> int:
     """device_timestamp (torch_utils.cu:150): device clock ticks (host sync, as the reference)."""
     t = torch.empty(1, dtype=torch.int64, device="cuda")

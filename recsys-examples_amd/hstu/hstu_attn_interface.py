@@ -160,8 +160,10 @@ def hstu_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, seqused_q, sequse
         raise RuntimeError("max_seqlen_q must be <= max_seqlen_k")
     if scaling_seqlen is None or scaling_seqlen == -1:
         scaling_seqlen = max_seqlen_q
-    same = cu_seqlens_q.data_ptr() == cu_seqlens_k.data_ptr() or (
-        cu_seqlens_q.shape == cu_seqlens_k.shape and bool(torch.equal(cu_seqlens_q, cu_seqlens_k)))
+    # (the comparison of two distinct offset tensors reads them back: only done when no cache was passed, so that the
+    # paged decode step stays free of host syncs and can be captured in a HIP graph)
+    same = kv_cache is None and (cu_seqlens_q.data_ptr() == cu_seqlens_k.data_ptr() or (
+        cu_seqlens_q.shape == cu_seqlens_k.shape and bool(torch.equal(cu_seqlens_q, cu_seqlens_k))))
     if kv_cache is not None or not same:
         # inference: keys longer than the queries and / or history keys in the paged cache; no backward
         if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):

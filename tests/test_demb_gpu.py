@@ -779,3 +779,17 @@ def test_segmented_unique_csr_and_group_by(n, T, zipf):
     for u in range(0, nu, max(1, nu // 200)):
         a, b = starts[u], starts[u + 1]
         assert sorted(c2[a:b].tolist()) == sorted(bag_of[rev_o == u].tolist())
+
+
+def test_vmm_tensors_extend_preserves_contents():
+    e = ext()
+    for cls in (e.VMMTensor, e.HostVMMTensor):
+        t = cls(1000, torch.float32, 0)
+        d = t.data()
+        assert d.numel() == 1000 and t.allocated_numel() >= 1000 and t.allocated_bytes() >= 4000
+        d.copy_(torch.arange(1000, dtype=torch.float32))
+        t.extend(5_000_000)   # beyond the slack: re-allocates
+        d2 = t.data()
+        assert d2.numel() == 5_000_000 == t.logical_numel()
+        assert torch.equal(d2[:1000].cpu(), torch.arange(1000, dtype=torch.float32))
+        assert d2.is_cuda == (cls is e.VMMTensor)

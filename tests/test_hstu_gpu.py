@@ -234,3 +234,53 @@ def test_paged_kvcache_ops_registration():
         page = [2, 0][pos // P]
         assert torch.equal(cache[page, 0, pos % P], key[i]) and torch.equal(cache[page, 1, pos % P], val[i])
     assert float(cache[1].abs().sum()) == 0 and float(cache[3].abs().sum()) == 0
+
+
+def test_decode_step_is_hipgraph_capturable():
+    """config 5: append the new history to the paged cache + paged attention, captured once in a HIP graph and
+    replayed on new data (static buffers) -- the step has no host sync and no allocation-dependent control flow"""
+    from hstu import append_kvcache, hstu_attn_varlen_func
+
+    H, d, P, B = 2, 64, 16, 3
+    rng = np.random.default_rng(1)
+    new_hist, num_cand, old = np.array([5, 9, 3]), np.array([2, 1, 4]), np.array([20, 0, 33])
+    qlen, cachelen = new_hist + num_cand, old + new_hist
+    q_off = np.concatenate([[0], np.cumsum(qlen)]).astype(np.int32)
+    k_off = np.concatenate([[0], np.cumsum(cachelen + num_cand)]).astype(np.int32)
+    T = int(q_off[-1])
+    ti = lambda a: torch.tensor(np.asarray(a), dtype=torch.int32, device=DEV)
+    npg = (cachelen + P - 1) // P
+    page_ids = ti(rng.permutation(int(npg.sum())))
+    page_off = ti(np.concatenate([[0], np.cumsum(npg)]))
+    last = ti(cachelen - (npg - 1) * P)
+    cuq, cuk, tgt = ti(q_off), ti(k_off), ti(num_cand)
+    bidx = ti(np.repeat(np.arange(B), new_hist))
+    pos = ti(np.concatenate([old[b] + np.arange(new_hist[b]) for b in range(B)]))
+    cand_off = ti(np.concatenate([[0], np.cumsum(num_cand)]))
+    nnz = ti([int(new_hist.sum())])
+    cache = torch.randn(int(npg.sum()), 2, P, H, d, device=DEV).bfloat16()
+    q, k, v = (torch.randn(T, H, d, device=DEV).bfloat16() for _ in range(3))
+    out = torch.empty_like(q)
+
+    def step():
+        append_kvcache(k, v, bidx, pos, cand_off, nnz, 0, cache, page_ids, page_off, last, 0)
+        out.copy_(hstu_attn_varlen_func(q, k, v, cuq, cuk, None, None, int(qlen.max()), 64, 100.0, None, tgt,
+                                        window_size=(-1, 0), alpha=0.125, kv_cache=cache, page_offsets=page_off,
+                                        page_ids=page_ids, last_page_lens=last))
+
+    step()   # warm up (library load, attribute setting) outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            step()
+    for _ in range(2):
+        for t in (q, k, v):
+            t.copy_(torch.randn_like(t.float()).bfloat16())
+        graph.replay()
+        torch.cuda.synchronize()
+        got = out.clone()
+        step()
+        torch.cuda.synchronize()
+        assert torch.equal(got, out)
