@@ -426,7 +426,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         return t
 
     def size(self, table_id: Optional[int] = None):
-        return sum(int(tb.size(table_id)) for tb, _ in self._tiers())
+        return sum(tb.size(table_id).to(self.device_) for tb, _ in self._tiers())
 
     def lookup_rows(self, keys: torch.Tensor, table_id: int = 0):
         """(found, rows [n, value_dim]) of `keys` over all storage tiers -- test / debugging helper (CONST lookup)."""

@@ -303,4 +303,4 @@ def test_storage_tiers_are_transparent(mode, pooling, optimizer):
         torch.testing.assert_close(r2, r1, rtol=1e-5, atol=1e-6)
     if mode == "hybrid":
         assert int(dut.table_host.size()) > 0, "the HBM tier never spilled: the test does not exercise eviction"
-        assert dut.size() == ref.size()
+        assert int(dut.size()) == int(ref.size())
