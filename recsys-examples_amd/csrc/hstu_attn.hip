@@ -25,6 +25,8 @@
 #include "common.h"
 #include "../../include/recsys_amd.h"
 #include <stdlib.h>
+#include <type_traits>
+
 
 namespace mi355 {
 
@@ -340,6 +342,70 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
     // ---- P^T = mask * SiLU(alpha S^T) / scaling, packed straight into the B operand of GEMM 2.
     // Tiles strictly below the diagonal of every row of the wave need no per-element mask.
     const bool full = a.causal && (n0 + kBN - 1 <= dq + qrow0) && (!s.has_ctx || dq + qrow0 >= s.c) && (!s.has_tgt || n0 + kBN - 1 < s.hlen);
+    if constexpr (D >= 256) {
+    // ---- GEMM 2: O^T[D x 32 q] += V^T[D x 64 keys] P^T, software-pipelined with the SiLU epilogue of GEMM 1: the
+    // 16-key slice ks+1 of P is computed (VALU + transcendental pipes) while the MFMAs of slice ks run -- at one wave
+    // per SIMD nothing else overlaps the ~1.8 K cycles of SiLU per tile with the ~2 K cycles of MFMA.  `full` is
+    // hoisted out as a compile-time variant so that the pipelined region is one basic block.
+    constexpr int NDT = D / 32;
+    constexpr int DB = NDT < 8 ? NDT : 8;
+    pin_agpr(acc_o);
+    auto gemm2 = [&](auto fullc) {
+      constexpr bool kFull = decltype(fullc)::value;
+      auto ew = [&](int ks) -> bf16x8_t {   // P^T slice ks: keys 16*ks .. 16*ks+15 of the tile (register order of acc_s)
+        const int t = ks >> 1, r0 = (ks & 1) * 8;
+        uint32_t pk[4];
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+          float p2[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int rr = r0 + r + u;
+            const float pv = silu_scaled(acc_s[t][rr], nal2e, ais);
+            if (kFull) p2[u] = pv;
+            else {
+              const int key = n0 + 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+              p2[u] = key_ok(key, rm) ? pv : 0.f;
+            }
+          }
+          pk[r >> 1] = pack_bf16(p2[0], p2[1]);
+        }
+        const u32x4_t x = {pk[0], pk[1], pk[2], pk[3]};
+        return __builtin_bit_cast(bf16x8_t, x);
+      };
+      constexpr int NBAT2 = 4 * (NDT / DB);
+      bf16x8_t vfr[2][DB];
+      auto load_v = [&](int bi, int buf) {
+        const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
+#pragma unroll
+        for (int u = 0; u < DB; ++u)
+          vfr[buf][u] = *reinterpret_cast<const bf16x8_t*>(Vt + (32 * (dt0 + u) + l31) * VS + 16 * ks + 8 * hi);
+      };
+      load_v(0, 0);
+      constexpr bool kPipe = true;
+      bf16x8_t pf[4];
+      pf[0] = ew(0);
+      if constexpr (!kPipe) { pf[1] = ew(1); pf[2] = ew(2); pf[3] = ew(3); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int bi = 0; bi < NBAT2; ++bi) {
+        const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
+        const bool last_of_ks = (bi % (NDT / DB)) == (NDT / DB) - 1;
+        if (bi + 1 < NBAT2) load_v(bi + 1, (bi + 1) & 1);
+        if constexpr (kPipe) {
+          if (last_of_ks && ks + 1 < 4) pf[ks + 1] = ew(ks + 1);   // independent of this batch's MFMAs: fills their shadow
+        } else {
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < DB; ++u) mfma_a(acc_o[dt0 + u], vfr[bi & 1][u], pf[ks]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (full) gemm2(std::true_type{}); else gemm2(std::false_type{});
+    } else {
+    // smaller head dims: 2-3 waves per SIMD already overlap SiLU with another wave's MFMAs, and the pipelined form costs
+    // ~30 VGPRs (one occupancy step at d = 128)
     bf16x8_t pf[4];
     if (full) {
 #pragma unroll
@@ -397,6 +463,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
         for (int u = 0; u < DB; ++u) mfma_a(acc_o[dt0 + u], vfr[bi & 1][u], pf[ks]);
         __builtin_amdgcn_sched_barrier(0);
       }
+    }
     }
   }
   fence_a(acc_o);
