@@ -419,6 +419,193 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         return out
 
     # ---------------------------------------------------------------------------------- inspection
+    # ---------------------------------------------------------------------------------- checkpoint wire format
+    # Files of the reference (batched_dynamicemb_tables.py:73-92,1262-1409; key_value_table.py:1134-1290):
+    #   {table}_emb_keys.rank_R.world_size_W        int64  [n]
+    #   {table}_emb_values.rank_R.world_size_W      fp32   [n, dim]
+    #   {table}_emb_scores.rank_R.world_size_W      int64  [n]   (LRU / timestamp scores are stored as AGE = now - score)
+    #   {table}_emb_opt_values.rank_R.world_size_W  fp32   [n, ckpt_state_dim]   (optim=True)
+    #   {table}_opt_args.json                       optimizer hyper-parameters + evict_strategy + dist_type (rank 0)
+    # all raw little-endian, no headers; on load every rank reads every file and keeps the keys with key % W == rank.
+    def _ckpt_state_dim(self, dim: int) -> int:
+        return {1: 0, 2: 2 * dim, 3: dim, 4: 1}[self._opt_kind]
+
+    def _opt_args(self):
+        name = {1: "sgd", 2: "adam", 3: "exact_adagrad", 4: "exact_row_wise_adagrad"}[self._opt_kind]
+        a = {"opt_type": name, "lr": self.learning_rate}
+        if self._opt_kind == 2:
+            a.update(iters=self._iter_num, beta1=self.beta1, beta2=self.beta2, eps=self.eps, weight_decay=self.weight_decay)
+        elif self._opt_kind in (3, 4):
+            a.update(eps=self.eps, initial_accumulator_value=self.initial_accumulator_value)
+        return a
+
+    def _is_lru(self) -> bool:
+        return self._score_strategy == DynamicEmbScoreStrategy.TIMESTAMP
+
+    @staticmethod
+    def _rank_world(pg):
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(group=pg), dist.get_world_size(group=pg)
+        return 0, 1
+
+    def _export_table(self, table_id: int, batch: int = 1 << 16):
+        """yields (keys i64[n], rows [n, value_dim], scores i64[n]) of one logical table over all storage tiers"""
+        for tb, vals in self._tiers():
+            C = tb.bucket_capacity_
+            b0, b1 = int(tb.table_bucket_offsets_cpu_[table_id]), int(tb.table_bucket_offsets_cpu_[table_id + 1])
+            lo, hi = b0 * C, b1 * C
+            v = vals[table_id]
+            for off in range(lo, hi, batch):
+                n = min(batch, hi - off)
+                cnt, keys, scores, idx = ext.table_export_batch(tb.table_storage_, C, n, off, torch.int64, None, lo,
+                                                                tb.num_scores_, 0)
+                c = int(cnt.item())
+                if c == 0:
+                    continue
+                rows = v[idx[:c].to(v.device)].to(self.device_)
+                yield keys[:c], rows, scores[:c]
+
+    def dump(self, save_dir: str, optim: bool = False, counter: bool = False, table_names: Optional[List[str]] = None,
+             pg=None) -> None:
+        import json
+        import os
+
+        rank, world = self._rank_world(pg)
+        names = table_names if table_names is not None else self._table_names
+        os.makedirs(save_dir, exist_ok=True)
+        now = ext.device_timestamp()
+        for t, name in enumerate(self._table_names):
+            if name not in set(names):
+                continue
+            D = self.dims[t]
+            base = lambda item: os.path.join(save_dir, f"{name}_emb_{item}.rank_{rank}.world_size_{world}")  # noqa: E731
+            if rank == 0:
+                meta = self._opt_args()
+                meta["evict_strategy"] = "EvictStrategy.KLru" if self._is_lru() else "EvictStrategy.KCustomized"
+                meta["dist_type"] = self._dynamicemb_options[t].dist_type
+                if self._score_strategy == DynamicEmbScoreStrategy.STEP:
+                    meta["step_score"] = self._step
+                with open(os.path.join(save_dir, f"{name}_opt_args.json"), "w") as f:
+                    json.dump(meta, f)
+            cs = self._ckpt_state_dim(D)
+            with open(base("keys"), "wb") as fk, open(base("values"), "wb") as fv, open(base("scores"), "wb") as fs:
+                fo = open(base("opt_values"), "wb") if optim else None
+                for keys, rows, scores in self._export_table(t):
+                    fk.write(keys.cpu().numpy().tobytes())
+                    fv.write(rows[:, :D].float().contiguous().cpu().numpy().tobytes())
+                    sc = (now - scores) if self._is_lru() else scores
+                    fs.write(sc.cpu().numpy().tobytes())
+                    if fo is not None and cs:
+                        fo.write(rows[:, D:D + cs].float().contiguous().cpu().numpy().tobytes())
+                if fo is not None:
+                    fo.close()
+
+    def load(self, save_dir: str, optim: bool = False, counter: bool = False, table_names: Optional[List[str]] = None,
+             pg=None) -> None:
+        import glob
+        import json
+        import os
+
+        import numpy as np
+
+        from .scored_hashtable import ScoreArg
+
+        rank, world = self._rank_world(pg)
+        names = table_names if table_names is not None else self._table_names
+        now = ext.device_timestamp()
+        dev = self.device_
+        for t, name in enumerate(self._table_names):
+            if name not in set(names):
+                continue
+            key_files = sorted(glob.glob(os.path.join(save_dir, f"{name}_emb_keys.rank_*.world_size_*")))
+            if not key_files:
+                continue
+            meta_path = os.path.join(save_dir, f"{name}_opt_args.json")
+            meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
+            use_opt = optim
+            if meta.get("opt_type") and meta["opt_type"] != self._opt_args()["opt_type"]:
+                print(f"Optimizer type mismatch: {meta['opt_type']} != {self._opt_args()['opt_type']}. Will not load optimizer states.")
+                use_opt = False
+            if meta.get("dist_type", "roundrobin") != self._dynamicemb_options[t].dist_type:
+                raise ValueError(f"Input dist_type mismatch: checkpoint was dumped with {meta.get('dist_type')!r}")
+            if "step_score" in meta and self._score_strategy == DynamicEmbScoreStrategy.STEP:
+                self._step = max(self._step, int(meta["step_score"]))
+            if use_opt and self._opt_kind == 2 and "iters" in meta:
+                self._iter_num = int(meta["iters"])
+            D, V = self.dims[t], self.value_dims[t]
+            cs = self._ckpt_state_dim(D)
+            for kf in key_files:
+                suffix = kf[kf.index("_emb_keys") + len("_emb_keys"):]
+                path = lambda item: os.path.join(save_dir, f"{name}_emb_{item}{suffix}")  # noqa: E731
+                nkeys = os.path.getsize(kf) // 8
+                B = 1 << 16
+                with open(kf, "rb") as fk, open(path("values"), "rb") as fv:
+                    fs = open(path("scores"), "rb") if os.path.exists(path("scores")) else None
+                    fo = open(path("opt_values"), "rb") if (use_opt and cs and os.path.exists(path("opt_values"))) else None
+                    for start in range(0, nkeys, B):
+                        n = min(B, nkeys - start)
+                        keys = np.frombuffer(fk.read(8 * n), dtype=np.int64)
+                        emb = np.frombuffer(fv.read(4 * D * n), dtype=np.float32).reshape(n, D)
+                        sc = np.frombuffer(fs.read(8 * n), dtype=np.int64) if fs else None
+                        op = np.frombuffer(fo.read(4 * cs * n), dtype=np.float32).reshape(n, cs) if fo else None
+                        if world > 1:
+                            m = (keys % world) == rank
+                            keys, emb = keys[m], emb[m]
+                            sc = sc[m] if sc is not None else None
+                            op = op[m] if op is not None else None
+                        if keys.size == 0:
+                            continue
+                        k_t = torch.from_numpy(keys.copy()).to(dev)
+                        rows = torch.full((keys.size, V), float(self.initial_accumulator_value), dtype=torch.float32, device=dev)
+                        rows[:, :D] = torch.from_numpy(emb.copy()).to(dev)
+                        if op is not None:
+                            rows[:, D:D + cs] = torch.from_numpy(op.copy()).to(dev)
+                        elif self._opt_kind == 2:
+                            rows[:, D:] = 0.0
+                        if sc is not None:
+                            s_t = torch.from_numpy(sc.copy()).to(dev)
+                            s_t = (now - s_t) if self._is_lru() else s_t
+                        else:
+                            s_t = torch.full((keys.size,), now if self._is_lru() else 0, dtype=torch.int64, device=dev)
+                        self._insert_rows(t, k_t, rows.to(self.embedding_dtype), s_t)
+                    if fs:
+                        fs.close()
+                    if fo:
+                        fo.close()
+
+    def flush(self) -> None:
+        """write-back of a promoting cache (batched_dynamicemb_tables.py:955); the tiers here hold each key once"""
+
+    def export_keys_values(self, table_name: str, device: torch.device, batch_size: int = 65536):
+        """(keys i64[n], embeddings fp32[n, dim]) of one table (batched_dynamicemb_tables.py:1411-1430)"""
+        t = self._table_names.index(table_name)
+        ks, vs = [], []
+        for keys, rows, _ in self._export_table(t, batch_size):
+            ks.append(keys.to(device))
+            vs.append(rows[:, : self.dims[t]].float().to(device))
+        if not ks:
+            return torch.empty(0, dtype=torch.int64, device=device), torch.empty(0, self.dims[t], device=device)
+        return torch.cat(ks), torch.cat(vs)
+
+    def _insert_rows(self, table_id: int, keys: torch.Tensor, rows: torch.Tensor, scores: torch.Tensor) -> None:
+        """insert (key, score) pairs and store their full rows: the first tier that takes a key keeps it"""
+        from .scored_hashtable import ScoreArg
+
+        tids = torch.full_like(keys, table_id)
+        todo = torch.arange(keys.numel(), device=keys.device)
+        for tb, vals in self._tiers():
+            if todo.numel() == 0:
+                break
+            k, sc = keys[todo].contiguous(), scores[todo].contiguous()
+            idx = tb.insert(k, tids[todo].contiguous(), ScoreArg("score", sc, ext.ScorePolicy.ASSIGN))
+            ok = (idx >= 0).nonzero().squeeze(1)
+            if ok.numel():
+                v = vals[table_id]
+                v[idx[ok].to(v.device)] = rows[todo[ok]].to(v.device)
+            todo = todo[(idx < 0).nonzero().squeeze(1)]
+
     def _tiers(self):
         t = [(self.table, self.values)]
         if self.table_host is not None:
