@@ -29,7 +29,8 @@ int64_t mi355_demb_forward_workspace_bytes(int64_t num_keys, int64_t num_tables)
 //  slots [num_keys] i64, row_addr [num_keys] i64.
 //  train != 0: missing keys are inserted (insert_policy / insert_scores) and their rows initialised in
 //  place; train == 0: missing keys contribute zeros (eval, key_value_table.py:2915-2949).
-//  pooling: combiner 0 sum / 1 mean -> out [batch_size, total_D]; combiner -1 sequence -> out [num_keys, dim].
+//  pooling: combiner 0 sum / 1 mean -> out [batch_size, total_D]; combiner -1 sequence -> out [num_keys, dim];
+//  combiner -2: no output (prefetch of BatchedDynamicEmbeddingTablesV2.prefetch, batched_dynamicemb_tables.py:1090-1137).
 int mi355_demb_forward(
     /* table */ void* storage, const int64_t* table_bucket_offsets, int64_t bucket_capacity, int64_t num_scores,
     int32_t* bucket_sizes, int32_t* counter, int64_t counter_numel,
@@ -48,7 +49,7 @@ int mi355_demb_forward(
     /* scratch */ void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   MI355_CHECK_ARG(workspace && workspace_bytes >= mi355_demb_forward_workspace_bytes(num_keys, num_tables),
                   "workspace too small");
-  if (num_keys == 0 && combiner < 0) return MI355_OK;
+  if (num_keys == 0 && combiner < 0) return MI355_OK;  // (pooled output of an empty batch is still zero-filled below)
   uint8_t* w = (uint8_t*)workspace;
   int64_t* table_range = (int64_t*)w; w += al(8 * (num_tables + 1));
   void* unique_keys = w; w += al(8 * num_keys);
@@ -88,6 +89,8 @@ int mi355_demb_forward(
   if (combiner >= 0) {
     STEP(mi355_gather_pooled(nullptr, 0, row_addr, value_dtype, reverse_indices, num_keys, offsets, num_bags, batch_size,
                              combiner, emb_dim, D_offsets, total_D, out, out_dtype, aligned16, stream));
+  } else if (combiner == -2) {
+    // prefetch: the index stage only (dedup, find / insert, pin, row addresses); the rows are gathered by the forward
   } else {
     STEP(mi355_gather_rows(nullptr, 0, row_addr, value_dtype, reverse_indices, num_keys, nullptr, emb_dim, out,
                            emb_dim, out_dtype, aligned16, stream));

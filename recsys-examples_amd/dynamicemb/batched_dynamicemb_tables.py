@@ -38,7 +38,7 @@ class _StepCtx:
     """What one forward leaves for its backward (the reference's PrefetchState + autograd ctx)."""
 
     __slots__ = ("rev", "uoff", "tids", "slots", "row_addr", "offsets", "num_keys", "batch_size", "num_bags", "csr_cnt",
-                 "csr_rank")
+                 "csr_rank", "pinned", "event", "indices")
 
 
 class _LookupFunction(torch.autograd.Function):
@@ -183,6 +183,9 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         self._empty_tensor = nn.Parameter(torch.empty(10, requires_grad=True, device=self.device_,
                                                       dtype=self.embedding_dtype))
         self._pin = False  # ref-counter pinning is only needed when prefetch runs ahead of backward
+        from collections import deque
+
+        self._prefetch_states = deque()
 
     # ---------------------------------------------------------------------------------- helpers
     def set_score(self, score: int) -> None:
@@ -227,13 +230,20 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         return P.LRU_LFU, None, P.LRU_LFU, None, True
 
     # ---------------------------------------------------------------------------------- forward
-    def _forward_impl(self, indices: torch.Tensor, offsets: torch.Tensor, train: bool):
+    def _forward_impl(self, indices: torch.Tensor, offsets: torch.Tensor, train: bool, prefetch_only: bool = False):
         indices = indices.contiguous()
         offsets = offsets.to(torch.int64).contiguous()
         if indices.dtype != torch.int64:
             indices = indices.to(torch.int64)
         if self.storage_mode == "hybrid":
+            if prefetch_only:
+                raise NotImplementedError("prefetch() with hybrid storage")
             return self._forward_hybrid(indices, offsets, train)
+        if not prefetch_only and train and self._prefetch_states:
+            st = self._prefetch_states.popleft()
+            if st.num_keys != indices.numel() or st.num_bags != offsets.numel() - 1:
+                raise RuntimeError("forward() received a batch that was not the oldest prefetched one")
+            return self._gather_prefetched(st), st
         n = indices.numel()
         num_bags = offsets.numel() - 1
         B = num_bags // self.feature_num
@@ -250,7 +260,11 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         st.csr_cnt = torch.empty(n, dtype=torch.int32, device=dev) if train else None
         st.csr_rank = torch.empty(n, dtype=torch.int32, device=dev) if train else None
         st.offsets, st.num_keys, st.batch_size, st.num_bags = offsets, n, B, num_bags
-        if pooled:
+        st.pinned = bool((self._pin or prefetch_only) and train)
+        st.event = None
+        if prefetch_only:
+            out, combiner = None, -2
+        elif pooled:
             out = torch.empty(B, self.total_D, dtype=self.output_dtype, device=dev)
             combiner = 0 if self.pooling_mode == DynamicEmbPoolingMode.SUM else 1
         else:
@@ -269,9 +283,9 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             ptr(self.table_ptrs), ptr(self.table_value_dims), ptr(self.table_emb_dims), dt(self.embedding_dtype),
             self.max_D, max(self.value_dims),
             ptr(indices), n, ptr(offsets), num_bags, B, ptr(self.feature_offsets), T,
-            int(train), int(fp), ptr(fs), int(ip), ptr(isc), c_u64(ext.TIMER_OVERRIDE), int(self._pin and train),
+            int(train), int(fp), ptr(fs), int(ip), ptr(isc), c_u64(ext.TIMER_OVERRIDE), int(st.pinned),
             mode, c_f(p[0]), c_f(p[1]), c_f(p[2]), c_f(p[3]), c_u64(self._seed), c_f(state_init),
-            combiner, ptr(self.D_offsets_t), self.total_D, ptr(out), dt(out), int(al),
+            combiner, ptr(self.D_offsets_t), self.total_D, ptr(out), dt(out) if out is not None else 0, int(al),
             ptr(st.rev), ptr(st.uoff), ptr(st.tids), ptr(st.slots), ptr(st.row_addr), ptr(freq),
             ptr(st.csr_cnt), ptr(st.csr_rank), ptr(ws), ws.numel(), stream()), "demb_forward")
         if train:
@@ -298,6 +312,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         st = _StepCtx()
         st.offsets, st.num_keys, st.batch_size, st.num_bags = offsets, n, B, num_bags
         st.tids = st.slots = None
+        st.pinned, st.event = False, None
         if pooled:
             out = torch.empty(B, self.total_D, dtype=self.output_dtype, device=dev)
             combiner = 0 if self.pooling_mode == DynamicEmbPoolingMode.SUM else 1
@@ -380,6 +395,42 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             self._step += 1
         return out, st
 
+    # ---------------------------------------------------------------------------------- prefetch
+    def prefetch(self, indices: torch.Tensor, offsets: torch.Tensor, forward_stream: Optional[torch.cuda.Stream] = None,
+                 batch_size_per_feature_per_rank=None, frequency_counters=None) -> None:
+        """BatchedDynamicEmbeddingTablesV2.prefetch (batched_dynamicemb_tables.py:1090-1137): run the index stage of a
+        later batch (dedup, find, insert + first-touch init of unseen keys, pin) on the CURRENT stream, typically a side
+        stream, while earlier batches still compute.  The rows it touches stay pinned (ref-counters) until the batch's
+        backward releases them, so a later prefetch cannot evict them.  forward() consumes the states in FIFO order and
+        only gathers."""
+        if not self.training:
+            return
+        _, st = self._forward_impl(indices, offsets, train=True, prefetch_only=True)
+        st.event = torch.cuda.Event()
+        st.event.record()
+        st.indices = indices   # keeps the key tensor alive until the forward
+        self._prefetch_states.append(st)
+
+    def _gather_prefetched(self, st):
+        if st.event is not None:
+            torch.cuda.current_stream().wait_event(st.event)
+        dev = self.device_
+        pooled = self.pooling_mode != DynamicEmbPoolingMode.NONE
+        al = all(d % 4 == 0 for d in self.dims) and all(v % 4 == 0 for v in self.value_dims)
+        n = st.num_keys
+        if pooled:
+            out = torch.empty(st.batch_size, self.total_D, dtype=self.output_dtype, device=dev)
+            combiner = 0 if self.pooling_mode == DynamicEmbPoolingMode.SUM else 1
+            check(lib().mi355_gather_pooled(None, 0, ptr(st.row_addr), dt(self.embedding_dtype), ptr(st.rev), n, ptr(st.offsets),
+                                            st.num_bags, st.batch_size, combiner, self.max_D, ptr(self.D_offsets_t), self.total_D,
+                                            ptr(out), dt(out), int(al), stream()), "gather_pooled")
+        else:
+            out = torch.empty(n, self.dims[0], dtype=self.output_dtype, device=dev)
+            if n:
+                check(lib().mi355_gather_rows(None, 0, ptr(st.row_addr), dt(self.embedding_dtype), ptr(st.rev), n, None,
+                                              self.max_D, ptr(out), out.stride(0), dt(out), int(al), stream()), "gather_rows")
+        return out
+
     def _safe_check(self, st):
         nu = int(st.uoff[-1].item())
         failed = int((st.slots[:nu] < 0).sum().item())
@@ -406,8 +457,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             dt(self.embedding_dtype), self._opt_kind, c_f(self.learning_rate), c_f(self.beta1), c_f(self.beta2),
             c_f(self.eps), c_f(self.weight_decay), self._iter_num, -1, 1, int(al),
             ptr(tb._ref_counter), tb._ref_counter.numel(), ptr(st.slots), ptr(st.tids), ptr(tb.table_bucket_offsets_),
-            tb.bucket_capacity_, int(self._pin), ptr(st.csr_cnt), ptr(st.csr_rank), ptr(ws), ws.numel(), stream()),
-            "demb_backward")
+            tb.bucket_capacity_, int(bool(getattr(st, "pinned", False)) and st.slots is not None), ptr(st.csr_cnt),
+            ptr(st.csr_rank), ptr(ws), ws.numel(), stream()), "demb_backward")
 
     def forward(self, indices: torch.Tensor, offsets: torch.Tensor, per_sample_weights=None,
                 feature_requires_grad=None, batch_size_per_feature_per_rank=None, total_unique_indices=None):

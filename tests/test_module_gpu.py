@@ -386,3 +386,65 @@ def test_dump_load_wire_format_roundtrip(tmp_path, optimizer, strategy):
     ck = torch.from_numpy(np.fromfile(tmp_path / "user_emb_keys.rank_0.world_size_1", dtype=np.int64)).cuda()
     sel = torch.isin(probe, ck) & both
     torch.testing.assert_close(r1[sel][:, :dims[0]], r2[sel][:, :dims[0]], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("pooling", ["SUM", "NONE"])
+def test_prefetch_one_batch_ahead_matches_plain_training(pooling):
+    """prefetch(batch i+1) on a side stream before backward(batch i) (PrefetchTrainPipelineSparseDist's order,
+    examples/commons/pipeline/train_pipeline.py:533-692): outputs and final rows equal those of plain
+    forward / backward, and every pin is released at the end"""
+    from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
+    from dynamicemb.dynamicemb_config import (DynamicEmbInitializerArgs, DynamicEmbInitializerMode, DynamicEmbPoolingMode,
+                                              DynamicEmbScoreStrategy, DynamicEmbTableOptions, EmbOptimType)
+
+    rng = np.random.default_rng(2)
+    torch.manual_seed(2)
+    dims, F, B = [8, 8], 2, 20
+    pm = DynamicEmbPoolingMode.SUM if pooling == "SUM" else DynamicEmbPoolingMode.NONE
+
+    def make():
+        opts = [DynamicEmbTableOptions(dim=d, max_capacity=4096, index_type=torch.int64, embedding_dtype=torch.float32,
+                                       score_strategy=DynamicEmbScoreStrategy.STEP,
+                                       initializer_args=DynamicEmbInitializerArgs(mode=DynamicEmbInitializerMode.DEBUG))
+                for d in dims]
+        m = BatchedDynamicEmbeddingTablesV2(opts, pooling_mode=pm, output_dtype=torch.float32, optimizer=EmbOptimType.ADAM,
+                                            learning_rate=0.05, device=torch.device("cuda", 0))
+        m.train()
+        return m
+
+    batches = []
+    for _ in range(6):
+        lens = rng.integers(0, 5, F * B)
+        off = np.zeros(F * B + 1, np.int64)
+        off[1:] = np.cumsum(lens)
+        batches.append((torch.from_numpy(rng.integers(0, 300, off[-1]).astype(np.int64)).cuda(), torch.from_numpy(off).cuda()))
+    plain, piped = make(), make()
+    grads, outs_plain = [], []
+    for k, o in batches:
+        out, st = plain._forward_impl(k, o, train=True)
+        g = torch.randn_like(out)
+        grads.append(g)
+        outs_plain.append(out)
+        plain._backward_impl(st, g)
+    side = torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+    with torch.cuda.stream(side):
+        piped.prefetch(*batches[0], forward_stream=main)
+    for i, (k, o) in enumerate(batches):
+        out, st = piped._forward_impl(k, o, train=True)       # consumes the prefetched state
+        if i + 1 < len(batches):
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                piped.prefetch(*batches[i + 1], forward_stream=main)   # runs ahead of this batch's backward
+        torch.testing.assert_close(out, outs_plain[i], rtol=1e-6, atol=1e-6)
+        piped._backward_impl(st, grads[i])
+        main.wait_stream(side)
+    torch.cuda.synchronize()
+    probe = torch.arange(0, 300, device="cuda", dtype=torch.int64)
+    for t in range(2):
+        f1, r1 = plain.lookup_rows(probe, t)
+        f2, r2 = piped.lookup_rows(probe, t)
+        assert torch.equal(f1, f2)
+        torch.testing.assert_close(r2, r1, rtol=1e-5, atol=1e-6)
+    assert int(piped.table._ref_counter.abs().sum()) == 0, "a prefetched row stayed pinned"
+    assert not piped._prefetch_states
