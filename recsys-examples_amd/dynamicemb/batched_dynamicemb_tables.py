@@ -71,8 +71,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         opt0 = table_options[0]
         for o in table_options:
             assert opt0 == o, "All tables must match in grouped keys."
-            if o.caching or o.external_storage is not None or o.admit_strategy is not None:
-                raise NotImplementedError("cache-with-promotion / external storage / admission are 'next' rows (DESIGN.md)")
+            if o.external_storage is not None or o.admit_strategy is not None:
+                raise NotImplementedError("external storage / admission are 'next' rows (DESIGN.md)")
         self._dynamicemb_options = table_options
         self._table_names = table_names or [f"t{i}" for i in range(len(table_options))]
         self.pooling_mode = pooling_mode
@@ -148,7 +148,15 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         total_bytes = sum(c * b for c, b in zip(caps, row_bytes))
         if storage_mode is None:
             storage_mode = "hybrid" if 0 < opt0.local_hbm_for_values < total_bytes else "hbm"
-        assert storage_mode in ("hbm", "host", "hybrid")
+            if opt0.caching and storage_mode == "hybrid":
+                storage_mode = "cache"
+        assert storage_mode in ("hbm", "host", "hybrid", "cache")
+        #  cache  : `caching=True` (DynamicEmbCache + backing storage, key_value_table.py:1522-1647): the hybrid layout
+        #           plus PROMOTION -- a key found in the host tier moves into the HBM tier (whose evictions move down), so
+        #           the HBM tier converges to the hot set.  A key still lives in exactly one tier, hence flush() is a no-op.
+        self._promote = storage_mode == "cache"
+        if storage_mode == "cache":
+            storage_mode = "hybrid"
         self.storage_mode = storage_mode
         C = opt0.bucket_capacity
 
@@ -345,44 +353,66 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                 if hit1.numel():
                     addr[miss[hit1]] = ext.row_addresses(s1[hit1], t1[hit1], self.table_ptrs_host, self.table_value_dims, eb)
                 new = miss[(~f1).nonzero().squeeze(1)]
-                if train and new.numel():
-                    kn, tn = uk[new].contiguous(), tids[new].contiguous()
-                    insn = ScoreArg("score", None if ins.value is None else ins.value[new].contiguous(), ip)
+                # cache mode: host-tier hits are promoted into the HBM tier together with the unseen keys
+                prom = miss[hit1] if (train and self._promote) else miss[:0]
+                cand = torch.cat([new, prom]) if prom.numel() else new
+                if train and cand.numel():
+                    kn, tn = uk[cand].contiguous(), tids[cand].contiguous()
+                    n_new = new.numel()
+                    insn = ScoreArg("score", None if ins.value is None else ins.value[cand].contiguous(), ip)
+                    vmax = max(self.value_dims)
+                    if prom.numel():   # their rows leave the host tier first: nothing below may overwrite them
+                        buf_prom = torch.empty(prom.numel(), vmax, dtype=self.embedding_dtype, device=dev)
+                        ext.load_from_flat_table_value(self.table_ptrs_host, s1[hit1].contiguous(), t1[hit1].contiguous(), buf_prom,
+                                                       self.table_value_dims, self.table_emb_dims, self.max_D, True)
                     # rows found in the HBM tier for THIS batch must not be evicted by this batch's inserts
                     if hit0.numel():
                         self.table.increment_counter(s0[hit0].contiguous(), tids[hit0].contiguous())
                     idxn, h, ek, ei, es, et = self.table.insert_and_evict(kn, tn, insn)
                     if hit0.numel():
                         self.table.decrement_counter(s0[hit0].contiguous(), tids[hit0].contiguous())
+                    buf_ev = None
                     if h:
                         ev = (ei >= 0).nonzero().squeeze(1)   # real evictions (negative entries mark refused inputs)
-                        if ev.numel():
+                        if ev.numel():   # take the evicted rows (embedding + optimizer state) out before they are overwritten
                             e_k, e_s, e_sc, e_t = ek[ev].contiguous(), ei[ev].contiguous(), es[ev].contiguous(), et[ev].contiguous()
-                            dst = self.table_host.insert(e_k, e_t, ScoreArg("score", e_sc, ext.ScorePolicy.ASSIGN))
-                            ok = (dst >= 0).nonzero().squeeze(1)
-                            if ok.numel():   # move the evicted rows (embedding + optimizer state) before they are overwritten
-                                buf = torch.empty(ok.numel(), max(self.value_dims), dtype=self.embedding_dtype, device=dev)
-                                ext.load_from_flat_table_value(self.table_ptrs, e_s[ok].contiguous(), e_t[ok].contiguous(), buf,
-                                                               self.table_value_dims, self.table_emb_dims, self.max_D, True)
-                                ext.store_to_flat_table_value(self.table_ptrs_host, dst[ok].contiguous(), e_t[ok].contiguous(), buf,
-                                                              self.table_value_dims, self.table_emb_dims, self.max_D, True)
+                            buf_ev = torch.empty(ev.numel(), vmax, dtype=self.embedding_dtype, device=dev)
+                            ext.load_from_flat_table_value(self.table_ptrs, e_s, e_t, buf_ev, self.table_value_dims,
+                                                           self.table_emb_dims, self.max_D, True)
                     okn = (idxn >= 0).nonzero().squeeze(1)
                     if okn.numel():
-                        addr[new[okn]] = ext.row_addresses(idxn[okn].contiguous(), tn[okn].contiguous(), self.table_ptrs,
-                                                           self.table_value_dims, eb)
-                    bad = (idxn < 0).nonzero().squeeze(1)
+                        addr[cand[okn]] = ext.row_addresses(idxn[okn].contiguous(), tn[okn].contiguous(), self.table_ptrs,
+                                                            self.table_value_dims, eb)
+                    if prom.numel():
+                        pok = (idxn[n_new:] >= 0).nonzero().squeeze(1)   # promoted keys the HBM tier accepted
+                        if pok.numel():
+                            ext.store_to_flat_table_value(self.table_ptrs, idxn[n_new:][pok].contiguous(), tn[n_new:][pok].contiguous(),
+                                                          buf_prom[pok].contiguous(), self.table_value_dims, self.table_emb_dims,
+                                                          self.max_D, True)
+                            self.table_host.erase(kn[n_new:][pok].contiguous(), tn[n_new:][pok].contiguous())
+                        # the others stay where they are (their host address is already in `addr`)
+                    if buf_ev is not None:   # spill the evicted rows into the host tier
+                        dst = self.table_host.insert(e_k, e_t, ScoreArg("score", e_sc, ext.ScorePolicy.ASSIGN))
+                        ok = (dst >= 0).nonzero().squeeze(1)
+                        if ok.numel():
+                            ext.store_to_flat_table_value(self.table_ptrs_host, dst[ok].contiguous(), e_t[ok].contiguous(),
+                                                          buf_ev[ok].contiguous(), self.table_value_dims, self.table_emb_dims,
+                                                          self.max_D, True)
+                    bad = (idxn[:n_new] < 0).nonzero().squeeze(1)
                     if bad.numel():   # the HBM tier refused them (bucket full of pinned rows): they live in the host tier
-                        insb = ScoreArg("score", None if insn.value is None else insn.value[bad].contiguous(), ip)
-                        sh = self.table_host.insert(kn[bad].contiguous(), tn[bad].contiguous(), insb)
+                        insb = ScoreArg("score", None if insn.value is None else insn.value[:n_new][bad].contiguous(), ip)
+                        sh = self.table_host.insert(kn[:n_new][bad].contiguous(), tn[:n_new][bad].contiguous(), insb)
                         okb = (sh >= 0).nonzero().squeeze(1)
                         if okb.numel():
-                            addr[new[bad[okb]]] = ext.row_addresses(sh[okb].contiguous(), tn[bad[okb]].contiguous(),
+                            addr[new[bad[okb]]] = ext.row_addresses(sh[okb].contiguous(), tn[:n_new][bad[okb]].contiguous(),
                                                                     self.table_ptrs_host, self.table_value_dims, eb)
-                    mode, p = self._init_params()
-                    a_new = addr[new].contiguous()
-                    ext.init_rows(mode, p, self._seed, self.initial_accumulator_value, kn, a_new, self.embedding_dtype,
-                                  self.max_D, max(self.value_dims), skip=(a_new == 0), table_ids=tn,
-                                  table_emb_dims=self.table_emb_dims, table_value_dims=self.table_value_dims)
+                    if n_new:
+                        mode, p = self._init_params()
+                        a_new = addr[new].contiguous()
+                        ext.init_rows(mode, p, self._seed, self.initial_accumulator_value, kn[:n_new].contiguous(), a_new,
+                                      self.embedding_dtype, self.max_D, max(self.value_dims), skip=(a_new == 0),
+                                      table_ids=tn[:n_new].contiguous(), table_emb_dims=self.table_emb_dims,
+                                      table_value_dims=self.table_value_dims)
         al = all(d % 4 == 0 for d in self.dims) and all(v % 4 == 0 for v in self.value_dims)
         if pooled:
             check(lib().mi355_gather_pooled(None, 0, ptr(st.row_addr), dt(self.embedding_dtype), ptr(st.rev), n, ptr(offsets),

@@ -242,7 +242,7 @@ def test_bf16_output_matches_fp32_within_1e3():
 
 
 # ---------------------------------------------------------------------------------------- storage tiers
-@pytest.mark.parametrize("mode", ["host", "hybrid"])
+@pytest.mark.parametrize("mode", ["host", "hybrid", "cache"])
 @pytest.mark.parametrize("pooling", ["SUM", "NONE"])
 @pytest.mark.parametrize("optimizer", ["SGD", "ADAM"])
 def test_storage_tiers_are_transparent(mode, pooling, optimizer):
@@ -260,8 +260,11 @@ def test_storage_tiers_are_transparent(mode, pooling, optimizer):
     pm = DynamicEmbPoolingMode.SUM if pooling == "SUM" else DynamicEmbPoolingMode.NONE
 
     def make(storage_mode, local_hbm=0):
+        caching = storage_mode == "cache"
+        if caching:
+            storage_mode = None   # selected through the options, as the reference does (caching=True + an HBM budget)
         opts = [DynamicEmbTableOptions(dim=d, max_capacity=4096, index_type=torch.int64, embedding_dtype=torch.float32,
-                                       score_strategy=DynamicEmbScoreStrategy.STEP, local_hbm_for_values=local_hbm,
+                                       score_strategy=DynamicEmbScoreStrategy.STEP, local_hbm_for_values=local_hbm, caching=caching,
                                        initializer_args=DynamicEmbInitializerArgs(mode=DynamicEmbInitializerMode.DEBUG))
                 for d in dims]
         m = BatchedDynamicEmbeddingTablesV2(opts, pooling_mode=pm, output_dtype=torch.float32, optimizer=opt_t,
@@ -272,8 +275,8 @@ def test_storage_tiers_are_transparent(mode, pooling, optimizer):
     ref = make("hbm")
     # hybrid: room for 128 rows per table in HBM (one bucket), everything else spills to the host tier
     row_bytes = 4 * (dims[0] * (3 if optimizer == "ADAM" else 1))
-    dut = make(mode, local_hbm=2 * 128 * row_bytes if mode == "hybrid" else 0)
-    assert dut.storage_mode == mode
+    dut = make(mode, local_hbm=2 * 128 * row_bytes if mode in ("hybrid", "cache") else 0)
+    assert dut.storage_mode == ("hybrid" if mode == "cache" else mode) and dut._promote == (mode == "cache")
     seen = set()
     for step in range(8):
         lens = rng.integers(0, 5, F * B)
@@ -301,9 +304,24 @@ def test_storage_tiers_are_transparent(mode, pooling, optimizer):
         f2, r2 = dut.lookup_rows(probe, t)
         assert torch.equal(f1, f2)
         torch.testing.assert_close(r2, r1, rtol=1e-5, atol=1e-6)
-    if mode == "hybrid":
+    if mode in ("hybrid", "cache"):
         assert int(dut.table_host.size()) > 0, "the HBM tier never spilled: the test does not exercise eviction"
         assert int(dut.size()) == int(ref.size())
+    if mode == "cache":
+        # a key that sits in the host tier comes back to the HBM tier when it is used again
+        from dynamicemb.scored_hashtable import ScoreArg
+        import dynamicemb_extensions as e
+
+        allk = probe[dut.lookup_rows(probe, 0)[0]]
+        tid0 = torch.zeros_like(allk)
+        _, in_host, _ = dut.table_host.lookup(allk, tid0, ScoreArg("score", None, e.ScorePolicy.CONST))
+        victim = allk[in_host][:4].contiguous()
+        assert victim.numel() > 0
+        offv = torch.arange(0, F * B + 1, device="cuda", dtype=torch.int64).clamp(max=victim.numel())
+        dut._forward_impl(victim, offv, train=True)
+        _, now_hbm, _ = dut.table.lookup(victim, torch.zeros_like(victim), ScoreArg("score", None, e.ScorePolicy.CONST))
+        _, still_host, _ = dut.table_host.lookup(victim, torch.zeros_like(victim), ScoreArg("score", None, e.ScorePolicy.CONST))
+        assert bool(now_hbm.all()) and not bool(still_host.any())
 
 
 @pytest.mark.parametrize("optimizer", ["SGD", "ADAM", "ROWWISE"])
