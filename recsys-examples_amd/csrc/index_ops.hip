@@ -800,11 +800,79 @@ __global__ void __launch_bounds__(1024) scan_i64_kernel(const int64_t* __restric
   if (threadIdx.x == 0) out[n] = s_carry;
 }
 
+// multi-block variant for long inputs (the W*F*B bag lengths of the sharded path): tile sums, the single-block scan
+// above over the tile sums, then a per-tile scan that starts from its tile's prefix
+constexpr int kScan64Tile = 1024 * 4;
+__device__ __forceinline__ int64_t block_incl_scan_i64(int64_t v, int64_t& total) {
+  __shared__ int64_t s_w64[16];
+  const int w = threadIdx.x >> 6, lane = lane_id();
+  int64_t incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int lo = __shfl_up((int)(uint32_t)incl, off, 64), hi = __shfl_up((int)(uint32_t)((uint64_t)incl >> 32), off, 64);
+    int64_t o = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+    if (lane >= off) incl += o;
+  }
+  __syncthreads();
+  if (lane == 63) s_w64[w] = incl;
+  __syncthreads();
+  int64_t base = 0, tot = 0;
+  for (int k = 0; k < 16; ++k) { if (k < w) base += s_w64[k]; tot += s_w64[k]; }
+  total = tot;
+  return base + incl;
+}
+__global__ void __launch_bounds__(1024) scan64_tile_sums_kernel(const int64_t* __restrict__ in, int64_t n, int64_t* __restrict__ sums) {
+  const int64_t i0 = (int64_t)blockIdx.x * kScan64Tile + threadIdx.x * 4;
+  int64_t v = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v += i0 + k < n ? in[i0 + k] : 0;
+  int64_t tot;
+  block_incl_scan_i64(v, tot);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(1024) scan64_tiles_kernel(const int64_t* __restrict__ in, int64_t n, const int64_t* __restrict__ tile_prefix,
+                                                            int64_t* __restrict__ out) {
+  const int64_t i0 = (int64_t)blockIdx.x * kScan64Tile + threadIdx.x * 4;
+  int64_t x[4], v = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { x[k] = i0 + k < n ? in[i0 + k] : 0; v += x[k]; }
+  int64_t tot;
+  int64_t run = tile_prefix[blockIdx.x] + block_incl_scan_i64(v, tot) - v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { if (i0 + k < n) out[i0 + k] = run; run += x[k]; }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = tile_prefix[gridDim.x];
+}
+
 }  // namespace mi355
 
 using namespace mi355;
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// library-owned scratch for the tile sums of the long int64 scan (grown on demand; one process drives one GPU)
+static int64_t* scan64_scratch(int64_t words) {
+  static int64_t* p = nullptr;
+  static int64_t cap = 0;
+  if (words > cap) {
+    if (p) (void)hipFree(p);
+    cap = words < 8192 ? 8192 : 2 * words;
+    if (hipMalloc(&p, cap * sizeof(int64_t)) != hipSuccess) { p = nullptr; cap = 0; }
+  }
+  return p;
+}
+static int scan_i64(const int64_t* in, int64_t n, int64_t* out, hipStream_t stream) {
+  if (n <= 4 * kScan64Tile) {
+    hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, stream, in, n, out);
+    return MI355_OK;
+  }
+  const int64_t nt = ceil_div(n, kScan64Tile);
+  int64_t* sc = scan64_scratch(2 * nt + 2);
+  if (!sc) { mi355_set_error("scan scratch allocation failed"); return MI355_ELAUNCH; }
+  hipLaunchKernelGGL(scan64_tile_sums_kernel, dim3((unsigned)nt), dim3(1024), 0, stream, in, n, sc);
+  hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, stream, sc, nt, sc + nt);
+  hipLaunchKernelGGL(scan64_tiles_kernel, dim3((unsigned)nt), dim3(1024), 0, stream, in, n, sc + nt, out);
+  return MI355_OK;
+}
 
 extern "C" {
 
@@ -1053,7 +1121,7 @@ int mi355_block_bucketize(int64_t world_size, int64_t num_bags, int64_t batch_si
   const int W = (int)world_size;
   hipLaunchKernelGGL(bucketize_count_kernel, dim3(grid_for(num_bags, 4)), dim3(256), 0, stream, num_bags, batch_size, W, offsets,
                      (const uint64_t*)indices, block_sizes, dist_type_per_feature, new_lengths);
-  hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, stream, new_lengths, world_size * num_bags, new_offsets);
+  if (scan_i64(new_lengths, world_size * num_bags, new_offsets, stream) != MI355_OK) return MI355_ELAUNCH;
   hipLaunchKernelGGL(bucketize_scatter_kernel, dim3(grid_for(num_bags, 4)), dim3(256), 0, stream, num_bags, batch_size, W, offsets,
                      (const uint64_t*)indices, block_sizes, dist_type_per_feature, new_offsets, (uint64_t*)new_indices,
                      unbucketize_permute, weights, new_weights);

@@ -69,13 +69,14 @@ class HipOps:
 
     # ---- local dedup / pooling around the exchange (rows-back pooled mode, sharded.py) ----
     def unique(self, keys, offsets, feature_offsets):
-        """-> (unique_keys [Nt] (first Nu valid), reverse [Nt], unique_offsets [T+1]) per-table dedup."""
+        """-> (unique_keys [Nt] (first Nu valid), reverse [Nt], unique_offsets [T+1], aux) per-table dedup; `aux` carries
+        the per-unique counts / per-key ranks from which reduce_grads builds its CSR without a histogram pass."""
         import dynamicemb_extensions as ext
 
         T = feature_offsets.numel() - 1
         rng = ext.get_table_range(offsets, feature_offsets)
-        _, ukeys, rev, uoff, _ = ext.segmented_unique_cuda(keys, rng, T)
-        return ukeys, rev, uoff
+        ukeys, rev, uoff, cnt, rank = ext.segmented_unique_csr(keys, rng, T)
+        return ukeys, rev, uoff, (cnt, rank, uoff)
 
     def pool(self, rows, reverse, offsets, batch_size, combiner, total_D, D_offsets, max_D, out_dtype):
         import dynamicemb_extensions as ext
@@ -85,11 +86,21 @@ class HipOps:
                                     max_D=max_D)
         return out
 
-    def reduce_grads(self, reverse, grads, num_unique, batch_size, dim, offsets, D_offsets, combiner):
+    def reduce_grads(self, reverse, grads, num_unique, batch_size, dim, offsets, D_offsets, combiner, aux=None):
         import dynamicemb_extensions as ext
 
-        return ext.reduce_grads(reverse, grads, num_unique, batch_size, dim, offsets=offsets, D_offsets=D_offsets,
-                                combiner=combiner, out_dtype=torch.float32)
+        if aux is None:
+            return ext.reduce_grads(reverse, grads, num_unique, batch_size, dim, offsets=offsets, D_offsets=D_offsets,
+                                    combiner=combiner, out_dtype=torch.float32)
+        cnt, rank, uoff = aux
+        n = reverse.numel()
+        out = torch.empty(num_unique, dim, dtype=torch.float32, device=grads.device)
+        if n == 0 or num_unique == 0:
+            return out
+        ptr_t, csr, hot = ext.group_by_unique_csr(cnt, rank, reverse, num_unique, offsets, nu_dev=uoff[-1:], dim=dim)
+        ext.backward_fused(ptr_t, csr, n, num_unique, grads.contiguous(), batch_size, dim, combiner, offsets, D_offsets,
+                           weight_dtype=torch.float32, opt_kind=0, out=out, round_grad=False, nu_dev=uoff[-1:], hot=hot)
+        return out
 
 
 def exclusive_offsets(lengths: torch.Tensor) -> torch.Tensor:

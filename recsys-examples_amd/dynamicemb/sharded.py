@@ -138,7 +138,7 @@ class RowWiseShardedPooledRows:
 
     def forward(self, values: torch.Tensor, offsets: torch.Tensor, train: bool = True):
         B = (offsets.numel() - 1) // self.F
-        ukeys, rev, uoff = self.ops.unique(values, offsets, self.feature_offsets)
+        ukeys, rev, uoff, aux = self.ops.unique(values, offsets, self.feature_offsets)
         nchunk = max(1, (values.numel() + self.chunk - 1) // self.chunk)
         counts = (uoff[1:] - uoff[:-1]).view(self.T, 1)
         steps = torch.arange(nchunk, dtype=torch.int64, device=values.device).view(1, nchunk) * self.chunk
@@ -147,11 +147,11 @@ class RowWiseShardedPooledRows:
         torch.cumsum(lengths, 0, out=u_offsets[1:])
         rows, ictx = self.inner.forward(ukeys, u_offsets, train, collapse_batch=True)  # [Nu, D] fp32
         out = self.ops.pool(rows, rev, offsets, B, self.combiner, self.F * self.dim, None, self.dim, self.out_dtype)
-        return out, (ictx, rev, offsets, B, rows.size(0))
+        return out, (ictx, rev, offsets, B, rows.size(0), aux)
 
     def backward(self, ctx, grads: torch.Tensor) -> None:
-        ictx, rev, offsets, B, nu = ctx
-        ug = self.ops.reduce_grads(rev, grads.contiguous(), nu, B, self.dim, offsets, None, self.combiner)
+        ictx, rev, offsets, B, nu, aux = ctx
+        ug = self.ops.reduce_grads(rev, grads.contiguous(), nu, B, self.dim, offsets, None, self.combiner, aux)
         self.inner.backward(ictx, ug)
 
 

@@ -793,3 +793,20 @@ def test_vmm_tensors_extend_preserves_contents():
         assert d2.numel() == 5_000_000 == t.logical_numel()
         assert torch.equal(d2[:1000].cpu(), torch.arange(1000, dtype=torch.float32))
         assert d2.is_cuda == (cls is e.VMMTensor)
+
+
+def test_block_bucketize_many_bags_full_oracle():
+    """W * F * B past the single-block scan (multi-block offsets path): whole output against the oracle"""
+    e = ext()
+    rng = np.random.default_rng(77)
+    W, F, B = 8, 2, 6000   # 96 000 destination bags
+    lens = rng.integers(0, 4, size=F * B)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    idx = rng.integers(0, 1 << 40, size=int(offsets[-1])).astype(np.int64)
+    blk = np.array([(1 << 40) // W + 1] * F, np.int64)
+    gl, gi, _, _, gperm = e.block_bucketize_sparse_features(T(lens.astype(np.int64)), T(idx), False, True,
+                                                             T(np.array([1] * F, np.int32)), T(blk), W)
+    onl, ono, oni, operm = orc.block_bucketize(offsets, idx, W, B, blk, 1)
+    np.testing.assert_array_equal(gl.cpu().numpy(), onl)
+    np.testing.assert_array_equal(gi.cpu().numpy(), oni.view(np.int64))
+    np.testing.assert_array_equal(gperm.cpu().numpy(), operm)

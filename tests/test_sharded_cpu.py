@@ -75,7 +75,7 @@ class NumpyOps:
         uk, rev, uoff, _ = orc.segmented_unique(keys.numpy(), rng)
         padded = np.full(keys.numel(), -7, np.int64)  # padded like the device buffer: only [:Nu] is valid
         padded[:uk.size] = uk.astype(np.int64)
-        return torch.from_numpy(padded), torch.from_numpy(rev), torch.from_numpy(uoff)
+        return torch.from_numpy(padded), torch.from_numpy(rev), torch.from_numpy(uoff), None
 
     def pool(self, rows, reverse, offsets, batch_size, combiner, total_D, D_offsets, max_D, out_dtype):
         from oracle import oracle as orc
@@ -83,7 +83,7 @@ class NumpyOps:
         out = orc.gather_pooled(rows.numpy(), reverse.numpy(), offsets.numpy(), batch_size, combiner)
         return torch.from_numpy(out).to(out_dtype)
 
-    def reduce_grads(self, reverse, grads, num_unique, batch_size, dim, offsets, D_offsets, combiner):
+    def reduce_grads(self, reverse, grads, num_unique, batch_size, dim, offsets, D_offsets, combiner, aux=None):
         from oracle import oracle as orc
 
         return torch.from_numpy(orc.reduce_grads(reverse.numpy(), grads.numpy(), num_unique, batch_size,
