@@ -597,7 +597,7 @@ struct BwdAttnArgs {
 // K / V fragments exceed the register file of one wave, so the pass is split: MODE 1 = dV only (S -> P -> dV),
 // MODE 2 = dK only (S, dP -> dS -> dK).  Loop structure as in the forward: register-prefetched tiles, explicit
 // AGPR output accumulators, double-buffered LDS fragment batches, branch-free mask.
-template <int D, int BQ, int MODE>
+template <int D, int BQ, int MODE, bool kPre>
 __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
   const AttnArgs& a = g.f;
   constexpr bool kDV = MODE != 2, kDK = MODE != 1;
@@ -663,9 +663,8 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
     q_tr.fetch(qbase, a.q_row, i, s.L);
     do_tr.fetch(dobase, g.do_row, i, s.L);
   };
-  // small head dims run several waves per SIMD, which hides the staging latency better than holding a tile in
+  // kPre: small head dims run several waves per SIMD, which hides the staging latency better than holding a tile in
   // registers does (the prefetch registers would halve the occupancy); d = 256 runs one wave per SIMD and prefetches
-  constexpr bool kPre = D >= 256;
   if (kPre && i0 < s.L) fetch_all(i0);
   for (; i0 < s.L; i0 = advance(i0)) {
     if (kDV) pin_agpr(acc_dv);
@@ -822,7 +821,7 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
 }
 
 // pass B: one workgroup = 128 queries (32 per wave); loops over key tiles of BK keys -> dQ
-template <int D, int BK>
+template <int D, int BK, bool kPre>
 __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
   const AttnArgs& a = g.f;
   constexpr int RS = D + 8, TS = BK + 8, NT = BK / 32;
@@ -875,7 +874,6 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
     v_rows.fetch(vbase, a.v_row, n, s.L);
     k_tr.fetch(kbase, a.k_row, n, s.L);
   };
-  constexpr bool kPre = D >= 256;
   if (kPre && n_end > 0) fetch_all(0);
   for (int n0 = 0; n0 < n_end; n0 += BK) {
     pin_agpr(acc_dq);
@@ -983,35 +981,48 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
   }
 }
 
-template <int D, int BQ, int MODE>
+template <int D, int BQ, int MODE, bool kPre>
 static void launch_bwd_kv(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
   constexpr bool kDV = MODE != 2, kDK = MODE != 1;
   const size_t smem = (size_t)(BQ * (D + 8) + (kDK ? BQ * (D + 8) + D * (BQ + 8) : 0) + (kDV ? D * (BQ + 8) : 0)) * sizeof(uint16_t);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_kv_kernel<D, BQ, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_kv_kernel<D, BQ, MODE, kPre>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((hstu_bwd_kv_kernel<D, BQ, MODE>), grid, dim3(256), smem, stream, g);
+  hipLaunchKernelGGL((hstu_bwd_kv_kernel<D, BQ, MODE, kPre>), grid, dim3(256), smem, stream, g);
+}
+template <int D, int BK, bool kPre>
+static void launch_bwd_q(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
+  const size_t smem_q = (size_t)(2 * BK * (D + 8) + D * (BK + 8)) * sizeof(uint16_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_q_kernel<D, BK, kPre>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_q);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((hstu_bwd_q_kernel<D, BK, kPre>), grid, dim3(256), smem_q, stream, g);
 }
 
 template <int D>
 static int launch_bwd(const BwdAttnArgs& g, int B, int max_seqlen, hipStream_t stream) {
-  constexpr int BK = D >= 256 ? 32 : 64;
-  const size_t smem_q = (size_t)(2 * BK * (D + 8) + D * (BK + 8)) * sizeof(uint16_t);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_q_kernel<D, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_q);
-    attr_set = true;
-  }
   dim3 grid((max_seqlen + kBM - 1) / kBM, g.f.H, B);
-  if constexpr (D >= 128) {
-    launch_bwd_kv<D, 64, 1>(g, grid, stream);
-    launch_bwd_kv<D, 32, 2>(g, grid, stream);
+  if constexpr (D >= 256) {
+    static const int var = getenv("MI355_HSTU_VAR") ? atoi(getenv("MI355_HSTU_VAR")) : 1;   // tuning sweeps only; measured best = 1
+    if (var & 4) launch_bwd_kv<D, 64, 1, false>(g, grid, stream); else launch_bwd_kv<D, 64, 1, true>(g, grid, stream);
+    if (var & 1) launch_bwd_kv<D, 64, 2, false>(g, grid, stream);
+    else if (var & 8) launch_bwd_kv<D, 32, 2, false>(g, grid, stream);
+    else launch_bwd_kv<D, 32, 2, true>(g, grid, stream);
+    if (var & 2) launch_bwd_q<D, 64, false>(g, grid, stream);
+    else if (var & 16) launch_bwd_q<D, 32, false>(g, grid, stream);
+    else launch_bwd_q<D, 32, true>(g, grid, stream);
+  } else if constexpr (D >= 128) {
+    launch_bwd_kv<D, 64, 1, false>(g, grid, stream);
+    launch_bwd_kv<D, 32, 2, false>(g, grid, stream);
+    launch_bwd_q<D, 64, false>(g, grid, stream);
   } else {
-    launch_bwd_kv<D, 64, 0>(g, grid, stream);
+    launch_bwd_kv<D, 64, 0, false>(g, grid, stream);
+    launch_bwd_q<D, 64, false>(g, grid, stream);
   }
-  hipLaunchKernelGGL((hstu_bwd_q_kernel<D, BK>), grid, dim3(256), smem_q, stream, g);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }
