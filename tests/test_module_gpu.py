@@ -466,3 +466,98 @@ def test_prefetch_one_batch_ahead_matches_plain_training(pooling):
         torch.testing.assert_close(r2, r1, rtol=1e-5, atol=1e-6)
     assert int(piped.table._ref_counter.abs().sum()) == 0, "a prefetched row stayed pinned"
     assert not piped._prefetch_states
+
+
+# ---------------------------------------------------------------------------------------- BASELINE configs at full size
+def _zipf_batch(rows, alpha, B, seed):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    w = torch.arange(1, rows + 1, device="cuda", dtype=torch.float64).pow_(-alpha)
+    cdf = torch.cumsum(w, 0)
+    cdf /= cdf[-1].clone()
+    lens = torch.randint(1, 11, (B,), device="cuda", generator=g)
+    off = torch.zeros(B + 1, dtype=torch.int64, device="cuda")
+    off[1:] = torch.cumsum(lens, 0)
+    u = torch.rand(int(off[-1]), device="cuda", dtype=torch.float64, generator=g)
+    perm = torch.randperm(rows, device="cuda", generator=g)
+    return perm[torch.searchsorted(cdf, u).clamp_(max=rows - 1)].contiguous(), off
+
+
+def test_c2_full_size_properties():
+    """BASELINE configs[1] at full size (10 M x 128 fp32, 65 536 bags, Zipf 0.99): no oracle can run this in seconds, so
+    the checks are size-independent properties -- dedup round trip, every key found after insertion, the checksum of the
+    pooled output equals the count-weighted checksum of the looked-up rows, and one SGD step with an all-ones gradient
+    moves every row by exactly lr x (its number of occurrences)."""
+    from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
+    from dynamicemb.dynamicemb_config import (DynamicEmbInitializerArgs, DynamicEmbInitializerMode, DynamicEmbPoolingMode,
+                                              DynamicEmbScoreStrategy, DynamicEmbTableOptions, EmbOptimType)
+    import dynamicemb_extensions as e
+
+    rows, D, B, lr = 10_000_000, 128, 65536, 0.25
+    opt = DynamicEmbTableOptions(dim=D, max_capacity=rows, index_type=torch.int64, embedding_dtype=torch.float32,
+                                 score_strategy=DynamicEmbScoreStrategy.TIMESTAMP,
+                                 initializer_args=DynamicEmbInitializerArgs(mode=DynamicEmbInitializerMode.UNIFORM, lower=-1, upper=1))
+    m = BatchedDynamicEmbeddingTablesV2([opt], pooling_mode=DynamicEmbPoolingMode.SUM, output_dtype=torch.float32,
+                                        optimizer=EmbOptimType.SGD, learning_rate=lr, device=torch.device("cuda", 0))
+    m.train()
+    keys, off = _zipf_batch(rows, 0.99, B, 5)
+    nt = keys.numel()
+    out, st = m._forward_impl(keys, off, train=True)
+    # dedup round trip + counts
+    nu = int(st.uoff[-1])
+    rng_t = e.get_table_range(off, m.feature_offsets)
+    uk, rev, uoff, cnt, rank = e.segmented_unique_csr(keys, rng_t, 1)
+    assert int(uoff[-1]) == nu and torch.equal(uk[:nu][rev], keys) and torch.equal(rev, st.rev)
+    assert int(cnt[:nu].sum()) == nt and torch.equal(torch.bincount(rev, minlength=nu).to(torch.int32), cnt[:nu])
+    assert nu == torch.unique(keys).numel()
+    # every key of the batch is in the table, once
+    found, rows0 = m.lookup_rows(uk[:nu].contiguous(), 0)
+    assert bool(found.all()) and int(m.size()) == nu
+    # checksum of checksums: sum of all pooled outputs == sum_u cnt[u] * row[u]   (fp64 on both sides)
+    lhs = out.double().sum(0)
+    rhs = (rows0[:, :D].double() * cnt[:nu].double()[:, None]).sum(0)
+    torch.testing.assert_close(lhs, rhs, rtol=1e-6, atol=1e-3)
+    # one SGD step, gradient of ones: w' = w - lr * bf16(occurrences) -- the reduced gradient is rounded to the gradient
+    # dtype once before the update, as the reference's reduce_grads returns it (dynamic_emb_op.cu:159-285)
+    m._backward_impl(st, torch.ones(B, D, device="cuda", dtype=torch.bfloat16))
+    _, rows1 = m.lookup_rows(uk[:nu].contiguous(), 0)
+    g_sum = cnt[:nu].float().bfloat16().float()
+    torch.testing.assert_close(rows1[:, :D], rows0[:, :D] - lr * g_sum[:, None], rtol=0, atol=2e-6 * float(cnt[:nu].max()))
+    # idempotence of the steady state: a second forward of the same batch inserts nothing
+    out2, _ = m._forward_impl(keys, off, train=True)
+    assert int(m.size()) == nu
+    torch.testing.assert_close(out2.double().sum(0), (rows1[:, :D].double() * cnt[:nu].double()[:, None]).sum(0), rtol=1e-6, atol=1e-3)
+
+
+def test_c1_matches_torch_embedding_bag():
+    """BASELINE configs[0]: 1 table x 100 K rows x 32-D, batch 512 -- the CPU path a TorchRec EmbeddingBagCollection runs
+    is torch.nn.functional.embedding_bag(mode='sum'); load the same weights, compare the pooled output and one sparse SGD
+    step (no reference test pins the CPU EBC output, so this is the pin)."""
+    from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
+    from dynamicemb.dynamicemb_config import (DynamicEmbPoolingMode, DynamicEmbScoreStrategy, DynamicEmbTableOptions,
+                                              EmbOptimType)
+
+    rows, D, B, lr = 100_000, 32, 512, 0.1
+    torch.manual_seed(0)
+    weight = torch.randn(rows, D)
+    opt = DynamicEmbTableOptions(dim=D, max_capacity=2 * rows, index_type=torch.int64, embedding_dtype=torch.float32,
+                                 score_strategy=DynamicEmbScoreStrategy.STEP)
+    m = BatchedDynamicEmbeddingTablesV2([opt], pooling_mode=DynamicEmbPoolingMode.SUM, output_dtype=torch.float32,
+                                        optimizer=EmbOptimType.SGD, learning_rate=lr, device=torch.device("cuda", 0))
+    m.train()
+    m._insert_rows(0, torch.arange(rows, device="cuda"), weight.cuda(), torch.ones(rows, dtype=torch.int64, device="cuda"))
+    g = torch.Generator().manual_seed(1)
+    lens = torch.randint(0, 20, (B,), generator=g)
+    off = torch.zeros(B + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(lens, 0)
+    keys = torch.randint(0, rows, (int(off[-1]),), generator=g)
+    w_cpu = weight.clone().requires_grad_()
+    ref = torch.nn.functional.embedding_bag(keys, w_cpu, off, mode="sum", include_last_offset=True, sparse=False)
+    out, st = m._forward_impl(keys.cuda(), off.cuda(), train=True)
+    torch.testing.assert_close(out.cpu(), ref.detach(), rtol=1e-6, atol=1e-5)
+    grad = torch.randn(B, D)
+    ref.backward(grad)
+    m._backward_impl(st, grad.cuda())
+    touched = torch.unique(keys)
+    _, rows1 = m.lookup_rows(touched.cuda(), 0)
+    torch.testing.assert_close(rows1.cpu(), (weight - lr * w_cpu.grad)[touched], rtol=1e-5, atol=1e-5)
