@@ -284,3 +284,44 @@ def test_decode_step_is_hipgraph_capturable():
         step()
         torch.cuda.synchronize()
         assert torch.equal(got, out)
+
+
+def test_c3_full_size_properties():
+    """BASELINE configs[2] attention shape (B=32, L=512, H=4, d=256, causal) at full size, through properties of the
+    operator: causality (outputs do not see later tokens, bit-exact), batch independence, linearity in V, and the
+    adjoint identity <dV, V> = <dO, O> that holds because O is linear in V."""
+    from hstu import hstu_varlen_bwd, hstu_varlen_fwd
+
+    B, L, H, d = 32, 512, 4, 256
+    T = B * L
+    torch.manual_seed(3)
+    cu = torch.arange(0, T + 1, L, dtype=torch.int32, device=DEV)
+    q, k, v, do = (torch.empty(T, H, d, device=DEV).uniform_(-1, 1).bfloat16() for _ in range(4))
+    alpha = 1.0 / d ** 0.5
+    fwd = lambda q_, k_, v_: hstu_varlen_fwd(q_, k_, v_, cu, L, L, None, None, 1, True, alpha)
+    out = fwd(q, k, v)
+    # causality: garbage in the last 100 tokens of every sequence leaves the first 412 outputs bit-identical
+    k2, v2, q2 = k.clone(), v.clone(), q.clone()
+    tail = (torch.arange(T, device=DEV) % L) >= L - 100
+    for t in (k2, v2, q2):
+        t[tail] = torch.randn_like(t[tail].float()).bfloat16() * 3
+    out2 = fwd(q2, k2, v2)
+    assert torch.equal(out[~tail], out2[~tail]) and not torch.equal(out[tail], out2[tail])
+    # batch independence: rolling the sequences rolls the outputs
+    roll = lambda t: t.view(B, L, H, d).roll(5, 0).reshape(T, H, d).contiguous()
+    assert torch.equal(fwd(roll(q), roll(k), roll(v)), roll(out))
+    # linearity in V (bf16 rounding of the two outputs bounds the error)
+    va = torch.empty_like(v).uniform_(-1, 1)
+    o_sum = fwd(q, k, (v.float() + va.float()).bfloat16()).float()
+    o_parts = out.float() + fwd(q, k, va).float()
+    assert (o_sum - o_parts).abs().max() <= 2.0 ** -6 * o_parts.abs().max() + 1e-6
+    # adjoint identity of the backward, with dO = O so that the inner product is a well-conditioned positive number
+    dq, dk, dv = hstu_varlen_bwd(out, q, k, v, cu, L, L, None, None, 1, True, alpha)
+    lhs = (dv.double() * v.double()).sum()
+    rhs = (out.double() * out.double()).sum()
+    assert abs(float(lhs - rhs)) <= 5e-3 * abs(float(rhs)), (float(lhs), float(rhs))
+    # the gradient of a causal operator is anti-causal: dK / dV of the last tokens only depend on the last queries
+    do2 = do.clone()
+    do2[~tail] = 0
+    dq3, dk3, dv3 = hstu_varlen_bwd(do2, q, k, v, cu, L, L, None, None, 1, True, alpha)
+    assert float(dq3[~tail].abs().max()) == 0.0
