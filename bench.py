@@ -125,6 +125,59 @@ def cpu_baseline(args, batches_cpu):
                       f"os.cpu_count()={os.cpu_count()}, table init {setup:.1f}s not timed"}
 
 
+def kernel_roofline(module, batches, grad, batch, D, e=4, o=2):
+    """The two bandwidth kernels of the step, each timed live with HIP events on the launch stream (torch's current
+    stream) against its own algorithmic bytes -> (`roofline` object, step algorithmic bytes)."""
+    import dynamicemb_extensions as ext
+
+    nu_list, fwd_ms, bwd_ms = [], [], []
+    for keys, offsets in batches:
+        out, st = module._forward_impl(keys, offsets, train=True)
+        nu = int(st.uoff[-1].item())
+        nt = keys.numel()
+        nu_list.append((nt, nu))
+        out2 = torch.empty_like(out)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        ext.gather_embedding_pooled(None, out2, st.rev, offsets, 0, D, batch, max_D=D, row_addr=st.row_addr,
+                                    src_dtype=torch.float32)
+        ev[1].record()
+        ptr_t, csr, hot = ext.group_by_unique(st.rev, nt, offsets, nu_dev=st.uoff[-1:], dim=D)
+        ev[2].record()
+        ext.backward_fused(ptr_t, csr, nt, nt, grad, batch, D, 0, offsets, None, st.row_addr, torch.float32, 1,
+                           lr=0.1, nu_dev=st.uoff[-1:], hot=hot)
+        ev[3].record()
+        torch.cuda.synchronize()
+        fwd_ms.append(ev[0].elapsed_time(ev[1]))
+        bwd_ms.append(ev[2].elapsed_time(ev[3]))
+    nt_avg = float(np.mean([a for a, _ in nu_list]))
+    nu_avg = float(np.mean([b for _, b in nu_list]))
+    FB = batch
+    fwd_bytes = 8 * nt_avg + 8 * (FB + 1) + 8 * nu_avg + nu_avg * D * e + FB * D * o
+    bwd_bytes = 4 * nt_avg + 4 * (nu_avg + 1) + 8 * nu_avg + FB * D * o + 2 * nu_avg * D * e
+    f_ms, b_ms = float(np.median(fwd_ms)), float(np.median(bwd_ms))
+    kern = {
+        "gather_pooled_vec_kernel": {"ms": f_ms, "algorithmic_bytes": fwd_bytes, "GB/s": fwd_bytes / f_ms / 1e6},
+        "bwd_kernel": {"ms": b_ms, "algorithmic_bytes": bwd_bytes, "GB/s": bwd_bytes / b_ms / 1e6},
+    }
+    dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
+    # HBM traffic of the dominant kernel per launch from the committed PMC passes (counters cannot be read from
+    # inside this process): 2*FETCH_SIZE + WRITE_SIZE, see profiles/r01_pmc_traffic.json (C2 batch size only)
+    traffic = None
+    if batch == 65536:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            traffic = pmc[dom[0]]["traffic_bytes"]
+        except Exception:
+            pass
+    roof = {"bound": "hbm", "kernel": dom[0], "achieved": dom[1]["GB/s"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": dom[1]["GB/s"] / HBM_PEAK_GBPS, "traffic": traffic, "kernels": kern, "keys_per_launch": nt_avg,
+            "unique_rows_per_launch": nu_avg}
+    step_bytes = (8 * nt_avg + 8 * (FB + 1) + 16 * nu_avg + nu_avg * D * e + FB * D * o) + \
+                 (8 * nt_avg + FB * D * o + 2 * nu_avg * D * e)
+    return roof, step_bytes
+
+
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
@@ -280,54 +333,8 @@ def main():
     }
 
     if rank == 0 and not sharded_path and not args.no_kernel_timing:
-        # ---- dominant kernels, timed live with HIP events on the launch stream (torch's current stream) ----
-        nu_list, fwd_ms, bwd_ms = [], [], []
-        D, e, o = args.dim, 4, 2
-        for i in range(args.warmup, n_batches):
-            keys, offsets = batches[i]
-            out, st = fwd(keys, offsets)
-            nu = int(st.uoff[-1].item())
-            nt = keys.numel()
-            nu_list.append((nt, nu))
-            out2 = torch.empty_like(out)
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            ev[0].record()
-            ext.gather_embedding_pooled(None, out2, st.rev, offsets, 0, D, args.batch, max_D=D, row_addr=st.row_addr,
-                                        src_dtype=torch.float32)
-            ev[1].record()
-            ptr_t, csr, hot = ext.group_by_unique(st.rev, nt, offsets, nu_dev=st.uoff[-1:], dim=D)
-            ev[2].record()
-            ext.backward_fused(ptr_t, csr, nt, nt, grad, args.batch, D, 0, offsets, None, st.row_addr, torch.float32, 1,
-                               lr=0.1, nu_dev=st.uoff[-1:], hot=hot)
-            ev[3].record()
-            torch.cuda.synchronize()
-            fwd_ms.append(ev[0].elapsed_time(ev[1]))
-            bwd_ms.append(ev[2].elapsed_time(ev[3]))
-        nt_avg = float(np.mean([a for a, _ in nu_list]))
-        nu_avg = float(np.mean([b for _, b in nu_list]))
-        FB = args.batch
-        fwd_bytes = 8 * nt_avg + 8 * (FB + 1) + 8 * nu_avg + nu_avg * D * e + FB * D * o
-        bwd_bytes = 4 * nt_avg + 4 * (nu_avg + 1) + 8 * nu_avg + FB * D * o + 2 * nu_avg * D * e
-        f_ms, b_ms = float(np.median(fwd_ms)), float(np.median(bwd_ms))
-        kern = {
-            "gather_pooled_vec_kernel": {"ms": f_ms, "algorithmic_bytes": fwd_bytes, "GB/s": fwd_bytes / f_ms / 1e6},
-            "bwd_rows_kernel(+bwd_hot_kernel)": {"ms": b_ms, "algorithmic_bytes": bwd_bytes, "GB/s": bwd_bytes / b_ms / 1e6},
-        }
-        dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
-        # HBM traffic of the dominant kernel per launch from the committed PMC passes (counters cannot be read from
-        # inside this process): 2*FETCH_SIZE + WRITE_SIZE, see profiles/r01_pmc_traffic.json
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            key = "bwd_kernel" if dom[0].startswith("bwd") else "gather_pooled_vec_kernel"
-            traffic = pmc[key]["traffic_bytes"]
-        except Exception:
-            pass
-        result["roofline"] = {"bound": "hbm", "kernel": dom[0], "achieved": dom[1]["GB/s"], "peak": HBM_PEAK_GBPS,
-                              "unit": "GB/s", "frac": dom[1]["GB/s"] / HBM_PEAK_GBPS, "traffic": traffic,
-                              "kernels": kern, "keys_per_launch": nt_avg, "unique_rows_per_launch": nu_avg}
-        step_bytes = (8 * nt_avg + 8 * (FB + 1) + 16 * nu_avg + nu_avg * D * e + FB * D * o) + \
-                     (8 * nt_avg + FB * D * o + 2 * nu_avg * D * e)
+        roof, step_bytes = kernel_roofline(module, batches[args.warmup:], grad, args.batch, args.dim)
+        result["roofline"] = roof
         result["step_algorithmic_GBps"] = step_bytes / (elapsed / args.steps) / 1e9
 
     if not args.no_hstu:

@@ -55,6 +55,20 @@ struct BwdArgs {
   int hot_blocks;           // leading blocks of the launch that serve the hot tasks
 };
 
+#ifndef PIPE_NB
+#define PIPE_NB 2
+#endif
+#ifndef PIPE_RPR
+#define PIPE_RPR 2
+#endif
+#ifndef HOT_UNR
+#define HOT_UNR 8
+#endif
+#ifndef PIPE_KIT
+#define PIPE_KIT 4
+#endif
+constexpr int kBwdGroupsPerLaneGroup = PIPE_KIT;  // consecutive row groups walked by one lane group (regular rows)
+
 __device__ __attribute__((aligned(16))) float g_zero_grad[1024];  // see g_zero_row in value_ops.hip
 
 typedef const __attribute__((address_space(1))) char* gptr_t;
@@ -164,6 +178,74 @@ __device__ __forceinline__ void reduce_multi(const BwdArgs& a, const int (&lo)[N
   }
 }
 
+// Sum of the gradient rows of the CSR entries [slo, shi) by ONE lane group, for slices of up to `per` entries
+// (`per` is wave uniform).  The entry indices are fetched LPR at a time -- one per lane, coalesced -- and every
+// lane turns ITS entry into a gradient-row address; the addresses are then handed round the group with
+// shuffles, so the UNR gradient rows of a batch are independent loads instead of a csr -> address -> row chain
+// per round (a hot task used to be 16 dependent latencies long).  Entries are added in CSR order.
+template <int GDT, int NCOL, bool kVec, int UNR>
+__device__ __forceinline__ void reduce_chunk(const BwdArgs& a, int slo, int shi, int per, int lpr_log2, float (&acc)[NCOL][4]) {
+  const int LPR = 1 << lpr_log2;
+  const int c = lane_id() & (LPR - 1);
+  constexpr int W = kVec ? 4 : 1;
+  constexpr int EB = GDT == kF32 ? 4 : 2;
+  const gptr_t zero = (gptr_t)(uintptr_t)g_zero_grad;
+#pragma unroll
+  for (int k = 0; k < NCOL; ++k)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) acc[k][w] = 0.f;
+  const bool need_df = a.D_offsets != nullptr && a.combiner >= 0;
+  const bool need_sc = a.combiner == 1;
+  for (int j0 = 0; j0 < per; j0 += LPR) {
+    // my entry of this sub-chunk -> address of its gradient row (0: none), its width and scale
+    int e = slo + j0 + c;
+    const bool mine = e < shi;
+    e = e < a.n_entries ? e : a.n_entries - 1;
+    const int sv = a.csr_src[e < 0 ? 0 : e];
+    int myDf = a.D;
+    float mysc = 1.f;
+    int64_t off;
+    if (a.combiner < 0) {
+      off = (int64_t)sv * a.grad_stride;
+    } else {
+      const int f = sv / a.B, bb = sv - f * a.B;
+      int d0 = f * a.D;
+      if (need_df) { d0 = a.D_offsets[f]; myDf = a.D_offsets[f + 1] - d0; }
+      if (need_sc) {
+        const int64_t L = a.offsets[sv + 1] - a.offsets[sv];
+        mysc = L > 0 ? 1.0f / (float)L : 1.f;
+      }
+      off = (int64_t)bb * a.grad_stride + d0;
+    }
+    const uintptr_t mybase = mine ? (uintptr_t)a.grads + (uintptr_t)(off * EB) : 0;
+    const int blo = (int)(mybase & 0xffffffffu), bhi = (int)(mybase >> 32);
+    int left = shi - (slo + j0);
+    left = left < 0 ? 0 : left;
+    for (int q0 = 0; q0 < LPR; q0 += UNR) {
+      if (__ballot(q0 < left) == 0) break;  // wave uniform
+      float v[UNR][NCOL][4], sc[UNR];
+#pragma unroll
+      for (int q = 0; q < UNR; ++q) {
+        const uintptr_t base = (uintptr_t)(unsigned)__shfl(blo, q0 + q, LPR) | ((uintptr_t)(unsigned)__shfl(bhi, q0 + q, LPR) << 32);
+        const int Df = need_df ? __shfl(myDf, q0 + q, LPR) : a.D;
+        sc[q] = need_sc ? __shfl(mysc, q0 + q, LPR) : 1.f;
+#pragma unroll
+        for (int k = 0; k < NCOL; ++k) {
+          const int el = W * (c + k * LPR);
+          const gptr_t p = (base != 0 && el < Df) ? (gptr_t)(base + (uintptr_t)(el * EB)) : zero;
+          ldNg<GDT>(p, kVec, v[q][k]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < UNR; ++q)
+#pragma unroll
+        for (int k = 0; k < NCOL; ++k)
+#pragma unroll
+          for (int w = 0; w < W; ++w) acc[k][w] += v[q][k][w] * sc[q];
+    }
+  }
+}
+
 // sum over the LPR lanes of a column group (every lane gets the total)
 __device__ __forceinline__ float group_sum(float v, int lpr_log2) {
   for (int o = 1; o < (1 << lpr_log2); o <<= 1) v += __shfl_xor(v, o, 64);
@@ -260,6 +342,146 @@ __device__ __forceinline__ void apply_sink(const OptArgs& o_in, int64_t u, void*
   }
 }
 
+// Regular rows, SGD on vector rows (the common case): a software pipeline over KIT consecutive groups of NB
+// unique rows per lane group.  The walk of one group is a chain of dependent loads (ptr -> CSR entries ->
+// gradient rows; row_addr -> table row); run group by group a wave spends most of its life waiting on the small
+// index loads with nothing heavy in flight.  Here the index loads of group i+1 (CSR entries) and i+2 (ptr,
+// row_addr) are issued BEFORE the heavy loads of group i, so each iteration has one wait with everything in
+// flight (vmcnt retires in order: the index loads must be older than the heavy ones).  The first RPR entries of
+// every row ride the pipeline; the few rows with more entries (<= hot threshold) take dependent extra rounds.
+template <int WDT, int GDT, int NCOL, int NB, int RPR, int KIT>
+__device__ __forceinline__ void sgd_rows_pipelined(const BwdArgs& a, const OptArgs& o, int lpr_log2, int64_t nu, int64_t sg) {
+  const int LPR = 1 << lpr_log2;
+  const int c = lane_id() & (LPR - 1);
+  constexpr int EB = GDT == kF32 ? 4 : 2;
+  constexpr int WB = WDT == kF32 ? 4 : 2;
+  const gptr_t zero = (gptr_t)(uintptr_t)g_zero_grad;
+  const bool hot_on = a.hot.n_tasks != nullptr;
+  const int64_t ubase = sg * (int64_t)(KIT * NB);
+  if (ubase >= nu) return;  // no cross-lane operation below
+  int pA[NB + 1];
+  int64_t rA[NB];
+  struct Idx { int lo[NB], cnt[NB]; uintptr_t rowp[NB]; int src[NB][RPR]; };
+  auto stageP = [&](int it) {
+    const int64_t u0 = ubase + (int64_t)it * NB;
+#pragma unroll
+    for (int b = 0; b <= NB; ++b) { int64_t u = u0 + b; u = u < nu ? u : nu; pA[b] = a.ptr[u]; }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { int64_t u = u0 + b; u = u < nu ? u : nu - 1; rA[b] = a.row_addr[u]; }
+  };
+  auto entry = [&](int lo, int cnt, int q) {
+    int e = lo + (q < cnt ? q : 0);
+    e = e < a.n_entries ? e : a.n_entries - 1;
+    return a.csr_src[e < 0 ? 0 : e];
+  };
+  auto stageS = [&](Idx& x) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int n = pA[b + 1] - pA[b];
+      const bool work = n > 0 && !(hot_on && n > a.hot.khot);
+      x.lo[b] = pA[b];
+      x.cnt[b] = work ? n : 0;
+      x.rowp[b] = work ? (uintptr_t)rA[b] : 0;
+#pragma unroll
+      for (int q = 0; q < RPR; ++q) x.src[b][q] = entry(pA[b], x.cnt[b], q);
+    }
+  };
+  // one round of gradient rows: entries r .. r+RPR-1 of every row, indices already in `src`
+  auto grads_round = [&](const Idx& x, const int (&src)[NB][RPR], int r, float (&acc)[NB][NCOL][4]) {
+    uintptr_t base[NB][RPR];
+    float sc[NB][RPR];
+    int64_t L0[NB][RPR], L1[NB][RPR];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int q = 0; q < RPR; ++q) {
+        const int sv = src[b][q];
+        int64_t off;
+        if (a.combiner < 0) {
+          off = (int64_t)sv * a.grad_stride;
+        } else {
+          const int f = sv / a.B, bb = sv - f * a.B;
+          off = (int64_t)bb * a.grad_stride + (int64_t)f * a.D;
+          if (a.combiner == 1) { L0[b][q] = a.offsets[sv]; L1[b][q] = a.offsets[sv + 1]; }
+        }
+        base[b][q] = r + q < x.cnt[b] ? (uintptr_t)a.grads + (uintptr_t)(off * EB) : 0;
+      }
+    float v[NB][RPR][NCOL][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int q = 0; q < RPR; ++q)
+#pragma unroll
+        for (int k = 0; k < NCOL; ++k) {
+          const int e = 4 * (c + k * LPR);
+          const gptr_t p = (base[b][q] != 0 && e < a.D) ? (gptr_t)(base[b][q] + (uintptr_t)(e * EB)) : zero;
+          ldNg<GDT>(p, true, v[b][q][k]);
+        }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int q = 0; q < RPR; ++q) {
+        sc[b][q] = 1.f;
+        if (a.combiner == 1) { const int64_t L = L1[b][q] - L0[b][q]; sc[b][q] = L > 0 ? 1.0f / (float)L : 1.f; }
+#pragma unroll
+        for (int k = 0; k < NCOL; ++k)
+#pragma unroll
+          for (int w = 0; w < 4; ++w) acc[b][k][w] += v[b][q][k][w] * sc[b][q];
+      }
+  };
+  Idx cur, nxt;
+  stageP(0);
+  stageS(cur);
+  stageP(1);
+#pragma unroll
+  for (int it = 0; it < KIT; ++it) {
+    if (ubase + (int64_t)it * NB >= nu) break;
+    stageS(nxt);       // CSR entries of group it+1 (its ptr / row_addr arrived with the previous wait)
+    stageP(it + 2);    // ptr / row_addr of group it+2
+    float wrow[NB][NCOL][4], acc[NB][NCOL][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int k = 0; k < NCOL; ++k) {
+        const int e = 4 * (c + k * LPR);
+        const gptr_t p = (cur.rowp[b] != 0 && e < a.D) ? (gptr_t)(cur.rowp[b] + (uintptr_t)(e * WB)) : zero;
+        ldNg<WDT>(p, true, wrow[b][k]);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) acc[b][k][w] = 0.f;
+      }
+    grads_round(cur, cur.src, 0, acc);
+    int maxcnt = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) maxcnt = cur.cnt[b] > maxcnt ? cur.cnt[b] : maxcnt;
+    for (int r = RPR; r < maxcnt; r += RPR) {
+      int src[NB][RPR];
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int q = 0; q < RPR; ++q) src[b][q] = entry(cur.lo[b], cur.cnt[b], r + q);
+      grads_round(cur, src, r, acc);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (cur.rowp[b] == 0) continue;
+#pragma unroll
+      for (int k = 0; k < NCOL; ++k) {
+        const int e = 4 * (c + k * LPR);
+        if (e < a.D) {
+          float r4[4];
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            const float gr = a.round_grad ? Elem<GDT>::rnd(acc[b][k][w]) : acc[b][k][w];
+            r4[w] = wrow[b][k][w] - gr * o.lr;
+          }
+          st4<WDT>(reinterpret_cast<void*>(cur.rowp[b]), e, make_float4(r4[0], r4[1], r4[2], r4[3]));
+        }
+      }
+    }
+    cur = nxt;
+  }
+}
+
 template <int WDT, int GDT, int NCOL, bool kVec>
 __global__ void __launch_bounds__(256) bwd_kernel(BwdArgs a, OptArgs o, int lpr_log2) {
   const int lane = lane_id();
@@ -269,8 +491,8 @@ __global__ void __launch_bounds__(256) bwd_kernel(BwdArgs a, OptArgs o, int lpr_
   constexpr int W = kVec ? 4 : 1;
   if ((int)blockIdx.x < a.hot_blocks) {
     // ------------------------------------------------ hot tasks: one BLOCK per chunk of CSR entries
-    // The chunk is split over the block's 4*NSUB lane groups (<= 16 entries each at the default chunk of
-    // 128), folded inside the wave with shuffles and across the 4 waves through LDS.  A row that fits one
+    // The chunk (1024 entries by default, hot.h) is split over the block's 4*NSUB lane groups, each slice summed by
+    // reduce_chunk, folded inside the wave with shuffles and across the 4 waves through LDS.  A row that fits one
     // chunk is finished right here; longer rows add one partial per chunk into the row's fp32 accumulator
     // (agent-scope atomics: ~0.1-0.2 us each when thousands hit one address, hence block-sized chunks)
     // and the chunk that draws the last ticket applies the sink.
@@ -285,12 +507,8 @@ __global__ void __launch_bounds__(256) bwd_kernel(BwdArgs a, OptArgs o, int lpr_
       const int per = (hi - lo + ngroups - 1) / ngroups;
       int slo = lo + (wv * NSUB + sub) * per, shi = slo + per;
       shi = shi < hi ? shi : hi;
-      float g1[1][NCOL][4];
-      {
-        const int l1[1] = {slo < shi ? slo : 0}, h1[1] = {slo < shi ? shi : 0};
-        reduce_multi<GDT, NCOL, kVec, 1, 4>(a, l1, h1, lpr_log2, g1);
-      }
-      float (&g)[NCOL][4] = g1[0];
+      float g[NCOL][4];
+      reduce_chunk<GDT, NCOL, kVec, HOT_UNR>(a, slo, shi, per, lpr_log2, g);
       for (int off = LPR; off < 64; off <<= 1)
 #pragma unroll
         for (int k = 0; k < NCOL; ++k)
@@ -364,15 +582,20 @@ __global__ void __launch_bounds__(256) bwd_kernel(BwdArgs a, OptArgs o, int lpr_
   // in flight per ~5 us dependent chain (ptr -> CSR entry -> gradient row).  Each lane group therefore
   // takes NB consecutive unique rows and walks their entries in lock step, RPR entries of each per round;
   // the table rows themselves are fetched up front (SGD) since their address only needs row_addr[u].
-  constexpr int NB = NCOL == 1 ? 4 : (NCOL == 2 ? 2 : 1);
+  constexpr int NB = NCOL == 1 ? PIPE_NB : (NCOL == 2 ? 2 : 1);
   constexpr int RPR = 2;
+  constexpr int KIT = kBwdGroupsPerLaneGroup;
   int64_t nu = a.max_unique;
   if (a.nu_dev) { int64_t m = *a.nu_dev; nu = m < nu ? m : nu; }
   const int64_t sg = ((int64_t)(blockIdx.x - a.hot_blocks) * wpb + (threadIdx.x >> 6)) * NSUB + sub;
-  const int64_t total_sg = (int64_t)(gridDim.x - a.hot_blocks) * wpb * NSUB;
-  const int64_t rounds = (nu + total_sg * NB - 1) / (total_sg * NB);
-  for (int64_t it = 0; it < rounds; ++it) {   // wave-uniform trip count (apply_sink shuffles inside)
-    const int64_t u0 = (it * total_sg + sg) * NB;
+  if constexpr (kVec) {
+    if (o.kind == kOptSgd && a.D_offsets == nullptr) {
+      sgd_rows_pipelined<WDT, GDT, NCOL, NB, PIPE_RPR, KIT>(a, o, lpr_log2, nu, sg);
+      return;
+    }
+  }
+  for (int it = 0; it < KIT; ++it) {   // wave-uniform trip count (apply_sink shuffles inside)
+    const int64_t u0 = (sg * KIT + it) * NB;
     int lo[NB], hi[NB];
     bool work[NB], have[NB], hotrow[NB];
     uintptr_t rowp[NB];
@@ -388,41 +611,10 @@ __global__ void __launch_bounds__(256) bwd_kernel(BwdArgs a, OptArgs o, int lpr_
       hi[b] = work[b] ? h : 0;
       rowp[b] = (work[b] && o.kind != kOptStore) ? (uintptr_t)a.row_addr[uc] : 0;
     }
-    const bool pre = kVec && o.kind == kOptSgd && a.D_offsets == nullptr;
-    float wpre[NB][NCOL][4];
-    if (pre) {
-      constexpr int WB = WDT == kF32 ? 4 : 2;
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int k = 0; k < NCOL; ++k) {
-          const int e = 4 * (c + k * LPR);
-          const gptr_t p = (rowp[b] != 0 && e < a.D) ? (gptr_t)(rowp[b] + (uintptr_t)(e * WB)) : (gptr_t)(uintptr_t)g_zero_grad;
-          ldNg<WDT>(p, true, wpre[b][k]);
-        }
-    }
     float g[NB][NCOL][4];
     reduce_multi<GDT, NCOL, kVec, NB, RPR>(a, lo, hi, lpr_log2, g);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      if (pre) {
-        if (rowp[b] != 0) {
-#pragma unroll
-          for (int k = 0; k < NCOL; ++k) {
-            const int e = 4 * (c + k * LPR);
-            if (e < a.D) {
-              float r4[4];
-#pragma unroll
-              for (int w = 0; w < 4; ++w) {
-                const float gr = a.round_grad ? Elem<GDT>::rnd(g[b][k][w]) : g[b][k][w];
-                r4[w] = wpre[b][k][w] - gr * o.lr;
-              }
-              st4<WDT>(reinterpret_cast<void*>(rowp[b]), e, make_float4(r4[0], r4[1], r4[2], r4[3]));
-            }
-          }
-        }
-        continue;
-      }
       int Drow = a.D;
       if (work[b] && a.D_offsets && a.combiner >= 0 && o.kind != kOptStore) {
         const int f = a.csr_src[lo[b]] / a.B;
@@ -485,8 +677,8 @@ static int launch_bwd(BwdArgs a, OptArgs o, bool vec, hipStream_t stream) {
   const int nsub = 64 >> l;
   a.hot_blocks = a.hot.n_tasks ? (a.hot.max_tasks < 2048 ? a.hot.max_tasks : 2048) : 0;
   const size_t smem = a.hot.n_tasks ? 4 * (size_t)a.D * sizeof(float) : 0;
-  const int nb = ncol <= 1 ? 4 : (ncol <= 2 ? 2 : 1);
-  const int grid = a.hot_blocks + grid_for(a.max_unique, 4 * nsub * nb, 1 << 20);
+  const int nb = ncol <= 1 ? PIPE_NB : (ncol <= 2 ? 2 : 1);
+  const int grid = a.hot_blocks + grid_for(a.max_unique, 4 * nsub * nb * kBwdGroupsPerLaneGroup, 1 << 20);
 #define MI355_BWD_LAUNCH(NC, V) hipLaunchKernelGGL((bwd_kernel<WDT, GDT, NC, V>), dim3(grid), dim3(256), smem, stream, a, o, l)
   if (vec) {
     if (ncol <= 1) MI355_BWD_LAUNCH(1, true); else if (ncol <= 2) MI355_BWD_LAUNCH(2, true); else MI355_BWD_LAUNCH(4, true);

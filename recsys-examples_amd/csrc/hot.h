@@ -11,7 +11,7 @@ namespace mi355 {
 // occurrences above which a row takes the chunked path / CSR entries per task (one wave per task).
 // Tunable through MI355_HOT / MI355_CHUNK (read once per process) for profiling sweeps.
 static inline int hot_threshold() { static const int v = getenv("MI355_HOT") ? atoi(getenv("MI355_HOT")) : 8; return v < 1 ? 1 : v; }
-static inline int hot_chunk() { static const int v = getenv("MI355_CHUNK") ? atoi(getenv("MI355_CHUNK")) : 256; return v < 4 ? 4 : v; }
+static inline int hot_chunk() { static const int v = getenv("MI355_CHUNK") ? atoi(getenv("MI355_CHUNK")) : 1024; return v < 4 ? 4 : v; }
 
 struct HotList {
   int* n_hot;        // [1]
