@@ -157,7 +157,7 @@ def kernel_roofline(module, batches, grad, batch, D, e=4, o=2):
     bwd_bytes = 4 * nt_avg + 4 * (nu_avg + 1) + 8 * nu_avg + FB * D * o + 2 * nu_avg * D * e
     f_ms, b_ms = float(np.median(fwd_ms)), float(np.median(bwd_ms))
     kern = {
-        "gather_pooled_vec_kernel": {"ms": f_ms, "algorithmic_bytes": fwd_bytes, "GB/s": fwd_bytes / f_ms / 1e6},
+        "gather_pooled_pipe_kernel": {"ms": f_ms, "algorithmic_bytes": fwd_bytes, "GB/s": fwd_bytes / f_ms / 1e6},
         "bwd_kernel": {"ms": b_ms, "algorithmic_bytes": bwd_bytes, "GB/s": bwd_bytes / b_ms / 1e6},
     }
     dom = max(kern.items(), key=lambda kv: kv[1]["ms"])

@@ -92,35 +92,42 @@ uniq_prepare_kernel(uint4* __restrict__ fill, int64_t n16, const int64_t* __rest
   }
 }
 
-// One 1024-key tile per block.  Keys are first de-duplicated INSIDE the tile in an LDS hash set (block
+// One kUniqTile-key tile per block.  Keys are first de-duplicated INSIDE the tile in an LDS hash set (block
 // representative = smallest position), then only the tile representatives touch the global set.  Under a
 // Zipf stream this turns (#occurrences) same-address CAS/atomicMin operations on a hot key -- which
 // serialise at ~12 ns each in the L2 atomic unit -- into at most (#tiles).
-constexpr int kUniqTile = 1024;
-constexpr int kUniqLds = 2048;
-
-__global__ void __launch_bounds__(256)
+#ifndef UNIQ_TILE
+#define UNIQ_TILE 2048
+#endif
+#ifndef UNIQ_THREADS
+#define UNIQ_THREADS 512
+#endif
+constexpr int kUniqTile = UNIQ_TILE;        // keys per block: the hottest key costs one serialised global atomic per TILE
+constexpr int kUniqLds = 2 * kUniqTile;     // LDS set slots
+constexpr int kUniqThreads = UNIQ_THREADS;
+constexpr int kUniqPer = kUniqTile / kUniqThreads;
+__global__ void __launch_bounds__(kUniqThreads)
 uniq_insert_kernel(const uint64_t* __restrict__ keys, int64_t n, const int64_t* __restrict__ seg, int T, UniqWs ws,
                    int* __restrict__ csr_rank) {
   __shared__ uint64_t s_key[kUniqTile];
-  __shared__ int s_tab[kUniqLds];   // tile-local position of the representative, -1 empty
-  __shared__ int s_pos[kUniqLds];   // global slot of that representative
-  __shared__ int s_cnt[kUniqLds];   // occurrences of the key inside the tile
-  __shared__ int s_base[kUniqLds];  // occurrences of the key in the tiles that got to the global counter first
-  __shared__ int s_t[kUniqTile];    // table of each key of the tile
+  __shared__ int s_tab[kUniqLds];   // tile-local position of the representative (-1 empty); after the global insert:
+                                    // the key's global slot
+  __shared__ int s_cnt[kUniqLds];   // occurrences of the key inside the tile; after the global insert: occurrences of
+                                    // the key in the tiles that got to the global counter first
+  __shared__ uint16_t s_t[kUniqTile];  // table of each key of the tile (T <= 65535, checked by the launcher)
   const int64_t tile0 = (int64_t)blockIdx.x * kUniqTile;
-  for (int s = threadIdx.x; s < kUniqLds; s += blockDim.x) { s_tab[s] = -1; s_cnt[s] = 0; }
-  int hh[kUniqTile / 256], rk[kUniqTile / 256];
+  for (int s = threadIdx.x; s < kUniqLds; s += kUniqThreads) { s_tab[s] = -1; s_cnt[s] = 0; }
+  int hh[kUniqPer], rk[kUniqPer];
 #pragma unroll
-  for (int q = 0; q < kUniqTile / 256; ++q) {
-    const int li = q * 256 + threadIdx.x;
+  for (int q = 0; q < kUniqPer; ++q) {
+    const int li = q * kUniqThreads + threadIdx.x;
     const int64_t i = tile0 + li;
-    if (i < n) { s_key[li] = keys[i]; s_t[li] = upper_bound_i64(seg, T + 1, i) - 1; }
+    if (i < n) { s_key[li] = keys[i]; s_t[li] = (uint16_t)(upper_bound_i64(seg, T + 1, i) - 1); }
   }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < kUniqTile / 256; ++q) {
-    const int li = q * 256 + threadIdx.x;
+  for (int q = 0; q < kUniqPer; ++q) {
+    const int li = q * kUniqThreads + threadIdx.x;
     hh[q] = -1;
     if (tile0 + li < n) {
       const uint64_t key = s_key[li];
@@ -137,10 +144,14 @@ uniq_insert_kernel(const uint64_t* __restrict__ keys, int64_t n, const int64_t* 
     }
   }
   __syncthreads();
+  bool isrep[kUniqPer];
 #pragma unroll
-  for (int q = 0; q < kUniqTile / 256; ++q) {
-    const int li = q * 256 + threadIdx.x;
-    if (hh[q] >= 0 && s_tab[hh[q]] == li) {  // tile representative: insert into the global per-table set
+  for (int q = 0; q < kUniqPer; ++q) isrep[q] = hh[q] >= 0 && s_tab[hh[q]] == q * kUniqThreads + (int)threadIdx.x;
+  __syncthreads();   // s_tab / s_cnt change meaning below
+#pragma unroll
+  for (int q = 0; q < kUniqPer; ++q) {
+    const int li = q * kUniqThreads + threadIdx.x;
+    if (isrep[q]) {  // tile representative: insert into the global per-table set
       const int64_t i = tile0 + li;
       const uint64_t key = s_key[li];
       const int t = s_t[li];
@@ -166,19 +177,20 @@ uniq_insert_kernel(const uint64_t* __restrict__ keys, int64_t n, const int64_t* 
         if ((uint64_t)off == range) off = 0;
         pos = base + off;
       }
-      s_pos[hh[q]] = (int)pos;
       // one counter update per distinct key per tile; the value before it places this tile's occurrences in
       // the key's list (counter starts at -1: see UniqWs::gcnt)
-      s_base[hh[q]] = atomicAdd(&ws.gcnt[pos], s_cnt[hh[q]]) + 1;
+      const int cnt = s_cnt[hh[q]];
+      s_tab[hh[q]] = (int)pos;
+      s_cnt[hh[q]] = atomicAdd(&ws.gcnt[pos], cnt) + 1;
     }
   }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < kUniqTile / 256; ++q) {
-    const int li = q * 256 + threadIdx.x;
+  for (int q = 0; q < kUniqPer; ++q) {
+    const int li = q * kUniqThreads + threadIdx.x;
     if (hh[q] >= 0) {
-      ws.rep[tile0 + li] = s_pos[hh[q]];
-      if (csr_rank) csr_rank[tile0 + li] = s_base[hh[q]] + rk[q];
+      ws.rep[tile0 + li] = s_tab[hh[q]];
+      if (csr_rank) csr_rank[tile0 + li] = s_cnt[hh[q]] + rk[q];
     }
   }
 }
@@ -904,7 +916,7 @@ int mi355i_segmented_unique(const void* keys, int64_t n, const int64_t* segmente
                             int32_t* csr_rank, const int64_t* offsets, const int64_t* feature_offsets,
                             int64_t feature_x_batch, int64_t* table_range_out, int64_t* table_ids_out, void* workspace,
                             int64_t workspace_bytes, hipStream_t stream) {
-  MI355_CHECK_ARG(num_tables > 0, "num_tables must be positive");
+  MI355_CHECK_ARG(num_tables > 0 && num_tables <= 65535, "num_tables must be in [1, 65535]");
   MI355_CHECK_ARG(n < 0x7fffffffLL / 2, "num_keys must be < 2^30");
   MI355_CHECK_ARG(segmented_range || (offsets && feature_offsets && table_range_out), "table ranges or bag offsets required");
   if (n == 0) {
@@ -929,7 +941,7 @@ int mi355i_segmented_unique(const void* keys, int64_t n, const int64_t* segmente
                      feature_offsets, T, feature_x_batch, segmented_range ? (int64_t*)nullptr : table_range_out);
   if (!segmented_range) segmented_range = table_range_out;
   const uint64_t* k = (const uint64_t*)keys;
-  hipLaunchKernelGGL(uniq_insert_kernel, dim3((unsigned)ceil_div(n, kUniqTile)), dim3(256), 0, stream, k, n, segmented_range, T, ws,
+  hipLaunchKernelGGL(uniq_insert_kernel, dim3((unsigned)ceil_div(n, kUniqTile)), dim3(kUniqThreads), 0, stream, k, n, segmented_range, T, ws,
                      csr_rank);
   hipLaunchKernelGGL(uniq_flag_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, n, ws);
   hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, stream, ws.partial, nb, ws.total);

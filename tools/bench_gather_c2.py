@@ -1,4 +1,5 @@
-"""Runs only the C2 (Zipf) pattern of the fused gather+pool kernel a few times (for rocprofv3 --pmc)."""
+"""C2 (Zipf) pattern of the fused gather+pool kernel: event-timed, checked against torch (MI355_POOL_VARIANT picks a kernel
+variant, see value_ops.hip).  Usage: bench_gather_c2.py [iters]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "recsys-examples_amd")); sys.path.insert(0, ROOT)
@@ -15,7 +16,18 @@ keys = perm[torch.searchsorted(cdf, torch.rand(nt, device=dev, dtype=torch.float
 uk, rev = torch.unique(keys, return_inverse=True); rev = rev.contiguous()
 addr = table.data_ptr() + uk * (D * 4)
 out = torch.empty(B, D, dtype=torch.bfloat16, device=dev)
-print("nt", nt, "nu", uk.numel())
-for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
+bag = torch.repeat_interleave(torch.arange(B, device=dev), lens)
+want = torch.zeros(B, D, device=dev).index_add_(0, bag, table[keys])
+times = []
+for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     ext.gather_embedding_pooled(None, out, rev, off, 0, D, B, max_D=D, row_addr=addr, src_dtype=torch.float32)
-torch.cuda.synchronize()
+    e1.record()
+    torch.cuda.synchronize()
+    times.append(e0.elapsed_time(e1) * 1e3)
+times.sort()
+err = (out.float() - want).abs().max().item()
+exact = torch.equal(out, want.bfloat16())
+print(f"variant {os.environ.get('MI355_POOL_VARIANT', '0'):>2s} nt {nt} nu {uk.numel()} gather median {times[len(times) // 2]:.1f} us min {times[0]:.1f} us  "
+      f"max_err {err:.2e} exact_vs_sequential_fp32 {exact}")
