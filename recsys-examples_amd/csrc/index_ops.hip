@@ -58,6 +58,18 @@ __device__ __forceinline__ int block_excl_scan(int v, int& total) {
   return base + incl - v;
 }
 
+// Tile prefix without a scan launch: the block sums the per-tile counts of all earlier tiles itself.  With a few
+// hundred tiles that is one or two loads per thread, cheaper than the ~5 us a dependent one-block kernel costs in the
+// launch chain.  (Callers fall back to scan_partials_kernel above kSelfPrefixMaxTiles.)
+constexpr int64_t kSelfPrefixMaxTiles = 4096;
+__device__ __forceinline__ int self_prefix(const int* __restrict__ partial, int b) {
+  int s = 0;
+  for (int j = threadIdx.x; j < b; j += kScanThreads) s += partial[j];
+  int tot;
+  block_excl_scan(s, tot);
+  return tot;
+}
+
 __device__ __forceinline__ int upper_bound_i64(const int64_t* __restrict__ a, int n, int64_t x) {
   int lo = 0, hi = n;  // first index with a[idx] > x
   while (lo < hi) {
@@ -233,13 +245,7 @@ __device__ __forceinline__ void scan_partials_body(int* partial, int64_t nb, int
 __global__ void __launch_bounds__(kScanThreads) scan_partials_kernel(int* partial, int64_t nb, int* total) {
   scan_partials_body(partial, nb, total);
 }
-// same, and clears the two counters of a hot-row list on the way (saves a memset launch)
-__global__ void __launch_bounds__(kScanThreads) scan_partials_clear_kernel(int* partial, int64_t nb, int* total, int* c0, int* c1) {
-  if (threadIdx.x == 0) { *c0 = 0; *c1 = 0; }
-  scan_partials_body(partial, nb, total);
-}
-
-template <bool kFreq>
+template <bool kFreq, bool kSelf>
 __global__ void __launch_bounds__(kScanThreads)
 uniq_emit_kernel(const uint64_t* __restrict__ keys, int64_t n, const int64_t* __restrict__ seg, int T, UniqWs ws,
                  uint64_t* __restrict__ unique_keys, int64_t* __restrict__ table_offsets, int64_t* __restrict__ freq,
@@ -254,7 +260,13 @@ uniq_emit_kernel(const uint64_t* __restrict__ keys, int64_t n, const int64_t* __
     c += f[k];
   }
   int tot;
-  int ex = block_excl_scan(c, tot) + ws.partial[blockIdx.x];
+  const int pre = kSelf ? self_prefix(ws.partial, blockIdx.x) : ws.partial[blockIdx.x];
+  int ex = block_excl_scan(c, tot) + pre;
+  if (kSelf && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {   // the last tile knows the number of uniques
+    const int64_t total = pre + tot;
+    *ws.total = (int)total;
+    for (int t = T; t >= 0 && seg[t] >= n; --t) table_offsets[t] = total;
+  }
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
     int64_t i = tile0 + threadIdx.x * kScanItems + k;
@@ -273,7 +285,7 @@ uniq_emit_kernel(const uint64_t* __restrict__ keys, int64_t n, const int64_t* __
       }
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (!kSelf && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t total = *ws.total;
     for (int t = T; t >= 0 && seg[t] >= n; --t) table_offsets[t] = total;
   }
@@ -404,7 +416,9 @@ csr_hist_kernel(const int64_t* __restrict__ rev, int64_t n, int* __restrict__ cn
 
 // exclusive scan of cnt[0..nu) -> ptr[0..nu], nu read from the device
 __global__ void __launch_bounds__(kScanThreads)
-scan_reduce_kernel(const int* __restrict__ in, int64_t n, const int64_t* __restrict__ n_dev, int* partial) {
+scan_reduce_kernel(const int* __restrict__ in, int64_t n, const int64_t* __restrict__ n_dev, int* partial, int* c0 = nullptr,
+                   int* c1 = nullptr) {
+  if (c0 && blockIdx.x == 0 && threadIdx.x == 0) { *c0 = 0; *c1 = 0; }   // hot-row list counters (used by scan_down)
   if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
   const int64_t tile0 = (int64_t)blockIdx.x * kScanTile;
   int c = 0;
@@ -417,9 +431,10 @@ scan_reduce_kernel(const int* __restrict__ in, int64_t n, const int64_t* __restr
   block_excl_scan(c, tot);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
+template <bool kSelf>
 __global__ void __launch_bounds__(kScanThreads)
 scan_down_kernel(const int* __restrict__ in, int64_t n, const int64_t* __restrict__ n_dev, const int* __restrict__ partial,
-                 const int* __restrict__ total, int* __restrict__ out, HotList hot, bool build_hot) {
+                 int* __restrict__ total, int* __restrict__ out, HotList hot, bool build_hot) {
   if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
   const int64_t tile0 = (int64_t)blockIdx.x * kScanTile;
   int v[kScanItems];
@@ -431,7 +446,9 @@ scan_down_kernel(const int* __restrict__ in, int64_t n, const int64_t* __restric
     c += v[k];
   }
   int tot;
-  int ex = block_excl_scan(c, tot) + partial[blockIdx.x];
+  const int pre = kSelf ? self_prefix(partial, blockIdx.x) : partial[blockIdx.x];
+  int ex = block_excl_scan(c, tot) + pre;
+  if (kSelf && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { *total = pre + tot; out[n] = pre + tot; }
   // hot rows of this tile: ids and task ranges are reserved with ONE atomic pair per block
   int nh_local = 0, nt_local = 0;
   if (build_hot) {
@@ -474,7 +491,7 @@ scan_down_kernel(const int* __restrict__ in, int64_t n, const int64_t* __restric
       ex += v[k];
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
+  if (!kSelf && blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
 }
 
 // pass 2: scatter.  src id of key j: pooled -> bag id, sequence -> j.  The bag of every key of the tile is
@@ -944,18 +961,21 @@ int mi355i_segmented_unique(const void* keys, int64_t n, const int64_t* segmente
   hipLaunchKernelGGL(uniq_insert_kernel, dim3((unsigned)ceil_div(n, kUniqTile)), dim3(kUniqThreads), 0, stream, k, n, segmented_range, T, ws,
                      csr_rank);
   hipLaunchKernelGGL(uniq_flag_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, n, ws);
-  hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, stream, ws.partial, nb, ws.total);
+  const bool self = nb <= kSelfPrefixMaxTiles;   // emit blocks sum the earlier tiles' counts themselves: one launch less
+  if (!self) hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, stream, ws.partial, nb, ws.total);
+#define MI355_EMIT(FREQ, SELF)                                                                                          \
+  hipLaunchKernelGGL((uniq_emit_kernel<FREQ, SELF>), dim3((unsigned)nb), dim3(kScanThreads), 0, stream, k, n, segmented_range, T, \
+                     ws, (uint64_t*)unique_keys, table_offsets, freq, input_frequencies, csr_cnt)
   if (count_freq) {
-    hipLaunchKernelGGL(uniq_emit_kernel<true>, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, k, n, segmented_range, T, ws,
-                       (uint64_t*)unique_keys, table_offsets, freq, input_frequencies, csr_cnt);
+    if (self) MI355_EMIT(true, true); else MI355_EMIT(true, false);
     hipLaunchKernelGGL(uniq_finish_kernel<true>, dim3(grid_for(n, 256, 256 * 32)), dim3(256), 0, stream, n, ws, input_frequencies,
                        output_indices, freq, table_offsets, T, table_ids_out);
   } else {
-    hipLaunchKernelGGL(uniq_emit_kernel<false>, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, k, n, segmented_range, T, ws,
-                       (uint64_t*)unique_keys, table_offsets, freq, input_frequencies, csr_cnt);
+    if (self) MI355_EMIT(false, true); else MI355_EMIT(false, false);
     hipLaunchKernelGGL(uniq_finish_kernel<false>, dim3(grid_for(n, 256, 256 * 32)), dim3(256), 0, stream, n, ws, input_frequencies,
                        output_indices, freq, table_offsets, T, table_ids_out);
   }
+#undef MI355_EMIT
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }
@@ -1031,9 +1051,10 @@ int mi355_group_by_unique(const int64_t* reverse_indices, int64_t n, const int64
   }
   if (hipMemsetAsync(cnt, 0, 2 * align_up(4 * (max_unique + 1), 256), stream) != hipSuccess) { mi355_set_error("memset failed"); return MI355_ELAUNCH; }
   if (n > 0) hipLaunchKernelGGL(csr_hist_kernel, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, reverse_indices, n, cnt);
-  hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, cnt, max_unique, nu_dev, partial);
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, cnt, max_unique, nu_dev, partial, (int*)nullptr,
+                     (int*)nullptr);
   hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, stream, partial, nbu, total);
-  hipLaunchKernelGGL(scan_down_kernel, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, cnt, max_unique, nu_dev, partial, total, ptr,
+  hipLaunchKernelGGL(scan_down_kernel<false>, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, cnt, max_unique, nu_dev, partial, total, ptr,
                      hot, hot_workspace != nullptr);
   if (n > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, reverse_indices, n, offsets,
                                 num_bags, ptr, cursor, csr_src, hot, hot_workspace != nullptr);
@@ -1060,13 +1081,18 @@ int mi355_group_by_unique_csr(const int32_t* csr_cnt, const int32_t* csr_rank, c
     MI355_CHECK_ARG(hot_workspace_bytes >= hot_bytes(n, dim), "hot workspace too small");
     hot = hot_carve(hot_workspace, n, dim);
   }
-  hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, csr_cnt, max_unique, nu_dev, partial);
-  if (hot_workspace)
-    hipLaunchKernelGGL(scan_partials_clear_kernel, dim3(1), dim3(kScanThreads), 0, stream, partial, nbu, total, hot.n_hot, hot.n_tasks);
-  else
+  // the hot-list counters are cleared by the reduce pass; the down pass sums the earlier tiles' counts itself when
+  // there are few tiles (no one-block scan launch in between)
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, csr_cnt, max_unique, nu_dev, partial,
+                     hot_workspace ? hot.n_hot : (int*)nullptr, hot_workspace ? hot.n_tasks : (int*)nullptr);
+  if (nbu <= kSelfPrefixMaxTiles) {
+    hipLaunchKernelGGL(scan_down_kernel<true>, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, csr_cnt, max_unique, nu_dev, partial, total,
+                       ptr, hot, hot_workspace != nullptr);
+  } else {
     hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, stream, partial, nbu, total);
-  hipLaunchKernelGGL(scan_down_kernel, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, csr_cnt, max_unique, nu_dev, partial, total, ptr,
-                     hot, hot_workspace != nullptr);
+    hipLaunchKernelGGL(scan_down_kernel<false>, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, csr_cnt, max_unique, nu_dev, partial, total,
+                       ptr, hot, hot_workspace != nullptr);
+  }
   if (n > 0) hipLaunchKernelGGL(csr_scatter_kernel, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, reverse_indices, csr_rank, n,
                                 offsets, num_bags, ptr, csr_src, hot, hot_workspace != nullptr);
   MI355_LAUNCH_CHECK();

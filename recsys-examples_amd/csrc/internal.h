@@ -20,6 +20,12 @@ int mi355i_segmented_unique(const void* keys, int64_t n, const int64_t* segmente
                             int64_t feature_x_batch, int64_t* table_range_out, int64_t* table_ids_out, void* workspace,
                             int64_t workspace_bytes, hipStream_t stream);
 
+// mi355_table_lookup without the slot lock for ASSIGN / GLOBAL_TIMER score updates (single-stream callers only)
+int mi355i_table_lookup(void* storage, const int64_t* table_bucket_offsets, int64_t C, int64_t num_scores, int64_t n,
+                        const int64_t* n_dev, const void* keys, const int64_t* table_ids, const void* score_in,
+                        int policy, uint64_t timer_override, int64_t* score_out, uint8_t* founds, int64_t* indices,
+                        hipStream_t stream);
+
 // mi355_table_insert whose unlock pass also produces the row address of every key (replaces mi355_row_addresses)
 int mi355i_table_insert(void* storage, const int64_t* table_bucket_offsets, int64_t C, int64_t num_scores,
                         int32_t* bucket_sizes, int32_t* counter, int64_t n, const int64_t* n_dev, const void* keys,

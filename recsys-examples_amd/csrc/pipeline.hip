@@ -67,7 +67,7 @@ int mi355_demb_forward(
   if (!find_scores) find_scores = freq;      // LFU: scores are the occurrence counts of this batch
   if (!insert_scores) insert_scores = freq;
   if (num_keys > 0) {
-    STEP(mi355_table_lookup(storage, table_bucket_offsets, bucket_capacity, num_scores, num_keys, nu_dev, unique_keys,
+    STEP(mi355i_table_lookup(storage, table_bucket_offsets, bucket_capacity, num_scores, num_keys, nu_dev, unique_keys,
                             table_ids, find_scores, find_policy, timer_override, nullptr, founds, slots, stream));
     if (train) {
       // insert + unlock; the unlock pass also writes the row address of every unique key

@@ -189,6 +189,7 @@ __global__ void __launch_bounds__(256) table_init_kernel(Table t, int64_t num_bu
   }
 }
 
+template <bool kLockFree>
 __global__ void __launch_bounds__(256)
 table_lookup_kernel(Table t, const int64_t* __restrict__ tbo, int64_t n, const int64_t* __restrict__ n_dev,
                     const uint64_t* __restrict__ keys, const int64_t* __restrict__ table_ids,
@@ -214,6 +215,11 @@ table_lookup_kernel(Table t, const int64_t* __restrict__ tbo, int64_t n, const i
         uint64_t* sc = t.scores(L.bucket) + (int64_t)found_slot * t.ns;
         if (policy == kConst) {
           score = sc[t.ns - 1];
+        } else if (kLockFree && (policy == kAssign || policy == kGlobalTimer)) {
+          // Callers that order every table-mutating kernel on ONE stream (the fused forward) need no slot lock to
+          // overwrite a score: the store is idempotent and nothing can evict the slot meanwhile.  Saves one
+          // device-scope CAS + drain + unlock store per found key (~10 G/s of atomics is the whole kernel otherwise).
+          ast64(sc, score);
         } else {
           uint64_t* kp = t.keys(L.bucket) + found_slot;
           uint64_t exp = key;
@@ -541,21 +547,35 @@ int mi355_table_init(void* storage, int64_t num_buckets, int64_t C, int64_t num_
   return MI355_OK;
 }
 
-int mi355_table_lookup(void* storage, const int64_t* table_bucket_offsets, int64_t C, int64_t num_scores, int64_t n,
-                       const int64_t* n_dev, const void* keys, const int64_t* table_ids, const void* score_in,
-                       int policy, uint64_t timer_override, int64_t* score_out, uint8_t* founds, int64_t* indices,
-                       hipStream_t stream) {
+static int table_lookup_impl(void* storage, const int64_t* table_bucket_offsets, int64_t C, int64_t num_scores, int64_t n,
+                             const int64_t* n_dev, const void* keys, const int64_t* table_ids, const void* score_in,
+                             int policy, uint64_t timer_override, int64_t* score_out, uint8_t* founds, int64_t* indices,
+                             bool lock_free, hipStream_t stream) {
   MI355_CHECK_ARG(C > 0 && C % 16 == 0, "bucket capacity must be a positive multiple of 16");
   MI355_CHECK_ARG(policy >= kConst && policy <= kLruLfu, "bad score policy");
   MI355_CHECK_ARG(policy == kConst || policy == kGlobalTimer || score_in, "score_in required by this policy");
   MI355_CHECK_ARG(policy != kLruLfu || num_scores == 2, "LRU_LFU needs num_scores == 2");
   if (n == 0) return MI355_OK;
   Table t = make_table(storage, C, num_scores);
-  hipLaunchKernelGGL(table_lookup_kernel, dim3(grid_for(n, 256 / G)), dim3(256), 0, stream, t, table_bucket_offsets, n,
-                     n_dev, (const uint64_t*)keys, table_ids, (const uint64_t*)score_in, policy, timer_override,
-                     score_out, founds, indices);
+  if (lock_free)
+    hipLaunchKernelGGL(table_lookup_kernel<true>, dim3(grid_for(n, 256 / G)), dim3(256), 0, stream, t, table_bucket_offsets, n,
+                       n_dev, (const uint64_t*)keys, table_ids, (const uint64_t*)score_in, policy, timer_override,
+                       score_out, founds, indices);
+  else
+    hipLaunchKernelGGL(table_lookup_kernel<false>, dim3(grid_for(n, 256 / G)), dim3(256), 0, stream, t, table_bucket_offsets, n,
+                       n_dev, (const uint64_t*)keys, table_ids, (const uint64_t*)score_in, policy, timer_override,
+                       score_out, founds, indices);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
+}
+
+// table_lookup with the reference's slot-lock protocol (safe against concurrent inserts on other streams)
+int mi355_table_lookup(void* storage, const int64_t* table_bucket_offsets, int64_t C, int64_t num_scores, int64_t n,
+                       const int64_t* n_dev, const void* keys, const int64_t* table_ids, const void* score_in,
+                       int policy, uint64_t timer_override, int64_t* score_out, uint8_t* founds, int64_t* indices,
+                       hipStream_t stream) {
+  return table_lookup_impl(storage, table_bucket_offsets, C, num_scores, n, n_dev, keys, table_ids, score_in, policy,
+                           timer_override, score_out, founds, indices, false, stream);
 }
 
 int mi355_table_insert(void* storage, const int64_t* table_bucket_offsets, int64_t C, int64_t num_scores,
@@ -585,6 +605,16 @@ int mi355_table_insert(void* storage, const int64_t* table_bucket_offsets, int64
                      (int64_t*)nullptr);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
+}
+
+// table_lookup for callers that keep every table-mutating kernel on one stream: ASSIGN / GLOBAL_TIMER scores are written
+// without the slot lock (see table_lookup_kernel)
+int mi355i_table_lookup(void* storage, const int64_t* table_bucket_offsets, int64_t C, int64_t num_scores, int64_t n,
+                        const int64_t* n_dev, const void* keys, const int64_t* table_ids, const void* score_in,
+                        int policy, uint64_t timer_override, int64_t* score_out, uint8_t* founds, int64_t* indices,
+                        hipStream_t stream) {
+  return table_lookup_impl(storage, table_bucket_offsets, C, num_scores, n, n_dev, keys, table_ids, score_in, policy,
+                           timer_override, score_out, founds, indices, true, stream);
 }
 
 int mi355i_table_insert(void* storage, const int64_t* table_bucket_offsets, int64_t C, int64_t num_scores,
