@@ -174,6 +174,17 @@ int mi355_block_bucketize(int64_t world_size, int64_t num_bags, int64_t batch_si
                           const float* weights, int64_t* new_lengths, int64_t* new_offsets, void* new_indices,
                           float* new_weights, int64_t* unbucketize_permute, hipStream_t stream);
 
+/* Glue of the row-wise input dist (dynamicemb/input_dist.py :199-285 + TorchRec KJTAllToAll, third party): exclusive
+ * offsets of a lengths vector (offsets has n+1 entries); the keys sent to / received from every peer as differences of
+ * the send / receive offsets at the peer boundaries (`splits` [2*W]: send then receive; may be pinned host memory --
+ * it is the one host read of the exchange); pseudo-bags of at most `chunk` keys over per-table unique-key lists for
+ * the pre-communication dedup (shard/embedding.py:183-275), lengths [T*num_chunks], offsets [T*num_chunks+1]. */
+int mi355_exclusive_offsets(const int64_t* lengths, int64_t n, int64_t* offsets, hipStream_t stream);
+int mi355_peer_splits(const int64_t* send_offsets, const int64_t* recv_offsets, int64_t bags_per_peer, int64_t world_size,
+                      int64_t* splits, hipStream_t stream);
+int mi355_chunk_bags(const int64_t* unique_offsets, int64_t num_tables, int64_t chunk, int64_t num_chunks, int64_t* lengths,
+                     int64_t* offsets, hipStream_t stream);
+
 /* compute_dedup_lengths_cuda, src/unique_op.cu:753-789 (kernel lookup_kernel.cuh:1049-1090): lengths/offsets that
  * spread each table's unique keys evenly over its (feature, batch) bags.  new_offsets has new_lengths_size+1. */
 int mi355_compute_dedup_lengths(const int64_t* unique_offsets, const int64_t* table_offsets_in_feature,

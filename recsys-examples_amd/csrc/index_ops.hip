@@ -889,6 +889,32 @@ static int64_t* scan64_scratch(int64_t words) {
   }
   return p;
 }
+// Pseudo-bags over per-table unique-key lists (sharded rows-back mode, dynamicemb/sharded.py): table t's
+// unique_offsets[t+1]-unique_offsets[t] keys are cut into `num_chunks` bags of at most `chunk` keys.
+__global__ void __launch_bounds__(256)
+chunk_bags_kernel(const int64_t* __restrict__ uoff, int64_t T, int64_t chunk, int64_t nchunk, int64_t* __restrict__ lengths,
+                  int64_t* __restrict__ offsets) {
+  const int64_t total = T * nchunk;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= total; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i == total) { offsets[i] = uoff[T]; continue; }
+    const int64_t t = i / nchunk, c = i - t * nchunk;
+    const int64_t lo = uoff[t], cnt = uoff[t + 1] - lo;
+    const int64_t a = c * chunk < cnt ? c * chunk : cnt, b = (c + 1) * chunk < cnt ? (c + 1) * chunk : cnt;
+    offsets[i] = lo + a;
+    lengths[i] = b - a;
+  }
+}
+
+// keys sent to / received from every peer = differences of the send / receive offsets at the peer boundaries;
+// `splits` [2 * W] may live in pinned host memory (the one host read of the exchange)
+__global__ void peer_splits_kernel(const int64_t* __restrict__ send_off, const int64_t* __restrict__ recv_off, int64_t per_peer,
+                                   int64_t W, int64_t* __restrict__ splits) {
+  for (int64_t p = threadIdx.x; p < W; p += blockDim.x) {
+    splits[p] = send_off[(p + 1) * per_peer] - send_off[p * per_peer];
+    splits[W + p] = recv_off[(p + 1) * per_peer] - recv_off[p * per_peer];
+  }
+}
+
 static int scan_i64(const int64_t* in, int64_t n, int64_t* out, hipStream_t stream) {
   if (n <= 4 * kScan64Tile) {
     hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, stream, in, n, out);
@@ -1146,6 +1172,35 @@ int mi355_permute_bags(int64_t num_sources, int64_t num_features, int64_t batch_
   }
   hipLaunchKernelGGL(permute_bags_kernel, dim3(grid_for(nb, 4, 1 << 16)), dim3(256), 0, stream, num_sources, num_features, batch_size,
                      elem_bytes / 8, in_offsets, out_offsets, (const uint64_t*)in_keys, (uint64_t*)out_keys);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int mi355_exclusive_offsets(const int64_t* lengths, int64_t n, int64_t* offsets, hipStream_t stream) {
+  MI355_CHECK_ARG(n >= 0 && offsets, "offsets output required");
+  if (n == 0) {
+    hipLaunchKernelGGL(zero_offsets_kernel, dim3(1), dim3(64), 0, stream, offsets, (int64_t)1);
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+  }
+  if (scan_i64(lengths, n, offsets, stream) != MI355_OK) return MI355_ELAUNCH;
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int mi355_chunk_bags(const int64_t* unique_offsets, int64_t num_tables, int64_t chunk, int64_t num_chunks, int64_t* lengths,
+                     int64_t* offsets, hipStream_t stream) {
+  MI355_CHECK_ARG(num_tables > 0 && chunk > 0 && num_chunks > 0, "tables, chunk and num_chunks must be positive");
+  hipLaunchKernelGGL(chunk_bags_kernel, dim3(grid_for(num_tables * num_chunks + 1, 256)), dim3(256), 0, stream, unique_offsets,
+                     num_tables, chunk, num_chunks, lengths, offsets);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int mi355_peer_splits(const int64_t* send_offsets, const int64_t* recv_offsets, int64_t bags_per_peer, int64_t world_size,
+                      int64_t* splits, hipStream_t stream) {
+  MI355_CHECK_ARG(world_size > 0 && bags_per_peer >= 0, "bad world size / bags per peer");
+  hipLaunchKernelGGL(peer_splits_kernel, dim3(1), dim3(64), 0, stream, send_offsets, recv_offsets, bags_per_peer, world_size, splits);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }

@@ -21,16 +21,92 @@ import torch.distributed as dist
 DIST_TYPES = {"continuous": 0, "roundrobin": 1, "hash_roundrobin": 2}
 
 
-class HipOps:
+class TorchGlue:
+    """Index bookkeeping of the exchange in plain torch (device agnostic): the base of every `ops` backend.  HipOps
+    overrides each method with ONE launch; the CPU test backend inherits these."""
+
+    def exclusive_offsets(self, lengths):
+        off = torch.zeros(lengths.numel() + 1, dtype=torch.int64, device=lengths.device)
+        torch.cumsum(lengths, 0, out=off[1:])
+        return off
+
+    def peer_splits(self, send_offsets, recv_offsets, per_peer, world):
+        """keys sent to / received from every peer (python lists): the one host read of the exchange"""
+        idx = torch.arange(world + 1, device=send_offsets.device) * per_peer
+        s, r = send_offsets[idx], recv_offsets[idx]
+        both = torch.stack([s[1:] - s[:-1], r[1:] - r[:-1]]).cpu()
+        return both[0].tolist(), both[1].tolist()
+
+    def chunk_bags(self, unique_offsets, num_tables, chunk, num_chunks):
+        """per-table unique-key lists cut into `num_chunks` pseudo-bags of <= chunk keys -> (lengths, offsets)"""
+        lo = unique_offsets[:-1].view(num_tables, 1)
+        cnt = (unique_offsets[1:] - unique_offsets[:-1]).view(num_tables, 1)
+        steps = torch.arange(num_chunks + 1, dtype=torch.int64, device=unique_offsets.device).view(1, -1) * chunk
+        cut = torch.minimum(steps, cnt)                        # [T, num_chunks + 1]
+        lengths = (cut[:, 1:] - cut[:, :-1]).reshape(-1)
+        offsets = torch.cat([(lo + cut[:, :-1]).reshape(-1), unique_offsets[-1:]])
+        return lengths, offsets
+
+    def compose(self, perm, index):
+        """perm[index]: lets a consumer read rows in exchange order instead of gathering them back first"""
+        return perm[index]
+
+    def permute_counts(self, counts, perm, n):
+        """out[perm[u]] = counts[u], u < n (per-unique occurrence counts re-keyed to exchange order)"""
+        if counts is None:
+            return None
+        out = torch.zeros(n, dtype=counts.dtype, device=counts.device)
+        out[perm] = counts[:n]
+        return out
+
+
+class HipOps(TorchGlue):
     """Compute backend of the sharded path: every method is one or two C-ABI launches."""
 
-    def bucketize(self, lengths, values, block_sizes, world, sequence, dist_types):
-        import dynamicemb_extensions as ext
+    def bucketize(self, offsets, values, block_sizes, world, sequence, dist_types):
+        """-> (new_lengths [W*F*B], new_offsets [W*F*B+1], new_values, unbucketize_permute | None)"""
+        from mi355_native import check, lib, ptr, stream
 
-        nl, nv, _, _, perm = ext.block_bucketize_sparse_features(
-            lengths, values, bucketize_pos=False, sequence=sequence, block_sizes=block_sizes, my_size=world,
-            dist_type_per_feature=dist_types)
-        return nl, nv, perm
+        FB = offsets.numel() - 1
+        B = FB // block_sizes.numel()
+        dev = values.device
+        new_lengths = torch.empty(world * FB, dtype=torch.int64, device=dev)
+        new_offsets = torch.empty(world * FB + 1, dtype=torch.int64, device=dev)
+        new_values = torch.empty_like(values)
+        perm = torch.empty(values.numel(), dtype=torch.int64, device=dev) if sequence else None
+        check(lib().mi355_block_bucketize(world, FB, B, ptr(offsets), ptr(values), ptr(block_sizes), ptr(dist_types), None,
+                                          ptr(new_lengths), ptr(new_offsets), ptr(new_values), None, ptr(perm), stream()),
+              "block_bucketize")
+        return new_lengths, new_offsets, new_values, perm
+
+    def exclusive_offsets(self, lengths):
+        from mi355_native import check, lib, ptr, stream
+
+        off = torch.empty(lengths.numel() + 1, dtype=torch.int64, device=lengths.device)
+        check(lib().mi355_exclusive_offsets(ptr(lengths), lengths.numel(), ptr(off), stream()), "exclusive_offsets")
+        return off
+
+    def peer_splits(self, send_offsets, recv_offsets, per_peer, world):
+        from mi355_native import check, lib, ptr, stream
+
+        buf = getattr(self, "_splits_host", None)
+        if buf is None or buf.numel() < 2 * world:
+            buf = self._splits_host = torch.empty(2 * world, dtype=torch.int64).pin_memory()
+        # the kernel writes straight into pinned host memory; the host waits for the stream, not for a copy
+        check(lib().mi355_peer_splits(ptr(send_offsets), ptr(recv_offsets), per_peer, world, ptr(buf), stream()), "peer_splits")
+        torch.cuda.current_stream().synchronize()
+        v = buf[:2 * world].tolist()
+        return v[:world], v[world:]
+
+    def chunk_bags(self, unique_offsets, num_tables, chunk, num_chunks):
+        from mi355_native import check, lib, ptr, stream
+
+        n = num_tables * num_chunks
+        lengths = torch.empty(n, dtype=torch.int64, device=unique_offsets.device)
+        offsets = torch.empty(n + 1, dtype=torch.int64, device=unique_offsets.device)
+        check(lib().mi355_chunk_bags(ptr(unique_offsets), num_tables, chunk, num_chunks, ptr(lengths), ptr(offsets), stream()),
+              "chunk_bags")
+        return lengths, offsets
 
     def permute_lengths(self, S, F, B, lengths):
         from mi355_native import check, lib, ptr, stream
@@ -124,8 +200,9 @@ class ShardedKeys:
 
 
 def bucketize_before_all2all(lengths, values, num_buckets, block_sizes, output_permute=False,
-                             dist_type_per_feature: Optional[Sequence[str]] = None, ops=None):
-    """bucketize_kjt_before_all2all (input_dist.py:80-173): -> (new_lengths [W*F*B], new_values, permute)."""
+                             dist_type_per_feature: Optional[Sequence[str]] = None, ops=None, offsets=None):
+    """bucketize_kjt_before_all2all (input_dist.py:80-173): -> (new_lengths [W*F*B], new_values, permute,
+    new_offsets [W*F*B+1])."""
     ops = ops or HipOps()
     F = block_sizes.numel()
     if dist_type_per_feature is None:
@@ -136,7 +213,10 @@ def bucketize_before_all2all(lengths, values, num_buckets, block_sizes, output_p
             raise ValueError("Not support dist type of ", d)
         codes.append(DIST_TYPES[d])
     dist_t = torch.tensor(codes, dtype=torch.int32, device=values.device)
-    return ops.bucketize(lengths.view(-1), values, block_sizes.to(values.device), num_buckets, output_permute, dist_t)
+    if offsets is None:
+        offsets = ops.exclusive_offsets(lengths.view(-1).to(torch.int64))
+    nl, no, nv, perm = ops.bucketize(offsets, values, block_sizes.to(values.device), num_buckets, output_permute, dist_t)
+    return nl, nv, perm, no
 
 
 class RwSparseFeaturesDist:
@@ -152,40 +232,58 @@ class RwSparseFeaturesDist:
         self._is_sequence = is_sequence
         self._dist_type_per_feature = list(dist_type_per_feature) if dist_type_per_feature is not None \
             else ["roundrobin"] * num_features
+        for d_ in self._dist_type_per_feature:
+            if d_ not in DIST_TYPES:
+                raise ValueError("Not support dist type of ", d_)
         self._ops = ops or HipOps()
+        self._dist_codes = None
         self.unbucketize_permute_tensor = None
 
-    def forward(self, lengths: torch.Tensor, values: torch.Tensor, collapse_batch: bool = False) -> ShardedKeys:
+    def forward(self, lengths: torch.Tensor, values: torch.Tensor, collapse_batch: bool = False,
+                offsets: Optional[torch.Tensor] = None) -> ShardedKeys:
         """collapse_batch: the batch dimension is only a local chunking of per-feature key lists (it may differ
-        between ranks); the exchange then carries one bag per (rank, feature)."""
+        between ranks); the exchange then carries one bag per (rank, feature).  `offsets` (optional): the exclusive
+        offsets of `lengths` when the caller already has them."""
         W, F, ops = self._world_size, self._num_features, self._ops
-        lengths = lengths.view(-1).to(torch.int64)
+        lengths = lengths.view(-1)
+        if lengths.dtype != torch.int64:
+            lengths = lengths.to(torch.int64)
         assert lengths.numel() % F == 0
         B = lengths.numel() // F
-        new_lengths, new_values, perm = bucketize_before_all2all(
-            lengths, values, W, self._block_sizes, self._is_sequence, self._dist_type_per_feature, ops)
+        if self._dist_codes is None or self._dist_codes.device != values.device:
+            self._dist_codes = torch.tensor([DIST_TYPES[d] for d in self._dist_type_per_feature], dtype=torch.int32,
+                                            device=values.device)
+            self._block_sizes = self._block_sizes.to(values.device)
+        if offsets is None:
+            offsets = ops.exclusive_offsets(lengths)
+        new_lengths, new_offsets, new_values, perm = ops.bucketize(offsets, values, self._block_sizes, W, self._is_sequence,
+                                                                   self._dist_codes)
         self.unbucketize_permute_tensor = perm
-        new_lengths = new_lengths.to(torch.int64)
         if collapse_batch:
-            new_lengths = new_lengths.view(W * F, B).sum(1)
+            # one bag per (peer, feature): its offsets are the bucketized offsets at the (peer, feature) boundaries
+            idx = torch.arange(W * F + 1, device=values.device) * B
+            new_offsets = new_offsets[idx]
+            new_lengths = new_offsets[1:] - new_offsets[:-1]
             B = 1
         # lengths all-to-all: equal splits of F*B per peer
         recv_lengths = torch.empty_like(new_lengths)
         dist.all_to_all_single(recv_lengths, new_lengths, group=self._pg)
+        recv_offsets = ops.exclusive_offsets(recv_lengths)
         # key counts per peer (the one host read of the step, as in KJTAllToAll)
-        splits = torch.stack([new_lengths.view(W, F * B).sum(1), recv_lengths.view(W, F * B).sum(1)]).cpu()
-        send_splits, recv_splits = splits[0].tolist(), splits[1].tolist()
+        send_splits, recv_splits = ops.peer_splits(new_offsets, recv_offsets, F * B, W)
         n_send = sum(send_splits)  # == values.numel() unless the caller passed a padded key buffer
         new_values = new_values[:n_send]
         if perm is not None:
             perm = perm[:n_send]
         recv_values = torch.empty(sum(recv_splits), dtype=new_values.dtype, device=new_values.device)
         dist.all_to_all_single(recv_values, new_values, recv_splits, send_splits, group=self._pg)
-        # recat (src, f, b) -> (f, src, b)
-        recv_offsets = exclusive_offsets(recv_lengths)
-        fm_lengths = ops.permute_lengths(W, F, B, recv_lengths)
-        fm_offsets = exclusive_offsets(fm_lengths)
-        fm_values = ops.permute_bags(W, F, B, recv_offsets, fm_offsets, recv_values)
+        # recat (src, f, b) -> (f, src, b); the two orders coincide when there is one source or one feature
+        if W == 1 or F == 1:
+            fm_lengths, fm_offsets, fm_values = recv_lengths, recv_offsets, recv_values
+        else:
+            fm_lengths = ops.permute_lengths(W, F, B, recv_lengths)
+            fm_offsets = ops.exclusive_offsets(fm_lengths)
+            fm_values = ops.permute_bags(W, F, B, recv_offsets, fm_offsets, recv_values)
         return ShardedKeys(fm_lengths, fm_offsets, fm_values, recv_offsets, send_splits, recv_splits, perm, B, F)
 
     __call__ = forward

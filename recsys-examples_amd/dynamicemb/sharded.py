@@ -57,9 +57,13 @@ class RowWiseShardedLookup:
                                                ops=self.ops)
 
     # ------------------------------------------------------------------------------ forward
-    def forward(self, values: torch.Tensor, offsets: torch.Tensor, train: bool = True, collapse_batch: bool = False):
-        lengths = offsets[1:] - offsets[:-1]
-        sk = self.input_dist(lengths, values, collapse_batch)
+    def forward(self, values: torch.Tensor, offsets: torch.Tensor, train: bool = True, collapse_batch: bool = False,
+                lengths: Optional[torch.Tensor] = None, bucketized: bool = False):
+        """bucketized (sequence mode): return the rows in EXCHANGE order (as they come back from the owners) instead of
+        gathering them into key order -- the caller composes `ctx.keys.unbucketize_permute` into its own index."""
+        if lengths is None:
+            lengths = offsets[1:] - offsets[:-1]
+        sk = self.input_dist(lengths, values, collapse_batch, offsets=offsets)
         out_local, lctx = self.local.forward(sk.values, sk.offsets, train)
         W, B = self.world, sk.batch_size
         if self.pooled:
@@ -75,24 +79,28 @@ class RowWiseShardedLookup:
             back = torch.empty(sum(sk.send_splits), D, dtype=out_local.dtype, device=out_local.device)
             dist.all_to_all_single(back, rows_sfb, [s for s in sk.send_splits], [r for r in sk.recv_splits],
                                    group=self.pg)
-            out = self.ops.gather_rows(back, sk.unbucketize_permute)
+            out = back if bucketized else self.ops.gather_rows(back, sk.unbucketize_permute)
             if out.dtype != self.out_dtype:
                 out = out.to(self.out_dtype)
         return out, _ShardedCtx(sk, lctx, sum(sk.send_splits))
 
     # ------------------------------------------------------------------------------ backward
-    def backward(self, ctx: _ShardedCtx, grads: torch.Tensor) -> None:
+    def backward(self, ctx: _ShardedCtx, grads: torch.Tensor, bucketized: bool = False) -> None:
+        """bucketized (sequence mode): `grads` rows are already in exchange order."""
         sk, W, B = ctx.keys, self.world, ctx.keys.batch_size
         grads = grads.contiguous()
         if self.pooled:
             g_all = torch.empty(W * grads.size(0), grads.size(1), dtype=grads.dtype, device=grads.device)
             dist.all_gather_into_tensor(g_all, grads, group=self.pg)
         else:
-            n = ctx.n_local
-            perm = sk.unbucketize_permute
-            inv = torch.empty_like(perm)
-            inv[perm] = torch.arange(n, dtype=perm.dtype, device=perm.device)
-            g_send = self.ops.gather_rows(grads, inv)  # bucketized order
+            if bucketized:
+                g_send = grads
+            else:
+                n = ctx.n_local
+                perm = sk.unbucketize_permute
+                inv = torch.empty_like(perm)
+                inv[perm] = torch.arange(n, dtype=perm.dtype, device=perm.device)
+                g_send = self.ops.gather_rows(grads, inv)  # bucketized order
             g_recv = torch.empty(sum(sk.recv_splits), grads.size(1), dtype=grads.dtype, device=grads.device)
             dist.all_to_all_single(g_recv, g_send, [r for r in sk.recv_splits], [s for s in sk.send_splits],
                                    group=self.pg)
@@ -140,19 +148,22 @@ class RowWiseShardedPooledRows:
         B = (offsets.numel() - 1) // self.F
         ukeys, rev, uoff, aux = self.ops.unique(values, offsets, self.feature_offsets)
         nchunk = max(1, (values.numel() + self.chunk - 1) // self.chunk)
-        counts = (uoff[1:] - uoff[:-1]).view(self.T, 1)
-        steps = torch.arange(nchunk, dtype=torch.int64, device=values.device).view(1, nchunk) * self.chunk
-        lengths = (counts - steps).clamp_(0, self.chunk).view(-1)
-        u_offsets = torch.zeros(lengths.numel() + 1, dtype=torch.int64, device=values.device)
-        torch.cumsum(lengths, 0, out=u_offsets[1:])
-        rows, ictx = self.inner.forward(ukeys, u_offsets, train, collapse_batch=True)  # [Nu, D] fp32
-        out = self.ops.pool(rows, rev, offsets, B, self.combiner, self.F * self.dim, None, self.dim, self.out_dtype)
-        return out, (ictx, rev, offsets, B, rows.size(0), aux)
+        lengths, u_offsets = self.ops.chunk_bags(uoff, self.T, self.chunk, nchunk)
+        # rows of the unique keys, in EXCHANGE order: the pooling index is composed with the exchange permutation
+        # instead of gathering [Nu, D] rows back into unique order (and the gradients out of it in the backward)
+        rows, ictx = self.inner.forward(ukeys, u_offsets, train, collapse_batch=True, lengths=lengths, bucketized=True)
+        perm = ictx.keys.unbucketize_permute
+        idx = self.ops.compose(perm, rev)
+        out = self.ops.pool(rows, idx, offsets, B, self.combiner, self.F * self.dim, None, self.dim, self.out_dtype)
+        return out, (ictx, idx, offsets, B, rows.size(0), aux, perm)
 
     def backward(self, ctx, grads: torch.Tensor) -> None:
-        ictx, rev, offsets, B, nu, aux = ctx
-        ug = self.ops.reduce_grads(rev, grads.contiguous(), nu, B, self.dim, offsets, None, self.combiner, aux)
-        self.inner.backward(ictx, ug)
+        ictx, idx, offsets, B, nu, aux, perm = ctx
+        if aux is not None:
+            cnt, rank, uoff = aux
+            aux = (self.ops.permute_counts(cnt, perm, nu), rank, uoff)
+        ug = self.ops.reduce_grads(idx, grads.contiguous(), nu, B, self.dim, offsets, None, self.combiner, aux)
+        self.inner.backward(ictx, ug, bucketized=True)
 
 
 class _ModuleLocal:

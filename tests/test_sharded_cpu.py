@@ -29,21 +29,28 @@ def init_row(key: int, table: int = 0) -> np.ndarray:
     return ((np.arange(D, dtype=np.float32) + 1.0 + table) * np.float32((key % 97) + 1) * np.float32(0.01)).astype(np.float32)
 
 
-class NumpyOps:
-    """CPU stand-in for HipOps (tests only): same contracts, oracle/numpy inside."""
+def _glue_base():
+    from dynamicemb.input_dist import TorchGlue
 
-    def bucketize(self, lengths, values, block_sizes, world, sequence, dist_types):
+    return TorchGlue
+
+
+class NumpyOps(_glue_base()):
+    """CPU stand-in for HipOps (tests only): same contracts, oracle/numpy inside; the index bookkeeping
+    (offsets, peer splits, pseudo-bags, index composition) is the product's own torch code (TorchGlue)."""
+
+    def bucketize(self, offsets, values, block_sizes, world, sequence, dist_types):
         from oracle import oracle as orc
 
-        ln = lengths.numpy().astype(np.int64)
-        off = np.zeros(ln.size + 1, np.int64)
-        off[1:] = np.cumsum(ln)
+        off = offsets.numpy().astype(np.int64)
         F = block_sizes.numel()
-        B = ln.size // F
+        B = (off.size - 1) // F
         dts = set(dist_types.tolist())
         assert len(dts) == 1
         nl, _, ni, perm = orc.block_bucketize(off, values.numpy(), world, B, block_sizes.numpy(), dts.pop())
-        return (torch.from_numpy(nl), torch.from_numpy(ni.astype(np.int64)),
+        no = np.zeros(nl.size + 1, np.int64)
+        no[1:] = np.cumsum(nl)
+        return (torch.from_numpy(nl.astype(np.int64)), torch.from_numpy(no), torch.from_numpy(ni.astype(np.int64)),
                 torch.from_numpy(perm) if sequence else None)
 
     def permute_lengths(self, S, F, B, lengths):

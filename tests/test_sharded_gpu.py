@@ -53,6 +53,33 @@ def test_permute_bags(S, F, B, maxlen, width):
     assert np.array_equal(back.cpu().numpy(), data)
 
 
+@pytest.mark.parametrize("n", [0, 1, 7, 1024, 4097, 300_000])
+def test_exchange_glue_kernels_match_torch(n):
+    """exclusive_offsets / peer_splits / chunk_bags (one launch each) against the torch bookkeeping they replace"""
+    from dynamicemb.input_dist import HipOps, TorchGlue
+
+    rng = np.random.default_rng(n)
+    hip, ref = HipOps(), TorchGlue()
+    lengths = torch.from_numpy(rng.integers(0, 50, n).astype(np.int64)).cuda()
+    off = hip.exclusive_offsets(lengths)
+    assert torch.equal(off, ref.exclusive_offsets(lengths))
+    for W in (1, 2, 8):
+        per = n // W
+        if per == 0:
+            continue
+        other = torch.from_numpy(rng.integers(0, 9, W * per).astype(np.int64)).cuda()
+        roff = ref.exclusive_offsets(other)
+        assert hip.peer_splits(off, roff, per, W) == ref.peer_splits(off, roff, per, W)
+    for T, chunk in ((1, 64), (3, 64), (5, 7)):
+        counts = torch.from_numpy(rng.integers(0, max(2, n // T + 1), T).astype(np.int64)).cuda()
+        uoff = ref.exclusive_offsets(counts)
+        nchunk = max(1, (int(counts.sum()) + 3 * chunk) // chunk)     # enough chunks for the longest list, as the caller sizes it
+        l1, o1 = hip.chunk_bags(uoff, T, chunk, nchunk)
+        l2, o2 = ref.chunk_bags(uoff, T, chunk, nchunk)
+        assert torch.equal(l1, l2) and torch.equal(o1, o2)
+        assert int(l1.sum()) == int(counts.sum()) and torch.equal(o1, ref.exclusive_offsets(l1))
+
+
 @pytest.mark.parametrize("chunks,n", [(1, 8), (2, 1024), (8, 65536 * 16 + 4)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_sum_chunks(chunks, n, dtype):
