@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
   constexpr bool QLDS = D >= 256;      // large head dim: Q fragments live in LDS to free 64 VGPRs for prefetching
   uint16_t* Qs = Vt + D * VS;          // [kBM][KS] (QLDS only)
 
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int b = blockIdx.y, h = blockIdx.x;   // grid (H, B, blocks): see launch_fwd
   SeqInfo s;
   s.start = a.cu_seqlens[b];
   const int Lq = a.cu_seqlens[b + 1] - s.start;
@@ -164,8 +164,8 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
   s.L = a.cu_seqlens_k ? a.cu_seqlens_k[b + 1] - kstart : Lq;
   const int dq = s.L - Lq;   // absolute position of query row r is dq + r
   const int nblk = (Lq + kBM - 1) / kBM;
-  if ((int)blockIdx.x >= nblk || dq < 0) return;
-  const int m0 = (nblk - 1 - (int)blockIdx.x) * kBM;  // heaviest (latest) row blocks first
+  if ((int)blockIdx.z >= nblk || dq < 0) return;
+  const int m0 = (nblk - 1 - (int)blockIdx.z) * kBM;  // heaviest (latest) row blocks first
   s.has_ctx = a.num_contexts != nullptr;
   s.has_tgt = a.num_targets != nullptr;
   s.c = s.has_ctx ? a.num_contexts[b] : 0;
@@ -608,11 +608,11 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
   uint16_t* Qt = dOs + (kDK ? BQ * RS : 0);         // [D][TS]    (dK; kDK only)
   uint16_t* dOt = Qt + (kDK ? D * TS : 0);          // [D][TS]    (dV; kDV only)
 
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int b = blockIdx.y, h = blockIdx.x;   // grid (H, B, blocks): see launch_fwd
   SeqInfo s;
   s.start = a.cu_seqlens[b];
   s.L = a.cu_seqlens[b + 1] - s.start;
-  const int n0 = blockIdx.x * kBM;
+  const int n0 = blockIdx.z * kBM;   // earliest key blocks (seen by most queries) first
   if (n0 >= s.L) return;
   s.has_ctx = a.num_contexts != nullptr;
   s.has_tgt = a.num_targets != nullptr;
@@ -830,13 +830,13 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
   uint16_t* Vs = Ks + BK * RS;       // [BK][RS]
   uint16_t* Kt = Vs + BK * RS;       // [D][TS]
 
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int b = blockIdx.y, h = blockIdx.x;   // grid (H, B, blocks): see launch_fwd
   SeqInfo s;
   s.start = a.cu_seqlens[b];
   s.L = a.cu_seqlens[b + 1] - s.start;
   const int nblk = (s.L + kBM - 1) / kBM;
-  if ((int)blockIdx.x >= nblk) return;
-  const int m0 = (nblk - 1 - (int)blockIdx.x) * kBM;
+  if ((int)blockIdx.z >= nblk) return;
+  const int m0 = (nblk - 1 - (int)blockIdx.z) * kBM;
   s.has_ctx = a.num_contexts != nullptr;
   s.has_tgt = a.num_targets != nullptr;
   s.c = s.has_ctx ? a.num_contexts[b] : 0;
@@ -1005,7 +1005,7 @@ static void launch_bwd_q(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
 
 template <int D>
 static int launch_bwd(const BwdAttnArgs& g, int B, int max_seqlen, hipStream_t stream) {
-  dim3 grid((max_seqlen + kBM - 1) / kBM, g.f.H, B);
+  dim3 grid(g.f.H, B, (max_seqlen + kBM - 1) / kBM);   // block rank slowest: see launch_fwd
   if constexpr (D >= 256) {
     static const int var = getenv("MI355_HSTU_VAR") ? atoi(getenv("MI355_HSTU_VAR")) : 1;   // tuning sweeps only; measured best = 1
     if (var & 4) launch_bwd_kv<D, 64, 1, false>(g, grid, stream); else launch_bwd_kv<D, 64, 1, true>(g, grid, stream);
@@ -1035,7 +1035,10 @@ static int launch_fwd(const AttnArgs& a, int B, int max_seqlen, hipStream_t stre
     hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  dim3 grid((max_seqlen + kBM - 1) / kBM, a.H, B);
+  // Dispatch order is x, then y, then z: with the block rank in z, ALL sequences' heaviest (causal: latest) row blocks
+  // are handed out first and the light ones fill in behind them.  With the rank in x (per-sequence order 8,6,4,2 key
+  // tiles at L = 512) the CUs freed first drew heavy blocks again and the slowest CU did 16 tiles where 10 is the mean.
+  dim3 grid(a.H, B, (max_seqlen + kBM - 1) / kBM);
   hipLaunchKernelGGL(hstu_fwd_kernel<D>, grid, dim3(256), smem, stream, a);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
