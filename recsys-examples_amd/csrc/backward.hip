@@ -349,8 +349,10 @@ __device__ __forceinline__ void apply_sink(const OptArgs& o_in, int64_t u, void*
 // row_addr) are issued BEFORE the heavy loads of group i, so each iteration has one wait with everything in
 // flight (vmcnt retires in order: the index loads must be older than the heavy ones).  The first RPR entries of
 // every row ride the pipeline; the few rows with more entries (<= hot threshold) take dependent extra rounds.
-template <int WDT, int GDT, int NCOL, int NB, int RPR, int KIT>
-__device__ __forceinline__ void sgd_rows_pipelined(const BwdArgs& a, const OptArgs& o, int lpr_log2, int64_t nu, int64_t sg) {
+// kSgd: the table row is prefetched with the gradients and updated in registers; otherwise the reduced gradient goes
+// through apply_sink (dense store, Adam, AdaGrad, row-wise AdaGrad), which fetches the row and its state itself.
+template <int WDT, int GDT, int NCOL, int NB, int RPR, int KIT, bool kSgd>
+__device__ __forceinline__ void rows_pipelined(const BwdArgs& a, const OptArgs& o, int lpr_log2, int64_t nu, int64_t sg) {
   const int LPR = 1 << lpr_log2;
   const int c = lane_id() & (LPR - 1);
   constexpr int EB = GDT == kF32 ? 4 : 2;
@@ -361,13 +363,13 @@ __device__ __forceinline__ void sgd_rows_pipelined(const BwdArgs& a, const OptAr
   if (ubase >= nu) return;  // no cross-lane operation below
   int pA[NB + 1];
   int64_t rA[NB];
-  struct Idx { int lo[NB], cnt[NB]; uintptr_t rowp[NB]; int src[NB][RPR]; };
+  struct Idx { int lo[NB], cnt[NB], n[NB]; uintptr_t rowp[NB]; int src[NB][RPR]; };
   auto stageP = [&](int it) {
     const int64_t u0 = ubase + (int64_t)it * NB;
 #pragma unroll
     for (int b = 0; b <= NB; ++b) { int64_t u = u0 + b; u = u < nu ? u : nu; pA[b] = a.ptr[u]; }
 #pragma unroll
-    for (int b = 0; b < NB; ++b) { int64_t u = u0 + b; u = u < nu ? u : nu - 1; rA[b] = a.row_addr[u]; }
+    for (int b = 0; b < NB; ++b) { int64_t u = u0 + b; u = u < nu ? u : nu - 1; rA[b] = (kSgd || a.row_addr) ? a.row_addr[u] : 0; }
   };
   auto entry = [&](int lo, int cnt, int q) {
     int e = lo + (q < cnt ? q : 0);
@@ -381,7 +383,8 @@ __device__ __forceinline__ void sgd_rows_pipelined(const BwdArgs& a, const OptAr
       const bool work = n > 0 && !(hot_on && n > a.hot.khot);
       x.lo[b] = pA[b];
       x.cnt[b] = work ? n : 0;
-      x.rowp[b] = work ? (uintptr_t)rA[b] : 0;
+      x.rowp[b] = (work && o.kind != kOptStore) ? (uintptr_t)rA[b] : 0;
+      x.n[b] = n;
 #pragma unroll
       for (int q = 0; q < RPR; ++q) x.src[b][q] = entry(pA[b], x.cnt[b], q);
     }
@@ -443,9 +446,11 @@ __device__ __forceinline__ void sgd_rows_pipelined(const BwdArgs& a, const OptAr
     for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int k = 0; k < NCOL; ++k) {
-        const int e = 4 * (c + k * LPR);
-        const gptr_t p = (cur.rowp[b] != 0 && e < a.D) ? (gptr_t)(cur.rowp[b] + (uintptr_t)(e * WB)) : zero;
-        ldNg<WDT>(p, true, wrow[b][k]);
+        if constexpr (kSgd) {
+          const int e = 4 * (c + k * LPR);
+          const gptr_t p = (cur.rowp[b] != 0 && e < a.D) ? (gptr_t)(cur.rowp[b] + (uintptr_t)(e * WB)) : zero;
+          ldNg<WDT>(p, true, wrow[b][k]);
+        }
 #pragma unroll
         for (int w = 0; w < 4; ++w) acc[b][k][w] = 0.f;
       }
@@ -460,6 +465,18 @@ __device__ __forceinline__ void sgd_rows_pipelined(const BwdArgs& a, const OptAr
 #pragma unroll
         for (int q = 0; q < RPR; ++q) src[b][q] = entry(cur.lo[b], cur.cnt[b], r + q);
       grads_round(cur, src, r, acc);
+    }
+    if constexpr (!kSgd) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int64_t u = ubase + (int64_t)it * NB + b;
+        // dense store: a row without occurrences is written as zeros; a hot row is written by its tasks
+        const bool empty_row = o.kind == kOptStore && u < nu && cur.n[b] == 0;
+        apply_sink<WDT, GDT, NCOL, true>(o, u < nu ? u : 0, reinterpret_cast<void*>(cur.rowp[b]), a.D, lpr_log2,
+                                         a.round_grad != 0, acc[b], cur.cnt[b] > 0 || empty_row);
+      }
+      cur = nxt;
+      continue;
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -482,7 +499,8 @@ __device__ __forceinline__ void sgd_rows_pipelined(const BwdArgs& a, const OptAr
   }
 }
 
-template <int WDT, int GDT, int NCOL, bool kVec>
+// kSgd: instantiation for SGD on vector rows without per-feature dims (its own register budget: 93 VGPRs)
+template <int WDT, int GDT, int NCOL, bool kVec, bool kSgd>
 __global__ void __launch_bounds__(256) bwd_kernel(BwdArgs a, OptArgs o, int lpr_log2) {
   const int lane = lane_id();
   const int LPR = 1 << lpr_log2, NSUB = 64 >> lpr_log2;
@@ -589,8 +607,11 @@ __global__ void __launch_bounds__(256) bwd_kernel(BwdArgs a, OptArgs o, int lpr_
   if (a.nu_dev) { int64_t m = *a.nu_dev; nu = m < nu ? m : nu; }
   const int64_t sg = ((int64_t)(blockIdx.x - a.hot_blocks) * wpb + (threadIdx.x >> 6)) * NSUB + sub;
   if constexpr (kVec) {
-    if (o.kind == kOptSgd && a.D_offsets == nullptr) {
-      sgd_rows_pipelined<WDT, GDT, NCOL, NB, PIPE_RPR, KIT>(a, o, lpr_log2, nu, sg);
+    if constexpr (kSgd) {
+      rows_pipelined<WDT, GDT, NCOL, NB, PIPE_RPR, KIT, true>(a, o, lpr_log2, nu, sg);
+      return;
+    } else if (a.D_offsets == nullptr) {
+      rows_pipelined<WDT, GDT, NCOL, NB, PIPE_RPR, KIT, false>(a, o, lpr_log2, nu, sg);
       return;
     }
   }
@@ -679,14 +700,18 @@ static int launch_bwd(BwdArgs a, OptArgs o, bool vec, hipStream_t stream) {
   const size_t smem = a.hot.n_tasks ? 4 * (size_t)a.D * sizeof(float) : 0;
   const int nb = ncol <= 1 ? PIPE_NB : (ncol <= 2 ? 2 : 1);
   const int grid = a.hot_blocks + grid_for(a.max_unique, 4 * nsub * nb * kBwdGroupsPerLaneGroup, 1 << 20);
-#define MI355_BWD_LAUNCH(NC, V) hipLaunchKernelGGL((bwd_kernel<WDT, GDT, NC, V>), dim3(grid), dim3(256), smem, stream, a, o, l)
-  if (vec) {
+#define MI355_BWD_LAUNCH(NC, V) hipLaunchKernelGGL((bwd_kernel<WDT, GDT, NC, V, false>), dim3(grid), dim3(256), smem, stream, a, o, l)
+#define MI355_BWD_LAUNCH_SGD(NC) hipLaunchKernelGGL((bwd_kernel<WDT, GDT, NC, true, true>), dim3(grid), dim3(256), smem, stream, a, o, l)
+  if (vec && o.kind == kOptSgd && a.D_offsets == nullptr) {
+    if (ncol <= 1) MI355_BWD_LAUNCH_SGD(1); else if (ncol <= 2) MI355_BWD_LAUNCH_SGD(2); else MI355_BWD_LAUNCH_SGD(4);
+  } else if (vec) {
     if (ncol <= 1) MI355_BWD_LAUNCH(1, true); else if (ncol <= 2) MI355_BWD_LAUNCH(2, true); else MI355_BWD_LAUNCH(4, true);
   } else {
     if (ncol <= 1) MI355_BWD_LAUNCH(1, false); else if (ncol <= 2) MI355_BWD_LAUNCH(2, false);
     else if (ncol <= 4) MI355_BWD_LAUNCH(4, false); else MI355_BWD_LAUNCH(16, false);
   }
 #undef MI355_BWD_LAUNCH
+#undef MI355_BWD_LAUNCH_SGD
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }
