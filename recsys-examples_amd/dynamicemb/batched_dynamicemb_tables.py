@@ -4,12 +4,11 @@ contract and train/eval semantics as the reference module
 batched_dynamicemb_function.py:1042-1300), on top of the sync-free gfx950 pipelines
 (mi355_demb_forward / mi355_demb_backward).
 
-What is implemented: HBM-only storage (the reference's `DynamicEmbStorage` in HBM_DIRECT mode),
-pooling SUM / MEAN / NONE, mixed per-table dims for pooled mode, SGD / Adam / AdaGrad /
-row-wise AdaGrad fused in the backward, score strategies TIMESTAMP / STEP / CUSTOMIZED / LFU,
-train == eval for known keys, zeros for unknown keys in eval, first-touch insert + initialise in train.
-Out of scope this round: cache / hybrid / host tiers, table growth (rehash), admission,
-NO_EVICTION, dump / load.
+What is implemented: HBM / host / hybrid / promoting-cache storage tiers, pooling SUM / MEAN / NONE, mixed per-table
+dims for pooled mode, SGD / Adam / AdaGrad / row-wise AdaGrad fused in the backward, score strategies TIMESTAMP /
+STEP / CUSTOMIZED / LFU, train == eval for known keys, zeros for unknown keys in eval, first-touch insert + initialise
+in train, prefetch(), dump / load / export, frequency admission (`admit_strategy` + `admission_counter`).
+Out of scope this round: table growth (rehash), NO_EVICTION, external storage.
 """
 from __future__ import annotations
 
@@ -32,6 +31,28 @@ _INIT_MODE = {DynamicEmbInitializerMode.UNIFORM: 0, DynamicEmbInitializerMode.NO
               DynamicEmbInitializerMode.TRUNCATED_NORMAL: 2, DynamicEmbInitializerMode.CONSTANT: 3,
               DynamicEmbInitializerMode.DEBUG: 4}
 _OPT_KIND = {"SGD": 1, "EXACT_SGD": 1, "ADAM": 2, "EXACT_ADAGRAD": 3, "EXACT_ROWWISE_ADAGRAD": 4}
+
+
+def init_dense_rows(buffer: torch.Tensor, indices: torch.Tensor, args) -> None:
+    """rows `indices` of the dense `buffer` <- initializer `args` (the reference's BaseDynamicEmbInitializer call on a
+    dense buffer, initializer.py); counter-based generators keyed by the row index"""
+    m = _INIT_MODE[args.mode]
+    if indices.numel() == 0:
+        return
+    if args.mode == DynamicEmbInitializerMode.UNIFORM:
+        p = (args.lower if args.lower is not None else 0.0, args.upper if args.upper is not None else 1.0, 0.0, 0.0)
+    elif args.mode == DynamicEmbInitializerMode.NORMAL:
+        p = (args.mean, args.std_dev, 0.0, 0.0)
+    elif args.mode == DynamicEmbInitializerMode.TRUNCATED_NORMAL:
+        p = (args.mean, args.std_dev, args.lower if args.lower is not None else -2.0, args.upper if args.upper is not None else 2.0)
+    elif args.mode == DynamicEmbInitializerMode.CONSTANT:
+        p = (args.value, 0.0, 0.0, 0.0)
+    else:
+        p = (0.0, 0.0, 0.0, 0.0)
+    eb = buffer.element_size()
+    addr = buffer.data_ptr() + indices.to(torch.int64) * (buffer.stride(0) * eb)
+    ext.init_rows(m, p, 1234, 0.0, indices.to(torch.int64).contiguous(), addr.contiguous(), buffer.dtype, buffer.size(1),
+                  buffer.size(1))
 
 
 class _StepCtx:
@@ -71,8 +92,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         opt0 = table_options[0]
         for o in table_options:
             assert opt0 == o, "All tables must match in grouped keys."
-            if o.external_storage is not None or o.admit_strategy is not None:
-                raise NotImplementedError("external storage / admission are 'next' rows (DESIGN.md)")
+            if o.external_storage is not None:
+                raise NotImplementedError("external storage is a 'next' row (DESIGN.md)")
         self._dynamicemb_options = table_options
         self._table_names = table_names or [f"t{i}" for i in range(len(table_options))]
         self.pooling_mode = pooling_mode
@@ -182,6 +203,21 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             self.table_host = None
             # flat value tables [capacity_t, value_dim_t]
             self.values = _values(self.table.per_table_capacity_, host)
+        # ---- admission (batched_dynamicemb_tables.py:526,624,798-812): one fused counter table for all logical tables
+        self._admit_strategy = opt0.admit_strategy
+        counters = [o.admission_counter for o in table_options]
+        if all(c is None for c in counters):
+            self._admission_counter = None
+        else:
+            assert all(c is not None for c in counters), "All tables must either have or not have an admission counter"
+            from .embedding_admission import MultiTableKVCounter
+
+            self._admission_counter = MultiTableKVCounter(counters, device=self.device_)
+        if self._admit_strategy is not None:
+            if self._admission_counter is None:
+                raise ValueError("admit_strategy needs an admission_counter (KVCounter) per table")
+            if storage_mode != "hbm":
+                raise NotImplementedError("admission with host / hybrid storage")
         self.table_ptrs = torch.tensor([v.data_ptr() for v in self.values], dtype=torch.int64, device=self.device_)
         self.table_value_dims = torch.tensor(self.value_dims, dtype=torch.int64, device=self.device_)
         self.table_emb_dims = torch.tensor(self.dims, dtype=torch.int64, device=self.device_)
@@ -206,8 +242,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
     def optimizer_step(self) -> int:
         return self._iter_num
 
-    def _init_params(self):
-        a = self.initializer_args
+    def _init_params(self, a=None):
+        a = a if a is not None else self.initializer_args
         m = _INIT_MODE[a.mode]
         if a.mode == DynamicEmbInitializerMode.UNIFORM:
             lo = a.lower if a.lower is not None else 0.0
@@ -247,6 +283,10 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             if prefetch_only:
                 raise NotImplementedError("prefetch() with hybrid storage")
             return self._forward_hybrid(indices, offsets, train)
+        if self._admit_strategy is not None and train:
+            if prefetch_only:
+                raise NotImplementedError("prefetch() with an admission strategy")
+            return self._forward_admission(indices, offsets)
         if not prefetch_only and train and self._prefetch_states:
             st = self._prefetch_states.popleft()
             if st.num_keys != indices.numel() or st.num_bags != offsets.numel() - 1:
@@ -423,6 +463,101 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                                           ptr(out), out.stride(0), dt(out), int(al), stream()), "gather_rows")
         if train:
             self._step += 1
+        return out, st
+
+    def _forward_admission(self, indices: torch.Tensor, offsets: torch.Tensor):
+        """Training forward with an admission strategy (_prefetch_hbm_direct_path, batched_dynamicemb_function.py:559-696,
+        + DynamicEmbeddingFunction.forward :1090-1097): keys found in the table are served as usual; the batch frequency
+        of every MISSING unique key is added to the admission counter, keys whose accumulated frequency passes
+        `admit()` are erased from the counter and inserted (first-touch init), the others are NOT stored -- their
+        embedding for this step is produced by the initializer into scratch rows and their gradients are dropped.
+        Orchestrated from Python over the per-op C ABI (the admitted / rejected split is read on the host, as the
+        reference does with its boolean-mask indexing); gather and backward are the launches of the plain path, because
+        they take row ADDRESSES and a scratch row is as good an address as a table row."""
+        from .scored_hashtable import ScoreArg
+
+        n = indices.numel()
+        num_bags = offsets.numel() - 1
+        B = num_bags // self.feature_num
+        pooled = self.pooling_mode != DynamicEmbPoolingMode.NONE
+        dev, T = self.device_, self.num_tables
+        eb = torch.empty((), dtype=self.embedding_dtype).element_size()
+        st = _StepCtx()
+        st.offsets, st.num_keys, st.batch_size, st.num_bags = offsets, n, B, num_bags
+        st.tids = st.slots = None
+        st.pinned, st.event = False, None
+        if pooled:
+            out = torch.empty(B, self.total_D, dtype=self.output_dtype, device=dev)
+            combiner = 0 if self.pooling_mode == DynamicEmbPoolingMode.SUM else 1
+        else:
+            out = torch.empty(n, self.dims[0], dtype=self.output_dtype, device=dev)
+            combiner = -1
+        rng = ext.get_table_range(offsets, self.feature_offsets)
+        ukeys, st.rev, st.uoff, st.csr_cnt, st.csr_rank = ext.segmented_unique_csr(indices, rng, T)
+        nu = int(st.uoff[-1].item())
+        st.row_addr = torch.zeros(max(n, 1), dtype=torch.int64, device=dev)   # what the backward updates: stored rows only
+        fwd_addr = st.row_addr
+        scratch = None
+        if nu > 0:
+            uk = ukeys[:nu].contiguous()
+            tids = ext.expand_table_ids_cuda(st.uoff, nu)
+            fp, fs, ip, isc, need_freq = self._scores(nu)
+            freq = st.csr_cnt[:nu].to(torch.int64)       # occurrences of every unique key in this batch
+            if need_freq:
+                fs = isc = freq
+            find = ScoreArg("score", None if fs is None else fs[:nu], fp)
+            addr = st.row_addr[:nu]
+            _, f0, s0 = self.table.lookup(uk, tids, find)
+            hit = f0.nonzero().squeeze(1)
+            if hit.numel():
+                addr[hit] = ext.row_addresses(s0[hit], tids[hit], self.table_ptrs, self.table_value_dims, eb)
+            miss = (~f0).nonzero().squeeze(1)
+            if miss.numel():
+                km, tm = uk[miss].contiguous(), tids[miss].contiguous()
+                acc = self._admission_counter.add(km, tm, freq[miss].contiguous())
+                admit = self._admit_strategy.admit(km, acc)
+                adm, rej = miss[admit], miss[~admit]
+                if adm.numel():
+                    ka, ta = uk[adm].contiguous(), tids[adm].contiguous()
+                    self._admission_counter.erase(ka, ta)
+                    ins = ScoreArg("score", None if isc is None else isc[:nu][adm].contiguous(), ip)
+                    if hit.numel():   # rows found for THIS batch must not be evicted by this batch's inserts
+                        self.table.increment_counter(s0[hit].contiguous(), tids[hit].contiguous())
+                    idx = self.table.insert(ka, ta, ins)
+                    if hit.numel():
+                        self.table.decrement_counter(s0[hit].contiguous(), tids[hit].contiguous())
+                    ok = (idx >= 0).nonzero().squeeze(1)
+                    if ok.numel():
+                        a_new = ext.row_addresses(idx[ok].contiguous(), ta[ok].contiguous(), self.table_ptrs, self.table_value_dims, eb)
+                        addr[adm[ok]] = a_new
+                        mode, p = self._init_params()
+                        ext.init_rows(mode, p, self._seed, self.initial_accumulator_value, ka[ok].contiguous(), a_new,
+                                      self.embedding_dtype, self.max_D, max(self.value_dims), table_ids=ta[ok].contiguous(),
+                                      table_emb_dims=self.table_emb_dims, table_value_dims=self.table_value_dims)
+                    bad = adm[(idx < 0).nonzero().squeeze(1)]
+                    if bad.numel():       # admitted but the table refused them (bucket full of pinned rows): served like
+                        rej = torch.cat([rej, bad])   # a rejected key for this step
+                if rej.numel():
+                    # scratch rows: embedding from the strategy's initializer (None: the table's), not stored, no update
+                    vmax = max(self.value_dims)
+                    scratch = torch.empty(rej.numel(), vmax, dtype=self.embedding_dtype, device=dev)
+                    a_rej = scratch.data_ptr() + torch.arange(rej.numel(), dtype=torch.int64, device=dev) * (vmax * eb)
+                    mode, p = self._init_params(getattr(self._admit_strategy, "initializer_args", None))
+                    ext.init_rows(mode, p, self._seed, self.initial_accumulator_value, uk[rej].contiguous(), a_rej,
+                                  self.embedding_dtype, self.max_D, vmax, table_ids=tids[rej].contiguous(),
+                                  table_emb_dims=self.table_emb_dims, table_value_dims=self.table_value_dims)
+                    fwd_addr = st.row_addr.clone()
+                    fwd_addr[rej] = a_rej
+        al = all(d % 4 == 0 for d in self.dims) and all(v % 4 == 0 for v in self.value_dims)
+        if pooled:
+            check(lib().mi355_gather_pooled(None, 0, ptr(fwd_addr), dt(self.embedding_dtype), ptr(st.rev), n, ptr(offsets),
+                                            num_bags, B, combiner, self.max_D, ptr(self.D_offsets_t), self.total_D, ptr(out),
+                                            dt(out), int(al), stream()), "gather_pooled")
+        elif n:
+            check(lib().mi355_gather_rows(None, 0, ptr(fwd_addr), dt(self.embedding_dtype), ptr(st.rev), n, None, self.max_D,
+                                          ptr(out), out.stride(0), dt(out), int(al), stream()), "gather_rows")
+        del scratch   # stream-ordered: the gather above is already queued
+        self._step += 1
         return out, st
 
     # ---------------------------------------------------------------------------------- prefetch

@@ -561,3 +561,91 @@ def test_c1_matches_torch_embedding_bag():
     touched = torch.unique(keys)
     _, rows1 = m.lookup_rows(touched.cuda(), 0)
     torch.testing.assert_close(rows1.cpu(), (weight - lr * w_cpu.grad)[touched], rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ admission
+@pytest.mark.parametrize("threshold", [1, 3, 5])
+@pytest.mark.parametrize("pooling", ["SUM", "NONE"])
+def test_frequency_admission_against_dict_twin(threshold, pooling):
+    """FrequencyAdmissionStrategy + KVCounter (reference test/unit_tests/test_embedding_admission.py: only keys whose
+    accumulated frequency reached the threshold are stored).  Stronger than the reference's set invariant: a dict twin
+    replays the admission rule step by step (batch frequency of every MISSING unique key is added to its counter; it is
+    admitted -- and leaves the counter -- when the sum reaches the threshold; a rejected key is served a constant 0
+    row and gets no update), so the stored key set, the counter population, every pooled output and every row after
+    SGD must match."""
+    (B2, IA, IM, PM, SS, TO, OT) = _mods()
+    from dynamicemb.embedding_admission import FrequencyAdmissionStrategy, KVCounter
+
+    D, F, B, steps, lr = 8, 2, 16, 6, 0.5
+    strategy = FrequencyAdmissionStrategy(threshold=threshold, initializer_args=IA(mode=IM.CONSTANT, value=0.0))
+    opts = [TO(dim=D, max_capacity=4096, index_type=torch.int64, embedding_dtype=torch.float32,
+               initializer_args=IA(mode=IM.CONSTANT, value=0.25), score_strategy=SS.TIMESTAMP,
+               admit_strategy=strategy, admission_counter=KVCounter(capacity=4096, bucket_capacity=128))]
+    m = B2(table_options=opts, table_names=["t0"], feature_table_map=[0, 0], pooling_mode=getattr(PM, pooling),
+           optimizer=OT.SGD, learning_rate=lr, output_dtype=torch.float32, device=torch.device(DEV))
+    m.train()
+    rng = np.random.default_rng(threshold * 7 + len(pooling))
+    rows, counter = {}, {}
+    for step in range(steps):
+        lens = rng.integers(0, 4, F * B)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        keys = rng.integers(0, 40, int(off[-1])).astype(np.int64)
+        # ---- twin: admission on the unique keys of the batch
+        uniq, cnt = np.unique(keys, return_counts=True)
+        served = {}
+        for k, c in zip(uniq.tolist(), cnt.tolist()):
+            if k in rows:
+                served[k] = True
+                continue
+            counter[k] = counter.get(k, 0) + c
+            if counter[k] >= threshold:
+                del counter[k]
+                rows[k] = np.full(D, 0.25, np.float32)
+                served[k] = True
+            else:
+                served[k] = False
+        vec = lambda k: rows[k] if served[k] else np.zeros(D, np.float32)
+        if pooling == "SUM":
+            exp = np.zeros((B, F * D), np.float32)
+            for f in range(F):
+                for b in range(B):
+                    for j in range(off[f * B + b], off[f * B + b + 1]):
+                        exp[b, f * D:(f + 1) * D] += vec(int(keys[j]))
+        else:
+            exp = np.stack([vec(int(k)) for k in keys]) if keys.size else np.zeros((0, D), np.float32)
+        out = m(torch.from_numpy(keys).to(DEV), torch.from_numpy(off).to(DEV))
+        np.testing.assert_allclose(out.detach().cpu().numpy(), exp, rtol=1e-5, atol=1e-6)
+        g = rng.standard_normal(exp.shape).astype(np.float32)
+        out.backward(torch.from_numpy(g).to(DEV))
+        # ---- twin: SGD on the stored rows only (the gradient of a rejected key is dropped)
+        acc = {}
+        if pooling == "SUM":
+            for f in range(F):
+                for b in range(B):
+                    for j in range(off[f * B + b], off[f * B + b + 1]):
+                        k = int(keys[j])
+                        acc[k] = acc.get(k, 0) + g[b, f * D:(f + 1) * D]
+        else:
+            for j, k in enumerate(keys.tolist()):
+                acc[k] = acc.get(k, 0) + g[j]
+        for k, gk in acc.items():
+            if served[k]:
+                rows[k] = rows[k] - lr * gk
+    got_k, got_v = m.export_keys_values("t0", torch.device("cpu"))
+    got = {int(k): v.numpy() for k, v in zip(got_k, got_v)}
+    assert set(got) == set(rows)
+    for k, v in rows.items():
+        np.testing.assert_allclose(got[k], v, rtol=1e-4, atol=1e-5)
+    assert int(m._admission_counter.size()) == len(counter)
+
+
+def test_admission_options_are_validated():
+    (B2, IA, IM, PM, SS, TO, OT) = _mods()
+    from dynamicemb.embedding_admission import FrequencyAdmissionStrategy
+
+    with pytest.raises(ValueError):
+        FrequencyAdmissionStrategy(threshold=-1)
+    opts = [TO(dim=8, max_capacity=256, index_type=torch.int64, embedding_dtype=torch.float32,
+               admit_strategy=FrequencyAdmissionStrategy(threshold=2))]
+    with pytest.raises(ValueError):   # a strategy needs its counter
+        B2(table_options=opts, pooling_mode=PM.SUM, device=torch.device(DEV))
