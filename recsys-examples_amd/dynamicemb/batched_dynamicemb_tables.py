@@ -666,8 +666,9 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             return dist.get_rank(group=pg), dist.get_world_size(group=pg)
         return 0, 1
 
-    def _export_table(self, table_id: int, batch: int = 1 << 16):
-        """yields (keys i64[n], rows [n, value_dim], scores i64[n]) of one logical table over all storage tiers"""
+    def _export_table(self, table_id: int, batch: int = 1 << 16, threshold: Optional[int] = None):
+        """yields (keys i64[n], rows [n, value_dim], scores i64[n]) of one logical table over all storage tiers;
+        `threshold`: only slots whose score is >= threshold (table_export_batch's filter, export_batch.cu:88-124)"""
         for tb, vals in self._tiers():
             C = tb.bucket_capacity_
             b0, b1 = int(tb.table_bucket_offsets_cpu_[table_id]), int(tb.table_bucket_offsets_cpu_[table_id + 1])
@@ -675,13 +676,70 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             v = vals[table_id]
             for off in range(lo, hi, batch):
                 n = min(batch, hi - off)
-                cnt, keys, scores, idx = ext.table_export_batch(tb.table_storage_, C, n, off, torch.int64, None, lo,
+                cnt, keys, scores, idx = ext.table_export_batch(tb.table_storage_, C, n, off, torch.int64, threshold, lo,
                                                                 tb.num_scores_, 0)
                 c = int(cnt.item())
                 if c == 0:
                     continue
                 rows = v[idx[:c].to(v.device)].to(self.device_)
                 yield keys[:c], rows, scores[:c]
+
+    # ---- incremental dump (batched_dynamicemb_tables.py:1166-1180,1432-1482; key_value_table.py:1977-2036) ----------
+    def get_score(self):
+        """{table: current score}: the device timestamp for TIMESTAMP-scored tables (the reference value to pass to
+        incremental_dump later), the stored step / custom score otherwise."""
+        s = self._score_strategy
+        if s == DynamicEmbScoreStrategy.TIMESTAMP or (isinstance(s, tuple) and DynamicEmbScoreStrategy.TIMESTAMP in s):
+            now = int(ext.device_timestamp())
+            return {n: now for n in self._table_names}
+        val = self._step if s == DynamicEmbScoreStrategy.STEP else self._custom_score
+        return {n: int(val) for n in self._table_names}
+
+    def incremental_dump(self, named_thresholds=None, pg=None):
+        """-> ({table: (keys i64[n], embeddings [n, dim])}, {table: score now}) with the rows whose score is >= the
+        table's threshold: for TIMESTAMP tables the rows touched since `get_score()` returned that threshold, otherwise
+        an absolute score cut.  Tensors are on the CPU for one rank; with a process group of more than one rank every
+        rank gets the concatenation of all ranks' rows (on the device), as the reference's all-gather does."""
+        import warnings
+
+        import torch.distributed as dist
+
+        ret, scores = {}, {}
+        now = self.get_score()
+        rank, world = self._rank_world(pg)
+        multi = pg is not None and world > 1
+        for name, thr in (named_thresholds or {}).items():
+            if name not in self._table_names:
+                warnings.warn(f"incremental_dump: table_name '{name}' is not in this module (available: "
+                              f"{self._table_names}); skipping.", UserWarning, stacklevel=2)
+                continue
+            t = self._table_names.index(name)
+            ks, vs = [], []
+            for keys, rows, _ in self._export_table(t, threshold=int(thr)):
+                ks.append(keys)
+                vs.append(rows[:, : self.dims[t]].to(self.embedding_dtype))
+            k = torch.cat(ks) if ks else torch.empty(0, dtype=torch.int64, device=self.device_)
+            v = torch.cat(vs) if vs else torch.empty(0, self.dims[t], dtype=self.embedding_dtype, device=self.device_)
+            if multi:
+                cnt = torch.tensor([k.numel()], dtype=torch.int64, device=self.device_)
+                cnts = [torch.zeros_like(cnt) for _ in range(world)]
+                dist.all_gather(cnts, cnt, group=pg)
+                sizes = [int(c.item()) for c in cnts]
+                m = max(max(sizes), 1)
+                kp = torch.zeros(m, dtype=torch.int64, device=self.device_)
+                vp = torch.zeros(m, self.dims[t], dtype=v.dtype, device=self.device_)
+                kp[: k.numel()], vp[: k.numel()] = k, v
+                kg = [torch.empty_like(kp) for _ in range(world)]
+                vg = [torch.empty_like(vp) for _ in range(world)]
+                dist.all_gather(kg, kp, group=pg)
+                dist.all_gather(vg, vp, group=pg)
+                k = torch.cat([a[:n] for a, n in zip(kg, sizes)])
+                v = torch.cat([a[:n] for a, n in zip(vg, sizes)])
+            else:
+                k, v = k.cpu(), v.cpu()
+            ret[name] = (k, v)
+            scores[name] = now[name]
+        return ret, scores
 
     def dump(self, save_dir: str, optim: bool = False, counter: bool = False, table_names: Optional[List[str]] = None,
              pg=None) -> None:

@@ -649,3 +649,41 @@ def test_admission_options_are_validated():
                admit_strategy=FrequencyAdmissionStrategy(threshold=2))]
     with pytest.raises(ValueError):   # a strategy needs its counter
         B2(table_options=opts, pooling_mode=PM.SUM, device=torch.device(DEV))
+
+
+@pytest.mark.parametrize("strategy", ["TIMESTAMP", "STEP"])
+def test_incremental_dump_returns_rows_touched_since_the_threshold(strategy):
+    """get_score() / incremental_dump() (reference batched_dynamicemb_tables.py:1166-1180,1432-1482): after a first
+    batch, take the current score; only the keys touched by LATER batches (score >= threshold) come back, with their
+    current rows; an unknown table name is skipped with a warning."""
+    (B2, IA, IM, PM, SS, TO, OT) = _mods()
+    D = 8
+    opts = [TO(dim=D, max_capacity=1024, index_type=torch.int64, embedding_dtype=torch.float32,
+               initializer_args=IA(mode=IM.UNIFORM, lower=-1.0, upper=1.0), score_strategy=getattr(SS, strategy))]
+    m = B2(table_options=opts, table_names=["t0"], feature_table_map=[0], pooling_mode=PM.NONE, optimizer=OT.SGD,
+           learning_rate=0.1, output_dtype=torch.float32, device=torch.device(DEV))
+    m.train()
+
+    def step(keys):
+        k = torch.tensor(keys, dtype=torch.int64, device=DEV)
+        off = torch.arange(len(keys) + 1, dtype=torch.int64, device=DEV)
+        out = m(k, off)
+        out.sum().backward()
+
+    step([1, 2, 3, 4, 5])
+    torch.cuda.synchronize()
+    thr = m.get_score()["t0"] if strategy == "TIMESTAMP" else m.get_score()["t0"]
+    step([4, 5, 6, 7])
+    step([7, 8])
+    with pytest.warns(UserWarning):
+        got, now = m.incremental_dump({"t0": thr, "nope": 0})
+    keys, vals = got["t0"]
+    assert set(keys.tolist()) == {4, 5, 6, 7, 8} and "nope" not in got
+    assert now["t0"] >= thr
+    all_k, all_v = m.export_keys_values("t0", torch.device("cpu"))
+    ref = {int(k): v for k, v in zip(all_k, all_v)}
+    for k, v in zip(keys.tolist(), vals):
+        torch.testing.assert_close(v.float(), ref[k])
+    # threshold 0 returns everything
+    everything, _ = m.incremental_dump({"t0": 0})
+    assert set(everything["t0"][0].tolist()) == {1, 2, 3, 4, 5, 6, 7, 8}
