@@ -37,6 +37,14 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;   // first-class 1
 constexpr int kBM = 128;  // query rows per workgroup (32 per wave)
 constexpr int kBN = 64;   // keys per tile
 
+#ifndef HSTU_QLDS_MIN
+#define HSTU_QLDS_MIN 512   // head dims from which the forward keeps its Q fragments in LDS instead of registers (none)
+#endif
+#ifndef HSTU_DB_MIN
+#define HSTU_DB_MIN 1024    // head dims from which the forward double-buffers its K / V tiles in LDS (one barrier per tile).
+                            // OFF: measured slower at d = 256 (L = 4096: 512 vs 586 TFLOP/s single-buffered, same at L = 512)
+#endif
+
 struct AttnArgs {
   const uint16_t* q; const uint16_t* k; const uint16_t* v;
   uint16_t* out;
@@ -149,10 +157,14 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
   constexpr int KS = D + 8;    // padded K row (elements)
   constexpr int VS = kBN + 8;  // padded V^T row (elements)
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-  uint16_t* Ks = smem;                 // [kBN][KS]
+  constexpr int TILE = kBN * KS + D * VS;   // elements of one staged (K, V^T) tile pair
+  // Optional (HSTU_DB_MIN, off by default): the tile pair DOUBLE-BUFFERED in LDS -- tile n+1 is committed into the other
+  // buffer inside the barrier interval in which tile n is consumed, one barrier per key tile instead of two.
+  constexpr bool kDB = D >= HSTU_DB_MIN;
+  uint16_t* Ks = smem;                 // [kBN][KS]           (of the tile being consumed)
   uint16_t* Vt = smem + kBN * KS;      // [D][VS], key positions permuted inside every 16-group
-  constexpr bool QLDS = D >= 256;      // large head dim: Q fragments live in LDS to free 64 VGPRs for prefetching
-  uint16_t* Qs = Vt + D * VS;          // [kBM][KS] (QLDS only)
+  constexpr bool QLDS = D >= HSTU_QLDS_MIN;      // Q fragments in LDS instead of 64 VGPRs (not used: 452 registers fit at d = 256)
+  uint16_t* Qs = smem + (kDB ? 2 : 1) * TILE;    // [kBM][KS] (QLDS only)
 
   const int b = blockIdx.y, h = blockIdx.x;   // grid (H, B, blocks): see launch_fwd
   SeqInfo s;
@@ -266,12 +278,12 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
       }
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](uint16_t* Kd, uint16_t* Vd) {
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
       const int ch = threadIdx.x + 256 * i;
       const int key = ch / (D / 8), dc = ch % (D / 8);
-      if (KCH % 256 == 0 || ch < KCH) *reinterpret_cast<u32x4_t*>(Ks + key * KS + 8 * dc) = kreg[i];
+      if (KCH % 256 == 0 || ch < KCH) *reinterpret_cast<u32x4_t*>(Kd + key * KS + 8 * dc) = kreg[i];
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
@@ -286,19 +298,37 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
         uint2 o;
         o.x = __builtin_amdgcn_perm(w1[e >> 1], w0[e >> 1], sel);
         o.y = __builtin_amdgcn_perm(w3[e >> 1], w2[e >> 1], sel);
-        *reinterpret_cast<uint2*>(Vt + (8 * dc + e) * VS + 16 * g16 + 4 * pg) = o;
+        *reinterpret_cast<uint2*>(Vd + (8 * dc + e) * VS + 16 * g16 + 4 * pg) = o;
       }
     }
   };
 
-  if (n_end > 0) fetch(0);
-  for (int n0 = 0; n0 < n_end; n0 += kBN) {
+  if (n_end > 0) {
+    fetch(0);
+    if constexpr (kDB) {
+      commit(smem, smem + kBN * KS);
+      if (kBN < n_end) fetch(kBN);
+    }
+  }
+  int it = 0;
+  for (int n0 = 0; n0 < n_end; n0 += kBN, ++it) {
     pin_agpr(acc_o);
-    __syncthreads();
-    commit();
-    pin_agpr(acc_o);
-    __syncthreads();
-    if (n0 + kBN < n_end) fetch(n0 + kBN);
+    __syncthreads();   // kDB: everyone is done with the other buffer, and this tile's commit (previous interval) is visible
+    if constexpr (kDB) {
+      uint16_t* cur = smem + (it & 1) * TILE;
+      uint16_t* oth = smem + ((it & 1) ^ 1) * TILE;
+      Ks = cur;
+      Vt = cur + kBN * KS;
+      if (n0 + kBN < n_end) {
+        commit(oth, oth + kBN * KS);                     // tile n0 + kBN (in registers since the previous interval)
+        if (n0 + 2 * kBN < n_end) fetch(n0 + 2 * kBN);
+      }
+    } else {
+      commit(Ks, Vt);
+      pin_agpr(acc_o);
+      __syncthreads();
+      if (n0 + kBN < n_end) fetch(n0 + kBN);
+    }
     pin_agpr(acc_o);
     if (!wave_live || n0 >= w_end) continue;
 
@@ -1029,7 +1059,7 @@ static int launch_bwd(const BwdAttnArgs& g, int B, int max_seqlen, hipStream_t s
 
 template <int D>
 static int launch_fwd(const AttnArgs& a, int B, int max_seqlen, hipStream_t stream) {
-  const size_t smem = (size_t)(kBN * (D + 8) + D * (kBN + 8) + (D >= 256 ? kBM * (D + 8) : 0)) * sizeof(uint16_t);
+  const size_t smem = (size_t)((D >= HSTU_DB_MIN ? 2 : 1) * (kBN * (D + 8) + D * (kBN + 8)) + (D >= HSTU_QLDS_MIN ? kBM * (D + 8) : 0)) * sizeof(uint16_t);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

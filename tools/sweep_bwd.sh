@@ -1,3 +1,6 @@
-# times every library variant under recsys-examples_amd/lib/var on the C2 dedup
+# A/B of attention kernel variants under recsys-examples_amd/lib/var (MI355_LIB) against the default build
 R=$GRAFT_REPO_ROOT
-for f in $R/recsys-examples_amd/lib/var/*.so; do MI355_LIB=$f timeout 120 python $R/tools/bench_uniq_c2.py 15 2>&1 | grep -E "segmented|rror" | tail -2; done
+for L in 512 4096; do
+  echo -n "default L=$L: "; python $R/tools/bench_hstu.py --seqlen $L --reps 10 2>&1 | grep fwd
+  for f in $R/recsys-examples_amd/lib/var/*.so; do echo -n "$(basename $f) L=$L: "; MI355_LIB=$f python $R/tools/bench_hstu.py --seqlen $L --reps 10 2>&1 | grep fwd; done
+done
