@@ -32,4 +32,12 @@ int mi355i_table_insert(void* storage, const int64_t* table_bucket_offsets, int6
                         const int64_t* table_ids, const void* score_in, int policy, uint64_t timer_override,
                         const uint8_t* skip, int64_t* indices, uint8_t* results, const int64_t* table_ptrs,
                         const int64_t* table_value_dims, int elem_bytes, int64_t* row_addr_out, hipStream_t stream);
+
+// the unlock pass of mi355i_table_insert (row_addr_out == NULL there: insert only) fused with mi355_init_rows
+int mi355i_unlock_init_rows(void* storage, const int64_t* table_bucket_offsets, int64_t C, int64_t num_scores,
+                            const int64_t* indices, const int64_t* table_ptrs, int elem_bytes, int64_t* row_addr_out, int mode,
+                            float p0, float p1, float p2, float p3, uint64_t seed, float state_init, int64_t n,
+                            const int64_t* n_dev, const void* keys, int dtype, int64_t emb_dim, int64_t value_dim,
+                            const uint8_t* results, const uint8_t* skip, const int64_t* table_ids,
+                            const int64_t* table_emb_dims, const int64_t* table_value_dims, hipStream_t stream);
 }

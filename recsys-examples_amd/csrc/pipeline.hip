@@ -70,14 +70,16 @@ int mi355_demb_forward(
     STEP(mi355i_table_lookup(storage, table_bucket_offsets, bucket_capacity, num_scores, num_keys, nu_dev, unique_keys,
                             table_ids, find_scores, find_policy, timer_override, nullptr, founds, slots, stream));
     if (train) {
-      // insert + unlock; the unlock pass also writes the row address of every unique key
+      // insert (slots stay locked); then ONE launch publishes the keys (unlock), writes the row address of every unique
+      // key and initialises the rows that are new
       STEP(mi355i_table_insert(storage, table_bucket_offsets, bucket_capacity, num_scores, bucket_sizes, counter,
                                num_keys, nu_dev, unique_keys, table_ids, insert_scores, insert_policy, timer_override,
-                               founds, slots, results, table_ptrs, table_value_dims, value_dtype == 0 ? 4 : 2, row_addr,
+                               founds, slots, results, table_ptrs, table_value_dims, value_dtype == 0 ? 4 : 2, nullptr,
                                stream));
-      STEP(mi355_init_rows(init_mode, p0, p1, p2, p3, seed, state_init, num_keys, nu_dev, unique_keys, nullptr,
-                           row_addr, nullptr, 0, value_dtype, emb_dim, value_dim, results, founds, table_ids, table_emb_dims,
-                           table_value_dims, stream));
+      STEP(mi355i_unlock_init_rows(storage, table_bucket_offsets, bucket_capacity, num_scores, slots, table_ptrs,
+                                   value_dtype == 0 ? 4 : 2, row_addr, init_mode, p0, p1, p2, p3, seed, state_init, num_keys,
+                                   nu_dev, unique_keys, value_dtype, emb_dim, value_dim, results, founds, table_ids,
+                                   table_emb_dims, table_value_dims, stream));
       if (pin)
         STEP(mi355_table_update_counter(counter, counter_numel, slots, num_keys, nu_dev, 1, table_ids,
                                         table_bucket_offsets, bucket_capacity, stream));

@@ -633,6 +633,7 @@ int mi355i_table_insert(void* storage, const int64_t* table_bucket_offsets, int6
                      policy, timer_override, skip, indices, results, (int64_t*)nullptr, (unsigned long long*)nullptr,
                      (uint64_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr);
   MI355_LAUNCH_CHECK();
+  if (!row_addr_out) return MI355_OK;   // the caller runs the unlock pass itself (mi355i_unlock_init_rows)
   hipLaunchKernelGGL(table_unlock_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, t, table_bucket_offsets, n, n_dev,
                      (const uint64_t*)keys, table_ids, skip, indices, table_ptrs, table_value_dims, elem_bytes, row_addr_out);
   MI355_LAUNCH_CHECK();

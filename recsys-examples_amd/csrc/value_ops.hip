@@ -19,6 +19,7 @@
 //    xor-shuffles; fp32 accumulation, one rounding at the store.
 //  * HBM-bound: no LDS, no MFMA.  Occupancy (small VGPR count) supplies the latency hiding.
 #include "common.h"
+#include "internal.h"
 #include <stdlib.h>
 
 namespace mi355 {
@@ -441,13 +442,26 @@ __device__ __forceinline__ float init_value(const InitArgs& a, uint64_t key, uin
 
 // rows[i] (by address or dense) <- initializer(key_i); only where mask[i] != 0 (mask nullable) and,
 // when `results` is given, where the insert result says the slot is NEW (Insert/Reclaim/Evict).
+// Optional first half of the kernel (fused forward): the unlock pass of the hash-table insert (table.hip
+// table_unlock_kernel, kernels.cuh:569-585) -- publish the real key into every slot the insert took and write the row
+// address of EVERY key -- so that unlock and first-touch initialisation are one launch.  storage == nullptr: off.
+struct UnlockArgs {
+  uint8_t* storage;               // hash-table arena
+  const int64_t* tbo;             // table bucket offsets
+  int64_t C, stride;              // slots per bucket, bytes per bucket
+  const int64_t* indices;         // slot of every key (-1: none)
+  const int64_t* table_ptrs;      // value-table base addresses
+  int elem_bytes;
+  int64_t* row_addr_out;          // [n]
+};
+
 template <int DT>
 __global__ void __launch_bounds__(256)
 init_rows_kernel(InitArgs a, int64_t n, const int64_t* __restrict__ n_dev, const uint64_t* __restrict__ keys,
                  const int64_t* __restrict__ sel, const int64_t* __restrict__ row_addr, void* dense, int64_t dense_stride,
                  int emb_dim, int value_dim, const uint8_t* __restrict__ results, const uint8_t* __restrict__ skip,
                  const int64_t* __restrict__ table_ids, const int64_t* __restrict__ table_emb_dims,
-                 const int64_t* __restrict__ table_value_dims) {
+                 const int64_t* __restrict__ table_value_dims, UnlockArgs u) {
   if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
   const int lane = lane_id();
   const int64_t wpb = blockDim.x >> 6;
@@ -458,9 +472,22 @@ init_rows_kernel(InitArgs a, int64_t n, const int64_t* __restrict__ n_dev, const
     const int64_t q = q0 + lane;
     bool need = q < n;
     int64_t i = 0;
+    int64_t my_addr = 0;   // unlock mode: the row address of my key, handed to the wave by shuffle below
     if (need) {
       i = sel ? sel[q] : q;
-      if (skip && skip[i]) need = false;
+      const bool skipped = skip && skip[i];
+      if (u.storage) {
+        const int64_t idx = u.indices[i];
+        const int64_t tid = table_ids ? table_ids[i] : 0;
+        my_addr = idx < 0 ? 0 : u.table_ptrs[tid] + idx * table_value_dims[tid] * u.elem_bytes;
+        u.row_addr_out[i] = my_addr;
+        if (!skipped && idx >= 0) {
+          const int64_t b = u.tbo[tid] + idx / u.C;
+          __hip_atomic_store(reinterpret_cast<uint64_t*>(u.storage + b * u.stride) + idx % u.C, keys[i], __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (skipped) need = false;
       if (need && results) { uint8_t r = results[i]; need = (r == 0 || r == 1 || r == 3); }
     }
     uint64_t todo = __ballot(need);
@@ -469,8 +496,14 @@ init_rows_kernel(InitArgs a, int64_t n, const int64_t* __restrict__ n_dev, const
       todo &= todo - 1;
       const uint32_t ilo = __shfl((int)(uint32_t)i, src, 64), ihi = __shfl((int)(uint32_t)((uint64_t)i >> 32), src, 64);
       const int64_t ii = (int64_t)(((uint64_t)ihi << 32) | ilo);
-      void* rp = row_addr ? reinterpret_cast<void*>(row_addr[ii])
-                          : (void*)(reinterpret_cast<typename Elem<DT>::T*>(dense) + ii * dense_stride);
+      void* rp;
+      if (u.storage) {
+        const uint32_t alo = __shfl((int)(uint32_t)my_addr, src, 64), ahi = __shfl((int)(uint32_t)((uint64_t)my_addr >> 32), src, 64);
+        rp = reinterpret_cast<void*>((uintptr_t)(((uint64_t)ahi << 32) | alo));
+      } else {
+        rp = row_addr ? reinterpret_cast<void*>(row_addr[ii])
+                      : (void*)(reinterpret_cast<typename Elem<DT>::T*>(dense) + ii * dense_stride);
+      }
       if (!rp) continue;
       const uint64_t key = keys[ii];
       int ed = emb_dim, vd = value_dim;
@@ -672,7 +705,29 @@ int mi355_init_rows(int mode, float p0, float p1, float p2, float p3, uint64_t s
   return MI355_DISPATCH_DTYPE(dtype, DT, [&] {
     hipLaunchKernelGGL((init_rows_kernel<DT>), dim3(grid), dim3(256), 0, stream, a, n, n_dev, (const uint64_t*)keys, sel, row_addr,
                        dense, dense_stride, (int)emb_dim, (int)value_dim, results, skip, table_ids, table_emb_dims,
-                       table_value_dims);
+                       table_value_dims, UnlockArgs{});
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+  });
+}
+
+// unlock pass of mi355_table_insert + row addresses of all keys + first-touch initialisation of the new rows: one launch
+int mi355i_unlock_init_rows(void* storage, const int64_t* table_bucket_offsets, int64_t C, int64_t num_scores,
+                            const int64_t* indices, const int64_t* table_ptrs, int elem_bytes, int64_t* row_addr_out, int mode,
+                            float p0, float p1, float p2, float p3, uint64_t seed, float state_init, int64_t n,
+                            const int64_t* n_dev, const void* keys, int dtype, int64_t emb_dim, int64_t value_dim,
+                            const uint8_t* results, const uint8_t* skip, const int64_t* table_ids,
+                            const int64_t* table_emb_dims, const int64_t* table_value_dims, hipStream_t stream) {
+  MI355_CHECK_ARG(mode >= 0 && mode <= 4, "bad initializer mode");
+  MI355_CHECK_ARG(storage && indices && table_ptrs && table_value_dims && row_addr_out, "unlock arguments required");
+  if (n == 0) return MI355_OK;
+  InitArgs a{mode, p0, p1, p2, p3, seed, state_init};
+  UnlockArgs u{(uint8_t*)storage, table_bucket_offsets, C, (9 + 8 * num_scores) * C, indices, table_ptrs, elem_bytes, row_addr_out};
+  const int grid = grid_for(n, 4 * 64, 1 << 20);
+  return MI355_DISPATCH_DTYPE(dtype, DT, [&] {
+    hipLaunchKernelGGL((init_rows_kernel<DT>), dim3(grid), dim3(256), 0, stream, a, n, n_dev, (const uint64_t*)keys,
+                       (const int64_t*)nullptr, (const int64_t*)nullptr, (void*)nullptr, (int64_t)0, (int)emb_dim, (int)value_dim,
+                       results, skip, table_ids, table_emb_dims, table_value_dims, u);
     MI355_LAUNCH_CHECK();
     return MI355_OK;
   });
