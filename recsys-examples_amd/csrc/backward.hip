@@ -53,6 +53,7 @@ struct BwdArgs {
   int n_entries;            // number of CSR entries (= num_keys)
   HotList hot;              // hot-row task list built by mi355_group_by_unique (hot.n_tasks == nullptr: none)
   int hot_blocks;           // leading blocks of the launch that serve the hot tasks
+  int wave_blocks;          // blocks after them whose waves serve the one-wave rows (hot.wave_*)
 };
 
 #ifndef PIPE_NB
@@ -595,6 +596,32 @@ __global__ void __launch_bounds__(256) bwd_kernel(BwdArgs a, OptArgs o, int lpr_
     }
     return;
   }
+  // ---------------------------------------------------- one-wave rows (khot < occurrences <= kwave)
+  // The wave's lane groups split the row's entries, reduce_chunk sums them with independent loads, an xor-shuffle
+  // folds the groups and group 0 applies the sink: no LDS, no atomics, four rows per block at a time.
+  if ((int)blockIdx.x < a.hot_blocks + a.wave_blocks) {
+    int nw = *a.hot.n_wave;
+    nw = nw < a.hot.max_hot ? nw : a.hot.max_hot;
+    for (int t = ((int)blockIdx.x - a.hot_blocks) * wpb + (int)(threadIdx.x >> 6); t < nw; t += a.wave_blocks * wpb) {
+      const int u = a.hot.wave_u[t], lo = a.hot.wave_lo[t], cnt = a.hot.wave_cnt[t];
+      const int per = (cnt + NSUB - 1) / NSUB;
+      const int slo = lo + sub * per;
+      int shi = slo + per;
+      shi = shi < lo + cnt ? shi : lo + cnt;
+      float g[NCOL][4];
+      reduce_chunk<GDT, NCOL, kVec, HOT_UNR>(a, slo, shi, per, lpr_log2, g);
+      for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+        for (int k = 0; k < NCOL; ++k)
+#pragma unroll
+          for (int w = 0; w < W; ++w) g[k][w] += __shfl_xor(g[k][w], off, 64);
+      int Drow = a.D;
+      if (a.D_offsets && a.combiner >= 0) { const int f = a.csr_src[lo] / a.B; Drow = a.D_offsets[f + 1] - a.D_offsets[f]; }
+      void* row = o.kind == kOptStore ? nullptr : reinterpret_cast<void*>(a.row_addr[u]);
+      apply_sink<WDT, GDT, NCOL, kVec>(o, u, row, Drow, lpr_log2, a.round_grad != 0, g, sub == 0);
+    }
+    return;
+  }
   // ---------------------------------------------------- regular rows: NB unique rows per lane group
   // Most rows of a batch occur once or twice, so one row per lane group would leave a wave with ~1.5 KB
   // in flight per ~5 us dependent chain (ptr -> CSR entry -> gradient row).  Each lane group therefore
@@ -605,7 +632,7 @@ __global__ void __launch_bounds__(256) bwd_kernel(BwdArgs a, OptArgs o, int lpr_
   constexpr int KIT = kBwdGroupsPerLaneGroup;
   int64_t nu = a.max_unique;
   if (a.nu_dev) { int64_t m = *a.nu_dev; nu = m < nu ? m : nu; }
-  const int64_t sg = ((int64_t)(blockIdx.x - a.hot_blocks) * wpb + (threadIdx.x >> 6)) * NSUB + sub;
+  const int64_t sg = ((int64_t)(blockIdx.x - a.hot_blocks - a.wave_blocks) * wpb + (threadIdx.x >> 6)) * NSUB + sub;
   if constexpr (kVec) {
     if constexpr (kSgd) {
       rows_pipelined<WDT, GDT, NCOL, NB, PIPE_RPR, KIT, true>(a, o, lpr_log2, nu, sg);
@@ -696,10 +723,14 @@ static int launch_bwd(BwdArgs a, OptArgs o, bool vec, hipStream_t stream) {
   const int per = vec ? 4 : 1;
   const int ncol = (a.D + (per << l) - 1) / (per << l);
   const int nsub = 64 >> l;
-  a.hot_blocks = a.hot.n_tasks ? (a.hot.max_tasks < 2048 ? a.hot.max_tasks : 2048) : 0;
+  static const int hot_cap = getenv("MI355_HOT_BLOCKS") ? atoi(getenv("MI355_HOT_BLOCKS")) : 2048;   // tuning knob
+  a.hot_blocks = a.hot.n_tasks ? (a.hot.max_tasks < hot_cap ? a.hot.max_tasks : hot_cap) : 0;
   const size_t smem = a.hot.n_tasks ? 4 * (size_t)a.D * sizeof(float) : 0;
   const int nb = ncol <= 1 ? PIPE_NB : (ncol <= 2 ? 2 : 1);
-  const int grid = a.hot_blocks + grid_for(a.max_unique, 4 * nsub * nb * kBwdGroupsPerLaneGroup, 1 << 20);
+  a.wave_blocks = 0;
+  static const int wave_cap = getenv("MI355_WAVE_BLOCKS") ? atoi(getenv("MI355_WAVE_BLOCKS")) : 1024;   // tuning knob
+  if (a.hot.n_tasks && a.hot.kwave > a.hot.khot) a.wave_blocks = a.hot.max_hot / 4 + 1 < wave_cap ? a.hot.max_hot / 4 + 1 : wave_cap;
+  const int grid = a.hot_blocks + a.wave_blocks + grid_for(a.max_unique, 4 * nsub * nb * kBwdGroupsPerLaneGroup, 1 << 20);
 #define MI355_BWD_LAUNCH(NC, V) hipLaunchKernelGGL((bwd_kernel<WDT, GDT, NC, V, false>), dim3(grid), dim3(256), smem, stream, a, o, l)
 #define MI355_BWD_LAUNCH_SGD(NC) hipLaunchKernelGGL((bwd_kernel<WDT, GDT, NC, true, true>), dim3(grid), dim3(256), smem, stream, a, o, l)
   if (vec && o.kind == kOptSgd && a.D_offsets == nullptr) {

@@ -418,7 +418,7 @@ csr_hist_kernel(const int64_t* __restrict__ rev, int64_t n, int* __restrict__ cn
 __global__ void __launch_bounds__(kScanThreads)
 scan_reduce_kernel(const int* __restrict__ in, int64_t n, const int64_t* __restrict__ n_dev, int* partial, int* c0 = nullptr,
                    int* c1 = nullptr) {
-  if (c0 && blockIdx.x == 0 && threadIdx.x == 0) { *c0 = 0; *c1 = 0; }   // hot-row list counters (used by scan_down)
+  if (c0 && blockIdx.x == 0 && threadIdx.x == 0) { *c0 = 0; *c1 = 0; c0[4] = 0; }   // hot-list counters n_hot, n_tasks, n_wave (hot.h header)
   if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
   const int64_t tile0 = (int64_t)blockIdx.x * kScanTile;
   int c = 0;
@@ -450,32 +450,41 @@ scan_down_kernel(const int* __restrict__ in, int64_t n, const int64_t* __restric
   int ex = block_excl_scan(c, tot) + pre;
   if (kSelf && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { *total = pre + tot; out[n] = pre + tot; }
   // hot rows of this tile: ids and task ranges are reserved with ONE atomic pair per block
-  int nh_local = 0, nt_local = 0;
+  // (rows with khot < count <= kwave go to the one-wave list, longer ones to the chunked block tasks)
+  int nh_local = 0, nt_local = 0, nw_local = 0;
   if (build_hot) {
 #pragma unroll
-    for (int k = 0; k < kScanItems; ++k)
-      if (v[k] > hot.khot) { ++nh_local; nt_local += (v[k] + hot.kchunk - 1) / hot.kchunk; }
+    for (int k = 0; k < kScanItems; ++k) {
+      if (v[k] > hot.khot && v[k] <= hot.kwave) ++nw_local;
+      else if (v[k] > hot.khot) { ++nh_local; nt_local += (v[k] + hot.kchunk - 1) / hot.kchunk; }
+    }
   }
-  __shared__ int s_hbase[2];
-  int h_ex = 0, t_ex = 0;
+  __shared__ int s_hbase[3];
+  int h_ex = 0, t_ex = 0, w_ex = 0;
   if (build_hot) {
-    int th, tt;
+    int th, tt, tw;
     h_ex = block_excl_scan(nh_local, th);
     t_ex = block_excl_scan(nt_local, tt);
+    w_ex = block_excl_scan(nw_local, tw);
     if (threadIdx.x == 0) {
       s_hbase[0] = th ? atomicAdd(hot.n_hot, th) : 0;
       s_hbase[1] = tt ? atomicAdd(hot.n_tasks, tt) : 0;
+      s_hbase[2] = tw ? atomicAdd(hot.n_wave, tw) : 0;
     }
     __syncthreads();
     h_ex += s_hbase[0];
     t_ex += s_hbase[1];
+    w_ex += s_hbase[2];
   }
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
     int64_t i = tile0 + threadIdx.x * kScanItems + k;
     if (i < n) {
       out[i] = ex;
-      if (build_hot && v[k] > hot.khot) {
+      if (build_hot && v[k] > hot.khot && v[k] <= hot.kwave) {
+        const int w = w_ex++;
+        if (w < hot.max_hot) { hot.wave_u[w] = (int)i; hot.wave_lo[w] = ex; hot.wave_cnt[w] = v[k]; }
+      } else if (build_hot && v[k] > hot.khot) {
         const int nch = (v[k] + hot.kchunk - 1) / hot.kchunk;
         const int h = h_ex++, t0 = t_ex;
         t_ex += nch;
