@@ -212,12 +212,18 @@ __global__ void __launch_bounds__(kScanThreads)
 uniq_flag_kernel(int64_t n, UniqWs ws) {
   const int64_t tile0 = (int64_t)blockIdx.x * kScanTile;
   int c = 0;
+  int rp[kScanItems], sl[kScanItems];   // branch-free (clamped) hops: the items' chains overlap
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
     int64_t i = tile0 + threadIdx.x * kScanItems + k;
-    if (i < n) {
-      c += (ws.slots[ws.rep[i]] == (int)i);
-    }
+    rp[k] = ws.rep[i < n ? i : n - 1];
+  }
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) sl[k] = ws.slots[rp[k]];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    int64_t i = tile0 + threadIdx.x * kScanItems + k;
+    c += (i < n) && (sl[k] == (int)i);
   }
   int tot;
   block_excl_scan(c, tot);
@@ -253,10 +259,18 @@ uniq_emit_kernel(const uint64_t* __restrict__ keys, int64_t n, const int64_t* __
   const int64_t tile0 = (int64_t)blockIdx.x * kScanTile;
   int f[kScanItems];
   int c = 0;
+  int rp[kScanItems], sl[kScanItems];   // branch-free (clamped) hops: the items' chains overlap
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
     int64_t i = tile0 + threadIdx.x * kScanItems + k;
-    f[k] = (i < n) && (ws.slots[ws.rep[i]] == (int)i);
+    rp[k] = ws.rep[i < n ? i : n - 1];
+  }
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) sl[k] = ws.slots[rp[k]];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    int64_t i = tile0 + threadIdx.x * kScanItems + k;
+    f[k] = (i < n) && (sl[k] == (int)i);
     c += f[k];
   }
   int tot;
@@ -649,10 +663,24 @@ csr_scatter_kernel(const int64_t* __restrict__ rev, const int* __restrict__ rank
     for (int k = 0; k < 4; ++k) s_bag[threadIdx.x * 4 + k] = v[k] > prev ? v[k] : prev;
     __syncthreads();
   }
+  // branch-free index hops (clamped), all reverse indices first, then all row pointers: the four chains of a thread
+  // overlap instead of running one after the other behind a predicated branch each
+  constexpr int NQ = kHistTile / 256;
+  int64_t r[NQ];
+  int rk[NQ], p[NQ];
 #pragma unroll
-  for (int q = 0; q < kHistTile / 256; ++q) {
+  for (int q = 0; q < NQ; ++q) {
+    int64_t j = tile0 + q * 256 + threadIdx.x;
+    j = j < n ? j : n - 1;
+    r[q] = rev[j];
+    rk[q] = rank[j];
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) p[q] = ptr[r[q]];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
     const int64_t j = tile0 + q * 256 + threadIdx.x;
-    if (j < n) csr_src[ptr[rev[j]] + rank[j]] = offsets ? s_bag[q * 256 + threadIdx.x] : (int)j;
+    if (j < n) csr_src[p[q] + rk[q]] = offsets ? s_bag[q * 256 + threadIdx.x] : (int)j;
   }
 }
 
