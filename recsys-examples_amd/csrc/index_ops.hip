@@ -916,9 +916,13 @@ using namespace mi355;
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 // library-owned scratch for the tile sums of the long int64 scan (grown on demand; one process drives one GPU)
+// Tile sums of the multi-block int64 scan.  One buffer per host thread, grown on demand (hipFree synchronises the
+// device, so a buffer still in use is never released under a running kernel).  Callers on ONE thread must not run the
+// scans of two streams concurrently; the sharded path issues them on a single stream.  Not hipGraph-capturable while
+// it grows -- warm the path up once before capturing.
 static int64_t* scan64_scratch(int64_t words) {
-  static int64_t* p = nullptr;
-  static int64_t cap = 0;
+  static thread_local int64_t* p = nullptr;
+  static thread_local int64_t cap = 0;
   if (words > cap) {
     if (p) (void)hipFree(p);
     cap = words < 8192 ? 8192 : 2 * words;
