@@ -292,10 +292,17 @@ int mi355_demb_forward(void* storage, const int64_t* table_bucket_offsets, int64
                        const int32_t* D_offsets, int64_t total_D, void* out, int out_dtype, int aligned16,
                        int64_t* reverse_indices, int64_t* unique_offsets, int64_t* table_ids, int64_t* slots,
                        int64_t* row_addr, int64_t* freq, int32_t* csr_cnt /* nullable */,
-                       int32_t* csr_rank /* nullable */, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+                       int32_t* csr_rank /* nullable */,
+                       void* backward_workspace /* nullable: early CSR, see mi355_demb_backward(prepared) */,
+                       int64_t backward_workspace_bytes, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+
+/* hipStream_t of the library's side stream (early CSR build of mi355_demb_forward); NULL if it cannot be created */
+void* mi355_early_csr_stream(void);
 
 /* One-call backward: DynamicEmbeddingFunction.backward (batched_dynamicemb_function.py:1193-1300):
- * reduce_grads + optimizer.fused_update_for_flat_table + decrement_counter. */
+ * reduce_grads + optimizer.fused_update_for_flat_table + decrement_counter.  Early CSR: when the forward was given
+ * `backward_workspace`, the key-grouping half of this call already ran on the library's side stream under the forward's
+ * own lookup / gather kernels; pass the same buffer with prepared = 1 and only the reduce + optimizer kernel remains. */
 int64_t mi355_demb_backward_workspace_bytes(int64_t num_keys, int64_t dim);
 int mi355_demb_backward(const int64_t* reverse_indices, int64_t num_keys, const int64_t* unique_offsets,
                         int64_t num_tables, const int64_t* offsets, int64_t num_bags, int64_t batch_size,
@@ -306,6 +313,7 @@ int mi355_demb_backward(const int64_t* reverse_indices, int64_t num_keys, const 
                         int64_t counter_numel, const int64_t* slots, const int64_t* table_ids,
                         const int64_t* table_bucket_offsets, int64_t bucket_capacity, int unpin,
                         const int32_t* csr_cnt, const int32_t* csr_rank /* from the forward, or both NULL */,
+                        int prepared /* workspace == the forward's backward_workspace: grouping already issued */,
                         void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* ---------------------------------------------------------------- HSTU jagged attention ---- */

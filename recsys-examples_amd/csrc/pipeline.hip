@@ -17,6 +17,31 @@ extern "C" {
 // Scratch layout helper: byte offsets of the per-step arrays inside one workspace.
 static inline int64_t al(int64_t x) { return (x + 255) / 256 * 256; }
 
+// Side stream on which the forward builds the backward's CSR while its own lookup / gather kernels run (early CSR,
+// see mi355_demb_forward).  One per host thread (= per GPU process here); events are recorded / waited in call order.
+struct EarlyCsr {
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false;
+};
+static EarlyCsr* early_csr() {
+  static thread_local EarlyCsr e;
+  if (!e.ok) {
+    if (hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    e.ok = true;
+  }
+  return &e;
+}
+
+// the side stream of the early CSR build (a caller whose allocator is stream aware -- torch -- records the backward
+// workspace on it, so that a buffer dropped without a backward is not reused under the running side kernels)
+void* mi355_early_csr_stream(void) {
+  EarlyCsr* e = early_csr();
+  return e ? (void*)e->side : nullptr;
+}
+
 int64_t mi355_demb_forward_workspace_bytes(int64_t num_keys, int64_t num_tables) {
   return al(8 * (num_tables + 1)) /*table_range*/ + al(8 * num_keys) /*unique_keys*/ + al(num_keys) /*founds*/ +
          al(num_keys) /*results*/ + mi355_segmented_unique_workspace_bytes(num_keys) + 256;
@@ -46,6 +71,10 @@ int mi355_demb_forward(
     /* persisted */ int64_t* reverse_indices, int64_t* unique_offsets, int64_t* table_ids, int64_t* slots,
     int64_t* row_addr, int64_t* freq /* nullable: per-unique occurrence counts (LFU scores) */,
     int32_t* csr_cnt, int32_t* csr_rank /* nullable: CSR ingredients for mi355_demb_backward */,
+    /* early CSR (nullable): the workspace the caller will hand to mi355_demb_backward(prepared = 1) for THIS batch; the
+       key-grouping half of the backward then runs on a side stream, forked right after the dedup, under the lookup /
+       gather kernels of this forward.  The buffer must stay alive until that backward has been issued. */
+    void* backward_workspace, int64_t backward_workspace_bytes,
     /* scratch */ void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   MI355_CHECK_ARG(workspace && workspace_bytes >= mi355_demb_forward_workspace_bytes(num_keys, num_tables),
                   "workspace too small");
@@ -64,6 +93,24 @@ int mi355_demb_forward(
   STEP(mi355i_segmented_unique(keys, num_keys, nullptr, num_tables, nullptr, freq ? 1 : 0, unique_keys, reverse_indices,
                                unique_offsets, freq, csr_cnt, csr_rank, offsets, feature_offsets, num_bags, table_range,
                                table_ids, uws, uws_bytes, stream));
+  if (backward_workspace && train && csr_cnt && csr_rank && num_keys > 0 && combiner != -2) {
+    MI355_CHECK_ARG(backward_workspace_bytes >= mi355_demb_backward_workspace_bytes(num_keys, emb_dim), "backward workspace too small");
+    EarlyCsr* e = early_csr();
+    if (!e) { mi355_set_error("side stream / event creation failed"); return MI355_ELAUNCH; }
+    if (hipEventRecord(e->fork, stream) != hipSuccess || hipStreamWaitEvent(e->side, e->fork, 0) != hipSuccess) {
+      mi355_set_error("early CSR fork failed"); return MI355_ELAUNCH;
+    }
+    uint8_t* bw = (uint8_t*)backward_workspace;
+    int32_t* bptr = (int32_t*)bw; bw += al(4 * (num_keys + 1));
+    int32_t* bcsr = (int32_t*)bw; bw += al(4 * num_keys);
+    void* gws = bw;
+    const int64_t gws_bytes = mi355_group_by_unique_workspace_bytes(num_keys, num_keys);
+    bw += gws_bytes;
+    STEP(mi355_group_by_unique_csr(csr_cnt, csr_rank, reverse_indices, num_keys, combiner >= 0 ? offsets : nullptr,
+                                   num_bags, num_keys, nu_dev, bptr, bcsr, gws, gws_bytes, bw,
+                                   mi355_backward_workspace_bytes(num_keys, emb_dim), emb_dim, e->side));
+    if (hipEventRecord(e->join, e->side) != hipSuccess) { mi355_set_error("early CSR join record failed"); return MI355_ELAUNCH; }
+  }
   if (!find_scores) find_scores = freq;      // LFU: scores are the occurrence counts of this batch
   if (!insert_scores) insert_scores = freq;
   if (num_keys > 0) {
@@ -117,6 +164,8 @@ int mi355_demb_backward(
     /* unpin */ int32_t* counter, int64_t counter_numel, const int64_t* slots, const int64_t* table_ids,
     const int64_t* table_bucket_offsets, int64_t bucket_capacity, int unpin,
     /* CSR ingredients persisted by the forward (both or neither) */ const int32_t* csr_cnt, const int32_t* csr_rank,
+    /* prepared != 0: `workspace` is the buffer the forward of this batch received as backward_workspace -- the grouping is
+       already done (or still running on the side stream: joined here) */ int prepared,
     void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   MI355_CHECK_ARG(workspace && workspace_bytes >= mi355_demb_backward_workspace_bytes(num_keys, dim), "workspace too small");
   if (num_keys == 0) return MI355_OK;
@@ -130,7 +179,11 @@ int mi355_demb_backward(
   const int64_t bws_bytes = mi355_backward_workspace_bytes(num_keys, dim);
   const int64_t* nu_dev = unique_offsets + num_tables;
   int rc;
-  if (csr_cnt && csr_rank)
+  if (prepared) {
+    EarlyCsr* e = early_csr();
+    if (!e || hipStreamWaitEvent(stream, e->join, 0) != hipSuccess) { mi355_set_error("early CSR join failed"); return MI355_ELAUNCH; }
+    rc = MI355_OK;
+  } else if (csr_cnt && csr_rank)
     rc = mi355_group_by_unique_csr(csr_cnt, csr_rank, reverse_indices, num_keys, combiner >= 0 ? offsets : nullptr, num_bags,
                                    num_keys, nu_dev, ptr, csr, gws, gws_bytes, bws, bws_bytes, dim, stream);
   else

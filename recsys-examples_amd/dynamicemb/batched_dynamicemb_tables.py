@@ -12,6 +12,7 @@ Out of scope this round: table growth (rehash), NO_EVICTION, externa
 """
 from __future__ import annotations
 
+import os
 from itertools import accumulate
 from typing import List, Optional
 
@@ -59,7 +60,7 @@ class _StepCtx:
     """What one forward leaves for its backward (the reference's PrefetchState + autograd ctx)."""
 
     __slots__ = ("rev", "uoff", "tids", "slots", "row_addr", "offsets", "num_keys", "batch_size", "num_bags", "csr_cnt",
-                 "csr_rank", "pinned", "event", "indices")
+                 "csr_rank", "pinned", "event", "indices", "bwd_ws")
 
 
 class _LookupFunction(torch.autograd.Function):
@@ -227,6 +228,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         self._empty_tensor = nn.Parameter(torch.empty(10, requires_grad=True, device=self.device_,
                                                       dtype=self.embedding_dtype))
         self._pin = False  # ref-counter pinning is only needed when prefetch runs ahead of backward
+        self._early_csr = os.environ.get("MI355_EARLY_CSR", "1") != "0"   # build the backward's CSR under the forward
+        self._side_stream = None
         from collections import deque
 
         self._prefetch_states = deque()
@@ -325,6 +328,17 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         ws = torch.empty(lib().mi355_demb_forward_workspace_bytes(n, T), dtype=torch.uint8, device=dev)
         al = all(d % 4 == 0 for d in self.dims) and all(v % 4 == 0 for v in self.value_dims)
         tb = self.table
+        # early CSR: the backward's key grouping runs on the library's side stream under this forward's lookup / gather
+        # kernels; the buffer travels to the backward in the step context.  Not under stream capture (the side stream
+        # joins in the backward, a forward captured alone would leave it dangling).
+        st.bwd_ws = None
+        if (train and n > 0 and self._early_csr and not prefetch_only and torch.is_grad_enabled()
+                and not torch.cuda.is_current_stream_capturing()):
+            st.bwd_ws = torch.empty(lib().mi355_demb_backward_workspace_bytes(n, self.max_D), dtype=torch.uint8, device=dev)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.ExternalStream(int(lib().mi355_early_csr_stream() or 0), device=dev)
+            # if this step never gets its backward the buffer must not be reused under the side-stream kernels
+            st.bwd_ws.record_stream(self._side_stream)
         check(lib().mi355_demb_forward(
             ptr(tb.table_storage_), ptr(tb.table_bucket_offsets_), tb.bucket_capacity_, tb.num_scores_,
             ptr(tb.bucket_sizes), ptr(tb._ref_counter), tb._ref_counter.numel(),
@@ -335,7 +349,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             mode, c_f(p[0]), c_f(p[1]), c_f(p[2]), c_f(p[3]), c_u64(self._seed), c_f(state_init),
             combiner, ptr(self.D_offsets_t), self.total_D, ptr(out), dt(out) if out is not None else 0, int(al),
             ptr(st.rev), ptr(st.uoff), ptr(st.tids), ptr(st.slots), ptr(st.row_addr), ptr(freq),
-            ptr(st.csr_cnt), ptr(st.csr_rank), ptr(ws), ws.numel(), stream()), "demb_forward")
+            ptr(st.csr_cnt), ptr(st.csr_rank), ptr(st.bwd_ws), st.bwd_ws.numel() if st.bwd_ws is not None else 0,
+            ptr(ws), ws.numel(), stream()), "demb_forward")
         if train:
             self._step += 1
             if self._dynamicemb_options[0].safe_check_mode != DynamicEmbCheckMode.IGNORE:
@@ -613,7 +628,9 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         pooled = self.pooling_mode != DynamicEmbPoolingMode.NONE
         combiner = -1 if not pooled else (0 if self.pooling_mode == DynamicEmbPoolingMode.SUM else 1)
         dim = self.max_D
-        ws = torch.empty(lib().mi355_demb_backward_workspace_bytes(st.num_keys, dim), dtype=torch.uint8, device=grads.device)
+        prepared = getattr(st, "bwd_ws", None) is not None
+        ws = st.bwd_ws if prepared else torch.empty(lib().mi355_demb_backward_workspace_bytes(st.num_keys, dim),
+                                                    dtype=torch.uint8, device=grads.device)
         al = all(d % 4 == 0 for d in self.dims) and all(v % 4 == 0 for v in self.value_dims) and grads.stride(0) % 4 == 0
         tb = self.table
         check(lib().mi355_demb_backward(
@@ -623,7 +640,9 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             c_f(self.eps), c_f(self.weight_decay), self._iter_num, -1, 1, int(al),
             ptr(tb._ref_counter), tb._ref_counter.numel(), ptr(st.slots), ptr(st.tids), ptr(tb.table_bucket_offsets_),
             tb.bucket_capacity_, int(bool(getattr(st, "pinned", False)) and st.slots is not None), ptr(st.csr_cnt),
-            ptr(st.csr_rank), ptr(ws), ws.numel(), stream()), "demb_backward")
+            ptr(st.csr_rank), int(prepared), ptr(ws), ws.numel(), stream()), "demb_backward")
+        if prepared:
+            st.bwd_ws = None   # consumed: a second backward of the same step would have to regroup
 
     def forward(self, indices: torch.Tensor, offsets: torch.Tensor, per_sample_weights=None,
                 feature_requires_grad=None, batch_size_per_feature_per_rank=None, total_unique_indices=None):
