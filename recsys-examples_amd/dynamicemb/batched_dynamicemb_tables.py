@@ -60,7 +60,17 @@ class _StepCtx:
     """What one forward leaves for its backward (the reference's PrefetchState + autograd ctx)."""
 
     __slots__ = ("rev", "uoff", "tids", "slots", "row_addr", "offsets", "num_keys", "batch_size", "num_bags", "csr_cnt",
-                 "csr_rank", "pinned", "event", "indices", "bwd_ws")
+                 "csr_rank", "pinned", "event", "indices", "bwd_ws", "ring")
+
+    def release_ring(self):
+        """hand the early-CSR ring slot back (after the backward, or when the step is dropped without one)"""
+        r = getattr(self, "ring", None)
+        if r is not None:
+            r[0][r[1]] = False
+            self.ring = None
+
+    def __del__(self):
+        self.release_ring()
 
 
 class _LookupFunction(torch.autograd.Function):
@@ -229,7 +239,9 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                                                       dtype=self.embedding_dtype))
         self._pin = False  # ref-counter pinning is only needed when prefetch runs ahead of backward
         self._early_csr = os.environ.get("MI355_EARLY_CSR", "1") != "0"   # build the backward's CSR under the forward
-        self._side_stream = None
+        self._bwd_ring = [None] * 4
+        self._bwd_busy = [False] * 4
+        self._bwd_ring_next = 0
         from collections import deque
 
         self._prefetch_states = deque()
@@ -334,11 +346,20 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         st.bwd_ws = None
         if (train and n > 0 and self._early_csr and not prefetch_only and torch.is_grad_enabled()
                 and not torch.cuda.is_current_stream_capturing()):
-            st.bwd_ws = torch.empty(lib().mi355_demb_backward_workspace_bytes(n, self.max_D), dtype=torch.uint8, device=dev)
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.ExternalStream(int(lib().mi355_early_csr_stream() or 0), device=dev)
-            # if this step never gets its backward the buffer must not be reused under the side-stream kernels
-            st.bwd_ws.record_stream(self._side_stream)
+            # a small ring of module-owned buffers (never handed back to the allocator, so a step that never gets its
+            # backward cannot have its buffer reused under the side-stream kernels; writers are ordered by the side stream)
+            # A slot is busy from its forward until its backward (or until the step context is dropped); when more steps
+            # are outstanding than the ring holds, the extra ones simply group in their backward as before.
+            slot = self._bwd_ring_next % len(self._bwd_ring)
+            if not self._bwd_busy[slot]:
+                self._bwd_ring_next += 1
+                need = lib().mi355_demb_backward_workspace_bytes(n, self.max_D)
+                buf = self._bwd_ring[slot]
+                if buf is None or buf.numel() < need:
+                    buf = self._bwd_ring[slot] = torch.empty(int(need * 1.25), dtype=torch.uint8, device=dev)
+                self._bwd_busy[slot] = True
+                st.ring = (self._bwd_busy, slot)
+                st.bwd_ws = buf
         check(lib().mi355_demb_forward(
             ptr(tb.table_storage_), ptr(tb.table_bucket_offsets_), tb.bucket_capacity_, tb.num_scores_,
             ptr(tb.bucket_sizes), ptr(tb._ref_counter), tb._ref_counter.numel(),
@@ -643,6 +664,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             ptr(st.csr_rank), int(prepared), ptr(ws), ws.numel(), stream()), "demb_backward")
         if prepared:
             st.bwd_ws = None   # consumed: a second backward of the same step would have to regroup
+            st.release_ring()
 
     def forward(self, indices: torch.Tensor, offsets: torch.Tensor, per_sample_weights=None,
                 feature_requires_grad=None, batch_size_per_feature_per_rank=None, total_unique_indices=None):
