@@ -687,3 +687,46 @@ def test_incremental_dump_returns_rows_touched_since_the_threshold(strategy):
     # threshold 0 returns everything
     everything, _ = m.incremental_dump({"t0": 0})
     assert set(everything["t0"][0].tolist()) == {1, 2, 3, 4, 5, 6, 7, 8}
+
+
+# ------------------------------------------------------------------------------------------ early CSR
+@pytest.mark.parametrize("pooling", ["SUM", "NONE"])
+def test_early_csr_matches_late_grouping_and_survives_outstanding_steps(pooling):
+    """The backward's key grouping forked onto the side stream by the forward (early CSR) must give the same table as
+    grouping inside the backward -- also when MORE forwards are outstanding than the workspace ring holds (the extra
+    ones fall back to late grouping), when a forward never gets its backward, and when backwards come in reverse."""
+    (B2, IA, IM, PM, SS, TO, OT) = _mods()
+    D, F, B = 16, 2, 64
+
+    def make(early):
+        opts = [TO(dim=D, max_capacity=4096, index_type=torch.int64, embedding_dtype=torch.float32,
+                   initializer_args=IA(mode=IM.UNIFORM, lower=-0.5, upper=0.5), score_strategy=SS.STEP)]
+        m = B2(table_options=opts, table_names=["t0"], feature_table_map=[0, 0], pooling_mode=getattr(PM, pooling),
+               optimizer=OT.ADAM, learning_rate=0.05, output_dtype=torch.float32, device=torch.device(DEV))
+        m.train()
+        m._early_csr = early
+        return m
+
+    rng = np.random.default_rng(11)
+    batches = []
+    for _ in range(7):
+        lens = rng.integers(0, 6, F * B)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        keys = rng.zipf(1.3, int(off[-1])).astype(np.int64) % 500      # skewed: hot rows take the chunked paths
+        n_out = B if pooling == "SUM" else int(off[-1])
+        g = rng.standard_normal((n_out, F * D if pooling == "SUM" else D)).astype(np.float32)
+        batches.append((torch.from_numpy(keys).to(DEV), torch.from_numpy(off).to(DEV), torch.from_numpy(g).to(DEV)))
+    tables = []
+    for early in (True, False):
+        m = make(early)
+        outs = [m(k, o) for k, o, _ in batches[:6]]           # six outstanding forwards, ring of four
+        with torch.enable_grad():
+            m(batches[6][0], batches[6][1])                   # a forward that never gets a backward
+        for out, (_, _, g) in reversed(list(zip(outs, batches[:6]))):
+            out.backward(g)
+        k, v = m.export_keys_values("t0", torch.device("cpu"))
+        order = torch.argsort(k)
+        tables.append((k[order], v[order]))
+        assert not any(m._bwd_busy) or early is False or sum(m._bwd_busy) <= 1   # only the dropped step may linger until GC
+    assert torch.equal(tables[0][0], tables[1][0])
+    torch.testing.assert_close(tables[0][1], tables[1][1], rtol=1e-5, atol=1e-6)
