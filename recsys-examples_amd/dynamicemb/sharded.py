@@ -202,8 +202,7 @@ class ShardedPooledLookup:
             score_strategy=DynamicEmbScoreStrategy.TIMESTAMP,
             initializer_args=DynamicEmbInitializerArgs(mode=DynamicEmbInitializerMode.UNIFORM, lower=-0.01, upper=0.01))
         if mode == "auto":
-            # rows-back moves ~Nu ~ 0.5 Nt rows, partial sums move W*B rows (both D wide)
-            mode = "rows" if (keys_per_step and batch and 0.5 * keys_per_step < world * batch) else "partial"
+            mode = self.choose_mode(world, keys_per_step, batch, dim, out_dtype)
         self.mode = mode
         module = BatchedDynamicEmbeddingTablesV2(
             [opt], pooling_mode=DynamicEmbPoolingMode.SUM if mode == "partial" else DynamicEmbPoolingMode.NONE,
@@ -217,6 +216,21 @@ class ShardedPooledLookup:
             self.impl = RowWiseShardedPooledRows(_ModuleLocal(module), [0], [rows], [dim], combiner=0, device=device,
                                                  out_dtype=out_dtype, dist_type_per_table=[dist_type])
         assert self.impl.world == world and self.impl.rank == rank
+
+    @staticmethod
+    def choose_mode(world, keys_per_step, batch, dim, out_dtype=torch.bfloat16) -> str:
+        """xGMI is a full mesh: what bounds an exchange is the bytes on ONE peer link per step, not the total.
+        partial: the [B, D] fp32 block of partial sums out + the [B, D] gradient block of the all-gather back, per peer,
+        whatever W is.  rows: the unique rows and their fp32 gradients of the keys a peer owns, ~ 0.45 Nt / W rows each
+        way -- it shrinks with W but its two-level dedup / reduce costs ~0.23 ms more compute per step (measured at
+        W = 1 on one MI355X), priced here at an effective 100 GB/s per link.  C2: partial up to W = 4, rows from W = 8."""
+        if not (keys_per_step and batch):
+            return "partial"
+        o = torch.empty((), dtype=out_dtype).element_size()
+        partial_link = batch * dim * (4 + o)
+        rows_link = 2 * 0.45 * keys_per_step * dim * 4 / world
+        handicap = 0.23e-3 * 100e9
+        return "rows" if rows_link + handicap < partial_link else "partial"
 
     def forward(self, values, offsets, train: bool = True):
         return self.impl.forward(values, offsets, train)
