@@ -761,6 +761,86 @@ bucketize_scatter_kernel(int64_t FB, int64_t B, int W, const int64_t* __restrict
   }
 }
 
+// Short-bag forms (many bags of a few keys: the C2 shape has 65 536 bags of ~5 keys): GL lanes per bag, 64 / GL bags per
+// wave, same counting by ballot -- the group's bits of the wave ballot -- and the same key order inside a (rank, bag)
+// segment as the wave-per-bag kernels above.
+template <int GL>
+__global__ void __launch_bounds__(256)
+bucketize_count_short_kernel(int64_t FB, int64_t B, int W, const int64_t* __restrict__ offsets, const uint64_t* __restrict__ indices,
+                             const int64_t* __restrict__ block_sizes, const int* __restrict__ dist_type,
+                             int64_t* __restrict__ new_lengths) {
+  constexpr int NG = 64 / GL;
+  const int lane = lane_id(), grp = lane / GL, gl = lane % GL;
+  const uint64_t gmask = ((1ull << GL) - 1);
+  const int64_t bag = ((int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * NG + grp;
+  const bool live = bag < FB;
+  const int64_t bg = live ? bag : FB - 1;
+  const int64_t f = bg / B;
+  const int dist = dist_type ? dist_type[f] : 0;
+  const uint64_t blk = (uint64_t)block_sizes[f];
+  const int64_t lo = offsets[bg], hi = live ? offsets[bg + 1] : lo;
+  int64_t len = hi - lo, maxlen = len;
+  for (int o = GL; o < 64; o <<= 1) { const int64_t t = __shfl_xor((int)maxlen, o, 64); maxlen = t > maxlen ? t : maxlen; }   // bag lengths fit 31 bits
+  for (int p0 = 0; p0 < W; p0 += GL) {
+    int64_t mycnt = 0;
+    const int nr = W - p0 < GL ? W - p0 : GL;
+    for (int64_t j0 = 0; j0 < maxlen; j0 += GL) {
+      const int64_t j = lo + j0 + gl;
+      uint64_t p = ~0ull, nw;
+      if (j < hi) route(indices[j], dist, blk, (uint64_t)W, p, nw);
+      for (int r = 0; r < nr; ++r) {
+        const int c = __popcll((__ballot(p == (uint64_t)(p0 + r)) >> (grp * GL)) & gmask);
+        if (gl == r) mycnt += c;
+      }
+    }
+    if (live && p0 + gl < W) new_lengths[(int64_t)(p0 + gl) * FB + bag] = mycnt;
+  }
+}
+
+template <int GL>
+__global__ void __launch_bounds__(256)
+bucketize_scatter_short_kernel(int64_t FB, int64_t B, int W, const int64_t* __restrict__ offsets, const uint64_t* __restrict__ indices,
+                               const int64_t* __restrict__ block_sizes, const int* __restrict__ dist_type,
+                               const int64_t* __restrict__ new_offsets, uint64_t* __restrict__ new_indices,
+                               int64_t* __restrict__ unbucketize_permute, const float* __restrict__ weights,
+                               float* __restrict__ new_weights) {
+  constexpr int NG = 64 / GL;
+  const int lane = lane_id(), grp = lane / GL, gl = lane % GL;
+  const uint64_t gmask = ((1ull << GL) - 1);
+  const int64_t bag = ((int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * NG + grp;
+  const bool live = bag < FB;
+  const int64_t bg = live ? bag : FB - 1;
+  const int64_t f = bg / B;
+  const int dist = dist_type ? dist_type[f] : 0;
+  const uint64_t blk = (uint64_t)block_sizes[f];
+  const int64_t lo = offsets[bg], hi = live ? offsets[bg + 1] : lo;
+  int64_t maxlen = hi - lo;
+  for (int o = GL; o < 64; o <<= 1) { const int64_t t = __shfl_xor((int)maxlen, o, 64); maxlen = t > maxlen ? t : maxlen; }
+  for (int p0 = 0; p0 < W; p0 += GL) {
+    int64_t cursor = (live && p0 + gl < W) ? new_offsets[(int64_t)(p0 + gl) * FB + bag] : 0;   // lane r of the group: head of rank p0+r
+    const int nr = W - p0 < GL ? W - p0 : GL;
+    for (int64_t j0 = 0; j0 < maxlen; j0 += GL) {
+      const int64_t j = lo + j0 + gl;
+      uint64_t p = ~0ull, nw = 0;
+      if (j < hi) route(indices[j], dist, blk, (uint64_t)W, p, nw);
+      int64_t dst = -1;
+      for (int r = 0; r < nr; ++r) {
+        const uint64_t m = (__ballot(p == (uint64_t)(p0 + r)) >> (grp * GL)) & gmask;
+        const int src = grp * GL + r;
+        const uint32_t clo = __shfl((int)(uint32_t)cursor, src, 64), chi = __shfl((int)(uint32_t)((uint64_t)cursor >> 32), src, 64);
+        const int64_t head = (int64_t)(((uint64_t)chi << 32) | clo);
+        if (p == (uint64_t)(p0 + r)) dst = head + __popcll(m & ((1ull << gl) - 1));
+        if (gl == r) cursor += __popcll(m);
+      }
+      if (dst >= 0) {
+        new_indices[dst] = nw;
+        if (unbucketize_permute) unbucketize_permute[j] = dst;
+        if (weights) new_weights[dst] = weights[j];
+      }
+    }
+  }
+}
+
 // compute_dedup_lengths (get_new_length_and_offsets_kernel, lookup_kernel.cuh:1049-1090): spread the Nu_t unique keys
 // of table t evenly over its (features of t) x local_batch pseudo-bags; first `remainder` bags get one more.
 __global__ void __launch_bounds__(256)
@@ -1253,12 +1333,26 @@ int mi355_block_bucketize(int64_t world_size, int64_t num_bags, int64_t batch_si
   MI355_CHECK_ARG(world_size >= 1 && world_size <= 4096, "bad world size");
   if (num_bags == 0) return MI355_OK;
   const int W = (int)world_size;
-  hipLaunchKernelGGL(bucketize_count_kernel, dim3(grid_for(num_bags, 4)), dim3(256), 0, stream, num_bags, batch_size, W, offsets,
-                     (const uint64_t*)indices, block_sizes, dist_type_per_feature, new_lengths);
+  // many bags (embedding-bag batches: tens of thousands of bags of a few keys) -> 8 lanes per bag; few bags (HSTU
+  // sequences, the pseudo-bags of the rows-back exchange) -> a wave per bag.  Same results either way.
+  const bool short_bags = num_bags >= 8192;
+  constexpr int GL = 8;
+  const int grid_s = grid_for(num_bags, 4 * (64 / GL), 1 << 20);
+  if (short_bags)
+    hipLaunchKernelGGL(bucketize_count_short_kernel<GL>, dim3(grid_s), dim3(256), 0, stream, num_bags, batch_size, W, offsets,
+                       (const uint64_t*)indices, block_sizes, dist_type_per_feature, new_lengths);
+  else
+    hipLaunchKernelGGL(bucketize_count_kernel, dim3(grid_for(num_bags, 4)), dim3(256), 0, stream, num_bags, batch_size, W, offsets,
+                       (const uint64_t*)indices, block_sizes, dist_type_per_feature, new_lengths);
   if (scan_i64(new_lengths, world_size * num_bags, new_offsets, stream) != MI355_OK) return MI355_ELAUNCH;
-  hipLaunchKernelGGL(bucketize_scatter_kernel, dim3(grid_for(num_bags, 4)), dim3(256), 0, stream, num_bags, batch_size, W, offsets,
-                     (const uint64_t*)indices, block_sizes, dist_type_per_feature, new_offsets, (uint64_t*)new_indices,
-                     unbucketize_permute, weights, new_weights);
+  if (short_bags)
+    hipLaunchKernelGGL(bucketize_scatter_short_kernel<GL>, dim3(grid_s), dim3(256), 0, stream, num_bags, batch_size, W, offsets,
+                       (const uint64_t*)indices, block_sizes, dist_type_per_feature, new_offsets, (uint64_t*)new_indices,
+                       unbucketize_permute, weights, new_weights);
+  else
+    hipLaunchKernelGGL(bucketize_scatter_kernel, dim3(grid_for(num_bags, 4)), dim3(256), 0, stream, num_bags, batch_size, W, offsets,
+                       (const uint64_t*)indices, block_sizes, dist_type_per_feature, new_offsets, (uint64_t*)new_indices,
+                       unbucketize_permute, weights, new_weights);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }

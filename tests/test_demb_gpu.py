@@ -810,3 +810,24 @@ def test_block_bucketize_many_bags_full_oracle():
     np.testing.assert_array_equal(gl.cpu().numpy(), onl)
     np.testing.assert_array_equal(gi.cpu().numpy(), oni.view(np.int64))
     np.testing.assert_array_equal(gperm.cpu().numpy(), operm)
+
+
+@pytest.mark.parametrize("W", [1, 3, 8, 11])
+@pytest.mark.parametrize("dist", [0, 1, 2])
+def test_block_bucketize_short_bag_kernels(W, dist):
+    """>= 8192 bags take the 8-lanes-per-bag kernels: ranks beyond one lane group (W = 11), bags longer than a lane
+    group, empty bags and a ragged last wave, whole output against the oracle"""
+    e = ext()
+    rng = np.random.default_rng(W * 10 + dist)
+    F, B = 3, 2803   # 8409 bags
+    lens = rng.integers(0, 21, size=F * B)
+    lens[rng.integers(0, F * B, 500)] = 0
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    idx = rng.integers(0, 1 << 30, size=int(offsets[-1])).astype(np.int64)
+    blk = np.array([(1 << 30) // W + 1] * F, np.int64)
+    gl, gi, _, _, gperm = e.block_bucketize_sparse_features(T(lens.astype(np.int64)), T(idx), False, True,
+                                                             T(np.array([dist] * F, np.int32)), T(blk), W)
+    onl, ono, oni, operm = orc.block_bucketize(offsets, idx, W, B, blk, dist)
+    np.testing.assert_array_equal(gl.cpu().numpy(), onl)
+    np.testing.assert_array_equal(gi.cpu().numpy(), oni.view(np.int64))
+    np.testing.assert_array_equal(gperm.cpu().numpy(), operm)
