@@ -347,10 +347,18 @@ def main():
         bc = [(k.cpu(), o.cpu()) for k, o in batches[: min(len(batches), 8)]]
         result["cpu_baseline"] = cpu_baseline(args, bc)
 
-    if rank == 0:
-        print(json.dumps(result))
     if sharded_path:
         dist.destroy_process_group()
+    if rank == 0:
+        # the box exports NCCL_DEBUG=VERSION: RCCL writes a five-line banner to the C stdout buffer; push it out first so
+        # that the JSON line is the LAST line of stdout
+        try:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -208,6 +208,9 @@ class ShardedPooledLookup:
             [opt], pooling_mode=DynamicEmbPoolingMode.SUM if mode == "partial" else DynamicEmbPoolingMode.NONE,
             output_dtype=torch.float32, device=device, optimizer=EmbOptimType.SGD, learning_rate=lr)
         module.train()
+        # with RCCL's streams in the process the side stream of the early CSR build shares a hardware queue with the main
+        # one and serialises (measured: no gain, +10 us of event edges): group in the backward here
+        module._early_csr = False
         self.module = module
         if mode == "partial":
             self.impl = RowWiseShardedLookup(_ModuleLocal(module), 1, [rows], pooled=True, device=device,
