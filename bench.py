@@ -233,6 +233,15 @@ def hstu_section(args, device, world, dist=None):
             "config": {"workload": f"C3 attention: batch {Bq} x L {L} (dense lengths), H {H}, d {d}, causal, alpha 1/sqrt(d)"}}
 
 
+def _flush_c_stdout():
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -295,6 +304,7 @@ def main():
         step(i)
     if sharded_path:
         dist.barrier()
+        _flush_c_stdout()   # every rank: RCCL's banner (NCCL_DEBUG=VERSION on the box) leaves the C buffer now, not at exit
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.warmup, n_batches):
@@ -352,12 +362,7 @@ def main():
     if rank == 0:
         # the box exports NCCL_DEBUG=VERSION: RCCL writes a five-line banner to the C stdout buffer; push it out first so
         # that the JSON line is the LAST line of stdout
-        try:
-            import ctypes
-
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
+        _flush_c_stdout()
         print(json.dumps(result), flush=True)
 
 
