@@ -730,3 +730,53 @@ def test_early_csr_matches_late_grouping_and_survives_outstanding_steps(pooling)
         assert not any(m._bwd_busy) or early is False or sum(m._bwd_busy) <= 1   # only the dropped step may linger until GC
     assert torch.equal(tables[0][0], tables[1][0])
     torch.testing.assert_close(tables[0][1], tables[1][1], rtol=1e-5, atol=1e-6)
+
+
+def test_training_step_is_hipgraph_capturable():
+    """the step is a fixed launch sequence with every count on the device -- capture forward + backward of
+    the module once in a HIP graph (static key / offset / gradient buffers), replay it on new batches, and compare the
+    table with an eager twin fed the same batches."""
+    (B2, IA, IM, PM, SS, TO, OT) = _mods()
+    D, B, NK = 32, 128, 640
+
+    def make():
+        opts = [TO(dim=D, max_capacity=8192, index_type=torch.int64, embedding_dtype=torch.float32,
+                   initializer_args=IA(mode=IM.UNIFORM, lower=-0.5, upper=0.5), score_strategy=SS.TIMESTAMP)]
+        m = B2(table_options=opts, table_names=["t0"], feature_table_map=[0], pooling_mode=PM.SUM, optimizer=OT.SGD,
+               learning_rate=0.1, output_dtype=torch.float32, device=torch.device(DEV))
+        m.train()
+        return m
+
+    rng = np.random.default_rng(5)
+
+    def batch():
+        cuts = np.sort(rng.integers(0, NK + 1, B - 1))
+        off = np.concatenate([[0], cuts, [NK]]).astype(np.int64)       # fixed number of keys, ragged bags
+        keys = rng.integers(0, 3000, NK).astype(np.int64)
+        g = rng.standard_normal((B, D)).astype(np.float32)
+        return torch.from_numpy(keys).to(DEV), torch.from_numpy(off).to(DEV), torch.from_numpy(g).to(DEV)
+
+    batches = [batch() for _ in range(4)]
+    eager, graphed = make(), make()
+    for k, o, g in batches:
+        out, st = eager._forward_impl(k, o, train=True)
+        eager._backward_impl(st, g)
+    sk, so, sg = (t.clone() for t in batches[0])
+    out0, st0 = graphed._forward_impl(sk, so, train=True)      # warm-up outside the capture (allocator, attributes)
+    graphed._backward_impl(st0, sg)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            out_g, st_g = graphed._forward_impl(sk, so, train=True)
+            graphed._backward_impl(st_g, sg)
+    for k, o, g in batches[1:]:
+        sk.copy_(k); so.copy_(o); sg.copy_(g)
+        graph.replay()
+    torch.cuda.synchronize()
+    ek, ev = eager.export_keys_values("t0", torch.device("cpu"))
+    gk, gv = graphed.export_keys_values("t0", torch.device("cpu"))
+    eo, go = torch.argsort(ek), torch.argsort(gk)
+    assert torch.equal(ek[eo], gk[go])
+    torch.testing.assert_close(ev[eo], gv[go], rtol=1e-5, atol=1e-6)
