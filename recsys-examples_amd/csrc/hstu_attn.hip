@@ -40,6 +40,11 @@ constexpr int kBN = 64;   // keys per tile
 #ifndef HSTU_QLDS_MIN
 #define HSTU_QLDS_MIN 512   // head dims from which the forward keeps its Q fragments in LDS instead of registers (none)
 #endif
+#ifndef HSTU_VTR
+#define HSTU_VTR 0           // forward: V tile row-major in LDS, V^T fragments through ds_read_b64_tr_b16 (no transposing commit).
+                            // OFF: correct on every head dim (tests), but no faster -- d = 256: 591 vs 603 TFLOP/s at L = 4096,
+                            // d = 128: +3 %; the transposing commit was not the bottleneck.  Kept for the backward rework.
+#endif
 #ifndef HSTU_DB_MIN
 #define HSTU_DB_MIN 1024    // head dims from which the forward double-buffers its K / V tiles in LDS (one barrier per tile).
                             // OFF: measured slower at d = 256 (L = 4096: 512 vs 586 TFLOP/s single-buffered, same at L = 512)
@@ -155,9 +160,14 @@ __device__ __forceinline__ void stage_rows(uint16_t* dst, const uint16_t* src, i
 template <int D>
 __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
   constexpr int KS = D + 8;    // padded K row (elements)
+  constexpr bool kVTR = HSTU_VTR != 0;
+  // V tile in LDS: kVTR -- row-major [kBN][VR] and the V^T fragments of GEMM 2 come out of the hardware transpose read
+  // (row stride D + 32 elements = 16 dwords mod 64: the 32 lanes of a half-wave hit 64 distinct banks); otherwise
+  // transposed [D][VS] by the committing threads (perm + 8-byte stores)
   constexpr int VS = kBN + 8;  // padded V^T row (elements)
+  constexpr int VR = D == 32 ? 32 : D + 32;   // V row (elements): row stride = 16 dwords mod 64 (48 at d = 64: also conflict free)
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-  constexpr int TILE = kBN * KS + D * VS;   // elements of one staged (K, V^T) tile pair
+  constexpr int TILE = kBN * KS + (kVTR ? kBN * VR : D * VS);   // elements of one staged (K, V) tile pair
   // Optional (HSTU_DB_MIN, off by default): the tile pair DOUBLE-BUFFERED in LDS -- tile n+1 is committed into the other
   // buffer inside the barrier interval in which tile n is consumed, one barrier per key tile instead of two.
   constexpr bool kDB = D >= HSTU_DB_MIN;
@@ -240,7 +250,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
   constexpr int KPT = (KCH + 255) / 256;      // per thread
   constexpr int VCH = (kBN / 4) * (D / 8);    // (4 keys x 8 d) blocks of the V tile
   constexpr int VPT = (VCH + 255) / 256;
-  u32x4_t kreg[KPT], vreg[VPT][4];
+  u32x4_t kreg[KPT], vreg[kVTR ? 1 : VPT][4], vrow[kVTR ? KPT : 1];
   // key j of the sequence: cached token (page table walk) or a token of k / v.  With a cache, k / v hold
   // [new history | candidates] per sequence and only the candidates are read from them (the history is in the cache).
   const int64_t tok0 = paged ? (int64_t)s.start + (Lq - ntgt) - cachelen : (int64_t)kstart;
@@ -264,6 +274,15 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
       const int row = n0 + key < s.L ? n0 + key : s.L - 1;
       if (KCH % 256 == 0 || ch < KCH) kreg[i] = *reinterpret_cast<const u32x4_t*>(kv_row(row, 0) + 8 * dc);
     }
+    if constexpr (kVTR) {
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {   // V rows exactly like K rows
+        const int ch = threadIdx.x + 256 * i;
+        const int key = ch / (D / 8), dc = ch % (D / 8);
+        const int row = n0 + key < s.L ? n0 + key : s.L - 1;
+        if (KCH % 256 == 0 || ch < KCH) vrow[i] = *reinterpret_cast<const u32x4_t*>(kv_row(row, 1) + 8 * dc);
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
       const int ch = threadIdx.x + 256 * i;
@@ -277,6 +296,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
         if (VCH % 256 == 0 || ch < VCH) vreg[i][kk] = *reinterpret_cast<const u32x4_t*>(kv_row(row, 1) + 8 * dc);
       }
     }
+    }
   };
   auto commit = [&](uint16_t* Kd, uint16_t* Vd) {
 #pragma unroll
@@ -284,6 +304,15 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
       const int ch = threadIdx.x + 256 * i;
       const int key = ch / (D / 8), dc = ch % (D / 8);
       if (KCH % 256 == 0 || ch < KCH) *reinterpret_cast<u32x4_t*>(Kd + key * KS + 8 * dc) = kreg[i];
+    }
+    if constexpr (kVTR) {
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        const int ch = threadIdx.x + 256 * i;
+        const int key = ch / (D / 8), dc = ch % (D / 8);
+        if (KCH % 256 == 0 || ch < KCH) *reinterpret_cast<u32x4_t*>(Vd + key * VR + 8 * dc) = vrow[i];
+      }
+      return;
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
@@ -300,6 +329,28 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
         o.y = __builtin_amdgcn_perm(w3[e >> 1], w2[e >> 1], sel);
         *reinterpret_cast<uint2*>(Vd + (8 * dc + e) * VS + 16 * g16 + 4 * pg) = o;
       }
+    }
+  };
+
+  // A operand of GEMM 2: V^T[32 d of tile dt][16 keys of slice ks], lane (d = l31, k half = hi) holds the 8 keys
+  // (j&3) + 8*(j>>2) + 4*hi of the slice (the register order of the S accumulator, see ew()).
+  // kVTR: two hardware transpose reads per fragment.  Within a 16-lane group the read returns to lane l column l of the
+  // 4 x 16 block whose row (i>>2), columns 4*(i&3)..+3 lane i points at: out_l[j] = in_{4j + (l>>2)}[l & 3] (probed on
+  // gfx950).  Groups: lanes 16g..16g+15 = d half (g & 1), k half (g >> 1) of the fragment.
+  const int tr_il = lane & 15;
+  const int tr_off = ((4 * hi + (tr_il >> 2)) * VR + 16 * ((lane >> 4) & 1) + 4 * (tr_il & 3));   // elements, inside (slice, d tile)
+  auto v_frag = [&](const uint16_t* Vb, int dt, int ks) -> bf16x8_t {
+    if constexpr (kVTR) {
+      typedef short v4s_t __attribute__((ext_vector_type(4)));
+      typedef __attribute__((address_space(3))) v4s_t* lds_v4s_t;
+      const uint16_t* p0 = Vb + (16 * ks) * VR + 32 * dt + tr_off;
+      const v4s_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(p0));
+      const v4s_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(p0 + 8 * VR));
+      typedef short v8s_t __attribute__((ext_vector_type(8)));
+      const v8s_t r = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+      return __builtin_bit_cast(bf16x8_t, r);
+    } else {
+      return *reinterpret_cast<const bf16x8_t*>(Vb + (32 * dt + l31) * VS + 16 * ks + 8 * hi);
     }
   };
 
@@ -409,7 +460,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
         const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
 #pragma unroll
         for (int u = 0; u < DB; ++u)
-          vfr[buf][u] = *reinterpret_cast<const bf16x8_t*>(Vt + (32 * (dt0 + u) + l31) * VS + 16 * ks + 8 * hi);
+          vfr[buf][u] = v_frag(Vt, dt0 + u, ks);
       };
       load_v(0, 0);
       constexpr bool kPipe = true;
@@ -481,7 +532,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
         const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
 #pragma unroll
         for (int u = 0; u < DB; ++u)
-          vfr[buf][u] = *reinterpret_cast<const bf16x8_t*>(Vt + (32 * (dt0 + u) + l31) * VS + 16 * ks + 8 * hi);
+          vfr[buf][u] = v_frag(Vt, dt0 + u, ks);
       };
       load_v(0, 0);
 #pragma unroll
@@ -1059,7 +1110,8 @@ static int launch_bwd(const BwdAttnArgs& g, int B, int max_seqlen, hipStream_t s
 
 template <int D>
 static int launch_fwd(const AttnArgs& a, int B, int max_seqlen, hipStream_t stream) {
-  const size_t smem = (size_t)((D >= HSTU_DB_MIN ? 2 : 1) * (kBN * (D + 8) + D * (kBN + 8)) + (D >= HSTU_QLDS_MIN ? kBM * (D + 8) : 0)) * sizeof(uint16_t);
+  const size_t vtile = HSTU_VTR ? (size_t)kBN * (D == 32 ? 32 : D + 32) : (size_t)D * (kBN + 8);
+  const size_t smem = (size_t)((D >= HSTU_DB_MIN ? 2 : 1) * (kBN * (D + 8) + vtile) + (D >= HSTU_QLDS_MIN ? kBM * (D + 8) : 0)) * sizeof(uint16_t);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
