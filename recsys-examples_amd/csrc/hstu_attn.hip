@@ -45,6 +45,9 @@ constexpr int kBN = 64;   // keys per tile
                             // OFF: correct on every head dim (tests), but no faster -- d = 256: 591 vs 603 TFLOP/s at L = 4096,
                             // d = 128: +3 %; the transposing commit was not the bottleneck.  Kept for the backward rework.
 #endif
+#ifndef HSTU_BWD_TR
+#define HSTU_BWD_TR 1        // backward: GEMM 3/4/5 A operands by transpose reads from row-major tiles (no transposed copies)
+#endif
 #ifndef HSTU_DB_MIN
 #define HSTU_DB_MIN 1024    // head dims from which the forward double-buffers its K / V tiles in LDS (one barrier per tile).
                             // OFF: measured slower at d = 256 (L = 4096: 512 vs 586 TFLOP/s single-buffered, same at L = 512)
@@ -581,6 +584,26 @@ __device__ __forceinline__ float dsilu_f(float x) {
 // ---- register-prefetched tile staging (issue the global loads of tile n+1 before the MFMAs of tile n, write them
 // to LDS after the barrier).  Rows past the sequence end are read clamped and zeroed with selects: no branches.
 // RowTile: rows [row0, row0+NR) -> LDS [NR][D+8] row-major.
+// Row stride (elements) of a tile that is read with ds_read_b64_tr_b16: 16 dwords mod 64 (48 at d = 64) keeps the 32
+// lanes of a half-wave on 64 distinct banks.
+template <int D> struct TrStride { static constexpr int value = D == 32 ? 32 : D + 32; };
+// A operand [32 rows of tile dt][16 k of slice ks] of a GEMM whose A is the TRANSPOSE of a row-major LDS tile
+// base[k][...]: lane (row = l31, k half = hi) receives the 8 k positions (j&3) + 8*(j>>2) + 4*hi of the slice -- the
+// register order of the 32x32 accumulator that produced the B operand.  Two hardware transpose reads; within a 16-lane
+// group out_l[j] = in_{4j + (l>>2)}[l & 3] (probed on gfx950).
+template <int STRIDE>
+__device__ __forceinline__ bf16x8_t tr_frag(const uint16_t* base, int dt, int ks, int lane, int hi) {
+  typedef short v4s_t __attribute__((ext_vector_type(4)));
+  typedef short v8s_t __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) v4s_t* lds_v4s_t;
+  const int il = lane & 15;
+  const uint16_t* p0 = base + (16 * ks + 4 * hi + (il >> 2)) * STRIDE + 32 * dt + 16 * ((lane >> 4) & 1) + 4 * (il & 3);
+  const v4s_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(p0));
+  const v4s_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(p0 + 8 * STRIDE));
+  const v8s_t r = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
 template <int D, int NR>
 struct RowTile {
   static constexpr int NCH = NR * D / 8, PT = (NCH + 255) / 256;
@@ -602,6 +625,16 @@ struct RowTile {
       const u32x4_t z = {0u, 0u, 0u, 0u};
       const u32x4_t v = (row0 + ch / (D / 8) < L) ? r[i] : z;
       if (NCH % 256 == 0 || ch < NCH) *reinterpret_cast<u32x4_t*>(dst + (ch / (D / 8)) * (D + 8) + 8 * (ch % (D / 8))) = v;
+    }
+  }
+  // the same rows once more with the transpose-read stride (tr_frag): the image a TransTile would have transposed
+  __device__ __forceinline__ void commit_tr(uint16_t* dst, int row0, int L) const {
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int ch = threadIdx.x + 256 * i;
+      const u32x4_t z = {0u, 0u, 0u, 0u};
+      const u32x4_t v = (row0 + ch / (D / 8) < L) ? r[i] : z;
+      if (NCH % 256 == 0 || ch < NCH) *reinterpret_cast<u32x4_t*>(dst + (ch / (D / 8)) * TrStride<D>::value + 8 * (ch % (D / 8))) = v;
     }
   }
 };
@@ -652,6 +685,7 @@ struct TransTile {
 struct NoTile {
   __device__ __forceinline__ void fetch(const uint16_t*, int64_t, int, int) {}
   __device__ __forceinline__ void commit(uint16_t*, int, int) const {}
+  __device__ __forceinline__ void commit_tr(uint16_t*, int, int) const {}
 };
 template <bool C, typename A, typename B> struct SelT { typedef A type; };
 template <typename A, typename B> struct SelT<false, A, B> { typedef B type; };
@@ -683,11 +717,14 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
   const AttnArgs& a = g.f;
   constexpr bool kDV = MODE != 2, kDK = MODE != 1;
   constexpr int RS = D + 8, TS = BQ + 8, NT = BQ / 32;
+  constexpr bool kTR = HSTU_BWD_TR != 0;            // Q^T / dO^T operands by transpose reads from row-major images
+  constexpr int TRS = TrStride<D>::value;
+  constexpr int TIMG = kTR ? BQ * TRS : D * TS;     // elements of one "transposed" image
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   uint16_t* Qs = smem;                              // [BQ][RS]   (S)
   uint16_t* dOs = Qs + BQ * RS;                     // [BQ][RS]   (dP; kDK only)
-  uint16_t* Qt = dOs + (kDK ? BQ * RS : 0);         // [D][TS]    (dK; kDK only)
-  uint16_t* dOt = Qt + (kDK ? D * TS : 0);          // [D][TS]    (dV; kDV only)
+  uint16_t* Qt = dOs + (kDK ? BQ * RS : 0);         // [D][TS] or [BQ][TRS]   (dK; kDK only)
+  uint16_t* dOt = Qt + (kDK ? TIMG : 0);            // [D][TS] or [BQ][TRS]   (dV; kDV only)
 
   const int b = blockIdx.y, h = blockIdx.x;   // grid (H, B, blocks): see launch_fwd
   SeqInfo s;
@@ -734,10 +771,12 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
   auto advance = [&](int i) { i += BQ; return (i >= c_end && i < jump) ? jump : i; };
   int i0 = c_end > 0 ? 0 : jump;
 
+  // kTR: the "transposed" images are second row-major copies of the SAME fetched registers (no second global read,
+  // no perm network); only MODE 1, which has no other use for dO rows, fetches dO for that image alone
   typename SelT<true, RowTile<D, BQ>, NoTile>::type q_rows;
-  typename SelT<kDK, RowTile<D, BQ>, NoTile>::type do_rows;
-  typename SelT<kDK, TransTile<D, BQ>, NoTile>::type q_tr;
-  typename SelT<kDV, TransTile<D, BQ>, NoTile>::type do_tr;
+  typename SelT<kDK || (kTR && kDV), RowTile<D, BQ>, NoTile>::type do_rows;
+  typename SelT<kDK && !kTR, TransTile<D, BQ>, NoTile>::type q_tr;
+  typename SelT<kDV && !kTR, TransTile<D, BQ>, NoTile>::type do_tr;
   auto fetch_all = [&](int i) {
     q_rows.fetch(qbase, a.q_row, i, s.L);
     do_rows.fetch(dobase, g.do_row, i, s.L);
@@ -753,9 +792,14 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
     __syncthreads();
     if (!kPre) fetch_all(i0);
     q_rows.commit(Qs, i0, s.L);
-    do_rows.commit(dOs, i0, s.L);
-    q_tr.commit(Qt, i0, s.L);
-    do_tr.commit(dOt, i0, s.L);
+    if (kDK) do_rows.commit(dOs, i0, s.L);
+    if constexpr (kTR) {
+      if (kDK) q_rows.commit_tr(Qt, i0, s.L);
+      if (kDV) do_rows.commit_tr(dOt, i0, s.L);
+    } else {
+      q_tr.commit(Qt, i0, s.L);
+      do_tr.commit(dOt, i0, s.L);
+    }
     if (kDV) pin_agpr(acc_dv);
     if (kDK) pin_agpr(acc_dk);
     __syncthreads();
@@ -857,9 +901,14 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
         const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
 #pragma unroll
         for (int u = 0; u < DB; ++u) {
-          const int off = (32 * (dt0 + u) + l31) * TS + 16 * ks + 8 * hi;
-          if (kDV) fa[buf][u] = *reinterpret_cast<const bf16x8_t*>(dOt + off);
-          if (kDK) fb[buf][u] = *reinterpret_cast<const bf16x8_t*>(Qt + off);
+          if constexpr (kTR) {
+            if (kDV) fa[buf][u] = tr_frag<TRS>(dOt, dt0 + u, ks, lane, hi);
+            if (kDK) fb[buf][u] = tr_frag<TRS>(Qt, dt0 + u, ks, lane, hi);
+          } else {
+            const int off = (32 * (dt0 + u) + l31) * TS + 16 * ks + 8 * hi;
+            if (kDV) fa[buf][u] = *reinterpret_cast<const bf16x8_t*>(dOt + off);
+            if (kDK) fb[buf][u] = *reinterpret_cast<const bf16x8_t*>(Qt + off);
+          }
         }
       };
       load_t(0, 0);
@@ -906,10 +955,12 @@ template <int D, int BK, bool kPre>
 __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
   const AttnArgs& a = g.f;
   constexpr int RS = D + 8, TS = BK + 8, NT = BK / 32;
+  constexpr bool kTR = HSTU_BWD_TR != 0;   // K^T operand of the dQ GEMM by transpose reads from a row-major image
+  constexpr int TRS = TrStride<D>::value;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   uint16_t* Ks = smem;               // [BK][RS]
   uint16_t* Vs = Ks + BK * RS;       // [BK][RS]
-  uint16_t* Kt = Vs + BK * RS;       // [D][TS]
+  uint16_t* Kt = Vs + BK * RS;       // [D][TS] or [BK][TRS]
 
   const int b = blockIdx.y, h = blockIdx.x;   // grid (H, B, blocks): see launch_fwd
   SeqInfo s;
@@ -949,7 +1000,7 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
   const uint16_t* kbase = a.k + (int64_t)s.start * a.k_row + (int64_t)h * a.k_head;
   const uint16_t* vbase = a.v + (int64_t)s.start * a.v_row + (int64_t)h * a.v_head;
   RowTile<D, BK> k_rows, v_rows;
-  TransTile<D, BK> k_tr;
+  typename SelT<!kTR, TransTile<D, BK>, NoTile>::type k_tr;
   auto fetch_all = [&](int n) {
     k_rows.fetch(kbase, a.k_row, n, s.L);
     v_rows.fetch(vbase, a.v_row, n, s.L);
@@ -962,7 +1013,7 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
     if (!kPre) fetch_all(n0);
     k_rows.commit(Ks, n0, s.L);
     v_rows.commit(Vs, n0, s.L);
-    k_tr.commit(Kt, n0, s.L);
+    if constexpr (kTR) k_rows.commit_tr(Kt, n0, s.L); else k_tr.commit(Kt, n0, s.L);
     pin_agpr(acc_dq);
     __syncthreads();
     if (kPre && n0 + BK < n_end) fetch_all(n0 + BK);
@@ -1033,7 +1084,8 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
         const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
 #pragma unroll
         for (int u = 0; u < DB; ++u)
-          fk[buf][u] = *reinterpret_cast<const bf16x8_t*>(Kt + (32 * (dt0 + u) + l31) * TS + 16 * ks + 8 * hi);
+          if constexpr (kTR) fk[buf][u] = tr_frag<TRS>(Kt, dt0 + u, ks, lane, hi);
+          else fk[buf][u] = *reinterpret_cast<const bf16x8_t*>(Kt + (32 * (dt0 + u) + l31) * TS + 16 * ks + 8 * hi);
       };
       load_t(0, 0);
 #pragma unroll
@@ -1065,7 +1117,8 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
 template <int D, int BQ, int MODE, bool kPre>
 static void launch_bwd_kv(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
   constexpr bool kDV = MODE != 2, kDK = MODE != 1;
-  const size_t smem = (size_t)(BQ * (D + 8) + (kDK ? BQ * (D + 8) + D * (BQ + 8) : 0) + (kDV ? D * (BQ + 8) : 0)) * sizeof(uint16_t);
+  const size_t timg = HSTU_BWD_TR ? (size_t)BQ * (D == 32 ? 32 : D + 32) : (size_t)D * (BQ + 8);
+  const size_t smem = (size_t)(BQ * (D + 8) + (kDK ? BQ * (D + 8) + timg : 0) + (kDV ? timg : 0)) * sizeof(uint16_t);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_kv_kernel<D, BQ, MODE, kPre>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1075,7 +1128,7 @@ static void launch_bwd_kv(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
 }
 template <int D, int BK, bool kPre>
 static void launch_bwd_q(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
-  const size_t smem_q = (size_t)(2 * BK * (D + 8) + D * (BK + 8)) * sizeof(uint16_t);
+  const size_t smem_q = (size_t)(2 * BK * (D + 8) + (HSTU_BWD_TR ? (size_t)BK * (D == 32 ? 32 : D + 32) : (size_t)D * (BK + 8))) * sizeof(uint16_t);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_q_kernel<D, BK, kPre>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_q);
