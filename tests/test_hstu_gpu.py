@@ -360,3 +360,42 @@ def test_c4_jagged_long_sequences_properties():
     lhs = (dv.double() * v.double()).sum()
     rhs = (out.double() * out.double()).sum()
     assert abs(float(lhs - rhs)) <= 5e-3 * abs(float(rhs)), (float(lhs), float(rhs))
+
+
+def test_c5_paged_decode_full_size_equals_contiguous_keys():
+    """BASELINE config 5 at full size (page 32, 3968 cached + 128 new history + 256 candidates per sequence, d = 256):
+    the paged-KV forward must be bit-identical to the delta-q forward over the same keys laid out contiguously (only the
+    key addressing differs), after append_kvcache wrote the new history into randomly permuted pages."""
+    from hstu import append_kvcache, hstu_attn_varlen_func
+
+    B, H, d, P, old, new_hist, cand = 4, 4, 256, 32, 3968, 128, 256
+    qlen, cachelen = new_hist + cand, old + new_hist
+    klen = cachelen + cand
+    npg = cachelen // P
+    rng = np.random.default_rng(9)
+    ti = lambda a: torch.tensor(np.asarray(a), dtype=torch.int32, device=DEV)
+    page_ids = ti(rng.permutation(B * npg))
+    page_off, last = ti(np.arange(B + 1) * npg), ti(np.full(B, P))
+    cuq, cuk, tgt = ti(np.arange(B + 1) * qlen), ti(np.arange(B + 1) * klen), ti(np.full(B, cand))
+    torch.manual_seed(2)
+    cache = torch.zeros(B * npg, 2, P, H, d, device=DEV, dtype=torch.bfloat16)
+    hist_k, hist_v = (torch.empty(B, old, H, d, device=DEV).uniform_(-1, 1).bfloat16() for _ in range(2))
+    q, k, v = (torch.empty(B * qlen, H, d, device=DEV).uniform_(-1, 1).bfloat16() for _ in range(3))
+    pid = page_ids.view(B, npg).long()
+    for b in range(B):      # old history page by page (host-side fill of the fixture)
+        pages = pid[b, : old // P]
+        cache[pages, 0] = hist_k[b].view(old // P, P, H, d)
+        cache[pages, 1] = hist_v[b].view(old // P, P, H, d)
+    bidx = ti(np.repeat(np.arange(B), new_hist))
+    pos = ti(np.tile(old + np.arange(new_hist), B))
+    append_kvcache(k, v, bidx, pos, ti(np.arange(B + 1) * cand), ti([B * new_hist]), 0, cache, page_ids, page_off, last, 0)
+    out_paged = hstu_attn_varlen_func(q, k, v, cuq, cuk, None, None, qlen, klen, float(klen), None, tgt, window_size=(-1, 0),
+                                      alpha=1.0 / d ** 0.5, kv_cache=cache, page_offsets=page_off, page_ids=page_ids,
+                                      last_page_lens=last)
+    kq, vq = k.view(B, qlen, H, d), v.view(B, qlen, H, d)
+    k_full = torch.cat([hist_k, kq], 1).reshape(B * klen, H, d).contiguous()
+    v_full = torch.cat([hist_v, vq], 1).reshape(B * klen, H, d).contiguous()
+    out_flat = hstu_attn_varlen_func(q, k_full, v_full, cuq, cuk, None, None, qlen, klen, float(klen), None, tgt,
+                                     window_size=(-1, 0), alpha=1.0 / d ** 0.5)
+    assert torch.equal(out_paged, out_flat)
+    assert float(out_paged.float().abs().max()) > 0
