@@ -294,7 +294,38 @@ int mi355_demb_forward(void* storage, const int64_t* table_bucket_offsets, int64
                        int64_t* row_addr, int64_t* freq, int32_t* csr_cnt /* nullable */,
                        int32_t* csr_rank /* nullable */,
                        void* backward_workspace /* nullable: early CSR, see mi355_demb_backward(prepared) */,
-                       int64_t backward_workspace_bytes, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+                       int64_t backward_workspace_bytes,
+                       int* join_token /* out, nullable: side-stream join point of the early CSR (-1: none) */,
+                       void* workspace, int64_t workspace_bytes, hipStream_t stream);
+
+/* The same step with the index stage FUSED into one kernel (csrc/fused_fwd.hip): tile dedup in LDS, hash-table probe of
+ * the tile's distinct keys, per-slot occurrence counting (dedup BY SLOT), in-place insert + first-touch initialisation of
+ * unseen keys, deferred min-score eviction for full buckets -- segmented_unique_cuda (src/unique_op.cu:484-714) +
+ * table_lookup / table_insert / table_unlock (src/table_operation/kernels.cuh:81-585) + initializer + the pin bracket of
+ * _prefetch_hbm_direct_path (dynamicemb/batched_dynamicemb_function.py:559-696) in ONE launch; the pooled / sequence
+ * gather reads per-occurrence row addresses and the unique numbering + the backward's CSR run on the library's side
+ * stream (use_side_stream) under it.  `aux`: persistent int32 scratch of mi355_demb_aux_numel() elements owned by the
+ * table, zero-initialised once by the caller and left all-zero by every call.  Scores are scalar: `score_value`, or the
+ * per-key occurrence count when use_count != 0 (LFU).  Unique keys come out in representative order (not first
+ * occurrence); in eval mode (train == 0) only `out` is produced.  join_token as in mi355_demb_forward. */
+int64_t mi355_demb_aux_numel(int64_t total_slots, int64_t num_buckets);
+/* `stream` waits for the side-stream work a forward announced through join_token */
+int mi355_side_join(int token, hipStream_t stream);
+int64_t mi355_demb_forward_fused_workspace_bytes(int64_t num_keys, int64_t num_tables);
+int mi355_demb_forward_fused(void* storage, const int64_t* table_bucket_offsets, int64_t bucket_capacity,
+                             int64_t num_scores, int32_t* bucket_sizes, int32_t* counter, int64_t counter_numel,
+                             int32_t* aux, int64_t aux_numel, int64_t num_buckets, const int64_t* table_ptrs,
+                             const int64_t* table_value_dims, const int64_t* table_emb_dims, int value_dtype,
+                             int64_t emb_dim, int64_t value_dim, const void* keys, int64_t num_keys,
+                             const int64_t* offsets, int64_t num_bags, int64_t batch_size,
+                             const int64_t* feature_offsets, int64_t num_tables, int train, int find_policy,
+                             int insert_policy, uint64_t score_value, int use_count, uint64_t timer_override, int pin,
+                             int init_mode, float p0, float p1, float p2, float p3, uint64_t seed, float state_init,
+                             int combiner, const int32_t* D_offsets, int64_t total_D, void* out, int out_dtype,
+                             int aligned16, int64_t* reverse_indices, int64_t* unique_offsets, int64_t* table_ids,
+                             int64_t* slots, int64_t* row_addr, int64_t* freq, int32_t* csr_cnt, int32_t* csr_rank,
+                             void* backward_workspace, int64_t backward_workspace_bytes, int use_side_stream,
+                             int* join_token, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* hipStream_t of the library's side stream (early CSR build of mi355_demb_forward); NULL if it cannot be created */
 void* mi355_early_csr_stream(void);
@@ -302,7 +333,8 @@ void* mi355_early_csr_stream(void);
 /* One-call backward: DynamicEmbeddingFunction.backward (batched_dynamicemb_function.py:1193-1300):
  * reduce_grads + optimizer.fused_update_for_flat_table + decrement_counter.  Early CSR: when the forward was given
  * `backward_workspace`, the key-grouping half of this call already ran on the library's side stream under the forward's
- * own lookup / gather kernels; pass the same buffer with prepared = 1 and only the reduce + optimizer kernel remains. */
+ * own lookup / gather kernels; pass the same buffer with prepared = 2 + join_token (1: the grouping was issued on this
+ * very stream, nothing to join) and only the reduce + optimizer kernel remains. */
 int64_t mi355_demb_backward_workspace_bytes(int64_t num_keys, int64_t dim);
 int mi355_demb_backward(const int64_t* reverse_indices, int64_t num_keys, const int64_t* unique_offsets,
                         int64_t num_tables, const int64_t* offsets, int64_t num_bags, int64_t batch_size,
@@ -313,7 +345,7 @@ int mi355_demb_backward(const int64_t* reverse_indices, int64_t num_keys, const 
                         int64_t counter_numel, const int64_t* slots, const int64_t* table_ids,
                         const int64_t* table_bucket_offsets, int64_t bucket_capacity, int unpin,
                         const int32_t* csr_cnt, const int32_t* csr_rank /* from the forward, or both NULL */,
-                        int prepared /* workspace == the forward's backward_workspace: grouping already issued */,
+                        int prepared /* 0 group here; 1 / 2 + token: workspace == the forward's backward_workspace */,
                         void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* ---------------------------------------------------------------- HSTU jagged attention ---- */

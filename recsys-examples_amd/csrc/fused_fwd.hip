@@ -1,0 +1,848 @@
+// Fused index stage of the DynamicEmb forward for gfx950: ONE kernel de-duplicates a tile of the batch in LDS, probes the
+// scored hash table with the tile's distinct keys, counts / ranks the occurrences of every table slot, inserts unseen keys
+// into free slots and initialises their rows -- the work of segmented_unique + table_lookup + table_insert + unlock +
+// init_rows + row_addresses of the unfused chain (five dedup launches, lookup, insert, unlock/init: 10 launches, ~120 us
+// at C2) in one launch.
+//
+// Restates (reference, corelib/dynamicemb/): segmented_unique_cuda (src/unique_op.cu:484-714), table_lookup_kernel /
+// table_insert_kernel / table_unlock_kernel (src/table_operation/kernels.cuh:81-585), the first-touch initialisation and
+// the hit-slot pinning of _prefetch_hbm_direct_path (dynamicemb/batched_dynamicemb_function.py:559-696).
+//
+// Design (MI355X-first, not a translation):
+//  * In steady state every key of the batch already owns a table slot, and the slot IS the identity of the unique row.
+//    So the batch is de-duplicated BY SLOT: a persistent int32 counter per slot (`occ`, all zero between steps) receives
+//    one atomicAdd per (tile, distinct key) pair; the value it returns ranks the tile's occurrences inside the row's
+//    list (the backward's CSR needs exactly that), and the occurrence that draws rank 0 is the row's representative.
+//    No scratch hash set, no clear pass, no separate lookup over the uniques.
+//  * The pooled gather takes the row address of every OCCURRENCE (written here), so it does not wait for the unique
+//    numbering at all: numbering (emit), scan and CSR scatter run on a side stream under the gather.
+//  * Unseen keys are inserted in place when their bucket has a free slot: CAS Empty -> Locked, digest, score, publish
+//    the key.  A prober that meets a Locked slot re-reads until the key is published, so two tiles inserting the same key
+//    agree on one slot.  Full buckets are deferred to ONE persistent kernel (early exit when the list is empty) that
+//    evicts the minimum score under a per-bucket lock; slots with occ > 0 (hit or inserted by THIS batch) and pinned
+//    slots are never candidates -- the reference's increment_counter / decrement_counter bracket comes for free.
+//  * Probing is one lane per key with 16-B digest vectors (the first vector resolves the probe at normal load factors):
+//    64 independent probes per wave in flight instead of 8 with the 8-lane groups of the per-op kernels.
+#include "common.h"
+#include "hot.h"
+#include "../../include/recsys_amd.h"
+#include "internal.h"
+#include "scan_dev.h"
+#include "table_dev.h"
+#include "init_dev.h"
+#include <pthread.h>
+#include <stdlib.h>
+
+namespace mi355 {
+
+constexpr int kFusedMaxT = 128;     // tables per fused launch (per-table metadata lives in LDS)
+constexpr int kAuxHdr = 64;         // ints in front of the occ array: [0] deferred keys, [1] grid barrier
+
+struct FusedArgs {
+  Table t;
+  const int64_t* tbo;             // [T+1] bucket offsets
+  int32_t* bucket_sizes;
+  const int32_t* counter;         // pin counters per slot (nullable)
+  int32_t* hdr;                   // aux header
+  int32_t* occ;                   // [S+1] occurrences of the slot in this batch (last entry: keys without a slot)
+  int32_t* uidmap;                // [S+1] unique id of the slot
+  int32_t* locks;                 // [num_buckets] eviction lock
+  int64_t S;                      // total slots
+  const int64_t* table_ptrs;
+  const int64_t* table_value_dims;
+  const int64_t* table_emb_dims;
+  int elem_bytes, value_dtype;
+  const uint64_t* keys;
+  int64_t n;
+  const int64_t* offsets;
+  const int64_t* feature_offsets;
+  int64_t num_bags;
+  int T;
+  int find_policy, insert_policy, use_count;
+  uint64_t score_value, timer;
+  InitArgs init;
+  // per-step outputs
+  int64_t* occ_addr;              // [n] row address of every occurrence (0: no row)
+  int32_t* occ_slot;              // [n] global slot (S: none; <= -2: deferred entry -(e+2))
+  int32_t* csr_rank;              // [n]
+  int32_t* partial;               // [ceil(n/1024)] representatives per 1024 occurrences
+  int32_t* partial2;              // [ceil((n+1)/1024)+1] occurrences per 1024 uniques (zeroed here, filled by emit)
+  int64_t nbu;
+  int64_t* seg_out;               // [T+1] table ranges
+  uint64_t* d_key; int32_t* d_tid; int32_t* d_cnt; int32_t* d_slot; int32_t* d_base;   // deferred (bucket full) keys
+};
+
+__device__ __forceinline__ void store_digest(uint8_t* p, uint8_t d) {
+  __hip_atomic_store(p, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// score of a key that is already stored (score.cuh:72-96); `cnt` = occurrences of the key in the caller's tile
+__device__ __forceinline__ void score_found(const FusedArgs& a, uint64_t* sc, int cnt) {
+  const uint64_t v = a.use_count ? (uint64_t)cnt : a.score_value;
+  switch (a.find_policy) {
+    // Assign / timer scores are idempotent and nobody reads a score before the next kernel: plain (write-back cached)
+    // stores.  Device-scope (sc1) stores resolve at the memory side like atomics, ~10 G/s on this part, and were half of
+    // the kernel when every (tile, key) pair issued one.
+    case kConst: break;
+    case kAccumulate: atomicAdd((unsigned long long*)sc, (unsigned long long)v); break;
+    case kLruLfu: *sc = a.timer; atomicAdd((unsigned long long*)(sc + 1), (unsigned long long)v); break;
+    case kGlobalTimer: *sc = a.timer; break;
+    default: *sc = v; break;
+  }
+}
+// score of a key placed in a fresh (or evicted and cleared) slot: Accumulate acts as Assign (key_value_table.py:881-925)
+__device__ __forceinline__ void score_new(const FusedArgs& a, uint64_t* sc, int cnt) {
+  const uint64_t v = a.use_count ? (uint64_t)cnt : a.score_value;
+  switch (a.insert_policy) {
+    case kConst: ast64(sc, 0); break;
+    case kLruLfu: ast64(sc, a.timer); ast64(sc + 1, v); break;
+    case kGlobalTimer: ast64(sc, a.timer); break;
+    default: ast64(sc, v); break;
+  }
+}
+
+// One lane probes one key (types.cuh:308-396 order: 16-aligned start, wrap around; inside a 16-slot vector first the
+// slots whose digest matches, then the first Empty one).  kInsert: an absent key takes the first Empty slot.
+// Returns the slot, -1 (absent, lookup only) or -2 (no Empty slot in the bucket / gave up on a stuck lock).
+template <bool kInsert>
+__device__ __forceinline__ int thread_probe(const FusedArgs& a, int64_t b, uint64_t key, int64_t hash, int cnt, bool& inserted) {
+  const Table& t = a.t;
+  const int C = (int)t.C;
+  const uint32_t d = digest_of(hash);
+  const uint32_t ed = digest_of((int64_t)(fmix64(kEmptyKey) & 0x7FFFFFFFFFFFFFFFull));
+  const int start = (int)(((C & (C - 1)) == 0 ? ((uint64_t)hash & (uint64_t)(C - 1)) : ((uint64_t)hash % (uint64_t)C))) & ~15;
+  uint64_t* ks = t.keys(b);
+  uint8_t* dg = t.dig(b);
+  inserted = false;
+  const int ngroups = C >> 4;
+  int gi = 0, guard = 0;
+  bool fresh = false;
+  while (gi < ngroups) {
+    int p0 = start + (gi << 4);
+    if (p0 >= C) p0 -= C;
+    const uint4 dv = load_dig16(dg + p0, fresh);
+    bool again = false;
+    uint32_t m = eq_mask16(dv, d);
+    while (m) {
+      const int bit = __ffs(m) - 1;
+      m &= m - 1;
+      const uint64_t k = fresh ? ald64(ks + p0 + bit) : ks[p0 + bit];
+      if (k == key) return p0 + bit;
+      if (kInsert && k == kLockedKey) again = true;   // being inserted right now -- possibly this very key
+    }
+    if (!again) {
+      uint32_t me = eq_mask16(dv, ed);
+      while (me) {
+        const int bit = __ffs(me) - 1;
+        me &= me - 1;
+        const uint64_t k = fresh ? ald64(ks + p0 + bit) : ks[p0 + bit];
+        if (k == kEmptyKey) {
+          if (!kInsert) return -1;
+          uint64_t e = kEmptyKey;
+          if (cas64(ks + p0 + bit, e, kLockedKey)) {
+            store_digest(dg + p0 + bit, (uint8_t)d);
+            score_new(a, t.scores(b) + (int64_t)(p0 + bit) * t.ns, cnt);
+            atomicAdd(&a.bucket_sizes[b], 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ast64(ks + p0 + bit, key);     // publish: probers waiting on the Locked word now see the key
+            inserted = true;
+            return p0 + bit;
+          }
+          again = true;                    // lost the slot: look at this vector again
+          break;
+        }
+        if (k == key) return p0 + bit;     // published after the digest snapshot was taken
+        if (kInsert && k == kLockedKey) { again = true; break; }
+        // a tombstone or another key behind a stale digest: keep scanning
+      }
+    }
+    if (again) {
+      fresh = true;
+      if (++guard > (1 << 16)) return -2;  // a slot stuck in Locked (foreign writer): leave it to the deferred pass
+      __builtin_amdgcn_s_sleep(1);
+      continue;
+    }
+    ++gi;
+  }
+  return kInsert ? -2 : -1;
+}
+
+// whole wave initialises one row (initializer.cu:64-83 semantics, counter-based generator of init_dev.h)
+__device__ __forceinline__ void wave_init_row(const FusedArgs& a, void* rp, uint64_t key, int ed, int vd) {
+  const int lane = lane_id();
+  for (int e = lane; e < vd; e += 64) {
+    const float v = e < ed ? init_value(a.init, key, (uint32_t)e) : a.init.state_init;
+    if (a.value_dtype == kF32) st1<kF32>(rp, e, v);
+    else if (a.value_dtype == kBF16) st1<kBF16>(rp, e, v);
+    else st1<kF16>(rp, e, v);
+  }
+}
+
+template <int TILE, int THREADS, bool kTrain>
+__global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
+  if (!a.timer) a.timer = device_clock();
+  constexpr int PER = TILE / THREADS;
+  constexpr int LDS = 2 * TILE;
+  constexpr int HALVES = TILE / 1024;
+  __shared__ uint64_t s_key[TILE];
+  __shared__ int s_tab[LDS];        // dedup: tile position of the key's representative; after the probe: its global slot
+  __shared__ int s_cnt[LDS];        // dedup: occurrences inside the tile; after the probe: rank base of the tile
+  __shared__ uint16_t s_t[TILE];    // table of every key (bit 15: representative whose row is new)
+  __shared__ int s_gs[TILE];        // global slot of new rows (by representative position)
+  __shared__ int64_t s_seg[kFusedMaxT + 1];
+  __shared__ int64_t s_tbo[kFusedMaxT + 1];
+  __shared__ int64_t s_tptr[kFusedMaxT];
+  __shared__ int s_rowb[kFusedMaxT];
+  __shared__ int s_nrep[HALVES];
+  const int T = a.T;
+  const int64_t tile0 = (int64_t)blockIdx.x * TILE;
+  {
+    const int64_t nfeat = a.feature_offsets[T];
+    const int64_t B = nfeat > 0 ? a.num_bags / nfeat : 0;
+    for (int t = threadIdx.x; t <= T; t += THREADS) {
+      s_seg[t] = a.offsets[a.feature_offsets[t] * B];
+      s_tbo[t] = a.tbo[t];
+      if (t < T) { s_tptr[t] = a.table_ptrs[t]; s_rowb[t] = (int)a.table_value_dims[t] * a.elem_bytes; }
+      if (blockIdx.x == 0) a.seg_out[t] = s_seg[t];
+    }
+    if (blockIdx.x == 0 && kTrain)
+      for (int64_t j = threadIdx.x; j <= a.nbu; j += THREADS) a.partial2[j] = 0;
+  }
+  for (int s = threadIdx.x; s < LDS; s += THREADS) { s_tab[s] = -1; s_cnt[s] = 0; }
+  if (threadIdx.x < HALVES) s_nrep[threadIdx.x] = 0;
+  __syncthreads();
+  int hh[PER], rk[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int li = q * THREADS + threadIdx.x;
+    const int64_t i = tile0 + li;
+    uint16_t tt = 0;
+    if (i < a.n) {
+      s_key[li] = a.keys[i];
+      int lo = 0, hi = T + 1;  // first t with seg[t] > i
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_seg[mid] <= i) lo = mid + 1; else hi = mid; }
+      tt = (uint16_t)(lo - 1 < 0 ? 0 : (lo - 1 >= T ? T - 1 : lo - 1));
+    }
+    s_t[li] = tt;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int li = q * THREADS + threadIdx.x;
+    hh[q] = -1;
+    rk[q] = 0;
+    if (tile0 + li < a.n) {
+      const uint64_t key = s_key[li];
+      const int t = s_t[li];
+      int h = (int)(fmix64(key + 0x9E3779B97F4A7C15ull * (uint64_t)t) >> 40) & (LDS - 1);
+      while (true) {
+        const int cur = atomicCAS(&s_tab[h], -1, li);
+        if (cur == -1) break;
+        if (s_key[cur] == key && s_t[cur] == t) { atomicMin(&s_tab[h], li); break; }
+        h = (h + 1) & (LDS - 1);
+      }
+      hh[q] = h;
+      rk[q] = atomicAdd(&s_cnt[h], 1);
+    }
+  }
+  __syncthreads();
+  bool isrep[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) isrep[q] = hh[q] >= 0 && s_tab[hh[q]] == q * THREADS + (int)threadIdx.x;
+  __syncthreads();   // s_tab / s_cnt change meaning below
+  // ---- probe: one lane per distinct key of the tile.  All bucket addresses first, then the first digest vector of
+  //      every probe (independent loads in flight), then the resolution.
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    if (!isrep[q]) continue;
+    const int li = q * THREADS + threadIdx.x;
+    const uint64_t key = s_key[li];
+    const int t = s_t[li];
+    const int cnt = s_cnt[hh[q]];
+    int gslot = (int)a.S, base = 0;     // default: no slot
+    bool defer = false;
+    if (is_valid(key)) {
+      const int64_t hash = (int64_t)(fmix64(key) & 0x7FFFFFFFFFFFFFFFull);
+      const int64_t bb = s_tbo[t];
+      const int64_t cap = (s_tbo[t + 1] - bb) * a.t.C;
+      if (cap > 0) {
+        const uint64_t local = (uint64_t)hash % (uint64_t)cap;
+        const int64_t b = bb + (int64_t)(local / (uint64_t)a.t.C);
+        bool inserted = false;
+        const int slot = thread_probe<kTrain>(a, b, key, hash, cnt, inserted);
+        if (slot >= 0) {
+          gslot = (int)(b * a.t.C + slot);
+          if (!inserted) score_found(a, a.t.scores(b) + (int64_t)slot * a.t.ns, cnt);
+          else { s_t[li] = (uint16_t)(t | 0x8000); s_gs[li] = gslot; }
+        } else if (slot == -2) {
+          defer = true;
+        }
+      }
+    }
+    if (kTrain) {
+      if (defer) {
+        const int e = atomicAdd(&a.hdr[0], 1);
+        a.d_key[e] = key; a.d_tid[e] = t; a.d_cnt[e] = cnt;
+        gslot = -(e + 2);
+      } else {
+        base = atomicAdd(&a.occ[gslot], cnt);
+      }
+    }
+    s_tab[hh[q]] = gslot;
+    s_cnt[hh[q]] = base;
+  }
+  __syncthreads();
+  int nrep[HALVES];
+#pragma unroll
+  for (int hq = 0; hq < HALVES; ++hq) nrep[hq] = 0;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int li = q * THREADS + threadIdx.x;
+    if (hh[q] >= 0) {
+      const int64_t i = tile0 + li;
+      const int g = s_tab[hh[q]];
+      const int r = s_cnt[hh[q]] + rk[q];
+      const int t = s_t[li] & 0x7fff;
+      a.occ_slot[i] = g;
+      if (kTrain) a.csr_rank[i] = r;
+      a.occ_addr[i] = (g >= 0 && g < a.S) ? s_tptr[t] + ((int64_t)g - s_tbo[t] * a.t.C) * s_rowb[t] : 0;
+      if (kTrain && g >= 0 && r == 0) ++nrep[li >> 10];
+    }
+  }
+  if (kTrain) {
+#pragma unroll
+    for (int hq = 0; hq < HALVES; ++hq) {
+      int v = nrep[hq];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane_id() == 0 && v) atomicAdd(&s_nrep[hq], v);
+    }
+    // first-touch initialisation of the rows this block inserted: a wave per row, coalesced stores
+    const int wave = threadIdx.x >> 6, nw = THREADS >> 6;
+    for (int base = wave * 64; base < TILE; base += nw * 64) {
+      const int li = base + lane_id();
+      uint64_t todo = __ballot((s_t[li] & 0x8000) != 0);
+      while (todo) {
+        const int src = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        const int l2 = base + src;
+        const int t = s_t[l2] & 0x7fff;
+        const int g = s_gs[l2];
+        void* rp = reinterpret_cast<void*>((uintptr_t)(s_tptr[t] + ((int64_t)g - s_tbo[t] * a.t.C) * s_rowb[t]));
+        wave_init_row(a, rp, s_key[l2], (int)a.table_emb_dims[t], (int)a.table_value_dims[t]);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < HALVES) {
+      const int64_t pt = (int64_t)blockIdx.x * HALVES + threadIdx.x;
+      if (pt * 1024 < a.n) a.partial[pt] = s_nrep[threadIdx.x];
+    }
+  }
+}
+
+// ---- deferred keys: bucket without a free slot -> evict the minimum score (kernels.cuh:226-287, types.cuh:398-512) ----
+__device__ __forceinline__ void grid_sync(int* ctr, int nblocks) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicAdd(ctr, 1);
+    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < nblocks) __builtin_amdgcn_s_sleep(4);
+    __threadfence();
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) fused_evict_kernel(FusedArgs a) {
+  if (!a.timer) a.timer = device_clock();
+  int nd = __hip_atomic_load(&a.hdr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (nd == 0) return;          // steady state: one empty launch
+  if ((int64_t)nd > a.n) nd = (int)a.n;
+  const int g = lane_id() & (G - 1);
+  const int gpb = blockDim.x / G;
+  const int C = (int)a.t.C;
+  for (int e0 = blockIdx.x * gpb; e0 < nd; e0 += gridDim.x * gpb) {
+    const int e = e0 + threadIdx.x / G;
+    const bool act = e < nd;
+    const uint64_t key = act ? a.d_key[e] : kEmptyKey;
+    const int tid = act ? a.d_tid[e] : 0;
+    const int cnt = act ? a.d_cnt[e] : 0;
+    Located L = locate(key, tid, a.tbo, a.t.C);
+    int gslot = (int)a.S;
+    bool done = !(act && L.ok);
+    int guard = 0;
+    while (__ballot(!done)) {
+      if (!done) {
+        int got = 0;
+        if (g == 0) got = atomicCAS(&a.locks[L.bucket], 0, 1) == 0 ? 1 : 0;
+        got = group_bcast(got, 0);
+        if (got) {
+          uint64_t* ks = a.t.keys(L.bucket);
+          int found_slot, empty_slot;
+          group_probe(a.t, L.bucket, key, L.hash, true, true, found_slot, empty_slot);
+          int slot = -1;
+          bool fresh_row = false;
+          if (found_slot >= 0) {             // another deferred entry of the same key got here first
+            slot = found_slot;
+            if (g == 0) score_found(a, a.t.scores(L.bucket) + (int64_t)slot * a.t.ns, cnt);
+          } else if (empty_slot >= 0) {      // a slot was freed meanwhile
+            slot = empty_slot;
+            fresh_row = true;
+            if (g == 0) {
+              store_digest(a.t.dig(L.bucket) + slot, digest_of(L.hash));
+              score_new(a, a.t.scores(L.bucket) + (int64_t)slot * a.t.ns, cnt);
+              atomicAdd(&a.bucket_sizes[L.bucket], 1);
+            }
+          } else {
+            uint64_t best = ~0ull, bkey = 0;
+            int bslot = -1;
+            const uint64_t* sc = a.t.scores(L.bucket);
+            const int32_t* pin = a.counter ? a.counter + L.bucket * a.t.C : nullptr;
+            const int32_t* oc = a.occ + L.bucket * a.t.C;
+            for (int s0 = 2 * g; s0 < C; s0 += 2 * G) {
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                const int s = s0 + u;
+                const uint64_t v = ald64(sc + (int64_t)s * a.t.ns + (a.t.ns - 1));
+                if (v < best) {
+                  const uint64_t k = ald64(ks + s);
+                  if (k == kLockedKey || k == kEmptyKey) continue;
+                  if (pin && __hip_atomic_load(pin + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;
+                  if (__hip_atomic_load(oc + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;  // used by this batch
+                  best = v; bslot = s; bkey = k;
+                }
+              }
+            }
+            group_argmin(best, bslot, bkey);
+            if (bslot >= 0) {
+              slot = bslot;
+              fresh_row = true;
+              if (g == 0) {
+                ast64(ks + slot, kLockedKey);
+                store_digest(a.t.dig(L.bucket) + slot, digest_of(L.hash));
+                for (int64_t w = 0; w < a.t.ns; ++w) ast64((uint64_t*)sc + (int64_t)slot * a.t.ns + w, 0);
+                score_new(a, a.t.scores(L.bucket) + (int64_t)slot * a.t.ns, cnt);
+                if (bkey == kReclaimKey) atomicAdd(&a.bucket_sizes[L.bucket], 1);
+              }
+            }
+          }
+          if (slot >= 0) {
+            gslot = (int)(L.bucket * a.t.C + slot);
+            if (fresh_row) {
+              void* rp = reinterpret_cast<void*>((uintptr_t)(a.table_ptrs[tid] + ((int64_t)gslot - a.tbo[tid] * a.t.C) *
+                                                                                a.table_value_dims[tid] * a.elem_bytes));
+              const int ed = (int)a.table_emb_dims[tid], vd = (int)a.table_value_dims[tid];
+              for (int el = g; el < vd; el += G) {
+                const float v = el < ed ? init_value(a.init, key, (uint32_t)el) : a.init.state_init;
+                if (a.value_dtype == kF32) st1<kF32>(rp, el, v);
+                else if (a.value_dtype == kBF16) st1<kBF16>(rp, el, v);
+                else st1<kF16>(rp, el, v);
+              }
+              if (g == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                ast64(ks + slot, key);
+              }
+            }
+          }
+          if (g == 0) {
+            // count the key's occurrences BEFORE the lock is released: occ > 0 is what protects the slot from the next
+            // eviction in this bucket
+            if (slot >= 0) { a.d_slot[e] = gslot; a.d_base[e] = atomicAdd(&a.occ[gslot], cnt); }
+            __threadfence();
+            __hip_atomic_store(&a.locks[L.bucket], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          done = true;
+        } else if (++guard > (1 << 22)) {
+          done = true;   // give up: the key gets no slot this step
+        }
+      }
+    }
+    if (act && g == 0 && gslot == (int)a.S) {   // no slot could be had: the key is served without a row this step
+      a.d_slot[e] = gslot;
+      a.d_base[e] = atomicAdd(&a.occ[gslot], cnt);
+    }
+  }
+  grid_sync(&a.hdr[1], (int)gridDim.x);
+  // patch the occurrences of the deferred keys
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int s = a.occ_slot[i];
+    if (s <= -2) {
+      const int e = -(s + 2);
+      const int gs = a.d_slot[e];
+      const int r = a.csr_rank[i] + a.d_base[e];
+      a.occ_slot[i] = gs;
+      a.csr_rank[i] = r;
+      int64_t addr = 0;
+      if (gs < a.S) {
+        const int t = a.d_tid[e];
+        addr = a.table_ptrs[t] + ((int64_t)gs - a.tbo[t] * a.t.C) * a.table_value_dims[t] * a.elem_bytes;
+      }
+      a.occ_addr[i] = addr;
+      if (r == 0) atomicAdd(&a.partial[i >> 10], 1);
+    }
+  }
+}
+
+// ---- unique numbering: the occurrence with rank 0 represents its slot -------------------------------------------------
+struct EmitOut {
+  uint64_t* unique_keys;
+  int64_t* table_offsets;   // [T+1]
+  int64_t* table_ids;       // [n] (nullable)
+  int64_t* slots;           // [n] table-relative slot of every unique key (-1: none)
+  int64_t* row_addr;        // [n] row address of every unique key
+  int64_t* freq;            // [n] nullable
+  int32_t* csr_cnt;         // [n]
+  int32_t* total;           // [1]
+  int* hot_counters;        // hot-list header (n_hot, n_tasks, .., n_wave) cleared here (nullable)
+};
+
+template <bool kSelf>
+__global__ void __launch_bounds__(kScanThreads)
+fused_emit_kernel(FusedArgs a, EmitOut o) {
+  __shared__ int s_p2[4];
+  __shared__ int s_ex[kScanTile + 1];       // exclusive representative count in front of every item of the tile
+  __shared__ int64_t s_seg[kFusedMaxT + 1];
+  const int64_t tile0 = (int64_t)blockIdx.x * kScanTile;
+  const int64_t n = a.n;
+  const int T = a.T;
+  int sl[kScanItems], rk[kScanItems], f[kScanItems], oc[kScanItems];
+  uint64_t ky[kScanItems];
+  int64_t ad[kScanItems];
+  int c = 0;
+  if (threadIdx.x < 4) s_p2[threadIdx.x] = 0;
+  for (int t = threadIdx.x; t <= T; t += kScanThreads) s_seg[t] = a.seg_out[t];
+  // every load is unconditional (clamped) and issued up front: the loads of a thread's four items overlap instead of
+  // queueing behind one exec-masked branch each
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const int64_t i = tile0 + threadIdx.x * kScanItems + k;
+    const int64_t ic = i < n ? i : n - 1;
+    sl[k] = a.occ_slot[ic];
+    rk[k] = a.csr_rank[ic];
+    ky[k] = a.keys[ic];
+    ad[k] = a.occ_addr[ic];
+  }
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const int64_t i = tile0 + threadIdx.x * kScanItems + k;
+    f[k] = (i < n) && (rk[k] == 0) && (sl[k] >= 0);
+    oc[k] = a.occ[sl[k] >= 0 ? sl[k] : 0];
+    c += f[k];
+  }
+  int tot;
+  const int pre = kSelf ? self_prefix(a.partial, blockIdx.x) : a.partial[blockIdx.x];
+  int ex = block_excl_scan(c, tot) + pre;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (o.hot_counters) { o.hot_counters[0] = 0; o.hot_counters[2] = 0; o.hot_counters[4] = 0; }
+    a.hdr[0] = 0;   // deferred-key list and grid barrier of the next step
+    a.hdr[1] = 0;
+  }
+  const int first_tile = pre >> 10;
+  int b0 = 0, b1 = 0;     // occurrences of my representatives that fall into unique tile first_tile / first_tile + 1
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    s_ex[threadIdx.x * kScanItems + k] = ex;
+    if (f[k]) {
+      const int s = sl[k];
+      a.occ[s] = 0;
+      a.uidmap[s] = ex;
+      o.unique_keys[ex] = ky[k];
+      o.csr_cnt[ex] = oc[k];
+      if (o.freq) o.freq[ex] = oc[k];
+      o.row_addr[ex] = ad[k];
+      int ti = 0;
+      if (T > 1) {
+        const int64_t i = tile0 + threadIdx.x * kScanItems + k;
+        int lo = 0, hi = T + 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_seg[mid] <= i) lo = mid + 1; else hi = mid; }
+        ti = lo - 1 < 0 ? 0 : (lo - 1 >= T ? T - 1 : lo - 1);
+      }
+      if (o.table_ids) o.table_ids[ex] = ti;
+      o.slots[ex] = s < a.S ? (int64_t)s - a.tbo[ti] * a.t.C : -1;
+      if ((ex >> 10) == first_tile) b0 += oc[k]; else b1 += oc[k];
+      ++ex;
+    }
+  }
+  if (threadIdx.x == kScanThreads - 1) s_ex[kScanTile] = ex;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { b0 += __shfl_down(b0, off, 64); b1 += __shfl_down(b1, off, 64); }
+  if (lane_id() == 0) { if (b0) atomicAdd(&s_p2[0], b0); if (b1) atomicAdd(&s_p2[1], b1); }
+  __syncthreads();
+  // unique offsets of the tables whose first key lies in this tile (or behind the batch: the last tile writes those)
+  for (int t = threadIdx.x; t <= T; t += kScanThreads) {
+    const int64_t p = s_seg[t];
+    if (p >= tile0 && p < tile0 + kScanTile && p < n) o.table_offsets[t] = s_ex[p - tile0];
+    else if (p >= n && blockIdx.x == gridDim.x - 1) o.table_offsets[t] = pre + tot;
+  }
+  if (threadIdx.x < 2 && s_p2[threadIdx.x]) atomicAdd(&a.partial2[first_tile + threadIdx.x], s_p2[threadIdx.x]);
+}
+
+// exclusive scan of the per-tile representative counts when there are too many tiles for every block to sum its
+// predecessors itself (batches beyond 4 M keys)
+__global__ void __launch_bounds__(kScanThreads) fused_scan_partials_kernel(int* partial, int64_t nb) {
+  __shared__ int s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int64_t b0 = 0; b0 < nb; b0 += kScanThreads) {
+    const int64_t b = b0 + threadIdx.x;
+    const int v = b < nb ? partial[b] : 0;
+    int tot;
+    const int ex = block_excl_scan(v, tot);
+    const int carry = s_carry;
+    if (b < nb) partial[b] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry = carry + tot;
+    __syncthreads();
+  }
+}
+
+}  // namespace mi355
+
+using namespace mi355;
+
+// Side stream on which the forward numbers the uniques and builds the backward's CSR while its own gather runs.
+// One per process; the join events form a small ring, a forward hands its token to the backward of the same batch
+// (the backward of a CUDA autograd node runs on another host thread than the forward: no thread-local state here).
+namespace {
+struct SideCsr {
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr;
+  hipEvent_t join[8] = {};
+  unsigned next = 0;
+  int last = -1;        // token of the most recent fork
+  bool joined = true;   // the most recent side work has been waited for on the main stream
+  bool ok = false;
+  pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+};
+SideCsr g_side;
+bool side_init() {
+  if (g_side.ok) return true;
+  if (hipStreamCreateWithFlags(&g_side.side, hipStreamNonBlocking) != hipSuccess) return false;
+  if (hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming) != hipSuccess) return false;
+  for (auto& e : g_side.join)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+  g_side.ok = true;
+  return true;
+}
+}  // namespace
+
+extern "C" {
+
+// (exported for callers with a stream-aware allocator, and used by pipeline.hip)
+void* mi355_early_csr_stream(void) {
+  pthread_mutex_lock(&g_side.mu);
+  const bool ok = side_init();
+  pthread_mutex_unlock(&g_side.mu);
+  return ok ? (void*)g_side.side : nullptr;
+}
+
+// fork: side waits for everything issued on `stream`; returns the side stream (nullptr on failure)
+hipStream_t mi355i_side_fork(hipStream_t stream) {
+  pthread_mutex_lock(&g_side.mu);
+  hipStream_t r = nullptr;
+  if (side_init() && hipEventRecord(g_side.fork, stream) == hipSuccess &&
+      hipStreamWaitEvent(g_side.side, g_side.fork, 0) == hipSuccess)
+    r = g_side.side;
+  pthread_mutex_unlock(&g_side.mu);
+  return r;
+}
+// record the join point of the work issued on the side stream since the fork; returns its token (< 0: failure)
+int mi355i_side_mark(void) {
+  pthread_mutex_lock(&g_side.mu);
+  int tok = (int)(g_side.next++ % 8);
+  if (hipEventRecord(g_side.join[tok], g_side.side) != hipSuccess) tok = -1;
+  else { g_side.last = tok; g_side.joined = false; }
+  pthread_mutex_unlock(&g_side.mu);
+  return tok;
+}
+// `stream` waits for the join point `token` (the side stream is in order, so a re-used event still covers the work)
+int mi355i_side_join(int token, hipStream_t stream) {
+  pthread_mutex_lock(&g_side.mu);
+  int rc = MI355_OK;
+  if (!g_side.ok || token < 0 || token >= 8 || hipStreamWaitEvent(stream, g_side.join[token], 0) != hipSuccess) rc = MI355_ELAUNCH;
+  else if (token == g_side.last) g_side.joined = true;
+  pthread_mutex_unlock(&g_side.mu);
+  return rc;
+}
+// a new forward must not start before the previous side work (which clears the slot counters) is done
+int mi355i_side_join_pending(hipStream_t stream) {
+  pthread_mutex_lock(&g_side.mu);
+  int rc = MI355_OK;
+  if (g_side.ok && !g_side.joined && g_side.last >= 0) {
+    if (hipStreamWaitEvent(stream, g_side.join[g_side.last], 0) != hipSuccess) rc = MI355_ELAUNCH;
+    else g_side.joined = true;
+  }
+  pthread_mutex_unlock(&g_side.mu);
+  return rc;
+}
+
+// public form of the join (a caller that reads the unique numbering of a fused forward before its backward)
+int mi355_side_join(int token, hipStream_t stream) {
+  const int rc = mi355i_side_join(token, stream);
+  if (rc != MI355_OK) mi355_set_error("side-stream join failed");
+  return rc;
+}
+
+int64_t mi355_demb_aux_numel(int64_t total_slots, int64_t num_buckets) {
+  return kAuxHdr + 2 * (total_slots + 1) + num_buckets;
+}
+
+static inline int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
+
+int64_t mi355_demb_forward_fused_workspace_bytes(int64_t n, int64_t num_tables) {
+  const int64_t nt = (n + 1023) / 1024 + 2, nbu = (n + 1) / 1024 + 3;
+  return al256(8 * (num_tables + 1)) + al256(8 * n) /*unique keys*/ + al256(8 * n) /*occ_addr*/ + al256(4 * n) /*occ_slot*/ +
+         al256(4 * nt) + al256(4 * nbu) + 256 /*total*/ + al256(8 * n) + 4 * al256(4 * n) /*deferred*/ + 256;
+}
+
+// The fused forward (see the header of this file).  Persisted outputs as mi355_demb_forward; in eval mode (train == 0)
+// only `out` is produced (no unique numbering).  `join_token` (train): >= 0 when the CSR was built on the side stream --
+// hand it to mi355_demb_backward(prepared = 2 + token); -1: built on `stream`.
+int mi355_demb_forward_fused(
+    /* table */ void* storage, const int64_t* table_bucket_offsets, int64_t bucket_capacity, int64_t num_scores,
+    int32_t* bucket_sizes, int32_t* counter, int64_t counter_numel, int32_t* aux, int64_t aux_numel, int64_t num_buckets,
+    /* values */ const int64_t* table_ptrs, const int64_t* table_value_dims, const int64_t* table_emb_dims,
+    int value_dtype, int64_t emb_dim, int64_t value_dim,
+    /* batch */ const void* keys, int64_t num_keys, const int64_t* offsets, int64_t num_bags, int64_t batch_size,
+    const int64_t* feature_offsets, int64_t num_tables,
+    /* policies */ int train, int find_policy, int insert_policy, uint64_t score_value, int use_count,
+    uint64_t timer_override, int pin,
+    /* initializer */ int init_mode, float p0, float p1, float p2, float p3, uint64_t seed, float state_init,
+    /* output */ int combiner, const int32_t* D_offsets, int64_t total_D, void* out, int out_dtype, int aligned16,
+    /* persisted */ int64_t* reverse_indices, int64_t* unique_offsets, int64_t* table_ids, int64_t* slots,
+    int64_t* row_addr, int64_t* freq, int32_t* csr_cnt, int32_t* csr_rank,
+    /* CSR of the backward */ void* backward_workspace, int64_t backward_workspace_bytes, int use_side_stream,
+    int* join_token,
+    /* scratch */ void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  MI355_CHECK_ARG(workspace && workspace_bytes >= mi355_demb_forward_fused_workspace_bytes(num_keys, num_tables), "workspace too small");
+  MI355_CHECK_ARG(num_tables >= 1 && num_tables <= kFusedMaxT, "fused forward: too many tables");
+  MI355_CHECK_ARG(bucket_capacity > 0 && bucket_capacity % 16 == 0, "bucket capacity must be a positive multiple of 16");
+  const int64_t S = num_buckets * bucket_capacity;
+  MI355_CHECK_ARG(S < 0x7fffff00LL && num_keys < 0x7fffff00LL, "fused forward: table / batch too large for 32-bit slots");
+  MI355_CHECK_ARG(aux && aux_numel >= mi355_demb_aux_numel(S, num_buckets), "aux buffer too small");
+  MI355_CHECK_ARG(find_policy >= kConst && find_policy <= kLruLfu && insert_policy >= kConst && insert_policy <= kLruLfu, "bad score policy");
+  MI355_CHECK_ARG((find_policy != kLruLfu && insert_policy != kLruLfu) || num_scores == 2, "LRU_LFU needs num_scores == 2");
+  if (join_token) *join_token = -1;
+  if (num_keys == 0 && combiner < 0) return MI355_OK;
+  int rc;
+#define STEP(call) do { rc = (call); if (rc != MI355_OK) return rc; } while (0)
+  STEP(mi355i_side_join_pending(stream));
+  uint8_t* w = (uint8_t*)workspace;
+  const int64_t n = num_keys;
+  const int64_t nt = (n + 1023) / 1024 + 2, nbu = (n + 1) / 1024 + 1;
+  FusedArgs a;
+  a.t = make_table(storage, bucket_capacity, num_scores);
+  a.tbo = table_bucket_offsets; a.bucket_sizes = bucket_sizes; a.counter = counter;
+  a.hdr = aux; a.occ = aux + kAuxHdr; a.uidmap = a.occ + (S + 1); a.locks = a.uidmap + (S + 1); a.S = S;
+  a.table_ptrs = table_ptrs; a.table_value_dims = table_value_dims; a.table_emb_dims = table_emb_dims;
+  a.elem_bytes = value_dtype == 0 ? 4 : 2; a.value_dtype = value_dtype;
+  a.keys = (const uint64_t*)keys; a.n = n; a.offsets = offsets; a.feature_offsets = feature_offsets; a.num_bags = num_bags;
+  a.T = (int)num_tables; a.find_policy = find_policy; a.insert_policy = insert_policy; a.use_count = use_count;
+  a.score_value = score_value; a.timer = timer_override;
+  a.init = InitArgs{init_mode, p0, p1, p2, p3, seed, state_init};
+  a.seg_out = (int64_t*)w; w += al256(8 * (num_tables + 1));
+  uint64_t* unique_keys = (uint64_t*)w; w += al256(8 * n);
+  a.occ_addr = (int64_t*)w; w += al256(8 * n);
+  a.occ_slot = (int32_t*)w; w += al256(4 * n);
+  a.partial = (int32_t*)w; w += al256(4 * nt);
+  a.partial2 = (int32_t*)w; w += al256(4 * (nbu + 2));
+  int32_t* total = (int32_t*)w; w += 256;
+  a.nbu = nbu;
+  a.d_key = (uint64_t*)w; w += al256(8 * n);
+  a.d_tid = (int32_t*)w; w += al256(4 * n);
+  a.d_cnt = (int32_t*)w; w += al256(4 * n);
+  a.d_slot = (int32_t*)w; w += al256(4 * n);
+  a.d_base = (int32_t*)w; w += al256(4 * n);
+  a.csr_rank = csr_rank;
+  if (train) MI355_CHECK_ARG(reverse_indices && unique_offsets && slots && row_addr && csr_cnt && csr_rank, "persisted outputs required in train mode");
+  if (n > 0) {
+    // keys per tile / threads per block: one key per thread keeps every probe chain (digest vector -> key -> slot counter)
+    // in flight at once; larger tiles cost fewer (tile, key) pairs = fewer device-scope atomics
+    static const int cfg_env = getenv("MI355_FUSED_CFG") ? atoi(getenv("MI355_FUSED_CFG")) : -1;
+    const int cfg = cfg_env >= 0 ? cfg_env : 0;
+#define LAUNCH_PROBE(TILE, THREADS)                                                                                        \
+  do {                                                                                                                     \
+    const unsigned grid = (unsigned)ceil_div(n, TILE);                                                                     \
+    if (train) hipLaunchKernelGGL((fused_probe_kernel<TILE, THREADS, true>), dim3(grid), dim3(THREADS), 0, stream, a);    \
+    else hipLaunchKernelGGL((fused_probe_kernel<TILE, THREADS, false>), dim3(grid), dim3(THREADS), 0, stream, a);         \
+  } while (0)
+    switch (cfg) {
+      case 1: LAUNCH_PROBE(1024, 256); break;
+      case 2: LAUNCH_PROBE(2048, 512); break;
+      case 3: LAUNCH_PROBE(2048, 1024); break;
+      case 4: LAUNCH_PROBE(1024, 512); break;
+      default: LAUNCH_PROBE(1024, 1024); break;
+    }
+#undef LAUNCH_PROBE
+    MI355_LAUNCH_CHECK();
+    if (train) {
+      static int ncu = 0;
+      if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+        if (ncu <= 0) ncu = 64;
+      }
+      hipLaunchKernelGGL(fused_evict_kernel, dim3((unsigned)ncu), dim3(256), 0, stream, a);
+      MI355_LAUNCH_CHECK();
+    }
+  }
+  // ---- train: unique numbering + CSR of the backward on the side stream (forked BEFORE the gather is queued, so both
+  //      start as soon as the index stage is done); eval: only the gather
+  hipStream_t cs = stream;
+  bool forked = false;
+  if (train && n > 0 && use_side_stream && combiner != -2) {
+    hipStream_t s2 = mi355i_side_fork(stream);
+    if (!s2) { mi355_set_error("side stream fork failed"); return MI355_ELAUNCH; }
+    cs = s2;
+    forked = true;
+  }
+  auto gather = [&]() -> int {
+    if (combiner >= 0)
+      return mi355_gather_pooled(nullptr, 0, a.occ_addr, value_dtype, nullptr, n, offsets, num_bags, batch_size, combiner,
+                                 emb_dim, D_offsets, total_D, out, out_dtype, aligned16, stream);
+    if (combiner == -1)
+      return mi355_gather_rows(nullptr, 0, a.occ_addr, value_dtype, nullptr, n, nullptr, emb_dim, out, emb_dim, out_dtype,
+                               aligned16, stream);
+    return MI355_OK;
+  };
+  if (forked) STEP(gather());
+  if (train && n > 0) {
+    EmitOut o;
+    o.unique_keys = unique_keys; o.table_offsets = unique_offsets; o.table_ids = table_ids; o.slots = slots;
+    o.row_addr = row_addr; o.freq = freq; o.csr_cnt = csr_cnt; o.total = total + 8; o.hot_counters = nullptr;
+    const int64_t* nu_dev = unique_offsets + num_tables;
+    uint8_t* bw = (uint8_t*)backward_workspace;
+    int32_t* bptr = nullptr; int32_t* bcsr = nullptr; void* hot_ws = nullptr; int64_t hot_bytes_ = 0;
+    if (backward_workspace) {
+      MI355_CHECK_ARG(backward_workspace_bytes >= mi355_demb_backward_workspace_bytes(n, emb_dim), "backward workspace too small");
+      bptr = (int32_t*)bw; bw += al256(4 * (n + 1));
+      bcsr = (int32_t*)bw; bw += al256(4 * n);
+      bw += mi355_group_by_unique_workspace_bytes(n, n);
+      hot_ws = bw; hot_bytes_ = mi355_backward_workspace_bytes(n, emb_dim);
+      o.hot_counters = (int*)hot_ws;
+    }
+    const int64_t ntile = ceil_div(n, kScanTile);
+    if (ntile <= kSelfPrefixMaxTiles) {
+      hipLaunchKernelGGL(fused_emit_kernel<true>, dim3((unsigned)ntile), dim3(kScanThreads), 0, cs, a, o);
+    } else {
+      hipLaunchKernelGGL(fused_scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, cs, a.partial, ntile);
+      hipLaunchKernelGGL(fused_emit_kernel<false>, dim3((unsigned)ntile), dim3(kScanThreads), 0, cs, a, o);
+    }
+    MI355_LAUNCH_CHECK();
+    STEP(mi355i_csr_from_slots(csr_cnt, csr_rank, a.occ_slot, a.uidmap, reverse_indices, n, combiner >= 0 ? offsets : nullptr,
+                               num_bags, nu_dev, a.partial2, total, bptr, bcsr, hot_ws, hot_bytes_, emb_dim, cs));
+    if (pin) STEP(mi355_table_update_counter(counter, counter_numel, slots, n, nu_dev, 1, table_ids, table_bucket_offsets,
+                                             bucket_capacity, cs));
+    if (forked) {
+      const int tok = mi355i_side_mark();
+      if (tok < 0) { mi355_set_error("side stream join record failed"); return MI355_ELAUNCH; }
+      if (join_token) *join_token = tok;
+      else STEP(mi355i_side_join(tok, stream));
+    }
+  }
+  if (!forked) STEP(gather());
+#undef STEP
+  return MI355_OK;
+}
+
+}  // extern "C"

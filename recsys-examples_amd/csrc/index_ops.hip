@@ -23,61 +23,9 @@
 #include "hot.h"
 #include "../../include/recsys_amd.h"
 #include "internal.h"
+#include "scan_dev.h"
 
 namespace mi355 {
-
-constexpr int kScanThreads = 256;
-constexpr int kScanItems = 4;
-constexpr int kScanTile = kScanThreads * kScanItems;  // 1024
-
-__device__ __forceinline__ int wave_incl_scan(int v) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    int o = __shfl_up(v, off, 64);
-    if (lane_id() >= off) v += o;
-  }
-  return v;
-}
-
-// exclusive scan of one int per thread across a 256-thread block; returns the block total in `total`
-__device__ __forceinline__ int block_excl_scan(int v, int& total) {
-  __shared__ int s_w[kScanThreads / 64 + 1];
-  const int w = threadIdx.x >> 6;
-  int incl = wave_incl_scan(v);
-  if (lane_id() == 63) s_w[w] = incl;
-  __syncthreads();
-  int base = 0, tot = 0;
-#pragma unroll
-  for (int k = 0; k < kScanThreads / 64; ++k) {
-    int x = s_w[k];
-    if (k < w) base += x;
-    tot += x;
-  }
-  __syncthreads();
-  total = tot;
-  return base + incl - v;
-}
-
-// Tile prefix without a scan launch: the block sums the per-tile counts of all earlier tiles itself.  With a few
-// hundred tiles that is one or two loads per thread, cheaper than the ~5 us a dependent one-block kernel costs in the
-// launch chain.  (Callers fall back to scan_partials_kernel above kSelfPrefixMaxTiles.)
-constexpr int64_t kSelfPrefixMaxTiles = 4096;
-__device__ __forceinline__ int self_prefix(const int* __restrict__ partial, int b) {
-  int s = 0;
-  for (int j = threadIdx.x; j < b; j += kScanThreads) s += partial[j];
-  int tot;
-  block_excl_scan(s, tot);
-  return tot;
-}
-
-__device__ __forceinline__ int upper_bound_i64(const int64_t* __restrict__ a, int n, int64_t x) {
-  int lo = 0, hi = n;  // first index with a[idx] > x
-  while (lo < hi) {
-    int mid = (lo + hi) >> 1;
-    if (a[mid] <= x) lo = mid + 1; else hi = mid;
-  }
-  return lo;
-}
 
 // ---------------------------------------------------------------------------------------------
 // segmented unique
@@ -606,9 +554,12 @@ csr_fill_kernel(const int64_t* __restrict__ rev, int64_t n, const int64_t* __res
 // pass 2 when the forward already ranked every occurrence inside its unique row (mi355_segmented_unique_csr):
 // csr_src[ptr[rev[j]] + rank[j]] = src id of key j.  No atomics, no LDS hash; the bag resolution and the hot-row task
 // expansion are those of csr_fill_kernel.
+// kSlot: the unique id of key j is uidmap[slot[j]] (fused forward, fused_fwd.hip) and is also written to rev_out[j].
+template <bool kSlot>
 __global__ void __launch_bounds__(256)
 csr_scatter_kernel(const int64_t* __restrict__ rev, const int* __restrict__ rank, int64_t n, const int64_t* __restrict__ offsets,
-                   int64_t num_bags, const int* __restrict__ ptr, int* __restrict__ csr_src, HotList hot, bool build_hot) {
+                   int64_t num_bags, const int* __restrict__ ptr, int* __restrict__ csr_src, HotList hot, bool build_hot,
+                   const int* __restrict__ slot, const int* __restrict__ uidmap, int64_t* __restrict__ rev_out) {
   if (build_hot) {
     int nh = *hot.n_hot;
     nh = nh < hot.max_hot ? nh : hot.max_hot;
@@ -672,16 +623,28 @@ csr_scatter_kernel(const int64_t* __restrict__ rev, const int* __restrict__ rank
   for (int q = 0; q < NQ; ++q) {
     int64_t j = tile0 + q * 256 + threadIdx.x;
     j = j < n ? j : n - 1;
-    r[q] = rev[j];
+    if constexpr (kSlot) r[q] = slot[j]; else r[q] = rev[j];
     rk[q] = rank[j];
+  }
+  if constexpr (kSlot) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) r[q] = uidmap[r[q]];
   }
 #pragma unroll
   for (int q = 0; q < NQ; ++q) p[q] = ptr[r[q]];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int64_t j = tile0 + q * 256 + threadIdx.x;
-    if (j < n) csr_src[p[q] + rk[q]] = offsets ? s_bag[q * 256 + threadIdx.x] : (int)j;
+    if (j < n) {
+      csr_src[p[q] + rk[q]] = offsets ? s_bag[q * 256 + threadIdx.x] : (int)j;
+      if constexpr (kSlot) rev_out[j] = r[q];
+    }
   }
+}
+
+__global__ void __launch_bounds__(256)
+rev_from_slots_kernel(const int* __restrict__ slot, const int* __restrict__ uidmap, int64_t n, int64_t* __restrict__ rev) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) rev[i] = uidmap[slot[i]];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1240,8 +1203,43 @@ int mi355_group_by_unique_csr(const int32_t* csr_cnt, const int32_t* csr_rank, c
     hipLaunchKernelGGL(scan_down_kernel<false>, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, csr_cnt, max_unique, nu_dev, partial, total,
                        ptr, hot, hot_workspace != nullptr);
   }
-  if (n > 0) hipLaunchKernelGGL(csr_scatter_kernel, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, reverse_indices, csr_rank, n,
-                                offsets, num_bags, ptr, csr_src, hot, hot_workspace != nullptr);
+  if (n > 0) hipLaunchKernelGGL(csr_scatter_kernel<false>, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, reverse_indices, csr_rank, n,
+                                offsets, num_bags, ptr, csr_src, hot, hot_workspace != nullptr, (const int*)nullptr, (const int*)nullptr,
+                                (int64_t*)nullptr);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+// Second half of the fused forward (fused_fwd.hip): the emit pass left occurrences per unique row in csr_cnt, their sums
+// per 1024 uniques in `partial2` and the unique id of every table slot in `uidmap`; this scans the counts into `ptr`,
+// registers the hot rows and scatters the bag of every key into its row's list -- and writes the reverse indices.
+// ptr == NULL (no backward workspace): only the reverse indices are produced.
+int mi355i_csr_from_slots(const int32_t* csr_cnt, const int32_t* csr_rank, const int32_t* occ_slot, const int32_t* uidmap,
+                          int64_t* reverse_indices, int64_t n, const int64_t* offsets, int64_t num_bags, const int64_t* nu_dev,
+                          const int32_t* partial2, int32_t* total, int32_t* ptr, int32_t* csr_src, void* hot_workspace,
+                          int64_t hot_workspace_bytes, int64_t dim, hipStream_t stream) {
+  MI355_CHECK_ARG(n < 0x7fffffffLL, "n must be < 2^31");
+  if (n == 0) return MI355_OK;
+  const int64_t nbu = ceil_div(n + 1, kScanTile);
+  HotList hot{};
+  if (hot_workspace) {
+    MI355_CHECK_ARG(hot_workspace_bytes >= hot_bytes(n, dim), "hot workspace too small");
+    hot = hot_carve(hot_workspace, n, dim);
+  }
+  if (ptr) {
+    if (nbu <= kSelfPrefixMaxTiles) {
+      hipLaunchKernelGGL(scan_down_kernel<true>, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, csr_cnt, n, nu_dev, partial2, total, ptr,
+                         hot, hot_workspace != nullptr);
+    } else {
+      hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, stream, const_cast<int32_t*>(partial2), nbu, total);
+      hipLaunchKernelGGL(scan_down_kernel<false>, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, csr_cnt, n, nu_dev, partial2, total, ptr,
+                         hot, hot_workspace != nullptr);
+    }
+    hipLaunchKernelGGL(csr_scatter_kernel<true>, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, (const int64_t*)nullptr,
+                       csr_rank, n, offsets, num_bags, ptr, csr_src, hot, hot_workspace != nullptr, occ_slot, uidmap, reverse_indices);
+  } else {
+    hipLaunchKernelGGL(rev_from_slots_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, occ_slot, uidmap, n, reverse_indices);
+  }
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }

@@ -40,4 +40,23 @@ int mi355i_unlock_init_rows(void* storage, const int64_t* table_bucket_offsets, 
                             const int64_t* n_dev, const void* keys, int dtype, int64_t emb_dim, int64_t value_dim,
                             const uint8_t* results, const uint8_t* skip, const int64_t* table_ids,
                             const int64_t* table_emb_dims, const int64_t* table_value_dims, hipStream_t stream);
+
+int mi355i_table_update_counter_where(int32_t* counter, int64_t counter_numel, const int64_t* slot_indices, int64_t n,
+                                      const int64_t* n_dev, int32_t delta, const int64_t* table_ids,
+                                      const int64_t* table_bucket_offsets, int64_t C, const uint8_t* flags, int want,
+                                      hipStream_t stream);
+
+// second half of the fused forward (fused_fwd.hip): scan of the per-unique counts, hot-row registration, CSR scatter and
+// reverse indices from the slot-indexed unique ids
+int mi355i_csr_from_slots(const int32_t* csr_cnt, const int32_t* csr_rank, const int32_t* occ_slot, const int32_t* uidmap,
+                          int64_t* reverse_indices, int64_t n, const int64_t* offsets, int64_t num_bags, const int64_t* nu_dev,
+                          const int32_t* partial2, int32_t* total, int32_t* ptr, int32_t* csr_src, void* hot_workspace,
+                          int64_t hot_workspace_bytes, int64_t dim, hipStream_t stream);
+
+// the library's side stream (fused_fwd.hip): fork from `stream`, mark the join point of the side work (-> token), make a
+// stream wait for a token, make a stream wait for whatever side work has not been joined yet
+hipStream_t mi355i_side_fork(hipStream_t stream);
+int mi355i_side_mark(void);
+int mi355i_side_join(int token, hipStream_t stream);
+int mi355i_side_join_pending(hipStream_t stream);
 }

@@ -17,31 +17,6 @@ extern "C" {
 // Scratch layout helper: byte offsets of the per-step arrays inside one workspace.
 static inline int64_t al(int64_t x) { return (x + 255) / 256 * 256; }
 
-// Side stream on which the forward builds the backward's CSR while its own lookup / gather kernels run (early CSR,
-// see mi355_demb_forward).  One per host thread (= per GPU process here); events are recorded / waited in call order.
-struct EarlyCsr {
-  hipStream_t side = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  bool ok = false;
-};
-static EarlyCsr* early_csr() {
-  static thread_local EarlyCsr e;
-  if (!e.ok) {
-    if (hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-    e.ok = true;
-  }
-  return &e;
-}
-
-// the side stream of the early CSR build (a caller whose allocator is stream aware -- torch -- records the backward
-// workspace on it, so that a buffer dropped without a backward is not reused under the running side kernels)
-void* mi355_early_csr_stream(void) {
-  EarlyCsr* e = early_csr();
-  return e ? (void*)e->side : nullptr;
-}
-
 int64_t mi355_demb_forward_workspace_bytes(int64_t num_keys, int64_t num_tables) {
   return al(8 * (num_tables + 1)) /*table_range*/ + al(8 * num_keys) /*unique_keys*/ + al(num_keys) /*founds*/ +
          al(num_keys) /*results*/ + mi355_segmented_unique_workspace_bytes(num_keys) + 256;
@@ -75,9 +50,13 @@ int mi355_demb_forward(
        key-grouping half of the backward then runs on a side stream, forked right after the dedup, under the lookup /
        gather kernels of this forward.  The buffer must stay alive until that backward has been issued. */
     void* backward_workspace, int64_t backward_workspace_bytes,
+    /* out (nullable): token of the side-stream join point, for mi355_demb_backward(prepared = 2 + token); -1 when no
+       early CSR was started.  NULL: the early CSR is joined on `stream` before this call returns. */
+    int* join_token,
     /* scratch */ void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   MI355_CHECK_ARG(workspace && workspace_bytes >= mi355_demb_forward_workspace_bytes(num_keys, num_tables),
                   "workspace too small");
+  if (join_token) *join_token = -1;
   if (num_keys == 0 && combiner < 0) return MI355_OK;  // (pooled output of an empty batch is still zero-filled below)
   uint8_t* w = (uint8_t*)workspace;
   int64_t* table_range = (int64_t*)w; w += al(8 * (num_tables + 1));
@@ -95,11 +74,8 @@ int mi355_demb_forward(
                                table_ids, uws, uws_bytes, stream));
   if (backward_workspace && train && csr_cnt && csr_rank && num_keys > 0 && combiner != -2) {
     MI355_CHECK_ARG(backward_workspace_bytes >= mi355_demb_backward_workspace_bytes(num_keys, emb_dim), "backward workspace too small");
-    EarlyCsr* e = early_csr();
-    if (!e) { mi355_set_error("side stream / event creation failed"); return MI355_ELAUNCH; }
-    if (hipEventRecord(e->fork, stream) != hipSuccess || hipStreamWaitEvent(e->side, e->fork, 0) != hipSuccess) {
-      mi355_set_error("early CSR fork failed"); return MI355_ELAUNCH;
-    }
+    hipStream_t side = mi355i_side_fork(stream);
+    if (!side) { mi355_set_error("early CSR fork failed"); return MI355_ELAUNCH; }
     uint8_t* bw = (uint8_t*)backward_workspace;
     int32_t* bptr = (int32_t*)bw; bw += al(4 * (num_keys + 1));
     int32_t* bcsr = (int32_t*)bw; bw += al(4 * num_keys);
@@ -108,8 +84,11 @@ int mi355_demb_forward(
     bw += gws_bytes;
     STEP(mi355_group_by_unique_csr(csr_cnt, csr_rank, reverse_indices, num_keys, combiner >= 0 ? offsets : nullptr,
                                    num_bags, num_keys, nu_dev, bptr, bcsr, gws, gws_bytes, bw,
-                                   mi355_backward_workspace_bytes(num_keys, emb_dim), emb_dim, e->side));
-    if (hipEventRecord(e->join, e->side) != hipSuccess) { mi355_set_error("early CSR join record failed"); return MI355_ELAUNCH; }
+                                   mi355_backward_workspace_bytes(num_keys, emb_dim), emb_dim, side));
+    const int tok = mi355i_side_mark();
+    if (tok < 0) { mi355_set_error("early CSR join record failed"); return MI355_ELAUNCH; }
+    if (join_token) *join_token = tok;
+    else STEP(mi355i_side_join(tok, stream));
   }
   if (!find_scores) find_scores = freq;      // LFU: scores are the occurrence counts of this batch
   if (!insert_scores) insert_scores = freq;
@@ -117,6 +96,11 @@ int mi355_demb_forward(
     STEP(mi355i_table_lookup(storage, table_bucket_offsets, bucket_capacity, num_scores, num_keys, nu_dev, unique_keys,
                             table_ids, find_scores, find_policy, timer_override, nullptr, founds, slots, stream));
     if (train) {
+      // The slots this batch's lookup found must not be evicted by this batch's insert (the reference pins them with
+      // increment_counter before the insert, _prefetch_hbm_direct_path batched_dynamicemb_function.py:559-696): +1 on the
+      // found slots now, released after the unlock pass unless the caller keeps the pin (prefetch).
+      STEP(mi355_table_update_counter(counter, counter_numel, slots, num_keys, nu_dev, 1, table_ids, table_bucket_offsets,
+                                      bucket_capacity, stream));
       // insert (slots stay locked); then ONE launch publishes the keys (unlock), writes the row address of every unique
       // key and initialises the rows that are new
       STEP(mi355i_table_insert(storage, table_bucket_offsets, bucket_capacity, num_scores, bucket_sizes, counter,
@@ -127,9 +111,14 @@ int mi355_demb_forward(
                                    value_dtype == 0 ? 4 : 2, row_addr, init_mode, p0, p1, p2, p3, seed, state_init, num_keys,
                                    nu_dev, unique_keys, value_dtype, emb_dim, value_dim, results, founds, table_ids,
                                    table_emb_dims, table_value_dims, stream));
+      // the pre-insert pin covered the FOUND slots only (-1 elsewhere then); prefetch keeps a pin on every slot of the
+      // batch, so: release the found ones when nothing is kept, or add the new ones when it is
       if (pin)
-        STEP(mi355_table_update_counter(counter, counter_numel, slots, num_keys, nu_dev, 1, table_ids,
-                                        table_bucket_offsets, bucket_capacity, stream));
+        STEP(mi355i_table_update_counter_where(counter, counter_numel, slots, num_keys, nu_dev, 1, table_ids,
+                                               table_bucket_offsets, bucket_capacity, founds, 0, stream));
+      else
+        STEP(mi355i_table_update_counter_where(counter, counter_numel, slots, num_keys, nu_dev, -1, table_ids,
+                                               table_bucket_offsets, bucket_capacity, founds, 1, stream));
     } else {
       STEP(mi355_row_addresses(num_keys, nu_dev, slots, table_ids, table_ptrs, table_value_dims,
                                value_dtype == 0 ? 4 : 2, row_addr, stream));
@@ -165,7 +154,8 @@ int mi355_demb_backward(
     const int64_t* table_bucket_offsets, int64_t bucket_capacity, int unpin,
     /* CSR ingredients persisted by the forward (both or neither) */ const int32_t* csr_cnt, const int32_t* csr_rank,
     /* prepared != 0: `workspace` is the buffer the forward of this batch received as backward_workspace -- the grouping is
-       already done (or still running on the side stream: joined here) */ int prepared,
+       already done: 1 = on this stream, 2 + token = on the library's side stream (joined here; token from the forward) */
+    int prepared,
     void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   MI355_CHECK_ARG(workspace && workspace_bytes >= mi355_demb_backward_workspace_bytes(num_keys, dim), "workspace too small");
   if (num_keys == 0) return MI355_OK;
@@ -179,9 +169,10 @@ int mi355_demb_backward(
   const int64_t bws_bytes = mi355_backward_workspace_bytes(num_keys, dim);
   const int64_t* nu_dev = unique_offsets + num_tables;
   int rc;
-  if (prepared) {
-    EarlyCsr* e = early_csr();
-    if (!e || hipStreamWaitEvent(stream, e->join, 0) != hipSuccess) { mi355_set_error("early CSR join failed"); return MI355_ELAUNCH; }
+  if (prepared >= 2) {
+    rc = mi355i_side_join(prepared - 2, stream);
+    if (rc != MI355_OK) { mi355_set_error("early CSR join failed"); return rc; }
+  } else if (prepared == 1) {
     rc = MI355_OK;
   } else if (csr_cnt && csr_rank)
     rc = mi355_group_by_unique_csr(csr_cnt, csr_rank, reverse_indices, num_keys, combiner >= 0 ? offsets : nullptr, num_bags,

@@ -20,6 +20,7 @@
 //  * HBM-bound: no LDS, no MFMA.  Occupancy (small VGPR count) supplies the latency hiding.
 #include "common.h"
 #include "internal.h"
+#include "init_dev.h"
 #include <stdlib.h>
 
 namespace mi355 {
@@ -130,7 +131,7 @@ __global__ void __launch_bounds__(256) gather_pooled_vec_kernel(PoolArgs a, int 
           j = j < hi[b] ? j : hi[b] - 1;
           j = j < lo[b] ? lo[b] : j;           // empty bag: any in-range key (a.n > 0 here)
           j = j < a.n ? j : a.n - 1;
-          u[b][q] = a.rev[j];
+          u[b][q] = a.rev ? a.rev[j] : j;
         }
       // hop 2: row addresses
       uintptr_t rp[NB][RPR];
@@ -190,7 +191,9 @@ __global__ void __launch_bounds__(256) gather_pooled_vec_kernel(PoolArgs a, int 
 // of a bag are independent loads instead of RPR-wide rounds of a three-hop chain.  The index hops of bag i+1 (row
 // addresses) and i+2 (reverse indices) are issued BEFORE the row loads of bag i -- one wait per bag with everything
 // in flight.  Rows are added in key order (bit-identical to the sequential sum).
-template <int SDT, int DDT, bool kAddr, int UNR, int KIT>
+// kAddr: 0 dense source, 1 row addresses per UNIQUE key (through rev), 2 row addresses per OCCURRENCE (fused forward: the
+// reverse-index hop does not exist)
+template <int SDT, int DDT, int kAddr, int UNR, int KIT>
 __global__ void __launch_bounds__(256) gather_pooled_pipe_kernel(PoolArgs a, int lpr_log2) {
   const int lane = lane_id();
   const int LPR = 1 << lpr_log2;
@@ -221,7 +224,7 @@ __global__ void __launch_bounds__(256) gather_pooled_pipe_kernel(PoolArgs a, int
     j = j < hi ? j : hi - 1;
     j = j < 0 ? 0 : j;
     j = j < a.n ? j : a.n - 1;
-    return a.rev[j];
+    if constexpr (kAddr == 2) return j; else return a.rev[j];
   };
   // stage 2: its row address (0: no such key in this sub-chunk / missing row)
   auto my_row = [&](int64_t u, int64_t lo, int64_t hi, int64_t r) -> uintptr_t {
@@ -299,7 +302,7 @@ __global__ void __launch_bounds__(256) gather_pooled_scalar_kernel(PoolArgs a) {
 #pragma unroll
     for (int k = 0; k < kMaxCol; ++k) acc[k] = 0.f;
     for (int64_t j = lo; j < hi; ++j) {
-      const void* rp = src_row<SDT>(a, a.rev[j]);
+      const void* rp = src_row<SDT>(a, a.rev ? a.rev[j] : j);
       if (!rp) continue;
 #pragma unroll
       for (int k = 0; k < kMaxCol; ++k) {
@@ -397,47 +400,6 @@ row_addr_kernel(int64_t n, const int64_t* __restrict__ n_dev, const int64_t* __r
     const int64_t t = table_ids ? table_ids[i] : 0;
     addr[i] = s < 0 ? 0 : table_ptrs[t] + s * table_value_dims[t] * elem_bytes;
   }
-}
-
-// ---- counter-based RNG (Philox4x32-10): value depends only on (seed, row key, element), never on
-// the launch geometry, so first-touch initialisation is reproducible on any device layout ----
-__device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key) {
-  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
-    uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
-    ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
-    key.x += W0; key.y += W1;
-  }
-  return ctr;
-}
-__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
-
-enum InitMode : int { kInitUniform = 0, kInitNormal = 1, kInitTruncNormal = 2, kInitConst = 3, kInitDebug = 4 };
-
-struct InitArgs {
-  int mode;
-  float p0, p1, p2, p3;  // uniform: lower, upper; normal: mean, std; trunc: mean, std, lower, upper; const: value
-  uint64_t seed;
-  float state_init;      // initial optimizer-state value for elements [emb_dim, value_dim)
-};
-
-__device__ __forceinline__ float init_value(const InitArgs& a, uint64_t key, uint32_t e) {
-  if (a.mode == kInitConst) return a.p0;
-  if (a.mode == kInitDebug) return (float)(key % 100000ull);  // initializer.cuh:158-176
-  uint4 r = philox4x32(make_uint4((uint32_t)key, (uint32_t)(key >> 32), e, 0u),
-                       make_uint2((uint32_t)a.seed, (uint32_t)(a.seed >> 32)));
-  if (a.mode == kInitUniform) return a.p0 + (a.p1 - a.p0) * u01(r.x);
-  // Box-Muller; truncated normal by rejection over the 2 x 2 draws, then clamp (initializer.cuh)
-  float n0 = sqrtf(-2.f * __logf(u01(r.x))) * __cosf(6.28318530718f * u01(r.y));
-  float n1 = sqrtf(-2.f * __logf(u01(r.z))) * __cosf(6.28318530718f * u01(r.w));
-  float v = a.p0 + a.p1 * n0;
-  if (a.mode == kInitTruncNormal) {
-    if (v < a.p2 || v > a.p3) v = a.p0 + a.p1 * n1;
-    v = fminf(fmaxf(v, a.p2), a.p3);
-  }
-  return v;
 }
 
 // rows[i] (by address or dense) <- initializer(key_i); only where mask[i] != 0 (mask nullable) and,
@@ -559,8 +521,9 @@ static int launch_pooled(PoolArgs a, bool vec, hipStream_t stream) {
         const int grid = grid_for(a.FB, 4 * nsub * KIT, 1 << 20);
 #define MI355_POOL_P(UNRV)                                                                                                   \
   do {                                                                                                                       \
-    if (a.row_addr) hipLaunchKernelGGL((gather_pooled_pipe_kernel<SDT, DDT, true, UNRV, KIT>), dim3(grid), dim3(256), 0, stream, a, l); \
-    else hipLaunchKernelGGL((gather_pooled_pipe_kernel<SDT, DDT, false, UNRV, KIT>), dim3(grid), dim3(256), 0, stream, a, l); \
+    if (a.row_addr && !a.rev) hipLaunchKernelGGL((gather_pooled_pipe_kernel<SDT, DDT, 2, UNRV, KIT>), dim3(grid), dim3(256), 0, stream, a, l); \
+    else if (a.row_addr) hipLaunchKernelGGL((gather_pooled_pipe_kernel<SDT, DDT, 1, UNRV, KIT>), dim3(grid), dim3(256), 0, stream, a, l); \
+    else hipLaunchKernelGGL((gather_pooled_pipe_kernel<SDT, DDT, 0, UNRV, KIT>), dim3(grid), dim3(256), 0, stream, a, l); \
   } while (0)
         // rows per load batch: short bags (C2: 1..10 keys) run best with 4 (8 waves / SIMD), long bags with 8
         const bool small = variant == 20 || (variant != 21 && a.n <= 8 * a.FB);
@@ -605,6 +568,7 @@ int mi355_gather_pooled(const void* src, int64_t src_stride, const int64_t* row_
                         int combiner, int64_t dim, const int32_t* D_offsets, int64_t total_D, void* dst, int dst_dtype,
                         int aligned16, hipStream_t stream) {
   MI355_CHECK_ARG(src || row_addr, "src or row_addr required");
+  MI355_CHECK_ARG(reverse_indices || row_addr, "reverse_indices may only be NULL with per-key row addresses");
   MI355_CHECK_ARG(batch_size > 0 && num_bags % batch_size == 0, "num_bags must be a multiple of batch_size");
   MI355_CHECK_ARG(dim > 0 && dim <= 1024, "embedding dim must be in (0, 1024]");
   MI355_CHECK_ARG(combiner == 0 || combiner == 1, "combiner must be 0 (sum) or 1 (mean)");

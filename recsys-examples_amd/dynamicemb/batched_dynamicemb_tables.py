@@ -12,6 +12,7 @@ Out of scope this round: table growth (rehash), NO_EVICTION, externa
 """
 from __future__ import annotations
 
+import ctypes
 import os
 from itertools import accumulate
 from typing import List, Optional
@@ -60,11 +61,91 @@ class _StepCtx:
     """What one forward leaves for its backward (the reference's PrefetchState + autograd ctx)."""
 
     __slots__ = ("rev", "uoff", "tids", "slots", "row_addr", "offsets", "num_keys", "batch_size", "num_bags", "csr_cnt",
-                 "csr_rank", "pinned", "event", "indices", "bwd_ws", "ring")
+                 "csr_rank", "pinned", "event", "indices", "bwd_ws", "ring", "token")
 
     def release_ring(self):
         """hand the early-CSR ring slot back (after the backward, or when the step is dropped without one)"""
         r = getattr(self, "ring", None)
+        if r is not None:
+            r[0][r[1]] = False
+            self.ring = None
+
+    def __del__(self):
+        self.release_ring()
+
+
+def _al256(x: int) -> int:
+    return (x + 255) // 256 * 256
+
+
+class _FusedStep:
+    """Step context of the fused forward (mi355_demb_forward_fused): every per-step array lives in ONE buffer (a slot of
+    the module's ring, or a fresh allocation); the arrays the side stream produces (unique numbering, CSR) are joined
+    before anybody looks at them."""
+
+    _FIELDS = (("rev", 8, torch.int64), ("tids", 8, torch.int64), ("slots", 8, torch.int64), ("row_addr", 8, torch.int64),
+               ("freq", 8, torch.int64), ("csr_cnt", 4, torch.int32), ("csr_rank", 4, torch.int32))
+
+    def __init__(self, module, buf, n, T, fwd_ws_bytes, bwd_ws_bytes):
+        self.module, self.buf, self.num_keys, self.T = module, buf, n, T
+        off = 0
+        self.off = {}
+        for name, eb, _ in self._FIELDS:
+            self.off[name] = off
+            off += _al256(eb * max(n, 1))
+        self.off["uoff"] = off
+        off += _al256(8 * (T + 1))
+        self.off["fwd_ws"] = off
+        off += _al256(fwd_ws_bytes)
+        self.off["bwd_ws"] = off
+        off += _al256(bwd_ws_bytes)
+        self.total = off
+        self.fwd_ws_bytes, self.bwd_ws_bytes = fwd_ws_bytes, bwd_ws_bytes
+        self.token = -1        # side-stream join point (-1: nothing to join)
+        self.ring = None
+        self.pinned = False
+        self.event = None
+        self.indices = None
+        self.offsets = None
+        self.prepared = 0
+
+    @staticmethod
+    def nbytes(n, T, fwd_ws_bytes, bwd_ws_bytes):
+        return (sum(_al256(eb * max(n, 1)) for _, eb, _ in _FusedStep._FIELDS) + _al256(8 * (T + 1)) + _al256(fwd_ws_bytes)
+                + _al256(bwd_ws_bytes))
+
+    def p(self, name):
+        return c_p(self.buf.data_ptr() + self.off[name])
+
+    def join(self):
+        """make the current stream wait for the side-stream half of this step's forward"""
+        if self.token >= 0:
+            check(lib().mi355_side_join(self.token, stream()), "side join")
+            self.token = -1
+
+    def _view(self, name):
+        self.join()
+        for nm, eb, dtp in self._FIELDS:
+            if nm == name:
+                o = self.off[nm]
+                return self.buf[o:o + eb * self.num_keys].view(dtp)
+        raise AttributeError(name)
+
+    rev = property(lambda self: self._view("rev"))
+    tids = property(lambda self: self._view("tids"))
+    slots = property(lambda self: self._view("slots"))
+    row_addr = property(lambda self: self._view("row_addr"))
+    csr_cnt = property(lambda self: self._view("csr_cnt"))
+    csr_rank = property(lambda self: self._view("csr_rank"))
+
+    @property
+    def uoff(self):
+        self.join()
+        o = self.off["uoff"]
+        return self.buf[o:o + 8 * (self.T + 1)].view(torch.int64)
+
+    def release_ring(self):
+        r = self.ring
         if r is not None:
             r[0][r[1]] = False
             self.ring = None
@@ -239,6 +320,12 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                                                       dtype=self.embedding_dtype))
         self._pin = False  # ref-counter pinning is only needed when prefetch runs ahead of backward
         self._early_csr = os.environ.get("MI355_EARLY_CSR", "1") != "0"   # build the backward's CSR under the forward
+        # fused index stage (csrc/fused_fwd.hip): HBM storage, no admission, 32-bit slot ids, not the deterministic mode
+        self._fused = (os.environ.get("MI355_FUSED", "1") != "0" and storage_mode == "hbm" and self._admit_strategy is None
+                       and T_ <= 128 and self.table.capacity_ < (1 << 31) - 512
+                       and os.environ.get("DEMB_DETERMINISM_MODE", "") in ("", "0"))
+        self._fused_aux = None
+        self._step_ring = [None] * 4
         self._bwd_ring = [None] * 4
         self._bwd_busy = [False] * 4
         self._bwd_ring_next = 0
@@ -307,6 +394,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             if st.num_keys != indices.numel() or st.num_bags != offsets.numel() - 1:
                 raise RuntimeError("forward() received a batch that was not the oldest prefetched one")
             return self._gather_prefetched(st), st
+        if self._fused:
+            return self._forward_fused(indices, offsets, train, prefetch_only)
         n = indices.numel()
         num_bags = offsets.numel() - 1
         B = num_bags // self.feature_num
@@ -360,6 +449,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                 self._bwd_busy[slot] = True
                 st.ring = (self._bwd_busy, slot)
                 st.bwd_ws = buf
+        tok = ctypes.c_int(-1)
         check(lib().mi355_demb_forward(
             ptr(tb.table_storage_), ptr(tb.table_bucket_offsets_), tb.bucket_capacity_, tb.num_scores_,
             ptr(tb.bucket_sizes), ptr(tb._ref_counter), tb._ref_counter.numel(),
@@ -371,12 +461,124 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             combiner, ptr(self.D_offsets_t), self.total_D, ptr(out), dt(out) if out is not None else 0, int(al),
             ptr(st.rev), ptr(st.uoff), ptr(st.tids), ptr(st.slots), ptr(st.row_addr), ptr(freq),
             ptr(st.csr_cnt), ptr(st.csr_rank), ptr(st.bwd_ws), st.bwd_ws.numel() if st.bwd_ws is not None else 0,
-            ptr(ws), ws.numel(), stream()), "demb_forward")
+            ctypes.byref(tok), ptr(ws), ws.numel(), stream()), "demb_forward")
+        st.token = tok.value
         if train:
             self._step += 1
             if self._dynamicemb_options[0].safe_check_mode != DynamicEmbCheckMode.IGNORE:
                 self._safe_check(st)
         return out, st
+
+    # ---------------------------------------------------------------------------------- fused forward / backward
+    def _fused_scores(self):
+        """(find_policy, insert_policy, score_value, use_count) of mi355_demb_forward_fused"""
+        P = ext.ScorePolicy
+        s = self._score_strategy
+        if s == DynamicEmbScoreStrategy.TIMESTAMP:
+            return P.GLOBAL_TIMER, P.GLOBAL_TIMER, 0, 0
+        if s in (DynamicEmbScoreStrategy.STEP, DynamicEmbScoreStrategy.CUSTOMIZED):
+            return P.ASSIGN, P.ASSIGN, (self._step if s == DynamicEmbScoreStrategy.STEP else self._custom_score), 0
+        if s == DynamicEmbScoreStrategy.LFU:
+            return P.ACCUMULATE, P.ASSIGN, 0, 1
+        return P.LRU_LFU, P.LRU_LFU, 0, 1
+
+    def _forward_fused(self, indices: torch.Tensor, offsets: torch.Tensor, train: bool, prefetch_only: bool):
+        L = lib()
+        n = indices.numel()
+        num_bags = offsets.numel() - 1
+        B = num_bags // self.feature_num
+        pooled = self.pooling_mode != DynamicEmbPoolingMode.NONE
+        dev, T, tb = self.device_, self.num_tables, self.table
+        if self._fused_aux is None:
+            self._fused_aux = torch.zeros(L.mi355_demb_aux_numel(tb.capacity_, tb.num_buckets_), dtype=torch.int32, device=dev)
+        fwd_b = L.mi355_demb_forward_fused_workspace_bytes(n, T)
+        bwd_b = L.mi355_demb_backward_workspace_bytes(n, self.max_D) if (train and not prefetch_only) else 0
+        need = _FusedStep.nbytes(n, T, fwd_b, bwd_b)
+        capturing = torch.cuda.is_current_stream_capturing()
+        buf, ring = None, None
+        # the side stream works on module-owned memory only (a ring of step buffers): a step dropped without its backward
+        # can then never hand memory that side kernels still write back to the allocator
+        if train and not capturing:
+            slot = self._bwd_ring_next % len(self._step_ring)
+            if not self._bwd_busy[slot]:
+                self._bwd_ring_next += 1
+                buf = self._step_ring[slot]
+                if buf is None or buf.numel() < need:
+                    buf = self._step_ring[slot] = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=dev)
+                self._bwd_busy[slot] = True
+                ring = (self._bwd_busy, slot)
+        use_side = int(ring is not None and self._early_csr and not prefetch_only and torch.is_grad_enabled())
+        if buf is None:
+            buf = torch.empty(need, dtype=torch.uint8, device=dev)
+        st = _FusedStep(self, buf, n, T, fwd_b, bwd_b)
+        st.ring = ring
+        st.offsets, st.batch_size, st.num_bags = offsets, B, num_bags
+        st.pinned = bool((self._pin or prefetch_only) and train)
+        if prefetch_only:
+            out, combiner = None, -2
+        elif pooled:
+            out = torch.empty(B, self.total_D, dtype=self.output_dtype, device=dev)
+            combiner = 0 if self.pooling_mode == DynamicEmbPoolingMode.SUM else 1
+        else:
+            out = torch.empty(n, self.dims[0], dtype=self.output_dtype, device=dev)
+            combiner = -1
+        fp, ip, sval, use_cnt = self._fused_scores()
+        mode, p = self._init_params()
+        al = all(d % 4 == 0 for d in self.dims) and all(v % 4 == 0 for v in self.value_dims)
+        tok = ctypes.c_int(-1)
+        need_freq = use_cnt
+        check(L.mi355_demb_forward_fused(
+            ptr(tb.table_storage_), ptr(tb.table_bucket_offsets_), tb.bucket_capacity_, tb.num_scores_,
+            ptr(tb.bucket_sizes), ptr(tb._ref_counter), tb._ref_counter.numel(), ptr(self._fused_aux),
+            self._fused_aux.numel(), tb.num_buckets_,
+            ptr(self.table_ptrs), ptr(self.table_value_dims), ptr(self.table_emb_dims), dt(self.embedding_dtype),
+            self.max_D, max(self.value_dims),
+            ptr(indices), n, ptr(offsets), num_bags, B, ptr(self.feature_offsets), T,
+            int(train), int(fp), int(ip), c_u64(int(sval)), int(use_cnt), c_u64(ext.TIMER_OVERRIDE), int(st.pinned),
+            mode, c_f(p[0]), c_f(p[1]), c_f(p[2]), c_f(p[3]), c_u64(self._seed), c_f(self.initial_accumulator_value),
+            combiner, ptr(self.D_offsets_t), self.total_D, ptr(out), dt(out) if out is not None else 0, int(al),
+            st.p("rev"), st.p("uoff"), st.p("tids"), st.p("slots"), st.p("row_addr"), st.p("freq") if need_freq else None,
+            st.p("csr_cnt"), st.p("csr_rank"), st.p("bwd_ws") if bwd_b else None, bwd_b, use_side, ctypes.byref(tok),
+            st.p("fwd_ws"), fwd_b, stream()), "demb_forward_fused")
+        st.token = tok.value
+        st.prepared = (2 + tok.value) if tok.value >= 0 else (1 if bwd_b and n > 0 else 0)
+        if train:
+            self._step += 1
+            if self._dynamicemb_options[0].safe_check_mode != DynamicEmbCheckMode.IGNORE:
+                self._safe_check(st)
+        return out, st
+
+    def _backward_fused(self, st, grads: torch.Tensor):
+        grads = grads.contiguous()
+        self._iter_num += 1
+        pooled = self.pooling_mode != DynamicEmbPoolingMode.NONE
+        combiner = -1 if not pooled else (0 if self.pooling_mode == DynamicEmbPoolingMode.SUM else 1)
+        dim = self.max_D
+        L = lib()
+        prepared = st.prepared
+        if prepared and st.bwd_ws_bytes:
+            ws_p, ws_b, ws = st.p("bwd_ws"), st.bwd_ws_bytes, None
+        else:       # a prefetched step (no CSR yet) or a second backward of the same step: group here
+            prepared = 0
+            st.join()
+            ws_b = L.mi355_demb_backward_workspace_bytes(st.num_keys, dim)
+            ws = torch.empty(ws_b, dtype=torch.uint8, device=grads.device)
+            ws_p = ptr(ws)
+        if prepared >= 2 and st.token < 0:
+            prepared = 1     # somebody (a property access) joined already
+        al = all(d % 4 == 0 for d in self.dims) and all(v % 4 == 0 for v in self.value_dims) and grads.stride(0) % 4 == 0
+        tb = self.table
+        check(L.mi355_demb_backward(
+            st.p("rev"), st.num_keys, st.p("uoff"), self.num_tables, ptr(st.offsets), st.num_bags, st.batch_size,
+            ptr(grads), grads.stride(0), dt(grads), ptr(self.D_offsets_t), dim, combiner, st.p("row_addr"),
+            dt(self.embedding_dtype), self._opt_kind, c_f(self.learning_rate), c_f(self.beta1), c_f(self.beta2),
+            c_f(self.eps), c_f(self.weight_decay), self._iter_num, -1, 1, int(al),
+            ptr(tb._ref_counter), tb._ref_counter.numel(), st.p("slots"), st.p("tids"), ptr(tb.table_bucket_offsets_),
+            tb.bucket_capacity_, int(bool(st.pinned)), st.p("csr_cnt"), st.p("csr_rank"), int(prepared), ws_p, ws_b,
+            stream()), "demb_backward")
+        st.token = -1
+        st.prepared = 0
+        st.release_ring()
 
     # ---------------------------------------------------------------------------------- hybrid tiers
     def _forward_hybrid(self, indices: torch.Tensor, offsets: torch.Tensor, train: bool):
@@ -644,6 +846,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             warnings.warn(msg)
 
     def _backward_impl(self, st, grads: torch.Tensor):
+        if isinstance(st, _FusedStep):
+            return self._backward_fused(st, grads)
         grads = grads.contiguous()
         self._iter_num += 1
         pooled = self.pooling_mode != DynamicEmbPoolingMode.NONE
@@ -661,7 +865,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             c_f(self.eps), c_f(self.weight_decay), self._iter_num, -1, 1, int(al),
             ptr(tb._ref_counter), tb._ref_counter.numel(), ptr(st.slots), ptr(st.tids), ptr(tb.table_bucket_offsets_),
             tb.bucket_capacity_, int(bool(getattr(st, "pinned", False)) and st.slots is not None), ptr(st.csr_cnt),
-            ptr(st.csr_rank), int(prepared), ptr(ws), ws.numel(), stream()), "demb_backward")
+            ptr(st.csr_rank), (2 + st.token) if (prepared and getattr(st, "token", -1) >= 0) else 0, ptr(ws), ws.numel(),
+            stream()), "demb_backward")
         if prepared:
             st.bwd_ws = None   # consumed: a second backward of the same step would have to regroup
             st.release_ring()

@@ -79,7 +79,20 @@ _SIGS = {
                            c_int, c_p, c_i64, c_p, c_int, c_int,  # output
                            c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,  # persisted (+ freq, csr_cnt, csr_rank)
                            c_p, c_i64,  # backward workspace (early CSR)
+                           c_p,  # join token (out)
                            c_p, c_i64, c_p],
+    "mi355_demb_forward_fused": [c_p, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_i64,  # table + aux
+                                 c_p, c_p, c_p, c_int, c_i64, c_i64,  # values
+                                 c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i64,  # batch
+                                 c_int, c_int, c_int, c_u64, c_int, c_u64, c_int,  # policies
+                                 c_int, c_f, c_f, c_f, c_f, c_u64, c_f,  # initializer
+                                 c_int, c_p, c_i64, c_p, c_int, c_int,  # output
+                                 c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,  # persisted
+                                 c_p, c_i64, c_int, c_p,  # backward workspace, side stream, join token
+                                 c_p, c_i64, c_p],
+    "mi355_demb_aux_numel": [c_i64, c_i64],
+    "mi355_demb_forward_fused_workspace_bytes": [c_i64, c_i64],
+    "mi355_side_join": [c_int, c_p],
     "mi355_demb_backward": [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_int, c_p, c_i64, c_int, c_p,
                             c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_int, c_int, c_p, c_i64, c_p, c_p,
                             c_p, c_i64, c_int, c_p, c_p, c_int, c_p, c_i64, c_p],
@@ -109,6 +122,8 @@ _RESTYPES = {
     "mi355_demb_forward_workspace_bytes": c_i64,
     "mi355_demb_backward_workspace_bytes": c_i64,
     "mi355_early_csr_stream": c_p,
+    "mi355_demb_aux_numel": c_i64,
+    "mi355_demb_forward_fused_workspace_bytes": c_i64,
     "mi355_last_error": ctypes.c_char_p,
 }
 _OPTIONAL_SIGS = {}  # filled by optional modules (e.g. hstu) before first load

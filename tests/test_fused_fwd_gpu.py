@@ -1,0 +1,181 @@
+"""GPU tests of the fused index stage (csrc/fused_fwd.hip, mi355_demb_forward_fused) against the per-op chain
+(MI355_FUSED=0: segmented_unique + table_lookup + table_insert + unlock/init) and against the oracle's dict twin:
+same pooled / sequence outputs bit for bit, same rows after training steps, same table contents; dedup of one new key
+arriving from many tiles; hits + misses in a full bucket (a key the batch just hit must never be evicted by the batch's
+own inserts: the reference pins found slots before the insert, _prefetch_hbm_direct_path
+batched_dynamicemb_function.py:559-696)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _mk(fused, dims=(16,), cap=4096, pooling="SUM", opt="SGD", strategy="TIMESTAMP", bucket=128, fmap=None, monkeypatch=None, **kw):
+    from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2 as B2
+    from dynamicemb.dynamicemb_config import (DynamicEmbInitializerArgs as IA, DynamicEmbInitializerMode as IM,
+                                              DynamicEmbPoolingMode as PM, DynamicEmbScoreStrategy as SS,
+                                              DynamicEmbTableOptions as TO, EmbOptimType as OT)
+    monkeypatch.setenv("MI355_FUSED", "1" if fused else "0")
+    opts = [TO(dim=d, max_capacity=cap, index_type=torch.int64, embedding_dtype=torch.float32, bucket_capacity=bucket,
+               initializer_args=IA(mode=IM.UNIFORM, lower=-0.5, upper=0.5), score_strategy=getattr(SS, strategy)) for d in dims]
+    m = B2(table_options=opts, feature_table_map=fmap or list(range(len(dims))), pooling_mode=getattr(PM, pooling),
+           optimizer=getattr(OT, opt), output_dtype=torch.float32, device=torch.device(DEV), **kw)
+    assert m._fused == bool(fused)
+    return m
+
+
+def _counters_clear(m):
+    """header + per-slot occurrence counters of the fused forward are all zero between steps (the unique-id map behind
+    them is scratch)"""
+    torch.cuda.synchronize()
+    return int(m._fused_aux[: 64 + m.table.capacity_ + 1].abs().sum()) == 0
+
+
+def _batch(rng, F, B, hi, maxlen=6):
+    lens = rng.integers(0, maxlen, size=F * B)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    keys = rng.integers(0, hi, size=int(lens.sum())).astype(np.int64)
+    return torch.from_numpy(keys).to(DEV), torch.from_numpy(off).to(DEV)
+
+
+@pytest.mark.parametrize("pooling", ["SUM", "MEAN", "NONE"])
+@pytest.mark.parametrize("opt", ["SGD", "ADAM", "EXACT_ROWWISE_ADAGRAD"])
+@pytest.mark.parametrize("strategy", ["TIMESTAMP", "STEP", "LFU"])
+def test_fused_matches_per_op_chain_over_training_steps(pooling, opt, strategy, monkeypatch):
+    dims = (16, 16, 16) if pooling == "NONE" else (8, 16, 32)
+    ref = _mk(False, dims, pooling=pooling, opt=opt, strategy=strategy, learning_rate=0.2, monkeypatch=monkeypatch)
+    dut = _mk(True, dims, pooling=pooling, opt=opt, strategy=strategy, learning_rate=0.2, monkeypatch=monkeypatch)
+    rng = np.random.default_rng(5)
+    F, B = 3, 700     # ~5 K keys: several 1024-key tiles, many keys shared between tiles
+    for it in range(5):
+        keys, off = _batch(rng, F, B, 900 + 300 * it)
+        ref.train(); dut.train()
+        o_ref = ref(keys, off)
+        o_dut = dut(keys, off)
+        # (the rows differ by the fp32 rounding of a different gradient summation order from the second step on)
+        torch.testing.assert_close(o_ref, o_dut, rtol=1e-5, atol=1e-5, msg=f"iteration {it}: forward differs")
+        g = torch.randn_like(o_ref)
+        o_ref.backward(g)
+        o_dut.backward(g)
+        assert torch.equal(ref.size(), dut.size())
+    # same keys stored, same rows (fp32 sums of fp32 gradients in a different order: 1e-6 relative)
+    for t in range(len(dims)):
+        k1, v1 = ref.export_keys_values(ref._table_names[t], torch.device(DEV))
+        k2, v2 = dut.export_keys_values(dut._table_names[t], torch.device(DEV))
+        o1, o2 = torch.argsort(k1), torch.argsort(k2)
+        assert torch.equal(k1[o1], k2[o2])
+        torch.testing.assert_close(v1[o1], v2[o2], rtol=2e-5, atol=2e-6)
+    ref.eval(); dut.eval()
+    keys, off = _batch(rng, F, B, 3000)     # known and unknown keys
+    with torch.no_grad():
+        torch.testing.assert_close(ref(keys, off), dut(keys, off), rtol=1e-5, atol=1e-5)
+
+
+def test_one_new_key_in_every_tile_gets_one_slot(monkeypatch):
+    """cold start: the same unseen keys arrive from dozens of tiles at once; every key must end in exactly one slot and
+    the reverse indices must group all its occurrences"""
+    m = _mk(True, (8,), cap=1 << 16, pooling="NONE", monkeypatch=monkeypatch)
+    rng = np.random.default_rng(0)
+    hot = rng.integers(0, 1 << 40, size=50).astype(np.int64)
+    keys = np.concatenate([hot[rng.integers(0, 50, size=60_000)], rng.integers(0, 1 << 40, size=20_000)]).astype(np.int64)
+    rng.shuffle(keys)
+    kt = torch.from_numpy(keys).to(DEV)
+    off = torch.arange(keys.size + 1, dtype=torch.int64, device=DEV)
+    m.train()
+    out, st = m._forward_impl(kt, off, train=True)
+    nu = int(st.uoff[-1])
+    assert nu == np.unique(keys).size == int(m.size())
+    rev = st.rev
+    # occurrences of one key share one unique id, distinct keys never do
+    first = torch.full((nu,), -1, dtype=torch.int64, device=DEV)
+    first[rev] = kt
+    assert torch.equal(first[rev], kt)
+    assert torch.equal(torch.bincount(rev, minlength=nu).to(torch.int32), st.csr_cnt[:nu])
+    # sequence output row j == the stored row of key j
+    found, rows = m.lookup_rows(kt, 0)
+    assert bool(found.all()) and torch.equal(out, rows[:, :8])
+    # the scratch counters are back to zero
+    assert _counters_clear(m)
+    m._backward_impl(st, torch.zeros_like(out))
+
+
+@pytest.mark.parametrize("strategy", ["LFU", "CUSTOMIZED", "STEP"])
+@pytest.mark.parametrize("fused", [True, False])
+def test_hits_and_misses_in_a_full_bucket(strategy, fused, monkeypatch):
+    """one bucket, full; a batch of keys it holds plus new keys: the new keys may only evict keys that are NOT in the batch,
+    every key of the batch reads its own row, and the backward updates every row once"""
+    m = _mk(fused, (8,), cap=128, pooling="NONE", strategy=strategy, learning_rate=1.0, monkeypatch=monkeypatch)
+    m.train()
+    if strategy == "CUSTOMIZED":
+        m.set_score(7)      # constant score: ties everywhere
+    old = torch.arange(1000, 1128, dtype=torch.int64, device=DEV)
+    off = lambda n: torch.arange(n + 1, dtype=torch.int64, device=DEV)
+    m(old, off(128))
+    assert int(m.size()) == 128
+    _, rows_old = m.lookup_rows(old, 0)
+    hits = old[:96]                                   # the LOWEST slots are the tie-break's first victims
+    new = torch.arange(5000, 5032, dtype=torch.int64, device=DEV)
+    batch = torch.cat([hits, new])
+    out, st = m._forward_impl(batch, off(128), train=True)
+    # every hit key reads the row it had before; nothing of the batch was evicted
+    assert torch.equal(out[:96], rows_old[:96, :8])
+    found, rows_now = m.lookup_rows(batch, 0)
+    assert bool(found.all())
+    assert torch.equal(out, rows_now[:, :8])
+    # exactly the 32 keys outside the batch made room
+    found_rest, _ = m.lookup_rows(old[96:], 0)
+    assert int(found_rest.sum()) == 0 and int(m.size()) == 128
+    # one SGD step with a gradient of ones: every row of the batch moves by exactly -1
+    m._backward_impl(st, torch.ones_like(out))
+    _, rows_after = m.lookup_rows(batch, 0)
+    torch.testing.assert_close(rows_after[:, :8], rows_now[:, :8] - 1.0, rtol=0, atol=1e-6)
+
+
+def test_full_bucket_without_a_victim_reports_no_slot(monkeypatch):
+    """every slot of the bucket is used by the batch itself: the extra keys get no slot (index -1, zero rows, no update),
+    exactly like an insert that returns Busy"""
+    m = _mk(True, (8,), cap=128, pooling="NONE", strategy="STEP", monkeypatch=monkeypatch)
+    m.train()
+    off = lambda n: torch.arange(n + 1, dtype=torch.int64, device=DEV)
+    old = torch.arange(1000, 1128, dtype=torch.int64, device=DEV)
+    m(old, off(128))
+    batch = torch.cat([old, torch.arange(7000, 7010, dtype=torch.int64, device=DEV)])
+    out, st = m._forward_impl(batch, off(138), train=True)
+    assert bool((out[128:] == 0).all()) and int(m.size()) == 128
+    found, rows = m.lookup_rows(old, 0)
+    assert bool(found.all()) and torch.equal(out[:128], rows[:, :8])
+    nu = int(st.uoff[-1])
+    assert int((st.slots[:nu] < 0).sum()) == 1      # the keys without a slot share one placeholder entry
+    m._backward_impl(st, torch.ones_like(out))
+    assert _counters_clear(m)
+
+
+def test_fused_forward_from_another_thread_backward(monkeypatch):
+    """autograd runs the backward of a CUDA node on its own host thread: the side-stream join must not depend on
+    thread-local state (round-1 advisor finding)"""
+    import threading
+
+    m = _mk(True, (16,), cap=1 << 14, pooling="SUM", learning_rate=1.0, monkeypatch=monkeypatch)
+    m.train()
+    rng = np.random.default_rng(2)
+    keys, off = _batch(rng, 1, 4000, 3000)
+    out, st = m._forward_impl(keys, off, train=True)
+    _, rows0 = m.lookup_rows(torch.unique(keys), 0)
+    err = []
+
+    def bw():
+        try:
+            torch.cuda.set_device(0)
+            m._backward_impl(st, torch.ones_like(out))
+            torch.cuda.synchronize()
+        except Exception as e:  # pragma: no cover
+            err.append(e)
+
+    t = threading.Thread(target=bw)
+    t.start(); t.join()
+    assert not err
+    uk, cnt = torch.unique(keys, return_counts=True)
+    _, rows1 = m.lookup_rows(uk, 0)
+    torch.testing.assert_close(rows1[:, :16], rows0[:, :16] - cnt[:, None].float(), rtol=0, atol=1e-4)
