@@ -57,8 +57,10 @@ struct FusedArgs {
   const int64_t* offsets;
   const int64_t* feature_offsets;
   int64_t num_bags;
+  int64_t batch;                  // bags per feature
   int T;
   int find_policy, insert_policy, use_count;
+  int dbg;                        // MI355_FUSED_DBG (profiling only): 1 skip the slot-counter atomic, 2 skip the probe
   uint64_t score_value, timer;
   InitArgs init;
   // per-step outputs
@@ -128,7 +130,10 @@ __device__ __forceinline__ int thread_probe(const FusedArgs& a, int64_t b, uint6
       m &= m - 1;
       const uint64_t k = fresh ? ald64(ks + p0 + bit) : ks[p0 + bit];
       if (k == key) return p0 + bit;
-      if (kInsert && k == kLockedKey) again = true;   // being inserted right now -- possibly this very key
+      // Locked: being inserted right now -- possibly this very key.  Empty behind a non-empty digest: the digest is
+      // current but the key word comes from a stale cache line (the two live in different lines) -- look again with
+      // device-scope loads, or the key would be inserted a second time further down the probe order.
+      if (kInsert && (k == kLockedKey || (k == kEmptyKey && d != ed))) again = true;
     }
     if (!again) {
       uint32_t me = eq_mask16(dv, ed);
@@ -196,34 +201,53 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   __shared__ int s_nrep[HALVES];
   const int T = a.T;
   const int64_t tile0 = (int64_t)blockIdx.x * TILE;
-  {
-    const int64_t nfeat = a.feature_offsets[T];
-    const int64_t B = nfeat > 0 ? a.num_bags / nfeat : 0;
-    for (int t = threadIdx.x; t <= T; t += THREADS) {
-      s_seg[t] = a.offsets[a.feature_offsets[t] * B];
-      s_tbo[t] = a.tbo[t];
-      if (t < T) { s_tptr[t] = a.table_ptrs[t]; s_rowb[t] = (int)a.table_value_dims[t] * a.elem_bytes; }
-      if (blockIdx.x == 0) a.seg_out[t] = s_seg[t];
-    }
-    if (blockIdx.x == 0 && kTrain)
-      for (int64_t j = threadIdx.x; j <= a.nbu; j += THREADS) a.partial2[j] = 0;
+  // The kernel is a chain of dependent memory round trips (keys -> digest vector -> key word -> slot counter), every block
+  // of the grid is resident at once, so its duration is the latency of ONE chain: the key loads go out first, the
+  // per-table metadata next (one hop, or none for a single table), and the first digest vector of EVERY key is fetched
+  // before the LDS dedup -- speculative for the duplicates, but the dedup then runs in the shadow of that load.
+  uint64_t kreg[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int64_t i = tile0 + q * THREADS + threadIdx.x;
+    kreg[q] = a.keys[i < a.n ? i : a.n - 1];
   }
+  for (int t = threadIdx.x; t <= T; t += THREADS) {
+    s_seg[t] = T == 1 ? (t == 0 ? 0 : a.n) : a.offsets[a.feature_offsets[t] * a.batch];
+    s_tbo[t] = a.tbo[t];
+    if (t < T) { s_tptr[t] = a.table_ptrs[t]; s_rowb[t] = (int)a.table_value_dims[t] * a.elem_bytes; }
+  }
+  if (blockIdx.x == 0 && kTrain)
+    for (int64_t j = threadIdx.x; j <= a.nbu; j += THREADS) a.partial2[j] = 0;
   for (int s = threadIdx.x; s < LDS; s += THREADS) { s_tab[s] = -1; s_cnt[s] = 0; }
   if (threadIdx.x < HALVES) s_nrep[threadIdx.x] = 0;
   __syncthreads();
   int hh[PER], rk[PER];
+  int64_t bq[PER], hq[PER];      // bucket and hash of my keys (bucket -1: key without a home)
+  uint4 dvq[PER];                // first digest vector of the probe
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
     const int li = q * THREADS + threadIdx.x;
     const int64_t i = tile0 + li;
     uint16_t tt = 0;
-    if (i < a.n) {
-      s_key[li] = a.keys[i];
+    if (T > 1) {
       int lo = 0, hi = T + 1;  // first t with seg[t] > i
       while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_seg[mid] <= i) lo = mid + 1; else hi = mid; }
       tt = (uint16_t)(lo - 1 < 0 ? 0 : (lo - 1 >= T ? T - 1 : lo - 1));
     }
+    s_key[li] = kreg[q];
     s_t[li] = tt;
+    const uint64_t key = kreg[q];
+    const int64_t hash = (int64_t)(fmix64(key) & 0x7FFFFFFFFFFFFFFFull);
+    const int64_t bb = s_tbo[tt];
+    const int64_t cap = (s_tbo[tt + 1] - bb) * a.t.C;
+    const bool ok = i < a.n && is_valid(key) && cap > 0;
+    const uint64_t local = (uint64_t)hash % (uint64_t)(cap > 0 ? cap : 1);
+    const int64_t b = bb + (int64_t)(local / (uint64_t)a.t.C);
+    hq[q] = hash;
+    bq[q] = ok ? b : -1;
+    const int C = (int)a.t.C;
+    const int start = (int)(((C & (C - 1)) == 0 ? ((uint64_t)hash & (uint64_t)(C - 1)) : ((uint64_t)hash % (uint64_t)C))) & ~15;
+    dvq[q] = *reinterpret_cast<const uint4*>(a.t.dig(ok ? b : 0) + start);   // unconditional: bucket 0 for homeless keys
   }
   __syncthreads();
 #pragma unroll
@@ -232,7 +256,7 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     hh[q] = -1;
     rk[q] = 0;
     if (tile0 + li < a.n) {
-      const uint64_t key = s_key[li];
+      const uint64_t key = kreg[q];
       const int t = s_t[li];
       int h = (int)(fmix64(key + 0x9E3779B97F4A7C15ull * (uint64_t)t) >> 40) & (LDS - 1);
       while (true) {
@@ -249,34 +273,42 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   bool isrep[PER];
 #pragma unroll
   for (int q = 0; q < PER; ++q) isrep[q] = hh[q] >= 0 && s_tab[hh[q]] == q * THREADS + (int)threadIdx.x;
+  // first candidate of the prefetched vector: its key word is loaded by every lane (clamped address), so that the loads
+  // of a thread's keys overlap; everything the fast path cannot decide goes to thread_probe
+  uint64_t kc[PER];
+  int cand[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const uint32_t m = eq_mask16(dvq[q], digest_of(hq[q]));
+    const int C = (int)a.t.C;
+    const int start = (int)(((C & (C - 1)) == 0 ? ((uint64_t)hq[q] & (uint64_t)(C - 1)) : ((uint64_t)hq[q] % (uint64_t)C))) & ~15;
+    cand[q] = m ? start + __ffs(m) - 1 : -1;
+    kc[q] = a.t.keys(bq[q] >= 0 ? bq[q] : 0)[cand[q] >= 0 ? cand[q] : 0];
+  }
   __syncthreads();   // s_tab / s_cnt change meaning below
-  // ---- probe: one lane per distinct key of the tile.  All bucket addresses first, then the first digest vector of
-  //      every probe (independent loads in flight), then the resolution.
+  // ---- probe: one lane per distinct key of the tile
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
     if (!isrep[q]) continue;
     const int li = q * THREADS + threadIdx.x;
-    const uint64_t key = s_key[li];
+    const uint64_t key = kreg[q];
     const int t = s_t[li];
     const int cnt = s_cnt[hh[q]];
     int gslot = (int)a.S, base = 0;     // default: no slot
     bool defer = false;
-    if (is_valid(key)) {
-      const int64_t hash = (int64_t)(fmix64(key) & 0x7FFFFFFFFFFFFFFFull);
-      const int64_t bb = s_tbo[t];
-      const int64_t cap = (s_tbo[t + 1] - bb) * a.t.C;
-      if (cap > 0) {
-        const uint64_t local = (uint64_t)hash % (uint64_t)cap;
-        const int64_t b = bb + (int64_t)(local / (uint64_t)a.t.C);
-        bool inserted = false;
-        const int slot = thread_probe<kTrain>(a, b, key, hash, cnt, inserted);
-        if (slot >= 0) {
-          gslot = (int)(b * a.t.C + slot);
-          if (!inserted) score_found(a, a.t.scores(b) + (int64_t)slot * a.t.ns, cnt);
-          else { s_t[li] = (uint16_t)(t | 0x8000); s_gs[li] = gslot; }
-        } else if (slot == -2) {
-          defer = true;
-        }
+    if (bq[q] >= 0) {
+      const int64_t b = bq[q];
+      bool inserted = false;
+      int slot;
+      if (a.dbg & 2) slot = (int)((uint64_t)hq[q] & (uint64_t)(a.t.C - 1));
+      else if (cand[q] >= 0 && kc[q] == key) slot = cand[q];
+      else slot = thread_probe<kTrain>(a, b, key, hq[q], cnt, inserted);
+      if (slot >= 0) {
+        gslot = (int)(b * a.t.C + slot);
+        if (!inserted) score_found(a, a.t.scores(b) + (int64_t)slot * a.t.ns, cnt);
+        else { s_t[li] = (uint16_t)(t | 0x8000); s_gs[li] = gslot; }
+      } else if (slot == -2) {
+        defer = true;
       }
     }
     if (kTrain) {
@@ -285,7 +317,7 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
         a.d_key[e] = key; a.d_tid[e] = t; a.d_cnt[e] = cnt;
         gslot = -(e + 2);
       } else {
-        base = atomicAdd(&a.occ[gslot], cnt);
+        base = (a.dbg & 1) ? 0 : atomicAdd(&a.occ[gslot], cnt);
       }
     }
     s_tab[hh[q]] = gslot;
@@ -338,25 +370,43 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
       if (pt * 1024 < a.n) a.partial[pt] = s_nrep[threadIdx.x];
     }
   }
+  if (blockIdx.x == 0)
+    for (int t = threadIdx.x; t <= T; t += THREADS) a.seg_out[t] = s_seg[t];
 }
 
 // ---- deferred keys: bucket without a free slot -> evict the minimum score (kernels.cuh:226-287, types.cuh:398-512) ----
-__device__ __forceinline__ void grid_sync(int* ctr, int nblocks) {
+// Barrier across a grid whose blocks are all resident.  Two levels -- 16 blocks share a counter, the last arrival of a group
+// bumps the top counter, the last group publishes the generation -- because same-address device atomics serialise at
+// ~40 ns each: 352 arrivals on ONE word (plus the pollers) cost ~50 us per barrier, 16 + 22 cost ~1.5 us.
+// hdr: [1] top counter, [3] generation, [8 + g] group counters; all monotonic within a launch, cleared by its last block.
+__device__ __forceinline__ void grid_sync(int* hdr, int k /* 1-based barrier number */) {
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence();
-    atomicAdd(ctr, 1);
-    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < nblocks) __builtin_amdgcn_s_sleep(4);
+    const int nblk = (int)gridDim.x;
+    const int ngroups = (nblk + 15) >> 4;
+    const int g = (int)blockIdx.x >> 4;
+    const int gsize = nblk - (g << 4) < 16 ? nblk - (g << 4) : 16;
+    if (atomicAdd(&hdr[8 + g], 1) == k * gsize - 1) {
+      if (atomicAdd(&hdr[1], 1) == k * ngroups - 1) {
+        __threadfence();
+        __hip_atomic_store(&hdr[3], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // (bounded: a grid that is not fully resident would otherwise hang the device; ~1 s, then the step is garbage)
+    int spins = 0;
+    while (__hip_atomic_load(&hdr[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < k && ++spins < (1 << 23)) __builtin_amdgcn_s_sleep(2);
     __threadfence();
   }
   __syncthreads();
 }
+__device__ __forceinline__ void grid_sync_reset(int* hdr) {
+  hdr[1] = 0; hdr[3] = 0;
+  const int ngroups = ((int)gridDim.x + 15) >> 4;
+  for (int g = 0; g < ngroups; ++g) hdr[8 + g] = 0;
+}
 
-__global__ void __launch_bounds__(256) fused_evict_kernel(FusedArgs a) {
-  if (!a.timer) a.timer = device_clock();
-  int nd = __hip_atomic_load(&a.hdr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (nd == 0) return;          // steady state: one empty launch
-  if ((int64_t)nd > a.n) nd = (int)a.n;
+__device__ __forceinline__ void evict_phase(const FusedArgs& a, int nd) {
   const int g = lane_id() & (G - 1);
   const int gpb = blockDim.x / G;
   const int C = (int)a.t.C;
@@ -461,8 +511,10 @@ __global__ void __launch_bounds__(256) fused_evict_kernel(FusedArgs a) {
       a.d_base[e] = atomicAdd(&a.occ[gslot], cnt);
     }
   }
-  grid_sync(&a.hdr[1], (int)gridDim.x);
-  // patch the occurrences of the deferred keys
+}
+
+// the occurrences of the deferred keys learn their slot / rank / row address
+__device__ __forceinline__ void patch_phase(const FusedArgs& a) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
     const int s = a.occ_slot[i];
     if (s <= -2) {
@@ -480,6 +532,16 @@ __global__ void __launch_bounds__(256) fused_evict_kernel(FusedArgs a) {
       if (r == 0) atomicAdd(&a.partial[i >> 10], 1);
     }
   }
+}
+
+__global__ void __launch_bounds__(256) fused_evict_kernel(FusedArgs a) {
+  if (!a.timer) a.timer = device_clock();
+  int nd = __hip_atomic_load(&a.hdr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (nd == 0) return;          // steady state: one empty launch
+  if ((int64_t)nd > a.n) nd = (int)a.n;
+  evict_phase(a, nd);
+  grid_sync(a.hdr, 1);
+  patch_phase(a);
 }
 
 // ---- unique numbering: the occurrence with rank 0 represents its slot -------------------------------------------------
@@ -534,7 +596,8 @@ fused_emit_kernel(FusedArgs a, EmitOut o) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (o.hot_counters) { o.hot_counters[0] = 0; o.hot_counters[2] = 0; o.hot_counters[4] = 0; }
     a.hdr[0] = 0;   // deferred-key list and grid barrier of the next step
-    a.hdr[1] = 0;
+    a.hdr[1] = 0; a.hdr[3] = 0;
+    for (int g = 0; g < 64 - 8; ++g) a.hdr[8 + g] = 0;
   }
   const int first_tile = pre >> 10;
   int b0 = 0, b1 = 0;     // occurrences of my representatives that fall into unique tile first_tile / first_tile + 1
@@ -735,9 +798,11 @@ int mi355_demb_forward_fused(
   a.hdr = aux; a.occ = aux + kAuxHdr; a.uidmap = a.occ + (S + 1); a.locks = a.uidmap + (S + 1); a.S = S;
   a.table_ptrs = table_ptrs; a.table_value_dims = table_value_dims; a.table_emb_dims = table_emb_dims;
   a.elem_bytes = value_dtype == 0 ? 4 : 2; a.value_dtype = value_dtype;
-  a.keys = (const uint64_t*)keys; a.n = n; a.offsets = offsets; a.feature_offsets = feature_offsets; a.num_bags = num_bags;
+  a.keys = (const uint64_t*)keys; a.n = n; a.offsets = offsets; a.feature_offsets = feature_offsets; a.num_bags = num_bags; a.batch = batch_size;
   a.T = (int)num_tables; a.find_policy = find_policy; a.insert_policy = insert_policy; a.use_count = use_count;
   a.score_value = score_value; a.timer = timer_override;
+  static const int dbg_env = getenv("MI355_FUSED_DBG") ? atoi(getenv("MI355_FUSED_DBG")) : 0;
+  a.dbg = dbg_env;
   a.init = InitArgs{init_mode, p0, p1, p2, p3, seed, state_init};
   a.seg_out = (int64_t*)w; w += al256(8 * (num_tables + 1));
   uint64_t* unique_keys = (uint64_t*)w; w += al256(8 * n);
@@ -758,7 +823,8 @@ int mi355_demb_forward_fused(
     // keys per tile / threads per block: one key per thread keeps every probe chain (digest vector -> key -> slot counter)
     // in flight at once; larger tiles cost fewer (tile, key) pairs = fewer device-scope atomics
     static const int cfg_env = getenv("MI355_FUSED_CFG") ? atoi(getenv("MI355_FUSED_CFG")) : -1;
-    const int cfg = cfg_env >= 0 ? cfg_env : 0;
+    // measured at C2 (360 K keys): 2048-key tiles / 1024 threads 33.5 us, 1024 / 1024 37.8 us, 1024 / 512 35.2 us
+    const int cfg = cfg_env >= 0 ? cfg_env : (n >= (64 << 10) ? 3 : 0);
 #define LAUNCH_PROBE(TILE, THREADS)                                                                                        \
   do {                                                                                                                     \
     const unsigned grid = (unsigned)ceil_div(n, TILE);                                                                     \

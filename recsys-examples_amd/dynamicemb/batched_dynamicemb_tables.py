@@ -325,6 +325,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                        and T_ <= 128 and self.table.capacity_ < (1 << 31) - 512
                        and os.environ.get("DEMB_DETERMINISM_MODE", "") in ("", "0"))
         self._fused_aux = None
+        self._fused_side = os.environ.get("MI355_FUSED_SIDE", "0") != "0"
         self._step_ring = [None] * 4
         self._bwd_ring = [None] * 4
         self._bwd_busy = [False] * 4
@@ -507,7 +508,10 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                     buf = self._step_ring[slot] = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=dev)
                 self._bwd_busy[slot] = True
                 ring = (self._bwd_busy, slot)
-        use_side = int(ring is not None and self._early_csr and not prefetch_only and torch.is_grad_enabled())
+        # side stream for the unique numbering + CSR: off by default -- at C2 the side kernels and the gather slow each
+        # other down by more than the overlap saves (measured: 192 us with, 174 us without); worth it when a dense model
+        # runs between this forward and its backward
+        use_side = int(ring is not None and self._fused_side and not prefetch_only and torch.is_grad_enabled())
         if buf is None:
             buf = torch.empty(need, dtype=torch.uint8, device=dev)
         st = _FusedStep(self, buf, n, T, fwd_b, bwd_b)
