@@ -56,56 +56,67 @@ class RowWiseShardedLookup:
                                                is_sequence=not pooled, dist_type_per_feature=dist_type_per_feature,
                                                ops=self.ops)
 
-    # ------------------------------------------------------------------------------ forward
-    def forward(self, values: torch.Tensor, offsets: torch.Tensor, train: bool = True, collapse_batch: bool = False,
-                lengths: Optional[torch.Tensor] = None, bucketized: bool = False):
-        """bucketized (sequence mode): return the rows in EXCHANGE order (as they come back from the owners) instead of
-        gathering them into key order -- the caller composes `ctx.keys.unbucketize_permute` into its own index."""
+    # ------------------------------------------------------------------------------ the three stages of a forward
+    # (what TorchRec's ShardedModule calls input_dist / compute / output_dist; forward() below runs them back to back)
+    def dist_input(self, values: torch.Tensor, offsets: torch.Tensor, collapse_batch: bool = False,
+                   lengths: Optional[torch.Tensor] = None):
         if lengths is None:
             lengths = offsets[1:] - offsets[:-1]
-        sk = self.input_dist(lengths, values, collapse_batch, offsets=offsets)
-        out_local, lctx = self.local.forward(sk.values, sk.offsets, train)
+        return self.input_dist(lengths, values, collapse_batch, offsets=offsets)
+
+    def lookup(self, sk, train: bool = True):
+        """-> (local output: pooled partial sums [W*B, total_D] fp32 or rows [n_recv, D]; local context)"""
+        return self.local.forward(sk.values, sk.offsets, train)
+
+    def dist_output(self, sk, out_local: torch.Tensor, bucketized: bool = False) -> torch.Tensor:
         W, B = self.world, sk.batch_size
         if self.pooled:
             # out_local [W*B, total_D] fp32: block p belongs to rank p's samples
             assert out_local.dtype == torch.float32 and out_local.size(0) == W * B
             recv = torch.empty_like(out_local)
             dist.all_to_all_single(recv, out_local.contiguous(), group=self.pg)
-            out = self.ops.sum_chunks(recv.view(W, B * out_local.size(1)), self.out_dtype).view(B, out_local.size(1))
+            return self.ops.sum_chunks(recv.view(W, B * out_local.size(1)), self.out_dtype).view(B, out_local.size(1))
+        D = out_local.size(1)
+        # rows come out in (f, src, b) order; send them back in the order they arrived: (src, f, b)
+        rows_sfb = self.ops.permute_bags(sk.num_features, W, B, sk.offsets, sk.recv_offsets, out_local.contiguous())
+        back = torch.empty(sum(sk.send_splits), D, dtype=out_local.dtype, device=out_local.device)
+        dist.all_to_all_single(back, rows_sfb, [s for s in sk.send_splits], [r for r in sk.recv_splits], group=self.pg)
+        out = back if bucketized else self.ops.gather_rows(back, sk.unbucketize_permute)
+        return out if out.dtype == self.out_dtype else out.to(self.out_dtype)
+
+    def dist_grads(self, sk, grads: torch.Tensor, bucketized: bool = False) -> torch.Tensor:
+        """gradients of the stage-3 output -> gradients of the local lookup's output (the reverse exchange)"""
+        W, B = self.world, sk.batch_size
+        grads = grads.contiguous()
+        if self.pooled:
+            g_all = torch.empty(W * grads.size(0), grads.size(1), dtype=grads.dtype, device=grads.device)
+            dist.all_gather_into_tensor(g_all, grads, group=self.pg)
+            return g_all
+        if bucketized:
+            g_send = grads
         else:
-            D = out_local.size(1)
-            # rows come out in (f, src, b) order; send them back in the order they arrived: (src, f, b)
-            rows_sfb = self.ops.permute_bags(sk.num_features, W, B, sk.offsets, sk.recv_offsets, out_local.contiguous())
-            back = torch.empty(sum(sk.send_splits), D, dtype=out_local.dtype, device=out_local.device)
-            dist.all_to_all_single(back, rows_sfb, [s for s in sk.send_splits], [r for r in sk.recv_splits],
-                                   group=self.pg)
-            out = back if bucketized else self.ops.gather_rows(back, sk.unbucketize_permute)
-            if out.dtype != self.out_dtype:
-                out = out.to(self.out_dtype)
+            perm = sk.unbucketize_permute
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(perm.numel(), dtype=perm.dtype, device=perm.device)
+            g_send = self.ops.gather_rows(grads, inv)  # bucketized order
+        g_recv = torch.empty(sum(sk.recv_splits), grads.size(1), dtype=grads.dtype, device=grads.device)
+        dist.all_to_all_single(g_recv, g_send, [r for r in sk.recv_splits], [s for s in sk.send_splits], group=self.pg)
+        return self.ops.permute_bags(W, sk.num_features, B, sk.recv_offsets, sk.offsets, g_recv)
+
+    # ------------------------------------------------------------------------------ forward
+    def forward(self, values: torch.Tensor, offsets: torch.Tensor, train: bool = True, collapse_batch: bool = False,
+                lengths: Optional[torch.Tensor] = None, bucketized: bool = False):
+        """bucketized (sequence mode): return the rows in EXCHANGE order (as they come back from the owners) instead of
+        gathering them into key order -- the caller composes `ctx.keys.unbucketize_permute` into its own index."""
+        sk = self.dist_input(values, offsets, collapse_batch, lengths)
+        out_local, lctx = self.lookup(sk, train)
+        out = self.dist_output(sk, out_local, bucketized)
         return out, _ShardedCtx(sk, lctx, sum(sk.send_splits))
 
     # ------------------------------------------------------------------------------ backward
     def backward(self, ctx: _ShardedCtx, grads: torch.Tensor, bucketized: bool = False) -> None:
         """bucketized (sequence mode): `grads` rows are already in exchange order."""
-        sk, W, B = ctx.keys, self.world, ctx.keys.batch_size
-        grads = grads.contiguous()
-        if self.pooled:
-            g_all = torch.empty(W * grads.size(0), grads.size(1), dtype=grads.dtype, device=grads.device)
-            dist.all_gather_into_tensor(g_all, grads, group=self.pg)
-        else:
-            if bucketized:
-                g_send = grads
-            else:
-                n = ctx.n_local
-                perm = sk.unbucketize_permute
-                inv = torch.empty_like(perm)
-                inv[perm] = torch.arange(n, dtype=perm.dtype, device=perm.device)
-                g_send = self.ops.gather_rows(grads, inv)  # bucketized order
-            g_recv = torch.empty(sum(sk.recv_splits), grads.size(1), dtype=grads.dtype, device=grads.device)
-            dist.all_to_all_single(g_recv, g_send, [r for r in sk.recv_splits], [s for s in sk.send_splits],
-                                   group=self.pg)
-            g_all = self.ops.permute_bags(W, sk.num_features, B, sk.recv_offsets, sk.offsets, g_recv)
-        self.local.backward(ctx.local_ctx, g_all)
+        self.local.backward(ctx.local_ctx, self.dist_grads(ctx.keys, grads, bucketized))
 
 
 class RowWiseShardedPooledRows:
@@ -170,6 +181,14 @@ class _ModuleLocal:
     """Adapter: BatchedDynamicEmbeddingTablesV2 as the `local` of RowWiseShardedLookup."""
 
     def __init__(self, module):
+        from .dynamicemb_config import DynamicEmbPoolingMode
+
+        # partial pooled sums of the shards are ADDED by the output dist: a local MEAN would divide by the local bag
+        # length on every shard.  Pool with SUM here and divide by the global bag length after the exchange
+        # (dynamicemb/shard/embeddingbag.py does), as TorchRec applies the mean after its reduce-scatter.
+        if module.pooling_mode == DynamicEmbPoolingMode.MEAN:
+            raise ValueError("the local module of a row-wise sharded pooled lookup must pool with SUM (apply the mean "
+                             "after the output dist)")
         self.module = module
 
     def forward(self, values, offsets, train):

@@ -5,3 +5,10 @@ the gfx950 MFMA kernels (mi355_hstu_attn_fwd / mi355_hstu_attn_bwd).
 """
 from .hstu_attn_interface import (HstuAttnVarlenFunc, append_kvcache, hstu_attn_varlen_func, hstu_varlen_bwd,  # noqa: F401
                                   hstu_varlen_fwd, hstu_varlen_fwd_kv)
+
+try:  # `import hstu` registers torch.ops.fbgemm.hstu_varlen_* (the example relies on it: fused_hstu_op.py:19)
+    from . import hstu_ops_gpu  # noqa: F401
+except Exception as _e:  # pragma: no cover - e.g. a torch build without torch.library
+    import warnings
+
+    warnings.warn(f"hstu: torch.ops.fbgemm.hstu_varlen_* were not registered ({_e})")

@@ -7,7 +7,8 @@ examples/hstu/modules/hstu_attention.py:296-314): same argument meaning, same in
 contextual / target masks require causal -- hstu_api.cpp:359-430).
 Inference extensions (forward only): cu_seqlens_k longer than cu_seqlens_q (delta-q) and the paged KV cache
 (kv_cache / page_offsets / page_ids / last_page_lens).
-Not supported this round (raise): rab / drab, seqused_*, local windows, fp16 (bf16 only).
+Not supported (raise): rab / drab, seqused_*, local windows, fp16 (bf16 only).  The raw ops of the fused layer
+(`torch.ops.fbgemm.hstu_varlen_{fwd,bwd}_{80,90}`) are registered by `hstu.hstu_ops_gpu`.
 """
 from __future__ import annotations
 
@@ -160,10 +161,13 @@ def hstu_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, seqused_q, sequse
         raise RuntimeError("max_seqlen_q must be <= max_seqlen_k")
     if scaling_seqlen is None or scaling_seqlen == -1:
         scaling_seqlen = max_seqlen_q
-    # (the comparison of two distinct offset tensors reads them back: only done when no cache was passed, so that the
-    # paged decode step stays free of host syncs and can be captured in a HIP graph)
+    # Self-attention (training) or delta-q / paged KV (inference)?  Decided from what the HOST knows -- the example passes
+    # two distinct `offsets.to(int32)` tensors for the same offsets (hstu_attention.py:299-300), and reading them back to
+    # compare would be a blocking device-to-host copy per attention layer per step (and impossible under graph capture).
+    # Equal shapes of q / k and of the offset arrays with equal max lengths is self-attention; a delta-q call has more
+    # keys than queries.
     same = kv_cache is None and (cu_seqlens_q.data_ptr() == cu_seqlens_k.data_ptr() or (
-        cu_seqlens_q.shape == cu_seqlens_k.shape and bool(torch.equal(cu_seqlens_q, cu_seqlens_k))))
+        cu_seqlens_q.shape == cu_seqlens_k.shape and q.shape[0] == k.shape[0] and int(max_seqlen_q) == int(max_seqlen_k)))
     if kv_cache is not None or not same:
         # inference: keys longer than the queries and / or history keys in the paged cache; no backward
         if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):

@@ -1,0 +1,117 @@
+"""`torch.ops.fbgemm.hstu_varlen_{fwd,bwd}_{80,90}` on MI355X.
+
+The reference's fused HSTU layer does not go through `hstu_attn_varlen_func`: it calls the raw ops of the `hstu` pip package
+(examples/hstu/ops/fused_hstu_op.py:318-366 forward, :682-750 backward), picking the `_80` or `_90` flavour from
+`torch.cuda.get_device_properties(0).major` -- which is 9 on gfx950, so an unchanged example lands on the `_90` names here.
+Importing this module (the example does: `import hstu.hstu_ops_gpu`, fused_hstu_op.py:19-20) defines all four ops with the
+positional order of those call sites, backed by the gfx950 kernels, plus Meta kernels for export.  Arguments this build has
+no kernel for (rab / drab, seqused, arbitrary mask functions, fp8 quantisation, local windows) must be None / default; the
+ops raise otherwise."""
+import torch
+
+from .hstu_attn_interface import hstu_varlen_bwd, hstu_varlen_fwd
+
+_T = "Tensor"
+_O = "Tensor?"
+
+
+def _already_there(name: str) -> bool:
+    try:
+        getattr(torch.ops.fbgemm, name)
+        return True
+    except (AttributeError, RuntimeError):
+        return False
+
+
+def _check(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, wl, wr, rab, func, quant_mode=-1, extra=()):
+    if seqused_q is not None or seqused_k is not None:
+        raise NotImplementedError("seqused_q / seqused_k are not supported")
+    if rab is not None or func is not None:
+        raise NotImplementedError("rab / arbitrary mask functions are not supported")
+    if quant_mode not in (-1, None) or any(e is not None for e in extra):
+        raise NotImplementedError("fp8 quantisation is not supported")
+    if wl != -1 or wr not in (-1, 0):
+        raise NotImplementedError("local attention windows are not supported; use (-1, 0) causal or (-1, -1) full")
+    if q.dtype != torch.bfloat16:
+        raise RuntimeError("hstu_varlen ops support bf16 only in this build")
+    if max_q != max_k or q.shape[0] != k.shape[0] or cu_q.shape != cu_k.shape:
+        raise NotImplementedError("the raw training ops are self-attention only (cu_seqlens_q == cu_seqlens_k)")
+    if v.shape != k.shape:
+        raise RuntimeError("v must have the shape of k (the fused layer asserts linear_dim == attention_dim, hstu_attention.py:248-250)")
+    return wr == 0
+
+
+def _fwd(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, scaling_seqlen, num_contexts, num_targets, target_group_size,
+         wl, wr, alpha, rab, func, quant_mode=-1, output_dtype=0):
+    causal = _check(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, wl, wr, rab, func, quant_mode)
+    if output_dtype not in (0, None):
+        raise NotImplementedError("output_dtype must be 0 (bf16)")
+    out = hstu_varlen_fwd(q, k, v, cu_q, int(max_k), scaling_seqlen, num_contexts, num_targets, int(target_group_size), causal,
+                          float(alpha))
+    return out, None
+
+
+def _bwd(dout, q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, scaling_seqlen, dq, dk, dv, num_contexts, num_targets,
+         target_group_size, wl, wr, alpha, rab, has_drab, func, deterministic, quant_mode=-1, extra=()):
+    causal = _check(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, wl, wr, rab, func, quant_mode, extra)
+    if has_drab:
+        raise NotImplementedError("drab is not supported")
+    g = hstu_varlen_bwd(dout, q, k, v, cu_q, int(max_k), scaling_seqlen, num_contexts, num_targets, int(target_group_size),
+                        causal, float(alpha))       # (deterministic by construction: no atomics in the dQ pass)
+    res = []
+    for given, new in zip((dq, dk, dv), g):
+        if given is not None:
+            given.copy_(new)
+            new = given
+        res.append(new)
+    return res[0], res[1], res[2], None
+
+
+def _fwd_90(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, scaling_seqlen, num_contexts, num_targets,
+            target_group_size, wl, wr, alpha, rab, func, quant_mode, output_dtype):
+    return _fwd(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, scaling_seqlen, num_contexts, num_targets,
+                target_group_size, wl, wr, alpha, rab, func, quant_mode, output_dtype)
+
+
+def _bwd_90(dout, dout_t, q, q_t, k, k_t, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, scaling_seqlen, dq, dk, dv,
+            num_contexts, num_targets, target_group_size, wl, wr, alpha, quant_mode, rab, has_drab, func, d0, d1, d2, d3, d4,
+            d5, d6, d7, d8, d9, d10, output_dtype, deterministic):
+    return _bwd(dout, q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, scaling_seqlen, dq, dk, dv, num_contexts,
+                num_targets, target_group_size, wl, wr, alpha, rab, has_drab, func, deterministic, quant_mode,
+                (dout_t, q_t, k_t, d0, d1, d2, d3, d4, d5, d6, d7, d8, d9, d10))
+
+
+def _fwd_meta(q, *a, **kw):
+    return torch.empty_like(q), None
+
+
+def _bwd80_meta(dout, q, k, v, *a, **kw):
+    return torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), None
+
+
+def _bwd90_meta(dout, dout_t, q, q_t, k, k_t, v, *a, **kw):
+    return torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), None
+
+
+_FWD_ARGS = (f"{_T} q, {_T} k, {_T} v, {_T} cu_seqlens_q, {_T} cu_seqlens_k, {_O} seqused_q, {_O} seqused_k, int max_seqlen_q, "
+             f"int max_seqlen_k, float scaling_seqlen, {_O} num_contexts, {_O} num_targets, int target_group_size, "
+             f"int window_size_left, int window_size_right, float alpha, {_O} rab, {_O} func")
+_BWD_TAIL = (f"{_T} cu_seqlens_q, {_T} cu_seqlens_k, {_O} seqused_q, {_O} seqused_k, int max_seqlen_q, int max_seqlen_k, "
+             f"float scaling_seqlen, Tensor(a!)? dq, Tensor(b!)? dk, Tensor(c!)? dv, {_O} num_contexts, {_O} num_targets, "
+             "int target_group_size, int window_size_left, int window_size_right, float alpha")
+_DESCALE = ", ".join(f"{_O} descale_{i}" for i in range(11))
+
+_lib = None
+if not _already_there("hstu_varlen_fwd_80"):
+    _lib = torch.library.Library("fbgemm", "FRAGMENT")
+    _lib.define(f"hstu_varlen_fwd_80({_FWD_ARGS}) -> (Tensor, Tensor?)")
+    _lib.define(f"hstu_varlen_fwd_90({_FWD_ARGS}, int quant_mode, int output_dtype) -> (Tensor, Tensor?)")
+    _lib.define(f"hstu_varlen_bwd_80({_T} dout, {_T} q, {_T} k, {_T} v, {_BWD_TAIL}, {_O} rab, bool has_drab, {_O} func, "
+                "bool deterministic) -> (Tensor, Tensor, Tensor, Tensor?)")
+    _lib.define(f"hstu_varlen_bwd_90({_T} dout, {_O} dout_t, {_T} q, {_O} q_t, {_T} k, {_O} k_t, {_T} v, {_BWD_TAIL}, "
+                f"int quant_mode, {_O} rab, bool has_drab, {_O} func, {_DESCALE}, int output_dtype, bool deterministic) "
+                "-> (Tensor, Tensor, Tensor, Tensor?)")
+    for name, impl, meta in (("hstu_varlen_fwd_80", _fwd, _fwd_meta), ("hstu_varlen_fwd_90", _fwd_90, _fwd_meta),
+                             ("hstu_varlen_bwd_80", _bwd, _bwd80_meta), ("hstu_varlen_bwd_90", _bwd_90, _bwd90_meta)):
+        _lib.impl(name, impl, "CUDA")
+        _lib.impl(name, meta, "Meta")

@@ -399,3 +399,36 @@ def test_c5_paged_decode_full_size_equals_contiguous_keys():
                                      window_size=(-1, 0), alpha=1.0 / d ** 0.5)
     assert torch.equal(out_paged, out_flat)
     assert float(out_paged.float().abs().max()) > 0
+
+
+def test_raw_fbgemm_ops_of_the_fused_layer_match_the_wrapper():
+    """torch.ops.fbgemm.hstu_varlen_{fwd,bwd}_{80,90} with the positional order of examples/hstu/ops/fused_hstu_op.py
+    :318-366,:682-750 give what hstu_attn_varlen_func + autograd give"""
+    import hstu  # noqa: F401 (registers the ops)
+    from hstu import hstu_attn_varlen_func
+
+    torch.manual_seed(0)
+    lens = [37, 0, 128, 5]
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+    T, H, D = int(cu[-1]), 2, 64
+    q, k, v = (torch.randn(T, H, D, device="cuda", dtype=torch.bfloat16).requires_grad_() for _ in range(3))
+    nt = torch.tensor([3, 0, 10, 1], dtype=torch.int32, device="cuda")
+    nc = torch.tensor([2, 0, 4, 0], dtype=torch.int32, device="cuda")
+    alpha, L = 1.0 / 8, 128
+    ref = hstu_attn_varlen_func(q, k, v, cu, cu.clone(), None, None, L, L, L, nc, nt, 1, (-1, 0), alpha)
+    dout = torch.randn_like(ref)
+    gq, gk, gv = torch.autograd.grad(ref, (q, k, v), dout)
+    with torch.no_grad():
+        o80, rab = torch.ops.fbgemm.hstu_varlen_fwd_80(q, k, v, cu, cu, None, None, L, L, L, nc, nt, 1, -1, 0, alpha, None, None)
+        o90, _ = torch.ops.fbgemm.hstu_varlen_fwd_90(q, k, v, cu, cu, None, None, L, L, L, nc, nt, 1, -1, 0, alpha, None, None, -1, 0)
+        assert rab is None and torch.equal(o80, ref) and torch.equal(o90, ref)
+        dq, dk, dv, drab = torch.ops.fbgemm.hstu_varlen_bwd_80(dout, q, k, v, cu, cu, None, None, L, L, L, None, None, None, nc, nt,
+                                                               1, -1, 0, alpha, None, False, None, False)
+        assert drab is None and torch.equal(dq, gq) and torch.equal(dk, gk) and torch.equal(dv, gv)
+        bq = torch.empty_like(q)
+        r = torch.ops.fbgemm.hstu_varlen_bwd_90(dout, None, q, None, k, None, v, cu, cu, None, None, L, L, L, bq, None, None, nc, nt,
+                                                1, -1, 0, alpha, -1, None, False, None, None, None, None, None, None, None, None,
+                                                None, None, None, None, 0, False)
+        assert torch.equal(r[0], gq) and r[0].data_ptr() == bq.data_ptr() and torch.equal(r[1], gk) and torch.equal(r[2], gv)
+        with pytest.raises(NotImplementedError):
+            torch.ops.fbgemm.hstu_varlen_fwd_80(q, k, v, cu, cu, None, None, L, L, L, nc, nt, 1, 16, 0, alpha, None, None)
