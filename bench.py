@@ -57,9 +57,24 @@ def parse():
     return ap.parse_args()
 
 
+def zipf_keys(min_val, max_val, exponent, size, device):
+    """The reference harness's `zipf()` (corelib/dynamicemb/benchmark/dataset_generator.py:75-103) restated call for call:
+    p_r = r^-a over r = 1..n in float64, normalised, cast to float32; the value range shuffled by `randperm`; `size`
+    draws with replacement by `multinomial` -- the same three generator calls in the same order, so under the same
+    `torch.manual_seed` the key stream is bit-identical to the reference's (pinned by tests/golden/demb_flow_golden.npz,
+    which holds what the reference's own function returns on the CPU)."""
+    n = max_val - min_val
+    probs = 1.0 / torch.arange(1, n + 1, dtype=torch.float64, device=device) ** exponent
+    probs = (probs / probs.sum()).float()
+    shuffled = torch.arange(min_val, max_val, dtype=torch.long, device=device)[torch.randperm(n, device=device)]
+    return shuffled[torch.multinomial(probs, size, replacement=True)]
+
+
 def zipf_batches(rows, alpha, batch, n_batches, device, seed=1234):
-    """Key stream of the reference's dataset_generator.zipf() recipe (benchmark/dataset_generator.py:75-103):
-    p_r ~ r^-alpha over ranks 1..rows, sampled with replacement, rank -> key by a fixed permutation."""
+    """Key stream of the reference's dataset_generator.zipf() recipe (benchmark/dataset_generator.py:75-103; `zipf_keys`
+    above is its literal restatement): p_r ~ r^-alpha over ranks 1..rows, sampled with replacement, rank -> key by ONE
+    fixed permutation for all batches (a stable hot set), drawn by inverse CDF in float64 -- multinomial is
+    limited to 2^24 categories and float32 probabilities."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     w = torch.arange(1, rows + 1, device=device, dtype=torch.float64).pow_(-alpha)

@@ -56,6 +56,9 @@ CASES = [
     ("causal_ctx_targets_group2", [12, 31, 8, 50], [4, 6, 2, 9], [1, 3, 0, 2], 1, 32, True, 2),
     ("noncausal", [7, 19, 3], None, None, 2, 32, False, 1),
     ("d128_long", [130, 77, 200], [5, 0, 9], [2, 1, 0], 1, 128, True, 1),
+    # d = 256: the head dim of BASELINE configs 3-5 (C3 / C4 attention, H = 4 there; one head keeps the fixture small)
+    ("d256_causal_plain", [40, 9, 75], None, None, 1, 256, True, 1),
+    ("d256_ctx_targets", [66, 21, 90], [6, 2, 11], [3, 0, 2], 1, 256, True, 1),
 ]
 
 

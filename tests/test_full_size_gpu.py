@@ -1,0 +1,159 @@
+"""The TABLE halves of BASELINE configs 3 and 4 at full size on one MI355X (the attention halves are in test_hstu_gpu.py):
+
+C3: 8 tables x 50 M rows x 128-D sharded 8-way with hash_roundrobin -> what ONE rank holds and serves: 8 tables x 6 250 112
+    rows (25.6 GB of fp32 rows) and, per step, the keys the 8 source ranks route to it out of 8 x (32 sequences x 512 ids) per
+    table, Zipf-1.05 (E2E_BENCHMARK.md:41-63).  The routing itself runs through the bucketize kernel.
+C4: one table of >= 100 M logical rows whose HBM tier is capped far below the working set, so new keys keep evicting rows
+    into the pinned host tier (HybridStorage, key_value_table.py:2107-2403).
+No oracle runs at these sizes in seconds: the checks are the size-independent properties of the domain (routing rule,
+dedup counts, every stored row readable, known-answer DEBUG rows, exactly-once SGD update)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _fmix64(k: np.ndarray) -> np.ndarray:
+    k = k.astype(np.uint64)
+    k ^= k >> np.uint64(33)
+    k *= np.uint64(0xff51afd7ed558ccd)
+    k ^= k >> np.uint64(33)
+    k *= np.uint64(0xc4ceb9fe1a85ec53)
+    k ^= k >> np.uint64(33)
+    return k
+
+
+def _zipf_ids(n, rows, alpha, gen):
+    """inverse-CDF draw of n ids ~ Zipf(alpha) over [0, rows), rank -> id by a multiplicative scramble"""
+    w = torch.arange(1, rows + 1, device=DEV, dtype=torch.float64).pow_(-alpha)
+    cdf = torch.cumsum(w, 0)
+    cdf /= cdf[-1].clone()
+    u = torch.rand(n, device=DEV, dtype=torch.float64, generator=gen)
+    rank = torch.searchsorted(cdf, u).clamp_(max=rows - 1)
+    return (rank * 2654435761 + 12345) % rows
+
+
+def test_c3_per_rank_table_slice():
+    import dynamicemb_extensions as ext
+    from dynamicemb import (DynamicEmbInitializerArgs, DynamicEmbInitializerMode, DynamicEmbPoolingMode, DynamicEmbScoreStrategy,
+                            DynamicEmbTableOptions, EmbOptimType)
+    from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 << 30:
+        pytest.skip("needs ~30 GB of HBM")
+    W, T, rows_global, D, B, L, lr = 8, 8, 50_000_000, 128, 32, 512, 0.5
+    cap = -(-(-(-rows_global // W)) // 128) * 128        # ceil(N / W) rounded up to buckets: 6 250 112
+    assert cap == 6_250_112
+    opts = [DynamicEmbTableOptions(dim=D, max_capacity=cap, index_type=torch.int64, embedding_dtype=torch.float32,
+                                   score_strategy=DynamicEmbScoreStrategy.TIMESTAMP, dist_type="hash_roundrobin",
+                                   initializer_args=DynamicEmbInitializerArgs(mode=DynamicEmbInitializerMode.DEBUG)) for _ in range(T)]
+    m = BatchedDynamicEmbeddingTablesV2(opts, pooling_mode=DynamicEmbPoolingMode.NONE, output_dtype=torch.float32,
+                                        optimizer=EmbOptimType.SGD, learning_rate=lr, device=DEV)
+    m.train()
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(33)
+    block = torch.full((T,), -(-rows_global // W), dtype=torch.int64, device=DEV)
+    dist = torch.full((T,), 2, dtype=torch.int32, device=DEV)          # hash_roundrobin
+    for step in range(3):
+        # every source rank's batch goes through the bucketize kernel; this rank keeps bucket 0 of each
+        parts_v, parts_l = [], []
+        for src in range(W):
+            ids = torch.cat([_zipf_ids(B * L, rows_global, 1.05, gen) for _ in range(T)])
+            lengths = torch.full((T * B,), L, dtype=torch.int64, device=DEV)
+            nl, nv, _, _, perm = ext.block_bucketize_sparse_features(lengths, ids, False, True, dist, block, W)
+            n0 = int(nl[:T * B].sum())
+            parts_v.append((nv[:n0], nl[:T * B].view(T, B)))
+        # recat (src, f, b) -> (f, src, b)
+        lens_fsb = torch.stack([p[1] for p in parts_v], 1)                       # [T, W, B]
+        vals = []
+        for f in range(T):
+            for src in range(W):
+                v, l = parts_v[src]
+                o = int(l[:f].sum())
+                vals.append(v[o:o + int(l[f].sum())])
+        keys = torch.cat(vals).contiguous()
+        off = torch.zeros(T * W * B + 1, dtype=torch.int64, device=DEV)
+        off[1:] = torch.cumsum(lens_fsb.reshape(-1), 0)
+        n = keys.numel()
+        # ~1/8 of the 8 ranks' keys -- give or take the Zipf head: a hot id goes to ONE rank with all its occurrences
+        assert 0.4 * B * L * T < n < 2.5 * B * L * T
+        # routing rule: every key this rank received hashes to it
+        assert (_fmix64(keys.cpu().numpy().view(np.uint64)) % np.uint64(W) == 0).all()
+        out, st = m._forward_impl(keys, off, train=True)
+        # known answer: DEBUG rows are float(key % 100000) until a gradient arrives; after, lookup_rows is the truth
+        seg = torch.repeat_interleave(torch.arange(T, device=DEV), off.view(-1)[torch.arange(0, T + 1, device=DEV) * W * B].diff())
+        uniq_total = 0
+        for t in range(T):
+            kt = keys[seg == t]
+            found, rows = m.lookup_rows(kt, t)
+            assert bool(found.all()) and torch.equal(out[seg == t], rows[:, :D])
+            uniq_total += int(torch.unique(kt).numel())
+        assert int(st.uoff[-1]) == uniq_total
+        if step == 0:
+            assert torch.equal(out[:, 0], (keys % 100000).float())
+        # one SGD step, gradient of ones: every row moves by exactly lr x its number of occurrences (exactly once each)
+        before = [m.lookup_rows(torch.unique(keys[seg == t]), t)[1][:, :D] for t in range(T)]
+        m._backward_impl(st, torch.ones_like(out))
+        for t in range(T):
+            uk, cnt = torch.unique(keys[seg == t], return_counts=True)
+            after = m.lookup_rows(uk, t)[1][:, :D]
+            torch.testing.assert_close(after, before[t] - lr * cnt[:, None].float(), rtol=0, atol=lr * 2e-3 * float(cnt.max()))
+    assert int(m.size()) <= T * cap
+
+
+def test_c4_table_overflows_into_the_host_tier():
+    from dynamicemb import (DynamicEmbInitializerArgs, DynamicEmbInitializerMode, DynamicEmbPoolingMode, DynamicEmbScoreStrategy,
+                            DynamicEmbTableOptions, EmbOptimType)
+    from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
+
+    rows, D, lr = 100_000_000, 128, 0.25
+    need = rows * D * 4 + (64 << 30)
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    if avail is not None and avail < need:
+        pytest.skip(f"needs {need >> 30} GB of host memory for the pinned tier, {avail >> 30} GB available")
+    hbm_rows = 1 << 20            # HBM tier: 1 M rows (0.5 GB) for a 100 M-row logical table
+    opt = DynamicEmbTableOptions(dim=D, max_capacity=rows, index_type=torch.int64, embedding_dtype=torch.float32,
+                                 score_strategy=DynamicEmbScoreStrategy.STEP, local_hbm_for_values=hbm_rows * D * 4,
+                                 initializer_args=DynamicEmbInitializerArgs(mode=DynamicEmbInitializerMode.DEBUG))
+    m = BatchedDynamicEmbeddingTablesV2([opt], pooling_mode=DynamicEmbPoolingMode.SUM, output_dtype=torch.float32,
+                                        optimizer=EmbOptimType.SGD, learning_rate=lr, device=DEV)
+    assert m.storage_mode == "hybrid" and m.table.capacity_ == hbm_rows and m.table_host.capacity_ >= rows
+    m.train()
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(44)
+    B = 65536
+    seen = []
+    for step in range(4):
+        # 600 K mostly-new keys per step from the 100 M id space: after two steps the HBM tier is full and every further
+        # new key pushes a resident row down into the host tier
+        keys = torch.randint(0, rows, (B * 9,), device=DEV, generator=gen)
+        off = torch.arange(0, B * 9 + 1, 9, device=DEV, dtype=torch.int64)
+        out, st = m._forward_impl(keys, off, train=True)
+        ref = (keys % 100000).float().view(B, 9).sum(1)
+        if step == 0:
+            torch.testing.assert_close(out[:, 0], ref, rtol=1e-6, atol=1e-2)     # DEBUG known answer, pooled
+        seen.append(torch.unique(keys))
+        m._backward_impl(st, torch.ones(B, D, device=DEV))
+    allk = torch.unique(torch.cat(seen))
+    # nothing was lost: every key ever inserted is found in one of the tiers
+    found, rows_now = m.lookup_rows(allk, 0)
+    assert bool(found.all())
+    assert int(m.size()) == allk.numel()
+    assert int(m.table.size()) <= hbm_rows and int(m.table_host.size()) > allk.numel() - hbm_rows - 1
+    # exactly-once updates survived the moves between the tiers: row = DEBUG value - lr x (total occurrences so far)
+    gen.manual_seed(44)
+    counts = torch.zeros(allk.numel(), dtype=torch.int64, device=DEV)
+    for step in range(4):
+        keys = torch.randint(0, rows, (B * 9,), device=DEV, generator=gen)
+        counts += torch.bincount(torch.searchsorted(allk, keys), minlength=allk.numel())
+    want = (allk % 100000).float()[:, None] - lr * counts[:, None].float()
+    torch.testing.assert_close(rows_now[:, :D], want.expand(-1, D), rtol=1e-6, atol=1e-2)

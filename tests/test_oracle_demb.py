@@ -12,6 +12,7 @@ against the reference's own fixtures and invariants:
 """
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -292,3 +293,51 @@ def test_block_bucketize_routing():
                 assert p == orc.fmix64(int(k)) % W and ni[perm[j]] == k
             else:
                 assert p == k // 250 and ni[perm[j]] == k % 250
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# pins from the reference's own pure-Python code (tests/golden/gen_demb_flow_golden.py pulls it out of the AST)
+FLOW = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "demb_flow_golden.npz"))
+
+
+@pytest.mark.parametrize("name", [str(x) for x in FLOW["flow_cases"]])
+def test_deterministic_insert_follows_the_reference_wave_order(name):
+    """oracle.insert_deterministic == the reference's `_bucketize_and_pad` + `_deterministic_insert`
+    (scored_hashtable.py:1451-1558) driving the same oracle kernels: same slot for every key, same arena bytes"""
+    g = lambda k: FLOW[f"{name}/{k}"]
+    C, policy, nb = [int(x) for x in g("C")]
+    t = orc.OracleTable([int(c) for c in g("caps")], C)
+    for i in range(nb):
+        idx = t.insert_deterministic(g(f"keys{i}"), g(f"tids{i}"), g(f"scores{i}"), policy)
+        assert np.array_equal(idx, g(f"idx{i}")), f"batch {i}"
+    assert np.array_equal(t.storage, g("arena")) and np.array_equal(t.bucket_sizes, g("bucket_sizes"))
+
+
+def test_optimizer_state_layout_matches_the_reference_functions():
+    """row = [embedding | optimizer state]: get_optimizer_state_dim / get_optimizer_ckpt_state_dim (optimizer.py:36-75)"""
+    import torch
+
+    from dynamicemb.dynamicemb_config import EmbOptimType, get_optimizer_state_dim
+    from dynamicemb.optimizer import get_optimizer_ckpt_state_dim
+
+    names = [str(x) for x in FLOW["opt_names"]]
+    dts = [torch.float32, torch.bfloat16, torch.float16]
+    for oi, dim, dc, state, ckpt in FLOW["opt_rows"]:
+        o = EmbOptimType[names[oi]]
+        assert get_optimizer_state_dim(o, int(dim), dts[dc]) == state, (o, dim, dts[dc])
+        assert get_optimizer_ckpt_state_dim(o, int(dim)) == ckpt, (o, dim)
+
+
+@pytest.mark.parametrize("name", [str(x) for x in FLOW["zipf_cases"]])
+def test_zipf_key_stream_is_the_reference_generator(name):
+    """bench.zipf_keys reproduces dataset_generator.zipf (benchmark/dataset_generator.py:75-103) bit for bit under the
+    same torch seed (CPU generator)"""
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    lo, hi, n, seed = [int(x) for x in FLOW[f"zipf/{name}/meta"]]
+    torch.manual_seed(seed)
+    got = bench.zipf_keys(lo, hi, float(FLOW[f"zipf/{name}/alpha"]), n, torch.device("cpu")).numpy()
+    assert np.array_equal(got, FLOW[f"zipf/{name}/samples"])
