@@ -108,86 +108,133 @@ def build_module(rows, dim, device):
                                            device=device)
 
 
-def cpu_baseline(args, batches_cpu):
-    """The path an unsharded TorchRec CPU EmbeddingBagCollection executes: nn.EmbeddingBag(mode='sum',
-    include_last_offset=True) forward + sparse-gradient SGD, timed on this host on a bounded sample."""
-    torch.set_num_threads(os.cpu_count() or 1)
-    t0 = time.time()
-    emb = torch.nn.EmbeddingBag(args.rows, args.dim, mode="sum", include_last_offset=True, sparse=True)
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_ebc_run(emb, dim, batches_cpu, threads, seconds, lr=0.1):
+    """What an unsharded TorchRec CPU EmbeddingBagCollection executes for one table: nn.EmbeddingBag(mode='sum',
+    include_last_offset=True) forward, backward to a SPARSE gradient, SGD on the touched rows only (index_add_ of the
+    coalesced gradient rows: `weight.add_(sparse)` densifies on some builds).  -> (keys/s, batches timed, keys timed)"""
+    torch.set_num_threads(threads)
+    keys_done, spent, iters = 0, 0.0, 0
+    while spent < seconds:
+        for keys, offsets in batches_cpu:
+            g = torch.ones(offsets.numel() - 1, dim)
+            t = time.perf_counter()
+            out = emb(keys, offsets)
+            out.backward(g)
+            with torch.no_grad():
+                sg = emb.weight.grad.coalesce()
+                emb.weight.index_add_(0, sg.indices()[0], sg.values(), alpha=-lr)
+            emb.weight.grad = None
+            dt_ = time.perf_counter() - t
+            if iters > 0:  # the first iteration is warm-up
+                spent += dt_
+                keys_done += keys.numel()
+            iters += 1
+            if spent >= seconds:
+                break
+    return (keys_done / spent if spent > 0 else 0.0), iters - 1, keys_done
+
+
+def _cpu_table(rows, dim):
+    emb = torch.nn.EmbeddingBag(rows, dim, mode="sum", include_last_offset=True, sparse=True)
     with torch.no_grad():
         emb.weight.uniform_(-0.01, 0.01)
-    setup = time.time() - t0
-    keys_done, spent, iters = 0, 0.0, 0
-    for keys, offsets in batches_cpu:
-        g = torch.ones(offsets.numel() - 1, args.dim)
-        t = time.time()
-        out = emb(keys, offsets)
-        out.backward(g)
-        with torch.no_grad():
-            emb.weight.add_(emb.weight.grad, alpha=-0.1)
-        emb.weight.grad = None
-        dt_ = time.time() - t
-        if iters > 0:  # first iteration is warm-up
-            spent += dt_
-            keys_done += keys.numel()
-        iters += 1
-        if spent > args.cpu_seconds:
-            break
-    val = keys_done / spent if spent > 0 else 0.0
-    return {"value": val, "unit": "lookups/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{iters - 1} batches of {args.batch} bags ({keys_done} keys) fwd+bwd+sparse SGD through "
-                      f"torch.nn.EmbeddingBag(mode=sum) on a {args.rows}x{args.dim} fp32 host table; "
-                      f"os.cpu_count()={os.cpu_count()}, table init {setup:.1f}s not timed"}
+    return emb
+
+
+def cpu_baseline(args, batches_cpu):
+    """SURVEY 8(d) CPU baseline: the reference's TorchRec CPU EmbeddingBagCollection path (TorchRec itself is not
+    installed: what its unsharded CPU EBC executes per table is torch.nn.EmbeddingBag) on THIS host, same key stream,
+    fwd + bwd + sparse SGD, over several thread counts (all host threads is NOT the fastest: the sparse backward does not
+    scale); `value` is the best of them and `cores` the thread count it used.  Plus the C1 plumbing configuration."""
+    ncpu = os.cpu_count() or 1
+    t0 = time.time()
+    emb = _cpu_table(args.rows, args.dim)
+    counts = sorted({1, min(16, ncpu), min(64, ncpu), ncpu})
+    per = {}
+    sample = []
+    for th in counts:
+        v, nb, nk = _cpu_ebc_run(emb, args.dim, batches_cpu, th, args.cpu_seconds / len(counts))
+        per[th] = v
+        sample.append(f"{th} threads: {nb} batches / {nk} keys")
+    best = max(per, key=per.get)
+    # C1 (BASELINE configs[0]): 1 table x 100 K rows x 32-D, batch 512 bags of 1..10 keys, CPU path only
+    g = torch.Generator().manual_seed(0)
+    c1 = []
+    for _ in range(8):
+        lens = torch.randint(1, 11, (512,), generator=g)
+        off = torch.zeros(513, dtype=torch.int64)
+        off[1:] = torch.cumsum(lens, 0)
+        c1.append((torch.randint(0, 100_000, (int(off[-1]),), generator=g), off))
+    emb1 = _cpu_table(100_000, 32)
+    c1_per = {th: _cpu_ebc_run(emb1, 32, c1, th, 0.5)[0] for th in counts}
+    torch.set_num_threads(ncpu)
+    return {"value": per[best], "unit": "lookups/s", "cores": best, "kind": "port",
+            "value_by_threads": {str(k): v for k, v in per.items()}, "value_1_thread": per[1],
+            "cpu_model": _cpu_model(), "os_cpu_count": ncpu,
+            "c1": {"workload": "C1: 1 table x 100000 rows x 32-D fp32, batch 512 bags x randint(1,11) keys, SUM, SGD",
+                   "value_by_threads": {str(k): v for k, v in c1_per.items()}, "value": max(c1_per.values()),
+                   "unit": "lookups/s"},
+            "sample": f"C2 key stream on a {args.rows}x{args.dim} fp32 host table through torch.nn.EmbeddingBag(mode=sum, "
+                      f"sparse=True) fwd + bwd + SGD on the touched rows; " + "; ".join(sample) +
+                      f"; {time.time() - t0:.0f} s of host time incl. table setup"}
 
 
 def kernel_roofline(module, batches, grad, batch, D, e=4, o=2):
-    """The two bandwidth kernels of the step, each timed live with HIP events on the launch stream (torch's current
-    stream) against its own algorithmic bytes -> (`roofline` object, step algorithmic bytes)."""
-    import dynamicemb_extensions as ext
+    """The two bandwidth kernels of the step, timed live with HIP events on the launch stream inside the REAL step calls:
+    the library brackets the gather launch of its fused forward and the fused reduce + optimizer launch of its backward
+    (mi355_profile_kernels / mi355_profile_ms).  Each against its own algorithmic bytes
+     -> (`roofline` object, step algorithmic bytes)."""
+    from mi355_native import check, lib
 
+    L = lib()
+    fused = bool(getattr(module, "_fused", False))
+    check(L.mi355_profile_kernels(1), "profile_kernels")
     nu_list, fwd_ms, bwd_ms = [], [], []
     for keys, offsets in batches:
         out, st = module._forward_impl(keys, offsets, train=True)
-        nu = int(st.uoff[-1].item())
-        nt = keys.numel()
-        nu_list.append((nt, nu))
-        out2 = torch.empty_like(out)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        ev[0].record()
-        ext.gather_embedding_pooled(None, out2, st.rev, offsets, 0, D, batch, max_D=D, row_addr=st.row_addr,
-                                    src_dtype=torch.float32)
-        ev[1].record()
-        ptr_t, csr, hot = ext.group_by_unique(st.rev, nt, offsets, nu_dev=st.uoff[-1:], dim=D)
-        ev[2].record()
-        ext.backward_fused(ptr_t, csr, nt, nt, grad, batch, D, 0, offsets, None, st.row_addr, torch.float32, 1,
-                           lr=0.1, nu_dev=st.uoff[-1:], hot=hot)
-        ev[3].record()
-        torch.cuda.synchronize()
-        fwd_ms.append(ev[0].elapsed_time(ev[1]))
-        bwd_ms.append(ev[2].elapsed_time(ev[3]))
+        if fused:
+            fwd_ms.append(float(L.mi355_profile_ms(0)))
+        nu_list.append((keys.numel(), int(st.uoff[-1].item())))
+        module._backward_impl(st, grad)
+        bwd_ms.append(float(L.mi355_profile_ms(1)))
+    L.mi355_profile_kernels(0)
     nt_avg = float(np.mean([a for a, _ in nu_list]))
     nu_avg = float(np.mean([b for _, b in nu_list]))
     FB = batch
-    fwd_bytes = 8 * nt_avg + 8 * (FB + 1) + 8 * nu_avg + nu_avg * D * e + FB * D * o
+    # gather: row address of every key + offsets + each unique row once (the duplicates are L2 hits) + pooled output
+    fwd_bytes = 8 * nt_avg + 8 * (FB + 1) + nu_avg * D * e + FB * D * o
     bwd_bytes = 4 * nt_avg + 4 * (nu_avg + 1) + 8 * nu_avg + FB * D * o + 2 * nu_avg * D * e
-    f_ms, b_ms = float(np.median(fwd_ms)), float(np.median(bwd_ms))
-    kern = {
-        "gather_pooled_pipe_kernel": {"ms": f_ms, "algorithmic_bytes": fwd_bytes, "GB/s": fwd_bytes / f_ms / 1e6},
-        "bwd_kernel": {"ms": b_ms, "algorithmic_bytes": bwd_bytes, "GB/s": bwd_bytes / b_ms / 1e6},
-    }
+    b_ms = float(np.median(bwd_ms))
+    kern = {"bwd_kernel": {"ms": b_ms, "algorithmic_bytes": bwd_bytes, "GB/s": bwd_bytes / b_ms / 1e6}}
+    if fwd_ms:
+        f_ms = float(np.median(fwd_ms))
+        kern["gather_pooled_pipe_kernel"] = {"ms": f_ms, "algorithmic_bytes": fwd_bytes, "GB/s": fwd_bytes / f_ms / 1e6}
     dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
-    # HBM traffic of the dominant kernel per launch from the committed PMC passes (counters cannot be read from
-    # inside this process): 2*FETCH_SIZE + WRITE_SIZE, see profiles/r01_pmc_traffic.json (C2 batch size only)
-    traffic = None
+    # HBM traffic of the dominant kernel per launch: PMC counters cannot be read from inside this process; the figure is
+    # the one of the committed separate rocprofv3 --pmc passes over THIS command (tools/pmc_run.sh, C2 batch size only)
+    traffic, src = None, None
     if batch == 65536:
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            traffic = pmc[dom[0]]["traffic_bytes"]
-        except Exception:
-            pass
+        for tag in ("r02", "r01"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")))["kernels"]
+                traffic, src = pmc[dom[0]]["traffic_bytes"], f"profiles/{tag}_pmc_traffic.json"
+                break
+            except Exception:
+                continue
     roof = {"bound": "hbm", "kernel": dom[0], "achieved": dom[1]["GB/s"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": dom[1]["GB/s"] / HBM_PEAK_GBPS, "traffic": traffic, "kernels": kern, "keys_per_launch": nt_avg,
-            "unique_rows_per_launch": nu_avg}
+            "frac": dom[1]["GB/s"] / HBM_PEAK_GBPS, "traffic": traffic,
+            "traffic_source": (src + ": separate rocprofv3 --pmc passes of this command (2*FETCH_SIZE + WRITE_SIZE)") if src else None,
+            "kernels": kern, "keys_per_launch": nt_avg, "unique_rows_per_launch": nu_avg}
     step_bytes = (8 * nt_avg + 8 * (FB + 1) + 16 * nu_avg + nu_avg * D * e + FB * D * o) + \
                  (8 * nt_avg + FB * D * o + 2 * nu_avg * D * e)
     return roof, step_bytes
@@ -357,10 +404,32 @@ def main():
                    "keys_per_step": keys_total / args.steps / world, "parallelism": f"row-wise mp{world}" if world > 1 else "1 GPU"},
     }
 
+    # the K timed steps above are a few milliseconds of GPU time at the driver's K = 20: a second, longer window (cycling
+    # over the same batches until >= 0.25 s) shows what the rate is once clocks and caches have settled
+    sus_steps, t1 = 0, time.perf_counter()
+    while True:
+        for i in range(args.warmup, n_batches):
+            step(i)
+        sus_steps += args.steps
+        torch.cuda.synchronize()
+        if time.perf_counter() - t1 >= 0.25 or sus_steps >= 200 * args.steps:
+            break
+    sus = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([sus], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sus = float(t.item())
+    result["sustained"] = {"steps": sus_steps, "seconds": sus, "ms_per_step": 1e3 * sus / sus_steps,
+                           "value": keys_total / args.steps * sus_steps / sus, "unit": "lookups/s"}
+
     if rank == 0 and not sharded_path and not args.no_kernel_timing:
         roof, step_bytes = kernel_roofline(module, batches[args.warmup:], grad, args.batch, args.dim)
         result["roofline"] = roof
-        result["step_algorithmic_GBps"] = step_bytes / (elapsed / args.steps) / 1e9
+        gbps = step_bytes / (sus / sus_steps) / 1e9
+        result["step_algorithmic_GBps"] = gbps
+        result["step_roofline"] = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                   "frac": gbps / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": step_bytes,
+                                   "note": "whole fwd+bwd step (SURVEY 8(d) minimal bytes) over the sustained window"}
 
     if not args.no_hstu:
         h = hstu_section(args, device, world, dist if sharded_path else None)

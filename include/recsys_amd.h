@@ -309,6 +309,10 @@ int mi355_demb_forward(void* storage, const int64_t* table_bucket_offsets, int64
  * per-key occurrence count when use_count != 0 (LFU).  Unique keys come out in representative order (not first
  * occurrence); in eval mode (train == 0) only `out` is produced.  join_token as in mi355_demb_forward. */
 int64_t mi355_demb_aux_numel(int64_t total_slots, int64_t num_buckets);
+/* measurement hook of bench.py: while enabled, the library brackets the launches of its two bandwidth kernels with HIP
+ * events on the launch stream; mi355_profile_ms(slot) returns the duration of the last one (-1: none) */
+int mi355_profile_kernels(int enable);
+float mi355_profile_ms(int slot /* 0: gather of the fused forward, 1: backward kernel */);
 /* `stream` waits for the side-stream work a forward announced through join_token */
 int mi355_side_join(int token, hipStream_t stream);
 int64_t mi355_demb_forward_fused_workspace_bytes(int64_t num_keys, int64_t num_tables);

@@ -22,6 +22,7 @@
 //    last task, which applies the sink after an agent-scope acquire (CDNA hand-off recipe).
 #include "common.h"
 #include "hot.h"
+#include "internal.h"
 
 namespace mi355 {
 
@@ -803,9 +804,12 @@ int mi355_backward_fused(const int32_t* ptr, const int32_t* csr_src, int64_t num
   o.bias2 = (float)(1.0 - pow((double)beta2, (double)iter_num));
   o.state_offset = (int)state_offset; o.out = out; o.out_stride = out_stride;
   const bool vec = aligned16 != 0;
-  return MI355_DISPATCH_DTYPE(weight_dtype, Wd, [&] {
+  mi355i_prof_mark(1, 0, stream);
+  const int rc = MI355_DISPATCH_DTYPE(weight_dtype, Wd, [&] {
     return MI355_DISPATCH_DTYPE(grad_dtype, Gd, [&] { return launch_bwd<Wd, Gd>(a, o, vec, stream); });
   });
+  mi355i_prof_mark(1, 1, stream);
+  return rc;
 }
 
 // optimizer step on dense unique gradients [n, grad_stride]; rows by address (flat table) or in a

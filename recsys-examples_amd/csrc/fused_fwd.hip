@@ -30,6 +30,7 @@
 #include "scan_dev.h"
 #include "table_dev.h"
 #include "init_dev.h"
+#include "roctx.h"
 #include <pthread.h>
 #include <stdlib.h>
 
@@ -690,6 +691,12 @@ bool side_init() {
 
 extern "C" {
 
+struct GatherTimer {   // bench.py's live timing of the gather launch (err.hip: mi355_profile_kernels)
+  hipStream_t s;
+  explicit GatherTimer(hipStream_t st) : s(st) { mi355i_prof_mark(0, 0, s); }
+  ~GatherTimer() { mi355i_prof_mark(0, 1, s); }
+};
+
 // (exported for callers with a stream-aware allocator, and used by pipeline.hip)
 void* mi355_early_csr_stream(void) {
   pthread_mutex_lock(&g_side.mu);
@@ -820,6 +827,7 @@ int mi355_demb_forward_fused(
   a.csr_rank = csr_rank;
   if (train) MI355_CHECK_ARG(reverse_indices && unique_offsets && slots && row_addr && csr_cnt && csr_rank, "persisted outputs required in train mode");
   if (n > 0) {
+    RoctxRange rr("op:fused_index(segmented_unique+storage_find+storage_insert+initializer)");
     // keys per tile / threads per block: one key per thread keeps every probe chain (digest vector -> key -> slot counter)
     // in flight at once; larger tiles cost fewer (tile, key) pairs = fewer device-scope atomics
     static const int cfg_env = getenv("MI355_FUSED_CFG") ? atoi(getenv("MI355_FUSED_CFG")) : -1;
@@ -863,6 +871,8 @@ int mi355_demb_forward_fused(
     forked = true;
   }
   auto gather = [&]() -> int {
+    RoctxRange rr("op:gather_embedding");
+    GatherTimer gt(stream);
     if (combiner >= 0)
       return mi355_gather_pooled(nullptr, 0, a.occ_addr, value_dtype, nullptr, n, offsets, num_bags, batch_size, combiner,
                                  emb_dim, D_offsets, total_D, out, out_dtype, aligned16, stream);
@@ -873,6 +883,7 @@ int mi355_demb_forward_fused(
   };
   if (forked) STEP(gather());
   if (train && n > 0) {
+    RoctxRange rr("op:unique_numbering+backward_csr");
     EmitOut o;
     o.unique_keys = unique_keys; o.table_offsets = unique_offsets; o.table_ids = table_ids; o.slots = slots;
     o.row_addr = row_addr; o.freq = freq; o.csr_cnt = csr_cnt; o.total = total + 8; o.hot_counters = nullptr;

@@ -53,6 +53,9 @@ int mi355i_csr_from_slots(const int32_t* csr_cnt, const int32_t* csr_rank, const
                           const int32_t* partial2, int32_t* total, int32_t* ptr, int32_t* csr_src, void* hot_workspace,
                           int64_t hot_workspace_bytes, int64_t dim, hipStream_t stream);
 
+// bench.py's live kernel timing (err.hip): event of slot (0 gather, 1 backward kernel), end 0 / 1
+void mi355i_prof_mark(int slot, int end, hipStream_t stream);
+
 // the library's side stream (fused_fwd.hip): fork from `stream`, mark the join point of the side work (-> token), make a
 // stream wait for a token, make a stream wait for whatever side work has not been joined yet
 hipStream_t mi355i_side_fork(hipStream_t stream);

@@ -11,6 +11,7 @@
 #include "common.h"
 #include "../../include/recsys_amd.h"
 #include "internal.h"
+#include "roctx.h"
 
 extern "C" {
 
@@ -69,9 +70,10 @@ int mi355_demb_forward(
   int rc;
 #define STEP(call) do { rc = (call); if (rc != MI355_OK) return rc; } while (0)
   // table ranges, dedup, table ids of the unique keys: one call, no separate range / memset / expand launches
+  { mi355::RoctxRange rr("op:segmented_unique");
   STEP(mi355i_segmented_unique(keys, num_keys, nullptr, num_tables, nullptr, freq ? 1 : 0, unique_keys, reverse_indices,
                                unique_offsets, freq, csr_cnt, csr_rank, offsets, feature_offsets, num_bags, table_range,
-                               table_ids, uws, uws_bytes, stream));
+                               table_ids, uws, uws_bytes, stream)); }
   if (backward_workspace && train && csr_cnt && csr_rank && num_keys > 0 && combiner != -2) {
     MI355_CHECK_ARG(backward_workspace_bytes >= mi355_demb_backward_workspace_bytes(num_keys, emb_dim), "backward workspace too small");
     hipStream_t side = mi355i_side_fork(stream);
@@ -93,9 +95,11 @@ int mi355_demb_forward(
   if (!find_scores) find_scores = freq;      // LFU: scores are the occurrence counts of this batch
   if (!insert_scores) insert_scores = freq;
   if (num_keys > 0) {
+    { mi355::RoctxRange rr("op:storage_find");
     STEP(mi355i_table_lookup(storage, table_bucket_offsets, bucket_capacity, num_scores, num_keys, nu_dev, unique_keys,
-                            table_ids, find_scores, find_policy, timer_override, nullptr, founds, slots, stream));
+                            table_ids, find_scores, find_policy, timer_override, nullptr, founds, slots, stream)); }
     if (train) {
+      mi355::RoctxRange rr("op:storage_insert+initializer");
       // The slots this batch's lookup found must not be evicted by this batch's insert (the reference pins them with
       // increment_counter before the insert, _prefetch_hbm_direct_path batched_dynamicemb_function.py:559-696): +1 on the
       // found slots now, released after the unlock pass unless the caller keeps the pin (prefetch).
@@ -124,6 +128,7 @@ int mi355_demb_forward(
                                value_dtype == 0 ? 4 : 2, row_addr, stream));
     }
   }
+  mi355::RoctxRange rr_g("op:gather_embedding");
   if (combiner >= 0) {
     STEP(mi355_gather_pooled(nullptr, 0, row_addr, value_dtype, reverse_indices, num_keys, offsets, num_bags, batch_size,
                              combiner, emb_dim, D_offsets, total_D, out, out_dtype, aligned16, stream));
@@ -181,6 +186,7 @@ int mi355_demb_backward(
     rc = mi355_group_by_unique(reverse_indices, num_keys, combiner >= 0 ? offsets : nullptr, num_bags, num_keys, nu_dev, ptr,
                                csr, gws, gws_bytes, bws, bws_bytes, dim, stream);
   if (rc != MI355_OK) return rc;
+  mi355::RoctxRange rr_b("op:reduce_grads+optimizer_update");
   rc = mi355_backward_fused(ptr, csr, num_keys, num_keys, nu_dev, grads, grad_stride, grad_dtype, offsets, D_offsets,
                             batch_size, dim, combiner, row_addr, value_dtype, opt_kind, lr, beta1, beta2, eps, weight_decay,
                             iter_num, state_offset, round_grad, nullptr, 0, aligned16, bws, bws_bytes, stream);

@@ -93,6 +93,8 @@ _SIGS = {
     "mi355_demb_aux_numel": [c_i64, c_i64],
     "mi355_demb_forward_fused_workspace_bytes": [c_i64, c_i64],
     "mi355_side_join": [c_int, c_p],
+    "mi355_profile_kernels": [c_int],
+    "mi355_profile_ms": [c_int],
     "mi355_demb_backward": [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_int, c_p, c_i64, c_int, c_p,
                             c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_int, c_int, c_p, c_i64, c_p, c_p,
                             c_p, c_i64, c_int, c_p, c_p, c_int, c_p, c_i64, c_p],
@@ -122,6 +124,7 @@ _RESTYPES = {
     "mi355_demb_forward_workspace_bytes": c_i64,
     "mi355_demb_backward_workspace_bytes": c_i64,
     "mi355_early_csr_stream": c_p,
+    "mi355_profile_ms": c_f,
     "mi355_demb_aux_numel": c_i64,
     "mi355_demb_forward_fused_workspace_bytes": c_i64,
     "mi355_last_error": ctypes.c_char_p,
