@@ -342,8 +342,8 @@ def main():
         sharded = ShardedPooledLookup(args.rows, args.dim, device, world, rank, mode=args.shard_mode,
                                       keys_per_step=int(args.batch * 5.5), batch=args.batch)
 
-        def fwd(keys, offsets):
-            return sharded.forward(keys, offsets)
+        def fwd(keys, offsets, nxt=None):
+            return sharded.forward(keys, offsets, next_batch=nxt)
 
         def bwd(st, grad):
             sharded.backward(st, grad)
@@ -358,7 +358,10 @@ def main():
 
     def step(i):
         keys, offsets = batches[i]
-        out, st = fwd(keys, offsets)
+        if sharded_path:   # the next batch's key exchange goes out under this batch's lookup / backward (exchange stream)
+            out, st = fwd(keys, offsets, batches[i + 1] if i + 1 < n_batches else None)
+        else:
+            out, st = fwd(keys, offsets)
         bwd(st, grad)
         return out, st
 

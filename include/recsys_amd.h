@@ -274,6 +274,19 @@ int mi355_optimizer_update(int opt_kind, const void* grads, int64_t grad_stride,
                            float beta2, float eps, float weight_decay, int64_t iter_num, int aligned16,
                            hipStream_t stream);
 
+/* ---------------------------------------------------------------- growable buffers ---- */
+
+/* VMMTensor / HostVMMTensor (src/vmm_tensor.cu:30-585, pybind :555-585): a buffer that grows IN PLACE.  Address space for
+ * `reserve_bytes` is reserved once; `initial_bytes` (then every mi355_vmm_extend) maps zero-filled physical memory at the
+ * tail -- HBM through hipMemCreate / hipMemMap for host == 0, pinned host memory (mmap + hipHostRegister, addressable by
+ * the kernels through the same pointer) for host != 0.  The data pointer never changes. */
+int mi355_vmm_create(int64_t reserve_bytes, int64_t initial_bytes, int device, int host, void** handle_out);
+int mi355_vmm_extend(void* handle, int64_t new_total_bytes);
+void* mi355_vmm_data(void* handle);
+int64_t mi355_vmm_mapped_bytes(void* handle);
+int64_t mi355_vmm_reserved_bytes(void* handle);
+int mi355_vmm_destroy(void* handle);
+
 /* ------------------------------------------------------------------ fused pipelines ---- */
 
 /* One-call forward of BatchedDynamicEmbeddingTablesV2 with HBM-only storage:

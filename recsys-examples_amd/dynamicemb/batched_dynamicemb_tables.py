@@ -8,7 +8,8 @@ What is implemented: HBM / host / hybrid / promoting-cache storage tiers, poolin
 dims for pooled mode, SGD / Adam / AdaGrad / row-wise AdaGrad fused in the backward, score strategies TIMESTAMP /
 STEP / CUSTOMIZED / LFU, train == eval for known keys, zeros for unknown keys in eval, first-touch insert + initialise
 in train, prefetch(), dump / load / export, frequency admission (`admit_strategy` + `admission_counter`).
-Out of scope this round: table growth (rehash), NO_EVICTION, external storage.
+Table growth by rehash (init_capacity -> max_capacity, VMM value buffers) for HBM storage.  Not built: NO_EVICTION,
+external storage.
 """
 from __future__ import annotations
 
@@ -248,6 +249,17 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         self._policy = pol
 
         caps = [o.max_capacity for o in table_options]
+        # table growth (key_value_table.py:440-666): start at init_capacity, double by rehash while
+        # (size + incoming) / capacity > max_load_factor, up to max_capacity.  HBM storage only; the value buffers are
+        # VMM tensors reserved for max_capacity rows, so their base address survives every growth step.
+        self._max_caps = list(caps)
+        self._growth = False
+        if (storage_mode in (None, "hbm") and all(o.init_capacity is not None and 0 < o.init_capacity < o.max_capacity
+                                                  for o in table_options)
+                and not (0 < opt0.local_hbm_for_values < sum(c * v * torch.empty((), dtype=self.embedding_dtype).element_size()
+                                                             for c, v in zip(caps, self.value_dims)))):
+            self._growth = True
+            caps = [o.init_capacity for o in table_options]
         # ---- storage tiers (batched_dynamicemb_tables.py:637-787, key_value_table.py:1522-2403) -------------------
         #  hbm    : hash table + rows in HBM (DynamicEmbStorage on device)
         #  host   : hash table + rows in pinned host memory, driven by the same kernels over the host link
@@ -273,7 +285,13 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         self.storage_mode = storage_mode
         C = opt0.bucket_capacity
 
+        self._vmm = None
+
         def _values(capacities, host):
+            if self._growth and not host:
+                self._vmm = [ext.VMMTensor(c * v, self.embedding_dtype, self.device_.index or 0, reserve_numel=m * v)
+                             for c, v, m in zip(capacities, self.value_dims, self._max_caps)]
+                return [b.data().view(c, v) for b, c, v in zip(self._vmm, capacities, self.value_dims)]
             if host:
                 return [torch.zeros(c, v, dtype=self.embedding_dtype).pin_memory() for c, v in zip(capacities, self.value_dims)]
             return [torch.zeros(c, v, dtype=self.embedding_dtype, device=self.device_) for c, v in zip(capacities, self.value_dims)]
@@ -395,6 +413,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             if st.num_keys != indices.numel() or st.num_bags != offsets.numel() - 1:
                 raise RuntimeError("forward() received a batch that was not the oldest prefetched one")
             return self._gather_prefetched(st), st
+        if self._growth and train:
+            self._maybe_grow(indices.numel())
         if self._fused:
             return self._forward_fused(indices, offsets, train, prefetch_only)
         n = indices.numel()
@@ -469,6 +489,53 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             if self._dynamicemb_options[0].safe_check_mode != DynamicEmbCheckMode.IGNORE:
                 self._safe_check(st)
         return out, st
+
+    # ---------------------------------------------------------------------------------- table growth
+    def _maybe_grow(self, incoming: int) -> None:
+        """Grow the tables whose fill (as of the previous step: the sizes travel to pinned memory asynchronously, no sync on
+        the step) plus the incoming keys passes max_load_factor: capacity doubles, by rehash, up to max_capacity."""
+        tb = self.table
+        if getattr(self, "_fill_event", None) is not None and self._fill_event.query():
+            sizes = self._fill_host.tolist()
+            lf = self._dynamicemb_options[0].max_load_factor
+            caps = list(tb.per_table_capacity_)
+            new_caps = list(caps)
+            per_table_in = incoming / max(self.num_tables, 1)
+            for t in range(self.num_tables):
+                while new_caps[t] < self._max_caps[t] and (sizes[t] + per_table_in) / new_caps[t] > lf:
+                    new_caps[t] = min(2 * new_caps[t], self._max_caps[t])
+            if new_caps != caps and not self._prefetch_states:
+                self._expand(new_caps)
+                tb = self.table
+        if getattr(self, "_fill_host", None) is None:
+            self._fill_host = torch.zeros(self.num_tables, dtype=torch.int64).pin_memory()
+        self._fill_host.copy_(ext.segmented_sum_cuda(tb.bucket_sizes, tb.table_bucket_offsets_), non_blocking=True)
+        self._fill_event = torch.cuda.Event()
+        self._fill_event.record()
+
+    def _expand(self, new_caps) -> None:
+        """rehash into a table of `new_caps` rows per table (key_value_table.py:559-666: export, re-insert with the stored
+        scores, move the rows); the value buffers grow in place (VMM), rows move to their new slots"""
+        from .scored_hashtable import ScoreArg
+
+        old_tb = self.table
+        C = old_tb.bucket_capacity_
+        content = [list(self._export_table(t)) for t in range(self.num_tables)]   # (keys, full rows, scores) copies
+        new_tb = LinearBucketTable([int(c) for c in new_caps], [ScoreSpec("score", self._policy)], key_type=torch.int64,
+                                   bucket_capacity=C, device=self.device_)
+        for t in range(self.num_tables):
+            cap_t, vd = new_tb.per_table_capacity_[t], self.value_dims[t]
+            self._vmm[t].extend(cap_t * vd)
+            self.values[t] = self._vmm[t].data().view(cap_t, vd)
+            for keys, rows, scores in content[t]:
+                tids = torch.full_like(keys, t)
+                idx = new_tb.insert(keys, tids, ScoreArg("score", scores.contiguous(), ext.ScorePolicy.ASSIGN))
+                ok = idx >= 0
+                self.values[t][idx[ok]] = rows[ok].to(self.embedding_dtype)
+        self.table = new_tb
+        self.table_ptrs = torch.tensor([v.data_ptr() for v in self.values], dtype=torch.int64, device=self.device_)
+        self._fused_aux = None            # sized by the table
+        self._fill_event = None
 
     # ---------------------------------------------------------------------------------- fused forward / backward
     def _fused_scores(self):

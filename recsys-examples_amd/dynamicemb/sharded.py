@@ -36,6 +36,19 @@ class _ShardedCtx:
     n_local: int
 
 
+class PendingKeys:
+    """an input dist in flight on the exchange stream; wait() orders the current stream behind it and hands the keys over"""
+
+    def __init__(self, sk, event=None):
+        self._sk, self._event = sk, event
+
+    def wait(self):
+        if self._event is not None:
+            torch.cuda.current_stream().wait_event(self._event)
+            self._event = None
+        return self._sk
+
+
 class RowWiseShardedLookup:
     """`local` must provide
          forward(values, offsets, train) -> (out, ctx)   out: pooled [W*B, total_D] fp32 or rows [n, D]
@@ -44,7 +57,12 @@ class RowWiseShardedLookup:
 
     def __init__(self, local, num_features: int, feature_hash_sizes: List[int], pooled: bool, pg=None,
                  device=None, out_dtype=torch.float32, dist_type_per_feature: Optional[Sequence[str]] = None,
-                 ops=None):
+                 ops=None, wire_dtype: Optional[torch.dtype] = None):
+        """wire_dtype (pooled): element type of the partial sums on the fabric.  None = fp32 (the sums of the shards are
+        added in fp32, one rounding at the end); torch.bfloat16 halves the bytes per xGMI link at the price of one more
+        rounding per shard (what TorchRec's qcomm codec does for its reduce-scatter)."""
+        self.wire_dtype = wire_dtype
+        self._comm = None
         self.pg = pg if pg is not None else dist.group.WORLD
         self.world = dist.get_world_size(self.pg)
         self.rank = dist.get_rank(self.pg)
@@ -64,6 +82,28 @@ class RowWiseShardedLookup:
             lengths = offsets[1:] - offsets[:-1]
         return self.input_dist(lengths, values, collapse_batch, offsets=offsets)
 
+    def dist_input_async(self, values: torch.Tensor, offsets: torch.Tensor, collapse_batch: bool = False,
+                         lengths: Optional[torch.Tensor] = None) -> PendingKeys:
+        """The input dist of a LATER batch on the exchange stream (a side HIP stream), so that bucketize, the two
+        all-to-alls and the one host read of their sizes run under whatever the caller has queued on its own stream -- the
+        local lookup / backward of the current batch.  (north star: "all-to-all ... overlapped with local lookup on a side
+        HIP stream"; reference precedent: the data-dist stream of train_pipeline.py:155-170,589-597.)  On the CPU (gloo
+        tests) there are no streams: the dist runs in place, which still exercises the reordered schedule."""
+        if not values.is_cuda:
+            return PendingKeys(self.dist_input(values, offsets, collapse_batch, lengths))
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=values.device)
+        cur = torch.cuda.current_stream()
+        self._comm.wait_stream(cur)       # the batch tensors were produced on the caller's stream
+        with torch.cuda.stream(self._comm):
+            sk = self.dist_input(values, offsets, collapse_batch, lengths)
+            ev = torch.cuda.Event()
+            ev.record(self._comm)
+        for t in (sk.lengths, sk.offsets, sk.values, sk.recv_offsets, sk.unbucketize_permute):
+            if t is not None:
+                t.record_stream(cur)      # allocated on the exchange stream, consumed on the caller's
+        return PendingKeys(sk, ev)
+
     def lookup(self, sk, train: bool = True):
         """-> (local output: pooled partial sums [W*B, total_D] fp32 or rows [n_recv, D]; local context)"""
         return self.local.forward(sk.values, sk.offsets, train)
@@ -73,8 +113,11 @@ class RowWiseShardedLookup:
         if self.pooled:
             # out_local [W*B, total_D] fp32: block p belongs to rank p's samples
             assert out_local.dtype == torch.float32 and out_local.size(0) == W * B
-            recv = torch.empty_like(out_local)
-            dist.all_to_all_single(recv, out_local.contiguous(), group=self.pg)
+            send = out_local.contiguous() if self.wire_dtype is None else out_local.to(self.wire_dtype)
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send, group=self.pg)
+            if self.wire_dtype is not None:
+                recv = recv.float()
             return self.ops.sum_chunks(recv.view(W, B * out_local.size(1)), self.out_dtype).view(B, out_local.size(1))
         D = out_local.size(1)
         # rows come out in (f, src, b) order; send them back in the order they arrived: (src, f, b)
@@ -117,6 +160,40 @@ class RowWiseShardedLookup:
     def backward(self, ctx: _ShardedCtx, grads: torch.Tensor, bucketized: bool = False) -> None:
         """bucketized (sequence mode): `grads` rows are already in exchange order."""
         self.local.backward(ctx.local_ctx, self.dist_grads(ctx.keys, grads, bucketized))
+
+
+class OverlappedSteps:
+    """Training steps of a row-wise sharded lookup with the input dist of batch i+1 in flight while batch i computes:
+
+        forward(batch i, next_batch = batch i+1):
+            keys of batch i (already exchanged) -> local lookup queued on the caller's stream
+            input dist of batch i+1 issued on the exchange stream          <- runs under the lookup / backward of batch i
+            output dist of batch i
+        backward(batch i) ...
+
+    The key exchange touches no table state, so moving it ahead of the previous batch's backward changes nothing in the
+    results (tested against the plain schedule over gloo, tests/test_sharded_cpu.py)."""
+
+    def __init__(self, lookup: RowWiseShardedLookup):
+        self.lookup = lookup
+        self._pending: Optional[PendingKeys] = None
+
+    def prefetch(self, values: torch.Tensor, offsets: torch.Tensor) -> None:
+        self._pending = self.lookup.dist_input_async(values, offsets)
+
+    def forward(self, values: torch.Tensor, offsets: torch.Tensor, train: bool = True, next_batch=None):
+        lk = self.lookup
+        pend = self._pending if self._pending is not None else lk.dist_input_async(values, offsets)
+        self._pending = None
+        sk = pend.wait()
+        out_local, lctx = lk.lookup(sk, train)
+        if next_batch is not None:
+            self._pending = lk.dist_input_async(*next_batch)
+        out = lk.dist_output(sk, out_local)
+        return out, _ShardedCtx(sk, lctx, sum(sk.send_splits))
+
+    def backward(self, ctx: _ShardedCtx, grads: torch.Tensor) -> None:
+        self.lookup.backward(ctx, grads)
 
 
 class RowWiseShardedPooledRows:
@@ -211,7 +288,7 @@ class ShardedPooledLookup:
 
     def __init__(self, rows: int, dim: int, device, world: int, rank: int, lr: float = 0.1,
                  out_dtype=torch.bfloat16, dist_type: str = "roundrobin", mode: str = "auto",
-                 keys_per_step: Optional[int] = None, batch: Optional[int] = None):
+                 keys_per_step: Optional[int] = None, batch: Optional[int] = None, wire_dtype: Optional[torch.dtype] = None):
         from .batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
         from .dynamicemb_config import (DynamicEmbInitializerArgs, DynamicEmbInitializerMode, DynamicEmbPoolingMode,
                                         DynamicEmbScoreStrategy, DynamicEmbTableOptions, EmbOptimType)
@@ -231,9 +308,11 @@ class ShardedPooledLookup:
         # one and serialises (measured: no gain, +10 us of event edges): group in the backward here
         module._early_csr = False
         self.module = module
+        self._steps = None
         if mode == "partial":
             self.impl = RowWiseShardedLookup(_ModuleLocal(module), 1, [rows], pooled=True, device=device,
-                                             out_dtype=out_dtype, dist_type_per_feature=[dist_type])
+                                             out_dtype=out_dtype, dist_type_per_feature=[dist_type], wire_dtype=wire_dtype)
+            self._steps = OverlappedSteps(self.impl)
         else:
             self.impl = RowWiseShardedPooledRows(_ModuleLocal(module), [0], [rows], [dim], combiner=0, device=device,
                                                  out_dtype=out_dtype, dist_type_per_table=[dist_type])
@@ -254,7 +333,10 @@ class ShardedPooledLookup:
         handicap = 0.23e-3 * 100e9
         return "rows" if rows_link + handicap < partial_link else "partial"
 
-    def forward(self, values, offsets, train: bool = True):
+    def forward(self, values, offsets, train: bool = True, next_batch=None):
+        """next_batch = (values, offsets) of the following step: its key exchange starts under this step's lookup"""
+        if self._steps is not None:
+            return self._steps.forward(values, offsets, train, next_batch)
         return self.impl.forward(values, offsets, train)
 
     def backward(self, ctx, grads):

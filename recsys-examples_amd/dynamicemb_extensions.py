@@ -8,6 +8,7 @@ Reference citations are relative to /root/reference/corelib/dynamicemb/.
 """
 from __future__ import annotations
 
+import ctypes
 import enum
 from typing import List, Optional, Sequence, Tuple
 
@@ -262,62 +263,82 @@ def table_scatter_score_blocks(table_storage, bucket_capacity, num_scores, bkt_b
                                          ptr(slots.contiguous()), ptr(vals), stream()), "table_scatter_score_blocks")
 
 
+class _CudaArrayView:
+    """zero-copy holder of a raw device-addressable range for torch.as_tensor (CUDA array interface v2, bytes)"""
+
+    def __init__(self, ptr_: int, nbytes: int, owner):
+        self._owner = owner   # keeps the mapping alive as long as a tensor views it
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr_, False), "version": 2}
+
+
 class _GrowableTensor:
-    """VMMTensor / HostVMMTensor of the reference (src/vmm_tensor.cu:555-585): a 1-D buffer whose logical size can be
-    extended in place (`extend`), `data()` returning the current logical view.  The reference reserves virtual address
-    space and maps physical pages on demand; here the buffer over-allocates geometrically and re-allocates + copies
-    when the slack is used up (callers re-read `data()` after `extend`, extendable_tensor.py:120-130), which on a
-    288 GB device is the simpler trade.  Host flavour = pinned memory, directly addressable by the kernels."""
+    """VMMTensor / HostVMMTensor of the reference (src/vmm_tensor.cu:30-585): a 1-D buffer whose logical size is extended
+    IN PLACE -- address space is reserved once (mi355_vmm_create), `extend` maps more physical memory at the tail
+    (hipMemCreate + hipMemMap in HBM; mmap + hipHostRegister pinned host memory for the host flavour), `data()` is the
+    current logical view and its data_ptr never changes.  `reserve_numel` bounds the growth (default: 16 x the initial
+    size, at least 1 GiB)."""
 
-    _PAGE = 2 << 20
-
-    def __init__(self, numel: int, dtype: torch.dtype, device: int, host: bool):
+    def __init__(self, numel: int, dtype: torch.dtype, device: int, host: bool, reserve_numel: Optional[int] = None):
         if numel <= 0:
             raise ValueError("numel must be positive")
         self._dtype, self._device, self._host = dtype, device, host
+        self._eb = torch.empty((), dtype=dtype).element_size()
         self._logical = int(numel)
-        self._buf = self._alloc(self._round(numel))
-
-    def _round(self, numel):
-        eb = torch.empty((), dtype=self._dtype).element_size()
-        return (numel * eb + self._PAGE - 1) // self._PAGE * self._PAGE // eb
-
-    def _alloc(self, numel):
-        if self._host:
-            return torch.empty(numel, dtype=self._dtype, pin_memory=True)
-        return torch.empty(numel, dtype=self._dtype, device=torch.device("cuda", self._device))
+        reserve = max(int(reserve_numel) if reserve_numel else 16 * int(numel), int(numel)) * self._eb
+        reserve = max(reserve, 1 << 30)
+        h = c_p()
+        check(lib().mi355_vmm_create(reserve, self._logical * self._eb, int(device), int(host), ctypes.byref(h)), "vmm_create")
+        self._h = h
 
     def extend(self, new_total_logical_numel: int) -> None:
         n = int(new_total_logical_numel)
         if n <= self._logical:
             return
-        if n > self._buf.numel():
-            new = self._alloc(self._round(max(n, 2 * self._buf.numel())))
-            new[: self._logical].copy_(self._buf[: self._logical])
-            self._buf = new
+        check(lib().mi355_vmm_extend(self._h, n * self._eb), "vmm_extend")
         self._logical = n
 
     def data(self) -> torch.Tensor:
-        return self._buf[: self._logical]
+        base = lib().mi355_vmm_data(self._h)
+        view = _CudaArrayView(int(base), self._logical * self._eb, self)
+        if self._host:
+            # pinned, registered host memory: torch sees it as a CPU tensor; kernels address it through the same pointer
+            buf = (ctypes.c_uint8 * (self._logical * self._eb)).from_address(int(base))
+            t = torch.frombuffer(buf, dtype=torch.uint8)
+            t._vmm_owner = self
+            return t.view(self._dtype)
+        t = torch.as_tensor(view, device=torch.device("cuda", self._device))
+        return t.view(self._dtype)
+
+    def data_ptr(self) -> int:
+        return int(lib().mi355_vmm_data(self._h))
 
     def logical_numel(self) -> int:
         return self._logical
 
     def allocated_numel(self) -> int:
-        return self._buf.numel()
+        return int(lib().mi355_vmm_mapped_bytes(self._h)) // self._eb
 
     def allocated_bytes(self) -> int:
-        return self._buf.numel() * self._buf.element_size()
+        return int(lib().mi355_vmm_mapped_bytes(self._h))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                lib().mi355_vmm_destroy(h)
+            except Exception:
+                pass
+            self._h = None
 
 
 class VMMTensor(_GrowableTensor):
-    def __init__(self, numel: int, dtype: torch.dtype, device: int):
-        super().__init__(numel, dtype, device, host=False)
+    def __init__(self, numel: int, dtype: torch.dtype, device: int, reserve_numel: Optional[int] = None):
+        super().__init__(numel, dtype, device, host=False, reserve_numel=reserve_numel)
 
 
 class HostVMMTensor(_GrowableTensor):
-    def __init__(self, numel: int, dtype: torch.dtype, device: int):
-        super().__init__(numel, dtype, device, host=True)
+    def __init__(self, numel: int, dtype: torch.dtype, device: int, reserve_numel: Optional[int] = None):
+        super().__init__(numel, dtype, device, host=True, reserve_numel=reserve_numel)
 
 
 def device_timestamp() -> int:

@@ -110,6 +110,12 @@ _SIGS = {
     "mi355_flagged_compact_workspace_bytes": [c_i64],
     "mi355_group_by_unique_workspace_bytes": [c_i64, c_i64],
     "mi355_backward_workspace_bytes": [c_i64, c_i64],
+    "mi355_vmm_create": [c_i64, c_i64, c_int, c_int, c_p],
+    "mi355_vmm_extend": [c_p, c_i64],
+    "mi355_vmm_data": [c_p],
+    "mi355_vmm_mapped_bytes": [c_p],
+    "mi355_vmm_reserved_bytes": [c_p],
+    "mi355_vmm_destroy": [c_p],
     "mi355_abi_version": [],
     "mi355_last_error": [],
 }
@@ -124,6 +130,9 @@ _RESTYPES = {
     "mi355_demb_forward_workspace_bytes": c_i64,
     "mi355_demb_backward_workspace_bytes": c_i64,
     "mi355_early_csr_stream": c_p,
+    "mi355_vmm_data": c_p,
+    "mi355_vmm_mapped_bytes": c_i64,
+    "mi355_vmm_reserved_bytes": c_i64,
     "mi355_profile_ms": c_f,
     "mi355_demb_aux_numel": c_i64,
     "mi355_demb_forward_fused_workspace_bytes": c_i64,

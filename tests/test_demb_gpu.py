@@ -835,18 +835,36 @@ def test_segmented_unique_csr_and_group_by(n, T, zipf):
         assert sorted(c2[a:b].tolist()) == sorted(bag_of[rev_o == u].tolist())
 
 
-def test_vmm_tensors_extend_preserves_contents():
+def test_vmm_tensors_grow_in_place():
+    """VMMTensor / HostVMMTensor (vmm_tensor.cu:555-585): extend maps more memory behind the SAME base address (address
+    space reserved once, hipMemMap / hipHostRegister per chunk); old contents stay, new memory reads as zero, kernels
+    address both flavours"""
     e = ext()
     for cls in (e.VMMTensor, e.HostVMMTensor):
-        t = cls(1000, torch.float32, 0)
+        t = cls(1000, torch.float32, 0, reserve_numel=64_000_000)
         d = t.data()
         assert d.numel() == 1000 and t.allocated_numel() >= 1000 and t.allocated_bytes() >= 4000
+        assert d.is_cuda == (cls is e.VMMTensor)
+        p0 = d.data_ptr()
         d.copy_(torch.arange(1000, dtype=torch.float32))
-        t.extend(5_000_000)   # beyond the slack: re-allocates
-        d2 = t.data()
-        assert d2.numel() == 5_000_000 == t.logical_numel()
-        assert torch.equal(d2[:1000].cpu(), torch.arange(1000, dtype=torch.float32))
-        assert d2.is_cuda == (cls is e.VMMTensor)
+        for n in (5_000_000, 40_000_000):
+            t.extend(n)
+            d2 = t.data()
+            assert d2.numel() == n == t.logical_numel() and d2.data_ptr() == p0 == t.data_ptr()
+            assert torch.equal(d2[:1000].cpu(), torch.arange(1000, dtype=torch.float32))
+            assert float(d2[1000:].abs().sum()) == 0.0
+        # a kernel reads and writes through the raw address (the host flavour over the host link)
+        rows = d2.view(-1, 8)
+        idx = torch.tensor([0, 3, 4_999_999], dtype=torch.int64, device=DEV)
+        out = torch.empty(3, 8, device=DEV)
+        addr = torch.tensor([p0], dtype=torch.int64, device=DEV)
+        a = e.row_addresses(idx, None, addr, torch.tensor([8], dtype=torch.int64, device=DEV), 4)
+        from mi355_native import check, lib, ptr, stream
+        check(lib().mi355_gather_rows(None, 0, ptr(a), 0, None, 3, None, 8, ptr(out), 8, 0, 1, stream()), "gather_rows")
+        assert torch.equal(out.cpu(), rows[idx.cpu()].cpu())
+        with pytest.raises(Exception):
+            t.extend(65_000_000 + (1 << 28))      # beyond the reservation
+        del d, d2, rows, t
 
 
 def test_block_bucketize_many_bags_full_oracle():

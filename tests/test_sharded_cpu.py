@@ -197,11 +197,23 @@ def _worker(rank, W, port, F, B, pooled, dist_type, steps, q):
             sh = RowWiseShardedLookup(local, F, [200] * F, pooled=pooled, device="cpu", out_dtype=torch.float32,
                                       dist_type_per_feature=[dist_type] * F, ops=NumpyOps())
         outs = []
-        for step in range(steps):
-            keys, off = make_batch(rank, F, B, step)
-            out, ctx = sh.forward(keys, off, True)
-            outs.append(out.numpy().copy())
-            sh.backward(ctx, grads_for(rank, tuple(out.shape), step))
+        if pooled in (True, False) and os.environ.get("TEST_OVERLAPPED") == "1":
+            from dynamicemb.sharded import OverlappedSteps
+
+            # batch i+1's key exchange is issued before batch i's output dist and backward (the overlapped schedule)
+            st = OverlappedSteps(sh)
+            batches = [make_batch(rank, F, B, step) for step in range(steps)]
+            st.prefetch(*batches[0])
+            for step in range(steps):
+                out, ctx = st.forward(*batches[step], True, batches[step + 1] if step + 1 < steps else None)
+                outs.append(out.numpy().copy())
+                st.backward(ctx, grads_for(rank, tuple(out.shape), step))
+        else:
+            for step in range(steps):
+                keys, off = make_batch(rank, F, B, step)
+                out, ctx = sh.forward(keys, off, True)
+                outs.append(out.numpy().copy())
+                sh.backward(ctx, grads_for(rank, tuple(out.shape), step))
         q.put((rank, outs, dict(local.rows)))
     finally:
         dist.destroy_process_group()
@@ -273,7 +285,13 @@ def _owner(key, W, dist_type):
     (2, 2, 5, "rows", "hash_roundrobin"),
     (3, 3, 4, "rows", "continuous"),
 ])
-def test_rowwise_sharded_matches_single_process(W, F, B, pooled, dist_type):
+@pytest.mark.parametrize("overlapped", [False, True])
+def test_rowwise_sharded_matches_single_process(W, F, B, pooled, dist_type, overlapped, monkeypatch):
+    """overlapped: the key exchange of batch i+1 runs ahead of batch i's output dist / backward (OverlappedSteps) -- the
+    results must be those of the plain schedule, i.e. of one process doing the global batch"""
+    if overlapped and pooled == "rows":
+        pytest.skip("the rows-back pooled mode has its own two-level schedule")
+    monkeypatch.setenv("TEST_OVERLAPPED", "1" if overlapped else "0")
     steps = 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -210,3 +210,56 @@ def test_sharded_lookup_one_rank_matches_unsharded(one_rank_group, pooled):
             f1, r1 = ref.lookup_rows(probe, t)
             f2, r2 = loc.lookup_rows(probe, t)
             assert torch.equal(f1, f2) and torch.equal(r1, r2)
+
+
+@pytest.mark.parametrize("pooled", [True, False])
+def test_overlapped_steps_on_the_exchange_stream_match_the_plain_schedule(one_rank_group, pooled):
+    """OverlappedSteps: the input dist of batch i+1 runs on the side (exchange) HIP stream under the lookup / backward of
+    batch i; outputs and rows are those of the plain schedule, bit for bit"""
+    from dynamicemb.sharded import OverlappedSteps, RowWiseShardedLookup, _ModuleLocal
+
+    F, B, dim = 2, 64, 16
+    rng = np.random.default_rng(9)
+    mods = [_module(pooled, F, dim, torch.float32) for _ in range(2)]
+    shs = [RowWiseShardedLookup(_ModuleLocal(m), F, [5000] * F, pooled=pooled, device=torch.device("cuda", 0),
+                                out_dtype=torch.float32, dist_type_per_feature=["hash_roundrobin"] * F) for m in mods]
+    batches = []
+    for _ in range(6):
+        lens = rng.integers(0, 8, F * B)
+        off = np.zeros(F * B + 1, np.int64)
+        off[1:] = np.cumsum(lens)
+        batches.append((torch.from_numpy(rng.integers(0, 5000, off[-1]).astype(np.int64)).cuda(), torch.from_numpy(off).cuda()))
+    ov = OverlappedSteps(shs[1])
+    ov.prefetch(*batches[0])
+    for i, (k, o) in enumerate(batches):
+        o_plain, c_plain = shs[0].forward(k, o, True)
+        o_ov, c_ov = ov.forward(k, o, True, batches[i + 1] if i + 1 < len(batches) else None)
+        assert torch.equal(o_plain, o_ov)
+        g = torch.randn_like(o_plain)
+        shs[0].backward(c_plain, g)
+        ov.backward(c_ov, g)
+    assert shs[1]._comm is not None and shs[1]._comm != torch.cuda.current_stream()
+    probe = torch.arange(0, 5000, device="cuda", dtype=torch.int64)
+    for t in range(F):
+        f1, r1 = mods[0].lookup_rows(probe, t)
+        f2, r2 = mods[1].lookup_rows(probe, t)
+        assert torch.equal(f1, f2) and torch.equal(r1, r2)
+
+
+def test_bf16_wire_for_partial_sums_is_one_rounding_away(one_rank_group):
+    from dynamicemb.sharded import RowWiseShardedLookup, _ModuleLocal
+
+    F, B, dim = 2, 32, 16
+    rng = np.random.default_rng(10)
+    a, b = _module(True, F, dim, torch.float32), _module(True, F, dim, torch.float32)
+    s32 = RowWiseShardedLookup(_ModuleLocal(a), F, [1000] * F, pooled=True, device=torch.device("cuda", 0), out_dtype=torch.float32,
+                               dist_type_per_feature=["roundrobin"] * F)
+    s16 = RowWiseShardedLookup(_ModuleLocal(b), F, [1000] * F, pooled=True, device=torch.device("cuda", 0), out_dtype=torch.float32,
+                               dist_type_per_feature=["roundrobin"] * F, wire_dtype=torch.bfloat16)
+    lens = rng.integers(0, 6, F * B)
+    off = np.zeros(F * B + 1, np.int64)
+    off[1:] = np.cumsum(lens)
+    keys = torch.from_numpy(rng.integers(0, 1000, off[-1]).astype(np.int64)).cuda()
+    o32, _ = s32.forward(keys, torch.from_numpy(off).cuda(), True)
+    o16, _ = s16.forward(keys, torch.from_numpy(off).cuda(), True)
+    assert torch.equal(o16, o32.bfloat16().float())      # W = 1: exactly the bf16 rounding of the fp32 sums

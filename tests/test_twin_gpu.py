@@ -191,3 +191,40 @@ def test_checkpoint_files_against_the_dict_twin(tmp_path, optimizer):
     fresh._backward_impl(st, torch.from_numpy(g).to(DEV))
     twin.backward(g)
     _check_rows(fresh, twin, hi)
+
+
+def test_table_growth_by_rehash_against_the_dict_twin():
+    """init_capacity 256 -> max_capacity 16384 (key_value_table.py:559-666): the table doubles by rehash when its fill
+    passes max_load_factor; every key keeps its row and optimizer state across the moves, the value buffer keeps its base
+    address (VMM), nothing is evicted on the way"""
+    from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
+    from dynamicemb.dynamicemb_config import (DynamicEmbInitializerArgs, DynamicEmbInitializerMode, DynamicEmbPoolingMode,
+                                              DynamicEmbScoreStrategy, DynamicEmbTableOptions, EmbOptimType)
+
+    dims, fmap, F, B, lr = [8, 8], [0, 1], 2, 64, 0.05
+    opts = [DynamicEmbTableOptions(dim=d, init_capacity=256, max_capacity=16384, max_load_factor=0.5, index_type=torch.int64,
+                                   embedding_dtype=torch.float32, score_strategy=DynamicEmbScoreStrategy.STEP,
+                                   initializer_args=DynamicEmbInitializerArgs(mode=DynamicEmbInitializerMode.DEBUG)) for d in dims]
+    m = BatchedDynamicEmbeddingTablesV2(opts, feature_table_map=fmap, pooling_mode=DynamicEmbPoolingMode.SUM,
+                                        output_dtype=torch.float32, optimizer=EmbOptimType.ADAM, learning_rate=lr, device=DEV)
+    m.train()
+    assert m._growth and m.table.per_table_capacity_ == [256, 256]
+    base = [v.data_ptr() for v in m.values]
+    twin = DictEmbeddingTwin(dims, fmap, "SUM", "adam", lr=lr)
+    rng = np.random.default_rng(12)
+    caps_seen = set()
+    for step in range(24):
+        hi = 200 * (step + 1)                       # the key space keeps widening: ~4000 keys per table at the end
+        keys, off = _batch(rng, F, B, hi)
+        out, st = m._forward_impl(torch.from_numpy(keys).to(DEV), torch.from_numpy(off).to(DEV), train=True)
+        ref = twin.forward(keys, off, True)
+        np.testing.assert_allclose(out.double().cpu().numpy(), ref, rtol=1e-6, atol=1e-3)
+        g = rng.uniform(0.1, 1.1, size=ref.shape).astype(np.float32)
+        m._backward_impl(st, torch.from_numpy(g).to(DEV))
+        twin.backward(g)
+        torch.cuda.synchronize()
+        caps_seen.add(tuple(m.table.per_table_capacity_))
+    assert len(caps_seen) >= 4 and max(caps_seen)[0] >= 4096, caps_seen
+    assert [v.data_ptr() for v in m.values] == base
+    _check_rows(m, twin, 4800)
+    assert int(m.size()) == sum(len(t) for t in twin.tables)
