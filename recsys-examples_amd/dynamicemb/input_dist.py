@@ -47,6 +47,34 @@ class TorchGlue:
         offsets = torch.cat([(lo + cut[:, :-1]).reshape(-1), unique_offsets[-1:]])
         return lengths, offsets
 
+    def pad_for_exchange(self, new_values, new_offsets, new_lengths, perm, world, per_peer, cap, pad_key=-1):
+        """Fixed-capacity layout of a bucketized key stream: peer p's keys at [p*cap, p*cap + count_p), the rest of its slot
+        filled with an INVALID key (the table kernels give it no slot: zero row, no update), the padding counted into the last
+        bag of the peer so that lengths and values stay consistent.  -> (values [W*cap], lengths [W*per_peer],
+        positions of the original keys in the padded layout | None, overflow flag [1] bool: some peer got more than cap)"""
+        dev = new_values.device
+        peer_off = new_offsets[torch.arange(world + 1, device=dev) * per_peer]
+        cnt = peer_off[1:] - peer_off[:-1]
+        overflow = (cnt > cap).any().view(1)
+        pos = torch.arange(world * cap, device=dev)
+        pp, r = pos // cap, pos % cap
+        src = (peer_off[pp] + r).clamp_(max=max(new_values.numel() - 1, 0))
+        valid = r < cnt[pp]
+        if new_values.numel():
+            vals = torch.where(valid, new_values[src], torch.full_like(src, pad_key).to(new_values.dtype))
+        else:
+            vals = torch.full((world * cap,), pad_key, dtype=new_values.dtype, device=dev)
+        lens = new_lengths.clone()
+        if per_peer > 0:
+            last = torch.arange(1, world + 1, device=dev) * per_peer - 1
+            lens[last] += (cap - cnt).clamp_(min=0)
+        perm_p = None
+        if perm is not None:
+            q = torch.searchsorted(peer_off, perm, right=True) - 1
+            q.clamp_(0, world - 1)
+            perm_p = q * cap + (perm - peer_off[q])
+        return vals, lens, perm_p, overflow
+
     def compose(self, perm, index):
         """perm[index]: lets a consumer read rows in exchange order instead of gathering them back first"""
         return perm[index]
@@ -223,7 +251,21 @@ class RwSparseFeaturesDist:
     """RwSparseFeaturesDist (input_dist.py:199-285) + KJTAllToAll, for equal local batch sizes."""
 
     def __init__(self, pg, num_features: int, feature_hash_sizes: List[int], device=None, is_sequence: bool = False,
-                 dist_type_per_feature: Optional[Sequence[str]] = None, ops=None):
+                 dist_type_per_feature: Optional[Sequence[str]] = None, ops=None, capacity_factor: Optional[float] = None,
+                 expected_keys: Optional[int] = None):
+        """capacity_factor: None = exact all-to-all-v (one host read of the per-peer key counts per step, as KJTAllToAll).
+        A number = FIXED-CAPACITY exchange: every peer slot carries ceil(factor * expected_keys / W) keys (`expected_keys`: the
+        keys of one rank's batch, the SAME number on every rank -- the slot size must agree), padded with invalid keys, so
+        every size is known on the host and the step has no device-to-host read at all (and a fixed launch sequence).  A
+        peer whose share exceeds the slot sets a sticky overflow flag that `check_overflow()` turns into an error; with
+        hash_roundrobin routing factor 2 covers a Zipf-0.99 stream (the hottest key drags 6 % of a batch to one rank)."""
+        self._cap_factor = capacity_factor
+        if capacity_factor is not None and not expected_keys:
+            raise ValueError("capacity_factor needs expected_keys (keys per rank and step, identical on every rank)")
+        self._expected_keys = expected_keys
+        self._overflow = None
+        self._overflow_host = None
+        self._overflow_event = None
         self._pg = pg
         self._world_size = dist.get_world_size(pg)
         self._num_features = num_features
@@ -259,6 +301,8 @@ class RwSparseFeaturesDist:
         new_lengths, new_offsets, new_values, perm = ops.bucketize(offsets, values, self._block_sizes, W, self._is_sequence,
                                                                    self._dist_codes)
         self.unbucketize_permute_tensor = perm
+        if self._cap_factor is not None and not collapse_batch:
+            return self._forward_fixed(new_lengths, new_offsets, new_values, perm, values, B)
         if collapse_batch:
             # one bag per (peer, feature): its offsets are the bucketized offsets at the (peer, feature) boundaries
             idx = torch.arange(W * F + 1, device=values.device) * B
@@ -285,5 +329,45 @@ class RwSparseFeaturesDist:
             fm_offsets = ops.exclusive_offsets(fm_lengths)
             fm_values = ops.permute_bags(W, F, B, recv_offsets, fm_offsets, recv_values)
         return ShardedKeys(fm_lengths, fm_offsets, fm_values, recv_offsets, send_splits, recv_splits, perm, B, F)
+
+    def _forward_fixed(self, new_lengths, new_offsets, new_values, perm, values, B):
+        W, F, ops = self._world_size, self._num_features, self._ops
+        self.check_overflow()
+        cap = max(8, -(-int(self._cap_factor * self._expected_keys) // W))
+        cap = (cap + 7) // 8 * 8
+        vals, lens, perm_p, ov = ops.pad_for_exchange(new_values, new_offsets, new_lengths, perm, W, F * B, cap)
+        self._overflow = ov if self._overflow is None else (self._overflow | ov)
+        if ov.is_cuda:   # the flag travels to pinned memory behind the step; the host looks at it one step later
+            if self._overflow_host is None:
+                self._overflow_host = torch.zeros(1, dtype=torch.bool).pin_memory()
+            self._overflow_host.copy_(self._overflow, non_blocking=True)
+            self._overflow_event = torch.cuda.Event()
+            self._overflow_event.record()
+        self.unbucketize_permute_tensor = perm_p
+        recv_lengths = torch.empty_like(lens)
+        dist.all_to_all_single(recv_lengths, lens, group=self._pg)
+        recv_offsets = ops.exclusive_offsets(recv_lengths)
+        recv_values = torch.empty_like(vals)
+        dist.all_to_all_single(recv_values, vals, group=self._pg)        # equal splits: nothing to read back
+        splits = [cap] * W
+        if W == 1 or F == 1:
+            fm_lengths, fm_offsets, fm_values = recv_lengths, recv_offsets, recv_values
+        else:
+            fm_lengths = ops.permute_lengths(W, F, B, recv_lengths)
+            fm_offsets = ops.exclusive_offsets(fm_lengths)
+            fm_values = ops.permute_bags(W, F, B, recv_offsets, fm_offsets, recv_values)
+        return ShardedKeys(fm_lengths, fm_offsets, fm_values, recv_offsets, splits, list(splits), perm_p, B, F)
+
+    def check_overflow(self) -> None:
+        """raises if a previous fixed-capacity exchange had to drop keys (its results are invalid)"""
+        bad = False
+        if self._overflow is not None and not self._overflow.is_cuda:
+            bad = bool(self._overflow.item())
+        elif self._overflow_event is not None and self._overflow_event.query():
+            bad = bool(self._overflow_host.item())
+        if bad:
+            raise RuntimeError("fixed-capacity key exchange overflowed: a peer's share of a batch exceeded "
+                               f"capacity_factor = {self._cap_factor} x (keys / world size); raise the factor or use the "
+                               "exact exchange (capacity_factor=None)")
 
     __call__ = forward

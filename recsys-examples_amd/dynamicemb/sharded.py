@@ -57,7 +57,8 @@ class RowWiseShardedLookup:
 
     def __init__(self, local, num_features: int, feature_hash_sizes: List[int], pooled: bool, pg=None,
                  device=None, out_dtype=torch.float32, dist_type_per_feature: Optional[Sequence[str]] = None,
-                 ops=None, wire_dtype: Optional[torch.dtype] = None):
+                 ops=None, wire_dtype: Optional[torch.dtype] = None, capacity_factor: Optional[float] = None,
+                 expected_keys: Optional[int] = None):
         """wire_dtype (pooled): element type of the partial sums on the fabric.  None = fp32 (the sums of the shards are
         added in fp32, one rounding at the end); torch.bfloat16 halves the bytes per xGMI link at the price of one more
         rounding per shard (what TorchRec's qcomm codec does for its reduce-scatter)."""
@@ -72,7 +73,8 @@ class RowWiseShardedLookup:
         self.ops = ops or HipOps()
         self.input_dist = RwSparseFeaturesDist(self.pg, num_features, feature_hash_sizes, device,
                                                is_sequence=not pooled, dist_type_per_feature=dist_type_per_feature,
-                                               ops=self.ops)
+                                               ops=self.ops, capacity_factor=capacity_factor, expected_keys=expected_keys)
+        self.fixed_capacity = capacity_factor is not None
 
     # ------------------------------------------------------------------------------ the three stages of a forward
     # (what TorchRec's ShardedModule calls input_dist / compute / output_dist; forward() below runs them back to back)
@@ -137,6 +139,10 @@ class RowWiseShardedLookup:
             return g_all
         if bucketized:
             g_send = grads
+        elif self.fixed_capacity:
+            # padded layout: the gradient rows go to the positions of their keys, the padding rows stay zero
+            g_send = torch.zeros(sum(sk.send_splits), grads.size(1), dtype=grads.dtype, device=grads.device)
+            g_send.index_copy_(0, sk.unbucketize_permute, grads)
         else:
             perm = sk.unbucketize_permute
             inv = torch.empty_like(perm)
@@ -288,7 +294,8 @@ class ShardedPooledLookup:
 
     def __init__(self, rows: int, dim: int, device, world: int, rank: int, lr: float = 0.1,
                  out_dtype=torch.bfloat16, dist_type: str = "roundrobin", mode: str = "auto",
-                 keys_per_step: Optional[int] = None, batch: Optional[int] = None, wire_dtype: Optional[torch.dtype] = None):
+                 keys_per_step: Optional[int] = None, batch: Optional[int] = None, wire_dtype: Optional[torch.dtype] = None,
+                 capacity_factor: Optional[float] = None):
         from .batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
         from .dynamicemb_config import (DynamicEmbInitializerArgs, DynamicEmbInitializerMode, DynamicEmbPoolingMode,
                                         DynamicEmbScoreStrategy, DynamicEmbTableOptions, EmbOptimType)
@@ -311,7 +318,8 @@ class ShardedPooledLookup:
         self._steps = None
         if mode == "partial":
             self.impl = RowWiseShardedLookup(_ModuleLocal(module), 1, [rows], pooled=True, device=device,
-                                             out_dtype=out_dtype, dist_type_per_feature=[dist_type], wire_dtype=wire_dtype)
+                                             out_dtype=out_dtype, dist_type_per_feature=[dist_type], wire_dtype=wire_dtype,
+                                             capacity_factor=capacity_factor, expected_keys=keys_per_step)
             self._steps = OverlappedSteps(self.impl)
         else:
             self.impl = RowWiseShardedPooledRows(_ModuleLocal(module), [0], [rows], [dim], combiner=0, device=device,

@@ -109,6 +109,8 @@ class DictLocal:
         self.F = num_features
         self.pooled = pooled
 
+    INVALID = -1   # the padding key of the fixed-capacity exchange: no row, no update (as the table kernels treat it)
+
     def _tagged(self, values, off):
         nb = len(off) - 1
         B = nb // self.F
@@ -121,8 +123,9 @@ class DictLocal:
     def forward(self, values, offsets, train):
         off = offsets.tolist()
         keys, B = self._tagged(values.tolist(), off)
+        zero = np.zeros(D, np.float32)
         for tk in keys:
-            if tk not in self.rows:
+            if tk[1] - self.key_offset != self.INVALID and tk not in self.rows:
                 self.rows[tk] = init_row(tk[1], tk[0])
         if self.pooled:
             out = np.zeros((B, self.F * D), np.float32)
@@ -130,9 +133,9 @@ class DictLocal:
                 for b in range(B):
                     bag = f * B + b
                     for j in range(off[bag], off[bag + 1]):
-                        out[b, f * D:(f + 1) * D] += self.rows[keys[j]]
+                        out[b, f * D:(f + 1) * D] += self.rows.get(keys[j], zero)
         else:
-            out = np.stack([self.rows[k] for k in keys]) if keys else np.zeros((0, D), np.float32)
+            out = np.stack([self.rows.get(k, zero) for k in keys]) if keys else np.zeros((0, D), np.float32)
         return torch.from_numpy(out), (keys, off, B)
 
     def backward(self, ctx, grads):
@@ -149,7 +152,8 @@ class DictLocal:
             for j, k in enumerate(keys):
                 acc[k] = acc.get(k, 0) + g[j]
         for k, v in acc.items():
-            self.rows[k] = (self.rows[k] - np.float32(LR) * v).astype(np.float32)
+            if k in self.rows:
+                self.rows[k] = (self.rows[k] - np.float32(LR) * v).astype(np.float32)
 
 
 def make_batch(rank, F, B, seed, max_len=5, key_space=200):
@@ -194,8 +198,10 @@ def _worker(rank, W, port, F, B, pooled, dist_type, steps, q):
                                           chunk=4)
         else:
             local = DictLocal(F, pooled, key_offset=koff)
+            cf = float(os.environ["TEST_CAPACITY_FACTOR"]) if os.environ.get("TEST_CAPACITY_FACTOR") else None
             sh = RowWiseShardedLookup(local, F, [200] * F, pooled=pooled, device="cpu", out_dtype=torch.float32,
-                                      dist_type_per_feature=[dist_type] * F, ops=NumpyOps())
+                                      dist_type_per_feature=[dist_type] * F, ops=NumpyOps(), capacity_factor=cf,
+                                      expected_keys=F * B * 5 if cf else None)
         outs = []
         if pooled in (True, False) and os.environ.get("TEST_OVERLAPPED") == "1":
             from dynamicemb.sharded import OverlappedSteps
@@ -292,6 +298,10 @@ def test_rowwise_sharded_matches_single_process(W, F, B, pooled, dist_type, over
     if overlapped and pooled == "rows":
         pytest.skip("the rows-back pooled mode has its own two-level schedule")
     monkeypatch.setenv("TEST_OVERLAPPED", "1" if overlapped else "0")
+    _run_and_compare(W, F, B, pooled, dist_type)
+
+
+def _run_and_compare(W, F, B, pooled, dist_type):
     steps = 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -320,3 +330,31 @@ def test_rowwise_sharded_matches_single_process(W, F, B, pooled, dist_type, over
     assert set(seen) == set(exp_rows)
     for k in exp_rows:
         np.testing.assert_allclose(seen[k], exp_rows[k], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("W,F,B,pooled,dist_type", [(2, 2, 5, True, "roundrobin"), (2, 3, 4, False, "hash_roundrobin"),
+                                                    (3, 2, 4, False, "roundrobin")])
+def test_fixed_capacity_exchange_matches_single_process(W, F, B, pooled, dist_type, monkeypatch):
+    """capacity_factor: every peer slot of the key exchange has a fixed size (padded with invalid keys), so no per-peer
+    count is read back; results are those of the exact exchange"""
+    monkeypatch.setenv("TEST_CAPACITY_FACTOR", "3.0")
+    monkeypatch.setenv("TEST_OVERLAPPED", "1")
+    _run_and_compare(W, F, B, pooled, dist_type)
+
+
+def test_fixed_capacity_overflow_is_reported():
+    """one rank, capacity far below the batch: the overflow flag turns into an error at the next exchange"""
+    from dynamicemb.input_dist import RwSparseFeaturesDist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        d = RwSparseFeaturesDist(dist.group.WORLD, 1, [200], "cpu", is_sequence=True, dist_type_per_feature=["roundrobin"],
+                                 ops=NumpyOps(), capacity_factor=0.25, expected_keys=8)   # slot of 8 keys
+        keys, off = make_batch(0, 1, 40, 0)        # ~100 keys into a slot of 8
+        assert keys.numel() > 8
+        d(off[1:] - off[:-1], keys, offsets=off)
+        with pytest.raises(RuntimeError, match="overflowed"):
+            d(off[1:] - off[:-1], keys, offsets=off)
+    finally:
+        dist.destroy_process_group()

@@ -6,7 +6,7 @@
 #   <tag>_pmc_c2.txt / _pmc_traffic.json   PMC passes (counters only) and the HBM traffic derived from them
 #   <tag>_pmc_hstu.txt                SQ counters of the attention kernels at C3 (L = 512)
 #   <tag>_extended.json               tools/bench_extended.py (secondary configurations of SURVEY 8(d))
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
