@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--hstu-reps", type=int, default=20)
     ap.add_argument("--force-sharded", action="store_true", help="run the row-wise sharded path even at N=1 (debug)")
     ap.add_argument("--shard-mode", default="auto", choices=["auto", "rows", "partial"])
+    ap.add_argument("--capacity-factor", type=float, default=0.0,
+                    help="sharded path: fixed-capacity key exchange with this factor (0: exact all-to-all-v with one host read)")
     return ap.parse_args()
 
 
@@ -340,7 +342,8 @@ def main():
         from dynamicemb.sharded import ShardedPooledLookup
 
         sharded = ShardedPooledLookup(args.rows, args.dim, device, world, rank, mode=args.shard_mode,
-                                      keys_per_step=int(args.batch * 5.5), batch=args.batch)
+                                      keys_per_step=int(args.batch * 5.5), batch=args.batch,
+                                      capacity_factor=args.capacity_factor or None)
 
         def fwd(keys, offsets, nxt=None):
             return sharded.forward(keys, offsets, next_batch=nxt)

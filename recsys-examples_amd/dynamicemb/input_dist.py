@@ -48,32 +48,31 @@ class TorchGlue:
         return lengths, offsets
 
     def pad_for_exchange(self, new_values, new_offsets, new_lengths, perm, world, per_peer, cap, pad_key=-1):
-        """Fixed-capacity layout of a bucketized key stream: peer p's keys at [p*cap, p*cap + count_p), the rest of its slot
-        filled with an INVALID key (the table kernels give it no slot: zero row, no update), the padding counted into the last
-        bag of the peer so that lengths and values stay consistent.  -> (values [W*cap], lengths [W*per_peer],
-        positions of the original keys in the padded layout | None, overflow flag [1] bool: some peer got more than cap)"""
+        """Fixed-capacity layout of a bucketized key stream: peer p's slot [p*cap, (p+1)*cap) holds its keys plus padding
+        with an INVALID key (the table kernels give it no slot: zero row, no update).  The padding is spread EVENLY over
+        the peer's bags, behind each bag's real keys -- one giant padding bag would be walked by a single lane group of the
+        pooled gather (measured: 20 ms).  -> (values [W*cap], lengths [W*per_peer], positions of the original keys in the
+        padded layout | None, overflow flag [1] bool: some peer got more than cap)"""
         dev = new_values.device
+        n = new_values.numel()
         peer_off = new_offsets[torch.arange(world + 1, device=dev) * per_peer]
         cnt = peer_off[1:] - peer_off[:-1]
         overflow = (cnt > cap).any().view(1)
-        pos = torch.arange(world * cap, device=dev)
-        pp, r = pos // cap, pos % cap
-        src = (peer_off[pp] + r).clamp_(max=max(new_values.numel() - 1, 0))
-        valid = r < cnt[pp]
-        if new_values.numel():
-            vals = torch.where(valid, new_values[src], torch.full_like(src, pad_key).to(new_values.dtype))
-        else:
-            vals = torch.full((world * cap,), pad_key, dtype=new_values.dtype, device=dev)
-        lens = new_lengths.clone()
-        if per_peer > 0:
-            last = torch.arange(1, world + 1, device=dev) * per_peer - 1
-            lens[last] += (cap - cnt).clamp_(min=0)
+        pad = (cap - cnt).clamp_(min=0)
+        bag_pad = (pad // per_peer).view(world, 1) + (torch.arange(per_peer, device=dev).view(1, -1) < (pad % per_peer).view(world, 1))
+        lens2 = new_lengths.view(world, per_peer) + bag_pad
+        off2 = torch.cumsum(lens2, 1) - lens2 + (torch.arange(world, device=dev) * cap).view(world, 1)   # start of every bag
+        off2 = off2.reshape(-1)
+        vals = torch.full((world * cap,), pad_key, dtype=new_values.dtype, device=dev)
+        dst = None
+        if n:
+            bag = torch.repeat_interleave(torch.arange(world * per_peer, device=dev), new_lengths, output_size=n)
+            dst = off2[bag] + (torch.arange(n, device=dev) - new_offsets[bag])
+            vals[dst.clamp(max=world * cap - 1)] = new_values       # (an overflowing peer spills into garbage: flagged)
         perm_p = None
         if perm is not None:
-            q = torch.searchsorted(peer_off, perm, right=True) - 1
-            q.clamp_(0, world - 1)
-            perm_p = q * cap + (perm - peer_off[q])
-        return vals, lens, perm_p, overflow
+            perm_p = dst[perm] if n else perm
+        return vals, lens2.reshape(-1), perm_p, overflow
 
     def compose(self, perm, index):
         """perm[index]: lets a consumer read rows in exchange order instead of gathering them back first"""

@@ -263,3 +263,40 @@ def test_bf16_wire_for_partial_sums_is_one_rounding_away(one_rank_group):
     o32, _ = s32.forward(keys, torch.from_numpy(off).cuda(), True)
     o16, _ = s16.forward(keys, torch.from_numpy(off).cuda(), True)
     assert torch.equal(o16, o32.bfloat16().float())      # W = 1: exactly the bf16 rounding of the fp32 sums
+
+
+@pytest.mark.parametrize("pooled", [True, False])
+def test_fixed_capacity_exchange_on_the_gpu_matches_the_exact_one(one_rank_group, pooled):
+    """capacity_factor: padded peer slots (invalid keys get no table slot: zero rows, no update), no host read of the
+    per-peer counts; same outputs and rows as the exact all-to-all-v"""
+    from dynamicemb.sharded import OverlappedSteps, RowWiseShardedLookup, _ModuleLocal
+
+    F, B, dim = 2, 64, 16
+    rng = np.random.default_rng(19)
+    mods = [_module(pooled, F, dim, torch.float32) for _ in range(2)]
+    exact = RowWiseShardedLookup(_ModuleLocal(mods[0]), F, [5000] * F, pooled=pooled, device=torch.device("cuda", 0),
+                                 out_dtype=torch.float32, dist_type_per_feature=["hash_roundrobin"] * F)
+    fixed = OverlappedSteps(RowWiseShardedLookup(_ModuleLocal(mods[1]), F, [5000] * F, pooled=pooled, device=torch.device("cuda", 0),
+                                                 out_dtype=torch.float32, dist_type_per_feature=["hash_roundrobin"] * F,
+                                                 capacity_factor=2.0, expected_keys=F * B * 4))
+    batches = []
+    for _ in range(5):
+        lens = rng.integers(0, 8, F * B)
+        off = np.zeros(F * B + 1, np.int64)
+        off[1:] = np.cumsum(lens)
+        batches.append((torch.from_numpy(rng.integers(0, 5000, off[-1]).astype(np.int64)).cuda(), torch.from_numpy(off).cuda()))
+    fixed.prefetch(*batches[0])
+    for i, (k, o) in enumerate(batches):
+        o1, c1 = exact.forward(k, o, True)
+        o2, c2 = fixed.forward(k, o, True, batches[i + 1] if i + 1 < len(batches) else None)
+        assert torch.equal(o1, o2)
+        g = torch.randn_like(o1)
+        exact.backward(c1, g)
+        fixed.backward(c2, g)
+    fixed.lookup.input_dist.check_overflow()
+    probe = torch.arange(0, 5000, device="cuda", dtype=torch.int64)
+    for t in range(F):
+        f1, r1 = mods[0].lookup_rows(probe, t)
+        f2, r2 = mods[1].lookup_rows(probe, t)
+        assert torch.equal(f1, f2) and torch.equal(r1, r2)
+        assert int(mods[1].size(t)) == int(mods[0].size(t))      # the padding keys were never stored
