@@ -113,6 +113,45 @@ int mi355_table_update_counter(int32_t* counter, int64_t counter_numel, const in
                                const int64_t* n_dev, int32_t delta, const int64_t* table_ids,
                                const int64_t* table_bucket_offsets, int64_t bucket_capacity, hipStream_t stream);
 
+/* ---- overflow region of cache tables (scored_hashtable.py:426-474, DynamicEmbCache key_value_table.py:1522-1590).
+ * ovf_storage: a second table arena with ONE bucket of ovf_capacity (= 3 x bucket_capacity) slots per logical table
+ * (same SoA layout, mi355_table_init(ovf_storage, num_tables, ovf_capacity, num_scores)); ovf_bucket_sizes int32[T];
+ * ovf_counter int32[T * ovf_capacity] (the tail of the ref-counter array); ovf_output_offsets int64[T] = main capacity
+ * of each table: an overflow entry's table-relative index is ovf_output_offsets[t] + position.
+ *
+ * table_lookup with ovf_storage (lookup.cu:82-150, kernels.cuh:153-183,711-736): keys the main table does not hold are
+ * searched in their table's overflow bucket (linear probing from hash % ovf_capacity, stops at Empty). */
+int mi355_table_lookup_overflow(void* storage, const int64_t* table_bucket_offsets, int64_t bucket_capacity,
+                                int64_t num_scores, int64_t n, const int64_t* n_dev, const void* keys,
+                                const int64_t* table_ids, const void* score_in, int policy, uint64_t timer_override,
+                                void* ovf_storage, int64_t ovf_capacity, const int64_t* ovf_output_offsets,
+                                int64_t* score_out, uint8_t* founds, int64_t* indices, hipStream_t stream);
+
+/* table_insert_and_evict with counter and overflow (insert_and_evict.cu:201-395, kernels.cuh:389-566,738-800): keys whose
+ * main bucket is entirely pinned (result Busy) find-or-insert in the overflow bucket; its victims are entries with
+ * ref-counter 0.  `results` is required (Insert / Evict / Assign name overflow successes too; compare the index with
+ * ovf_output_offsets to tell the regions apart).  Evicted stream as mi355_table_insert: a main-table eviction reports
+ * (victim key, its slot), an overflow eviction (victim key, overflow index), a key nobody took (key, -(i+1)).
+ * workspace: mi355_table_insert_overflow_workspace_bytes(n). */
+int64_t mi355_table_insert_overflow_workspace_bytes(int64_t n);
+int mi355_table_insert_overflow(void* storage, const int64_t* table_bucket_offsets, int64_t bucket_capacity,
+                                int64_t num_scores, int32_t* bucket_sizes, int32_t* counter, int64_t n,
+                                const int64_t* n_dev, const void* keys, const int64_t* table_ids, const void* score_in,
+                                int policy, uint64_t timer_override, const uint8_t* skip, void* ovf_storage,
+                                int64_t ovf_capacity, int32_t* ovf_bucket_sizes, int32_t* ovf_counter,
+                                const int64_t* ovf_output_offsets, int64_t* indices, uint8_t* results, int64_t* score_out,
+                                int64_t* num_evicted, void* evicted_keys, int64_t* evicted_indices,
+                                int64_t* evicted_scores, int64_t* evicted_table_ids, void* workspace,
+                                int64_t workspace_bytes, hipStream_t stream);
+
+/* table_update_counter_with_layout with the overflow layout (insert_and_evict.cu:27-58): slot < ovf_output_offsets[t]
+ * -> counter[table_bucket_offsets[t]*C + slot], else counter[main_capacity + t*ovf_capacity + slot - offsets[t]]. */
+int mi355_table_update_counter_overflow(int32_t* counter, int64_t counter_numel, const int64_t* slot_indices, int64_t n,
+                                        const int64_t* n_dev, int32_t delta, const int64_t* table_ids,
+                                        const int64_t* table_bucket_offsets, int64_t bucket_capacity,
+                                        int64_t main_capacity, const int64_t* ovf_output_offsets, int64_t ovf_capacity,
+                                        hipStream_t stream);
+
 /* device_timestamp, src/torch_utils.cu:22-40,150 */
 int mi355_device_timestamp(int64_t* out, hipStream_t stream);
 

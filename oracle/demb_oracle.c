@@ -177,6 +177,68 @@ static int reduce_min(bucket_t bk, int64_t C, int64_t ns, const uint8_t *locked,
   return ok;
 }
 
+/* One key of table_insert_kernel / table_insert_and_evict_kernel (kernels.cuh:189-369, 389-466): probe, take an
+ * Empty slot, or evict the minimum score among the unpinned slots.  Returns the InsertResult; *index = table-relative
+ * slot on success; (*ekey, *escore) = the evicted record (Evict) or the key itself and its input score (Busy). */
+static int insert_one(uint8_t *storage, const int64_t *tbo, int64_t C, int64_t ns, int32_t *bucket_sizes,
+                      int32_t *counter, uint8_t *lock_scratch, uint64_t key, int64_t tid, uint64_t *score,
+                      int policy, uint64_t timer, int64_t *index, uint64_t *ekey, uint64_t *escore) {
+  int64_t hash = 0, bb = 0, b = 0;
+  int res = RES_ILLEGAL;
+  *index = -1; *ekey = 0; *escore = 0;
+  if (!locate(key, tid, tbo, C, &hash, &bb, &b)) return res;
+  bucket_t bk = bucket_at(storage, C, ns, b);
+  uint8_t *lk = lock_scratch + b * C;
+  int64_t it = 0;
+  int pr = probe(bk, C, key, hash, &it);
+  res = RES_INIT;
+  if (pr == 1) { res = RES_ASSIGN; lk[it] = 1; }           /* kernels.cuh:201-207 */
+  else if (pr == 2) {                                        /* kernels.cuh:208-216 */
+    lk[it] = 1; bk.keys[it] = LOCKED_KEY; bk.dig[it] = (uint8_t)(hash >> 32);
+    bucket_sizes[b] += 1; res = RES_INSERT;
+  } else {                                                   /* kernels.cuh:226-287 */
+    /* ref-counter: one int32 per slot of the whole arena, table t's region
+     * starting at tbo[t]*C (update_counter_with_layout_kernel,
+     * insert_and_evict.cu:27-58).  NOTE: the reference's insert kernels read
+     * counter[(bucket_id - bkt_begin)*C + iter] (kernels.cuh:355,451), which
+     * for table_id > 0 does not match the layout its own update kernel
+     * writes; both agree for a single table.  This build uses the update
+     * kernel's layout everywhere (counter[bucket_id*C + iter]). */
+    const int32_t *c0 = counter ? counter + b * C : NULL;
+    int64_t slot = 0;
+    if (reduce_min(bk, C, ns, lk, c0, &slot, ekey, escore)) {
+      it = slot; lk[it] = 1; bk.keys[it] = LOCKED_KEY;
+      bk.dig[it] = (uint8_t)(hash >> 32);
+      if (*ekey == RECLAIM_KEY) { bucket_sizes[b] += 1; res = RES_RECLAIM; }
+      else {
+        for (int64_t s = 0; s < ns; ++s) bk.scores[it * ns + s] = 0;
+        res = RES_EVICT;
+      }
+    } else {
+      res = RES_BUSY; *ekey = key; *escore = *score;          /* kernels.cuh:277-282 */
+    }
+  }
+  if (res <= RES_EVICT) {                                    /* kernels.cuh:363-369 */
+    *score = policy_update(policy, bk.scores + it * ns, *score, timer);
+    *index = (b - bb) * C + it;
+  }
+  return res;
+}
+
+/* table_unlock_kernel: kernels.cuh:569-585 (main-table slots) */
+static void unlock_main(uint8_t *storage, const int64_t *tbo, int64_t C, int64_t ns, uint8_t *lock_scratch,
+                        int64_t n, const uint64_t *keys, const int64_t *table_ids, const int64_t *indices,
+                        const int64_t *main_cap) {
+  for (int64_t i = 0; i < n; ++i) {
+    if (indices[i] < 0) continue;
+    if (main_cap && indices[i] >= main_cap[table_ids[i]]) continue;   /* overflow slot */
+    int64_t bb = tbo[table_ids[i]];
+    int64_t b = bb + indices[i] / C, it = indices[i] % C;
+    bucket_at(storage, C, ns, b).keys[it] = keys[i];
+    lock_scratch[b * C + it] = 0;
+  }
+}
+
 /* table_insert_kernel / table_insert_and_evict_kernel + table_unlock_kernel:
  * kernels.cuh:189-585.  Evicted streams may be NULL (plain insert).
  * `lock_scratch` : num_buckets_total * C bytes, zero on entry, zero on exit. */
@@ -189,66 +251,122 @@ void orc_table_insert(uint8_t *storage, const int64_t *tbo, int64_t C, int64_t n
                       int64_t *ev_scores, int64_t *ev_table_ids) {
   int64_t nev = 0;
   for (int64_t i = 0; i < n; ++i) {
-    uint64_t key = keys[i];
-    uint64_t score = policy_get(policy, score_in, i, timer);
-    int64_t hash = 0, bb = 0, b = 0;
-    int res = RES_ILLEGAL; int64_t index = -1;
-    if (locate(key, table_ids[i], tbo, C, &hash, &bb, &b)) {
-      bucket_t bk = bucket_at(storage, C, ns, b);
-      uint8_t *lk = lock_scratch + b * C;
-      int64_t it = 0;
-      int pr = probe(bk, C, key, hash, &it);
-      res = RES_INIT;
-      if (pr == 1) { res = RES_ASSIGN; lk[it] = 1; }           /* kernels.cuh:201-207 */
-      else if (pr == 2) {                                        /* kernels.cuh:208-216 */
-        lk[it] = 1; bk.keys[it] = LOCKED_KEY; bk.dig[it] = (uint8_t)(hash >> 32);
-        bucket_sizes[b] += 1; res = RES_INSERT;
-      } else {                                                   /* kernels.cuh:226-287 */
-        /* ref-counter: one int32 per slot of the whole arena, table t's region
-         * starting at tbo[t]*C (update_counter_with_layout_kernel,
-         * insert_and_evict.cu:27-58).  NOTE: the reference's insert kernels read
-         * counter[(bucket_id - bkt_begin)*C + iter] (kernels.cuh:355,451), which
-         * for table_id > 0 does not match the layout its own update kernel
-         * writes; both agree for a single table.  This build uses the update
-         * kernel's layout everywhere (counter[bucket_id*C + iter]). */
-        const int32_t *c0 = counter ? counter + b * C : NULL;
-        uint64_t ekey = 0, escore = 0; int64_t slot = 0;
-        if (reduce_min(bk, C, ns, lk, c0, &slot, &ekey, &escore)) {
-          it = slot; lk[it] = 1; bk.keys[it] = LOCKED_KEY;
-          bk.dig[it] = (uint8_t)(hash >> 32);
-          if (ekey == RECLAIM_KEY) { bucket_sizes[b] += 1; res = RES_RECLAIM; }
-          else {
-            for (int64_t s = 0; s < ns; ++s) bk.scores[it * ns + s] = 0;
-            res = RES_EVICT;
-          }
-          if (ev_keys && res == RES_EVICT) {
-            ev_keys[nev] = ekey; ev_scores[nev] = (int64_t)escore;
-            ev_indices[nev] = (b - bb) * C + it; ev_table_ids[nev] = table_ids[i]; ++nev;
-          }
-        } else {
-          res = RES_BUSY;
-          if (ev_keys) {                                         /* kernels.cuh:277-282,548-552 */
-            ev_keys[nev] = key; ev_scores[nev] = (int64_t)score;
-            ev_indices[nev] = -(i + 1); ev_table_ids[nev] = table_ids[i]; ++nev;
-          }
-        }
-      }
-      if (res <= RES_EVICT) {                                    /* kernels.cuh:363-369 */
-        score = policy_update(policy, bk.scores + it * ns, score, timer);
-        index = (b - bb) * C + it;
-      }
+    uint64_t score = policy_get(policy, score_in, i, timer), ekey = 0, escore = 0;
+    int64_t index = -1;
+    int res = insert_one(storage, tbo, C, ns, bucket_sizes, counter, lock_scratch, keys[i], table_ids[i], &score,
+                         policy, timer, &index, &ekey, &escore);
+    if (ev_keys && (res == RES_EVICT || res == RES_BUSY)) {   /* kernels.cuh:522-556 */
+      ev_keys[nev] = ekey; ev_scores[nev] = (int64_t)escore;
+      ev_indices[nev] = res == RES_EVICT ? index : -(i + 1); ev_table_ids[nev] = table_ids[i]; ++nev;
     }
     indices[i] = index;
     if (results) results[i] = (uint8_t)res;
     if (score_out) score_out[i] = (int64_t)score;
   }
-  /* table_unlock_kernel: kernels.cuh:569-585 */
+  unlock_main(storage, tbo, C, ns, lock_scratch, n, keys, table_ids, indices, NULL);
+  if (num_evicted) *num_evicted = nev;
+}
+
+/* ---- overflow region (scored_hashtable.py:426-474): one bucket of `ocap` slots per logical table in a second arena;
+ * table-relative index of an overflow entry = out_off[t] + position. */
+
+/* table_lookup_kernel with EnableOverflow (kernels.cuh:153-183) + overflow_find (:711-736) */
+void orc_table_lookup_ovf(uint8_t *storage, const int64_t *tbo, int64_t C, int64_t ns,
+                          uint8_t *ovf_storage, int64_t ocap, const int64_t *out_off,
+                          int64_t n, const uint64_t *keys, const int64_t *table_ids,
+                          const uint64_t *score_in, int policy, uint64_t timer,
+                          int64_t *score_out, uint8_t *founds, int64_t *indices) {
+  orc_table_lookup(storage, tbo, C, ns, n, keys, table_ids, score_in, policy, timer, score_out, founds, indices);
   for (int64_t i = 0; i < n; ++i) {
-    if (indices[i] < 0) continue;
-    int64_t bb = tbo[table_ids[i]];
-    int64_t b = bb + indices[i] / C, it = indices[i] % C;
-    bucket_at(storage, C, ns, b).keys[it] = keys[i];
-    lock_scratch[b * C + it] = 0;
+    if (founds[i] || !orc_is_valid(keys[i])) continue;
+    int64_t t = table_ids[i], hash = orc_hash(keys[i]);
+    bucket_t ob = bucket_at(ovf_storage, ocap, ns, t);
+    for (int64_t scan = 0; scan < ocap; ++scan) {
+      int64_t pos = (hash % ocap + scan) % ocap;
+      uint64_t k = ob.keys[pos];
+      if (k == keys[i]) {
+        uint64_t score = policy_get(policy, score_in, i, timer);
+        if (policy == POLICY_CONST) score = ob.scores[pos * ns + (ns - 1)];
+        else score = policy_update(policy, ob.scores + pos * ns, score, timer);
+        score_out[i] = (int64_t)score; founds[i] = 1; indices[i] = pos + out_off[t];
+        break;
+      }
+      if (k == EMPTY_KEY) break;
+    }
+  }
+}
+
+/* table_insert_and_evict_kernel with UseOverflow (kernels.cuh:468-566) + overflow_insert_and_evict (:738-800).
+ * `ovf_lock` : T * ocap bytes, zero on entry and exit (slots taken in this call stay Locked until the unlock pass). */
+void orc_table_insert_ovf(uint8_t *storage, const int64_t *tbo, int64_t C, int64_t ns,
+                          int32_t *bucket_sizes, int32_t *counter, uint8_t *lock_scratch,
+                          uint8_t *ovf_storage, int64_t ocap, int32_t *ovf_sizes, int32_t *ovf_counter,
+                          const int64_t *out_off, uint8_t *ovf_lock,
+                          int64_t n, const uint64_t *keys, const int64_t *table_ids,
+                          const uint64_t *score_in, int policy, uint64_t timer,
+                          int64_t *indices, uint8_t *results, int64_t *score_out,
+                          int64_t *num_evicted, uint64_t *ev_keys, int64_t *ev_indices,
+                          int64_t *ev_scores, int64_t *ev_table_ids) {
+  int64_t nev = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    uint64_t key = keys[i];
+    int64_t t = table_ids[i];
+    uint64_t score = policy_get(policy, score_in, i, timer), ekey = 0, escore = 0;
+    int64_t index = -1;
+    int res = insert_one(storage, tbo, C, ns, bucket_sizes, counter, lock_scratch, key, t, &score,
+                         policy, timer, &index, &ekey, &escore);
+    uint64_t f_key = ekey; int64_t f_index = res == RES_EVICT ? index : -(i + 1);
+    if (res == RES_BUSY && orc_is_valid(key)) {
+      int64_t hash = orc_hash(key);
+      bucket_t ob = bucket_at(ovf_storage, ocap, ns, t);
+      uint8_t *lk = ovf_lock + t * ocap;
+      int32_t *cnt = ovf_counter + t * ocap;
+      int ores = RES_BUSY; int64_t at = -1; uint64_t okey = 0;
+      for (int64_t scan = 0; scan < ocap; ++scan) {
+        int64_t pos = (hash % ocap + scan) % ocap;
+        if (lk[pos]) continue;                                   /* LockedKey */
+        uint64_t k = ob.keys[pos];
+        if (k == key) { at = pos; ores = RES_ASSIGN; break; }
+        if (k == EMPTY_KEY) {
+          lk[pos] = 1; ob.dig[pos] = (uint8_t)(hash >> 32); ovf_sizes[t] += 1;
+          at = pos; ores = RES_INSERT; break;
+        }
+        if (k == RECLAIM_KEY) continue;
+        if (cnt[pos] == 0) {
+          lk[pos] = 1; ob.dig[pos] = (uint8_t)(hash >> 32);
+          okey = k; at = pos; ores = RES_EVICT; break;
+        }
+      }
+      if (at >= 0) {
+        index = at + out_off[t];
+        res = ores;
+        score = policy_get(policy, score_in, i, timer);
+        if (ores == RES_ASSIGN) score = policy_update(policy, ob.scores + at * ns, score, timer);
+        else {
+          for (int64_t s = 0; s < ns; ++s) ob.scores[at * ns + s] = 0;
+          score = policy_update(policy, ob.scores + at * ns, score, timer);
+          ob.keys[at] = LOCKED_KEY;
+          if (ores == RES_EVICT) { f_key = okey; f_index = index; }
+        }
+      }
+    }
+    if (ev_keys && (res == RES_EVICT || res == RES_BUSY)) {
+      ev_keys[nev] = f_key; ev_scores[nev] = (int64_t)escore;
+      ev_indices[nev] = f_index; ev_table_ids[nev] = t; ++nev;
+    }
+    indices[i] = index;
+    if (results) results[i] = (uint8_t)res;
+    if (score_out) score_out[i] = (int64_t)score;
+  }
+  unlock_main(storage, tbo, C, ns, lock_scratch, n, keys, table_ids, indices, out_off);
+  for (int64_t i = 0; i < n; ++i) {                              /* overflow slots taken above */
+    int64_t t = table_ids[i];
+    if (indices[i] < out_off[t]) continue;
+    int64_t pos = indices[i] - out_off[t];
+    if (ovf_lock[t * ocap + pos]) {
+      bucket_at(ovf_storage, ocap, ns, t).keys[pos] = keys[i];
+      ovf_lock[t * ocap + pos] = 0;
+    }
   }
   if (num_evicted) *num_evicted = nev;
 }

@@ -103,7 +103,7 @@ def _keys(a) -> np.ndarray:
 class OracleTable:
     """``LinearBucketTable`` (scored_hashtable.py:294-474) restated on numpy."""
 
-    def __init__(self, capacities, bucket_capacity: int = 128, num_scores: int = 1):
+    def __init__(self, capacities, bucket_capacity: int = 128, num_scores: int = 1, enable_overflow: bool = False):
         C = ((bucket_capacity + 15) // 16) * 16  # scored_hashtable.py:362-375
         self.C, self.ns = C, num_scores
         nb = [(c + C - 1) // C for c in capacities]  # :381-393
@@ -116,6 +116,60 @@ class OracleTable:
         self.counter = np.zeros(self.capacity, dtype=np.int32)
         self._lock = np.zeros(max(self.capacity, 1), dtype=np.uint8)
         lib().orc_table_init(_p(self.storage), _i64(self.num_buckets), _i64(C), _i64(num_scores))
+        # overflow region (scored_hashtable.py:426-474): one bucket of 3*C slots per logical table, ref-counter tail
+        self.enable_overflow = enable_overflow
+        if enable_overflow:
+            T = len(capacities)
+            self.ocap = 3 * C
+            self.ovf_storage = np.empty(T * self.ocap * (9 + 8 * num_scores), dtype=np.uint8)
+            lib().orc_table_init(_p(self.ovf_storage), _i64(T), _i64(self.ocap), _i64(num_scores))
+            self.ovf_sizes = np.zeros(T, dtype=np.int32)
+            self.out_off = np.asarray(self.per_table_capacity, dtype=np.int64)
+            self.counter = np.zeros(self.capacity + T * self.ocap, dtype=np.int32)
+            self._ovf_lock = np.zeros(T * self.ocap, dtype=np.uint8)
+
+    def counter_index(self, slots, table_ids):
+        """flat ref-counter index of table-relative slots (update_counter_with_layout_kernel, insert_and_evict.cu:27-58)"""
+        slots = np.asarray(slots, np.int64)
+        tids = np.asarray(table_ids, np.int64)
+        flat = self.tbo[tids] * self.C + slots
+        if self.enable_overflow:
+            per = self.out_off[tids]
+            flat = np.where(slots < per, flat, self.capacity + tids * self.ocap + (slots - per))
+        return flat
+
+    def lookup_ovf(self, keys, table_ids, score_in=None, policy=POLICY_CONST, timer=0):
+        keys = _keys(keys)
+        n = keys.size
+        tids = np.ascontiguousarray(table_ids, dtype=np.int64)
+        so = np.empty(n, np.int64)
+        fo = np.empty(n, np.uint8)
+        idx = np.empty(n, np.int64)
+        si = None if score_in is None else _keys(score_in)
+        lib().orc_table_lookup_ovf(_p(self.storage), _p(self.tbo), _i64(self.C), _i64(self.ns), _p(self.ovf_storage),
+                                   _i64(self.ocap), _p(self.out_off), _i64(n), _p(keys), _p(tids), _p(si),
+                                   ctypes.c_int(policy), _u64(timer), _p(so), _p(fo), _p(idx))
+        return so, fo.astype(bool), idx
+
+    def insert_ovf(self, keys, table_ids, score_in=None, policy=POLICY_ASSIGN, timer=0):
+        """insert_and_evict_with_counter_and_overflow -> (indices, results, score_out, (ev_keys, ev_idx, ev_scores, ev_tids))"""
+        keys = _keys(keys)
+        n = keys.size
+        tids = np.ascontiguousarray(table_ids, dtype=np.int64)
+        idx = np.empty(n, np.int64)
+        res = np.empty(n, np.uint8)
+        so = np.empty(n, np.int64)
+        si = None if score_in is None else _keys(score_in)
+        nev = np.zeros(1, np.int64)
+        ek, ei, es, et = np.empty(n, np.uint64), np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n, np.int64)
+        ovf_counter = self.counter[self.capacity:]
+        lib().orc_table_insert_ovf(_p(self.storage), _p(self.tbo), _i64(self.C), _i64(self.ns), _p(self.bucket_sizes),
+                                   _p(self.counter), _p(self._lock), _p(self.ovf_storage), _i64(self.ocap),
+                                   _p(self.ovf_sizes), _p(ovf_counter), _p(self.out_off), _p(self._ovf_lock), _i64(n),
+                                   _p(keys), _p(tids), _p(si), ctypes.c_int(policy), _u64(timer), _p(idx), _p(res),
+                                   _p(so), _p(nev), _p(ek), _p(ei), _p(es), _p(et))
+        m = int(nev[0])
+        return idx, res, so, (ek[:m], ei[:m], es[:m], et[:m])
 
     # views (table_partition, src/table_operation/table.cu:21-65)
     def _view(self):

@@ -103,7 +103,8 @@ table_insert_kernel(Table t, const int64_t* __restrict__ tbo, int32_t* __restric
                     uint8_t* __restrict__ results, int64_t* __restrict__ score_out,
                     unsigned long long* __restrict__ num_evicted, uint64_t* __restrict__ ev_keys,
                     int64_t* __restrict__ ev_indices, int64_t* __restrict__ ev_scores,
-                    int64_t* __restrict__ ev_table_ids) {
+                    int64_t* __restrict__ ev_table_ids, uint64_t* __restrict__ dense_ev_key = nullptr,
+                    int64_t* __restrict__ dense_ev_score = nullptr) {
   if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
   const int g = lane_id() & (G - 1);
   const int64_t gpb = blockDim.x / G;
@@ -226,7 +227,173 @@ table_insert_kernel(Table t, const int64_t* __restrict__ tbo, int32_t* __restric
       indices[i] = index;
       if (results) results[i] = (uint8_t)res;
       if (score_out) score_out[i] = (int64_t)score;
+      // overflow build: the evicted record stays per key; the overflow pass decides what is reported and compacts
+      if (dense_ev_key) { dense_ev_key[i] = ev_key; dense_ev_score[i] = (int64_t)ev_score; }
     }
+  }
+}
+
+// ---- overflow region (scored_hashtable.py:426-474): ONE bucket of `ovf.C` (= 3 x bucket capacity) slots per logical
+// table, linear probing from hash % ovf.C, victims chosen by ref-counter == 0 instead of by score.  Indices of overflow
+// entries are table-relative: out_off[t] (= the table's main capacity) + position.  The region is only touched by keys
+// the main table refused (every slot of their bucket pinned), so one thread per key is enough.
+
+// overflow_find + the overflow branch of table_lookup_kernel (kernels.cuh:153-183, 711-736)
+__global__ void __launch_bounds__(256)
+table_lookup_ovf_kernel(Table ovf, const int64_t* __restrict__ out_off, int64_t n, const int64_t* __restrict__ n_dev,
+                        const uint64_t* __restrict__ keys, const int64_t* __restrict__ table_ids,
+                        const uint64_t* __restrict__ score_in, int policy, uint64_t timer_override,
+                        int64_t* __restrict__ score_out, uint8_t* __restrict__ founds, int64_t* __restrict__ indices) {
+  if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
+  const uint64_t timer = timer_override ? timer_override : device_clock();
+  const int64_t cap = ovf.C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (founds[i]) continue;
+    const uint64_t key = keys[i];
+    if (!is_valid(key)) continue;
+    const int64_t tid = table_ids ? table_ids[i] : 0;
+    const int64_t hash = (int64_t)(fmix64(key) & 0x7FFFFFFFFFFFFFFFull);
+    uint64_t* ks = ovf.keys(tid);
+    int64_t pos = hash % cap, hit = -1;
+    for (int64_t scan = 0; scan < cap; ++scan) {
+      const uint64_t k = ald64(ks + pos);
+      if (k == key) { hit = pos; break; }
+      if (k == kEmptyKey) break;
+      if (++pos == cap) pos = 0;
+    }
+    if (hit < 0) continue;
+    uint64_t* sc = ovf.scores(tid) + hit * ovf.ns;
+    uint64_t score = policy_get(policy, score_in, i, timer);
+    if (policy == kConst) {
+      score = sc[ovf.ns - 1];
+    } else {
+      uint64_t e = key;
+      if (cas64(ks + hit, e, kLockedKey)) {   // (an entry that moved out meanwhile keeps the input score, :170-176)
+        score = policy_update(policy, sc, score, timer);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ast64(ks + hit, key);
+      }
+    }
+    if (score_out) score_out[i] = (int64_t)score;
+    founds[i] = 1;
+    indices[i] = hit + out_off[tid];
+  }
+}
+
+// overflow_insert_and_evict + the overflow branch of table_insert_and_evict_kernel (kernels.cuh:468-566, 738-800):
+// second pass over the keys the main insert left Busy, then the evicted-stream compaction for ALL keys (the main kernel
+// ran with per-key evicted records: dense_ev_*).
+__global__ void __launch_bounds__(256)
+table_insert_ovf_kernel(Table ovf, const int64_t* __restrict__ out_off, int32_t* __restrict__ ovf_sizes,
+                        int32_t* __restrict__ ovf_counter, int64_t n, const int64_t* __restrict__ n_dev,
+                        const uint64_t* __restrict__ keys, const int64_t* __restrict__ table_ids,
+                        const uint64_t* __restrict__ score_in, int policy, uint64_t timer_override,
+                        const uint8_t* __restrict__ skip, int64_t* __restrict__ indices, uint8_t* __restrict__ results,
+                        int64_t* __restrict__ score_out, const uint64_t* __restrict__ dense_ev_key,
+                        const int64_t* __restrict__ dense_ev_score, unsigned long long* __restrict__ num_evicted,
+                        uint64_t* __restrict__ ev_keys, int64_t* __restrict__ ev_indices, int64_t* __restrict__ ev_scores,
+                        int64_t* __restrict__ ev_table_ids) {
+  if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
+  const uint64_t timer = timer_override ? timer_override : device_clock();
+  const int64_t cap = ovf.C;
+  const int64_t n_up = (n + 63) / 64 * 64;   // whole waves: every lane takes part in the ballot
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_up; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool act = i < n && !(skip && skip[i]);
+    int res = act ? (int)results[i] : (int)kIllegal;
+    const uint64_t key = act ? keys[i] : kEmptyKey;
+    const int64_t tid = act ? (table_ids ? table_ids[i] : 0) : 0;
+    uint64_t f_key = act ? dense_ev_key[i] : 0;
+    const int64_t f_score = act ? dense_ev_score[i] : 0;
+    int64_t f_index = res == kEvict ? indices[i] : -(i + 1);
+    if (res == kBusy && is_valid(key)) {
+      const int64_t hash = (int64_t)(fmix64(key) & 0x7FFFFFFFFFFFFFFFull);
+      uint64_t* ks = ovf.keys(tid);
+      int32_t* cnt = ovf_counter + tid * cap;
+      int64_t pos = hash % cap, at = -1;
+      int ores = kBusy;
+      uint64_t okey = 0;
+      for (int64_t scan = 0; scan < cap; ++scan, pos = pos + 1 == cap ? 0 : pos + 1) {
+        uint64_t k = ald64(ks + pos);
+        if (k == key) { at = pos; ores = kAssigned; break; }
+        if (k == kEmptyKey) {
+          uint64_t e = kEmptyKey;
+          if (cas64(ks + pos, e, kLockedKey)) {
+            ovf.dig(tid)[pos] = digest_of(hash);
+            atomicAdd(&ovf_sizes[tid], 1);
+            at = pos; ores = kInsert; break;
+          }
+          k = ald64(ks + pos);
+          if (k == key) { at = pos; ores = kAssigned; break; }
+          continue;
+        }
+        if (k == kLockedKey || k == kReclaimKey) continue;
+        if (__hip_atomic_load(cnt + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+          uint64_t e = k;
+          if (cas64(ks + pos, e, kLockedKey)) {
+            if (atomicAdd(cnt + pos, 0) > 0) { ast64(ks + pos, k); continue; }
+            ovf.dig(tid)[pos] = digest_of(hash);
+            okey = k; at = pos; ores = kEvict; break;
+          }
+        }
+      }
+      if (at >= 0) {
+        uint64_t* sc = ovf.scores(tid) + at * ovf.ns;
+        uint64_t score = policy_get(policy, score_in, i, timer);
+        if (ores == kAssigned) {   // not locked by the find: guard the score write (:505-513)
+          uint64_t e = key;
+          if (cas64(ks + at, e, kLockedKey)) {
+            score = policy_update(policy, sc, score, timer);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ast64(ks + at, key);
+          }
+        } else {                   // newly occupied, stays locked until table_unlock_ovf_kernel
+          for (int64_t w = 0; w < ovf.ns; ++w) sc[w] = 0;
+          score = policy_update(policy, sc, score, timer);
+          if (ores == kEvict) { f_key = okey; f_index = at + out_off[tid]; }
+        }
+        res = ores;
+        indices[i] = at + out_off[tid];
+        results[i] = (uint8_t)res;
+        if (score_out) score_out[i] = (int64_t)score;
+      }
+    }
+    if (num_evicted) {
+      const bool ev = act && (res == kEvict || res == kBusy);
+      const uint64_t vote = __ballot(ev);
+      if (vote) {
+        const int lane = lane_id();
+        const int leader = __ffsll((unsigned long long)vote) - 1;
+        unsigned long long off = 0;
+        if (lane == leader) off = atomicAdd(num_evicted, (unsigned long long)__popcll(vote));
+        uint32_t lo = __shfl((int)(uint32_t)off, leader, 64), hi = __shfl((int)(uint32_t)(off >> 32), leader, 64);
+        off = ((unsigned long long)hi << 32) | lo;
+        if (ev) {
+          int64_t o = (int64_t)off + __popcll(vote & ((1ull << lane) - 1));
+          ev_keys[o] = f_key;
+          ev_scores[o] = f_score;
+          ev_indices[o] = f_index;
+          ev_table_ids[o] = tid;
+        }
+      }
+    }
+  }
+}
+
+// table_unlock_kernel for the overflow slots taken above (Insert / Evict results whose index lies in the overflow range)
+__global__ void __launch_bounds__(256)
+table_unlock_ovf_kernel(Table ovf, const int64_t* __restrict__ out_off, int64_t n, const int64_t* __restrict__ n_dev,
+                        const uint64_t* __restrict__ keys, const int64_t* __restrict__ table_ids,
+                        const uint8_t* __restrict__ skip, const int64_t* __restrict__ indices,
+                        const uint8_t* __restrict__ results) {
+  if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (skip && skip[i]) continue;
+    const int r = results[i];
+    if (r != kInsert && r != kEvict) continue;
+    const int64_t tid = table_ids ? table_ids[i] : 0;
+    const int64_t local = indices[i] - out_off[tid];
+    if (local < 0) continue;
+    ast64(ovf.keys(tid) + local, keys[i]);
   }
 }
 
@@ -290,13 +457,19 @@ table_erase_kernel(Table t, const int64_t* __restrict__ tbo, int32_t* __restrict
 __global__ void __launch_bounds__(256)
 update_counter_kernel(int32_t* __restrict__ counter, int64_t total, const int64_t* __restrict__ slots, int64_t n,
                       const int64_t* __restrict__ n_dev, int32_t delta, const int64_t* __restrict__ table_ids,
-                      const int64_t* __restrict__ tbo, int64_t C, const uint8_t* __restrict__ flags = nullptr, int want = 0) {
+                      const int64_t* __restrict__ tbo, int64_t C, const uint8_t* __restrict__ flags = nullptr, int want = 0,
+                      int64_t main_capacity = 0, const int64_t* __restrict__ ovf_out_off = nullptr, int64_t ovf_cap = 0) {
   if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t s = slots[i];
     if (s < 0) continue;
     if (flags && (flags[i] != 0) != (want != 0)) continue;
     int64_t flat = (table_ids && tbo) ? tbo[table_ids[i]] * C + s : s;
+    if (ovf_out_off) {   // insert_and_evict.cu:42-50: overflow slots live behind the main arena, table by table
+      const int64_t tid = table_ids ? table_ids[i] : 0;
+      const int64_t per = ovf_out_off[tid];
+      flat = s < per ? tbo[tid] * C + s : main_capacity + tid * ovf_cap + (s - per);
+    }
     if (flat >= 0 && flat < total) counter[flat] += delta;
   }
 }
@@ -488,6 +661,87 @@ int mi355_table_update_counter(int32_t* counter, int64_t counter_numel, const in
   if (n == 0) return MI355_OK;
   hipLaunchKernelGGL(update_counter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, counter, counter_numel,
                      slot_indices, n, n_dev, delta, table_ids, table_bucket_offsets, C);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int mi355_table_update_counter_overflow(int32_t* counter, int64_t counter_numel, const int64_t* slot_indices, int64_t n,
+                                        const int64_t* n_dev, int32_t delta, const int64_t* table_ids,
+                                        const int64_t* table_bucket_offsets, int64_t C, int64_t main_capacity,
+                                        const int64_t* ovf_output_offsets, int64_t ovf_capacity, hipStream_t stream) {
+  MI355_CHECK_ARG(table_bucket_offsets && ovf_output_offsets, "table_bucket_offsets and ovf_output_offsets required");
+  if (n == 0) return MI355_OK;
+  hipLaunchKernelGGL(update_counter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, counter, counter_numel,
+                     slot_indices, n, n_dev, delta, table_ids, table_bucket_offsets, C, (const uint8_t*)nullptr, 0,
+                     main_capacity, ovf_output_offsets, ovf_capacity);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int mi355_table_lookup_overflow(void* storage, const int64_t* table_bucket_offsets, int64_t C, int64_t num_scores, int64_t n,
+                                const int64_t* n_dev, const void* keys, const int64_t* table_ids, const void* score_in,
+                                int policy, uint64_t timer_override, void* ovf_storage, int64_t ovf_capacity,
+                                const int64_t* ovf_output_offsets, int64_t* score_out, uint8_t* founds, int64_t* indices,
+                                hipStream_t stream) {
+  MI355_CHECK_ARG(ovf_storage && ovf_output_offsets && ovf_capacity > 0 && ovf_capacity % 16 == 0,
+                  "overflow storage, output offsets and a positive capacity (multiple of 16) required");
+  int rc = table_lookup_impl(storage, table_bucket_offsets, C, num_scores, n, n_dev, keys, table_ids, score_in, policy,
+                             timer_override, score_out, founds, indices, false, stream);
+  if (rc != MI355_OK || n == 0) return rc;
+  Table ovf = make_table(ovf_storage, ovf_capacity, num_scores);
+  hipLaunchKernelGGL(table_lookup_ovf_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, ovf, ovf_output_offsets, n,
+                     n_dev, (const uint64_t*)keys, table_ids, (const uint64_t*)score_in, policy, timer_override, score_out,
+                     founds, indices);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+int64_t mi355_table_insert_overflow_workspace_bytes(int64_t n) { return 16 * (n > 0 ? n : 1); }
+
+int mi355_table_insert_overflow(void* storage, const int64_t* table_bucket_offsets, int64_t C, int64_t num_scores,
+                                int32_t* bucket_sizes, int32_t* counter, int64_t n, const int64_t* n_dev, const void* keys,
+                                const int64_t* table_ids, const void* score_in, int policy, uint64_t timer_override,
+                                const uint8_t* skip, void* ovf_storage, int64_t ovf_capacity, int32_t* ovf_bucket_sizes,
+                                int32_t* ovf_counter, const int64_t* ovf_output_offsets, int64_t* indices,
+                                uint8_t* results, int64_t* score_out, int64_t* num_evicted, void* evicted_keys,
+                                int64_t* evicted_indices, int64_t* evicted_scores, int64_t* evicted_table_ids,
+                                void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  MI355_CHECK_ARG(C > 0 && C % 16 == 0, "bucket capacity must be a positive multiple of 16");
+  MI355_CHECK_ARG(policy >= kConst && policy <= kLruLfu, "bad score policy");
+  MI355_CHECK_ARG(policy == kConst || policy == kGlobalTimer || score_in, "score_in required by this policy");
+  MI355_CHECK_ARG(policy != kLruLfu || num_scores == 2, "LRU_LFU needs num_scores == 2");
+  MI355_CHECK_ARG(ovf_storage && ovf_bucket_sizes && ovf_counter && ovf_output_offsets && ovf_capacity > 0 &&
+                      ovf_capacity % 16 == 0, "overflow storage / sizes / counter / output offsets required");
+  MI355_CHECK_ARG(counter && results, "the overflow insert needs the ref-counter and a results buffer");
+  MI355_CHECK_ARG(!num_evicted || (evicted_keys && evicted_indices && evicted_scores && evicted_table_ids),
+                  "evicted output buffers required with num_evicted");
+  MI355_CHECK_ARG(workspace && workspace_bytes >= mi355_table_insert_overflow_workspace_bytes(n), "workspace too small");
+  if (num_evicted) {
+    if (hipMemsetAsync(num_evicted, 0, sizeof(int64_t), stream) != hipSuccess) { mi355_set_error("memset failed"); return MI355_ELAUNCH; }
+  }
+  if (n == 0) return MI355_OK;
+  Table t = make_table(storage, C, num_scores);
+  Table ovf = make_table(ovf_storage, ovf_capacity, num_scores);
+  uint64_t* d_key = (uint64_t*)workspace;
+  int64_t* d_score = (int64_t*)workspace + n;
+  // main table, evicted records kept per key; its own slots are published before the overflow pass runs
+  hipLaunchKernelGGL(table_insert_kernel, dim3(grid_for(n, 256 / G)), dim3(256), 0, stream, t, table_bucket_offsets,
+                     bucket_sizes, counter, n, n_dev, (const uint64_t*)keys, table_ids, (const uint64_t*)score_in,
+                     policy, timer_override, skip, indices, results, score_out, (unsigned long long*)nullptr,
+                     (uint64_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr, d_key, d_score);
+  MI355_LAUNCH_CHECK();
+  hipLaunchKernelGGL(table_unlock_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, t, table_bucket_offsets, n, n_dev,
+                     (const uint64_t*)keys, table_ids, skip, indices, (const int64_t*)nullptr, (const int64_t*)nullptr, 0,
+                     (int64_t*)nullptr);
+  MI355_LAUNCH_CHECK();
+  hipLaunchKernelGGL(table_insert_ovf_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, ovf, ovf_output_offsets,
+                     ovf_bucket_sizes, ovf_counter, n, n_dev, (const uint64_t*)keys, table_ids,
+                     (const uint64_t*)score_in, policy, timer_override, skip, indices, results, score_out, d_key, d_score,
+                     (unsigned long long*)num_evicted, (uint64_t*)evicted_keys, evicted_indices, evicted_scores,
+                     evicted_table_ids);
+  MI355_LAUNCH_CHECK();
+  hipLaunchKernelGGL(table_unlock_ovf_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, ovf, ovf_output_offsets, n,
+                     n_dev, (const uint64_t*)keys, table_ids, skip, indices, results);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }

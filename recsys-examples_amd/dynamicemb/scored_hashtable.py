@@ -6,7 +6,8 @@ behaviour -- on top of the gfx950 kernels (dynamicemb_extensions -> librecsys_am
 State is plain tensors owned here (one uint8 arena: per bucket [keys u64 x C][digests u8 x C]
 [scores u64 x C x num_scores], bucket_sizes i32, ref counter i32, bucket offsets i64), exactly the
 layout the reference documents, so dumps of the arena are interchangeable.
-Out of scope this round: overflow buckets of cache tables, dump/load/incremental_dump.
+Overflow buckets of cache tables (enable_overflow=True, scored_hashtable.py:426-474 of the reference) are built;
+dump / load / incremental_dump live at the module level (batched_dynamicemb_tables.py).
 """
 from __future__ import annotations
 
@@ -74,8 +75,7 @@ class LinearBucketTable(ScoredHashTable):
         """host=True keeps the table (keys / digests / scores, bucket sizes, pin counters) in pinned host memory, which
         the GPU kernels address directly (the host tier of the reference's HybridStorage / host-only storage,
         key_value_table.py:2107-2403; the reference stages through HostVMMTensor)."""
-        if enable_overflow:
-            raise NotImplementedError("overflow buckets (cache tables) are a 'next' row; see DESIGN.md")
+        assert not (enable_overflow and host), "the overflow region belongs to the HBM cache table"
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         assert key_type in (torch.int64, torch.uint64), "Only accept 64 bits integer as key's type."
         self.key_type_ = key_type
@@ -110,7 +110,27 @@ class LinearBucketTable(ScoredHashTable):
             self.table_storage_ = torch.empty(self.storage_bytes_, dtype=torch.uint8, device=self.device)
             self.bucket_sizes = torch.zeros(self.num_buckets_, dtype=torch.int32, device=self.device)
             self._ref_counter = torch.zeros(self.capacity_, dtype=torch.int32, device=self.device)
-        self.enable_overflow_ = False
+        # overflow region (scored_hashtable.py:426-474): one bucket of 3*C slots per logical table in its own arena, its
+        # ref-counters behind the main ones, indices of its entries offset by the table's main capacity
+        self.enable_overflow_ = bool(enable_overflow)
+        if self.enable_overflow_:
+            self.overflow_bucket_capacity_ = 3 * C
+            self.overflow_num_buckets_ = self.num_tables_
+            self.overflow_table_storage_ = torch.empty(
+                (9 + 8 * self.num_scores_) * self.overflow_bucket_capacity_ * self.overflow_num_buckets_, dtype=torch.uint8,
+                device=self.device)
+            self.overflow_bucket_sizes = torch.zeros(self.overflow_num_buckets_, dtype=torch.int32, device=self.device)
+            self.overflow_output_offsets_ = torch.tensor(self.per_table_capacity_, dtype=torch.int64, device=self.device)
+            self._ref_counter = torch.zeros(self.capacity_ + self.overflow_bucket_capacity_ * self.num_tables_,
+                                            dtype=torch.int32, device=self.device)
+            self._ovf_counter = self._ref_counter[self.capacity_:]
+        else:
+            self.overflow_bucket_capacity_ = 0
+            self.overflow_num_buckets_ = 0
+            self.overflow_table_storage_ = None
+            self.overflow_bucket_sizes = None
+            self.overflow_output_offsets_ = None
+            self._ovf_counter = None
         self.reset()
 
     # -- views (table_partition) ---------------------------------------------------------
@@ -136,6 +156,67 @@ class LinearBucketTable(ScoredHashTable):
         ext.table_init(self.table_storage_, self.bucket_capacity_, self.num_buckets_, self.num_scores_)
         self.bucket_sizes.zero_()
         self._ref_counter.zero_()
+        if self.enable_overflow_:
+            ext.table_init(self.overflow_table_storage_, self.overflow_bucket_capacity_, self.overflow_num_buckets_,
+                           self.num_scores_)
+            self.overflow_bucket_sizes.zero_()
+
+    def _ovf(self):
+        return dict(overflow_output_offsets=self.overflow_output_offsets_ if self.enable_overflow_ else None,
+                    overflow_bucket_capacity=self.overflow_bucket_capacity_)
+
+    # -- overflow (DynamicEmbCache, key_value_table.py:1522-1590) -----------------------------
+    def lookup_with_overflow(self, keys, table_ids, score: ScoreArg):
+        """scored_hashtable.py:736-763: lookup, then the table's overflow bucket for the keys the main table does not
+        hold; overflow indices are offset by the per-table main capacity."""
+        assert self.enable_overflow_, "lookup_with_overflow requires enable_overflow=True"
+        value, policy = self._parse_score(score)
+        return ext.table_lookup(self.table_storage_, self.table_bucket_offsets_, self.bucket_capacity_, keys, table_ids,
+                                value, policy, ovf_storage=self.overflow_table_storage_,
+                                ovf_bucket_capacity=self.overflow_bucket_capacity_,
+                                ovf_output_offsets=self.overflow_output_offsets_, num_scores=self.num_scores_)
+
+    def _insert_ovf(self, keys, table_ids, value, policy, insert_results=None, score_out=None):
+        return ext.table_insert_and_evict(
+            self.table_storage_, self.table_bucket_offsets_, self.bucket_capacity_, self.bucket_sizes, keys, table_ids,
+            value, policy, self._ref_counter, insert_results, score_out, ovf_storage=self.overflow_table_storage_,
+            ovf_bucket_capacity=self.overflow_bucket_capacity_, ovf_bucket_sizes=self.overflow_bucket_sizes,
+            ovf_counter=self._ovf_counter, ovf_output_offsets=self.overflow_output_offsets_, num_scores=self.num_scores_)
+
+    def insert_and_evict_with_counter_and_overflow(self, keys, table_ids, score: ScoreArg, insert_results=None,
+                                                   score_out=None):
+        """scored_hashtable.py:765-824: counter-aware insert; keys whose bucket is entirely pinned go to the overflow
+        bucket (victims there: ref-counter 0).  Same tuple as insert_and_evict."""
+        assert self.enable_overflow_, "insert_and_evict_with_counter_and_overflow requires enable_overflow=True"
+        value, policy = self._parse_score(score)
+        if os.environ.get("DEMB_DETERMINISM_MODE") is not None:
+            assert self.num_scores_ == 1, "DEMB_DETERMINISM_MODE does not support auxiliary score columns yet."
+            return self._deterministic_insert_and_evict_with_overflow(keys, table_ids, value, policy)
+        idx, nev, ek, ei, es, et = self._insert_ovf(keys, table_ids, value, policy, insert_results, score_out)
+        h = int(nev.cpu().item())
+        return idx, h, ek[:h], ei[:h], es[:h], et[:h]
+
+    def _deterministic_insert_and_evict_with_overflow(self, keys, table_ids, score_value, policy):
+        """scored_hashtable.py:1643-1735: bucket waves through the overflow insert, final indices by one CONST lookup"""
+        n = keys.numel()
+        dev = keys.device
+        if n == 0:
+            e = torch.empty(0, dtype=torch.int64, device=dev)
+            return e, 0, torch.empty_like(keys[:0]), e.clone(), e.clone(), e.clone()
+        acc = [[], [], [], []]
+        for vk, vt, vs in self._waves(keys, table_ids, score_value):
+            _, nev, ek, ei, es, et = self._insert_ovf(vk, vt, vs, policy)
+            h = int(nev.cpu().item())
+            if h:
+                for lst, a in zip(acc, (ek, ei, es, et)):
+                    lst.append(a[:h])
+        _, _, indices = ext.table_lookup(self.table_storage_, self.table_bucket_offsets_, self.bucket_capacity_, keys,
+                                         table_ids, None, ScorePolicy.CONST, ovf_storage=self.overflow_table_storage_,
+                                         ovf_bucket_capacity=self.overflow_bucket_capacity_,
+                                         ovf_output_offsets=self.overflow_output_offsets_)
+        cat = [torch.cat(x) if x else torch.empty(0, dtype=(keys.dtype if i == 0 else torch.int64), device=dev)
+               for i, x in enumerate(acc)]
+        return indices, cat[0].numel(), cat[0], cat[1], cat[2], cat[3]
 
     # -- lookup / insert --------------------------------------------------------------------
     def lookup(self, keys, table_ids, score: ScoreArg, n_dev=None):
@@ -171,23 +252,31 @@ class LinearBucketTable(ScoredHashTable):
     def increment_counter(self, slot_indices, table_ids, n_dev=None) -> None:
         ext.table_update_counter_with_layout(self._ref_counter, slot_indices, 1, self.table_bucket_offsets_,
                                              self.bucket_capacity_, self.capacity_, self.num_tables_, table_ids=table_ids,
-                                             n_dev=n_dev)
+                                             n_dev=n_dev, **self._ovf())
 
     def decrement_counter(self, slot_indices, table_ids, n_dev=None) -> None:
         ext.table_update_counter_with_layout(self._ref_counter, slot_indices, -1, self.table_bucket_offsets_,
                                              self.bucket_capacity_, self.capacity_, self.num_tables_, table_ids=table_ids,
-                                             n_dev=n_dev)
+                                             n_dev=n_dev, **self._ovf())
 
     # -- bookkeeping -------------------------------------------------------------------------
     def capacity(self, table_id: Optional[int] = None) -> int:
+        """main + overflow (scored_hashtable.py:1379-1391)"""
+        if table_id is not None:
+            return self.per_table_capacity_[table_id] + self.overflow_bucket_capacity_
+        return self.capacity_ + self.overflow_bucket_capacity_ * self.overflow_num_buckets_
+
+    def main_capacity(self, table_id: Optional[int] = None) -> int:
         return self.capacity_ if table_id is None else self.per_table_capacity_[table_id]
 
     def size(self, table_id: Optional[int] = None):
         if table_id is not None:
             b0 = int(self.table_bucket_offsets_cpu_[table_id])
             b1 = int(self.table_bucket_offsets_cpu_[table_id + 1])
-            return self.bucket_sizes[b0:b1].sum()
-        return self.bucket_sizes.sum()
+            s = self.bucket_sizes[b0:b1].sum()
+            return s + self.overflow_bucket_sizes[table_id] if self.enable_overflow_ else s
+        s = self.bucket_sizes.sum()
+        return s + self.overflow_bucket_sizes.sum() if self.enable_overflow_ else s
 
     def load_factor(self) -> float:
         return self.bucket_sizes.sum() / self.capacity_

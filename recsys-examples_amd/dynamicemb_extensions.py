@@ -114,13 +114,18 @@ def table_init(table_storage, bucket_capacity: int, num_buckets: int, num_scores
 def table_lookup(table_storage, table_bucket_offsets, bucket_capacity, keys, table_ids, score_input, policy_type,
                  ovf_storage=None, ovf_bucket_capacity=0, ovf_output_offsets=None, num_scores=1, n_dev=None):
     """table_lookup (lookup.cu:151-191) -> (score_out i64[N], founds bool[N], indices i64[N])."""
-    if ovf_storage is not None:
-        raise NotImplementedError("overflow buckets (cache tables) are a 'next' row; see DESIGN.md")
     n = keys.numel()
     dev = keys.device
     score_out = torch.empty(n, dtype=torch.int64, device=dev)
     founds = torch.empty(n, dtype=torch.bool, device=dev)
     indices = torch.empty(n, dtype=torch.int64, device=dev)
+    if ovf_storage is not None:   # lookup.cu:82-150: main table, then the table's overflow bucket
+        check(lib().mi355_table_lookup_overflow(ptr(table_storage), ptr(table_bucket_offsets), bucket_capacity, num_scores, n,
+                                                ptr(n_dev), ptr(keys), ptr(table_ids), ptr(score_input), int(policy_type),
+                                                c_u64(TIMER_OVERRIDE), ptr(ovf_storage), ovf_bucket_capacity,
+                                                ptr(ovf_output_offsets), ptr(score_out), ptr(_u8(founds)), ptr(indices),
+                                                stream()), "table_lookup (overflow)")
+        return score_out, founds, indices
     check(lib().mi355_table_lookup(ptr(table_storage), ptr(table_bucket_offsets), bucket_capacity, num_scores, n,
                                    ptr(n_dev), ptr(keys), ptr(table_ids), ptr(score_input), int(policy_type),
                                    c_u64(TIMER_OVERRIDE), ptr(score_out), ptr(_u8(founds)), ptr(indices), stream()),
@@ -162,8 +167,23 @@ def table_insert_and_evict(table_storage, table_bucket_offsets, bucket_capacity,
                            ovf_output_offsets=None, num_scores=1):
     """table_insert_and_evict (insert_and_evict.cu) -> (indices, num_evicted[1] (device), evicted_keys,
     evicted_indices, evicted_scores (uint64 bits as in the reference), evicted_table_ids)."""
-    if ovf_storage is not None:
-        raise NotImplementedError("overflow buckets (cache tables) are a 'next' row; see DESIGN.md")
+    if ovf_storage is not None:   # insert_and_evict.cu:201-395
+        n = keys.numel()
+        dev = keys.device
+        indices = torch.empty(n, dtype=torch.int64, device=dev)
+        if insert_results is None:
+            insert_results = torch.empty(n, dtype=torch.uint8, device=dev)
+        ev = [torch.zeros(1, dtype=torch.int64, device=dev), torch.empty_like(keys),
+              torch.empty(n, dtype=torch.int64, device=dev), torch.empty(n, dtype=torch.int64, device=dev),
+              torch.empty(n, dtype=torch.int64, device=dev)]
+        ws = torch.empty(int(lib().mi355_table_insert_overflow_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        check(lib().mi355_table_insert_overflow(
+            ptr(table_storage), ptr(table_bucket_offsets), bucket_capacity, num_scores, ptr(bucket_sizes), ptr(counter), n,
+            None, ptr(keys), ptr(table_ids), ptr(score_input), int(policy_type), c_u64(TIMER_OVERRIDE), None,
+            ptr(ovf_storage), ovf_bucket_capacity, ptr(ovf_bucket_sizes), ptr(ovf_counter), ptr(ovf_output_offsets),
+            ptr(indices), ptr(insert_results), ptr(score_output), ptr(ev[0]), ptr(ev[1]), ptr(ev[2]), ptr(ev[3]), ptr(ev[4]),
+            ptr(ws), ws.numel(), stream()), "table_insert_and_evict (overflow)")
+        return indices, ev[0], ev[1], ev[2], ev[3], ev[4]
     idx, ev = _insert(table_storage, table_bucket_offsets, bucket_capacity, bucket_sizes, keys, table_ids, score_input,
                       policy_type, counter, insert_results, score_output, num_scores, True)
     return idx, ev[0], ev[1], ev[2], ev[3], ev[4]
@@ -180,7 +200,13 @@ def table_update_counter_with_layout(counter, slot_indices, delta, table_bucket_
                                      main_capacity, num_tables, table_ids=None, overflow_output_offsets=None,
                                      overflow_bucket_capacity=0, n_dev=None):
     if overflow_output_offsets is not None:
-        raise NotImplementedError("overflow buckets (cache tables) are a 'next' row; see DESIGN.md")
+        tids = table_ids if table_ids is not None else torch.zeros_like(slot_indices)
+        check(lib().mi355_table_update_counter_overflow(ptr(counter), counter.numel(), ptr(slot_indices),
+                                                        slot_indices.numel(), ptr(n_dev), int(delta), ptr(tids),
+                                                        ptr(table_bucket_offsets), bucket_capacity, main_capacity,
+                                                        ptr(overflow_output_offsets), overflow_bucket_capacity, stream()),
+              "table_update_counter (overflow)")
+        return
     use_layout = table_ids is not None and num_tables > 1
     check(lib().mi355_table_update_counter(ptr(counter), counter.numel(), ptr(slot_indices), slot_indices.numel(),
                                            ptr(n_dev), int(delta), ptr(table_ids if use_layout else None),

@@ -39,6 +39,13 @@ _SIGS = {
                            c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "mi355_table_erase": [c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p],
     "mi355_table_update_counter": [c_p, c_i64, c_p, c_i64, c_p, ctypes.c_int32, c_p, c_p, c_i64, c_p],
+    "mi355_table_lookup_overflow": [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_int, c_u64, c_p, c_i64, c_p, c_p,
+                                    c_p, c_p, c_p],
+    "mi355_table_insert_overflow_workspace_bytes": [c_i64],
+    "mi355_table_insert_overflow": [c_p, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_int, c_u64, c_p,
+                                    c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p],
+    "mi355_table_update_counter_overflow": [c_p, c_i64, c_p, c_i64, c_p, ctypes.c_int32, c_p, c_p, c_i64, c_i64, c_p,
+                                            c_i64, c_p],
     "mi355_device_timestamp": [c_p, c_p],
     "mi355_table_export_batch": [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_u64, c_i64, c_i64, c_p, c_p, c_p, c_p,
                                  c_p, c_i64, c_p],
@@ -123,6 +130,7 @@ _RESTYPES = {
     "mi355_segmented_unique_workspace_bytes": c_i64,
     "mi355_group_by_unique_csr_workspace_bytes": c_i64,
     "mi355_table_export_batch_workspace_bytes": c_i64,
+    "mi355_table_insert_overflow_workspace_bytes": c_i64,
     "mi355_flagged_compact_workspace_bytes": c_i64,
     "mi355_group_by_unique_workspace_bytes": c_i64,
     "mi355_backward_workspace_bytes": c_i64,

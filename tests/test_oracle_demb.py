@@ -341,3 +341,95 @@ def test_zipf_key_stream_is_the_reference_generator(name):
     torch.manual_seed(seed)
     got = bench.zipf_keys(lo, hi, float(FLOW[f"zipf/{name}/alpha"]), n, torch.device("cpu")).numpy()
     assert np.array_equal(got, FLOW[f"zipf/{name}/samples"])
+
+
+# ----------------------------------------------------------------------------- overflow region of cache tables
+@pytest.mark.parametrize("nb,C", [([1], 128), ([1, 3], 128), ([1, 2, 4], 64)])
+def test_overflow_with_counter_oracle(nb, C):
+    """the scenario of the reference's test_overflow_with_counter (test/unit_tests/table_operation/test_table_operation.py
+    :676-1063) on the oracle restatement: fill + pin the main tables, overflow insertion in ten rounds, lookups through
+    both regions, counter release, eviction, and what it implies for sizes / counters"""
+    caps = [n * C for n in nb]
+    Tn, ocap = len(caps), 3 * C
+    o = orc.OracleTable(caps, bucket_capacity=C, enable_overflow=True)
+    assert o.counter.size == sum(caps) + ocap * Tn
+    main = np.array(caps)
+    key = 1
+    fk, ft, fi = [], [], []
+    for _ in range(100):                                           # phase 2
+        if all(o.bucket_sizes[o.tbo[t]:o.tbo[t + 1]].sum() == caps[t] for t in range(Tn)):
+            break
+        per = sum(caps)
+        bk = np.concatenate([np.arange(key + t * per, key + (t + 1) * per) for t in range(Tn)])
+        bt = np.repeat(np.arange(Tn), per)
+        key += per * Tn
+        idx, res, _ = o.insert(bk, bt, np.full(bk.size, 100, np.uint64))
+        ok = np.isin(res, (0, 1, 2))
+        _, still, _ = o.lookup(bk[ok], bt[ok])                     # (not displaced by a later key of the same call)
+        sel = np.nonzero(ok)[0][still]
+        o.counter[o.counter_index(idx[sel], bt[sel])] += 1
+        fk.append(bk[sel]); ft.append(bt[sel]); fi.append(idx[sel])
+    fk, ft, fi = np.concatenate(fk), np.concatenate(ft), np.concatenate(fi)
+    assert all(o.bucket_sizes[o.tbo[t]:o.tbo[t + 1]].sum() == caps[t] for t in range(Tn))
+    _, f, li = o.lookup_ovf(fk, ft)
+    assert f.all() and np.array_equal(li, fi) and (o.counter[o.counter_index(fi, ft)] >= 1).all()   # phase 3
+    pools = [np.arange(key + t * ocap, key + (t + 1) * ocap) for t in range(Tn)]
+    key += Tn * ocap
+    per = ocap // 10
+    ak, at, ai = [], [], []
+    for r in range(10):                                            # phase 4
+        bk = np.concatenate([p[r * per:(r + 1) * per] for p in pools])
+        bt = np.repeat(np.arange(Tn), per)
+        idx, res, so, ev = o.insert_ovf(bk, bt, np.ones(bk.size, np.uint64))
+        assert (res == 0).all() and ev[0].size == 0 and (idx >= main[bt]).all() and (idx < main[bt] + ocap).all()
+        o.counter[o.counter_index(idx, bt)] += 1
+        ak.append(bk); at.append(bt); ai.append(idx)
+    ak, at, ai = np.concatenate(ak), np.concatenate(at), np.concatenate(ai)
+    assert (o.ovf_sizes == 10 * per).all()
+    _, f, li = o.lookup_ovf(fk, ft)                                # phase 5
+    assert f.all() and np.array_equal(li, fi)
+    so, f, li = o.lookup_ovf(ak, at)
+    assert f.all() and np.array_equal(li, ai) and (so == 1).all()
+    _, f, li = o.lookup_ovf(np.arange(key, key + 50), np.zeros(50, np.int64))
+    assert not f.any() and (li == -1).all()
+    _, f, _ = o.lookup(ak, at)                                     # the main-only lookup does not see them
+    assert not f.any()
+    o.counter[o.counter_index(fi, ft)] -= 1                        # phase 6
+    o.counter[o.counter_index(ai, at)] -= 1
+    assert (o.counter == 0).all()
+    ek = np.arange(key + 100, key + 132)
+    idx, res, so, ev = o.insert_ovf(ek, np.zeros(32, np.int64), np.full(32, 200, np.uint64))
+    assert (res == 3).all() and ev[0].size == 32 and (idx < caps[0]).all()      # main-table evictions again
+    assert np.isin(ev[0].view(np.int64), fk[ft == 0]).all() and (ev[2] == 100).all()
+
+
+def test_overflow_oracle_evicts_by_counter_and_reports_busy():
+    """overflow victims are the entries with ref-counter 0 in probe order (kernels.cuh:779-791); with every entry pinned
+    the key is refused and reported as (key, -(i+1)) (kernels.cuh:797-799, 470-472)"""
+    C = 16
+    o = orc.OracleTable([C], bucket_capacity=C, enable_overflow=True)
+    idx, _, _ = o.insert(np.arange(1, C + 1), np.zeros(C, np.int64), np.full(C, 5, np.uint64))
+    o.counter[o.counter_index(idx, np.zeros(C, np.int64))] += 1
+    k = np.arange(100, 100 + 3 * C)
+    idx, res, _, ev = o.insert_ovf(k, np.zeros(k.size, np.int64), np.ones(k.size, np.uint64))
+    assert (res == 0).all() and np.unique(idx).size == 3 * C and idx.min() == C and idx.max() == 4 * C - 1
+    pin = idx[::2]
+    o.counter[o.counter_index(pin, np.zeros(pin.size, np.int64))] += 1
+    k2 = np.arange(1000, 1000 + 3 * C)            # 24 unpinned victims for 48 keys
+    idx2, res2, _, ev = o.insert_ovf(k2, np.zeros(k2.size, np.int64), np.full(k2.size, 2, np.uint64))
+    assert (res2 == 3).sum() == 3 * C // 2 and (res2 == 5).sum() == 3 * C // 2
+    ek, ei, es, et = ev
+    assert ek.size == 3 * C
+    took = res2 == 3
+    assert np.array_equal(np.sort(ek[ei >= 0].view(np.int64)), np.sort(k[1::2]))      # the unpinned half left
+    assert np.array_equal(np.sort(ei[ei >= 0]), np.sort(idx[1::2])) and np.array_equal(np.sort(idx2[took]), np.sort(idx[1::2]))
+    assert np.array_equal(ek[ei < 0].view(np.int64), k2[~took]) and np.array_equal(-(ei[ei < 0] + 1), np.nonzero(~took)[0])
+    _, f, li = o.lookup_ovf(k[::2], np.zeros(pin.size, np.int64))
+    assert f.all() and np.array_equal(li, pin)
+    # A resident overflow key that comes again is an Assign on its slot (ACCUMULATE adds to its score) PROVIDED no
+    # unpinned entry sits in front of it in probe order -- the single-pass scan would take that one as a victim first and
+    # duplicate the key (kernels.cuh:755-791; the cache only inserts keys its lookup missed, so this does not arise there).
+    o.counter[o.counter_index(idx2[took], np.zeros(int(took.sum()), np.int64))] += 1
+    idx3, res3, so3, ev3 = o.insert_ovf(k[::2], np.zeros(pin.size, np.int64), np.full(pin.size, 10, np.uint64),
+                                        orc.POLICY_ACCUMULATE)
+    assert (res3 == 2).all() and np.array_equal(idx3, pin) and (so3 == 11).all() and ev3[0].size == 0
