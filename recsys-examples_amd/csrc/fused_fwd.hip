@@ -73,6 +73,8 @@ struct FusedArgs {
   int64_t nbu;
   int64_t* seg_out;               // [T+1] table ranges
   uint64_t* d_key; int32_t* d_tid; int32_t* d_cnt; int32_t* d_slot; int32_t* d_base;   // deferred (bucket full) keys
+  unsigned long long* tstat;      // [ceil(n/1024)] look-back words of the merged numbering kernel (zeroed by the probe)
+  int* hot_counters;              // hot-list header of the backward (cleared by the probe; nullable)
 };
 
 __device__ __forceinline__ void store_digest(uint8_t* p, uint8_t d) {
@@ -217,8 +219,14 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     s_tbo[t] = a.tbo[t];
     if (t < T) { s_tptr[t] = a.table_ptrs[t]; s_rowb[t] = (int)a.table_value_dims[t] * a.elem_bytes; }
   }
-  if (blockIdx.x == 0 && kTrain)
+  if (blockIdx.x == 0 && kTrain) {
     for (int64_t j = threadIdx.x; j <= a.nbu; j += THREADS) a.partial2[j] = 0;
+    if (a.hot_counters && threadIdx.x < 3) a.hot_counters[2 * threadIdx.x] = 0;   // n_hot, n_tasks, n_wave
+  }
+  if (kTrain && a.tstat && threadIdx.x < HALVES) {
+    const int64_t pt = (int64_t)blockIdx.x * HALVES + threadIdx.x;
+    if (pt * 1024 < a.n) a.tstat[pt] = 0ull;
+  }
   for (int s = threadIdx.x; s < LDS; s += THREADS) { s_tab[s] = -1; s_cnt[s] = 0; }
   if (threadIdx.x < HALVES) s_nrep[threadIdx.x] = 0;
   __syncthreads();
@@ -380,11 +388,10 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
 // bumps the top counter, the last group publishes the generation -- because same-address device atomics serialise at
 // ~40 ns each: 352 arrivals on ONE word (plus the pollers) cost ~50 us per barrier, 16 + 22 cost ~1.5 us.
 // hdr: [1] top counter, [3] generation, [8 + g] group counters; all monotonic within a launch, cleared by its last block.
-__device__ __forceinline__ void grid_sync(int* hdr, int k /* 1-based barrier number */) {
+__device__ __forceinline__ void grid_sync(int* hdr, int k /* 1-based barrier number */, int nblk) {
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence();
-    const int nblk = (int)gridDim.x;
     const int ngroups = (nblk + 15) >> 4;
     const int g = (int)blockIdx.x >> 4;
     const int gsize = nblk - (g << 4) < 16 ? nblk - (g << 4) : 16;
@@ -407,11 +414,11 @@ __device__ __forceinline__ void grid_sync_reset(int* hdr) {
   for (int g = 0; g < ngroups; ++g) hdr[8 + g] = 0;
 }
 
-__device__ __forceinline__ void evict_phase(const FusedArgs& a, int nd) {
+__device__ __forceinline__ void evict_phase(const FusedArgs& a, int nd, int nblk) {
   const int g = lane_id() & (G - 1);
   const int gpb = blockDim.x / G;
   const int C = (int)a.t.C;
-  for (int e0 = blockIdx.x * gpb; e0 < nd; e0 += gridDim.x * gpb) {
+  for (int e0 = blockIdx.x * gpb; e0 < nd; e0 += nblk * gpb) {
     const int e = e0 + threadIdx.x / G;
     const bool act = e < nd;
     const uint64_t key = act ? a.d_key[e] : kEmptyKey;
@@ -515,8 +522,8 @@ __device__ __forceinline__ void evict_phase(const FusedArgs& a, int nd) {
 }
 
 // the occurrences of the deferred keys learn their slot / rank / row address
-__device__ __forceinline__ void patch_phase(const FusedArgs& a) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void patch_phase(const FusedArgs& a, int nblk) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)nblk * blockDim.x) {
     const int s = a.occ_slot[i];
     if (s <= -2) {
       const int e = -(s + 2);
@@ -540,9 +547,9 @@ __global__ void __launch_bounds__(256) fused_evict_kernel(FusedArgs a) {
   int nd = __hip_atomic_load(&a.hdr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (nd == 0) return;          // steady state: one empty launch
   if ((int64_t)nd > a.n) nd = (int)a.n;
-  evict_phase(a, nd);
-  grid_sync(a.hdr, 1);
-  patch_phase(a);
+  evict_phase(a, nd, (int)gridDim.x);
+  grid_sync(a.hdr, 1, (int)gridDim.x);
+  patch_phase(a, (int)gridDim.x);
 }
 
 // ---- unique numbering: the occurrence with rank 0 represents its slot -------------------------------------------------
@@ -638,6 +645,215 @@ fused_emit_kernel(FusedArgs a, EmitOut o) {
     else if (p >= n && blockIdx.x == gridDim.x - 1) o.table_offsets[t] = pre + tot;
   }
   if (threadIdx.x < 2 && s_p2[threadIdx.x]) atomicAdd(&a.partial2[first_tile + threadIdx.x], s_p2[threadIdx.x]);
+}
+
+// ---- merged numbering kernel: deferred keys (if any) + unique numbering + CSR row pointers + hot-row registration --------
+// One launch instead of three (evict, emit, scan_down).  Unique ids need only the per-tile representative counts the probe
+// left in `partial` (every block sums its predecessors itself).  The row pointers are a second scan in unique order --
+// over the occurrence counts, which are final only now -- and that one is chained across blocks by decoupled look-back:
+// a block publishes the sum of its tile, then its inclusive prefix, in ONE 64-bit word per tile (status in the top bits)
+// with device-scope stores; successors poll those words.  Nothing but the word itself crosses blocks, so no fence (= no
+// L2 write-back) is involved; blocks are dispatched in index order, so a predecessor is always resident or finished.
+// Deferred keys: the first `resident` blocks run the eviction and patch phases between two barriers of their own while
+// the later blocks wait for the release flag -- the steady state (no deferred key) takes none of it.
+constexpr unsigned long long kStatAgg = 1ull << 62, kStatPre = 2ull << 62, kStatMask = 3ull << 62;
+
+__device__ __forceinline__ unsigned long long stat_load(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void stat_store(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// exclusive prefix of the tile sums in front of tile `t` (whose own sum is already published); called by the whole
+// block, every thread returns the result.
+// All predecessors of a round (256 per round) are polled at once -- one memory round trip for batches up to 256 K keys --
+// and the walk stops at the nearest tile that already knows its inclusive prefix.
+__device__ __forceinline__ int lookback_prefix(unsigned long long* tstat, int t, int my_sum) {
+  __shared__ int s_first, s_sum;
+  if (t == 0) return 0;   // (the caller published the tile's sum -- tile 0: as its inclusive prefix -- earlier)
+  int run = 0;
+  for (int pos = t - 1;; pos -= kScanThreads) {
+    if (threadIdx.x == 0) { s_first = kScanThreads; s_sum = 0; }
+    __syncthreads();
+    const int idx = pos - (int)threadIdx.x;
+    unsigned long long v = idx >= 0 ? stat_load(tstat + idx) : kStatPre;   // in front of tile 0: prefix 0
+    while ((v & kStatMask) == 0) { __builtin_amdgcn_s_sleep(1); v = stat_load(tstat + idx); }
+    if ((v & kStatMask) == kStatPre) atomicMin(&s_first, (int)threadIdx.x);
+    __syncthreads();
+    const int first = s_first;      // nearest predecessor of this round that knows its inclusive prefix (256: none)
+    int val = (int)threadIdx.x <= first ? (int)(unsigned)(v & 0xFFFFFFFFull) : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off, 64);
+    if (lane_id() == 0 && val) atomicAdd(&s_sum, val);
+    __syncthreads();
+    run += s_sum;
+    __syncthreads();
+    if (first < kScanThreads) break;
+  }
+  if (threadIdx.x == 0) stat_store(tstat + t, kStatPre | (unsigned)(run + my_sum));
+  return run;
+}
+
+template <bool kSelf>
+__global__ void __launch_bounds__(kScanThreads)
+fused_mid_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, bool build_hot, int resident) {
+  __shared__ int s_ex[kScanTile + 1];       // exclusive representative count in front of every item of the tile
+  __shared__ int64_t s_seg[kFusedMaxT + 1];
+  __shared__ int s_hbase[3];
+  const int64_t tile0 = (int64_t)blockIdx.x * kScanTile;
+  const int64_t n = a.n;
+  const int T = a.T;
+  int sl[kScanItems], rk[kScanItems], f[kScanItems], oc[kScanItems];
+  uint64_t ky[kScanItems];
+  int64_t ad[kScanItems];
+  // every load is unconditional (clamped) and issued up front, in front of the deferred-key count as well: in the steady
+  // state (no deferred key) nothing changes them any more, otherwise they are read again behind the eviction
+  auto load_items = [&]() {
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      const int64_t i = tile0 + threadIdx.x * kScanItems + k;
+      const int64_t ic = i < n ? i : n - 1;
+      sl[k] = a.occ_slot[ic];
+      rk[k] = a.csr_rank[ic];
+      ky[k] = a.keys[ic];
+      ad[k] = a.occ_addr[ic];
+    }
+  };
+  load_items();
+  // representatives of the earlier tiles (self_prefix of scan_dev.h, its loads hoisted to the top of the chain)
+  int pre_part = 0;
+  if (kSelf) for (int j = threadIdx.x; j < (int)blockIdx.x; j += kScanThreads) pre_part += a.partial[j];
+  else pre_part = a.partial[blockIdx.x];
+  for (int t = threadIdx.x; t <= T; t += kScanThreads) s_seg[t] = a.seg_out[t];
+  // ---- deferred keys (bucket without a free slot) ----
+  int nd = __hip_atomic_load(&a.hdr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (nd > 0) {
+    if (!a.timer) a.timer = device_clock();
+    if ((int64_t)nd > a.n) nd = (int)a.n;
+    const int R = (int)gridDim.x < resident ? (int)gridDim.x : resident;
+    if ((int)blockIdx.x < R) {
+      evict_phase(a, nd, R);
+      grid_sync(a.hdr, 1, R);
+      patch_phase(a, R);
+      grid_sync(a.hdr, 2, R);
+      if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&a.hdr[4], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(&a.hdr[4], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(4);
+        __threadfence();
+      }
+      __syncthreads();
+    }
+    load_items();
+    pre_part = 0;   // (patch_phase adds the deferred keys' representatives to `partial`)
+    if (kSelf) for (int j = threadIdx.x; j < (int)blockIdx.x; j += kScanThreads) pre_part += a.partial[j];
+    else pre_part = a.partial[blockIdx.x];
+  }
+  // ---- unique numbering: the occurrence with rank 0 represents its slot ----
+  int c = 0, cs = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const int64_t i = tile0 + threadIdx.x * kScanItems + k;
+    f[k] = (i < n) && (rk[k] == 0) && (sl[k] >= 0);
+    oc[k] = a.occ[sl[k] >= 0 ? sl[k] : 0];
+    c += f[k];
+  }
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) cs += f[k] ? oc[k] : 0;
+  // the tile's occurrence sum goes out first: the successors' look-back waits for it
+  int tot, tot2 = 0;
+  int ex2 = ptr ? block_excl_scan(cs, tot2) : 0;     // occurrences of the tile's earlier representatives
+  if (ptr && threadIdx.x == 0)
+    stat_store(a.tstat + blockIdx.x, (blockIdx.x == 0 ? kStatPre : kStatAgg) | (unsigned)tot2);
+  int pre = pre_part;
+  if (kSelf) block_excl_scan(pre_part, pre);
+  int ex = block_excl_scan(c, tot) + pre;
+  const int ex_first = ex;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    s_ex[threadIdx.x * kScanItems + k] = ex;
+    if (f[k]) {
+      const int s = sl[k];
+      a.occ[s] = 0;
+      a.uidmap[s] = ex;
+      o.unique_keys[ex] = ky[k];
+      o.csr_cnt[ex] = oc[k];
+      if (o.freq) o.freq[ex] = oc[k];
+      o.row_addr[ex] = ad[k];
+      int ti = 0;
+      if (T > 1) {
+        const int64_t i = tile0 + threadIdx.x * kScanItems + k;
+        int lo = 0, hi = T + 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_seg[mid] <= i) lo = mid + 1; else hi = mid; }
+        ti = lo - 1 < 0 ? 0 : (lo - 1 >= T ? T - 1 : lo - 1);
+      }
+      if (o.table_ids) o.table_ids[ex] = ti;
+      o.slots[ex] = s < a.S ? (int64_t)s - a.tbo[ti] * a.t.C : -1;
+      ++ex;
+    }
+  }
+  if (threadIdx.x == kScanThreads - 1) s_ex[kScanTile] = ex;
+  __syncthreads();
+  // unique offsets of the tables whose first key lies in this tile (or behind the batch: the last tile writes those)
+  for (int t = threadIdx.x; t <= T; t += kScanThreads) {
+    const int64_t p = s_seg[t];
+    if (p >= tile0 && p < tile0 + kScanTile && p < n) o.table_offsets[t] = s_ex[p - tile0];
+    else if (p >= n && blockIdx.x == gridDim.x - 1) o.table_offsets[t] = pre + tot;
+  }
+  if (!ptr) return;
+  // ---- row pointers of the backward's CSR + hot rows (scan_down_kernel's scheme: ONE atomic triple per block) ----
+  int h_ex = 0, t_ex = 0, w_ex = 0;
+  if (build_hot) {
+    int nh_local = 0, nt_local = 0, nw_local = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      if (!f[k]) continue;
+      if (oc[k] > hot.khot && oc[k] <= hot.kwave) ++nw_local;
+      else if (oc[k] > hot.khot) { ++nh_local; nt_local += (oc[k] + hot.kchunk - 1) / hot.kchunk; }
+    }
+    int th, tt, tw;
+    h_ex = block_excl_scan(nh_local, th);
+    t_ex = block_excl_scan(nt_local, tt);
+    w_ex = block_excl_scan(nw_local, tw);
+    if (threadIdx.x == 0) {
+      s_hbase[0] = th ? atomicAdd(hot.n_hot, th) : 0;
+      s_hbase[1] = tt ? atomicAdd(hot.n_tasks, tt) : 0;
+      s_hbase[2] = tw ? atomicAdd(hot.n_wave, tw) : 0;
+    }
+    __syncthreads();
+    h_ex += s_hbase[0];
+    t_ex += s_hbase[1];
+    w_ex += s_hbase[2];
+  }
+  const int p2 = lookback_prefix(a.tstat, (int)blockIdx.x, tot2);
+  ex2 += p2;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { ptr[pre + tot] = p2 + tot2; *o.total = p2 + tot2; }
+  ex = ex_first;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (!f[k]) continue;
+    ptr[ex] = ex2;
+    if (build_hot && oc[k] > hot.khot && oc[k] <= hot.kwave) {
+      const int w = w_ex++;
+      if (w < hot.max_hot) { hot.wave_u[w] = ex; hot.wave_lo[w] = ex2; hot.wave_cnt[w] = oc[k]; }
+    } else if (build_hot && oc[k] > hot.khot) {
+      const int nch = (oc[k] + hot.kchunk - 1) / hot.kchunk;
+      const int h = h_ex++, t0 = t_ex;
+      t_ex += nch;
+      if (h < hot.max_hot && t0 + nch <= hot.max_tasks) {   // tasks are written out by csr_scatter_kernel
+        hot.hot_done[h] = 0;
+        hot.hot_nchunks[h] = nch;
+        hot.hot_u[h] = ex;
+        hot.hot_lo[h] = ex2;
+        hot.hot_cnt[h] = oc[k];
+        hot.hot_t0[h] = t0;
+      }
+    }
+    ex2 += oc[k];
+    ++ex;
+  }
 }
 
 // exclusive scan of the per-tile representative counts when there are too many tiles for every block to sum its
@@ -761,7 +977,7 @@ static inline int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
 int64_t mi355_demb_forward_fused_workspace_bytes(int64_t n, int64_t num_tables) {
   const int64_t nt = (n + 1023) / 1024 + 2, nbu = (n + 1) / 1024 + 3;
   return al256(8 * (num_tables + 1)) + al256(8 * n) /*unique keys*/ + al256(8 * n) /*occ_addr*/ + al256(4 * n) /*occ_slot*/ +
-         al256(4 * nt) + al256(4 * nbu) + 256 /*total*/ + al256(8 * n) + 4 * al256(4 * n) /*deferred*/ + 256;
+         al256(4 * nt) + al256(4 * nbu) + 256 /*total*/ + al256(8 * n) + 4 * al256(4 * n) /*deferred*/ + al256(8 * nt) /*look-back*/ + 256;
 }
 
 // The fused forward (see the header of this file).  Persisted outputs as mi355_demb_forward; in eval mode (train == 0)
@@ -824,7 +1040,22 @@ int mi355_demb_forward_fused(
   a.d_cnt = (int32_t*)w; w += al256(4 * n);
   a.d_slot = (int32_t*)w; w += al256(4 * n);
   a.d_base = (int32_t*)w; w += al256(4 * n);
+  a.tstat = (unsigned long long*)w; w += al256(8 * nt);
   a.csr_rank = csr_rank;
+  // backward workspace (row pointers, CSR, hot lists) -- carved before the probe launch, which clears the hot-list header
+  int32_t* bptr = nullptr; int32_t* bcsr = nullptr; void* hot_ws = nullptr; int64_t hot_bytes_ = 0;
+  a.hot_counters = nullptr;
+  if (train && backward_workspace) {
+    MI355_CHECK_ARG(backward_workspace_bytes >= mi355_demb_backward_workspace_bytes(n, emb_dim), "backward workspace too small");
+    uint8_t* bw = (uint8_t*)backward_workspace;
+    bptr = (int32_t*)bw; bw += al256(4 * (n + 1));
+    bcsr = (int32_t*)bw; bw += al256(4 * n);
+    bw += mi355_group_by_unique_workspace_bytes(n, n);
+    hot_ws = bw; hot_bytes_ = mi355_backward_workspace_bytes(n, emb_dim);
+    a.hot_counters = (int*)hot_ws;
+  }
+  static const int mid_env = getenv("MI355_FUSED_MID") ? atoi(getenv("MI355_FUSED_MID")) : 1;
+  const bool merged = mid_env != 0;   // 0: the separate evict / emit / scan launches (A/B only)
   if (train) MI355_CHECK_ARG(reverse_indices && unique_offsets && slots && row_addr && csr_cnt && csr_rank, "persisted outputs required in train mode");
   if (n > 0) {
     RoctxRange rr("op:fused_index(segmented_unique+storage_find+storage_insert+initializer)");
@@ -848,7 +1079,7 @@ int mi355_demb_forward_fused(
     }
 #undef LAUNCH_PROBE
     MI355_LAUNCH_CHECK();
-    if (train) {
+    if (train && !merged) {
       static int ncu = 0;
       if (!ncu) {
         int dev = 0;
@@ -888,18 +1119,25 @@ int mi355_demb_forward_fused(
     o.unique_keys = unique_keys; o.table_offsets = unique_offsets; o.table_ids = table_ids; o.slots = slots;
     o.row_addr = row_addr; o.freq = freq; o.csr_cnt = csr_cnt; o.total = total + 8; o.hot_counters = nullptr;
     const int64_t* nu_dev = unique_offsets + num_tables;
-    uint8_t* bw = (uint8_t*)backward_workspace;
-    int32_t* bptr = nullptr; int32_t* bcsr = nullptr; void* hot_ws = nullptr; int64_t hot_bytes_ = 0;
-    if (backward_workspace) {
-      MI355_CHECK_ARG(backward_workspace_bytes >= mi355_demb_backward_workspace_bytes(n, emb_dim), "backward workspace too small");
-      bptr = (int32_t*)bw; bw += al256(4 * (n + 1));
-      bcsr = (int32_t*)bw; bw += al256(4 * n);
-      bw += mi355_group_by_unique_workspace_bytes(n, n);
-      hot_ws = bw; hot_bytes_ = mi355_backward_workspace_bytes(n, emb_dim);
-      o.hot_counters = (int*)hot_ws;
-    }
+    if (!merged) o.hot_counters = (int*)hot_ws;   // (the merged path clears them in the probe kernel)
     const int64_t ntile = ceil_div(n, kScanTile);
-    if (ntile <= kSelfPrefixMaxTiles) {
+    if (merged) {
+      static int ncu2 = 0;
+      if (!ncu2) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu2 = prop.multiProcessorCount;
+        if (ncu2 <= 0) ncu2 = 64;
+      }
+      HotList hot{};
+      if (hot_ws) hot = hot_carve(hot_ws, n, emb_dim);
+      if (ntile <= kSelfPrefixMaxTiles) {
+        hipLaunchKernelGGL(fused_mid_kernel<true>, dim3((unsigned)ntile), dim3(kScanThreads), 0, cs, a, o, bptr, hot, hot_ws != nullptr, ncu2);
+      } else {
+        hipLaunchKernelGGL(fused_scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, cs, a.partial, ntile);
+        hipLaunchKernelGGL(fused_mid_kernel<false>, dim3((unsigned)ntile), dim3(kScanThreads), 0, cs, a, o, bptr, hot, hot_ws != nullptr, ncu2);
+      }
+    } else if (ntile <= kSelfPrefixMaxTiles) {
       hipLaunchKernelGGL(fused_emit_kernel<true>, dim3((unsigned)ntile), dim3(kScanThreads), 0, cs, a, o);
     } else {
       hipLaunchKernelGGL(fused_scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, cs, a.partial, ntile);
@@ -907,7 +1145,8 @@ int mi355_demb_forward_fused(
     }
     MI355_LAUNCH_CHECK();
     STEP(mi355i_csr_from_slots(csr_cnt, csr_rank, a.occ_slot, a.uidmap, reverse_indices, n, combiner >= 0 ? offsets : nullptr,
-                               num_bags, nu_dev, a.partial2, total, bptr, bcsr, hot_ws, hot_bytes_, emb_dim, cs));
+                               num_bags, nu_dev, a.partial2, total, bptr, bcsr, hot_ws, hot_bytes_, emb_dim, merged ? 1 : 0,
+                               merged ? a.hdr : nullptr, cs));
     if (pin) STEP(mi355_table_update_counter(counter, counter_numel, slots, n, nu_dev, 1, table_ids, table_bucket_offsets,
                                              bucket_capacity, cs));
     if (forked) {

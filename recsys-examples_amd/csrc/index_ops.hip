@@ -559,7 +559,11 @@ template <bool kSlot>
 __global__ void __launch_bounds__(256)
 csr_scatter_kernel(const int64_t* __restrict__ rev, const int* __restrict__ rank, int64_t n, const int64_t* __restrict__ offsets,
                    int64_t num_bags, const int* __restrict__ ptr, int* __restrict__ csr_src, HotList hot, bool build_hot,
-                   const int* __restrict__ slot, const int* __restrict__ uidmap, int64_t* __restrict__ rev_out) {
+                   const int* __restrict__ slot, const int* __restrict__ uidmap, int64_t* __restrict__ rev_out,
+                   int* __restrict__ hdr_reset = nullptr) {
+  // fused forward: the deferred-key count, barrier words and release flag of the table's aux header are cleared for the
+  // next step here, behind the numbering kernel that read them
+  if (hdr_reset && blockIdx.x == 0 && threadIdx.x < 64) hdr_reset[threadIdx.x] = 0;
   if (build_hot) {
     int nh = *hot.n_hot;
     nh = nh < hot.max_hot ? nh : hot.max_hot;
@@ -581,19 +585,51 @@ csr_scatter_kernel(const int64_t* __restrict__ rev, const int* __restrict__ rank
   __shared__ int s_wmax[4];
   const int64_t tile0 = (int64_t)blockIdx.x * kHistTile;
   const int64_t tile_end = tile0 + kHistTile < n ? tile0 + kHistTile : n;
+  // The kernel is a chain of dependent loads, so everything that can start at once does: the index hops of the keys
+  // (slot -> unique id -> row pointer; clamped, branch-free, the four chains of a thread overlap) are issued first and
+  // run under the bag search below, which itself is 64-ary (one probe per lane: 3 rounds for 64 K bags, not 16).
+  constexpr int NQ = kHistTile / 256;
+  int64_t r[NQ];
+  int rk[NQ], p[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    int64_t j = tile0 + q * 256 + threadIdx.x;
+    j = j < n ? j : n - 1;
+    if constexpr (kSlot) r[q] = slot[j]; else r[q] = rev[j];
+    rk[q] = rank[j];
+  }
   if (offsets) {
     for (int k = threadIdx.x; k < kHistTile; k += blockDim.x) s_bag[k] = -1;
-    if (threadIdx.x == 0 || threadIdx.x == 64) {
-      const int64_t key = threadIdx.x == 0 ? tile0 : tile_end - 1;
-      int lo = 0, hi = (int)num_bags;  // first idx with offsets[idx] > key
-      while (lo < hi) { int mid = (lo + hi) >> 1; if (offsets[mid] <= key) lo = mid + 1; else hi = mid; }
-      s_range[threadIdx.x == 0 ? 0 : 1] = lo - 1;
+    if (threadIdx.x < 128) {
+      const int64_t key = threadIdx.x < 64 ? tile0 : tile_end - 1;
+      int lo = 0, hi = (int)num_bags;  // first idx with offsets[idx] > key, in [lo, hi]
+      while (hi > lo) {
+        const int step = (hi - lo + 63) >> 6;
+        const int64_t pi = (int64_t)lo + (int64_t)(lane_id() + 1) * step - 1;
+        const bool gt = pi >= hi ? true : offsets[pi] > key;
+        const uint64_t gm = __ballot(gt);
+        if (!gm) { lo = hi; break; }                     // every probe <= key: the answer is the upper end
+        const int first = __ffsll((unsigned long long)gm) - 1;
+        const int nlo = first ? lo + first * step : lo;
+        const int64_t nhi = (int64_t)lo + (int64_t)(first + 1) * step - 1;
+        lo = nlo;
+        hi = nhi < hi ? (int)nhi : hi;
+      }
+      if (lane_id() == 0) s_range[threadIdx.x < 64 ? 0 : 1] = lo - 1;
     }
+  }
+  if constexpr (kSlot) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) r[q] = uidmap[r[q]];
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) p[q] = ptr[r[q]];
+  if (offsets) {
     __syncthreads();
     const int b_lo = s_range[0], b_hi = s_range[1];
     for (int b = b_lo + threadIdx.x; b <= b_hi; b += blockDim.x) {
       const int64_t o0 = offsets[b], o1 = offsets[b + 1];
-      if (o1 > o0) { const int64_t p = o0 > tile0 ? o0 - tile0 : 0; if (p < kHistTile) s_bag[p] = b; }
+      if (o1 > o0) { const int64_t pp = o0 > tile0 ? o0 - tile0 : 0; if (pp < kHistTile) s_bag[pp] = b; }
     }
     __syncthreads();
     int v[4];
@@ -614,24 +650,6 @@ csr_scatter_kernel(const int64_t* __restrict__ rev, const int* __restrict__ rank
     for (int k = 0; k < 4; ++k) s_bag[threadIdx.x * 4 + k] = v[k] > prev ? v[k] : prev;
     __syncthreads();
   }
-  // branch-free index hops (clamped), all reverse indices first, then all row pointers: the four chains of a thread
-  // overlap instead of running one after the other behind a predicated branch each
-  constexpr int NQ = kHistTile / 256;
-  int64_t r[NQ];
-  int rk[NQ], p[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    int64_t j = tile0 + q * 256 + threadIdx.x;
-    j = j < n ? j : n - 1;
-    if constexpr (kSlot) r[q] = slot[j]; else r[q] = rev[j];
-    rk[q] = rank[j];
-  }
-  if constexpr (kSlot) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) r[q] = uidmap[r[q]];
-  }
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) p[q] = ptr[r[q]];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int64_t j = tile0 + q * 256 + threadIdx.x;
@@ -643,7 +661,9 @@ csr_scatter_kernel(const int64_t* __restrict__ rev, const int* __restrict__ rank
 }
 
 __global__ void __launch_bounds__(256)
-rev_from_slots_kernel(const int* __restrict__ slot, const int* __restrict__ uidmap, int64_t n, int64_t* __restrict__ rev) {
+rev_from_slots_kernel(const int* __restrict__ slot, const int* __restrict__ uidmap, int64_t n, int64_t* __restrict__ rev,
+                      int* __restrict__ hdr_reset = nullptr) {
+  if (hdr_reset && blockIdx.x == 0 && threadIdx.x < 64) hdr_reset[threadIdx.x] = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) rev[i] = uidmap[slot[i]];
 }
 
@@ -1217,7 +1237,7 @@ int mi355_group_by_unique_csr(const int32_t* csr_cnt, const int32_t* csr_rank, c
 int mi355i_csr_from_slots(const int32_t* csr_cnt, const int32_t* csr_rank, const int32_t* occ_slot, const int32_t* uidmap,
                           int64_t* reverse_indices, int64_t n, const int64_t* offsets, int64_t num_bags, const int64_t* nu_dev,
                           const int32_t* partial2, int32_t* total, int32_t* ptr, int32_t* csr_src, void* hot_workspace,
-                          int64_t hot_workspace_bytes, int64_t dim, hipStream_t stream) {
+                          int64_t hot_workspace_bytes, int64_t dim, int ptr_ready, int32_t* hdr_reset, hipStream_t stream) {
   MI355_CHECK_ARG(n < 0x7fffffffLL, "n must be < 2^31");
   if (n == 0) return MI355_OK;
   const int64_t nbu = ceil_div(n + 1, kScanTile);
@@ -1227,7 +1247,9 @@ int mi355i_csr_from_slots(const int32_t* csr_cnt, const int32_t* csr_rank, const
     hot = hot_carve(hot_workspace, n, dim);
   }
   if (ptr) {
-    if (nbu <= kSelfPrefixMaxTiles) {
+    if (ptr_ready) {
+      // the merged numbering kernel of the fused forward already wrote the row pointers and registered the hot rows
+    } else if (nbu <= kSelfPrefixMaxTiles) {
       hipLaunchKernelGGL(scan_down_kernel<true>, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, csr_cnt, n, nu_dev, partial2, total, ptr,
                          hot, hot_workspace != nullptr);
     } else {
@@ -1236,9 +1258,11 @@ int mi355i_csr_from_slots(const int32_t* csr_cnt, const int32_t* csr_rank, const
                          hot, hot_workspace != nullptr);
     }
     hipLaunchKernelGGL(csr_scatter_kernel<true>, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, (const int64_t*)nullptr,
-                       csr_rank, n, offsets, num_bags, ptr, csr_src, hot, hot_workspace != nullptr, occ_slot, uidmap, reverse_indices);
+                       csr_rank, n, offsets, num_bags, ptr, csr_src, hot, hot_workspace != nullptr, occ_slot, uidmap, reverse_indices,
+                       hdr_reset);
   } else {
-    hipLaunchKernelGGL(rev_from_slots_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, occ_slot, uidmap, n, reverse_indices);
+    hipLaunchKernelGGL(rev_from_slots_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, occ_slot, uidmap, n, reverse_indices,
+                       hdr_reset);
   }
   MI355_LAUNCH_CHECK();
   return MI355_OK;
