@@ -45,8 +45,8 @@ struct FusedArgs {
   int32_t* bucket_sizes;
   const int32_t* counter;         // pin counters per slot (nullable)
   int32_t* hdr;                   // aux header
-  int32_t* occ;                   // [S+1] occurrences of the slot in this batch (last entry: keys without a slot)
-  int32_t* uidmap;                // [S+1] unique id of the slot
+  int32_t* occ;                   // [S+1] pairs {occurrences of the slot in this batch, unique id of the slot}: occ[2 s], occ[2 s + 1]
+                                  // (one 8-byte line-local pair per slot; the last entry serves keys without a slot)
   int32_t* locks;                 // [num_buckets] eviction lock
   int64_t S;                      // total slots
   const int64_t* table_ptrs;
@@ -305,6 +305,8 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     const int cnt = s_cnt[hh[q]];
     int gslot = (int)a.S, base = 0;     // default: no slot
     bool defer = false;
+    uint64_t* found_sc = nullptr;
+    const bool idem = !a.use_count && (a.find_policy == kAssign || a.find_policy == kGlobalTimer);
     if (bq[q] >= 0) {
       const int64_t b = bq[q];
       bool inserted = false;
@@ -314,8 +316,9 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
       else slot = thread_probe<kTrain>(a, b, key, hq[q], cnt, inserted);
       if (slot >= 0) {
         gslot = (int)(b * a.t.C + slot);
-        if (!inserted) score_found(a, a.t.scores(b) + (int64_t)slot * a.t.ns, cnt);
-        else { s_t[li] = (uint16_t)(t | 0x8000); s_gs[li] = gslot; }
+        if (inserted) { s_t[li] = (uint16_t)(t | 0x8000); s_gs[li] = gslot; }
+        else if (!idem) score_found(a, a.t.scores(b) + (int64_t)slot * a.t.ns, cnt);
+        else found_sc = a.t.scores(b) + (int64_t)slot * a.t.ns;
       } else if (slot == -2) {
         defer = true;
       }
@@ -326,8 +329,12 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
         a.d_key[e] = key; a.d_tid[e] = t; a.d_cnt[e] = cnt;
         gslot = -(e + 2);
       } else {
-        base = (a.dbg & 1) ? 0 : atomicAdd(&a.occ[gslot], cnt);
+        base = (a.dbg & 1) ? 0 : atomicAdd(&a.occ[2 * (int64_t)gslot], cnt);
+        // Assign / timer scores are the same value from every tile: only the row's representative writes it
+        if (found_sc && base == 0) score_found(a, found_sc, cnt);
       }
+    } else if (found_sc) {
+      score_found(a, found_sc, cnt);
     }
     s_tab[hh[q]] = gslot;
     s_cnt[hh[q]] = base;
@@ -455,7 +462,7 @@ __device__ __forceinline__ void evict_phase(const FusedArgs& a, int nd, int nblk
             int bslot = -1;
             const uint64_t* sc = a.t.scores(L.bucket);
             const int32_t* pin = a.counter ? a.counter + L.bucket * a.t.C : nullptr;
-            const int32_t* oc = a.occ + L.bucket * a.t.C;
+            const int32_t* oc = a.occ + 2 * (L.bucket * a.t.C);
             for (int s0 = 2 * g; s0 < C; s0 += 2 * G) {
 #pragma unroll
               for (int u = 0; u < 2; ++u) {
@@ -465,7 +472,7 @@ __device__ __forceinline__ void evict_phase(const FusedArgs& a, int nd, int nblk
                   const uint64_t k = ald64(ks + s);
                   if (k == kLockedKey || k == kEmptyKey) continue;
                   if (pin && __hip_atomic_load(pin + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;
-                  if (__hip_atomic_load(oc + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;  // used by this batch
+                  if (__hip_atomic_load(oc + 2 * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;  // used by this batch
                   best = v; bslot = s; bkey = k;
                 }
               }
@@ -504,7 +511,7 @@ __device__ __forceinline__ void evict_phase(const FusedArgs& a, int nd, int nblk
           if (g == 0) {
             // count the key's occurrences BEFORE the lock is released: occ > 0 is what protects the slot from the next
             // eviction in this bucket
-            if (slot >= 0) { a.d_slot[e] = gslot; a.d_base[e] = atomicAdd(&a.occ[gslot], cnt); }
+            if (slot >= 0) { a.d_slot[e] = gslot; a.d_base[e] = atomicAdd(&a.occ[2 * (int64_t)gslot], cnt); }
             __threadfence();
             __hip_atomic_store(&a.locks[L.bucket], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
           }
@@ -516,7 +523,7 @@ __device__ __forceinline__ void evict_phase(const FusedArgs& a, int nd, int nblk
     }
     if (act && g == 0 && gslot == (int)a.S) {   // no slot could be had: the key is served without a row this step
       a.d_slot[e] = gslot;
-      a.d_base[e] = atomicAdd(&a.occ[gslot], cnt);
+      a.d_base[e] = atomicAdd(&a.occ[2 * (int64_t)gslot], cnt);
     }
   }
 }
@@ -595,7 +602,7 @@ fused_emit_kernel(FusedArgs a, EmitOut o) {
   for (int k = 0; k < kScanItems; ++k) {
     const int64_t i = tile0 + threadIdx.x * kScanItems + k;
     f[k] = (i < n) && (rk[k] == 0) && (sl[k] >= 0);
-    oc[k] = a.occ[sl[k] >= 0 ? sl[k] : 0];
+    oc[k] = a.occ[2 * (int64_t)(sl[k] >= 0 ? sl[k] : 0)];
     c += f[k];
   }
   int tot;
@@ -614,8 +621,7 @@ fused_emit_kernel(FusedArgs a, EmitOut o) {
     s_ex[threadIdx.x * kScanItems + k] = ex;
     if (f[k]) {
       const int s = sl[k];
-      a.occ[s] = 0;
-      a.uidmap[s] = ex;
+      *reinterpret_cast<int2*>(a.occ + 2 * (int64_t)s) = make_int2(0, ex);   // counter cleared, unique id set: one store
       o.unique_keys[ex] = ky[k];
       o.csr_cnt[ex] = oc[k];
       if (o.freq) o.freq[ex] = oc[k];
@@ -751,13 +757,14 @@ fused_mid_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, boo
     if (kSelf) for (int j = threadIdx.x; j < (int)blockIdx.x; j += kScanThreads) pre_part += a.partial[j];
     else pre_part = a.partial[blockIdx.x];
   }
+  if (a.dbg & 32) { if (sl[0] == -77 && rk[1] == -5 && ky[2] == 1 && ad[3] == 1 && pre_part == -1) a.occ[1] = 0; return; }
   // ---- unique numbering: the occurrence with rank 0 represents its slot ----
   int c = 0, cs = 0;
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
     const int64_t i = tile0 + threadIdx.x * kScanItems + k;
     f[k] = (i < n) && (rk[k] == 0) && (sl[k] >= 0);
-    oc[k] = a.occ[sl[k] >= 0 ? sl[k] : 0];
+    oc[k] = a.occ[2 * (int64_t)(f[k] ? sl[k] : 0)];     // random 4-byte gathers: only the representatives' (the others hit one line)
     c += f[k];
   }
 #pragma unroll
@@ -771,13 +778,13 @@ fused_mid_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, boo
   if (kSelf) block_excl_scan(pre_part, pre);
   int ex = block_excl_scan(c, tot) + pre;
   const int ex_first = ex;
+  if (a.dbg & 64) { if (ex == -12345 && ex2 == -3) a.occ[1] = 0; return; }
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
     s_ex[threadIdx.x * kScanItems + k] = ex;
     if (f[k]) {
       const int s = sl[k];
-      a.occ[s] = 0;
-      a.uidmap[s] = ex;
+      *reinterpret_cast<int2*>(a.occ + 2 * (int64_t)s) = make_int2(0, ex);   // counter cleared, unique id set: one store
       o.unique_keys[ex] = ky[k];
       o.csr_cnt[ex] = oc[k];
       if (o.freq) o.freq[ex] = oc[k];
@@ -802,7 +809,7 @@ fused_mid_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, boo
     if (p >= tile0 && p < tile0 + kScanTile && p < n) o.table_offsets[t] = s_ex[p - tile0];
     else if (p >= n && blockIdx.x == gridDim.x - 1) o.table_offsets[t] = pre + tot;
   }
-  if (!ptr) return;
+  if (!ptr || (a.dbg & 128)) return;
   // ---- row pointers of the backward's CSR + hot rows (scan_down_kernel's scheme: ONE atomic triple per block) ----
   int h_ex = 0, t_ex = 0, w_ex = 0;
   if (build_hot) {
@@ -813,19 +820,21 @@ fused_mid_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, boo
       if (oc[k] > hot.khot && oc[k] <= hot.kwave) ++nw_local;
       else if (oc[k] > hot.khot) { ++nh_local; nt_local += (oc[k] + hot.kchunk - 1) / hot.kchunk; }
     }
-    int th, tt, tw;
-    h_ex = block_excl_scan(nh_local, th);
-    t_ex = block_excl_scan(nt_local, tt);
-    w_ex = block_excl_scan(nw_local, tw);
-    if (threadIdx.x == 0) {
-      s_hbase[0] = th ? atomicAdd(hot.n_hot, th) : 0;
-      s_hbase[1] = tt ? atomicAdd(hot.n_tasks, tt) : 0;
-      s_hbase[2] = tw ? atomicAdd(hot.n_wave, tw) : 0;
+    if (__syncthreads_or(nh_local | nw_local)) {   // (most tiles hold no hot row: the Zipf head is numbered by the first ones)
+      int th, tt, tw;
+      h_ex = block_excl_scan(nh_local, th);
+      t_ex = block_excl_scan(nt_local, tt);
+      w_ex = block_excl_scan(nw_local, tw);
+      if (threadIdx.x == 0) {
+        s_hbase[0] = th ? atomicAdd(hot.n_hot, th) : 0;
+        s_hbase[1] = tt ? atomicAdd(hot.n_tasks, tt) : 0;
+        s_hbase[2] = tw ? atomicAdd(hot.n_wave, tw) : 0;
+      }
+      __syncthreads();
+      h_ex += s_hbase[0];
+      t_ex += s_hbase[1];
+      w_ex += s_hbase[2];
     }
-    __syncthreads();
-    h_ex += s_hbase[0];
-    t_ex += s_hbase[1];
-    w_ex += s_hbase[2];
   }
   const int p2 = lookback_prefix(a.tstat, (int)blockIdx.x, tot2);
   ex2 += p2;
@@ -1018,7 +1027,7 @@ int mi355_demb_forward_fused(
   FusedArgs a;
   a.t = make_table(storage, bucket_capacity, num_scores);
   a.tbo = table_bucket_offsets; a.bucket_sizes = bucket_sizes; a.counter = counter;
-  a.hdr = aux; a.occ = aux + kAuxHdr; a.uidmap = a.occ + (S + 1); a.locks = a.uidmap + (S + 1); a.S = S;
+  a.hdr = aux; a.occ = aux + kAuxHdr; a.locks = a.occ + 2 * (S + 1); a.S = S;
   a.table_ptrs = table_ptrs; a.table_value_dims = table_value_dims; a.table_emb_dims = table_emb_dims;
   a.elem_bytes = value_dtype == 0 ? 4 : 2; a.value_dtype = value_dtype;
   a.keys = (const uint64_t*)keys; a.n = n; a.offsets = offsets; a.feature_offsets = feature_offsets; a.num_bags = num_bags; a.batch = batch_size;
@@ -1144,7 +1153,8 @@ int mi355_demb_forward_fused(
       hipLaunchKernelGGL(fused_emit_kernel<false>, dim3((unsigned)ntile), dim3(kScanThreads), 0, cs, a, o);
     }
     MI355_LAUNCH_CHECK();
-    STEP(mi355i_csr_from_slots(csr_cnt, csr_rank, a.occ_slot, a.uidmap, reverse_indices, n, combiner >= 0 ? offsets : nullptr,
+    if (!(a.dbg & (32 | 64 | 128)))
+    STEP(mi355i_csr_from_slots(csr_cnt, csr_rank, a.occ_slot, a.occ + 1, reverse_indices, n, combiner >= 0 ? offsets : nullptr,
                                num_bags, nu_dev, a.partial2, total, bptr, bcsr, hot_ws, hot_bytes_, emb_dim, merged ? 1 : 0,
                                merged ? a.hdr : nullptr, cs));
     if (pin) STEP(mi355_table_update_counter(counter, counter_numel, slots, n, nu_dev, 1, table_ids, table_bucket_offsets,

@@ -554,7 +554,7 @@ csr_fill_kernel(const int64_t* __restrict__ rev, int64_t n, const int64_t* __res
 // pass 2 when the forward already ranked every occurrence inside its unique row (mi355_segmented_unique_csr):
 // csr_src[ptr[rev[j]] + rank[j]] = src id of key j.  No atomics, no LDS hash; the bag resolution and the hot-row task
 // expansion are those of csr_fill_kernel.
-// kSlot: the unique id of key j is uidmap[slot[j]] (fused forward, fused_fwd.hip) and is also written to rev_out[j].
+// kSlot: the unique id of key j is uidmap[2 * slot[j]] (fused forward, fused_fwd.hip: pairs per slot) and is also written to rev_out[j].
 template <bool kSlot>
 __global__ void __launch_bounds__(256)
 csr_scatter_kernel(const int64_t* __restrict__ rev, const int* __restrict__ rank, int64_t n, const int64_t* __restrict__ offsets,
@@ -620,7 +620,7 @@ csr_scatter_kernel(const int64_t* __restrict__ rev, const int* __restrict__ rank
   }
   if constexpr (kSlot) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) r[q] = uidmap[r[q]];
+    for (int q = 0; q < NQ; ++q) r[q] = uidmap[2 * r[q]];   // {counter, unique id} pairs per slot
   }
 #pragma unroll
   for (int q = 0; q < NQ; ++q) p[q] = ptr[r[q]];
@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(256)
 rev_from_slots_kernel(const int* __restrict__ slot, const int* __restrict__ uidmap, int64_t n, int64_t* __restrict__ rev,
                       int* __restrict__ hdr_reset = nullptr) {
   if (hdr_reset && blockIdx.x == 0 && threadIdx.x < 64) hdr_reset[threadIdx.x] = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) rev[i] = uidmap[slot[i]];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) rev[i] = uidmap[2 * (int64_t)slot[i]];
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -30,7 +30,8 @@ def _counters_clear(m):
     """header + per-slot occurrence counters of the fused forward are all zero between steps (the unique-id map behind
     them is scratch)"""
     torch.cuda.synchronize()
-    return int(m._fused_aux[: 64 + m.table.capacity_ + 1].abs().sum()) == 0
+    cap = m.table.capacity_   # aux = [hdr 64][{occ, uid} x (S + 1)][locks]: header and the occ halves must be zero between steps
+    return int(m._fused_aux[:64].abs().sum()) == 0 and int(m._fused_aux[64: 64 + 2 * (cap + 1): 2].abs().sum()) == 0
 
 
 def _batch(rng, F, B, hi, maxlen=6):
