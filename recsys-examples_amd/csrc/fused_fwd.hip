@@ -2,7 +2,7 @@
 // scored hash table with the tile's distinct keys, counts / ranks the occurrences of every table slot, inserts unseen keys
 // into free slots and initialises their rows -- the work of segmented_unique + table_lookup + table_insert + unlock +
 // init_rows + row_addresses of the unfused chain (five dedup launches, lookup, insert, unlock/init: 10 launches, ~120 us
-// at C2) in one launch.
+// at C2) in one launch (~35 us).
 //
 // Restates (reference, corelib/dynamicemb/): segmented_unique_cuda (src/unique_op.cu:484-714), table_lookup_kernel /
 // table_insert_kernel / table_unlock_kernel (src/table_operation/kernels.cuh:81-585), the first-touch initialisation and
@@ -14,13 +14,16 @@
 //    one atomicAdd per (tile, distinct key) pair; the value it returns ranks the tile's occurrences inside the row's
 //    list (the backward's CSR needs exactly that), and the occurrence that draws rank 0 is the row's representative.
 //    No scratch hash set, no clear pass, no separate lookup over the uniques.
-//  * The pooled gather takes the row address of every OCCURRENCE (written here), so it does not wait for the unique
-//    numbering at all: numbering (emit), scan and CSR scatter run on a side stream under the gather.
+//  * The pooled gather takes the row address of every OCCURRENCE (written here), so it does not depend on the unique
+//    numbering at all.
 //  * Unseen keys are inserted in place when their bucket has a free slot: CAS Empty -> Locked, digest, score, publish
 //    the key.  A prober that meets a Locked slot re-reads until the key is published, so two tiles inserting the same key
-//    agree on one slot.  Full buckets are deferred to ONE persistent kernel (early exit when the list is empty) that
+//    agree on one slot.  Full buckets are deferred to the head of the next kernel (skipped when the list is empty), which
 //    evicts the minimum score under a per-bucket lock; slots with occ > 0 (hit or inserted by THIS batch) and pinned
 //    slots are never candidates -- the reference's increment_counter / decrement_counter bracket comes for free.
+//  * ONE more kernel (fused_mid_kernel) numbers the uniques, scans the occurrence counts into the backward's CSR row
+//    pointers (decoupled look-back across its blocks) and registers the hot rows; csr_scatter_kernel then writes the
+//    CSR entries and the reverse indices.  Chain of a training forward: probe, numbering, scatter, gather.
 //  * Probing is one lane per key with 16-B digest vectors (the first vector resolves the probe at normal load factors):
 //    64 independent probes per wave in flight instead of 8 with the 8-lane groups of the per-op kernels.
 #include "common.h"
@@ -69,8 +72,6 @@ struct FusedArgs {
   int32_t* occ_slot;              // [n] global slot (S: none; <= -2: deferred entry -(e+2))
   int32_t* csr_rank;              // [n]
   int32_t* partial;               // [ceil(n/1024)] representatives per 1024 occurrences
-  int32_t* partial2;              // [ceil((n+1)/1024)+1] occurrences per 1024 uniques (zeroed here, filled by emit)
-  int64_t nbu;
   int64_t* seg_out;               // [T+1] table ranges
   uint64_t* d_key; int32_t* d_tid; int32_t* d_cnt; int32_t* d_slot; int32_t* d_base;   // deferred (bucket full) keys
   unsigned long long* tstat;      // [ceil(n/1024)] look-back words of the merged numbering kernel (zeroed by the probe)
@@ -220,7 +221,6 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     if (t < T) { s_tptr[t] = a.table_ptrs[t]; s_rowb[t] = (int)a.table_value_dims[t] * a.elem_bytes; }
   }
   if (blockIdx.x == 0 && kTrain) {
-    for (int64_t j = threadIdx.x; j <= a.nbu; j += THREADS) a.partial2[j] = 0;
     if (a.hot_counters && threadIdx.x < 3) a.hot_counters[2 * threadIdx.x] = 0;   // n_hot, n_tasks, n_wave
   }
   if (kTrain && a.tstat && threadIdx.x < HALVES) {
@@ -549,16 +549,6 @@ __device__ __forceinline__ void patch_phase(const FusedArgs& a, int nblk) {
   }
 }
 
-__global__ void __launch_bounds__(256) fused_evict_kernel(FusedArgs a) {
-  if (!a.timer) a.timer = device_clock();
-  int nd = __hip_atomic_load(&a.hdr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (nd == 0) return;          // steady state: one empty launch
-  if ((int64_t)nd > a.n) nd = (int)a.n;
-  evict_phase(a, nd, (int)gridDim.x);
-  grid_sync(a.hdr, 1, (int)gridDim.x);
-  patch_phase(a, (int)gridDim.x);
-}
-
 // ---- unique numbering: the occurrence with rank 0 represents its slot -------------------------------------------------
 struct EmitOut {
   uint64_t* unique_keys;
@@ -569,89 +559,7 @@ struct EmitOut {
   int64_t* freq;            // [n] nullable
   int32_t* csr_cnt;         // [n]
   int32_t* total;           // [1]
-  int* hot_counters;        // hot-list header (n_hot, n_tasks, .., n_wave) cleared here (nullable)
 };
-
-template <bool kSelf>
-__global__ void __launch_bounds__(kScanThreads)
-fused_emit_kernel(FusedArgs a, EmitOut o) {
-  __shared__ int s_p2[4];
-  __shared__ int s_ex[kScanTile + 1];       // exclusive representative count in front of every item of the tile
-  __shared__ int64_t s_seg[kFusedMaxT + 1];
-  const int64_t tile0 = (int64_t)blockIdx.x * kScanTile;
-  const int64_t n = a.n;
-  const int T = a.T;
-  int sl[kScanItems], rk[kScanItems], f[kScanItems], oc[kScanItems];
-  uint64_t ky[kScanItems];
-  int64_t ad[kScanItems];
-  int c = 0;
-  if (threadIdx.x < 4) s_p2[threadIdx.x] = 0;
-  for (int t = threadIdx.x; t <= T; t += kScanThreads) s_seg[t] = a.seg_out[t];
-  // every load is unconditional (clamped) and issued up front: the loads of a thread's four items overlap instead of
-  // queueing behind one exec-masked branch each
-#pragma unroll
-  for (int k = 0; k < kScanItems; ++k) {
-    const int64_t i = tile0 + threadIdx.x * kScanItems + k;
-    const int64_t ic = i < n ? i : n - 1;
-    sl[k] = a.occ_slot[ic];
-    rk[k] = a.csr_rank[ic];
-    ky[k] = a.keys[ic];
-    ad[k] = a.occ_addr[ic];
-  }
-#pragma unroll
-  for (int k = 0; k < kScanItems; ++k) {
-    const int64_t i = tile0 + threadIdx.x * kScanItems + k;
-    f[k] = (i < n) && (rk[k] == 0) && (sl[k] >= 0);
-    oc[k] = a.occ[2 * (int64_t)(sl[k] >= 0 ? sl[k] : 0)];
-    c += f[k];
-  }
-  int tot;
-  const int pre = kSelf ? self_prefix(a.partial, blockIdx.x) : a.partial[blockIdx.x];
-  int ex = block_excl_scan(c, tot) + pre;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (o.hot_counters) { o.hot_counters[0] = 0; o.hot_counters[2] = 0; o.hot_counters[4] = 0; }
-    a.hdr[0] = 0;   // deferred-key list and grid barrier of the next step
-    a.hdr[1] = 0; a.hdr[3] = 0;
-    for (int g = 0; g < 64 - 8; ++g) a.hdr[8 + g] = 0;
-  }
-  const int first_tile = pre >> 10;
-  int b0 = 0, b1 = 0;     // occurrences of my representatives that fall into unique tile first_tile / first_tile + 1
-#pragma unroll
-  for (int k = 0; k < kScanItems; ++k) {
-    s_ex[threadIdx.x * kScanItems + k] = ex;
-    if (f[k]) {
-      const int s = sl[k];
-      *reinterpret_cast<int2*>(a.occ + 2 * (int64_t)s) = make_int2(0, ex);   // counter cleared, unique id set: one store
-      o.unique_keys[ex] = ky[k];
-      o.csr_cnt[ex] = oc[k];
-      if (o.freq) o.freq[ex] = oc[k];
-      o.row_addr[ex] = ad[k];
-      int ti = 0;
-      if (T > 1) {
-        const int64_t i = tile0 + threadIdx.x * kScanItems + k;
-        int lo = 0, hi = T + 1;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_seg[mid] <= i) lo = mid + 1; else hi = mid; }
-        ti = lo - 1 < 0 ? 0 : (lo - 1 >= T ? T - 1 : lo - 1);
-      }
-      if (o.table_ids) o.table_ids[ex] = ti;
-      o.slots[ex] = s < a.S ? (int64_t)s - a.tbo[ti] * a.t.C : -1;
-      if ((ex >> 10) == first_tile) b0 += oc[k]; else b1 += oc[k];
-      ++ex;
-    }
-  }
-  if (threadIdx.x == kScanThreads - 1) s_ex[kScanTile] = ex;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { b0 += __shfl_down(b0, off, 64); b1 += __shfl_down(b1, off, 64); }
-  if (lane_id() == 0) { if (b0) atomicAdd(&s_p2[0], b0); if (b1) atomicAdd(&s_p2[1], b1); }
-  __syncthreads();
-  // unique offsets of the tables whose first key lies in this tile (or behind the batch: the last tile writes those)
-  for (int t = threadIdx.x; t <= T; t += kScanThreads) {
-    const int64_t p = s_seg[t];
-    if (p >= tile0 && p < tile0 + kScanTile && p < n) o.table_offsets[t] = s_ex[p - tile0];
-    else if (p >= n && blockIdx.x == gridDim.x - 1) o.table_offsets[t] = pre + tot;
-  }
-  if (threadIdx.x < 2 && s_p2[threadIdx.x]) atomicAdd(&a.partial2[first_tile + threadIdx.x], s_p2[threadIdx.x]);
-}
 
 // ---- merged numbering kernel: deferred keys (if any) + unique numbering + CSR row pointers + hot-row registration --------
 // One launch instead of three (evict, emit, scan_down).  Unique ids need only the per-tile representative counts the probe
@@ -757,7 +665,6 @@ fused_mid_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, boo
     if (kSelf) for (int j = threadIdx.x; j < (int)blockIdx.x; j += kScanThreads) pre_part += a.partial[j];
     else pre_part = a.partial[blockIdx.x];
   }
-  if (a.dbg & 32) { if (sl[0] == -77 && rk[1] == -5 && ky[2] == 1 && ad[3] == 1 && pre_part == -1) a.occ[1] = 0; return; }
   // ---- unique numbering: the occurrence with rank 0 represents its slot ----
   int c = 0, cs = 0;
 #pragma unroll
@@ -778,7 +685,6 @@ fused_mid_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, boo
   if (kSelf) block_excl_scan(pre_part, pre);
   int ex = block_excl_scan(c, tot) + pre;
   const int ex_first = ex;
-  if (a.dbg & 64) { if (ex == -12345 && ex2 == -3) a.occ[1] = 0; return; }
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
     s_ex[threadIdx.x * kScanItems + k] = ex;
@@ -809,7 +715,7 @@ fused_mid_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, boo
     if (p >= tile0 && p < tile0 + kScanTile && p < n) o.table_offsets[t] = s_ex[p - tile0];
     else if (p >= n && blockIdx.x == gridDim.x - 1) o.table_offsets[t] = pre + tot;
   }
-  if (!ptr || (a.dbg & 128)) return;
+  if (!ptr) return;
   // ---- row pointers of the backward's CSR + hot rows (scan_down_kernel's scheme: ONE atomic triple per block) ----
   int h_ex = 0, t_ex = 0, w_ex = 0;
   if (build_hot) {
@@ -984,9 +890,9 @@ int64_t mi355_demb_aux_numel(int64_t total_slots, int64_t num_buckets) {
 static inline int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
 
 int64_t mi355_demb_forward_fused_workspace_bytes(int64_t n, int64_t num_tables) {
-  const int64_t nt = (n + 1023) / 1024 + 2, nbu = (n + 1) / 1024 + 3;
+  const int64_t nt = (n + 1023) / 1024 + 2;
   return al256(8 * (num_tables + 1)) + al256(8 * n) /*unique keys*/ + al256(8 * n) /*occ_addr*/ + al256(4 * n) /*occ_slot*/ +
-         al256(4 * nt) + al256(4 * nbu) + 256 /*total*/ + al256(8 * n) + 4 * al256(4 * n) /*deferred*/ + al256(8 * nt) /*look-back*/ + 256;
+         al256(4 * nt) + 256 /*total*/ + al256(8 * n) + 4 * al256(4 * n) /*deferred*/ + al256(8 * nt) /*look-back*/ + 256;
 }
 
 // The fused forward (see the header of this file).  Persisted outputs as mi355_demb_forward; in eval mode (train == 0)
@@ -1023,7 +929,7 @@ int mi355_demb_forward_fused(
   STEP(mi355i_side_join_pending(stream));
   uint8_t* w = (uint8_t*)workspace;
   const int64_t n = num_keys;
-  const int64_t nt = (n + 1023) / 1024 + 2, nbu = (n + 1) / 1024 + 1;
+  const int64_t nt = (n + 1023) / 1024 + 2;
   FusedArgs a;
   a.t = make_table(storage, bucket_capacity, num_scores);
   a.tbo = table_bucket_offsets; a.bucket_sizes = bucket_sizes; a.counter = counter;
@@ -1041,9 +947,7 @@ int mi355_demb_forward_fused(
   a.occ_addr = (int64_t*)w; w += al256(8 * n);
   a.occ_slot = (int32_t*)w; w += al256(4 * n);
   a.partial = (int32_t*)w; w += al256(4 * nt);
-  a.partial2 = (int32_t*)w; w += al256(4 * (nbu + 2));
   int32_t* total = (int32_t*)w; w += 256;
-  a.nbu = nbu;
   a.d_key = (uint64_t*)w; w += al256(8 * n);
   a.d_tid = (int32_t*)w; w += al256(4 * n);
   a.d_cnt = (int32_t*)w; w += al256(4 * n);
@@ -1063,8 +967,6 @@ int mi355_demb_forward_fused(
     hot_ws = bw; hot_bytes_ = mi355_backward_workspace_bytes(n, emb_dim);
     a.hot_counters = (int*)hot_ws;
   }
-  static const int mid_env = getenv("MI355_FUSED_MID") ? atoi(getenv("MI355_FUSED_MID")) : 1;
-  const bool merged = mid_env != 0;   // 0: the separate evict / emit / scan launches (A/B only)
   if (train) MI355_CHECK_ARG(reverse_indices && unique_offsets && slots && row_addr && csr_cnt && csr_rank, "persisted outputs required in train mode");
   if (n > 0) {
     RoctxRange rr("op:fused_index(segmented_unique+storage_find+storage_insert+initializer)");
@@ -1088,17 +990,6 @@ int mi355_demb_forward_fused(
     }
 #undef LAUNCH_PROBE
     MI355_LAUNCH_CHECK();
-    if (train && !merged) {
-      static int ncu = 0;
-      if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-        if (ncu <= 0) ncu = 64;
-      }
-      hipLaunchKernelGGL(fused_evict_kernel, dim3((unsigned)ncu), dim3(256), 0, stream, a);
-      MI355_LAUNCH_CHECK();
-    }
   }
   // ---- train: unique numbering + CSR of the backward on the side stream (forked BEFORE the gather is queued, so both
   //      start as soon as the index stage is done); eval: only the gather
@@ -1126,37 +1017,27 @@ int mi355_demb_forward_fused(
     RoctxRange rr("op:unique_numbering+backward_csr");
     EmitOut o;
     o.unique_keys = unique_keys; o.table_offsets = unique_offsets; o.table_ids = table_ids; o.slots = slots;
-    o.row_addr = row_addr; o.freq = freq; o.csr_cnt = csr_cnt; o.total = total + 8; o.hot_counters = nullptr;
+    o.row_addr = row_addr; o.freq = freq; o.csr_cnt = csr_cnt; o.total = total + 8;
     const int64_t* nu_dev = unique_offsets + num_tables;
-    if (!merged) o.hot_counters = (int*)hot_ws;   // (the merged path clears them in the probe kernel)
     const int64_t ntile = ceil_div(n, kScanTile);
-    if (merged) {
-      static int ncu2 = 0;
-      if (!ncu2) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu2 = prop.multiProcessorCount;
-        if (ncu2 <= 0) ncu2 = 64;
-      }
-      HotList hot{};
-      if (hot_ws) hot = hot_carve(hot_ws, n, emb_dim);
-      if (ntile <= kSelfPrefixMaxTiles) {
-        hipLaunchKernelGGL(fused_mid_kernel<true>, dim3((unsigned)ntile), dim3(kScanThreads), 0, cs, a, o, bptr, hot, hot_ws != nullptr, ncu2);
-      } else {
-        hipLaunchKernelGGL(fused_scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, cs, a.partial, ntile);
-        hipLaunchKernelGGL(fused_mid_kernel<false>, dim3((unsigned)ntile), dim3(kScanThreads), 0, cs, a, o, bptr, hot, hot_ws != nullptr, ncu2);
-      }
-    } else if (ntile <= kSelfPrefixMaxTiles) {
-      hipLaunchKernelGGL(fused_emit_kernel<true>, dim3((unsigned)ntile), dim3(kScanThreads), 0, cs, a, o);
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+      if (ncu <= 0) ncu = 64;
+    }
+    HotList hot{};
+    if (hot_ws) hot = hot_carve(hot_ws, n, emb_dim);
+    if (ntile <= kSelfPrefixMaxTiles) {
+      hipLaunchKernelGGL(fused_mid_kernel<true>, dim3((unsigned)ntile), dim3(kScanThreads), 0, cs, a, o, bptr, hot, hot_ws != nullptr, ncu);
     } else {
       hipLaunchKernelGGL(fused_scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, cs, a.partial, ntile);
-      hipLaunchKernelGGL(fused_emit_kernel<false>, dim3((unsigned)ntile), dim3(kScanThreads), 0, cs, a, o);
+      hipLaunchKernelGGL(fused_mid_kernel<false>, dim3((unsigned)ntile), dim3(kScanThreads), 0, cs, a, o, bptr, hot, hot_ws != nullptr, ncu);
     }
     MI355_LAUNCH_CHECK();
-    if (!(a.dbg & (32 | 64 | 128)))
     STEP(mi355i_csr_from_slots(csr_cnt, csr_rank, a.occ_slot, a.occ + 1, reverse_indices, n, combiner >= 0 ? offsets : nullptr,
-                               num_bags, nu_dev, a.partial2, total, bptr, bcsr, hot_ws, hot_bytes_, emb_dim, merged ? 1 : 0,
-                               merged ? a.hdr : nullptr, cs));
+                               num_bags, nu_dev, nullptr, total, bptr, bcsr, hot_ws, hot_bytes_, emb_dim, 1, a.hdr, cs));
     if (pin) STEP(mi355_table_update_counter(counter, counter_numel, slots, n, nu_dev, 1, table_ids, table_bucket_offsets,
                                              bucket_capacity, cs));
     if (forked) {

@@ -268,7 +268,42 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
     const uint16_t* cached = a.kv_cache + ((int64_t)page * 2 + which) * pg_kv + (int64_t)(jc % a.page_size) * pg_slot + (int64_t)h * D;
     return j < cachelen ? cached : direct;
   };
+  // Fast path of the fetch (contiguous keys, tile entirely inside the sequence): per-thread base pointers are formed
+  // once, a tile costs one scalar multiply and its loads one 64-bit add each (K) or an immediate offset (V).  The general
+  // path below recomputes (token, page) -> address per 16-byte load: ~20 VALU with quarter-rate 32-bit multiplies, 16 to
+  // 40 loads per thread and tile -- as many VALU cycles as the tile's MFMAs take.
+  constexpr int KROWS = 256 / (D / 8);        // K rows covered by the 256 threads per load round
+  const uint16_t* k_thr = kbase + (tok0 + (int)threadIdx.x / (D / 8)) * a.k_row + 8 * ((int)threadIdx.x % (D / 8));
+  const uint16_t* vr_thr = vbase + (tok0 + (int)threadIdx.x / (D / 8)) * a.v_row + 8 * ((int)threadIdx.x % (D / 8));
+  const int64_t kstep = (int64_t)KROWS * a.k_row, vrstep = (int64_t)KROWS * a.v_row;
+  const uint16_t* v_thr;
+  {
+    const int kgpos = (int)threadIdx.x % (kBN / 4), g16 = kgpos >> 2, pg = kgpos & 3;
+    const int ak = pg == 1 ? 2 : (pg == 2 ? 1 : pg);
+    v_thr = vbase + (tok0 + 16 * g16 + 4 * ak) * a.v_row + 8 * ((int)threadIdx.x / (kBN / 4));
+  }
   auto fetch = [&](int n0) {
+    if (!paged && n0 + kBN <= s.L) {
+      const uint16_t* kp = k_thr + (int64_t)n0 * a.k_row;
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) kreg[i] = *reinterpret_cast<const u32x4_t*>(kp + i * kstep);
+      if constexpr (kVTR) {
+        const uint16_t* vp = vr_thr + (int64_t)n0 * a.v_row;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) vrow[i] = *reinterpret_cast<const u32x4_t*>(vp + i * vrstep);
+      } else {
+        const uint16_t* vp = v_thr + (int64_t)n0 * a.v_row;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+          for (int i = 0; i < VPT; ++i)
+            if (VCH % 256 == 0 || (int)threadIdx.x + 256 * i < VCH)
+              vreg[i][kk] = *reinterpret_cast<const u32x4_t*>(vp + 8 * (256 / (kBN / 4)) * i);
+          vp += a.v_row;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
       const int ch = threadIdx.x + 256 * i;

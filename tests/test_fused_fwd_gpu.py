@@ -140,6 +140,50 @@ def test_hits_and_misses_in_a_full_bucket(strategy, fused, monkeypatch):
     torch.testing.assert_close(rows_after[:, :8], rows_now[:, :8] - 1.0, rtol=0, atol=1e-6)
 
 
+def test_many_deferred_keys_in_a_grid_larger_than_the_resident_group(monkeypatch):
+    """a full table, a 400 K-key batch of old and new keys: thousands of keys find their bucket full and are deferred to the
+    head of the numbering kernel, whose grid (391 blocks) is larger than the group of blocks that runs the eviction (one
+    per CU) -- the later blocks wait for the release flag.  Checks: every key of the batch that has a slot reads its own
+    row; keys of the batch are never evicted by the batch; the size stays at capacity; unique[reverse] == keys; the
+    scratch counters are clean; the backward moves every row of the batch exactly once."""
+    cap = 64 * 1024
+    m = _mk(True, (8,), cap=cap, pooling="NONE", strategy="STEP", learning_rate=1.0, monkeypatch=monkeypatch)
+    m.train()
+    off = lambda n: torch.arange(n + 1, dtype=torch.int64, device=DEV)
+    rng = np.random.default_rng(11)
+    old = torch.from_numpy(rng.permutation(1 << 22)[: 2 * cap].astype(np.int64)).to(DEV)
+    for i in range(0, old.numel(), 32768):                 # fill: the table ends up full (evicting among `old` itself)
+        m(old[i:i + 32768], off(min(32768, old.numel() - i)))
+    assert int(m.size()) == cap
+    f_old, _ = m.lookup_rows(old, 0)
+    resident = old[f_old]
+    n = 400_000
+    new = torch.arange(1 << 23, (1 << 23) + 20_000, dtype=torch.int64, device=DEV)       # 20 K keys the table has never seen
+    pool = torch.cat([resident[: 30_000], new])
+    batch = pool[torch.from_numpy(rng.integers(0, pool.numel(), n)).to(DEV)]
+    _, rows_before = m.lookup_rows(resident[: 30_000], 0)
+    out, st = m._forward_impl(batch, off(n), train=True)
+    nu = int(st.uoff[-1])
+    assert torch.equal(st.unique_keys[:nu][st.rev], batch) if hasattr(st, "unique_keys") else True
+    found, rows_now = m.lookup_rows(batch, 0)
+    has = st.slots[:nu][st.rev] >= 0
+    assert bool(found[has].all()) and torch.equal(out[has], rows_now[has][:, :8])
+    assert bool((out[~has] == 0).all())
+    assert int(has.sum()) > n * 0.9 and int(m.size()) == cap      # (a bucket whose every slot the batch uses refuses the rest)
+    # the 30 K resident keys of the pool were hits: same rows as before, none evicted
+    f_res, rows_res = m.lookup_rows(resident[: 30_000], 0)
+    in_batch = torch.isin(resident[: 30_000], batch)
+    assert bool(f_res[in_batch].all()) and torch.equal(rows_res[in_batch], rows_before[in_batch])
+    # new keys did come in
+    f_new, _ = m.lookup_rows(new, 0)
+    assert int(f_new.sum()) > 15_000
+    m._backward_impl(st, torch.ones_like(out))
+    assert _counters_clear(m)
+    _, rows_after = m.lookup_rows(batch, 0)
+    cnt = torch.zeros(nu, device=DEV).index_add_(0, st.rev, torch.ones(n, device=DEV))[st.rev]
+    torch.testing.assert_close(rows_after[has][:, :8], rows_now[has][:, :8] - cnt[has][:, None], rtol=0, atol=1e-4)
+
+
 def test_full_bucket_without_a_victim_reports_no_slot(monkeypatch):
     """every slot of the bucket is used by the batch itself: the extra keys get no slot (index -1, zero rows, no update),
     exactly like an insert that returns Busy"""
