@@ -283,7 +283,8 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
     v_thr = vbase + (tok0 + 16 * g16 + 4 * ak) * a.v_row + 8 * ((int)threadIdx.x / (kBN / 4));
   }
   auto fetch = [&](int n0) {
-    if (!paged && n0 + kBN <= s.L) {
+    // (d = 256 only: the kernel runs one wave per SIMD there anyway; at d = 128 the extra pointers cost the second wave)
+    if (D >= 256 && !paged && n0 + kBN <= s.L) {
       const uint16_t* kp = k_thr + (int64_t)n0 * a.k_row;
 #pragma unroll
       for (int i = 0; i < KPT; ++i) kreg[i] = *reinterpret_cast<const u32x4_t*>(kp + i * kstep);
@@ -644,6 +645,15 @@ struct RowTile {
   static constexpr int NCH = NR * D / 8, PT = (NCH + 255) / 256;
   u32x4_t r[PT];
   __device__ __forceinline__ void fetch(const uint16_t* src, int64_t row_stride, int row0, int L) {
+    if constexpr (NCH % 256 == 0) {
+      if (row0 + NR <= L) {   // tile inside the sequence (uniform): one address per thread, one 64-bit add per load
+        const uint16_t* p = src + (int64_t)(row0 + (int)threadIdx.x / (D / 8)) * row_stride + 8 * ((int)threadIdx.x % (D / 8));
+        const int64_t step = (int64_t)(256 / (D / 8)) * row_stride;
+#pragma unroll
+        for (int i = 0; i < PT; ++i) r[i] = *reinterpret_cast<const u32x4_t*>(p + i * step);
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
       const int ch = threadIdx.x + 256 * i;
@@ -680,6 +690,20 @@ struct TransTile {
   static constexpr int NCH = (NR / 4) * (D / 8), PT = (NCH + 255) / 256;
   u32x4_t r[PT][4];
   __device__ __forceinline__ void fetch(const uint16_t* src, int64_t row_stride, int row0, int L) {
+    if constexpr (NCH % 256 == 0) {
+      if (row0 + NR <= L) {   // tile inside the sequence (uniform): four row pointers per thread, immediate column offsets
+        const int gpos = (int)threadIdx.x % (NR / 4), g16 = gpos >> 2, pg = gpos & 3;
+        const int ak = pg == 1 ? 2 : (pg == 2 ? 1 : pg);
+        const uint16_t* p = src + (int64_t)(row0 + 16 * g16 + 4 * ak) * row_stride + 8 * ((int)threadIdx.x / (NR / 4));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+          for (int i = 0; i < PT; ++i) r[i][kk] = *reinterpret_cast<const u32x4_t*>(p + 8 * (256 / (NR / 4)) * i);
+          p += row_stride;
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
       const int ch = (threadIdx.x + 256 * i) % NCH;   // threads past NCH repeat a block (their writes are skipped)
