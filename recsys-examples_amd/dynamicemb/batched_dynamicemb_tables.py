@@ -484,11 +484,27 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             ptr(st.csr_cnt), ptr(st.csr_rank), ptr(st.bwd_ws), st.bwd_ws.numel() if st.bwd_ws is not None else 0,
             ctypes.byref(tok), ptr(ws), ws.numel(), stream()), "demb_forward")
         st.token = tok.value
+        if st.token >= 0:
+            # the side-stream kernels read these allocator-owned tensors: a step that is dropped without its backward must
+            # not hand them back to the allocator while they are in use there
+            side = self._side_stream_obj()
+            for t_ in (st.rev, st.csr_cnt, st.csr_rank, st.uoff, offsets):
+                if t_ is not None:
+                    t_.record_stream(side)
         if train:
             self._step += 1
             if self._dynamicemb_options[0].safe_check_mode != DynamicEmbCheckMode.IGNORE:
                 self._safe_check(st)
         return out, st
+
+    def _side_stream_obj(self):
+        """the library's side stream (mi355_early_csr_stream) as a torch stream, for record_stream"""
+        so = getattr(self, "_side_stream_cache", None)
+        if so is None:
+            L = lib()
+            L.mi355_early_csr_stream.restype = ctypes.c_void_p
+            so = self._side_stream_cache = torch.cuda.ExternalStream(int(L.mi355_early_csr_stream()), device=self.device_)
+        return so
 
     # ---------------------------------------------------------------------------------- table growth
     def _maybe_grow(self, incoming: int) -> None:
