@@ -367,6 +367,10 @@ int mi355_profile_kernels(int enable);
 float mi355_profile_ms(int slot /* 0: gather of the fused forward, 1: backward kernel */);
 /* `stream` waits for the side-stream work a forward announced through join_token */
 int mi355_side_join(int token, hipStream_t stream);
+/* Slot-range partitions the fused forward uses for a training batch of n keys (0: the per-slot-counter path).  One table,
+ * 64 K .. 1 M keys and at least 8 buckets per partition take the partitioned index stage: (tile, key) records grouped by
+ * slot range, one block per range merges them in LDS -- no global atomic per key, no per-slot scratch. */
+int mi355_demb_forward_fused_partitions(int64_t n, int64_t num_tables, int64_t num_buckets);
 int64_t mi355_demb_forward_fused_workspace_bytes(int64_t num_keys, int64_t num_tables);
 int mi355_demb_forward_fused(void* storage, const int64_t* table_bucket_offsets, int64_t bucket_capacity,
                              int64_t num_scores, int32_t* bucket_sizes, int32_t* counter, int64_t counter_numel,

@@ -40,7 +40,13 @@
 namespace mi355 {
 
 constexpr int kFusedMaxT = 128;     // tables per fused launch (per-table metadata lives in LDS)
-constexpr int kAuxHdr = 64;         // ints in front of the occ array: [0] deferred keys, [1] grid barrier
+constexpr int kPartMax = 1024;      // partitions of the partitioned index stage (their counters live in the aux header)
+constexpr int kPartCap = 2048;      // (tile, key) records per partition
+constexpr int kPartSub = 4;         // sub-lists per partition (tile % kPartSub picks one): same-address atomics serialise at
+                                    // ~40 ns each, 176 tiles on ONE counter per partition is a 7 us chain, on four 1.8 us
+constexpr int kSubCap = kPartCap / kPartSub;
+constexpr int kAuxHdr = 64 + kPartMax * 4;   // ints in front of the occ array: [0] deferred keys, [1..] grid barrier, [5] sticky
+                                    // error flag of the partitioned stage, [64 + 4 p + r] records of sub-list r of partition p (zero between steps)
 
 struct FusedArgs {
   Table t;
@@ -74,6 +80,15 @@ struct FusedArgs {
   int32_t* partial;               // [ceil(n/1024)] representatives per 1024 occurrences
   int64_t* seg_out;               // [T+1] table ranges
   uint64_t* d_key; int32_t* d_tid; int32_t* d_cnt; int32_t* d_slot; int32_t* d_base;   // deferred (bucket full) keys
+  // partitioned index stage (single table, 64 K .. 1 M keys): records of the (tile, key) pairs, grouped by slot range
+  int P;                          // partitions (0: not partitioned)
+  int spp;                        // slots per partition (multiple of the bucket capacity)
+  int32_t* pcount;                // [P * kPartSub] records per sub-list (aux header; zero between steps)
+  uint4* rec;                     // [P * kPartCap] {key lo, key hi, slot code, occurrences of the key in the record's tile}: ONE
+                                  // 16-byte store per record; slot code = global slot, S (no slot), or -(bucket + 2) (bucket
+                                  // full: deferred)
+  int2* rec_out;                  // [P * kPartCap] out: {unique id, rank base of the tile inside the row's list; < 0: ~base of a
+                                  // record whose row address was resolved late}
   unsigned long long* tstat;      // [ceil(n/1024)] look-back words of the merged numbering kernel (zeroed by the probe)
   int* hot_counters;              // hot-list header of the backward (cleared by the probe; nullable)
 };
@@ -187,8 +202,9 @@ __device__ __forceinline__ void wave_init_row(const FusedArgs& a, void* rp, uint
   }
 }
 
-template <int TILE, int THREADS, bool kTrain>
+template <int TILE, int THREADS, bool kTrain, bool kPart = false>
 __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
+  __shared__ int s_hist[kPart ? kPartMax : 1];    // kPart: records of this tile per partition, then their base in the partition
   if (!a.timer) a.timer = device_clock();
   constexpr int PER = TILE / THREADS;
   constexpr int LDS = 2 * TILE;
@@ -225,10 +241,11 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   }
   if (kTrain && a.tstat && threadIdx.x < HALVES) {
     const int64_t pt = (int64_t)blockIdx.x * HALVES + threadIdx.x;
-    if (pt * 1024 < a.n) a.tstat[pt] = 0ull;
+    if (pt * 1024 < a.n) { a.tstat[pt] = 0ull; if (kPart) a.tstat[a.P + pt] = 0ull; }
   }
   for (int s = threadIdx.x; s < LDS; s += THREADS) { s_tab[s] = -1; s_cnt[s] = 0; }
   if (threadIdx.x < HALVES) s_nrep[threadIdx.x] = 0;
+  if constexpr (kPart) for (int p = threadIdx.x; p < a.P; p += THREADS) s_hist[p] = 0;
   __syncthreads();
   int hh[PER], rk[PER];
   int64_t bq[PER], hq[PER];      // bucket and hash of my keys (bucket -1: key without a home)
@@ -282,6 +299,25 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   bool isrep[PER];
 #pragma unroll
   for (int q = 0; q < PER; ++q) isrep[q] = hh[q] >= 0 && s_tab[hh[q]] == q * THREADS + (int)threadIdx.x;
+  // kPart: the partition of a pair follows from its BUCKET (keys without a home: the last partition), which is known
+  // before the probe -- so the tile's histogram and the one global atomic per (tile, partition) go out here and their
+  // round trip runs under the probe; the bases are read when the records are written.
+  int lpq[PER], my_base = 0;
+  if constexpr (kPart) {
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      lpq[q] = 0;
+      if (isrep[q]) {
+        const int pk = bq[q] >= 0 ? (int)(bq[q] * a.t.C / a.spp) : a.P - 1;
+        lpq[q] = pk * 4096 + atomicAdd(&s_hist[pk], 1);
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < a.P) {     // (P <= kPartMax = THREADS)
+      const int c = s_hist[threadIdx.x];
+      if (c) my_base = atomicAdd(&a.pcount[threadIdx.x * kPartSub + (int)blockIdx.x % kPartSub], c);
+    }
+  }
   // first candidate of the prefetched vector: its key word is loaded by every lane (clamped address), so that the loads
   // of a thread's keys overlap; everything the fast path cannot decide goes to thread_probe
   uint64_t kc[PER];
@@ -296,6 +332,9 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   }
   __syncthreads();   // s_tab / s_cnt change meaning below
   // ---- probe: one lane per distinct key of the tile
+  int cnt_tile[PER];   // (kPart) occurrences of my distinct keys inside the tile
+#pragma unroll
+  for (int q = 0; q < PER; ++q) cnt_tile[q] = 0;
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
     if (!isrep[q]) continue;
@@ -303,6 +342,7 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     const uint64_t key = kreg[q];
     const int t = s_t[li];
     const int cnt = s_cnt[hh[q]];
+    if constexpr (kPart) cnt_tile[q] = cnt;
     int gslot = (int)a.S, base = 0;     // default: no slot
     bool defer = false;
     uint64_t* found_sc = nullptr;
@@ -323,6 +363,14 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
         defer = true;
       }
     }
+    if constexpr (kPart) {
+      // no global counter per slot: the pair becomes a record of the partition that owns its slot range; the partition's
+      // block (fused_part_kernel) merges the records of a slot and ranks the tiles.  One LDS atomic here, one global
+      // atomic per (tile, partition) below.
+      if (found_sc) score_found(a, found_sc, cnt);
+      s_tab[hh[q]] = lpq[q];              // (partition, position among the tile's records of the partition)
+      s_cnt[hh[q]] = defer ? -(int)bq[q] - 2 : gslot;
+    } else {
     if (kTrain) {
       if (defer) {
         const int e = atomicAdd(&a.hdr[0], 1);
@@ -338,8 +386,29 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     }
     s_tab[hh[q]] = gslot;
     s_cnt[hh[q]] = base;
+    }
   }
   __syncthreads();
+  if constexpr (kPart) {
+    const int sub = (int)blockIdx.x % kPartSub;
+    if ((int)threadIdx.x < a.P) s_hist[threadIdx.x] = my_base;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      if (!isrep[q]) continue;
+      const int v = s_tab[hh[q]];
+      const int pk = v >> 12, idx = s_hist[pk] + (v & 4095);
+      int ref = -1;
+      if (idx < kSubCap) {
+        ref = pk * kPartCap + sub * kSubCap + idx;
+        a.rec[ref] = make_uint4((uint32_t)kreg[q], (uint32_t)(kreg[q] >> 32), (uint32_t)s_cnt[hh[q]], (uint32_t)cnt_tile[q]);
+      } else {
+        a.hdr[5] = 1;     // a partition received more records than it can hold: the step is flagged (see the module)
+      }
+      s_tab[hh[q]] = ref;
+    }
+    __syncthreads();
+  }
   int nrep[HALVES];
 #pragma unroll
   for (int hq = 0; hq < HALVES; ++hq) nrep[hq] = 0;
@@ -348,9 +417,16 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     const int li = q * THREADS + threadIdx.x;
     if (hh[q] >= 0) {
       const int64_t i = tile0 + li;
+      const int t = s_t[li] & 0x7fff;
+      if constexpr (kPart) {
+        const int g = s_cnt[hh[q]];           // slot code of the key's record
+        a.occ_slot[i] = s_tab[hh[q]];         // the record
+        a.csr_rank[i] = rk[q];                // rank inside the tile (completed by the scatter kernel)
+        a.occ_addr[i] = (g >= 0 && g < a.S) ? s_tptr[t] + ((int64_t)g - s_tbo[t] * a.t.C) * s_rowb[t] : 0;
+        continue;
+      }
       const int g = s_tab[hh[q]];
       const int r = s_cnt[hh[q]] + rk[q];
-      const int t = s_t[li] & 0x7fff;
       a.occ_slot[i] = g;
       if (kTrain) a.csr_rank[i] = r;
       a.occ_addr[i] = (g >= 0 && g < a.S) ? s_tptr[t] + ((int64_t)g - s_tbo[t] * a.t.C) * s_rowb[t] : 0;
@@ -583,10 +659,11 @@ __device__ __forceinline__ void stat_store(unsigned long long* p, unsigned long 
 // block, every thread returns the result.
 // All predecessors of a round (256 per round) are polled at once -- one memory round trip for batches up to 256 K keys --
 // and the walk stops at the nearest tile that already knows its inclusive prefix.
-__device__ __forceinline__ int lookback_prefix(unsigned long long* tstat, int t, int my_sum) {
-  __shared__ int s_first, s_sum;
+__device__ __forceinline__ unsigned long long lookback_prefix64(unsigned long long* tstat, int t, unsigned long long my_sum) {
+  __shared__ int s_first;
+  __shared__ unsigned long long s_sum;
   if (t == 0) return 0;   // (the caller published the tile's sum -- tile 0: as its inclusive prefix -- earlier)
-  int run = 0;
+  unsigned long long run = 0;
   for (int pos = t - 1;; pos -= kScanThreads) {
     if (threadIdx.x == 0) { s_first = kScanThreads; s_sum = 0; }
     __syncthreads();
@@ -596,17 +673,59 @@ __device__ __forceinline__ int lookback_prefix(unsigned long long* tstat, int t,
     if ((v & kStatMask) == kStatPre) atomicMin(&s_first, (int)threadIdx.x);
     __syncthreads();
     const int first = s_first;      // nearest predecessor of this round that knows its inclusive prefix (256: none)
-    int val = (int)threadIdx.x <= first ? (int)(unsigned)(v & 0xFFFFFFFFull) : 0;
+    unsigned long long val = (int)threadIdx.x <= first ? (v & ~kStatMask) : 0ull;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off, 64);
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint32_t lo = __shfl_xor((int)(uint32_t)val, off, 64), hi = __shfl_xor((int)(uint32_t)(val >> 32), off, 64);
+      val += ((unsigned long long)hi << 32) | lo;
+    }
     if (lane_id() == 0 && val) atomicAdd(&s_sum, val);
     __syncthreads();
     run += s_sum;
     __syncthreads();
     if (first < kScanThreads) break;
   }
-  if (threadIdx.x == 0) stat_store(tstat + t, kStatPre | (unsigned)(run + my_sum));
+  if (threadIdx.x == 0) stat_store(tstat + t, kStatPre | (run + my_sum));
   return run;
+}
+// Sums of two packed words over ALL predecessors of partition `t` (t < kPartMax): the words only ever hold a partition's
+// own sums (status kStatAgg), every block adds up its predecessors itself -- up to 4 per thread, all polled at once, so
+// the whole look-back is one memory round trip once the predecessors have published.
+__device__ __forceinline__ void lookback_sum2(const unsigned long long* ta, const unsigned long long* tb, int t,
+                                              unsigned long long& pre_a, unsigned long long& pre_b) {
+  __shared__ unsigned long long s_sa, s_sb;
+  if (threadIdx.x == 0) { s_sa = 0; s_sb = 0; }
+  __syncthreads();
+  constexpr int NJ = kPartMax / kScanThreads;
+  unsigned long long va[NJ], vb[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int idx = t - 1 - ((int)threadIdx.x + j * kScanThreads);
+    va[j] = idx >= 0 ? stat_load(ta + idx) : kStatAgg;
+    vb[j] = idx >= 0 ? stat_load(tb + idx) : kStatAgg;
+  }
+  unsigned long long xa = 0, xb = 0;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int idx = t - 1 - ((int)threadIdx.x + j * kScanThreads);
+    while ((va[j] & kStatMask) == 0) { __builtin_amdgcn_s_sleep(1); va[j] = stat_load(ta + idx); }
+    while ((vb[j] & kStatMask) == 0) { __builtin_amdgcn_s_sleep(1); vb[j] = stat_load(tb + idx); }
+    xa += va[j] & ~kStatMask;
+    xb += vb[j] & ~kStatMask;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    uint32_t lo = __shfl_xor((int)(uint32_t)xa, off, 64), hi = __shfl_xor((int)(uint32_t)(xa >> 32), off, 64);
+    xa += ((unsigned long long)hi << 32) | lo;
+    lo = __shfl_xor((int)(uint32_t)xb, off, 64); hi = __shfl_xor((int)(uint32_t)(xb >> 32), off, 64);
+    xb += ((unsigned long long)hi << 32) | lo;
+  }
+  if (lane_id() == 0) { if (xa) atomicAdd(&s_sa, xa); if (xb) atomicAdd(&s_sb, xb); }
+  __syncthreads();
+  pre_a = s_sa; pre_b = s_sb;
+}
+__device__ __forceinline__ int lookback_prefix(unsigned long long* tstat, int t, int my_sum) {
+  return (int)lookback_prefix64(tstat, t, (unsigned long long)(unsigned)my_sum);
 }
 
 template <bool kSelf>
@@ -771,6 +890,338 @@ fused_mid_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, boo
   }
 }
 
+// ---- partitioned index stage, second kernel: ONE block per slot range ---------------------------------------------------
+// All (tile, key) records of a slot range meet in one block, so merging the records of a slot, ranking the tiles inside
+// the row's list, numbering the uniques and even evicting for the keys whose bucket was full are LDS work: no global
+// atomics, no per-slot scratch, no locks outside the block.  Only the two running sums (uniques, occurrences) cross
+// blocks -- one packed look-back word per partition.  Unique order: partition-major (= slot order), arbitrary inside.
+constexpr int kPartHash = 2 * kPartCap;          // LDS hash of the partition's slots
+constexpr int kPartItems = kPartCap / kScanThreads;
+
+__device__ __forceinline__ int part_hash_find(const int* h_slot, int slot) {   // -1: not present
+  int h = (int)((uint32_t)slot * 2654435761u >> 20) & (kPartHash - 1);
+  while (true) {
+    const int cur = h_slot[h];
+    if (cur == slot) return h;
+    if (cur == -1) return -1;
+    h = (h + 1) & (kPartHash - 1);
+  }
+}
+// claim or find the entry of `slot`; *claimed: this caller created it
+__device__ __forceinline__ int part_hash_insert(int* h_slot, int slot, bool* claimed) {
+  int h = (int)((uint32_t)slot * 2654435761u >> 20) & (kPartHash - 1);
+  *claimed = false;
+  while (true) {
+    const int cur = atomicCAS(&h_slot[h], -1, slot);
+    if (cur == -1) { *claimed = true; return h; }
+    if (cur == slot) return h;
+    h = (h + 1) & (kPartHash - 1);
+  }
+}
+
+__global__ void __launch_bounds__(kScanThreads)
+fused_part_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, bool build_hot) {
+  __shared__ int h_slot[kPartHash];       // slot of the entry (-1: free)
+  __shared__ int h_cnt[kPartHash];        // occurrences accumulated so far; at the end: all occurrences of the slot
+  __shared__ int h_lid[kPartHash];        // local unique id of the entry
+  __shared__ int l_cnt[kPartCap];         // occurrences by local unique id, then their exclusive prefix
+  constexpr int kDefMax = 512;            // deferred records handled per partition and step (more: served without a row)
+  __shared__ int d_rec[kDefMax];          // deferred records (bucket full) of the partition
+  __shared__ int d_ent[kDefMax], d_base[kDefMax];   // their hash entry / rank base once resolved
+  __shared__ int s_lock[256];             // bucket locks of the eviction (hashed)
+  __shared__ int s_nu, s_nd, s_tot, s_th, s_tt, s_tw;
+  const int p = blockIdx.x;
+  // the records come in kPartSub sub-lists of kSubCap; every load is issued unconditionally (the arrays are fully
+  // allocated), so the records are in flight together with their counts
+  int msub[kPartSub];
+#pragma unroll
+  for (int r = 0; r < kPartSub; ++r) msub[r] = a.pcount[p * kPartSub + r];
+  for (int i = threadIdx.x; i < kPartHash; i += kScanThreads) { h_slot[i] = -1; h_cnt[i] = 0; }
+  if (threadIdx.x < 256) s_lock[threadIdx.x] = 0;
+  if (threadIdx.x == 0) { s_nu = 0; s_nd = 0; s_tot = 0; s_th = 0; s_tt = 0; s_tw = 0; }
+  uint64_t ky[kPartItems];
+  int sl[kPartItems], cn[kPartItems], en[kPartItems], bs[kPartItems], dj[kPartItems];
+  bool mine[kPartItems];
+  bool live[kPartItems];
+#pragma unroll
+  for (int k = 0; k < kPartItems; ++k) {
+    const int idx = threadIdx.x + k * kScanThreads;
+    const int64_t r = (int64_t)p * kPartCap + idx;
+    const uint4 rc = a.rec[r];
+    ky[k] = ((uint64_t)rc.y << 32) | rc.x; sl[k] = (int)rc.z; cn[k] = (int)rc.w;
+    en[k] = -1; bs[k] = 0; dj[k] = -1; mine[k] = false;
+  }
+#pragma unroll
+  for (int k = 0; k < kPartItems; ++k) {
+    const int idx = threadIdx.x + k * kScanThreads;
+    const int ms = msub[k / (kSubCap / kScanThreads)];   // (kSubCap is a multiple of the block size)
+    live[k] = (idx % kSubCap) < (ms < kSubCap ? ms : kSubCap);
+  }
+  __syncthreads();
+  if (threadIdx.x < kPartSub) a.pcount[p * kPartSub + threadIdx.x] = 0;       // the counters are clean for the next step
+  // ---- merge the records of a slot; the record that creates the entry owns the unique row's outputs
+  {
+    int mysum = 0;
+#pragma unroll
+    for (int k = 0; k < kPartItems; ++k) mysum += live[k] ? cn[k] : 0;
+    if (mysum) atomicAdd(&s_tot, mysum);
+  }
+#pragma unroll
+  for (int k = 0; k < kPartItems; ++k) {
+    const int idx = threadIdx.x + k * kScanThreads;
+    if (!live[k]) continue;
+    if (sl[k] >= 0) {
+      bool cl;
+      en[k] = part_hash_insert(h_slot, sl[k], &cl);
+      mine[k] = cl;
+      if (cl) h_lid[en[k]] = atomicAdd(&s_nu, 1);
+      bs[k] = atomicAdd(&h_cnt[en[k]], cn[k]);
+    } else {
+      dj[k] = atomicAdd(&s_nd, 1);
+      if (dj[k] < kDefMax) {
+        d_rec[dj[k]] = idx;
+      } else {                           // beyond what one step evicts for: no slot this step (like an insert that returns Busy)
+        dj[k] = -1;
+        bool cl;
+        en[k] = part_hash_insert(h_slot, (int)a.S, &cl);
+        mine[k] = cl;
+        if (cl) h_lid[en[k]] = atomicAdd(&s_nu, 1);
+        bs[k] = atomicAdd(&h_cnt[en[k]], cn[k]);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- deferred keys: the bucket had no free slot.  Evict the minimum score among the slots this batch does not use
+  //      (the hash above knows them all: every record of the bucket is in this block) and that nobody pinned
+  //      (kernels.cuh:226-287, types.cuh:398-512); 8 lanes per key, a hashed LDS lock per bucket.
+  const int nd = s_nd < kDefMax ? s_nd : kDefMax;
+  if (nd > 0) {
+    if (!a.timer) a.timer = device_clock();
+    const int g = lane_id() & (G - 1);
+    const int gpb = kScanThreads / G;
+    const int C = (int)a.t.C;
+    for (int e0 = 0; e0 < nd; e0 += gpb) {
+      const int e = e0 + (int)threadIdx.x / G;
+      const bool act = e < nd;
+      const int64_t r = (int64_t)p * kPartCap + (act ? d_rec[e] : 0);
+      const uint4 rc = a.rec[r];
+      const uint64_t key = ((uint64_t)rc.y << 32) | rc.x;
+      const int cnt = (int)rc.w;
+      const int64_t bucket = act ? -(int64_t)(int)rc.z - 2 : 0;
+      const int64_t hash = (int64_t)(fmix64(key) & 0x7FFFFFFFFFFFFFFFull);
+      int ent = -1, base = 0;
+      bool done = !act;
+      int guard = 0;
+      while (__ballot(!done)) {
+        if (!done) {
+          int got = 0;
+          if (g == 0) got = atomicCAS(&s_lock[bucket & 255], 0, 1) == 0 ? 1 : 0;
+          got = group_bcast(got, 0);
+          if (got) {
+            uint64_t* ks = a.t.keys(bucket);
+            int found_slot, empty_slot;
+            group_probe(a.t, bucket, key, hash, true, true, found_slot, empty_slot);
+            int slot = -1;
+            bool fresh_row = false;
+            if (found_slot >= 0) {             // another record of the same key got here first
+              slot = found_slot;
+              if (g == 0) score_found(a, a.t.scores(bucket) + (int64_t)slot * a.t.ns, cnt);
+            } else if (empty_slot >= 0) {      // a slot was freed meanwhile
+              slot = empty_slot;
+              fresh_row = true;
+              if (g == 0) {
+                store_digest(a.t.dig(bucket) + slot, digest_of(hash));
+                score_new(a, a.t.scores(bucket) + (int64_t)slot * a.t.ns, cnt);
+                atomicAdd(&a.bucket_sizes[bucket], 1);
+              }
+            } else {
+              uint64_t best = ~0ull, bkey = 0;
+              int bslot = -1;
+              const uint64_t* sc = a.t.scores(bucket);
+              const int32_t* pin = a.counter ? a.counter + bucket * a.t.C : nullptr;
+              for (int s0 = 2 * g; s0 < C; s0 += 2 * G) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                  const int s2 = s0 + u;
+                  const uint64_t v = ald64(sc + (int64_t)s2 * a.t.ns + (a.t.ns - 1));
+                  if (v < best) {
+                    const uint64_t k2 = ald64(ks + s2);
+                    if (k2 == kLockedKey || k2 == kEmptyKey) continue;
+                    if (pin && __hip_atomic_load(pin + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;
+                    if (part_hash_find(h_slot, (int)(bucket * a.t.C + s2)) >= 0) continue;   // used by this batch
+                    best = v; bslot = s2; bkey = k2;
+                  }
+                }
+              }
+              group_argmin(best, bslot, bkey);
+              if (bslot >= 0) {
+                slot = bslot;
+                fresh_row = true;
+                if (g == 0) {
+                  ast64(ks + slot, kLockedKey);
+                  store_digest(a.t.dig(bucket) + slot, digest_of(hash));
+                  for (int64_t w = 0; w < a.t.ns; ++w) ast64((uint64_t*)sc + (int64_t)slot * a.t.ns + w, 0);
+                  score_new(a, a.t.scores(bucket) + (int64_t)slot * a.t.ns, cnt);
+                  if (bkey == kReclaimKey) atomicAdd(&a.bucket_sizes[bucket], 1);
+                }
+              }
+            }
+            int gslot = (int)a.S;             // no slot could be had: the key is served without a row this step
+            if (slot >= 0) {
+              gslot = (int)(bucket * a.t.C + slot);
+              if (fresh_row) {
+                void* rp = reinterpret_cast<void*>((uintptr_t)(a.table_ptrs[0] + ((int64_t)gslot - a.tbo[0] * a.t.C) *
+                                                                                  a.table_value_dims[0] * a.elem_bytes));
+                const int ed = (int)a.table_emb_dims[0], vd = (int)a.table_value_dims[0];
+                for (int el = g; el < vd; el += G) {
+                  const float v = el < ed ? init_value(a.init, key, (uint32_t)el) : a.init.state_init;
+                  if (a.value_dtype == kF32) st1<kF32>(rp, el, v);
+                  else if (a.value_dtype == kBF16) st1<kBF16>(rp, el, v);
+                  else st1<kF16>(rp, el, v);
+                }
+                if (g == 0) {
+                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                  ast64(ks + slot, key);
+                }
+              }
+            }
+            if (g == 0) {
+              // the slot enters the hash BEFORE the lock is released: that is what protects it from the next eviction
+              bool cl;
+              ent = part_hash_insert(h_slot, gslot, &cl);
+              if (cl) h_lid[ent] = atomicAdd(&s_nu, 1) | 0x40000000;    // created late: outputs written by the record below
+              base = atomicAdd(&h_cnt[ent], cnt);
+              d_ent[e] = ent; d_base[e] = base;
+              __threadfence_block();
+              atomicExch(&s_lock[bucket & 255], 0);
+            }
+            done = true;
+          } else if (++guard > (1 << 22)) {
+            if (g == 0) { bool cl; ent = part_hash_insert(h_slot, (int)a.S, &cl); if (cl) h_lid[ent] = atomicAdd(&s_nu, 1) | 0x40000000;
+                          d_ent[e] = ent; d_base[e] = atomicAdd(&h_cnt[ent], cnt); }
+            done = true;
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPartItems; ++k)
+      if (dj[k] >= 0) {
+        en[k] = d_ent[dj[k]]; bs[k] = d_base[dj[k]];
+        // the first record (rank base 0) of an entry created by the eviction writes the unique row's outputs
+        if ((h_lid[en[k]] & 0x40000000) && bs[k] == 0) mine[k] = true;
+      }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kPartHash; i += kScanThreads) h_lid[i] &= 0x3fffffff;
+  }
+  __syncthreads();
+  // ---- the partition's sums go out as early as they are known (uniques, occurrences | hot rows, hot tasks, one-wave
+  //      rows): the successors' look-back waits for them, the local scans below run meanwhile.  (The Zipf head is spread
+  //      over ALL slot ranges, so every block has hot rows: their list positions come from the look-back too -- one atomic
+  //      per block on the three list counters would be a ~14 us same-address chain.)
+  const int nu = s_nu;
+  const int tot2 = s_tot;
+  const bool hots = ptr && build_hot;
+  int nh_local = 0, nt_local = 0, nw_local = 0;
+  if (hots) {
+#pragma unroll
+    for (int k = 0; k < kPartItems; ++k) {
+      if (!mine[k]) continue;
+      const int c = h_cnt[en[k]];
+      if (c > hot.khot && c <= hot.kwave) ++nw_local;
+      else if (c > hot.khot) { ++nh_local; nt_local += (c + hot.kchunk - 1) / hot.kchunk; }
+    }
+    if (nh_local) { atomicAdd(&s_th, nh_local); atomicAdd(&s_tt, nt_local); }
+    if (nw_local) atomicAdd(&s_tw, nw_local);
+  }
+#pragma unroll
+  for (int k = 0; k < kPartItems; ++k)
+    if (mine[k]) l_cnt[h_lid[en[k]]] = h_cnt[en[k]];
+  __syncthreads();
+  const int th = s_th, tt = s_tt, tw = s_tw;
+  unsigned long long* tb = a.tstat + a.P;
+  if (threadIdx.x == 0) {
+    stat_store(a.tstat + p, kStatAgg | ((unsigned long long)nu << 31) | (unsigned)tot2);
+    stat_store(tb + p, kStatAgg | ((unsigned long long)th << 40) | ((unsigned long long)tt << 20) | (unsigned long long)tw);
+  }
+  // ---- local prefix of the occurrence counts in local-unique-id order, local positions of the hot rows
+  int lc[kPartItems], csum = 0;
+#pragma unroll
+  for (int k = 0; k < kPartItems; ++k) {
+    const int i = threadIdx.x * kPartItems + k;
+    lc[k] = i < nu ? l_cnt[i] : 0;
+    csum += lc[k];
+  }
+  int dummy;
+  int ex2 = block_excl_scan(csum, dummy);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kPartItems; ++k) {
+    const int i = threadIdx.x * kPartItems + k;
+    if (i < nu) l_cnt[i] = ex2;
+    ex2 += lc[k];
+  }
+  int h_ex = 0, t_ex = 0, w_ex = 0;
+  if (hots) {
+    h_ex = block_excl_scan(nh_local, dummy);
+    t_ex = block_excl_scan(nt_local, dummy);
+    w_ex = block_excl_scan(nw_local, dummy);
+  }
+  unsigned long long pre_a = 0, pre_b = 0;
+  lookback_sum2(a.tstat, tb, p, pre_a, pre_b);
+  const int upre = (int)(pre_a >> 31), spre = (int)(pre_a & 0x7fffffffull);
+  h_ex += (int)(pre_b >> 40); t_ex += (int)((pre_b >> 20) & 0xfffff); w_ex += (int)(pre_b & 0xfffff);
+  __syncthreads();
+  // ---- outputs: per unique row (by the record that owns it), per record
+#pragma unroll
+  for (int k = 0; k < kPartItems; ++k) {
+    const int idx = threadIdx.x + k * kScanThreads;
+    if (!live[k]) continue;
+    const int lid = h_lid[en[k]];
+    const int uid = upre + lid;
+    const int64_t r = (int64_t)p * kPartCap + idx;
+    a.rec_out[r] = make_int2(uid, sl[k] < 0 ? ~bs[k] : bs[k]);
+    if (!mine[k]) continue;
+    const int gs = h_slot[en[k]];
+    const int c = h_cnt[en[k]];
+    o.unique_keys[uid] = ky[k];
+    o.csr_cnt[uid] = c;
+    if (o.freq) o.freq[uid] = c;
+    o.row_addr[uid] = gs < a.S ? a.table_ptrs[0] + ((int64_t)gs - a.tbo[0] * a.t.C) * a.table_value_dims[0] * a.elem_bytes : 0;
+    if (o.table_ids) o.table_ids[uid] = 0;
+    o.slots[uid] = gs < a.S ? (int64_t)gs - a.tbo[0] * a.t.C : -1;
+    if (ptr) {
+      const int pv = spre + l_cnt[lid];
+      ptr[uid] = pv;
+      if (build_hot && c > hot.khot && c <= hot.kwave) {
+        const int w = w_ex++;
+        if (w < hot.max_hot) { hot.wave_u[w] = uid; hot.wave_lo[w] = pv; hot.wave_cnt[w] = c; }
+      } else if (build_hot && c > hot.khot) {
+        const int nch = (c + hot.kchunk - 1) / hot.kchunk;
+        const int h = h_ex++, t0 = t_ex;
+        t_ex += nch;
+        if (h < hot.max_hot && t0 + nch <= hot.max_tasks) {
+          hot.hot_done[h] = 0;
+          hot.hot_nchunks[h] = nch;
+          hot.hot_u[h] = uid;
+          hot.hot_lo[h] = pv;
+          hot.hot_cnt[h] = c;
+          hot.hot_t0[h] = t0;
+        }
+      }
+    }
+  }
+  if (p == (int)gridDim.x - 1 && threadIdx.x == 0) {
+    const int U = upre + nu, O = spre + tot2;
+    if (hots) { *hot.n_hot = (int)(pre_b >> 40) + th; *hot.n_tasks = (int)((pre_b >> 20) & 0xfffff) + tt; *hot.n_wave = (int)(pre_b & 0xfffff) + tw; }
+    o.table_offsets[0] = 0;
+    o.table_offsets[1] = U;
+    *o.total = O;
+    if (ptr) ptr[U] = O;
+  }
+}
+
 // exclusive scan of the per-tile representative counts when there are too many tiles for every block to sum its
 // predecessors itself (batches beyond 4 M keys)
 __global__ void __launch_bounds__(kScanThreads) fused_scan_partials_kernel(int* partial, int64_t nb) {
@@ -889,10 +1340,24 @@ int64_t mi355_demb_aux_numel(int64_t total_slots, int64_t num_buckets) {
 
 static inline int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
 
+// partitions of the partitioned index stage for a batch of n keys (0: the batch takes the per-slot-counter path)
+static inline int part_count(int64_t n, int64_t num_tables) {
+  static const int env = getenv("MI355_FUSED_PART") ? atoi(getenv("MI355_FUSED_PART")) : 1;
+  if (!env || num_tables != 1 || n < (64 << 10) || n > (int64_t)kPartMax * 1024) return 0;
+  return (int)((n + 1023) / 1024);
+}
+
+// slot-range partitions the fused forward would use for this batch / table (0: the per-slot-counter path)
+int mi355_demb_forward_fused_partitions(int64_t n, int64_t num_tables, int64_t num_buckets) {
+  const int P = part_count(n, num_tables);
+  return (P > 0 && num_buckets >= 8 * (int64_t)P) ? P : 0;
+}
+
 int64_t mi355_demb_forward_fused_workspace_bytes(int64_t n, int64_t num_tables) {
   const int64_t nt = (n + 1023) / 1024 + 2;
   return al256(8 * (num_tables + 1)) + al256(8 * n) /*unique keys*/ + al256(8 * n) /*occ_addr*/ + al256(4 * n) /*occ_slot*/ +
-         al256(4 * nt) + 256 /*total*/ + al256(8 * n) + 4 * al256(4 * n) /*deferred*/ + al256(8 * nt) /*look-back*/ + 256;
+         al256(4 * nt) + 256 /*total*/ + al256(8 * n) + 4 * al256(4 * n) /*deferred*/ + al256(16 * nt) /*look-back*/ + 256 +
+         (part_count(n, num_tables) ? 24 * (int64_t)part_count(n, num_tables) * kPartCap + 5 * 256 : 0) /*partition records*/;
 }
 
 // The fused forward (see the header of this file).  Persisted outputs as mi355_demb_forward; in eval mode (train == 0)
@@ -953,7 +1418,23 @@ int mi355_demb_forward_fused(
   a.d_cnt = (int32_t*)w; w += al256(4 * n);
   a.d_slot = (int32_t*)w; w += al256(4 * n);
   a.d_base = (int32_t*)w; w += al256(4 * n);
-  a.tstat = (unsigned long long*)w; w += al256(8 * nt);
+  a.tstat = (unsigned long long*)w; w += al256(16 * nt);
+  // partitioned index stage: one table, a batch of 64 K .. 1 M keys, at least 8 buckets per partition, training
+  a.P = 0; a.spp = 1; a.pcount = aux + 64;
+  a.rec = nullptr; a.rec_out = nullptr;
+  {
+    const int P = train ? part_count(n, num_tables) : 0;
+    if (P > 0 && num_buckets >= 8 * (int64_t)P) {
+      const int64_t per = ((S + 1 + P - 1) / P + bucket_capacity - 1) / bucket_capacity * bucket_capacity;
+      if (per < 0x7fffffffLL) {
+        a.P = P; a.spp = (int)per;
+        const int64_t nr = (int64_t)P * kPartCap;
+        a.rec = (uint4*)w; w += al256(16 * nr);
+        a.rec_out = (int2*)w; w += al256(8 * nr);
+      }
+    }
+  }
+  const bool part = a.P > 0;
   a.csr_rank = csr_rank;
   // backward workspace (row pointers, CSR, hot lists) -- carved before the probe launch, which clears the hot-list header
   int32_t* bptr = nullptr; int32_t* bcsr = nullptr; void* hot_ws = nullptr; int64_t hot_bytes_ = 0;
@@ -981,6 +1462,9 @@ int mi355_demb_forward_fused(
     if (train) hipLaunchKernelGGL((fused_probe_kernel<TILE, THREADS, true>), dim3(grid), dim3(THREADS), 0, stream, a);    \
     else hipLaunchKernelGGL((fused_probe_kernel<TILE, THREADS, false>), dim3(grid), dim3(THREADS), 0, stream, a);         \
   } while (0)
+    if (part) {
+      hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
+    } else
     switch (cfg) {
       case 1: LAUNCH_PROBE(1024, 256); break;
       case 2: LAUNCH_PROBE(2048, 512); break;
@@ -1029,15 +1513,19 @@ int mi355_demb_forward_fused(
     }
     HotList hot{};
     if (hot_ws) hot = hot_carve(hot_ws, n, emb_dim);
-    if (ntile <= kSelfPrefixMaxTiles) {
+    if (part) {
+      hipLaunchKernelGGL(fused_part_kernel, dim3((unsigned)a.P), dim3(kScanThreads), 0, cs, a, o, bptr, hot, hot_ws != nullptr);
+    } else if (ntile <= kSelfPrefixMaxTiles) {
       hipLaunchKernelGGL(fused_mid_kernel<true>, dim3((unsigned)ntile), dim3(kScanThreads), 0, cs, a, o, bptr, hot, hot_ws != nullptr, ncu);
     } else {
       hipLaunchKernelGGL(fused_scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, cs, a.partial, ntile);
       hipLaunchKernelGGL(fused_mid_kernel<false>, dim3((unsigned)ntile), dim3(kScanThreads), 0, cs, a, o, bptr, hot, hot_ws != nullptr, ncu);
     }
     MI355_LAUNCH_CHECK();
+    PartRefs prf;
+    if (part) { prf.rec_out = a.rec_out; prf.row_addr = row_addr; prf.occ_addr = a.occ_addr; }
     STEP(mi355i_csr_from_slots(csr_cnt, csr_rank, a.occ_slot, a.occ + 1, reverse_indices, n, combiner >= 0 ? offsets : nullptr,
-                               num_bags, nu_dev, nullptr, total, bptr, bcsr, hot_ws, hot_bytes_, emb_dim, 1, a.hdr, cs));
+                               num_bags, nu_dev, nullptr, total, bptr, bcsr, hot_ws, hot_bytes_, emb_dim, 1, a.hdr, part ? &prf : nullptr, cs));
     if (pin) STEP(mi355_table_update_counter(counter, counter_numel, slots, n, nu_dev, 1, table_ids, table_bucket_offsets,
                                              bucket_capacity, cs));
     if (forked) {

@@ -554,16 +554,20 @@ csr_fill_kernel(const int64_t* __restrict__ rev, int64_t n, const int64_t* __res
 // pass 2 when the forward already ranked every occurrence inside its unique row (mi355_segmented_unique_csr):
 // csr_src[ptr[rev[j]] + rank[j]] = src id of key j.  No atomics, no LDS hash; the bag resolution and the hot-row task
 // expansion are those of csr_fill_kernel.
-// kSlot: the unique id of key j is uidmap[2 * slot[j]] (fused forward, fused_fwd.hip: pairs per slot) and is also written to rev_out[j].
-template <bool kSlot>
+// kMode 1: the unique id of key j is uidmap[2 * slot[j]] (fused forward, fused_fwd.hip: pairs per slot) and is also written
+// to rev_out[j].  kMode 2 (partitioned fused forward): slot[j] is the key's (tile, key) record; the record knows the unique
+// id and the rank base of its tile inside the row's list (PartRefs); rank[j] is the rank inside the tile and is replaced by
+// the full rank; keys whose slot was found late (deferred eviction) get their row address here.
+template <int kMode>
 __global__ void __launch_bounds__(256)
-csr_scatter_kernel(const int64_t* __restrict__ rev, const int* __restrict__ rank, int64_t n, const int64_t* __restrict__ offsets,
+csr_scatter_kernel(const int64_t* __restrict__ rev, int* __restrict__ rank, int64_t n, const int64_t* __restrict__ offsets,
                    int64_t num_bags, const int* __restrict__ ptr, int* __restrict__ csr_src, HotList hot, bool build_hot,
                    const int* __restrict__ slot, const int* __restrict__ uidmap, int64_t* __restrict__ rev_out,
-                   int* __restrict__ hdr_reset = nullptr) {
+                   int* __restrict__ hdr_reset = nullptr, PartRefs pr = PartRefs{}) {
+  constexpr bool kSlot = kMode == 1;
   // fused forward: the deferred-key count, barrier words and release flag of the table's aux header are cleared for the
   // next step here, behind the numbering kernel that read them
-  if (hdr_reset && blockIdx.x == 0 && threadIdx.x < 64) hdr_reset[threadIdx.x] = 0;
+  if (hdr_reset && blockIdx.x == 0 && threadIdx.x < 64 && threadIdx.x != 5) hdr_reset[threadIdx.x] = 0;   // ([5]: sticky error flag)
   if (build_hot) {
     int nh = *hot.n_hot;
     nh = nh < hot.max_hot ? nh : hot.max_hot;
@@ -591,12 +595,23 @@ csr_scatter_kernel(const int64_t* __restrict__ rev, const int* __restrict__ rank
   constexpr int NQ = kHistTile / 256;
   int64_t r[NQ];
   int rk[NQ], p[NQ];
+  int rec[NQ], late[NQ];   // kMode 2
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     int64_t j = tile0 + q * 256 + threadIdx.x;
     j = j < n ? j : n - 1;
-    if constexpr (kSlot) r[q] = slot[j]; else r[q] = rev[j];
+    if constexpr (kMode != 0) r[q] = slot[j]; else r[q] = rev[j];
     rk[q] = rank[j];
+  }
+  if constexpr (kMode == 2) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      rec[q] = (int)r[q];
+      const int2 ro = pr.rec_out[rec[q] >= 0 ? rec[q] : 0];
+      r[q] = ro.x;
+      late[q] = ro.y < 0;
+      rk[q] += late[q] ? ~ro.y : ro.y;
+    }
   }
   if (offsets) {
     for (int k = threadIdx.x; k < kHistTile; k += blockDim.x) s_bag[k] = -1;
@@ -654,8 +669,17 @@ csr_scatter_kernel(const int64_t* __restrict__ rev, const int* __restrict__ rank
   for (int q = 0; q < NQ; ++q) {
     const int64_t j = tile0 + q * 256 + threadIdx.x;
     if (j < n) {
-      csr_src[p[q] + rk[q]] = offsets ? s_bag[q * 256 + threadIdx.x] : (int)j;
-      if constexpr (kSlot) rev_out[j] = r[q];
+      if constexpr (kMode == 2) {
+        if (rec[q] >= 0) {
+          csr_src[p[q] + rk[q]] = offsets ? s_bag[q * 256 + threadIdx.x] : (int)j;
+          rank[j] = rk[q];
+          if (late[q]) pr.occ_addr[j] = pr.row_addr[r[q]];
+        }
+        rev_out[j] = r[q];
+      } else {
+        csr_src[p[q] + rk[q]] = offsets ? s_bag[q * 256 + threadIdx.x] : (int)j;
+        if constexpr (kSlot) rev_out[j] = r[q];
+      }
     }
   }
 }
@@ -663,8 +687,23 @@ csr_scatter_kernel(const int64_t* __restrict__ rev, const int* __restrict__ rank
 __global__ void __launch_bounds__(256)
 rev_from_slots_kernel(const int* __restrict__ slot, const int* __restrict__ uidmap, int64_t n, int64_t* __restrict__ rev,
                       int* __restrict__ hdr_reset = nullptr) {
-  if (hdr_reset && blockIdx.x == 0 && threadIdx.x < 64) hdr_reset[threadIdx.x] = 0;
+  if (hdr_reset && blockIdx.x == 0 && threadIdx.x < 64 && threadIdx.x != 5) hdr_reset[threadIdx.x] = 0;   // ([5]: sticky error flag)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) rev[i] = uidmap[2 * (int64_t)slot[i]];
+}
+
+// partitioned fused forward without a backward workspace: reverse indices, full ranks and late row addresses only
+__global__ void __launch_bounds__(256)
+rev_from_records_kernel(const int* __restrict__ slot, PartRefs pr, int* __restrict__ rank, int64_t n, int64_t* __restrict__ rev,
+                        int* __restrict__ hdr_reset) {
+  if (hdr_reset && blockIdx.x == 0 && threadIdx.x < 64 && threadIdx.x != 5) hdr_reset[threadIdx.x] = 0;   // ([5]: sticky error flag)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int rc = slot[i];
+    if (rc < 0) { rev[i] = 0; continue; }
+    const int2 ro = pr.rec_out[rc];
+    rev[i] = ro.x;
+    rank[i] += ro.y < 0 ? ~ro.y : ro.y;
+    if (ro.y < 0) pr.occ_addr[i] = pr.row_addr[ro.x];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1223,7 +1262,7 @@ int mi355_group_by_unique_csr(const int32_t* csr_cnt, const int32_t* csr_rank, c
     hipLaunchKernelGGL(scan_down_kernel<false>, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, csr_cnt, max_unique, nu_dev, partial, total,
                        ptr, hot, hot_workspace != nullptr);
   }
-  if (n > 0) hipLaunchKernelGGL(csr_scatter_kernel<false>, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, reverse_indices, csr_rank, n,
+  if (n > 0) hipLaunchKernelGGL(csr_scatter_kernel<0>, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, reverse_indices, const_cast<int32_t*>(csr_rank), n,
                                 offsets, num_bags, ptr, csr_src, hot, hot_workspace != nullptr, (const int*)nullptr, (const int*)nullptr,
                                 (int64_t*)nullptr);
   MI355_LAUNCH_CHECK();
@@ -1237,7 +1276,8 @@ int mi355_group_by_unique_csr(const int32_t* csr_cnt, const int32_t* csr_rank, c
 int mi355i_csr_from_slots(const int32_t* csr_cnt, const int32_t* csr_rank, const int32_t* occ_slot, const int32_t* uidmap,
                           int64_t* reverse_indices, int64_t n, const int64_t* offsets, int64_t num_bags, const int64_t* nu_dev,
                           const int32_t* partial2, int32_t* total, int32_t* ptr, int32_t* csr_src, void* hot_workspace,
-                          int64_t hot_workspace_bytes, int64_t dim, int ptr_ready, int32_t* hdr_reset, hipStream_t stream) {
+                          int64_t hot_workspace_bytes, int64_t dim, int ptr_ready, int32_t* hdr_reset, const PartRefs* part,
+                          hipStream_t stream) {
   MI355_CHECK_ARG(n < 0x7fffffffLL, "n must be < 2^31");
   if (n == 0) return MI355_OK;
   const int64_t nbu = ceil_div(n + 1, kScanTile);
@@ -1257,9 +1297,17 @@ int mi355i_csr_from_slots(const int32_t* csr_cnt, const int32_t* csr_rank, const
       hipLaunchKernelGGL(scan_down_kernel<false>, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, csr_cnt, n, nu_dev, partial2, total, ptr,
                          hot, hot_workspace != nullptr);
     }
-    hipLaunchKernelGGL(csr_scatter_kernel<true>, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, (const int64_t*)nullptr,
-                       csr_rank, n, offsets, num_bags, ptr, csr_src, hot, hot_workspace != nullptr, occ_slot, uidmap, reverse_indices,
-                       hdr_reset);
+    if (part && part->rec_out)
+      hipLaunchKernelGGL(csr_scatter_kernel<2>, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, (const int64_t*)nullptr,
+                         const_cast<int32_t*>(csr_rank), n, offsets, num_bags, ptr, csr_src, hot, hot_workspace != nullptr, occ_slot,
+                         uidmap, reverse_indices, hdr_reset, *part);
+    else
+      hipLaunchKernelGGL(csr_scatter_kernel<1>, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, (const int64_t*)nullptr,
+                         const_cast<int32_t*>(csr_rank), n, offsets, num_bags, ptr, csr_src, hot, hot_workspace != nullptr, occ_slot,
+                         uidmap, reverse_indices, hdr_reset);
+  } else if (part && part->rec_out) {
+    hipLaunchKernelGGL(rev_from_records_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, occ_slot, *part,
+                       const_cast<int32_t*>(csr_rank), n, reverse_indices, hdr_reset);
   } else {
     hipLaunchKernelGGL(rev_from_slots_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, occ_slot, uidmap, n, reverse_indices,
                        hdr_reset);

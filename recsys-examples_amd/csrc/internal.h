@@ -48,10 +48,19 @@ int mi355i_table_update_counter_where(int32_t* counter, int64_t counter_numel, c
 
 // second half of the fused forward (fused_fwd.hip): scan of the per-unique counts, hot-row registration, CSR scatter and
 // reverse indices from the slot-indexed unique ids
+// records of the partitioned fused forward (fused_fwd.hip): per (tile, key) record the unique id and the rank base of the
+// tile inside the row's list; plus the per-unique row addresses and the per-occurrence address array that keys resolved
+// late (deferred eviction) are patched into
+struct PartRefs {
+  const int2* rec_out = nullptr;     // {unique id, rank base; ~base (< 0) when the row address was resolved late}
+  const int64_t* row_addr = nullptr;
+  int64_t* occ_addr = nullptr;
+};
 int mi355i_csr_from_slots(const int32_t* csr_cnt, const int32_t* csr_rank, const int32_t* occ_slot, const int32_t* uidmap,
                           int64_t* reverse_indices, int64_t n, const int64_t* offsets, int64_t num_bags, const int64_t* nu_dev,
                           const int32_t* partial2, int32_t* total, int32_t* ptr, int32_t* csr_src, void* hot_workspace,
-                          int64_t hot_workspace_bytes, int64_t dim, int ptr_ready, int32_t* hdr_reset, hipStream_t stream);
+                          int64_t hot_workspace_bytes, int64_t dim, int ptr_ready, int32_t* hdr_reset, const PartRefs* part,
+                          hipStream_t stream);
 
 // bench.py's live kernel timing (err.hip): event of slot (0 gather, 1 backward kernel), end 0 / 1
 void mi355i_prof_mark(int slot, int end, hipStream_t stream);

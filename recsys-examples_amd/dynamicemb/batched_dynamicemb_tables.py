@@ -630,10 +630,30 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         st.token = tok.value
         st.prepared = (2 + tok.value) if tok.value >= 0 else (1 if bwd_b and n > 0 else 0)
         if train:
+            self._check_partition_flag()
             self._step += 1
             if self._dynamicemb_options[0].safe_check_mode != DynamicEmbCheckMode.IGNORE:
                 self._safe_check(st)
         return out, st
+
+    def _check_partition_flag(self):
+        """The partitioned index stage gives every slot range a fixed number of (tile, key) records per step; if a range ever
+        receives more (a key stream that defeats the hash: never seen with real keys), the surplus keys of that step took no
+        part in its backward and the kernel left a sticky flag in the aux header.  Read without a sync (the flag travels to
+        pinned memory every 64 steps) and reported as an error: the remedy is MI355_FUSED_PART=0."""
+        ev = getattr(self, "_part_flag_event", None)
+        if ev is not None and ev.query():
+            self._part_flag_event = None
+            if int(self._part_flag_host.item()) != 0:
+                self._fused_aux[5:6].zero_()
+                raise RuntimeError("fused forward: a slot-range partition overflowed its record list in an earlier step "
+                                   "(keys of that step were left out of its backward); set MI355_FUSED_PART=0")
+        if ev is None and self._step % 64 == 0 and not torch.cuda.is_current_stream_capturing():
+            if getattr(self, "_part_flag_host", None) is None:
+                self._part_flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._part_flag_host.copy_(self._fused_aux[5:6], non_blocking=True)
+            self._part_flag_event = torch.cuda.Event()
+            self._part_flag_event.record()
 
     def _backward_fused(self, st, grads: torch.Tensor):
         grads = grads.contiguous()
