@@ -745,15 +745,20 @@ def test_early_csr_matches_late_grouping_and_survives_outstanding_steps(pooling)
     torch.testing.assert_close(tables[0][1], tables[1][1], rtol=1e-5, atol=1e-6)
 
 
-def test_training_step_is_hipgraph_capturable():
+@pytest.mark.parametrize("B,NK,cap,hi", [(128, 640, 8192, 3000), (8192, 70_000, 1 << 20, 300_000)],
+                         ids=["per_slot_counters", "slot_range_partitions"])
+def test_training_step_is_hipgraph_capturable(B, NK, cap, hi):
     """the step is a fixed launch sequence with every count on the device -- capture forward + backward of
     the module once in a HIP graph (static key / offset / gradient buffers), replay it on new batches, and compare the
-    table with an eager twin fed the same batches."""
+    table with an eager twin fed the same batches.  The second size takes the partitioned index stage (its counters are
+    cleared by the kernels themselves, so a replay starts clean)."""
     (B2, IA, IM, PM, SS, TO, OT) = _mods()
-    D, B, NK = 32, 128, 640
+    D = 32
+    from mi355_native import lib
+    assert (lib().mi355_demb_forward_fused_partitions(NK, 1, cap // 128) > 0) == (NK >= 65536)
 
     def make():
-        opts = [TO(dim=D, max_capacity=8192, index_type=torch.int64, embedding_dtype=torch.float32,
+        opts = [TO(dim=D, max_capacity=cap, index_type=torch.int64, embedding_dtype=torch.float32,
                    initializer_args=IA(mode=IM.UNIFORM, lower=-0.5, upper=0.5), score_strategy=SS.TIMESTAMP)]
         m = B2(table_options=opts, table_names=["t0"], feature_table_map=[0], pooling_mode=PM.SUM, optimizer=OT.SGD,
                learning_rate=0.1, output_dtype=torch.float32, device=torch.device(DEV))
@@ -765,7 +770,7 @@ def test_training_step_is_hipgraph_capturable():
     def batch():
         cuts = np.sort(rng.integers(0, NK + 1, B - 1))
         off = np.concatenate([[0], cuts, [NK]]).astype(np.int64)       # fixed number of keys, ragged bags
-        keys = rng.integers(0, 3000, NK).astype(np.int64)
+        keys = rng.integers(0, hi, NK).astype(np.int64)
         g = rng.standard_normal((B, D)).astype(np.float32)
         return torch.from_numpy(keys).to(DEV), torch.from_numpy(off).to(DEV), torch.from_numpy(g).to(DEV)
 
