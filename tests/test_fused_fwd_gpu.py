@@ -146,15 +146,16 @@ def _partitions(m, n):
     return int(lib().mi355_demb_forward_fused_partitions(n, m.num_tables, m.table.num_buckets_))
 
 
+@pytest.mark.parametrize("strategy", ["STEP", "LFU"])
 @pytest.mark.parametrize("bucket,n", [(128, 400_000), (16, 100_000)], ids=["per_slot_counters", "slot_range_partitions"])
-def test_many_deferred_keys_in_a_grid_larger_than_the_resident_group(bucket, n, monkeypatch):
+def test_many_deferred_keys_in_a_grid_larger_than_the_resident_group(bucket, n, strategy, monkeypatch):
     """a full table, a 400 K-key batch of old and new keys: thousands of keys find their bucket full and are deferred to the
     head of the numbering kernel, whose grid (391 blocks) is larger than the group of blocks that runs the eviction (one
     per CU) -- the later blocks wait for the release flag.  Checks: every key of the batch that has a slot reads its own
     row; keys of the batch are never evicted by the batch; the size stays at capacity; unique[reverse] == keys; the
     scratch counters are clean; the backward moves every row of the batch exactly once."""
     cap = 64 * 1024
-    m = _mk(True, (8,), cap=cap, pooling="NONE", strategy="STEP", learning_rate=1.0, bucket=bucket, monkeypatch=monkeypatch)
+    m = _mk(True, (8,), cap=cap, pooling="NONE", strategy=strategy, learning_rate=1.0, bucket=bucket, monkeypatch=monkeypatch)
     m.train()
     # the second configuration (4096 small buckets) takes the partitioned index stage: the deferred keys are evicted for
     # inside the block that owns their slot range (fused_part_kernel)
@@ -202,13 +203,14 @@ def _fmix64(k):
     return k
 
 
-def test_partitioned_stage_matches_the_per_slot_counter_path_and_flags_a_flooded_partition(monkeypatch):
+@pytest.mark.parametrize("strategy,opt", [("TIMESTAMP", "SGD"), ("LFU", "ADAM")])
+def test_partitioned_stage_matches_the_per_slot_counter_path_and_flags_a_flooded_partition(strategy, opt, monkeypatch):
     """(i) the partitioned index stage (one table, >= 64 K keys) and the per-slot-counter path (MI355_FUSED_PART=0) give the
     same pooled output, the same rows after a training step and the same table; (ii) a key stream built to land in ONE slot
     range floods that partition's record list: the surplus keys take no part in that step's bookkeeping, and the module
     reports the sticky flag instead of training on silently."""
     cap, C, n = 1 << 20, 128, 80_000
-    a = _mk(True, (16,), cap=cap, pooling="SUM", learning_rate=0.5, monkeypatch=monkeypatch)
+    a = _mk(True, (16,), cap=cap, pooling="SUM", learning_rate=0.5, strategy=strategy, opt=opt, monkeypatch=monkeypatch)
     assert _partitions(a, n) > 0
     rng = np.random.default_rng(2)
     lens = rng.integers(1, 9, size=n // 4)
@@ -229,7 +231,7 @@ from test_fused_fwd_gpu import _mk
 class MP:
     def setenv(self, k, v):
         import os; os.environ[k] = v
-m = _mk(True, (16,), cap={cap}, pooling="SUM", learning_rate=0.5, monkeypatch=MP())
+m = _mk(True, (16,), cap={cap}, pooling="SUM", learning_rate=0.5, strategy={strategy!r}, opt={opt!r}, monkeypatch=MP())
 keys = torch.from_numpy(np.load(sys.argv[1])).cuda(); off = torch.from_numpy(np.load(sys.argv[2])).cuda()
 m.train(); out = m(keys, off); out.backward(torch.ones_like(out))
 uk = torch.unique(keys); f, rows = m.lookup_rows(uk, 0)
