@@ -37,6 +37,12 @@ class TorchGlue:
         both = torch.stack([s[1:] - s[:-1], r[1:] - r[:-1]]).cpu()
         return both[0].tolist(), both[1].tolist()
 
+    def peer_splits_begin(self, send_offsets, recv_offsets, per_peer, world):
+        return self.peer_splits(send_offsets, recv_offsets, per_peer, world)
+
+    def peer_splits_end(self, handle):
+        return handle
+
     def chunk_bags(self, unique_offsets, num_tables, chunk, num_chunks):
         """per-table unique-key lists cut into `num_chunks` pseudo-bags of <= chunk keys -> (lengths, offsets)"""
         lo = unique_offsets[:-1].view(num_tables, 1)
@@ -113,17 +119,31 @@ class HipOps(TorchGlue):
         check(lib().mi355_exclusive_offsets(ptr(lengths), lengths.numel(), ptr(off), stream()), "exclusive_offsets")
         return off
 
-    def peer_splits(self, send_offsets, recv_offsets, per_peer, world):
+    def peer_splits_begin(self, send_offsets, recv_offsets, per_peer, world):
+        """launch the per-peer key counts into pinned host memory (a small ring: a later dist may start before an earlier one
+        has been read); peer_splits_end() waits for exactly this launch and reads them"""
         from mi355_native import check, lib, ptr, stream
 
-        buf = getattr(self, "_splits_host", None)
-        if buf is None or buf.numel() < 2 * world:
-            buf = self._splits_host = torch.empty(2 * world, dtype=torch.int64).pin_memory()
-        # the kernel writes straight into pinned host memory; the host waits for the stream, not for a copy
+        ring = getattr(self, "_splits_ring", None)
+        if ring is None or ring[0].numel() < 2 * world:
+            ring = self._splits_ring = [torch.empty(2 * world, dtype=torch.int64).pin_memory() for _ in range(4)]
+            self._splits_next = 0
+        buf = ring[self._splits_next % len(ring)]
+        self._splits_next += 1
+        # the kernel writes straight into pinned host memory; the host waits for an event, not for a copy
         check(lib().mi355_peer_splits(ptr(send_offsets), ptr(recv_offsets), per_peer, world, ptr(buf), stream()), "peer_splits")
-        torch.cuda.current_stream().synchronize()
+        ev = torch.cuda.Event()
+        ev.record()
+        return buf, ev, world
+
+    def peer_splits_end(self, handle):
+        buf, ev, world = handle
+        ev.synchronize()
         v = buf[:2 * world].tolist()
         return v[:world], v[world:]
+
+    def peer_splits(self, send_offsets, recv_offsets, per_peer, world):
+        return self.peer_splits_end(self.peer_splits_begin(send_offsets, recv_offsets, per_peer, world))
 
     def chunk_bags(self, unique_offsets, num_tables, chunk, num_chunks):
         from mi355_native import check, lib, ptr, stream
@@ -281,16 +301,24 @@ class RwSparseFeaturesDist:
         self.unbucketize_permute_tensor = None
 
     def forward(self, lengths: torch.Tensor, values: torch.Tensor, collapse_batch: bool = False,
-                offsets: Optional[torch.Tensor] = None) -> ShardedKeys:
+                offsets: Optional[torch.Tensor] = None, two_phase: bool = False):
+        """two_phase: return after the launch of the per-peer key counts (everything up to the one host read of the step);
+        `finish(state)` completes the exchange.  A caller that has other work to queue in between never waits for the
+        read.  (Only the exact exchange has a second phase; the fixed-capacity one returns the keys directly.)"""
         """collapse_batch: the batch dimension is only a local chunking of per-feature key lists (it may differ
         between ranks); the exchange then carries one bag per (rank, feature).  `offsets` (optional): the exclusive
         offsets of `lengths` when the caller already has them."""
         W, F, ops = self._world_size, self._num_features, self._ops
-        lengths = lengths.view(-1)
-        if lengths.dtype != torch.int64:
-            lengths = lengths.to(torch.int64)
-        assert lengths.numel() % F == 0
-        B = lengths.numel() // F
+        if lengths is None:
+            assert offsets is not None, "lengths or offsets required"
+            nbags = offsets.numel() - 1
+        else:
+            lengths = lengths.view(-1)
+            if lengths.dtype != torch.int64:
+                lengths = lengths.to(torch.int64)
+            nbags = lengths.numel()
+        assert nbags % F == 0
+        B = nbags // F
         if self._dist_codes is None or self._dist_codes.device != values.device:
             self._dist_codes = torch.tensor([DIST_TYPES[d] for d in self._dist_type_per_feature], dtype=torch.int32,
                                             device=values.device)
@@ -312,8 +340,19 @@ class RwSparseFeaturesDist:
         recv_lengths = torch.empty_like(new_lengths)
         dist.all_to_all_single(recv_lengths, new_lengths, group=self._pg)
         recv_offsets = ops.exclusive_offsets(recv_lengths)
-        # key counts per peer (the one host read of the step, as in KJTAllToAll)
-        send_splits, recv_splits = ops.peer_splits(new_offsets, recv_offsets, F * B, W)
+        # key counts per peer (the one host read of the step, as in KJTAllToAll): launched here, read in finish()
+        handle = ops.peer_splits_begin(new_offsets, recv_offsets, F * B, W)
+        state = (handle, new_values, perm, recv_lengths, recv_offsets, B)
+        if two_phase:
+            return state
+        return self.finish(state)
+
+    def finish(self, state) -> ShardedKeys:
+        """second half of the exact exchange: read the per-peer key counts (the host waits for the launch that wrote them,
+        which by now is usually long done) and send the keys"""
+        W, F, ops = self._world_size, self._num_features, self._ops
+        handle, new_values, perm, recv_lengths, recv_offsets, B = state
+        send_splits, recv_splits = ops.peer_splits_end(handle)
         n_send = sum(send_splits)  # == values.numel() unless the caller passed a padded key buffer
         new_values = new_values[:n_send]
         if perm is not None:

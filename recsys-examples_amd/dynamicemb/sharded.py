@@ -37,12 +37,32 @@ class _ShardedCtx:
 
 
 class PendingKeys:
-    """an input dist in flight on the exchange stream; wait() orders the current stream behind it and hands the keys over"""
+    """an input dist in flight on the exchange stream; wait() orders the current stream behind it and hands the keys over.
+    Two-phase form: `state` is what RwSparseFeaturesDist.forward(two_phase=True) left; finish() -- called when the caller
+    has queued its other work -- reads the per-peer key counts and sends the keys (still on the exchange stream)."""
 
-    def __init__(self, sk, event=None):
+    def __init__(self, sk, event=None, dist=None, state=None, comm=None, consumer=None):
         self._sk, self._event = sk, event
+        self._dist, self._state, self._comm, self._consumer = dist, state, comm, consumer
+
+    def finish(self):
+        if self._state is None:
+            return
+        state, self._state = self._state, None
+        if self._comm is None:
+            self._sk = self._dist.finish(state)
+            return
+        with torch.cuda.stream(self._comm):
+            sk = self._dist.finish(state)
+            ev = torch.cuda.Event()
+            ev.record(self._comm)
+        for t in (sk.lengths, sk.offsets, sk.values, sk.recv_offsets, sk.unbucketize_permute):
+            if t is not None and self._consumer is not None:
+                t.record_stream(self._consumer)      # allocated on the exchange stream, consumed on the caller's
+        self._sk, self._event = sk, ev
 
     def wait(self):
+        self.finish()
         if self._event is not None:
             torch.cuda.current_stream().wait_event(self._event)
             self._event = None
@@ -80,23 +100,30 @@ class RowWiseShardedLookup:
     # (what TorchRec's ShardedModule calls input_dist / compute / output_dist; forward() below runs them back to back)
     def dist_input(self, values: torch.Tensor, offsets: torch.Tensor, collapse_batch: bool = False,
                    lengths: Optional[torch.Tensor] = None):
-        if lengths is None:
-            lengths = offsets[1:] - offsets[:-1]
+        # (the dist only needs the offsets; lengths are derived on the device where a caller has none)
         return self.input_dist(lengths, values, collapse_batch, offsets=offsets)
 
     def dist_input_async(self, values: torch.Tensor, offsets: torch.Tensor, collapse_batch: bool = False,
-                         lengths: Optional[torch.Tensor] = None) -> PendingKeys:
+                         lengths: Optional[torch.Tensor] = None, two_phase: bool = False) -> PendingKeys:
         """The input dist of a LATER batch on the exchange stream (a side HIP stream), so that bucketize, the two
         all-to-alls and the one host read of their sizes run under whatever the caller has queued on its own stream -- the
         local lookup / backward of the current batch.  (north star: "all-to-all ... overlapped with local lookup on a side
         HIP stream"; reference precedent: the data-dist stream of train_pipeline.py:155-170,589-597.)  On the CPU (gloo
         tests) there are no streams: the dist runs in place, which still exercises the reordered schedule."""
+        two_phase = two_phase and not self.fixed_capacity and not collapse_batch
         if not values.is_cuda:
+            if two_phase:
+                return PendingKeys(None, dist=self.input_dist,
+                                   state=self.input_dist(lengths, values, collapse_batch, offsets=offsets, two_phase=True))
             return PendingKeys(self.dist_input(values, offsets, collapse_batch, lengths))
         if self._comm is None:
             self._comm = torch.cuda.Stream(device=values.device)
         cur = torch.cuda.current_stream()
         self._comm.wait_stream(cur)       # the batch tensors were produced on the caller's stream
+        if two_phase:
+            with torch.cuda.stream(self._comm):
+                state = self.input_dist(lengths, values, collapse_batch, offsets=offsets, two_phase=True)
+            return PendingKeys(None, dist=self.input_dist, state=state, comm=self._comm, consumer=cur)
         with torch.cuda.stream(self._comm):
             sk = self.dist_input(values, offsets, collapse_batch, lengths)
             ev = torch.cuda.Event()
@@ -194,12 +221,16 @@ class OverlappedSteps:
         sk = pend.wait()
         out_local, lctx = lk.lookup(sk, train)
         if next_batch is not None:
-            self._pending = lk.dist_input_async(*next_batch)
+            # first half only: bucketize, lengths exchange, key counts on their way to pinned memory.  The host read and the
+            # key exchange follow in backward(), when this step's work is queued -- the host never sits waiting for the read
+            self._pending = lk.dist_input_async(*next_batch, two_phase=True)
         out = lk.dist_output(sk, out_local)
         return out, _ShardedCtx(sk, lctx, sum(sk.send_splits))
 
     def backward(self, ctx: _ShardedCtx, grads: torch.Tensor) -> None:
         self.lookup.backward(ctx, grads)
+        if self._pending is not None:
+            self._pending.finish()
 
 
 class RowWiseShardedPooledRows:
@@ -348,4 +379,6 @@ class ShardedPooledLookup:
         return self.impl.forward(values, offsets, train)
 
     def backward(self, ctx, grads):
+        if self._steps is not None:
+            return self._steps.backward(ctx, grads)
         self.impl.backward(ctx, grads)
