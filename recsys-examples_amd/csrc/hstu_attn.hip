@@ -764,7 +764,15 @@ struct BwdAttnArgs {
   AttnArgs f;                  // q, k, v (+ strides); f.out unused
   const uint16_t* dout; int64_t do_row, do_head;
   uint16_t* dq; uint16_t* dk; uint16_t* dv;   // contiguous [T, H, D]
+  // dS exchange between the dK pass and the dQ pass (nullable): 32 x 32 sub-tiles of dS in the dK pass's register layout
+  // (lane = key, 16 query rows per lane: 32 bytes per lane, 2 KB per sub-tile), indexed [b][h][key group][query group]
+  uint16_t* ds_ws;
+  int ng;                      // 32-row groups per sequence the buffer is laid out for: ceil(max_seqlen / 32)
+  int bq_kv;                   // query rows per step of the dK pass (the dQ pass must know which sub-tiles it wrote)
 };
+__device__ __forceinline__ uint16_t* ds_tile(const BwdAttnArgs& g, int b, int h, int kg, int qg) {
+  return g.ds_ws + ((((int64_t)b * g.f.H + h) * g.ng + kg) * g.ng + qg) * 1024;   // 1024 bf16 = 2 KB
+}
 
 // pass A: one workgroup = 128 keys (32 per wave) of one (sequence, head); loops over query tiles of BQ rows.
 // MODE 0: dV and dK together (d <= 64).  Larger d: the two output accumulators plus the S / dP accumulators and the
@@ -946,6 +954,10 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
       if (kDK) {
         const u32x4_t y0 = {sk[0], sk[1], sk[2], sk[3]}, y1 = {sk[4], sk[5], sk[6], sk[7]};
         sf[2 * t] = __builtin_bit_cast(bf16x8_t, y0); sf[2 * t + 1] = __builtin_bit_cast(bf16x8_t, y1);
+        if (g.ds_ws && i0 + 32 * t < s.L) {   // hand dS to the dQ pass: the B-operand registers as they are, 32 bytes per lane
+          u32x4_t* tp = reinterpret_cast<u32x4_t*>(ds_tile(g, b, h, key0 >> 5, (i0 >> 5) + t)) + 2 * lane;
+          tp[0] = y0; tp[1] = y1;
+        }
       }
     }
     if (kDV) pin_agpr(acc_dv);
@@ -1173,6 +1185,136 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
   }
 }
 
+// pass B': dQ from the dS the dK pass left in HBM -- no S / dP recomputation (2 of the 3 GEMMs of the dQ pass) and no
+// SiLU: per 32-key sub-tile a wave loads its 2 KB of dS (lane-major, as the dK pass held it: lane = key), turns it into
+// its own operand layout (lane = query) with four hardware transpose reads from a wave-private LDS patch, and runs
+// dQ^T[D x q] += K^T[D x keys] dS^T[keys x q].  A sub-tile the dK pass did not visit (entirely masked) counts as zero.
+template <int D>
+__global__ void __launch_bounds__(256) hstu_bwd_q_ds_kernel(BwdAttnArgs g) {
+  const AttnArgs& a = g.f;
+  constexpr int BK = 32;
+  constexpr int TRS = TrStride<D>::value;
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  uint16_t* Kt = smem;                          // [BK][TRS] row-major K tile, read transposed
+  uint16_t* dSw = Kt + BK * TRS + 1024 * (threadIdx.x >> 6);   // wave-private dS patch (2 KB)
+
+  const int b = blockIdx.y, h = blockIdx.x;
+  SeqInfo s;
+  s.start = a.cu_seqlens[b];
+  s.L = a.cu_seqlens[b + 1] - s.start;
+  const int nblk = (s.L + kBM - 1) / kBM;
+  if ((int)blockIdx.z >= nblk) return;
+  const int m0 = (nblk - 1 - (int)blockIdx.z) * kBM;
+  s.has_ctx = a.num_contexts != nullptr;
+  s.has_tgt = a.num_targets != nullptr;
+  s.c = s.has_ctx ? a.num_contexts[b] : 0;
+  s.hlen = s.L - (s.has_tgt ? a.num_targets[b] : 0);
+  const int lane = lane_id(), wv = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int qrow0 = m0 + 32 * wv;
+  const int qi = qrow0 + l31;
+  const bool wave_live = qrow0 < s.L;
+  int last_row = m0 + kBM - 1 < s.L - 1 ? m0 + kBM - 1 : s.L - 1;
+  int n_end = s.L;
+  if (a.causal) { n_end = last_row + 1; if (s.has_ctx && m0 < s.c && s.hlen > n_end) n_end = s.hlen; }
+  int w_last = qrow0 + 31 < s.L - 1 ? qrow0 + 31 : s.L - 1;
+  int w_end = s.L;
+  if (a.causal) { w_end = w_last + 1; if (s.has_ctx && qrow0 < s.c && s.hlen > w_end) w_end = s.hlen; }
+  // query tile of the dK pass that holds this wave's rows
+  const int it_kv = (qrow0 / g.bq_kv) * g.bq_kv;
+
+  f32x16_t acc_dq[D / 32];
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_dq[dt][r] = 0.f;
+
+  const uint16_t* kbase = a.k + (int64_t)s.start * a.k_row + (int64_t)h * a.k_head;
+  RowTile<D, BK> k_rows;
+  // transpose-read addresses of the dS patch (see DESIGN.md / tr_frag): lane i of a 16-lane group points at the 8-byte
+  // chunk {4 consecutive queries} of key (i >> 2) of the 4-key group; the group's lane l receives keys 0..3 for ITS query
+  const int il = lane & 15, g16 = (lane >> 4) & 1;
+  const int tr_lane_off = ((32 * (il & 1) + 4 * hi + (il >> 2)) * 32 + (2 * g16 + ((il & 3) >> 1)) * 8) / 2;   // elements
+  typedef short v4s_t __attribute__((ext_vector_type(4)));
+  typedef short v8s_t __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) v4s_t* lds_v4s_t;
+
+  u32x4_t ds0 = {0u, 0u, 0u, 0u}, ds1 = {0u, 0u, 0u, 0u};
+  auto tile_written = [&](int n0) -> bool {   // did the dK pass visit sub-tile (keys n0.., this wave's queries)?
+    if (n0 >= s.L) return false;
+    const int nkv = (n0 / kBM) * kBM;
+    int jump = 0, c_end = 0;
+    if (a.causal) {
+      jump = (nkv / g.bq_kv) * g.bq_kv;
+      if (s.has_ctx && s.c > 0 && nkv < s.hlen) c_end = ((s.c + g.bq_kv - 1) / g.bq_kv) * g.bq_kv;
+    }
+    return it_kv < c_end || it_kv >= jump;
+  };
+  auto fetch_all = [&](int n) {
+    k_rows.fetch(kbase, a.k_row, n, s.L);
+    if (wave_live && n < w_end && tile_written(n)) {
+      const u32x4_t* tp = reinterpret_cast<const u32x4_t*>(ds_tile(g, b, h, n >> 5, qrow0 >> 5)) + 2 * lane;
+      ds0 = tp[0]; ds1 = tp[1];
+    } else {
+      ds0 = u32x4_t{0u, 0u, 0u, 0u}; ds1 = u32x4_t{0u, 0u, 0u, 0u};
+    }
+  };
+  if (n_end > 0) fetch_all(0);
+  for (int n0 = 0; n0 < n_end; n0 += BK) {
+    pin_agpr(acc_dq);
+    __syncthreads();
+    k_rows.commit_tr(Kt, n0, s.L);
+    *reinterpret_cast<u32x4_t*>(dSw + 16 * lane) = ds0;
+    *reinterpret_cast<u32x4_t*>(dSw + 16 * lane + 8) = ds1;
+    pin_agpr(acc_dq);
+    __syncthreads();
+    if (n0 + BK < n_end) fetch_all(n0 + BK);
+    pin_agpr(acc_dq);
+    if (!wave_live || n0 >= w_end) continue;
+    bf16x8_t sf[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const v4s_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(dSw + tr_lane_off + (8 * (2 * half)) * 16));
+      const v4s_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(dSw + tr_lane_off + (8 * (2 * half + 1)) * 16));
+      const v8s_t r = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+      sf[half] = __builtin_bit_cast(bf16x8_t, r);
+    }
+    {
+      constexpr int NDT = D / 32;
+      constexpr int DB = 8 < NDT ? 8 : NDT;
+      constexpr int NBAT2 = (BK / 16) * (NDT / DB);
+      bf16x8_t fk[2][DB];
+      auto load_t = [&](int bi, int buf) {
+        const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
+#pragma unroll
+        for (int u = 0; u < DB; ++u) fk[buf][u] = tr_frag<TRS>(Kt, dt0 + u, ks, lane, hi);
+      };
+      load_t(0, 0);
+#pragma unroll
+      for (int bi = 0; bi < NBAT2; ++bi) {
+        if (bi + 1 < NBAT2) load_t(bi + 1, (bi + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
+#pragma unroll
+        for (int u = 0; u < DB; ++u) mfma_a(acc_dq[dt0 + u], fk[bi & 1][u], sf[ks]);   // dQ^T[D x q]
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  fence_a(acc_dq);
+  if (qi < s.L) {
+    uint16_t* dqp = g.dq + ((int64_t)(s.start + qi) * a.H + h) * D;
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        uint2 o;
+        o.x = pack_bf16(acc_dq[dt][4 * g4 + 0], acc_dq[dt][4 * g4 + 1]);
+        o.y = pack_bf16(acc_dq[dt][4 * g4 + 2], acc_dq[dt][4 * g4 + 3]);
+        *reinterpret_cast<uint2*>(dqp + 32 * dt + 8 * g4 + 4 * hi) = o;
+      }
+  }
+}
+
 template <int D, int BQ, int MODE, bool kPre>
 static void launch_bwd_kv(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
   constexpr bool kDV = MODE != 2, kDK = MODE != 1;
@@ -1197,21 +1339,31 @@ static void launch_bwd_q(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
 }
 
 template <int D>
-static int launch_bwd(const BwdAttnArgs& g, int B, int max_seqlen, hipStream_t stream) {
+static void launch_bwd_q_ds(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
+  const size_t smem = (size_t)(32 * TrStride<D>::value + 4 * 1024) * sizeof(uint16_t);
+  hipLaunchKernelGGL((hstu_bwd_q_ds_kernel<D>), grid, dim3(256), smem, stream, g);
+}
+
+template <int D>
+static int launch_bwd(BwdAttnArgs g, int B, int max_seqlen, hipStream_t stream) {
   dim3 grid(g.f.H, B, (max_seqlen + kBM - 1) / kBM);   // block rank slowest: see launch_fwd
   if constexpr (D >= 256) {
     static const int var = getenv("MI355_HSTU_VAR") ? atoi(getenv("MI355_HSTU_VAR")) : 1;   // tuning sweeps only; measured best = 1
     if (var & 4) launch_bwd_kv<D, 64, 1, false>(g, grid, stream); else launch_bwd_kv<D, 64, 1, true>(g, grid, stream);
+    g.bq_kv = (var & 1) ? 64 : 32;
     if (var & 1) launch_bwd_kv<D, 64, 2, false>(g, grid, stream);
     else if (var & 8) launch_bwd_kv<D, 32, 2, false>(g, grid, stream);
     else launch_bwd_kv<D, 32, 2, true>(g, grid, stream);
-    if (var & 2) launch_bwd_q<D, 64, false>(g, grid, stream);
+    if (g.ds_ws) launch_bwd_q_ds<D>(g, grid, stream);
+    else if (var & 2) launch_bwd_q<D, 64, false>(g, grid, stream);
     else if (var & 16) launch_bwd_q<D, 32, false>(g, grid, stream);
     else launch_bwd_q<D, 32, true>(g, grid, stream);
   } else if constexpr (D >= 128) {
     launch_bwd_kv<D, 64, 1, false>(g, grid, stream);
+    g.bq_kv = 32;
     launch_bwd_kv<D, 32, 2, false>(g, grid, stream);
-    launch_bwd_q<D, 64, false>(g, grid, stream);
+    if (g.ds_ws) launch_bwd_q_ds<D>(g, grid, stream);
+    else launch_bwd_q<D, 64, false>(g, grid, stream);
   } else {
     launch_bwd_kv<D, 64, 0, false>(g, grid, stream);
     launch_bwd_q<D, 64, false>(g, grid, stream);
@@ -1347,7 +1499,17 @@ int mi355_append_kvcache(void* kv_cache, const int32_t* kv_indices, const int32_
 
 int64_t mi355_hstu_attn_bwd_workspace_bytes(int64_t total_tokens, int64_t num_heads, int64_t head_dim) {
   (void)total_tokens; (void)num_heads; (void)head_dim;
-  return 0;  // the two-pass backward needs no scratch (no fp32 dQ accumulator, no atomics)
+  return 0;  // the backward needs no scratch (no fp32 dQ accumulator, no atomics); see mi355_hstu_attn_bwd_ds_bytes
+}
+
+// Optional scratch of the backward: with a workspace of at least this size the dK pass leaves dS (bf16, 32 x 32 sub-tiles
+// in its register layout) for the dQ pass, which then skips the S / dP recomputation -- 2 of its 3 GEMMs and the SiLU.
+// 0: no exchange for this shape (head_dim < 128 runs dV and dK in one pass and keeps the recomputing dQ pass).
+int64_t mi355_hstu_attn_bwd_ds_bytes(int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen) {
+  static const int env = getenv("MI355_HSTU_DS") ? atoi(getenv("MI355_HSTU_DS")) : 1;
+  if (!env || head_dim < 128 || batch <= 0 || max_seqlen <= 0) return 0;
+  const int64_t ng = (max_seqlen + 31) / 32;
+  return batch * num_heads * ng * ng * 2048;
 }
 
 // hstu_varlen_bwd (corelib/hstu/csrc/hstu_attn/hstu_api.cpp:525-719).  dq, dk, dv: contiguous bf16 [total, H, d].
@@ -1357,7 +1519,6 @@ int mi355_hstu_attn_bwd(const void* dout, const void* q, const void* k, const vo
                         const int32_t* cu_seqlens, int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen,
                         const int32_t* num_contexts, const int32_t* num_targets, int64_t target_group_size, int causal,
                         float alpha, float scaling_seqlen, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
-  (void)workspace; (void)workspace_bytes;
   MI355_CHECK_ARG(head_dim == 32 || head_dim == 64 || head_dim == 128 || head_dim == 256,
                   "head_dim must be one of 32, 64, 128, 256 (hstu_api.cpp:391)");
   MI355_CHECK_ARG(target_group_size >= 1, "target_group_size must be >= 1");
@@ -1377,6 +1538,11 @@ int mi355_hstu_attn_bwd(const void* dout, const void* q, const void* k, const vo
   a.alpha = alpha; a.inv_scale = 1.0f / scaling_seqlen;
   g.dout = (const uint16_t*)dout; g.do_row = do_row_stride; g.do_head = do_head_stride;
   g.dq = (uint16_t*)dq; g.dk = (uint16_t*)dk; g.dv = (uint16_t*)dv;
+  g.ds_ws = nullptr; g.ng = (int)((max_seqlen + 31) / 32); g.bq_kv = 32;
+  {
+    const int64_t need = mi355_hstu_attn_bwd_ds_bytes(batch, num_heads, head_dim, max_seqlen);
+    if (need > 0 && workspace && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0) g.ds_ws = (uint16_t*)workspace;
+  }
   switch (head_dim) {
     case 32: return launch_bwd<32>(g, (int)batch, (int)max_seqlen, stream);
     case 64: return launch_bwd<64>(g, (int)batch, (int)max_seqlen, stream);

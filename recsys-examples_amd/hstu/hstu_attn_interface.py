@@ -25,11 +25,12 @@ N.register_signatures({
     "mi355_hstu_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p,
                             c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_int, c_f, c_f, c_p, c_i64, c_p],
     "mi355_hstu_attn_bwd_workspace_bytes": [c_i64, c_i64, c_i64],
+    "mi355_hstu_attn_bwd_ds_bytes": [c_i64, c_i64, c_i64, c_i64],
     "mi355_hstu_attn_fwd_kv": [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64,
                                c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_int, c_f, c_f, c_p, c_p, c_p, c_p, c_i64, c_p],
     "mi355_append_kvcache": [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p,
                              c_i64, c_i64, c_p],
-}, {"mi355_hstu_attn_bwd_workspace_bytes": c_i64})
+}, {"mi355_hstu_attn_bwd_workspace_bytes": c_i64, "mi355_hstu_attn_bwd_ds_bytes": c_i64})
 
 
 def _check_inputs(q, k, v, cu_q, cu_k, num_contexts, num_targets, window_size, rab, kv_cache, seqused_q, seqused_k):
@@ -113,6 +114,9 @@ def append_kvcache(append_key, append_value, batch_indices, positions, seqlen_of
     return kv_cache_table
 
 
+_DS_MAX_BYTES = int(__import__("os").environ.get("MI355_HSTU_DS_MAX_BYTES", str(8 << 30)))
+
+
 def hstu_varlen_bwd(dout, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_contexts, num_targets, target_group_size,
                     causal, alpha):
     """Raw backward (stands in for hstu_varlen_bwd_80 / varlen_bwd): returns (dq, dk, dv)."""
@@ -123,7 +127,12 @@ def hstu_varlen_bwd(dout, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_c
     dv = torch.empty_like(dq)
     B = cu_seqlens.numel() - 1
     wsb = lib().mi355_hstu_attn_bwd_workspace_bytes(T, H, D)
-    ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=q.device)
+    # optional dS exchange between the dK and dQ passes (saves the dQ pass its S / dP recomputation); skipped when the
+    # buffer would be larger than MI355_HSTU_DS_MAX_BYTES (default 8 GiB: 32 x 4 heads x L = 4096 takes 4.3 GB)
+    dsb = lib().mi355_hstu_attn_bwd_ds_bytes(B, H, D, int(max_seqlen))
+    if dsb > _DS_MAX_BYTES:
+        dsb = 0
+    ws = torch.empty(max(wsb, dsb, 256), dtype=torch.uint8, device=q.device)
     check(lib().mi355_hstu_attn_bwd(ptr(dout), ptr(q), ptr(k), ptr(v), ptr(dq), ptr(dk), ptr(dv), q.stride(0), k.stride(0),
                                     v.stride(0), dout.stride(0), q.stride(1), k.stride(1), v.stride(1), dout.stride(1),
                                     ptr(cu_seqlens), B, H, D, int(max_seqlen), ptr(num_contexts), ptr(num_targets),
