@@ -767,11 +767,15 @@ struct BwdAttnArgs {
   // dS exchange between the dK pass and the dQ pass (nullable): 32 x 32 sub-tiles of dS in the dK pass's register layout
   // (lane = key, 16 query rows per lane: 32 bytes per lane, 2 KB per sub-tile), indexed [b][h][key group][query group]
   uint16_t* ds_ws;
+  uint16_t* p_ws;              // same layout, P = SiLU(alpha S) / scale: the dV pass then needs no S recomputation either
   int ng;                      // 32-row groups per sequence the buffer is laid out for: ceil(max_seqlen / 32)
   int bq_kv;                   // query rows per step of the dK pass (the dQ pass must know which sub-tiles it wrote)
 };
+__device__ __forceinline__ int64_t xch_tile(const BwdAttnArgs& g, int b, int h, int kg, int qg) {
+  return ((((int64_t)b * g.f.H + h) * g.ng + kg) * g.ng + qg) * 1024;   // 1024 bf16 = 2 KB
+}
 __device__ __forceinline__ uint16_t* ds_tile(const BwdAttnArgs& g, int b, int h, int kg, int qg) {
-  return g.ds_ws + ((((int64_t)b * g.f.H + h) * g.ng + kg) * g.ng + qg) * 1024;   // 1024 bf16 = 2 KB
+  return g.ds_ws + xch_tile(g, b, h, kg, qg);
 }
 
 // pass A: one workgroup = 128 keys (32 per wave) of one (sequence, head); loops over query tiles of BQ rows.
@@ -779,10 +783,10 @@ __device__ __forceinline__ uint16_t* ds_tile(const BwdAttnArgs& g, int b, int h,
 // K / V fragments exceed the register file of one wave, so the pass is split: MODE 1 = dV only (S -> P -> dV),
 // MODE 2 = dK only (S, dP -> dS -> dK).  Loop structure as in the forward: register-prefetched tiles, explicit
 // AGPR output accumulators, double-buffered LDS fragment batches, branch-free mask.
-template <int D, int BQ, int MODE, bool kPre>
+template <int D, int BQ, int MODE, bool kPre, bool kXP = false>
 __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
   const AttnArgs& a = g.f;
-  constexpr bool kDV = MODE != 2, kDK = MODE != 1;
+  constexpr bool kDV = MODE != 2, kDK = MODE != 1;   // kXP (MODE 2): P is computed as well and left for the dV pass
   constexpr int RS = D + 8, TS = BQ + 8, NT = BQ / 32;
   constexpr bool kTR = HSTU_BWD_TR != 0;            // Q^T / dO^T operands by transpose reads from row-major images
   constexpr int TRS = TrStride<D>::value;
@@ -938,14 +942,20 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
           }
           const float acc = acc_s[t][rr];
           const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc * neg_alpha_log2e));
-          if (kDV) p2[u] = ok ? acc * c_p * sg : 0.f;
+          if (kDV || kXP) p2[u] = ok ? acc * c_p * sg : 0.f;
           if (kDK) {
             const float x = acc * a.alpha;
             s2[u] = ok ? acc_p[t][rr] * c_ds * sg * (1.0f + x * (1.0f - sg)) : 0.f;
           }
         }
-        if (kDV) pk[r >> 1] = pack_bf16(p2[0], p2[1]);
+        if (kDV || kXP) pk[r >> 1] = pack_bf16(p2[0], p2[1]);
         if (kDK) sk[r >> 1] = pack_bf16(s2[0], s2[1]);
+      }
+      if constexpr (kXP) {
+        if (i0 + 32 * t < s.L) {   // P for the dV pass, same layout as dS below
+          u32x4_t* tp = reinterpret_cast<u32x4_t*>(g.p_ws + xch_tile(g, b, h, key0 >> 5, (i0 >> 5) + t)) + 2 * lane;
+          tp[0] = u32x4_t{pk[0], pk[1], pk[2], pk[3]}; tp[1] = u32x4_t{pk[4], pk[5], pk[6], pk[7]};
+        }
       }
       if (kDV) {
         const u32x4_t x0 = {pk[0], pk[1], pk[2], pk[3]}, x1 = {pk[4], pk[5], pk[6], pk[7]};
@@ -1315,17 +1325,114 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_ds_kernel(BwdAttnArgs g) {
   }
 }
 
-template <int D, int BQ, int MODE, bool kPre>
+// pass A': dV from the P the dK pass left in HBM -- the key-block owner loads, per 32-query sub-tile, its 2 KB of P straight
+// into the B-operand registers (the dK pass's lane = key layout IS the operand layout here) and runs
+// dV^T[D x keys] += dO^T[D x q] P[q x keys] against a transposed read of the staged dO rows: one GEMM, no SiLU.
+template <int D>
+__global__ void __launch_bounds__(256) hstu_bwd_v_p_kernel(BwdAttnArgs g) {
+  const AttnArgs& a = g.f;
+  constexpr int TRS = TrStride<D>::value;
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  uint16_t* dOt = smem;                         // [32][TRS] row-major dO tile, read transposed
+  const int b = blockIdx.y, h = blockIdx.x;
+  SeqInfo s;
+  s.start = a.cu_seqlens[b];
+  s.L = a.cu_seqlens[b + 1] - s.start;
+  const int n0 = blockIdx.z * kBM;
+  if (n0 >= s.L) return;
+  s.has_ctx = a.num_contexts != nullptr;
+  s.has_tgt = a.num_targets != nullptr;
+  s.c = s.has_ctx ? a.num_contexts[b] : 0;
+  s.hlen = s.L - (s.has_tgt ? a.num_targets[b] : 0);
+  const int lane = lane_id(), wv = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int key0 = n0 + 32 * wv;
+  const int kj = key0 + l31;
+  const bool wave_live = key0 < s.L;
+  const uint16_t* dobase = g.dout + (int64_t)s.start * g.do_row + (int64_t)h * g.do_head;
+  f32x16_t acc_dv[D / 32];
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_dv[dt][r] = 0.f;
+  // the 32-row query tiles the dK pass visited for this key block (its tiles are bq_kv rows: same set, finer steps)
+  int jump = 0, c_end = 0;
+  if (a.causal) {
+    jump = (n0 / g.bq_kv) * g.bq_kv;
+    if (s.has_ctx && s.c > 0 && n0 < s.hlen) c_end = ((s.c + g.bq_kv - 1) / g.bq_kv) * g.bq_kv;
+  }
+  auto advance = [&](int i) { i += 32; return (i >= c_end && i < jump) ? jump : i; };
+  int i0 = c_end > 0 ? 0 : jump;
+  RowTile<D, 32> do_rows;
+  u32x4_t p0 = {0u, 0u, 0u, 0u}, p1 = {0u, 0u, 0u, 0u};
+  auto fetch_all = [&](int i) {
+    do_rows.fetch(dobase, g.do_row, i, s.L);
+    if (wave_live) {
+      const u32x4_t* tp = reinterpret_cast<const u32x4_t*>(g.p_ws + xch_tile(g, b, h, key0 >> 5, i >> 5)) + 2 * lane;
+      p0 = tp[0]; p1 = tp[1];
+    }
+  };
+  if (i0 < s.L) fetch_all(i0);
+  for (; i0 < s.L; i0 = advance(i0)) {
+    pin_agpr(acc_dv);
+    __syncthreads();
+    do_rows.commit_tr(dOt, i0, s.L);
+    const bf16x8_t pf[2] = {__builtin_bit_cast(bf16x8_t, p0), __builtin_bit_cast(bf16x8_t, p1)};
+    pin_agpr(acc_dv);
+    __syncthreads();
+    {
+      const int nx = advance(i0);
+      if (nx < s.L) fetch_all(nx);
+    }
+    pin_agpr(acc_dv);
+    if (!wave_live) continue;
+    {
+      constexpr int NDT = D / 32;
+      constexpr int DB = 8 < NDT ? 8 : NDT;
+      constexpr int NBAT2 = 2 * (NDT / DB);
+      bf16x8_t fa[2][DB];
+      auto load_t = [&](int bi, int buf) {
+        const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
+#pragma unroll
+        for (int u = 0; u < DB; ++u) fa[buf][u] = tr_frag<TRS>(dOt, dt0 + u, ks, lane, hi);
+      };
+      load_t(0, 0);
+#pragma unroll
+      for (int bi = 0; bi < NBAT2; ++bi) {
+        if (bi + 1 < NBAT2) load_t(bi + 1, (bi + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
+#pragma unroll
+        for (int u = 0; u < DB; ++u) mfma_a(acc_dv[dt0 + u], fa[bi & 1][u], pf[ks]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  fence_a(acc_dv);
+  if (kj < s.L) {
+    uint16_t* dvp = g.dv + ((int64_t)(s.start + kj) * a.H + h) * D;
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        uint2 o;
+        o.x = pack_bf16(acc_dv[dt][4 * g4 + 0], acc_dv[dt][4 * g4 + 1]);
+        o.y = pack_bf16(acc_dv[dt][4 * g4 + 2], acc_dv[dt][4 * g4 + 3]);
+        *reinterpret_cast<uint2*>(dvp + 32 * dt + 8 * g4 + 4 * hi) = o;
+      }
+  }
+}
+
+template <int D, int BQ, int MODE, bool kPre, bool kXP = false>
 static void launch_bwd_kv(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
   constexpr bool kDV = MODE != 2, kDK = MODE != 1;
   const size_t timg = HSTU_BWD_TR ? (size_t)BQ * (D == 32 ? 32 : D + 32) : (size_t)D * (BQ + 8);
   const size_t smem = (size_t)(BQ * (D + 8) + (kDK ? BQ * (D + 8) + timg : 0) + (kDV ? timg : 0)) * sizeof(uint16_t);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_kv_kernel<D, BQ, MODE, kPre>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_kv_kernel<D, BQ, MODE, kPre, kXP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((hstu_bwd_kv_kernel<D, BQ, MODE, kPre>), grid, dim3(256), smem, stream, g);
+  hipLaunchKernelGGL((hstu_bwd_kv_kernel<D, BQ, MODE, kPre, kXP>), grid, dim3(256), smem, stream, g);
 }
 template <int D, int BK, bool kPre>
 static void launch_bwd_q(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
@@ -1339,6 +1446,12 @@ static void launch_bwd_q(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
 }
 
 template <int D>
+static void launch_bwd_v_p(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
+  const size_t smem = (size_t)(32 * TrStride<D>::value) * sizeof(uint16_t);
+  hipLaunchKernelGGL((hstu_bwd_v_p_kernel<D>), grid, dim3(256), smem, stream, g);
+}
+
+template <int D>
 static void launch_bwd_q_ds(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
   const size_t smem = (size_t)(32 * TrStride<D>::value + 4 * 1024) * sizeof(uint16_t);
   hipLaunchKernelGGL((hstu_bwd_q_ds_kernel<D>), grid, dim3(256), smem, stream, g);
@@ -1349,8 +1462,16 @@ static int launch_bwd(BwdAttnArgs g, int B, int max_seqlen, hipStream_t stream) 
   dim3 grid(g.f.H, B, (max_seqlen + kBM - 1) / kBM);   // block rank slowest: see launch_fwd
   if constexpr (D >= 256) {
     static const int var = getenv("MI355_HSTU_VAR") ? atoi(getenv("MI355_HSTU_VAR")) : 1;   // tuning sweeps only; measured best = 1
-    if (var & 4) launch_bwd_kv<D, 64, 1, false>(g, grid, stream); else launch_bwd_kv<D, 64, 1, true>(g, grid, stream);
     g.bq_kv = (var & 1) ? 64 : 32;
+    if (g.p_ws) {          // dK pass first (it writes P and dS), then the two one-GEMM passes
+      launch_bwd_kv<D, 64, 2, false, true>(g, grid, stream);
+      g.bq_kv = 64;
+      launch_bwd_v_p<D>(g, grid, stream);
+      launch_bwd_q_ds<D>(g, grid, stream);
+      MI355_LAUNCH_CHECK();
+      return MI355_OK;
+    }
+    if (var & 4) launch_bwd_kv<D, 64, 1, false>(g, grid, stream); else launch_bwd_kv<D, 64, 1, true>(g, grid, stream);
     if (var & 1) launch_bwd_kv<D, 64, 2, false>(g, grid, stream);
     else if (var & 8) launch_bwd_kv<D, 32, 2, false>(g, grid, stream);
     else launch_bwd_kv<D, 32, 2, true>(g, grid, stream);
@@ -1359,8 +1480,15 @@ static int launch_bwd(BwdAttnArgs g, int B, int max_seqlen, hipStream_t stream) 
     else if (var & 16) launch_bwd_q<D, 32, false>(g, grid, stream);
     else launch_bwd_q<D, 32, true>(g, grid, stream);
   } else if constexpr (D >= 128) {
-    launch_bwd_kv<D, 64, 1, false>(g, grid, stream);
     g.bq_kv = 32;
+    if (g.p_ws) {
+      launch_bwd_kv<D, 32, 2, false, true>(g, grid, stream);
+      launch_bwd_v_p<D>(g, grid, stream);
+      launch_bwd_q_ds<D>(g, grid, stream);
+      MI355_LAUNCH_CHECK();
+      return MI355_OK;
+    }
+    launch_bwd_kv<D, 64, 1, false>(g, grid, stream);
     launch_bwd_kv<D, 32, 2, false>(g, grid, stream);
     if (g.ds_ws) launch_bwd_q_ds<D>(g, grid, stream);
     else launch_bwd_q<D, 64, false>(g, grid, stream);
@@ -1508,8 +1636,9 @@ int64_t mi355_hstu_attn_bwd_workspace_bytes(int64_t total_tokens, int64_t num_he
 int64_t mi355_hstu_attn_bwd_ds_bytes(int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen) {
   static const int env = getenv("MI355_HSTU_DS") ? atoi(getenv("MI355_HSTU_DS")) : 1;
   if (!env || head_dim < 128 || batch <= 0 || max_seqlen <= 0) return 0;
+  static const int envp = getenv("MI355_HSTU_XP") ? atoi(getenv("MI355_HSTU_XP")) : 1;
   const int64_t ng = (max_seqlen + 31) / 32;
-  return batch * num_heads * ng * ng * 2048;
+  return batch * num_heads * ng * ng * 2048 * (envp ? 2 : 1);   // dS, and P behind it
 }
 
 // hstu_varlen_bwd (corelib/hstu/csrc/hstu_attn/hstu_api.cpp:525-719).  dq, dk, dv: contiguous bf16 [total, H, d].
@@ -1541,7 +1670,12 @@ int mi355_hstu_attn_bwd(const void* dout, const void* q, const void* k, const vo
   g.ds_ws = nullptr; g.ng = (int)((max_seqlen + 31) / 32); g.bq_kv = 32;
   {
     const int64_t need = mi355_hstu_attn_bwd_ds_bytes(batch, num_heads, head_dim, max_seqlen);
-    if (need > 0 && workspace && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0) g.ds_ws = (uint16_t*)workspace;
+    g.p_ws = nullptr;
+    if (need > 0 && workspace && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0) {
+      g.ds_ws = (uint16_t*)workspace;
+      const int64_t one = batch * num_heads * (int64_t)g.ng * g.ng * 2048;
+      if (need >= 2 * one) g.p_ws = (uint16_t*)((uint8_t*)workspace + one);
+    }
   }
   switch (head_dim) {
     case 32: return launch_bwd<32>(g, (int)batch, (int)max_seqlen, stream);
