@@ -1202,11 +1202,11 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
 template <int D>
 __global__ void __launch_bounds__(256) hstu_bwd_q_ds_kernel(BwdAttnArgs g) {
   const AttnArgs& a = g.f;
-  constexpr int BK = 32;
+  constexpr int BK = 64, NT = BK / 32;   // two 32-key sub-tiles per step: twice the MFMAs per barrier pair
   constexpr int TRS = TrStride<D>::value;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   uint16_t* Kt = smem;                          // [BK][TRS] row-major K tile, read transposed
-  uint16_t* dSw = Kt + BK * TRS + 1024 * (threadIdx.x >> 6);   // wave-private dS patch (2 KB)
+  uint16_t* dSw = Kt + BK * TRS + NT * 1024 * (threadIdx.x >> 6);   // wave-private dS patch (2 KB per sub-tile)
 
   const int b = blockIdx.y, h = blockIdx.x;
   SeqInfo s;
@@ -1248,7 +1248,7 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_ds_kernel(BwdAttnArgs g) {
   typedef short v8s_t __attribute__((ext_vector_type(8)));
   typedef __attribute__((address_space(3))) v4s_t* lds_v4s_t;
 
-  u32x4_t ds0 = {0u, 0u, 0u, 0u}, ds1 = {0u, 0u, 0u, 0u};
+  u32x4_t ds0[NT], ds1[NT];
   auto tile_written = [&](int n0) -> bool {   // did the dK pass visit sub-tile (keys n0.., this wave's queries)?
     if (n0 >= s.L) return false;
     const int nkv = (n0 / kBM) * kBM;
@@ -1261,11 +1261,15 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_ds_kernel(BwdAttnArgs g) {
   };
   auto fetch_all = [&](int n) {
     k_rows.fetch(kbase, a.k_row, n, s.L);
-    if (wave_live && n < w_end && tile_written(n)) {
-      const u32x4_t* tp = reinterpret_cast<const u32x4_t*>(ds_tile(g, b, h, n >> 5, qrow0 >> 5)) + 2 * lane;
-      ds0 = tp[0]; ds1 = tp[1];
-    } else {
-      ds0 = u32x4_t{0u, 0u, 0u, 0u}; ds1 = u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int nt = n + 32 * t;
+      if (wave_live && nt < w_end && tile_written(nt)) {
+        const u32x4_t* tp = reinterpret_cast<const u32x4_t*>(ds_tile(g, b, h, nt >> 5, qrow0 >> 5)) + 2 * lane;
+        ds0[t] = tp[0]; ds1[t] = tp[1];
+      } else {
+        ds0[t] = u32x4_t{0u, 0u, 0u, 0u}; ds1[t] = u32x4_t{0u, 0u, 0u, 0u};
+      }
     }
   };
   if (n_end > 0) fetch_all(0);
@@ -1273,21 +1277,27 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_ds_kernel(BwdAttnArgs g) {
     pin_agpr(acc_dq);
     __syncthreads();
     k_rows.commit_tr(Kt, n0, s.L);
-    *reinterpret_cast<u32x4_t*>(dSw + 16 * lane) = ds0;
-    *reinterpret_cast<u32x4_t*>(dSw + 16 * lane + 8) = ds1;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      *reinterpret_cast<u32x4_t*>(dSw + 1024 * t + 16 * lane) = ds0[t];
+      *reinterpret_cast<u32x4_t*>(dSw + 1024 * t + 16 * lane + 8) = ds1[t];
+    }
     pin_agpr(acc_dq);
     __syncthreads();
     if (n0 + BK < n_end) fetch_all(n0 + BK);
     pin_agpr(acc_dq);
     if (!wave_live || n0 >= w_end) continue;
-    bf16x8_t sf[2];
+    bf16x8_t sf[2 * NT];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const v4s_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(dSw + tr_lane_off + (8 * (2 * half)) * 16));
-      const v4s_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(dSw + tr_lane_off + (8 * (2 * half + 1)) * 16));
-      const v8s_t r = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-      sf[half] = __builtin_bit_cast(bf16x8_t, r);
-    }
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const uint16_t* pp = dSw + 1024 * t + tr_lane_off;
+        const v4s_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(pp + (8 * (2 * half)) * 16));
+        const v4s_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(pp + (8 * (2 * half + 1)) * 16));
+        const v8s_t r = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        sf[2 * t + half] = __builtin_bit_cast(bf16x8_t, r);
+      }
     {
       constexpr int NDT = D / 32;
       constexpr int DB = 8 < NDT ? 8 : NDT;
@@ -1333,7 +1343,8 @@ __global__ void __launch_bounds__(256) hstu_bwd_v_p_kernel(BwdAttnArgs g) {
   const AttnArgs& a = g.f;
   constexpr int TRS = TrStride<D>::value;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-  uint16_t* dOt = smem;                         // [32][TRS] row-major dO tile, read transposed
+  constexpr int BQ = 64, NT = BQ / 32;          // two 32-query sub-tiles per step
+  uint16_t* dOt = smem;                         // [BQ][TRS] row-major dO tile, read transposed
   const int b = blockIdx.y, h = blockIdx.x;
   SeqInfo s;
   s.start = a.cu_seqlens[b];
@@ -1354,21 +1365,30 @@ __global__ void __launch_bounds__(256) hstu_bwd_v_p_kernel(BwdAttnArgs g) {
   for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_dv[dt][r] = 0.f;
-  // the 32-row query tiles the dK pass visited for this key block (its tiles are bq_kv rows: same set, finer steps)
+  // the query rows the dK pass visited for this key block, in steps of BQ rows (its own steps are bq_kv rows: a sub-tile
+  // of a step may lie outside the visited set -- or past the sequence -- and then counts as zero)
   int jump = 0, c_end = 0;
   if (a.causal) {
     jump = (n0 / g.bq_kv) * g.bq_kv;
     if (s.has_ctx && s.c > 0 && n0 < s.hlen) c_end = ((s.c + g.bq_kv - 1) / g.bq_kv) * g.bq_kv;
   }
-  auto advance = [&](int i) { i += 32; return (i >= c_end && i < jump) ? jump : i; };
-  int i0 = c_end > 0 ? 0 : jump;
-  RowTile<D, 32> do_rows;
-  u32x4_t p0 = {0u, 0u, 0u, 0u}, p1 = {0u, 0u, 0u, 0u};
+  const int jump_s = (jump / BQ) * BQ, cend_s = ((c_end + BQ - 1) / BQ) * BQ;
+  auto advance = [&](int i) { i += BQ; return (i >= cend_s && i < jump_s) ? jump_s : i; };
+  auto visited = [&](int i) { return i < s.L && (i < c_end || i >= jump); };
+  int i0 = c_end > 0 ? 0 : jump_s;
+  RowTile<D, BQ> do_rows;
+  u32x4_t p0[NT], p1[NT];
   auto fetch_all = [&](int i) {
     do_rows.fetch(dobase, g.do_row, i, s.L);
-    if (wave_live) {
-      const u32x4_t* tp = reinterpret_cast<const u32x4_t*>(g.p_ws + xch_tile(g, b, h, key0 >> 5, i >> 5)) + 2 * lane;
-      p0 = tp[0]; p1 = tp[1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int it = i + 32 * t;
+      if (wave_live && visited(it)) {
+        const u32x4_t* tp = reinterpret_cast<const u32x4_t*>(g.p_ws + xch_tile(g, b, h, key0 >> 5, it >> 5)) + 2 * lane;
+        p0[t] = tp[0]; p1[t] = tp[1];
+      } else {
+        p0[t] = u32x4_t{0u, 0u, 0u, 0u}; p1[t] = u32x4_t{0u, 0u, 0u, 0u};
+      }
     }
   };
   if (i0 < s.L) fetch_all(i0);
@@ -1376,7 +1396,9 @@ __global__ void __launch_bounds__(256) hstu_bwd_v_p_kernel(BwdAttnArgs g) {
     pin_agpr(acc_dv);
     __syncthreads();
     do_rows.commit_tr(dOt, i0, s.L);
-    const bf16x8_t pf[2] = {__builtin_bit_cast(bf16x8_t, p0), __builtin_bit_cast(bf16x8_t, p1)};
+    bf16x8_t pf[2 * NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { pf[2 * t] = __builtin_bit_cast(bf16x8_t, p0[t]); pf[2 * t + 1] = __builtin_bit_cast(bf16x8_t, p1[t]); }
     pin_agpr(acc_dv);
     __syncthreads();
     {
@@ -1388,7 +1410,7 @@ __global__ void __launch_bounds__(256) hstu_bwd_v_p_kernel(BwdAttnArgs g) {
     {
       constexpr int NDT = D / 32;
       constexpr int DB = 8 < NDT ? 8 : NDT;
-      constexpr int NBAT2 = 2 * (NDT / DB);
+      constexpr int NBAT2 = (BQ / 16) * (NDT / DB);
       bf16x8_t fa[2][DB];
       auto load_t = [&](int bi, int buf) {
         const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
@@ -1447,13 +1469,13 @@ static void launch_bwd_q(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
 
 template <int D>
 static void launch_bwd_v_p(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
-  const size_t smem = (size_t)(32 * TrStride<D>::value) * sizeof(uint16_t);
+  const size_t smem = (size_t)(64 * TrStride<D>::value) * sizeof(uint16_t);
   hipLaunchKernelGGL((hstu_bwd_v_p_kernel<D>), grid, dim3(256), smem, stream, g);
 }
 
 template <int D>
 static void launch_bwd_q_ds(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
-  const size_t smem = (size_t)(32 * TrStride<D>::value + 4 * 1024) * sizeof(uint16_t);
+  const size_t smem = (size_t)(64 * TrStride<D>::value + 4 * 2 * 1024) * sizeof(uint16_t);
   hipLaunchKernelGGL((hstu_bwd_q_ds_kernel<D>), grid, dim3(256), smem, stream, g);
 }
 

@@ -114,7 +114,7 @@ def append_kvcache(append_key, append_value, batch_indices, positions, seqlen_of
     return kv_cache_table
 
 
-_DS_MAX_BYTES = int(__import__("os").environ.get("MI355_HSTU_DS_MAX_BYTES", str(8 << 30)))
+_DS_MAX_BYTES = int(__import__("os").environ.get("MI355_HSTU_DS_MAX_BYTES", str(16 << 30)))
 
 
 def hstu_varlen_bwd(dout, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_contexts, num_targets, target_group_size,
@@ -128,7 +128,7 @@ def hstu_varlen_bwd(dout, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_c
     B = cu_seqlens.numel() - 1
     wsb = lib().mi355_hstu_attn_bwd_workspace_bytes(T, H, D)
     # optional dS exchange between the dK and dQ passes (saves the dQ pass its S / dP recomputation); skipped when the
-    # buffer would be larger than MI355_HSTU_DS_MAX_BYTES (default 8 GiB: 32 x 4 heads x L = 4096 takes 4.3 GB)
+    # buffer would be larger than MI355_HSTU_DS_MAX_BYTES (default 16 GiB: 32 sequences x 4 heads x L = 4096 take 8.6 GB for P and dS)
     dsb = lib().mi355_hstu_attn_bwd_ds_bytes(B, H, D, int(max_seqlen))
     if dsb > _DS_MAX_BYTES:
         dsb = 0
