@@ -90,6 +90,38 @@ def test_random_jagged_vs_oracle(d, mode):
         assert err <= tol * np.abs(want).max() + 1e-6, f"{err} vs scale {np.abs(want).max()}"
 
 
+@pytest.mark.parametrize("d", [128, 256])
+@pytest.mark.parametrize("mode", ["causal", "ctx_targets", "group_targets", "noncausal"])
+def test_backward_exchange_is_bit_identical_to_the_recomputing_passes(d, mode, monkeypatch):
+    """d >= 128: the dK pass leaves P and dS in a scratch buffer and dV / dQ are one-GEMM passes over them
+    (hstu_bwd_v_p_kernel / hstu_bwd_q_ds_kernel); without the buffer three passes recompute S.  Same bf16 operands in the
+    same GEMMs: dq, dk, dv must agree bit for bit -- over several key / query blocks, ragged ends, empty and 1-token
+    sequences, targets (with and without groups) and contextual rows, causal and not."""
+    import hstu.hstu_attn_interface as hi
+
+    rng = np.random.default_rng(d + len(mode))
+    lengths = np.array([700, 1, 0, 333, 129, 64, 257, 31])
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    T, H = int(off[-1]), 2
+    causal = mode != "noncausal"
+    targets = ctx = None
+    grp = 1
+    if mode in ("ctx_targets", "group_targets"):
+        targets = np.minimum(rng.integers(0, 40, lengths.size), lengths)
+        ctx = np.minimum(rng.integers(0, 20, lengths.size), lengths - targets)
+        grp = 3 if mode == "group_targets" else 1
+    mk = lambda: torch.from_numpy(rng.uniform(-1, 1, (T, H, d)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    q, k, v, dout = mk(), mk(), mk(), mk()
+    N = int(lengths.max())
+    assert hi.lib().mi355_hstu_attn_bwd_ds_bytes(lengths.size, H, d, N) > 0
+    _, g_x = _run(q, k, v, off, N, targets, ctx, grp, causal, 1.0 / d ** 0.5, dout=dout)
+    monkeypatch.setattr(hi, "_DS_MAX_BYTES", 0)          # no scratch buffer: the recomputing passes
+    _, g_r = _run(q, k, v, off, N, targets, ctx, grp, causal, 1.0 / d ** 0.5, dout=dout)
+    for a, b, name in zip(g_x, g_r, ("dq", "dk", "dv")):
+        assert torch.equal(a, b), f"{name}: {(a.float() - b.float()).abs().max().item()}"
+    assert float(g_x[0].float().abs().max()) > 0
+
+
 def test_strided_inputs_and_scaling_seqlen():
     """q/k/v as slices of one fused [T, 3, H, d] tensor (what the fused HSTU layer hands over) and
     scaling_seqlen decoupled from max_seqlen."""
