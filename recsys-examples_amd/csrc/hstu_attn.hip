@@ -34,6 +34,15 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;   // first-class 16-B value (HIP's uint4 struct arrays end up in scratch)
 
+#ifndef HSTU_XSTEP
+#define HSTU_XSTEP 64   // rows per step of the one-GEMM backward passes (32 / 64)
+#endif
+#ifndef HSTU_XDB
+#define HSTU_XDB 8      // fragments per MFMA batch there
+#endif
+#ifndef HSTU_XOCC
+#define HSTU_XOCC 1     // blocks per CU the compiler must leave room for
+#endif
 constexpr int kBM = 128;  // query rows per workgroup (32 per wave)
 constexpr int kBN = 64;   // keys per tile
 
@@ -1200,9 +1209,9 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
 // its own operand layout (lane = query) with four hardware transpose reads from a wave-private LDS patch, and runs
 // dQ^T[D x q] += K^T[D x keys] dS^T[keys x q].  A sub-tile the dK pass did not visit (entirely masked) counts as zero.
 template <int D>
-__global__ void __launch_bounds__(256) hstu_bwd_q_ds_kernel(BwdAttnArgs g) {
+__global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_q_ds_kernel(BwdAttnArgs g) {
   const AttnArgs& a = g.f;
-  constexpr int BK = 64, NT = BK / 32;   // two 32-key sub-tiles per step: twice the MFMAs per barrier pair
+  constexpr int BK = HSTU_XSTEP, NT = BK / 32;   // 32-key sub-tiles per step
   constexpr int TRS = TrStride<D>::value;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   uint16_t* Kt = smem;                          // [BK][TRS] row-major K tile, read transposed
@@ -1300,7 +1309,7 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_ds_kernel(BwdAttnArgs g) {
       }
     {
       constexpr int NDT = D / 32;
-      constexpr int DB = 8 < NDT ? 8 : NDT;
+      constexpr int DB = HSTU_XDB < NDT ? HSTU_XDB : NDT;
       constexpr int NBAT2 = (BK / 16) * (NDT / DB);
       bf16x8_t fk[2][DB];
       auto load_t = [&](int bi, int buf) {
@@ -1339,11 +1348,11 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_ds_kernel(BwdAttnArgs g) {
 // into the B-operand registers (the dK pass's lane = key layout IS the operand layout here) and runs
 // dV^T[D x keys] += dO^T[D x q] P[q x keys] against a transposed read of the staged dO rows: one GEMM, no SiLU.
 template <int D>
-__global__ void __launch_bounds__(256) hstu_bwd_v_p_kernel(BwdAttnArgs g) {
+__global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_v_p_kernel(BwdAttnArgs g) {
   const AttnArgs& a = g.f;
   constexpr int TRS = TrStride<D>::value;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-  constexpr int BQ = 64, NT = BQ / 32;          // two 32-query sub-tiles per step
+  constexpr int BQ = HSTU_XSTEP, NT = BQ / 32;          // 32-query sub-tiles per step
   uint16_t* dOt = smem;                         // [BQ][TRS] row-major dO tile, read transposed
   const int b = blockIdx.y, h = blockIdx.x;
   SeqInfo s;
@@ -1409,7 +1418,7 @@ __global__ void __launch_bounds__(256) hstu_bwd_v_p_kernel(BwdAttnArgs g) {
     if (!wave_live) continue;
     {
       constexpr int NDT = D / 32;
-      constexpr int DB = 8 < NDT ? 8 : NDT;
+      constexpr int DB = HSTU_XDB < NDT ? HSTU_XDB : NDT;
       constexpr int NBAT2 = (BQ / 16) * (NDT / DB);
       bf16x8_t fa[2][DB];
       auto load_t = [&](int bi, int buf) {
@@ -1469,13 +1478,13 @@ static void launch_bwd_q(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
 
 template <int D>
 static void launch_bwd_v_p(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
-  const size_t smem = (size_t)(64 * TrStride<D>::value) * sizeof(uint16_t);
+  const size_t smem = (size_t)(HSTU_XSTEP * TrStride<D>::value) * sizeof(uint16_t);
   hipLaunchKernelGGL((hstu_bwd_v_p_kernel<D>), grid, dim3(256), smem, stream, g);
 }
 
 template <int D>
 static void launch_bwd_q_ds(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
-  const size_t smem = (size_t)(64 * TrStride<D>::value + 4 * 2 * 1024) * sizeof(uint16_t);
+  const size_t smem = (size_t)(HSTU_XSTEP * TrStride<D>::value + 4 * (HSTU_XSTEP / 32) * 1024) * sizeof(uint16_t);
   hipLaunchKernelGGL((hstu_bwd_q_ds_kernel<D>), grid, dim3(256), smem, stream, g);
 }
 
