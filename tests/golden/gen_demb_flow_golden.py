@@ -9,6 +9,8 @@ pulled out of its AST (the modules themselves cannot be imported: they need the 
    `LinearBucketTable._deterministic_insert` restate -- on top of the oracle's probe / eviction, which stay a restatement.
 2. `get_optimizer_state_dim` / `get_optimizer_ckpt_state_dim` (dynamicemb/optimizer.py:36-75): row layout [emb | state].
 3. `zipf` (benchmark/dataset_generator.py:75-103): the benchmark key stream, run on the CPU under a fixed torch seed.
+4. the planner's capacity arithmetic (dynamicemb_config.py:661-760): table alignment, per-rank bucket layout, HBM-budget
+   capacity.
 
 Run in the build container only:   python tests/golden/gen_demb_flow_golden.py
 """
@@ -136,6 +138,63 @@ def optimizer_dims():
     return np.array(rows, np.int64), [o.name for o in EmbOptimType]
 
 
+# ------------------------------------------------------------------------------------------------ 4. planner arithmetic
+def planner_arithmetic():
+    """align_to_table_size / _sharded_table_bucket_layout / get_sharded_table_capacity / get_constraint_capacity
+    (dynamicemb_config.py:661-760): the capacity rules the sharding planner writes into DynamicEmbTableOptions, executed
+    from the reference's AST on a grid of (rows, world size, bucket capacity) and (bytes, dtype, dim, optimizer)."""
+    import math
+    import warnings
+    from typing import Optional, Tuple
+
+    src = f"{REF}/dynamicemb/dynamicemb_config.py"
+    consts = {}
+    wanted = ("DEMB_TABLE_ALIGN_SIZE", "BUCKET_ALIGNMENT", "MAX_BUCKET_CAPACITY", "DEFAULT_BUCKET_CAPACITY")
+    for mod in (f"{REF}/dynamicemb/types.py", f"{REF}/dynamicemb/dynamicemb_config.py"):
+        for n in ast.parse(open(mod).read()).body:
+            tgt = None
+            if isinstance(n, ast.Assign) and len(n.targets) == 1 and isinstance(n.targets[0], ast.Name):
+                tgt = n.targets[0].id
+            elif isinstance(n, ast.AnnAssign) and isinstance(n.target, ast.Name) and n.value is not None:
+                tgt = n.target.id
+            if tgt in wanted:
+                consts[tgt] = eval(compile(ast.Expression(n.value), mod, "eval"), dict(consts))
+    ns = dict(math=math, warnings=warnings, Optional=Optional, Tuple=Tuple, torch=torch, EmbOptimType=EmbOptimType,
+              BaseEmbeddingConfig=object, DTYPE_NUM_BYTES={torch.float32: 4, torch.float16: 2, torch.bfloat16: 2}, **consts)
+    ns["dtype_to_bytes"] = lambda dt: ns["DTYPE_NUM_BYTES"][dt]
+    for fn in functions_of(f"{REF}/dynamicemb/optimizer.py", ("get_optimizer_state_dim",)):
+        exec(compile(ast.Module([fn], []), "optimizer.py", "exec"), ns)
+    for fn in functions_of(src, ("align_to_table_size", "_sharded_table_bucket_layout", "get_sharded_table_capacity",
+                                 "get_constraint_capacity")):
+        exec(compile(ast.Module([fn], []), "dynamicemb_config.py", "exec"), ns)
+
+    class Cfg:
+        def __init__(self, n):
+            self.num_embeddings = n
+
+    rng = np.random.default_rng(9)
+    align = [(int(n), int(a), ns["align_to_table_size"](int(n), int(a)))
+             for n in list(rng.integers(-5, 5000, 40)) + [0, 1, 16, 17] for a in (consts["DEMB_TABLE_ALIGN_SIZE"], 128, 1024)]
+    layout = []
+    for n in [1, 100, 1000, 12345, 10_000_000, 999_999_937]:
+        for w in (1, 2, 3, 8):
+            for bc in (16, 128, 1024, consts["MAX_BUCKET_CAPACITY"]):
+                nb, eff = ns["_sharded_table_bucket_layout"](Cfg(n), w, bc)
+                layout.append((n, w, bc, nb, eff, ns["get_sharded_table_capacity"](Cfg(n), w, bc)))
+    cap = []
+    dts = [torch.float32, torch.bfloat16, torch.float16]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for mem in (1, 4096, 1 << 20, 123_456_789, 5 << 30):
+            for dc, dt in enumerate(dts):
+                for dim in (8, 128):
+                    for oi, o in enumerate(EmbOptimType):
+                        for bc in (16, 128):
+                            cap.append((mem, dc, dim, oi, bc, ns["get_constraint_capacity"](mem, dt, dim, o, bc)))
+    return (np.array(align, np.int64), np.array(layout, np.int64), np.array(cap, np.int64),
+            np.array([consts["DEMB_TABLE_ALIGN_SIZE"], consts["BUCKET_ALIGNMENT"], consts["MAX_BUCKET_CAPACITY"]], np.int64))
+
+
 # ------------------------------------------------------------------------------------------------ 3. zipf key stream
 def zipf_stream():
     ns = dict(torch=torch)
@@ -166,6 +225,7 @@ def main():
     for name, (meta, a, samples) in zipf_stream().items():
         blob[f"zipf/{name}/meta"], blob[f"zipf/{name}/alpha"], blob[f"zipf/{name}/samples"] = meta, a, samples
     blob["zipf_cases"] = np.array(["a099", "a105"])
+    blob["plan_align"], blob["plan_layout"], blob["plan_capacity"], blob["plan_consts"] = planner_arithmetic()
     np.savez_compressed(OUT, **blob)
     print("wrote", OUT, os.path.getsize(OUT) // 1024, "KiB", names)
 

@@ -433,3 +433,36 @@ def test_overflow_oracle_evicts_by_counter_and_reports_busy():
     idx3, res3, so3, ev3 = o.insert_ovf(k[::2], np.zeros(pin.size, np.int64), np.full(pin.size, 10, np.uint64),
                                         orc.POLICY_ACCUMULATE)
     assert (res3 == 2).all() and np.array_equal(idx3, pin) and (so3 == 11).all() and ev3[0].size == 0
+
+
+def test_planner_capacity_arithmetic_matches_the_reference_functions():
+    """align_to_table_size / _sharded_table_bucket_layout / get_sharded_table_capacity / get_constraint_capacity
+    (dynamicemb_config.py:661-760, executed out of the reference's AST into the fixture): the per-rank capacities and
+    bucket layouts the sharding planner writes into DynamicEmbTableOptions"""
+    import warnings
+
+    import torch
+
+    import dynamicemb as de
+    from dynamicemb import dynamicemb_config as dc
+    from dynamicemb.dynamicemb_config import EmbOptimType
+
+    a, b, m = [int(x) for x in FLOW["plan_consts"]]
+    assert (de.DEMB_TABLE_ALIGN_SIZE, de.BUCKET_ALIGNMENT, de.MAX_BUCKET_CAPACITY) == (a, b, m)
+    for n, al, exp in FLOW["plan_align"]:
+        assert dc.align_to_table_size(int(n), int(al)) == int(exp), (n, al)
+
+    class Cfg:
+        def __init__(self, n):
+            self.num_embeddings = n
+
+    for n, w, bc, nb, eff, cap in FLOW["plan_layout"]:
+        assert dc._sharded_table_bucket_layout(Cfg(int(n)), int(w), int(bc)) == (int(nb), int(eff)), (n, w, bc)
+        assert dc.get_sharded_table_capacity(Cfg(int(n)), int(w), int(bc)) == int(cap), (n, w, bc)
+    names = [str(x) for x in FLOW["opt_names"]]
+    dts = [torch.float32, torch.bfloat16, torch.float16]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for mem, dci, dim, oi, bc, cap in FLOW["plan_capacity"]:
+            got = dc.get_constraint_capacity(int(mem), dts[dci], int(dim), EmbOptimType[names[oi]], int(bc))
+            assert got == int(cap), (mem, dts[dci], dim, names[oi], bc)
