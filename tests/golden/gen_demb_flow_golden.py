@@ -11,6 +11,8 @@ pulled out of its AST (the modules themselves cannot be imported: they need the 
 3. `zipf` (benchmark/dataset_generator.py:75-103): the benchmark key stream, run on the CPU under a fixed torch seed.
 4. the planner's capacity arithmetic (dynamicemb_config.py:661-760): table alignment, per-rank bucket layout, HBM-budget
    capacity.
+5. the key -> owner routing rule of the row-wise exchange (the reference's CPU check of its bucketize kernel,
+   test_hash_roundrobin_kuairand.py:16-45).
 
 Run in the build container only:   python tests/golden/gen_demb_flow_golden.py
 """
@@ -195,6 +197,25 @@ def planner_arithmetic():
             np.array([consts["DEMB_TABLE_ALIGN_SIZE"], consts["BUCKET_ALIGNMENT"], consts["MAX_BUCKET_CAPACITY"]], np.int64))
 
 
+# ------------------------------------------------------------------------------------------------ 5. key -> owner routing
+def routing_owners():
+    """`hash_key_cpu` / `assign_owner_cpu` of the reference's own CPU check of its bucketize kernel
+    (test/unit_tests/test_hash_roundrobin_kuairand.py:16-45): the owner rank of a key under continuous / roundrobin /
+    hash_roundrobin routing."""
+    ns = dict(np=np)
+    for fn in functions_of(f"{REF}/test/unit_tests/test_hash_roundrobin_kuairand.py", ("hash_key_cpu", "assign_owner_cpu")):
+        exec(compile(ast.Module([fn], []), "test_hash_roundrobin_kuairand.py", "exec"), ns)
+    rng = np.random.default_rng(21)
+    keys = np.concatenate([rng.integers(0, 10_000_000, 3000), np.arange(0, 4000, 8),            # modulo-aliasing keys
+                           rng.integers(0, 2 ** 62, 500)]).astype(np.int64)
+    out = {"keys": keys}
+    for W in (2, 3, 8):
+        blk = (10_000_000 + W - 1) // W
+        for name in ("continuous", "roundrobin", "hash_roundrobin"):
+            out[f"{name}/{W}"] = ns["assign_owner_cpu"](keys, W, name, blk).astype(np.int64)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ 3. zipf key stream
 def zipf_stream():
     ns = dict(torch=torch)
@@ -226,6 +247,8 @@ def main():
         blob[f"zipf/{name}/meta"], blob[f"zipf/{name}/alpha"], blob[f"zipf/{name}/samples"] = meta, a, samples
     blob["zipf_cases"] = np.array(["a099", "a105"])
     blob["plan_align"], blob["plan_layout"], blob["plan_capacity"], blob["plan_consts"] = planner_arithmetic()
+    for k, v in routing_owners().items():
+        blob[f"route/{k}"] = v
     np.savez_compressed(OUT, **blob)
     print("wrote", OUT, os.path.getsize(OUT) // 1024, "KiB", names)
 

@@ -466,3 +466,29 @@ def test_planner_capacity_arithmetic_matches_the_reference_functions():
         for mem, dci, dim, oi, bc, cap in FLOW["plan_capacity"]:
             got = dc.get_constraint_capacity(int(mem), dts[dci], int(dim), EmbOptimType[names[oi]], int(bc))
             assert got == int(cap), (mem, dts[dci], dim, names[oi], bc)
+
+
+@pytest.mark.parametrize("W", [2, 3, 8])
+@pytest.mark.parametrize("dist", ["continuous", "roundrobin", "hash_roundrobin"])
+def test_routing_owner_matches_the_reference_cpu_function(W, dist):
+    """owner rank of every key under the three routing rules = the reference's own `assign_owner_cpu`
+    (test/unit_tests/test_hash_roundrobin_kuairand.py:27-45, executed out of its AST into the fixture): the oracle's
+    block_bucketize must place every key in that owner's block"""
+    from dynamicemb.input_dist import DIST_TYPES
+
+    keys = FLOW["route/keys"]
+    owner = FLOW[f"route/{dist}/{W}"]
+    blk = (10_000_000 + W - 1) // W
+    off = np.array([0, keys.size], np.int64)                       # one feature, one bag
+    nl, no, ni, perm = orc.block_bucketize(off, keys, W, 1, np.array([blk], np.int64), DIST_TYPES[dist])
+    assert np.array_equal(nl, np.bincount(owner, minlength=W))
+    got_owner = np.empty(keys.size, np.int64)
+    for p in range(W):
+        got_owner[perm_positions(perm, no, p)] = p
+    assert np.array_equal(got_owner, owner)
+
+
+def perm_positions(perm, new_offsets, p):
+    """input positions of the keys that landed in peer p's block (perm[i] = output position of input key i)"""
+    lo, hi = int(new_offsets[p]), int(new_offsets[p + 1])
+    return np.nonzero((perm >= lo) & (perm < hi))[0]
