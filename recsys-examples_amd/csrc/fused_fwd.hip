@@ -1524,8 +1524,8 @@ int mi355_demb_forward_fused(
     MI355_LAUNCH_CHECK();
     PartRefs prf;
     if (part) { prf.rec_out = a.rec_out; prf.row_addr = row_addr; prf.occ_addr = a.occ_addr; }
-    STEP(mi355i_csr_from_slots(csr_cnt, csr_rank, a.occ_slot, a.occ + 1, reverse_indices, n, combiner >= 0 ? offsets : nullptr,
-                               num_bags, nu_dev, nullptr, total, bptr, bcsr, hot_ws, hot_bytes_, emb_dim, 1, a.hdr, part ? &prf : nullptr, cs));
+    STEP(mi355i_csr_from_slots(csr_rank, a.occ_slot, a.occ + 1, reverse_indices, n, combiner >= 0 ? offsets : nullptr, num_bags,
+                               bptr, bcsr, hot_ws, hot_bytes_, emb_dim, a.hdr, part ? &prf : nullptr, cs));
     if (pin) STEP(mi355_table_update_counter(counter, counter_numel, slots, n, nu_dev, 1, table_ids, table_bucket_offsets,
                                              bucket_capacity, cs));
     if (forked) {

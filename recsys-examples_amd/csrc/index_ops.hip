@@ -1269,34 +1269,22 @@ int mi355_group_by_unique_csr(const int32_t* csr_cnt, const int32_t* csr_rank, c
   return MI355_OK;
 }
 
-// Second half of the fused forward (fused_fwd.hip): the emit pass left occurrences per unique row in csr_cnt, their sums
-// per 1024 uniques in `partial2` and the unique id of every table slot in `uidmap`; this scans the counts into `ptr`,
-// registers the hot rows and scatters the bag of every key into its row's list -- and writes the reverse indices.
-// ptr == NULL (no backward workspace): only the reverse indices are produced.
-int mi355i_csr_from_slots(const int32_t* csr_cnt, const int32_t* csr_rank, const int32_t* occ_slot, const int32_t* uidmap,
-                          int64_t* reverse_indices, int64_t n, const int64_t* offsets, int64_t num_bags, const int64_t* nu_dev,
-                          const int32_t* partial2, int32_t* total, int32_t* ptr, int32_t* csr_src, void* hot_workspace,
-                          int64_t hot_workspace_bytes, int64_t dim, int ptr_ready, int32_t* hdr_reset, const PartRefs* part,
-                          hipStream_t stream) {
+// Last index kernel of the fused forward (fused_fwd.hip): its numbering kernel left the unique id of every occurrence's
+// slot pair (or (tile, key) record: `part`), the CSR row pointers in `ptr` and the hot rows registered; this scatters the
+// bag of every key into its row's list, expands the hot rows' chunk tasks and writes the reverse indices.
+// ptr == NULL (no backward workspace): only the reverse indices (and full ranks) are produced.
+int mi355i_csr_from_slots(const int32_t* csr_rank, const int32_t* occ_slot, const int32_t* uidmap, int64_t* reverse_indices,
+                          int64_t n, const int64_t* offsets, int64_t num_bags, int32_t* ptr, int32_t* csr_src,
+                          void* hot_workspace, int64_t hot_workspace_bytes, int64_t dim, int32_t* hdr_reset,
+                          const PartRefs* part, hipStream_t stream) {
   MI355_CHECK_ARG(n < 0x7fffffffLL, "n must be < 2^31");
   if (n == 0) return MI355_OK;
-  const int64_t nbu = ceil_div(n + 1, kScanTile);
   HotList hot{};
   if (hot_workspace) {
     MI355_CHECK_ARG(hot_workspace_bytes >= hot_bytes(n, dim), "hot workspace too small");
     hot = hot_carve(hot_workspace, n, dim);
   }
   if (ptr) {
-    if (ptr_ready) {
-      // the merged numbering kernel of the fused forward already wrote the row pointers and registered the hot rows
-    } else if (nbu <= kSelfPrefixMaxTiles) {
-      hipLaunchKernelGGL(scan_down_kernel<true>, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, csr_cnt, n, nu_dev, partial2, total, ptr,
-                         hot, hot_workspace != nullptr);
-    } else {
-      hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, stream, const_cast<int32_t*>(partial2), nbu, total);
-      hipLaunchKernelGGL(scan_down_kernel<false>, dim3((unsigned)nbu), dim3(kScanThreads), 0, stream, csr_cnt, n, nu_dev, partial2, total, ptr,
-                         hot, hot_workspace != nullptr);
-    }
     if (part && part->rec_out)
       hipLaunchKernelGGL(csr_scatter_kernel<2>, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, (const int64_t*)nullptr,
                          const_cast<int32_t*>(csr_rank), n, offsets, num_bags, ptr, csr_src, hot, hot_workspace != nullptr, occ_slot,

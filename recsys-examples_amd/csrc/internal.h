@@ -56,11 +56,10 @@ struct PartRefs {
   const int64_t* row_addr = nullptr;
   int64_t* occ_addr = nullptr;
 };
-int mi355i_csr_from_slots(const int32_t* csr_cnt, const int32_t* csr_rank, const int32_t* occ_slot, const int32_t* uidmap,
-                          int64_t* reverse_indices, int64_t n, const int64_t* offsets, int64_t num_bags, const int64_t* nu_dev,
-                          const int32_t* partial2, int32_t* total, int32_t* ptr, int32_t* csr_src, void* hot_workspace,
-                          int64_t hot_workspace_bytes, int64_t dim, int ptr_ready, int32_t* hdr_reset, const PartRefs* part,
-                          hipStream_t stream);
+int mi355i_csr_from_slots(const int32_t* csr_rank, const int32_t* occ_slot, const int32_t* uidmap, int64_t* reverse_indices,
+                          int64_t n, const int64_t* offsets, int64_t num_bags, int32_t* ptr, int32_t* csr_src,
+                          void* hot_workspace, int64_t hot_workspace_bytes, int64_t dim, int32_t* hdr_reset,
+                          const PartRefs* part, hipStream_t stream);
 
 // bench.py's live kernel timing (err.hip): event of slot (0 gather, 1 backward kernel), end 0 / 1
 void mi355i_prof_mark(int slot, int end, hipStream_t stream);
