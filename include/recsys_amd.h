@@ -458,7 +458,8 @@ int mi355_append_kvcache(void* kv_cache, const int32_t* kv_indices, const int32_
 int64_t mi355_hstu_attn_bwd_workspace_bytes(int64_t total_tokens, int64_t num_heads, int64_t head_dim);
 /* Optional scratch of mi355_hstu_attn_bwd: given a 16-byte aligned workspace of at least this many bytes, the dK pass
  * hands dS to the dQ pass through it (bf16, B * H * ceil(max_seqlen/32)^2 sub-tiles of 2 KB) and the dQ pass skips the
- * S / dP recomputation; with a smaller (or no) workspace the dQ pass recomputes.  0: no exchange for this shape.
+ * S / dP recomputation (head_dim >= 128: P travels too and the dV pass becomes one GEMM); with a smaller (or no)
+ * workspace the passes recompute.  0: exchange switched off.
  * Results are bit-identical either way (the dQ GEMM consumes the same bf16 dS). */
 int64_t mi355_hstu_attn_bwd_ds_bytes(int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen);
 int mi355_hstu_attn_bwd(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,

@@ -1524,8 +1524,11 @@ static int launch_bwd(BwdAttnArgs g, int B, int max_seqlen, hipStream_t stream) 
     if (g.ds_ws) launch_bwd_q_ds<D>(g, grid, stream);
     else launch_bwd_q<D, 64, false>(g, grid, stream);
   } else {
+    g.bq_kv = 64;
+    g.p_ws = nullptr;          // (dV and dK come out of ONE pass at these head dims: only dS is handed on)
     launch_bwd_kv<D, 64, 0, false>(g, grid, stream);
-    launch_bwd_q<D, 64, false>(g, grid, stream);
+    if (g.ds_ws) launch_bwd_q_ds<D>(g, grid, stream);
+    else launch_bwd_q<D, 64, false>(g, grid, stream);
   }
   MI355_LAUNCH_CHECK();
   return MI355_OK;
@@ -1663,13 +1666,14 @@ int64_t mi355_hstu_attn_bwd_workspace_bytes(int64_t total_tokens, int64_t num_he
 
 // Optional scratch of the backward: with a workspace of at least this size the dK pass leaves dS (bf16, 32 x 32 sub-tiles
 // in its register layout) for the dQ pass, which then skips the S / dP recomputation -- 2 of its 3 GEMMs and the SiLU.
-// 0: no exchange for this shape (head_dim < 128 runs dV and dK in one pass and keeps the recomputing dQ pass).
+// (head_dim < 128 runs dV and dK in one pass: only dS is exchanged there.)  0: the exchange is switched off.
 int64_t mi355_hstu_attn_bwd_ds_bytes(int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen) {
   static const int env = getenv("MI355_HSTU_DS") ? atoi(getenv("MI355_HSTU_DS")) : 1;
-  if (!env || head_dim < 128 || batch <= 0 || max_seqlen <= 0) return 0;
+  if (!env || batch <= 0 || max_seqlen <= 0) return 0;
   static const int envp = getenv("MI355_HSTU_XP") ? atoi(getenv("MI355_HSTU_XP")) : 1;
   const int64_t ng = (max_seqlen + 31) / 32;
-  return batch * num_heads * ng * ng * 2048 * (envp ? 2 : 1);   // dS, and P behind it
+  // dS, and (head_dim >= 128, where dV and dK are separate passes) P behind it
+  return batch * num_heads * ng * ng * 2048 * ((envp && head_dim >= 128) ? 2 : 1);
 }
 
 // hstu_varlen_bwd (corelib/hstu/csrc/hstu_attn/hstu_api.cpp:525-719).  dq, dk, dv: contiguous bf16 [total, H, d].
@@ -1705,7 +1709,7 @@ int mi355_hstu_attn_bwd(const void* dout, const void* q, const void* k, const vo
     if (need > 0 && workspace && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0) {
       g.ds_ws = (uint16_t*)workspace;
       const int64_t one = batch * num_heads * (int64_t)g.ng * g.ng * 2048;
-      if (need >= 2 * one) g.p_ws = (uint16_t*)((uint8_t*)workspace + one);
+      if (need >= 2 * one && head_dim >= 128) g.p_ws = (uint16_t*)((uint8_t*)workspace + one);
     }
   }
   switch (head_dim) {

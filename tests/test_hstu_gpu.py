@@ -90,10 +90,10 @@ def test_random_jagged_vs_oracle(d, mode):
         assert err <= tol * np.abs(want).max() + 1e-6, f"{err} vs scale {np.abs(want).max()}"
 
 
-@pytest.mark.parametrize("d", [128, 256])
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
 @pytest.mark.parametrize("mode", ["causal", "ctx_targets", "group_targets", "noncausal"])
 def test_backward_exchange_is_bit_identical_to_the_recomputing_passes(d, mode, monkeypatch):
-    """d >= 128: the dK pass leaves P and dS in a scratch buffer and dV / dQ are one-GEMM passes over them
+    """the dK pass leaves dS (d >= 128: and P) in a scratch buffer and dV / dQ are one-GEMM passes over them
     (hstu_bwd_v_p_kernel / hstu_bwd_q_ds_kernel); without the buffer three passes recompute S.  Same bf16 operands in the
     same GEMMs: dq, dk, dv must agree bit for bit -- over several key / query blocks, ragged ends, empty and 1-token
     sequences, targets (with and without groups) and contextual rows, causal and not."""
