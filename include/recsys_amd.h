@@ -456,6 +456,20 @@ int mi355_append_kvcache(void* kv_cache, const int32_t* kv_indices, const int32_
  * contiguous bf16 [total, H, d].  Deterministic (two passes, no atomics): `deterministic` of the
  * reference is always on. */
 int64_t mi355_hstu_attn_bwd_workspace_bytes(int64_t total_tokens, int64_t num_heads, int64_t head_dim);
+/* Local (sliding window) attention: window_size = (left, right) of hstu_attn_varlen_func (hstu_attn_interface.py:196-222,
+ * hstu_api.cpp:154-165): query i sees keys i - left .. i + right, a negative side is unbounded ((-1, 0) = causal,
+ * (-1, -1) = full).  No contextual / target rows with a window; self attention only. */
+int mi355_hstu_attn_fwd_window(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride,
+                               int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride,
+                               int64_t k_head_stride, int64_t v_head_stride, int64_t o_head_stride, const int32_t* cu_seqlens,
+                               int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen, int64_t window_left,
+                               int64_t window_right, float alpha, float scaling_seqlen, hipStream_t stream);
+int mi355_hstu_attn_bwd_window(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
+                               int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t do_row_stride,
+                               int64_t q_head_stride, int64_t k_head_stride, int64_t v_head_stride, int64_t do_head_stride,
+                               const int32_t* cu_seqlens, int64_t batch, int64_t num_heads, int64_t head_dim,
+                               int64_t max_seqlen, int64_t window_left, int64_t window_right, float alpha,
+                               float scaling_seqlen, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 /* Optional scratch of mi355_hstu_attn_bwd: given a 16-byte aligned workspace of at least this many bytes, the dK pass
  * hands dS to the dQ pass through it (bf16, B * H * ceil(max_seqlen/32)^2 sub-tiles of 2 KB) and the dQ pass skips the
  * S / dP recomputation (head_dim >= 128: P travels too and the dV pass becomes one GEMM); with a smaller (or no)

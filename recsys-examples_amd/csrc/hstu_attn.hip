@@ -71,6 +71,8 @@ struct AttnArgs {
   const int* num_contexts;  // [B] or nullptr
   const int* num_targets;   // [B] or nullptr
   int H, causal, group;
+  int wl, wr;                  // local window: keys i - wl .. i + wr of query i (-1: unbounded on that side)
+  int wskip;                   // 1: tile loops are clipped to the window's band (0: the mask alone applies it; for A/B tests)
   float alpha, inv_scale;
   // ---- inference extensions (forward only; NULL / 0 for training) ----
   const int* cu_seqlens_k;     // [B+1] key offsets when the keys are longer than the queries (delta-q); NULL = same as q
@@ -81,7 +83,7 @@ struct AttnArgs {
   int page_size;
 };
 
-struct SeqInfo { int start, L, c, hlen; bool has_ctx, has_tgt; };
+struct SeqInfo { int start, L, c, hlen; bool has_ctx, has_tgt; int wl = -1, wr = -1; };
 
 // M(i, j) of the reference (_get_valid_attn_mask / apply_mask); i, j are positions inside the sequence
 __device__ __forceinline__ bool attn_allowed(int i, int j, const SeqInfo& s, int causal, int group) {
@@ -139,17 +141,36 @@ template <int N> __device__ __forceinline__ void fence_a(f32x16_t (&c)[N]) { pin
 //   j <= jmax  and  (j < hlen  or  j >= jlo)
 // with jmax = i (history / target rows) or hlen-1 (contextual rows: they see the whole history), and
 // jlo = first key of the row's target group (0 for non-target rows).  Non causal: j < L.
+// Local window (hstu_api.cpp:154-165; no contextual / target rows with it): additionally i - wl <= j <= i + wr.  The
+// left bound reuses the target-group fields, which a window leaves free (hlen = 0: no key is "history", jlo = i - wl), so
+// that key_ok costs the plain masks nothing extra.
 struct RowMask { int jmax, jlo, hlen; };
 __device__ __forceinline__ RowMask row_mask(int i, const SeqInfo& s, int causal, int group) {
   RowMask m;
   m.hlen = s.hlen;
-  if (!causal) { m.jmax = s.L - 1; m.jlo = 0; m.hlen = s.L; return m; }
-  m.jmax = (s.has_ctx && i < s.c) ? s.hlen - 1 : i;
-  if (m.jmax > s.L - 1) m.jmax = s.L - 1;
-  m.jlo = (s.has_tgt && i >= s.hlen) ? s.hlen + ((i - s.hlen) / group) * group : 0;
+  if (!causal) {
+    m.jmax = s.L - 1; m.jlo = 0; m.hlen = s.L;
+    if (s.wr >= 0 && i + s.wr < m.jmax) m.jmax = i + s.wr;
+  } else {
+    m.jmax = (s.has_ctx && i < s.c) ? s.hlen - 1 : i;
+    if (m.jmax > s.L - 1) m.jmax = s.L - 1;
+    m.jlo = (s.has_tgt && i >= s.hlen) ? s.hlen + ((i - s.hlen) / group) * group : 0;
+  }
+  if (s.wl >= 0) { m.hlen = 0; m.jlo = i - s.wl; }
   return m;
 }
-__device__ __forceinline__ bool key_ok(int j, const RowMask& m) { return (j <= m.jmax) & ((j < m.hlen) | (j >= m.jlo)); }
+__device__ __forceinline__ bool key_ok(int j, const RowMask& m) {
+  return (j <= m.jmax) & ((j < m.hlen) | (j >= m.jlo));
+}
+// Key tiles (steps of `step` keys) a block of query rows first .. last can reach through the window: [beg, end)
+__device__ __forceinline__ int band_key_begin(const AttnArgs& a, int first_row, int step) {
+  const int lo = first_row - a.wl;
+  return (a.wskip && a.wl >= 0 && lo > 0) ? (lo / step) * step : 0;
+}
+__device__ __forceinline__ int band_key_end(const AttnArgs& a, int last_row, int end) {
+  const int hi = last_row + a.wr + 1;
+  return (a.wskip && a.wr >= 0 && hi < end) ? hi : end;
+}
 
 // SiLU(alpha * acc) * inv_scale from the raw accumulator: 4 plain VALU + 2 transcendental ops
 __device__ __forceinline__ float silu_scaled(float acc, float neg_alpha_log2e, float alpha_inv_scale) {
@@ -169,7 +190,7 @@ __device__ __forceinline__ void stage_rows(uint16_t* dst, const uint16_t* src, i
     *reinterpret_cast<uint4*>(dst + r * (D + 8) + 8 * dc) = t;
   }
 }
-template <int D>
+template <int D, bool kWin = false>   // kWin: local window; a variant of its own so that the plain masks pay nothing for it
 __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
   constexpr int KS = D + 8;    // padded K row (elements)
   constexpr bool kVTR = HSTU_VTR != 0;
@@ -205,6 +226,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
   s.c = s.has_ctx ? a.num_contexts[b] : 0;
   const int ntgt = s.has_tgt ? a.num_targets[b] : 0;
   s.hlen = s.L - ntgt;
+  s.wl = kWin ? a.wl : -1; s.wr = kWin ? a.wr : -1;
   const bool paged = a.kv_cache != nullptr;
   int cachelen = 0, pg0 = 0;
   if (paged) {
@@ -226,6 +248,8 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
     n_end = last_row + 1;
     if (s.has_ctx && dq + m0 < s.c && s.hlen > n_end) n_end = s.hlen;
   }
+  if (kWin) n_end = band_key_end(a, last_row, n_end);
+  const int n_beg = kWin ? band_key_begin(a, dq + m0, kBN) : 0;
   // the wave's own reach (skips MFMA work on tiles past it)
   int w_last = dq + (qrow0 + 31 < Lq - 1 ? qrow0 + 31 : Lq - 1);
   int w_end = s.L;
@@ -233,6 +257,8 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
     w_end = w_last + 1;
     if (s.has_ctx && dq + qrow0 < s.c && s.hlen > w_end) w_end = s.hlen;
   }
+  if (kWin) w_end = band_key_end(a, w_last, w_end);
+  const int w_beg = kWin ? band_key_begin(a, dq + qrow0, kBN) : 0;
 
   // ---- Q fragments (B operand of GEMM 1): lane = (query l31, k half hi), 8 consecutive d per 16-slice
   bf16x8_t qf[QLDS ? 1 : D / 16];
@@ -402,15 +428,15 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
     }
   };
 
-  if (n_end > 0) {
-    fetch(0);
+  if (n_end > n_beg) {
+    fetch(n_beg);
     if constexpr (kDB) {
       commit(smem, smem + kBN * KS);
-      if (kBN < n_end) fetch(kBN);
+      if (n_beg + kBN < n_end) fetch(n_beg + kBN);
     }
   }
   int it = 0;
-  for (int n0 = 0; n0 < n_end; n0 += kBN, ++it) {
+  for (int n0 = n_beg; n0 < n_end; n0 += kBN, ++it) {
     pin_agpr(acc_o);
     __syncthreads();   // kDB: everyone is done with the other buffer, and this tile's commit (previous interval) is visible
     if constexpr (kDB) {
@@ -429,7 +455,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
       if (n0 + kBN < n_end) fetch(n0 + kBN);
     }
     pin_agpr(acc_o);
-    if (!wave_live || n0 >= w_end) continue;
+    if (!wave_live || n0 >= w_end || n0 < w_beg) continue;
 
     // ---- GEMM 1: S^T[64 keys x 32 q] = K Q^T, two 32-key tiles.  Operand fragments are fetched from LDS
     // in batches of 8 ahead of the 8 MFMAs that consume them (hipcc otherwise emits read-wait-mfma triples).
@@ -470,7 +496,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
     pin_agpr(acc_o);
     // ---- P^T = mask * SiLU(alpha S^T) / scaling, packed straight into the B operand of GEMM 2.
     // Tiles strictly below the diagonal of every row of the wave need no per-element mask.
-    const bool full = a.causal && (n0 + kBN - 1 <= dq + qrow0) && (!s.has_ctx || dq + qrow0 >= s.c) && (!s.has_tgt || n0 + kBN - 1 < s.hlen);
+    const bool full = a.causal && s.wl < 0 && (n0 + kBN - 1 <= dq + qrow0) && (!s.has_ctx || dq + qrow0 >= s.c) && (!s.has_tgt || n0 + kBN - 1 < s.hlen);
     if constexpr (D >= 256) {
     // ---- GEMM 2: O^T[D x 32 q] += V^T[D x 64 keys] P^T, software-pipelined with the SiLU epilogue of GEMM 1: the
     // 16-key slice ks+1 of P is computed (VALU + transcendental pipes) while the MFMAs of slice ks run -- at one wave
@@ -787,6 +813,24 @@ __device__ __forceinline__ uint16_t* ds_tile(const BwdAttnArgs& g, int b, int h,
   return g.ds_ws + xch_tile(g, b, h, kg, qg);
 }
 
+// Query steps (multiples of `bq` rows) the dK pass runs for the key block n0 .. n0 + kBM - 1: [0, c_end) and [jump, lim).
+// The contextual rows (they see all history keys), then from the step holding row n0 on (causal) or from the first row
+// whose right window reaches key n0 (non causal); up to the last row whose left window still reaches the block.
+// hstu_bwd_v_p_kernel and hstu_bwd_q_ds_kernel replay it to tell which exchanged sub-tiles exist.
+struct KvSpan { int jump, c_end, lim; };
+__device__ __forceinline__ KvSpan kv_span(const AttnArgs& a, const SeqInfo& s, int n0, int bq) {
+  KvSpan v{0, 0, s.L};
+  if (a.causal) {
+    v.jump = (n0 / bq) * bq;
+    if (s.has_ctx && s.c > 0 && n0 < s.hlen) v.c_end = ((s.c + bq - 1) / bq) * bq;
+  } else if (a.wskip && a.wr >= 0 && n0 > a.wr) {
+    v.jump = ((n0 - a.wr) / bq) * bq;
+  }
+  if (a.wskip && a.wl >= 0 && n0 + kBM + a.wl < v.lim) v.lim = n0 + kBM + a.wl;
+  return v;
+}
+__device__ __forceinline__ bool kv_visited(const KvSpan& v, int step) { return (step < v.c_end || step >= v.jump) && step < v.lim; }
+
 // pass A: one workgroup = 128 keys (32 per wave) of one (sequence, head); loops over query tiles of BQ rows.
 // MODE 0: dV and dK together (d <= 64).  Larger d: the two output accumulators plus the S / dP accumulators and the
 // K / V fragments exceed the register file of one wave, so the pass is split: MODE 1 = dV only (S -> P -> dV),
@@ -816,11 +860,12 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
   s.has_tgt = a.num_targets != nullptr;
   s.c = s.has_ctx ? a.num_contexts[b] : 0;
   s.hlen = s.L - (s.has_tgt ? a.num_targets[b] : 0);
+  s.wl = a.wl; s.wr = a.wr;
   const int lane = lane_id(), wv = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int key0 = n0 + 32 * wv;
   const int kj = key0 + l31;
   const bool wave_live = key0 < s.L;
-  const bool plain = !s.has_ctx && !s.has_tgt;   // block-uniform: mask is kj <= qi (causal) or kj < L
+  const bool plain = !s.has_ctx && !s.has_tgt && s.wl < 0 && s.wr < 0;   // block-uniform: mask is kj <= qi (causal) or kj < L
 
   const uint16_t* qbase = a.q + (int64_t)s.start * a.q_row + (int64_t)h * a.q_head;
   const uint16_t* dobase = g.dout + (int64_t)s.start * g.do_row + (int64_t)h * g.do_head;
@@ -843,11 +888,8 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
   const float c_ds = a.alpha * a.inv_scale;  // dS = dP * c_ds * sigmoid * (1 + x (1 - sigmoid))
   // query tiles that can see this key block: the tiles holding contextual rows (they see all history keys), then
   // from the tile containing row n0 on (causal); everything (non causal)
-  int jump = 0, c_end = 0;
-  if (a.causal) {
-    jump = (n0 / BQ) * BQ;
-    if (s.has_ctx && s.c > 0 && n0 < s.hlen) c_end = ((s.c + BQ - 1) / BQ) * BQ;
-  }
+  const KvSpan span = kv_span(a, s, n0, BQ);
+  const int jump = span.jump, c_end = span.c_end, i_lim = span.lim;
   auto advance = [&](int i) { i += BQ; return (i >= c_end && i < jump) ? jump : i; };
   int i0 = c_end > 0 ? 0 : jump;
 
@@ -865,8 +907,8 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
   };
   // kPre: small head dims run several waves per SIMD, which hides the staging latency better than holding a tile in
   // registers does (the prefetch registers would halve the occupancy); d = 256 runs one wave per SIMD and prefetches
-  if (kPre && i0 < s.L) fetch_all(i0);
-  for (; i0 < s.L; i0 = advance(i0)) {
+  if (kPre && i0 < i_lim) fetch_all(i0);
+  for (; i0 < i_lim; i0 = advance(i0)) {
     if (kDV) pin_agpr(acc_dv);
     if (kDK) pin_agpr(acc_dk);
     __syncthreads();
@@ -885,7 +927,7 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
     __syncthreads();
     if (kPre) {
       const int nx = advance(i0);
-      if (nx < s.L) fetch_all(nx);
+      if (nx < i_lim) fetch_all(nx);
     }
     if (kDV) pin_agpr(acc_dv);
     if (kDK) pin_agpr(acc_dk);
@@ -1063,6 +1105,7 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
   s.has_tgt = a.num_targets != nullptr;
   s.c = s.has_ctx ? a.num_contexts[b] : 0;
   s.hlen = s.L - (s.has_tgt ? a.num_targets[b] : 0);
+  s.wl = a.wl; s.wr = a.wr;
   const int lane = lane_id(), wv = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int qrow0 = m0 + 32 * wv;
   const int qi = qrow0 + l31;
@@ -1073,6 +1116,9 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
   int w_last = qrow0 + 31 < s.L - 1 ? qrow0 + 31 : s.L - 1;
   int w_end = s.L;
   if (a.causal) { w_end = w_last + 1; if (s.has_ctx && qrow0 < s.c && s.hlen > w_end) w_end = s.hlen; }
+  n_end = band_key_end(a, last_row, n_end);
+  w_end = band_key_end(a, w_last, w_end);
+  const int n_beg = band_key_begin(a, m0, BK), w_beg = band_key_begin(a, qrow0, BK);
 
   // Q / dO fragments of the wave's 32 queries; rows beyond the sequence read a clamped row and are never stored
   bf16x8_t qf[D / 16], dof[D / 16];
@@ -1096,8 +1142,8 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
     v_rows.fetch(vbase, a.v_row, n, s.L);
     k_tr.fetch(kbase, a.k_row, n, s.L);
   };
-  if (kPre && n_end > 0) fetch_all(0);
-  for (int n0 = 0; n0 < n_end; n0 += BK) {
+  if (kPre && n_end > n_beg) fetch_all(n_beg);
+  for (int n0 = n_beg; n0 < n_end; n0 += BK) {
     pin_agpr(acc_dq);
     __syncthreads();
     if (!kPre) fetch_all(n0);
@@ -1108,7 +1154,7 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
     __syncthreads();
     if (kPre && n0 + BK < n_end) fetch_all(n0 + BK);
     pin_agpr(acc_dq);
-    if (!wave_live || n0 >= w_end) continue;
+    if (!wave_live || n0 >= w_end || n0 < w_beg) continue;
     f32x16_t acc_s[NT], acc_p[NT];   // S^T, dP^T [keys x q]
     {
       constexpr int SLB = 4 / NT < D / 16 ? 4 / NT : D / 16;
@@ -1228,6 +1274,7 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_q_ds_kernel(BwdAttnAr
   s.has_tgt = a.num_targets != nullptr;
   s.c = s.has_ctx ? a.num_contexts[b] : 0;
   s.hlen = s.L - (s.has_tgt ? a.num_targets[b] : 0);
+  s.wl = a.wl; s.wr = a.wr;
   const int lane = lane_id(), wv = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int qrow0 = m0 + 32 * wv;
   const int qi = qrow0 + l31;
@@ -1238,6 +1285,9 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_q_ds_kernel(BwdAttnAr
   int w_last = qrow0 + 31 < s.L - 1 ? qrow0 + 31 : s.L - 1;
   int w_end = s.L;
   if (a.causal) { w_end = w_last + 1; if (s.has_ctx && qrow0 < s.c && s.hlen > w_end) w_end = s.hlen; }
+  n_end = band_key_end(a, last_row, n_end);
+  w_end = band_key_end(a, w_last, w_end);
+  const int n_beg = band_key_begin(a, m0, BK), w_beg = band_key_begin(a, qrow0, BK);
   // query tile of the dK pass that holds this wave's rows
   const int it_kv = (qrow0 / g.bq_kv) * g.bq_kv;
 
@@ -1260,13 +1310,7 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_q_ds_kernel(BwdAttnAr
   u32x4_t ds0[NT], ds1[NT];
   auto tile_written = [&](int n0) -> bool {   // did the dK pass visit sub-tile (keys n0.., this wave's queries)?
     if (n0 >= s.L) return false;
-    const int nkv = (n0 / kBM) * kBM;
-    int jump = 0, c_end = 0;
-    if (a.causal) {
-      jump = (nkv / g.bq_kv) * g.bq_kv;
-      if (s.has_ctx && s.c > 0 && nkv < s.hlen) c_end = ((s.c + g.bq_kv - 1) / g.bq_kv) * g.bq_kv;
-    }
-    return it_kv < c_end || it_kv >= jump;
+    return kv_visited(kv_span(a, s, (n0 / kBM) * kBM, g.bq_kv), it_kv);
   };
   auto fetch_all = [&](int n) {
     k_rows.fetch(kbase, a.k_row, n, s.L);
@@ -1281,8 +1325,8 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_q_ds_kernel(BwdAttnAr
       }
     }
   };
-  if (n_end > 0) fetch_all(0);
-  for (int n0 = 0; n0 < n_end; n0 += BK) {
+  if (n_end > n_beg) fetch_all(n_beg);
+  for (int n0 = n_beg; n0 < n_end; n0 += BK) {
     pin_agpr(acc_dq);
     __syncthreads();
     k_rows.commit_tr(Kt, n0, s.L);
@@ -1295,7 +1339,7 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_q_ds_kernel(BwdAttnAr
     __syncthreads();
     if (n0 + BK < n_end) fetch_all(n0 + BK);
     pin_agpr(acc_dq);
-    if (!wave_live || n0 >= w_end) continue;
+    if (!wave_live || n0 >= w_end || n0 < w_beg) continue;
     bf16x8_t sf[2 * NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -1364,6 +1408,7 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_v_p_kernel(BwdAttnArg
   s.has_tgt = a.num_targets != nullptr;
   s.c = s.has_ctx ? a.num_contexts[b] : 0;
   s.hlen = s.L - (s.has_tgt ? a.num_targets[b] : 0);
+  s.wl = a.wl; s.wr = a.wr;
   const int lane = lane_id(), wv = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int key0 = n0 + 32 * wv;
   const int kj = key0 + l31;
@@ -1376,14 +1421,13 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_v_p_kernel(BwdAttnArg
     for (int r = 0; r < 16; ++r) acc_dv[dt][r] = 0.f;
   // the query rows the dK pass visited for this key block, in steps of BQ rows (its own steps are bq_kv rows: a sub-tile
   // of a step may lie outside the visited set -- or past the sequence -- and then counts as zero)
-  int jump = 0, c_end = 0;
-  if (a.causal) {
-    jump = (n0 / g.bq_kv) * g.bq_kv;
-    if (s.has_ctx && s.c > 0 && n0 < s.hlen) c_end = ((s.c + g.bq_kv - 1) / g.bq_kv) * g.bq_kv;
-  }
+  const KvSpan span = kv_span(a, s, n0, g.bq_kv);
+  const int jump = span.jump, c_end = span.c_end;
   const int jump_s = (jump / BQ) * BQ, cend_s = ((c_end + BQ - 1) / BQ) * BQ;
+  int i_lim = ((span.lim + g.bq_kv - 1) / g.bq_kv) * g.bq_kv;   // end of the dK pass' last step
+  if (i_lim > s.L) i_lim = s.L;
   auto advance = [&](int i) { i += BQ; return (i >= cend_s && i < jump_s) ? jump_s : i; };
-  auto visited = [&](int i) { return i < s.L && (i < c_end || i >= jump); };
+  auto visited = [&](int i) { return i < s.L && kv_visited(span, (i / g.bq_kv) * g.bq_kv); };
   int i0 = c_end > 0 ? 0 : jump_s;
   RowTile<D, BQ> do_rows;
   u32x4_t p0[NT], p1[NT];
@@ -1400,8 +1444,8 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_v_p_kernel(BwdAttnArg
       }
     }
   };
-  if (i0 < s.L) fetch_all(i0);
-  for (; i0 < s.L; i0 = advance(i0)) {
+  if (i0 < i_lim) fetch_all(i0);
+  for (; i0 < i_lim; i0 = advance(i0)) {
     pin_agpr(acc_dv);
     __syncthreads();
     do_rows.commit_tr(dOt, i0, s.L);
@@ -1412,7 +1456,7 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_v_p_kernel(BwdAttnArg
     __syncthreads();
     {
       const int nx = advance(i0);
-      if (nx < s.L) fetch_all(nx);
+      if (nx < i_lim) fetch_all(nx);
     }
     pin_agpr(acc_dv);
     if (!wave_live) continue;
@@ -1540,14 +1584,18 @@ static int launch_fwd(const AttnArgs& a, int B, int max_seqlen, hipStream_t stre
   const size_t smem = (size_t)((D >= HSTU_DB_MIN ? 2 : 1) * (kBN * (D + 8) + vtile) + (D >= HSTU_QLDS_MIN ? kBM * (D + 8) : 0)) * sizeof(uint16_t);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess) return MI355_ELAUNCH;
     attr_set = true;
   }
   // Dispatch order is x, then y, then z: with the block rank in z, ALL sequences' heaviest (causal: latest) row blocks
   // are handed out first and the light ones fill in behind them.  With the rank in x (per-sequence order 8,6,4,2 key
   // tiles at L = 512) the CUs freed first drew heavy blocks again and the slowest CU did 16 tiles where 10 is the mean.
   dim3 grid(a.H, B, (max_seqlen + kBM - 1) / kBM);
-  hipLaunchKernelGGL(hstu_fwd_kernel<D>, grid, dim3(256), smem, stream, a);
+  if (a.wl >= 0 || a.wr >= 0) hipLaunchKernelGGL((hstu_fwd_kernel<D, true>), grid, dim3(256), smem, stream, a);
+  else hipLaunchKernelGGL((hstu_fwd_kernel<D, false>), grid, dim3(256), smem, stream, a);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }
@@ -1555,6 +1603,13 @@ static int launch_fwd(const AttnArgs& a, int B, int max_seqlen, hipStream_t stre
 }  // namespace mi355
 
 using namespace mi355;
+
+// local window of the call in flight on this thread (set by the *_window entry points around the plain ones)
+static thread_local int tl_wl = -1, tl_wr = -1;
+static int window_skip() {   // MI355_HSTU_WSKIP=0: keep the full tile loops under a window (A/B tests of the band clipping)
+  static const int v = [] { const char* e = getenv("MI355_HSTU_WSKIP"); return e ? atoi(e) != 0 : 1; }();
+  return v;
+}
 
 extern "C" {
 
@@ -1601,6 +1656,7 @@ int mi355_hstu_attn_fwd_kv(const void* q, const void* k, const void* v, void* ou
   a.q_head = q_head_stride; a.k_head = k_head_stride; a.v_head = v_head_stride; a.o_head = o_head_stride;
   a.cu_seqlens = cu_seqlens_q; a.num_contexts = num_contexts; a.num_targets = num_targets;
   a.H = (int)num_heads; a.causal = causal; a.group = (int)target_group_size;
+  a.wl = tl_wl; a.wr = tl_wr; a.wskip = window_skip();
   a.alpha = alpha; a.inv_scale = 1.0f / scaling_seqlen;
   a.cu_seqlens_k = cu_seqlens_k; a.kv_cache = (const uint16_t*)kv_cache; a.page_offsets = page_offsets; a.page_ids = page_ids;
   a.last_page_lens = last_page_lens; a.page_size = (int)page_size;
@@ -1699,6 +1755,7 @@ int mi355_hstu_attn_bwd(const void* dout, const void* q, const void* k, const vo
   a.q_head = q_head_stride; a.k_head = k_head_stride; a.v_head = v_head_stride; a.o_head = 0;
   a.cu_seqlens = cu_seqlens; a.num_contexts = num_contexts; a.num_targets = num_targets;
   a.H = (int)num_heads; a.causal = causal; a.group = (int)target_group_size;
+  a.wl = tl_wl; a.wr = tl_wr; a.wskip = window_skip();
   a.alpha = alpha; a.inv_scale = 1.0f / scaling_seqlen;
   g.dout = (const uint16_t*)dout; g.do_row = do_row_stride; g.do_head = do_head_stride;
   g.dq = (uint16_t*)dq; g.dk = (uint16_t*)dk; g.dv = (uint16_t*)dv;
@@ -1718,6 +1775,43 @@ int mi355_hstu_attn_bwd(const void* dout, const void* q, const void* k, const vo
     case 128: return launch_bwd<128>(g, (int)batch, (int)max_seqlen, stream);
     default: return launch_bwd<256>(g, (int)batch, (int)max_seqlen, stream);
   }
+}
+
+
+// Local (sliding window) attention, window_size = (left, right) of hstu_attn_varlen_func (hstu_api.cpp:154-165: a negative
+// side is unbounded; (-1, 0) is causal, (-1, -1) full): query i sees keys i - left .. i + right.  No contextual / target
+// rows with a window (hstu_attn_interface.py:238-245), self attention only.
+static int window_causal(int64_t wl, int64_t wr) { return wr == 0 ? 1 : 0; }   // right == 0: the causal tile loops apply
+
+int mi355_hstu_attn_fwd_window(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride,
+                               int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride,
+                               int64_t k_head_stride, int64_t v_head_stride, int64_t o_head_stride, const int32_t* cu_seqlens,
+                               int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen, int64_t window_left,
+                               int64_t window_right, float alpha, float scaling_seqlen, hipStream_t stream) {
+  MI355_CHECK_ARG(window_left >= -1 && window_right >= -1 && window_left < (1 << 30) && window_right < (1 << 30), "bad window");
+  tl_wl = (int)window_left; tl_wr = window_right == 0 ? -1 : (int)window_right;   // (right == 0 is what `causal` already says)
+  const int rc = mi355_hstu_attn_fwd(q, k, v, out, q_row_stride, k_row_stride, v_row_stride, o_row_stride, q_head_stride,
+                                     k_head_stride, v_head_stride, o_head_stride, cu_seqlens, batch, num_heads, head_dim,
+                                     max_seqlen, nullptr, nullptr, 1, window_causal(window_left, window_right), alpha,
+                                     scaling_seqlen, stream);
+  tl_wl = tl_wr = -1;
+  return rc;
+}
+
+int mi355_hstu_attn_bwd_window(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
+                               int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t do_row_stride,
+                               int64_t q_head_stride, int64_t k_head_stride, int64_t v_head_stride, int64_t do_head_stride,
+                               const int32_t* cu_seqlens, int64_t batch, int64_t num_heads, int64_t head_dim,
+                               int64_t max_seqlen, int64_t window_left, int64_t window_right, float alpha,
+                               float scaling_seqlen, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  MI355_CHECK_ARG(window_left >= -1 && window_right >= -1 && window_left < (1 << 30) && window_right < (1 << 30), "bad window");
+  tl_wl = (int)window_left; tl_wr = window_right == 0 ? -1 : (int)window_right;
+  const int rc = mi355_hstu_attn_bwd(dout, q, k, v, dq, dk, dv, q_row_stride, k_row_stride, v_row_stride, do_row_stride,
+                                     q_head_stride, k_head_stride, v_head_stride, do_head_stride, cu_seqlens, batch, num_heads,
+                                     head_dim, max_seqlen, nullptr, nullptr, 1, window_causal(window_left, window_right), alpha,
+                                     scaling_seqlen, workspace, workspace_bytes, stream);
+  tl_wl = tl_wr = -1;
+  return rc;
 }
 
 }  // extern "C"

@@ -7,7 +7,7 @@ examples/hstu/modules/hstu_attention.py:296-314): same argument meaning, same in
 contextual / target masks require causal -- hstu_api.cpp:359-430).
 Inference extensions (forward only): cu_seqlens_k longer than cu_seqlens_q (delta-q) and the paged KV cache
 (kv_cache / page_offsets / page_ids / last_page_lens).
-Not supported (raise): rab / drab, seqused_*, local windows, fp16 (bf16 only).  The raw ops of the fused layer
+Not supported (raise): rab / drab, seqused_*, local windows over a KV cache / delta-q, fp16 (bf16 only).  The raw ops of the fused layer
 (`torch.ops.fbgemm.hstu_varlen_{fwd,bwd}_{80,90}`) are registered by `hstu.hstu_ops_gpu`.
 """
 from __future__ import annotations
@@ -26,6 +26,10 @@ N.register_signatures({
                             c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_int, c_f, c_f, c_p, c_i64, c_p],
     "mi355_hstu_attn_bwd_workspace_bytes": [c_i64, c_i64, c_i64],
     "mi355_hstu_attn_bwd_ds_bytes": [c_i64, c_i64, c_i64, c_i64],
+    "mi355_hstu_attn_fwd_window": [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_i64,
+                                   c_i64, c_i64, c_i64, c_i64, c_f, c_f, c_p],
+    "mi355_hstu_attn_bwd_window": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p,
+                                   c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_f, c_p, c_i64, c_p],
     "mi355_hstu_attn_fwd_kv": [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64,
                                c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_int, c_f, c_f, c_p, c_p, c_p, c_p, c_i64, c_p],
     "mi355_append_kvcache": [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p,
@@ -50,11 +54,16 @@ def _check_inputs(q, k, v, cu_q, cu_k, num_contexts, num_targets, window_size, r
         if t is not None and t.dtype != torch.int32:
             raise RuntimeError(f"{name} must be int32")
     wl, wr = window_size
-    if wl != -1 or wr not in (-1, 0):
-        raise NotImplementedError("local attention windows are not supported; use (-1, 0) causal or (-1, -1) full")
-    causal = wr == 0
-    if not causal and (num_contexts is not None or num_targets is not None):
-        raise RuntimeError("contextual / target masks require causal attention")
+    wl, wr = (-1 if wl < 0 else int(wl)), (-1 if wr < 0 else int(wr))
+    # hstu_attn_interface.py:238-245 of the reference: contextual / target rows only with the plain causal mask
+    if num_contexts is not None and (wl, wr) != (-1, 0):
+        raise ValueError("AssertError: context is True and causal is not True, this is undefined behavior")
+    if num_targets is not None and (wl, wr) != (-1, 0):
+        raise ValueError("AssertError: target is True and causal is not True, this is undefined behavior")
+    local = not (wl == -1 and wr in (-1, 0))
+    if local and kv_cache is not None:
+        raise NotImplementedError("local attention windows over a paged KV cache are not supported")
+    causal = wr == 0 and not local
     if q.shape[-1] not in (32, 64, 128, 256):
         raise RuntimeError("head_dim must be one of 32, 64, 128, 256")
     return causal
@@ -159,6 +168,55 @@ class HstuAttnVarlenFunc(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None, None, None, None, None
 
 
+def hstu_varlen_fwd_window(q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, wl, wr, alpha):
+    """Raw forward with a local window: query i sees keys i - wl .. i + wr (a negative side is unbounded)."""
+    T, H, D = q.shape
+    out = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
+    B = cu_seqlens.numel() - 1
+    check(lib().mi355_hstu_attn_fwd_window(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0),
+                                           out.stride(0), q.stride(1), k.stride(1), v.stride(1), out.stride(1),
+                                           ptr(cu_seqlens), B, H, D, int(max_seqlen), int(wl), int(wr), c_f(alpha),
+                                           c_f(float(scaling_seqlen)), stream()), "hstu_attn_fwd_window")
+    return out
+
+
+def hstu_varlen_bwd_window(dout, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, wl, wr, alpha):
+    """Raw backward with a local window: returns (dq, dk, dv); same optional dS / P exchange as hstu_varlen_bwd."""
+    T, H, D = q.shape
+    dout = dout.contiguous() if dout.stride(-1) != 1 else dout
+    dq = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
+    dk, dv = torch.empty_like(dq), torch.empty_like(dq)
+    B = cu_seqlens.numel() - 1
+    dsb = lib().mi355_hstu_attn_bwd_ds_bytes(B, H, D, int(max_seqlen))
+    if dsb > _DS_MAX_BYTES:
+        dsb = 0
+    ws = torch.empty(max(dsb, 256), dtype=torch.uint8, device=q.device)
+    check(lib().mi355_hstu_attn_bwd_window(ptr(dout), ptr(q), ptr(k), ptr(v), ptr(dq), ptr(dk), ptr(dv), q.stride(0),
+                                           k.stride(0), v.stride(0), dout.stride(0), q.stride(1), k.stride(1), v.stride(1),
+                                           dout.stride(1), ptr(cu_seqlens), B, H, D, int(max_seqlen), int(wl), int(wr),
+                                           c_f(alpha), c_f(float(scaling_seqlen)), ptr(ws), ws.numel(), stream()),
+          "hstu_attn_bwd_window")
+    return dq, dk, dv
+
+
+class HstuAttnWindowFunc(torch.autograd.Function):
+    """local (sliding window) attention: query i sees keys i - left .. i + right (mi355_hstu_attn_{fwd,bwd}_window)"""
+
+    @staticmethod
+    def forward(ctx, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, wl, wr, alpha):
+        out = hstu_varlen_fwd_window(q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, wl, wr, alpha)
+        ctx.save_for_backward(q, k, v, cu_seqlens)
+        ctx.meta = (max_seqlen, scaling_seqlen, wl, wr, alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, cu = ctx.saved_tensors
+        max_seqlen, scaling, wl, wr, alpha = ctx.meta
+        dq, dk, dv = hstu_varlen_bwd_window(dout, q, k, v, cu, max_seqlen, scaling, wl, wr, alpha)
+        return dq, dk, dv, None, None, None, None, None, None
+
+
 def hstu_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, seqused_q, seqused_k, max_seqlen_q, max_seqlen_k,
                           scaling_seqlen, num_contexts, num_targets, target_group_size=1, window_size=(-1, -1), alpha=1.0,
                           rab=None, has_drab=False, kv_cache=None, page_offsets=None, page_ids=None, last_page_lens=None,
@@ -177,6 +235,11 @@ def hstu_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, seqused_q, sequse
     # keys than queries.
     same = kv_cache is None and (cu_seqlens_q.data_ptr() == cu_seqlens_k.data_ptr() or (
         cu_seqlens_q.shape == cu_seqlens_k.shape and q.shape[0] == k.shape[0] and int(max_seqlen_q) == int(max_seqlen_k)))
+    wl, wr = (-1 if window_size[0] < 0 else int(window_size[0])), (-1 if window_size[1] < 0 else int(window_size[1]))
+    if not (wl == -1 and wr in (-1, 0)):
+        if not same:
+            raise NotImplementedError("local attention windows with delta-q keys are not supported")
+        return HstuAttnWindowFunc.apply(q, k, v, cu_seqlens_q, int(max_seqlen_k), scaling_seqlen, wl, wr, float(alpha))
     if kv_cache is not None or not same:
         # inference: keys longer than the queries and / or history keys in the paged cache; no backward
         if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):

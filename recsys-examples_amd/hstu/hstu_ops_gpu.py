@@ -5,11 +5,11 @@ The reference's fused HSTU layer does not go through `hstu_attn_varlen_func`: it
 `torch.cuda.get_device_properties(0).major` -- which is 9 on gfx950, so an unchanged example lands on the `_90` names here.
 Importing this module (the example does: `import hstu.hstu_ops_gpu`, fused_hstu_op.py:19-20) defines all four ops with the
 positional order of those call sites, backed by the gfx950 kernels, plus Meta kernels for export.  Arguments this build has
-no kernel for (rab / drab, seqused, arbitrary mask functions, fp8 quantisation, local windows) must be None / default; the
-ops raise otherwise."""
+no kernel for (rab / drab, seqused, arbitrary mask functions, fp8 quantisation) must be None / default; the ops raise
+otherwise.  `window_size_left / right` with a finite side run the local-window kernels."""
 import torch
 
-from .hstu_attn_interface import hstu_varlen_bwd, hstu_varlen_fwd
+from .hstu_attn_interface import hstu_varlen_bwd, hstu_varlen_bwd_window, hstu_varlen_fwd, hstu_varlen_fwd_window
 
 _T = "Tensor"
 _O = "Tensor?"
@@ -23,29 +23,36 @@ def _already_there(name: str) -> bool:
         return False
 
 
-def _check(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, wl, wr, rab, func, quant_mode=-1, extra=()):
+def _check(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, wl, wr, rab, func, quant_mode=-1, extra=(),
+           num_contexts=None, num_targets=None):
     if seqused_q is not None or seqused_k is not None:
         raise NotImplementedError("seqused_q / seqused_k are not supported")
     if rab is not None or func is not None:
         raise NotImplementedError("rab / arbitrary mask functions are not supported")
     if quant_mode not in (-1, None) or any(e is not None for e in extra):
         raise NotImplementedError("fp8 quantisation is not supported")
-    if wl != -1 or wr not in (-1, 0):
-        raise NotImplementedError("local attention windows are not supported; use (-1, 0) causal or (-1, -1) full")
     if q.dtype != torch.bfloat16:
         raise RuntimeError("hstu_varlen ops support bf16 only in this build")
     if max_q != max_k or q.shape[0] != k.shape[0] or cu_q.shape != cu_k.shape:
         raise NotImplementedError("the raw training ops are self-attention only (cu_seqlens_q == cu_seqlens_k)")
     if v.shape != k.shape:
         raise RuntimeError("v must have the shape of k (the fused layer asserts linear_dim == attention_dim, hstu_attention.py:248-250)")
-    return wr == 0
+    wl, wr = (-1 if wl < 0 else int(wl)), (-1 if wr < 0 else int(wr))
+    window = None if (wl == -1 and wr in (-1, 0)) else (wl, wr)
+    if (num_contexts is not None or num_targets is not None) and (wl, wr) != (-1, 0):
+        # hstu_api.cpp:163-164
+        raise ValueError("context / target masks need the causal mask (-1, 0): undefined behaviour otherwise")
+    return wr == 0 and window is None, window
 
 
 def _fwd(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, scaling_seqlen, num_contexts, num_targets, target_group_size,
          wl, wr, alpha, rab, func, quant_mode=-1, output_dtype=0):
-    causal = _check(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, wl, wr, rab, func, quant_mode)
+    causal, window = _check(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, wl, wr, rab, func, quant_mode,
+                            num_contexts=num_contexts, num_targets=num_targets)
     if output_dtype not in (0, None):
         raise NotImplementedError("output_dtype must be 0 (bf16)")
+    if window is not None:
+        return hstu_varlen_fwd_window(q, k, v, cu_q, int(max_k), scaling_seqlen, window[0], window[1], float(alpha)), None
     out = hstu_varlen_fwd(q, k, v, cu_q, int(max_k), scaling_seqlen, num_contexts, num_targets, int(target_group_size), causal,
                           float(alpha))
     return out, None
@@ -53,11 +60,15 @@ def _fwd(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, scaling_seqlen
 
 def _bwd(dout, q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, scaling_seqlen, dq, dk, dv, num_contexts, num_targets,
          target_group_size, wl, wr, alpha, rab, has_drab, func, deterministic, quant_mode=-1, extra=()):
-    causal = _check(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, wl, wr, rab, func, quant_mode, extra)
+    causal, window = _check(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, wl, wr, rab, func, quant_mode, extra,
+                            num_contexts=num_contexts, num_targets=num_targets)
     if has_drab:
         raise NotImplementedError("drab is not supported")
-    g = hstu_varlen_bwd(dout, q, k, v, cu_q, int(max_k), scaling_seqlen, num_contexts, num_targets, int(target_group_size),
-                        causal, float(alpha))       # (deterministic by construction: no atomics in the dQ pass)
+    if window is not None:
+        g = hstu_varlen_bwd_window(dout, q, k, v, cu_q, int(max_k), scaling_seqlen, window[0], window[1], float(alpha))
+    else:
+        g = hstu_varlen_bwd(dout, q, k, v, cu_q, int(max_k), scaling_seqlen, num_contexts, num_targets,
+                            int(target_group_size), causal, float(alpha))   # (deterministic by construction: no atomics)
     res = []
     for given, new in zip((dq, dk, dv), g):
         if given is not None:

@@ -21,7 +21,7 @@ def _bf(x):
     return torch.from_numpy(np.ascontiguousarray(x)).to(DEV).to(torch.bfloat16)
 
 
-def _run(q, k, v, off, N, targets, ctx, grp, causal, alpha, dout=None, scaling=None):
+def _run(q, k, v, off, N, targets, ctx, grp, causal, alpha, dout=None, scaling=None, window=None):
     from hstu import hstu_attn_varlen_func
 
     qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
@@ -29,7 +29,8 @@ def _run(q, k, v, off, N, targets, ctx, grp, causal, alpha, dout=None, scaling=N
     nt = None if targets is None else torch.from_numpy(np.asarray(targets, np.int32)).to(DEV)
     nc = None if ctx is None else torch.from_numpy(np.asarray(ctx, np.int32)).to(DEV)
     out = hstu_attn_varlen_func(qq, kk, vv, cu, cu, None, None, N, N, scaling if scaling is not None else N, nc, nt,
-                                target_group_size=grp, window_size=(-1, 0) if causal else (-1, -1), alpha=alpha)
+                                target_group_size=grp,
+                                window_size=window if window is not None else ((-1, 0) if causal else (-1, -1)), alpha=alpha)
     if dout is None:
         return out, None
     out.backward(dout)
@@ -122,6 +123,115 @@ def test_backward_exchange_is_bit_identical_to_the_recomputing_passes(d, mode, m
     assert float(g_x[0].float().abs().max()) > 0
 
 
+# ------------------------------------------------------------------------------------------ local (sliding) windows
+W = np.load(os.path.join(os.path.dirname(__file__), "golden", "hstu_window_golden.npz"))
+WINDOWS = [(111, 11), (111, 222), (50, 0), (0, 0), (0, 7), (-1, 40), (64, -1), (1000, 0), (3, 1000), (200, 130)]
+
+
+def _assert_vs_oracle(out, grads, ref, dq, dk, dv):
+    for got, want, tol in ((out, ref, 6e-3), (grads[0], dq, 1.2e-2), (grads[1], dk, 1.2e-2), (grads[2], dv, 1.2e-2)):
+        gn = got.detach().float().cpu().numpy()
+        err = np.abs(gn - want).max()
+        assert err <= tol * np.abs(want).max() + 1e-6, f"{err} vs scale {np.abs(want).max()}"
+
+
+@pytest.mark.parametrize("name", [str(c) for c in W["cases"]])
+def test_local_window_golden(name):
+    """sliding window forward + backward against the reference test's own dense statement (construct_mask +
+    _hstu_attention_maybe_from_cache of corelib/hstu/test.py, fp32; tests/golden/gen_hstu_window_golden.py)."""
+    H, d, wl, wr, N = (int(x) for x in W[f"{name}/meta"])
+    g = lambda k: W[f"{name}/{k}"]
+    out, grads = _run(_bf(g("q")), _bf(g("k")), _bf(g("v")), g("off"), N, None, None, 1, False, 1.0 / d ** 0.5,
+                      dout=_bf(g("dout")), window=(wl, wr))
+    _assert_vs_oracle(out, grads, g("out"), g("dq"), g("dk"), g("dv"))
+
+
+def test_local_window_with_the_mask_alone():
+    """by default the tile loops are clipped to the window's band; MI355_HSTU_WSKIP=0 keeps the full loops and lets the
+    per-element mask do all the work.  The library reads the switch once, so the window tests are re-run in a child
+    process with it: same goldens, same oracle comparisons, same exchange bit-identity."""
+    import subprocess
+    import sys
+
+    if os.environ.get("MI355_HSTU_WSKIP") == "0":
+        pytest.skip("already the unclipped run")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "local_window and not mask_alone"], env=dict(os.environ, MI355_HSTU_WSKIP="0"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+@pytest.mark.parametrize("window", WINDOWS, ids=lambda w: f"w{w[0]}_{w[1]}")
+def test_local_window_random_jagged_vs_oracle(d, window):
+    """windows narrower and wider than the 64 / 128-row tiles, one-sided, zero-width sides and wider than the sequence
+    (hstu_api.cpp:154-165: a side < 0 or > max_seqlen_k is unbounded), over sequences of several tiles, ragged ends,
+    an empty and a 1-token sequence."""
+    rng = np.random.default_rng(d + 7 * window[0] + window[1])
+    lengths = np.array([517, 1, 0, 333, 129, 64])
+    off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    T, H, N = int(off[-1]), 2, int(lengths.max())
+    mk = lambda lo, hi: torch.from_numpy(rng.uniform(lo, hi, (T, H, d)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    q, k, v, dout = mk(-1, 1), mk(-1, 1), mk(-1, 1), mk(0, 1)
+    alpha = 1.0 / d ** 0.5
+    out, grads = _run(q, k, v, off, N, None, None, 1, False, alpha, dout=dout, window=window)
+    qn, kn, vn, dn = (t.float().cpu().numpy() for t in (q, k, v, dout))
+    ref = ho.hstu_attn_fwd(qn, kn, vn, off, alpha, N, local_window=window)
+    dq, dk, dv = ho.hstu_attn_bwd(dn, qn, kn, vn, off, alpha, N, local_window=window)
+    _assert_vs_oracle(out, grads, ref, dq, dk, dv)
+
+
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+@pytest.mark.parametrize("window", [(70, 0), (33, 200), (-1, 65), (300, -1)], ids=lambda w: f"w{w[0]}_{w[1]}")
+def test_local_window_exchange_is_bit_identical_to_the_recomputing_passes(d, window, monkeypatch):
+    """the dV / dQ passes replay the dK pass' clipped query span (kv_span) to know which exchanged sub-tiles exist: with
+    and without the scratch buffer the gradients must agree bit for bit, and the clipped loops (default) must agree bit
+    for bit with... the forward of the unclipped ones is covered by test_local_window_golden[*-0]."""
+    import hstu.hstu_attn_interface as hi
+
+    rng = np.random.default_rng(d + window[0] + window[1])
+    lengths = np.array([700, 1, 0, 333, 129, 64, 257, 31])
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    T, H, N = int(off[-1]), 2, int(lengths.max())
+    mk = lambda: torch.from_numpy(rng.uniform(-1, 1, (T, H, d)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    q, k, v, dout = mk(), mk(), mk(), mk()
+    o_x, g_x = _run(q, k, v, off, N, None, None, 1, False, 1.0 / d ** 0.5, dout=dout, window=window)
+    monkeypatch.setattr(hi, "_DS_MAX_BYTES", 0)
+    o_r, g_r = _run(q, k, v, off, N, None, None, 1, False, 1.0 / d ** 0.5, dout=dout, window=window)
+    assert torch.equal(o_x, o_r)
+    for a, b, name in zip(g_x, g_r, ("dq", "dk", "dv")):
+        assert torch.equal(a, b), f"{name}: {(a.float() - b.float()).abs().max().item()}"
+    assert float(g_x[0].float().abs().max()) > 0
+
+
+def test_local_window_degenerate_pairs_equal_the_plain_masks():
+    """(L+, 0) is the causal mask and (L+, L+) the full one, bit for bit (hstu_api.cpp:154-159)."""
+    rng = np.random.default_rng(11)
+    lengths = np.array([300, 77, 129])
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    T, H, d, N = int(off[-1]), 2, 64, 300
+    mk = lambda: torch.from_numpy(rng.uniform(-1, 1, (T, H, d)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    q, k, v, dout = mk(), mk(), mk(), mk()
+    for window, causal in (((299, 0), True), ((5000, 0), True), ((299, 299), False), ((-1, 299), False), ((299, -1), False)):
+        o_w, g_w = _run(q, k, v, off, N, None, None, 1, False, 0.125, dout=dout, window=window)
+        o_p, g_p = _run(q, k, v, off, N, None, None, 1, causal, 0.125, dout=dout)
+        assert torch.equal(o_w, o_p), window
+        for a, b in zip(g_w, g_p):
+            assert torch.equal(a, b), window
+
+
+def test_local_window_rejects_contexts_and_targets():
+    from hstu import hstu_attn_varlen_func
+
+    q = torch.zeros(8, 1, 32, device=DEV, dtype=torch.bfloat16)
+    cu = torch.tensor([0, 8], dtype=torch.int32, device=DEV)
+    one = torch.tensor([1], dtype=torch.int32, device=DEV)
+    with pytest.raises(ValueError):   # hstu_attn_interface.py:238-245 of the reference
+        hstu_attn_varlen_func(q, q, q, cu, cu, None, None, 8, 8, 8, one, None, window_size=(3, 0))
+    with pytest.raises(ValueError):
+        hstu_attn_varlen_func(q, q, q, cu, cu, None, None, 8, 8, 8, None, one, window_size=(3, 2))
+
+
 def test_strided_inputs_and_scaling_seqlen():
     """q/k/v as slices of one fused [T, 3, H, d] tensor (what the fused HSTU layer hands over) and
     scaling_seqlen decoupled from max_seqlen."""
@@ -146,8 +256,8 @@ def test_rejects_unsupported():
         hstu_attn_varlen_func(q, q, q, cu, cu, None, None, 4, 4, 4, None, None)  # head_dim 48
     q = torch.zeros(4, 1, 32, device=DEV, dtype=torch.bfloat16)
     nt = torch.tensor([1], dtype=torch.int32, device=DEV)
-    with pytest.raises(RuntimeError):
-        hstu_attn_varlen_func(q, q, q, cu, cu, None, None, 4, 4, 4, None, nt, window_size=(-1, -1))  # targets need causal
+    with pytest.raises(ValueError):   # targets need causal (the reference's own check and message, :238-245)
+        hstu_attn_varlen_func(q, q, q, cu, cu, None, None, 4, 4, 4, None, nt, window_size=(-1, -1))
     with pytest.raises(RuntimeError):
         hstu_attn_varlen_func(q.float(), q.float(), q.float(), cu, cu, None, None, 4, 4, 4, None, None)
 
@@ -462,5 +572,15 @@ def test_raw_fbgemm_ops_of_the_fused_layer_match_the_wrapper():
                                                 1, -1, 0, alpha, -1, None, False, None, None, None, None, None, None, None, None,
                                                 None, None, None, None, 0, False)
         assert torch.equal(r[0], gq) and r[0].data_ptr() == bq.data_ptr() and torch.equal(r[1], gk) and torch.equal(r[2], gv)
-        with pytest.raises(NotImplementedError):
+        with pytest.raises(ValueError):   # contexts / targets with a window: undefined (hstu_api.cpp:163-164)
             torch.ops.fbgemm.hstu_varlen_fwd_80(q, k, v, cu, cu, None, None, L, L, L, nc, nt, 1, 16, 0, alpha, None, None)
+    # local window through the raw ops == through the wrapper
+    ref = hstu_attn_varlen_func(q, k, v, cu, cu.clone(), None, None, L, L, L, None, None, 1, (16, 5), alpha)
+    gq, gk, gv = torch.autograd.grad(ref, (q, k, v), dout)
+    with torch.no_grad():
+        o80, _ = torch.ops.fbgemm.hstu_varlen_fwd_80(q, k, v, cu, cu, None, None, L, L, L, None, None, 1, 16, 5, alpha, None, None)
+        assert torch.equal(o80, ref)
+        r = torch.ops.fbgemm.hstu_varlen_bwd_90(dout, None, q, None, k, None, v, cu, cu, None, None, L, L, L, None, None, None, None,
+                                                None, 1, 16, 5, alpha, -1, None, False, None, None, None, None, None, None, None,
+                                                None, None, None, None, None, 0, False)
+        assert torch.equal(r[0], gq) and torch.equal(r[1], gk) and torch.equal(r[2], gv)

@@ -10,6 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32); ap.add_argument("--seqlen", type=int, default=512)
 ap.add_argument("--heads", type=int, default=4); ap.add_argument("--dim", type=int, default=256)
 ap.add_argument("--jagged", action="store_true"); ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--window", type=int, nargs=2, default=None, help="local window (left right): times the windowed kernels too")
 a = ap.parse_args()
 dev = torch.device("cuda")
 rng = np.random.default_rng(0)
@@ -32,3 +33,15 @@ tf = timeit(lambda: hstu_varlen_fwd(q, k, v, cu, a.seqlen, a.seqlen, None, None,
 tb = timeit(lambda: hstu_varlen_bwd(do, q, k, v, cu, a.seqlen, a.seqlen, None, None, 1, True, alpha))
 print(f"T={T} H={a.heads} d={a.dim} causal  fwd {tf*1e3:.1f} us  {fl/tf/1e9:.1f} TFLOP/s  {T/tf/1e3:.3e} tok/s | "
       f"bwd {tb*1e3:.1f} us  {2.5*fl/tb/1e9:.1f} TFLOP/s | fwd+bwd {T/(tf+tb)/1e3:.3e} tok/s")
+if a.window is not None:
+    from hstu.hstu_attn_interface import HstuAttnWindowFunc
+    wl, wr = a.window
+    qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
+    def fwd_bwd():
+        out = HstuAttnWindowFunc.apply(qq, kk, vv, cu, a.seqlen, a.seqlen, wl, wr, alpha)
+        out.backward(do)
+    def fwd_only():
+        with torch.no_grad():
+            HstuAttnWindowFunc.apply(q, k, v, cu, a.seqlen, a.seqlen, wl, wr, alpha)
+    tw, twf = timeit(fwd_bwd), timeit(fwd_only)
+    print(f"window ({wl}, {wr}): fwd {twf*1e3:.1f} us  fwd+bwd {tw*1e3:.1f} us (autograd included)  vs causal fwd {tf*1e3:.1f} + bwd {tb*1e3:.1f} us")
