@@ -289,11 +289,22 @@ def hstu_section(args, device, world, dist=None):
         tf, tb = float(t[0]), float(t[1])
     fl = hstu_flops([L] * Bq, H, d)
     tot = (fl + 2.5 * fl) / (tf + tb) / 1e9
+    # Both roofs of the op.  Algorithmic bytes: forward reads q, k, v and writes o (4 tensors of T*H*d bf16); backward
+    # reads q, k, v, dO and writes dq, dk, dv (7).  At L = 512 the op has 128 FLOP per byte, below the machine balance of
+    # 2.5 PFLOP/s / 8 TB/s = 312: C3's attention is HBM-bound before it is MFMA-bound.
+    tensor_bytes = T * H * d * 2
+    t_hbm_ms = (4 + 7) * tensor_bytes / (HBM_PEAK_GBPS * 1e9) * 1e3
+    t_mfma_ms = 3.5 * fl / (MFMA_BF16_PEAK_TFLOPS * 1e12) * 1e3
     return {"metric": "HSTU seq-tokens/sec (hstu_attn_varlen fwd+bwd kernels)", "value": world * T / (tf + tb) * 1e3,
             "unit": "tokens/s", "fwd_ms": tf, "bwd_ms": tb, "fwd_TFLOPs": fl / tf / 1e9, "bwd_TFLOPs": 2.5 * fl / tb / 1e9,
             "dtype": "bf16 operands, f32 accumulate", "scaling": "replicas only",
             "roofline": {"bound": "mfma", "achieved": tot, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tot / MFMA_BF16_PEAK_TFLOPS},
+            "roofline_hbm": {"bound": "hbm", "achieved": (4 + 7) * tensor_bytes / ((tf + tb) * 1e-3) / 1e9,
+                             "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": (4 + 7) * tensor_bytes / ((tf + tb) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             "floor_ms": {"hbm": t_hbm_ms, "mfma": t_mfma_ms},
+                             "note": "the binding roof at this shape is the larger floor"},
             "config": {"workload": f"C3 attention: batch {Bq} x L {L} (dense lengths), H {H}, d {d}, causal, alpha 1/sqrt(d)"}}
 
 

@@ -190,6 +190,24 @@ __device__ __forceinline__ void stage_rows(uint16_t* dst, const uint16_t* src, i
     *reinterpret_cast<uint4*>(dst + r * (D + 8) + 8 * dc) = t;
   }
 }
+#ifndef HSTU_TIMING
+#define HSTU_TIMING 0
+#endif
+#if HSTU_TIMING
+__device__ unsigned long long g_hstu_dbg[8 * 65536];
+__device__ __forceinline__ unsigned tick() {
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned t = (unsigned)__builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define TICK(v) const unsigned v = tick()
+#define TACC(i, a, b) tsum[i] += (b) - (a)
+#else
+#define TICK(v)
+#define TACC(i, a, b)
+#endif
+
 template <int D, bool kWin = false>   // kWin: local window; a variant of its own so that the plain masks pay nothing for it
 __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
   constexpr int KS = D + 8;    // padded K row (elements)
@@ -436,8 +454,13 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
     }
   }
   int it = 0;
+#if HSTU_TIMING
+  unsigned tsum[7] = {0, 0, 0, 0, 0, 0, 0};
+  const unsigned t_start = tick();
+#endif
   for (int n0 = n_beg; n0 < n_end; n0 += kBN, ++it) {
     pin_agpr(acc_o);
+    TICK(t0);
     __syncthreads();   // kDB: everyone is done with the other buffer, and this tile's commit (previous interval) is visible
     if constexpr (kDB) {
       uint16_t* cur = smem + (it & 1) * TILE;
@@ -449,13 +472,19 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
         if (n0 + 2 * kBN < n_end) fetch(n0 + 2 * kBN);
       }
     } else {
+      TICK(t1);
       commit(Ks, Vt);
       pin_agpr(acc_o);
+      TICK(t2);
       __syncthreads();
+      TICK(t3);
       if (n0 + kBN < n_end) fetch(n0 + kBN);
+      TICK(t4);
+      TACC(0, t0, t1); TACC(1, t1, t2); TACC(2, t2, t3); TACC(3, t3, t4);
     }
     pin_agpr(acc_o);
     if (!wave_live || n0 >= w_end || n0 < w_beg) continue;
+    TICK(t5);
 
     // ---- GEMM 1: S^T[64 keys x 32 q] = K Q^T, two 32-key tiles.  Operand fragments are fetched from LDS
     // in batches of 8 ahead of the 8 MFMAs that consume them (hipcc otherwise emits read-wait-mfma triples).
@@ -494,6 +523,8 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
     }
     fence_v(acc_s);
     pin_agpr(acc_o);
+    TICK(t6);
+    TACC(4, t5, t6);
     // ---- P^T = mask * SiLU(alpha S^T) / scaling, packed straight into the B operand of GEMM 2.
     // Tiles strictly below the diagonal of every row of the wave need no per-element mask.
     const bool full = a.causal && s.wl < 0 && (n0 + kBN - 1 <= dq + qrow0) && (!s.has_ctx || dq + qrow0 >= s.c) && (!s.has_tgt || n0 + kBN - 1 < s.hlen);
@@ -558,6 +589,11 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
       }
     };
     if (full) gemm2(std::true_type{}); else gemm2(std::false_type{});
+    TICK(t7);
+    TACC(5, t6, t7);
+#if HSTU_TIMING
+    tsum[6] += 1;
+#endif
     } else {
     // smaller head dims: 2-3 waves per SIMD already overlap SiLU with another wave's MFMAs, and the pipelined form costs
     // ~30 VGPRs (one occupancy step at d = 128)
@@ -622,6 +658,17 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
     }
   }
   fence_a(acc_o);
+#if HSTU_TIMING
+  {
+    const unsigned t_end = tick();
+    if (lane == 0) {
+      const int blk = ((int)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      unsigned long long* d = g_hstu_dbg + ((size_t)(blk * 4 + wv) % 65536) * 8;
+      for (int i = 0; i < 7; ++i) d[i] = tsum[i];
+      d[7] = t_end - t_start;
+    }
+  }
+#endif
 
   // ---- epilogue: O^T accumulator -> out[token][head][d] (bf16), 4 consecutive d per store
   if (qloc < Lq) {
@@ -1612,6 +1659,11 @@ static int window_skip() {   // MI355_HSTU_WSKIP=0: keep the full tile loops und
 }
 
 extern "C" {
+#if HSTU_TIMING
+int mi355_hstu_dbg_dump(void* out, int64_t bytes) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mi355::g_hstu_dbg), (size_t)bytes);
+}
+#endif
 
 // hstu_varlen_fwd (corelib/hstu/csrc/hstu_attn/hstu_api.cpp:335-523).  q, k, v, out: bf16 [total, H, d] with
 // explicit token / head strides (elements); cu_seqlens int32 [B+1] shared by q and k (self attention over
