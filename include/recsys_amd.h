@@ -470,6 +470,27 @@ int mi355_hstu_attn_bwd_window(const void* dout, const void* q, const void* k, c
                                const int32_t* cu_seqlens, int64_t batch, int64_t num_heads, int64_t head_dim,
                                int64_t max_seqlen, int64_t window_left, int64_t window_right, float alpha,
                                float scaling_seqlen, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+/* Relative attention bias: `rab` / `has_drab` of hstu_attn_varlen_func (hstu_attn_interface.py:185-279; varlen_fwd /
+ * varlen_bwd hstu_api.cpp:100-111,253-263,417-430,659-667).  rab: bf16 [batch][heads or 1][max_seqlen][max_seqlen] by its
+ * batch / head / row strides in elements (head stride 0: one matrix for all heads), added to q_i . k_j before alpha and
+ * SiLU.  Mask as window_size of hstu_attn_varlen_func: (-1, 0) causal (num_contexts / num_targets allowed), (-1, -1) full,
+ * otherwise a local window.  Self attention over contiguous keys.  drab (nullable): bf16, one matrix per head with its own
+ * strides, zero-filled by the caller; receives d loss / d rab at every position inside the sequences. */
+int mi355_hstu_attn_fwd_rab(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride, int64_t k_row_stride,
+                            int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride, int64_t k_head_stride,
+                            int64_t v_head_stride, int64_t o_head_stride, const int32_t* cu_seqlens, int64_t batch,
+                            int64_t num_heads, int64_t head_dim, int64_t max_seqlen, const int32_t* num_contexts,
+                            const int32_t* num_targets, int64_t target_group_size, int64_t window_left, int64_t window_right,
+                            float alpha, float scaling_seqlen, const void* rab, int64_t rab_batch_stride,
+                            int64_t rab_head_stride, int64_t rab_row_stride, hipStream_t stream);
+int mi355_hstu_attn_bwd_rab(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
+                            int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t do_row_stride,
+                            int64_t q_head_stride, int64_t k_head_stride, int64_t v_head_stride, int64_t do_head_stride,
+                            const int32_t* cu_seqlens, int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen,
+                            const int32_t* num_contexts, const int32_t* num_targets, int64_t target_group_size,
+                            int64_t window_left, int64_t window_right, float alpha, float scaling_seqlen, const void* rab,
+                            int64_t rab_batch_stride, int64_t rab_head_stride, int64_t rab_row_stride, void* drab,
+                            int64_t drab_batch_stride, int64_t drab_head_stride, int64_t drab_row_stride, hipStream_t stream);
 /* Optional scratch of mi355_hstu_attn_bwd: given a 16-byte aligned workspace of at least this many bytes, the dK pass
  * hands dS to the dQ pass through it (bf16, B * H * ceil(max_seqlen/32)^2 sub-tiles of 2 KB) and the dQ pass skips the
  * S / dP recomputation (head_dim >= 128: P travels too and the dV pass becomes one GEMM); with a smaller (or no)

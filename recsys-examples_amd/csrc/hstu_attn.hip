@@ -73,6 +73,9 @@ struct AttnArgs {
   int H, causal, group;
   int wl, wr;                  // local window: keys i - wl .. i + wr of query i (-1: unbounded on that side)
   int wskip;                   // 1: tile loops are clipped to the window's band (0: the mask alone applies it; for A/B tests)
+  // relative attention bias (hstu_api.cpp:100-106,417-430): rab[b][h][i][j] (bf16, padded to max_seqlen_k in i and j) is
+  // added to q_i . k_j before alpha and SiLU; head stride 0 = one bias matrix shared by all heads.  NULL: none.
+  const uint16_t* rab; int64_t rab_b, rab_h, rab_r;
   float alpha, inv_scale;
   // ---- inference extensions (forward only; NULL / 0 for training) ----
   const int* cu_seqlens_k;     // [B+1] key offsets when the keys are longer than the queries (delta-q); NULL = same as q
@@ -172,6 +175,20 @@ __device__ __forceinline__ int band_key_end(const AttnArgs& a, int last_row, int
   return (a.wskip && a.wr >= 0 && hi < end) ? hi : end;
 }
 
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
+// S^T accumulators (lane = query row, registers = keys (rr & 3) + 8 (rr >> 2) + 4 hi of each 32-key sub-tile) += rab[i][.]
+// `row` points at rab[b][h][i][0] (NULL for a row past the sequence); 2-byte loads: the bias path is not a tuned one.
+template <int NT>
+__device__ __forceinline__ void add_rab_row(f32x16_t (&acc)[NT], const uint16_t* row, int n0, int hi, int L) {
+  if (row == nullptr) return;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int key = n0 + 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+      if (key < L) acc[t][rr] += bf16_bits_to_f32(row[key]);
+    }
+}
 // SiLU(alpha * acc) * inv_scale from the raw accumulator: 4 plain VALU + 2 transcendental ops
 __device__ __forceinline__ float silu_scaled(float acc, float neg_alpha_log2e, float alpha_inv_scale) {
   const float t = __builtin_amdgcn_exp2f(acc * neg_alpha_log2e);
@@ -208,7 +225,7 @@ __device__ __forceinline__ unsigned tick() {
 #define TACC(i, a, b)
 #endif
 
-template <int D, bool kWin = false>   // kWin: local window; a variant of its own so that the plain masks pay nothing for it
+template <int D, bool kWin = false, bool kRab = false>   // kWin: local window, kRab: attention bias; variants of their own so that the plain path pays nothing
 __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
   constexpr int KS = D + 8;    // padded K row (elements)
   constexpr bool kVTR = HSTU_VTR != 0;
@@ -522,6 +539,10 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
       }
     }
     fence_v(acc_s);
+    if constexpr (kRab) {
+      const uint16_t* row = qi < s.L ? a.rab + (int64_t)b * a.rab_b + (int64_t)h * a.rab_h + (int64_t)qi * a.rab_r : nullptr;
+      add_rab_row<2>(acc_s, row, n0, hi, s.L);
+    }
     pin_agpr(acc_o);
     TICK(t6);
     TACC(4, t5, t6);
@@ -852,6 +873,8 @@ struct BwdAttnArgs {
   uint16_t* p_ws;              // same layout, P = SiLU(alpha S) / scale: the dV pass then needs no S recomputation either
   int ng;                      // 32-row groups per sequence the buffer is laid out for: ceil(max_seqlen / 32)
   int bq_kv;                   // query rows per step of the dK pass (the dQ pass must know which sub-tiles it wrote)
+  // d loss / d rab (hstu_api.cpp:659-667): [b][h][i][j] bf16, zero-filled by the caller; the dK pass writes dS there
+  uint16_t* drab; int64_t drab_b, drab_h, drab_r;
 };
 __device__ __forceinline__ int64_t xch_tile(const BwdAttnArgs& g, int b, int h, int kg, int qg) {
   return ((((int64_t)b * g.f.H + h) * g.ng + kg) * g.ng + qg) * 1024;   // 1024 bf16 = 2 KB
@@ -883,7 +906,7 @@ __device__ __forceinline__ bool kv_visited(const KvSpan& v, int step) { return (
 // K / V fragments exceed the register file of one wave, so the pass is split: MODE 1 = dV only (S -> P -> dV),
 // MODE 2 = dK only (S, dP -> dS -> dK).  Loop structure as in the forward: register-prefetched tiles, explicit
 // AGPR output accumulators, double-buffered LDS fragment batches, branch-free mask.
-template <int D, int BQ, int MODE, bool kPre, bool kXP = false>
+template <int D, int BQ, int MODE, bool kPre, bool kXP = false, bool kRab = false>
 __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
   const AttnArgs& a = g.f;
   constexpr bool kDV = MODE != 2, kDK = MODE != 1;   // kXP (MODE 2): P is computed as well and left for the dV pass
@@ -1017,6 +1040,18 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
     }
     fence_v(acc_s);
     if (kDK) fence_v(acc_p);
+    if constexpr (kRab) {   // lane = key kj, registers = query rows: rab[qi][kj]
+      if (kj < s.L) {
+        const uint16_t* col = a.rab + (int64_t)b * a.rab_b + (int64_t)h * a.rab_h + kj;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) {
+            const int qi = i0 + 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+            if (qi < s.L) acc_s[t][rr] += bf16_bits_to_f32(col[(int64_t)qi * a.rab_r]);
+          }
+      }
+    }
     if (kDV) pin_agpr(acc_dv);
     if (kDK) pin_agpr(acc_dk);
     // P and dS packed as B operands (k = query rows held in the registers, lane = key)
@@ -1048,6 +1083,16 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
         }
         if (kDV || kXP) pk[r >> 1] = pack_bf16(p2[0], p2[1]);
         if (kDK) sk[r >> 1] = pack_bf16(s2[0], s2[1]);
+        if constexpr (kRab && kDK) {   // d rab = dS (x = alpha (q.k + rab): the same factor alpha as d (q.k))
+          if (g.drab && kj < s.L) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int qi = i0 + 32 * t + ((r + u) & 3) + 8 * ((r + u) >> 2) + 4 * hi;
+              if (qi < s.L)
+                g.drab[(int64_t)b * g.drab_b + (int64_t)h * g.drab_h + (int64_t)qi * g.drab_r + kj] = (uint16_t)(sk[r >> 1] >> (16 * u));
+            }
+          }
+        }
       }
       if constexpr (kXP) {
         if (i0 + 32 * t < s.L) {   // P for the dV pass, same layout as dS below
@@ -1130,7 +1175,7 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
 }
 
 // pass B: one workgroup = 128 queries (32 per wave); loops over key tiles of BK keys -> dQ
-template <int D, int BK, bool kPre>
+template <int D, int BK, bool kPre, bool kRab = false>
 __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
   const AttnArgs& a = g.f;
   constexpr int RS = D + 8, TS = BK + 8, NT = BK / 32;
@@ -1235,6 +1280,10 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
     }
     fence_v(acc_s);
     fence_v(acc_p);
+    if constexpr (kRab) {
+      const uint16_t* row = qi < s.L ? a.rab + (int64_t)b * a.rab_b + (int64_t)h * a.rab_h + (int64_t)qi * a.rab_r : nullptr;
+      add_rab_row<NT>(acc_s, row, n0, hi, s.L);
+    }
     pin_agpr(acc_dq);
     bf16x8_t sf[BK / 16];
 #pragma unroll
@@ -1544,27 +1593,27 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_v_p_kernel(BwdAttnArg
   }
 }
 
-template <int D, int BQ, int MODE, bool kPre, bool kXP = false>
+template <int D, int BQ, int MODE, bool kPre, bool kXP = false, bool kRab = false>
 static void launch_bwd_kv(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
   constexpr bool kDV = MODE != 2, kDK = MODE != 1;
   const size_t timg = HSTU_BWD_TR ? (size_t)BQ * (D == 32 ? 32 : D + 32) : (size_t)D * (BQ + 8);
   const size_t smem = (size_t)(BQ * (D + 8) + (kDK ? BQ * (D + 8) + timg : 0) + (kDV ? timg : 0)) * sizeof(uint16_t);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_kv_kernel<D, BQ, MODE, kPre, kXP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_kv_kernel<D, BQ, MODE, kPre, kXP, kRab>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((hstu_bwd_kv_kernel<D, BQ, MODE, kPre, kXP>), grid, dim3(256), smem, stream, g);
+  hipLaunchKernelGGL((hstu_bwd_kv_kernel<D, BQ, MODE, kPre, kXP, kRab>), grid, dim3(256), smem, stream, g);
 }
-template <int D, int BK, bool kPre>
+template <int D, int BK, bool kPre, bool kRab = false>
 static void launch_bwd_q(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
   const size_t smem_q = (size_t)(2 * BK * (D + 8) + (HSTU_BWD_TR ? (size_t)BK * (D == 32 ? 32 : D + 32) : (size_t)D * (BK + 8))) * sizeof(uint16_t);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_q_kernel<D, BK, kPre>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_q);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_q_kernel<D, BK, kPre, kRab>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_q);
     attr_set = true;
   }
-  hipLaunchKernelGGL((hstu_bwd_q_kernel<D, BK, kPre>), grid, dim3(256), smem_q, stream, g);
+  hipLaunchKernelGGL((hstu_bwd_q_kernel<D, BK, kPre, kRab>), grid, dim3(256), smem_q, stream, g);
 }
 
 template <int D>
@@ -1582,6 +1631,20 @@ static void launch_bwd_q_ds(const BwdAttnArgs& g, dim3 grid, hipStream_t stream)
 template <int D>
 static int launch_bwd(BwdAttnArgs g, int B, int max_seqlen, hipStream_t stream) {
   dim3 grid(g.f.H, B, (max_seqlen + kBM - 1) / kBM);   // block rank slowest: see launch_fwd
+  if (g.f.rab) {   // attention bias: the recomputing passes (S needs the bias in every pass), dS doubles as d rab
+    g.ds_ws = g.p_ws = nullptr;
+    g.bq_kv = 64;
+    if constexpr (D >= 128) {
+      launch_bwd_kv<D, 64, 1, false, false, true>(g, grid, stream);
+      launch_bwd_kv<D, 32, 2, false, false, true>(g, grid, stream);
+      launch_bwd_q<D, D >= 256 ? 32 : 64, false, true>(g, grid, stream);
+    } else {
+      launch_bwd_kv<D, 64, 0, false, false, true>(g, grid, stream);
+      launch_bwd_q<D, 64, false, true>(g, grid, stream);
+    }
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+  }
   if constexpr (D >= 256) {
     static const int var = getenv("MI355_HSTU_VAR") ? atoi(getenv("MI355_HSTU_VAR")) : 1;   // tuning sweeps only; measured best = 1
     g.bq_kv = (var & 1) ? 64 : 32;
@@ -1634,6 +1697,8 @@ static int launch_fwd(const AttnArgs& a, int B, int max_seqlen, hipStream_t stre
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_kernel<D, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem) != hipSuccess) return MI355_ELAUNCH;
     attr_set = true;
   }
@@ -1641,7 +1706,8 @@ static int launch_fwd(const AttnArgs& a, int B, int max_seqlen, hipStream_t stre
   // are handed out first and the light ones fill in behind them.  With the rank in x (per-sequence order 8,6,4,2 key
   // tiles at L = 512) the CUs freed first drew heavy blocks again and the slowest CU did 16 tiles where 10 is the mean.
   dim3 grid(a.H, B, (max_seqlen + kBM - 1) / kBM);
-  if (a.wl >= 0 || a.wr >= 0) hipLaunchKernelGGL((hstu_fwd_kernel<D, true>), grid, dim3(256), smem, stream, a);
+  if (a.rab) hipLaunchKernelGGL((hstu_fwd_kernel<D, true, true>), grid, dim3(256), smem, stream, a);
+  else if (a.wl >= 0 || a.wr >= 0) hipLaunchKernelGGL((hstu_fwd_kernel<D, true>), grid, dim3(256), smem, stream, a);
   else hipLaunchKernelGGL((hstu_fwd_kernel<D, false>), grid, dim3(256), smem, stream, a);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
@@ -1653,6 +1719,9 @@ using namespace mi355;
 
 // local window of the call in flight on this thread (set by the *_window entry points around the plain ones)
 static thread_local int tl_wl = -1, tl_wr = -1;
+// attention bias of the call in flight on this thread (set by the *_rab entry points)
+struct RabCall { const uint16_t* rab = nullptr; int64_t rb = 0, rh = 0, rr = 0; uint16_t* drab = nullptr; int64_t db = 0, dh = 0, dr = 0; };
+static thread_local RabCall tl_rab;
 static int window_skip() {   // MI355_HSTU_WSKIP=0: keep the full tile loops under a window (A/B tests of the band clipping)
   static const int v = [] { const char* e = getenv("MI355_HSTU_WSKIP"); return e ? atoi(e) != 0 : 1; }();
   return v;
@@ -1709,6 +1778,7 @@ int mi355_hstu_attn_fwd_kv(const void* q, const void* k, const void* v, void* ou
   a.cu_seqlens = cu_seqlens_q; a.num_contexts = num_contexts; a.num_targets = num_targets;
   a.H = (int)num_heads; a.causal = causal; a.group = (int)target_group_size;
   a.wl = tl_wl; a.wr = tl_wr; a.wskip = window_skip();
+  a.rab = tl_rab.rab; a.rab_b = tl_rab.rb; a.rab_h = tl_rab.rh; a.rab_r = tl_rab.rr;
   a.alpha = alpha; a.inv_scale = 1.0f / scaling_seqlen;
   a.cu_seqlens_k = cu_seqlens_k; a.kv_cache = (const uint16_t*)kv_cache; a.page_offsets = page_offsets; a.page_ids = page_ids;
   a.last_page_lens = last_page_lens; a.page_size = (int)page_size;
@@ -1808,10 +1878,12 @@ int mi355_hstu_attn_bwd(const void* dout, const void* q, const void* k, const vo
   a.cu_seqlens = cu_seqlens; a.num_contexts = num_contexts; a.num_targets = num_targets;
   a.H = (int)num_heads; a.causal = causal; a.group = (int)target_group_size;
   a.wl = tl_wl; a.wr = tl_wr; a.wskip = window_skip();
+  a.rab = tl_rab.rab; a.rab_b = tl_rab.rb; a.rab_h = tl_rab.rh; a.rab_r = tl_rab.rr;
   a.alpha = alpha; a.inv_scale = 1.0f / scaling_seqlen;
   g.dout = (const uint16_t*)dout; g.do_row = do_row_stride; g.do_head = do_head_stride;
   g.dq = (uint16_t*)dq; g.dk = (uint16_t*)dk; g.dv = (uint16_t*)dv;
   g.ds_ws = nullptr; g.ng = (int)((max_seqlen + 31) / 32); g.bq_kv = 32;
+  g.drab = tl_rab.drab; g.drab_b = tl_rab.db; g.drab_h = tl_rab.dh; g.drab_r = tl_rab.dr;
   {
     const int64_t need = mi355_hstu_attn_bwd_ds_bytes(batch, num_heads, head_dim, max_seqlen);
     g.p_ws = nullptr;
@@ -1862,6 +1934,66 @@ int mi355_hstu_attn_bwd_window(const void* dout, const void* q, const void* k, c
                                      q_head_stride, k_head_stride, v_head_stride, do_head_stride, cu_seqlens, batch, num_heads,
                                      head_dim, max_seqlen, nullptr, nullptr, 1, window_causal(window_left, window_right), alpha,
                                      scaling_seqlen, workspace, workspace_bytes, stream);
+  tl_wl = tl_wr = -1;
+  return rc;
+}
+
+// Relative attention bias (`rab` / `has_drab` of hstu_attn_varlen_func; hstu_api.cpp:100-111,253-263,417-430,659-667).
+// rab: bf16 [batch][heads or 1][max_seqlen][max_seqlen] given by its batch / head / row strides in elements (last dim
+// contiguous; head stride 0 = one matrix for all heads); added to q_i . k_j before alpha and SiLU.  The mask is given as
+// in hstu_attn_varlen_func: window (-1, 0) causal (contextual / target rows allowed), (-1, -1) full, else a local window.
+// Self attention over contiguous keys only.  drab (backward, nullable): bf16 with its own strides, one matrix per head,
+// zero-filled by the caller; receives d loss / d rab (= dS) at every position inside the sequences.
+static int rab_mask(int64_t wl, int64_t wr, const int32_t* nc, const int32_t* nt, int* causal) {
+  MI355_CHECK_ARG(wl >= -1 && wr >= -1 && wl < (1 << 30) && wr < (1 << 30), "bad window");
+  const bool local = !(wl == -1 && (wr == -1 || wr == 0));
+  MI355_CHECK_ARG(!(nc || nt) || (wl == -1 && wr == 0), "contextual / target masks require the causal mask (-1, 0)");
+  *causal = wr == 0 ? 1 : 0;
+  tl_wl = local ? (int)wl : -1;
+  tl_wr = (local && wr != 0) ? (int)wr : -1;
+  return MI355_OK;
+}
+
+int mi355_hstu_attn_fwd_rab(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride, int64_t k_row_stride,
+                            int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride, int64_t k_head_stride,
+                            int64_t v_head_stride, int64_t o_head_stride, const int32_t* cu_seqlens, int64_t batch,
+                            int64_t num_heads, int64_t head_dim, int64_t max_seqlen, const int32_t* num_contexts,
+                            const int32_t* num_targets, int64_t target_group_size, int64_t window_left, int64_t window_right,
+                            float alpha, float scaling_seqlen, const void* rab, int64_t rab_batch_stride,
+                            int64_t rab_head_stride, int64_t rab_row_stride, hipStream_t stream) {
+  MI355_CHECK_ARG(rab != nullptr && rab_row_stride >= max_seqlen, "rab must be [batch][heads or 1][max_seqlen][max_seqlen]");
+  int causal = 0;
+  if (const int rc = rab_mask(window_left, window_right, num_contexts, num_targets, &causal)) return rc;
+  tl_rab = RabCall{(const uint16_t*)rab, rab_batch_stride, rab_head_stride, rab_row_stride, nullptr, 0, 0, 0};
+  const int rc = mi355_hstu_attn_fwd(q, k, v, out, q_row_stride, k_row_stride, v_row_stride, o_row_stride, q_head_stride,
+                                     k_head_stride, v_head_stride, o_head_stride, cu_seqlens, batch, num_heads, head_dim,
+                                     max_seqlen, num_contexts, num_targets, target_group_size, causal, alpha, scaling_seqlen,
+                                     stream);
+  tl_rab = RabCall{};
+  tl_wl = tl_wr = -1;
+  return rc;
+}
+
+int mi355_hstu_attn_bwd_rab(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
+                            int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t do_row_stride,
+                            int64_t q_head_stride, int64_t k_head_stride, int64_t v_head_stride, int64_t do_head_stride,
+                            const int32_t* cu_seqlens, int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen,
+                            const int32_t* num_contexts, const int32_t* num_targets, int64_t target_group_size,
+                            int64_t window_left, int64_t window_right, float alpha, float scaling_seqlen, const void* rab,
+                            int64_t rab_batch_stride, int64_t rab_head_stride, int64_t rab_row_stride, void* drab,
+                            int64_t drab_batch_stride, int64_t drab_head_stride, int64_t drab_row_stride, hipStream_t stream) {
+  MI355_CHECK_ARG(rab != nullptr && rab_row_stride >= max_seqlen, "rab must be [batch][heads or 1][max_seqlen][max_seqlen]");
+  MI355_CHECK_ARG(drab == nullptr || (drab_row_stride >= max_seqlen && drab_head_stride > 0),
+                  "drab must hold one [max_seqlen][max_seqlen] matrix per head");
+  int causal = 0;
+  if (const int rc = rab_mask(window_left, window_right, num_contexts, num_targets, &causal)) return rc;
+  tl_rab = RabCall{(const uint16_t*)rab, rab_batch_stride, rab_head_stride, rab_row_stride,
+                   (uint16_t*)drab, drab_batch_stride, drab_head_stride, drab_row_stride};
+  const int rc = mi355_hstu_attn_bwd(dout, q, k, v, dq, dk, dv, q_row_stride, k_row_stride, v_row_stride, do_row_stride,
+                                     q_head_stride, k_head_stride, v_head_stride, do_head_stride, cu_seqlens, batch, num_heads,
+                                     head_dim, max_seqlen, num_contexts, num_targets, target_group_size, causal, alpha,
+                                     scaling_seqlen, nullptr, 0, stream);
+  tl_rab = RabCall{};
   tl_wl = tl_wr = -1;
   return rc;
 }

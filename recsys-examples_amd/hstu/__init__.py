@@ -5,7 +5,7 @@ the gfx950 MFMA kernels (mi355_hstu_attn_fwd / mi355_hstu_attn_bwd).
 """
 from .hstu_attn_interface import (HstuAttnVarlenFunc, HstuAttnWindowFunc, append_kvcache, hstu_attn_varlen_func,  # noqa: F401
                                   hstu_varlen_bwd, hstu_varlen_bwd_window, hstu_varlen_fwd, hstu_varlen_fwd_kv,
-                                  hstu_varlen_fwd_window)
+                                  hstu_varlen_fwd_window, HstuAttnRabFunc, hstu_varlen_fwd_rab, hstu_varlen_bwd_rab)
 
 try:  # `import hstu` registers torch.ops.fbgemm.hstu_varlen_* (the example relies on it: fused_hstu_op.py:19)
     from . import hstu_ops_gpu  # noqa: F401

@@ -7,7 +7,7 @@ examples/hstu/modules/hstu_attention.py:296-314): same argument meaning, same in
 contextual / target masks require causal -- hstu_api.cpp:359-430).
 Inference extensions (forward only): cu_seqlens_k longer than cu_seqlens_q (delta-q) and the paged KV cache
 (kv_cache / page_offsets / page_ids / last_page_lens).
-Not supported (raise): rab / drab, seqused_*, local windows over a KV cache / delta-q, fp16 (bf16 only).  The raw ops of the fused layer
+Not supported (raise): seqused_*, rab or local windows over a KV cache / delta-q, fp16 (bf16 only).  The raw ops of the fused layer
 (`torch.ops.fbgemm.hstu_varlen_{fwd,bwd}_{80,90}`) are registered by `hstu.hstu_ops_gpu`.
 """
 from __future__ import annotations
@@ -26,6 +26,11 @@ N.register_signatures({
                             c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_int, c_f, c_f, c_p, c_i64, c_p],
     "mi355_hstu_attn_bwd_workspace_bytes": [c_i64, c_i64, c_i64],
     "mi355_hstu_attn_bwd_ds_bytes": [c_i64, c_i64, c_i64, c_i64],
+    "mi355_hstu_attn_fwd_rab": [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_i64,
+                                c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_f, c_p, c_i64, c_i64, c_i64, c_p],
+    "mi355_hstu_attn_bwd_rab": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p,
+                                c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_f, c_p, c_i64, c_i64, c_i64,
+                                c_p, c_i64, c_i64, c_i64, c_p],
     "mi355_hstu_attn_fwd_window": [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_i64,
                                    c_i64, c_i64, c_i64, c_i64, c_f, c_f, c_p],
     "mi355_hstu_attn_bwd_window": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p,
@@ -39,7 +44,13 @@ N.register_signatures({
 
 def _check_inputs(q, k, v, cu_q, cu_k, num_contexts, num_targets, window_size, rab, kv_cache, seqused_q, seqused_k):
     if rab is not None:
-        raise NotImplementedError("rab / drab is a 'next' row (DESIGN.md)")
+        # hstu_api.cpp:417-430: (batch, heads or 1, max_seqlen_k, max_seqlen_k), contiguous last dimension
+        if rab.dtype != q.dtype or rab.dim() != 4 or rab.stride(-1) != 1:
+            raise RuntimeError("rab must be a bf16 (batch, nheads or 1, max_seqlen_k, max_seqlen_k) tensor with a contiguous last dimension")
+        if rab.shape[0] != cu_q.numel() - 1 or rab.shape[1] not in (1, q.shape[1]) or rab.shape[2] != rab.shape[3]:
+            raise RuntimeError("Number of heads in rab must be 1 or equal to number of heads in query; shape (batch, heads, max_seqlen_k, max_seqlen_k)")
+        if kv_cache is not None:
+            raise NotImplementedError("rab over a paged KV cache is not supported")
     if seqused_q is not None or seqused_k is not None:
         raise NotImplementedError("seqused_q / seqused_k are not supported")
     if q.dtype != torch.bfloat16 or k.dtype != q.dtype or v.dtype != q.dtype:
@@ -217,6 +228,70 @@ class HstuAttnWindowFunc(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None, None, None
 
 
+def _rab_strides(rab, num_heads):
+    """(batch, head, row) strides in elements; one shared bias head is a head stride of 0"""
+    return rab.stride(0), (0 if rab.shape[1] == 1 else rab.stride(1)), rab.stride(2)
+
+
+def hstu_varlen_fwd_rab(q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_contexts, num_targets, target_group_size, wl, wr,
+                        alpha, rab):
+    """Raw forward with a relative attention bias: SiLU(alpha (q.k + rab[b, h, i, j])) (hstu_api.cpp:417-430)."""
+    T, H, D = q.shape
+    out = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
+    B = cu_seqlens.numel() - 1
+    rb, rh, rr = _rab_strides(rab, H)
+    check(lib().mi355_hstu_attn_fwd_rab(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
+                                        q.stride(1), k.stride(1), v.stride(1), out.stride(1), ptr(cu_seqlens), B, H, D,
+                                        int(max_seqlen), ptr(num_contexts), ptr(num_targets), int(target_group_size), int(wl),
+                                        int(wr), c_f(alpha), c_f(float(scaling_seqlen)), ptr(rab), rb, rh, rr, stream()),
+          "hstu_attn_fwd_rab")
+    return out
+
+
+def hstu_varlen_bwd_rab(dout, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_contexts, num_targets, target_group_size,
+                        wl, wr, alpha, rab, has_drab):
+    """Raw backward with a relative attention bias: (dq, dk, dv, drab or None).  drab has the shape of rab
+    (hstu_api.cpp:659-667, zero outside the sequences / the mask); with one shared bias head it is the sum over the heads,
+    formed in fp32 from per-head matrices (the reference adds bf16 pairs atomically: same value, no fixed order)."""
+    T, H, D = q.shape
+    dout = dout.contiguous() if dout.stride(-1) != 1 else dout
+    dq = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
+    dk, dv = torch.empty_like(dq), torch.empty_like(dq)
+    B = cu_seqlens.numel() - 1
+    N = rab.shape[-1]
+    rb, rh, rr = _rab_strides(rab, H)
+    drab = torch.zeros((B, H, N, N), dtype=q.dtype, device=q.device) if has_drab else None
+    ds = (drab.stride(0), drab.stride(1), drab.stride(2)) if has_drab else (0, 0, 0)
+    check(lib().mi355_hstu_attn_bwd_rab(ptr(dout), ptr(q), ptr(k), ptr(v), ptr(dq), ptr(dk), ptr(dv), q.stride(0), k.stride(0),
+                                        v.stride(0), dout.stride(0), q.stride(1), k.stride(1), v.stride(1), dout.stride(1),
+                                        ptr(cu_seqlens), B, H, D, int(max_seqlen), ptr(num_contexts), ptr(num_targets),
+                                        int(target_group_size), int(wl), int(wr), c_f(alpha), c_f(float(scaling_seqlen)),
+                                        ptr(rab), rb, rh, rr, ptr(drab), ds[0], ds[1], ds[2], stream()), "hstu_attn_bwd_rab")
+    if has_drab and rab.shape[1] == 1 and H > 1:
+        drab = drab.float().sum(1, keepdim=True).to(q.dtype)
+    return dq, dk, dv, drab
+
+
+class HstuAttnRabFunc(torch.autograd.Function):
+    """attention with a relative bias; rab receives a gradient when has_drab (hstu_attn_interface.py:23-183 of the reference)"""
+
+    @staticmethod
+    def forward(ctx, q, k, v, rab, cu_seqlens, max_seqlen, scaling_seqlen, num_contexts, num_targets, target_group_size, wl,
+                wr, alpha, has_drab):
+        out = hstu_varlen_fwd_rab(q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_contexts, num_targets,
+                                  target_group_size, wl, wr, alpha, rab)
+        ctx.save_for_backward(q, k, v, rab, cu_seqlens, num_contexts, num_targets)
+        ctx.meta = (max_seqlen, scaling_seqlen, target_group_size, wl, wr, alpha, has_drab)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, rab, cu, nc, nt = ctx.saved_tensors
+        max_seqlen, scaling, g, wl, wr, alpha, has_drab = ctx.meta
+        dq, dk, dv, drab = hstu_varlen_bwd_rab(dout, q, k, v, cu, max_seqlen, scaling, nc, nt, g, wl, wr, alpha, rab, has_drab)
+        return dq, dk, dv, drab, None, None, None, None, None, None, None, None, None, None
+
+
 def hstu_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, seqused_q, seqused_k, max_seqlen_q, max_seqlen_k,
                           scaling_seqlen, num_contexts, num_targets, target_group_size=1, window_size=(-1, -1), alpha=1.0,
                           rab=None, has_drab=False, kv_cache=None, page_offsets=None, page_ids=None, last_page_lens=None,
@@ -236,6 +311,15 @@ def hstu_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, seqused_q, sequse
     same = kv_cache is None and (cu_seqlens_q.data_ptr() == cu_seqlens_k.data_ptr() or (
         cu_seqlens_q.shape == cu_seqlens_k.shape and q.shape[0] == k.shape[0] and int(max_seqlen_q) == int(max_seqlen_k)))
     wl, wr = (-1 if window_size[0] < 0 else int(window_size[0])), (-1 if window_size[1] < 0 else int(window_size[1]))
+    if has_drab and rab is None:   # hstu_attn_interface.py:234-237 of the reference
+        raise ValueError("AssertError: rab is None, but has_drab is True, is not allowed in backward")
+    if rab is not None:
+        if not same:
+            raise NotImplementedError("rab with delta-q keys is not supported")
+        if rab.shape[-1] != int(max_seqlen_k):
+            raise RuntimeError("rab must be (batch, nheads or 1, max_seqlen_k, max_seqlen_k)")
+        return HstuAttnRabFunc.apply(q, k, v, rab, cu_seqlens_q, int(max_seqlen_k), scaling_seqlen, num_contexts, num_targets,
+                                     int(target_group_size), wl, wr, float(alpha), bool(has_drab))
     if not (wl == -1 and wr in (-1, 0)):
         if not same:
             raise NotImplementedError("local attention windows with delta-q keys are not supported")

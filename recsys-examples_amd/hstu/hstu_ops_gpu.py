@@ -5,11 +5,12 @@ The reference's fused HSTU layer does not go through `hstu_attn_varlen_func`: it
 `torch.cuda.get_device_properties(0).major` -- which is 9 on gfx950, so an unchanged example lands on the `_90` names here.
 Importing this module (the example does: `import hstu.hstu_ops_gpu`, fused_hstu_op.py:19-20) defines all four ops with the
 positional order of those call sites, backed by the gfx950 kernels, plus Meta kernels for export.  Arguments this build has
-no kernel for (rab / drab, seqused, arbitrary mask functions, fp8 quantisation) must be None / default; the ops raise
-otherwise.  `window_size_left / right` with a finite side run the local-window kernels."""
+no kernel for (seqused, arbitrary mask functions, fp8 quantisation) must be None / default; the ops raise otherwise.
+`window_size_left / right` with a finite side run the local-window kernels, `rab` / `has_drab` the bias kernels."""
 import torch
 
-from .hstu_attn_interface import hstu_varlen_bwd, hstu_varlen_bwd_window, hstu_varlen_fwd, hstu_varlen_fwd_window
+from .hstu_attn_interface import (hstu_varlen_bwd, hstu_varlen_bwd_rab, hstu_varlen_bwd_window, hstu_varlen_fwd,
+                                  hstu_varlen_fwd_rab, hstu_varlen_fwd_window)
 
 _T = "Tensor"
 _O = "Tensor?"
@@ -27,8 +28,10 @@ def _check(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, wl, wr, rab,
            num_contexts=None, num_targets=None):
     if seqused_q is not None or seqused_k is not None:
         raise NotImplementedError("seqused_q / seqused_k are not supported")
-    if rab is not None or func is not None:
-        raise NotImplementedError("rab / arbitrary mask functions are not supported")
+    if func is not None:
+        raise NotImplementedError("arbitrary mask functions are not supported")
+    if rab is not None and (rab.dim() != 4 or rab.shape[1] not in (1, q.shape[1]) or rab.shape[-1] != max_k or rab.stride(-1) != 1):
+        raise RuntimeError("rab must be (batch, nheads or 1, max_seqlen_k, max_seqlen_k) with a contiguous last dimension")
     if quant_mode not in (-1, None) or any(e is not None for e in extra):
         raise NotImplementedError("fp8 quantisation is not supported")
     if q.dtype != torch.bfloat16:
@@ -51,6 +54,9 @@ def _fwd(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, scaling_seqlen
                             num_contexts=num_contexts, num_targets=num_targets)
     if output_dtype not in (0, None):
         raise NotImplementedError("output_dtype must be 0 (bf16)")
+    if rab is not None:
+        return hstu_varlen_fwd_rab(q, k, v, cu_q, int(max_k), scaling_seqlen, num_contexts, num_targets, int(target_group_size),
+                                   max(int(wl), -1), max(int(wr), -1), float(alpha), rab), rab
     if window is not None:
         return hstu_varlen_fwd_window(q, k, v, cu_q, int(max_k), scaling_seqlen, window[0], window[1], float(alpha)), None
     out = hstu_varlen_fwd(q, k, v, cu_q, int(max_k), scaling_seqlen, num_contexts, num_targets, int(target_group_size), causal,
@@ -62,9 +68,14 @@ def _bwd(dout, q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, scaling_
          target_group_size, wl, wr, alpha, rab, has_drab, func, deterministic, quant_mode=-1, extra=()):
     causal, window = _check(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, wl, wr, rab, func, quant_mode, extra,
                             num_contexts=num_contexts, num_targets=num_targets)
-    if has_drab:
-        raise NotImplementedError("drab is not supported")
-    if window is not None:
+    if has_drab and rab is None:
+        raise RuntimeError("rab must exist when using has_drab")   # hstu_api.cpp:660
+    drab = None
+    if rab is not None:
+        *g, drab = hstu_varlen_bwd_rab(dout, q, k, v, cu_q, int(max_k), scaling_seqlen, num_contexts, num_targets,
+                                       int(target_group_size), max(int(wl), -1), max(int(wr), -1), float(alpha), rab,
+                                       bool(has_drab))
+    elif window is not None:
         g = hstu_varlen_bwd_window(dout, q, k, v, cu_q, int(max_k), scaling_seqlen, window[0], window[1], float(alpha))
     else:
         g = hstu_varlen_bwd(dout, q, k, v, cu_q, int(max_k), scaling_seqlen, num_contexts, num_targets,
@@ -75,7 +86,7 @@ def _bwd(dout, q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, scaling_
             given.copy_(new)
             new = given
         res.append(new)
-    return res[0], res[1], res[2], None
+    return res[0], res[1], res[2], drab
 
 
 def _fwd_90(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, scaling_seqlen, num_contexts, num_targets,

@@ -232,6 +232,92 @@ def test_local_window_rejects_contexts_and_targets():
         hstu_attn_varlen_func(q, q, q, cu, cu, None, None, 8, 8, 8, None, one, window_size=(3, 2))
 
 
+# ------------------------------------------------------------------------------------- relative attention bias (rab)
+R = np.load(os.path.join(os.path.dirname(__file__), "golden", "hstu_rab_golden.npz"))
+
+
+def _run_rab(q, k, v, rab, off, N, targets, ctx, grp, window, alpha, dout, has_drab=True):
+    from hstu import hstu_attn_varlen_func
+
+    qq, kk, vv, rr = (t.clone().requires_grad_(True) for t in (q, k, v, rab))
+    cu = torch.from_numpy(np.asarray(off, np.int32)).to(DEV)
+    nt = None if targets is None else torch.from_numpy(np.asarray(targets, np.int32)).to(DEV)
+    nc = None if ctx is None else torch.from_numpy(np.asarray(ctx, np.int32)).to(DEV)
+    out = hstu_attn_varlen_func(qq, kk, vv, cu, cu, None, None, N, N, N, nc, nt, target_group_size=grp, window_size=window,
+                                alpha=alpha, rab=rr, has_drab=has_drab)
+    out.backward(dout)
+    return out, (qq.grad, kk.grad, vv.grad), rr.grad
+
+
+def _assert_drab(got, want):
+    gn = got.detach().float().cpu().numpy()
+    assert gn.shape == want.shape
+    err = np.abs(gn - want).max()
+    assert err <= 1.2e-2 * np.abs(want).max() + 1e-6, f"drab: {err} vs scale {np.abs(want).max()}"
+
+
+@pytest.mark.parametrize("name", [str(c) for c in R["cases"]])
+def test_rab_golden(name):
+    """rab forward + backward + drab against the reference test's dense statement (tests/golden/gen_hstu_rab_golden.py)"""
+    H, HR, d, wl, wr, N = (int(x) for x in R[f"{name}/meta"])
+    g = lambda k: R[f"{name}/{k}"]
+    out, grads, drab = _run_rab(_bf(g("q")), _bf(g("k")), _bf(g("v")), _bf(g("rab")), g("off"), N, None, None, 1, (wl, wr),
+                                1.0 / d ** 0.5, _bf(g("dout")))
+    _assert_vs_oracle(out, grads, g("out"), g("dq"), g("dk"), g("dv"))
+    _assert_drab(drab, g("drab"))
+
+
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+@pytest.mark.parametrize("mode", ["causal", "ctx_targets", "noncausal", "window", "one_head"])
+def test_rab_random_jagged_vs_oracle(d, mode):
+    """bias with every mask family (contextual / target rows included: the op allows them with the causal mask), per-head
+    and one shared head, over several key / query tiles, ragged ends, an empty and a 1-token sequence"""
+    rng = np.random.default_rng(d + len(mode))
+    lengths = np.array([300, 1, 0, 129, 64, 77])
+    B, H, N = lengths.size, 2, int(lengths.max())
+    off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    T = int(off[-1])
+    mk = lambda lo, hi, *shape: torch.from_numpy(rng.uniform(lo, hi, shape).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    q, k, v, dout = mk(-1, 1, T, H, d), mk(-1, 1, T, H, d), mk(-1, 1, T, H, d), mk(0, 1, T, H, d)
+    rab = mk(-2, 2, B, 1 if mode == "one_head" else H, N, N)
+    targets = ctx = None
+    grp, window = 1, (-1, 0)
+    if mode == "ctx_targets":
+        targets = np.minimum(rng.integers(0, 11, size=B), np.maximum(lengths - 1, 0))
+        ctx = np.minimum(rng.integers(0, 5, size=B), np.maximum(lengths - 1 - targets, 0))
+        grp = 2
+    elif mode == "noncausal":
+        window = (-1, -1)
+    elif mode == "window":
+        window = (40, 9)
+    alpha = 1.0 / d ** 0.5
+    out, grads, drab = _run_rab(q, k, v, rab, off, N, targets, ctx, grp, window, alpha, dout)
+    qn, kn, vn, dn, rn = (t.float().cpu().numpy() for t in (q, k, v, dout, rab))
+    kw = dict(causal=window == (-1, 0), num_targets=targets, num_contextuals=ctx, target_group_size=grp,
+              local_window=window if mode == "window" else None, rab=rn)
+    ref = ho.hstu_attn_fwd(qn, kn, vn, off, alpha, N, **kw)
+    dq, dk, dv, dr = ho.hstu_attn_bwd(dn, qn, kn, vn, off, alpha, N, **kw)
+    _assert_vs_oracle(out, grads, ref, dq, dk, dv)
+    _assert_drab(drab, dr)
+
+
+def test_rab_without_drab_and_zero_bias():
+    """has_drab=False: no gradient for rab; an all-zero bias reproduces the plain kernels bit for bit"""
+    rng = np.random.default_rng(5)
+    lengths = np.array([200, 64, 31])
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    T, H, d, N = int(off[-1]), 2, 64, 200
+    mk = lambda: torch.from_numpy(rng.uniform(-1, 1, (T, H, d)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    q, k, v, dout = mk(), mk(), mk(), mk()
+    rab = torch.zeros(3, H, N, N, device=DEV, dtype=torch.bfloat16)
+    out, grads, drab = _run_rab(q, k, v, rab, off, N, None, None, 1, (-1, 0), 0.125, dout, has_drab=False)
+    assert drab is None
+    o_p, g_p = _run(q, k, v, off, N, None, None, 1, True, 0.125, dout=dout)
+    assert torch.equal(out, o_p)
+    for a, b in zip(grads, g_p):
+        assert torch.equal(a, b)
+
+
 def test_strided_inputs_and_scaling_seqlen():
     """q/k/v as slices of one fused [T, 3, H, d] tensor (what the fused HSTU layer hands over) and
     scaling_seqlen decoupled from max_seqlen."""
@@ -574,6 +660,16 @@ def test_raw_fbgemm_ops_of_the_fused_layer_match_the_wrapper():
         assert torch.equal(r[0], gq) and r[0].data_ptr() == bq.data_ptr() and torch.equal(r[1], gk) and torch.equal(r[2], gv)
         with pytest.raises(ValueError):   # contexts / targets with a window: undefined (hstu_api.cpp:163-164)
             torch.ops.fbgemm.hstu_varlen_fwd_80(q, k, v, cu, cu, None, None, L, L, L, nc, nt, 1, 16, 0, alpha, None, None)
+    # bias through the raw ops == through the wrapper (the forward hands the bias back, the backward returns drab)
+    rab = torch.randn(4, 1, L, L, device="cuda", dtype=torch.bfloat16).requires_grad_()
+    ref = hstu_attn_varlen_func(q, k, v, cu, cu.clone(), None, None, L, L, L, nc, nt, 1, (-1, 0), alpha, rab=rab, has_drab=True)
+    gq, gk, gv, gr = torch.autograd.grad(ref, (q, k, v, rab), dout)
+    with torch.no_grad():
+        o80, rab_back = torch.ops.fbgemm.hstu_varlen_fwd_80(q, k, v, cu, cu, None, None, L, L, L, nc, nt, 1, -1, 0, alpha, rab, None)
+        assert torch.equal(o80, ref) and rab_back.data_ptr() == rab.data_ptr()
+        dq, dk, dv, drab = torch.ops.fbgemm.hstu_varlen_bwd_80(dout, q, k, v, cu, cu, None, None, L, L, L, None, None, None, nc, nt,
+                                                               1, -1, 0, alpha, rab, True, None, False)
+        assert torch.equal(dq, gq) and torch.equal(dk, gk) and torch.equal(dv, gv) and torch.equal(drab, gr)
     # local window through the raw ops == through the wrapper
     ref = hstu_attn_varlen_func(q, k, v, cu, cu.clone(), None, None, L, L, L, None, None, 1, (16, 5), alpha)
     gq, gk, gv = torch.autograd.grad(ref, (q, k, v), dout)
