@@ -189,6 +189,15 @@ __device__ __forceinline__ void add_rab_row(f32x16_t (&acc)[NT], const uint16_t*
       if (key < L) acc[t][rr] += bf16_bits_to_f32(row[key]);
     }
 }
+// dS = dP * (alpha / N) * SiLU'(x), x = alpha * acc, sg = sigmoid(x).  One statement of the roundings for every kernel that
+// forms dS (the dK pass and the recomputing dQ pass must agree bit for bit with each other and with the exchanged dS):
+// contraction is switched off and the one fused step is spelled out, so that the code around a call site cannot change it.
+__device__ __forceinline__ float ds_value(float acc, float dp, float sg, float alpha, float c_ds) {
+#pragma clang fp contract(off)
+  const float x = acc * alpha;
+  const float inner = __builtin_fmaf(x, 1.0f - sg, 1.0f);
+  return dp * c_ds * sg * inner;
+}
 // SiLU(alpha * acc) * inv_scale from the raw accumulator: 4 plain VALU + 2 transcendental ops
 __device__ __forceinline__ float silu_scaled(float acc, float neg_alpha_log2e, float alpha_inv_scale) {
   const float t = __builtin_amdgcn_exp2f(acc * neg_alpha_log2e);
@@ -978,11 +987,18 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
   // kPre: small head dims run several waves per SIMD, which hides the staging latency better than holding a tile in
   // registers does (the prefetch registers would halve the occupancy); d = 256 runs one wave per SIMD and prefetches
   if (kPre && i0 < i_lim) fetch_all(i0);
+#if HSTU_TIMING
+  unsigned tsum[7] = {0, 0, 0, 0, 0, 0, 0};
+  const unsigned t_start = tick();
+#endif
   for (; i0 < i_lim; i0 = advance(i0)) {
     if (kDV) pin_agpr(acc_dv);
     if (kDK) pin_agpr(acc_dk);
+    TICK(t0);
     __syncthreads();
+    TICK(t1);
     if (!kPre) fetch_all(i0);
+    TICK(t1b);
     q_rows.commit(Qs, i0, s.L);
     if (kDK) do_rows.commit(dOs, i0, s.L);
     if constexpr (kTR) {
@@ -994,14 +1010,18 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
     }
     if (kDV) pin_agpr(acc_dv);
     if (kDK) pin_agpr(acc_dk);
+    TICK(t2);
     __syncthreads();
+    TICK(t3);
     if (kPre) {
       const int nx = advance(i0);
       if (nx < i_lim) fetch_all(nx);
     }
     if (kDV) pin_agpr(acc_dv);
     if (kDK) pin_agpr(acc_dk);
+    TACC(0, t0, t1); TACC(1, t1, t1b); TACC(2, t1b, t2); TACC(3, t2, t3);
     if (!wave_live) continue;
+    TICK(t4);
     // GEMM 1 / 2: S[q x keys] = Q K^T, dP[q x keys] = dO V^T (A from LDS rows, B = register fragments)
     f32x16_t acc_s[NT], acc_p[kDK ? NT : 1];
     {
@@ -1040,6 +1060,8 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
     }
     fence_v(acc_s);
     if (kDK) fence_v(acc_p);
+    TICK(t5);
+    TACC(4, t4, t5);
     if constexpr (kRab) {   // lane = key kj, registers = query rows: rab[qi][kj]
       if (kj < s.L) {
         const uint16_t* col = a.rab + (int64_t)b * a.rab_b + (int64_t)h * a.rab_h + kj;
@@ -1054,67 +1076,82 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
     }
     if (kDV) pin_agpr(acc_dv);
     if (kDK) pin_agpr(acc_dk);
-    // P and dS packed as B operands (k = query rows held in the registers, lane = key)
+    // P and dS packed as B operands (k = query rows held in the registers, lane = key).  The mask variant is chosen once
+    // per step and wave and the 32 elements of a lane are then ONE basic block: with the (block-uniform) choice inside the
+    // element loop hipcc emitted a branch per element, every SiLU' chain (exp -> add -> rcp -> mul ...) ran alone with its
+    // full latency exposed, and this phase took 7.0 K of the 15.6 K cycles of a step at d = 256 (HSTU_TIMING stamps).
     bf16x8_t pf[kDV ? BQ / 16 : 1], sf[kDK ? BQ / 16 : 1];
+    auto elementwise = [&](auto modec) {
+      // 0: every (query, key) pair of the wave's step is visible; 1: key <= query (plain causal); 2: key < L; 3: row mask
+      constexpr int kMask = decltype(modec)::value;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      uint32_t pk[8], sk[8];
+      for (int t = 0; t < NT; ++t) {
+        uint32_t pk[8], sk[8];
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        float p2[2], s2[2];
+        for (int r = 0; r < 16; r += 2) {
+          float p2[2], s2[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int rr = r + u;
-          const int qi = i0 + 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
-          bool ok;
-          if (plain) {
-            ok = a.causal ? (kj <= qi) : (kj < s.L);
-          } else {
-            const RowMask m = row_mask(qi, s, a.causal, a.group);
-            ok = key_ok(kj, m);
+          for (int u = 0; u < 2; ++u) {
+            const int rr = r + u;
+            const int qi = i0 + 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+            bool ok = true;
+            if constexpr (kMask == 1) ok = kj <= qi;
+            else if constexpr (kMask == 2) ok = kj < s.L;
+            else if constexpr (kMask == 3) ok = key_ok(kj, row_mask(qi, s, a.causal, a.group));
+            const float acc = acc_s[t][rr];
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc * neg_alpha_log2e));
+            if (kDV || kXP) p2[u] = ok ? acc * c_p * sg : 0.f;
+            if (kDK) {
+              const float dsv = ds_value(acc, acc_p[t][rr], sg, a.alpha, c_ds);
+              s2[u] = ok ? dsv : 0.f;
+            }
           }
-          const float acc = acc_s[t][rr];
-          const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc * neg_alpha_log2e));
-          if (kDV || kXP) p2[u] = ok ? acc * c_p * sg : 0.f;
-          if (kDK) {
-            const float x = acc * a.alpha;
-            s2[u] = ok ? acc_p[t][rr] * c_ds * sg * (1.0f + x * (1.0f - sg)) : 0.f;
-          }
-        }
-        if (kDV || kXP) pk[r >> 1] = pack_bf16(p2[0], p2[1]);
-        if (kDK) sk[r >> 1] = pack_bf16(s2[0], s2[1]);
-        if constexpr (kRab && kDK) {   // d rab = dS (x = alpha (q.k + rab): the same factor alpha as d (q.k))
-          if (g.drab && kj < s.L) {
+          if (kDV || kXP) pk[r >> 1] = pack_bf16(p2[0], p2[1]);
+          if (kDK) sk[r >> 1] = pack_bf16(s2[0], s2[1]);
+          if constexpr (kRab && kDK) {   // d rab = dS (x = alpha (q.k + rab): the same factor alpha as d (q.k))
+            if (g.drab && kj < s.L) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const int qi = i0 + 32 * t + ((r + u) & 3) + 8 * ((r + u) >> 2) + 4 * hi;
-              if (qi < s.L)
-                g.drab[(int64_t)b * g.drab_b + (int64_t)h * g.drab_h + (int64_t)qi * g.drab_r + kj] = (uint16_t)(sk[r >> 1] >> (16 * u));
+              for (int u = 0; u < 2; ++u) {
+                const int qi = i0 + 32 * t + ((r + u) & 3) + 8 * ((r + u) >> 2) + 4 * hi;
+                if (qi < s.L)
+                  g.drab[(int64_t)b * g.drab_b + (int64_t)h * g.drab_h + (int64_t)qi * g.drab_r + kj] = (uint16_t)(sk[r >> 1] >> (16 * u));
+              }
             }
           }
         }
-      }
-      if constexpr (kXP) {
-        if (i0 + 32 * t < s.L) {   // P for the dV pass, same layout as dS below
-          u32x4_t* tp = reinterpret_cast<u32x4_t*>(g.p_ws + xch_tile(g, b, h, key0 >> 5, (i0 >> 5) + t)) + 2 * lane;
-          tp[0] = u32x4_t{pk[0], pk[1], pk[2], pk[3]}; tp[1] = u32x4_t{pk[4], pk[5], pk[6], pk[7]};
+        if constexpr (kXP) {
+          if (i0 + 32 * t < s.L) {   // P for the dV pass, same layout as dS below
+            u32x4_t* tp = reinterpret_cast<u32x4_t*>(g.p_ws + xch_tile(g, b, h, key0 >> 5, (i0 >> 5) + t)) + 2 * lane;
+            tp[0] = u32x4_t{pk[0], pk[1], pk[2], pk[3]}; tp[1] = u32x4_t{pk[4], pk[5], pk[6], pk[7]};
+          }
+        }
+        if (kDV) {
+          const u32x4_t x0 = {pk[0], pk[1], pk[2], pk[3]}, x1 = {pk[4], pk[5], pk[6], pk[7]};
+          pf[2 * t] = __builtin_bit_cast(bf16x8_t, x0); pf[2 * t + 1] = __builtin_bit_cast(bf16x8_t, x1);
+        }
+        if (kDK) {
+          const u32x4_t y0 = {sk[0], sk[1], sk[2], sk[3]}, y1 = {sk[4], sk[5], sk[6], sk[7]};
+          sf[2 * t] = __builtin_bit_cast(bf16x8_t, y0); sf[2 * t + 1] = __builtin_bit_cast(bf16x8_t, y1);
+          if (g.ds_ws && i0 + 32 * t < s.L) {   // hand dS to the dQ pass: the B-operand registers as they are, 32 bytes per lane
+            u32x4_t* tp = reinterpret_cast<u32x4_t*>(ds_tile(g, b, h, key0 >> 5, (i0 >> 5) + t)) + 2 * lane;
+            tp[0] = y0; tp[1] = y1;
+          }
         }
       }
-      if (kDV) {
-        const u32x4_t x0 = {pk[0], pk[1], pk[2], pk[3]}, x1 = {pk[4], pk[5], pk[6], pk[7]};
-        pf[2 * t] = __builtin_bit_cast(bf16x8_t, x0); pf[2 * t + 1] = __builtin_bit_cast(bf16x8_t, x1);
-      }
-      if (kDK) {
-        const u32x4_t y0 = {sk[0], sk[1], sk[2], sk[3]}, y1 = {sk[4], sk[5], sk[6], sk[7]};
-        sf[2 * t] = __builtin_bit_cast(bf16x8_t, y0); sf[2 * t + 1] = __builtin_bit_cast(bf16x8_t, y1);
-        if (g.ds_ws && i0 + 32 * t < s.L) {   // hand dS to the dQ pass: the B-operand registers as they are, 32 bytes per lane
-          u32x4_t* tp = reinterpret_cast<u32x4_t*>(ds_tile(g, b, h, key0 >> 5, (i0 >> 5) + t)) + 2 * lane;
-          tp[0] = y0; tp[1] = y1;
-        }
-      }
+    };
+    if (!plain) elementwise(std::integral_constant<int, 3>{});
+    else if (a.causal) {
+      if (key0 + 31 <= i0) elementwise(std::integral_constant<int, 0>{}); else elementwise(std::integral_constant<int, 1>{});
+    } else {
+      if (key0 + 31 < s.L) elementwise(std::integral_constant<int, 0>{}); else elementwise(std::integral_constant<int, 2>{});
     }
     if (kDV) pin_agpr(acc_dv);
     if (kDK) pin_agpr(acc_dk);
+    TICK(t6);
+    TACC(5, t5, t6);
+#if HSTU_TIMING
+    tsum[6] += 1;
+#endif
     // GEMM 3 / 4: dV^T[D x keys] += dO^T P, dK^T[D x keys] += Q^T dS
     {
       constexpr int NDT = D / 32;
@@ -1152,6 +1189,17 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
   }
   if (kDV) fence_a(acc_dv);
   if (kDK) fence_a(acc_dk);
+#if HSTU_TIMING
+  if (kXP) {
+    const unsigned t_end = tick();
+    if (lane == 0) {
+      const int blk = ((int)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      unsigned long long* d = g_hstu_dbg + ((size_t)(blk * 4 + wv) % 65536) * 8;
+      for (int i = 0; i < 6; ++i) d[i] = tsum[i];
+      d[6] = tsum[6]; d[7] = t_end - t_start;
+    }
+  }
+#endif
   if (kj < s.L) {
     uint16_t* dvp = g.dv + ((int64_t)(s.start + kj) * a.H + h) * D;
     uint16_t* dkp = g.dk + ((int64_t)(s.start + kj) * a.H + h) * D;
@@ -1297,9 +1345,8 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
           const int rr = r + u;
           const int key = n0 + 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
           const float acc = acc_s[t][rr];
-          const float x = acc * a.alpha;
           const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc * neg_alpha_log2e));
-          s2[u] = key_ok(key, rm) ? acc_p[t][rr] * c_ds * sg * (1.0f + x * (1.0f - sg)) : 0.f;
+          s2[u] = key_ok(key, rm) ? ds_value(acc, acc_p[t][rr], sg, a.alpha, c_ds) : 0.f;
         }
         sk[r >> 1] = pack_bf16(s2[0], s2[1]);
       }

@@ -4,19 +4,23 @@ import argparse, ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "recsys-examples_amd")); sys.path.insert(0, ROOT)
 import numpy as np, torch
-from hstu import hstu_varlen_fwd
+from hstu import hstu_varlen_bwd, hstu_varlen_fwd
 import mi355_native
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32); ap.add_argument("--seqlen", type=int, default=512)
 ap.add_argument("--heads", type=int, default=4); ap.add_argument("--dim", type=int, default=256)
+ap.add_argument("--bwd", action="store_true", help="the dK pass of the backward (hstu_bwd_kv_kernel, exchange mode) instead of the forward")
 a = ap.parse_args()
 dev = torch.device("cuda")
 T = a.batch * a.seqlen
 cu = torch.arange(0, T + 1, a.seqlen, dtype=torch.int32, device=dev)
 q, k, v = (torch.empty(T, a.heads, a.dim, device=dev).uniform_(-1, 1).bfloat16() for _ in range(3))
 for _ in range(3):
-    hstu_varlen_fwd(q, k, v, cu, a.seqlen, a.seqlen, None, None, 1, True, 1.0 / a.dim ** 0.5)
+    if a.bwd:
+        hstu_varlen_bwd(q, q, k, v, cu, a.seqlen, a.seqlen, None, None, 1, True, 1.0 / a.dim ** 0.5)
+    else:
+        hstu_varlen_fwd(q, k, v, cu, a.seqlen, a.seqlen, None, None, 1, True, 1.0 / a.dim ** 0.5)
 torch.cuda.synchronize()
 nblk = a.heads * a.batch * ((a.seqlen + 127) // 128)
 n = min(nblk * 4, 65536)
@@ -26,10 +30,11 @@ lib.mi355_hstu_dbg_dump.argtypes = [ctypes.c_void_p, ctypes.c_int64]
 assert lib.mi355_hstu_dbg_dump(buf.ctypes.data, buf.nbytes) == 0
 d = buf[:n].astype(np.float64)
 tiles = d[:, 6]
-names = ["barrier1", "commit", "barrier2", "fetch-issue", "gemm1", "silu+gemm2"]
+names = (["barrier1", "fetch (load + wait)", "commit x2 images", "barrier2", "gemm S + dP", "silu' + P/dS stores"] if a.bwd
+         else ["barrier1", "commit", "barrier2", "fetch-issue", "gemm1", "silu+gemm2"])
 tot = d[:, 7]
 print(f"waves {n}  tiles/wave avg {tiles.mean():.2f}  wave lifetime avg {tot.mean():.0f} cyc  max {tot.max():.0f}")
 loop_iters = np.maximum(tiles, 1)
 for i, nm in enumerate(names):
-    print(f"  {nm:12s} {d[:, i].sum() / tiles.sum():8.0f} cyc per computed tile   ({100 * d[:, i].sum() / tot.sum():5.1f} % of wave lifetime)")
-print(f"  other        {(tot.sum() - d[:, :6].sum()) / tiles.sum():8.0f} cyc per computed tile   ({100 * (tot.sum() - d[:, :6].sum()) / tot.sum():5.1f} %)")
+    print(f"  {nm:22s} {d[:, i].sum() / tiles.sum():8.0f} cyc per computed tile   ({100 * d[:, i].sum() / tot.sum():5.1f} % of wave lifetime)")
+print(f"  {'gemm dK + rest' if a.bwd else 'other':12s} {(tot.sum() - d[:, :6].sum()) / tiles.sum():8.0f} cyc per computed tile   ({100 * (tot.sum() - d[:, :6].sum()) / tot.sum():5.1f} %)")
