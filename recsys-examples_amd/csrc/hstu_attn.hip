@@ -175,6 +175,14 @@ __device__ __forceinline__ int band_key_end(const AttnArgs& a, int last_row, int
   return (a.wskip && a.wr >= 0 && hi < end) ? hi : end;
 }
 
+// Row block a query-block owner of dispatch rank `rank` takes: heaviest first = the latest rows first (causal).  With contextual
+// rows the FIRST block is the heaviest of all -- its contextual rows reach every history key -- and goes first: left at the
+// end of the order it was a 8-tile tail behind a CU's other blocks (C3 shape with 4 contextual rows: forward 66 -> 5x us).
+__device__ __forceinline__ int row_block_of_rank(int rank, int nblk, const AttnArgs& a, int b) {
+  const bool ctx_first = a.causal && a.num_contexts != nullptr && a.num_contexts[b] > 0;
+  if (!ctx_first) return nblk - 1 - rank;
+  return rank == 0 ? 0 : nblk - rank;
+}
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
 // S^T accumulators (lane = query row, registers = keys (rr & 3) + 8 (rr >> 2) + 4 hi of each 32-key sub-tile) += rab[i][.]
 // `row` points at rab[b][h][i][0] (NULL for a row past the sequence); 2-byte loads: the bias path is not a tuned one.
@@ -264,7 +272,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
   const int dq = s.L - Lq;   // absolute position of query row r is dq + r
   const int nblk = (Lq + kBM - 1) / kBM;
   if ((int)blockIdx.z >= nblk || dq < 0) return;
-  const int m0 = (nblk - 1 - (int)blockIdx.z) * kBM;  // heaviest (latest) row blocks first
+  const int m0 = row_block_of_rank((int)blockIdx.z, nblk, a, b) * kBM;  // heaviest row blocks first
   s.has_ctx = a.num_contexts != nullptr;
   s.has_tgt = a.num_targets != nullptr;
   s.c = s.has_ctx ? a.num_contexts[b] : 0;
@@ -945,6 +953,13 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
   const int kj = key0 + l31;
   const bool wave_live = key0 < s.L;
   const bool plain = !s.has_ctx && !s.has_tgt && s.wl < 0 && s.wr < 0;   // block-uniform: mask is kj <= qi (causal) or kj < L
+  // The general masks from the KEY's side (the lane owns key kj, the query rows run over its registers): per-lane constants
+  // once, a few compares per element -- row_mask() per element would cost a division by the group size each.
+  //   contextual row i < c: sees the history keys;  other rows: kj <= i;  a target key is seen only up to the end of its
+  //   own group (row_mask / key_ok: jlo(i) <= kj  <=>  i < hlen + (floor((kj - hlen) / g) + 1) g for kj <= i)
+  const bool key_in = kj < s.L, key_hist = kj < s.hlen;
+  const int key_iend = (s.has_tgt && kj >= s.hlen) ? s.hlen + ((kj - s.hlen) / a.group + 1) * a.group : 0x7fffffff;
+  const int ctx_end = s.has_ctx ? s.c : 0;
 
   const uint16_t* qbase = a.q + (int64_t)s.start * a.q_row + (int64_t)h * a.q_head;
   const uint16_t* dobase = g.dout + (int64_t)s.start * g.do_row + (int64_t)h * g.do_head;
@@ -1082,7 +1097,8 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
     // full latency exposed, and this phase took 7.0 K of the 15.6 K cycles of a step at d = 256 (HSTU_TIMING stamps).
     bf16x8_t pf[kDV ? BQ / 16 : 1], sf[kDK ? BQ / 16 : 1];
     auto elementwise = [&](auto modec) {
-      // 0: every (query, key) pair of the wave's step is visible; 1: key <= query (plain causal); 2: key < L; 3: row mask
+      // 0: every (query, key) pair of the wave's step is visible; 1: key <= query (plain causal); 2: key < L;
+      // 3: contextual / target rows (causal); 4: local window
       constexpr int kMask = decltype(modec)::value;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -1097,7 +1113,9 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
             bool ok = true;
             if constexpr (kMask == 1) ok = kj <= qi;
             else if constexpr (kMask == 2) ok = kj < s.L;
-            else if constexpr (kMask == 3) ok = key_ok(kj, row_mask(qi, s, a.causal, a.group));
+            else if constexpr (kMask == 3) ok = (qi < ctx_end ? key_hist : ((kj <= qi) & key_in)) & (key_hist | (qi < key_iend));
+            else if constexpr (kMask == 4)
+              ok = key_in & ((s.wl < 0) | (kj >= qi - s.wl)) & (a.causal ? (kj <= qi) : ((s.wr < 0) | (kj <= qi + s.wr)));
             const float acc = acc_s[t][rr];
             const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc * neg_alpha_log2e));
             if (kDV || kXP) p2[u] = ok ? acc * c_p * sg : 0.f;
@@ -1139,8 +1157,9 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
         }
       }
     };
-    if (!plain) elementwise(std::integral_constant<int, 3>{});
-    else if (a.causal) {
+    if (!plain) {
+      if (s.wl >= 0 || s.wr >= 0) elementwise(std::integral_constant<int, 4>{}); else elementwise(std::integral_constant<int, 3>{});
+    } else if (a.causal) {
       if (key0 + 31 <= i0) elementwise(std::integral_constant<int, 0>{}); else elementwise(std::integral_constant<int, 1>{});
     } else {
       if (key0 + 31 < s.L) elementwise(std::integral_constant<int, 0>{}); else elementwise(std::integral_constant<int, 2>{});
@@ -1240,7 +1259,7 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
   s.L = a.cu_seqlens[b + 1] - s.start;
   const int nblk = (s.L + kBM - 1) / kBM;
   if ((int)blockIdx.z >= nblk) return;
-  const int m0 = (nblk - 1 - (int)blockIdx.z) * kBM;
+  const int m0 = row_block_of_rank((int)blockIdx.z, nblk, a, b) * kBM;
   s.has_ctx = a.num_contexts != nullptr;
   s.has_tgt = a.num_targets != nullptr;
   s.c = s.has_ctx ? a.num_contexts[b] : 0;
@@ -1412,7 +1431,7 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_q_ds_kernel(BwdAttnAr
   s.L = a.cu_seqlens[b + 1] - s.start;
   const int nblk = (s.L + kBM - 1) / kBM;
   if ((int)blockIdx.z >= nblk) return;
-  const int m0 = (nblk - 1 - (int)blockIdx.z) * kBM;
+  const int m0 = row_block_of_rank((int)blockIdx.z, nblk, a, b) * kBM;
   s.has_ctx = a.num_contexts != nullptr;
   s.has_tgt = a.num_targets != nullptr;
   s.c = s.has_ctx ? a.num_contexts[b] : 0;

@@ -10,6 +10,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32); ap.add_argument("--seqlen", type=int, default=512)
 ap.add_argument("--heads", type=int, default=4); ap.add_argument("--dim", type=int, default=256)
 ap.add_argument("--jagged", action="store_true"); ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--ctx-targets", type=int, nargs=3, default=None, metavar=("CTX", "TGT", "GROUP"),
+                help="contextual rows / target rows per sequence and the target group size (the ranking model's mask)")
 ap.add_argument("--window", type=int, nargs=2, default=None, help="local window (left right): times the windowed kernels too")
 a = ap.parse_args()
 dev = torch.device("cuda")
@@ -29,9 +31,15 @@ def timeit(fn):
     for _ in range(a.reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / a.reps
-tf = timeit(lambda: hstu_varlen_fwd(q, k, v, cu, a.seqlen, a.seqlen, None, None, 1, True, alpha))
-tb = timeit(lambda: hstu_varlen_bwd(do, q, k, v, cu, a.seqlen, a.seqlen, None, None, 1, True, alpha))
-print(f"T={T} H={a.heads} d={a.dim} causal  fwd {tf*1e3:.1f} us  {fl/tf/1e9:.1f} TFLOP/s  {T/tf/1e3:.3e} tok/s | "
+nc = nt = None
+grp = 1
+if a.ctx_targets is not None:
+    nc = torch.full((a.batch,), a.ctx_targets[0], dtype=torch.int32, device=dev)
+    nt = torch.full((a.batch,), a.ctx_targets[1], dtype=torch.int32, device=dev)
+    grp = a.ctx_targets[2]
+tf = timeit(lambda: hstu_varlen_fwd(q, k, v, cu, a.seqlen, a.seqlen, nc, nt, grp, True, alpha))
+tb = timeit(lambda: hstu_varlen_bwd(do, q, k, v, cu, a.seqlen, a.seqlen, nc, nt, grp, True, alpha))
+print(f"T={T} H={a.heads} d={a.dim} causal{' ctx/targets ' + str(a.ctx_targets) if a.ctx_targets else ''}  fwd {tf*1e3:.1f} us  {fl/tf/1e9:.1f} TFLOP/s  {T/tf/1e3:.3e} tok/s | "
       f"bwd {tb*1e3:.1f} us  {2.5*fl/tb/1e9:.1f} TFLOP/s | fwd+bwd {T/(tf+tb)/1e3:.3e} tok/s")
 if a.window is not None:
     from hstu.hstu_attn_interface import HstuAttnWindowFunc
