@@ -724,6 +724,240 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Forward with LDS-DMA staging (opt-in: MI355_HSTU_DMA=1; head dim 256, contiguous keys).  Same GEMMs, masks and register
+// layouts as hstu_fwd_kernel; what differs is how a (K, V) tile reaches LDS.  The stamps of the register-staged kernel
+//  put 1.2 K cycles per tile into issuing 16 global loads per wave and 0.9 K into writing the
+// prefetched registers to LDS (K rows + the transposing V commit), against 2 K cycles of MFMA; `global_load_lds_dwordx4`
+// moves 1 KB per wave-instruction from global memory straight into LDS: no staging VGPRs, no commit, and with the tile
+// pair double-buffered one barrier per tile.  A DMA instruction writes 64 x 16 B contiguously (two 512-B rows), so rows
+// cannot be padded against bank conflicts; instead each lane FETCHES the 16-byte chunk that belongs at its LDS slot under
+// an XOR swizzle (free on the load side):
+//   K rows (read back with ds_read_b128, 16-lane groups over 16 different rows): chunk' = chunk ^ (row & 15)
+//   V rows (read back transposed with ds_read_b64_tr_b16, a half-wave covers 4 rows x 64 B): chunk' = chunk ^ ((row & 3) << 2)
+// -- the same bank sets per lane group as the padded layouts (strides of 4 resp. 16 dwords mod 64).
+// ---------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_void_t;
+typedef __attribute__((address_space(1))) const void* glb_void_t;
+
+template <int D, bool kWin>
+__global__ void __launch_bounds__(256) hstu_fwd_dma_kernel(AttnArgs a) {
+  static_assert(D == 256 || D == 128, "rows of 16 or 32 chunks");
+  constexpr int CPR = D / 8;            // 16-byte chunks per row
+  constexpr int RPI = 64 / CPR;         // rows per DMA wave-instruction (1 KB)
+  constexpr int ROWB = D;               // row stride in LDS (elements): unpadded
+  constexpr int TENS = kBN * ROWB;      // elements of one K (or V) tile
+  constexpr int IPW = (kBN / RPI) / 4;  // DMA instructions per wave and tensor
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [2 buffers][K tile | V tile]
+
+  const int b = blockIdx.y, h = blockIdx.x;
+  SeqInfo s;
+  s.start = a.cu_seqlens[b];
+  const int Lq = a.cu_seqlens[b + 1] - s.start;
+  const int kstart = a.cu_seqlens_k ? a.cu_seqlens_k[b] : s.start;
+  s.L = a.cu_seqlens_k ? a.cu_seqlens_k[b + 1] - kstart : Lq;
+  const int dq = s.L - Lq;
+  const int nblk = (Lq + kBM - 1) / kBM;
+  if ((int)blockIdx.z >= nblk || dq < 0) return;
+  const int m0 = row_block_of_rank((int)blockIdx.z, nblk, a, b) * kBM;
+  s.has_ctx = a.num_contexts != nullptr;
+  s.has_tgt = a.num_targets != nullptr;
+  s.c = s.has_ctx ? a.num_contexts[b] : 0;
+  s.hlen = s.L - (s.has_tgt ? a.num_targets[b] : 0);
+  s.wl = kWin ? a.wl : -1; s.wr = kWin ? a.wr : -1;
+
+  const int lane = lane_id(), wv = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int qrow0 = m0 + 32 * wv, qloc = qrow0 + l31, qi = dq + qloc;
+  const bool wave_live = qrow0 < Lq;
+  int last_row = dq + (m0 + kBM - 1 < Lq - 1 ? m0 + kBM - 1 : Lq - 1);
+  int n_end = s.L;
+  if (a.causal) {
+    n_end = last_row + 1;
+    if (s.has_ctx && dq + m0 < s.c && s.hlen > n_end) n_end = s.hlen;
+  }
+  if (kWin) n_end = band_key_end(a, last_row, n_end);
+  const int n_beg = kWin ? band_key_begin(a, dq + m0, kBN) : 0;
+  int w_last = dq + (qrow0 + 31 < Lq - 1 ? qrow0 + 31 : Lq - 1);
+  int w_end = s.L;
+  if (a.causal) {
+    w_end = w_last + 1;
+    if (s.has_ctx && dq + qrow0 < s.c && s.hlen > w_end) w_end = s.hlen;
+  }
+  if (kWin) w_end = band_key_end(a, w_last, w_end);
+  const int w_beg = kWin ? band_key_begin(a, dq + qrow0, kBN) : 0;
+
+  // ---- Q fragments in registers (as hstu_fwd_kernel)
+  bf16x8_t qf[D / 16];
+  {
+    const uint16_t* qp = a.q + (int64_t)(s.start + (qloc < Lq ? qloc : 0)) * a.q_row + (int64_t)h * a.q_head + 8 * hi;
+#pragma unroll
+    for (int sl = 0; sl < D / 16; ++sl) {
+      uint4 t = make_uint4(0, 0, 0, 0);
+      if (qloc < Lq) t = *reinterpret_cast<const uint4*>(qp + 16 * sl);
+      qf[sl] = *reinterpret_cast<bf16x8_t*>(&t);
+    }
+  }
+  f32x16_t acc_o[D / 32];
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_o[dt][r] = 0.f;
+  const float nal2e = -a.alpha * 1.44269504088896f, ais = a.alpha * a.inv_scale;
+  const RowMask rm = row_mask(qi < s.L ? qi : s.L - 1, s, a.causal, a.group);
+
+  // ---- the DMA of one tile: wave w moves rows [16 w, 16 w + 16) of K and of V, RPI rows per instruction.  Lane -> (row
+  // inside the instruction, LDS chunk slot p); the lane fetches global chunk p ^ swizzle(row).  Rows past the sequence end
+  // are read clamped to its last row (their P is masked to zero).
+  const uint16_t* kg = a.k + (int64_t)kstart * a.k_row + (int64_t)h * a.k_head;
+  const uint16_t* vg = a.v + (int64_t)kstart * a.v_row + (int64_t)h * a.v_head;
+  const int dma_r = lane / CPR, dma_p = lane % CPR;
+  auto issue_dma = [&](int n0, int buf) {
+    uint16_t* kd = smem + buf * 2 * TENS;
+    uint16_t* vd = kd + TENS;
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) {
+      const int r = (kBN / 4) * wv + RPI * j + dma_r;           // row of the tile
+      const int row = n0 + r < s.L ? n0 + r : s.L - 1;
+      const uint16_t* ksrc = kg + (int64_t)row * a.k_row + 8 * (dma_p ^ (r & 15));
+      const uint16_t* vsrc = vg + (int64_t)row * a.v_row + 8 * (dma_p ^ ((r & 3) << 2));
+      const int base = ((kBN / 4) * wv + RPI * j) * ROWB;       // wave-uniform LDS offset (elements) of the instruction's 1 KB
+      __builtin_amdgcn_global_load_lds((glb_void_t)ksrc, (lds_void_t)(kd + base), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t)vsrc, (lds_void_t)(vd + base), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment addresses under the swizzles
+  // K (B... A operand of GEMM 1): lane (row 32 t + l31, k half hi) reads chunk (2 sl + hi) ^ (l31 & 15) of its row
+  const int kx = l31 & 15;
+  // V^T (A operand of GEMM 2) through two transpose reads: within a 16-lane group lane i points at the 8-byte half
+  // (i & 1) of chunk 4 dt + 2 g1 + ((i & 3) >> 1) of row 16 ks + 4 hi + (i >> 2) (+ 8); chunk' = chunk ^ ((row & 3) << 2)
+  const int il = lane & 15, g1 = (lane >> 4) & 1, vq = il >> 2;
+  const int v_row_off = (4 * hi + vq) * ROWB + 4 * (il & 1);          // elements
+  const int v_chunk_lo = 2 * g1 + ((il & 3) >> 1);
+  auto v_frag = [&](const uint16_t* Vb, int dt, int ks) -> bf16x8_t {
+    typedef short v4s_t __attribute__((ext_vector_type(4)));
+    typedef short v8s_t __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) v4s_t* lds_v4s_t;
+    const uint16_t* p0 = Vb + (16 * ks) * ROWB + v_row_off + 8 * ((4 * (dt ^ vq)) + v_chunk_lo);
+    const v4s_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(p0));
+    const v4s_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(p0 + 8 * ROWB));
+    const v8s_t r = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    return __builtin_bit_cast(bf16x8_t, r);
+  };
+
+  if (n_end > n_beg) issue_dma(n_beg, 0);
+  int it = 0;
+  for (int n0 = n_beg; n0 < n_end; n0 += kBN, ++it) {
+    pin_agpr(acc_o);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile n0 have landed ...
+    __syncthreads();                                    // ... everyone's have, and everyone is done reading the other buffer
+    if (n0 + kBN < n_end) issue_dma(n0 + kBN, (it + 1) & 1);
+    const uint16_t* Ks = smem + (it & 1) * 2 * TENS;
+    const uint16_t* Vt = Ks + TENS;
+    pin_agpr(acc_o);
+    if (!wave_live || n0 >= w_end || n0 < w_beg) continue;
+
+    // ---- GEMM 1: S^T[64 keys x 32 q] = K Q^T (two 32-key tiles), fragment batches double-buffered
+    f32x16_t acc_s[2];
+    {
+      constexpr int SLB = 4, NBAT = (D / 16) / SLB;
+      bf16x8_t kfr[2][SLB][2];
+      auto load_b = [&](int bi, int buf) {
+#pragma unroll
+        for (int u = 0; u < SLB; ++u) {
+          const int sl = SLB * bi + u;
+          const int ch = ((2 * sl) ^ (kx & 14)) + (hi ^ (kx & 1));
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            kfr[buf][u][t] = *reinterpret_cast<const bf16x8_t*>(Ks + (32 * t + l31) * ROWB + 8 * ch);
+        }
+      };
+      load_b(0, 0);
+#pragma unroll
+      for (int bi = 0; bi < NBAT; ++bi) {
+        if (bi + 1 < NBAT) load_b(bi + 1, (bi + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < SLB; ++u)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            if (bi == 0 && u == 0) mfma_v0(acc_s[t], kfr[bi & 1][u][t], qf[SLB * bi + u]);
+            else mfma_v(acc_s[t], kfr[bi & 1][u][t], qf[SLB * bi + u]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    fence_v(acc_s);
+    pin_agpr(acc_o);
+    const bool full = a.causal && s.wl < 0 && (n0 + kBN - 1 <= dq + qrow0) && (!s.has_ctx || dq + qrow0 >= s.c) && (!s.has_tgt || n0 + kBN - 1 < s.hlen);
+    // ---- GEMM 2: O^T[D x 32 q] += V^T[D x 64 keys] P^T, pipelined with the SiLU of the next 16-key slice
+    constexpr int NDT = D / 32;
+    constexpr int DB = NDT < 8 ? NDT : 8;
+    auto gemm2 = [&](auto fullc) {
+      constexpr bool kFull = decltype(fullc)::value;
+      auto ew = [&](int ks) -> bf16x8_t {
+        const int t = ks >> 1, r0 = (ks & 1) * 8;
+        uint32_t pk[4];
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+          float p2[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int rr = r0 + r + u;
+            const float pv = silu_scaled(acc_s[t][rr], nal2e, ais);
+            if (kFull) p2[u] = pv;
+            else {
+              const int key = n0 + 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+              p2[u] = key_ok(key, rm) ? pv : 0.f;
+            }
+          }
+          pk[r >> 1] = pack_bf16(p2[0], p2[1]);
+        }
+        const u32x4_t x = {pk[0], pk[1], pk[2], pk[3]};
+        return __builtin_bit_cast(bf16x8_t, x);
+      };
+      constexpr int NBAT2 = 4 * (NDT / DB);
+      bf16x8_t vfr[2][DB];
+      auto load_v = [&](int bi, int buf) {
+        const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
+#pragma unroll
+        for (int u = 0; u < DB; ++u) vfr[buf][u] = v_frag(Vt, dt0 + u, ks);
+      };
+      load_v(0, 0);
+      bf16x8_t pf[4];
+      pf[0] = ew(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int bi = 0; bi < NBAT2; ++bi) {
+        const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
+        const bool last_of_ks = (bi % (NDT / DB)) == (NDT / DB) - 1;
+        if (bi + 1 < NBAT2) load_v(bi + 1, (bi + 1) & 1);
+        if (last_of_ks && ks + 1 < 4) pf[ks + 1] = ew(ks + 1);
+#pragma unroll
+        for (int u = 0; u < DB; ++u) mfma_a(acc_o[dt0 + u], vfr[bi & 1][u], pf[ks]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    pin_agpr(acc_o);
+    if (full) gemm2(std::true_type{}); else gemm2(std::false_type{});
+  }
+  fence_a(acc_o);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no DMA may be in flight into LDS when the block retires)
+
+  if (qloc < Lq) {
+    uint16_t* op = a.out + (int64_t)(s.start + qloc) * a.o_row + (int64_t)h * a.o_head;
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        uint2 o;
+        o.x = pack_bf16(acc_o[dt][4 * g4 + 0], acc_o[dt][4 * g4 + 1]);
+        o.y = pack_bf16(acc_o[dt][4 * g4 + 2], acc_o[dt][4 * g4 + 3]);
+        *reinterpret_cast<uint2*>(op + 32 * dt + 8 * g4 + 4 * hi) = o;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Backward (reference: hstu_varlen_bwd -> hstu_bwd.h, core maths :687-729).  With s = alpha <q,k>:
 //   P  = M SiLU(s) / N            dV = P^T dO
 //   dP = dO V^T                   dS = M dP SiLU'(s) alpha / N       dQ = dS K      dK = dS^T Q
@@ -1756,6 +1990,25 @@ static int launch_bwd(BwdAttnArgs g, int B, int max_seqlen, hipStream_t stream) 
   return MI355_OK;
 }
 
+// opt-in (MI355_HSTU_DMA=1): the LDS-DMA staged forward; head dim 256, contiguous keys, no bias
+template <int D>
+static int launch_fwd_dma(const AttnArgs& a, int B, int max_seqlen, hipStream_t stream) {
+  const size_t smem = (size_t)2 * 2 * kBN * D * sizeof(uint16_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_dma_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_dma_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess) return MI355_ELAUNCH;
+    attr_set = true;
+  }
+  dim3 grid(a.H, B, (max_seqlen + kBM - 1) / kBM);
+  if (a.wl >= 0 || a.wr >= 0) hipLaunchKernelGGL((hstu_fwd_dma_kernel<D, true>), grid, dim3(256), smem, stream, a);
+  else hipLaunchKernelGGL((hstu_fwd_dma_kernel<D, false>), grid, dim3(256), smem, stream, a);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
 template <int D>
 static int launch_fwd(const AttnArgs& a, int B, int max_seqlen, hipStream_t stream) {
   const size_t vtile = HSTU_VTR ? (size_t)kBN * (D == 32 ? 32 : D + 32) : (size_t)D * (kBN + 8);
@@ -1850,6 +2103,8 @@ int mi355_hstu_attn_fwd_kv(const void* q, const void* k, const void* v, void* ou
   a.alpha = alpha; a.inv_scale = 1.0f / scaling_seqlen;
   a.cu_seqlens_k = cu_seqlens_k; a.kv_cache = (const uint16_t*)kv_cache; a.page_offsets = page_offsets; a.page_ids = page_ids;
   a.last_page_lens = last_page_lens; a.page_size = (int)page_size;
+  static const int use_dma = getenv("MI355_HSTU_DMA") ? atoi(getenv("MI355_HSTU_DMA")) : 0;
+  if (use_dma && head_dim == 256 && !a.kv_cache && !a.rab) return launch_fwd_dma<256>(a, (int)batch, (int)max_seqlen_q, stream);
   switch (head_dim) {
     case 32: return launch_fwd<32>(a, (int)batch, (int)max_seqlen_q, stream);
     case 64: return launch_fwd<64>(a, (int)batch, (int)max_seqlen_q, stream);

@@ -318,6 +318,23 @@ def test_rab_without_drab_and_zero_bias():
         assert torch.equal(a, b)
 
 
+def test_forward_with_lds_dma_staging():
+    """MI355_HSTU_DMA=1 runs the d = 256 forward with its K / V tiles moved global -> LDS by `global_load_lds_dwordx4`
+    (XOR-swizzled rows, double-buffered, one barrier per tile: hstu_fwd_dma_kernel) instead of the register-staged kernel.
+    The library reads the switch once, so every d = 256 test of this file (goldens, random jagged batches, contexts /
+    targets, local windows, delta-q) is re-run in a child process with it."""
+    import subprocess
+    import sys
+
+    if os.environ.get("MI355_HSTU_DMA") == "1":
+        pytest.skip("already the DMA run")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "256 and not mask_alone and not rab and not lds_dma"], env=dict(os.environ, MI355_HSTU_DMA="1"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout, r.stdout[-500:]
+
+
 def test_strided_inputs_and_scaling_seqlen():
     """q/k/v as slices of one fused [T, 3, H, d] tensor (what the fused HSTU layer hands over) and
     scaling_seqlen decoupled from max_seqlen."""
