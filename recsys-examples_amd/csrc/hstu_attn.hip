@@ -846,15 +846,25 @@ __global__ void __launch_bounds__(256) hstu_fwd_dma_kernel(AttnArgs a) {
 
   if (n_end > n_beg) issue_dma(n_beg, 0);
   int it = 0;
+#if HSTU_TIMING
+  unsigned tsum[7] = {0, 0, 0, 0, 0, 0, 0};   // wait for own DMA, barrier, DMA issue, -, GEMM 1, SiLU + GEMM 2, tiles
+  const unsigned t_start = tick();
+#endif
   for (int n0 = n_beg; n0 < n_end; n0 += kBN, ++it) {
     pin_agpr(acc_o);
+    TICK(t0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile n0 have landed ...
+    TICK(t1);
     __syncthreads();                                    // ... everyone's have, and everyone is done reading the other buffer
+    TICK(t2);
     if (n0 + kBN < n_end) issue_dma(n0 + kBN, (it + 1) & 1);
+    TICK(t3);
+    TACC(0, t0, t1); TACC(1, t1, t2); TACC(2, t2, t3);
     const uint16_t* Ks = smem + (it & 1) * 2 * TENS;
     const uint16_t* Vt = Ks + TENS;
     pin_agpr(acc_o);
     if (!wave_live || n0 >= w_end || n0 < w_beg) continue;
+    TICK(t5);
 
     // ---- GEMM 1: S^T[64 keys x 32 q] = K Q^T (two 32-key tiles), fragment batches double-buffered
     f32x16_t acc_s[2];
@@ -888,6 +898,8 @@ __global__ void __launch_bounds__(256) hstu_fwd_dma_kernel(AttnArgs a) {
     }
     fence_v(acc_s);
     pin_agpr(acc_o);
+    TICK(t6);
+    TACC(4, t5, t6);
     const bool full = a.causal && s.wl < 0 && (n0 + kBN - 1 <= dq + qrow0) && (!s.has_ctx || dq + qrow0 >= s.c) && (!s.has_tgt || n0 + kBN - 1 < s.hlen);
     // ---- GEMM 2: O^T[D x 32 q] += V^T[D x 64 keys] P^T, pipelined with the SiLU of the next 16-key slice
     constexpr int NDT = D / 32;
@@ -939,9 +951,25 @@ __global__ void __launch_bounds__(256) hstu_fwd_dma_kernel(AttnArgs a) {
     };
     pin_agpr(acc_o);
     if (full) gemm2(std::true_type{}); else gemm2(std::false_type{});
+    TICK(t7);
+    TACC(5, t6, t7);
+#if HSTU_TIMING
+    tsum[6] += 1;
+#endif
   }
   fence_a(acc_o);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no DMA may be in flight into LDS when the block retires)
+#if HSTU_TIMING
+  {
+    const unsigned t_end = tick();
+    if (lane == 0) {
+      const int blk = ((int)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      unsigned long long* d = g_hstu_dbg + ((size_t)(blk * 4 + wv) % 65536) * 8;
+      for (int i = 0; i < 7; ++i) d[i] = tsum[i];
+      d[7] = t_end - t_start;
+    }
+  }
+#endif
 
   if (qloc < Lq) {
     uint16_t* op = a.out + (int64_t)(s.start + qloc) * a.o_row + (int64_t)h * a.o_head;

@@ -1,5 +1,10 @@
-"""Per-phase cycle breakdown of hstu_fwd_kernel<256> (needs a library built with -DHSTU_TIMING=1):
-MI355_LIB=.../librecsys_amd_tim.so python tools/hstu_phase_cycles.py [--seqlen L --batch B]"""
+"""Per-phase cycle breakdown of the d = 256 attention kernels -- hstu_fwd_kernel, hstu_fwd_dma_kernel (--dma), the dK pass of
+the backward (--bwd).  Needs a library whose hstu_attn.hip was compiled with -DHSTU_TIMING=1:
+
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DHSTU_TIMING=1 -c recsys-examples_amd/csrc/hstu_attn.hip -o /tmp/h.o
+    hipcc --offload-arch=gfx950 -shared -fPIC -o recsys-examples_amd/lib/librecsys_amd_tim.so \
+        $(ls recsys-examples_amd/lib/obj/*.o | grep -v hstu_attn.o) /tmp/h.o
+    MI355_LIB=$PWD/recsys-examples_amd/lib/librecsys_amd_tim.so python tools/hstu_phase_cycles.py [--dma | --bwd] [--seqlen L --batch B]"""
 import argparse, ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "recsys-examples_amd")); sys.path.insert(0, ROOT)
@@ -10,8 +15,11 @@ import mi355_native
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32); ap.add_argument("--seqlen", type=int, default=512)
 ap.add_argument("--heads", type=int, default=4); ap.add_argument("--dim", type=int, default=256)
+ap.add_argument("--dma", action="store_true", help="the LDS-DMA staged forward (sets MI355_HSTU_DMA=1)")
 ap.add_argument("--bwd", action="store_true", help="the dK pass of the backward (hstu_bwd_kv_kernel, exchange mode) instead of the forward")
 a = ap.parse_args()
+if a.dma:
+    os.environ["MI355_HSTU_DMA"] = "1"   # read by the library at its first forward
 dev = torch.device("cuda")
 T = a.batch * a.seqlen
 cu = torch.arange(0, T + 1, a.seqlen, dtype=torch.int32, device=dev)
@@ -31,6 +39,7 @@ assert lib.mi355_hstu_dbg_dump(buf.ctypes.data, buf.nbytes) == 0
 d = buf[:n].astype(np.float64)
 tiles = d[:, 6]
 names = (["barrier1", "fetch (load + wait)", "commit x2 images", "barrier2", "gemm S + dP", "silu' + P/dS stores"] if a.bwd
+         else ["wait own DMA", "barrier", "DMA issue (next tile)", "-", "gemm1", "silu+gemm2"] if a.dma
          else ["barrier1", "commit", "barrier2", "fetch-issue", "gemm1", "silu+gemm2"])
 tot = d[:, 7]
 print(f"waves {n}  tiles/wave avg {tiles.mean():.2f}  wave lifetime avg {tot.mean():.0f} cyc  max {tot.max():.0f}")
