@@ -202,9 +202,15 @@ __device__ __forceinline__ void wave_init_row(const FusedArgs& a, void* rp, uint
   }
 }
 
-template <int TILE, int THREADS, bool kTrain, bool kPart = false>
+// kFast (opt-in, MI355_FUSED_FASTMOD=1; bucket capacity a power of two): the key's bucket without 64-bit divisions.  gfx950
+// has no 64-bit divide -- `(hash % (buckets * C)) / C` expands to ~400 instructions per key ahead of the digest load.
+// floor((h mod n C) / C) = floor(h / C) mod n; h / C is a shift, and x mod n = x - mulhi64(x, M) n with M = floor((2^64 - 1) / n)
+// leaves a quotient that is at most one short: two conditional subtractions make it exact.  M is formed once per table and
+// block (s_magic).  The partition of a slot, slot / spp with spp a multiple of C, is bucket / (spp / C): 32-bit.
+template <int TILE, int THREADS, bool kTrain, bool kPart = false, bool kFast = false>
 __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   __shared__ int s_hist[kPart ? kPartMax : 1];    // kPart: records of this tile per partition, then their base in the partition
+  __shared__ uint64_t s_magic[kFast ? kFusedMaxT : 1];
   if (!a.timer) a.timer = device_clock();
   constexpr int PER = TILE / THREADS;
   constexpr int LDS = 2 * TILE;
@@ -235,7 +241,11 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     s_seg[t] = T == 1 ? (t == 0 ? 0 : a.n) : a.offsets[a.feature_offsets[t] * a.batch];
     s_tbo[t] = a.tbo[t];
     if (t < T) { s_tptr[t] = a.table_ptrs[t]; s_rowb[t] = (int)a.table_value_dims[t] * a.elem_bytes; }
+    if constexpr (kFast) {
+      if (t < T) { const uint64_t nb = (uint64_t)(a.tbo[t + 1] - a.tbo[t]); s_magic[t] = nb ? ~0ull / nb : 0ull; }
+    }
   }
+  const int cshift = kFast ? __builtin_ctzll((unsigned long long)a.t.C) : 0;
   if (blockIdx.x == 0 && kTrain) {
     if (a.hot_counters && threadIdx.x < 3) a.hot_counters[2 * threadIdx.x] = 0;   // n_hot, n_tasks, n_wave
   }
@@ -265,10 +275,22 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     const uint64_t key = kreg[q];
     const int64_t hash = (int64_t)(fmix64(key) & 0x7FFFFFFFFFFFFFFFull);
     const int64_t bb = s_tbo[tt];
-    const int64_t cap = (s_tbo[tt + 1] - bb) * a.t.C;
-    const bool ok = i < a.n && is_valid(key) && cap > 0;
-    const uint64_t local = (uint64_t)hash % (uint64_t)(cap > 0 ? cap : 1);
-    const int64_t b = bb + (int64_t)(local / (uint64_t)a.t.C);
+    bool ok;
+    int64_t b;
+    if constexpr (kFast) {
+      const uint64_t nb = (uint64_t)(s_tbo[tt + 1] - bb);
+      const uint64_t x = (uint64_t)hash >> cshift;
+      uint64_t r = x - __umul64hi(x, s_magic[tt]) * nb;
+      if (r >= nb) r -= nb;
+      if (r >= nb) r -= nb;
+      ok = i < a.n && is_valid(key) && nb > 0;
+      b = bb + (int64_t)(nb ? r : 0ull);
+    } else {
+      const int64_t cap = (s_tbo[tt + 1] - bb) * a.t.C;
+      ok = i < a.n && is_valid(key) && cap > 0;
+      const uint64_t local = (uint64_t)hash % (uint64_t)(cap > 0 ? cap : 1);
+      b = bb + (int64_t)(local / (uint64_t)a.t.C);
+    }
     hq[q] = hash;
     bq[q] = ok ? b : -1;
     const int C = (int)a.t.C;
@@ -308,7 +330,8 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     for (int q = 0; q < PER; ++q) {
       lpq[q] = 0;
       if (isrep[q]) {
-        const int pk = bq[q] >= 0 ? (int)(bq[q] * a.t.C / a.spp) : a.P - 1;
+        const int pk = bq[q] < 0 ? a.P - 1
+                       : kFast ? (int)((uint32_t)bq[q] / (uint32_t)(a.spp >> cshift)) : (int)(bq[q] * a.t.C / a.spp);
         lpq[q] = pk * 4096 + atomicAdd(&s_hist[pk], 1);
       }
     }
@@ -1463,7 +1486,10 @@ int mi355_demb_forward_fused(
     else hipLaunchKernelGGL((fused_probe_kernel<TILE, THREADS, false>), dim3(grid), dim3(THREADS), 0, stream, a);         \
   } while (0)
     if (part) {
-      hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
+      const char* fm = getenv("MI355_FUSED_FASTMOD");   // (read per call: A/B inside one process; opt-in this round)
+      const bool fast = fm && atoi(fm) != 0 && (a.t.C & (a.t.C - 1)) == 0 && (a.S >> __builtin_ctzll((unsigned long long)a.t.C)) < (1ll << 31);
+      if (fast) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
+      else hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
     } else
     switch (cfg) {
       case 1: LAUNCH_PROBE(1024, 256); break;
