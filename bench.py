@@ -317,8 +317,30 @@ def _flush_c_stdout():
         pass
 
 
+def _self_launch(args):
+    """`python bench.py --gpus N` outside a launcher: re-exec under torch.distributed.run (one rank per GPU over RCCL), the
+    command the driver uses for N > 1; rank 0 of the child job prints the JSON line."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver (RCCL needs it)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -408,6 +430,7 @@ def main():
         "value": keys_total / elapsed,
         "unit": "lookups/s",
         "n_gpus": world,
+        "ranks": (dist.get_world_size() if sharded_path else 1),   # what the process group (RCCL) actually holds
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,

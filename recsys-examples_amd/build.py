@@ -28,7 +28,22 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, variant: str = "", defines=(), only=()) -> str:
+    """variant / defines: a side build for A/B sweeps and profiling (lib/librecsys_amd_<variant>.so, objects under
+    lib/obj_<variant>/), selected at run time with MI355_LIB; the default build is the product."""
+    global OBJDIR, LIB
+    objdir_saved, lib_saved = OBJDIR, LIB
+    if variant:
+        OBJDIR = os.path.join(LIBDIR, "obj_" + variant)
+        LIB = os.path.join(LIBDIR, f"librecsys_amd_{variant}.so")
+    try:
+        return _build(force, verbose, list(defines), tuple(only), objdir_saved)
+    finally:
+        OBJDIR, LIB = objdir_saved, lib_saved
+
+
+def _build(force, verbose, defines, only=(), base_objdir=None) -> str:
+    """only: sources a variant build recompiles with `defines`; every other object is taken from the default build"""
     os.makedirs(OBJDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     jobs = []
@@ -36,9 +51,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in _sources():
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        if only and src not in only:
+            objs.append(os.path.join(base_objdir, src.replace(".hip", ".o")))
+            continue
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([HIPCC] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + FLAGS + defines + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -54,4 +72,6 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    _variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
+    _only = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else ()
+    print(build(force="--force" in sys.argv, variant=_variant, defines=[a for a in sys.argv[1:] if a.startswith("-D")], only=_only))

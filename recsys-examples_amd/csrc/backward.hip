@@ -23,6 +23,7 @@
 #include "common.h"
 #include "hot.h"
 #include "internal.h"
+#include "stamps.h"
 
 namespace mi355 {
 
@@ -502,8 +503,16 @@ __device__ __forceinline__ void rows_pipelined(const BwdArgs& a, const OptArgs& 
 }
 
 // kSgd: instantiation for SGD on vector rows without per-feature dims (its own register budget: 93 VGPRs)
+STAMP_ARRAY(g_st_bwd, 16384, 2)
+#if MI355_STAMPS
+struct BwdEndStamp { __device__ ~BwdEndStamp() { STAMP(g_st_bwd, 16384, 2, 1); } };
+#endif
 template <int WDT, int GDT, int NCOL, bool kVec, bool kSgd>
 __global__ void __launch_bounds__(256) bwd_kernel(BwdArgs a, OptArgs o, int lpr_log2) {
+  STAMP(g_st_bwd, 16384, 2, 0);
+#if MI355_STAMPS
+  BwdEndStamp end_stamp__;
+#endif
   const int lane = lane_id();
   const int LPR = 1 << lpr_log2, NSUB = 64 >> lpr_log2;
   const int sub = lane >> lpr_log2, c = lane & (LPR - 1);
@@ -709,6 +718,7 @@ opt_rows_kernel(OptArgs o, const void* grads, int64_t grad_stride, int64_t n, co
 }  // namespace mi355
 
 using namespace mi355;
+STAMP_EXPORT(mi355_debug_stamps_bwd, g_st_bwd)
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 static int lpr_log2_for(int D, bool vec) {

@@ -34,10 +34,16 @@
 #include "table_dev.h"
 #include "init_dev.h"
 #include "roctx.h"
+#include "stamps.h"
 #include <pthread.h>
 #include <stdlib.h>
 
 namespace mi355 {
+
+STAMP_ARRAY(g_st_probe, 1024, 12)
+STAMP_ARRAY(g_st_part, 1024, 10)
+#define PST(ph) STAMP(g_st_probe, 1024, 12, ph)
+#define QST(ph) STAMP(g_st_part, 1024, 10, ph)
 
 constexpr int kFusedMaxT = 128;     // tables per fused launch (per-table metadata lives in LDS)
 constexpr int kPartMax = 1024;      // partitions of the partitioned index stage (their counters live in the aux header)
@@ -211,6 +217,7 @@ template <int TILE, int THREADS, bool kTrain, bool kPart = false, bool kFast = f
 __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   __shared__ int s_hist[kPart ? kPartMax : 1];    // kPart: records of this tile per partition, then their base in the partition
   __shared__ uint64_t s_magic[kFast ? kFusedMaxT : 1];
+  PST(0);
   if (!a.timer) a.timer = device_clock();
   constexpr int PER = TILE / THREADS;
   constexpr int LDS = 2 * TILE;
@@ -257,6 +264,7 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   if (threadIdx.x < HALVES) s_nrep[threadIdx.x] = 0;
   if constexpr (kPart) for (int p = threadIdx.x; p < a.P; p += THREADS) s_hist[p] = 0;
   __syncthreads();
+  PST(1);
   int hh[PER], rk[PER];
   int64_t bq[PER], hq[PER];      // bucket and hash of my keys (bucket -1: key without a home)
   uint4 dvq[PER];                // first digest vector of the probe
@@ -297,7 +305,9 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     const int start = (int)(((C & (C - 1)) == 0 ? ((uint64_t)hash & (uint64_t)(C - 1)) : ((uint64_t)hash % (uint64_t)C))) & ~15;
     dvq[q] = *reinterpret_cast<const uint4*>(a.t.dig(ok ? b : 0) + start);   // unconditional: bucket 0 for homeless keys
   }
+  PST(2);
   __syncthreads();
+  PST(3);
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
     const int li = q * THREADS + threadIdx.x;
@@ -317,7 +327,9 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
       rk[q] = atomicAdd(&s_cnt[h], 1);
     }
   }
+  PST(4);
   __syncthreads();
+  PST(5);
   bool isrep[PER];
 #pragma unroll
   for (int q = 0; q < PER; ++q) isrep[q] = hh[q] >= 0 && s_tab[hh[q]] == q * THREADS + (int)threadIdx.x;
@@ -353,7 +365,9 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     cand[q] = m ? start + __ffs(m) - 1 : -1;
     kc[q] = a.t.keys(bq[q] >= 0 ? bq[q] : 0)[cand[q] >= 0 ? cand[q] : 0];
   }
+  PST(6);
   __syncthreads();   // s_tab / s_cnt change meaning below
+  PST(7);
   // ---- probe: one lane per distinct key of the tile
   int cnt_tile[PER];   // (kPart) occurrences of my distinct keys inside the tile
 #pragma unroll
@@ -411,7 +425,9 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     s_cnt[hh[q]] = base;
     }
   }
+  PST(8);
   __syncthreads();
+  PST(9);
   if constexpr (kPart) {
     const int sub = (int)blockIdx.x % kPartSub;
     if ((int)threadIdx.x < a.P) s_hist[threadIdx.x] = my_base;
@@ -432,6 +448,7 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     }
     __syncthreads();
   }
+  PST(10);
   int nrep[HALVES];
 #pragma unroll
   for (int hq = 0; hq < HALVES; ++hq) nrep[hq] = 0;
@@ -487,6 +504,7 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   }
   if (blockIdx.x == 0)
     for (int t = threadIdx.x; t <= T; t += THREADS) a.seg_out[t] = s_seg[t];
+  PST(11);
 }
 
 // ---- deferred keys: bucket without a free slot -> evict the minimum score (kernels.cuh:226-287, types.cuh:398-512) ----
@@ -954,6 +972,7 @@ fused_part_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, bo
   __shared__ int s_lock[256];             // bucket locks of the eviction (hashed)
   __shared__ int s_nu, s_nd, s_tot, s_th, s_tt, s_tw;
   const int p = blockIdx.x;
+  QST(0);
   // the records come in kPartSub sub-lists of kSubCap; every load is issued unconditionally (the arrays are fully
   // allocated), so the records are in flight together with their counts
   int msub[kPartSub];
@@ -980,7 +999,9 @@ fused_part_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, bo
     const int ms = msub[k / (kSubCap / kScanThreads)];   // (kSubCap is a multiple of the block size)
     live[k] = (idx % kSubCap) < (ms < kSubCap ? ms : kSubCap);
   }
+  QST(1);
   __syncthreads();
+  QST(2);
   if (threadIdx.x < kPartSub) a.pcount[p * kPartSub + threadIdx.x] = 0;       // the counters are clean for the next step
   // ---- merge the records of a slot; the record that creates the entry owns the unique row's outputs
   {
@@ -1013,7 +1034,9 @@ fused_part_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, bo
       }
     }
   }
+  QST(3);
   __syncthreads();
+  QST(4);
   // ---- deferred keys: the bucket had no free slot.  Evict the minimum score among the slots this batch does not use
   //      (the hash above knows them all: every record of the bucket is in this block) and that nobody pinned
   //      (kernels.cuh:226-287, types.cuh:398-512); 8 lanes per key, a hashed LDS lock per bucket.
@@ -1168,6 +1191,7 @@ fused_part_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, bo
     stat_store(a.tstat + p, kStatAgg | ((unsigned long long)nu << 31) | (unsigned)tot2);
     stat_store(tb + p, kStatAgg | ((unsigned long long)th << 40) | ((unsigned long long)tt << 20) | (unsigned long long)tw);
   }
+  QST(5);
   // ---- local prefix of the occurrence counts in local-unique-id order, local positions of the hot rows
   int lc[kPartItems], csum = 0;
 #pragma unroll
@@ -1192,7 +1216,9 @@ fused_part_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, bo
     w_ex = block_excl_scan(nw_local, dummy);
   }
   unsigned long long pre_a = 0, pre_b = 0;
+  QST(6);
   lookback_sum2(a.tstat, tb, p, pre_a, pre_b);
+  QST(7);
   const int upre = (int)(pre_a >> 31), spre = (int)(pre_a & 0x7fffffffull);
   h_ex += (int)(pre_b >> 40); t_ex += (int)((pre_b >> 20) & 0xfffff); w_ex += (int)(pre_b & 0xfffff);
   __syncthreads();
@@ -1243,6 +1269,8 @@ fused_part_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, bo
     *o.total = O;
     if (ptr) ptr[U] = O;
   }
+  QST(8);
+  QST(9);
 }
 
 // exclusive scan of the per-tile representative counts when there are too many tiles for every block to sum its
@@ -1267,6 +1295,8 @@ __global__ void __launch_bounds__(kScanThreads) fused_scan_partials_kernel(int* 
 }  // namespace mi355
 
 using namespace mi355;
+STAMP_EXPORT(mi355_debug_stamps_probe, g_st_probe)
+STAMP_EXPORT(mi355_debug_stamps_part, g_st_part)
 
 // Side stream on which the forward numbers the uniques and builds the backward's CSR while its own gather runs.
 // One per process; the join events form a small ring, a forward hands its token to the backward of the same batch

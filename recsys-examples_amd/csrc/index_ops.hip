@@ -21,6 +21,7 @@
 //    hottest row of a Zipf stream costs (#tiles) atomics instead of (#occurrences).
 #include "common.h"
 #include "hot.h"
+#include "stamps.h"
 #include "../../include/recsys_amd.h"
 #include "internal.h"
 #include "scan_dev.h"
@@ -558,6 +559,8 @@ csr_fill_kernel(const int64_t* __restrict__ rev, int64_t n, const int64_t* __res
 // to rev_out[j].  kMode 2 (partitioned fused forward): slot[j] is the key's (tile, key) record; the record knows the unique
 // id and the rank base of its tile inside the row's list (PartRefs); rank[j] is the rank inside the tile and is replaced by
 // the full rank; keys whose slot was found late (deferred eviction) get their row address here.
+STAMP_ARRAY(g_st_scatter, 2048, 6)
+#define SST(ph) STAMP(g_st_scatter, 2048, 6, ph)
 template <int kMode>
 __global__ void __launch_bounds__(256)
 csr_scatter_kernel(const int64_t* __restrict__ rev, int* __restrict__ rank, int64_t n, const int64_t* __restrict__ offsets,
@@ -565,6 +568,7 @@ csr_scatter_kernel(const int64_t* __restrict__ rev, int* __restrict__ rank, int6
                    const int* __restrict__ slot, const int* __restrict__ uidmap, int64_t* __restrict__ rev_out,
                    int* __restrict__ hdr_reset = nullptr, PartRefs pr = PartRefs{}) {
   constexpr bool kSlot = kMode == 1;
+  SST(0);
   // fused forward: the deferred-key count, barrier words and release flag of the table's aux header are cleared for the
   // next step here, behind the numbering kernel that read them
   if (hdr_reset && blockIdx.x == 0 && threadIdx.x < 64 && threadIdx.x != 5) hdr_reset[threadIdx.x] = 0;   // ([5]: sticky error flag)
@@ -639,8 +643,10 @@ csr_scatter_kernel(const int64_t* __restrict__ rev, int* __restrict__ rank, int6
   }
 #pragma unroll
   for (int q = 0; q < NQ; ++q) p[q] = ptr[r[q]];
+  SST(1);
   if (offsets) {
     __syncthreads();
+    SST(2);
     const int b_lo = s_range[0], b_hi = s_range[1];
     for (int b = b_lo + threadIdx.x; b <= b_hi; b += blockDim.x) {
       const int64_t o0 = offsets[b], o1 = offsets[b + 1];
@@ -665,6 +671,12 @@ csr_scatter_kernel(const int64_t* __restrict__ rev, int* __restrict__ rank, int6
     for (int k = 0; k < 4; ++k) s_bag[threadIdx.x * 4 + k] = v[k] > prev ? v[k] : prev;
     __syncthreads();
   }
+  SST(3);
+  int keep_alive = 0;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) keep_alive += p[q] + rk[q];
+  asm volatile("" :: "v"(keep_alive));
+  SST(4);
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int64_t j = tile0 + q * 256 + threadIdx.x;
@@ -682,6 +694,7 @@ csr_scatter_kernel(const int64_t* __restrict__ rev, int* __restrict__ rank, int6
       }
     }
   }
+  SST(5);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1014,6 +1027,7 @@ __global__ void __launch_bounds__(1024) scan64_tiles_kernel(const int64_t* __res
 }  // namespace mi355
 
 using namespace mi355;
+STAMP_EXPORT(mi355_debug_stamps_scatter, g_st_scatter)
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 

@@ -21,33 +21,17 @@
 #include "common.h"
 #include "internal.h"
 #include "init_dev.h"
+#include "stamps.h"
+#include "gather_dev.h"
 #include <stdlib.h>
 
 namespace mi355 {
-
-struct PoolArgs {
-  const void* src;             // dense source [*, src_stride] (row_addr == nullptr)
-  int64_t src_stride;          // elements
-  const int64_t* row_addr;     // per-unique absolute row address (0 = missing row -> contributes 0)
-  const int64_t* rev;          // [Nt] key -> unique
-  const int64_t* offsets;      // [FB+1] feature-major bag offsets
-  const int32_t* D_offsets;    // [F+1] or nullptr (uniform D)
-  void* dst;                   // [B, total_D]
-  int64_t FB;
-  int64_t n;                   // number of keys (= offsets[FB])
-  int B;
-  int D;                       // uniform dim, or max_D when D_offsets != nullptr
-  int total_D;
-  int combiner;                // 0 sum, 1 mean
-};
 
 template <int SDT>
 __device__ __forceinline__ const void* src_row(const PoolArgs& a, int64_t u) {
   if (a.row_addr) return reinterpret_cast<const void*>(a.row_addr[u]);
   return reinterpret_cast<const typename Elem<SDT>::T*>(a.src) + u * a.src_stride;
 }
-
-__device__ __forceinline__ void add4(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 
 // vectorised: D_f % 4 == 0, rows 16-B (fp32) / 8-B (16-bit) aligned.  NCOL = ceil(D / (4*LPR)).
 //
@@ -58,37 +42,7 @@ __device__ __forceinline__ void add4(float4& a, const float4& b) { a.x += b.x; a
 // four rows per bag per round; all index loads of a round are issued before the row loads, all row
 // loads before the adds.  A bag never leaves its lane group, so there is no cross-lane reduction and
 // the fp32 sum runs in bag order (bit-identical to a sequential sum).
-// 4 KiB of zeros every lane may read: padding rows, missing rows (address 0) and lanes beyond a
-// row's width load from here, so EVERY load of a round is unconditional -- hipcc otherwise wraps each
-// predicated load in its own exec-masked branch with an s_waitcnt vmcnt(0), which serialises the
-// whole round into one long dependent chain (measured: 3x slower).
-__device__ __attribute__((aligned(16))) float g_zero_row[1024];
-
-typedef const __attribute__((address_space(1))) char* gptr_t;   // explicit GLOBAL pointers: keeps the
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-typedef const __attribute__((address_space(1))) u32x2_t* gptr2_t;  // row loads global_load, not flat_load
-typedef const __attribute__((address_space(1))) f32x4_t* gptr4_t;
-
-template <int DT>
-__device__ __forceinline__ float4 ld4g(gptr_t p) {
-  if constexpr (DT == kF32) {
-    const f32x4_t t = *reinterpret_cast<gptr4_t>(p);
-    return make_float4(t.x, t.y, t.z, t.w);
-  } else {
-    const u32x2_t r = *reinterpret_cast<gptr2_t>(p);
-    float4 o;
-    if constexpr (DT == kBF16) {
-      o.x = __uint_as_float(r.x << 16); o.y = __uint_as_float(r.x & 0xffff0000u);
-      o.z = __uint_as_float(r.y << 16); o.w = __uint_as_float(r.y & 0xffff0000u);
-    } else {
-      o.x = f16_to_f32((uint16_t)(r.x & 0xffff)); o.y = f16_to_f32((uint16_t)(r.x >> 16));
-      o.z = f16_to_f32((uint16_t)(r.y & 0xffff)); o.w = f16_to_f32((uint16_t)(r.y >> 16));
-    }
-    return o;
-  }
-}
-
+// (PoolArgs, the zero row, ld4g and the flat-stream gather live in gather_dev.h)
 template <int SDT, int DDT, int NCOL, int NB, bool kAddr, int RPR = 4>
 __global__ void __launch_bounds__(256) gather_pooled_vec_kernel(PoolArgs a, int lpr_log2) {
   const int lane = lane_id();
@@ -193,8 +147,10 @@ __global__ void __launch_bounds__(256) gather_pooled_vec_kernel(PoolArgs a, int 
 // in flight.  Rows are added in key order (bit-identical to the sequential sum).
 // kAddr: 0 dense source, 1 row addresses per UNIQUE key (through rev), 2 row addresses per OCCURRENCE (fused forward: the
 // reverse-index hop does not exist)
+STAMP_ARRAY(g_st_gather, 16384, 2)
 template <int SDT, int DDT, int kAddr, int UNR, int KIT>
 __global__ void __launch_bounds__(256) gather_pooled_pipe_kernel(PoolArgs a, int lpr_log2) {
+  STAMP(g_st_gather, 16384, 2, 0);
   const int lane = lane_id();
   const int LPR = 1 << lpr_log2;
   const int NSUB = 64 >> lpr_log2;
@@ -285,6 +241,18 @@ __global__ void __launch_bounds__(256) gather_pooled_pipe_kernel(PoolArgs a, int
     lo_c = lo_n; hi_c = hi_n; rp_c = rp_n;
     lo_n = lo_nn; hi_n = hi_nn; u_n = u_nn;
   }
+  STAMP(g_st_gather, 16384, 2, 1);
+}
+
+// flat-stream form (gather_dev.h): a lane group owns KB consecutive bags and keeps U .. 2U rows in flight for its whole life
+template <int SDT, int DDT, int kAddr, int U, int KB>
+__global__ void __launch_bounds__(256) gather_pooled_flat_kernel(PoolArgs a, int lpr_log2) {
+  STAMP(g_st_gather, 16384, 2, 0);
+  const int NSUB = 64 >> lpr_log2;
+  const int64_t sg = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * NSUB + (lane_id() >> lpr_log2);
+  const int64_t b0 = sg * KB;
+  if (b0 < a.FB) gather_pooled_flat<SDT, DDT, kAddr, U, KB>(a, lpr_log2, b0);
+  STAMP(g_st_gather, 16384, 2, 1);
 }
 
 // scalar fallback (odd dims such as 7 / 11 / 13): lane handles elements lane, lane+64, ...
@@ -492,6 +460,7 @@ sum_chunks_kernel(const float* __restrict__ in, int64_t chunks, int64_t n, void*
 }  // namespace mi355
 
 using namespace mi355;
+STAMP_EXPORT(mi355_debug_stamps_gather, g_st_gather)
 
 static int lpr_log2_for(int D) {
   int l = 3;  // at least 8 lanes
@@ -516,8 +485,28 @@ static int launch_pooled(PoolArgs a, bool vec, hipStream_t stream) {
     if (a.row_addr) hipLaunchKernelGGL((gather_pooled_vec_kernel<SDT, DDT, 1, NBV, true, RPRV>), dim3(grid_for(a.FB, 4 * nsub * NBV, 1 << 20)), dim3(256), 0, stream, a, l); \
     else hipLaunchKernelGGL((gather_pooled_vec_kernel<SDT, DDT, 1, NBV, false, RPRV>), dim3(grid_for(a.FB, 4 * nsub * NBV, 1 << 20)), dim3(256), 0, stream, a, l); \
   } while (0)
-      if (variant <= 0 || variant >= 20) {
-        constexpr int KIT = 4;
+      // MI355_POOL_VARIANT=31: the flat-stream kernel of gather_dev.h (uniform D).  Measured equal to the pipelined kernel below
+      // on C2 (30.2 vs 29.7 us under rocprofv3 in the real step; 29.0 vs 27.9 us standalone on tools/ubench_gather.hip's data):
+      // both keep ~U rows per lane group in flight all the time; what is left is the imbalance of the bag lengths
+#ifndef POOL_FLAT_U
+#define POOL_FLAT_U 4
+#endif
+      if (variant == 31 && a.D_offsets == nullptr && a.FB < (1ll << 31) - 64) {
+#define MI355_POOL_F(KBV)                                                                                                          \
+  do {                                                                                                                             \
+    const int64_t groups = ceil_div(a.FB, KBV);                                                                                    \
+    const int grid = (int)ceil_div(groups, 4 * nsub);                                                                              \
+    if (a.row_addr && !a.rev) hipLaunchKernelGGL((gather_pooled_flat_kernel<SDT, DDT, 2, POOL_FLAT_U, KBV>), dim3(grid), dim3(256), 0, stream, a, l); \
+    else if (a.row_addr) hipLaunchKernelGGL((gather_pooled_flat_kernel<SDT, DDT, 1, POOL_FLAT_U, KBV>), dim3(grid), dim3(256), 0, stream, a, l);      \
+    else hipLaunchKernelGGL((gather_pooled_flat_kernel<SDT, DDT, 0, POOL_FLAT_U, KBV>), dim3(grid), dim3(256), 0, stream, a, l);  \
+  } while (0)
+        if (l == 3) MI355_POOL_F(4); else MI355_POOL_F(8);
+#undef MI355_POOL_F
+      } else if (variant <= 0 || variant >= 20) {
+#ifndef POOL_KIT
+#define POOL_KIT 4
+#endif
+        constexpr int KIT = POOL_KIT;
         const int grid = grid_for(a.FB, 4 * nsub * KIT, 1 << 20);
 #define MI355_POOL_P(UNRV)                                                                                                   \
   do {                                                                                                                       \
