@@ -56,7 +56,16 @@ struct BwdArgs {
   HotList hot;              // hot-row task list built by mi355_group_by_unique (hot.n_tasks == nullptr: none)
   int hot_blocks;           // leading blocks of the launch that serve the hot tasks
   int wave_blocks;          // blocks after them whose waves serve the one-wave rows (hot.wave_*)
+  const int32_t* tile_bags; // nullable.  Round 3 (fused forward, csrc/fused_fwd.hip): a CSR entry e < 0 is a REFERENCE -- the
+                            // source id is tile_bags[~e] (occurrences of one key inside one 2048-key tile are listed there by
+                            // the probe kernel; the partition kernel only stores the references, nobody copies the lists)
 };
+
+// source id of a CSR entry value (see BwdArgs::tile_bags); the reference form costs one more dependent load
+__device__ __forceinline__ int entry_src(const BwdArgs& a, int sv) {
+  if (a.tile_bags && sv < 0) sv = a.tile_bags[~sv];
+  return sv;
+}
 
 #ifndef PIPE_NB
 #define PIPE_NB 2
@@ -134,7 +143,7 @@ __device__ __forceinline__ void reduce_multi(const BwdArgs& a, const int (&lo)[N
         p = p < hi[b] ? p : hi[b] - 1;
         p = p < lo[b] ? lo[b] : p;
         p = p < a.n_entries ? p : a.n_entries - 1;
-        src[b][q] = a.csr_src[p];
+        src[b][q] = entry_src(a, a.csr_src[p]);
       }
     uintptr_t base[NB][RPR]; int Df[NB][RPR]; float sc[NB][RPR];
 #pragma unroll
@@ -204,7 +213,11 @@ __device__ __forceinline__ void reduce_chunk(const BwdArgs& a, int slo, int shi,
     int e = slo + j0 + c;
     const bool mine = e < shi;
     e = e < a.n_entries ? e : a.n_entries - 1;
-    const int sv = a.csr_src[e < 0 ? 0 : e];
+    int sv = a.csr_src[e < 0 ? 0 : e];
+    if (a.tile_bags) {   // (wave uniform) references are the rule in hot rows: the second load is unconditional
+      const int t = a.tile_bags[sv < 0 ? ~sv : 0];
+      sv = sv < 0 ? t : sv;
+    }
     int myDf = a.D;
     float mysc = 1.f;
     int64_t off;
@@ -444,6 +457,19 @@ __device__ __forceinline__ void rows_pipelined(const BwdArgs& a, const OptArgs& 
     if (ubase + (int64_t)it * NB >= nu) break;
     stageS(nxt);       // CSR entries of group it+1 (its ptr / row_addr arrived with the previous wait)
     stageP(it + 2);    // ptr / row_addr of group it+2
+    if (a.tile_bags) {   // reference entries (two occurrences of a cold key in one tile: ~1 % of these rows): a rare dependent hop
+      bool neg = false;
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int q = 0; q < RPR; ++q) neg |= cur.src[b][q] < 0;
+      if (__ballot(neg)) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int q = 0; q < RPR; ++q) cur.src[b][q] = entry_src(a, cur.src[b][q]);
+      }
+    }
     float wrow[NB][NCOL][4], acc[NB][NCOL][4];
 #pragma unroll
     for (int b = 0; b < NB; ++b)
@@ -467,6 +493,19 @@ __device__ __forceinline__ void rows_pipelined(const BwdArgs& a, const OptArgs& 
       for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int q = 0; q < RPR; ++q) src[b][q] = entry(cur.lo[b], cur.cnt[b], r + q);
+      if (a.tile_bags) {
+        bool neg = false;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int q = 0; q < RPR; ++q) neg |= src[b][q] < 0;
+        if (__ballot(neg)) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < RPR; ++q) src[b][q] = entry_src(a, src[b][q]);
+        }
+      }
       grads_round(cur, src, r, acc);
     }
     if constexpr (!kSgd) {
@@ -552,7 +591,7 @@ __global__ void __launch_bounds__(256) bwd_kernel(BwdArgs a, OptArgs o, int lpr_
       __syncthreads();
       if (wv == 0) {
         int Drow = a.D;
-        if (a.D_offsets && a.combiner >= 0) { const int f = a.csr_src[lo] / a.B; Drow = a.D_offsets[f + 1] - a.D_offsets[f]; }
+        if (a.D_offsets && a.combiner >= 0) { const int f = entry_src(a, a.csr_src[lo]) / a.B; Drow = a.D_offsets[f + 1] - a.D_offsets[f]; }
         float gg[NCOL][4];
 #pragma unroll
         for (int k = 0; k < NCOL; ++k)
@@ -626,7 +665,7 @@ __global__ void __launch_bounds__(256) bwd_kernel(BwdArgs a, OptArgs o, int lpr_
 #pragma unroll
           for (int w = 0; w < W; ++w) g[k][w] += __shfl_xor(g[k][w], off, 64);
       int Drow = a.D;
-      if (a.D_offsets && a.combiner >= 0) { const int f = a.csr_src[lo] / a.B; Drow = a.D_offsets[f + 1] - a.D_offsets[f]; }
+      if (a.D_offsets && a.combiner >= 0) { const int f = entry_src(a, a.csr_src[lo]) / a.B; Drow = a.D_offsets[f + 1] - a.D_offsets[f]; }
       void* row = o.kind == kOptStore ? nullptr : reinterpret_cast<void*>(a.row_addr[u]);
       apply_sink<WDT, GDT, NCOL, kVec>(o, u, row, Drow, lpr_log2, a.round_grad != 0, g, sub == 0);
     }
@@ -675,7 +714,7 @@ __global__ void __launch_bounds__(256) bwd_kernel(BwdArgs a, OptArgs o, int lpr_
     for (int b = 0; b < NB; ++b) {
       int Drow = a.D;
       if (work[b] && a.D_offsets && a.combiner >= 0 && o.kind != kOptStore) {
-        const int f = a.csr_src[lo[b]] / a.B;
+        const int f = entry_src(a, a.csr_src[lo[b]]) / a.B;
         Drow = a.D_offsets[f + 1] - a.D_offsets[f];
       }
       // rows without occurrences: the reference's reduce_grads leaves them unwritten; store zeros
@@ -794,6 +833,20 @@ int mi355_backward_fused(const int32_t* ptr, const int32_t* csr_src, int64_t num
                          float eps, float weight_decay, int64_t iter_num, int64_t state_offset, int round_grad,
                          void* out, int64_t out_stride, int aligned16, void* workspace, int64_t workspace_bytes,
                          hipStream_t stream) {
+  return mi355i_backward_fused(ptr, csr_src, num_keys, max_unique, nu_dev, grads, grad_stride, grad_dtype, offsets, D_offsets,
+                               batch_size, dim, combiner, row_addr, weight_dtype, opt_kind, lr, beta1, beta2, eps, weight_decay,
+                               iter_num, state_offset, round_grad, out, out_stride, aligned16, workspace, workspace_bytes,
+                               nullptr, stream);
+}
+
+// the same with the tile lists CSR reference entries point into (internal.h; only the fused forward produces references)
+int mi355i_backward_fused(const int32_t* ptr, const int32_t* csr_src, int64_t num_keys, int64_t max_unique,
+                          const int64_t* nu_dev, const void* grads, int64_t grad_stride, int grad_dtype,
+                          const int64_t* offsets, const int32_t* D_offsets, int64_t batch_size, int64_t dim, int combiner,
+                          const int64_t* row_addr, int weight_dtype, int opt_kind, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, int64_t iter_num, int64_t state_offset, int round_grad,
+                          void* out, int64_t out_stride, int aligned16, void* workspace, int64_t workspace_bytes,
+                          const int32_t* tile_bags, hipStream_t stream) {
   MI355_CHECK_ARG(opt_kind >= 0 && opt_kind <= 4, "bad optimizer kind");
   MI355_CHECK_ARG(opt_kind != kOptStore || out, "out required for opt_kind 0");
   MI355_CHECK_ARG(opt_kind == kOptStore || row_addr, "row_addr required for optimizer kinds");
@@ -803,7 +856,7 @@ int mi355_backward_fused(const int32_t* ptr, const int32_t* csr_src, int64_t num
   BwdArgs a{};
   a.ptr = ptr; a.csr_src = csr_src; a.grads = grads; a.grad_stride = grad_stride; a.offsets = offsets; a.D_offsets = D_offsets;
   a.B = (int)batch_size; a.D = (int)dim; a.combiner = combiner; a.row_addr = row_addr; a.max_unique = max_unique;
-  a.nu_dev = nu_dev; a.round_grad = round_grad; a.n_entries = (int)num_keys;
+  a.nu_dev = nu_dev; a.round_grad = round_grad; a.n_entries = (int)num_keys; a.tile_bags = tile_bags;
   if (workspace) {  // the hot-row task list filled by mi355_group_by_unique(..., hot_workspace = workspace, dim)
     MI355_CHECK_ARG(workspace_bytes >= hot_bytes(num_keys, dim), "workspace too small");
     a.hot = hot_carve(workspace, num_keys, dim);

@@ -35,6 +35,7 @@
 #include "init_dev.h"
 #include "roctx.h"
 #include "stamps.h"
+#include "gather_dev.h"
 #include <pthread.h>
 #include <stdlib.h>
 
@@ -42,6 +43,7 @@ namespace mi355 {
 
 STAMP_ARRAY(g_st_probe, 1024, 12)
 STAMP_ARRAY(g_st_part, 1024, 10)
+STAMP_ARRAY(g_st_fgather, 16384, 2)
 #define PST(ph) STAMP(g_st_probe, 1024, 12, ph)
 #define QST(ph) STAMP(g_st_part, 1024, 10, ph)
 
@@ -97,6 +99,11 @@ struct FusedArgs {
                                   // record whose row address was resolved late}
   unsigned long long* tstat;      // [ceil(n/1024)] look-back words of the merged numbering kernel (zeroed by the probe)
   int* hot_counters;              // hot-list header of the backward (cleared by the probe; nullable)
+  // round 3, path (c): the probe kernel also lists, per tile, the bag ids of the keys that occur more than once in the tile
+  // (grouped by key), so that the partition kernel can write the backward's CSR itself -- no scatter kernel
+  int32_t* tile_bags;             // [n] tile t owns [t * TILE, ...): bag ids of its multi-occurrence keys, key after key
+  int32_t* occ_trank;             // [n] rank of every occurrence among its key's occurrences in the tile (lazy reverse indices)
+  int4* rec_out4;                 // [P * kPartCap] out of path (c): {unique id (~id: row resolved late), rank base, CSR position, 0}
 };
 
 __device__ __forceinline__ void store_digest(uint8_t* p, uint8_t d) {
@@ -213,8 +220,15 @@ __device__ __forceinline__ void wave_init_row(const FusedArgs& a, void* rp, uint
 // floor((h mod n C) / C) = floor(h / C) mod n; h / C is a shift, and x mod n = x - mulhi64(x, M) n with M = floor((2^64 - 1) / n)
 // leaves a quotient that is at most one short: two conditional subtractions make it exact.  M is formed once per table and
 // block (s_magic).  The partition of a slot, slot / spp with spp a multiple of C, is bucket / (spp / C): 32-bit.
-template <int TILE, int THREADS, bool kTrain, bool kPart = false, bool kFast = false>
+// kBags (path (c) of round 3, with kPart): the tile also resolves the BAG of every occurrence (64-ary search of the tile's ends in
+// the offsets, bag starts marked in LDS, max-scan) and groups the bag ids of the keys that occur more than once in the tile --
+// key after key, an exclusive scan over the representatives' counts gives the starts -- into tile_bags; a record carries
+// {position of the representative, bag id | start of the key's list, slot code, occurrences}.
+template <int TILE, int THREADS, bool kTrain, bool kPart = false, bool kFast = false, bool kBags = false>
 __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
+  __shared__ int s_bag[kBags ? TILE : 1];          // bag of every occurrence of the tile
+  __shared__ uint16_t s_sm[kBags ? 2 * TILE : 1];  // per dedup entry: start of the key's list in the tile | multi flag << 15
+  __shared__ int s_brange[2], s_wmax[THREADS / 64], s_wsum[THREADS / 64];
   __shared__ int s_hist[kPart ? kPartMax : 1];    // kPart: records of this tile per partition, then their base in the partition
   __shared__ uint64_t s_magic[kFast ? kFusedMaxT : 1];
   PST(0);
@@ -256,6 +270,27 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   if (blockIdx.x == 0 && kTrain) {
     if (a.hot_counters && threadIdx.x < 3) a.hot_counters[2 * threadIdx.x] = 0;   // n_hot, n_tasks, n_wave
   }
+  if constexpr (kBags) {
+    for (int k = threadIdx.x; k < TILE; k += THREADS) s_bag[k] = -1;
+    if (threadIdx.x < 128) {   // waves 0 / 1: bags of the tile's first / last occurrence (first idx with offsets[idx] > key, minus 1)
+      const int64_t tile_end = tile0 + TILE < a.n ? tile0 + TILE : a.n;
+      const int64_t key = threadIdx.x < 64 ? tile0 : tile_end - 1;
+      int lo = 0, hi = (int)a.num_bags;
+      while (hi > lo) {
+        const int step = (hi - lo + 63) >> 6;
+        const int64_t pi = (int64_t)lo + (int64_t)(lane_id() + 1) * step - 1;
+        const bool gt = pi >= hi ? true : a.offsets[pi] > key;
+        const uint64_t gm = __ballot(gt);
+        if (!gm) { lo = hi; break; }
+        const int first = __ffsll((unsigned long long)gm) - 1;
+        const int nlo = first ? lo + first * step : lo;
+        const int64_t nhi = (int64_t)lo + (int64_t)(first + 1) * step - 1;
+        lo = nlo;
+        hi = nhi < hi ? (int)nhi : hi;
+      }
+      if (lane_id() == 0) s_brange[threadIdx.x < 64 ? 0 : 1] = lo - 1;
+    }
+  }
   if (kTrain && a.tstat && threadIdx.x < HALVES) {
     const int64_t pt = (int64_t)blockIdx.x * HALVES + threadIdx.x;
     if (pt * 1024 < a.n) { a.tstat[pt] = 0ull; if (kPart) a.tstat[a.P + pt] = 0ull; }
@@ -265,6 +300,15 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   if constexpr (kPart) for (int p = threadIdx.x; p < a.P; p += THREADS) s_hist[p] = 0;
   __syncthreads();
   PST(1);
+  // kBags: the offsets of "my" bag of the tile's range are fetched now and used behind the next barrier
+  int mb = 0;
+  int64_t mo0 = 0, mo1 = 0;
+  if constexpr (kBags) {
+    mb = s_brange[0] + (int)threadIdx.x;
+    const int bc = mb <= s_brange[1] ? mb : s_brange[1];
+    mo0 = a.offsets[bc < 0 ? 0 : bc];
+    mo1 = a.offsets[(bc < 0 ? 0 : bc) + 1];
+  }
   int hh[PER], rk[PER];
   int64_t bq[PER], hq[PER];      // bucket and hash of my keys (bucket -1: key without a home)
   uint4 dvq[PER];                // first digest vector of the probe
@@ -308,6 +352,14 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   PST(2);
   __syncthreads();
   PST(3);
+  if constexpr (kBags) {
+    const int bhi = s_brange[1];
+    if (mb >= 0 && mb <= bhi && mo1 > mo0) { const int64_t pp = mo0 > tile0 ? mo0 - tile0 : 0; if (pp < TILE) s_bag[pp] = mb; }
+    for (int b = mb + THREADS; b <= bhi; b += THREADS) {      // (more bags than threads in the tile's range: empty / one-key bags)
+      const int64_t o0 = a.offsets[b], o1 = a.offsets[b + 1];
+      if (o1 > o0) { const int64_t pp = o0 > tile0 ? o0 - tile0 : 0; if (pp < TILE) s_bag[pp] = b; }
+    }
+  }
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
     const int li = q * THREADS + threadIdx.x;
@@ -333,6 +385,23 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   bool isrep[PER];
 #pragma unroll
   for (int q = 0; q < PER; ++q) isrep[q] = hh[q] >= 0 && s_tab[hh[q]] == q * THREADS + (int)threadIdx.x;
+  // kBags, first half of two block scans (their second halves sit behind the next barrier): running maximum of the bag marks
+  // (thread t owns the occurrences t * PER ..), and the list starts of the keys that occur more than once
+  int bagv[PER], bag_incl = -1, mcnt[PER], m_incl = 0, m_mine = 0;
+  if constexpr (kBags) {
+    int m = -1;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { const int v = s_bag[threadIdx.x * PER + k]; m = v > m ? v : m; bagv[k] = m; }
+    bag_incl = m;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(bag_incl, off, 64); if (lane_id() >= off) bag_incl = o > bag_incl ? o : bag_incl; }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { const int c = isrep[q] ? s_cnt[hh[q]] : 0; mcnt[q] = c > 1 ? c : 0; m_mine += mcnt[q]; }
+    m_incl = m_mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(m_incl, off, 64); if (lane_id() >= off) m_incl += o; }
+    if (lane_id() == 63) { s_wmax[threadIdx.x >> 6] = bag_incl; s_wsum[threadIdx.x >> 6] = m_incl; }
+  }
   // kPart: the partition of a pair follows from its BUCKET (keys without a home: the last partition), which is known
   // before the probe -- so the tile's histogram and the one global atomic per (tile, partition) go out here and their
   // round trip runs under the probe; the bases are read when the records are written.
@@ -351,6 +420,22 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     if ((int)threadIdx.x < a.P) {     // (P <= kPartMax = THREADS)
       const int c = s_hist[threadIdx.x];
       if (c) my_base = atomicAdd(&a.pcount[threadIdx.x * kPartSub + (int)blockIdx.x % kPartSub], c);
+    }
+    if constexpr (kBags) {
+      const int w = threadIdx.x >> 6;
+      int bbase = -1, sbase = 0;
+      for (int k = 0; k < w; ++k) { bbase = s_wmax[k] > bbase ? s_wmax[k] : bbase; sbase += s_wsum[k]; }
+      int prev = __shfl_up(bag_incl, 1, 64);
+      if (lane_id() == 0) prev = -1;
+      prev = prev > bbase ? prev : bbase;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) s_bag[threadIdx.x * PER + k] = bagv[k] > prev ? bagv[k] : prev;
+      int st = sbase + m_incl - m_mine;
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        if (isrep[q]) s_sm[hh[q]] = (uint16_t)(mcnt[q] ? (st | 0x8000) : 0);
+        st += mcnt[q];
+      }
     }
   }
   // first candidate of the prefetched vector: its key word is loaded by every lane (clamped address), so that the loads
@@ -440,6 +525,12 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
       int ref = -1;
       if (idx < kSubCap) {
         ref = pk * kPartCap + sub * kSubCap + idx;
+        if constexpr (kBags) {
+          const int li = q * THREADS + threadIdx.x;
+          const int sm = s_sm[hh[q]];
+          a.rec[ref] = make_uint4((uint32_t)(tile0 + li), (uint32_t)((sm & 0x8000) ? (int)tile0 + (sm & 0x7fff) : s_bag[li]),
+                                  (uint32_t)s_cnt[hh[q]], (uint32_t)cnt_tile[q]);
+        } else
         a.rec[ref] = make_uint4((uint32_t)kreg[q], (uint32_t)(kreg[q] >> 32), (uint32_t)s_cnt[hh[q]], (uint32_t)cnt_tile[q]);
       } else {
         a.hdr[5] = 1;     // a partition received more records than it can hold: the step is flagged (see the module)
@@ -461,6 +552,14 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
       if constexpr (kPart) {
         const int g = s_cnt[hh[q]];           // slot code of the key's record
         a.occ_slot[i] = s_tab[hh[q]];         // the record
+        if constexpr (kBags) {
+          a.occ_trank[i] = rk[q];
+          const int sm = s_sm[hh[q]];
+          if (sm & 0x8000) a.tile_bags[tile0 + (sm & 0x7fff) + rk[q]] = s_bag[li];
+          // address word 1: the row comes out of the partition kernel's eviction (gather_dev.h: LateRefs)
+          a.occ_addr[i] = (g >= 0 && g < a.S) ? s_tptr[t] + ((int64_t)g - s_tbo[t] * a.t.C) * s_rowb[t] : (g <= -2 ? 1 : 0);
+          continue;
+        }
         a.csr_rank[i] = rk[q];                // rank inside the tile (completed by the scatter kernel)
         a.occ_addr[i] = (g >= 0 && g < a.S) ? s_tptr[t] + ((int64_t)g - s_tbo[t] * a.t.C) * s_rowb[t] : 0;
         continue;
@@ -1273,6 +1372,470 @@ fused_part_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, bo
   QST(9);
 }
 
+// ---- round 3, path (c): the partition kernel ALSO writes the backward's CSR -- no scatter kernel ---------------------------------
+// Measured in round 2 / 3 (phase stamps, tools/index_phase_stamps.py): every kernel of the chain costs 4-8 us beyond the life of
+// its blocks (dispatch ramp, tail, end-of-kernel write-back), and the scatter kernel existed only because the CSR positions come
+// out of the partition kernel.  Here the probe kernel leaves the bag id in every record (key seen once in its tile) or a pointer
+// to the key's bag list of the tile (tile_bags), so the partition block writes the CSR entries itself: the bag id, or REFERENCES
+// ~(list index) that the backward follows (backward.hip: entry_src) -- nobody copies the lists, the hot partition stores 20 K
+// words and is done.  The per-occurrence outputs nothing on the training path reads (reverse indices, full ranks) come out of
+// the records on demand (mi355_demb_fused_materialize).
+//  * 1024 threads per partition (two records, two hash entries per thread): the block is a chain of short phases, and its
+//    life is what the launch costs;
+//  * a 2048-entry LDS hash whose entry ORDER is the unique order: ONE block scan over the entries yields the local unique ids,
+//    the CSR prefix and the hot-list positions (no per-unique counters, no second id array);
+//  * keys whose bucket was full are evicted for right here (every record of a bucket is in this block); their occurrences
+//    carry the address word 1 and the gather finds the row through the record (gather_dev.h: LateRefs).
+//  (Measured and rejected in round 3: the partition blocks riding in the gather's launch.  The gather's throughput is
+//   proportional to its resident waves -- 4.6 us per bag and lane group whatever the occupancy -- and the partition code's 79
+//   registers / 24 KB of LDS take a quarter of them: 54-60 us for the fused launch against 21 + 30 us apart.)
+constexpr int kP2Hash = kPartCap;      // a partition holds at most kPartCap records, hence at most as many distinct slots
+constexpr int kP3Threads = 1024;
+constexpr int kP3Items = kPartCap / kP3Threads;
+constexpr int kP3Ent = kP2Hash / kP3Threads;
+constexpr int kRecLate = 1 << 30;      // count word of a record whose key took the eviction path
+
+__device__ __forceinline__ int p2_hash(int slot) { return (int)((uint32_t)slot * 2654435761u >> 21) & (kP2Hash - 1); }
+__device__ __forceinline__ int p2_find(const int* h_slot, int slot) {   // -1: not present
+  int h = p2_hash(slot);
+  for (int n = 0; n < kP2Hash; ++n) {
+    const int cur = h_slot[h];
+    if (cur == slot) return h;
+    if (cur == -1) return -1;
+    h = (h + 1) & (kP2Hash - 1);
+  }
+  return -1;
+}
+__device__ __forceinline__ int p2_insert(int* h_slot, int slot, bool* claimed) {
+  int h = p2_hash(slot);
+  *claimed = false;
+  while (true) {
+    const int cur = atomicCAS(&h_slot[h], -1, slot);
+    if (cur == -1) { *claimed = true; return h; }
+    if (cur == slot) return h;
+    h = (h + 1) & (kP2Hash - 1);
+  }
+}
+
+// exclusive scan of five ints per thread across a THREADS-thread block; totals in `tot`.  Two levels: every wave scans its own
+// values, ONE wave scans the wave totals (a thread reading all 16 totals of five values itself was 80 LDS reads per thread).
+template <int THREADS>
+__device__ __forceinline__ void block_scan5(int (&v)[5], int (&tot)[5]) {
+  constexpr int NW = THREADS / 64;
+  __shared__ int s_w5[5][NW + 1];      // [i][w]: exclusive base of wave w; [i][NW]: total
+  const int w = threadIdx.x >> 6;
+  int incl[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) incl[i] = wave_incl_scan(v[i]);
+  if (lane_id() == 63) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) s_w5[i][w] = incl[i];
+  }
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int x = lane_id() < NW ? s_w5[i][lane_id()] : 0;
+      const int in2 = wave_incl_scan(x);
+      if (lane_id() < NW) s_w5[i][lane_id()] = in2 - x;
+      if (lane_id() == NW - 1) s_w5[i][NW] = in2;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    tot[i] = s_w5[i][NW];
+    v[i] = s_w5[i][w] + incl[i] - v[i];
+  }
+  __syncthreads();
+}
+
+// sums of two packed words over ALL predecessors of partition t (t < kPartMax = 1024 threads: one word pair per thread)
+__device__ __forceinline__ void lookback_sum2_1024(const unsigned long long* ta, const unsigned long long* tb, int t,
+                                                   unsigned long long& pre_a, unsigned long long& pre_b) {
+  __shared__ unsigned long long s_sa, s_sb;
+  if (threadIdx.x == 0) { s_sa = 0; s_sb = 0; }
+  __syncthreads();
+  const int idx = t - 1 - (int)threadIdx.x;
+  unsigned long long va = idx >= 0 ? stat_load(ta + idx) : kStatAgg, vb = idx >= 0 ? stat_load(tb + idx) : kStatAgg;
+  while ((va & kStatMask) == 0) { __builtin_amdgcn_s_sleep(1); va = stat_load(ta + idx); }
+  while ((vb & kStatMask) == 0) { __builtin_amdgcn_s_sleep(1); vb = stat_load(tb + idx); }
+  unsigned long long xa = va & ~kStatMask, xb = vb & ~kStatMask;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    uint32_t lo = __shfl_xor((int)(uint32_t)xa, off, 64), hi = __shfl_xor((int)(uint32_t)(xa >> 32), off, 64);
+    xa += ((unsigned long long)hi << 32) | lo;
+    lo = __shfl_xor((int)(uint32_t)xb, off, 64); hi = __shfl_xor((int)(uint32_t)(xb >> 32), off, 64);
+    xb += ((unsigned long long)hi << 32) | lo;
+  }
+  if (lane_id() == 0) { if (xa) atomicAdd(&s_sa, xa); if (xb) atomicAdd(&s_sb, xb); }
+  __syncthreads();
+  pre_a = s_sa; pre_b = s_sb;
+}
+
+__global__ void __launch_bounds__(kP3Threads)
+fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restrict__ csr_src, HotList hot) {
+  __shared__ int h_slot[kP2Hash];         // slot of the entry (-1: free)
+  __shared__ int h_cnt[kP2Hash];          // occurrences of the slot
+  __shared__ int h_pl[kP2Hash];           // (local unique id << 21) | occurrences in front of the entry's row (partition-local)
+  __shared__ short d_rec[kPartCap];       // deferred records (bucket full)
+  __shared__ int d_ent[kPartCap / 4], d_base[kPartCap / 4];   // their hash entry / rank base once resolved (first 512 per step)
+  __shared__ int s_lock[256];             // bucket locks of the eviction (hashed)
+  __shared__ unsigned s_late[kP2Hash / 32];
+  __shared__ int s_nd, s_nbig;
+  constexpr int kBigMax = 512;            // records with more than 8 occurrences (reference lists expanded wave by wave)
+  __shared__ int b_pos[kBigMax], b_ref[kBigMax], b_cnt[kBigMax];
+  QST(0);
+  constexpr int kDefMax = kPartCap / 4;
+  const int p = blockIdx.x;
+  int msub[kPartSub];
+#pragma unroll
+  for (int r = 0; r < kPartSub; ++r) msub[r] = a.pcount[p * kPartSub + r];
+  uint4 rc[kP3Items];
+#pragma unroll
+  for (int k = 0; k < kP3Items; ++k) rc[k] = a.rec[(int64_t)p * kPartCap + threadIdx.x + k * kP3Threads];
+  // (rows of the single table of this path: three scalars every output needs, fetched with the records)
+  const int64_t tp0 = a.table_ptrs[0], rowb = a.table_value_dims[0] * a.elem_bytes, s0 = a.tbo[0] * a.t.C;
+  for (int i = threadIdx.x; i < kP2Hash; i += kP3Threads) { h_slot[i] = -1; h_cnt[i] = 0; }
+  if (threadIdx.x < 256) s_lock[threadIdx.x] = 0;
+  if (threadIdx.x < kP2Hash / 32) s_late[threadIdx.x] = 0;
+  if (threadIdx.x == 0) { s_nd = 0; s_nbig = 0; }
+  QST(1);
+  __syncthreads();
+  QST(2);
+  if (threadIdx.x < kPartSub) a.pcount[p * kPartSub + threadIdx.x] = 0;       // clean for the next step
+  // ---- merge the records of a slot; the record that creates the entry owns the unique row's key
+  int en[kP3Items], bs[kP3Items], dj[kP3Items];
+  bool live[kP3Items], mine[kP3Items];
+#pragma unroll
+  for (int k = 0; k < kP3Items; ++k) {
+    const int idx = threadIdx.x + k * kP3Threads;
+    const int ms = msub[idx / kSubCap];
+    live[k] = (idx % kSubCap) < (ms < kSubCap ? ms : kSubCap);
+    en[k] = -1; bs[k] = 0; dj[k] = -1; mine[k] = false;
+    if (!live[k]) continue;
+    const int sl = (int)rc[k].z, cn = (int)rc[k].w;
+    if (sl >= 0) {
+      bool cl;
+      en[k] = p2_insert(h_slot, sl, &cl);
+      mine[k] = cl;
+      bs[k] = atomicAdd(&h_cnt[en[k]], cn);
+    } else {
+      dj[k] = atomicAdd(&s_nd, 1);
+      if (dj[k] < kDefMax) {
+        d_rec[dj[k]] = (short)idx;
+      } else {                           // beyond what one step evicts for: no slot this step (like an insert that returns Busy)
+        dj[k] = -2;
+        bool cl;
+        en[k] = p2_insert(h_slot, (int)a.S, &cl);
+        mine[k] = cl;
+        bs[k] = atomicAdd(&h_cnt[en[k]], cn);
+      }
+    }
+  }
+  // the key of a record that created an entry is the unique key of its row (fetched now, stored with the outputs)
+  uint64_t ky[kP3Items];
+#pragma unroll
+  for (int k = 0; k < kP3Items; ++k) {
+    int64_t pc = live[k] ? (int64_t)rc[k].x : 0;
+    pc = pc < a.n ? pc : a.n - 1;
+    ky[k] = a.keys[pc];
+  }
+  QST(3);
+  __syncthreads();
+  QST(4);
+  // ---- deferred keys: the bucket had no free slot.  Evict the minimum score among the slots this batch does not use (the
+  //      hash above knows them all: every record of the bucket is in this block) and that nobody pinned (kernels.cuh:226-287,
+  //      types.cuh:398-512); 8 lanes per key, a hashed LDS lock per bucket.  The slot goes back into the record: the gather
+  //      finds the rows of the key's occurrences there.
+#ifdef P3_NO_EVICT
+  const int nd = 0;
+#else
+  const int nd = s_nd < kDefMax ? s_nd : kDefMax;
+#endif
+  if (nd > 0) {
+    if (!a.timer) a.timer = device_clock();
+    const int g = lane_id() & (G - 1);
+    const int gpb = kP3Threads / G;
+    const int C = (int)a.t.C;
+    for (int e0 = 0; e0 < nd; e0 += gpb) {
+      const int e = e0 + (int)threadIdx.x / G;
+      const bool act = e < nd;
+      const int64_t r = (int64_t)p * kPartCap + (act ? (int)d_rec[e] : 0);
+      const uint4 rd = a.rec[r];
+      int64_t kp = (int64_t)rd.x; kp = kp < a.n ? kp : a.n - 1;
+      const uint64_t key = a.keys[kp];
+      const int cnt = (int)rd.w;
+      const int64_t bucket = act ? -(int64_t)(int)rd.z - 2 : 0;
+      const int64_t hash = (int64_t)(fmix64(key) & 0x7FFFFFFFFFFFFFFFull);
+      bool done = !act;
+      int guard = 0;
+      while (__ballot(!done)) {
+        if (!done) {
+          int got = 0;
+          if (g == 0) got = atomicCAS(&s_lock[bucket & 255], 0, 1) == 0 ? 1 : 0;
+          got = group_bcast(got, 0);
+          if (got) {
+            uint64_t* ks = a.t.keys(bucket);
+            int found_slot, empty_slot;
+            group_probe(a.t, bucket, key, hash, true, true, found_slot, empty_slot);
+            int slot = -1;
+            bool fresh_row = false;
+            if (found_slot >= 0) {             // another record of the same key got here first
+              slot = found_slot;
+              if (g == 0) score_found(a, a.t.scores(bucket) + (int64_t)slot * a.t.ns, cnt);
+            } else if (empty_slot >= 0) {      // a slot was freed meanwhile
+              slot = empty_slot;
+              fresh_row = true;
+              if (g == 0) {
+                store_digest(a.t.dig(bucket) + slot, digest_of(hash));
+                score_new(a, a.t.scores(bucket) + (int64_t)slot * a.t.ns, cnt);
+                atomicAdd(&a.bucket_sizes[bucket], 1);
+              }
+            } else {
+              uint64_t best = ~0ull, bkey = 0;
+              int bslot = -1;
+              const uint64_t* sc = a.t.scores(bucket);
+              const int32_t* pin = a.counter ? a.counter + bucket * a.t.C : nullptr;
+              for (int s1 = 2 * g; s1 < C; s1 += 2 * G) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                  const int s2 = s1 + u;
+                  const uint64_t v = ald64(sc + (int64_t)s2 * a.t.ns + (a.t.ns - 1));
+                  if (v < best) {
+                    const uint64_t k2 = ald64(ks + s2);
+                    if (k2 == kLockedKey || k2 == kEmptyKey) continue;
+                    if (pin && __hip_atomic_load(pin + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;
+                    if (p2_find(h_slot, (int)(bucket * a.t.C + s2)) >= 0) continue;   // used by this batch
+                    best = v; bslot = s2; bkey = k2;
+                  }
+                }
+              }
+              group_argmin(best, bslot, bkey);
+              if (bslot >= 0) {
+                slot = bslot;
+                fresh_row = true;
+                if (g == 0) {
+                  ast64(ks + slot, kLockedKey);
+                  store_digest(a.t.dig(bucket) + slot, digest_of(hash));
+                  for (int64_t w = 0; w < a.t.ns; ++w) ast64((uint64_t*)sc + (int64_t)slot * a.t.ns + w, 0);
+                  score_new(a, a.t.scores(bucket) + (int64_t)slot * a.t.ns, cnt);
+                  if (bkey == kReclaimKey) atomicAdd(&a.bucket_sizes[bucket], 1);
+                }
+              }
+            }
+            int gslot = (int)a.S;             // no slot could be had: the key is served without a row this step
+            if (slot >= 0) {
+              gslot = (int)(bucket * a.t.C + slot);
+              if (fresh_row) {
+                void* rp = reinterpret_cast<void*>((uintptr_t)(tp0 + ((int64_t)gslot - s0) * rowb));
+                const int ed = (int)a.table_emb_dims[0], vd = (int)a.table_value_dims[0];
+                for (int el = g; el < vd; el += G) {
+                  const float v = el < ed ? init_value(a.init, key, (uint32_t)el) : a.init.state_init;
+                  if (a.value_dtype == kF32) st1<kF32>(rp, el, v);
+                  else if (a.value_dtype == kBF16) st1<kBF16>(rp, el, v);
+                  else st1<kF16>(rp, el, v);
+                }
+                if (g == 0) {
+                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                  ast64(ks + slot, key);
+                }
+              }
+            }
+            if (g == 0) {
+              // the slot enters the hash BEFORE the lock is released: that is what protects it from the next eviction
+              bool cl;
+              const int ent = p2_insert(h_slot, gslot, &cl);
+              if (cl) atomicOr(&s_late[ent >> 5], 1u << (ent & 31));
+              d_ent[e] = ent; d_base[e] = atomicAdd(&h_cnt[ent], cnt);
+              a.rec[r].z = (uint32_t)gslot;
+              a.rec[r].w = (uint32_t)(cnt | kRecLate);
+              __threadfence_block();
+              atomicExch(&s_lock[bucket & 255], 0);
+            }
+            done = true;
+          } else if (++guard > (1 << 22)) {
+            if (g == 0) {
+              bool cl;
+              const int ent = p2_insert(h_slot, (int)a.S, &cl);
+              if (cl) atomicOr(&s_late[ent >> 5], 1u << (ent & 31));
+              d_ent[e] = ent; d_base[e] = atomicAdd(&h_cnt[ent], cnt);
+              a.rec[r].z = (uint32_t)a.S;
+              a.rec[r].w = (uint32_t)(cnt | kRecLate);
+            }
+            done = true;
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kP3Items; ++k)
+      if (dj[k] >= 0) {
+        en[k] = d_ent[dj[k]]; bs[k] = d_base[dj[k]];
+        // the first record (rank base 0) of an entry created by the eviction owns the unique row's key
+        if (((s_late[en[k] >> 5] >> (en[k] & 31)) & 1u) && bs[k] == 0) mine[k] = true;
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < kP3Items; ++k)
+    if (dj[k] == -2) {   // beyond the eviction budget: the record says "no slot"
+      const int64_t r = (int64_t)p * kPartCap + threadIdx.x + k * kP3Threads;
+      a.rec[r].z = (uint32_t)a.S;
+      a.rec[r].w = (uint32_t)((int)rc[k].w | kRecLate);
+    }
+  __syncthreads();
+  // ---- one scan over the hash ENTRIES: local unique id, occurrence prefix, hot-list positions (entry order = unique order)
+  const bool hots = hot.n_tasks != nullptr;
+  int es[kP3Ent], ec[kP3Ent];
+  int v5[5] = {0, 0, 0, 0, 0}, tot5[5];
+#pragma unroll
+  for (int k = 0; k < kP3Ent; ++k) {
+    const int e = threadIdx.x * kP3Ent + k;
+    es[k] = h_slot[e];
+    ec[k] = es[k] != -1 ? h_cnt[e] : 0;
+    if (es[k] == -1) continue;
+    ++v5[0];
+    v5[1] += ec[k];
+    if (hots && ec[k] > hot.khot && ec[k] <= hot.kwave) ++v5[4];
+    else if (hots && ec[k] > hot.khot) { ++v5[2]; v5[3] += (ec[k] + hot.kchunk - 1) / hot.kchunk; }
+  }
+  block_scan5<kP3Threads>(v5, tot5);
+  const int nu = tot5[0], tot2 = tot5[1], th = tot5[2], tt = tot5[3], tw = tot5[4];
+  unsigned long long* tb = a.tstat + a.P;
+  if (threadIdx.x == 0) {   // the partition's sums go out as early as they are known: the successors' look-back waits for them
+    stat_store(a.tstat + p, kStatAgg | ((unsigned long long)nu << 31) | (unsigned)tot2);
+    stat_store(tb + p, kStatAgg | ((unsigned long long)th << 40) | ((unsigned long long)tt << 20) | (unsigned long long)tw);
+  }
+  {
+    int lid = v5[0], pre = v5[1];
+#pragma unroll
+    for (int k = 0; k < kP3Ent; ++k) {
+      if (es[k] == -1) continue;
+      h_pl[threadIdx.x * kP3Ent + k] = (lid << 21) | pre;
+      ++lid; pre += ec[k];
+    }
+  }
+  QST(5);
+  unsigned long long pre_a = 0, pre_b = 0;
+  lookback_sum2_1024(a.tstat, tb, p, pre_a, pre_b);     // (its barriers also publish h_pl to the block)
+  QST(6);
+  const int upre = (int)(pre_a >> 31), spre = (int)(pre_a & 0x7fffffffull);
+  // ---- outputs per unique row: by the thread that owns the entry (consecutive entries -> consecutive unique ids)
+  {
+    int h_ex = v5[2] + (int)(pre_b >> 40), t_ex = v5[3] + (int)((pre_b >> 20) & 0xfffff), w_ex = v5[4] + (int)(pre_b & 0xfffff);
+    int uid = upre + v5[0], pv = spre + v5[1];
+#pragma unroll
+    for (int k = 0; k < kP3Ent; ++k) {
+      const int gs = es[k];
+      if (gs == -1) continue;
+      const int c = ec[k];
+      o.csr_cnt[uid] = c;
+      if (o.freq) o.freq[uid] = c;
+      o.row_addr[uid] = gs < a.S ? tp0 + ((int64_t)gs - s0) * rowb : 0;
+      if (o.table_ids) o.table_ids[uid] = 0;
+      o.slots[uid] = gs < a.S ? (int64_t)gs - s0 : -1;
+      ptr[uid] = pv;
+      if (hots && c > hot.khot && c <= hot.kwave) {
+        const int w = w_ex++;
+        if (w < hot.max_hot) { hot.wave_u[w] = uid; hot.wave_lo[w] = pv; hot.wave_cnt[w] = c; }
+      } else if (hots && c > hot.khot) {
+        const int nch = (c + hot.kchunk - 1) / hot.kchunk;
+        const int h = h_ex++, t0 = t_ex;
+        t_ex += nch;
+        if (h < hot.max_hot && t0 + nch <= hot.max_tasks) {
+          hot.hot_done[h] = 0;
+          hot.hot_nchunks[h] = nch;
+          hot.hot_u[h] = uid;
+          hot.hot_lo[h] = pv;
+          hot.hot_cnt[h] = c;
+          hot.hot_t0[h] = t0;
+          for (int cc = 0; cc < nch; ++cc) {
+            hot.task_u[t0 + cc] = uid;
+            hot.task_h[t0 + cc] = h;
+            hot.task_lo[t0 + cc] = pv + cc * hot.kchunk;
+            const int hi2 = pv + (cc + 1) * hot.kchunk;
+            hot.task_hi[t0 + cc] = hi2 < pv + c ? hi2 : pv + c;
+          }
+          if (nch > 1)
+            for (int e2 = 0; e2 < hot.dim; ++e2) hot.hot_acc[(int64_t)h * hot.dim + e2] = 0.f;
+        }
+      }
+      ++uid; pv += c;
+    }
+  }
+  QST(7);
+  // ---- outputs per record: unique id / rank base / CSR position (lazy reverse indices), the unique row's key, the CSR entries
+#pragma unroll
+  for (int k = 0; k < kP3Items; ++k) {
+    if (!live[k]) continue;
+    const int idx = threadIdx.x + k * kP3Threads;
+    const int pl = h_pl[en[k]];
+    const int uid = upre + (int)((unsigned)pl >> 21);
+    const int pos = spre + (pl & 0x1fffff) + bs[k];
+    const int cn = (int)rc[k].w, br = (int)rc[k].y;
+    a.rec_out4[(int64_t)p * kPartCap + idx] = make_int4((int)rc[k].z < 0 ? ~uid : uid, bs[k], pos, 0);
+    if (mine[k]) o.unique_keys[uid] = ky[k];
+    if (cn == 1) csr_src[pos] = br;
+    else if (cn <= 8) {
+      for (int j = 0; j < cn; ++j) csr_src[pos + j] = ~(br + j);
+    } else {   // a long list (a hot key's occurrences in one tile): expanded by a whole wave below, not by this thread alone
+      const int q = atomicAdd(&s_nbig, 1);
+      if (q < kBigMax) { b_pos[q] = pos; b_ref[q] = br; b_cnt[q] = cn; }
+      else for (int j = 0; j < cn; ++j) csr_src[pos + j] = ~(br + j);
+    }
+  }
+  __syncthreads();
+  {
+    const int nbig = s_nbig < kBigMax ? s_nbig : kBigMax;
+    for (int q = threadIdx.x >> 6; q < nbig; q += kP3Threads >> 6) {
+      const int pos = b_pos[q], br = b_ref[q], cn = b_cnt[q];
+      for (int j = lane_id(); j < cn; j += 64) csr_src[pos + j] = ~(br + j);
+    }
+  }
+  if (p == (int)a.P - 1 && threadIdx.x == 0) {
+    const int U = upre + nu, O = spre + tot2;
+    if (hots) { *hot.n_hot = (int)(pre_b >> 40) + th; *hot.n_tasks = (int)((pre_b >> 20) & 0xfffff) + tt; *hot.n_wave = (int)(pre_b & 0xfffff) + tw; }
+    o.table_offsets[0] = 0;
+    o.table_offsets[1] = U;
+    *o.total = O;
+    ptr[U] = O;
+  }
+  QST(8);
+  QST(9);
+}
+
+// pooled gather of path (c): per-occurrence addresses with late rows (address word 1 -> the slot in the key's record)
+template <int SDT, int DDT>
+__global__ void __launch_bounds__(256) gather_pooled_late_kernel(PoolArgs g, LateRefs late, int lpr_log2) {
+#if MI355_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 16384) { g_st_fgather[blockIdx.x * 4] = __builtin_amdgcn_s_memtime(); g_st_fgather[blockIdx.x * 4 + 2] = wall_clock64(); }
+#endif
+  const int64_t sg = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (64 >> lpr_log2) + (lane_id() >> lpr_log2);
+  gather_pooled_pipe<SDT, DDT, 3, 4, 4>(g, late, lpr_log2, sg);
+#if MI355_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 16384) { g_st_fgather[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime(); g_st_fgather[blockIdx.x * 4 + 3] = wall_clock64(); }
+#endif
+}
+
+// lazy per-occurrence outputs of path (c): reverse index and full rank of every occurrence from its record, late row addresses
+__global__ void __launch_bounds__(256)
+occ_from_records_kernel(const int32_t* __restrict__ occ_slot, const int32_t* __restrict__ occ_trank, const int4* __restrict__ rec_out4,
+                        const int64_t* __restrict__ row_addr, int64_t n, int64_t* __restrict__ rev, int32_t* __restrict__ rank,
+                        int64_t* __restrict__ occ_addr) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+    const int ref = occ_slot[j];
+    const int4 ro = rec_out4[ref >= 0 ? ref : 0];
+    const bool late = ro.x < 0;
+    const int uid = late ? ~ro.x : ro.x;
+    rev[j] = uid;
+    if (ref >= 0) {
+      rank[j] = occ_trank[j] + ro.y;
+      if (late) occ_addr[j] = row_addr[uid];
+    }
+  }
+}
+
 // exclusive scan of the per-tile representative counts when there are too many tiles for every block to sum its
 // predecessors itself (batches beyond 4 M keys)
 __global__ void __launch_bounds__(kScanThreads) fused_scan_partials_kernel(int* partial, int64_t nb) {
@@ -1297,6 +1860,7 @@ __global__ void __launch_bounds__(kScanThreads) fused_scan_partials_kernel(int* 
 using namespace mi355;
 STAMP_EXPORT(mi355_debug_stamps_probe, g_st_probe)
 STAMP_EXPORT(mi355_debug_stamps_part, g_st_part)
+STAMP_EXPORT(mi355_debug_stamps_fgather, g_st_fgather)
 
 // Side stream on which the forward numbers the uniques and builds the backward's CSR while its own gather runs.
 // One per process; the join events form a small ring, a forward hands its token to the backward of the same batch
@@ -1395,9 +1959,13 @@ static inline int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
 
 // partitions of the partitioned index stage for a batch of n keys (0: the batch takes the per-slot-counter path)
 static inline int part_count(int64_t n, int64_t num_tables) {
-  static const int env = getenv("MI355_FUSED_PART") ? atoi(getenv("MI355_FUSED_PART")) : 1;
+  static const int env = getenv("MI355_FUSED_PART") ? atoi(getenv("MI355_FUSED_PART")) : 2;
   if (!env || num_tables != 1 || n < (64 << 10) || n > (int64_t)kPartMax * 1024) return 0;
-  return (int)((n + 1023) / 1024);
+  int P = (int)((n + 1023) / 1024);
+  // the partition kernel of path (c) is one 1024-thread block per partition and per CU: up to 1.5 K keys per partition (about
+  // 1.1 K records of the 2 K a partition can hold) the batch gets exactly one block per CU instead of a second, thin generation
+  if (env >= 2 && P > 256 && n <= 256 * 1536) P = 256;
+  return P;
 }
 
 // slot-range partitions the fused forward would use for this batch / table (0: the per-slot-counter path)
@@ -1410,7 +1978,7 @@ int64_t mi355_demb_forward_fused_workspace_bytes(int64_t n, int64_t num_tables) 
   const int64_t nt = (n + 1023) / 1024 + 2;
   return al256(8 * (num_tables + 1)) + al256(8 * n) /*unique keys*/ + al256(8 * n) /*occ_addr*/ + al256(4 * n) /*occ_slot*/ +
          al256(4 * nt) + 256 /*total*/ + al256(8 * n) + 4 * al256(4 * n) /*deferred*/ + al256(16 * nt) /*look-back*/ + 256 +
-         (part_count(n, num_tables) ? 24 * (int64_t)part_count(n, num_tables) * kPartCap + 5 * 256 : 0) /*partition records*/;
+         (part_count(n, num_tables) ? 32 * (int64_t)part_count(n, num_tables) * kPartCap + 5 * 256 : 0) /*partition records*/;
 }
 
 // The fused forward (see the header of this file).  Persisted outputs as mi355_demb_forward; in eval mode (train == 0)
@@ -1474,7 +2042,8 @@ int mi355_demb_forward_fused(
   a.tstat = (unsigned long long*)w; w += al256(16 * nt);
   // partitioned index stage: one table, a batch of 64 K .. 1 M keys, at least 8 buckets per partition, training
   a.P = 0; a.spp = 1; a.pcount = aux + 64;
-  a.rec = nullptr; a.rec_out = nullptr;
+  a.rec = nullptr; a.rec_out = nullptr; a.rec_out4 = nullptr;
+  a.tile_bags = nullptr; a.occ_trank = nullptr;
   {
     const int P = train ? part_count(n, num_tables) : 0;
     if (P > 0 && num_buckets >= 8 * (int64_t)P) {
@@ -1483,7 +2052,7 @@ int mi355_demb_forward_fused(
         a.P = P; a.spp = (int)per;
         const int64_t nr = (int64_t)P * kPartCap;
         a.rec = (uint4*)w; w += al256(16 * nr);
-        a.rec_out = (int2*)w; w += al256(8 * nr);
+        a.rec_out = (int2*)w; a.rec_out4 = (int4*)w; w += al256(16 * nr);   // (path (a): 8-byte entries, path (c): 16-byte ones)
       }
     }
   }
@@ -1502,6 +2071,17 @@ int mi355_demb_forward_fused(
     a.hot_counters = (int*)hot_ws;
   }
   if (train) MI355_CHECK_ARG(reverse_indices && unique_offsets && slots && row_addr && csr_cnt && csr_rank, "persisted outputs required in train mode");
+  // ---- path (c): partition blocks write the CSR and ride in the gather's launch (pooled training forward of one-column-group
+  //      rows with short bags; MI355_FUSED_PART=1 keeps round 2's probe / partition / scatter / gather chain)
+  static const int part_env = getenv("MI355_FUSED_PART") ? atoi(getenv("MI355_FUSED_PART")) : 2;
+  int lg = 3;
+  while ((4 << lg) < emb_dim && lg < 6) ++lg;
+  const bool pathc = part && part_env >= 2 && train && combiner >= 0 && hot_ws && bcsr && aligned16 && emb_dim <= (4 << lg) &&
+                     n <= 8 * num_bags && value_dtype <= 1 && out_dtype <= 1 && num_bags < (1ll << 31) - 4096;
+  if (pathc) {
+    a.tile_bags = (int32_t*)((uint8_t*)backward_workspace + al256(4 * (n + 1)) + al256(4 * n));   // head of the grouping workspace
+    a.occ_trank = a.d_tid;   // (the deferred-key arrays belong to path (b))
+  }
   if (n > 0) {
     RoctxRange rr("op:fused_index(segmented_unique+storage_find+storage_insert+initializer)");
     // keys per tile / threads per block: one key per thread keeps every probe chain (digest vector -> key -> slot counter)
@@ -1516,9 +2096,11 @@ int mi355_demb_forward_fused(
     else hipLaunchKernelGGL((fused_probe_kernel<TILE, THREADS, false>), dim3(grid), dim3(THREADS), 0, stream, a);         \
   } while (0)
     if (part) {
-      const char* fm = getenv("MI355_FUSED_FASTMOD");   // (read per call: A/B inside one process; opt-in this round)
-      const bool fast = fm && atoi(fm) != 0 && (a.t.C & (a.t.C - 1)) == 0 && (a.S >> __builtin_ctzll((unsigned long long)a.t.C)) < (1ll << 31);
-      if (fast) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
+      const char* fm = getenv("MI355_FUSED_FASTMOD");   // (read per call: A/B inside one process; default on with path (c))
+      const bool fast = (fm ? atoi(fm) != 0 : pathc) && (a.t.C & (a.t.C - 1)) == 0 && (a.S >> __builtin_ctzll((unsigned long long)a.t.C)) < (1ll << 31);
+      if (pathc && fast) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
+      else if (pathc) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, false, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
+      else if (fast) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
       else hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
     } else
     switch (cfg) {
@@ -1533,6 +2115,39 @@ int mi355_demb_forward_fused(
   }
   // ---- train: unique numbering + CSR of the backward on the side stream (forked BEFORE the gather is queued, so both
   //      start as soon as the index stage is done); eval: only the gather
+  if (pathc) {
+    RoctxRange rr("op:unique_numbering+backward_csr");
+    EmitOut o;
+    o.unique_keys = unique_keys; o.table_offsets = unique_offsets; o.table_ids = table_ids; o.slots = slots;
+    o.row_addr = row_addr; o.freq = freq; o.csr_cnt = csr_cnt; o.total = total + 8;
+    HotList hot = hot_carve(hot_ws, n, emb_dim);
+    PoolArgs g;
+    g.src = nullptr; g.src_stride = 0; g.row_addr = a.occ_addr; g.rev = nullptr; g.offsets = offsets; g.D_offsets = D_offsets;
+    g.dst = out; g.FB = num_bags; g.n = n; g.B = (int)batch_size; g.D = (int)emb_dim; g.total_D = (int)total_D; g.combiner = combiner;
+    LateRefs late; late.occ_slot = a.occ_slot; late.rec = a.rec; late.S = (int)S;
+    late.table_ptrs = table_ptrs; late.table_value_dims = table_value_dims; late.tbo = table_bucket_offsets;
+    late.C = bucket_capacity; late.elem_bytes = a.elem_bytes;
+    const int nsub = 64 >> lg;
+    hipLaunchKernelGGL(fused_part3_kernel, dim3((unsigned)a.P), dim3(kP3Threads), 0, stream, a, o, bptr, bcsr, hot);
+    MI355_LAUNCH_CHECK();
+    {
+      RoctxRange rg("op:gather_embedding");
+      GatherTimer gt(stream);
+      const unsigned grid = (unsigned)grid_for(num_bags, 4 * nsub * 4, 1 << 20);
+#define LAUNCH_PG(S, D) hipLaunchKernelGGL((gather_pooled_late_kernel<S, D>), dim3(grid), dim3(256), 0, stream, g, late, lg)
+      if (value_dtype == 0 && out_dtype == 0) LAUNCH_PG(kF32, kF32);
+      else if (value_dtype == 0) LAUNCH_PG(kF32, kBF16);
+      else if (out_dtype == 0) LAUNCH_PG(kBF16, kF32);
+      else LAUNCH_PG(kBF16, kBF16);
+#undef LAUNCH_PG
+    }
+    MI355_LAUNCH_CHECK();
+    const int64_t* nu_dev = unique_offsets + num_tables;
+    if (pin) STEP(mi355_table_update_counter(counter, counter_numel, slots, n, nu_dev, 1, table_ids, table_bucket_offsets,
+                                             bucket_capacity, stream));
+    if (join_token) *join_token = -2;   // reverse indices / full ranks: on demand (mi355_demb_fused_materialize)
+    return MI355_OK;
+  }
   hipStream_t cs = stream;
   bool forked = false;
   if (train && n > 0 && use_side_stream && combiner != -2) {
@@ -1593,6 +2208,34 @@ int mi355_demb_forward_fused(
   }
   if (!forked) STEP(gather());
 #undef STEP
+  return MI355_OK;
+}
+
+
+// Per-occurrence outputs of a path-(c) forward that nothing on the training path reads (reference: the `inverse` of
+// segmented_unique_cuda, unique_op.cu:484-714): reverse_indices [num_keys] and the rank of every occurrence inside its unique
+// row's list (csr_rank), produced on demand from the records of the step's workspace; late (evicted-into) rows are patched into
+// the per-occurrence address array as well.  `workspace` is the forward's, untouched since.
+int mi355_demb_fused_materialize(void* workspace, int64_t workspace_bytes, int64_t num_keys, int64_t num_tables,
+                                 const int64_t* row_addr, int64_t* reverse_indices, int32_t* csr_rank, hipStream_t stream) {
+  MI355_CHECK_ARG(workspace && workspace_bytes >= mi355_demb_forward_fused_workspace_bytes(num_keys, num_tables), "workspace too small");
+  MI355_CHECK_ARG(row_addr && reverse_indices && csr_rank, "outputs required");
+  const int P = part_count(num_keys, num_tables);
+  MI355_CHECK_ARG(P > 0, "not a partitioned step");
+  if (num_keys == 0) return MI355_OK;
+  uint8_t* w = (uint8_t*)workspace;
+  const int64_t n = num_keys, nt = (n + 1023) / 1024 + 2;
+  w += al256(8 * (num_tables + 1)) + al256(8 * n);
+  int64_t* occ_addr = (int64_t*)w; w += al256(8 * n);
+  const int32_t* occ_slot = (const int32_t*)w; w += al256(4 * n);
+  w += al256(4 * nt) + 256 + al256(8 * n);
+  const int32_t* occ_trank = (const int32_t*)w; w += 4 * al256(4 * n);
+  w += al256(16 * nt);
+  w += al256(16 * (int64_t)P * kPartCap);
+  const int4* rec_out4 = (const int4*)w;
+  hipLaunchKernelGGL(occ_from_records_kernel, dim3((unsigned)grid_for(n, 256, 4096)), dim3(256), 0, stream, occ_slot, occ_trank, rec_out4,
+                     row_addr, n, reverse_indices, csr_rank, occ_addr);
+  MI355_LAUNCH_CHECK();
   return MI355_OK;
 }
 

@@ -64,6 +64,129 @@ __device__ __forceinline__ float4 ld4g(gptr_t p) {
   }
 }
 
+// Late rows of the fused forward (fused_fwd.hip): a key whose bucket had no free slot gets its slot from the eviction kernel,
+// after the probe kernel wrote the per-occurrence addresses.  Such an occurrence carries the address word 1 and finds its row
+// through its (tile, key) record: occ_slot[j] = record, whose third word is the slot by then (>= S: no row this step).
+struct LateRefs {
+  const int32_t* occ_slot = nullptr;
+  const uint4* rec = nullptr;
+  const int64_t* table_ptrs = nullptr;        // rows of the (single) table: base address, elements per row, first bucket
+  const int64_t* table_value_dims = nullptr;
+  const int64_t* tbo = nullptr;
+  int64_t C = 0;
+  int elem_bytes = 0;
+  int S = 0;
+};
+__device__ __forceinline__ uintptr_t late_row(const LateRefs& L, int64_t j) {
+  const int ref = L.occ_slot[j];
+  if (ref < 0) return 0;
+  const int z = (int)L.rec[ref].z;
+  if (z < 0 || z >= L.S) return 0;
+  return (uintptr_t)(L.table_ptrs[0] + ((int64_t)z - L.tbo[0] * L.C) * L.table_value_dims[0] * L.elem_bytes);
+}
+
+// Software-pipelined form for rows of one column group (NCOL == 1, the C2 shape): an LPR-lane group owns KIT
+// consecutive bags.  The bag offsets are fetched once (one per lane), a bag's keys one per lane (coalesced): every
+// lane resolves ITS key to a row address, and the addresses are handed round the group with shuffles, so the rows
+// of a bag are independent loads instead of RPR-wide rounds of a three-hop chain.  The index hops of bag i+1 (row
+// addresses) and i+2 (reverse indices) are issued BEFORE the row loads of bag i -- one wait per bag with everything
+// in flight.  Rows are added in key order (bit-identical to the sequential sum).
+// kAddr: 0 dense source, 1 row addresses per UNIQUE key (through rev), 2 row addresses per OCCURRENCE (fused forward: the
+// reverse-index hop does not exist), 3 = 2 with late rows: an address word of 1 stands for a key whose row was resolved
+// by the partition kernel (bucket full -> eviction) and is looked up through its record (LateRefs)
+template <int SDT, int DDT, int kAddr, int UNR, int KIT>
+__device__ __forceinline__ void gather_pooled_pipe(const PoolArgs& a, const LateRefs& late, int lpr_log2, int64_t sg) {
+  const int lane = lane_id();
+  const int LPR = 1 << lpr_log2;
+  const int c = lane & (LPR - 1);
+  const gptr_t zero = (gptr_t)(uintptr_t)g_zero_row;
+  constexpr int EB = SDT == kF32 ? 4 : 2;
+  const int64_t bag0 = sg * KIT;
+  if (bag0 >= a.FB) return;  // lane groups are independent below (shuffles stay inside the group)
+  // offsets of my KIT bags: lane i of the group holds offsets[bag0 + i], i <= KIT (KIT < 8 <= LPR)
+  int64_t myoff;
+  {
+    int64_t b = bag0 + (c < KIT ? c : KIT);
+    b = b < a.FB ? b : a.FB;
+    myoff = a.offsets[b];
+  }
+  const int off_lo = (int)(myoff & 0xffffffff), off_hi = (int)(myoff >> 32);
+  auto bag_off = [&](int i) -> int64_t {
+    i = i <= KIT ? i : KIT;
+    return (int64_t)(((uint64_t)(unsigned)__shfl(off_hi, i, LPR) << 32) | (uint64_t)(unsigned)__shfl(off_lo, i, LPR));
+  };
+  // stage 1: the reverse index of MY key of the sub-chunk [lo + r, ...) of a bag
+  auto my_index = [&](int64_t lo, int64_t hi, int64_t r) -> int64_t {
+    int64_t j = lo + r + c;
+    j = j < hi ? j : hi - 1;
+    j = j < 0 ? 0 : j;
+    j = j < a.n ? j : a.n - 1;
+    if constexpr (kAddr >= 2) return j; else return a.rev[j];
+  };
+  // stage 2: its row address (0: no such key in this sub-chunk / missing row)
+  auto my_row = [&](int64_t u, int64_t lo, int64_t hi, int64_t r) -> uintptr_t {
+    uintptr_t p;
+    if constexpr (kAddr) p = (uintptr_t)a.row_addr[u];
+    else p = (uintptr_t)a.src + (uintptr_t)(u * a.src_stride * EB);
+    return lo + r + c < hi ? p : 0;
+  };
+  auto add_rows = [&](uintptr_t rp, int nq, int Df, float4& acc) {
+    const int rlo = (int)(rp & 0xffffffffu), rhi = (int)(rp >> 32);
+    for (int q0 = 0; q0 < LPR; q0 += UNR) {
+      if (__ballot(q0 < nq) == 0) break;
+      float4 v[UNR];
+#pragma unroll
+      for (int q = 0; q < UNR; ++q) {
+        const uintptr_t base = (uintptr_t)(unsigned)__shfl(rlo, q0 + q, LPR) | ((uintptr_t)(unsigned)__shfl(rhi, q0 + q, LPR) << 32);
+        const int e = 4 * c;
+        const gptr_t p = (base != 0 && e < Df) ? (gptr_t)(base + (uintptr_t)(e * EB)) : zero;
+        v[q] = ld4g<SDT>(p);
+      }
+#pragma unroll
+      for (int q = 0; q < UNR; ++q) add4(acc, v[q]);
+    }
+  };
+  int64_t lo_c = bag_off(0), hi_c = bag_off(1);          // current bag
+  int64_t lo_n = hi_c, hi_n = bag_off(2);                // next bag
+  int64_t u_n;
+  uintptr_t rp_c;
+  {
+    const int64_t u0 = my_index(lo_c, hi_c, 0);
+    u_n = my_index(lo_n, hi_n, 0);
+    rp_c = my_row(u0, lo_c, hi_c, 0);
+  }
+#pragma unroll
+  for (int it = 0; it < KIT; ++it) {
+    const int64_t bag = bag0 + it;
+    if (bag >= a.FB) break;
+    const int64_t lo_nn = hi_n, hi_nn = bag_off(it + 3);
+    const uintptr_t rp_n = my_row(u_n, lo_n, hi_n, 0);    // row addresses of bag it+1
+    const int64_t u_nn = my_index(lo_nn, hi_nn, 0);        // reverse indices of bag it+2
+    const int f = (int)(bag / a.B), bb = (int)(bag - (int64_t)f * a.B);
+    int d0 = f * a.D, Df = a.D;
+    if (a.D_offsets) { d0 = a.D_offsets[f]; Df = a.D_offsets[f + 1] - d0; }
+    const int64_t L = hi_c - lo_c;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (kAddr == 3) { if (__ballot(rp_c == 1)) { if (rp_c == 1) rp_c = late_row(late, lo_c + c); } }
+    add_rows(rp_c, (int)(L < LPR ? L : LPR), Df, acc);
+    for (int64_t r = LPR; __ballot(r < L) != 0; r += LPR) {   // bags longer than a lane group: dependent hops
+      const int64_t u = my_index(lo_c, hi_c, r);
+      uintptr_t rp = my_row(u, lo_c, hi_c, r);
+      if constexpr (kAddr == 3) { if (__ballot(rp == 1)) { if (rp == 1) rp = late_row(late, lo_c + r + c); } }
+      const int64_t left = L - r;
+      add_rows(rp, (int)(left < 0 ? 0 : (left < LPR ? left : LPR)), Df, acc);
+    }
+    if (a.combiner == 1 && L > 0) {
+      const float fl = (float)L;
+      acc.x /= fl; acc.y /= fl; acc.z /= fl; acc.w /= fl;
+    }
+    if (4 * c < Df) st4<DDT>(a.dst, (int64_t)bb * a.total_D + d0 + 4 * c, acc);
+    lo_c = lo_n; hi_c = hi_n; rp_c = rp_n;
+    lo_n = lo_nn; hi_n = hi_nn; u_n = u_nn;
+  }
+}
+
+
 // Flat-stream pooled gather of the bags [b0, b0 + bn) by ONE lane group of LPR = 1 << lpr_log2 lanes (rows of one column
 // group: D <= 4 * LPR; uniform D: a.D_offsets == nullptr; bn <= KB < LPR).  Called by whole lane groups; groups of a wave are
 // independent (shuffles stay inside the group).

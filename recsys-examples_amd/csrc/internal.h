@@ -61,6 +61,15 @@ int mi355i_csr_from_slots(const int32_t* csr_rank, const int32_t* occ_slot, cons
                           void* hot_workspace, int64_t hot_workspace_bytes, int64_t dim, int32_t* hdr_reset,
                           const PartRefs* part, hipStream_t stream);
 
+// mi355_backward_fused with the tile lists that CSR reference entries (< 0: source id = tile_bags[~entry]) point into
+int mi355i_backward_fused(const int32_t* ptr, const int32_t* csr_src, int64_t num_keys, int64_t max_unique,
+                          const int64_t* nu_dev, const void* grads, int64_t grad_stride, int grad_dtype,
+                          const int64_t* offsets, const int32_t* D_offsets, int64_t batch_size, int64_t dim, int combiner,
+                          const int64_t* row_addr, int weight_dtype, int opt_kind, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, int64_t iter_num, int64_t state_offset, int round_grad,
+                          void* out, int64_t out_stride, int aligned16, void* workspace, int64_t workspace_bytes,
+                          const int32_t* tile_bags, hipStream_t stream);
+
 // bench.py's live kernel timing (err.hip): event of slot (0 gather, 1 backward kernel), end 0 / 1
 void mi355i_prof_mark(int slot, int end, hipStream_t stream);
 

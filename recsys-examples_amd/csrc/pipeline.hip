@@ -187,9 +187,12 @@ int mi355_demb_backward(
                                csr, gws, gws_bytes, bws, bws_bytes, dim, stream);
   if (rc != MI355_OK) return rc;
   mi355::RoctxRange rr_b("op:reduce_grads+optimizer_update");
-  rc = mi355_backward_fused(ptr, csr, num_keys, num_keys, nu_dev, grads, grad_stride, grad_dtype, offsets, D_offsets,
-                            batch_size, dim, combiner, row_addr, value_dtype, opt_kind, lr, beta1, beta2, eps, weight_decay,
-                            iter_num, state_offset, round_grad, nullptr, 0, aligned16, bws, bws_bytes, stream);
+  // (prepared by the fused forward: CSR reference entries point into the tile lists it left at the head of the grouping
+  //  workspace; every other producer writes plain source ids, for which the pointer is never dereferenced)
+  rc = mi355i_backward_fused(ptr, csr, num_keys, num_keys, nu_dev, grads, grad_stride, grad_dtype, offsets, D_offsets,
+                             batch_size, dim, combiner, row_addr, value_dtype, opt_kind, lr, beta1, beta2, eps, weight_decay,
+                             iter_num, state_offset, round_grad, nullptr, 0, aligned16, bws, bws_bytes,
+                             prepared ? (const int32_t*)gws : nullptr, stream);
   if (rc != MI355_OK) return rc;
   if (unpin)
     rc = mi355_table_update_counter(counter, counter_numel, slots, num_keys, nu_dev, -1, table_ids, table_bucket_offsets,

@@ -109,6 +109,14 @@ class _FusedStep:
         self.indices = None
         self.offsets = None
         self.prepared = 0
+        self.lazy = False      # reverse indices / ranks not produced yet (mi355_demb_fused_materialize on first use)
+
+    def materialize(self):
+        """per-occurrence outputs of a forward whose partition blocks wrote the CSR themselves (join_token == -2)"""
+        if self.lazy:
+            self.lazy = False
+            check(lib().mi355_demb_fused_materialize(self.p("fwd_ws"), self.fwd_ws_bytes, self.num_keys, self.T, self.p("row_addr"),
+                                                     self.p("rev"), self.p("csr_rank"), stream()), "fused_materialize")
 
     @staticmethod
     def nbytes(n, T, fwd_ws_bytes, bwd_ws_bytes):
@@ -126,6 +134,8 @@ class _FusedStep:
 
     def _view(self, name):
         self.join()
+        if name in ("rev", "csr_rank"):
+            self.materialize()
         for nm, eb, dtp in self._FIELDS:
             if nm == name:
                 o = self.off[nm]
@@ -627,7 +637,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             st.p("rev"), st.p("uoff"), st.p("tids"), st.p("slots"), st.p("row_addr"), st.p("freq") if need_freq else None,
             st.p("csr_cnt"), st.p("csr_rank"), st.p("bwd_ws") if bwd_b else None, bwd_b, use_side, ctypes.byref(tok),
             st.p("fwd_ws"), fwd_b, stream()), "demb_forward_fused")
-        st.token = tok.value
+        st.lazy = tok.value == -2
+        st.token = tok.value if tok.value >= 0 else -1
         st.prepared = (2 + tok.value) if tok.value >= 0 else (1 if bwd_b and n > 0 else 0)
         if train:
             self._check_partition_flag()
@@ -670,6 +681,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         else:       # a prefetched step (no CSR yet) or a second backward of the same step: group here
             prepared = 0
             st.join()
+            st.materialize()
             ws_b = L.mi355_demb_backward_workspace_bytes(st.num_keys, dim)
             ws = torch.empty(ws_b, dtype=torch.uint8, device=grads.device)
             ws_p = ptr(ws)

@@ -101,6 +101,7 @@ _SIGS = {
     "mi355_demb_forward_fused_workspace_bytes": [c_i64, c_i64],
     "mi355_demb_forward_fused_partitions": [c_i64, c_i64, c_i64],
     "mi355_side_join": [c_int, c_p],
+    "mi355_demb_fused_materialize": [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p],
     "mi355_profile_kernels": [c_int],
     "mi355_profile_ms": [c_int],
     "mi355_demb_backward": [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_int, c_p, c_i64, c_int, c_p,

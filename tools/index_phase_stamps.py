@@ -39,6 +39,9 @@ PART = ["start -> record loads issued + LDS init", "wait: barrier", "merge (LDS 
 SCAT = ["start -> index hops issued + bag range search", "wait: barrier", "bag marks + max-scan", "wait for index hops", "stores"]
 
 
+SPANS = []
+
+
 def dump(fn, nblk, nph, names, title, nlive=None):
     f = getattr(lib, fn, None)
     if f is None:
@@ -63,7 +66,10 @@ def dump(fn, nblk, nph, names, title, nlive=None):
     print(f"   block life (shader cycles): avg {life.mean():.0f}  p50 {np.median(life):.0f}  max {life.max():.0f}")
     w0, w1 = d[:, nph], d[:, nph + 1]
     ok = w1 > 0
+    recent = w0 > w0.max() - 20000       # (blocks only an earlier, larger launch used keep their old stamps: drop them)
+    d, w0, w1, ok, life = d[recent], w0[recent], w1[recent], ok[recent], life[recent]
     t0 = w0.min()
+    SPANS.append((title.split(":")[0].split(" (")[0], w0.min() / 100.0, w1[ok].max() / 100.0))
     print(f"   wall clock (us, 100 MHz): starts {((w0 - t0) / 100).min():.2f} .. {((w0 - t0) / 100).max():.2f}  "
           f"ends p10 {np.percentile((w1[ok] - t0) / 100, 10):.2f}  p50 {np.median((w1[ok] - t0) / 100):.2f}  p90 {np.percentile((w1[ok] - t0) / 100, 90):.2f}  "
           f"max {((w1[ok] - t0) / 100).max():.2f};  block wall life avg {((w1[ok] - w0[ok]) / 100).mean():.2f} us"
@@ -77,7 +83,22 @@ def dump(fn, nblk, nph, names, title, nlive=None):
 
 
 dump("mi355_debug_stamps_probe", 1024, 12, PROBE, "fused_probe_kernel")
-dump("mi355_debug_stamps_part", 1024, 10, PART, "fused_part_kernel")
-dump("mi355_debug_stamps_scatter", 2048, 6, SCAT, "csr_scatter_kernel")
+if os.environ.get("MI355_FUSED_PART", "2") == "1":
+    dump("mi355_debug_stamps_part", 1024, 10, PART, "fused_part_kernel")
+    dump("mi355_debug_stamps_scatter", 2048, 6, SCAT, "csr_scatter_kernel")
+PART2 = ["start -> record loads issued + LDS init", "wait: barrier", "merge (LDS hash insert + counts + rank bases out)", "wait: barrier",
+         "entry scan + publish sums", "look-back", "outputs per unique row", "outputs per record (CSR entries)", "-"]
+if os.environ.get("MI355_FUSED_PART", "2") != "1":
+    dump("mi355_debug_stamps_part", 1024, 10, PART2, "part2 blocks of fused_part_gather_kernel")
+    dump("mi355_debug_stamps_fgather", 16384, 2, None, "gather blocks of fused_part_gather_kernel (thread 0 of each block)")
 dump("mi355_debug_stamps_gather", 16384, 2, None, "gather_pooled_pipe_kernel (thread 0 of each block)")
 dump("mi355_debug_stamps_bwd", 16384, 2, None, "bwd_kernel (thread 0 of each block)")
+
+print("== absolute wall clock of the last step (us): first block start .. last block end, and the gap to the previous kernel")
+SPANS.sort(key=lambda x: x[1])
+base = SPANS[0][1] if SPANS else 0
+prev_end = None
+for name, a0, a1 in SPANS:
+    gap = "" if prev_end is None else f"   gap after previous: {a0 - prev_end:6.2f}"
+    print(f"   {name:60s} {a0 - base:8.2f} .. {a1 - base:8.2f}{gap}")
+    prev_end = a1
