@@ -1818,6 +1818,13 @@ __global__ void __launch_bounds__(256) gather_pooled_late_kernel(PoolArgs g, Lat
 #endif
 }
 
+// eval / inference forward in one launch (gather_dev.h: gather_pooled_eval)
+template <int SDT, int DDT>
+__global__ void __launch_bounds__(256) gather_pooled_eval_kernel(PoolArgs g, ProbeRefs pr, int lpr_log2) {
+  const int64_t sg = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (64 >> lpr_log2) + (lane_id() >> lpr_log2);
+  gather_pooled_eval<SDT, DDT, 4, 4>(g, pr, lpr_log2, sg);
+}
+
 // lazy per-occurrence outputs of path (c): reverse index and full rank of every occurrence from its record, late row addresses
 __global__ void __launch_bounds__(256)
 occ_from_records_kernel(const int32_t* __restrict__ occ_slot, const int32_t* __restrict__ occ_trank, const int4* __restrict__ rec_out4,
@@ -2081,6 +2088,35 @@ int mi355_demb_forward_fused(
   if (pathc) {
     a.tile_bags = (int32_t*)((uint8_t*)backward_workspace + al256(4 * (n + 1)) + al256(4 * n));   // head of the grouping workspace
     a.occ_trank = a.d_tid;   // (the deferred-key arrays belong to path (b))
+  }
+  // ---- eval / inference forward of one table with pooled output: ONE kernel (every lane probes its own keys; no dedup, no
+  //      unique numbering, no address array).  MI355_EVAL_FUSED=0 keeps the probe + gather pair.
+  static const int eval_env = getenv("MI355_EVAL_FUSED") ? atoi(getenv("MI355_EVAL_FUSED")) : 1;
+  if (!train && eval_env && n > 0 && num_tables == 1 && combiner >= 0 && aligned16 && !use_count &&
+      (find_policy == kConst || find_policy == kAssign || find_policy == kGlobalTimer) && (bucket_capacity & (bucket_capacity - 1)) == 0 &&
+      value_dtype <= 1 && out_dtype <= 1 && num_buckets < (1ll << 31) && n <= 8 * num_bags) {
+    int le = 3;
+    while ((4 << le) < emb_dim && le < 6) ++le;
+    if (emb_dim <= (4 << le)) {
+      RoctxRange rr("op:eval_lookup+gather_embedding");
+      PoolArgs g;
+      g.src = nullptr; g.src_stride = 0; g.row_addr = nullptr; g.rev = nullptr; g.offsets = offsets; g.D_offsets = D_offsets;
+      g.dst = out; g.FB = num_bags; g.n = n; g.B = (int)batch_size; g.D = (int)emb_dim; g.total_D = (int)total_D; g.combiner = combiner;
+      ProbeRefs pr;
+      pr.keys = (const uint64_t*)keys; pr.t = a.t; pr.tbo = table_bucket_offsets; pr.table_ptrs = table_ptrs;
+      pr.table_value_dims = table_value_dims; pr.elem_bytes = a.elem_bytes; pr.find_policy = find_policy;
+      pr.score_value = score_value; pr.timer = timer_override;
+      const unsigned grid = (unsigned)grid_for(num_bags, 4 * (64 >> le) * 4, 1 << 20);
+      GatherTimer gt(stream);
+#define LAUNCH_EV(S, D) hipLaunchKernelGGL((gather_pooled_eval_kernel<S, D>), dim3(grid), dim3(256), 0, stream, g, pr, le)
+      if (value_dtype == 0 && out_dtype == 0) LAUNCH_EV(kF32, kF32);
+      else if (value_dtype == 0) LAUNCH_EV(kF32, kBF16);
+      else if (out_dtype == 0) LAUNCH_EV(kBF16, kF32);
+      else LAUNCH_EV(kBF16, kBF16);
+#undef LAUNCH_EV
+      MI355_LAUNCH_CHECK();
+      return MI355_OK;
+    }
   }
   if (n > 0) {
     RoctxRange rr("op:fused_index(segmented_unique+storage_find+storage_insert+initializer)");

@@ -13,6 +13,7 @@
 // life of the wave (27 us, same output bit for bit: rows are still added in key order, one rounding at the store).
 #pragma once
 #include "common.h"
+#include "table_dev.h"
 
 namespace mi355 {
 
@@ -186,6 +187,155 @@ __device__ __forceinline__ void gather_pooled_pipe(const PoolArgs& a, const Late
   }
 }
 
+
+// ---- eval / inference forward as ONE kernel (round 3): no dedup, no unique numbering, no per-occurrence address array -- the
+// lanes probe the scored hash table themselves (reference: table_lookup_kernel, kernels.cuh:81-187, and the eval path of
+// BatchedDynamicEmbeddingTablesV2, batched_dynamicemb_tables.py:1140-1218; unknown keys contribute zero rows,
+// test_batched_dynamic_embedding_tables_v2.py:1517-1591), then pool the rows exactly as gather_pooled_pipe does.
+// Single table, non-counting score policies (a found key's score is an idempotent store: every occurrence writes the same
+// value), bucket capacity a power of two (the bucket comes out of a multiply-high, not a 64-bit division).
+// Measured at C2 (rocprofv3): 41.5 us against 49-52 us for the probe + gather pair.  Forms tried on the way: KIT keys per lane
+// probed up front (84 registers, five waves per SIMD: 44 us); two phases per block through the address array (58 registers
+// but fifteen dependent hops per block: 46 us).
+struct ProbeRefs {
+  const uint64_t* keys = nullptr;
+  Table t{};
+  const int64_t* tbo = nullptr;               // [2] bucket range of the table
+  const int64_t* table_ptrs = nullptr;        // [1] rows: base address
+  const int64_t* table_value_dims = nullptr;  // [1] elements per row
+  int elem_bytes = 0;
+  int find_policy = 0;                        // kConst / kAssign / kGlobalTimer
+  uint64_t score_value = 0, timer = 0;        // timer == 0: the device clock
+};
+
+// one-launch eval forward, lane-group form: the KIT bags of a lane group are ONE contiguous run of keys, so lane c probes the
+// run's key c (one key per lane: ~12 registers of probe state instead of KIT times that) and the bag loop picks its rows'
+// addresses out of the lanes with shuffles.  Keys beyond the first LPR of the run (a few per cent of the groups at C2) are
+// probed when their bag is reached (dependent hops).
+template <int SDT, int DDT, int UNR, int KIT>
+__device__ __forceinline__ void gather_pooled_eval(const PoolArgs& a, ProbeRefs pr, int lpr_log2, int64_t sg) {
+  const int lane = lane_id();
+  const int LPR = 1 << lpr_log2;
+  const int c = lane & (LPR - 1);
+  const gptr_t zero = (gptr_t)(uintptr_t)g_zero_row;
+  constexpr int EB = SDT == kF32 ? 4 : 2;
+  const int64_t bag0 = sg * KIT;
+  if (bag0 >= a.FB) return;  // lane groups are independent below (shuffles stay inside the group)
+  int64_t myoff;
+  {
+    int64_t b = bag0 + (c < KIT ? c : KIT);
+    b = b < a.FB ? b : a.FB;
+    myoff = a.offsets[b];
+  }
+  const int64_t bkt0 = pr.tbo[0];
+  const uint64_t nb = (uint64_t)(pr.tbo[1] - bkt0);
+  const int64_t tp0 = pr.table_ptrs[0], rowb = pr.table_value_dims[0] * pr.elem_bytes;
+  if (!pr.timer) pr.timer = device_clock();
+  const int C = (int)pr.t.C;
+  const int cshift = __builtin_ctz((unsigned)C);
+  const uint64_t magic = nb ? ~0ull / nb : 0ull;
+  const int off_lo = (int)(myoff & 0xffffffff), off_hi = (int)(myoff >> 32);
+  auto bag_off = [&](int i) -> int64_t {
+    i = i <= KIT ? i : KIT;
+    return (int64_t)(((uint64_t)(unsigned)__shfl(off_hi, i, LPR) << 32) | (uint64_t)(unsigned)__shfl(off_lo, i, LPR));
+  };
+  // row address of the key at position j (0: unknown key / j >= jend): three dependent hops
+  auto probe = [&](int64_t j, int64_t jend) -> uintptr_t {
+    bool have = j < jend;
+    int64_t jc = have ? j : jend - 1;
+    jc = jc < 0 ? 0 : jc;
+    jc = jc < a.n ? jc : a.n - 1;
+    const uint64_t key = pr.keys[jc];
+    const int64_t hash = (int64_t)(fmix64(key) & 0x7FFFFFFFFFFFFFFFull);
+    const uint64_t x = (uint64_t)hash >> cshift;
+    uint64_t rr = x - __umul64hi(x, magic) * nb;
+    if (rr >= nb) rr -= nb;
+    if (rr >= nb) rr -= nb;
+    const int b = (int)(bkt0 + (int64_t)(nb ? rr : 0ull));
+    const int st = (int)((uint64_t)hash & (uint64_t)(C - 1)) & ~15;
+    have = have && is_valid(key) && nb > 0;
+    const uint4 dv = *reinterpret_cast<const uint4*>(pr.t.dig(b) + st);
+    const uint32_t m0 = eq_mask16(dv, digest_of(hash));
+    int slot = m0 ? st + __ffs(m0) - 1 : -1;
+    const uint64_t kw = pr.t.keys(b)[slot >= 0 ? slot : 0];
+    slot = (slot >= 0 && kw == key) ? slot : -2;
+    if (__ballot(have && slot == -2)) {   // the first candidate was another key, the key sits beyond the first vector, or is unknown
+      if (have && slot == -2) {
+        slot = -1;
+        const uint32_t d = digest_of(hash);
+        const uint64_t* ks = pr.t.keys(b);
+        const uint8_t* dg = pr.t.dig(b);
+        for (int gi = 0; gi < (C >> 4) && slot < 0; ++gi) {
+          int p0 = st + (gi << 4);
+          if (p0 >= C) p0 -= C;
+          uint32_t m = eq_mask16(*reinterpret_cast<const uint4*>(dg + p0), d);
+          while (m) {
+            const int bit = __ffs(m) - 1;
+            m &= m - 1;
+            if (ks[p0 + bit] == key) { slot = p0 + bit; break; }
+          }
+        }
+      }
+    }
+    if (!have || slot < 0) return 0;
+    uint64_t* sc = pr.t.scores(b) + (int64_t)slot * pr.t.ns;
+    if (pr.find_policy == kGlobalTimer) *sc = pr.timer;        // (score.cuh:72-96; idempotent across the key's occurrences)
+    else if (pr.find_policy == kAssign) *sc = pr.score_value;
+    return (uintptr_t)(tp0 + (((int64_t)b - bkt0) * C + slot) * rowb);
+  };
+  // rows whose addresses sit in lanes base .. base + nq - 1 of `rp`
+  auto add_rows = [&](uintptr_t rp, int base, int nq, int Df, float4& acc) {
+    const int rlo = (int)(rp & 0xffffffffu), rhi = (int)(rp >> 32);
+    for (int q0 = 0; q0 < LPR; q0 += UNR) {
+      if (__ballot(q0 < nq) == 0) break;
+      float4 v[UNR];
+#pragma unroll
+      for (int q = 0; q < UNR; ++q) {
+        const int src = base + q0 + q;
+        uintptr_t ad = (uintptr_t)(unsigned)__shfl(rlo, src & (LPR - 1), LPR) | ((uintptr_t)(unsigned)__shfl(rhi, src & (LPR - 1), LPR) << 32);
+        ad = q0 + q < nq ? ad : 0;
+        const int e = 4 * c;
+        const gptr_t p = (ad != 0 && e < Df) ? (gptr_t)(ad + (uintptr_t)(e * EB)) : zero;
+        v[q] = ld4g<SDT>(p);
+      }
+#pragma unroll
+      for (int q = 0; q < UNR; ++q) add4(acc, v[q]);
+    }
+  };
+  const int64_t run_lo = bag_off(0);
+  int64_t run_hi = bag_off(KIT);
+  run_hi = run_hi < a.n ? run_hi : a.n;
+  const uintptr_t rp0 = probe(run_lo + c, run_hi);      // the run's first LPR keys, one per lane
+#pragma unroll
+  for (int it = 0; it < KIT; ++it) {
+    const int64_t bag = bag0 + it;
+    if (bag >= a.FB) break;
+    const int64_t lo_c = bag_off(it), hi_c = bag_off(it + 1);
+    const int f = (int)(bag / a.B), bb = (int)(bag - (int64_t)f * a.B);
+    int d0 = f * a.D, Df = a.D;
+    if (a.D_offsets) { d0 = a.D_offsets[f]; Df = a.D_offsets[f + 1] - d0; }
+    const int64_t L = hi_c - lo_c;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // keys of this bag inside the first LPR of the run come out of rp0, the rest is probed now, LPR at a time
+    int64_t r = 0;
+    const int64_t in_first = run_lo + LPR - lo_c;      // keys of the bag covered by rp0 (may be <= 0 or >= L)
+    if (__ballot(in_first > 0 && L > 0)) {
+      const int64_t nq = in_first < L ? (in_first > 0 ? in_first : 0) : L;
+      add_rows(rp0, (int)(lo_c - run_lo), (int)nq, Df, acc);
+      r = nq;
+    }
+    for (; __ballot(r < L) != 0; r += LPR) {
+      const uintptr_t rr = probe(lo_c + r + c, hi_c);
+      const int64_t left = L - r;
+      add_rows(rr, 0, (int)(left < 0 ? 0 : (left < LPR ? left : LPR)), Df, acc);
+    }
+    if (a.combiner == 1 && L > 0) {
+      const float fl = (float)L;
+      acc.x /= fl; acc.y /= fl; acc.z /= fl; acc.w /= fl;
+    }
+    if (4 * c < Df) st4<DDT>(a.dst, (int64_t)bb * a.total_D + d0 + 4 * c, acc);
+  }
+}
 
 // Flat-stream pooled gather of the bags [b0, b0 + bn) by ONE lane group of LPR = 1 << lpr_log2 lanes (rows of one column
 // group: D <= 4 * LPR; uniform D: a.D_offsets == nullptr; bn <= KB < LPR).  Called by whole lane groups; groups of a wave are
