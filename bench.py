@@ -43,10 +43,11 @@ def parse():
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--alpha", type=float, default=0.99)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-hstu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the 16x-batch C2 step and the jagged attention shape")
     ap.add_argument("--hstu-batch", type=int, default=32)
     ap.add_argument("--hstu-seqlen", type=int, default=512)
     ap.add_argument("--hstu-heads", type=int, default=4)
@@ -120,22 +121,20 @@ def _cpu_model() -> str:
     return "unknown"
 
 
-def _cpu_ebc_run(emb, dim, batches_cpu, threads, seconds, lr=0.1):
-    """What an unsharded TorchRec CPU EmbeddingBagCollection executes for one table: nn.EmbeddingBag(mode='sum',
-    include_last_offset=True) forward, backward to a SPARSE gradient, SGD on the touched rows only (index_add_ of the
-    coalesced gradient rows: `weight.add_(sparse)` densifies on some builds).  -> (keys/s, batches timed, keys timed)"""
+def _cpu_ebc_run(weight, dim, batches_cpu, threads, seconds, lr=0.1):
+    """What an unsharded CPU embedding-bag lookup + sparse SGD costs on this host WITHOUT FBGEMM's fused TBE kernels: pooled
+    forward = dense `index_add_` of the looked-up rows into their bags, backward = `index_add_` of -lr * (the bag's gradient
+    row) into the table rows of its keys (duplicates accumulate inside index_add_; no sparse tensor, no coalesce()).
+    -> (keys/s, batches timed, keys timed)"""
     torch.set_num_threads(threads)
     keys_done, spent, iters = 0, 0.0, 0
     while spent < seconds:
-        for keys, offsets in batches_cpu:
-            g = torch.ones(offsets.numel() - 1, dim)
+        for keys, offsets, bag in batches_cpu:
+            B = offsets.numel() - 1
+            g = torch.ones(B, dim)
             t = time.perf_counter()
-            out = emb(keys, offsets)
-            out.backward(g)
-            with torch.no_grad():
-                sg = emb.weight.grad.coalesce()
-                emb.weight.index_add_(0, sg.indices()[0], sg.values(), alpha=-lr)
-            emb.weight.grad = None
+            out = torch.zeros(B, dim).index_add_(0, bag, weight[keys])       # forward: gather + pool
+            weight.index_add_(0, keys, g[bag], alpha=-lr)                     # backward: per-key gradient rows, SGD in place
             dt_ = time.perf_counter() - t
             if iters > 0:  # the first iteration is warm-up
                 spent += dt_
@@ -143,29 +142,32 @@ def _cpu_ebc_run(emb, dim, batches_cpu, threads, seconds, lr=0.1):
             iters += 1
             if spent >= seconds:
                 break
+    del out
     return (keys_done / spent if spent > 0 else 0.0), iters - 1, keys_done
 
 
 def _cpu_table(rows, dim):
-    emb = torch.nn.EmbeddingBag(rows, dim, mode="sum", include_last_offset=True, sparse=True)
-    with torch.no_grad():
-        emb.weight.uniform_(-0.01, 0.01)
-    return emb
+    return torch.empty(rows, dim).uniform_(-0.01, 0.01)
+
+
+def _with_bag_ids(batches):
+    return [(k, o, torch.repeat_interleave(torch.arange(o.numel() - 1), o[1:] - o[:-1])) for k, o in batches]
 
 
 def cpu_baseline(args, batches_cpu):
-    """SURVEY 8(d) CPU baseline: the reference's TorchRec CPU EmbeddingBagCollection path (TorchRec itself is not
-    installed: what its unsharded CPU EBC executes per table is torch.nn.EmbeddingBag) on THIS host, same key stream,
-    fwd + bwd + sparse SGD, over several thread counts (all host threads is NOT the fastest: the sparse backward does not
-    scale); `value` is the best of them and `cores` the thread count it used.  Plus the C1 plumbing configuration."""
+    """SURVEY 8(d) CPU baseline: the reference's TorchRec CPU EmbeddingBagCollection path on THIS host (TorchRec / FBGEMM are
+    not installed: the same arithmetic as dense index_add_ accumulation per bag and per key), same key stream, fwd + bwd +
+    SGD, at 1 thread and at all host threads; `value` is the better of the two and `cores` the thread count it used.  About
+    8 s of host time (`--cpu-seconds`).  Plus the C1 plumbing configuration."""
     ncpu = os.cpu_count() or 1
     t0 = time.time()
-    emb = _cpu_table(args.rows, args.dim)
-    counts = sorted({1, min(16, ncpu), min(64, ncpu), ncpu})
+    weight = _cpu_table(args.rows, args.dim)
+    batches_cpu = _with_bag_ids(batches_cpu)
+    counts = sorted({1, ncpu})
     per = {}
     sample = []
     for th in counts:
-        v, nb, nk = _cpu_ebc_run(emb, args.dim, batches_cpu, th, args.cpu_seconds / len(counts))
+        v, nb, nk = _cpu_ebc_run(weight, args.dim, batches_cpu, th, 0.8 * args.cpu_seconds / len(counts))
         per[th] = v
         sample.append(f"{th} threads: {nb} batches / {nk} keys")
     best = max(per, key=per.get)
@@ -177,17 +179,18 @@ def cpu_baseline(args, batches_cpu):
         off = torch.zeros(513, dtype=torch.int64)
         off[1:] = torch.cumsum(lens, 0)
         c1.append((torch.randint(0, 100_000, (int(off[-1]),), generator=g), off))
-    emb1 = _cpu_table(100_000, 32)
-    c1_per = {th: _cpu_ebc_run(emb1, 32, c1, th, 0.5)[0] for th in counts}
+    w1 = _cpu_table(100_000, 32)
+    c1 = _with_bag_ids(c1)
+    c1_per = {th: _cpu_ebc_run(w1, 32, c1, th, 0.1 * args.cpu_seconds / len(counts))[0] for th in counts}
     torch.set_num_threads(ncpu)
     return {"value": per[best], "unit": "lookups/s", "cores": best, "kind": "port",
-            "value_by_threads": {str(k): v for k, v in per.items()}, "value_1_thread": per[1],
+            "value_by_threads": {str(k): v for k, v in per.items()}, "value_1_thread": per[1], "value_all_threads": per[ncpu],
             "cpu_model": _cpu_model(), "os_cpu_count": ncpu,
             "c1": {"workload": "C1: 1 table x 100000 rows x 32-D fp32, batch 512 bags x randint(1,11) keys, SUM, SGD",
                    "value_by_threads": {str(k): v for k, v in c1_per.items()}, "value": max(c1_per.values()),
                    "unit": "lookups/s"},
-            "sample": f"C2 key stream on a {args.rows}x{args.dim} fp32 host table through torch.nn.EmbeddingBag(mode=sum, "
-                      f"sparse=True) fwd + bwd + SGD on the touched rows; " + "; ".join(sample) +
+            "sample": f"C2 key stream on a {args.rows}x{args.dim} fp32 host table: pooled forward and SGD backward as dense "
+                      f"index_add_ accumulation (no FBGEMM, no sparse coalesce); " + "; ".join(sample) +
                       f"; {time.time() - t0:.0f} s of host time incl. table setup"}
 
 
@@ -220,16 +223,17 @@ def kernel_roofline(module, batches, grad, batch, D, e=4, o=2):
     kern = {"bwd_kernel": {"ms": b_ms, "algorithmic_bytes": bwd_bytes, "GB/s": bwd_bytes / b_ms / 1e6}}
     if fwd_ms:
         f_ms = float(np.median(fwd_ms))
-        kern["gather_pooled_pipe_kernel"] = {"ms": f_ms, "algorithmic_bytes": fwd_bytes, "GB/s": fwd_bytes / f_ms / 1e6}
+        kern["gather_pooled_late_kernel"] = {"ms": f_ms, "algorithmic_bytes": fwd_bytes, "GB/s": fwd_bytes / f_ms / 1e6}
     dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
     # HBM traffic of the dominant kernel per launch: PMC counters cannot be read from inside this process; the figure is
     # the one of the committed separate rocprofv3 --pmc passes over THIS command (tools/pmc_run.sh, C2 batch size only)
     traffic, src = None, None
     if batch == 65536:
-        for tag in ("r02", "r01"):
+        for tag in ("r03", "r02", "r01"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")))["kernels"]
-                traffic, src = pmc[dom[0]]["traffic_bytes"], f"profiles/{tag}_pmc_traffic.json"
+                key = dom[0] if dom[0] in pmc else dom[0].replace("late", "pipe")
+                traffic, src = pmc[key]["traffic_bytes"], f"profiles/{tag}_pmc_traffic.json"
                 break
             except Exception:
                 continue
@@ -306,6 +310,79 @@ def hstu_section(args, device, world, dist=None):
                              "floor_ms": {"hbm": t_hbm_ms, "mfma": t_mfma_ms},
                              "note": "the binding roof at this shape is the larger floor"},
             "config": {"workload": f"C3 attention: batch {Bq} x L {L} (dense lengths), H {H}, d {d}, causal, alpha 1/sqrt(d)"}}
+
+
+def hstu_jagged_section(args, device):
+    """Path B on the C4 attention shape the retrieval model actually runs: jagged sequences, lengths Zipf(1.2) clipped to
+    [32, 4096], 32 sequences, H 4, d 256, causal -- fwd + bwd kernels event-timed, FLOPs by the reference's model."""
+    from hstu import hstu_varlen_bwd, hstu_varlen_fwd
+
+    rng = np.random.default_rng(1)
+    lengths = np.clip(rng.zipf(1.2, 32) + 31, 32, 4096).astype(np.int64)
+    H, d = args.hstu_heads, args.hstu_dim
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(lengths)]), dtype=torch.int32, device=device)
+    T, L = int(cu[-1]), int(lengths.max())
+    g = torch.Generator(device=device)
+    g.manual_seed(11)
+    q, k, v, do = (torch.empty(T, H, d, device=device).uniform_(-1, 1, generator=g).bfloat16() for _ in range(4))
+    alpha = 1.0 / d ** 0.5
+
+    def timeit(fn, reps):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    tf = timeit(lambda: hstu_varlen_fwd(q, k, v, cu, L, L, None, None, 1, True, alpha), 8)
+    tb = timeit(lambda: hstu_varlen_bwd(do, q, k, v, cu, L, L, None, None, 1, True, alpha), 6)
+    fl = hstu_flops([int(x) for x in lengths], H, d)
+    tot = 3.5 * fl / (tf + tb) / 1e9
+    return {"metric": "HSTU seq-tokens/sec, jagged (C4 attention shape)", "value": T / (tf + tb) * 1e3, "unit": "tokens/s",
+            "fwd_ms": tf, "bwd_ms": tb, "fwd_TFLOPs": fl / tf / 1e9, "bwd_TFLOPs": 2.5 * fl / tb / 1e9, "tokens": T,
+            "roofline": {"bound": "mfma", "achieved": tot, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tot / MFMA_BF16_PEAK_TFLOPS},
+            "config": {"workload": f"C4 attention: 32 jagged sequences, lengths Zipf(1.2) in [32, 4096] (max {L}, {T} tokens), "
+                                   f"H {H}, d {d}, causal"}}
+
+
+def c2_16x_section(args, module, device):
+    """The bandwidth-regime figure SURVEY 8(d) asks for: the C2 step at 16 x the batch (B = 1,048,576 bags, ~5.8 M keys) on
+    the same table: step time and the step-level roofline (minimal bytes / time)."""
+    B16 = 16 * args.batch
+    batches = zipf_batches(args.rows, args.alpha, B16, 3, device, seed=777)
+    grad = (torch.randn(B16, args.dim, device=device) * 0.01).to(torch.bfloat16)
+    with torch.no_grad():
+        for keys, offsets in batches:
+            module._forward_impl(keys, offsets, train=True)
+    nu = []
+    for keys, offsets in batches:   # warm-up (and the unique counts)
+        out, st = module._forward_impl(keys, offsets, train=True)
+        nu.append(int(st.uoff[-1].item()))
+        module._backward_impl(st, grad)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        for keys, offsets in batches:
+            out, st = module._forward_impl(keys, offsets, train=True)
+            module._backward_impl(st, grad)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / (reps * len(batches)) * 1e3
+    nt = float(np.mean([k.numel() for k, _ in batches]))
+    nua = float(np.mean(nu))
+    D, e, o = args.dim, 4, 2
+    step_bytes = (8 * nt + 8 * (B16 + 1) + 16 * nua + nua * D * e + B16 * D * o) + (8 * nt + B16 * D * o + 2 * nua * D * e)
+    gbps = step_bytes / ms / 1e6
+    del batches, grad
+    torch.cuda.empty_cache()
+    return {"ms_per_step": ms, "keys_per_step": nt, "unique_rows_per_step": nua, "lookups_per_s": nt / ms * 1e3,
+            "step_roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                              "algorithmic_bytes_per_step": step_bytes}}
 
 
 def _flush_c_stdout():
@@ -471,14 +548,19 @@ def main():
                                    "frac": gbps / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": step_bytes,
                                    "note": "whole fwd+bwd step (SURVEY 8(d) minimal bytes) over the sustained window"}
 
+    if rank == 0 and not sharded_path and not args.no_kernel_timing and not args.no_extra:
+        result["c2_16x"] = c2_16x_section(args, module, device)
+
     if not args.no_hstu:
         h = hstu_section(args, device, world, dist if sharded_path else None)
         if rank == 0:
             result["hstu"] = h
+        if rank == 0 and world == 1 and not args.no_extra:
+            result["hstu_jagged"] = hstu_jagged_section(args, device)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # keys index host rows directly (the permuted keys are already in [0, rows))
-        bc = [(k.cpu(), o.cpu()) for k, o in batches[: min(len(batches), 8)]]
+        bc = [(k.cpu(), o.cpu()) for k, o in batches[: min(len(batches), 4)]]
         result["cpu_baseline"] = cpu_baseline(args, bc)
 
     if sharded_path:

@@ -2186,7 +2186,11 @@ int mi355_demb_forward_fused(
   }
   hipStream_t cs = stream;
   bool forked = false;
-  if (train && n > 0 && use_side_stream && combiner != -2) {
+  // The side stream (numbering / CSR under the gather) is NOT used any more: the kernels that give evicted-into keys their row
+  // address run behind the gather there, which then pools zero rows for them (round-2 advisor finding); measured slower back to
+  // back anyway, and path (c) has nothing left to fork.  The argument is kept for ABI stability.
+  (void)use_side_stream;
+  if (false) {
     hipStream_t s2 = mi355i_side_fork(stream);
     if (!s2) { mi355_set_error("side stream fork failed"); return MI355_ELAUNCH; }
     cs = s2;

@@ -62,7 +62,7 @@ class _StepCtx:
     """What one forward leaves for its backward (the reference's PrefetchState + autograd ctx)."""
 
     __slots__ = ("rev", "uoff", "tids", "slots", "row_addr", "offsets", "num_keys", "batch_size", "num_bags", "csr_cnt",
-                 "csr_rank", "pinned", "event", "indices", "bwd_ws", "ring", "token")
+                 "csr_rank", "pinned", "event", "indices", "bwd_ws", "ring", "token", "__weakref__")
 
     def release_ring(self):
         """hand the early-CSR ring slot back (after the backward, or when the step is dropped without one)"""
@@ -353,6 +353,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                        and T_ <= 128 and self.table.capacity_ < (1 << 31) - 512
                        and os.environ.get("DEMB_DETERMINISM_MODE", "") in ("", "0"))
         self._fused_aux = None
+        import weakref
+        self._live_steps = weakref.WeakSet()   # forward contexts whose backward is still to come
         self._fused_side = os.environ.get("MI355_FUSED_SIDE", "0") != "0"
         self._step_ring = [None] * 4
         self._bwd_ring = [None] * 4
@@ -406,6 +408,14 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
 
     # ---------------------------------------------------------------------------------- forward
     def _forward_impl(self, indices: torch.Tensor, offsets: torch.Tensor, train: bool, prefetch_only: bool = False):
+        out, st = self._forward_impl_inner(indices, offsets, train, prefetch_only)
+        if train and st is not None:
+            # steps whose backward has not been issued yet hold slots / row addresses of the CURRENT table: growth (a rehash
+            # moves every row) waits for them (_maybe_grow); a step dropped without a backward leaves the set when it dies
+            self._live_steps.add(st)
+        return out, st
+
+    def _forward_impl_inner(self, indices: torch.Tensor, offsets: torch.Tensor, train: bool, prefetch_only: bool = False):
         indices = indices.contiguous()
         offsets = offsets.to(torch.int64).contiguous()
         if indices.dtype != torch.int64:
@@ -425,7 +435,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             return self._gather_prefetched(st), st
         if self._growth and train:
             self._maybe_grow(indices.numel())
-        if self._fused:
+        if self._fused and self.table.capacity_ < (1 << 31) - 512:   # (a table grown past 32-bit slot ids takes the per-op chain)
             return self._forward_fused(indices, offsets, train, prefetch_only)
         n = indices.numel()
         num_bags = offsets.numel() - 1
@@ -530,7 +540,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             for t in range(self.num_tables):
                 while new_caps[t] < self._max_caps[t] and (sizes[t] + per_table_in) / new_caps[t] > lf:
                     new_caps[t] = min(2 * new_caps[t], self._max_caps[t])
-            if new_caps != caps and not self._prefetch_states:
+            if new_caps != caps and not self._prefetch_states and len(self._live_steps) == 0:
                 self._expand(new_caps)
                 tb = self.table
         if getattr(self, "_fill_host", None) is None:
@@ -967,6 +977,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             warnings.warn(msg)
 
     def _backward_impl(self, st, grads: torch.Tensor):
+        self._live_steps.discard(st)
         if isinstance(st, _FusedStep):
             return self._backward_fused(st, grads)
         grads = grads.contiguous()

@@ -120,6 +120,9 @@ class RowWiseShardedLookup:
             self._comm = torch.cuda.Stream(device=values.device)
         cur = torch.cuda.current_stream()
         self._comm.wait_stream(cur)       # the batch tensors were produced on the caller's stream
+        for t in (values, offsets, lengths):
+            if t is not None and t.is_cuda:
+                t.record_stream(self._comm)   # ... and are read on the exchange stream: the allocator must not recycle them earlier
         if two_phase:
             with torch.cuda.stream(self._comm):
                 state = self.input_dist(lengths, values, collapse_batch, offsets=offsets, two_phase=True)

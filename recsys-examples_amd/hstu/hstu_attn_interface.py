@@ -150,7 +150,8 @@ def hstu_varlen_bwd(dout, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_c
     # optional dS exchange between the dK and dQ passes (saves the dQ pass its S / dP recomputation); skipped when the
     # buffer would be larger than MI355_HSTU_DS_MAX_BYTES (default 16 GiB: 32 sequences x 4 heads x L = 4096 take 8.6 GB for P and dS)
     dsb = lib().mi355_hstu_attn_bwd_ds_bytes(B, H, D, int(max_seqlen))
-    if dsb > _DS_MAX_BYTES:
+    # (O(B H L^2) scratch: never more than a quarter of what the device has free right now -- the recomputing passes need none)
+    if dsb > _DS_MAX_BYTES or (dsb > (256 << 20) and dsb > torch.cuda.mem_get_info(q.device)[0] // 4):
         dsb = 0
     ws = torch.empty(max(wsb, dsb, 256), dtype=torch.uint8, device=q.device)
     check(lib().mi355_hstu_attn_bwd(ptr(dout), ptr(q), ptr(k), ptr(v), ptr(dq), ptr(dk), ptr(dv), q.stride(0), k.stride(0),
