@@ -56,6 +56,7 @@ struct BwdArgs {
   HotList hot;              // hot-row task list built by mi355_group_by_unique (hot.n_tasks == nullptr: none)
   int hot_blocks;           // leading blocks of the launch that serve the hot tasks
   int wave_blocks;          // blocks after them whose waves serve the one-wave rows (hot.wave_*)
+  int one_feature;          // pooled, one feature (num_bags == batch): a source id IS the gradient row -- no division by the batch
   const int32_t* tile_bags; // nullable.  Round 3 (fused forward, csrc/fused_fwd.hip): a CSR entry e < 0 is a REFERENCE -- the
                             // source id is tile_bags[~e] (occurrences of one key inside one 2048-key tile are listed there by
                             // the probe kernel; the partition kernel only stores the references, nobody copies the lists)
@@ -224,7 +225,7 @@ __device__ __forceinline__ void reduce_chunk(const BwdArgs& a, int slo, int shi,
     if (a.combiner < 0) {
       off = (int64_t)sv * a.grad_stride;
     } else {
-      const int f = sv / a.B, bb = sv - f * a.B;
+      const int f = a.one_feature ? 0 : sv / a.B, bb = sv - f * a.B;
       int d0 = f * a.D;
       if (need_df) { d0 = a.D_offsets[f]; myDf = a.D_offsets[f + 1] - d0; }
       if (need_sc) {
@@ -419,7 +420,8 @@ __device__ __forceinline__ void rows_pipelined(const BwdArgs& a, const OptArgs& 
         if (a.combiner < 0) {
           off = (int64_t)sv * a.grad_stride;
         } else {
-          const int f = sv / a.B, bb = sv - f * a.B;
+          // (gfx950 has no integer divide: `sv / B` by a run-time B is ~40 instructions per gathered gradient row)
+          const int f = a.one_feature ? 0 : sv / a.B, bb = sv - f * a.B;
           off = (int64_t)bb * a.grad_stride + (int64_t)f * a.D;
           if (a.combiner == 1) { L0[b][q] = a.offsets[sv]; L1[b][q] = a.offsets[sv + 1]; }
         }
@@ -836,7 +838,7 @@ int mi355_backward_fused(const int32_t* ptr, const int32_t* csr_src, int64_t num
   return mi355i_backward_fused(ptr, csr_src, num_keys, max_unique, nu_dev, grads, grad_stride, grad_dtype, offsets, D_offsets,
                                batch_size, dim, combiner, row_addr, weight_dtype, opt_kind, lr, beta1, beta2, eps, weight_decay,
                                iter_num, state_offset, round_grad, out, out_stride, aligned16, workspace, workspace_bytes,
-                               nullptr, stream);
+                               nullptr, 0, stream);
 }
 
 // the same with the tile lists CSR reference entries point into (internal.h; only the fused forward produces references)
@@ -846,7 +848,7 @@ int mi355i_backward_fused(const int32_t* ptr, const int32_t* csr_src, int64_t nu
                           const int64_t* row_addr, int weight_dtype, int opt_kind, float lr, float beta1, float beta2,
                           float eps, float weight_decay, int64_t iter_num, int64_t state_offset, int round_grad,
                           void* out, int64_t out_stride, int aligned16, void* workspace, int64_t workspace_bytes,
-                          const int32_t* tile_bags, hipStream_t stream) {
+                          const int32_t* tile_bags, int one_feature, hipStream_t stream) {
   MI355_CHECK_ARG(opt_kind >= 0 && opt_kind <= 4, "bad optimizer kind");
   MI355_CHECK_ARG(opt_kind != kOptStore || out, "out required for opt_kind 0");
   MI355_CHECK_ARG(opt_kind == kOptStore || row_addr, "row_addr required for optimizer kinds");
@@ -857,6 +859,7 @@ int mi355i_backward_fused(const int32_t* ptr, const int32_t* csr_src, int64_t nu
   a.ptr = ptr; a.csr_src = csr_src; a.grads = grads; a.grad_stride = grad_stride; a.offsets = offsets; a.D_offsets = D_offsets;
   a.B = (int)batch_size; a.D = (int)dim; a.combiner = combiner; a.row_addr = row_addr; a.max_unique = max_unique;
   a.nu_dev = nu_dev; a.round_grad = round_grad; a.n_entries = (int)num_keys; a.tile_bags = tile_bags;
+  a.one_feature = combiner >= 0 && one_feature;
   if (workspace) {  // the hot-row task list filled by mi355_group_by_unique(..., hot_workspace = workspace, dim)
     MI355_CHECK_ARG(workspace_bytes >= hot_bytes(num_keys, dim), "workspace too small");
     a.hot = hot_carve(workspace, num_keys, dim);

@@ -103,6 +103,7 @@ struct FusedArgs {
   // (grouped by key), so that the partition kernel can write the backward's CSR itself -- no scatter kernel
   int32_t* tile_bags;             // [n] tile t owns [t * TILE, ...): bag ids of its multi-occurrence keys, key after key
   int32_t* occ_trank;             // [n] rank of every occurrence among its key's occurrences in the tile (lazy reverse indices)
+  uint64_t magic0;                // floor((2^64 - 1) / buckets of table 0): the multiply-high modulus of the one-table paths
   int4* rec_out4;                 // [P * kPartCap] out of path (c): {unique id (~id: row resolved late), rank base, CSR position, 0}
 };
 
@@ -258,7 +259,15 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     const int64_t i = tile0 + q * THREADS + threadIdx.x;
     kreg[q] = a.keys[i < a.n ? i : a.n - 1];
   }
-  for (int t = threadIdx.x; t <= T; t += THREADS) {
+  // kPart (one table): the table's scalars come straight from memory with uniform loads issued here and used two phases later --
+  // staged through LDS by threads 0 / 1 they were a global round trip in front of the FIRST barrier of every block
+  int64_t m_tbo0 = 0, m_tbo1 = 0, m_tptr0 = 0;
+  int m_rowb0 = 0;
+  if constexpr (kPart) { m_tbo0 = a.tbo[0]; m_tbo1 = a.tbo[1]; m_tptr0 = a.table_ptrs[0]; m_rowb0 = (int)a.table_value_dims[0] * a.elem_bytes; }
+  auto tbo_of = [&](int t) -> int64_t { if constexpr (kPart) return t == 0 ? m_tbo0 : m_tbo1; else return s_tbo[t]; };
+  auto tptr_of = [&](int t) -> int64_t { if constexpr (kPart) return m_tptr0; else return s_tptr[t]; };
+  auto rowb_of = [&](int t) -> int { if constexpr (kPart) return m_rowb0; else return s_rowb[t]; };
+  for (int t = threadIdx.x; t <= T && !kPart; t += THREADS) {
     s_seg[t] = T == 1 ? (t == 0 ? 0 : a.n) : a.offsets[a.feature_offsets[t] * a.batch];
     s_tbo[t] = a.tbo[t];
     if (t < T) { s_tptr[t] = a.table_ptrs[t]; s_rowb[t] = (int)a.table_value_dims[t] * a.elem_bytes; }
@@ -273,6 +282,9 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   if constexpr (kBags) {
     for (int k = threadIdx.x; k < TILE; k += THREADS) s_bag[k] = -1;
     if (threadIdx.x < 128) {   // waves 0 / 1: bags of the tile's first / last occurrence (first idx with offsets[idx] > key, minus 1)
+      // 64-ary rounds, one probe per lane: three dependent round trips for 64 K bags.  Measured against wider rounds -- 4 probes
+      // per lane (two rounds) took this phase from 8.6 K to 10.9 K cycles, 16 per lane (1024 scattered lines per wave and
+      // round) the whole kernel from 28 to 38 us: the scattered lines cost more than the round they save.
       const int64_t tile_end = tile0 + TILE < a.n ? tile0 + TILE : a.n;
       const int64_t key = threadIdx.x < 64 ? tile0 : tile_end - 1;
       int lo = 0, hi = (int)a.num_bags;
@@ -326,19 +338,19 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     s_t[li] = tt;
     const uint64_t key = kreg[q];
     const int64_t hash = (int64_t)(fmix64(key) & 0x7FFFFFFFFFFFFFFFull);
-    const int64_t bb = s_tbo[tt];
+    const int64_t bb = tbo_of(tt);
     bool ok;
     int64_t b;
     if constexpr (kFast) {
-      const uint64_t nb = (uint64_t)(s_tbo[tt + 1] - bb);
+      const uint64_t nb = (uint64_t)(tbo_of(tt + 1) - bb);
       const uint64_t x = (uint64_t)hash >> cshift;
-      uint64_t r = x - __umul64hi(x, s_magic[tt]) * nb;
+      uint64_t r = x - __umul64hi(x, kPart ? a.magic0 : s_magic[tt]) * nb;
       if (r >= nb) r -= nb;
       if (r >= nb) r -= nb;
       ok = i < a.n && is_valid(key) && nb > 0;
       b = bb + (int64_t)(nb ? r : 0ull);
     } else {
-      const int64_t cap = (s_tbo[tt + 1] - bb) * a.t.C;
+      const int64_t cap = (tbo_of(tt + 1) - bb) * a.t.C;
       ok = i < a.n && is_valid(key) && cap > 0;
       const uint64_t local = (uint64_t)hash % (uint64_t)(cap > 0 ? cap : 1);
       b = bb + (int64_t)(local / (uint64_t)a.t.C);
@@ -557,18 +569,18 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
           const int sm = s_sm[hh[q]];
           if (sm & 0x8000) a.tile_bags[tile0 + (sm & 0x7fff) + rk[q]] = s_bag[li];
           // address word 1: the row comes out of the partition kernel's eviction (gather_dev.h: LateRefs)
-          a.occ_addr[i] = (g >= 0 && g < a.S) ? s_tptr[t] + ((int64_t)g - s_tbo[t] * a.t.C) * s_rowb[t] : (g <= -2 ? 1 : 0);
+          a.occ_addr[i] = (g >= 0 && g < a.S) ? tptr_of(t) + ((int64_t)g - tbo_of(t) * a.t.C) * rowb_of(t) : (g <= -2 ? 1 : 0);
           continue;
         }
         a.csr_rank[i] = rk[q];                // rank inside the tile (completed by the scatter kernel)
-        a.occ_addr[i] = (g >= 0 && g < a.S) ? s_tptr[t] + ((int64_t)g - s_tbo[t] * a.t.C) * s_rowb[t] : 0;
+        a.occ_addr[i] = (g >= 0 && g < a.S) ? tptr_of(t) + ((int64_t)g - tbo_of(t) * a.t.C) * rowb_of(t) : 0;
         continue;
       }
       const int g = s_tab[hh[q]];
       const int r = s_cnt[hh[q]] + rk[q];
       a.occ_slot[i] = g;
       if (kTrain) a.csr_rank[i] = r;
-      a.occ_addr[i] = (g >= 0 && g < a.S) ? s_tptr[t] + ((int64_t)g - s_tbo[t] * a.t.C) * s_rowb[t] : 0;
+      a.occ_addr[i] = (g >= 0 && g < a.S) ? tptr_of(t) + ((int64_t)g - tbo_of(t) * a.t.C) * rowb_of(t) : 0;
       if (kTrain && g >= 0 && r == 0) ++nrep[li >> 10];
     }
   }
@@ -591,7 +603,7 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
         const int l2 = base + src;
         const int t = s_t[l2] & 0x7fff;
         const int g = s_gs[l2];
-        void* rp = reinterpret_cast<void*>((uintptr_t)(s_tptr[t] + ((int64_t)g - s_tbo[t] * a.t.C) * s_rowb[t]));
+        void* rp = reinterpret_cast<void*>((uintptr_t)(tptr_of(t) + ((int64_t)g - tbo_of(t) * a.t.C) * rowb_of(t)));
         wave_init_row(a, rp, s_key[l2], (int)a.table_emb_dims[t], (int)a.table_value_dims[t]);
       }
     }
@@ -602,7 +614,7 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     }
   }
   if (blockIdx.x == 0)
-    for (int t = threadIdx.x; t <= T; t += THREADS) a.seg_out[t] = s_seg[t];
+    for (int t = threadIdx.x; t <= T; t += THREADS) a.seg_out[t] = kPart ? (t == 0 ? 0 : a.n) : s_seg[t];
   PST(11);
 }
 
@@ -1447,7 +1459,7 @@ __device__ __forceinline__ void block_scan5(int (&v)[5], int (&tot)[5]) {
     tot[i] = s_w5[i][NW];
     v[i] = s_w5[i][w] + incl[i] - v[i];
   }
-  __syncthreads();
+  // (no trailing barrier: the one caller uses the staging array once per block)
 }
 
 // sums of two packed words over ALL predecessors of partition t (t < kPartMax = 1024 threads: one word pair per thread)
@@ -1684,7 +1696,7 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
       a.rec[r].z = (uint32_t)a.S;
       a.rec[r].w = (uint32_t)((int)rc[k].w | kRecLate);
     }
-  __syncthreads();
+  if (nd > 0) __syncthreads();      // (block uniform; without deferred keys the hash has not changed since the barrier above)
   // ---- one scan over the hash ENTRIES: local unique id, occurrence prefix, hot-list positions (entry order = unique order)
   const bool hots = hot.n_tasks != nullptr;
   int es[kP3Ent], ec[kP3Ent];
@@ -2051,6 +2063,7 @@ int mi355_demb_forward_fused(
   a.P = 0; a.spp = 1; a.pcount = aux + 64;
   a.rec = nullptr; a.rec_out = nullptr; a.rec_out4 = nullptr;
   a.tile_bags = nullptr; a.occ_trank = nullptr;
+  a.magic0 = num_buckets > 0 ? ~0ull / (uint64_t)num_buckets : 0ull;   // (one table: its buckets are all the buckets)
   {
     const int P = train ? part_count(n, num_tables) : 0;
     if (P > 0 && num_buckets >= 8 * (int64_t)P) {

@@ -68,7 +68,7 @@ int mi355i_backward_fused(const int32_t* ptr, const int32_t* csr_src, int64_t nu
                           const int64_t* row_addr, int weight_dtype, int opt_kind, float lr, float beta1, float beta2,
                           float eps, float weight_decay, int64_t iter_num, int64_t state_offset, int round_grad,
                           void* out, int64_t out_stride, int aligned16, void* workspace, int64_t workspace_bytes,
-                          const int32_t* tile_bags, hipStream_t stream);
+                          const int32_t* tile_bags, int one_feature, hipStream_t stream);
 
 // bench.py's live kernel timing (err.hip): event of slot (0 gather, 1 backward kernel), end 0 / 1
 void mi355i_prof_mark(int slot, int end, hipStream_t stream);

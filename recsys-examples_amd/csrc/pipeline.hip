@@ -192,7 +192,7 @@ int mi355_demb_backward(
   rc = mi355i_backward_fused(ptr, csr, num_keys, num_keys, nu_dev, grads, grad_stride, grad_dtype, offsets, D_offsets,
                              batch_size, dim, combiner, row_addr, value_dtype, opt_kind, lr, beta1, beta2, eps, weight_decay,
                              iter_num, state_offset, round_grad, nullptr, 0, aligned16, bws, bws_bytes,
-                             prepared ? (const int32_t*)gws : nullptr, stream);
+                             prepared ? (const int32_t*)gws : nullptr, num_bags == batch_size, stream);
   if (rc != MI355_OK) return rc;
   if (unpin)
     rc = mi355_table_update_counter(counter, counter_numel, slots, num_keys, nu_dev, -1, table_ids, table_bucket_offsets,

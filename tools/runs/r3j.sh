@@ -14,7 +14,7 @@ for f in sorted(glob.glob('$O/bench_*.json')):
         print(os.path.basename(f), round(d['ms_per_step']*1e3,1), round(d['sustained']['ms_per_step']*1e3,1), {k:round(v['ms']*1e3,1) for k,v in d['roofline']['kernels'].items()})
     except Exception as e: print(f, 'ERR', e)
 PY
-MI355_LIB=$L/librecsys_amd_stamps.so timeout 300 python tools/index_phase_stamps.py 2>&1 | sed -n '/part2 blocks/,/bwd_kernel/p' > $O/stamps.txt
+MI355_LIB=$L/librecsys_amd_stamps.so timeout 300 python tools/index_phase_stamps.py 2>&1 | cat > $O/stamps.txt
 cat $O/stamps.txt
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt
