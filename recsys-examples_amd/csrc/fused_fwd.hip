@@ -1806,12 +1806,18 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
     }
   }
   if (p == (int)a.P - 1 && threadIdx.x == 0) {
-    const int U = upre + nu, O = spre + tot2;
-    if (hots) { *hot.n_hot = (int)(pre_b >> 40) + th; *hot.n_tasks = (int)((pre_b >> 20) & 0xfffff) + tt; *hot.n_wave = (int)(pre_b & 0xfffff) + tw; }
+    int U = upre + nu;
+    const int O = spre + tot2;
+    int nh = (int)(pre_b >> 40) + th, ntk = (int)((pre_b >> 20) & 0xfffff) + tt, nwv = (int)(pre_b & 0xfffff) + tw;
+    // A record list overflowed in the probe kernel (sticky flag, a key stream that defeats the hash): the CSR of this step lacks
+    // occurrences, so NO row may be updated from it -- the step reports zero unique rows, its backward does nothing, and the
+    // module raises at its next check (the pooled output of the forward is complete: it does not depend on the records).
+    if (__hip_atomic_load(&a.hdr[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { U = 0; nh = 0; ntk = 0; nwv = 0; }
+    if (hots) { *hot.n_hot = nh; *hot.n_tasks = ntk; *hot.n_wave = nwv; }
     o.table_offsets[0] = 0;
     o.table_offsets[1] = U;
     *o.total = O;
-    ptr[U] = O;
+    if (U) ptr[U] = O;
   }
   QST(8);
   QST(9);

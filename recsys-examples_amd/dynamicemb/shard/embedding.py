@@ -144,6 +144,21 @@ class ShardedDynamicEmbeddingCollection(ShardedModule):
                 lo = hi
         return NoWait(result)
 
+    def prefetch(self, dist_input, forward_stream=None, ctx=None) -> None:
+        """ShardedModule.prefetch of TorchRec's prefetch pipeline (examples/commons/pipeline/train_pipeline.py:663-692 ->
+        lookup.prefetch -> emb_module.prefetch, corelib/dynamicemb/dynamicemb/batched_dynamicemb_tables.py:1090-1137): the
+        index stage (dedup, find, insert + first-touch init, pin) of this rank's shard for a batch whose input dist is done,
+        run on the CURRENT stream -- the pipeline's prefetch stream -- while earlier batches still compute on
+        `forward_stream`.  compute() of the same batch then only gathers (the module consumes its prefetch states in FIFO
+        order)."""
+        di = dist_input
+        while not isinstance(di, DistInput) and hasattr(di, "wait"):
+            di = di.wait()
+        if not (self.training and torch.is_grad_enabled()):
+            return
+        for lk, sk in zip(self._lookups, di.sharded_keys):
+            lk.local.module.prefetch(sk.values, sk.offsets, forward_stream)
+
     def compute_and_output_dist(self, ctx, input: DistInput):
         return self.output_dist(ctx, self.compute(ctx, input))
 

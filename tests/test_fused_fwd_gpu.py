@@ -265,6 +265,13 @@ np.save(sys.argv[3], out.detach().cpu().numpy()); np.save(sys.argv[4], rows.cpu(
     out = a(fk, foff)
     torch.cuda.synchronize()
     assert int(a._fused_aux[5]) == 1
+    # the step's CSR is incomplete, so its backward must not touch ANY row (no partial update): the step reports no uniques
+    probe_keys = torch.cat([fk[:4096], keys[:4096]])
+    f_before, rows_before = a.lookup_rows(probe_keys, 0)
+    out.backward(torch.ones_like(out))
+    torch.cuda.synchronize()
+    f_after, rows_after = a.lookup_rows(probe_keys, 0)
+    assert torch.equal(f_before, f_after) and torch.equal(rows_before, rows_after)
     served = (out.abs().sum(1) > 0)
     assert 2048 <= int(served.sum()) < n          # (the slot range holds ~13 K rows; its record list 4 x 512 records per step)
     assert _counters_clear_except_flag(a)

@@ -164,3 +164,47 @@ def test_keyed_jagged_tensor_standin_split_and_permute():
     assert s[1].keys() == ["b", "c"] and s[1].values().tolist() == [1, 2, 3, 4, 5, 6, 7] and s[0].values().tolist() == [0]
     d = kjt.to_dict()
     assert d["b"].values().tolist() == [1, 2, 3, 4, 5] and d["b"].lengths().tolist() == [2, 3]
+
+
+def _params(fn):
+    import inspect
+
+    return [p for p in inspect.signature(fn).parameters if p != "self"]
+
+
+def test_torchrec_protocol_conformance():
+    """Method and argument names of TorchRec's ShardedModule / ModuleSharder / BaseBatchedEmbedding protocols, held as data
+    (tests/golden/torchrec_protocol.json: the names the reference's pipeline / planner call and its subclasses override),
+    against the sharded modules, the sharders and the compute kernels of this package AND against the stand-in they are
+    tested on -- a stand-in that drifted from the protocol would make every plugin-surface test vacuous."""
+    import json
+    import os
+
+    import dynamicemb
+    from dynamicemb import _torchrec
+    from dynamicemb.batched_dynamicemb_compute_kernel import BatchedDynamicEmbedding, BatchedDynamicEmbeddingBag
+    from dynamicemb.shard.embedding import DynamicEmbeddingCollectionSharder, ShardedDynamicEmbeddingCollection
+    from dynamicemb.shard.embeddingbag import DynamicEmbeddingBagCollectionSharder, ShardedDynamicEmbeddingBagCollection
+
+    spec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "torchrec_protocol.json")))
+
+    def check(cls, methods, props):
+        for name, args in methods.items():
+            fn = getattr(cls, name, None)
+            assert callable(fn), f"{cls.__name__}.{name} missing"
+            have = _params(fn)
+            # the protocol's arguments, by name and in its order (extra trailing keyword arguments with defaults are fine)
+            assert have[:len(args)] == args or all(a in have for a in args), f"{cls.__name__}.{name}{tuple(have)} vs protocol {tuple(args)}"
+        for name in props:
+            assert hasattr(cls, name), f"{cls.__name__}.{name} missing"
+
+    for cls in (ShardedDynamicEmbeddingCollection, ShardedDynamicEmbeddingBagCollection):
+        check(cls, spec["ShardedModule"], spec["ShardedModule_properties"])
+    for cls in (DynamicEmbeddingCollectionSharder, DynamicEmbeddingBagCollectionSharder):
+        check(cls, spec["ModuleSharder"], spec["ModuleSharder_properties"])
+    for cls in (BatchedDynamicEmbedding, BatchedDynamicEmbeddingBag):
+        check(cls, spec["BaseBatchedEmbedding"], spec["BaseBatchedEmbedding_properties"])
+    # the pipeline calls prefetch with keywords (utils.py:1663-1667)
+    for cls in (ShardedDynamicEmbeddingCollection, ShardedDynamicEmbeddingBagCollection):
+        assert set(_params(cls.prefetch)) >= {"ctx", "dist_input", "forward_stream"}
+    assert dynamicemb is not None and _torchrec is not None

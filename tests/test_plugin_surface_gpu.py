@@ -209,3 +209,46 @@ def test_static_table_in_a_dynamic_collection_is_rejected(pg):
     plan = planner.collective_plan(holder, [sh], pg)
     with pytest.raises(NotImplementedError, match="dynamic tables only"):
         sh.shard(coll, plan.plan["ec"], ShardingEnv.from_process_group(pg), DEV)
+
+
+@pytest.mark.parametrize("ebc", [False, True])
+def test_prefetch_hook_of_the_sharded_modules(pg, ebc):
+    """ShardedModule.prefetch as TorchRec's prefetch pipeline calls it (examples/commons/pipeline/utils.py:1663-1667:
+    keywords ctx / dist_input / forward_stream, on the pipeline's prefetch stream, between input_dist and
+    compute_and_output_dist): the index stage of the batch runs ahead on a side stream, compute() then only gathers.  Three
+    training steps with the hook against three without it on identically built models: same outputs, same rows."""
+    torch.manual_seed(0)
+    dmp_a, cfgs, _ = _build(pg, ebc=ebc)
+    dmp_b, _, _ = _build(pg, ebc=ebc)
+    sa, sb = dmp_a.module.sparse, dmp_b.module.sparse
+    keys = ["fa0", "fa1", "fb", "fm"] if ebc else ["fa0", "fa1", "fb"]
+    rng = np.random.default_rng(3)
+    dmp_a.train(); dmp_b.train()
+    side = torch.cuda.Stream()
+    for it in range(3):
+        kjt = _kjt(rng, keys, 19, 700)
+        # (a) the pipeline's sequence: input dist, prefetch on the prefetch stream, compute + output dist on the default one
+        ctx = sa.create_context()
+        di = sa.input_dist(ctx, kjt).wait().wait()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            sa.prefetch(ctx=ctx, dist_input=di, forward_stream=torch.cuda.current_stream())
+        torch.cuda.current_stream().wait_stream(side)
+        out_a = sa.compute_and_output_dist(ctx, di).wait()
+        # (b) plain forward
+        out_b = sb(kjt)
+        if ebc:
+            va, vb = out_a.values(), out_b.values()
+        else:
+            va = torch.cat([out_a[k].values() for k in keys]); vb = torch.cat([out_b[k].values() for k in keys])
+        assert torch.equal(va, vb)
+        g = torch.rand_like(va) + 0.1
+        va.backward(g); vb.backward(g)
+    for ma, mb in zip(sa.dynamic_embedding_modules(), sb.dynamic_embedding_modules()):
+        assert not ma._prefetch_states          # every prefetched state was consumed by its forward
+        for name in ma._table_names:
+            ka, ra = ma.export_keys_values(name, DEV)
+            kb, rb = mb.export_keys_values(name, DEV)
+            oa, ob = torch.argsort(ka), torch.argsort(kb)
+            assert torch.equal(ka[oa], kb[ob])
+            torch.testing.assert_close(ra[oa], rb[ob], rtol=1e-6, atol=1e-6)
