@@ -66,7 +66,7 @@ def dump(fn, nblk, nph, names, title, nlive=None):
     print(f"   block life (shader cycles): avg {life.mean():.0f}  p50 {np.median(life):.0f}  max {life.max():.0f}")
     w0, w1 = d[:, nph], d[:, nph + 1]
     ok = w1 > 0
-    recent = w0 > w0.max() - 20000       # (blocks only an earlier, larger launch used keep their old stamps: drop them)
+    recent = w0 > w0.max() - 6000        # (blocks only an earlier launch used keep their old stamps: drop what is > 60 us older)
     d, w0, w1, ok, life = d[recent], w0[recent], w1[recent], ok[recent], life[recent]
     t0 = w0.min()
     SPANS.append((title.split(":")[0].split(" (")[0], w0.min() / 100.0, w1[ok].max() / 100.0))
@@ -89,8 +89,8 @@ if os.environ.get("MI355_FUSED_PART", "2") == "1":
 PART2 = ["start -> record loads issued + LDS init", "wait: barrier", "merge (LDS hash insert + counts + rank bases out)", "wait: barrier",
          "entry scan + publish sums", "look-back", "outputs per unique row", "outputs per record (CSR entries)", "-"]
 if os.environ.get("MI355_FUSED_PART", "2") != "1":
-    dump("mi355_debug_stamps_part", 1024, 10, PART2, "part2 blocks of fused_part_gather_kernel")
-    dump("mi355_debug_stamps_fgather", 16384, 2, None, "gather blocks of fused_part_gather_kernel (thread 0 of each block)")
+    dump("mi355_debug_stamps_part", 1024, 10, PART2, "fused_part3_kernel")
+    dump("mi355_debug_stamps_fgather", 16384, 2, None, "gather_pooled_late_kernel (thread 0 of each block)")
 dump("mi355_debug_stamps_gather", 16384, 2, None, "gather_pooled_pipe_kernel (thread 0 of each block)")
 dump("mi355_debug_stamps_bwd", 16384, 2, None, "bwd_kernel (thread 0 of each block)")
 
