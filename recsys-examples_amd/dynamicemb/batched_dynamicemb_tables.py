@@ -659,8 +659,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
 
     def _check_partition_flag(self):
         """The partitioned index stage gives every slot range a fixed number of (tile, key) records per step; if a range ever
-        receives more (a key stream that defeats the hash: never seen with real keys), the surplus keys of that step took no
-        part in its backward and the kernel left a sticky flag in the aux header.  Read without a sync (the flag travels to
+        receives more (a key stream that defeats the hash: never seen with real keys), that step reported zero unique rows --
+        its forward output is complete, its backward updated NO row -- and the kernel left a sticky flag in the aux header.  Read without a sync (the flag travels to
         pinned memory every 64 steps) and reported as an error: the remedy is MI355_FUSED_PART=0."""
         if torch.cuda.is_current_stream_capturing():
             return
@@ -670,7 +670,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             if int(self._part_flag_host.item()) != 0:
                 self._fused_aux[5:6].zero_()
                 raise RuntimeError("fused forward: a slot-range partition overflowed its record list in an earlier step "
-                                   "(keys of that step were left out of its backward); set MI355_FUSED_PART=0")
+                                   "(that step's backward updated no row); set MI355_FUSED_PART=0")
         if ev is None and self._step % 64 == 0:
             if getattr(self, "_part_flag_host", None) is None:
                 self._part_flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()

@@ -77,12 +77,17 @@ class RowWiseShardedLookup:
 
     def __init__(self, local, num_features: int, feature_hash_sizes: List[int], pooled: bool, pg=None,
                  device=None, out_dtype=torch.float32, dist_type_per_feature: Optional[Sequence[str]] = None,
-                 ops=None, wire_dtype: Optional[torch.dtype] = None, capacity_factor: Optional[float] = None,
+                 ops=None, wire_dtype="auto", capacity_factor: Optional[float] = None,
                  expected_keys: Optional[int] = None):
-        """wire_dtype (pooled): element type of the partial sums on the fabric.  None = fp32 (the sums of the shards are
-        added in fp32, one rounding at the end); torch.bfloat16 halves the bytes per xGMI link at the price of one more
-        rounding per shard (what TorchRec's qcomm codec does for its reduce-scatter)."""
-        self.wire_dtype = wire_dtype
+        """wire_dtype (pooled): element type of the partial sums on the fabric.  None / torch.float32 = fp32 (the sums of
+        the shards are added in fp32, one rounding at the end); torch.bfloat16 halves the bytes per xGMI link at the price
+        of one more rounding per shard (what TorchRec's qcomm codec does for its reduce-scatter).  "auto" (default): bf16
+        when the caller asked for bf16 OUTPUT -- the result is rounded to bf16 anyway, the extra error is at most half a
+        bf16 ulp of each shard's partial sum (bounded in tests/test_sharded_gpu.py; at W = 1 it is bit-identical) -- and
+        fp32 for an fp32 output, which stays bit-identical to the single-GPU sum order."""
+        if wire_dtype == "auto":
+            wire_dtype = torch.bfloat16 if (pooled and out_dtype == torch.bfloat16) else None
+        self.wire_dtype = None if wire_dtype == torch.float32 else wire_dtype
         self._comm = None
         self.pg = pg if pg is not None else dist.group.WORLD
         self.world = dist.get_world_size(self.pg)
@@ -328,7 +333,7 @@ class ShardedPooledLookup:
 
     def __init__(self, rows: int, dim: int, device, world: int, rank: int, lr: float = 0.1,
                  out_dtype=torch.bfloat16, dist_type: str = "roundrobin", mode: str = "auto",
-                 keys_per_step: Optional[int] = None, batch: Optional[int] = None, wire_dtype: Optional[torch.dtype] = None,
+                 keys_per_step: Optional[int] = None, batch: Optional[int] = None, wire_dtype="auto",
                  capacity_factor: Optional[float] = None):
         from .batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
         from .dynamicemb_config import (DynamicEmbInitializerArgs, DynamicEmbInitializerMode, DynamicEmbPoolingMode,
@@ -339,7 +344,7 @@ class ShardedPooledLookup:
             score_strategy=DynamicEmbScoreStrategy.TIMESTAMP,
             initializer_args=DynamicEmbInitializerArgs(mode=DynamicEmbInitializerMode.UNIFORM, lower=-0.01, upper=0.01))
         if mode == "auto":
-            mode = self.choose_mode(world, keys_per_step, batch, dim, out_dtype)
+            mode = self.choose_mode(world, keys_per_step, batch, dim, out_dtype, wire_dtype)
         self.mode = mode
         module = BatchedDynamicEmbeddingTablesV2(
             [opt], pooling_mode=DynamicEmbPoolingMode.SUM if mode == "partial" else DynamicEmbPoolingMode.NONE,
@@ -361,16 +366,20 @@ class ShardedPooledLookup:
         assert self.impl.world == world and self.impl.rank == rank
 
     @staticmethod
-    def choose_mode(world, keys_per_step, batch, dim, out_dtype=torch.bfloat16) -> str:
+    def choose_mode(world, keys_per_step, batch, dim, out_dtype=torch.bfloat16, wire_dtype="auto") -> str:
         """xGMI is a full mesh: what bounds an exchange is the bytes on ONE peer link per step, not the total.
-        partial: the [B, D] fp32 block of partial sums out + the [B, D] gradient block of the all-gather back, per peer,
-        whatever W is.  rows: the unique rows and their fp32 gradients of the keys a peer owns, ~ 0.45 Nt / W rows each
+        partial: the [B, D] block of partial sums out (fp32, or bf16 on the default wire of a bf16 output) + the [B, D]
+        gradient block of the all-gather back, per peer, whatever W is.  rows: the unique rows and their fp32 gradients of the keys a peer owns, ~ 0.45 Nt / W rows each
         way -- it shrinks with W but its two-level dedup / reduce costs ~0.23 ms more compute per step (measured at
-        W = 1 on one MI355X), priced here at an effective 100 GB/s per link.  C2: partial up to W = 4, rows from W = 8."""
+        W = 1 on one MI355X), priced here at an effective 100 GB/s per link.  C2: fp32 wire -> partial up to W = 4, rows from
+        W = 8; bf16 wire (the default with bf16 outputs) -> partial at every W of one node."""
         if not (keys_per_step and batch):
             return "partial"
         o = torch.empty((), dtype=out_dtype).element_size()
-        partial_link = batch * dim * (4 + o)
+        if wire_dtype == "auto":
+            wire_dtype = torch.bfloat16 if out_dtype == torch.bfloat16 else torch.float32
+        w = 4 if wire_dtype is None else torch.empty((), dtype=wire_dtype).element_size()
+        partial_link = batch * dim * (w + o)
         rows_link = 2 * 0.45 * keys_per_step * dim * 4 / world
         handicap = 0.23e-3 * 100e9
         return "rows" if rows_link + handicap < partial_link else "partial"

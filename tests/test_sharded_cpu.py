@@ -358,3 +358,16 @@ def test_fixed_capacity_overflow_is_reported():
             d(off[1:] - off[:-1], keys, offsets=off)
     finally:
         dist.destroy_process_group()
+
+
+def test_per_link_bytes_decide_the_pooled_dist_mode():
+    """xGMI is a full mesh: the dist that puts fewer bytes on ONE peer link wins.  At C2 the fp32 wire
+    keeps the reference's partial-sum dist up to W = 4 and switches to the rows-back dist at W = 8; the bf16 wire (the default
+    whenever the caller wants bf16 outputs) halves the forward block and keeps partial sums at every W of one node."""
+    from dynamicemb.sharded import ShardedPooledLookup as S
+
+    Nt, B, Dm = 360_000, 65_536, 128
+    assert [S.choose_mode(w, Nt, B, Dm, torch.bfloat16, torch.float32) for w in (2, 4, 8)] == ["partial", "partial", "rows"]
+    assert [S.choose_mode(w, Nt, B, Dm, torch.bfloat16) for w in (2, 4, 8)] == ["partial"] * 3
+    assert S.choose_mode(8, Nt, B, Dm, torch.float32) == "rows"          # fp32 outputs: fp32 wire
+    assert S.choose_mode(8, None, None, Dm) == "partial"                  # nothing known about the batch: the reference's dist
