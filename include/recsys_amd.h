@@ -371,8 +371,8 @@ int mi355_side_join(int token, hipStream_t stream);
  * 64 K .. 1 M keys and at least 8 buckets per partition take the partitioned index stage: (tile, key) records grouped by
  * slot range, one block per range merges them in LDS -- no global atomic per key, no per-slot scratch. */
 int mi355_demb_forward_fused_partitions(int64_t n, int64_t num_tables, int64_t num_buckets);
-/* Round 3: a pooled training forward of the partitioned stage returns *join_token == -2.  Its partition blocks wrote the
- * backward's CSR themselves and rode in the gather's launch; the per-occurrence outputs nothing on the training path reads --
+/* Round 3: a pooled training forward of the partitioned stage (path (c), MI355_FUSED_PART=2) returns *join_token == -2.  Its
+ * partition kernel wrote the backward's CSR itself (no scatter kernel); the per-occurrence outputs nothing on the training path reads --
  * reverse_indices (the `inverse` of segmented_unique_cuda, src/unique_op.cu:484-714) and csr_rank -- are produced by this call
  * on demand, from the step's forward workspace (untouched since the forward). */
 int mi355_demb_fused_materialize(void* workspace, int64_t workspace_bytes, int64_t num_keys, int64_t num_tables,
