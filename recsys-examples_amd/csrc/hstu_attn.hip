@@ -73,6 +73,7 @@ struct AttnArgs {
   int H, causal, group;
   int wl, wr;                  // local window: keys i - wl .. i + wr of query i (-1: unbounded on that side)
   int wskip;                   // 1: tile loops are clipped to the window's band (0: the mask alone applies it; for A/B tests)
+  int rot, max_len;            // (sequence, head) slot of a block rotates with blockIdx.z: see seq_head_of_block
   // relative attention bias (hstu_api.cpp:100-106,417-430): rab[b][h][i][j] (bf16, padded to max_seqlen_k in i and j) is
   // added to q_i . k_j before alpha and SiLU; head stride 0 = one bias matrix shared by all heads.  NULL: none.
   const uint16_t* rab; int64_t rab_b, rab_h, rab_r;
@@ -175,6 +176,27 @@ __device__ __forceinline__ int band_key_end(const AttnArgs& a, int last_row, int
   return (a.wskip && a.wr >= 0 && hi < end) ? hi : end;
 }
 
+// Block -> (sequence, head).  The grid is (H, B, blocks) and the hardware deals consecutive workgroup ids round-robin over
+// the 8 XCDs, so with b = blockIdx.y, h = blockIdx.x an XCD only ever sees the sequences of ONE residue class of
+// (h + H b) mod 8 -- at H = 4 the sequences of one parity.  On a jagged batch whose few long sequences share a parity
+// half the chip idles (C4 shape, 7 sequences of 4096 among 32: 5 odd, 2 even -> forward 830 us, 300 TFLOP/s).  Rotating
+// the slot by H per dispatch rank -- sequence b + z takes the z-th heaviest block -- deals every sequence's row blocks over
+// all XCDs: 442 us, 567 TFLOP/s on the same batch (rotation by 1 or H + 1: 632 / 503 us).  A batch whose sequences all
+// have max_len rows gains nothing and keeps the plain grid, where a (sequence, head) column stays on one XCD's L2
+// (rot < 0: rotate by -rot unless the batch is dense; rot > 0: always; 0: never).  All loads below are independent.
+struct BlockSeq { int b, h, start, end; };
+__device__ __forceinline__ BlockSeq seq_head_of_block(const AttnArgs& a) {
+  const int b0 = blockIdx.y, h0 = blockIdx.x;
+  if (a.rot == 0) return {b0, h0, a.cu_seqlens[b0], a.cu_seqlens[b0 + 1]};
+  const unsigned bh = gridDim.x * gridDim.y;
+  const unsigned step = (unsigned)(a.rot < 0 ? -a.rot : a.rot);
+  const unsigned slot = (blockIdx.x + gridDim.x * blockIdx.y + step * blockIdx.z) % bh;
+  const int b1 = (int)(slot / gridDim.x), h1 = (int)(slot - (unsigned)b1 * gridDim.x);
+  const int t0 = a.cu_seqlens[0], t1 = a.cu_seqlens[gridDim.y];
+  const int s0 = a.cu_seqlens[b0], e0 = a.cu_seqlens[b0 + 1], s1 = a.cu_seqlens[b1], e1 = a.cu_seqlens[b1 + 1];
+  const bool dense = a.rot < 0 && t1 - t0 == (int)gridDim.y * a.max_len;
+  return dense ? BlockSeq{b0, h0, s0, e0} : BlockSeq{b1, h1, s1, e1};
+}
 // Row block a query-block owner of dispatch rank `rank` takes: heaviest first = the latest rows first (causal).  With contextual
 // rows the FIRST block is the heaviest of all -- its contextual rows reach every history key -- and goes first: left at the
 // end of the order it was a 8-tile tail behind a CU's other blocks (C3 shape with 4 contextual rows: forward 66 -> 5x us).
@@ -261,10 +283,11 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
   constexpr bool QLDS = D >= HSTU_QLDS_MIN;      // Q fragments in LDS instead of 64 VGPRs (not used: 452 registers fit at d = 256)
   uint16_t* Qs = smem + (kDB ? 2 : 1) * TILE;    // [kBM][KS] (QLDS only)
 
-  const int b = blockIdx.y, h = blockIdx.x;   // grid (H, B, blocks): see launch_fwd
+  const BlockSeq bs = seq_head_of_block(a);   // grid (H, B, blocks): see launch_fwd
+  const int b = bs.b, h = bs.h;
   SeqInfo s;
-  s.start = a.cu_seqlens[b];
-  const int Lq = a.cu_seqlens[b + 1] - s.start;
+  s.start = bs.start;
+  const int Lq = bs.end - s.start;
   // keys: the same tokens (training), a longer key sequence (delta-q: the queries are its LAST Lq positions), or the
   // user's paged cache followed by the candidate tokens of k / v
   const int kstart = a.cu_seqlens_k ? a.cu_seqlens_k[b] : s.start;
@@ -749,10 +772,11 @@ __global__ void __launch_bounds__(256) hstu_fwd_dma_kernel(AttnArgs a) {
   constexpr int IPW = (kBN / RPI) / 4;  // DMA instructions per wave and tensor
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [2 buffers][K tile | V tile]
 
-  const int b = blockIdx.y, h = blockIdx.x;
+  const BlockSeq bs = seq_head_of_block(a);
+  const int b = bs.b, h = bs.h;
   SeqInfo s;
-  s.start = a.cu_seqlens[b];
-  const int Lq = a.cu_seqlens[b + 1] - s.start;
+  s.start = bs.start;
+  const int Lq = bs.end - s.start;
   const int kstart = a.cu_seqlens_k ? a.cu_seqlens_k[b] : s.start;
   s.L = a.cu_seqlens_k ? a.cu_seqlens_k[b + 1] - kstart : Lq;
   const int dq = s.L - Lq;
@@ -1199,10 +1223,11 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
   uint16_t* Qt = dOs + (kDK ? BQ * RS : 0);         // [D][TS] or [BQ][TRS]   (dK; kDK only)
   uint16_t* dOt = Qt + (kDK ? TIMG : 0);            // [D][TS] or [BQ][TRS]   (dV; kDV only)
 
-  const int b = blockIdx.y, h = blockIdx.x;   // grid (H, B, blocks): see launch_fwd
+  const BlockSeq bs = seq_head_of_block(a);   // grid (H, B, blocks): see launch_fwd
+  const int b = bs.b, h = bs.h;
   SeqInfo s;
-  s.start = a.cu_seqlens[b];
-  s.L = a.cu_seqlens[b + 1] - s.start;
+  s.start = bs.start;
+  s.L = bs.end - s.start;
   const int n0 = blockIdx.z * kBM;   // earliest key blocks (seen by most queries) first
   if (n0 >= s.L) return;
   s.has_ctx = a.num_contexts != nullptr;
@@ -1515,10 +1540,11 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
   uint16_t* Vs = Ks + BK * RS;       // [BK][RS]
   uint16_t* Kt = Vs + BK * RS;       // [D][TS] or [BK][TRS]
 
-  const int b = blockIdx.y, h = blockIdx.x;   // grid (H, B, blocks): see launch_fwd
+  const BlockSeq bs = seq_head_of_block(a);   // grid (H, B, blocks): see launch_fwd
+  const int b = bs.b, h = bs.h;
   SeqInfo s;
-  s.start = a.cu_seqlens[b];
-  s.L = a.cu_seqlens[b + 1] - s.start;
+  s.start = bs.start;
+  s.L = bs.end - s.start;
   const int nblk = (s.L + kBM - 1) / kBM;
   if ((int)blockIdx.z >= nblk) return;
   const int m0 = row_block_of_rank((int)blockIdx.z, nblk, a, b) * kBM;
@@ -1687,10 +1713,11 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_q_ds_kernel(BwdAttnAr
   uint16_t* Kt = smem;                          // [BK][TRS] row-major K tile, read transposed
   uint16_t* dSw = Kt + BK * TRS + NT * 1024 * (threadIdx.x >> 6);   // wave-private dS patch (2 KB per sub-tile)
 
-  const int b = blockIdx.y, h = blockIdx.x;
+  const BlockSeq bs = seq_head_of_block(a);
+  const int b = bs.b, h = bs.h;
   SeqInfo s;
-  s.start = a.cu_seqlens[b];
-  s.L = a.cu_seqlens[b + 1] - s.start;
+  s.start = bs.start;
+  s.L = bs.end - s.start;
   const int nblk = (s.L + kBM - 1) / kBM;
   if ((int)blockIdx.z >= nblk) return;
   const int m0 = row_block_of_rank((int)blockIdx.z, nblk, a, b) * kBM;
@@ -1822,10 +1849,11 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_v_p_kernel(BwdAttnArg
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   constexpr int BQ = HSTU_XSTEP, NT = BQ / 32;          // 32-query sub-tiles per step
   uint16_t* dOt = smem;                         // [BQ][TRS] row-major dO tile, read transposed
-  const int b = blockIdx.y, h = blockIdx.x;
+  const BlockSeq bs = seq_head_of_block(a);
+  const int b = bs.b, h = bs.h;
   SeqInfo s;
-  s.start = a.cu_seqlens[b];
-  s.L = a.cu_seqlens[b + 1] - s.start;
+  s.start = bs.start;
+  s.L = bs.end - s.start;
   const int n0 = blockIdx.z * kBM;
   if (n0 >= s.L) return;
   s.has_ctx = a.num_contexts != nullptr;
@@ -2071,6 +2099,10 @@ static thread_local int tl_wl = -1, tl_wr = -1;
 // attention bias of the call in flight on this thread (set by the *_rab entry points)
 struct RabCall { const uint16_t* rab = nullptr; int64_t rb = 0, rh = 0, rr = 0; uint16_t* drab = nullptr; int64_t db = 0, dh = 0, dr = 0; };
 static thread_local RabCall tl_rab;
+static int block_rotation(int heads) {   // MI355_HSTU_ROT (A/B): see seq_head_of_block; default -H = by a sequence per rank, jagged batches only
+  static const int v = [] { const char* e = getenv("MI355_HSTU_ROT"); return e ? atoi(e) : 0x7fffffff; }();
+  return v == 0x7fffffff ? -heads : v;
+}
 static int window_skip() {   // MI355_HSTU_WSKIP=0: keep the full tile loops under a window (A/B tests of the band clipping)
   static const int v = [] { const char* e = getenv("MI355_HSTU_WSKIP"); return e ? atoi(e) != 0 : 1; }();
   return v;
@@ -2126,7 +2158,7 @@ int mi355_hstu_attn_fwd_kv(const void* q, const void* k, const void* v, void* ou
   a.q_head = q_head_stride; a.k_head = k_head_stride; a.v_head = v_head_stride; a.o_head = o_head_stride;
   a.cu_seqlens = cu_seqlens_q; a.num_contexts = num_contexts; a.num_targets = num_targets;
   a.H = (int)num_heads; a.causal = causal; a.group = (int)target_group_size;
-  a.wl = tl_wl; a.wr = tl_wr; a.wskip = window_skip();
+  a.wl = tl_wl; a.wr = tl_wr; a.wskip = window_skip(); a.rot = block_rotation((int)num_heads); a.max_len = (int)max_seqlen_q;
   a.rab = tl_rab.rab; a.rab_b = tl_rab.rb; a.rab_h = tl_rab.rh; a.rab_r = tl_rab.rr;
   a.alpha = alpha; a.inv_scale = 1.0f / scaling_seqlen;
   a.cu_seqlens_k = cu_seqlens_k; a.kv_cache = (const uint16_t*)kv_cache; a.page_offsets = page_offsets; a.page_ids = page_ids;
@@ -2228,7 +2260,7 @@ int mi355_hstu_attn_bwd(const void* dout, const void* q, const void* k, const vo
   a.q_head = q_head_stride; a.k_head = k_head_stride; a.v_head = v_head_stride; a.o_head = 0;
   a.cu_seqlens = cu_seqlens; a.num_contexts = num_contexts; a.num_targets = num_targets;
   a.H = (int)num_heads; a.causal = causal; a.group = (int)target_group_size;
-  a.wl = tl_wl; a.wr = tl_wr; a.wskip = window_skip();
+  a.wl = tl_wl; a.wr = tl_wr; a.wskip = window_skip(); a.rot = block_rotation((int)num_heads); a.max_len = (int)max_seqlen;
   a.rab = tl_rab.rab; a.rab_b = tl_rab.rb; a.rab_h = tl_rab.rh; a.rab_r = tl_rab.rr;
   a.alpha = alpha; a.inv_scale = 1.0f / scaling_seqlen;
   g.dout = (const uint16_t*)dout; g.do_row = do_row_stride; g.do_head = do_head_stride;
