@@ -747,7 +747,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Forward with LDS-DMA staging (opt-in: MI355_HSTU_DMA=1; head dim 256, contiguous keys).  Same GEMMs, masks and register
+// Forward with LDS-DMA staging (the default at head dim 256 with contiguous keys; MI355_HSTU_DMA=0 turns it off).  Same GEMMs, masks and register
 // layouts as hstu_fwd_kernel; what differs is how a (K, V) tile reaches LDS.  The stamps of the register-staged kernel
 //  put 1.2 K cycles per tile into issuing 16 global loads per wave and 0.9 K into writing the
 // prefetched registers to LDS (K rows + the transposing V commit), against 2 K cycles of MFMA; `global_load_lds_dwordx4`
@@ -2046,7 +2046,7 @@ static int launch_bwd(BwdAttnArgs g, int B, int max_seqlen, hipStream_t stream) 
   return MI355_OK;
 }
 
-// opt-in (MI355_HSTU_DMA=1): the LDS-DMA staged forward; head dim 256, contiguous keys, no bias
+// the LDS-DMA staged forward (default; MI355_HSTU_DMA=0 = register-staged): head dim 256, contiguous keys, no bias
 template <int D>
 static int launch_fwd_dma(const AttnArgs& a, int B, int max_seqlen, hipStream_t stream) {
   const size_t smem = (size_t)2 * 2 * kBN * D * sizeof(uint16_t);
@@ -2163,7 +2163,7 @@ int mi355_hstu_attn_fwd_kv(const void* q, const void* k, const void* v, void* ou
   a.alpha = alpha; a.inv_scale = 1.0f / scaling_seqlen;
   a.cu_seqlens_k = cu_seqlens_k; a.kv_cache = (const uint16_t*)kv_cache; a.page_offsets = page_offsets; a.page_ids = page_ids;
   a.last_page_lens = last_page_lens; a.page_size = (int)page_size;
-  static const int use_dma = getenv("MI355_HSTU_DMA") ? atoi(getenv("MI355_HSTU_DMA")) : 0;
+  static const int use_dma = getenv("MI355_HSTU_DMA") ? atoi(getenv("MI355_HSTU_DMA")) : 1;   // default since round 3: +4..9 % on every d = 256 shape measured
   if (use_dma && head_dim == 256 && !a.kv_cache && !a.rab) return launch_fwd_dma<256>(a, (int)batch, (int)max_seqlen_q, stream);
   switch (head_dim) {
     case 32: return launch_fwd<32>(a, (int)batch, (int)max_seqlen_q, stream);

@@ -23,7 +23,7 @@ from torch import nn
 
 import dynamicemb_extensions as ext
 import mi355_native as N
-from mi355_native import c_f, c_p, c_u64, check, dt, lib, ptr, stream
+from mi355_native import c_f, c_p, c_u64, check, current_torch_stream, dt, lib, ptr, stream
 
 from .dynamicemb_config import (DynamicEmbCheckMode, DynamicEmbInitializerMode, DynamicEmbPoolingMode,
                                 DynamicEmbScoreStrategy, DynamicEmbTableOptions, EmbOptimType,
@@ -547,7 +547,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             self._fill_host = torch.zeros(self.num_tables, dtype=torch.int64).pin_memory()
         self._fill_host.copy_(ext.segmented_sum_cuda(tb.bucket_sizes, tb.table_bucket_offsets_), non_blocking=True)
         self._fill_event = torch.cuda.Event()
-        self._fill_event.record()
+        self._fill_event.record(current_torch_stream())
 
     def _expand(self, new_caps) -> None:
         """rehash into a table of `new_caps` rows per table (key_value_table.py:559-666: export, re-insert with the stored
@@ -676,7 +676,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                 self._part_flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
             self._part_flag_host.copy_(self._fused_aux[5:6], non_blocking=True)
             self._part_flag_event = torch.cuda.Event()
-            self._part_flag_event.record()
+            self._part_flag_event.record(current_torch_stream())
 
     def _backward_fused(self, st, grads: torch.Tensor):
         grads = grads.contiguous()
@@ -941,13 +941,13 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             return
         _, st = self._forward_impl(indices, offsets, train=True, prefetch_only=True)
         st.event = torch.cuda.Event()
-        st.event.record()
+        st.event.record(current_torch_stream())
         st.indices = indices   # keeps the key tensor alive until the forward
         self._prefetch_states.append(st)
 
     def _gather_prefetched(self, st):
         if st.event is not None:
-            torch.cuda.current_stream().wait_event(st.event)
+            current_torch_stream().wait_event(st.event)
         dev = self.device_
         pooled = self.pooling_mode != DynamicEmbPoolingMode.NONE
         al = all(d % 4 == 0 for d in self.dims) and all(v % 4 == 0 for v in self.value_dims)

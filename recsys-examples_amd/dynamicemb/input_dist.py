@@ -21,6 +21,11 @@ import torch.distributed as dist
 DIST_TYPES = {"continuous": 0, "roundrobin": 1, "hash_roundrobin": 2}
 
 
+
+def _cur_stream():
+    from mi355_native import current_torch_stream     # (GPU tensors only)
+    return current_torch_stream()
+
 class TorchGlue:
     """Index bookkeeping of the exchange in plain torch (device agnostic): the base of every `ops` backend.  HipOps
     overrides each method with ONE launch; the CPU test backend inherits these."""
@@ -122,7 +127,7 @@ class HipOps(TorchGlue):
     def peer_splits_begin(self, send_offsets, recv_offsets, per_peer, world):
         """launch the per-peer key counts into pinned host memory (a small ring: a later dist may start before an earlier one
         has been read); peer_splits_end() waits for exactly this launch and reads them"""
-        from mi355_native import check, lib, ptr, stream
+        from mi355_native import check, current_torch_stream, lib, ptr, stream
 
         ring = getattr(self, "_splits_ring", None)
         if ring is None or ring[0].numel() < 2 * world:
@@ -133,7 +138,7 @@ class HipOps(TorchGlue):
         # the kernel writes straight into pinned host memory; the host waits for an event, not for a copy
         check(lib().mi355_peer_splits(ptr(send_offsets), ptr(recv_offsets), per_peer, world, ptr(buf), stream()), "peer_splits")
         ev = torch.cuda.Event()
-        ev.record()
+        ev.record(current_torch_stream())
         return buf, ev, world
 
     def peer_splits_end(self, handle):
@@ -380,7 +385,7 @@ class RwSparseFeaturesDist:
                 self._overflow_host = torch.zeros(1, dtype=torch.bool).pin_memory()
             self._overflow_host.copy_(self._overflow, non_blocking=True)
             self._overflow_event = torch.cuda.Event()
-            self._overflow_event.record()
+            self._overflow_event.record(_cur_stream())
         self.unbucketize_permute_tensor = perm_p
         recv_lengths = torch.empty_like(lens)
         dist.all_to_all_single(recv_lengths, lens, group=self._pg)

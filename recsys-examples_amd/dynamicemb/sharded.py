@@ -29,6 +29,16 @@ import torch.distributed as dist
 from .input_dist import HipOps, RwSparseFeaturesDist, ShardedKeys
 
 
+def current_torch_stream():
+    from mi355_native import current_torch_stream as f     # (GPU paths only; the gloo tests never get here)
+    return f()
+
+
+def on_stream(s):
+    from mi355_native import on_stream as c
+    return c(s)
+
+
 @dataclass
 class _ShardedCtx:
     keys: ShardedKeys
@@ -52,7 +62,7 @@ class PendingKeys:
         if self._comm is None:
             self._sk = self._dist.finish(state)
             return
-        with torch.cuda.stream(self._comm):
+        with on_stream(self._comm):
             sk = self._dist.finish(state)
             ev = torch.cuda.Event()
             ev.record(self._comm)
@@ -64,7 +74,7 @@ class PendingKeys:
     def wait(self):
         self.finish()
         if self._event is not None:
-            torch.cuda.current_stream().wait_event(self._event)
+            current_torch_stream().wait_event(self._event)
             self._event = None
         return self._sk
 
@@ -123,16 +133,16 @@ class RowWiseShardedLookup:
             return PendingKeys(self.dist_input(values, offsets, collapse_batch, lengths))
         if self._comm is None:
             self._comm = torch.cuda.Stream(device=values.device)
-        cur = torch.cuda.current_stream()
+        cur = current_torch_stream()
         self._comm.wait_stream(cur)       # the batch tensors were produced on the caller's stream
         for t in (values, offsets, lengths):
             if t is not None and t.is_cuda:
                 t.record_stream(self._comm)   # ... and are read on the exchange stream: the allocator must not recycle them earlier
         if two_phase:
-            with torch.cuda.stream(self._comm):
+            with on_stream(self._comm):
                 state = self.input_dist(lengths, values, collapse_batch, offsets=offsets, two_phase=True)
             return PendingKeys(None, dist=self.input_dist, state=state, comm=self._comm, consumer=cur)
-        with torch.cuda.stream(self._comm):
+        with on_stream(self._comm):
             sk = self.dist_input(values, offsets, collapse_batch, lengths)
             ev = torch.cuda.Event()
             ev.record(self._comm)

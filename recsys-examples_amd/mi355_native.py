@@ -216,6 +216,31 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _cur_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
+def current_torch_stream():
+    """torch.cuda.current_stream() of the current device WITHOUT the device-availability probe the default-argument form
+    runs (torch.cuda.is_available -> hipGetDeviceCount, 5-10 us per call; the sharded step made ~7 such calls)."""
+    if _cur_device is not None:
+        return torch.cuda.current_stream(_cur_device())
+    return torch.cuda.current_stream()
+
+
+class on_stream:
+    """`with torch.cuda.stream(s):` for a stream of the CURRENT device, without StreamContext's availability probes."""
+    __slots__ = ("s", "prev")
+
+    def __init__(self, s):
+        self.s = s
+
+    def __enter__(self):
+        self.prev = current_torch_stream()
+        torch.cuda.set_stream(self.s)
+        return self.s
+
+    def __exit__(self, *exc):
+        torch.cuda.set_stream(self.prev)
+        return False
+
+
 def stream() -> ctypes.c_void_p:
     """current HIP stream of the current device.  (torch.cuda.current_stream() costs ~6 us of Python per call -- ten native
     calls per step made that a visible part of the sharded step's host time; the raw-stream query is a plain C call.)"""
