@@ -251,6 +251,10 @@ int mi355_permute_bags(int64_t num_sources, int64_t num_features, int64_t batch_
  * pooled output dist (TorchRec RwPooledEmbeddingSharding reduce-scatter, planner/rw_sharding.py:191-261). */
 int mi355_sum_chunks(const float* in, int64_t chunks, int64_t numel_per_chunk, void* out, int out_dtype,
                      hipStream_t stream);
+/* the same for chunks in a 16-bit wire type (TorchRec's qcomm codec on the reduce-scatter: the shards' partial sums cross the
+ * fabric in bf16 / fp16, fbgemm_gpu quantize_comm; here the sum reads them directly, fp32 accumulation) */
+int mi355_sum_chunks_typed(const void* in, int in_dtype, int64_t chunks, int64_t numel_per_chunk, void* out, int out_dtype,
+                           hipStream_t stream);
 
 
 /* gather_embedding_pooled, src/dynamic_emb_op.cu:106-133 (kernels lookup_kernel.cuh:859-998).

@@ -1024,6 +1024,68 @@ __global__ void __launch_bounds__(1024) scan64_tiles_kernel(const int64_t* __res
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = tile_prefix[gridDim.x];
 }
 
+// Single-pass form (round 3): ONE launch instead of three.  Every block scans its tile, publishes the tile's sum in one
+// 64-bit word (status in the top bits; the value travels IN the word, so no fence), and the first wave walks back over its
+// predecessors' words -- 64 at a time, all polled at once -- until it meets one that already knows its inclusive prefix
+// (decoupled look-back; blocks are dispatched in index order, so a predecessor is always resident or finished).  The status
+// words are all-zero between calls: the block that finishes LAST (ticket) clears them and the ticket.
+constexpr unsigned long long kS64Agg = 1ull << 62, kS64Pre = 2ull << 62, kS64Mask = 3ull << 62;
+__global__ void __launch_bounds__(1024) scan64_chained_kernel(const int64_t* __restrict__ in, int64_t n, int64_t* __restrict__ out,
+                                                              unsigned long long* __restrict__ state, int* __restrict__ ticket) {
+  __shared__ unsigned long long s_pre;
+  __shared__ int s_last;
+  const int t = blockIdx.x;
+  const int64_t i0 = (int64_t)t * kScan64Tile + threadIdx.x * 4;
+  int64_t x[4], v = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { x[k] = i0 + k < n ? in[i0 + k] : 0; v += x[k]; }
+  int64_t tot;
+  const int64_t incl = block_incl_scan_i64(v, tot);
+  if (threadIdx.x == 0)
+    __hip_atomic_store(state + t, (t == 0 ? kS64Pre : kS64Agg) | (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x < 64) {
+    unsigned long long run = 0;
+    for (int pos = t - 1; t > 0;) {
+      const int idx = pos - (int)threadIdx.x;
+      unsigned long long w = idx >= 0 ? __hip_atomic_load(state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kS64Pre;
+      while ((w & kS64Mask) == 0) {
+        __builtin_amdgcn_s_sleep(1);
+        w = __hip_atomic_load(state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const unsigned long long pre = __ballot((w & kS64Mask) == kS64Pre);
+      const int first = pre ? __builtin_ctzll(pre) : 64;     // nearest predecessor of this round with an inclusive prefix
+      unsigned long long val = (int)threadIdx.x <= first ? (w & ~kS64Mask) : 0ull;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t lo = __shfl_xor((int)(uint32_t)val, off, 64), hi = __shfl_xor((int)(uint32_t)(val >> 32), off, 64);
+        val += ((unsigned long long)hi << 32) | lo;
+      }
+      run += val;
+      if (first < 64) break;
+      pos -= 64;
+    }
+    if (threadIdx.x == 0) {
+      if (t > 0) __hip_atomic_store(state + t, kS64Pre | (run + (unsigned long long)tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_pre = run;
+    }
+  }
+  __syncthreads();
+  int64_t run = (int64_t)s_pre + incl - v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { if (i0 + k < n) out[i0 + k] = run; run += x[k]; }
+  if (t == (int)gridDim.x - 1 && threadIdx.x == 0) out[n] = (int64_t)s_pre + tot;
+  // ---- the last block to get here has no reader left behind it: it clears the words for the next call
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (s_last) {
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 1024) state[i] = 0ull;
+    if (threadIdx.x == 0) *ticket = 0;
+  }
+}
+
 }  // namespace mi355
 
 using namespace mi355;
@@ -1031,18 +1093,20 @@ STAMP_EXPORT(mi355_debug_stamps_scatter, g_st_scatter)
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
-// library-owned scratch for the tile sums of the long int64 scan (grown on demand; one process drives one GPU)
-// Tile sums of the multi-block int64 scan.  One buffer per host thread, grown on demand (hipFree synchronises the
-// device, so a buffer still in use is never released under a running kernel).  Callers on ONE thread must not run the
-// scans of two streams concurrently; the sharded path issues them on a single stream.  Not hipGraph-capturable while
-// it grows -- warm the path up once before capturing.
+// Library-owned look-back words of the long int64 scan (+ its ticket in the word in front of them): one buffer per host
+// thread, grown on demand and ZERO between calls (the kernel's last block clears what the call used; a fresh buffer is
+// cleared here).  hipFree synchronises the device, so a buffer still in use is never released under a running kernel.
+// Callers on ONE thread must not run the scans of two streams concurrently; the sharded path issues them on a single
+// stream.  Not hipGraph-capturable while it grows -- warm the path up once before capturing.
 static int64_t* scan64_scratch(int64_t words) {
   static thread_local int64_t* p = nullptr;
   static thread_local int64_t cap = 0;
   if (words > cap) {
     if (p) (void)hipFree(p);
     cap = words < 8192 ? 8192 : 2 * words;
-    if (hipMalloc(&p, cap * sizeof(int64_t)) != hipSuccess) { p = nullptr; cap = 0; }
+    if (hipMalloc(&p, cap * sizeof(int64_t)) != hipSuccess || hipMemset(p, 0, cap * sizeof(int64_t)) != hipSuccess) {
+      p = nullptr; cap = 0;
+    }
   }
   return p;
 }
@@ -1078,11 +1142,24 @@ static int scan_i64(const int64_t* in, int64_t n, int64_t* out, hipStream_t stre
     return MI355_OK;
   }
   const int64_t nt = ceil_div(n, kScan64Tile);
-  int64_t* sc = scan64_scratch(2 * nt + 2);
+  int64_t* sc = scan64_scratch(nt + 2);
   if (!sc) { mi355_set_error("scan scratch allocation failed"); return MI355_ELAUNCH; }
-  hipLaunchKernelGGL(scan64_tile_sums_kernel, dim3((unsigned)nt), dim3(1024), 0, stream, in, n, sc);
-  hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, stream, sc, nt, sc + nt);
-  hipLaunchKernelGGL(scan64_tiles_kernel, dim3((unsigned)nt), dim3(1024), 0, stream, in, n, sc + nt, out);
+  static const int three = getenv("MI355_SCAN3") ? atoi(getenv("MI355_SCAN3")) : 0;   // (A/B: the three-launch form)
+  if (three) {
+    static thread_local int64_t* sc3 = nullptr;
+    static thread_local int64_t cap3 = 0;
+    if (2 * nt + 2 > cap3) {
+      if (sc3) (void)hipFree(sc3);
+      cap3 = 4 * nt + 8192;
+      if (hipMalloc(&sc3, cap3 * sizeof(int64_t)) != hipSuccess) { sc3 = nullptr; cap3 = 0; mi355_set_error("scan scratch allocation failed"); return MI355_ELAUNCH; }
+    }
+    hipLaunchKernelGGL(scan64_tile_sums_kernel, dim3((unsigned)nt), dim3(1024), 0, stream, in, n, sc3);
+    hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, stream, sc3, nt, sc3 + nt);
+    hipLaunchKernelGGL(scan64_tiles_kernel, dim3((unsigned)nt), dim3(1024), 0, stream, in, n, sc3 + nt, out);
+    return MI355_OK;
+  }
+  hipLaunchKernelGGL(scan64_chained_kernel, dim3((unsigned)nt), dim3(1024), 0, stream, in, n, out, (unsigned long long*)(sc + 2),
+                     (int*)sc);
   return MI355_OK;
 }
 

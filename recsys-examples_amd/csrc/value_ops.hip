@@ -361,6 +361,16 @@ sum_chunks_kernel(const float* __restrict__ in, int64_t chunks, int64_t n, void*
     st4<DDT>(out, i, acc);
   }
 }
+// the same for chunks that crossed the fabric in a 16-bit wire type (fp32 accumulation, one rounding at the end)
+template <int SDT, int DDT>
+__global__ void __launch_bounds__(256)
+sum_chunks_typed_kernel(const void* __restrict__ in, int64_t chunks, int64_t n, void* out) {
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t c = 0; c < chunks; ++c) add4(acc, ld4<SDT>(in, c * n + i));
+    st4<DDT>(out, i, acc);
+  }
+}
 
 }  // namespace mi355
 
@@ -535,6 +545,20 @@ int mi355_sum_chunks(const float* in, int64_t chunks, int64_t numel_per_chunk, v
                        numel_per_chunk, out);
     MI355_LAUNCH_CHECK();
     return MI355_OK;
+  });
+}
+
+int mi355_sum_chunks_typed(const void* in, int in_dtype, int64_t chunks, int64_t numel_per_chunk, void* out, int out_dtype,
+                           hipStream_t stream) {
+  MI355_CHECK_ARG(numel_per_chunk % 4 == 0, "chunk size must be a multiple of 4 elements");
+  if (numel_per_chunk == 0) return MI355_OK;
+  return MI355_DISPATCH_DTYPE(in_dtype, Sd, [&] {
+    return MI355_DISPATCH_DTYPE(out_dtype, Dd, [&] {
+      hipLaunchKernelGGL((sum_chunks_typed_kernel<Sd, Dd>), dim3(grid_for(numel_per_chunk, 1024)), dim3(256), 0, stream, in,
+                         chunks, numel_per_chunk, out);
+      MI355_LAUNCH_CHECK();
+      return MI355_OK;
+    });
   });
 }
 

@@ -184,7 +184,11 @@ class HipOps(TorchGlue):
         from mi355_native import check, dt, lib, ptr, stream
 
         out = torch.empty(x.shape[1:], dtype=out_dtype, device=x.device)
-        check(lib().mi355_sum_chunks(ptr(x), x.size(0), out.numel(), ptr(out), dt(out_dtype), stream()), "sum_chunks")
+        if x.dtype == torch.float32:
+            check(lib().mi355_sum_chunks(ptr(x), x.size(0), out.numel(), ptr(out), dt(out_dtype), stream()), "sum_chunks")
+        else:     # chunks in the wire type: read as they arrived, fp32 accumulation
+            check(lib().mi355_sum_chunks_typed(ptr(x), dt(x.dtype), x.size(0), out.numel(), ptr(out), dt(out_dtype), stream()),
+                  "sum_chunks")
         return out
 
     def gather_rows(self, src, index):

@@ -158,13 +158,13 @@ class RowWiseShardedLookup:
     def dist_output(self, sk, out_local: torch.Tensor, bucketized: bool = False) -> torch.Tensor:
         W, B = self.world, sk.batch_size
         if self.pooled:
-            # out_local [W*B, total_D] fp32: block p belongs to rank p's samples
-            assert out_local.dtype == torch.float32 and out_local.size(0) == W * B
-            send = out_local.contiguous() if self.wire_dtype is None else out_local.to(self.wire_dtype)
+            # out_local [W*B, total_D] partial sums (fp32, or already in the wire type): block p belongs to rank p's samples
+            assert out_local.size(0) == W * B
+            wire = self.wire_dtype or torch.float32
+            send = out_local.contiguous() if out_local.dtype == wire else out_local.to(wire)
             recv = torch.empty_like(send)
             dist.all_to_all_single(recv, send, group=self.pg)
-            if self.wire_dtype is not None:
-                recv = recv.float()
+            # (the sum reads the chunks in the wire type and accumulates in fp32: no conversion pass on either side)
             return self.ops.sum_chunks(recv.view(W, B * out_local.size(1)), self.out_dtype).view(B, out_local.size(1))
         D = out_local.size(1)
         # rows come out in (f, src, b) order; send them back in the order they arrived: (src, f, b)
@@ -356,9 +356,14 @@ class ShardedPooledLookup:
         if mode == "auto":
             mode = self.choose_mode(world, keys_per_step, batch, dim, out_dtype, wire_dtype)
         self.mode = mode
+        if wire_dtype == "auto":
+            wire_dtype = torch.bfloat16 if out_dtype == torch.bfloat16 else torch.float32
+        # partial sums leave the pooling kernel in the wire type (fp32 accumulation inside it, one rounding at its store):
+        # no conversion pass between the lookup and the exchange
+        local_dtype = wire_dtype if (mode == "partial" and wire_dtype is not None) else torch.float32
         module = BatchedDynamicEmbeddingTablesV2(
             [opt], pooling_mode=DynamicEmbPoolingMode.SUM if mode == "partial" else DynamicEmbPoolingMode.NONE,
-            output_dtype=torch.float32, device=device, optimizer=EmbOptimType.SGD, learning_rate=lr)
+            output_dtype=local_dtype, device=device, optimizer=EmbOptimType.SGD, learning_rate=lr)
         module.train()
         # with RCCL's streams in the process the side stream of the early CSR build shares a hardware queue with the main
         # one and serialises (measured: no gain, +10 us of event edges): group in the backward here

@@ -66,6 +66,7 @@ _SIGS = {
     "mi355_permute_lengths": [c_i64, c_i64, c_i64, c_p, c_p, c_p],
     "mi355_permute_bags": [c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p],
     "mi355_sum_chunks": [c_p, c_i64, c_i64, c_p, c_int, c_p],
+    "mi355_sum_chunks_typed": [c_p, c_int, c_i64, c_i64, c_p, c_int, c_p],
     "mi355_exclusive_offsets": [c_p, c_i64, c_p, c_p],
     "mi355_peer_splits": [c_p, c_p, c_i64, c_i64, c_p, c_p],
     "mi355_chunk_bags": [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p],

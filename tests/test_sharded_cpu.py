@@ -70,7 +70,7 @@ class NumpyOps(_glue_base()):
         return out
 
     def sum_chunks(self, x, out_dtype):
-        return x.sum(0).to(out_dtype)
+        return x.float().sum(0).to(out_dtype)
 
     def gather_rows(self, src, index):
         return src[index]

@@ -53,6 +53,19 @@ def test_permute_bags(S, F, B, maxlen, width):
     assert np.array_equal(back.cpu().numpy(), data)
 
 
+@pytest.mark.parametrize("n", [16_385, 300_000, 5_000_001])
+def test_single_pass_offsets_scan_repeats_cleanly(n):
+    """the chained one-launch scan (decoupled look-back over the tile sums): more tiles than resident blocks, and its status
+    words are clean again after every call -- three calls in a row on different data give three right answers"""
+    from dynamicemb.input_dist import HipOps, TorchGlue
+
+    rng = np.random.default_rng(n)
+    hip, ref = HipOps(), TorchGlue()
+    for rep in range(3):
+        lengths = torch.from_numpy(rng.integers(0, 1 << (10 * rep + 4), n).astype(np.int64)).cuda()
+        assert torch.equal(hip.exclusive_offsets(lengths), ref.exclusive_offsets(lengths))
+
+
 @pytest.mark.parametrize("n", [0, 1, 7, 1024, 4097, 300_000])
 def test_exchange_glue_kernels_match_torch(n):
     """exclusive_offsets / peer_splits / chunk_bags (one launch each) against the torch bookkeeping they replace"""
@@ -91,6 +104,20 @@ def test_sum_chunks(chunks, n, dtype):
     for c in range(1, chunks):  # same left-to-right fp32 order as the kernel
         ref += x[c]
     assert torch.equal(out, ref.to(dtype))
+
+
+@pytest.mark.parametrize("wire", [torch.bfloat16, torch.float16])
+def test_sum_chunks_reads_the_wire_type(wire):
+    """partial sums that crossed the fabric in a 16-bit type are summed as they arrived: fp32 accumulation, one rounding"""
+    from dynamicemb.input_dist import HipOps
+
+    x = torch.randn(8, 65536 + 4, device="cuda").to(wire)
+    for dtype in (torch.float32, torch.bfloat16):
+        out = HipOps().sum_chunks(x, dtype)
+        ref = x[0].float()
+        for c in range(1, 8):
+            ref += x[c].float()
+        assert torch.equal(out, ref.to(dtype))
 
 
 def _free_port():
