@@ -62,7 +62,8 @@ class _StepCtx:
     """What one forward leaves for its backward (the reference's PrefetchState + autograd ctx)."""
 
     __slots__ = ("rev", "uoff", "tids", "slots", "row_addr", "offsets", "num_keys", "batch_size", "num_bags", "csr_cnt",
-                 "csr_rank", "pinned", "event", "indices", "bwd_ws", "ring", "token", "__weakref__")
+                 "csr_rank", "pinned", "event", "indices", "bwd_ws", "ring", "token", "tier_pins", "fwd_addr", "scratch",
+                 "__weakref__")
 
     def release_ring(self):
         """hand the early-CSR ring slot back (after the backward, or when the step is dropped without one)"""
@@ -363,6 +364,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         from collections import deque
 
         self._prefetch_states = deque()
+        self._tier_prefetched = 0      # prefetched batches of the tier / admission paths whose backward has not run yet
 
     # ---------------------------------------------------------------------------------- helpers
     def set_score(self, score: int) -> None:
@@ -420,19 +422,15 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         offsets = offsets.to(torch.int64).contiguous()
         if indices.dtype != torch.int64:
             indices = indices.to(torch.int64)
-        if self.storage_mode == "hybrid":
-            if prefetch_only:
-                raise NotImplementedError("prefetch() with hybrid storage")
-            return self._forward_hybrid(indices, offsets, train)
-        if self._admit_strategy is not None and train:
-            if prefetch_only:
-                raise NotImplementedError("prefetch() with an admission strategy")
-            return self._forward_admission(indices, offsets)
         if not prefetch_only and train and self._prefetch_states:
             st = self._prefetch_states.popleft()
             if st.num_keys != indices.numel() or st.num_bags != offsets.numel() - 1:
                 raise RuntimeError("forward() received a batch that was not the oldest prefetched one")
             return self._gather_prefetched(st), st
+        if self.storage_mode == "hybrid":
+            return self._forward_hybrid(indices, offsets, train, prefetch_only)
+        if self._admit_strategy is not None and train:
+            return self._forward_admission(indices, offsets, prefetch_only)
         if self._growth and train:
             self._maybe_grow(indices.numel())
         if self._fused and self.table.capacity_ < (1 << 31) - 512:   # (a table grown past 32-bit slot ids takes the per-op chain)
@@ -712,12 +710,18 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         st.release_ring()
 
     # ---------------------------------------------------------------------------------- hybrid tiers
-    def _forward_hybrid(self, indices: torch.Tensor, offsets: torch.Tensor, train: bool):
+    def _forward_hybrid(self, indices: torch.Tensor, offsets: torch.Tensor, train: bool, prefetch_only: bool = False):
         """HybridStorage forward (key_value_table.py:2107-2403, _prefetch path of batched_dynamicemb_function.py:298-556):
         find in the HBM tier, then the host tier; unseen keys enter the HBM tier, its evictions spill (key, score, row)
         to the host tier, keys the HBM tier cannot take go to the host tier directly.  Orchestrated from Python over the
         per-op C ABI (it needs the miss counts on the host, as the reference does); the result is one row address per
-        unique key, after which gather and backward are the same launches as for HBM-only storage."""
+        unique key, after which gather and backward are the same launches as for HBM-only storage.
+
+        prefetch_only (_prefetch_cache_path, batched_dynamicemb_function.py:298-556): the tier walk of a LATER batch, no
+        gather.  Every row it resolved -- in either tier -- is pinned (ref counters of that tier's table) until the batch's
+        backward, so the evictions of the batches prefetched after it cannot move it; and while prefetched batches are
+        outstanding no key is PROMOTED from the host tier (a promotion moves a row, and an outstanding step may hold its
+        host address): promotion resumes with the first forward that finds the queue empty."""
         from .scored_hashtable import ScoreArg
 
         n = indices.numel()
@@ -730,7 +734,10 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         st.offsets, st.num_keys, st.batch_size, st.num_bags = offsets, n, B, num_bags
         st.tids = st.slots = None
         st.pinned, st.event = False, None
-        if pooled:
+        pins = []      # prefetch_only: (tier table, slots, table ids) of every row this batch resolved
+        if prefetch_only:
+            out, combiner = None, -2
+        elif pooled:
             out = torch.empty(B, self.total_D, dtype=self.output_dtype, device=dev)
             combiner = 0 if self.pooling_mode == DynamicEmbPoolingMode.SUM else 1
         else:
@@ -753,6 +760,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             hit0 = f0.nonzero().squeeze(1)
             if hit0.numel():
                 addr[hit0] = ext.row_addresses(s0[hit0], tids[hit0], self.table_ptrs, self.table_value_dims, eb)
+                if prefetch_only:
+                    pins.append((self.table, s0[hit0].contiguous(), tids[hit0].contiguous()))
             miss = (~f0).nonzero().squeeze(1)
             if miss.numel():
                 k1, t1 = uk[miss].contiguous(), tids[miss].contiguous()
@@ -762,8 +771,12 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                 if hit1.numel():
                     addr[miss[hit1]] = ext.row_addresses(s1[hit1], t1[hit1], self.table_ptrs_host, self.table_value_dims, eb)
                 new = miss[(~f1).nonzero().squeeze(1)]
-                # cache mode: host-tier hits are promoted into the HBM tier together with the unseen keys
-                prom = miss[hit1] if (train and self._promote) else miss[:0]
+                # cache mode: host-tier hits are promoted into the HBM tier together with the unseen keys (never while a
+                # prefetched batch is outstanding: it may hold the host address of the row a promotion would move)
+                may_promote = train and self._promote and not prefetch_only and self._tier_prefetched == 0
+                prom = miss[hit1] if may_promote else miss[:0]
+                if prefetch_only and hit1.numel():
+                    pins.append((self.table_host, s1[hit1].contiguous(), t1[hit1].contiguous()))
                 cand = torch.cat([new, prom]) if prom.numel() else new
                 if train and cand.numel():
                     kn, tn = uk[cand].contiguous(), tids[cand].contiguous()
@@ -792,6 +805,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                     if okn.numel():
                         addr[cand[okn]] = ext.row_addresses(idxn[okn].contiguous(), tn[okn].contiguous(), self.table_ptrs,
                                                             self.table_value_dims, eb)
+                        if prefetch_only:
+                            pins.append((self.table, idxn[okn].contiguous(), tn[okn].contiguous()))
                     if prom.numel():
                         pok = (idxn[n_new:] >= 0).nonzero().squeeze(1)   # promoted keys the HBM tier accepted
                         if pok.numel():
@@ -815,6 +830,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                         if okb.numel():
                             addr[new[bad[okb]]] = ext.row_addresses(sh[okb].contiguous(), tn[:n_new][bad[okb]].contiguous(),
                                                                     self.table_ptrs_host, self.table_value_dims, eb)
+                            if prefetch_only:
+                                pins.append((self.table_host, sh[okb].contiguous(), tn[:n_new][bad[okb]].contiguous()))
                     if n_new:
                         mode, p = self._init_params()
                         a_new = addr[new].contiguous()
@@ -822,6 +839,10 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                                       self.embedding_dtype, self.max_D, max(self.value_dims), skip=(a_new == 0),
                                       table_ids=tn[:n_new].contiguous(), table_emb_dims=self.table_emb_dims,
                                       table_value_dims=self.table_value_dims)
+        if prefetch_only:
+            self._pin_tier_rows(st, pins)
+            self._step += 1
+            return None, st
         al = all(d % 4 == 0 for d in self.dims) and all(v % 4 == 0 for v in self.value_dims)
         if pooled:
             check(lib().mi355_gather_pooled(None, 0, ptr(st.row_addr), dt(self.embedding_dtype), ptr(st.rev), n, ptr(offsets),
@@ -834,7 +855,24 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             self._step += 1
         return out, st
 
-    def _forward_admission(self, indices: torch.Tensor, offsets: torch.Tensor):
+    def _pin_tier_rows(self, st, pins) -> None:
+        """rows a prefetched batch resolved through the Python-orchestrated paths (tiers, admission): pinned in their tier's
+        table until the batch's backward (_release_tier_rows), like the `pinned` steps of the one-call pipeline"""
+        for table, slots, tids in pins:
+            table.increment_counter(slots, tids)
+        st.tier_pins = pins
+        self._tier_prefetched += 1
+
+    def _release_tier_rows(self, st) -> None:
+        pins = getattr(st, "tier_pins", None)
+        if pins is None:
+            return
+        st.tier_pins = None
+        for table, slots, tids in pins:
+            table.decrement_counter(slots, tids)
+        self._tier_prefetched -= 1
+
+    def _forward_admission(self, indices: torch.Tensor, offsets: torch.Tensor, prefetch_only: bool = False):
         """Training forward with an admission strategy (_prefetch_hbm_direct_path, batched_dynamicemb_function.py:559-696,
         + DynamicEmbeddingFunction.forward :1090-1097): keys found in the table are served as usual; the batch frequency
         of every MISSING unique key is added to the admission counter, keys whose accumulated frequency passes
@@ -842,7 +880,9 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         embedding for this step is produced by the initializer into scratch rows and their gradients are dropped.
         Orchestrated from Python over the per-op C ABI (the admitted / rejected split is read on the host, as the
         reference does with its boolean-mask indexing); gather and backward are the launches of the plain path, because
-        they take row ADDRESSES and a scratch row is as good an address as a table row."""
+        they take row ADDRESSES and a scratch row is as good an address as a table row.
+        prefetch_only: the same walk for a later batch without the gather; found and admitted rows stay pinned until the
+        batch's backward, the scratch rows of the rejected keys travel in the step context."""
         from .scored_hashtable import ScoreArg
 
         n = indices.numel()
@@ -855,7 +895,10 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         st.offsets, st.num_keys, st.batch_size, st.num_bags = offsets, n, B, num_bags
         st.tids = st.slots = None
         st.pinned, st.event = False, None
-        if pooled:
+        pins = []
+        if prefetch_only:
+            out, combiner = None, -2
+        elif pooled:
             out = torch.empty(B, self.total_D, dtype=self.output_dtype, device=dev)
             combiner = 0 if self.pooling_mode == DynamicEmbPoolingMode.SUM else 1
         else:
@@ -880,6 +923,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             hit = f0.nonzero().squeeze(1)
             if hit.numel():
                 addr[hit] = ext.row_addresses(s0[hit], tids[hit], self.table_ptrs, self.table_value_dims, eb)
+                if prefetch_only:
+                    pins.append((self.table, s0[hit].contiguous(), tids[hit].contiguous()))
             miss = (~f0).nonzero().squeeze(1)
             if miss.numel():
                 km, tm = uk[miss].contiguous(), tids[miss].contiguous()
@@ -899,6 +944,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                     if ok.numel():
                         a_new = ext.row_addresses(idx[ok].contiguous(), ta[ok].contiguous(), self.table_ptrs, self.table_value_dims, eb)
                         addr[adm[ok]] = a_new
+                        if prefetch_only:
+                            pins.append((self.table, idx[ok].contiguous(), ta[ok].contiguous()))
                         mode, p = self._init_params()
                         ext.init_rows(mode, p, self._seed, self.initial_accumulator_value, ka[ok].contiguous(), a_new,
                                       self.embedding_dtype, self.max_D, max(self.value_dims), table_ids=ta[ok].contiguous(),
@@ -917,6 +964,11 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                                   table_emb_dims=self.table_emb_dims, table_value_dims=self.table_value_dims)
                     fwd_addr = st.row_addr.clone()
                     fwd_addr[rej] = a_rej
+        if prefetch_only:
+            st.fwd_addr, st.scratch = fwd_addr, scratch      # the forward gathers from these (scratch rows stay alive with the step)
+            self._pin_tier_rows(st, pins)
+            self._step += 1
+            return None, st
         al = all(d % 4 == 0 for d in self.dims) and all(v % 4 == 0 for v in self.value_dims)
         if pooled:
             check(lib().mi355_gather_pooled(None, 0, ptr(fwd_addr), dt(self.embedding_dtype), ptr(st.rev), n, ptr(offsets),
@@ -952,17 +1004,21 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         pooled = self.pooling_mode != DynamicEmbPoolingMode.NONE
         al = all(d % 4 == 0 for d in self.dims) and all(v % 4 == 0 for v in self.value_dims)
         n = st.num_keys
+        src_addr = getattr(st, "fwd_addr", None)      # admission: rejected keys are served from scratch rows
+        if src_addr is None:
+            src_addr = st.row_addr
         if pooled:
             out = torch.empty(st.batch_size, self.total_D, dtype=self.output_dtype, device=dev)
             combiner = 0 if self.pooling_mode == DynamicEmbPoolingMode.SUM else 1
-            check(lib().mi355_gather_pooled(None, 0, ptr(st.row_addr), dt(self.embedding_dtype), ptr(st.rev), n, ptr(st.offsets),
+            check(lib().mi355_gather_pooled(None, 0, ptr(src_addr), dt(self.embedding_dtype), ptr(st.rev), n, ptr(st.offsets),
                                             st.num_bags, st.batch_size, combiner, self.max_D, ptr(self.D_offsets_t), self.total_D,
                                             ptr(out), dt(out), int(al), stream()), "gather_pooled")
         else:
             out = torch.empty(n, self.dims[0], dtype=self.output_dtype, device=dev)
             if n:
-                check(lib().mi355_gather_rows(None, 0, ptr(st.row_addr), dt(self.embedding_dtype), ptr(st.rev), n, None,
+                check(lib().mi355_gather_rows(None, 0, ptr(src_addr), dt(self.embedding_dtype), ptr(st.rev), n, None,
                                               self.max_D, ptr(out), out.stride(0), dt(out), int(al), stream()), "gather_rows")
+        st.scratch = None      # stream-ordered: the gather is queued
         return out
 
     def _safe_check(self, st):
@@ -1002,6 +1058,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         if prepared:
             st.bwd_ws = None   # consumed: a second backward of the same step would have to regroup
             st.release_ring()
+        self._release_tier_rows(st)
 
     def forward(self, indices: torch.Tensor, offsets: torch.Tensor, per_sample_weights=None,
                 feature_requires_grad=None, batch_size_per_feature_per_rank=None, total_unique_indices=None):

@@ -577,15 +577,17 @@ def test_c1_matches_torch_embedding_bag():
 
 
 # ------------------------------------------------------------------------------------------ admission
+@pytest.mark.parametrize("prefetch", [False, True])
 @pytest.mark.parametrize("threshold", [1, 3, 5])
 @pytest.mark.parametrize("pooling", ["SUM", "NONE"])
-def test_frequency_admission_against_dict_twin(threshold, pooling):
+def test_frequency_admission_against_dict_twin(threshold, pooling, prefetch):
     """FrequencyAdmissionStrategy + KVCounter (reference test/unit_tests/test_embedding_admission.py: only keys whose
     accumulated frequency reached the threshold are stored).  Stronger than the reference's set invariant: a dict twin
     replays the admission rule step by step (batch frequency of every MISSING unique key is added to its counter; it is
     admitted -- and leaves the counter -- when the sum reaches the threshold; a rejected key is served a constant 0
     row and gets no update), so the stored key set, the counter population, every pooled output and every row after
-    SGD must match."""
+    SGD must match.  prefetch: batch i + 1 walks the admission path (prefetch()) BEFORE batch i's backward, as the reference's
+    prefetch pipeline does (batched_dynamicemb_function.py:559-696); the stored set, the outputs and the rows are the same."""
     (B2, IA, IM, PM, SS, TO, OT) = _mods()
     from dynamicemb.embedding_admission import FrequencyAdmissionStrategy, KVCounter
 
@@ -599,10 +601,16 @@ def test_frequency_admission_against_dict_twin(threshold, pooling):
     m.train()
     rng = np.random.default_rng(threshold * 7 + len(pooling))
     rows, counter = {}, {}
+    batches = []
     for step in range(steps):
         lens = rng.integers(0, 4, F * B)
         off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-        keys = rng.integers(0, 40, int(off[-1])).astype(np.int64)
+        batches.append((rng.integers(0, 40, int(off[-1])).astype(np.int64), off))
+    dev = [(torch.from_numpy(k).to(DEV), torch.from_numpy(o).to(DEV)) for k, o in batches]
+    if prefetch:
+        m.prefetch(*dev[0])
+    for step in range(steps):
+        keys, off = batches[step]
         # ---- twin: admission on the unique keys of the batch
         uniq, cnt = np.unique(keys, return_counts=True)
         served = {}
@@ -626,7 +634,9 @@ def test_frequency_admission_against_dict_twin(threshold, pooling):
                         exp[b, f * D:(f + 1) * D] += vec(int(keys[j]))
         else:
             exp = np.stack([vec(int(k)) for k in keys]) if keys.size else np.zeros((0, D), np.float32)
-        out = m(torch.from_numpy(keys).to(DEV), torch.from_numpy(off).to(DEV))
+        out = m(*dev[step])
+        if prefetch and step + 1 < steps:
+            m.prefetch(*dev[step + 1])
         np.testing.assert_allclose(out.detach().cpu().numpy(), exp, rtol=1e-5, atol=1e-6)
         g = rng.standard_normal(exp.shape).astype(np.float32)
         out.backward(torch.from_numpy(g).to(DEV))
@@ -650,6 +660,7 @@ def test_frequency_admission_against_dict_twin(threshold, pooling):
     for k, v in rows.items():
         np.testing.assert_allclose(got[k], v, rtol=1e-4, atol=1e-5)
     assert int(m._admission_counter.size()) == len(counter)
+    assert m._tier_prefetched == 0 and int(m.table._ref_counter.sum()) == 0      # every pin was released by its backward
 
 
 def test_admission_options_are_validated():

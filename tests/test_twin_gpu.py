@@ -108,6 +108,41 @@ def test_prefetch_pipeline_against_the_dict_twin(pooling):
     _check_rows(m, twin, hi)
 
 
+@pytest.mark.parametrize("mode", ["hybrid", "cache"])
+@pytest.mark.parametrize("pooling", ["SUM", "NONE"])
+def test_prefetch_pipeline_through_the_tiers_against_the_dict_twin(mode, pooling):
+    """_prefetch_cache_path (batched_dynamicemb_function.py:298-556): prefetch(batch i+1) walks BOTH tiers before
+    backward(batch i) -- HBM tier of one bucket per table, so its inserts evict into the host tier all the time -- and the
+    rows an outstanding batch resolved stay where they are (pinned) until its backward.  Outputs and final rows equal the
+    dict twin's; every pin is released at the end."""
+    dims, fmap, F, B, hi, lr = [8, 8], [0, 1, 1], 3, 24, 500, 0.1
+    m = _module(dims, fmap, pooling, "SGD", lr, local_hbm=2 * 128 * 4 * dims[0], caching=mode == "cache", prefetch_pipeline=True)
+    assert m.storage_mode == "hybrid"
+    twin = DictEmbeddingTwin(dims, fmap, pooling, "sgd", lr=lr)
+    rng = np.random.default_rng(29)
+    batches = [_batch(rng, F, B, hi) for _ in range(8)]
+    dev = [(torch.from_numpy(k).to(DEV), torch.from_numpy(o).to(DEV)) for k, o in batches]
+    m.prefetch(*dev[0])
+    for i, (keys, off) in enumerate(batches):
+        out, st = m._forward_impl(*dev[i], train=True)
+        if i + 1 < len(batches):
+            m.prefetch(*dev[i + 1])
+        ref = twin.forward(keys, off, train=True)
+        np.testing.assert_allclose(out.double().cpu().numpy(), ref, rtol=1e-6, atol=1e-3)
+        g = rng.uniform(0.1, 1.1, size=ref.shape).astype(np.float32)
+        m._backward_impl(st, torch.from_numpy(g).to(DEV))
+        twin.backward(g)
+    _check_rows(m, twin, hi)
+    assert int(m.size()) == sum(len(t) for t in twin.tables)
+    assert int(m.table_host.size()) > 0, "the HBM tier never spilled"
+    assert m._tier_prefetched == 0
+    assert int(m.table._ref_counter.sum()) == 0 and int(m.table_host._ref_counter.sum()) == 0
+    # a plain (not prefetched) step afterwards still works, and promotion is allowed again
+    keys, off = _batch(rng, F, B, hi)
+    out, st = m._forward_impl(torch.from_numpy(keys).to(DEV), torch.from_numpy(off).to(DEV), train=True)
+    np.testing.assert_allclose(out.double().cpu().numpy(), twin.forward(keys, off, train=True), rtol=1e-6, atol=1e-3)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
