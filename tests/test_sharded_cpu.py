@@ -199,7 +199,8 @@ def _worker(rank, W, port, F, B, pooled, dist_type, steps, q):
         else:
             local = DictLocal(F, pooled, key_offset=koff)
             cf = float(os.environ["TEST_CAPACITY_FACTOR"]) if os.environ.get("TEST_CAPACITY_FACTOR") else None
-            sh = RowWiseShardedLookup(local, F, [200] * F, pooled=pooled, device="cpu", out_dtype=torch.float32,
+            odt = torch.bfloat16 if os.environ.get("TEST_OUT_DTYPE") == "bf16" else torch.float32
+            sh = RowWiseShardedLookup(local, F, [200] * F, pooled=pooled, device="cpu", out_dtype=odt,
                                       dist_type_per_feature=[dist_type] * F, ops=NumpyOps(), capacity_factor=cf,
                                       expected_keys=F * B * 5 if cf else None)
         outs = []
@@ -212,13 +213,13 @@ def _worker(rank, W, port, F, B, pooled, dist_type, steps, q):
             st.prefetch(*batches[0])
             for step in range(steps):
                 out, ctx = st.forward(*batches[step], True, batches[step + 1] if step + 1 < steps else None)
-                outs.append(out.numpy().copy())
+                outs.append(out.float().numpy().copy())
                 st.backward(ctx, grads_for(rank, tuple(out.shape), step))
         else:
             for step in range(steps):
                 keys, off = make_batch(rank, F, B, step)
                 out, ctx = sh.forward(keys, off, True)
-                outs.append(out.numpy().copy())
+                outs.append(out.float().numpy().copy())
                 sh.backward(ctx, grads_for(rank, tuple(out.shape), step))
         q.put((rank, outs, dict(local.rows)))
     finally:
@@ -301,7 +302,7 @@ def test_rowwise_sharded_matches_single_process(W, F, B, pooled, dist_type, over
     _run_and_compare(W, F, B, pooled, dist_type)
 
 
-def _run_and_compare(W, F, B, pooled, dist_type):
+def _run_and_compare(W, F, B, pooled, dist_type, out_rtol=1e-5, out_atol=1e-6):
     steps = 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -321,7 +322,7 @@ def _run_and_compare(W, F, B, pooled, dist_type):
     for r in range(W):
         outs, rows = got[r]
         for step in range(steps):
-            np.testing.assert_allclose(outs[step], exp_outs[r][step], rtol=1e-5, atol=1e-6,
+            np.testing.assert_allclose(outs[step], exp_outs[r][step], rtol=out_rtol, atol=out_atol,
                                        err_msg=f"rank {r} step {step}")
         for k, v in rows.items():
             assert _owner(k[1], W, dist_type) == r, f"key {k} landed on rank {r}"
@@ -340,6 +341,16 @@ def test_fixed_capacity_exchange_matches_single_process(W, F, B, pooled, dist_ty
     monkeypatch.setenv("TEST_CAPACITY_FACTOR", "3.0")
     monkeypatch.setenv("TEST_OVERLAPPED", "1")
     _run_and_compare(W, F, B, pooled, dist_type)
+
+
+@pytest.mark.parametrize("W", [2, 3])
+def test_bf16_outputs_take_the_bf16_wire(W, monkeypatch):
+    """bf16 pooled outputs (what bench.py --gpus N asks for): the partial sums cross the fabric in bf16 by default
+    (wire_dtype "auto"), are summed in fp32 and rounded once more -- every output within (W + 1) half-ulps of the bf16
+    value of the exact sum; the table rows, updated from fp32 gradients, are exactly those of the fp32 run."""
+    monkeypatch.setenv("TEST_OUT_DTYPE", "bf16")
+    monkeypatch.setenv("TEST_OVERLAPPED", "1")
+    _run_and_compare(W, 2, 5, True, "roundrobin", out_rtol=(W + 1) * 2.0 ** -9, out_atol=(W + 1) * 2.0 ** -9 * 8.0)
 
 
 def test_fixed_capacity_overflow_is_reported():
