@@ -529,7 +529,12 @@ def main():
             step(i)
         sus_steps += args.steps
         torch.cuda.synchronize()
-        if time.perf_counter() - t1 >= 0.25 or sus_steps >= 200 * args.steps:
+        spent = time.perf_counter() - t1
+        if world > 1:   # ONE decision for all ranks (each reading its own clock would leave a rank alone in a collective)
+            t = torch.tensor([spent], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            spent = float(t.item())
+        if spent >= 0.25 or sus_steps >= 200 * args.steps:
             break
     sus = time.perf_counter() - t1
     if world > 1:
