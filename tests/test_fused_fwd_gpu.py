@@ -81,6 +81,53 @@ def test_fused_matches_per_op_chain_over_training_steps(pooling, opt, strategy, 
         torch.testing.assert_close(ref(keys, off), dut(keys, off), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("bags,opt,strategy", [(15_000, "SGD", "TIMESTAMP"), (86_000, "ADAM", "LFU"), (87_500, "SGD", "STEP"),
+                                               (88_500, "EXACT_ROWWISE_ADAGRAD", "TIMESTAMP"), (225_000, "SGD", "LFU")])
+def test_csr_writing_partition_kernel_against_the_per_op_chain_around_its_size_limits(bags, opt, strategy, monkeypatch):
+    """path (c) of the fused forward (fused_part3_kernel writes the backward's CSR; reverse indices are materialised on
+    demand) against the per-op chain over training steps, at key counts around its switches: just above 64 K keys, either
+    side of the 256-partition rule (393 216 keys: above it the partition blocks run in more than one generation), and near
+    the 1 M-key end.  Same outputs, same stored keys, same rows; the lazily produced reverse indices equal the eager ones."""
+    ref = _mk(False, (16,), cap=1 << 21, opt=opt, strategy=strategy, learning_rate=0.2, monkeypatch=monkeypatch)
+    dut = _mk(True, (16,), cap=1 << 21, opt=opt, strategy=strategy, learning_rate=0.2, monkeypatch=monkeypatch)
+    rng = np.random.default_rng(bags)
+    ref.train(); dut.train()
+    took_c = 0
+    for it in range(3):
+        lens = rng.integers(1, 9, size=bags)
+        off = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)).to(DEV)
+        nk = int(off[-1])
+        keys = torch.from_numpy(((rng.zipf(1.15, nk) + 7 * it) % (400_000 + 100_000 * it)).astype(np.int64)).to(DEV)
+        o_ref, s_ref = ref._forward_impl(keys, off, train=True)
+        o_dut, s_dut = dut._forward_impl(keys, off, train=True)
+        took_c += int(bool(getattr(s_dut, "lazy", False)))
+        torch.testing.assert_close(o_ref, o_dut, rtol=1e-5, atol=1e-5, msg=f"step {it} ({nk} keys): forward differs")
+        # the unique ORDER differs between the paths; what must agree is the grouping: unique[reverse] == keys on both
+        nu_r, nu_d = int(s_ref.uoff[-1]), int(s_dut.uoff[-1])
+        assert nu_r == nu_d
+        if it == 1:
+            uk = torch.empty(nu_d, dtype=torch.int64, device=DEV)
+            rev = s_dut.rev                      # materialises (one kernel) when the step was lazy
+            assert int(rev.min()) >= 0 and int(rev.max()) < nu_d
+            uk[rev] = keys
+            assert torch.equal(uk[rev], keys) and int(torch.unique(rev).numel()) == nu_d
+        g = torch.rand_like(o_ref) + 0.1
+        ref._backward_impl(s_ref, g)
+        dut._backward_impl(s_dut, g)
+        assert torch.equal(ref.size(), dut.size())
+        assert _counters_clear(dut)
+    assert took_c == 3, "the batch did not take the CSR-writing partition path"
+    k1, v1 = ref.export_keys_values(ref._table_names[0], torch.device(DEV))
+    k2, v2 = dut.export_keys_values(dut._table_names[0], torch.device(DEV))
+    o1, o2 = torch.argsort(k1), torch.argsort(k2)
+    assert k1.numel() == k2.numel() and torch.equal(k1[o1], k2[o2])
+    torch.testing.assert_close(v1[o1], v2[o2], rtol=3e-5, atol=3e-6)
+    ref.eval(); dut.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(ref._forward_impl(keys, off, train=False)[0], dut._forward_impl(keys, off, train=False)[0],
+                                   rtol=1e-5, atol=1e-5)
+
+
 def test_one_new_key_in_every_tile_gets_one_slot(monkeypatch):
     """cold start: the same unseen keys arrive from dozens of tiles at once; every key must end in exactly one slot and
     the reverse indices must group all its occurrences"""
