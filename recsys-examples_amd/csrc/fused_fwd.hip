@@ -1373,8 +1373,12 @@ fused_part_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, bo
     }
   }
   if (p == (int)gridDim.x - 1 && threadIdx.x == 0) {
-    const int U = upre + nu, O = spre + tot2;
-    if (hots) { *hot.n_hot = (int)(pre_b >> 40) + th; *hot.n_tasks = (int)((pre_b >> 20) & 0xfffff) + tt; *hot.n_wave = (int)(pre_b & 0xfffff) + tw; }
+    int U = upre + nu;
+    const int O = spre + tot2;
+    int nh = (int)(pre_b >> 40) + th, ntk = (int)((pre_b >> 20) & 0xfffff) + tt, nwv = (int)(pre_b & 0xfffff) + tw;
+    // a record list overflowed in the probe kernel (sticky flag): no row may be updated from an incomplete CSR -- as in path (c)
+    if (__hip_atomic_load(&a.hdr[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { U = 0; nh = 0; ntk = 0; nwv = 0; }
+    if (hots) { *hot.n_hot = nh; *hot.n_tasks = ntk; *hot.n_wave = nwv; }
     o.table_offsets[0] = 0;
     o.table_offsets[1] = U;
     *o.total = O;
@@ -1853,10 +1857,14 @@ occ_from_records_kernel(const int32_t* __restrict__ occ_slot, const int32_t* __r
     const int4 ro = rec_out4[ref >= 0 ? ref : 0];
     const bool late = ro.x < 0;
     const int uid = late ? ~ro.x : ro.x;
-    rev[j] = uid;
+    // an occurrence the probe could not record (its slot range's list overflowed: sticky flag, the step reports no uniques)
+    // belongs to no unique row: -1, not the id of an unrelated one
+    rev[j] = ref >= 0 ? uid : -1;
     if (ref >= 0) {
       rank[j] = occ_trank[j] + ro.y;
       if (late) occ_addr[j] = row_addr[uid];
+    } else {
+      rank[j] = 0;
     }
   }
 }

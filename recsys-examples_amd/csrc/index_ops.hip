@@ -711,7 +711,7 @@ rev_from_records_kernel(const int* __restrict__ slot, PartRefs pr, int* __restri
   if (hdr_reset && blockIdx.x == 0 && threadIdx.x < 64 && threadIdx.x != 5) hdr_reset[threadIdx.x] = 0;   // ([5]: sticky error flag)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int rc = slot[i];
-    if (rc < 0) { rev[i] = 0; continue; }
+    if (rc < 0) { rev[i] = -1; continue; }     // (no record: its list overflowed, the step reports no uniques)
     const int2 ro = pr.rec_out[rc];
     rev[i] = ro.x;
     rank[i] += ro.y < 0 ? ~ro.y : ro.y;
