@@ -55,6 +55,7 @@ int mi355_demb_forward(
        early CSR was started.  NULL: the early CSR is joined on `stream` before this call returns. */
     int* join_token,
     /* scratch */ void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  MI355_CHECK_ARG(counter || !train, "a training forward needs the ref-counter array (found slots are pinned across the insert)");
   MI355_CHECK_ARG(workspace && workspace_bytes >= mi355_demb_forward_workspace_bytes(num_keys, num_tables),
                   "workspace too small");
   if (join_token) *join_token = -1;

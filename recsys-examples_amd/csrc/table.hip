@@ -658,6 +658,7 @@ int mi355_table_erase(void* storage, const int64_t* table_bucket_offsets, int64_
 int mi355_table_update_counter(int32_t* counter, int64_t counter_numel, const int64_t* slot_indices, int64_t n,
                                const int64_t* n_dev, int32_t delta, const int64_t* table_ids,
                                const int64_t* table_bucket_offsets, int64_t C, hipStream_t stream) {
+  MI355_CHECK_ARG(counter && slot_indices, "counter and slot_indices required");
   if (n == 0) return MI355_OK;
   hipLaunchKernelGGL(update_counter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, counter, counter_numel,
                      slot_indices, n, n_dev, delta, table_ids, table_bucket_offsets, C);
