@@ -515,6 +515,60 @@ int mi355_hstu_attn_bwd(const void* dout, const void* q, const void* k, const vo
                         const int32_t* num_targets, int64_t target_group_size, int causal, float alpha,
                         float scaling_seqlen, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
+/* fp16 operands (hstu_api.cpp:359-366: "HSTU only supports fp16 and bf16"): the same seven entry points for q / k / v / out /
+ * gradients (and rab) in IEEE half instead of bf16 -- same kernels compiled with v_mfma_f32_32x32x16_f16, fp32
+ * accumulation, round-to-nearest-even packing.  The size queries and append_kvcache are type-agnostic. */
+int mi355_hstu_attn_fwd_f16(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride,
+                        int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride,
+                        int64_t k_head_stride, int64_t v_head_stride, int64_t o_head_stride,
+                        const int32_t* cu_seqlens, int64_t batch, int64_t num_heads, int64_t head_dim,
+                        int64_t max_seqlen, const int32_t* num_contexts, const int32_t* num_targets,
+                        int64_t target_group_size, int causal, float alpha, float scaling_seqlen,
+                        hipStream_t stream);
+int mi355_hstu_attn_fwd_kv_f16(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride,
+                           int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride,
+                           int64_t k_head_stride, int64_t v_head_stride, int64_t o_head_stride,
+                           const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int64_t batch, int64_t num_heads,
+                           int64_t head_dim, int64_t max_seqlen_q, const int32_t* num_contexts,
+                           const int32_t* num_targets, int64_t target_group_size, int causal, float alpha,
+                           float scaling_seqlen, const void* kv_cache, const int32_t* page_offsets,
+                           const int32_t* page_ids, const int32_t* last_page_lens, int64_t page_size,
+                           hipStream_t stream);
+int mi355_hstu_attn_bwd_f16(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
+                        int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t do_row_stride,
+                        int64_t q_head_stride, int64_t k_head_stride, int64_t v_head_stride,
+                        int64_t do_head_stride, const int32_t* cu_seqlens, int64_t batch, int64_t num_heads,
+                        int64_t head_dim, int64_t max_seqlen, const int32_t* num_contexts,
+                        const int32_t* num_targets, int64_t target_group_size, int causal, float alpha,
+                        float scaling_seqlen, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+int mi355_hstu_attn_fwd_window_f16(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride,
+                               int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride,
+                               int64_t k_head_stride, int64_t v_head_stride, int64_t o_head_stride, const int32_t* cu_seqlens,
+                               int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen, int64_t window_left,
+                               int64_t window_right, float alpha, float scaling_seqlen, hipStream_t stream);
+int mi355_hstu_attn_bwd_window_f16(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
+                               int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t do_row_stride,
+                               int64_t q_head_stride, int64_t k_head_stride, int64_t v_head_stride, int64_t do_head_stride,
+                               const int32_t* cu_seqlens, int64_t batch, int64_t num_heads, int64_t head_dim,
+                               int64_t max_seqlen, int64_t window_left, int64_t window_right, float alpha,
+                               float scaling_seqlen, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+int mi355_hstu_attn_fwd_rab_f16(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride, int64_t k_row_stride,
+                            int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride, int64_t k_head_stride,
+                            int64_t v_head_stride, int64_t o_head_stride, const int32_t* cu_seqlens, int64_t batch,
+                            int64_t num_heads, int64_t head_dim, int64_t max_seqlen, const int32_t* num_contexts,
+                            const int32_t* num_targets, int64_t target_group_size, int64_t window_left, int64_t window_right,
+                            float alpha, float scaling_seqlen, const void* rab, int64_t rab_batch_stride,
+                            int64_t rab_head_stride, int64_t rab_row_stride, hipStream_t stream);
+int mi355_hstu_attn_bwd_rab_f16(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
+                            int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t do_row_stride,
+                            int64_t q_head_stride, int64_t k_head_stride, int64_t v_head_stride, int64_t do_head_stride,
+                            const int32_t* cu_seqlens, int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen,
+                            const int32_t* num_contexts, const int32_t* num_targets, int64_t target_group_size,
+                            int64_t window_left, int64_t window_right, float alpha, float scaling_seqlen, const void* rab,
+                            int64_t rab_batch_stride, int64_t rab_head_stride, int64_t rab_row_stride, void* drab,
+                            int64_t drab_batch_stride, int64_t drab_head_stride, int64_t drab_row_stride, hipStream_t stream);
+
+
 #ifdef __cplusplus
 }
 #endif

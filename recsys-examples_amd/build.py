@@ -55,7 +55,9 @@ def _build(force, verbose, defines, only=(), base_objdir=None) -> str:
             objs.append(os.path.join(base_objdir, src.replace(".hip", ".o")))
             continue
         objs.append(o)
-        if force or _stale(o, [s] + headers):
+        # (a source may be a second translation unit of another one: hstu_attn_f16.hip includes hstu_attn.hip)
+        inc = [os.path.join(CSRC, m) for m in __import__("re").findall(r'#include "([^"]+\.hip)"', open(s).read())]
+        if force or _stale(o, [s] + inc + headers):
             jobs.append([HIPCC] + FLAGS + defines + ["-c", s, "-o", o])
 
     def run(cmd):

@@ -28,9 +28,32 @@
 #include <type_traits>
 
 
-namespace mi355 {
+// Operand type.  This file is compiled twice: as it stands (bf16 operands) and through hstu_attn_f16.hip, which defines
+// HSTU_F16 (fp16 operands: hstu_api.cpp:359-366 accepts both).  Everything between memory and the MFMA is 16-bit data moved
+// as bits, so what differs is the MFMA instruction, the fp32 -> 16-bit packing and the 16-bit -> fp32 read of the bias; the
+// fp16 copy lives in an inline namespace of its own and its entry points carry the suffix _f16.
+#ifndef HSTU_F16
+#define HSTU_F16 0
+#endif
+#if HSTU_F16
+#define HSTU_FN(name) name##_f16
+#define HSTU_NS_BEGIN namespace mi355 { inline namespace hstu_f16 {
+#define HSTU_NS_END } }
+#else
+#define HSTU_FN(name) name
+#define HSTU_NS_BEGIN namespace mi355 {
+#define HSTU_NS_END }
+#endif
 
+HSTU_NS_BEGIN
+
+#if HSTU_F16
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8_t;   // (the name stays: "the 8-element MFMA operand")
+#define HSTU_MFMA __builtin_amdgcn_mfma_f32_32x32x16_f16
+#else
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+#define HSTU_MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#endif
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;   // first-class 16-B value (HIP's uint4 struct arrays end up in scratch)
 
@@ -105,7 +128,11 @@ __device__ __forceinline__ bool attn_allowed(int i, int j, const SeqInfo& s, int
 
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
   uint32_t r;
+#if HSTU_F16
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+#else
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+#endif
   return r;
 }
 
@@ -119,16 +146,16 @@ __device__ __forceinline__ float silu_f(float x) {
 // bit-stable.  What the asm forms were meant to achieve -- keeping the long-lived output accumulators in AGPRs -- is
 // done with pin_agpr() below, which costs no instructions.
 __device__ __forceinline__ void mfma_a(f32x16_t& c, const bf16x8_t& a, const bf16x8_t& b) {
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  c = HSTU_MFMA(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ void mfma_v(f32x16_t& c, const bf16x8_t& a, const bf16x8_t& b) {
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  c = HSTU_MFMA(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ void mfma_v0(f32x16_t& c, const bf16x8_t& a, const bf16x8_t& b) {  // c = a b
   f32x16_t z;
 #pragma unroll
   for (int i = 0; i < 16; ++i) z[i] = 0.f;
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, z, 0, 0, 0);
+  c = HSTU_MFMA(a, b, z, 0, 0, 0);
 }
 __device__ __forceinline__ void mfma_fence() {}
 // keeps a long-lived accumulator resident in AGPRs at this program point (the allocator otherwise splits its live
@@ -205,7 +232,11 @@ __device__ __forceinline__ int row_block_of_rank(int rank, int nblk, const AttnA
   if (!ctx_first) return nblk - 1 - rank;
   return rank == 0 ? 0 : nblk - rank;
 }
+#if HSTU_F16
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+#else
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
+#endif
 // S^T accumulators (lane = query row, registers = keys (rr & 3) + 8 (rr >> 2) + 4 hi of each 32-key sub-tile) += rab[i][.]
 // `row` points at rab[b][h][i][0] (NULL for a row past the sequence); 2-byte loads: the bias path is not a tuned one.
 template <int NT>
@@ -2090,7 +2121,7 @@ static int launch_fwd(const AttnArgs& a, int B, int max_seqlen, hipStream_t stre
   return MI355_OK;
 }
 
-}  // namespace mi355
+HSTU_NS_END
 
 using namespace mi355;
 
@@ -2109,7 +2140,7 @@ static int window_skip() {   // MI355_HSTU_WSKIP=0: keep the full tile loops und
 }
 
 extern "C" {
-#if HSTU_TIMING
+#if HSTU_TIMING && !HSTU_F16
 int mi355_hstu_dbg_dump(void* out, int64_t bytes) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mi355::g_hstu_dbg), (size_t)bytes);
 }
@@ -2118,13 +2149,13 @@ int mi355_hstu_dbg_dump(void* out, int64_t bytes) {
 // hstu_varlen_fwd (corelib/hstu/csrc/hstu_attn/hstu_api.cpp:335-523).  q, k, v, out: bf16 [total, H, d] with
 // explicit token / head strides (elements); cu_seqlens int32 [B+1] shared by q and k (self attention over
 // jagged sequences); num_contexts / num_targets int32 [B] or NULL; window (-1, 0) = causal, (-1, -1) = full.
-int mi355_hstu_attn_fwd(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride,
+int HSTU_FN(mi355_hstu_attn_fwd)(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride,
                         int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride,
                         int64_t k_head_stride, int64_t v_head_stride, int64_t o_head_stride, const int32_t* cu_seqlens,
                         int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen,
                         const int32_t* num_contexts, const int32_t* num_targets, int64_t target_group_size, int causal,
                         float alpha, float scaling_seqlen, hipStream_t stream) {
-  return mi355_hstu_attn_fwd_kv(q, k, v, out, q_row_stride, k_row_stride, v_row_stride, o_row_stride, q_head_stride,
+  return HSTU_FN(mi355_hstu_attn_fwd_kv)(q, k, v, out, q_row_stride, k_row_stride, v_row_stride, o_row_stride, q_head_stride,
                                 k_head_stride, v_head_stride, o_head_stride, cu_seqlens, nullptr, batch, num_heads, head_dim,
                                 max_seqlen, num_contexts, num_targets, target_group_size, causal, alpha, scaling_seqlen,
                                 nullptr, nullptr, nullptr, nullptr, 0, stream);
@@ -2133,7 +2164,7 @@ int mi355_hstu_attn_fwd(const void* q, const void* k, const void* v, void* out, 
 // Inference forward: queries may be the tail of a longer key sequence (cu_seqlens_k, "delta-q") and the keys / values
 // of the history may live in a paged cache [num_pages, 2, page_size, H, d] (hstu_attn_varlen_func kv_cache /
 // page_offsets / page_ids / last_page_lens, hstu_attn_interface.py; kernel hstu_fwd.h Paged_KV paths :104-131,516-545).
-int mi355_hstu_attn_fwd_kv(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride,
+int HSTU_FN(mi355_hstu_attn_fwd_kv)(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride,
                            int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride,
                            int64_t k_head_stride, int64_t v_head_stride, int64_t o_head_stride, const int32_t* cu_seqlens_q,
                            const int32_t* cu_seqlens_k, int64_t batch, int64_t num_heads, int64_t head_dim,
@@ -2173,6 +2204,7 @@ int mi355_hstu_attn_fwd_kv(const void* q, const void* k, const void* v, void* ou
   }
 }
 
+#if !HSTU_F16   // (type-agnostic: once, in the bf16 translation unit)
 // append_kvcache (examples/commons/ops/cuda_ops/csrc/paged_kvcache_ops_kernel.cu:106-140): token i of the new history
 // (i < *nnz) of sequence batch_indices[i] goes to position positions[i] of that user's paged cache, NHD layout
 // [num_pages, 2, page_size, H, d]; its source row in append_key / append_value is i + seqlen_offsets[batch] (the
@@ -2237,8 +2269,10 @@ int64_t mi355_hstu_attn_bwd_ds_bytes(int64_t batch, int64_t num_heads, int64_t h
   return batch * num_heads * ng * ng * 2048 * ((envp && head_dim >= 128) ? 2 : 1);
 }
 
+#endif
+
 // hstu_varlen_bwd (corelib/hstu/csrc/hstu_attn/hstu_api.cpp:525-719).  dq, dk, dv: contiguous bf16 [total, H, d].
-int mi355_hstu_attn_bwd(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
+int HSTU_FN(mi355_hstu_attn_bwd)(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
                         int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t do_row_stride,
                         int64_t q_head_stride, int64_t k_head_stride, int64_t v_head_stride, int64_t do_head_stride,
                         const int32_t* cu_seqlens, int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen,
@@ -2290,14 +2324,14 @@ int mi355_hstu_attn_bwd(const void* dout, const void* q, const void* k, const vo
 // rows with a window (hstu_attn_interface.py:238-245), self attention only.
 static int window_causal(int64_t wl, int64_t wr) { return wr == 0 ? 1 : 0; }   // right == 0: the causal tile loops apply
 
-int mi355_hstu_attn_fwd_window(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride,
+int HSTU_FN(mi355_hstu_attn_fwd_window)(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride,
                                int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride,
                                int64_t k_head_stride, int64_t v_head_stride, int64_t o_head_stride, const int32_t* cu_seqlens,
                                int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen, int64_t window_left,
                                int64_t window_right, float alpha, float scaling_seqlen, hipStream_t stream) {
   MI355_CHECK_ARG(window_left >= -1 && window_right >= -1 && window_left < (1 << 30) && window_right < (1 << 30), "bad window");
   tl_wl = (int)window_left; tl_wr = window_right == 0 ? -1 : (int)window_right;   // (right == 0 is what `causal` already says)
-  const int rc = mi355_hstu_attn_fwd(q, k, v, out, q_row_stride, k_row_stride, v_row_stride, o_row_stride, q_head_stride,
+  const int rc = HSTU_FN(mi355_hstu_attn_fwd)(q, k, v, out, q_row_stride, k_row_stride, v_row_stride, o_row_stride, q_head_stride,
                                      k_head_stride, v_head_stride, o_head_stride, cu_seqlens, batch, num_heads, head_dim,
                                      max_seqlen, nullptr, nullptr, 1, window_causal(window_left, window_right), alpha,
                                      scaling_seqlen, stream);
@@ -2305,7 +2339,7 @@ int mi355_hstu_attn_fwd_window(const void* q, const void* k, const void* v, void
   return rc;
 }
 
-int mi355_hstu_attn_bwd_window(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
+int HSTU_FN(mi355_hstu_attn_bwd_window)(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
                                int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t do_row_stride,
                                int64_t q_head_stride, int64_t k_head_stride, int64_t v_head_stride, int64_t do_head_stride,
                                const int32_t* cu_seqlens, int64_t batch, int64_t num_heads, int64_t head_dim,
@@ -2313,7 +2347,7 @@ int mi355_hstu_attn_bwd_window(const void* dout, const void* q, const void* k, c
                                float scaling_seqlen, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   MI355_CHECK_ARG(window_left >= -1 && window_right >= -1 && window_left < (1 << 30) && window_right < (1 << 30), "bad window");
   tl_wl = (int)window_left; tl_wr = window_right == 0 ? -1 : (int)window_right;
-  const int rc = mi355_hstu_attn_bwd(dout, q, k, v, dq, dk, dv, q_row_stride, k_row_stride, v_row_stride, do_row_stride,
+  const int rc = HSTU_FN(mi355_hstu_attn_bwd)(dout, q, k, v, dq, dk, dv, q_row_stride, k_row_stride, v_row_stride, do_row_stride,
                                      q_head_stride, k_head_stride, v_head_stride, do_head_stride, cu_seqlens, batch, num_heads,
                                      head_dim, max_seqlen, nullptr, nullptr, 1, window_causal(window_left, window_right), alpha,
                                      scaling_seqlen, workspace, workspace_bytes, stream);
@@ -2337,7 +2371,7 @@ static int rab_mask(int64_t wl, int64_t wr, const int32_t* nc, const int32_t* nt
   return MI355_OK;
 }
 
-int mi355_hstu_attn_fwd_rab(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride, int64_t k_row_stride,
+int HSTU_FN(mi355_hstu_attn_fwd_rab)(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride, int64_t k_row_stride,
                             int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride, int64_t k_head_stride,
                             int64_t v_head_stride, int64_t o_head_stride, const int32_t* cu_seqlens, int64_t batch,
                             int64_t num_heads, int64_t head_dim, int64_t max_seqlen, const int32_t* num_contexts,
@@ -2348,7 +2382,7 @@ int mi355_hstu_attn_fwd_rab(const void* q, const void* k, const void* v, void* o
   int causal = 0;
   if (const int rc = rab_mask(window_left, window_right, num_contexts, num_targets, &causal)) return rc;
   tl_rab = RabCall{(const uint16_t*)rab, rab_batch_stride, rab_head_stride, rab_row_stride, nullptr, 0, 0, 0};
-  const int rc = mi355_hstu_attn_fwd(q, k, v, out, q_row_stride, k_row_stride, v_row_stride, o_row_stride, q_head_stride,
+  const int rc = HSTU_FN(mi355_hstu_attn_fwd)(q, k, v, out, q_row_stride, k_row_stride, v_row_stride, o_row_stride, q_head_stride,
                                      k_head_stride, v_head_stride, o_head_stride, cu_seqlens, batch, num_heads, head_dim,
                                      max_seqlen, num_contexts, num_targets, target_group_size, causal, alpha, scaling_seqlen,
                                      stream);
@@ -2357,7 +2391,7 @@ int mi355_hstu_attn_fwd_rab(const void* q, const void* k, const void* v, void* o
   return rc;
 }
 
-int mi355_hstu_attn_bwd_rab(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
+int HSTU_FN(mi355_hstu_attn_bwd_rab)(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
                             int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t do_row_stride,
                             int64_t q_head_stride, int64_t k_head_stride, int64_t v_head_stride, int64_t do_head_stride,
                             const int32_t* cu_seqlens, int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen,
@@ -2372,7 +2406,7 @@ int mi355_hstu_attn_bwd_rab(const void* dout, const void* q, const void* k, cons
   if (const int rc = rab_mask(window_left, window_right, num_contexts, num_targets, &causal)) return rc;
   tl_rab = RabCall{(const uint16_t*)rab, rab_batch_stride, rab_head_stride, rab_row_stride,
                    (uint16_t*)drab, drab_batch_stride, drab_head_stride, drab_row_stride};
-  const int rc = mi355_hstu_attn_bwd(dout, q, k, v, dq, dk, dv, q_row_stride, k_row_stride, v_row_stride, do_row_stride,
+  const int rc = HSTU_FN(mi355_hstu_attn_bwd)(dout, q, k, v, dq, dk, dv, q_row_stride, k_row_stride, v_row_stride, do_row_stride,
                                      q_head_stride, k_head_stride, v_head_stride, do_head_stride, cu_seqlens, batch, num_heads,
                                      head_dim, max_seqlen, num_contexts, num_targets, target_group_size, causal, alpha,
                                      scaling_seqlen, nullptr, 0, stream);

@@ -3,11 +3,11 @@
 Mirrors `HstuAttnVarlenFunc` / `hstu_attn_varlen_func` of the reference
 (corelib/hstu/hstu_attn/hstu_attn_interface.py:23-279 legacy signature; new positional order of
 examples/hstu/modules/hstu_attention.py:296-314): same argument meaning, same input checks
-(bf16/fp16-class inputs, int32 cu_seqlens / num_contexts / num_targets, head_dim in {32, 64, 128, 256},
+(bf16 or fp16 q / k / v, int32 cu_seqlens / num_contexts / num_targets, head_dim in {32, 64, 128, 256},
 contextual / target masks require causal -- hstu_api.cpp:359-430).
 Inference extensions (forward only): cu_seqlens_k longer than cu_seqlens_q (delta-q) and the paged KV cache
 (kv_cache / page_offsets / page_ids / last_page_lens).
-Not supported (raise): seqused_*, rab or local windows over a KV cache / delta-q, fp16 (bf16 only).  The raw ops of the fused layer
+Not supported (raise): seqused_*, rab or local windows over a KV cache / delta-q.  The raw ops of the fused layer
 (`torch.ops.fbgemm.hstu_varlen_{fwd,bwd}_{80,90}`) are registered by `hstu.hstu_ops_gpu`.
 """
 from __future__ import annotations
@@ -40,21 +40,31 @@ N.register_signatures({
     "mi355_append_kvcache": [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p,
                              c_i64, c_i64, c_p],
 }, {"mi355_hstu_attn_bwd_workspace_bytes": c_i64, "mi355_hstu_attn_bwd_ds_bytes": c_i64})
+# the fp16-operand twins of the seven type-specific entry points (same argument lists)
+_TYPED = ("mi355_hstu_attn_fwd", "mi355_hstu_attn_fwd_kv", "mi355_hstu_attn_bwd", "mi355_hstu_attn_fwd_window",
+          "mi355_hstu_attn_bwd_window", "mi355_hstu_attn_fwd_rab", "mi355_hstu_attn_bwd_rab")
+N.register_signatures({n + "_f16": N.signature_of(n) for n in _TYPED})
+
+
+def _fn(name: str, t: torch.Tensor):
+    """the entry point for the operand type of `t` (bf16: the plain name, fp16: its _f16 twin)"""
+    return getattr(lib(), name + ("_f16" if t.dtype == torch.float16 else ""))
+
 
 
 def _check_inputs(q, k, v, cu_q, cu_k, num_contexts, num_targets, window_size, rab, kv_cache, seqused_q, seqused_k):
     if rab is not None:
         # hstu_api.cpp:417-430: (batch, heads or 1, max_seqlen_k, max_seqlen_k), contiguous last dimension
         if rab.dtype != q.dtype or rab.dim() != 4 or rab.stride(-1) != 1:
-            raise RuntimeError("rab must be a bf16 (batch, nheads or 1, max_seqlen_k, max_seqlen_k) tensor with a contiguous last dimension")
+            raise RuntimeError("rab must be a (batch, nheads or 1, max_seqlen_k, max_seqlen_k) tensor of the dtype of q with a contiguous last dimension")
         if rab.shape[0] != cu_q.numel() - 1 or rab.shape[1] not in (1, q.shape[1]) or rab.shape[2] != rab.shape[3]:
             raise RuntimeError("Number of heads in rab must be 1 or equal to number of heads in query; shape (batch, heads, max_seqlen_k, max_seqlen_k)")
         if kv_cache is not None:
             raise NotImplementedError("rab over a paged KV cache is not supported")
     if seqused_q is not None or seqused_k is not None:
         raise NotImplementedError("seqused_q / seqused_k are not supported")
-    if q.dtype != torch.bfloat16 or k.dtype != q.dtype or v.dtype != q.dtype:
-        raise RuntimeError("hstu_attn only supports bf16 q/k/v in this build")
+    if q.dtype not in (torch.bfloat16, torch.float16) or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise RuntimeError("HSTU only supports fp16 and bf16 data type")      # (hstu_api.cpp:359-366)
     if q.dim() != 3 or k.dim() != 3 or k.shape[1:] != q.shape[1:] or v.shape != k.shape:
         raise RuntimeError("q, k, v must be (total, nheads, head_dim); k and v of equal shape")
     if q.stride(-1) != 1 or k.stride(-1) != 1 or v.stride(-1) != 1:
@@ -86,7 +96,7 @@ def hstu_varlen_fwd(q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_context
     T, H, D = q.shape
     out = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
     B = cu_seqlens.numel() - 1
-    check(lib().mi355_hstu_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
+    check(_fn("mi355_hstu_attn_fwd", q)(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
                                     q.stride(1), k.stride(1), v.stride(1), out.stride(1), ptr(cu_seqlens), B, H, D,
                                     int(max_seqlen), ptr(num_contexts), ptr(num_targets), int(target_group_size), int(causal),
                                     c_f(alpha), c_f(float(scaling_seqlen)), stream()), "hstu_attn_fwd")
@@ -110,7 +120,7 @@ def hstu_varlen_fwd_kv(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, scalin
             if t is None or t.dtype != torch.int32:
                 raise RuntimeError(f"{name} must be an int32 tensor")
         page_size = kv_cache.size(2)
-    check(lib().mi355_hstu_attn_fwd_kv(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
+    check(_fn("mi355_hstu_attn_fwd_kv", q)(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
                                        q.stride(1), k.stride(1), v.stride(1), out.stride(1), ptr(cu_seqlens_q),
                                        ptr(cu_seqlens_k), B, H, D, int(max_seqlen_q), ptr(num_contexts), ptr(num_targets),
                                        int(target_group_size), int(causal), c_f(alpha), c_f(float(scaling_seqlen)),
@@ -154,7 +164,7 @@ def hstu_varlen_bwd(dout, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_c
     if dsb > _DS_MAX_BYTES or (dsb > (256 << 20) and dsb > torch.cuda.mem_get_info(q.device)[0] // 4):
         dsb = 0
     ws = torch.empty(max(wsb, dsb, 256), dtype=torch.uint8, device=q.device)
-    check(lib().mi355_hstu_attn_bwd(ptr(dout), ptr(q), ptr(k), ptr(v), ptr(dq), ptr(dk), ptr(dv), q.stride(0), k.stride(0),
+    check(_fn("mi355_hstu_attn_bwd", q)(ptr(dout), ptr(q), ptr(k), ptr(v), ptr(dq), ptr(dk), ptr(dv), q.stride(0), k.stride(0),
                                     v.stride(0), dout.stride(0), q.stride(1), k.stride(1), v.stride(1), dout.stride(1),
                                     ptr(cu_seqlens), B, H, D, int(max_seqlen), ptr(num_contexts), ptr(num_targets),
                                     int(target_group_size), int(causal), c_f(alpha), c_f(float(scaling_seqlen)), ptr(ws),
@@ -185,7 +195,7 @@ def hstu_varlen_fwd_window(q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, wl, 
     T, H, D = q.shape
     out = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
     B = cu_seqlens.numel() - 1
-    check(lib().mi355_hstu_attn_fwd_window(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0),
+    check(_fn("mi355_hstu_attn_fwd_window", q)(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0),
                                            out.stride(0), q.stride(1), k.stride(1), v.stride(1), out.stride(1),
                                            ptr(cu_seqlens), B, H, D, int(max_seqlen), int(wl), int(wr), c_f(alpha),
                                            c_f(float(scaling_seqlen)), stream()), "hstu_attn_fwd_window")
@@ -203,7 +213,7 @@ def hstu_varlen_bwd_window(dout, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen
     if dsb > _DS_MAX_BYTES:
         dsb = 0
     ws = torch.empty(max(dsb, 256), dtype=torch.uint8, device=q.device)
-    check(lib().mi355_hstu_attn_bwd_window(ptr(dout), ptr(q), ptr(k), ptr(v), ptr(dq), ptr(dk), ptr(dv), q.stride(0),
+    check(_fn("mi355_hstu_attn_bwd_window", q)(ptr(dout), ptr(q), ptr(k), ptr(v), ptr(dq), ptr(dk), ptr(dv), q.stride(0),
                                            k.stride(0), v.stride(0), dout.stride(0), q.stride(1), k.stride(1), v.stride(1),
                                            dout.stride(1), ptr(cu_seqlens), B, H, D, int(max_seqlen), int(wl), int(wr),
                                            c_f(alpha), c_f(float(scaling_seqlen)), ptr(ws), ws.numel(), stream()),
@@ -241,7 +251,7 @@ def hstu_varlen_fwd_rab(q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_con
     out = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
     B = cu_seqlens.numel() - 1
     rb, rh, rr = _rab_strides(rab, H)
-    check(lib().mi355_hstu_attn_fwd_rab(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
+    check(_fn("mi355_hstu_attn_fwd_rab", q)(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
                                         q.stride(1), k.stride(1), v.stride(1), out.stride(1), ptr(cu_seqlens), B, H, D,
                                         int(max_seqlen), ptr(num_contexts), ptr(num_targets), int(target_group_size), int(wl),
                                         int(wr), c_f(alpha), c_f(float(scaling_seqlen)), ptr(rab), rb, rh, rr, stream()),
@@ -263,7 +273,7 @@ def hstu_varlen_bwd_rab(dout, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, n
     rb, rh, rr = _rab_strides(rab, H)
     drab = torch.zeros((B, H, N, N), dtype=q.dtype, device=q.device) if has_drab else None
     ds = (drab.stride(0), drab.stride(1), drab.stride(2)) if has_drab else (0, 0, 0)
-    check(lib().mi355_hstu_attn_bwd_rab(ptr(dout), ptr(q), ptr(k), ptr(v), ptr(dq), ptr(dk), ptr(dv), q.stride(0), k.stride(0),
+    check(_fn("mi355_hstu_attn_bwd_rab", q)(ptr(dout), ptr(q), ptr(k), ptr(v), ptr(dq), ptr(dk), ptr(dv), q.stride(0), k.stride(0),
                                         v.stride(0), dout.stride(0), q.stride(1), k.stride(1), v.stride(1), dout.stride(1),
                                         ptr(cu_seqlens), B, H, D, int(max_seqlen), ptr(num_contexts), ptr(num_targets),
                                         int(target_group_size), int(wl), int(wr), c_f(alpha), c_f(float(scaling_seqlen)),

@@ -34,8 +34,8 @@ def _check(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, wl, wr, rab,
         raise RuntimeError("rab must be (batch, nheads or 1, max_seqlen_k, max_seqlen_k) with a contiguous last dimension")
     if quant_mode not in (-1, None) or any(e is not None for e in extra):
         raise NotImplementedError("fp8 quantisation is not supported")
-    if q.dtype != torch.bfloat16:
-        raise RuntimeError("hstu_varlen ops support bf16 only in this build")
+    if q.dtype not in (torch.bfloat16, torch.float16):
+        raise RuntimeError("HSTU only supports fp16 and bf16 data type")
     if max_q != max_k or q.shape[0] != k.shape[0] or cu_q.shape != cu_k.shape:
         raise NotImplementedError("the raw training ops are self-attention only (cu_seqlens_q == cu_seqlens_k)")
     if v.shape != k.shape:

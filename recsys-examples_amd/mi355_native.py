@@ -160,6 +160,11 @@ def register_signatures(sigs, restypes=None):
         _bind(_lib, sigs)
 
 
+def signature_of(name):
+    """argument types registered for `name` (for twins that share a signature, e.g. the fp16 entry points of the attention)"""
+    return (_OPTIONAL_SIGS.get(name) or _SIGS[name])
+
+
 def _bind(lib, sigs):
     for name, args in sigs.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly

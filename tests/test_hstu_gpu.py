@@ -43,15 +43,19 @@ def _bf16_ulp(x):
     return 2.0 ** (np.floor(np.log2(ax)) - 7)
 
 
-def _close_elementwise(actual, ref, mag, k):
-    """The bf16 rule of path A (tests/test_demb_gpu.py: assert_close_lowp), element by element: |x - ref| <= 1e-3 |ref| +
+def _close_elementwise(actual, ref, mag, k, bits=7):
+    """(bits = fraction bits of the operand type: 7 bf16, 10 fp16 -- ulp = 2^(e - bits), rounding floor k * 2^-(bits + 2).)
+    The bf16 rule of path A (tests/test_demb_gpu.py: assert_close_lowp), element by element: |x - ref| <= 1e-3 |ref| +
     1 ulp_bf16(ref) + k * 2^-9 * mag, where mag = the accumulated magnitude of the element's summands (oracle:
     hstu_attn_magnitudes) and k * 2^-9 the relative rounding the kernels apply to them before the second GEMMs (P: one bf16
     rounding, k = 2 with margin; dS: P-dependent products of two rounded factors, k = 4).  The floor is per ELEMENT, so an
     error confined to small rows cannot hide under the tensor's maximum."""
     a = actual.detach().float().cpu().numpy().astype(np.float64)
     ref = np.asarray(ref, np.float64)
-    tol = 1e-3 * np.abs(ref) + _bf16_ulp(ref) + k * 2.0 ** -9 * np.asarray(mag, np.float64) + 1e-30
+    ulp = _bf16_ulp(ref) * 2.0 ** (7 - bits)
+    if bits == 10:
+        ulp = np.maximum(ulp, 2.0 ** -24)       # fp16 is subnormal below 6.1e-5: fixed spacing (the first tokens' outputs, ~ 1 / N)
+    tol = 1e-3 * np.abs(ref) + ulp + k * 2.0 ** -(bits + 2) * np.asarray(mag, np.float64) + 1e-30
     bad = np.abs(a - ref) > tol
     assert not bad.any(), (f"{int(bad.sum())} of {bad.size} elements off: worst excess "
                            f"{float((np.abs(a - ref) / tol).max()):.2f} x its tolerance")
@@ -379,6 +383,52 @@ def test_strided_inputs_and_scaling_seqlen():
     out, _ = _run(q, k, v, off, 129, None, None, 1, True, 0.125, scaling=1000)
     ref = ho.hstu_attn_fwd(*(t.float().cpu().numpy() for t in (q, k, v)), off, 0.125, 1000, True)
     assert np.abs(out.detach().float().cpu().numpy() - ref).max() <= 6e-3 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("d", [32, 128, 256])
+@pytest.mark.parametrize("mode", ["causal", "ctx_targets", "noncausal", "window", "rab"])
+def test_fp16_operands_vs_oracle(d, mode):
+    """hstu_api.cpp:359-366 accepts fp16 as well as bf16: the fp16 build of the kernels (mi355_hstu_attn_*_f16:
+    v_mfma_f32_32x32x16_f16, round-to-nearest-even packing) against the float64 oracle on the same fp16 inputs, element by
+    element with fp16's ulp (2^-10) and rounding floor -- an eighth of the bf16 tolerance, so a bf16 instruction left in the
+    fp16 path cannot pass."""
+    rng = np.random.default_rng(7 * d + len(mode))
+    lengths = np.array([300, 1, 0, 129, 64, 77])
+    B, H, N = lengths.size, 2, int(lengths.max())
+    off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    T = int(off[-1])
+    mk = lambda lo, hi, *shape: torch.from_numpy(rng.uniform(lo, hi, shape).astype(np.float32)).to(DEV).to(torch.float16)
+    q, k, v, dout = mk(-1, 1, T, H, d), mk(-1, 1, T, H, d), mk(-1, 1, T, H, d), mk(0, 1, T, H, d)
+    targets = ctx = None
+    grp, window, rab = 1, (-1, 0), None
+    if mode == "ctx_targets":
+        targets = np.minimum(rng.integers(0, 11, size=B), np.maximum(lengths - 1, 0))
+        ctx = np.minimum(rng.integers(0, 5, size=B), np.maximum(lengths - 1 - targets, 0))
+        grp = 2
+    elif mode == "noncausal":
+        window = (-1, -1)
+    elif mode == "window":
+        window = (40, 9)
+    elif mode == "rab":
+        rab = mk(-2, 2, B, H, N, N)
+    alpha = 1.0 / d ** 0.5
+    if rab is not None:
+        out, grads, drab = _run_rab(q, k, v, rab, off, N, targets, ctx, grp, window, alpha, dout)
+    else:
+        out, grads = _run(q, k, v, off, N, targets, ctx, grp, window == (-1, 0), alpha, dout=dout, window=window)
+    assert out.dtype == torch.float16 and all(g.dtype == torch.float16 for g in grads)
+    qn, kn, vn, dn = (t.float().cpu().numpy() for t in (q, k, v, dout))
+    kw = dict(causal=window == (-1, 0), num_targets=targets, num_contextuals=ctx, target_group_size=grp,
+              local_window=window if mode == "window" else None, rab=None if rab is None else rab.float().cpu().numpy())
+    ref = ho.hstu_attn_fwd(qn, kn, vn, off, alpha, N, **kw)
+    res = ho.hstu_attn_bwd(dn, qn, kn, vn, off, alpha, N, **kw)
+    mags = ho.hstu_attn_magnitudes(dn, qn, kn, vn, off, alpha, N, **kw)
+    for got, want, mag, kk in ((out, ref, mags[0], 2), (grads[0], res[0], mags[1], 4), (grads[1], res[1], mags[2], 4),
+                               (grads[2], res[2], mags[3], 4)):
+        _close_elementwise(got, want, mag, kk, bits=10)
+    if rab is not None:
+        gn = drab.detach().float().cpu().numpy()
+        assert np.abs(gn - res[3]).max() <= 2e-3 * np.abs(res[3]).max() + 1e-6
 
 
 def test_rejects_unsupported():

@@ -57,7 +57,7 @@ def test_rab_checks():
     bad_heads = torch.zeros(1, 3, 8, 8, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError, match="Number of heads in rab must be 1 or equal"):
         hstu_attn_varlen_func(q, k, v, cu, cu, None, None, 8, 8, 8, None, None, rab=bad_heads)
-    with pytest.raises(RuntimeError, match="rab must be a bf16"):
+    with pytest.raises(RuntimeError, match="tensor of the dtype of q"):
         hstu_attn_varlen_func(q, k, v, cu, cu, None, None, 8, 8, 8, None, None, rab=torch.zeros(1, 2, 8, 8))
     with pytest.raises(RuntimeError, match="max_seqlen_k"):
         hstu_attn_varlen_func(q, k, v, cu, cu, None, None, 8, 8, 8, None, None, rab=torch.zeros(1, 2, 9, 9, dtype=torch.bfloat16))
