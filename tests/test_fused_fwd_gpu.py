@@ -128,6 +128,36 @@ def test_csr_writing_partition_kernel_against_the_per_op_chain_around_its_size_l
                                    rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("pooling,opt,strategy", [("NONE", "SGD", "TIMESTAMP"), ("SUM", "ADAM", "LFU"), ("MEAN", "EXACT_ROWWISE_ADAGRAD", "STEP")])
+def test_multi_table_batches_of_a_few_hundred_thousand_keys_against_the_per_op_chain(pooling, opt, strategy, monkeypatch):
+    """what the HSTU example's embedding collection sends: several tables, sequence or pooled lookups, 10^5 keys per step --
+    the per-slot-counter path of the fused forward on grids larger than the resident group, against the per-op chain"""
+    dims = (16, 16, 16) if pooling == "NONE" else (8, 16, 32)
+    fmap = [0, 1, 1, 2]
+    ref = _mk(False, dims, cap=1 << 19, pooling=pooling, opt=opt, strategy=strategy, fmap=fmap, learning_rate=0.2, monkeypatch=monkeypatch)
+    dut = _mk(True, dims, cap=1 << 19, pooling=pooling, opt=opt, strategy=strategy, fmap=fmap, learning_rate=0.2, monkeypatch=monkeypatch)
+    rng = np.random.default_rng(11)
+    F, B = 4, 12_000
+    ref.train(); dut.train()
+    for it in range(3):
+        lens = rng.integers(0, 9, size=F * B)
+        off = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)).to(DEV)
+        nk = int(off[-1])
+        keys = torch.from_numpy(((rng.zipf(1.2, nk) + 3 * it) % (150_000 + 40_000 * it)).astype(np.int64)).to(DEV)
+        o_ref, o_dut = ref(keys, off), dut(keys, off)
+        torch.testing.assert_close(o_ref, o_dut, rtol=1e-5, atol=1e-5, msg=f"step {it} ({nk} keys): forward differs")
+        g = torch.rand_like(o_ref) + 0.1
+        o_ref.backward(g); o_dut.backward(g)
+        assert torch.equal(ref.size(), dut.size())
+        assert _counters_clear(dut)
+    for t in range(len(dims)):
+        k1, v1 = ref.export_keys_values(ref._table_names[t], torch.device(DEV))
+        k2, v2 = dut.export_keys_values(dut._table_names[t], torch.device(DEV))
+        o1, o2 = torch.argsort(k1), torch.argsort(k2)
+        assert k1.numel() == k2.numel() and torch.equal(k1[o1], k2[o2])
+        torch.testing.assert_close(v1[o1], v2[o2], rtol=3e-5, atol=3e-6)
+
+
 def test_one_new_key_in_every_tile_gets_one_slot(monkeypatch):
     """cold start: the same unseen keys arrive from dozens of tiles at once; every key must end in exactly one slot and
     the reverse indices must group all its occurrences"""
