@@ -96,7 +96,7 @@ struct AttnArgs {
   int H, causal, group;
   int wl, wr;                  // local window: keys i - wl .. i + wr of query i (-1: unbounded on that side)
   int wskip;                   // 1: tile loops are clipped to the window's band (0: the mask alone applies it; for A/B tests)
-  int rot, max_len;            // (sequence, head) slot of a block rotates with blockIdx.z: see seq_head_of_block
+  int rot, max_len, colmajor;  // block -> (sequence, head, rank) maps: see seq_head_of_block
   // relative attention bias (hstu_api.cpp:100-106,417-430): rab[b][h][i][j] (bf16, padded to max_seqlen_k in i and j) is
   // added to q_i . k_j before alpha and SiLU; head stride 0 = one bias matrix shared by all heads.  NULL: none.
   const uint16_t* rab; int64_t rab_b, rab_h, rab_r;
@@ -211,18 +211,36 @@ __device__ __forceinline__ int band_key_end(const AttnArgs& a, int last_row, int
 // all XCDs: 442 us, 567 TFLOP/s on the same batch (rotation by 1 or H + 1: 632 / 503 us).  A batch whose sequences all
 // have max_len rows gains nothing and keeps the plain grid, where a (sequence, head) column stays on one XCD's L2
 // (rot < 0: rotate by -rot unless the batch is dense; rot > 0: always; 0: never).  All loads below are independent.
-struct BlockSeq { int b, h, start, end; };
+struct BlockSeq { int b, h, start, end, z; };   // z: the block's rank inside its (sequence, head) column
+// A DENSE batch (every sequence has max_len rows) takes the column-major map instead (a.colmajor): the q blocks of one
+// (sequence, head) column stream the SAME K / V tiles, and at L = 4096 the forward moves 64 KB of them per 8.4 MFLOP tile --
+// 128 FLOP per byte, i.e. 640 TFLOP/s at the ~5 TB/s the fabric delivers, which is what the rank-major grid measures
+// (645): there the 256 resident blocks are two ranks of ALL 128 columns, each column's tiles fetched again for every rank.
+// Column-major: workgroup id i goes to XCD i mod 8 (hardware), and ids with the same residue are made the blocks of ONE
+// column after another, heaviest first -- an XCD's 32 CUs then walk a column's key tiles in step and all but the first
+// reader hit that XCD's L2.  Needs B * H to be a multiple of 8 (else the plain grid).  Measured: dense 32 x 4096 forward 1.71 ->
+// 1.66 ms, backward 5.11 -> 4.94 ms; 8 x 4096 unchanged; C3 (4 blocks per column) 48 -> 58 us, hence columns of >= 16 blocks only.
 __device__ __forceinline__ BlockSeq seq_head_of_block(const AttnArgs& a) {
-  const int b0 = blockIdx.y, h0 = blockIdx.x;
-  if (a.rot == 0) return {b0, h0, a.cu_seqlens[b0], a.cu_seqlens[b0 + 1]};
+  const int b0 = blockIdx.y, h0 = blockIdx.x, z0 = blockIdx.z;
+  if (a.rot == 0 && a.colmajor == 0) return {b0, h0, a.cu_seqlens[b0], a.cu_seqlens[b0 + 1], z0};
   const unsigned bh = gridDim.x * gridDim.y;
   const unsigned step = (unsigned)(a.rot < 0 ? -a.rot : a.rot);
-  const unsigned slot = (blockIdx.x + gridDim.x * blockIdx.y + step * blockIdx.z) % bh;
+  const unsigned lin0 = blockIdx.x + gridDim.x * blockIdx.y;
+  const unsigned slot = (lin0 + step * blockIdx.z) % bh;
   const int b1 = (int)(slot / gridDim.x), h1 = (int)(slot - (unsigned)b1 * gridDim.x);
+  // column-major candidate
+  const unsigned lin = lin0 + bh * blockIdx.z, xcd = lin & 7u, k = lin >> 3;
+  const unsigned col = xcd + 8u * (k / gridDim.z);
+  const int z2 = (int)(k % gridDim.z);
+  const bool cm_ok = a.colmajor != 0 && (bh & 7u) == 0 && gridDim.z >= 16;   // (long columns only: at 4 blocks per column it costs 20 %)
+  const int b2 = cm_ok ? (int)(col / gridDim.x) : b0, h2 = cm_ok ? (int)(col % gridDim.x) : h0;
   const int t0 = a.cu_seqlens[0], t1 = a.cu_seqlens[gridDim.y];
   const int s0 = a.cu_seqlens[b0], e0 = a.cu_seqlens[b0 + 1], s1 = a.cu_seqlens[b1], e1 = a.cu_seqlens[b1 + 1];
-  const bool dense = a.rot < 0 && t1 - t0 == (int)gridDim.y * a.max_len;
-  return dense ? BlockSeq{b0, h0, s0, e0} : BlockSeq{b1, h1, s1, e1};
+  const int s2 = a.cu_seqlens[b2], e2 = a.cu_seqlens[b2 + 1];
+  const bool dense = t1 - t0 == (int)gridDim.y * a.max_len;
+  if (dense) return cm_ok ? BlockSeq{b2, h2, s2, e2, z2} : BlockSeq{b0, h0, s0, e0, z0};
+  if (a.rot > 0 || a.rot < 0) return BlockSeq{b1, h1, s1, e1, z0};
+  return BlockSeq{b0, h0, s0, e0, z0};
 }
 // Row block a query-block owner of dispatch rank `rank` takes: heaviest first = the latest rows first (causal).  With contextual
 // rows the FIRST block is the heaviest of all -- its contextual rows reach every history key -- and goes first: left at the
@@ -325,8 +343,8 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
   s.L = a.cu_seqlens_k ? a.cu_seqlens_k[b + 1] - kstart : Lq;
   const int dq = s.L - Lq;   // absolute position of query row r is dq + r
   const int nblk = (Lq + kBM - 1) / kBM;
-  if ((int)blockIdx.z >= nblk || dq < 0) return;
-  const int m0 = row_block_of_rank((int)blockIdx.z, nblk, a, b) * kBM;  // heaviest row blocks first
+  if (bs.z >= nblk || dq < 0) return;
+  const int m0 = row_block_of_rank(bs.z, nblk, a, b) * kBM;  // heaviest row blocks first
   s.has_ctx = a.num_contexts != nullptr;
   s.has_tgt = a.num_targets != nullptr;
   s.c = s.has_ctx ? a.num_contexts[b] : 0;
@@ -812,8 +830,8 @@ __global__ void __launch_bounds__(256) hstu_fwd_dma_kernel(AttnArgs a) {
   s.L = a.cu_seqlens_k ? a.cu_seqlens_k[b + 1] - kstart : Lq;
   const int dq = s.L - Lq;
   const int nblk = (Lq + kBM - 1) / kBM;
-  if ((int)blockIdx.z >= nblk || dq < 0) return;
-  const int m0 = row_block_of_rank((int)blockIdx.z, nblk, a, b) * kBM;
+  if (bs.z >= nblk || dq < 0) return;
+  const int m0 = row_block_of_rank(bs.z, nblk, a, b) * kBM;
   s.has_ctx = a.num_contexts != nullptr;
   s.has_tgt = a.num_targets != nullptr;
   s.c = s.has_ctx ? a.num_contexts[b] : 0;
@@ -1259,7 +1277,7 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
   SeqInfo s;
   s.start = bs.start;
   s.L = bs.end - s.start;
-  const int n0 = blockIdx.z * kBM;   // earliest key blocks (seen by most queries) first
+  const int n0 = bs.z * kBM;   // earliest key blocks (seen by most queries) first
   if (n0 >= s.L) return;
   s.has_ctx = a.num_contexts != nullptr;
   s.has_tgt = a.num_targets != nullptr;
@@ -1577,8 +1595,8 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
   s.start = bs.start;
   s.L = bs.end - s.start;
   const int nblk = (s.L + kBM - 1) / kBM;
-  if ((int)blockIdx.z >= nblk) return;
-  const int m0 = row_block_of_rank((int)blockIdx.z, nblk, a, b) * kBM;
+  if (bs.z >= nblk) return;
+  const int m0 = row_block_of_rank(bs.z, nblk, a, b) * kBM;
   s.has_ctx = a.num_contexts != nullptr;
   s.has_tgt = a.num_targets != nullptr;
   s.c = s.has_ctx ? a.num_contexts[b] : 0;
@@ -1750,8 +1768,8 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_q_ds_kernel(BwdAttnAr
   s.start = bs.start;
   s.L = bs.end - s.start;
   const int nblk = (s.L + kBM - 1) / kBM;
-  if ((int)blockIdx.z >= nblk) return;
-  const int m0 = row_block_of_rank((int)blockIdx.z, nblk, a, b) * kBM;
+  if (bs.z >= nblk) return;
+  const int m0 = row_block_of_rank(bs.z, nblk, a, b) * kBM;
   s.has_ctx = a.num_contexts != nullptr;
   s.has_tgt = a.num_targets != nullptr;
   s.c = s.has_ctx ? a.num_contexts[b] : 0;
@@ -1885,7 +1903,7 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_v_p_kernel(BwdAttnArg
   SeqInfo s;
   s.start = bs.start;
   s.L = bs.end - s.start;
-  const int n0 = blockIdx.z * kBM;
+  const int n0 = bs.z * kBM;
   if (n0 >= s.L) return;
   s.has_ctx = a.num_contexts != nullptr;
   s.has_tgt = a.num_targets != nullptr;
@@ -2134,6 +2152,10 @@ static int block_rotation(int heads) {   // MI355_HSTU_ROT (A/B): see seq_head_o
   static const int v = [] { const char* e = getenv("MI355_HSTU_ROT"); return e ? atoi(e) : 0x7fffffff; }();
   return v == 0x7fffffff ? -heads : v;
 }
+static int column_major() {   // MI355_HSTU_CM=0: dense batches keep the rank-major grid (A/B)
+  static const int v = [] { const char* e = getenv("MI355_HSTU_CM"); return e ? atoi(e) : 1; }();
+  return v;
+}
 static int window_skip() {   // MI355_HSTU_WSKIP=0: keep the full tile loops under a window (A/B tests of the band clipping)
   static const int v = [] { const char* e = getenv("MI355_HSTU_WSKIP"); return e ? atoi(e) != 0 : 1; }();
   return v;
@@ -2189,7 +2211,7 @@ int HSTU_FN(mi355_hstu_attn_fwd_kv)(const void* q, const void* k, const void* v,
   a.q_head = q_head_stride; a.k_head = k_head_stride; a.v_head = v_head_stride; a.o_head = o_head_stride;
   a.cu_seqlens = cu_seqlens_q; a.num_contexts = num_contexts; a.num_targets = num_targets;
   a.H = (int)num_heads; a.causal = causal; a.group = (int)target_group_size;
-  a.wl = tl_wl; a.wr = tl_wr; a.wskip = window_skip(); a.rot = block_rotation((int)num_heads); a.max_len = (int)max_seqlen_q;
+  a.wl = tl_wl; a.wr = tl_wr; a.wskip = window_skip(); a.rot = block_rotation((int)num_heads); a.colmajor = column_major(); a.max_len = (int)max_seqlen_q;
   a.rab = tl_rab.rab; a.rab_b = tl_rab.rb; a.rab_h = tl_rab.rh; a.rab_r = tl_rab.rr;
   a.alpha = alpha; a.inv_scale = 1.0f / scaling_seqlen;
   a.cu_seqlens_k = cu_seqlens_k; a.kv_cache = (const uint16_t*)kv_cache; a.page_offsets = page_offsets; a.page_ids = page_ids;
@@ -2294,7 +2316,7 @@ int HSTU_FN(mi355_hstu_attn_bwd)(const void* dout, const void* q, const void* k,
   a.q_head = q_head_stride; a.k_head = k_head_stride; a.v_head = v_head_stride; a.o_head = 0;
   a.cu_seqlens = cu_seqlens; a.num_contexts = num_contexts; a.num_targets = num_targets;
   a.H = (int)num_heads; a.causal = causal; a.group = (int)target_group_size;
-  a.wl = tl_wl; a.wr = tl_wr; a.wskip = window_skip(); a.rot = block_rotation((int)num_heads); a.max_len = (int)max_seqlen;
+  a.wl = tl_wl; a.wr = tl_wr; a.wskip = window_skip(); a.rot = block_rotation((int)num_heads); a.colmajor = column_major(); a.max_len = (int)max_seqlen;
   a.rab = tl_rab.rab; a.rab_b = tl_rab.rb; a.rab_h = tl_rab.rh; a.rab_r = tl_rab.rr;
   a.alpha = alpha; a.inv_scale = 1.0f / scaling_seqlen;
   g.dout = (const uint16_t*)dout; g.do_row = do_row_stride; g.do_head = do_head_stride;
