@@ -431,6 +431,31 @@ def test_fp16_operands_vs_oracle(d, mode):
         assert np.abs(gn - res[3]).max() <= 2e-3 * np.abs(res[3]).max() + 1e-6
 
 
+@pytest.mark.parametrize("d", [64, 256])
+def test_dense_long_batch_block_map_equals_the_jagged_one(d):
+    """A dense batch of long sequences (every length == max_seqlen, >= 16 blocks per column, B * H a multiple of 8) takes the
+    column-major block -> (sequence, head, rank) map, a batch with one more, short sequence the rotating one
+    (seq_head_of_block): the shared sequences must come out bit-identical, forward and backward -- the map only decides
+    where a block runs."""
+    torch.manual_seed(d)
+    B, H, L = 4, 2, 2048
+    T = B * L
+    q, k, v, dout = (torch.empty(T + 100, H, d, device=DEV).uniform_(-1, 1).bfloat16() for _ in range(4))
+    off_d = np.arange(0, T + 1, L)
+    off_j = np.concatenate([off_d, [T + 100]])
+    alpha = 1.0 / d ** 0.5
+    o_d, g_d = _run(q[:T], k[:T], v[:T], off_d, L, None, None, 1, True, alpha, dout=dout[:T], scaling=L)
+    o_j, g_j = _run(q, k, v, off_j, L, None, None, 1, True, alpha, dout=dout, scaling=L)
+    assert torch.equal(o_d, o_j[:T])
+    for a_, b_ in zip(g_d, g_j):
+        assert torch.equal(a_, b_[:T])
+    # and against the float64 oracle on one (sequence, head) column
+    qn, kn, vn = (t[L:2 * L, 1:2].float().cpu().numpy() for t in (q, k, v))
+    ref = ho.hstu_attn_fwd(qn, kn, vn, np.array([0, L]), alpha, L, True, None, None, 1)
+    got = o_d.detach()[L:2 * L, 1:2].float().cpu().numpy()
+    assert np.abs(got - ref).max() <= 6e-3 * np.abs(ref).max() + 1e-6
+
+
 def test_rejects_unsupported():
     from hstu import hstu_attn_varlen_func
 
