@@ -1,17 +1,11 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r3m; mkdir -p $O; L=$R/recsys-examples_amd/lib
-cd $R
-( timeout 900 python -m pytest tests/test_fused_fwd_gpu.py tests/test_module_gpu.py tests/test_twin_gpu.py tests/test_plugin_surface_gpu.py -m gpu -x -q ) > $O/pytest.log 2>&1
-grep -E "passed|failed|error" $O/pytest.log | tail -3
-E="timeout 300 python tools/bench_extended.py --only c2_fwd_only_eval,c2_fwd_only_train,c2_16x_batch,c2_adam,c2_bf16_table"
-$E > $O/ext_ev6.json 2> $O/err.txt
-for w in 5 8; do MI355_LIB=$L/librecsys_amd_ev$w.so timeout 300 python tools/bench_extended.py --only c2_fwd_only_eval > $O/ext_ev$w.json 2>> $O/err.txt; done
-MI355_EVAL_FUSED=0 timeout 300 python tools/bench_extended.py --only c2_fwd_only_eval > $O/ext_ev_off.json 2>> $O/err.txt
-python - <<PY
-import json,glob,os
-for f in sorted(glob.glob('$O/ext_*.json')):
-    try:
-        d=json.loads(open(f).read().strip().splitlines()[-1])
-        print(os.path.basename(f), {k:(round(v['ms_per_step']*1e3,1) if 'ms_per_step' in v else v) for k,v in d.items() if isinstance(v,dict)})
-    except Exception as e: print(f, 'ERR', e)
-PY
+mkdir -p gpurun_out/r3m
+timeout 600 python tools/bench_model_shapes.py > gpurun_out/r3m/out.txt 2>&1; grep -v amdgpu gpurun_out/r3m/out.txt | tail -12
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace -d $R/gpurun_out/r3m/prof -o t -- python $R/tools/bench_model_shapes.py --steps 20 > /dev/null 2>&1
+db=$(find $R/gpurun_out/r3m/prof -name '*.db' | head -1)
+python $R/tools/rocpd_timeline.py $db 60 > $R/gpurun_out/r3m/timeline.txt
+python $R/tools/rocpd_stats.py $db > $R/gpurun_out/r3m/stats.txt
+rm -rf $R/gpurun_out/r3m/prof
+head -25 $R/gpurun_out/r3m/stats.txt | cut -c1-150
