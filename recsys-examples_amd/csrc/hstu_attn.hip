@@ -1059,6 +1059,335 @@ __global__ void __launch_bounds__(256) hstu_fwd_dma_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Forward with TWO waves per SIMD (round 4; head dim 256, contiguous keys, no bias): an 8-wave workgroup whose waves are
+// specialised by GEMM instead of sharing one instruction stream.
+//   waves 0-3 ("S waves"):  hold the Q fragments (64 registers); per 64-key tile S^T = K Q^T (32 MFMAs), alpha / SiLU /
+//                           mask / 1/N on the accumulator, pack to bf16 -- the result is already the B operand of GEMM 2
+//                           -- and hand it on through LDS: 4 x ds_write_b128 per lane and tile (4 KB per wave).
+//   waves 4-7 ("O waves"):  hold the O^T accumulator (128 AGPRs); per tile read that P^T back (4 x ds_read_b128, the same
+//                           lane-linear image: conflict free) and run O^T += V^T P^T (32 MFMAs, V^T fragments by
+//                           transpose reads).  They also issue the LDS-DMA of the K / V tiles: they have no VALU work.
+// Wave w and wave w + 4 own the same 32 query rows and sit on the same SIMD (a workgroup's waves go round the 4 SIMDs), so
+// every SIMD alternates a matrix + VALU stream with a matrix + memory stream: the SiLU of one no longer stalls the MFMAs of
+// the other, and neither wave needs more than ~200 registers (the one-stream kernel: 222 + 160).  The O wave runs ONE tile
+// behind its S wave: iteration i = { S wave: tile i -> P[i & 1] | O wave: P[(i - 1) & 1], V tile i - 1 }, one barrier per
+// iteration.  LDS = K ring 2 x 32 KB + V ring 2 x 32 KB + P ring 2 x 4 x 4 KB = 160 KB, all of it.
+// The K / V images and swizzles are those of hstu_fwd_dma_kernel.
+// ---------------------------------------------------------------------------------------------------
+#ifndef HSTU_PC_SDMA
+#define HSTU_PC_SDMA 0   // LDS-DMA instructions per tile and tensor issued by each S wave (of 32; the O waves issue the rest)
+#endif
+#ifndef HSTU_PC_PRIO
+#define HSTU_PC_PRIO 0   // static wave priority: 1 = the O waves (the younger half) at s_setprio 1, 2 = the S waves
+#endif
+template <int D, bool kWin>
+__global__ void __launch_bounds__(512) hstu_fwd_pc_kernel(AttnArgs a) {
+  static_assert(D == 256, "rows of 32 chunks");
+  constexpr int CPR = D / 8;            // 16-byte chunks per row
+  constexpr int RPI = 64 / CPR;         // rows per DMA wave-instruction (1 KB)
+  constexpr int ROWB = D;               // row stride in LDS (elements): unpadded
+  constexpr int TENS = kBN * ROWB;      // elements of one K (or V) tile
+  constexpr int NINS = kBN / RPI;       // DMA instructions per tile and tensor (32)
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [K 0 | K 1 | V 0 | V 1 | P 0 | P 1]
+  uint16_t* const Kring = smem;
+  uint16_t* const Vring = smem + 2 * TENS;
+  uint16_t* const Pring = smem + 4 * TENS;   // [2][4 pairs][4 key slices][64 lanes] x 16 B
+
+  const BlockSeq bs = seq_head_of_block(a);
+  const int b = bs.b, h = bs.h;
+  SeqInfo s;
+  s.start = bs.start;
+  const int Lq = bs.end - s.start;
+  const int kstart = a.cu_seqlens_k ? a.cu_seqlens_k[b] : s.start;
+  s.L = a.cu_seqlens_k ? a.cu_seqlens_k[b + 1] - kstart : Lq;
+  const int dq = s.L - Lq;
+  const int nblk = (Lq + kBM - 1) / kBM;
+  if (bs.z >= nblk || dq < 0) return;
+  const int m0 = row_block_of_rank(bs.z, nblk, a, b) * kBM;
+  s.has_ctx = a.num_contexts != nullptr;
+  s.has_tgt = a.num_targets != nullptr;
+  s.c = s.has_ctx ? a.num_contexts[b] : 0;
+  s.hlen = s.L - (s.has_tgt ? a.num_targets[b] : 0);
+  s.wl = kWin ? a.wl : -1; s.wr = kWin ? a.wr : -1;
+
+  const int lane = lane_id(), hi = lane >> 5, l31 = lane & 31;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int role = wv >> 2, pw = wv & 3;    // role 0: S wave, 1: O wave; pw: the pair's 32-row group
+  const int qrow0 = m0 + 32 * pw, qloc = qrow0 + l31, qi = dq + qloc;
+  const bool wave_live = qrow0 < Lq;
+  int last_row = dq + (m0 + kBM - 1 < Lq - 1 ? m0 + kBM - 1 : Lq - 1);
+  int n_end = s.L;
+  if (a.causal) {
+    n_end = last_row + 1;
+    if (s.has_ctx && dq + m0 < s.c && s.hlen > n_end) n_end = s.hlen;
+  }
+  if (kWin) n_end = band_key_end(a, last_row, n_end);
+  const int n_beg = kWin ? band_key_begin(a, dq + m0, kBN) : 0;
+  int w_last = dq + (qrow0 + 31 < Lq - 1 ? qrow0 + 31 : Lq - 1);
+  int w_end = s.L;
+  if (a.causal) {
+    w_end = w_last + 1;
+    if (s.has_ctx && dq + qrow0 < s.c && s.hlen > w_end) w_end = s.hlen;
+  }
+  if (kWin) w_end = band_key_end(a, w_last, w_end);
+  const int w_beg = kWin ? band_key_begin(a, dq + qrow0, kBN) : 0;
+  const int T = n_end > n_beg ? (n_end - n_beg + kBN - 1) / kBN : 0;   // key tiles of the block
+
+  // ---- the DMA of one tile of one tensor: instruction j moves rows 2 j, 2 j + 1.  S wave pw issues instructions
+  // [HSTU_PC_SDMA pw, + HSTU_PC_SDMA), O wave pw the rest dealt evenly.  Lane -> (row inside the instruction, LDS chunk slot p);
+  // the lane fetches global chunk p ^ swizzle(row).  Addressing: a wave-uniform 64-bit row base (SGPR arithmetic) plus a
+  // per-lane 32-bit offset that depends on the instruction only through j mod 8 -- NMY registers per tensor computed once
+  // (64-bit per-lane pointers per instruction cost 2 multiplies and a spilled pointer each, and the reload's vmcnt(0)
+  // serialised the DMAs).  Rows past the sequence end (the sequence's last tile only) are read clamped: their P is zero.
+  const uint16_t* kg = a.k + (int64_t)kstart * a.k_row + (int64_t)h * a.k_head;
+  const uint16_t* vg = a.v + (int64_t)kstart * a.v_row + (int64_t)h * a.v_head;
+  const int dma_r = lane / CPR, dma_p = lane % CPR;
+  constexpr int NS = HSTU_PC_SDMA, NO = (NINS - 4 * NS) / 4;
+  static_assert(4 * NS + 4 * NO == NINS, "the instruction split must cover the tile");
+  constexpr int NMY = NS > NO ? NS : NO;
+  const int j_first = role == 0 ? NS * pw : 4 * NS + NO * pw;
+  const int n_my = role == 0 ? NS : NO;
+  uint32_t kvoff[NMY], vvoff[NMY];
+#pragma unroll
+  for (int u = 0; u < NMY; ++u) {
+    const int r = RPI * (j_first + u) + dma_r;
+    kvoff[u] = (uint32_t)dma_r * (uint32_t)a.k_row * 2u + 16u * (uint32_t)(dma_p ^ (r & 15));
+    vvoff[u] = (uint32_t)dma_r * (uint32_t)a.v_row * 2u + 16u * (uint32_t)(dma_p ^ ((r & 3) << 2));
+  }
+  // The DMA instruction is issued from inline asm: hipcc models the builtin as an LDS store in flight and puts a
+  // vmcnt(0) in front of the next transpose read of ANY LDS address (seen in hstu_fwd_dma_kernel's GEMM 2: the prefetch
+  // it was meant to overlap is drained first).  Here the completion is counted by hand: vmcnt(0) + barrier at the loop head.
+  auto dma16 = [&](const char* sbase, uint32_t voff, uint32_t lds_byte) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_byte), "s"(sbase) : "memory");
+  };
+  auto issue_dma = [&](const uint16_t* g, int64_t g_row, const uint32_t (&voff)[NMY], uint16_t* ring, int tile) {
+    const int n0 = n_beg + kBN * tile;
+    const uint32_t dst = (uint32_t)(uintptr_t)(lds_void_t)(ring + (tile & 1) * TENS + RPI * j_first * ROWB);
+    if (n0 + kBN <= s.L) {
+      const char* sb = reinterpret_cast<const char*>(g + (int64_t)(n0 + RPI * j_first) * g_row);
+      const int64_t step = (int64_t)RPI * g_row * 2;
+#pragma unroll
+      for (int u = 0; u < NMY; ++u)
+        if (u < n_my) dma16(sb + u * step, voff[u], dst + u * (RPI * ROWB * 2));
+    } else {
+      const uint32_t rowterm = (uint32_t)dma_r * (uint32_t)g_row * 2u;
+#pragma unroll
+      for (int u = 0; u < NMY; ++u)
+        if (u < n_my) {
+          const int row0 = n0 + RPI * (j_first + u);                   // wave-uniform: the instruction's first row
+          const int rowc = row0 < s.L ? row0 : s.L - 1;                // clamped to the sequence
+          const uint32_t drop = row0 + 1 < s.L ? 0u : 0xffffffffu;     // its second row is past the end: read the first again
+          dma16(reinterpret_cast<const char*>(g + (int64_t)rowc * g_row), voff[u] - (rowterm & drop), dst + u * (RPI * ROWB * 2));
+        }
+    }
+  };
+
+  // ---- S wave state: Q fragments (B operand of GEMM 1) and the row mask
+  bf16x8_t qf[D / 16];
+  const float nal2e = -a.alpha * 1.44269504088896f, ais = a.alpha * a.inv_scale;
+  const RowMask rm = row_mask(qi < s.L ? qi : s.L - 1, s, a.causal, a.group);
+  // ---- O wave state
+  f32x16_t acc_o[D / 32];
+
+  if (T > 0) issue_dma(kg, a.k_row, kvoff, Kring, 0);
+  if (HSTU_PC_PRIO != 0 && role == (HSTU_PC_PRIO == 1 ? 1 : 0)) __builtin_amdgcn_s_setprio(1);
+
+  // fragment addresses under the swizzles (as hstu_fwd_dma_kernel)
+  const int kx = l31 & 15;
+  const int il = lane & 15, g1 = (lane >> 4) & 1, vq = il >> 2;
+  const int v_row_off = (4 * hi + vq) * ROWB + 4 * (il & 1);
+  const int v_chunk_lo = 2 * g1 + ((il & 3) >> 1);
+  auto v_frag = [&](const uint16_t* Vb, int dt, int ks) -> bf16x8_t {
+    typedef short v4s_t __attribute__((ext_vector_type(4)));
+    typedef short v8s_t __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) v4s_t* lds_v4s_t;
+    const uint16_t* p0 = Vb + (16 * ks) * ROWB + v_row_off + 8 * ((4 * (dt ^ vq)) + v_chunk_lo);
+    const v4s_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(p0));
+    const v4s_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(p0 + 8 * ROWB));
+    const v8s_t r = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    return __builtin_bit_cast(bf16x8_t, r);
+  };
+
+  // Two loops, one per role, with the same trip count and ONE barrier per iteration each (a single loop with the role
+  // test inside keeps Q and the O accumulator live together: 192 registers before anything else, 363 spilled).
+#if HSTU_TIMING
+  unsigned tsum[7] = {0, 0, 0, 0, 0, 0, 0};   // wait for own DMA, barrier, DMA issue, role, GEMM 1, SiLU + hand-off | GEMM 2, tiles
+  tsum[3] = (unsigned)role;
+  const unsigned t_start = tick();
+  auto t_dump = [&]() {
+    const unsigned t_end = tick();
+    if (lane == 0) {
+      const int blk = ((int)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      unsigned long long* d = g_hstu_dbg + ((size_t)(blk * 8 + wv) % 65536) * 8;
+      for (int i = 0; i < 7; ++i) d[i] = tsum[i];
+      d[7] = t_end - t_start;
+    }
+  };
+#endif
+  auto head = [&](int it) {
+    TICK(t0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces (K tile it, V tile it - 1) have landed ...
+    TICK(t1);
+    __syncthreads();                                    // ... everyone's have, P[it - 1] is written, the other buffers are free
+    TICK(t2);
+    if (it + 1 < T) issue_dma(kg, a.k_row, kvoff, Kring, it + 1);
+    if (it < T) issue_dma(vg, a.v_row, vvoff, Vring, it);
+    TICK(t3);
+    TACC(0, t0, t1); TACC(1, t1, t2); TACC(2, t2, t3);
+  };
+  if (role == 0) {
+    // =========================== S wave: tile `it` -> P ring slot it & 1 ===========================
+    {
+      const uint16_t* qp = a.q + (int64_t)(s.start + (qloc < Lq ? qloc : 0)) * a.q_row + (int64_t)h * a.q_head + 8 * hi;
+#pragma unroll
+      for (int sl = 0; sl < D / 16; ++sl) {
+        uint4 t = make_uint4(0, 0, 0, 0);
+        if (qloc < Lq) t = *reinterpret_cast<const uint4*>(qp + 16 * sl);
+        qf[sl] = *reinterpret_cast<bf16x8_t*>(&t);
+      }
+    }
+    for (int it = 0; it <= T; ++it) {
+      head(it);
+      const int n0 = n_beg + kBN * it;
+      if (it >= T || !wave_live || n0 >= w_end || n0 < w_beg) continue;
+      const uint16_t* Ks = Kring + (it & 1) * TENS;
+      TICK(t5);
+      f32x16_t acc_s[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        constexpr int SLB = 4, NBAT = (D / 16) / SLB;
+        bf16x8_t kfr[2][SLB];
+        auto load_b = [&](int bi, int buf) {
+#pragma unroll
+          for (int u = 0; u < SLB; ++u) {
+            const int sl = SLB * bi + u;
+            const int ch = ((2 * sl) ^ (kx & 14)) + (hi ^ (kx & 1));
+            kfr[buf][u] = *reinterpret_cast<const bf16x8_t*>(Ks + (32 * t + l31) * ROWB + 8 * ch);
+          }
+        };
+        load_b(0, 0);
+#pragma unroll
+        for (int bi = 0; bi < NBAT; ++bi) {
+          if (bi + 1 < NBAT) load_b(bi + 1, (bi + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < SLB; ++u) {
+            if (bi == 0 && u == 0) mfma_v0(acc_s[t], kfr[bi & 1][u], qf[SLB * bi + u]);
+            else mfma_v(acc_s[t], kfr[bi & 1][u], qf[SLB * bi + u]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      TICK(t6);
+      TACC(4, t5, t6);
+      const bool full = a.causal && s.wl < 0 && (n0 + kBN - 1 <= dq + qrow0) && (!s.has_ctx || dq + qrow0 >= s.c) && (!s.has_tgt || n0 + kBN - 1 < s.hlen);
+      u32x4_t* pdst = reinterpret_cast<u32x4_t*>(Pring) + (((it & 1) * 4 + pw) * 4) * 64 + lane;
+      auto emit = [&](auto fullc) {
+        constexpr bool kFull = decltype(fullc)::value;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int t = ks >> 1, r0 = (ks & 1) * 8;
+          uint32_t pk[4];
+#pragma unroll
+          for (int r = 0; r < 8; r += 2) {
+            float p2[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int rr = r0 + r + u;
+              const float pv = silu_scaled(acc_s[t][rr], nal2e, ais);
+              if (kFull) p2[u] = pv;
+              else {
+                const int key = n0 + 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+                p2[u] = key_ok(key, rm) ? pv : 0.f;
+              }
+            }
+            pk[r >> 1] = pack_bf16(p2[0], p2[1]);
+          }
+          const u32x4_t x = {pk[0], pk[1], pk[2], pk[3]};
+          pdst[ks * 64] = x;
+        }
+      };
+      if (full) emit(std::true_type{}); else emit(std::false_type{});
+      TICK(t7);
+      TACC(5, t6, t7);
+#if HSTU_TIMING
+      tsum[6] += 1;
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no DMA may be in flight into LDS when the block retires)
+#if HSTU_TIMING
+    t_dump();
+#endif
+    return;
+  }
+  {
+    // =========================== O wave: tile `it - 1` from P ring slot (it - 1) & 1 ===========================
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_o[dt][r] = 0.f;
+    for (int it = 0; it <= T; ++it) {
+      pin_agpr(acc_o);
+      head(it);
+      pin_agpr(acc_o);
+      const int tl = it - 1, n0 = n_beg + kBN * tl;
+      if (it == 0 || !wave_live || n0 >= w_end || n0 < w_beg) continue;
+      const uint16_t* Vt = Vring + (tl & 1) * TENS;
+      TICK(t6);
+      const u32x4_t* psrc = reinterpret_cast<const u32x4_t*>(Pring) + (((tl & 1) * 4 + pw) * 4) * 64 + lane;
+      bf16x8_t pf[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) pf[ks] = __builtin_bit_cast(bf16x8_t, psrc[ks * 64]);
+      constexpr int NDT = D / 32, DB = 4;
+      constexpr int NBAT2 = 4 * (NDT / DB);
+      bf16x8_t vfr[2][DB];
+      auto load_v = [&](int bi, int buf) {
+        const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
+#pragma unroll
+        for (int u = 0; u < DB; ++u) vfr[buf][u] = v_frag(Vt, dt0 + u, ks);
+      };
+      load_v(0, 0);
+      pin_agpr(acc_o);
+#pragma unroll
+      for (int bi = 0; bi < NBAT2; ++bi) {
+        const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
+        if (bi + 1 < NBAT2) load_v(bi + 1, (bi + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < DB; ++u) mfma_a(acc_o[dt0 + u], vfr[bi & 1][u], pf[ks]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      TICK(t7);
+      TACC(5, t6, t7);
+#if HSTU_TIMING
+      tsum[6] += 1;
+#endif
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no DMA may be in flight into LDS when the block retires)
+#if HSTU_TIMING
+  t_dump();
+#endif
+  {
+    fence_a(acc_o);
+    if (qloc < Lq) {
+      uint16_t* op = a.out + (int64_t)(s.start + qloc) * a.o_row + (int64_t)h * a.o_head;
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          uint2 o;
+          o.x = pack_bf16(acc_o[dt][4 * g4 + 0], acc_o[dt][4 * g4 + 1]);
+          o.y = pack_bf16(acc_o[dt][4 * g4 + 2], acc_o[dt][4 * g4 + 3]);
+          *reinterpret_cast<uint2*>(op + 32 * dt + 8 * g4 + 4 * hi) = o;
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Backward (reference: hstu_varlen_bwd -> hstu_bwd.h, core maths :687-729).  With s = alpha <q,k>:
 //   P  = M SiLU(s) / N            dV = P^T dO
 //   dP = dO V^T                   dS = M dP SiLU'(s) alpha / N       dQ = dS K      dK = dS^T Q
@@ -2114,6 +2443,25 @@ static int launch_fwd_dma(const AttnArgs& a, int B, int max_seqlen, hipStream_t 
   return MI355_OK;
 }
 
+// the two-waves-per-SIMD forward (default at head dim 256; MI355_HSTU_PC=0 = the one-stream LDS-DMA kernel)
+template <int D>
+static int launch_fwd_pc(const AttnArgs& a, int B, int max_seqlen, hipStream_t stream) {
+  const size_t smem = (size_t)(4 * kBN * D + 2 * 4 * 4 * 64 * 8) * sizeof(uint16_t);   // K ring + V ring + P ring = 160 KB
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_pc_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_pc_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess) return MI355_ELAUNCH;
+    attr_set = true;
+  }
+  dim3 grid(a.H, B, (max_seqlen + kBM - 1) / kBM);
+  if (a.wl >= 0 || a.wr >= 0) hipLaunchKernelGGL((hstu_fwd_pc_kernel<D, true>), grid, dim3(512), smem, stream, a);
+  else hipLaunchKernelGGL((hstu_fwd_pc_kernel<D, false>), grid, dim3(512), smem, stream, a);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
 template <int D>
 static int launch_fwd(const AttnArgs& a, int B, int max_seqlen, hipStream_t stream) {
   const size_t vtile = HSTU_VTR ? (size_t)kBN * (D == 32 ? 32 : D + 32) : (size_t)D * (kBN + 8);
@@ -2217,6 +2565,8 @@ int HSTU_FN(mi355_hstu_attn_fwd_kv)(const void* q, const void* k, const void* v,
   a.cu_seqlens_k = cu_seqlens_k; a.kv_cache = (const uint16_t*)kv_cache; a.page_offsets = page_offsets; a.page_ids = page_ids;
   a.last_page_lens = last_page_lens; a.page_size = (int)page_size;
   static const int use_dma = getenv("MI355_HSTU_DMA") ? atoi(getenv("MI355_HSTU_DMA")) : 1;   // default since round 3: +4..9 % on every d = 256 shape measured
+  static const int use_pc = getenv("MI355_HSTU_PC") ? atoi(getenv("MI355_HSTU_PC")) : 1;   // round 4: two waves per SIMD, S waves + O waves
+  if (use_pc && head_dim == 256 && !a.kv_cache && !a.rab) return launch_fwd_pc<256>(a, (int)batch, (int)max_seqlen_q, stream);
   if (use_dma && head_dim == 256 && !a.kv_cache && !a.rab) return launch_fwd_dma<256>(a, (int)batch, (int)max_seqlen_q, stream);
   switch (head_dim) {
     case 32: return launch_fwd<32>(a, (int)batch, (int)max_seqlen_q, stream);

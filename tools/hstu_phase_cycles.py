@@ -16,10 +16,16 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32); ap.add_argument("--seqlen", type=int, default=512)
 ap.add_argument("--heads", type=int, default=4); ap.add_argument("--dim", type=int, default=256)
 ap.add_argument("--dma", action="store_true", help="the LDS-DMA staged forward (sets MI355_HSTU_DMA=1)")
+ap.add_argument("--pc", action="store_true", help="the two-waves-per-SIMD forward (hstu_fwd_pc_kernel: S waves / O waves; the default forward)")
 ap.add_argument("--bwd", action="store_true", help="the dK pass of the backward (hstu_bwd_kv_kernel, exchange mode) instead of the forward")
 a = ap.parse_args()
 if a.dma:
     os.environ["MI355_HSTU_DMA"] = "1"   # read by the library at its first forward
+    os.environ["MI355_HSTU_PC"] = "0"
+if a.pc:
+    os.environ["MI355_HSTU_PC"] = "1"
+elif not a.bwd:
+    os.environ.setdefault("MI355_HSTU_PC", "0")
 dev = torch.device("cuda")
 T = a.batch * a.seqlen
 cu = torch.arange(0, T + 1, a.seqlen, dtype=torch.int32, device=dev)
@@ -36,6 +42,21 @@ buf = np.zeros((65536, 8), np.uint64)
 lib = ctypes.CDLL(mi355_native.LIB_PATH)
 lib.mi355_hstu_dbg_dump.argtypes = [ctypes.c_void_p, ctypes.c_int64]
 assert lib.mi355_hstu_dbg_dump(buf.ctypes.data, buf.nbytes) == 0
+if a.pc:
+    n = min(nblk * 8, 65536)
+    dd = buf[:n].astype(np.float64)
+    for role, nm0 in ((0, "S waves (GEMM 1 + SiLU -> P)"), (1, "O waves (DMA + GEMM 2)")):
+        d = dd[dd[:, 3] == role]
+        tiles, tot = d[:, 6], d[:, 7]
+        print(f"{nm0}: waves {len(d)}  tiles/wave avg {tiles.mean():.2f}  wave lifetime avg {tot.mean():.0f} cyc  max {tot.max():.0f}")
+        names = ["wait own DMA", "barrier", "DMA issue", None, "gemm1", "silu + P hand-off" if role == 0 else "P read + gemm2"]
+        for i, nm in enumerate(names):
+            if nm is None or (role == 1 and i == 4):
+                continue
+            print(f"  {nm:22s} {d[:, i].sum() / tiles.sum():8.0f} cyc per computed tile   ({100 * d[:, i].sum() / tot.sum():5.1f} % of wave lifetime)")
+        used = d[:, [0, 1, 2, 4, 5]].sum()
+        print(f"  {'other':22s} {(tot.sum() - used) / tiles.sum():8.0f} cyc per computed tile   ({100 * (tot.sum() - used) / tot.sum():5.1f} %)")
+    sys.exit(0)
 d = buf[:n].astype(np.float64)
 tiles = d[:, 6]
 names = (["barrier1", "fetch (load + wait)", "commit x2 images", "barrier2", "gemm S + dP", "silu' + P/dS stores"] if a.bwd
