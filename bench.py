@@ -154,22 +154,74 @@ def _with_bag_ids(batches):
     return [(k, o, torch.repeat_interleave(torch.arange(o.numel() - 1), o[1:] - o[:-1])) for k, o in batches]
 
 
+def _physical_cores() -> int:
+    """Physical cores of this host (SMT siblings counted once): distinct thread_siblings_list entries under sysfs, the
+    figure `lscpu` derives its "Core(s) per socket x Socket(s)" from; falls back to os.cpu_count()."""
+    import glob
+
+    sibs = set()
+    for f in glob.glob("/sys/devices/system/cpu/cpu[0-9]*/topology/thread_siblings_list"):
+        try:
+            sibs.add(open(f).read().strip())
+        except OSError:
+            pass
+    n = len(sibs) or (os.cpu_count() or 1)
+    try:   # never more threads than this process may run on (cgroup / affinity limits of the box)
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    return max(n, 1)
+
+
+def _cpu_torch_ebc_run(weight, dim, batches_cpu, threads, seconds, lr=0.1):
+    """What an unsharded TorchRec CPU EmbeddingBagCollection executes per step: TorchRec's CPU EBC is a dict of
+    `torch.nn.EmbeddingBag(mode="sum", include_last_offset=True)` modules; its forward is `F.embedding_bag`, its backward with
+    `sparse=True` leaves a sparse gradient of the touched rows and `torch.optim.SGD` applies it row-wise.  Same key stream,
+    fwd + bwd + SGD.  -> (keys/s, batches timed, keys timed)"""
+    torch.set_num_threads(threads)
+    emb = torch.nn.EmbeddingBag(weight.shape[0], dim, mode="sum", sparse=True, include_last_offset=True, _weight=weight)
+    opt = torch.optim.SGD(emb.parameters(), lr=lr)
+    keys_done, spent, iters = 0, 0.0, 0
+    while spent < seconds:
+        for keys, offsets, _bag in batches_cpu:
+            B = offsets.numel() - 1
+            g = torch.ones(B, dim)
+            t = time.perf_counter()
+            out = emb(keys, offsets)            # F.embedding_bag(mode="sum", include_last_offset=True)
+            opt.zero_grad(set_to_none=True)
+            out.backward(g)                     # sparse gradient (sparse=True)
+            opt.step()                          # sparse SGD
+            dt_ = time.perf_counter() - t
+            if iters > 0:  # the first iteration is warm-up
+                spent += dt_
+                keys_done += keys.numel()
+            iters += 1
+            if spent >= seconds:
+                break
+    return (keys_done / spent if spent > 0 else 0.0), iters - 1, keys_done
+
+
 def cpu_baseline(args, batches_cpu):
-    """SURVEY 8(d) CPU baseline: the reference's TorchRec CPU EmbeddingBagCollection path on THIS host (TorchRec / FBGEMM are
-    not installed: the same arithmetic as dense index_add_ accumulation per bag and per key), same key stream, fwd + bwd +
-    SGD, at 1 thread and at all host threads; `value` is the better of the two and `cores` the thread count it used.  About
-    8 s of host time (`--cpu-seconds`).  Plus the C1 plumbing configuration."""
+    """SURVEY 8(d) CPU baseline: the reference's TorchRec CPU EmbeddingBagCollection path on THIS host -- TorchRec itself is
+    not installed on the box, so its per-table module is timed directly: `torch.nn.EmbeddingBag(mode="sum",
+    include_last_offset=True, sparse=True)` forward + sparse backward + `torch.optim.SGD` (kind "port": the same torch
+    operators TorchRec's CPU EBC dispatches to), on the C2 key stream, at 1 thread and at the host's PHYSICAL cores; `value`
+    is the better of the two and `cores` the thread count it used.  Second key `index_add_port`: the dense `index_add_`
+    restatement of rounds 2-3 at the same thread counts.  About `--cpu-seconds` of host time.  Plus the C1 plumbing
+    configuration (BASELINE configs[0]) through the same EmbeddingBag path."""
     ncpu = os.cpu_count() or 1
+    phys = _physical_cores()
     t0 = time.time()
     weight = _cpu_table(args.rows, args.dim)
     batches_cpu = _with_bag_ids(batches_cpu)
-    counts = sorted({1, ncpu})
-    per = {}
+    counts = sorted({1, phys})
+    per, per_port = {}, {}
     sample = []
     for th in counts:
-        v, nb, nk = _cpu_ebc_run(weight, args.dim, batches_cpu, th, 0.8 * args.cpu_seconds / len(counts))
+        v, nb, nk = _cpu_torch_ebc_run(weight, args.dim, batches_cpu, th, 0.55 * args.cpu_seconds / len(counts))
         per[th] = v
         sample.append(f"{th} threads: {nb} batches / {nk} keys")
+        per_port[th] = _cpu_ebc_run(weight, args.dim, batches_cpu, th, 0.25 * args.cpu_seconds / len(counts))[0]
     best = max(per, key=per.get)
     # C1 (BASELINE configs[0]): 1 table x 100 K rows x 32-D, batch 512 bags of 1..10 keys, CPU path only
     g = torch.Generator().manual_seed(0)
@@ -181,17 +233,20 @@ def cpu_baseline(args, batches_cpu):
         c1.append((torch.randint(0, 100_000, (int(off[-1]),), generator=g), off))
     w1 = _cpu_table(100_000, 32)
     c1 = _with_bag_ids(c1)
-    c1_per = {th: _cpu_ebc_run(w1, 32, c1, th, 0.1 * args.cpu_seconds / len(counts))[0] for th in counts}
+    c1_per = {th: _cpu_torch_ebc_run(w1, 32, c1, th, 0.1 * args.cpu_seconds / len(counts))[0] for th in counts}
     torch.set_num_threads(ncpu)
     return {"value": per[best], "unit": "lookups/s", "cores": best, "kind": "port",
-            "value_by_threads": {str(k): v for k, v in per.items()}, "value_1_thread": per[1], "value_all_threads": per[ncpu],
-            "cpu_model": _cpu_model(), "os_cpu_count": ncpu,
+            "what": "torch.nn.EmbeddingBag(mode='sum', include_last_offset=True, sparse=True) fwd + sparse bwd + torch.optim.SGD "
+                    "(the operators TorchRec's CPU EmbeddingBagCollection dispatches to; TorchRec is not installed here)",
+            "value_by_threads": {str(k): v for k, v in per.items()}, "value_1_thread": per[1], "value_physical_cores": per[phys],
+            "physical_cores": phys, "cpu_model": _cpu_model(), "os_cpu_count": ncpu,
+            "index_add_port": {"what": "dense index_add_ accumulation per bag / per key (rounds 2-3 baseline)",
+                               "value_by_threads": {str(k): v for k, v in per_port.items()}},
             "c1": {"workload": "C1: 1 table x 100000 rows x 32-D fp32, batch 512 bags x randint(1,11) keys, SUM, SGD",
                    "value_by_threads": {str(k): v for k, v in c1_per.items()}, "value": max(c1_per.values()),
                    "unit": "lookups/s"},
-            "sample": f"C2 key stream on a {args.rows}x{args.dim} fp32 host table: pooled forward and SGD backward as dense "
-                      f"index_add_ accumulation (no FBGEMM, no sparse coalesce); " + "; ".join(sample) +
-                      f"; {time.time() - t0:.0f} s of host time incl. table setup"}
+            "sample": f"C2 key stream on a {args.rows}x{args.dim} fp32 host table: EmbeddingBag(sum) forward, sparse backward, "
+                      f"sparse SGD; " + "; ".join(sample) + f"; {time.time() - t0:.0f} s of host time incl. table setup"}
 
 
 def kernel_roofline(module, batches, grad, batch, D, e=4, o=2):
@@ -229,7 +284,7 @@ def kernel_roofline(module, batches, grad, batch, D, e=4, o=2):
     # the one of the committed separate rocprofv3 --pmc passes over THIS command (tools/pmc_run.sh, C2 batch size only)
     traffic, src = None, None
     if batch == 65536:
-        for tag in ("r03", "r02", "r01"):
+        for tag in ("r04", "r03", "r02", "r01"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")))["kernels"]
                 key = dom[0] if dom[0] in pmc else dom[0].replace("late", "pipe")
@@ -543,6 +598,30 @@ def main():
         sus = float(t.item())
     result["sustained"] = {"steps": sus_steps, "seconds": sus, "ms_per_step": 1e3 * sus / sus_steps,
                            "value": keys_total / args.steps * sus_steps / sus, "unit": "lookups/s"}
+
+    if rank == 0 and not sharded_path:
+        # the same step through the module's PUBLIC path -- forward() -> _LookupFunction.apply -> autograd backward -- which
+        # is what a TorchRec caller drives; the headline above calls _forward_impl / _backward_impl directly
+        def step_autograd(i):
+            keys, offsets = batches[i]
+            out = module(keys, offsets)
+            out.backward(grad)
+
+        for i in range(args.warmup):
+            step_autograd(i)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        n_auto = 0
+        while True:
+            for i in range(args.warmup, n_batches):
+                step_autograd(i)
+            n_auto += args.steps
+            torch.cuda.synchronize()
+            if time.perf_counter() - ta >= 0.25 or n_auto >= 200 * args.steps:
+                break
+        result["step_via_autograd_ms"] = 1e3 * (time.perf_counter() - ta) / n_auto
+        result["step_via_autograd_note"] = ("module.forward(keys, offsets) + out.backward(grad) over the same batches "
+                                            "(sustained window); compare with sustained.ms_per_step")
 
     if rank == 0 and not sharded_path and not args.no_kernel_timing:
         roof, step_bytes = kernel_roofline(module, batches[args.warmup:], grad, args.batch, args.dim)

@@ -55,6 +55,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 #define HSTU_MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
 #endif
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;   // first-class 16-B value (HIP's uint4 struct arrays end up in scratch)
 
 #ifndef HSTU_XSTEP
@@ -1077,6 +1078,19 @@ __global__ void __launch_bounds__(256) hstu_fwd_dma_kernel(AttnArgs a) {
 #ifndef HSTU_PC_SDMA
 #define HSTU_PC_SDMA 0   // LDS-DMA instructions per tile and tensor issued by each S wave (of 32; the O waves issue the rest)
 #endif
+#ifndef HSTU_PC_DSPREAD
+#define HSTU_PC_DSPREAD 0   // O waves: 0 = their LDS-DMA share in one burst behind the barrier, n = dealt over the first n MFMA batches of GEMM 2
+#endif
+#ifndef HSTU_PC_KBUF
+#define HSTU_PC_KBUF 3   // S waves: K fragment batches (4 slices) in registers, KBUF - 1 of them in flight ahead of the MFMAs
+#endif
+#ifndef HSTU_PC_VBUF
+#define HSTU_PC_VBUF 3   // O waves: V^T fragment batches likewise
+#endif
+#ifndef HSTU_PC_PROBE
+#define HSTU_PC_PROBE 0  // timing probes, results WRONG on purpose: 1 = SiLU without transcendentals, 2 = no SiLU (pack the raw S), 4 = DMA of
+                         // the first two tiles only, 8 = no GEMM 2 MFMAs, 16 = no GEMM 1 MFMAs
+#endif
 #ifndef HSTU_PC_PRIO
 #define HSTU_PC_PRIO 0   // static wave priority: 1 = the O waves (the younger half) at s_setprio 1, 2 = the S waves
 #endif
@@ -1157,25 +1171,27 @@ __global__ void __launch_bounds__(512) hstu_fwd_pc_kernel(AttnArgs a) {
   // The DMA instruction is issued from inline asm: hipcc models the builtin as an LDS store in flight and puts a
   // vmcnt(0) in front of the next transpose read of ANY LDS address (seen in hstu_fwd_dma_kernel's GEMM 2: the prefetch
   // it was meant to overlap is drained first).  Here the completion is counted by hand: vmcnt(0) + barrier at the loop head.
+  bool dma_on = true;
   auto dma16 = [&](const char* sbase, uint32_t voff, uint32_t lds_byte) {
+    if ((HSTU_PC_PROBE & 4) && !dma_on) return;
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(lds_byte), "s"(sbase) : "memory");
   };
-  auto issue_dma = [&](const uint16_t* g, int64_t g_row, const uint32_t (&voff)[NMY], uint16_t* ring, int tile) {
-    const int n0 = n_beg + kBN * tile;
+  auto issue_dma = [&](const uint16_t* g, int64_t g_row, const uint32_t (&voff)[NMY], uint16_t* ring, int tile, int u0, int u1) {
+    const int n0 = n_beg + kBN * tile;                                // (instructions [u0, u1) of this wave's share)
     const uint32_t dst = (uint32_t)(uintptr_t)(lds_void_t)(ring + (tile & 1) * TENS + RPI * j_first * ROWB);
     if (n0 + kBN <= s.L) {
       const char* sb = reinterpret_cast<const char*>(g + (int64_t)(n0 + RPI * j_first) * g_row);
       const int64_t step = (int64_t)RPI * g_row * 2;
 #pragma unroll
       for (int u = 0; u < NMY; ++u)
-        if (u < n_my) dma16(sb + u * step, voff[u], dst + u * (RPI * ROWB * 2));
+        if (u >= u0 && u < u1 && u < n_my) dma16(sb + u * step, voff[u], dst + u * (RPI * ROWB * 2));
     } else {
       const uint32_t rowterm = (uint32_t)dma_r * (uint32_t)g_row * 2u;
 #pragma unroll
       for (int u = 0; u < NMY; ++u)
-        if (u < n_my) {
+        if (u >= u0 && u < u1 && u < n_my) {
           const int row0 = n0 + RPI * (j_first + u);                   // wave-uniform: the instruction's first row
           const int rowc = row0 < s.L ? row0 : s.L - 1;                // clamped to the sequence
           const uint32_t drop = row0 + 1 < s.L ? 0u : 0xffffffffu;     // its second row is past the end: read the first again
@@ -1191,7 +1207,7 @@ __global__ void __launch_bounds__(512) hstu_fwd_pc_kernel(AttnArgs a) {
   // ---- O wave state
   f32x16_t acc_o[D / 32];
 
-  if (T > 0) issue_dma(kg, a.k_row, kvoff, Kring, 0);
+  if (T > 0) issue_dma(kg, a.k_row, kvoff, Kring, 0, 0, NMY);
   if (HSTU_PC_PRIO != 0 && role == (HSTU_PC_PRIO == 1 ? 1 : 0)) __builtin_amdgcn_s_setprio(1);
 
   // fragment addresses under the swizzles (as hstu_fwd_dma_kernel)
@@ -1214,7 +1230,6 @@ __global__ void __launch_bounds__(512) hstu_fwd_pc_kernel(AttnArgs a) {
   // test inside keeps Q and the O accumulator live together: 192 registers before anything else, 363 spilled).
 #if HSTU_TIMING
   unsigned tsum[7] = {0, 0, 0, 0, 0, 0, 0};   // wait for own DMA, barrier, DMA issue, role, GEMM 1, SiLU + hand-off | GEMM 2, tiles
-  tsum[3] = (unsigned)role;
   const unsigned t_start = tick();
   auto t_dump = [&]() {
     const unsigned t_end = tick();
@@ -1222,18 +1237,22 @@ __global__ void __launch_bounds__(512) hstu_fwd_pc_kernel(AttnArgs a) {
       const int blk = ((int)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
       unsigned long long* d = g_hstu_dbg + ((size_t)(blk * 8 + wv) % 65536) * 8;
       for (int i = 0; i < 7; ++i) d[i] = tsum[i];
+      d[6] |= (unsigned long long)role << 32;
       d[7] = t_end - t_start;
     }
   };
 #endif
   auto head = [&](int it) {
+    if (HSTU_PC_PROBE & 4) dma_on = it < 1;
     TICK(t0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces (K tile it, V tile it - 1) have landed ...
     TICK(t1);
     __syncthreads();                                    // ... everyone's have, P[it - 1] is written, the other buffers are free
     TICK(t2);
-    if (it + 1 < T) issue_dma(kg, a.k_row, kvoff, Kring, it + 1);
-    if (it < T) issue_dma(vg, a.v_row, vvoff, Vring, it);
+    if (role == 0 || HSTU_PC_DSPREAD == 0) {
+      if (it + 1 < T) issue_dma(kg, a.k_row, kvoff, Kring, it + 1, 0, NMY);
+      if (it < T) issue_dma(vg, a.v_row, vvoff, Vring, it, 0, NMY);
+    }
     TICK(t3);
     TACC(0, t0, t1); TACC(1, t1, t2); TACC(2, t2, t3);
   };
@@ -1254,64 +1273,104 @@ __global__ void __launch_bounds__(512) hstu_fwd_pc_kernel(AttnArgs a) {
       if (it >= T || !wave_live || n0 >= w_end || n0 < w_beg) continue;
       const uint16_t* Ks = Kring + (it & 1) * TENS;
       TICK(t5);
-      f32x16_t acc_s[2];
+      // mask mode of the tile (wave-uniform): 0 = every key visible, 1 = key <= jmax only (plain causal / sequence end:
+      // one compare per element against a per-lane threshold), 2 = the general rule (contextual / target rows, windows)
+      const bool full = a.causal && s.wl < 0 && (n0 + kBN - 1 <= dq + qrow0) && (!s.has_ctx || dq + qrow0 >= s.c) && (!s.has_tgt || n0 + kBN - 1 < s.hlen);
+      const int mode = full ? 0 : ((!s.has_ctx && !s.has_tgt && s.wl < 0) ? 1 : 2);
+      u32x4_t* pdst = reinterpret_cast<u32x4_t*>(Pring) + (((it & 1) * 4 + pw) * 4) * 64 + lane;
+      // One tile, software-pipelined inside the wave: GEMM 1 of the second 32-key sub-tile carries the SiLU of the first
+      // (one element pair per two MFMAs), so that only the second sub-tile's SiLU runs without MFMAs of this wave.
+      auto tile = [&](auto modec) {
+        constexpr int kMode = decltype(modec)::value;
+        constexpr int SLB = 4, NBAT = (D / 16) / SLB, NKB = HSTU_PC_KBUF;   // fragment batches of 4 slices, NKB - 1 batches in flight
+        f32x16_t acc_s[2];
+        // (measured and rejected: two accumulator chains per sub-tile -- even / odd slices of d, added in the SiLU -- so that
+        // consecutive MFMAs never share an accumulator: 805 vs 841 TFLOP/s at 32 x 4096; the chain is not what paces GEMM 1)
+        const int th = rm.jmax - n0 - 4 * hi;       // kMode 1: element (t, rr) is visible iff 32 t + (rr & 3) + 8 (rr >> 2) <= th
+        // NE elements r0 .. r0 + NE - 1 of sub-tile t -> NE / 2 packed P words, stage by stage over the group
+        auto group = [&](auto nec, int t, int r0, uint32_t* out) {
+          constexpr int NE = decltype(nec)::value;
+          float x[NE], e[NE], y[NE];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        constexpr int SLB = 4, NBAT = (D / 16) / SLB;
-        bf16x8_t kfr[2][SLB];
-        auto load_b = [&](int bi, int buf) {
+          for (int i = 0; i < NE; ++i) x[i] = acc_s[t][r0 + i];
+#pragma unroll
+          for (int i = 0; i < NE; ++i) e[i] = x[i] * nal2e;
+#pragma unroll
+          for (int i = 0; i < NE; ++i) e[i] = (HSTU_PC_PROBE & 1) ? e[i] * 0.5f : __builtin_amdgcn_exp2f(e[i]);
+#pragma unroll
+          for (int i = 0; i < NE; ++i) e[i] = 1.0f + e[i];
+#pragma unroll
+          for (int i = 0; i < NE; ++i) e[i] = (HSTU_PC_PROBE & 1) ? e[i] * 0.25f : __builtin_amdgcn_rcpf(e[i]);
+#pragma unroll
+          for (int i = 0; i < NE; ++i) y[i] = (HSTU_PC_PROBE & 2) ? x[i] : x[i] * ais * e[i];
+          if (kMode != 0) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+              const int rr = r0 + i, off = 32 * t + (rr & 3) + 8 * (rr >> 2);
+              const bool ok = kMode == 1 ? off <= th : key_ok(n0 + off + 4 * hi, rm);
+              y[i] = ok ? y[i] : 0.f;
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < NE; i += 2) out[i >> 1] = pack_bf16(y[i], y[i + 1]);
+        };
+        bf16x8_t kfr[NKB][SLB];
+        auto load_b = [&](int gb) {               // global batch gb = NBAT t + bi
+          const int t = gb / NBAT, bi = gb % NBAT;
 #pragma unroll
           for (int u = 0; u < SLB; ++u) {
             const int sl = SLB * bi + u;
             const int ch = ((2 * sl) ^ (kx & 14)) + (hi ^ (kx & 1));
-            kfr[buf][u] = *reinterpret_cast<const bf16x8_t*>(Ks + (32 * t + l31) * ROWB + 8 * ch);
+            kfr[gb % NKB][u] = *reinterpret_cast<const bf16x8_t*>(Ks + (32 * t + l31) * ROWB + 8 * ch);
           }
         };
-        load_b(0, 0);
-#pragma unroll
-        for (int bi = 0; bi < NBAT; ++bi) {
-          if (bi + 1 < NBAT) load_b(bi + 1, (bi + 1) & 1);
-          __builtin_amdgcn_sched_barrier(0);
+        auto mfma_b = [&](int gb) {
+          const int t = gb / NBAT, bi = gb % NBAT;
 #pragma unroll
           for (int u = 0; u < SLB; ++u) {
-            if (bi == 0 && u == 0) mfma_v0(acc_s[t], kfr[bi & 1][u], qf[SLB * bi + u]);
-            else mfma_v(acc_s[t], kfr[bi & 1][u], qf[SLB * bi + u]);
+            f32x16_t& c = acc_s[t];
+            if (HSTU_PC_PROBE & 16) { if (bi == 0) for (int z = 0; z < 16; ++z) c[z] = __builtin_bit_cast(float, __builtin_bit_cast(u32x4_t, kfr[0][0])[z & 3]); }
+            else if (bi == 0 && u == 0) mfma_v0(c, kfr[gb % NKB][u], qf[SLB * bi + u]);
+            else mfma_v(c, kfr[gb % NKB][u], qf[SLB * bi + u]);
           }
+        };
+#pragma unroll
+        for (int gb = 0; gb < NKB - 1; ++gb) load_b(gb);
+        // ---- sub-tile 0: MFMAs only
+#pragma unroll
+        for (int gb = 0; gb < NBAT; ++gb) {
+          if (gb + NKB - 1 < 2 * NBAT) load_b(gb + NKB - 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_b(gb);
           __builtin_amdgcn_sched_barrier(0);
         }
-      }
-      TICK(t6);
-      TACC(4, t5, t6);
-      const bool full = a.causal && s.wl < 0 && (n0 + kBN - 1 <= dq + qrow0) && (!s.has_ctx || dq + qrow0 >= s.c) && (!s.has_tgt || n0 + kBN - 1 < s.hlen);
-      u32x4_t* pdst = reinterpret_cast<u32x4_t*>(Pring) + (((it & 1) * 4 + pw) * 4) * 64 + lane;
-      auto emit = [&](auto fullc) {
-        constexpr bool kFull = decltype(fullc)::value;
+        TICK(t6);
+        TACC(4, t5, t6);
+        // ---- sub-tile 1: MFMAs + the SiLU of sub-tile 0 (4 elements per batch of 4 MFMAs)
+        uint32_t pk[8];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int t = ks >> 1, r0 = (ks & 1) * 8;
-          uint32_t pk[4];
-#pragma unroll
-          for (int r = 0; r < 8; r += 2) {
-            float p2[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const int rr = r0 + r + u;
-              const float pv = silu_scaled(acc_s[t][rr], nal2e, ais);
-              if (kFull) p2[u] = pv;
-              else {
-                const int key = n0 + 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
-                p2[u] = key_ok(key, rm) ? pv : 0.f;
-              }
-            }
-            pk[r >> 1] = pack_bf16(p2[0], p2[1]);
-          }
-          const u32x4_t x = {pk[0], pk[1], pk[2], pk[3]};
-          pdst[ks * 64] = x;
+        for (int gb = NBAT; gb < 2 * NBAT; ++gb) {
+          const int bi = gb - NBAT;
+          if (gb + NKB - 1 < 2 * NBAT) load_b(gb + NKB - 1);
+          mfma_b(gb);
+          group(std::integral_constant<int, 4>{}, 0, 4 * bi, pk + 2 * bi);
+          if (bi == 1) pdst[0 * 64] = u32x4_t{pk[0], pk[1], pk[2], pk[3]};
+          if (bi == 3) pdst[1 * 64] = u32x4_t{pk[4], pk[5], pk[6], pk[7]};
+          __builtin_amdgcn_sched_barrier(0);
         }
+        TICK(t6b);
+        TACC(3, t6, t6b);
+        // ---- the SiLU of sub-tile 1
+        group(std::integral_constant<int, 8>{}, 1, 0, pk);
+        pdst[2 * 64] = u32x4_t{pk[0], pk[1], pk[2], pk[3]};
+        group(std::integral_constant<int, 8>{}, 1, 8, pk + 4);
+        pdst[3 * 64] = u32x4_t{pk[4], pk[5], pk[6], pk[7]};
+        TICK(t7);
+        TACC(5, t6b, t7);
       };
-      if (full) emit(std::true_type{}); else emit(std::false_type{});
-      TICK(t7);
-      TACC(5, t6, t7);
+      if (mode == 0) tile(std::integral_constant<int, 0>{});
+      else if (mode == 1) tile(std::integral_constant<int, 1>{});
+      else tile(std::integral_constant<int, 2>{});
 #if HSTU_TIMING
       tsum[6] += 1;
 #endif
@@ -1333,31 +1392,65 @@ __global__ void __launch_bounds__(512) hstu_fwd_pc_kernel(AttnArgs a) {
       head(it);
       pin_agpr(acc_o);
       const int tl = it - 1, n0 = n_beg + kBN * tl;
-      if (it == 0 || !wave_live || n0 >= w_end || n0 < w_beg) continue;
+      const bool live = it != 0 && wave_live && n0 < w_end && n0 >= w_beg;
+      // HSTU_PC_DSPREAD: this wave's DMA share (K tile it + 1, V tile it) is dealt over the first MFMA batches of GEMM 2
+      // when there is a GEMM 2 and both tiles lie inside the sequence (no clamped rows); otherwise one burst, as at the head.
+      const int nk0 = n_beg + kBN * (it + 1), nv0 = n_beg + kBN * it;
+      const bool spread = HSTU_PC_DSPREAD != 0 && live && it + 1 < T && nk0 + kBN <= s.L;   // (then V tile `it` is inside as well)
+      if (HSTU_PC_DSPREAD != 0 && !spread) {
+        if (it + 1 < T) issue_dma(kg, a.k_row, kvoff, Kring, it + 1, 0, NMY);
+        if (it < T) issue_dma(vg, a.v_row, vvoff, Vring, it, 0, NMY);
+      }
+      if (!live) continue;
       const uint16_t* Vt = Vring + (tl & 1) * TENS;
       TICK(t6);
       const u32x4_t* psrc = reinterpret_cast<const u32x4_t*>(Pring) + (((tl & 1) * 4 + pw) * 4) * 64 + lane;
-      bf16x8_t pf[4];
+      {
+        // (ONE copy of GEMM 2 with the DMA statements behind a wave-uniform test: two specialised copies made hipcc carry
+        // the accumulator through a phi and spill it)
+        const char* kb = reinterpret_cast<const char*>(kg + (int64_t)(nk0 + RPI * j_first) * a.k_row);
+        const char* vb = reinterpret_cast<const char*>(vg + (int64_t)(nv0 + RPI * j_first) * a.v_row);
+        const int64_t kstep = (int64_t)RPI * a.k_row * 2, vstep = (int64_t)RPI * a.v_row * 2;
+        const uint32_t kdst = (uint32_t)(uintptr_t)(lds_void_t)(Kring + ((it + 1) & 1) * TENS + RPI * j_first * ROWB);
+        const uint32_t vdst = (uint32_t)(uintptr_t)(lds_void_t)(Vring + (it & 1) * TENS + RPI * j_first * ROWB);
+        bf16x8_t pf[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) pf[ks] = __builtin_bit_cast(bf16x8_t, psrc[ks * 64]);
-      constexpr int NDT = D / 32, DB = 4;
-      constexpr int NBAT2 = 4 * (NDT / DB);
-      bf16x8_t vfr[2][DB];
-      auto load_v = [&](int bi, int buf) {
-        const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
+        for (int ks = 0; ks < 4; ++ks) pf[ks] = __builtin_bit_cast(bf16x8_t, psrc[ks * 64]);
+        constexpr int NDT = D / 32, DB = 4, NVB = HSTU_PC_VBUF;
+        constexpr int NBAT2 = 4 * (NDT / DB);
+        bf16x8_t vfr[NVB][DB];
+        auto load_v = [&](int bi) {
+          const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
 #pragma unroll
-        for (int u = 0; u < DB; ++u) vfr[buf][u] = v_frag(Vt, dt0 + u, ks);
-      };
-      load_v(0, 0);
-      pin_agpr(acc_o);
+          for (int u = 0; u < DB; ++u) vfr[bi % NVB][u] = v_frag(Vt, dt0 + u, ks);
+        };
 #pragma unroll
-      for (int bi = 0; bi < NBAT2; ++bi) {
-        const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
-        if (bi + 1 < NBAT2) load_v(bi + 1, (bi + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int bi = 0; bi < NVB - 1; ++bi) load_v(bi);
+        pin_agpr(acc_o);
 #pragma unroll
-        for (int u = 0; u < DB; ++u) mfma_a(acc_o[dt0 + u], vfr[bi & 1][u], pf[ks]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int bi = 0; bi < NBAT2; ++bi) {
+          const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
+          if (bi + NVB - 1 < NBAT2) load_v(bi + NVB - 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < DB; ++u) {
+            if (HSTU_PC_PROBE & 8) { if (u == 0 && bi == 0) acc_o[0][0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4_t, vfr[bi % NVB][0])[0] ^ __builtin_bit_cast(u32x4_t, pf[ks])[0]); }
+            else mfma_a(acc_o[dt0 + u], vfr[bi % NVB][u], pf[ks]);
+            if (HSTU_PC_DSPREAD != 0 && bi < HSTU_PC_DSPREAD && (u & 1)) {   // behind every second MFMA of the first batches: PER K + PER V instructions
+              constexpr int NSLOT = 2 * (HSTU_PC_DSPREAD ? HSTU_PC_DSPREAD : 1), PER = (NO + NSLOT - 1) / NSLOT;
+              const int slot = 2 * bi + (u >> 1);
+              if (spread) {
+#pragma unroll
+                for (int x = PER * slot; x < PER * slot + PER; ++x)
+                  if (x < NO) {
+                    dma16(kb + x * kstep, kvoff[x], kdst + x * (RPI * ROWB * 2));
+                    dma16(vb + x * vstep, vvoff[x], vdst + x * (RPI * ROWB * 2));
+                  }
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       TICK(t7);
       TACC(5, t6, t7);

@@ -63,7 +63,7 @@ class _StepCtx:
 
     __slots__ = ("rev", "uoff", "tids", "slots", "row_addr", "offsets", "num_keys", "batch_size", "num_bags", "csr_cnt",
                  "csr_rank", "pinned", "event", "indices", "bwd_ws", "ring", "token", "tier_pins", "fwd_addr", "scratch",
-                 "__weakref__")
+                 "pin_cell", "__weakref__")
 
     def release_ring(self):
         """hand the early-CSR ring slot back (after the backward, or when the step is dropped without one)"""
@@ -365,6 +365,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
 
         self._prefetch_states = deque()
         self._tier_prefetched = 0      # prefetched batches of the tier / admission paths whose backward has not run yet
+        self._orphan_pins = []         # pins of steps that died without a backward (released at the next call)
+        self._grow_deferred = False    # a growth that had to wait for live / prefetched steps (retried after a backward)
 
     # ---------------------------------------------------------------------------------- helpers
     def set_score(self, score: int) -> None:
@@ -410,6 +412,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
 
     # ---------------------------------------------------------------------------------- forward
     def _forward_impl(self, indices: torch.Tensor, offsets: torch.Tensor, train: bool, prefetch_only: bool = False):
+        if self._orphan_pins:
+            self._drain_orphan_pins()
         out, st = self._forward_impl_inner(indices, offsets, train, prefetch_only)
         if train and st is not None:
             # steps whose backward has not been issued yet hold slots / row addresses of the CURRENT table: growth (a rehash
@@ -538,9 +542,19 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             for t in range(self.num_tables):
                 while new_caps[t] < self._max_caps[t] and (sizes[t] + per_table_in) / new_caps[t] > lf:
                     new_caps[t] = min(2 * new_caps[t], self._max_caps[t])
-            if new_caps != caps and not self._prefetch_states and len(self._live_steps) == 0:
-                self._expand(new_caps)
-                tb = self.table
+            if new_caps != caps:
+                if not self._prefetch_states and len(self._live_steps) == 0:
+                    self._expand(new_caps)
+                    tb = self.table
+                    self._grow_deferred = False
+                else:
+                    if not self._grow_deferred and getattr(self, "_grow_skips", 0) == 64:
+                        import warnings
+
+                        warnings.warn("DynamicEmb: table growth has been waiting for live / prefetched steps for 64 steps "
+                                      "(rows evict at max capacity of the current size until a step boundary is free)")
+                    self._grow_skips = getattr(self, "_grow_skips", 0) + 1
+                    self._grow_deferred = True     # retried at the end of the next backward that leaves no step alive
         if getattr(self, "_fill_host", None) is None:
             self._fill_host = torch.zeros(self.num_tables, dtype=torch.int64).pin_memory()
         self._fill_host.copy_(ext.segmented_sum_cuda(tb.bucket_sizes, tb.table_bucket_offsets_), non_blocking=True)
@@ -855,22 +869,83 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             self._step += 1
         return out, st
 
+    @staticmethod
+    def _step_tensors(st):
+        """every device tensor a step context holds (the arrays its gather / backward read)"""
+        if isinstance(st, _FusedStep):
+            return [st.buf] if isinstance(st.buf, torch.Tensor) else []
+        out = []
+        for name in _StepCtx.__slots__:
+            v = getattr(st, name, None)
+            if isinstance(v, torch.Tensor) and v.is_cuda:
+                out.append(v)
+        return out
+
+    def _record_step_on(self, st, stream_) -> None:
+        """A PREFETCHED step's arrays were allocated under the prefetch stream and are read by the gather / backward on
+        another one: tell the caching allocator (record_stream), or a block freed with the step could be handed to the
+        next prefetch while those kernels still read it."""
+        if stream_ is None or getattr(st, "event", None) is None:
+            return
+        for t in self._step_tensors(st):
+            t.record_stream(stream_)
+
     def _pin_tier_rows(self, st, pins) -> None:
         """rows a prefetched batch resolved through the Python-orchestrated paths (tiers, admission): pinned in their tier's
-        table until the batch's backward (_release_tier_rows), like the `pinned` steps of the one-call pipeline"""
+        table until the batch's backward (_release_tier_rows), like the `pinned` steps of the one-call pipeline.  A step that
+        dies WITHOUT a backward (exception, eval() with batches queued, a drained pipeline) hands its pins to
+        `_orphan_pins` through a finalizer; they are released at the module's next call (on a stream of ours, not in the
+        garbage collector)."""
+        import weakref
+
         for table, slots, tids in pins:
             table.increment_counter(slots, tids)
         st.tier_pins = pins
         self._tier_prefetched += 1
+        cell = [pins]
+        st.pin_cell = cell
+        weakref.finalize(st, BatchedDynamicEmbeddingTablesV2._orphan_step, weakref.ref(self), cell)
+
+    @staticmethod
+    def _orphan_step(module_ref, cell) -> None:
+        m = module_ref()
+        if m is not None and cell[0] is not None:
+            m._orphan_pins.append(cell[0])
+            cell[0] = None
+
+    def _drain_orphan_pins(self) -> None:
+        while self._orphan_pins:
+            for table, slots, tids in self._orphan_pins.pop():
+                table.decrement_counter(slots, tids)
+            self._tier_prefetched -= 1
 
     def _release_tier_rows(self, st) -> None:
         pins = getattr(st, "tier_pins", None)
         if pins is None:
             return
         st.tier_pins = None
+        cell = getattr(st, "pin_cell", None)
+        if cell is not None:
+            cell[0] = None
         for table, slots, tids in pins:
             table.decrement_counter(slots, tids)
         self._tier_prefetched -= 1
+
+    def reset_prefetch(self) -> None:
+        """Drop every prefetched batch that has not been consumed: unpin its rows, release its ring slot.  Called when the
+        module leaves training mode (train(False) / eval()) and usable by a pipeline that is drained early."""
+        while self._prefetch_states:
+            st = self._prefetch_states.popleft()
+            self._live_steps.discard(st)
+            self._release_tier_rows(st)
+            if isinstance(st, _FusedStep) or getattr(st, "ring", None) is not None:
+                st.release_ring()
+        self._drain_orphan_pins()
+
+    def train(self, mode: bool = True):
+        if not mode and getattr(self, "_prefetch_states", None):
+            self.reset_prefetch()
+        return super().train(mode)
 
     def _forward_admission(self, indices: torch.Tensor, offsets: torch.Tensor, prefetch_only: bool = False):
         """Training forward with an admission strategy (_prefetch_hbm_direct_path, batched_dynamicemb_function.py:559-696,
@@ -995,11 +1070,19 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         st.event = torch.cuda.Event()
         st.event.record(current_torch_stream())
         st.indices = indices   # keeps the key tensor alive until the forward
+        # the step's arrays were allocated under THIS (prefetch) stream; the gather and the backward read them on
+        # `forward_stream` (reference signature: prefetch(..., forward_stream)): make the allocator aware now, and again on
+        # whatever stream actually consumes them (_gather_prefetched / _backward_impl)
+        if forward_stream is not None and forward_stream != current_torch_stream():
+            self._record_step_on(st, forward_stream)
+            if isinstance(indices, torch.Tensor) and indices.is_cuda:
+                indices.record_stream(forward_stream)
         self._prefetch_states.append(st)
 
     def _gather_prefetched(self, st):
         if st.event is not None:
             current_torch_stream().wait_event(st.event)
+            self._record_step_on(st, current_torch_stream())
         dev = self.device_
         pooled = self.pooling_mode != DynamicEmbPoolingMode.NONE
         al = all(d % 4 == 0 for d in self.dims) and all(v % 4 == 0 for v in self.value_dims)
@@ -1018,7 +1101,11 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             if n:
                 check(lib().mi355_gather_rows(None, 0, ptr(src_addr), dt(self.embedding_dtype), ptr(st.rev), n, None,
                                               self.max_D, ptr(out), out.stride(0), dt(out), int(al), stream()), "gather_rows")
-        st.scratch = None      # stream-ordered: the gather is queued
+        if st.event is not None and getattr(st, "scratch", None) is not None:
+            for t in (st.scratch if isinstance(st.scratch, (list, tuple)) else [st.scratch]):
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(current_torch_stream())   # allocated under the prefetch stream, read by the gather above
+        st.scratch = None      # stream-ordered on THIS stream: the gather is queued
         return out
 
     def _safe_check(self, st):
@@ -1034,6 +1121,16 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
 
     def _backward_impl(self, st, grads: torch.Tensor):
         self._live_steps.discard(st)
+        self._record_step_on(st, current_torch_stream())   # (prefetched steps only: see _record_step_on)
+        try:
+            return self._backward_impl_inner(st, grads)
+        finally:
+            # a growth that had to wait for live / prefetched steps (under the prefetch pipeline one always exists when
+            # _maybe_grow runs) is retried at the first safe point: here, when none is left
+            if self._grow_deferred and not self._prefetch_states and len(self._live_steps) == 0:
+                self._maybe_grow(0)
+
+    def _backward_impl_inner(self, st, grads: torch.Tensor):
         if isinstance(st, _FusedStep):
             return self._backward_fused(st, grads)
         grads = grads.contiguous()

@@ -55,7 +55,8 @@ class ShardedDynamicEmbeddingBagCollection(ShardedModule):
             if mean:      # the shards pool with SUM; the mean is taken after the output dist
                 g.pooling = PoolingType.SUM
             fp = dict(g.fused_params)
-            fp["output_dtype"] = torch.float32     # partial sums travel and add up in fp32
+            fp["output_dtype"] = torch.float32     # the shards' partial sums leave the local lookup in fp32; on the fabric they
+                                                   # travel in fp32 too unless fused_params["wire_dtype"] opts into bf16
             out_dtype = (fused_params or {}).get("output_dtype", torch.float32)
             if not isinstance(out_dtype, torch.dtype):
                 out_dtype = out_dtype.as_dtype() if hasattr(out_dtype, "as_dtype") else torch.float32
@@ -66,7 +67,8 @@ class ShardedDynamicEmbeddingBagCollection(ShardedModule):
             dist_types = [t.fused_params.get("dist_type", "roundrobin") for t in g.embedding_tables for _ in t.feature_names]
             self._lookups.append(RowWiseShardedLookup(_ModuleLocal(k.emb_module), len(hash_sizes), hash_sizes, pooled=True,
                                                       pg=env.process_group, device=device, out_dtype=out_dtype,
-                                                      dist_type_per_feature=dist_types, ops=self._ops))
+                                                      dist_type_per_feature=dist_types, ops=self._ops,
+                                                      wire_dtype=(fused_params or {}).get("wire_dtype", None)))
             dims = [t.embedding_dim for t in g.embedding_tables for _ in t.feature_names]
             self._dim_of_col.append(torch.repeat_interleave(torch.arange(len(dims), device=device),
                                                             torch.tensor(dims, device=device)) if mean else None)

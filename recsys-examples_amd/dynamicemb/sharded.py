@@ -87,14 +87,16 @@ class RowWiseShardedLookup:
 
     def __init__(self, local, num_features: int, feature_hash_sizes: List[int], pooled: bool, pg=None,
                  device=None, out_dtype=torch.float32, dist_type_per_feature: Optional[Sequence[str]] = None,
-                 ops=None, wire_dtype="auto", capacity_factor: Optional[float] = None,
+                 ops=None, wire_dtype=None, capacity_factor: Optional[float] = None,
                  expected_keys: Optional[int] = None):
-        """wire_dtype (pooled): element type of the partial sums on the fabric.  None / torch.float32 = fp32 (the sums of
-        the shards are added in fp32, one rounding at the end); torch.bfloat16 halves the bytes per xGMI link at the price
-        of one more rounding per shard (what TorchRec's qcomm codec does for its reduce-scatter).  "auto" (default): bf16
-        when the caller asked for bf16 OUTPUT -- the result is rounded to bf16 anyway, the extra error is at most half a
-        bf16 ulp of each shard's partial sum (bounded in tests/test_sharded_gpu.py; at W = 1 it is bit-identical) -- and
-        fp32 for an fp32 output, which stays bit-identical to the single-GPU sum order."""
+        """wire_dtype (pooled): element type of the partial sums on the fabric.  None / torch.float32 (DEFAULT, what TorchRec
+        and the reference exchange unless a qcomm codec is configured) = fp32: the sums of the shards are added in fp32, one
+        rounding at the end, bit-identical to the single-GPU sum order for an fp32 output.  torch.bfloat16 (opt-in; the
+        TorchRec-facing collection takes it from fused_params["wire_dtype"]) halves the bytes per xGMI link at the price of
+        one more rounding per shard -- what TorchRec's qcomm codec does for its reduce-scatter.  "auto" = bf16 when the
+        caller asked for bf16 OUTPUT (the result is rounded to bf16 anyway, the extra error is at most half a bf16 ulp of
+        each shard's partial sum: bounded in tests/test_sharded_gpu.py; at W = 1 bit-identical), fp32 otherwise: the
+        default of the benchmark helper ShardedPooledLookup only."""
         if wire_dtype == "auto":
             wire_dtype = torch.bfloat16 if (pooled and out_dtype == torch.bfloat16) else None
         self.wire_dtype = None if wire_dtype == torch.float32 else wire_dtype

@@ -6,9 +6,19 @@ import torch
 
 from dynamicemb_extensions import DynamicEmbDataType
 
-from ._torchrec import EmbeddingBagCollection, EmbeddingCollection
 
-TORCHREC_TYPES: Set[Type] = {EmbeddingBagCollection, EmbeddingCollection}
+
+def __getattr__(name):
+    """`TORCHREC_TYPES` (reference utils.py:28) resolves TorchRec on first use: `import dynamicemb` itself must work on a box
+    without TorchRec (the lookup modules and the benchmark do not touch the plugin surface)."""
+    if name == "TORCHREC_TYPES":
+        from ._torchrec import EmbeddingBagCollection, EmbeddingCollection
+
+        types: Set[Type] = {EmbeddingBagCollection, EmbeddingCollection}
+        globals()["TORCHREC_TYPES"] = types
+        return types
+    raise AttributeError(name)
+
 
 DTYPE_NUM_BYTES: Dict[torch.dtype, int] = {torch.float32: 4, torch.float16: 2, torch.bfloat16: 2}
 

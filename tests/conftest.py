@@ -11,6 +11,11 @@ PKG = os.path.join(ROOT, "recsys-examples_amd")
 for p in (PKG, ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
+# TorchRec protocol stand-ins: test infrastructure (tests/standins/torchrec_standin.py), bound by dynamicemb/_torchrec.py only
+# when the real package is absent.  Appended LAST so that an installed torchrec always wins.
+STANDINS = os.path.join(ROOT, "tests", "standins")
+if STANDINS not in sys.path:
+    sys.path.append(STANDINS)
 
 
 def pytest_configure(config):
@@ -26,3 +31,24 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# ---- how much of the HSTU element-wise tolerance the kernels actually use (tests/test_hstu_gpu.py: _close_elementwise
+# records the worst |err| / tol of every comparison here; the summary below prints the worst per tensor kind, so that the
+# GPU test log says whether the rounding floor k * 2^-9 * magnitude is generous or tight)
+HSTU_TOL_USAGE = {}
+
+
+def record_tolerance_use(kind: str, test: str, ratio: float):
+    worst = HSTU_TOL_USAGE.get(kind)
+    if worst is None or ratio > worst[0]:
+        HSTU_TOL_USAGE[kind] = (ratio, test)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if not HSTU_TOL_USAGE:
+        return
+    terminalreporter.write_sep("-", "HSTU attention: worst |err| / tolerance per tensor kind")
+    for kind in sorted(HSTU_TOL_USAGE):
+        ratio, test = HSTU_TOL_USAGE[kind]
+        terminalreporter.write_line(f"hstu_tolerance_used {kind:14s} {ratio:6.3f}   ({test})")

@@ -110,7 +110,9 @@ def test_c4_table_overflows_into_the_host_tier():
     from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
 
     rows, D, lr = 100_000_000, 128, 0.25
-    need = rows * D * 4 + (64 << 30)
+    # The pinned host tier holds the whole logical table (51 GB at 100 M rows).  On a box with less free host memory the
+    # logical table SHRINKS (never below 10 M rows = 10 x the HBM tier, the overflow path is the same) instead of the test
+    # being skipped: this row of the scope table must run every round, and the log says at which size it ran.
     avail = None
     try:
         for line in open("/proc/meminfo"):
@@ -118,8 +120,11 @@ def test_c4_table_overflows_into_the_host_tier():
                 avail = int(line.split()[1]) * 1024
     except OSError:
         pass
-    if avail is not None and avail < need:
-        pytest.skip(f"needs {need >> 30} GB of host memory for the pinned tier, {avail >> 30} GB available")
+    if avail is not None:
+        fit = (avail - (24 << 30)) // (D * 4 * 2)          # (export / growth copies: keep half of what is free)
+        rows = int(max(min(rows, fit // 10_000_000 * 10_000_000), 0))
+        assert rows >= 10_000_000, f"{avail >> 30} GB of host memory available: not even a 10 M-row host tier fits"
+    print(f"C4 host-tier test: logical table of {rows} rows ({rows * D * 4 >> 30} GB pinned host tier)")
     hbm_rows = 1 << 20            # HBM tier: 1 M rows (0.5 GB) for a 100 M-row logical table
     opt = DynamicEmbTableOptions(dim=D, max_capacity=rows, index_type=torch.int64, embedding_dtype=torch.float32,
                                  score_strategy=DynamicEmbScoreStrategy.STEP, local_hbm_for_values=hbm_rows * D * 4,

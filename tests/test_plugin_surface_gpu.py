@@ -1,5 +1,6 @@
 """GPU tests of the TorchRec plugin surface (dynamicemb.shard / planner / get_planner / compute kernels) driven through the
-protocol stand-ins (TorchRec is not installed here): get_planner -> collective_plan -> DistributedModelParallel with the
+protocol stand-ins of tests/standins/torchrec_standin.py when TorchRec is not installed (`test_which_torchrec_world` records
+which world a run was in; `test_real_torchrec_embedding_collection_through_dmp` runs only against the real package): get_planner -> collective_plan -> DistributedModelParallel with the
 DynamicEmb sharders -> forward / backward on a 1-rank RCCL group, checked against a directly built
 BatchedDynamicEmbeddingTablesV2 with the same options (the first-touch initialiser is counter based: same seed + key ->
 same row), and the DynamicEmbDump / DynamicEmbLoad round trip.  Mirrors the shape of the reference's distributed tests
@@ -252,3 +253,48 @@ def test_prefetch_hook_of_the_sharded_modules(pg, ebc):
             oa, ob = torch.argsort(ka), torch.argsort(kb)
             assert torch.equal(ka[oa], kb[ob])
             torch.testing.assert_close(ra[oa], rb[ob], rtol=1e-6, atol=1e-6)
+
+
+def test_which_torchrec_world():
+    """Records in the test log whether this run exercised the plugin surface against the REAL TorchRec or against the
+    protocol stand-ins (tests/standins/torchrec_standin.py) -- so that a green plugin-surface suite cannot be read as
+    'drops into TorchRec' when TorchRec was never imported."""
+    from dynamicemb import _torchrec
+
+    world = "real torchrec" if _torchrec.HAVE_TORCHREC else "stand-ins (torchrec not installed)"
+    print(f"plugin surface tested against: {world}")
+    if not _torchrec.HAVE_TORCHREC:
+        import torchrec_standin   # noqa: F401  (the module the product bound to must be the one under tests/)
+
+        assert os.path.dirname(os.path.abspath(torchrec_standin.__file__)).endswith(os.path.join("tests", "standins"))
+
+
+def test_real_torchrec_embedding_collection_through_dmp(pg):
+    """The reference's own wiring (examples/commons/distributed/sharding.py:156-267): an `EmbeddingCollection` on the meta
+    device pushed through TorchRec's REAL `DistributedModelParallel` with `DynamicEmbeddingCollectionSharder`, the plan from
+    `get_planner(...).collective_plan`, one forward / backward, rows compared with a directly built module.  Needs the real
+    package: skipped -- explicitly, so that the GPU test record says so -- where TorchRec is not installed."""
+    from dynamicemb import _torchrec
+
+    if not _torchrec.HAVE_TORCHREC:
+        pytest.skip("torchrec not installed: the plugin surface ran against tests/standins/torchrec_standin.py only")
+    import dynamicemb as de
+    from dynamicemb.shard import ShardedDynamicEmbeddingCollection
+
+    dmp, cfgs, opts = _build(pg, ebc=False, dedup=False)
+    sharded = dmp.module.sparse
+    assert isinstance(sharded, ShardedDynamicEmbeddingCollection)
+    twin = _twin(cfgs, opts, {"a", "b"}, de.DynamicEmbPoolingMode.NONE, 0.5)
+    rng = np.random.default_rng(0)
+    dmp.train(); twin.train()
+    keys = ["fb", "fa0", "fa1"]
+    kjt = _kjt(rng, keys, 17, 900)
+    out = dmp(kjt)
+    out = out.wait() if hasattr(out, "wait") else out
+    ordered = kjt.permute([1, 2, 0])
+    ref = twin(ordered.values(), ordered.offsets())
+    got = torch.cat([out[k].values() for k in ("fa0", "fa1", "fb")])
+    assert torch.equal(got, ref)
+    g = torch.rand_like(ref) + 0.1
+    got.backward(g)
+    ref.backward(g)

@@ -201,6 +201,7 @@ def _worker(rank, W, port, F, B, pooled, dist_type, steps, q):
             cf = float(os.environ["TEST_CAPACITY_FACTOR"]) if os.environ.get("TEST_CAPACITY_FACTOR") else None
             odt = torch.bfloat16 if os.environ.get("TEST_OUT_DTYPE") == "bf16" else torch.float32
             sh = RowWiseShardedLookup(local, F, [200] * F, pooled=pooled, device="cpu", out_dtype=odt,
+                                      wire_dtype=os.environ.get("TEST_WIRE_DTYPE") or None,
                                       dist_type_per_feature=[dist_type] * F, ops=NumpyOps(), capacity_factor=cf,
                                       expected_keys=F * B * 5 if cf else None)
         outs = []
@@ -345,10 +346,12 @@ def test_fixed_capacity_exchange_matches_single_process(W, F, B, pooled, dist_ty
 
 @pytest.mark.parametrize("W", [2, 3])
 def test_bf16_outputs_take_the_bf16_wire(W, monkeypatch):
-    """bf16 pooled outputs (what bench.py --gpus N asks for): the partial sums cross the fabric in bf16 by default
-    (wire_dtype "auto"), are summed in fp32 and rounded once more -- every output within (W + 1) half-ulps of the bf16
+    """bf16 pooled outputs (what bench.py --gpus N asks for): with wire_dtype "auto" (the benchmark helper's default; the
+    TorchRec-facing collection exchanges fp32 unless fused_params opt in) the partial sums cross the fabric in bf16,
+    are summed in fp32 and rounded once more -- every output within (W + 1) half-ulps of the bf16
     value of the exact sum; the table rows, updated from fp32 gradients, are exactly those of the fp32 run."""
     monkeypatch.setenv("TEST_OUT_DTYPE", "bf16")
+    monkeypatch.setenv("TEST_WIRE_DTYPE", "auto")
     monkeypatch.setenv("TEST_OVERLAPPED", "1")
     _run_and_compare(W, 2, 5, True, "roundrobin", out_rtol=(W + 1) * 2.0 ** -9, out_atol=(W + 1) * 2.0 ** -9 * 8.0)
 

@@ -45,17 +45,20 @@ assert lib.mi355_hstu_dbg_dump(buf.ctypes.data, buf.nbytes) == 0
 if a.pc:
     n = min(nblk * 8, 65536)
     dd = buf[:n].astype(np.float64)
+    role_of = (buf[:n, 6] >> np.uint64(32)).astype(np.int64)
+    dd[:, 6] = (buf[:n, 6] & np.uint64(0xffffffff)).astype(np.float64)
     for role, nm0 in ((0, "S waves (GEMM 1 + SiLU -> P)"), (1, "O waves (DMA + GEMM 2)")):
-        d = dd[dd[:, 3] == role]
+        d = dd[role_of == role]
         tiles, tot = d[:, 6], d[:, 7]
         print(f"{nm0}: waves {len(d)}  tiles/wave avg {tiles.mean():.2f}  wave lifetime avg {tot.mean():.0f} cyc  max {tot.max():.0f}")
-        names = ["wait own DMA", "barrier", "DMA issue", None, "gemm1", "silu + P hand-off" if role == 0 else "P read + gemm2"]
+        names = (["wait own DMA", "barrier", "DMA issue", "gemm1 sub-tile 1 + silu 0", "gemm1 sub-tile 0", "silu sub-tile 1"] if role == 0
+                 else ["wait own DMA", "barrier", "DMA issue", None, None, "P read + gemm2"])
         for i, nm in enumerate(names):
-            if nm is None or (role == 1 and i == 4):
+            if nm is None:
                 continue
-            print(f"  {nm:22s} {d[:, i].sum() / tiles.sum():8.0f} cyc per computed tile   ({100 * d[:, i].sum() / tot.sum():5.1f} % of wave lifetime)")
-        used = d[:, [0, 1, 2, 4, 5]].sum()
-        print(f"  {'other':22s} {(tot.sum() - used) / tiles.sum():8.0f} cyc per computed tile   ({100 * (tot.sum() - used) / tot.sum():5.1f} %)")
+            print(f"  {nm:26s} {d[:, i].sum() / tiles.sum():8.0f} cyc per computed tile   ({100 * d[:, i].sum() / tot.sum():5.1f} % of wave lifetime)")
+        used = d[:, :6].sum()
+        print(f"  {'other':26s} {(tot.sum() - used) / tiles.sum():8.0f} cyc per computed tile   ({100 * (tot.sum() - used) / tot.sum():5.1f} %)")
     sys.exit(0)
 d = buf[:n].astype(np.float64)
 tiles = d[:, 6]
