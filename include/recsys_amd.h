@@ -507,6 +507,17 @@ int mi355_hstu_attn_bwd_rab(const void* dout, const void* q, const void* k, cons
  * workspace the passes recompute.  0: exchange switched off.
  * Results are bit-identical either way (the dQ GEMM consumes the same bf16 dS). */
 int64_t mi355_hstu_attn_bwd_ds_bytes(int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen);
+/* The same exchange under a byte cap: the workspace holds one chunk of (sequence, head) units at a time, each with the
+ * ceil(L_b / 32)^2 tiles of its own length (scratch by the jagged sum, not B x max_seqlen^2), and mi355_hstu_attn_bwd walks
+ * the chunks -- the reference's backward needs O(T) memory (hstu_bwd.h:687-729: dQ by atomics, no score-sized buffer); this
+ * keeps the one-GEMM dV / dQ passes of the exchange with a bounded buffer.  Returns the workspace bytes to allocate
+ * (<= cap_bytes, 256-byte aligned base required; 0 = no exchange fits, the recomputing passes run).  total_tokens: rows of q;
+ * plain_causal: causal mask without contextual rows, window or bias -- the sub-tiles above the diagonal are then not stored. */
+int64_t mi355_hstu_attn_bwd_ds_bytes_capped(int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen,
+                                            int64_t total_tokens, int64_t cap_bytes, int plain_causal);
+/* total tokens of the NEXT mi355_hstu_attn_bwd call on this thread (its signature is the reference's hstu_varlen_bwd and
+ * does not carry them): bounds the number of chunk passes; optional. */
+void mi355_hstu_attn_bwd_hint_tokens(int64_t total_tokens);
 int mi355_hstu_attn_bwd(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
                         int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t do_row_stride,
                         int64_t q_head_stride, int64_t k_head_stride, int64_t v_head_stride,

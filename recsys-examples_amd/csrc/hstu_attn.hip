@@ -1647,14 +1647,83 @@ struct BwdAttnArgs {
   uint16_t* p_ws;              // same layout, P = SiLU(alpha S) / scale: the dV pass then needs no S recomputation either
   int ng;                      // 32-row groups per sequence the buffer is laid out for: ceil(max_seqlen / 32)
   int bq_kv;                   // query rows per step of the dK pass (the dQ pass must know which sub-tiles it wrote)
+  // Jagged, chunked layout (round 4; NULL = the dense layout above): the buffer holds ONE chunk of (sequence, head) units at
+  // a time, unit u = b H + h at tile offset plan_base[u] with its OWN ceil(L_b / 32)^2 tiles -- the scratch is sized by the
+  // jagged sum, not by B x max_seqlen^2, and capped; the three passes run once per chunk and blocks of other chunks leave
+  // at once (hstu_bwd_plan_kernel fills the plan on the device: no host read of the lengths).
+  const int64_t* plan_base;
+  const int32_t* plan_chunk;
+  int chunk;
+  int tri;                     // plain causal mask (no contextual rows, no window, no bias): only the sub-tiles with key group <=
+                               // query group exist -- a unit has ng (ng + 1) / 2 tiles, index qg (qg + 1) / 2 + kg; the others
+                               // are all zero, never written and never read (xch_absent)
   // d loss / d rab (hstu_api.cpp:659-667): [b][h][i][j] bf16, zero-filled by the caller; the dK pass writes dS there
   uint16_t* drab; int64_t drab_b, drab_h, drab_r;
 };
-__device__ __forceinline__ int64_t xch_tile(const BwdAttnArgs& g, int b, int h, int kg, int qg) {
-  return ((((int64_t)b * g.f.H + h) * g.ng + kg) * g.ng + qg) * 1024;   // 1024 bf16 = 2 KB
+// where a (sequence, head) unit's sub-tiles live: read ONCE per block (inside the step loops a load of the plan could not be
+// hoisted over the stores and cost a scalar-load latency per step: +27 % on a jagged batch)
+struct XchUnit { int64_t base; int ngb; int tri; };
+__device__ __forceinline__ XchUnit xch_unit(const BwdAttnArgs& g, int b, int h, int L) {
+  XchUnit u;
+  if (g.plan_base) { u.base = g.plan_base[b * g.f.H + h]; u.ngb = (L + 31) >> 5; u.tri = g.tri; }
+  else { u.base = ((int64_t)b * g.f.H + h) * g.ng * g.ng; u.ngb = g.ng; u.tri = 0; }
+  return u;
 }
-__device__ __forceinline__ uint16_t* ds_tile(const BwdAttnArgs& g, int b, int h, int kg, int qg) {
-  return g.ds_ws + xch_tile(g, b, h, kg, qg);
+__device__ __forceinline__ int64_t xch_tile(const XchUnit& u, int kg, int qg) {   // element offset of sub-tile (kg, qg): 1024 bf16 = 2 KB
+  return (u.base + (u.tri ? (int64_t)qg * (qg + 1) / 2 + kg : (int64_t)kg * u.ngb + qg)) * 1024;
+}
+__device__ __forceinline__ bool xch_absent(const XchUnit& u, int kg, int qg) { return u.tri && kg > qg; }
+__device__ __forceinline__ bool xch_other_chunk(const BwdAttnArgs& g, int b, int h) {
+  return g.plan_chunk != nullptr && g.plan_chunk[b * g.f.H + h] != g.chunk;
+}
+// Plan of the chunked exchange (one wave): the (sequence, head) units, in index order, are cut into the FEWEST contiguous
+// chunks of at most cap_tiles tiles (greedy), and among the cuts with that many chunks the one with the smallest largest
+// chunk is taken -- every lane tries one capacity between the largest unit and the cap -- because a chunk's passes are as
+// long as its longest column of blocks however few units it holds: chunks of (15, 15, 2) units cost three full passes,
+// (11, 11, 10) not much more than one and a half.  A unit = ceil(L_b / 32)^2 tiles of 2 KB (tri: ng (ng + 1) / 2) in each of
+// the dS and P regions.  nchunks_out[0] = chunks used (diagnostics: the host launches its upper bound).
+__global__ void hstu_bwd_plan_kernel(const int* cu, int B, int H, int64_t cap_tiles, int tri, int64_t* base, int32_t* chunk,
+                                     int32_t* nchunks_out) {
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  auto unit = [&](int b) -> int64_t {
+    const int64_t ngb = (cu[b + 1] - cu[b] + 31) >> 5;
+    return tri ? ngb * (ngb + 1) / 2 : ngb * ngb;
+  };
+  auto count = [&](int64_t c) -> int {
+    int64_t cur = 0;
+    int n = 1;
+    for (int b = 0; b < B; ++b) {
+      const int64_t need = unit(b);
+      for (int h = 0; h < H; ++h) {
+        if (cur + need > c && cur > 0) { ++n; cur = 0; }
+        cur += need;
+      }
+    }
+    return n;
+  };
+  int64_t umax = 1;
+  for (int b = 0; b < B; ++b) { const int64_t u = unit(b); umax = u > umax ? u : umax; }
+  const int best = count(cap_tiles);
+  const int64_t lo = umax < cap_tiles ? umax : cap_tiles;
+  const int64_t mine = lo + (cap_tiles - lo) * (lane + 1) / 64;                     // lane 63 tries the cap itself
+  const bool ok = count(mine) <= best;
+  const unsigned long long okm = __ballot(ok);
+  const int pick = __ffsll(okm) - 1;                                                 // the smallest capacity that still needs `best` chunks
+  const int64_t c = lo + (cap_tiles - lo) * (pick + 1) / 64;
+  if (lane != 0) return;
+  int64_t cur = 0;
+  int n = 0;
+  for (int b = 0; b < B; ++b) {
+    const int64_t need = unit(b);
+    for (int h = 0; h < H; ++h) {
+      if (cur + need > c && cur > 0) { ++n; cur = 0; }
+      base[b * H + h] = cur;
+      chunk[b * H + h] = n;
+      cur += need;
+    }
+  }
+  nchunks_out[0] = n + 1;
 }
 
 // Query steps (multiples of `bq` rows) the dK pass runs for the key block n0 .. n0 + kBM - 1: [0, c_end) and [jump, lim).
@@ -1700,7 +1769,8 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
   s.start = bs.start;
   s.L = bs.end - s.start;
   const int n0 = bs.z * kBM;   // earliest key blocks (seen by most queries) first
-  if (n0 >= s.L) return;
+  if (n0 >= s.L || xch_other_chunk(g, b, h)) return;
+  const XchUnit xu = xch_unit(g, b, h, s.L);
   s.has_ctx = a.num_contexts != nullptr;
   s.has_tgt = a.num_targets != nullptr;
   s.c = s.has_ctx ? a.num_contexts[b] : 0;
@@ -1896,8 +1966,8 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
           }
         }
         if constexpr (kXP) {
-          if (i0 + 32 * t < s.L) {   // P for the dV pass, same layout as dS below
-            u32x4_t* tp = reinterpret_cast<u32x4_t*>(g.p_ws + xch_tile(g, b, h, key0 >> 5, (i0 >> 5) + t)) + 2 * lane;
+          if (i0 + 32 * t < s.L && !xch_absent(xu, key0 >> 5, (i0 >> 5) + t)) {   // P for the dV pass, same layout as dS below
+            u32x4_t* tp = reinterpret_cast<u32x4_t*>(g.p_ws + xch_tile(xu, key0 >> 5, (i0 >> 5) + t)) + 2 * lane;
             tp[0] = u32x4_t{pk[0], pk[1], pk[2], pk[3]}; tp[1] = u32x4_t{pk[4], pk[5], pk[6], pk[7]};
           }
         }
@@ -1908,8 +1978,8 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
         if (kDK) {
           const u32x4_t y0 = {sk[0], sk[1], sk[2], sk[3]}, y1 = {sk[4], sk[5], sk[6], sk[7]};
           sf[2 * t] = __builtin_bit_cast(bf16x8_t, y0); sf[2 * t + 1] = __builtin_bit_cast(bf16x8_t, y1);
-          if (g.ds_ws && i0 + 32 * t < s.L) {   // hand dS to the dQ pass: the B-operand registers as they are, 32 bytes per lane
-            u32x4_t* tp = reinterpret_cast<u32x4_t*>(ds_tile(g, b, h, key0 >> 5, (i0 >> 5) + t)) + 2 * lane;
+          if (g.ds_ws && i0 + 32 * t < s.L && !xch_absent(xu, key0 >> 5, (i0 >> 5) + t)) {   // hand dS to the dQ pass: the B-operand registers as they are, 32 bytes per lane
+            u32x4_t* tp = reinterpret_cast<u32x4_t*>(g.ds_ws + xch_tile(xu, key0 >> 5, (i0 >> 5) + t)) + 2 * lane;
             tp[0] = y0; tp[1] = y1;
           }
         }
@@ -2190,7 +2260,8 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_q_ds_kernel(BwdAttnAr
   s.start = bs.start;
   s.L = bs.end - s.start;
   const int nblk = (s.L + kBM - 1) / kBM;
-  if (bs.z >= nblk) return;
+  if (bs.z >= nblk || xch_other_chunk(g, b, h)) return;
+  const XchUnit xu = xch_unit(g, b, h, s.L);
   const int m0 = row_block_of_rank(bs.z, nblk, a, b) * kBM;
   s.has_ctx = a.num_contexts != nullptr;
   s.has_tgt = a.num_targets != nullptr;
@@ -2239,8 +2310,8 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_q_ds_kernel(BwdAttnAr
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int nt = n + 32 * t;
-      if (wave_live && nt < w_end && tile_written(nt)) {
-        const u32x4_t* tp = reinterpret_cast<const u32x4_t*>(ds_tile(g, b, h, nt >> 5, qrow0 >> 5)) + 2 * lane;
+      if (wave_live && nt < w_end && tile_written(nt) && !xch_absent(xu, nt >> 5, qrow0 >> 5)) {
+        const u32x4_t* tp = reinterpret_cast<const u32x4_t*>(g.ds_ws + xch_tile(xu, nt >> 5, qrow0 >> 5)) + 2 * lane;
         ds0[t] = tp[0]; ds1[t] = tp[1];
       } else {
         ds0[t] = u32x4_t{0u, 0u, 0u, 0u}; ds1[t] = u32x4_t{0u, 0u, 0u, 0u};
@@ -2326,7 +2397,8 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_v_p_kernel(BwdAttnArg
   s.start = bs.start;
   s.L = bs.end - s.start;
   const int n0 = bs.z * kBM;
-  if (n0 >= s.L) return;
+  if (n0 >= s.L || xch_other_chunk(g, b, h)) return;
+  const XchUnit xu = xch_unit(g, b, h, s.L);
   s.has_ctx = a.num_contexts != nullptr;
   s.has_tgt = a.num_targets != nullptr;
   s.c = s.has_ctx ? a.num_contexts[b] : 0;
@@ -2359,8 +2431,8 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_v_p_kernel(BwdAttnArg
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int it = i + 32 * t;
-      if (wave_live && visited(it)) {
-        const u32x4_t* tp = reinterpret_cast<const u32x4_t*>(g.p_ws + xch_tile(g, b, h, key0 >> 5, it >> 5)) + 2 * lane;
+      if (wave_live && visited(it) && !xch_absent(xu, key0 >> 5, it >> 5)) {
+        const u32x4_t* tp = reinterpret_cast<const u32x4_t*>(g.p_ws + xch_tile(xu, key0 >> 5, it >> 5)) + 2 * lane;
         p0[t] = tp[0]; p1[t] = tp[1];
       } else {
         p0[t] = u32x4_t{0u, 0u, 0u, 0u}; p1[t] = u32x4_t{0u, 0u, 0u, 0u};
@@ -2602,6 +2674,23 @@ static int window_skip() {   // MI355_HSTU_WSKIP=0: keep the full tile loops und
   return v;
 }
 
+// ---- sizes of the backward's optional P / dS exchange (shared by both translation units)
+static int xch_regions(int64_t head_dim) {   // dS, and (head_dim >= 128, where dV and dK are separate passes) P behind it
+  static const int envp = getenv("MI355_HSTU_XP") ? atoi(getenv("MI355_HSTU_XP")) : 1;
+  return (envp && head_dim >= 128) ? 2 : 1;
+}
+static int64_t xch_plan_header(int64_t units) { return ((units * 8 + 255) / 256 + (units * 4 + 255) / 256 + 1) * 256; }
+static int64_t xch_unit_tiles(int64_t ng, int tri) { return tri ? ng * (ng + 1) / 2 : ng * ng; }
+// tiles per region of the whole batch, bounded without reading the lengths: sum_b f(ng_b) <= (sum_b ng_b) x f(ng_max) / ng_max,
+// sum_b ng_b <= T / 32 + B
+static int64_t xch_tiles_bound(int64_t batch, int64_t num_heads, int64_t ng, int64_t total_tokens, int tri) {
+  const int64_t umax = xch_unit_tiles(ng, tri);
+  const int64_t dense = batch * umax;
+  const int64_t jag = total_tokens > 0 ? (((total_tokens + 31) / 32 + batch) * umax + ng - 1) / ng : dense;
+  return num_heads * (jag < dense ? jag : dense);
+}
+extern "C" int64_t mi355_hstu_attn_bwd_take_hint_(void);
+
 extern "C" {
 #if HSTU_TIMING && !HSTU_F16
 int mi355_hstu_dbg_dump(void* out, int64_t bytes) {
@@ -2728,11 +2817,29 @@ int64_t mi355_hstu_attn_bwd_workspace_bytes(int64_t total_tokens, int64_t num_he
 int64_t mi355_hstu_attn_bwd_ds_bytes(int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen) {
   static const int env = getenv("MI355_HSTU_DS") ? atoi(getenv("MI355_HSTU_DS")) : 1;
   if (!env || batch <= 0 || max_seqlen <= 0) return 0;
-  static const int envp = getenv("MI355_HSTU_XP") ? atoi(getenv("MI355_HSTU_XP")) : 1;
   const int64_t ng = (max_seqlen + 31) / 32;
-  // dS, and (head_dim >= 128, where dV and dK are separate passes) P behind it
-  return batch * num_heads * ng * ng * 2048 * ((envp && head_dim >= 128) ? 2 : 1);
+  return batch * num_heads * ng * ng * 2048 * xch_regions(head_dim);
 }
+
+// The same exchange under a byte cap (round 4): the buffer holds one CHUNK of (sequence, head) units at a time, each unit
+// with the ceil(L_b / 32)^2 tiles of its own length, and the three passes run once per chunk -- scratch by the jagged sum of
+// the batch (bounded on the host, without reading the lengths, by (T / 32 + B) x ceil(max_seqlen / 32) tiles per head),
+// never more than `cap_bytes`.  Returns the workspace size to hand to mi355_hstu_attn_bwd (plan header included); 0 when even
+// two units of the longest sequence do not fit under the cap (the recomputing passes then run: no scratch at all).
+int64_t mi355_hstu_attn_bwd_ds_bytes_capped(int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen,
+                                            int64_t total_tokens, int64_t cap_bytes, int plain_causal) {
+  if (mi355_hstu_attn_bwd_ds_bytes(batch, num_heads, head_dim, max_seqlen) == 0) return 0;
+  const int64_t ng = (max_seqlen + 31) / 32, regions = xch_regions(head_dim), hdr = xch_plan_header(batch * num_heads);
+  const int tri = plain_causal != 0;
+  const int64_t want = hdr + regions * xch_tiles_bound(batch, num_heads, ng, total_tokens, tri) * 2048;
+  const int64_t bytes = want < cap_bytes ? want : cap_bytes;
+  return (bytes - hdr) / regions / 2048 >= 2 * xch_unit_tiles(ng, tri) ? bytes : 0;
+}
+// total tokens of the NEXT mi355_hstu_attn_bwd call on this thread (its signature, the reference's, does not carry them):
+// tightens the number of chunk passes a capped workspace is walked in; 0 / not set = the dense bound
+static thread_local int64_t tl_bwd_tokens = 0;
+void mi355_hstu_attn_bwd_hint_tokens(int64_t total_tokens) { tl_bwd_tokens = total_tokens; }
+int64_t mi355_hstu_attn_bwd_take_hint_(void) { const int64_t t = tl_bwd_tokens; tl_bwd_tokens = 0; return t; }   // (internal: both translation units)
 
 #endif
 
@@ -2766,21 +2873,54 @@ int HSTU_FN(mi355_hstu_attn_bwd)(const void* dout, const void* q, const void* k,
   g.dq = (uint16_t*)dq; g.dk = (uint16_t*)dk; g.dv = (uint16_t*)dv;
   g.ds_ws = nullptr; g.ng = (int)((max_seqlen + 31) / 32); g.bq_kv = 32;
   g.drab = tl_rab.drab; g.drab_b = tl_rab.db; g.drab_h = tl_rab.dh; g.drab_r = tl_rab.dr;
+  g.plan_base = nullptr; g.plan_chunk = nullptr; g.chunk = 0;
+  const int64_t tokens_hint = mi355_hstu_attn_bwd_take_hint_();
+  int nchunks = 1;
   {
     const int64_t need = mi355_hstu_attn_bwd_ds_bytes(batch, num_heads, head_dim, max_seqlen);
+    const int64_t regions = xch_regions(head_dim), units = batch * num_heads, hdr = xch_plan_header(units);
+    const int64_t udense = (int64_t)g.ng * g.ng;
+    // plain causal mask: the sub-tiles above the diagonal do not exist in the chunked layout (see BwdAttnArgs::tri)
+    g.tri = (causal && !num_contexts && tl_wl < 0 && tl_wr < 0 && !tl_rab.rab) ? 1 : 0;
+    const int64_t umax = xch_unit_tiles(g.ng, g.tri);
     g.p_ws = nullptr;
     if (need > 0 && workspace && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0) {
+      // the dense layout: everything in one pass
       g.ds_ws = (uint16_t*)workspace;
-      const int64_t one = batch * num_heads * (int64_t)g.ng * g.ng * 2048;
+      const int64_t one = batch * num_heads * udense * 2048;
       if (need >= 2 * one && head_dim >= 128) g.p_ws = (uint16_t*)((uint8_t*)workspace + one);
+    } else if (need > 0 && workspace && ((uintptr_t)workspace & 255) == 0 && !tl_rab.rab && workspace_bytes > hdr &&
+               (workspace_bytes - hdr) / regions / 2048 >= 2 * umax) {
+      // the jagged, chunked layout: [plan_base | plan_chunk | nchunks | dS region | P region]
+      const int64_t cap_tiles = (workspace_bytes - hdr) / regions / 2048;
+      uint8_t* w = (uint8_t*)workspace;
+      int64_t* base = (int64_t*)w;
+      int32_t* chunk = (int32_t*)(w + (units * 8 + 255) / 256 * 256);
+      int32_t* nch = (int32_t*)(w + hdr - 256);
+      hipLaunchKernelGGL(hstu_bwd_plan_kernel, dim3(1), dim3(64), 0, stream, cu_seqlens, (int)batch, (int)num_heads, cap_tiles, g.tri,
+                         base, chunk, nch);
+      g.plan_base = base; g.plan_chunk = chunk;
+      g.ds_ws = (uint16_t*)(w + hdr);
+      if (regions == 2) g.p_ws = (uint16_t*)(w + hdr + cap_tiles * 2048);
+      // chunks the greedy cut can need at most: every chunk but the last holds more than cap_tiles - umax tiles
+      const int64_t bound = xch_tiles_bound(batch, num_heads, g.ng, tokens_hint, g.tri);
+      nchunks = (int)((bound + (cap_tiles - umax)) / (cap_tiles - umax + 1));
+      if (nchunks < 1) nchunks = 1;
+      if (nchunks > units) nchunks = (int)units;
     }
   }
-  switch (head_dim) {
-    case 32: return launch_bwd<32>(g, (int)batch, (int)max_seqlen, stream);
-    case 64: return launch_bwd<64>(g, (int)batch, (int)max_seqlen, stream);
-    case 128: return launch_bwd<128>(g, (int)batch, (int)max_seqlen, stream);
-    default: return launch_bwd<256>(g, (int)batch, (int)max_seqlen, stream);
+  for (int c = 0; c < nchunks; ++c) {
+    g.chunk = c;
+    int rc;
+    switch (head_dim) {
+      case 32: rc = launch_bwd<32>(g, (int)batch, (int)max_seqlen, stream); break;
+      case 64: rc = launch_bwd<64>(g, (int)batch, (int)max_seqlen, stream); break;
+      case 128: rc = launch_bwd<128>(g, (int)batch, (int)max_seqlen, stream); break;
+      default: rc = launch_bwd<256>(g, (int)batch, (int)max_seqlen, stream); break;
+    }
+    if (rc != MI355_OK) return rc;
   }
+  return MI355_OK;
 }
 
 

@@ -26,6 +26,8 @@ N.register_signatures({
                             c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_int, c_f, c_f, c_p, c_i64, c_p],
     "mi355_hstu_attn_bwd_workspace_bytes": [c_i64, c_i64, c_i64],
     "mi355_hstu_attn_bwd_ds_bytes": [c_i64, c_i64, c_i64, c_i64],
+    "mi355_hstu_attn_bwd_ds_bytes_capped": [c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int],
+    "mi355_hstu_attn_bwd_hint_tokens": [c_i64],
     "mi355_hstu_attn_fwd_rab": [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_i64,
                                 c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_f, c_p, c_i64, c_i64, c_i64, c_p],
     "mi355_hstu_attn_bwd_rab": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p,
@@ -39,7 +41,8 @@ N.register_signatures({
                                c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_int, c_f, c_f, c_p, c_p, c_p, c_p, c_i64, c_p],
     "mi355_append_kvcache": [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p,
                              c_i64, c_i64, c_p],
-}, {"mi355_hstu_attn_bwd_workspace_bytes": c_i64, "mi355_hstu_attn_bwd_ds_bytes": c_i64})
+}, {"mi355_hstu_attn_bwd_workspace_bytes": c_i64, "mi355_hstu_attn_bwd_ds_bytes": c_i64,
+    "mi355_hstu_attn_bwd_ds_bytes_capped": c_i64, "mi355_hstu_attn_bwd_hint_tokens": None})
 # the fp16-operand twins of the seven type-specific entry points (same argument lists)
 _TYPED = ("mi355_hstu_attn_fwd", "mi355_hstu_attn_fwd_kv", "mi355_hstu_attn_bwd", "mi355_hstu_attn_fwd_window",
           "mi355_hstu_attn_bwd_window", "mi355_hstu_attn_fwd_rab", "mi355_hstu_attn_bwd_rab")
@@ -144,7 +147,20 @@ def append_kvcache(append_key, append_value, batch_indices, positions, seqlen_of
     return kv_cache_table
 
 
-_DS_MAX_BYTES = int(__import__("os").environ.get("MI355_HSTU_DS_MAX_BYTES", str(16 << 30)))
+_DS_MAX_BYTES = int(__import__("os").environ.get("MI355_HSTU_DS_MAX_BYTES", str(1 << 30)))
+
+
+def _bwd_exchange_workspace(q, B, H, D, max_seqlen, plain_causal):
+    """Scratch of the backward's P / dS exchange (the dK pass leaves them for the one-GEMM dV / dQ passes): the dense layout
+    B x H x ceil(max_seqlen / 32)^2 tiles when that fits under MI355_HSTU_DS_MAX_BYTES (default 1 GiB), else the jagged,
+    chunked layout of mi355_hstu_attn_bwd_ds_bytes_capped -- sized by the batch's own lengths, never above the cap, walked in
+    chunks by the library.  No driver query, no host read of the lengths; the decision depends on the shapes only."""
+    L = lib()
+    dense = L.mi355_hstu_attn_bwd_ds_bytes(B, H, D, int(max_seqlen))
+    n = dense if dense <= _DS_MAX_BYTES else L.mi355_hstu_attn_bwd_ds_bytes_capped(B, H, D, int(max_seqlen), int(q.shape[0]),
+                                                                                 _DS_MAX_BYTES, int(bool(plain_causal)))
+    L.mi355_hstu_attn_bwd_hint_tokens(int(q.shape[0]))
+    return torch.empty(max(int(n), 256), dtype=torch.uint8, device=q.device)
 
 
 def hstu_varlen_bwd(dout, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_contexts, num_targets, target_group_size,
@@ -156,14 +172,7 @@ def hstu_varlen_bwd(dout, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_c
     dk = torch.empty_like(dq)
     dv = torch.empty_like(dq)
     B = cu_seqlens.numel() - 1
-    wsb = lib().mi355_hstu_attn_bwd_workspace_bytes(T, H, D)
-    # optional dS exchange between the dK and dQ passes (saves the dQ pass its S / dP recomputation); skipped when the
-    # buffer would be larger than MI355_HSTU_DS_MAX_BYTES (default 16 GiB: 32 sequences x 4 heads x L = 4096 take 8.6 GB for P and dS)
-    dsb = lib().mi355_hstu_attn_bwd_ds_bytes(B, H, D, int(max_seqlen))
-    # (O(B H L^2) scratch: never more than a quarter of what the device has free right now -- the recomputing passes need none)
-    if dsb > _DS_MAX_BYTES or (dsb > (256 << 20) and dsb > torch.cuda.mem_get_info(q.device)[0] // 4):
-        dsb = 0
-    ws = torch.empty(max(wsb, dsb, 256), dtype=torch.uint8, device=q.device)
+    ws = _bwd_exchange_workspace(q, B, H, D, max_seqlen, bool(causal) and num_contexts is None)
     check(_fn("mi355_hstu_attn_bwd", q)(ptr(dout), ptr(q), ptr(k), ptr(v), ptr(dq), ptr(dk), ptr(dv), q.stride(0), k.stride(0),
                                     v.stride(0), dout.stride(0), q.stride(1), k.stride(1), v.stride(1), dout.stride(1),
                                     ptr(cu_seqlens), B, H, D, int(max_seqlen), ptr(num_contexts), ptr(num_targets),
@@ -209,10 +218,7 @@ def hstu_varlen_bwd_window(dout, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen
     dq = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
     dk, dv = torch.empty_like(dq), torch.empty_like(dq)
     B = cu_seqlens.numel() - 1
-    dsb = lib().mi355_hstu_attn_bwd_ds_bytes(B, H, D, int(max_seqlen))
-    if dsb > _DS_MAX_BYTES:
-        dsb = 0
-    ws = torch.empty(max(dsb, 256), dtype=torch.uint8, device=q.device)
+    ws = _bwd_exchange_workspace(q, B, H, D, max_seqlen, False)
     check(_fn("mi355_hstu_attn_bwd_window", q)(ptr(dout), ptr(q), ptr(k), ptr(v), ptr(dq), ptr(dk), ptr(dv), q.stride(0),
                                            k.stride(0), v.stride(0), dout.stride(0), q.stride(1), k.stride(1), v.stride(1),
                                            dout.stride(1), ptr(cu_seqlens), B, H, D, int(max_seqlen), int(wl), int(wr),

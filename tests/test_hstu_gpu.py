@@ -156,6 +156,79 @@ def test_backward_exchange_is_bit_identical_to_the_recomputing_passes(d, mode, m
     assert float(g_x[0].float().abs().max()) > 0
 
 
+@pytest.mark.parametrize("d", [64, 256])
+@pytest.mark.parametrize("mode", ["causal", "ctx_targets", "noncausal"])
+def test_backward_exchange_in_chunks_under_a_cap_is_bit_identical(d, mode, monkeypatch):
+    """MI355_HSTU_DS_MAX_BYTES caps the P / dS scratch: above it the buffer holds one chunk of (sequence, head) units at a
+    time -- each with the tiles of its own length (jagged layout, planned on the device) -- and the three passes run once per
+    chunk.  Same kernels, same tiles: dq, dk, dv agree bit for bit with the dense one-pass exchange.  The cap here leaves
+    room for two units of the longest sequence, so the 16 units of the batch take many chunks."""
+    import hstu.hstu_attn_interface as hi
+
+    rng = np.random.default_rng(7 * d + len(mode))
+    lengths = np.array([700, 1, 0, 333, 129, 64, 257, 31])
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    T, H = int(off[-1]), 2
+    causal = mode != "noncausal"
+    targets = ctx = None
+    if mode == "ctx_targets":
+        targets = np.minimum(rng.integers(0, 40, lengths.size), lengths)
+        ctx = np.minimum(rng.integers(0, 20, lengths.size), lengths - targets)
+    mk = lambda: torch.from_numpy(rng.uniform(-1, 1, (T, H, d)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    q, k, v, dout = mk(), mk(), mk(), mk()
+    N = int(lengths.max())
+    L = hi.lib()
+    dense = L.mi355_hstu_attn_bwd_ds_bytes(lengths.size, H, d, N)
+    assert dense > 0
+    _, g_dense = _run(q, k, v, off, N, targets, ctx, 1, causal, 1.0 / d ** 0.5, dout=dout)
+    ng = (N + 31) // 32
+    tri = causal and ctx is None
+    umax = ng * (ng + 1) // 2 if tri else ng * ng
+    regions = 2 if d >= 128 else 1
+    cap = 4096 + regions * int(2.3 * umax) * 2048
+    assert cap < dense
+    got = L.mi355_hstu_attn_bwd_ds_bytes_capped(lengths.size, H, d, N, T, cap, int(tri))
+    assert 0 < got <= cap
+    # below two units of the longest sequence nothing fits: the library says so (0) and the recomputing passes run
+    assert L.mi355_hstu_attn_bwd_ds_bytes_capped(lengths.size, H, d, N, T, 4096 + regions * int(1.5 * umax) * 2048, int(tri)) == 0
+    monkeypatch.setattr(hi, "_DS_MAX_BYTES", cap)
+    _, g_chunk = _run(q, k, v, off, N, targets, ctx, 1, causal, 1.0 / d ** 0.5, dout=dout)
+    for a, b, name in zip(g_chunk, g_dense, ("dq", "dk", "dv")):
+        assert torch.equal(a, b), f"{name}: {(a.float() - b.float()).abs().max().item()}"
+    assert float(g_chunk[0].float().abs().max()) > 0
+
+
+def test_backward_scratch_stays_under_one_gib_at_32x4096():
+    """The dense layout of the exchange would take B H ceil(L / 32)^2 x 4 KB = 8.6 GB at 32 sequences x 4096 tokens x 4 heads
+    (d = 256); with the default cap the backward allocates at most 1 GiB of scratch next to its three outputs (peak allocator
+    use checked), and its dq, dk, dv are those of the recomputing passes bit for bit."""
+    import hstu.hstu_attn_interface as hi
+
+    Bq, L, H, d = 32, 4096, 4, 256
+    T = Bq * L
+    cu = torch.arange(0, T + 1, L, dtype=torch.int32, device=DEV)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    q, k, v, dout = (torch.empty(T, H, d, device=DEV).uniform_(-1, 1, generator=g).bfloat16() for _ in range(4))
+    assert hi.lib().mi355_hstu_attn_bwd_ds_bytes(Bq, H, d, L) >= (8 << 30)
+    assert hi._DS_MAX_BYTES <= (1 << 30)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    dq, dk, dv = hi.hstu_varlen_bwd(dout, q, k, v, cu, L, L, None, None, 1, True, 1.0 / d ** 0.5)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    outs = 3 * T * H * d * 2
+    assert peak <= outs + (1 << 30) + (64 << 20), f"backward peak {peak >> 20} MB for {outs >> 20} MB of outputs"
+    old = hi._DS_MAX_BYTES
+    try:
+        hi._DS_MAX_BYTES = 0      # no scratch at all: the recomputing passes
+        rq, rk, rv = hi.hstu_varlen_bwd(dout, q, k, v, cu, L, L, None, None, 1, True, 1.0 / d ** 0.5)
+    finally:
+        hi._DS_MAX_BYTES = old
+    assert torch.equal(dq, rq) and torch.equal(dk, rk) and torch.equal(dv, rv)
+
+
 # ------------------------------------------------------------------------------------------ local (sliding) windows
 W = np.load(os.path.join(os.path.dirname(__file__), "golden", "hstu_window_golden.npz"))
 WINDOWS = [(111, 11), (111, 222), (50, 0), (0, 0), (0, 7), (-1, 40), (64, -1), (1000, 0), (3, 1000), (200, 130)]
