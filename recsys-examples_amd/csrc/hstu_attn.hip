@@ -2492,6 +2492,540 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_v_p_kernel(BwdAttnArg
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The one-GEMM passes of the exchange with EIGHT waves (round 4, head dim 256): one workgroup owns 256 keys (dV from P) or
+// 256 query rows (dQ from dS), 32 per wave, two waves per SIMD (128 accumulator registers + < 128 others each), and streams
+// the other side's rows -- dO resp. K -- in 64-row tiles that go global -> LDS by LDS-DMA (inline asm: see
+// hstu_fwd_pc_kernel), double-buffered, one barrier per step, read back transposed under the forward's V swizzle.  Against
+// the 4-wave kernels: the staged tile feeds twice the MFMAs (half the L2 -> LDS bytes per FLOP: those passes moved 13 B per
+// clock and CU, what L2 + HBM deliver), no staging registers, no commit phase, and a second wave per SIMD to cover the P / dS
+// loads and the fragment reads.
+// ---------------------------------------------------------------------------------------------------
+#ifndef HSTU_X8_VBUF
+#define HSTU_X8_VBUF 2   // fragment batches (4 slices) in registers in the 8-wave passes (3 spills at 128 + 128 registers)
+#endif
+constexpr int kBM8 = 256;   // rows per workgroup of the 8-wave passes
+struct Dma64 {   // LDS-DMA of one 64-row x 256-column bf16 tile by 8 waves: 32 instructions of 2 rows, 4 per wave
+  uint32_t voff[4];
+  int j0;
+  __device__ __forceinline__ void init(int wv, int lane, int64_t row_stride) {
+    j0 = 4 * wv;
+    const int dr = lane >> 5, dp = lane & 31;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = 2 * (j0 + u) + dr;
+      voff[u] = (uint32_t)dr * (uint32_t)row_stride * 2u + 16u * (uint32_t)(dp ^ ((r & 3) << 2));
+    }
+  }
+  static __device__ __forceinline__ void dma16(const char* sbase, uint32_t vo, uint32_t lds_byte) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(vo), "s"(lds_byte), "s"(sbase) : "memory");
+  }
+  // rows row0 .. row0 + 63 of `g` (element row stride row_stride) -> the tile at `dst`; rows past L are read clamped
+  __device__ __forceinline__ void issue(const uint16_t* g, int64_t row_stride, int row0, int L, uint16_t* dst, int lane) const {
+    const uint32_t d0 = (uint32_t)(uintptr_t)(lds_void_t)(dst + 2 * j0 * 256);
+    if (row0 + 64 <= L) {
+      const char* sb = reinterpret_cast<const char*>(g + (int64_t)(row0 + 2 * j0) * row_stride);
+      const int64_t step = 2 * row_stride * 2;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dma16(sb + u * step, voff[u], d0 + u * 1024);
+    } else {
+      const uint32_t rowterm = (uint32_t)(lane >> 5) * (uint32_t)row_stride * 2u;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r0 = row0 + 2 * (j0 + u);
+        const int rc = r0 < L ? r0 : L - 1;
+        const uint32_t drop = r0 + 1 < L ? 0u : 0xffffffffu;
+        dma16(reinterpret_cast<const char*>(g + (int64_t)rc * row_stride), voff[u] - (rowterm & drop), d0 + u * 1024);
+      }
+    }
+  }
+};
+// A fragment [32 d x 16 rows] of a DMA-staged tile, read transposed (the forward's v_frag)
+__device__ __forceinline__ bf16x8_t tr_frag_sw(const uint16_t* tile, int dt, int ks, int lane, int hi) {
+  typedef short v4s_t __attribute__((ext_vector_type(4)));
+  typedef short v8s_t __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) v4s_t* lds_v4s_t;
+  const int il = lane & 15, g1 = (lane >> 4) & 1, vq = il >> 2;
+  const uint16_t* p0 = tile + (16 * ks + 4 * hi + vq) * 256 + 4 * (il & 1) + 8 * (4 * (dt ^ vq) + 2 * g1 + ((il & 3) >> 1));
+  const v4s_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(p0));
+  const v4s_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(p0 + 8 * 256));
+  const v8s_t r = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+// acc^T[256 x 32] += X^T[256 x 64 rows of tile BUF of the ring] B[64 x 32]: 32 MFMAs, fragment batches of 4.  BUF is a
+// compile-time constant (the step loops are unrolled by two): every fragment address is then one of eight per-lane registers
+// plus an immediate -- with a run-time buffer the addresses of the other buffer were carried in registers and spilled.
+template <int BUF>
+__device__ __forceinline__ void gemm_x8(f32x16_t (&acc)[8], const uint16_t* ring, const bf16x8_t (&bf)[4], int lane, int hi) {
+  constexpr int NB = 8, NVB = HSTU_X8_VBUF;
+  const uint16_t* tile = ring + BUF * 64 * 256;
+  bf16x8_t fr[NVB][4];
+  auto load = [&](int bi) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fr[bi % NVB][u] = tr_frag_sw(tile, 4 * (bi & 1) + u, bi >> 1, lane, hi);
+  };
+#pragma unroll
+  for (int bi = 0; bi < NVB - 1; ++bi) load(bi);
+#pragma unroll
+  for (int bi = 0; bi < NB; ++bi) {
+    if (bi + NVB - 1 < NB) load(bi + NVB - 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mfma_a(acc[4 * (bi & 1) + u], fr[bi % NVB][u], bf[bi >> 1]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+template <int D>
+__device__ __forceinline__ void store_acc_rows(const f32x16_t (&acc)[D / 32], uint16_t* rowp, int hi) {
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      uint2 o;
+      o.x = pack_bf16(acc[dt][4 * g4 + 0], acc[dt][4 * g4 + 1]);
+      o.y = pack_bf16(acc[dt][4 * g4 + 2], acc[dt][4 * g4 + 3]);
+      *reinterpret_cast<uint2*>(rowp + 32 * dt + 8 * g4 + 4 * hi) = o;
+    }
+}
+
+// dV from the stored P, 256 keys per workgroup.  The query steps are the union of what the dK pass ran for the block's two
+// 128-key halves (its blocks are kBM keys); a wave consults the span of ITS half to tell which sub-tiles exist.
+template <int D>
+__global__ void __launch_bounds__(512) hstu_bwd_v_p8_kernel(BwdAttnArgs g) {
+  static_assert(D == 256, "DMA rows of 32 chunks");
+  const AttnArgs& a = g.f;
+  constexpr int BQ = 64, NT = 2, TILE = BQ * D;
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [2][64][256] dO tiles
+  const BlockSeq bs = seq_head_of_block(a);
+  const int b = bs.b, h = bs.h;
+  SeqInfo s;
+  s.start = bs.start;
+  s.L = bs.end - s.start;
+  const int n0 = bs.z * kBM8;
+  if (n0 >= s.L || xch_other_chunk(g, b, h)) return;
+  const XchUnit xu = xch_unit(g, b, h, s.L);
+  s.has_ctx = a.num_contexts != nullptr;
+  s.has_tgt = a.num_targets != nullptr;
+  s.c = s.has_ctx ? a.num_contexts[b] : 0;
+  s.hlen = s.L - (s.has_tgt ? a.num_targets[b] : 0);
+  s.wl = a.wl; s.wr = a.wr;
+  const int lane = lane_id(), hi = lane >> 5, l31 = lane & 31;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int key0 = n0 + 32 * wv, kj = key0 + l31;
+  const bool wave_live = key0 < s.L;
+  const uint16_t* dobase = g.dout + (int64_t)s.start * g.do_row + (int64_t)h * g.do_head;
+  f32x16_t acc[D / 32];
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+  const KvSpan sp0 = kv_span(a, s, n0, g.bq_kv);
+  const KvSpan sp1 = n0 + kBM < s.L ? kv_span(a, s, n0 + kBM, g.bq_kv) : sp0;
+  const KvSpan mine = wv < 4 ? sp0 : sp1;
+  const int jump = sp0.jump < sp1.jump ? sp0.jump : sp1.jump, c_end = sp0.c_end > sp1.c_end ? sp0.c_end : sp1.c_end;
+  const int lim = sp0.lim > sp1.lim ? sp0.lim : sp1.lim;
+  const int jump_s = (jump / BQ) * BQ, cend_s = ((c_end + BQ - 1) / BQ) * BQ;
+  int i_lim = ((lim + g.bq_kv - 1) / g.bq_kv) * g.bq_kv;
+  if (i_lim > s.L) i_lim = s.L;
+  auto advance = [&](int i) { i += BQ; return (i >= cend_s && i < jump_s) ? jump_s : i; };
+  auto visited = [&](int i) { return i < s.L && kv_visited(mine, (i / g.bq_kv) * g.bq_kv); };
+  Dma64 dma;
+  dma.init(wv, lane, g.do_row);
+  u32x4_t pn0[NT], pn1[NT];
+  auto fetch_p = [&](int i) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int it = i + 32 * t;
+      if (wave_live && visited(it) && !xch_absent(xu, key0 >> 5, it >> 5)) {
+        const u32x4_t* tp = reinterpret_cast<const u32x4_t*>(g.p_ws + xch_tile(xu, key0 >> 5, it >> 5)) + 2 * lane;
+        pn0[t] = tp[0]; pn1[t] = tp[1];
+      } else {
+        pn0[t] = u32x4_t{0u, 0u, 0u, 0u}; pn1[t] = u32x4_t{0u, 0u, 0u, 0u};
+      }
+    }
+  };
+  int i0 = c_end > 0 ? 0 : jump_s;
+  if (i0 < i_lim) { dma.issue(dobase, g.do_row, i0, s.L, smem, lane); fetch_p(i0); }
+  auto step = [&](auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+    pin_agpr(acc);
+    bf16x8_t pf[2 * NT];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the step (and its P words) have arrived
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { pf[2 * t] = __builtin_bit_cast(bf16x8_t, pn0[t]); pf[2 * t + 1] = __builtin_bit_cast(bf16x8_t, pn1[t]); }
+    __syncthreads();                                    // everyone's have; everyone is done with the other buffer
+    {
+      const int nx = advance(i0);
+      if (nx < i_lim) { dma.issue(dobase, g.do_row, nx, s.L, smem + (BUF ^ 1) * TILE, lane); fetch_p(nx); }
+    }
+    pin_agpr(acc);
+    if (wave_live) gemm_x8<BUF>(acc, smem, pf, lane, hi);
+    i0 = advance(i0);
+  };
+  while (i0 < i_lim) {
+    step(std::integral_constant<int, 0>{});
+    if (i0 >= i_lim) break;
+    step(std::integral_constant<int, 1>{});
+  }
+  fence_a(acc);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (kj < s.L) store_acc_rows<D>(acc, g.dv + ((int64_t)(s.start + kj) * a.H + h) * D, hi);
+}
+
+// dQ from the stored dS, 256 query rows per workgroup (the layout juggling of hstu_bwd_q_ds_kernel: the 2 KB sub-tile goes
+// through a wave-private LDS patch and comes back through transpose reads)
+template <int D>
+__global__ void __launch_bounds__(512) hstu_bwd_q_ds8_kernel(BwdAttnArgs g) {
+  static_assert(D == 256, "DMA rows of 32 chunks");
+  const AttnArgs& a = g.f;
+  constexpr int BK = 64, NT = 2, TILE = BK * D;
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [2][64][256] K tiles | 8 waves x 2 x 2 KB dS patches
+  const BlockSeq bs = seq_head_of_block(a);
+  const int b = bs.b, h = bs.h;
+  SeqInfo s;
+  s.start = bs.start;
+  s.L = bs.end - s.start;
+  const int nblk = (s.L + kBM8 - 1) / kBM8;
+  if (bs.z >= nblk || xch_other_chunk(g, b, h)) return;
+  const XchUnit xu = xch_unit(g, b, h, s.L);
+  const int m0 = row_block_of_rank(bs.z, nblk, a, b) * kBM8;
+  s.has_ctx = a.num_contexts != nullptr;
+  s.has_tgt = a.num_targets != nullptr;
+  s.c = s.has_ctx ? a.num_contexts[b] : 0;
+  s.hlen = s.L - (s.has_tgt ? a.num_targets[b] : 0);
+  s.wl = a.wl; s.wr = a.wr;
+  const int lane = lane_id(), hi = lane >> 5, l31 = lane & 31;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint16_t* dSw = smem + 2 * TILE + NT * 1024 * wv;
+  const int qrow0 = m0 + 32 * wv, qi = qrow0 + l31;
+  const bool wave_live = qrow0 < s.L;
+  int last_row = m0 + kBM8 - 1 < s.L - 1 ? m0 + kBM8 - 1 : s.L - 1;
+  int n_end = s.L;
+  if (a.causal) { n_end = last_row + 1; if (s.has_ctx && m0 < s.c && s.hlen > n_end) n_end = s.hlen; }
+  int w_last = qrow0 + 31 < s.L - 1 ? qrow0 + 31 : s.L - 1;
+  int w_end = s.L;
+  if (a.causal) { w_end = w_last + 1; if (s.has_ctx && qrow0 < s.c && s.hlen > w_end) w_end = s.hlen; }
+  n_end = band_key_end(a, last_row, n_end);
+  w_end = band_key_end(a, w_last, w_end);
+  const int n_beg = band_key_begin(a, m0, BK), w_beg = band_key_begin(a, qrow0, BK);
+  const int it_kv = (qrow0 / g.bq_kv) * g.bq_kv;   // query tile of the dK pass that holds this wave's rows
+  f32x16_t acc[D / 32];
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+  const uint16_t* kbase = a.k + (int64_t)s.start * a.k_row + (int64_t)h * a.k_head;
+  const int il = lane & 15, g16 = (lane >> 4) & 1;
+  const int tr_lane_off = ((32 * (il & 1) + 4 * hi + (il >> 2)) * 32 + (2 * g16 + ((il & 3) >> 1)) * 8) / 2;   // elements
+  typedef short v4s_t __attribute__((ext_vector_type(4)));
+  typedef short v8s_t __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) v4s_t* lds_v4s_t;
+  Dma64 dma;
+  dma.init(wv, lane, a.k_row);
+  u32x4_t ds0[NT], ds1[NT];
+  auto tile_written = [&](int n0) -> bool {
+    if (n0 >= s.L) return false;
+    return kv_visited(kv_span(a, s, (n0 / kBM) * kBM, g.bq_kv), it_kv);
+  };
+  auto fetch_ds = [&](int n) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int nt = n + 32 * t;
+      if (wave_live && nt < w_end && tile_written(nt) && !xch_absent(xu, nt >> 5, qrow0 >> 5)) {
+        const u32x4_t* tp = reinterpret_cast<const u32x4_t*>(g.ds_ws + xch_tile(xu, nt >> 5, qrow0 >> 5)) + 2 * lane;
+        ds0[t] = tp[0]; ds1[t] = tp[1];
+      } else {
+        ds0[t] = u32x4_t{0u, 0u, 0u, 0u}; ds1[t] = u32x4_t{0u, 0u, 0u, 0u};
+      }
+    }
+  };
+  if (n_end > n_beg) { dma.issue(kbase, a.k_row, n_beg, s.L, smem, lane); fetch_ds(n_beg); }
+  int n0 = n_beg;
+  auto step = [&](auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+    pin_agpr(acc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the wave's dS sub-tiles of this step -> its private patch (read back transposed below; the previous step's reads of the
+    // patch are complete: their MFMAs have been issued)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      *reinterpret_cast<u32x4_t*>(dSw + 1024 * t + 16 * lane) = ds0[t];
+      *reinterpret_cast<u32x4_t*>(dSw + 1024 * t + 16 * lane + 8) = ds1[t];
+    }
+    __syncthreads();
+    if (n0 + BK < n_end) { dma.issue(kbase, a.k_row, n0 + BK, s.L, smem + (BUF ^ 1) * TILE, lane); fetch_ds(n0 + BK); }
+    pin_agpr(acc);
+    if (wave_live && n0 < w_end && n0 >= w_beg) {
+      bf16x8_t sf[2 * NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const uint16_t* pp = dSw + 1024 * t + tr_lane_off;
+          const v4s_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(pp + (8 * (2 * half)) * 16));
+          const v4s_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(pp + (8 * (2 * half + 1)) * 16));
+          const v8s_t r = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+          sf[2 * t + half] = __builtin_bit_cast(bf16x8_t, r);
+        }
+      gemm_x8<BUF>(acc, smem, sf, lane, hi);
+    }
+    n0 += BK;
+  };
+  while (n0 < n_end) {
+    step(std::integral_constant<int, 0>{});
+    if (n0 >= n_end) break;
+    step(std::integral_constant<int, 1>{});
+  }
+  fence_a(acc);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (qi < s.L) store_acc_rows<D>(acc, g.dq + ((int64_t)(s.start + qi) * a.H + h) * D, hi);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The dK pass of the exchange with two waves per SIMD (round 4, head dim 256, no bias): the forward's S-wave / O-wave split
+// applied to the backward.  One workgroup = 128 keys; waves 0-3 ("S waves") hold the K and V fragments of their 32 keys
+// (128 registers) and compute, per 32-query step, S = Q K^T and dP = dO V^T (32 MFMAs), the SiLU / SiLU' elementwise phase,
+// and write P and dS to the exchange buffer (for the one-GEMM dV / dQ passes) and dS to an LDS hand-off; waves 4-7 ("K waves")
+// hold the dK accumulator (128 AGPRs), read that dS one step later and run dK^T += Q^T dS (16 MFMAs, Q^T fragments by
+// transpose reads), and issue the LDS-DMA of the step's three images: Q rows and dO rows (K-style swizzle, b128 row reads of
+// the S waves) and Q rows once more under the V-style swizzle (transpose reads of the K waves).  One barrier per step,
+// every ring two deep; the step loop is unrolled by two so that every LDS address is a register plus an immediate.
+// Same MFMA order and roundings as hstu_bwd_kv_kernel<256, 32, 2>: bit-identical dK, P and dS.
+// ---------------------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
+  static_assert(D == 256, "DMA rows of 32 chunks");
+  const AttnArgs& a = g.f;
+  constexpr int BQ = 32, IMG = BQ * D;               // elements of one staged image (16 KB)
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  uint16_t* const Qr = smem;                         // [2][32][256] Q rows, K-style swizzle
+  uint16_t* const dOr = smem + 2 * IMG;              // [2][32][256] dO rows, K-style swizzle
+  uint16_t* const Qt = smem + 4 * IMG;               // [2][32][256] Q rows, V-style swizzle (read transposed)
+  uint16_t* const Hs = smem + 6 * IMG;               // [2][4 pairs][2 slices][64 lanes] x 16 B: dS hand-off
+
+  const BlockSeq bs = seq_head_of_block(a);
+  const int b = bs.b, h = bs.h;
+  SeqInfo s;
+  s.start = bs.start;
+  s.L = bs.end - s.start;
+  const int n0 = bs.z * kBM;
+  if (n0 >= s.L || xch_other_chunk(g, b, h)) return;
+  const XchUnit xu = xch_unit(g, b, h, s.L);
+  s.has_ctx = a.num_contexts != nullptr;
+  s.has_tgt = a.num_targets != nullptr;
+  s.c = s.has_ctx ? a.num_contexts[b] : 0;
+  s.hlen = s.L - (s.has_tgt ? a.num_targets[b] : 0);
+  s.wl = a.wl; s.wr = a.wr;
+  const int lane = lane_id(), hi = lane >> 5, l31 = lane & 31;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int role = wv >> 2, pw = wv & 3;
+  const int key0 = n0 + 32 * pw, kj = key0 + l31;
+  const bool wave_live = key0 < s.L;
+  const bool plain = !s.has_ctx && !s.has_tgt && s.wl < 0 && s.wr < 0;
+  const bool key_in = kj < s.L, key_hist = kj < s.hlen;
+  const int key_iend = (s.has_tgt && kj >= s.hlen) ? s.hlen + ((kj - s.hlen) / a.group + 1) * a.group : 0x7fffffff;
+  const int ctx_end = s.has_ctx ? s.c : 0;
+  const uint16_t* qbase = a.q + (int64_t)s.start * a.q_row + (int64_t)h * a.q_head;
+  const uint16_t* dobase = g.dout + (int64_t)s.start * g.do_row + (int64_t)h * g.do_head;
+  const float neg_alpha_log2e = -a.alpha * 1.4426950408889634f;
+  const float c_p = a.alpha * a.inv_scale, c_ds = a.alpha * a.inv_scale;
+  const KvSpan span = kv_span(a, s, n0, BQ);
+  const int jump = span.jump, c_end = span.c_end, i_lim = span.lim;
+  auto advance = [&](int i) { i += BQ; return (i >= c_end && i < jump) ? jump : i; };
+  const int first = c_end > 0 ? 0 : jump;
+
+  // ---- LDS-DMA of a 32-row image: 16 instructions of 2 rows, 4 per K wave (rows 8 pw .. 8 pw + 7)
+  const int dr = lane >> 5, dp = lane & 31;
+  uint32_t vq_k[4], vdo_k[4], vq_v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int r = 2 * (4 * pw + u) + dr;
+    vq_k[u] = (uint32_t)dr * (uint32_t)a.q_row * 2u + 16u * (uint32_t)(dp ^ (r & 15));
+    vdo_k[u] = (uint32_t)dr * (uint32_t)g.do_row * 2u + 16u * (uint32_t)(dp ^ (r & 15));
+    vq_v[u] = (uint32_t)dr * (uint32_t)a.q_row * 2u + 16u * (uint32_t)(dp ^ ((r & 3) << 2));
+  }
+  auto issue_img = [&](const uint16_t* gsrc, int64_t row_stride, const uint32_t (&voff)[4], int row0, uint16_t* dst) {
+    const uint32_t d0 = (uint32_t)(uintptr_t)(lds_void_t)(dst + 8 * pw * D);
+    if (row0 + BQ <= s.L) {
+      const char* sb = reinterpret_cast<const char*>(gsrc + (int64_t)(row0 + 8 * pw) * row_stride);
+      const int64_t step = 2 * row_stride * 2;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) Dma64::dma16(sb + u * step, voff[u], d0 + u * 1024);
+    } else {
+      const uint32_t rowterm = (uint32_t)dr * (uint32_t)row_stride * 2u;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r0 = row0 + 2 * (4 * pw + u);
+        const int rc = r0 < s.L ? r0 : s.L - 1;
+        const uint32_t drop = r0 + 1 < s.L ? 0u : 0xffffffffu;
+        Dma64::dma16(reinterpret_cast<const char*>(gsrc + (int64_t)rc * row_stride), voff[u] - (rowterm & drop), d0 + u * 1024);
+      }
+    }
+  };
+
+  if (role == 0) {
+    // =========================== S waves ===========================
+    bf16x8_t kf[D / 16], vf[D / 16];
+    load_own_frags<D>(kf, a.k + (int64_t)s.start * a.k_row + (int64_t)h * a.k_head, a.k_row, kj, s.L, hi);
+    load_own_frags<D>(vf, a.v + (int64_t)s.start * a.v_row + (int64_t)h * a.v_head, a.v_row, kj, s.L, hi);
+    const int kx = l31 & 15;
+    int cur = first, prev_valid = 0;
+    auto step = [&](auto parc) {
+      constexpr int PAR = decltype(parc)::value;
+      __syncthreads();     // (no vmcnt wait here: the S waves issue no DMA, and their exchange stores must not be drained per step)
+      const int i0 = cur;
+      const bool have = i0 < i_lim;
+      prev_valid = have;
+      cur = have ? advance(i0) : i0;
+      if (!have || !wave_live) return;
+      const uint16_t* Qs = Qr + PAR * IMG;
+      const uint16_t* Ds = dOr + PAR * IMG;
+      f32x16_t acc_s, acc_p;
+      {
+        constexpr int SLB = 2, NBAT = (D / 16) / SLB;
+        bf16x8_t qa[2][SLB], da[2][SLB];
+        auto load_b = [&](int bi, int buf) {
+#pragma unroll
+          for (int u = 0; u < SLB; ++u) {
+            const int sl = SLB * bi + u;
+            const int off = l31 * D + 8 * ((2 * sl + hi) ^ kx);
+            qa[buf][u] = *reinterpret_cast<const bf16x8_t*>(Qs + off);
+            da[buf][u] = *reinterpret_cast<const bf16x8_t*>(Ds + off);
+          }
+        };
+        load_b(0, 0);
+#pragma unroll
+        for (int bi = 0; bi < NBAT; ++bi) {
+          if (bi + 1 < NBAT) load_b(bi + 1, (bi + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < SLB; ++u) {
+            const int sl = SLB * bi + u;
+            if (sl == 0) { mfma_v0(acc_s, qa[bi & 1][u], kf[sl]); mfma_v0(acc_p, da[bi & 1][u], vf[sl]); }
+            else { mfma_v(acc_s, qa[bi & 1][u], kf[sl]); mfma_v(acc_p, da[bi & 1][u], vf[sl]); }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      const bool tail = i0 + BQ > s.L;     // rows past the sequence are clamped copies here (the 4-wave kernel stages zeros): masked
+      auto elementwise = [&](auto modec, auto tailc) {
+        constexpr int kMask = decltype(modec)::value;
+        constexpr bool kTail = decltype(tailc)::value;
+        uint32_t pk[8], sk[8];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          float p2[2], s2[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int rr = r + u;
+            const int qi = i0 + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+            bool ok = true;
+            if constexpr (kMask == 1) ok = kj <= qi;
+            else if constexpr (kMask == 2) ok = kj < s.L;
+            else if constexpr (kMask == 3) ok = (qi < ctx_end ? key_hist : ((kj <= qi) & key_in)) & (key_hist | (qi < key_iend));
+            else if constexpr (kMask == 4)
+              ok = key_in & ((s.wl < 0) | (kj >= qi - s.wl)) & (a.causal ? (kj <= qi) : ((s.wr < 0) | (kj <= qi + s.wr)));
+            if constexpr (kTail) ok = ok & (qi < s.L);
+            const float acc = acc_s[rr];
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc * neg_alpha_log2e));
+            p2[u] = ok ? acc * c_p * sg : 0.f;
+            const float dsv = ds_value(acc, acc_p[rr], sg, a.alpha, c_ds);
+            s2[u] = ok ? dsv : 0.f;
+          }
+          pk[r >> 1] = pack_bf16(p2[0], p2[1]);
+          sk[r >> 1] = pack_bf16(s2[0], s2[1]);
+        }
+        const u32x4_t y0 = {sk[0], sk[1], sk[2], sk[3]}, y1 = {sk[4], sk[5], sk[6], sk[7]};
+        u32x4_t* hp = reinterpret_cast<u32x4_t*>(Hs) + ((PAR * 4 + pw) * 2) * 64 + lane;
+        hp[0] = y0; hp[64] = y1;                                  // dS -> the K wave of the pair (next step)
+        if (i0 < s.L && !xch_absent(xu, key0 >> 5, i0 >> 5)) {    // P and dS -> the one-GEMM dV / dQ passes
+          u32x4_t* tp = reinterpret_cast<u32x4_t*>(g.p_ws + xch_tile(xu, key0 >> 5, i0 >> 5)) + 2 * lane;
+          tp[0] = u32x4_t{pk[0], pk[1], pk[2], pk[3]}; tp[1] = u32x4_t{pk[4], pk[5], pk[6], pk[7]};
+          u32x4_t* tq = reinterpret_cast<u32x4_t*>(g.ds_ws + xch_tile(xu, key0 >> 5, i0 >> 5)) + 2 * lane;
+          tq[0] = y0; tq[1] = y1;
+        }
+      };
+      auto ew = [&](auto modec) { if (tail) elementwise(modec, std::true_type{}); else elementwise(modec, std::false_type{}); };
+      if (!plain) {
+        if (s.wl >= 0 || s.wr >= 0) ew(std::integral_constant<int, 4>{}); else ew(std::integral_constant<int, 3>{});
+      } else if (a.causal) {
+        if (key0 + 31 <= i0) ew(std::integral_constant<int, 0>{}); else ew(std::integral_constant<int, 1>{});
+      } else {
+        if (key0 + 31 < s.L) ew(std::integral_constant<int, 0>{}); else ew(std::integral_constant<int, 2>{});
+      }
+    };
+    while (cur < i_lim || prev_valid) {
+      step(std::integral_constant<int, 0>{});
+      if (!(cur < i_lim || prev_valid)) break;
+      step(std::integral_constant<int, 1>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  // =========================== K waves ===========================
+  f32x16_t acc_dk[D / 32];
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_dk[dt][r] = 0.f;
+  if (first < i_lim) {
+    issue_img(qbase, a.q_row, vq_k, first, Qr);
+    issue_img(dobase, g.do_row, vdo_k, first, dOr);
+  }
+  int cur = first, prev_valid = 0;
+  auto step = [&](auto parc) {
+    constexpr int PAR = decltype(parc)::value;
+    pin_agpr(acc_dk);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int i0 = cur;
+    const bool have = i0 < i_lim, had = prev_valid != 0;
+    const int nxt = have ? advance(i0) : i0;
+    if (have) {
+      if (nxt < i_lim) {
+        issue_img(qbase, a.q_row, vq_k, nxt, Qr + (PAR ^ 1) * IMG);
+        issue_img(dobase, g.do_row, vdo_k, nxt, dOr + (PAR ^ 1) * IMG);
+      }
+      issue_img(qbase, a.q_row, vq_v, i0, Qt + PAR * IMG);      // read by the K waves in the NEXT step
+    }
+    prev_valid = have;
+    cur = nxt;
+    pin_agpr(acc_dk);
+    if (!had || !wave_live) return;
+    // dK^T[256 x 32 keys] += Q^T[256 x 32 q] dS[32 q x 32 keys] of the PREVIOUS step (rings slot PAR ^ 1)
+    const u32x4_t* hp = reinterpret_cast<const u32x4_t*>(Hs) + (((PAR ^ 1) * 4 + pw) * 2) * 64 + lane;
+    bf16x8_t sf[2];
+    sf[0] = __builtin_bit_cast(bf16x8_t, hp[0]);
+    sf[1] = __builtin_bit_cast(bf16x8_t, hp[64]);
+    const uint16_t* tile = Qt + (PAR ^ 1) * IMG;
+    constexpr int NB = 4;
+    bf16x8_t fr[2][4];
+    auto load = [&](int bi) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) fr[bi & 1][u] = tr_frag_sw(tile, 4 * (bi & 1) + u, bi >> 1, lane, hi);
+    };
+    load(0);
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+      if (bi + 1 < NB) load(bi + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) mfma_a(acc_dk[4 * (bi & 1) + u], fr[bi & 1][u], sf[bi >> 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  while (cur < i_lim || prev_valid) {
+    step(std::integral_constant<int, 0>{});
+    if (!(cur < i_lim || prev_valid)) break;
+    step(std::integral_constant<int, 1>{});
+  }
+  fence_a(acc_dk);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (kj < s.L) store_acc_rows<D>(acc_dk, g.dk + ((int64_t)(s.start + kj) * a.H + h) * D, hi);
+}
+
 template <int D, int BQ, int MODE, bool kPre, bool kXP = false, bool kRab = false>
 static void launch_bwd_kv(const BwdAttnArgs& g, dim3 grid, hipStream_t stream) {
   constexpr bool kDV = MODE != 2, kDK = MODE != 1;
@@ -2527,6 +3061,20 @@ static void launch_bwd_q_ds(const BwdAttnArgs& g, dim3 grid, hipStream_t stream)
   hipLaunchKernelGGL((hstu_bwd_q_ds_kernel<D>), grid, dim3(256), smem, stream, g);
 }
 
+// the 8-wave one-GEMM passes (head dim 256; MI355_HSTU_X8=0: the 4-wave kernels)
+static void launch_bwd_x8(const BwdAttnArgs& g, int B, int max_seqlen, hipStream_t stream) {
+  const size_t smem_v = (size_t)2 * 64 * 256 * sizeof(uint16_t), smem_q = smem_v + (size_t)8 * 2 * 1024 * sizeof(uint16_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_v_p8_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_v);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_q_ds8_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_q);
+    attr_set = true;
+  }
+  dim3 grid(g.f.H, B, (max_seqlen + kBM8 - 1) / kBM8);
+  hipLaunchKernelGGL((hstu_bwd_v_p8_kernel<256>), grid, dim3(512), smem_v, stream, g);
+  hipLaunchKernelGGL((hstu_bwd_q_ds8_kernel<256>), grid, dim3(512), smem_q, stream, g);
+}
+
 template <int D>
 static int launch_bwd(BwdAttnArgs g, int B, int max_seqlen, hipStream_t stream) {
   dim3 grid(g.f.H, B, (max_seqlen + kBM - 1) / kBM);   // block rank slowest: see launch_fwd
@@ -2551,9 +3099,25 @@ static int launch_bwd(BwdAttnArgs g, int B, int max_seqlen, hipStream_t stream) 
       // 32-row steps with the next step's Q / dO rows prefetched into registers (64-row steps leave no registers for it and
       // fetch synchronously): 0.153 -> 0.149 ms at C3, 1.33 -> 1.29 ms at L = 4096 once the elementwise phase was fixed
       if (var & 32) { g.bq_kv = 64; launch_bwd_kv<D, 64, 2, false, true>(g, grid, stream); }
-      else { g.bq_kv = 32; launch_bwd_kv<D, 32, 2, true, true>(g, grid, stream); }
-      launch_bwd_v_p<D>(g, grid, stream);
-      launch_bwd_q_ds<D>(g, grid, stream);
+      else {
+        g.bq_kv = 32;
+        static const int kvpc = getenv("MI355_HSTU_KVPC") ? atoi(getenv("MI355_HSTU_KVPC")) : 1;
+        if (kvpc) {   // the S-wave / K-wave dK pass (two waves per SIMD)
+          const size_t smem_pc = (size_t)(6 * 32 * 256 + 2 * 4 * 2 * 64 * 8) * sizeof(uint16_t);
+          static bool attr_pc = false;
+          if (!attr_pc) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_kv_pc_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_pc);
+            attr_pc = true;
+          }
+          hipLaunchKernelGGL((hstu_bwd_kv_pc_kernel<256>), grid, dim3(512), smem_pc, stream, g);
+        } else launch_bwd_kv<D, 32, 2, true, true>(g, grid, stream);
+      }
+      static const int x8 = getenv("MI355_HSTU_X8") ? atoi(getenv("MI355_HSTU_X8")) : 1;
+      if (x8) launch_bwd_x8(g, B, max_seqlen, stream);
+      else {
+        launch_bwd_v_p<D>(g, grid, stream);
+        launch_bwd_q_ds<D>(g, grid, stream);
+      }
       MI355_LAUNCH_CHECK();
       return MI355_OK;
     }

@@ -155,6 +155,102 @@ __global__ void __launch_bounds__(256) flat_kernel(const int64_t* __restrict__ o
     a1 = a3;
   }
 }
+// key-balanced flat stream (round 4): the bag -> lane group deal is by KEYS, not by bags.  Group g owns the bags whose first
+// key lies in [g Q, (g + 1) Q) of the batch's key stream (the offsets are the prefix sum): every group then moves Q +- one bag
+// of rows instead of KB bags of 1..10 keys each (4 bags: 4..40 rows -- all groups are resident at once, the kernel ends with the
+// unluckiest one).  The two slice ends are found by an LPR-ary search of the group's lanes over the offsets (4 rounds of one
+// load per lane at 64 K bags, both searches in the same rounds); the bags are then walked as flat_kernel does, in runs of at
+// most LPR - 1 bags.
+template <int LPR>
+__device__ __forceinline__ void lower_bound2(const int64_t* __restrict__ off, int nOff, int64_t t0, int64_t t1, int c, int& r0, int& r1) {
+  int lo0 = 0, len0 = nOff, lo1 = 0, len1 = nOff;     // answer_i in [lo_i, lo_i + len_i]: first index with off[index] >= t_i (nOff: none)
+  while (__any(len0 > 0 || len1 > 0)) {
+    const int st0 = (len0 + LPR - 1) / LPR, st1 = (len1 + LPR - 1) / LPR;
+    const int i0 = lo0 + c * st0, i1 = lo1 + c * st1;
+    const bool v0 = len0 > 0 && i0 < lo0 + len0, v1 = len1 > 0 && i1 < lo1 + len1;
+    const int64_t x0 = off[v0 ? i0 : 0], x1 = off[v1 ? i1 : 0];
+    const unsigned long long m0 = __ballot(v0 && x0 < t0), m1 = __ballot(v1 && x1 < t1);
+    const int sh = (threadIdx.x & 63) & ~(LPR - 1);
+    const unsigned long long gm = LPR == 64 ? ~0ull : ((1ull << LPR) - 1);
+    const int c0 = __popcll((m0 >> sh) & gm), c1 = __popcll((m1 >> sh) & gm);
+    if (len0 > 0) { if (c0 == 0) len0 = 0; else { const int nl = lo0 + (c0 - 1) * st0 + 1, end = lo0 + len0; lo0 = nl; len0 = end - nl < st0 - 1 ? end - nl : st0 - 1; } }
+    if (len1 > 0) { if (c1 == 0) len1 = 0; else { const int nl = lo1 + (c1 - 1) * st1 + 1, end = lo1 + len1; lo1 = nl; len1 = end - nl < st1 - 1 ? end - nl : st1 - 1; } }
+  }
+  r0 = lo0; r1 = lo1;
+}
+template <int U, int Q, int LPR>
+__global__ void __launch_bounds__(256) flat_bal_kernel(const int64_t* __restrict__ offsets, const int64_t* __restrict__ addr, int B, uint2* out) {
+  constexpr int NL = 32 / LPR, KB = LPR - 1;
+  const int lane = threadIdx.x & 63, c = lane & (LPR - 1);
+  const int g = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (64 / LPR) + (lane / LPR);
+  const uintptr_t zero = (uintptr_t)g_zero;
+  const int64_t n = offsets[B];
+  const int64_t t0 = (int64_t)g * Q, t1 = t0 + Q;
+  int blo, bhi;
+  lower_bound2<LPR>(offsets, B + 1, t0 < n ? t0 : n + 1, t1, c, blo, bhi);   // (whole waves search: the shuffles / ballots need every lane)
+  if (t0 >= n && !(n == 0 && g == 0)) return;
+  if (t1 >= n) bhi = B;                     // the last slice also owns the trailing empty bags
+  if (n == 0) blo = 0;
+  if (bhi > B) bhi = B;
+  for (int b0 = blo; b0 < bhi; b0 += KB) {
+    const int bn = bhi - b0 < KB ? bhi - b0 : KB;
+    int64_t myoff = offsets[b0 + (c <= bn ? c : bn)];
+    const int olo = (int)myoff, ohi = (int)(myoff >> 32);
+    auto off = [&](int i) -> int64_t { return (int64_t)(((uint64_t)(unsigned)__shfl(ohi, i, LPR) << 32) | (unsigned)__shfl(olo, i, LPR)); };
+    const int64_t lo = off(0), hi = off(bn);
+    auto fetch_addr = [&](int64_t r) -> uintptr_t { int64_t j = r + c; j = j < hi ? j : hi - 1; j = j < 0 ? 0 : j; return (uintptr_t)addr[j]; };
+    auto issue = [&](uintptr_t a, int64_t r, f4 (&v)[U][NL]) {
+      const int alo = (int)(a & 0xffffffffu), ahi = (int)(a >> 32);
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        const uintptr_t base = (uintptr_t)(unsigned)__shfl(alo, q, LPR) | ((uintptr_t)(unsigned)__shfl(ahi, q, LPR) << 32);
+        const uintptr_t p = r + q < hi ? base : zero;
+#pragma unroll
+        for (int h = 0; h < NL; ++h) v[q][h] = *(gp4)(p + (r + q < hi ? 16 * (c + h * LPR) : 0));
+      }
+    };
+    int b = 0;
+    int64_t bend = off(1);
+    f4 acc[NL];
+#pragma unroll
+    for (int h = 0; h < NL; ++h) acc[h] = (f4){0.f, 0.f, 0.f, 0.f};
+    auto flush = [&]() {
+#pragma unroll
+      for (int h = 0; h < NL; ++h) {
+        out[(int64_t)(b0 + b) * 32 + c + h * LPR] = make_uint2(bf16pack(acc[h].x, acc[h].y), bf16pack(acc[h].z, acc[h].w));
+        acc[h] = (f4){0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    auto consume = [&](int64_t r, f4 (&v)[U][NL]) {
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        const int64_t j = r + q;
+        if (j < hi) {
+#pragma unroll
+          for (int h = 0; h < NL; ++h) acc[h] += v[q][h];
+          while (b < bn && j + 1 == bend) { flush(); ++b; bend = off(b + 1 <= bn ? b + 1 : bn); if (b + 1 > bn) break; }
+        }
+      }
+    };
+    while (b < bn && bend == lo) { flush(); ++b; bend = off(b + 1 <= bn ? b + 1 : bn); }   // leading empty bags
+    if (lo < hi) {
+      uintptr_t a0 = fetch_addr(lo), a1 = fetch_addr(lo + U);
+      f4 va[U][NL], vb[U][NL];
+      issue(a0, lo, va);
+      for (int64_t r = lo; r < hi; r += 2 * U) {
+        const uintptr_t a2 = fetch_addr(r + 2 * U);
+        issue(a1, r + U, vb);
+        consume(r, va);
+        if (r + U >= hi) break;
+        const uintptr_t a3 = fetch_addr(r + 3 * U);
+        issue(a2, r + 2 * U, va);
+        consume(r + U, vb);
+        a1 = a3;
+      }
+    }
+    while (b < bn) { flush(); ++b; }
+  }
+}
 __global__ void fill_kernel(float* p, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = (float)(i & 1023) * 1e-3f;
 }
@@ -209,6 +305,9 @@ int main() {
     chk(flat_kernel<4, 8, 32>, "flat U=4 KB=8 LPR=32", (B / 8 + 7) / 8);
     chk(flat_kernel<2, 4, 16>, "flat U=2 KB=4 LPR=16", (B / 4 + 15) / 16);
     chk(flat_kernel<4, 16, 32>, "flat U=4 KB=16 LPR=32", (B / 16 + 7) / 8);
+    chk(flat_bal_kernel<4, 22, 32>, "balanced U=4 Q=22 LPR=32", (int)((nts[0] / 22 + 1 + 7) / 8));
+    chk(flat_bal_kernel<4, 32, 32>, "balanced U=4 Q=32 LPR=32", (int)((nts[0] / 32 + 1 + 7) / 8));
+    chk(flat_bal_kernel<4, 16, 16>, "balanced U=4 Q=16 LPR=16", (int)((nts[0] / 16 + 1 + 15) / 16));
   }
   {  // the library's own kernels on exactly this data (MI355_POOL_VARIANT picks: 0 flat, 30 the round-2 pipelined one)
     void* h = dlopen(getenv("MI355_LIB") ? getenv("MI355_LIB") : "recsys-examples_amd/lib/librecsys_amd.so", RTLD_NOW);
@@ -233,6 +332,8 @@ int main() {
 #define FLAT(U, KB, LPR) run(flat_kernel<U, KB, LPR>, "flat double-buffered U=" #U " KB=" #KB " LPR=" #LPR, (B / KB + (256 / LPR) - 1) / (256 / LPR))
   FLAT(4, 4, 32); FLAT(4, 8, 32); FLAT(4, 16, 32); FLAT(6, 8, 32); FLAT(8, 8, 32); FLAT(2, 4, 32); FLAT(2, 8, 32);
   FLAT(2, 4, 16); FLAT(2, 8, 16); FLAT(4, 4, 16); FLAT(4, 8, 16); FLAT(3, 8, 16);
+#define BAL(U, Q, LPR) run(flat_bal_kernel<U, Q, LPR>, "key-balanced flat U=" #U " Q=" #Q " LPR=" #LPR, (int)((*std::max_element(nts.begin(), nts.end()) / Q + 1 + (256 / LPR) - 1) / (256 / LPR)))
+  BAL(4, 16, 32); BAL(4, 22, 32); BAL(4, 28, 32); BAL(4, 44, 32); BAL(2, 22, 32); BAL(6, 22, 32); BAL(8, 44, 32); BAL(4, 22, 16); BAL(4, 44, 16); BAL(4, 88, 32);
   for (int bpc : {4}) { run(bag_persist_kernel<4>, "persistent pipelined U=4", 256 * bpc); run(bag_persist_kernel<8>, "persistent pipelined U=8", 256 * bpc);
                                  run(bag_persist_kernel<10>, "persistent pipelined U=10", 256 * bpc); }
   return 0;
