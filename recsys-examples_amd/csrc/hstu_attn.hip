@@ -2501,6 +2501,9 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_v_p_kernel(BwdAttnArg
 // clock and CU, what L2 + HBM deliver), no staging registers, no commit phase, and a second wave per SIMD to cover the P / dS
 // loads and the fragment reads.
 // ---------------------------------------------------------------------------------------------------
+#ifndef HSTU_KVPC_FBUF
+#define HSTU_KVPC_FBUF 3   // S waves of the dK pass: Q / dO fragment batches in registers (FBUF - 1 in flight ahead of the MFMAs)
+#endif
 #ifndef HSTU_X8_VBUF
 #define HSTU_X8_VBUF 2   // fragment batches (4 slices) in registers in the 8-wave passes (3 spills at 128 + 128 registers)
 #endif
@@ -2835,6 +2838,20 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
   const int jump = span.jump, c_end = span.c_end, i_lim = span.lim;
   auto advance = [&](int i) { i += BQ; return (i >= c_end && i < jump) ? jump : i; };
   const int first = c_end > 0 ? 0 : jump;
+#if HSTU_TIMING
+  unsigned tsum[7] = {0, 0, 0, 0, 0, 0, 0};   // S: barrier, -, -, -, GEMM S + dP, elementwise + stores, steps | K: vmcnt, barrier, DMA issue, -, -, GEMM dK, steps
+  const unsigned t_start = tick();
+  auto t_dump = [&]() {
+    const unsigned t_end = tick();
+    if (lane == 0) {
+      const int blk = ((int)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      unsigned long long* d = g_hstu_dbg + ((size_t)(blk * 8 + wv) % 65536) * 8;
+      for (int i = 0; i < 7; ++i) d[i] = tsum[i];
+      d[6] |= (unsigned long long)role << 32;
+      d[7] = t_end - t_start;
+    }
+  };
+#endif
 
   // ---- LDS-DMA of a 32-row image: 16 instructions of 2 rows, 4 per K wave (rows 8 pw .. 8 pw + 7)
   const int dr = lane >> 5, dp = lane & 31;
@@ -2874,7 +2891,10 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
     int cur = first, prev_valid = 0;
     auto step = [&](auto parc) {
       constexpr int PAR = decltype(parc)::value;
+      TICK(t0);
       __syncthreads();     // (no vmcnt wait here: the S waves issue no DMA, and their exchange stores must not be drained per step)
+      TICK(t1);
+      TACC(0, t0, t1);
       const int i0 = cur;
       const bool have = i0 < i_lim;
       prev_valid = have;
@@ -2884,31 +2904,34 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
       const uint16_t* Ds = dOr + PAR * IMG;
       f32x16_t acc_s, acc_p;
       {
-        constexpr int SLB = 2, NBAT = (D / 16) / SLB;
-        bf16x8_t qa[2][SLB], da[2][SLB];
-        auto load_b = [&](int bi, int buf) {
+        constexpr int SLB = 2, NBAT = (D / 16) / SLB, NFB = HSTU_KVPC_FBUF;   // batches of 2 slices (4 MFMAs), NFB - 1 in flight
+        bf16x8_t qa[NFB][SLB], da[NFB][SLB];
+        auto load_b = [&](int bi) {
 #pragma unroll
           for (int u = 0; u < SLB; ++u) {
             const int sl = SLB * bi + u;
             const int off = l31 * D + 8 * ((2 * sl + hi) ^ kx);
-            qa[buf][u] = *reinterpret_cast<const bf16x8_t*>(Qs + off);
-            da[buf][u] = *reinterpret_cast<const bf16x8_t*>(Ds + off);
+            qa[bi % NFB][u] = *reinterpret_cast<const bf16x8_t*>(Qs + off);
+            da[bi % NFB][u] = *reinterpret_cast<const bf16x8_t*>(Ds + off);
           }
         };
-        load_b(0, 0);
+#pragma unroll
+        for (int bi = 0; bi < NFB - 1; ++bi) load_b(bi);
 #pragma unroll
         for (int bi = 0; bi < NBAT; ++bi) {
-          if (bi + 1 < NBAT) load_b(bi + 1, (bi + 1) & 1);
+          if (bi + NFB - 1 < NBAT) load_b(bi + NFB - 1);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int u = 0; u < SLB; ++u) {
             const int sl = SLB * bi + u;
-            if (sl == 0) { mfma_v0(acc_s, qa[bi & 1][u], kf[sl]); mfma_v0(acc_p, da[bi & 1][u], vf[sl]); }
-            else { mfma_v(acc_s, qa[bi & 1][u], kf[sl]); mfma_v(acc_p, da[bi & 1][u], vf[sl]); }
+            if (sl == 0) { mfma_v0(acc_s, qa[bi % NFB][u], kf[sl]); mfma_v0(acc_p, da[bi % NFB][u], vf[sl]); }
+            else { mfma_v(acc_s, qa[bi % NFB][u], kf[sl]); mfma_v(acc_p, da[bi % NFB][u], vf[sl]); }
           }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      TICK(t2);
+      TACC(4, t1, t2);
       const bool tail = i0 + BQ > s.L;     // rows past the sequence are clamped copies here (the 4-wave kernel stages zeros): masked
       auto elementwise = [&](auto modec, auto tailc) {
         constexpr int kMask = decltype(modec)::value;
@@ -2943,9 +2966,7 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
         if (i0 < s.L && !xch_absent(xu, key0 >> 5, i0 >> 5)) {    // P and dS -> the one-GEMM dV / dQ passes
           u32x4_t* tp = reinterpret_cast<u32x4_t*>(g.p_ws + xch_tile(xu, key0 >> 5, i0 >> 5)) + 2 * lane;
           tp[0] = u32x4_t{pk[0], pk[1], pk[2], pk[3]}; tp[1] = u32x4_t{pk[4], pk[5], pk[6], pk[7]};
-          u32x4_t* tq = reinterpret_cast<u32x4_t*>(g.ds_ws + xch_tile(xu, key0 >> 5, i0 >> 5)) + 2 * lane;
-          tq[0] = y0; tq[1] = y1;
-        }
+        }   // (dS goes to the exchange buffer from the K wave, which has it in registers one step later: two stores fewer here)
       };
       auto ew = [&](auto modec) { if (tail) elementwise(modec, std::true_type{}); else elementwise(modec, std::false_type{}); };
       if (!plain) {
@@ -2955,6 +2976,11 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
       } else {
         if (key0 + 31 < s.L) ew(std::integral_constant<int, 0>{}); else ew(std::integral_constant<int, 2>{});
       }
+      TICK(t3);
+      TACC(5, t2, t3);
+#if HSTU_TIMING
+      tsum[6] += 1;
+#endif
     };
     while (cur < i_lim || prev_valid) {
       step(std::integral_constant<int, 0>{});
@@ -2962,6 +2988,9 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
       step(std::integral_constant<int, 1>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if HSTU_TIMING
+    t_dump();
+#endif
     return;
   }
   // =========================== K waves ===========================
@@ -2974,14 +3003,20 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
     issue_img(qbase, a.q_row, vq_k, first, Qr);
     issue_img(dobase, g.do_row, vdo_k, first, dOr);
   }
-  int cur = first, prev_valid = 0;
+  int cur = first, prev_valid = 0, prev_i = 0;
   auto step = [&](auto parc) {
     constexpr int PAR = decltype(parc)::value;
     pin_agpr(acc_dk);
+    TICK(t0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TICK(t1);
     __syncthreads();
+    TICK(t2);
+    TACC(0, t0, t1); TACC(1, t1, t2);
     const int i0 = cur;
     const bool have = i0 < i_lim, had = prev_valid != 0;
+    const int ip = prev_i;           // the step the S wave finished last
+    prev_i = i0;
     const int nxt = have ? advance(i0) : i0;
     if (have) {
       if (nxt < i_lim) {
@@ -2993,12 +3028,19 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
     prev_valid = have;
     cur = nxt;
     pin_agpr(acc_dk);
+    TICK(t3);
+    TACC(2, t2, t3);
     if (!had || !wave_live) return;
     // dK^T[256 x 32 keys] += Q^T[256 x 32 q] dS[32 q x 32 keys] of the PREVIOUS step (rings slot PAR ^ 1)
     const u32x4_t* hp = reinterpret_cast<const u32x4_t*>(Hs) + (((PAR ^ 1) * 4 + pw) * 2) * 64 + lane;
     bf16x8_t sf[2];
-    sf[0] = __builtin_bit_cast(bf16x8_t, hp[0]);
-    sf[1] = __builtin_bit_cast(bf16x8_t, hp[64]);
+    const u32x4_t y0 = hp[0], y1 = hp[64];
+    sf[0] = __builtin_bit_cast(bf16x8_t, y0);
+    sf[1] = __builtin_bit_cast(bf16x8_t, y1);
+    if (ip < s.L && !xch_absent(xu, key0 >> 5, ip >> 5)) {   // dS of that step -> the one-GEMM dQ pass
+      u32x4_t* tq = reinterpret_cast<u32x4_t*>(g.ds_ws + xch_tile(xu, key0 >> 5, ip >> 5)) + 2 * lane;
+      tq[0] = y0; tq[1] = y1;
+    }
     const uint16_t* tile = Qt + (PAR ^ 1) * IMG;
     constexpr int NB = 4;
     bf16x8_t fr[2][4];
@@ -3015,6 +3057,11 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
       for (int u = 0; u < 4; ++u) mfma_a(acc_dk[4 * (bi & 1) + u], fr[bi & 1][u], sf[bi >> 1]);
       __builtin_amdgcn_sched_barrier(0);
     }
+    TICK(t4);
+    TACC(5, t3, t4);
+#if HSTU_TIMING
+    tsum[6] += 1;
+#endif
   };
   while (cur < i_lim || prev_valid) {
     step(std::integral_constant<int, 0>{});
@@ -3023,6 +3070,9 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
   }
   fence_a(acc_dk);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if HSTU_TIMING
+  t_dump();
+#endif
   if (kj < s.L) store_acc_rows<D>(acc_dk, g.dk + ((int64_t)(s.start + kj) * a.H + h) * D, hi);
 }
 

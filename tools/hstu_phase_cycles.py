@@ -17,6 +17,7 @@ ap.add_argument("--batch", type=int, default=32); ap.add_argument("--seqlen", ty
 ap.add_argument("--heads", type=int, default=4); ap.add_argument("--dim", type=int, default=256)
 ap.add_argument("--dma", action="store_true", help="the LDS-DMA staged forward (sets MI355_HSTU_DMA=1)")
 ap.add_argument("--pc", action="store_true", help="the two-waves-per-SIMD forward (hstu_fwd_pc_kernel: S waves / O waves; the default forward)")
+ap.add_argument("--bwdpc", action="store_true", help="the S-wave / K-wave dK pass of the backward (hstu_bwd_kv_pc_kernel)")
 ap.add_argument("--bwd", action="store_true", help="the dK pass of the backward (hstu_bwd_kv_kernel, exchange mode) instead of the forward")
 a = ap.parse_args()
 if a.dma:
@@ -31,7 +32,7 @@ T = a.batch * a.seqlen
 cu = torch.arange(0, T + 1, a.seqlen, dtype=torch.int32, device=dev)
 q, k, v = (torch.empty(T, a.heads, a.dim, device=dev).uniform_(-1, 1).bfloat16() for _ in range(3))
 for _ in range(3):
-    if a.bwd:
+    if a.bwd or a.bwdpc:
         hstu_varlen_bwd(q, q, k, v, cu, a.seqlen, a.seqlen, None, None, 1, True, 1.0 / a.dim ** 0.5)
     else:
         hstu_varlen_fwd(q, k, v, cu, a.seqlen, a.seqlen, None, None, 1, True, 1.0 / a.dim ** 0.5)
@@ -42,6 +43,20 @@ buf = np.zeros((65536, 8), np.uint64)
 lib = ctypes.CDLL(mi355_native.LIB_PATH)
 lib.mi355_hstu_dbg_dump.argtypes = [ctypes.c_void_p, ctypes.c_int64]
 assert lib.mi355_hstu_dbg_dump(buf.ctypes.data, buf.nbytes) == 0
+if a.bwdpc:
+    n = min(nblk * 8, 65536)
+    dd = buf[:n].astype(np.float64)
+    role_of = (buf[:n, 6] >> np.uint64(32)).astype(np.int64)
+    dd[:, 6] = (buf[:n, 6] & np.uint64(0xffffffff)).astype(np.float64)
+    for role, nm0, names in ((0, 'S waves (S, dP, elementwise)', ['barrier', None, None, None, 'gemm S + dP', 'elementwise + stores']), (1, 'K waves (DMA, dK)', ['wait own DMA', 'barrier', 'DMA issue', None, None, 'gemm dK'])):
+        d = dd[role_of == role]
+        tiles, tot = d[:, 6], d[:, 7]
+        print(f'{nm0}: waves {len(d)}  steps/wave avg {tiles.mean():.2f}  wave lifetime avg {tot.mean():.0f} cyc  max {tot.max():.0f}')
+        for i, nm in enumerate(names):
+            if nm is None: continue
+            print(f'  {nm:26s} {d[:, i].sum() / tiles.sum():8.0f} cyc per computed step   ({100 * d[:, i].sum() / tot.sum():5.1f} % of wave lifetime)')
+        print(f"  {'other':26s} {(tot.sum() - d[:, :6].sum()) / tiles.sum():8.0f} cyc per computed step   ({100 * (tot.sum() - d[:, :6].sum()) / tot.sum():5.1f} %)")
+    sys.exit(0)
 if a.pc:
     n = min(nblk * 8, 65536)
     dd = buf[:n].astype(np.float64)

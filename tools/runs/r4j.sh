@@ -2,7 +2,7 @@
 # round 4: per-kernel times of the attention kernels (rocprofv3 kernel trace) at C3 and 8 x 4096, x8 on / off
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r4j; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for cfg in "c3 32 512 1" "c3x4 32 512 0" "l4096 8 4096 1" "l4096x4 8 4096 0"; do
+for cfg in "c3 32 512 1" "l4096 8 4096 1"; do
   set -- $cfg
   rm -rf /tmp/prof_$1
   MI355_HSTU_X8=$4 rocprofv3 --kernel-trace -d /tmp/prof_$1 -o t -- python $R/tools/bench_hstu.py --batch $2 --seqlen $3 --reps 10 > $O/$1.log 2>&1
