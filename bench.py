@@ -440,6 +440,51 @@ def c2_16x_section(args, module, device):
                               "algorithmic_bytes_per_step": step_bytes}}
 
 
+def sharded_stage_times(sharded, batches, grad, dist, device, world, step_ms):
+    """Where a sharded step's time goes, so that a scaling curve explains itself: the four stages of one step run back to
+    back WITHOUT overlap (plain schedule), each bracketed by HIP events on the launch stream -- input_dist (bucketize + the
+    two all-to-alls of lengths and keys), lookup (local fused forward), output_dist (all-to-all of partial sums + their sum),
+    backward (all-gather of the gradients + local reduce / SGD) -- max over ranks; `exposed_comm` = the overlapped step time
+    of the timed window minus the two compute stages, i.e. the communication (and host glue) the overlap did not hide.
+    Only the partial-sum dist has this stage structure (the rows dist reports its forward / backward halves)."""
+    impl = sharded.impl
+    n = min(len(batches), 10)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    acc = {}
+
+    def timed(name, fn):
+        e0, e1 = ev(), ev()
+        e0.record()
+        r = fn()
+        e1.record()
+        acc.setdefault(name, []).append((e0, e1))
+        return r
+
+    staged = hasattr(impl, "dist_input")
+    for keys, offsets in batches[:n]:
+        if staged:
+            sk = timed("input_dist", lambda: impl.dist_input(keys, offsets))
+            out_local, lctx = timed("lookup", lambda: impl.lookup(sk, True))
+            timed("output_dist", lambda: impl.dist_output(sk, out_local))
+            g_all = timed("backward_comm", lambda: impl.dist_grads(sk, grad))
+            timed("backward_local", lambda: impl.local.backward(lctx, g_all))
+        else:
+            out, ctx = timed("forward", lambda: impl.forward(keys, offsets, True))
+            timed("backward", lambda: impl.backward(ctx, grad))
+    torch.cuda.synchronize()
+    names = sorted(acc)
+    t = torch.tensor([float(np.median([a.elapsed_time(b) for a, b in acc[k]])) for k in names], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    out = {k: float(v) for k, v in zip(names, t.tolist())}
+    if staged:
+        out["backward"] = out["backward_comm"] + out["backward_local"]
+        out["exposed_comm"] = max(0.0, step_ms - out["lookup"] - out["backward_local"])
+    out["mode"] = getattr(sharded, "mode", "?")
+    out["note"] = "stages timed one after the other (no overlap), median of %d steps, max over ranks; the timed window overlaps them" % n
+    return out
+
+
 def _flush_c_stdout():
     try:
         import ctypes
@@ -598,6 +643,10 @@ def main():
         sus = float(t.item())
     result["sustained"] = {"steps": sus_steps, "seconds": sus, "ms_per_step": 1e3 * sus / sus_steps,
                            "value": keys_total / args.steps * sus_steps / sus, "unit": "lookups/s"}
+
+    if sharded_path:
+        result["stages_ms"] = sharded_stage_times(sharded, batches[args.warmup:], grad, dist, device, world,
+                                                  result["sustained"]["ms_per_step"])
 
     if rank == 0 and not sharded_path:
         # the same step through the module's PUBLIC path -- forward() -> _LookupFunction.apply -> autograd backward -- which

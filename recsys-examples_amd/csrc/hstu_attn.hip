@@ -2507,15 +2507,16 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_v_p_kernel(BwdAttnArg
 #ifndef HSTU_X8_VBUF
 #define HSTU_X8_VBUF 2   // fragment batches (4 slices) in registers in the 8-wave passes (3 spills at 128 + 128 registers)
 #endif
-constexpr int kBM8 = 256;   // rows per workgroup of the 8-wave passes
-struct Dma64 {   // LDS-DMA of one 64-row x 256-column bf16 tile by 8 waves: 32 instructions of 2 rows, 4 per wave
-  uint32_t voff[4];
+template <int NW>
+struct Dma64T {   // LDS-DMA of one 64-row x 256-column bf16 tile by NW waves: 32 instructions of 2 rows, 32 / NW per wave
+  static constexpr int PER = 32 / NW;
+  uint32_t voff[PER];
   int j0;
   __device__ __forceinline__ void init(int wv, int lane, int64_t row_stride) {
-    j0 = 4 * wv;
+    j0 = PER * wv;
     const int dr = lane >> 5, dp = lane & 31;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < PER; ++u) {
       const int r = 2 * (j0 + u) + dr;
       voff[u] = (uint32_t)dr * (uint32_t)row_stride * 2u + 16u * (uint32_t)(dp ^ ((r & 3) << 2));
     }
@@ -2532,11 +2533,11 @@ struct Dma64 {   // LDS-DMA of one 64-row x 256-column bf16 tile by 8 waves: 32 
       const char* sb = reinterpret_cast<const char*>(g + (int64_t)(row0 + 2 * j0) * row_stride);
       const int64_t step = 2 * row_stride * 2;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) dma16(sb + u * step, voff[u], d0 + u * 1024);
+      for (int u = 0; u < PER; ++u) dma16(sb + u * step, voff[u], d0 + u * 1024);
     } else {
       const uint32_t rowterm = (uint32_t)(lane >> 5) * (uint32_t)row_stride * 2u;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < PER; ++u) {
         const int r0 = row0 + 2 * (j0 + u);
         const int rc = r0 < L ? r0 : L - 1;
         const uint32_t drop = r0 + 1 < L ? 0u : 0xffffffffu;
@@ -2545,6 +2546,7 @@ struct Dma64 {   // LDS-DMA of one 64-row x 256-column bf16 tile by 8 waves: 32 
     }
   }
 };
+typedef Dma64T<8> Dma64;
 // A fragment [32 d x 16 rows] of a DMA-staged tile, read transposed (the forward's v_frag)
 __device__ __forceinline__ bf16x8_t tr_frag_sw(const uint16_t* tile, int dt, int ks, int lane, int hi) {
   typedef short v4s_t __attribute__((ext_vector_type(4)));
@@ -2595,8 +2597,9 @@ __device__ __forceinline__ void store_acc_rows(const f32x16_t (&acc)[D / 32], ui
 
 // dV from the stored P, 256 keys per workgroup.  The query steps are the union of what the dK pass ran for the block's two
 // 128-key halves (its blocks are kBM keys); a wave consults the span of ITS half to tell which sub-tiles exist.
-template <int D>
-__global__ void __launch_bounds__(512) hstu_bwd_v_p8_kernel(BwdAttnArgs g) {
+template <int D, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_v_p8_kernel(BwdAttnArgs g) {
+  constexpr int kBM8 = 32 * NW;   // keys per workgroup
   static_assert(D == 256, "DMA rows of 32 chunks");
   const AttnArgs& a = g.f;
   constexpr int BQ = 64, NT = 2, TILE = BQ * D;
@@ -2625,7 +2628,7 @@ __global__ void __launch_bounds__(512) hstu_bwd_v_p8_kernel(BwdAttnArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
   const KvSpan sp0 = kv_span(a, s, n0, g.bq_kv);
-  const KvSpan sp1 = n0 + kBM < s.L ? kv_span(a, s, n0 + kBM, g.bq_kv) : sp0;
+  const KvSpan sp1 = (NW == 8 && n0 + kBM < s.L) ? kv_span(a, s, n0 + kBM, g.bq_kv) : sp0;
   const KvSpan mine = wv < 4 ? sp0 : sp1;
   const int jump = sp0.jump < sp1.jump ? sp0.jump : sp1.jump, c_end = sp0.c_end > sp1.c_end ? sp0.c_end : sp1.c_end;
   const int lim = sp0.lim > sp1.lim ? sp0.lim : sp1.lim;
@@ -2634,7 +2637,7 @@ __global__ void __launch_bounds__(512) hstu_bwd_v_p8_kernel(BwdAttnArgs g) {
   if (i_lim > s.L) i_lim = s.L;
   auto advance = [&](int i) { i += BQ; return (i >= cend_s && i < jump_s) ? jump_s : i; };
   auto visited = [&](int i) { return i < s.L && kv_visited(mine, (i / g.bq_kv) * g.bq_kv); };
-  Dma64 dma;
+  Dma64T<NW> dma;
   dma.init(wv, lane, g.do_row);
   u32x4_t pn0[NT], pn1[NT];
   auto fetch_p = [&](int i) {
@@ -2679,8 +2682,9 @@ __global__ void __launch_bounds__(512) hstu_bwd_v_p8_kernel(BwdAttnArgs g) {
 
 // dQ from the stored dS, 256 query rows per workgroup (the layout juggling of hstu_bwd_q_ds_kernel: the 2 KB sub-tile goes
 // through a wave-private LDS patch and comes back through transpose reads)
-template <int D>
-__global__ void __launch_bounds__(512) hstu_bwd_q_ds8_kernel(BwdAttnArgs g) {
+template <int D, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_q_ds8_kernel(BwdAttnArgs g) {
+  constexpr int kBM8 = 32 * NW;   // query rows per workgroup
   static_assert(D == 256, "DMA rows of 32 chunks");
   const AttnArgs& a = g.f;
   constexpr int BK = 64, NT = 2, TILE = BK * D;
@@ -2701,7 +2705,7 @@ __global__ void __launch_bounds__(512) hstu_bwd_q_ds8_kernel(BwdAttnArgs g) {
   s.wl = a.wl; s.wr = a.wr;
   const int lane = lane_id(), hi = lane >> 5, l31 = lane & 31;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  uint16_t* dSw = smem + 2 * TILE + NT * 1024 * wv;
+  uint16_t* dSw = smem + 2 * TILE + NT * 1024 * wv;   // (NW patches behind the two K tiles)
   const int qrow0 = m0 + 32 * wv, qi = qrow0 + l31;
   const bool wave_live = qrow0 < s.L;
   int last_row = m0 + kBM8 - 1 < s.L - 1 ? m0 + kBM8 - 1 : s.L - 1;
@@ -2725,7 +2729,7 @@ __global__ void __launch_bounds__(512) hstu_bwd_q_ds8_kernel(BwdAttnArgs g) {
   typedef short v4s_t __attribute__((ext_vector_type(4)));
   typedef short v8s_t __attribute__((ext_vector_type(8)));
   typedef __attribute__((address_space(3))) v4s_t* lds_v4s_t;
-  Dma64 dma;
+  Dma64T<NW> dma;
   dma.init(wv, lane, a.k_row);
   u32x4_t ds0[NT], ds1[NT];
   auto tile_written = [&](int n0) -> bool {
@@ -3111,18 +3115,21 @@ static void launch_bwd_q_ds(const BwdAttnArgs& g, dim3 grid, hipStream_t stream)
   hipLaunchKernelGGL((hstu_bwd_q_ds_kernel<D>), grid, dim3(256), smem, stream, g);
 }
 
-// the 8-wave one-GEMM passes (head dim 256; MI355_HSTU_X8=0: the 4-wave kernels)
+// the DMA-staged one-GEMM passes (head dim 256): MI355_HSTU_X8 = 8: one 8-wave workgroup of 256 rows per CU; 4 (default):
+// 4-wave workgroups of 128 rows, TWO per CU -- the same two waves per SIMD, twice the blocks (causal work balances over the
+// CUs: a chunk of the capped exchange may hold only one 256-row block per CU); 0: the register-staged 4-wave kernels
+template <int NW>
 static void launch_bwd_x8(const BwdAttnArgs& g, int B, int max_seqlen, hipStream_t stream) {
-  const size_t smem_v = (size_t)2 * 64 * 256 * sizeof(uint16_t), smem_q = smem_v + (size_t)8 * 2 * 1024 * sizeof(uint16_t);
+  const size_t smem_v = (size_t)2 * 64 * 256 * sizeof(uint16_t), smem_q = smem_v + (size_t)NW * 2 * 1024 * sizeof(uint16_t);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_v_p8_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_v);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_q_ds8_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_q);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_v_p8_kernel<256, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_v);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_q_ds8_kernel<256, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_q);
     attr_set = true;
   }
-  dim3 grid(g.f.H, B, (max_seqlen + kBM8 - 1) / kBM8);
-  hipLaunchKernelGGL((hstu_bwd_v_p8_kernel<256>), grid, dim3(512), smem_v, stream, g);
-  hipLaunchKernelGGL((hstu_bwd_q_ds8_kernel<256>), grid, dim3(512), smem_q, stream, g);
+  dim3 grid(g.f.H, B, (max_seqlen + 32 * NW - 1) / (32 * NW));
+  hipLaunchKernelGGL((hstu_bwd_v_p8_kernel<256, NW>), grid, dim3(64 * NW), smem_v, stream, g);
+  hipLaunchKernelGGL((hstu_bwd_q_ds8_kernel<256, NW>), grid, dim3(64 * NW), smem_q, stream, g);
 }
 
 template <int D>
@@ -3162,8 +3169,9 @@ static int launch_bwd(BwdAttnArgs g, int B, int max_seqlen, hipStream_t stream) 
           hipLaunchKernelGGL((hstu_bwd_kv_pc_kernel<256>), grid, dim3(512), smem_pc, stream, g);
         } else launch_bwd_kv<D, 32, 2, true, true>(g, grid, stream);
       }
-      static const int x8 = getenv("MI355_HSTU_X8") ? atoi(getenv("MI355_HSTU_X8")) : 1;
-      if (x8) launch_bwd_x8(g, B, max_seqlen, stream);
+      static const int x8 = getenv("MI355_HSTU_X8") ? atoi(getenv("MI355_HSTU_X8")) : 4;
+      if (x8 == 8) launch_bwd_x8<8>(g, B, max_seqlen, stream);
+      else if (x8) launch_bwd_x8<4>(g, B, max_seqlen, stream);
       else {
         launch_bwd_v_p<D>(g, grid, stream);
         launch_bwd_q_ds<D>(g, grid, stream);
