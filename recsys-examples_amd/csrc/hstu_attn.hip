@@ -1180,7 +1180,7 @@ __global__ void __launch_bounds__(512) hstu_fwd_pc_kernel(AttnArgs a) {
   };
   auto issue_dma = [&](const uint16_t* g, int64_t g_row, const uint32_t (&voff)[NMY], uint16_t* ring, int tile, int u0, int u1) {
     const int n0 = n_beg + kBN * tile;                                // (instructions [u0, u1) of this wave's share)
-    const uint32_t dst = (uint32_t)(uintptr_t)(lds_void_t)(ring + (tile & 1) * TENS + RPI * j_first * ROWB);
+    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_t)(ring + (tile & 1) * TENS + RPI * j_first * ROWB));
     if (n0 + kBN <= s.L) {
       const char* sb = reinterpret_cast<const char*>(g + (int64_t)(n0 + RPI * j_first) * g_row);
       const int64_t step = (int64_t)RPI * g_row * 2;
@@ -1411,8 +1411,8 @@ __global__ void __launch_bounds__(512) hstu_fwd_pc_kernel(AttnArgs a) {
         const char* kb = reinterpret_cast<const char*>(kg + (int64_t)(nk0 + RPI * j_first) * a.k_row);
         const char* vb = reinterpret_cast<const char*>(vg + (int64_t)(nv0 + RPI * j_first) * a.v_row);
         const int64_t kstep = (int64_t)RPI * a.k_row * 2, vstep = (int64_t)RPI * a.v_row * 2;
-        const uint32_t kdst = (uint32_t)(uintptr_t)(lds_void_t)(Kring + ((it + 1) & 1) * TENS + RPI * j_first * ROWB);
-        const uint32_t vdst = (uint32_t)(uintptr_t)(lds_void_t)(Vring + (it & 1) * TENS + RPI * j_first * ROWB);
+        const uint32_t kdst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_t)(Kring + ((it + 1) & 1) * TENS + RPI * j_first * ROWB));
+        const uint32_t vdst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_t)(Vring + (it & 1) * TENS + RPI * j_first * ROWB));
         bf16x8_t pf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) pf[ks] = __builtin_bit_cast(bf16x8_t, psrc[ks * 64]);
@@ -2528,7 +2528,7 @@ struct Dma64T {   // LDS-DMA of one 64-row x 256-column bf16 tile by NW waves: 3
   }
   // rows row0 .. row0 + 63 of `g` (element row stride row_stride) -> the tile at `dst`; rows past L are read clamped
   __device__ __forceinline__ void issue(const uint16_t* g, int64_t row_stride, int row0, int L, uint16_t* dst, int lane) const {
-    const uint32_t d0 = (uint32_t)(uintptr_t)(lds_void_t)(dst + 2 * j0 * 256);
+    const uint32_t d0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_t)(dst + 2 * j0 * 256));   // (an "s" operand of the DMA statement: must be provably uniform)
     if (row0 + 64 <= L) {
       const char* sb = reinterpret_cast<const char*>(g + (int64_t)(row0 + 2 * j0) * row_stride);
       const int64_t step = 2 * row_stride * 2;
@@ -2868,7 +2868,7 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
     vq_v[u] = (uint32_t)dr * (uint32_t)a.q_row * 2u + 16u * (uint32_t)(dp ^ ((r & 3) << 2));
   }
   auto issue_img = [&](const uint16_t* gsrc, int64_t row_stride, const uint32_t (&voff)[4], int row0, uint16_t* dst) {
-    const uint32_t d0 = (uint32_t)(uintptr_t)(lds_void_t)(dst + 8 * pw * D);
+    const uint32_t d0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_t)(dst + 8 * pw * D));
     if (row0 + BQ <= s.L) {
       const char* sb = reinterpret_cast<const char*>(gsrc + (int64_t)(row0 + 8 * pw) * row_stride);
       const int64_t step = 2 * row_stride * 2;

@@ -55,23 +55,29 @@ def _hstu_smoke(dev):
     from hstu import hstu_attn_varlen_func
     from oracle import hstu_oracle as ho
 
-    rng = np.random.default_rng(1)
-    H, d = 2, 64
-    lengths = np.array([37, 5, 130])
+    _hstu_case(dev, 64, np.array([37, 5, 130]), ho, hstu_attn_varlen_func)
+    # head dim 256 = the BASELINE configs' attention: the two-waves-per-SIMD kernels of round 4 (S-wave / O-wave forward,
+    # S-wave / K-wave dK pass, DMA-staged dV / dQ passes)
+    _hstu_case(dev, 256, np.array([200, 5, 333]), ho, hstu_attn_varlen_func)
+    print("smoke ok: hstu_attn_varlen_func forward/backward match the oracle (d = 64 and d = 256)")
+
+
+def _hstu_case(dev, d, lengths, ho, hstu_attn_varlen_func):
+    H = 2
+    N = int(lengths.max())
     off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
     T = int(off[-1])
     q, k, v = (torch.empty(T, H, d, device=dev).uniform_(-1, 1).bfloat16().requires_grad_() for _ in range(3))
     dout = torch.empty(T, H, d, device=dev).uniform_(0, 1).bfloat16()
     tg = np.array([3, 1, 7])
     cu = torch.from_numpy(off.astype(np.int32)).to(dev)
-    out = hstu_attn_varlen_func(q, k, v, cu, cu, None, None, 130, 130, 130, None,
+    out = hstu_attn_varlen_func(q, k, v, cu, cu, None, None, N, N, N, None,
                                 torch.from_numpy(tg.astype(np.int32)).to(dev), target_group_size=1, window_size=(-1, 0),
                                 alpha=1.0 / d ** 0.5)
     out.backward(dout)
     qn, kn, vn, dn = (x.detach().float().cpu().numpy() for x in (q, k, v, dout))
-    ref = ho.hstu_attn_fwd(qn, kn, vn, off, 1.0 / d ** 0.5, 130, True, tg, None, 1)
-    dq, dk, dv = ho.hstu_attn_bwd(dn, qn, kn, vn, off, 1.0 / d ** 0.5, 130, True, tg, None, 1)
+    ref = ho.hstu_attn_fwd(qn, kn, vn, off, 1.0 / d ** 0.5, N, True, tg, None, 1)
+    dq, dk, dv = ho.hstu_attn_bwd(dn, qn, kn, vn, off, 1.0 / d ** 0.5, N, True, tg, None, 1)
     for got, want, tol in ((out, ref, 6e-3), (q.grad, dq, 1.2e-2), (k.grad, dk, 1.2e-2), (v.grad, dv, 1.2e-2)):
         err = np.abs(got.detach().float().cpu().numpy() - want).max()
-        assert err <= tol * np.abs(want).max() + 1e-6, f"hstu smoke mismatch {err}"
-    print("smoke ok: hstu_attn_varlen_func forward/backward match the oracle")
+        assert err <= tol * np.abs(want).max() + 1e-6, f"hstu smoke mismatch {err} (d = {d})"
