@@ -518,6 +518,11 @@ int64_t mi355_hstu_attn_bwd_ds_bytes_capped(int64_t batch, int64_t num_heads, in
 /* total tokens of the NEXT mi355_hstu_attn_bwd call on this thread (its signature is the reference's hstu_varlen_bwd and
  * does not carry them): bounds the number of chunk passes; optional. */
 void mi355_hstu_attn_bwd_hint_tokens(int64_t total_tokens);
+/* rows of q of the NEXT mi355_hstu_attn_fwd / _fwd_kv / _fwd_window call on this thread (optional): batch x max_seqlen rows
+ * = a dense batch, which the head-dim-256 forward runs with two row blocks (the z-th heaviest and z-th lightest of a column)
+ * per workgroup.  The fp16 entry points have their own hint (suffix _f16). */
+void mi355_hstu_attn_fwd_hint_tokens(int64_t total_tokens);
+void mi355_hstu_attn_fwd_hint_tokens_f16(int64_t total_tokens);
 int mi355_hstu_attn_bwd(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
                         int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t do_row_stride,
                         int64_t q_head_stride, int64_t k_head_stride, int64_t v_head_stride,

@@ -1481,6 +1481,328 @@ __global__ void __launch_bounds__(512) hstu_fwd_pc_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The S-wave / O-wave forward over PAIRS of row blocks (round 4; the default at head dim 256): one workgroup takes the z-th
+// heaviest and the z-th lightest row block of a (sequence, head) column and runs them as ONE tile stream -- block A's key
+// tiles, then block B's -- through the same rings.  Under a causal mask every pair carries the same number of key tiles
+// (C3: 8 + 2 and 6 + 4 of a column's four blocks; 32 x 4096: 33 each), so the grid is balanced by construction and, at C3,
+// exactly one workgroup per CU; the second block's first K tile is prefetched under the first block's last tile, the O waves
+// store block A's rows while the S waves already work on block B's first tile, and the pipeline fills and drains once per
+// pair instead of once per block.  Same tiles, same MFMA order, same roundings as hstu_fwd_pc_kernel: bit-identical output.
+// ---------------------------------------------------------------------------------------------------
+template <int D, bool kWin>
+__global__ void __launch_bounds__(512) hstu_fwd_pair_kernel(AttnArgs a) {
+  static_assert(D == 256, "rows of 32 chunks");
+  constexpr int CPR = D / 8, RPI = 64 / CPR, ROWB = D, TENS = kBN * ROWB, NINS = kBN / RPI;
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [K 0 | K 1 | V 0 | V 1 | P 0 | P 1]
+  uint16_t* const Kring = smem;
+  uint16_t* const Vring = smem + 2 * TENS;
+  uint16_t* const Pring = smem + 4 * TENS;
+
+  const BlockSeq bs = seq_head_of_block(a);   // grid (H, B, ceil(blocks / 2)): z = the pair's rank inside its column
+  const int b = bs.b, h = bs.h;
+  SeqInfo s;
+  s.start = bs.start;
+  const int Lq = bs.end - s.start;
+  const int kstart = a.cu_seqlens_k ? a.cu_seqlens_k[b] : s.start;
+  s.L = a.cu_seqlens_k ? a.cu_seqlens_k[b + 1] - kstart : Lq;
+  const int dq = s.L - Lq;
+  const int nblk = (Lq + kBM - 1) / kBM;
+  if (2 * bs.z >= nblk || dq < 0) return;
+  const int rank0 = bs.z, rank1 = nblk - 1 - bs.z;
+  const bool two = rank1 > rank0;
+  s.has_ctx = a.num_contexts != nullptr;
+  s.has_tgt = a.num_targets != nullptr;
+  s.c = s.has_ctx ? a.num_contexts[b] : 0;
+  s.hlen = s.L - (s.has_tgt ? a.num_targets[b] : 0);
+  s.wl = kWin ? a.wl : -1; s.wr = kWin ? a.wr : -1;
+
+  const int lane = lane_id(), hi = lane >> 5, l31 = lane & 31;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int role = wv >> 2, pw = wv & 3;
+  // ---- one row block of the pair
+  struct Blk { int m0, qrow0, qloc, n_beg, w_beg, w_end, T; bool wave_live; RowMask rm; };
+  auto setup = [&](int rank) -> Blk {
+    Blk k;
+    k.m0 = row_block_of_rank(rank, nblk, a, b) * kBM;
+    k.qrow0 = k.m0 + 32 * pw;
+    k.qloc = k.qrow0 + l31;
+    k.wave_live = k.qrow0 < Lq;
+    const int last_row = dq + (k.m0 + kBM - 1 < Lq - 1 ? k.m0 + kBM - 1 : Lq - 1);
+    int n_end = s.L;
+    if (a.causal) {
+      n_end = last_row + 1;
+      if (s.has_ctx && dq + k.m0 < s.c && s.hlen > n_end) n_end = s.hlen;
+    }
+    if (kWin) n_end = band_key_end(a, last_row, n_end);
+    k.n_beg = kWin ? band_key_begin(a, dq + k.m0, kBN) : 0;
+    const int w_last = dq + (k.qrow0 + 31 < Lq - 1 ? k.qrow0 + 31 : Lq - 1);
+    k.w_end = s.L;
+    if (a.causal) {
+      k.w_end = w_last + 1;
+      if (s.has_ctx && dq + k.qrow0 < s.c && s.hlen > k.w_end) k.w_end = s.hlen;
+    }
+    if (kWin) k.w_end = band_key_end(a, w_last, k.w_end);
+    k.w_beg = kWin ? band_key_begin(a, dq + k.qrow0, kBN) : 0;
+    k.T = n_end > k.n_beg ? (n_end - k.n_beg + kBN - 1) / kBN : 0;
+    const int qi = dq + k.qloc;
+    k.rm = row_mask(qi < s.L ? qi : s.L - 1, s, a.causal, a.group);
+    return k;
+  };
+  const Blk B0 = setup(rank0);
+  Blk B1 = B0;
+  if (two) B1 = setup(rank1);
+  const int T0 = B0.T, T1 = two ? B1.T : 0, N = T0 + T1;     // items of the tile stream: block A's tiles, then block B's
+  auto item_n0 = [&](int i) { return i < T0 ? B0.n_beg + kBN * i : B1.n_beg + kBN * (i - T0); };
+
+  // ---- LDS-DMA (as hstu_fwd_pc_kernel; the O waves issue everything)
+  const uint16_t* kg = a.k + (int64_t)kstart * a.k_row + (int64_t)h * a.k_head;
+  const uint16_t* vg = a.v + (int64_t)kstart * a.v_row + (int64_t)h * a.v_head;
+  const int dma_r = lane / CPR, dma_p = lane % CPR;
+  constexpr int NO = NINS / 4;
+  const int j_first = NO * pw;
+  uint32_t kvoff[NO], vvoff[NO];
+#pragma unroll
+  for (int u = 0; u < NO; ++u) {
+    const int r = RPI * (j_first + u) + dma_r;
+    kvoff[u] = (uint32_t)dma_r * (uint32_t)a.k_row * 2u + 16u * (uint32_t)(dma_p ^ (r & 15));
+    vvoff[u] = (uint32_t)dma_r * (uint32_t)a.v_row * 2u + 16u * (uint32_t)(dma_p ^ ((r & 3) << 2));
+  }
+  auto dma16 = [&](const char* sbase, uint32_t voff, uint32_t lds_byte) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_byte), "s"(sbase) : "memory");
+  };
+  auto issue_dma = [&](const uint16_t* g, int64_t g_row, const uint32_t (&voff)[NO], uint16_t* ring, int item) {
+    const int n0 = item_n0(item);
+    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_t)(ring + (item & 1) * TENS + RPI * j_first * ROWB));
+    if (n0 + kBN <= s.L) {
+      const char* sb = reinterpret_cast<const char*>(g + (int64_t)(n0 + RPI * j_first) * g_row);
+      const int64_t step = (int64_t)RPI * g_row * 2;
+#pragma unroll
+      for (int u = 0; u < NO; ++u) dma16(sb + u * step, voff[u], dst + u * (RPI * ROWB * 2));
+    } else {
+      const uint32_t rowterm = (uint32_t)dma_r * (uint32_t)g_row * 2u;
+#pragma unroll
+      for (int u = 0; u < NO; ++u) {
+        const int row0 = n0 + RPI * (j_first + u);
+        const int rowc = row0 < s.L ? row0 : s.L - 1;
+        const uint32_t drop = row0 + 1 < s.L ? 0u : 0xffffffffu;
+        dma16(reinterpret_cast<const char*>(g + (int64_t)rowc * g_row), voff[u] - (rowterm & drop), dst + u * (RPI * ROWB * 2));
+      }
+    }
+  };
+  const float nal2e = -a.alpha * 1.44269504088896f, ais = a.alpha * a.inv_scale;
+  const int kx = l31 & 15;
+  const int il = lane & 15, g1 = (lane >> 4) & 1, vq = il >> 2;
+  const int v_row_off = (4 * hi + vq) * ROWB + 4 * (il & 1);
+  const int v_chunk_lo = 2 * g1 + ((il & 3) >> 1);
+  auto v_frag = [&](const uint16_t* Vb, int dt, int ks) -> bf16x8_t {
+    typedef short v4s_t __attribute__((ext_vector_type(4)));
+    typedef short v8s_t __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) v4s_t* lds_v4s_t;
+    const uint16_t* p0 = Vb + (16 * ks) * ROWB + v_row_off + 8 * ((4 * (dt ^ vq)) + v_chunk_lo);
+    const v4s_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(p0));
+    const v4s_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(p0 + 8 * ROWB));
+    const v8s_t r = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    return __builtin_bit_cast(bf16x8_t, r);
+  };
+
+  if (role == 0) {
+    // =========================== S waves: item `it` -> P ring slot it & 1 ===========================
+    bf16x8_t qf[D / 16];
+    auto load_q = [&](const Blk& k) {
+      const uint16_t* qp = a.q + (int64_t)(s.start + (k.qloc < Lq ? k.qloc : 0)) * a.q_row + (int64_t)h * a.q_head + 8 * hi;
+#pragma unroll
+      for (int sl = 0; sl < D / 16; ++sl) {
+        uint4 t = make_uint4(0, 0, 0, 0);
+        if (k.qloc < Lq) t = *reinterpret_cast<const uint4*>(qp + 16 * sl);
+        qf[sl] = *reinterpret_cast<bf16x8_t*>(&t);
+      }
+    };
+    // Two loops over ONE stream of iterations (block A's items, then block B's + the draining iteration): with a single loop
+    // and the block switch inside it hipcc carried Q / the O accumulator through phis and spilled them.
+    auto s_iter = [&](int it) {
+      __syncthreads();                     // (no vmcnt wait here: the S waves issue no DMA)
+      if (it >= N) return;
+      const bool second = it >= T0;
+      const int t_in = second ? it - T0 : it;
+      const int n_beg = second ? B1.n_beg : B0.n_beg, w_end = second ? B1.w_end : B0.w_end, w_beg = second ? B1.w_beg : B0.w_beg;
+      const int qrow0 = second ? B1.qrow0 : B0.qrow0;
+      const bool wave_live = second ? B1.wave_live : B0.wave_live;
+      const int n0 = n_beg + kBN * t_in;
+      if (!wave_live || n0 >= w_end || n0 < w_beg) return;
+      RowMask rm;
+      rm.jmax = second ? B1.rm.jmax : B0.rm.jmax; rm.jlo = second ? B1.rm.jlo : B0.rm.jlo; rm.hlen = second ? B1.rm.hlen : B0.rm.hlen;
+      const uint16_t* Ks = Kring + (it & 1) * TENS;
+      const bool full = a.causal && s.wl < 0 && (n0 + kBN - 1 <= dq + qrow0) && (!s.has_ctx || dq + qrow0 >= s.c) && (!s.has_tgt || n0 + kBN - 1 < s.hlen);
+      const int mode = full ? 0 : ((!s.has_ctx && !s.has_tgt && s.wl < 0) ? 1 : 2);
+      u32x4_t* pdst = reinterpret_cast<u32x4_t*>(Pring) + (((it & 1) * 4 + pw) * 4) * 64 + lane;
+      auto tile = [&](auto modec) {
+        constexpr int kMode = decltype(modec)::value;
+        constexpr int SLB = 4, NBAT = (D / 16) / SLB, NKB = HSTU_PC_KBUF;
+        f32x16_t acc_s[2];
+        const int th = rm.jmax - n0 - 4 * hi;
+        auto group = [&](auto nec, int t, int r0, uint32_t* out) {
+          constexpr int NE = decltype(nec)::value;
+          float x[NE], e[NE], y[NE];
+#pragma unroll
+          for (int i = 0; i < NE; ++i) x[i] = acc_s[t][r0 + i];
+#pragma unroll
+          for (int i = 0; i < NE; ++i) e[i] = x[i] * nal2e;
+#pragma unroll
+          for (int i = 0; i < NE; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]);
+#pragma unroll
+          for (int i = 0; i < NE; ++i) e[i] = 1.0f + e[i];
+#pragma unroll
+          for (int i = 0; i < NE; ++i) e[i] = __builtin_amdgcn_rcpf(e[i]);
+#pragma unroll
+          for (int i = 0; i < NE; ++i) y[i] = x[i] * ais * e[i];
+          if (kMode != 0) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+              const int rr = r0 + i, off = 32 * t + (rr & 3) + 8 * (rr >> 2);
+              const bool ok = kMode == 1 ? off <= th : key_ok(n0 + off + 4 * hi, rm);
+              y[i] = ok ? y[i] : 0.f;
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < NE; i += 2) out[i >> 1] = pack_bf16(y[i], y[i + 1]);
+        };
+        bf16x8_t kfr[NKB][SLB];
+        auto load_b = [&](int gb) {
+          const int t = gb / NBAT, bi = gb % NBAT;
+#pragma unroll
+          for (int u = 0; u < SLB; ++u) {
+            const int sl = SLB * bi + u;
+            const int ch = ((2 * sl) ^ (kx & 14)) + (hi ^ (kx & 1));
+            kfr[gb % NKB][u] = *reinterpret_cast<const bf16x8_t*>(Ks + (32 * t + l31) * ROWB + 8 * ch);
+          }
+        };
+        auto mfma_b = [&](int gb) {
+          const int t = gb / NBAT, bi = gb % NBAT;
+#pragma unroll
+          for (int u = 0; u < SLB; ++u) {
+            if (bi == 0 && u == 0) mfma_v0(acc_s[t], kfr[gb % NKB][u], qf[SLB * bi + u]);
+            else mfma_v(acc_s[t], kfr[gb % NKB][u], qf[SLB * bi + u]);
+          }
+        };
+#pragma unroll
+        for (int gb = 0; gb < NKB - 1; ++gb) load_b(gb);
+#pragma unroll
+        for (int gb = 0; gb < NBAT; ++gb) {
+          if (gb + NKB - 1 < 2 * NBAT) load_b(gb + NKB - 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_b(gb);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        uint32_t pk[8];
+#pragma unroll
+        for (int gb = NBAT; gb < 2 * NBAT; ++gb) {
+          const int bi = gb - NBAT;
+          if (gb + NKB - 1 < 2 * NBAT) load_b(gb + NKB - 1);
+          mfma_b(gb);
+          group(std::integral_constant<int, 4>{}, 0, 4 * bi, pk + 2 * bi);
+          if (bi == 1) pdst[0 * 64] = u32x4_t{pk[0], pk[1], pk[2], pk[3]};
+          if (bi == 3) pdst[1 * 64] = u32x4_t{pk[4], pk[5], pk[6], pk[7]};
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        group(std::integral_constant<int, 8>{}, 1, 0, pk);
+        pdst[2 * 64] = u32x4_t{pk[0], pk[1], pk[2], pk[3]};
+        group(std::integral_constant<int, 8>{}, 1, 8, pk + 4);
+        pdst[3 * 64] = u32x4_t{pk[4], pk[5], pk[6], pk[7]};
+      };
+      if (mode == 0) tile(std::integral_constant<int, 0>{});
+      else if (mode == 1) tile(std::integral_constant<int, 1>{});
+      else tile(std::integral_constant<int, 2>{});
+    };
+    // (block B's queries are loaded at the switch, while the O waves finish block A's last tile and store its rows.  Fetched
+    // at kernel entry next to block A's -- hipcc parks them in scratch -- the prologue burst of all CUs doubles: C3 39.3 ->
+    // 44.2 us, 32 x 1024 101.7 -> 115.3 us.)
+    load_q(B0);
+    for (int it = 0; it < T0; ++it) s_iter(it);
+    if (two) load_q(B1);
+    for (int it = T0; it <= N; ++it) s_iter(it);
+    return;
+  }
+  // =========================== O waves: item `it - 1`; DMA of K item it + 1 and V item it ===========================
+  f32x16_t acc_o[D / 32];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_o[dt][r] = 0.f;
+  };
+  auto store_rows = [&](int qloc) {
+    fence_a(acc_o);
+    if (qloc < Lq) {
+      uint16_t* op = a.out + (int64_t)(s.start + qloc) * a.o_row + (int64_t)h * a.o_head;
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          uint2 o;
+          o.x = pack_bf16(acc_o[dt][4 * g4 + 0], acc_o[dt][4 * g4 + 1]);
+          o.y = pack_bf16(acc_o[dt][4 * g4 + 2], acc_o[dt][4 * g4 + 3]);
+          *reinterpret_cast<uint2*>(op + 32 * dt + 8 * g4 + 4 * hi) = o;
+        }
+    }
+  };
+  zero_acc();
+  if (N > 0) issue_dma(kg, a.k_row, kvoff, Kring, 0);
+  auto o_iter = [&](int it) {
+    pin_agpr(acc_o);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces (K item it, V item it - 1) have landed ...
+    __syncthreads();                                    // ... everyone's have, P[it - 1] is written, the other buffers are free
+    if (it + 1 < N) issue_dma(kg, a.k_row, kvoff, Kring, it + 1);
+    if (it < N) issue_dma(vg, a.v_row, vvoff, Vring, it);
+    pin_agpr(acc_o);
+    const int tl = it - 1;
+    if (tl >= 0) {
+      const bool second = tl >= T0;
+      const int t_in = second ? tl - T0 : tl;
+      const int n0 = (second ? B1.n_beg : B0.n_beg) + kBN * t_in;
+      const bool live = (second ? B1.wave_live : B0.wave_live) && n0 < (second ? B1.w_end : B0.w_end) && n0 >= (second ? B1.w_beg : B0.w_beg);
+      if (live) {
+        const uint16_t* Vt = Vring + (tl & 1) * TENS;
+        const u32x4_t* psrc = reinterpret_cast<const u32x4_t*>(Pring) + (((tl & 1) * 4 + pw) * 4) * 64 + lane;
+        bf16x8_t pf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) pf[ks] = __builtin_bit_cast(bf16x8_t, psrc[ks * 64]);
+        constexpr int NDT = D / 32, DB = 4, NVB = HSTU_PC_VBUF;
+        constexpr int NBAT2 = 4 * (NDT / DB);
+        bf16x8_t vfr[NVB][DB];
+        auto load_v = [&](int bi) {
+          const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
+#pragma unroll
+          for (int u = 0; u < DB; ++u) vfr[bi % NVB][u] = v_frag(Vt, dt0 + u, ks);
+        };
+#pragma unroll
+        for (int bi = 0; bi < NVB - 1; ++bi) load_v(bi);
+        pin_agpr(acc_o);
+#pragma unroll
+        for (int bi = 0; bi < NBAT2; ++bi) {
+          const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
+          if (bi + NVB - 1 < NBAT2) load_v(bi + NVB - 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < DB; ++u) mfma_a(acc_o[dt0 + u], vfr[bi % NVB][u], pf[ks]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  };
+  // iterations 0 .. T0 finish block A (its last tile is item T0 - 1, computed in iteration T0); T0 + 1 .. N are block B's
+  for (int it = 0; it <= (two ? T0 : N); ++it) o_iter(it);
+  if (two) {
+    store_rows(B0.qloc);     // block A's rows leave while the S waves already work on block B's first tile
+    zero_acc();
+    for (int it = T0 + 1; it <= N; ++it) o_iter(it);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no DMA may be in flight into LDS when the block retires)
+  store_rows(two ? B1.qloc : B0.qloc);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Backward (reference: hstu_varlen_bwd -> hstu_bwd.h, core maths :687-729).  With s = alpha <q,k>:
 //   P  = M SiLU(s) / N            dV = P^T dO
 //   dP = dO V^T                   dS = M dP SiLU'(s) alpha / N       dQ = dS K      dK = dS^T Q
@@ -3232,7 +3554,7 @@ static int launch_fwd_dma(const AttnArgs& a, int B, int max_seqlen, hipStream_t 
 
 // the two-waves-per-SIMD forward (default at head dim 256; MI355_HSTU_PC=0 = the one-stream LDS-DMA kernel)
 template <int D>
-static int launch_fwd_pc(const AttnArgs& a, int B, int max_seqlen, hipStream_t stream) {
+static int launch_fwd_pc(const AttnArgs& a, int B, int max_seqlen, hipStream_t stream, bool dense_batch) {
   const size_t smem = (size_t)(4 * kBN * D + 2 * 4 * 4 * 64 * 8) * sizeof(uint16_t);   // K ring + V ring + P ring = 160 KB
   static bool attr_set = false;
   if (!attr_set) {
@@ -3241,6 +3563,26 @@ static int launch_fwd_pc(const AttnArgs& a, int B, int max_seqlen, hipStream_t s
         hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_pc_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem) != hipSuccess) return MI355_ELAUNCH;
     attr_set = true;
+  }
+  // row blocks in (heavy, light) pairs per workgroup: dense batches only (every sequence max_seqlen rows: the caller said so with
+  // mi355_hstu_attn_fwd_hint_tokens).  On a jagged batch the pairs of a long column are as heavy as before but half as many
+  // workgroups share the machine and the tail grows (C4 shape 340 -> 355 us); MI355_HSTU_PAIR = 0 never, 2 always (A/B).
+  static const int pair = getenv("MI355_HSTU_PAIR") ? atoi(getenv("MI355_HSTU_PAIR")) : 1;
+  if (pair == 2 || (pair == 1 && dense_batch)) {
+    static bool attr_pair = false;
+    if (!attr_pair) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_pair_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_pair_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem) != hipSuccess) return MI355_ELAUNCH;
+      attr_pair = true;
+    }
+    const int nblk = (max_seqlen + kBM - 1) / kBM;
+    dim3 grid(a.H, B, (nblk + 1) / 2);
+    if (a.wl >= 0 || a.wr >= 0) hipLaunchKernelGGL((hstu_fwd_pair_kernel<D, true>), grid, dim3(512), smem, stream, a);
+    else hipLaunchKernelGGL((hstu_fwd_pair_kernel<D, false>), grid, dim3(512), smem, stream, a);
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
   }
   dim3 grid(a.H, B, (max_seqlen + kBM - 1) / kBM);
   if (a.wl >= 0 || a.wr >= 0) hipLaunchKernelGGL((hstu_fwd_pc_kernel<D, true>), grid, dim3(512), smem, stream, a);
@@ -3280,6 +3622,9 @@ using namespace mi355;
 
 // local window of the call in flight on this thread (set by the *_window entry points around the plain ones)
 static thread_local int tl_wl = -1, tl_wr = -1;
+// rows of q of the NEXT forward call on this thread (mi355_hstu_attn_fwd_hint_tokens; 0 = unknown): B x max_seqlen rows = a dense
+// batch, which takes the paired-row-block forward
+static thread_local int64_t tl_fwd_tokens = 0;
 // attention bias of the call in flight on this thread (set by the *_rab entry points)
 struct RabCall { const uint16_t* rab = nullptr; int64_t rb = 0, rh = 0, rr = 0; uint16_t* drab = nullptr; int64_t db = 0, dh = 0, dr = 0; };
 static thread_local RabCall tl_rab;
@@ -3370,7 +3715,10 @@ int HSTU_FN(mi355_hstu_attn_fwd_kv)(const void* q, const void* k, const void* v,
   a.last_page_lens = last_page_lens; a.page_size = (int)page_size;
   static const int use_dma = getenv("MI355_HSTU_DMA") ? atoi(getenv("MI355_HSTU_DMA")) : 1;   // default since round 3: +4..9 % on every d = 256 shape measured
   static const int use_pc = getenv("MI355_HSTU_PC") ? atoi(getenv("MI355_HSTU_PC")) : 1;   // round 4: two waves per SIMD, S waves + O waves
-  if (use_pc && head_dim == 256 && !a.kv_cache && !a.rab) return launch_fwd_pc<256>(a, (int)batch, (int)max_seqlen_q, stream);
+  const int64_t fwd_tokens = tl_fwd_tokens;
+  tl_fwd_tokens = 0;
+  if (use_pc && head_dim == 256 && !a.kv_cache && !a.rab)
+    return launch_fwd_pc<256>(a, (int)batch, (int)max_seqlen_q, stream, !cu_seqlens_k && fwd_tokens == batch * max_seqlen_q);
   if (use_dma && head_dim == 256 && !a.kv_cache && !a.rab) return launch_fwd_dma<256>(a, (int)batch, (int)max_seqlen_q, stream);
   switch (head_dim) {
     case 32: return launch_fwd<32>(a, (int)batch, (int)max_seqlen_q, stream);
@@ -3379,6 +3727,10 @@ int HSTU_FN(mi355_hstu_attn_fwd_kv)(const void* q, const void* k, const void* v,
     default: return launch_fwd<256>(a, (int)batch, (int)max_seqlen_q, stream);
   }
 }
+
+// rows of q of the NEXT forward call on this thread (the reference's forward signature does not carry them): a batch of
+// batch x max_seqlen rows is dense and takes the paired-row-block kernel.  Optional; without it the unpaired kernel runs.
+void HSTU_FN(mi355_hstu_attn_fwd_hint_tokens)(int64_t total_tokens) { tl_fwd_tokens = total_tokens; }
 
 #if !HSTU_F16   // (type-agnostic: once, in the bf16 translation unit)
 // append_kvcache (examples/commons/ops/cuda_ops/csrc/paged_kvcache_ops_kernel.cu:106-140): token i of the new history

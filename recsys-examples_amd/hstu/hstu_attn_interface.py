@@ -28,6 +28,7 @@ N.register_signatures({
     "mi355_hstu_attn_bwd_ds_bytes": [c_i64, c_i64, c_i64, c_i64],
     "mi355_hstu_attn_bwd_ds_bytes_capped": [c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int],
     "mi355_hstu_attn_bwd_hint_tokens": [c_i64],
+    "mi355_hstu_attn_fwd_hint_tokens": [c_i64],
     "mi355_hstu_attn_fwd_rab": [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_i64,
                                 c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_f, c_p, c_i64, c_i64, c_i64, c_p],
     "mi355_hstu_attn_bwd_rab": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p,
@@ -42,9 +43,10 @@ N.register_signatures({
     "mi355_append_kvcache": [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p,
                              c_i64, c_i64, c_p],
 }, {"mi355_hstu_attn_bwd_workspace_bytes": c_i64, "mi355_hstu_attn_bwd_ds_bytes": c_i64,
-    "mi355_hstu_attn_bwd_ds_bytes_capped": c_i64, "mi355_hstu_attn_bwd_hint_tokens": None})
+    "mi355_hstu_attn_bwd_ds_bytes_capped": c_i64, "mi355_hstu_attn_bwd_hint_tokens": None,
+    "mi355_hstu_attn_fwd_hint_tokens": None, "mi355_hstu_attn_fwd_hint_tokens_f16": None})
 # the fp16-operand twins of the seven type-specific entry points (same argument lists)
-_TYPED = ("mi355_hstu_attn_fwd", "mi355_hstu_attn_fwd_kv", "mi355_hstu_attn_bwd", "mi355_hstu_attn_fwd_window",
+_TYPED = ("mi355_hstu_attn_fwd_hint_tokens", "mi355_hstu_attn_fwd", "mi355_hstu_attn_fwd_kv", "mi355_hstu_attn_bwd", "mi355_hstu_attn_fwd_window",
           "mi355_hstu_attn_bwd_window", "mi355_hstu_attn_fwd_rab", "mi355_hstu_attn_bwd_rab")
 N.register_signatures({n + "_f16": N.signature_of(n) for n in _TYPED})
 
@@ -99,6 +101,7 @@ def hstu_varlen_fwd(q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_context
     T, H, D = q.shape
     out = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
     B = cu_seqlens.numel() - 1
+    _fn("mi355_hstu_attn_fwd_hint_tokens", q)(int(q.shape[0]))   # (dense batches take the paired-row-block kernel)
     check(_fn("mi355_hstu_attn_fwd", q)(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
                                     q.stride(1), k.stride(1), v.stride(1), out.stride(1), ptr(cu_seqlens), B, H, D,
                                     int(max_seqlen), ptr(num_contexts), ptr(num_targets), int(target_group_size), int(causal),
@@ -123,6 +126,7 @@ def hstu_varlen_fwd_kv(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, scalin
             if t is None or t.dtype != torch.int32:
                 raise RuntimeError(f"{name} must be an int32 tensor")
         page_size = kv_cache.size(2)
+    _fn("mi355_hstu_attn_fwd_hint_tokens", q)(int(q.shape[0]))   # (dense batches take the paired-row-block kernel)
     check(_fn("mi355_hstu_attn_fwd_kv", q)(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
                                        q.stride(1), k.stride(1), v.stride(1), out.stride(1), ptr(cu_seqlens_q),
                                        ptr(cu_seqlens_k), B, H, D, int(max_seqlen_q), ptr(num_contexts), ptr(num_targets),
@@ -204,6 +208,7 @@ def hstu_varlen_fwd_window(q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, wl, 
     T, H, D = q.shape
     out = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
     B = cu_seqlens.numel() - 1
+    _fn("mi355_hstu_attn_fwd_hint_tokens", q)(int(q.shape[0]))   # (dense batches take the paired-row-block kernel)
     check(_fn("mi355_hstu_attn_fwd_window", q)(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0),
                                            out.stride(0), q.stride(1), k.stride(1), v.stride(1), out.stride(1),
                                            ptr(cu_seqlens), B, H, D, int(max_seqlen), int(wl), int(wr), c_f(alpha),
