@@ -2823,6 +2823,12 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_v_p_kernel(BwdAttnArg
 // clock and CU, what L2 + HBM deliver), no staging registers, no commit phase, and a second wave per SIMD to cover the P / dS
 // loads and the fragment reads.
 // ---------------------------------------------------------------------------------------------------
+#ifndef HSTU_KVPC_PROBE
+#define HSTU_KVPC_PROBE 0   // timing probe (wrong results): 1 = the S waves' GEMMs reuse their first fragment batches (no LDS reads)
+#endif
+#ifndef HSTU_KVPC_KSLEEP
+#define HSTU_KVPC_KSLEEP 0   // K waves of the dK pass: s_sleep units (64 cycles each) between the DMA issue and the dK GEMM
+#endif
 #ifndef HSTU_KVPC_FBUF
 #define HSTU_KVPC_FBUF 3   // S waves of the dK pass: Q / dO fragment batches in registers (FBUF - 1 in flight ahead of the MFMAs)
 #endif
@@ -3245,7 +3251,7 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
         for (int bi = 0; bi < NFB - 1; ++bi) load_b(bi);
 #pragma unroll
         for (int bi = 0; bi < NBAT; ++bi) {
-          if (bi + NFB - 1 < NBAT) load_b(bi + NFB - 1);
+          if (bi + NFB - 1 < NBAT && !(HSTU_KVPC_PROBE & 1)) load_b(bi + NFB - 1);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int u = 0; u < SLB; ++u) {
@@ -3357,6 +3363,10 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
     TICK(t3);
     TACC(2, t2, t3);
     if (!had || !wave_live) return;
+    // The S waves open a step with 32 MFMAs and close it with ~250 VALU instructions; the K waves' 16 MFMAs belong under the
+    // second half.  Issued straight behind the DMA they fall into the S waves' GEMM (both streams then take turns on the
+    // SIMD's matrix pipe at ~64 cycles per MFMA and the pipe idles through the elementwise phase): park first.
+    if (HSTU_KVPC_KSLEEP) __builtin_amdgcn_s_sleep(HSTU_KVPC_KSLEEP);
     // dK^T[256 x 32 keys] += Q^T[256 x 32 q] dS[32 q x 32 keys] of the PREVIOUS step (rings slot PAR ^ 1)
     const u32x4_t* hp = reinterpret_cast<const u32x4_t*>(Hs) + (((PAR ^ 1) * 4 + pw) * 2) * 64 + lane;
     bf16x8_t sf[2];

@@ -25,6 +25,7 @@ if a.dma:
     os.environ["MI355_HSTU_PC"] = "0"
 if a.pc:
     os.environ["MI355_HSTU_PC"] = "1"
+    os.environ["MI355_HSTU_PAIR"] = "0"   # the stamps live in the unpaired kernel (hstu_fwd_pc_kernel)
 elif not a.bwd:
     os.environ.setdefault("MI355_HSTU_PC", "0")
 dev = torch.device("cuda")
