@@ -1803,6 +1803,423 @@ __global__ void __launch_bounds__(512) hstu_fwd_pair_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The S-wave / O-wave forward with TWO MFMAs per LDS fragment (round 4; the default at head dim 256).
+// tools/ubench_mfma.hip: the matrix pipe issues a 32x32x16 MFMA every 32 clocks whatever the partner wave does -- but in
+// hstu_fwd_pc_kernel / hstu_fwd_pair_kernel every MFMA consumes a fresh 1 KB fragment from LDS (each wave owns 32 query rows),
+// 4 SIMDs x 1 KB / 32 clk = the CU's whole 128 B/clk of LDS bandwidth before the DMA writes and the P hand-off: 352 KB per
+// 64-key tile, ~4 000 clocks per tile measured = 88 B/clk.  They are LDS-bound; that is the "45-52 clocks per MFMA" of their stamps.
+// Here a wave owns 64 query rows, so that every K and every V^T fragment read feeds two MFMAs:
+//   S wave (half, sub):  query rows 64 half .. + 63 (Q fragments: 128 registers), keys 32 sub .. + 31 of the tile:
+//                        16 K fragment reads (16 KB), 32 MFMAs, SiLU of 32 keys x 64 rows, P^T to the P ring.
+//   O wave (half, sub):  the same 64 rows, output columns 128 sub .. + 127 (accumulator: 128 registers): reads the half's P^T
+//                        (8 KB) and 16 V^T fragments (16 KB), 32 MFMAs; issues the tile's LDS-DMA as before.
+// LDS traffic per tile: K 64 + V 64 + P 16 written / 32 read + DMA 64 = 240 KB (352 before).  Rings, swizzles, the one barrier
+// per tile, the lag of one tile between the roles and the optional (heavy, light) pairing of row blocks (kPair) are those of
+// the two kernels above; same MFMA order per output element, same roundings: bit-identical output.
+// ---------------------------------------------------------------------------------------------------
+#ifndef HSTU_Q2_KBUF
+#define HSTU_Q2_KBUF 3   // S waves: K fragment batches (2 slices = 4 MFMAs) in registers, KBUF - 1 in flight
+#endif
+#ifndef HSTU_Q2_PK
+#define HSTU_Q2_PK 0   // S waves: SiLU's plain VALU work as packed fp32 pairs
+#endif
+#ifndef HSTU_Q2_VBUF
+#define HSTU_Q2_VBUF 3   // O waves: V^T fragment batches (2 fragments = 4 MFMAs) likewise
+#endif
+template <int D, bool kWin, bool kPair>
+__global__ void __launch_bounds__(512) hstu_fwd_q2_kernel(AttnArgs a) {
+  static_assert(D == 256, "rows of 32 chunks");
+  constexpr int CPR = D / 8, RPI = 64 / CPR, ROWB = D, TENS = kBN * ROWB, NINS = kBN / RPI;
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [K 0 | K 1 | V 0 | V 1 | P 0 | P 1]
+  uint16_t* const Kring = smem;
+  uint16_t* const Vring = smem + 2 * TENS;
+  u32x4_t* const Pring = reinterpret_cast<u32x4_t*>(smem + 4 * TENS);   // [2 slots][2 halves][2 q tiles][4 key slices][64 lanes] x 16 B
+
+  const BlockSeq bs = seq_head_of_block(a);   // grid (H, B, blocks) or, kPair, (H, B, ceil(blocks / 2))
+  const int b = bs.b, h = bs.h;
+  SeqInfo s;
+  s.start = bs.start;
+  const int Lq = bs.end - s.start;
+  const int kstart = a.cu_seqlens_k ? a.cu_seqlens_k[b] : s.start;
+  s.L = a.cu_seqlens_k ? a.cu_seqlens_k[b + 1] - kstart : Lq;
+  const int dq = s.L - Lq;
+  const int nblk = (Lq + kBM - 1) / kBM;
+  if ((kPair ? 2 * bs.z : bs.z) >= nblk || dq < 0) return;
+  const int rank0 = bs.z, rank1 = kPair ? nblk - 1 - bs.z : bs.z;
+  const bool two = kPair && rank1 > rank0;
+  s.has_ctx = a.num_contexts != nullptr;
+  s.has_tgt = a.num_targets != nullptr;
+  s.c = s.has_ctx ? a.num_contexts[b] : 0;
+  s.hlen = s.L - (s.has_tgt ? a.num_targets[b] : 0);
+  s.wl = kWin ? a.wl : -1; s.wr = kWin ? a.wr : -1;
+
+  const int lane = lane_id(), hi = lane >> 5, l31 = lane & 31;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int role = wv >> 2, pw = wv & 3, half = pw >> 1, sub = pw & 1;
+  // ---- one row block of the stream, seen from this wave's 64-row half
+  // t_lo .. t_hi: the tiles that reach the half's rows; S waves: tiles below tf need no mask (a prefix of the stream under every
+  // mask rule), tile t_dead has this wave's 32 keys past every row's reach (its P is zero, the O waves read the whole tile)
+  struct Blk { int m0, hrow0, n_beg, T, t_lo, t_hi, tf, t_dead; };
+  auto setup = [&](int rank) -> Blk {
+    Blk k;
+    k.m0 = row_block_of_rank(rank, nblk, a, b) * kBM;
+    k.hrow0 = k.m0 + 64 * half;
+    const bool half_live = k.hrow0 < Lq;
+    const int last_row = dq + (k.m0 + kBM - 1 < Lq - 1 ? k.m0 + kBM - 1 : Lq - 1);
+    int n_end = s.L;
+    if (a.causal) {
+      n_end = last_row + 1;
+      if (s.has_ctx && dq + k.m0 < s.c && s.hlen > n_end) n_end = s.hlen;
+    }
+    if (kWin) n_end = band_key_end(a, last_row, n_end);
+    k.n_beg = kWin ? band_key_begin(a, dq + k.m0, kBN) : 0;
+    const int h_last = dq + (k.hrow0 + 63 < Lq - 1 ? k.hrow0 + 63 : Lq - 1);
+    int h_end = s.L;
+    if (a.causal) {
+      h_end = h_last + 1;
+      if (s.has_ctx && dq + k.hrow0 < s.c && s.hlen > h_end) h_end = s.hlen;
+    }
+    if (kWin) h_end = band_key_end(a, h_last, h_end);
+    const int h_beg = kWin ? band_key_begin(a, dq + k.hrow0, kBN) : 0;     // (a multiple of the tile, >= n_beg)
+    k.T = n_end > k.n_beg ? (n_end - k.n_beg + kBN - 1) / kBN : 0;
+    k.t_lo = (h_beg - k.n_beg) / kBN;
+    k.t_hi = h_end > k.n_beg ? (h_end - k.n_beg + kBN - 1) / kBN : 0;
+    if (k.t_hi > k.T) k.t_hi = k.T;
+    if (!half_live || k.t_hi < k.t_lo) k.t_hi = k.t_lo;
+    // mode 0 (no mask): causal -- no window, the half holds no contextual row, the wave's last key <= the half's first row and
+    // inside the history; otherwise -- no mask rule at all and the wave's last key inside the sequence
+    const bool fc = a.causal ? (s.wl < 0 && (!s.has_ctx || dq + k.hrow0 >= s.c)) : (!s.has_ctx && !s.has_tgt && s.wl < 0 && s.wr < 0);
+    int lim = a.causal ? dq + k.hrow0 : s.L - 1;
+    if (a.causal && s.has_tgt && s.hlen - 1 < lim) lim = s.hlen - 1;
+    const int num = lim - 31 - 32 * sub - k.n_beg;
+    k.tf = (fc && num >= 0) ? num / kBN + 1 : 0;
+    k.t_dead = (sub == 1 && k.t_hi > k.t_lo && k.n_beg + kBN * (k.t_hi - 1) + 32 >= h_end) ? k.t_hi - 1 : -1;
+    return k;
+  };
+  const Blk B0 = setup(rank0);
+  Blk B1 = B0;
+  if (two) B1 = setup(rank1);
+  const int T0 = B0.T, T1 = two ? B1.T : 0, N = T0 + T1;     // items of the tile stream: block A's tiles, then block B's
+  auto item_n0 = [&](int i) { return i < T0 ? B0.n_beg + kBN * i : B1.n_beg + kBN * (i - T0); };
+#if HSTU_TIMING
+  unsigned tsum[7] = {0, 0, 0, 0, 0, 0, 0};   // O: wait for own DMA | barrier | O: DMA issue | - | S: GEMM 1 | S: SiLU + hand-off, O: GEMM 2 | tiles
+  const unsigned t_start = tick();
+  auto t_dump = [&]() {
+    const unsigned t_end = tick();
+    if (lane == 0) {
+      const int blk = ((int)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      unsigned long long* d = g_hstu_dbg + ((size_t)(blk * 8 + wv) % 65536) * 8;
+      for (int i = 0; i < 7; ++i) d[i] = tsum[i];
+      d[6] |= (unsigned long long)role << 32;
+      d[7] = t_end - t_start;
+    }
+  };
+#endif
+
+  if (role == 0) {
+    // =========================== S waves: item `it` -> P ring slot it & 1 ===========================
+    bf16x8_t qf[2][D / 16];
+    RowMask rm[2];
+    auto load_q = [&](const Blk& k) {
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const int qloc = k.hrow0 + 32 * qt + l31;
+        const uint16_t* qp = a.q + (int64_t)(s.start + (qloc < Lq ? qloc : 0)) * a.q_row + (int64_t)h * a.q_head + 8 * hi;
+#pragma unroll
+        for (int sl = 0; sl < D / 16; ++sl) {
+          uint4 t = make_uint4(0, 0, 0, 0);
+          if (qloc < Lq) t = *reinterpret_cast<const uint4*>(qp + 16 * sl);
+          qf[qt][sl] = *reinterpret_cast<bf16x8_t*>(&t);
+        }
+        const int qi = dq + qloc;
+        rm[qt] = row_mask(qi < s.L ? qi : s.L - 1, s, a.causal, a.group);
+      }
+    };
+    const float nal2e = -a.alpha * 1.44269504088896f, ais = a.alpha * a.inv_scale;
+    const int kx = l31 & 15;
+#if HSTU_TIMING
+    unsigned t_prev = 0;
+#endif
+    const int m12 = (!s.has_ctx && !s.has_tgt && s.wl < 0) ? 1 : 2;   // the masked tiles' rule: key <= jmax only, or the general one
+    auto s_iter = [&](int it, const Blk& k, int t_in) {    // t_in < 0: the draining iteration (barrier only)
+      TICK(t0);
+#if HSTU_TIMING
+      if (t_prev) TACC(3, t_prev, t0);
+      t_prev = 0;
+#endif
+      __syncthreads();                     // (no vmcnt wait here: the S waves issue no DMA)
+      TICK(t1);
+      TACC(1, t0, t1);
+      if (t_in < k.t_lo || t_in >= k.t_hi) return;
+      u32x4_t* pdst = Pring + ((((it & 1) * 2 + half) * 2) * 4 + 2 * sub) * 64 + lane;   // q tile qt: + 256 qt, second key slice: + 64
+      if (t_in == k.t_dead) {
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+        pdst[0] = z; pdst[64] = z; pdst[256] = z; pdst[320] = z;
+        return;
+      }
+      const int k0 = k.n_beg + kBN * t_in + 32 * sub;        // this wave's 32 keys
+      const uint16_t* Ks = Kring + (it & 1) * TENS + (32 * sub + l31) * ROWB;
+      auto tile = [&](auto modec) {
+        constexpr int kMode = decltype(modec)::value;
+        constexpr int SLB = 2, NBAT = (D / 16) / SLB, NKB = HSTU_Q2_KBUF;
+        TICK(t5);
+        TACC(0, t1, t5);
+        f32x16_t acc_s[2];
+        bf16x8_t kfr[NKB][SLB];
+        auto load_b = [&](int bi) {
+#pragma unroll
+          for (int u = 0; u < SLB; ++u) {
+            const int sl = SLB * bi + u;
+            const int ch = ((2 * sl) ^ (kx & 14)) + (hi ^ (kx & 1));
+            kfr[bi % NKB][u] = *reinterpret_cast<const bf16x8_t*>(Ks + 8 * ch);
+          }
+        };
+#pragma unroll
+        for (int bi = 0; bi < NKB - 1; ++bi) load_b(bi);
+#pragma unroll
+        for (int bi = 0; bi < NBAT; ++bi) {
+          if (bi + NKB - 1 < NBAT) load_b(bi + NKB - 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < SLB; ++u)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+              if (bi == 0 && u == 0) mfma_v0(acc_s[qt], kfr[bi % NKB][u], qf[qt][SLB * bi + u]);
+              else mfma_v(acc_s[qt], kfr[bi % NKB][u], qf[qt][SLB * bi + u]);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        TICK(t6);
+        TACC(4, t5, t6);
+        // SiLU, mask, 1 / N, pack: elements r0 .. r0 + 7 of q tile qt -> one key slice (4 packed words), stage by stage
+        auto group = [&](int qt, int r0, uint32_t* out) {
+          constexpr int NE = 8;
+          float y[NE];
+#if HSTU_Q2_PK
+          {   // the plain multiplies and the add as packed fp32 pairs (v_pk_mul_f32 / v_pk_add_f32): same operations, same roundings
+            f32x2_t x2[NE / 2], e2[NE / 2];
+#pragma unroll
+            for (int i = 0; i < NE / 2; ++i) x2[i] = f32x2_t{acc_s[qt][r0 + 2 * i], acc_s[qt][r0 + 2 * i + 1]};
+#pragma unroll
+            for (int i = 0; i < NE / 2; ++i) e2[i] = x2[i] * nal2e;
+#pragma unroll
+            for (int i = 0; i < NE / 2; ++i) e2[i] = f32x2_t{__builtin_amdgcn_exp2f(e2[i].x), __builtin_amdgcn_exp2f(e2[i].y)};
+#pragma unroll
+            for (int i = 0; i < NE / 2; ++i) e2[i] = e2[i] + 1.0f;
+#pragma unroll
+            for (int i = 0; i < NE / 2; ++i) e2[i] = f32x2_t{__builtin_amdgcn_rcpf(e2[i].x), __builtin_amdgcn_rcpf(e2[i].y)};
+#pragma unroll
+            for (int i = 0; i < NE / 2; ++i) { const f32x2_t t = x2[i] * ais * e2[i]; y[2 * i] = t.x; y[2 * i + 1] = t.y; }
+          }
+#else
+          float x[NE], e[NE];
+#pragma unroll
+          for (int i = 0; i < NE; ++i) x[i] = acc_s[qt][r0 + i];
+#pragma unroll
+          for (int i = 0; i < NE; ++i) e[i] = x[i] * nal2e;
+#pragma unroll
+          for (int i = 0; i < NE; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]);
+#pragma unroll
+          for (int i = 0; i < NE; ++i) e[i] = 1.0f + e[i];
+#pragma unroll
+          for (int i = 0; i < NE; ++i) e[i] = __builtin_amdgcn_rcpf(e[i]);
+#pragma unroll
+          for (int i = 0; i < NE; ++i) y[i] = x[i] * ais * e[i];
+#endif
+          if (kMode != 0) {
+            const int th = rm[qt].jmax - k0 - 4 * hi;     // kMode 1: element rr is visible iff (rr & 3) + 8 (rr >> 2) <= th
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+              const int rr = r0 + i, off = (rr & 3) + 8 * (rr >> 2);
+              const bool ok = kMode == 1 ? off <= th : key_ok(k0 + off + 4 * hi, rm[qt]);
+              y[i] = ok ? y[i] : 0.f;
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < NE; i += 2) out[i >> 1] = pack_bf16(y[i], y[i + 1]);
+        };
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            uint32_t pk[4];
+            group(qt, 8 * hf, pk);
+            pdst[256 * qt + 64 * hf] = u32x4_t{pk[0], pk[1], pk[2], pk[3]};
+          }
+        TICK(t7);
+        TACC(5, t6, t7);
+#if HSTU_TIMING
+        tsum[6] += 1;
+        t_prev = t7;
+#endif
+      };
+      if (t_in < k.tf) tile(std::integral_constant<int, 0>{});
+      else if (m12 == 1) tile(std::integral_constant<int, 1>{});
+      else tile(std::integral_constant<int, 2>{});
+    };
+    // Two loops over ONE stream of iterations (as hstu_fwd_pair_kernel): block B's queries are loaded at the switch
+    load_q(B0);
+    for (int it = 0; it < T0; ++it) s_iter(it, B0, it);
+    if (two) {
+      load_q(B1);
+      for (int it = T0; it < N; ++it) s_iter(it, B1, it - T0);
+    }
+    s_iter(N, B0, -1);
+#if HSTU_TIMING
+    t_dump();
+#endif
+    return;
+  }
+  // =========================== O waves: item `it - 1`; DMA of K item it + 1 and V item it ===========================
+  // (the DMA's base address is an "s" operand of the inline asm: spell out that these offsets are wave-uniform)
+  auto uni64 = [](int64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi32 << 32) | lo);
+  };
+  const uint16_t* kg = a.k + uni64((int64_t)kstart * a.k_row + (int64_t)h * a.k_head);
+  const uint16_t* vg = a.v + uni64((int64_t)kstart * a.v_row + (int64_t)h * a.v_head);
+  const int dma_r = lane / CPR, dma_p = lane % CPR;
+  constexpr int NO = NINS / 4;
+  const int j_first = NO * pw;
+  uint32_t kvoff[NO], vvoff[NO];
+#pragma unroll
+  for (int u = 0; u < NO; ++u) {
+    const int r = RPI * (j_first + u) + dma_r;
+    kvoff[u] = (uint32_t)dma_r * (uint32_t)a.k_row * 2u + 16u * (uint32_t)(dma_p ^ (r & 15));
+    vvoff[u] = (uint32_t)dma_r * (uint32_t)a.v_row * 2u + 16u * (uint32_t)(dma_p ^ ((r & 3) << 2));
+  }
+  auto dma16 = [&](const char* sbase_any, uint32_t voff, uint32_t lds_byte) {
+    const char* sbase = reinterpret_cast<const char*>(uni64((int64_t)reinterpret_cast<uintptr_t>(sbase_any)));   // (folds away where hipcc sees the uniformity itself)
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_byte), "s"(sbase) : "memory");
+  };
+  auto issue_dma = [&](const uint16_t* g, int64_t g_row, const uint32_t (&voff)[NO], uint16_t* ring, int item) {
+    const int n0 = __builtin_amdgcn_readfirstlane(item_n0(item));
+    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_t)(ring + (item & 1) * TENS + RPI * j_first * ROWB));
+    if (n0 + kBN <= s.L) {
+      const char* sb = reinterpret_cast<const char*>(g + (int64_t)(n0 + RPI * j_first) * g_row);
+      const int64_t step = (int64_t)RPI * g_row * 2;
+#pragma unroll
+      for (int u = 0; u < NO; ++u) dma16(sb + u * step, voff[u], dst + u * (RPI * ROWB * 2));
+    } else {
+      const uint32_t rowterm = (uint32_t)dma_r * (uint32_t)g_row * 2u;
+#pragma unroll
+      for (int u = 0; u < NO; ++u) {
+        const int row0 = n0 + RPI * (j_first + u);
+        const int rowc = row0 < s.L ? row0 : s.L - 1;
+        const uint32_t drop = row0 + 1 < s.L ? 0u : 0xffffffffu;
+        dma16(reinterpret_cast<const char*>(g + (int64_t)rowc * g_row), voff[u] - (rowterm & drop), dst + u * (RPI * ROWB * 2));
+      }
+    }
+  };
+  const int il = lane & 15, g1 = (lane >> 4) & 1, vq = il >> 2;
+  const int v_row_off = (4 * hi + vq) * ROWB + 4 * (il & 1);
+  const int v_chunk_lo = 2 * g1 + ((il & 3) >> 1);
+  auto v_frag = [&](const uint16_t* Vb, int dt, int ks) -> bf16x8_t {
+    typedef short v4s_t __attribute__((ext_vector_type(4)));
+    typedef short v8s_t __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) v4s_t* lds_v4s_t;
+    const uint16_t* p0 = Vb + (16 * ks) * ROWB + v_row_off + 8 * ((4 * (dt ^ vq)) + v_chunk_lo);
+    const v4s_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(p0));
+    const v4s_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(p0 + 8 * ROWB));
+    const v8s_t r = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    return __builtin_bit_cast(bf16x8_t, r);
+  };
+  f32x16_t acc_o[8];     // [4 column tiles of this wave's 128][2 q tiles]
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_o[t][r] = 0.f;
+  };
+  auto store_rows = [&](const Blk& k) {
+    fence_a(acc_o);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int qloc = k.hrow0 + 32 * qt + l31;
+      if (qloc < Lq) {
+        uint16_t* op = a.out + (int64_t)(s.start + qloc) * a.o_row + (int64_t)h * a.o_head + 128 * sub;
+#pragma unroll
+        for (int dtl = 0; dtl < 4; ++dtl)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            uint2 o;
+            o.x = pack_bf16(acc_o[2 * dtl + qt][4 * g4 + 0], acc_o[2 * dtl + qt][4 * g4 + 1]);
+            o.y = pack_bf16(acc_o[2 * dtl + qt][4 * g4 + 2], acc_o[2 * dtl + qt][4 * g4 + 3]);
+            *reinterpret_cast<uint2*>(op + 32 * dtl + 8 * g4 + 4 * hi) = o;
+          }
+      }
+    }
+  };
+  zero_acc();
+  if (N > 0) issue_dma(kg, a.k_row, kvoff, Kring, 0);
+  auto o_iter = [&](int it, const Blk& k, int t_in) {     // k, t_in: the block and tile of item it - 1 (t_in < 0: none)
+    pin_agpr(acc_o);
+    TICK(t0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces (K item it, V item it - 1) have landed ...
+    TICK(t1);
+    __syncthreads();                                    // ... everyone's have, P[it - 1] is written, the other buffers are free
+    TICK(t2);
+    if (it + 1 < N) issue_dma(kg, a.k_row, kvoff, Kring, it + 1);
+    if (it < N) issue_dma(vg, a.v_row, vvoff, Vring, it);
+    pin_agpr(acc_o);
+    TICK(t3);
+    TACC(0, t0, t1); TACC(1, t1, t2); TACC(2, t2, t3);
+    const int tl = it - 1;
+    {
+      if (t_in >= k.t_lo && t_in < k.t_hi) {
+        const uint16_t* Vt = Vring + (tl & 1) * TENS;
+        const u32x4_t* psrc = Pring + (((tl & 1) * 2 + half) * 2 * 4) * 64 + lane;
+        bf16x8_t pf[2][4];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) pf[qt][ks] = __builtin_bit_cast(bf16x8_t, psrc[(4 * qt + ks) * 64]);
+        constexpr int DB = 2, NVB = HSTU_Q2_VBUF, NBAT2 = 16 / DB;   // 16 V^T fragments per tile: (key slice ks, column tile dtl)
+        bf16x8_t vfr[NVB][DB];
+        auto load_v = [&](int bi) {
+          const int ks = bi / (4 / DB), dtl0 = (bi % (4 / DB)) * DB;
+#pragma unroll
+          for (int u = 0; u < DB; ++u) vfr[bi % NVB][u] = v_frag(Vt, 4 * sub + dtl0 + u, ks);
+        };
+#pragma unroll
+        for (int bi = 0; bi < NVB - 1; ++bi) load_v(bi);
+        pin_agpr(acc_o);
+#pragma unroll
+        for (int bi = 0; bi < NBAT2; ++bi) {
+          const int ks = bi / (4 / DB), dtl0 = (bi % (4 / DB)) * DB;
+          if (bi + NVB - 1 < NBAT2) load_v(bi + NVB - 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < DB; ++u)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) mfma_a(acc_o[2 * (dtl0 + u) + qt], vfr[bi % NVB][u], pf[qt][ks]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        TICK(t4);
+        TACC(5, t3, t4);
+#if HSTU_TIMING
+        tsum[6] += 1;
+#endif
+      }
+    }
+  };
+  // iterations 0 .. T0 finish block A (its last tile is item T0 - 1, computed in iteration T0); T0 + 1 .. N are block B's
+  for (int it = 0; it <= T0; ++it) o_iter(it, B0, it - 1);
+  if (two) {
+    store_rows(B0);          // block A's rows leave while the S waves already work on block B's first tile
+    zero_acc();
+    for (int it = T0 + 1; it <= N; ++it) o_iter(it, B1, it - 1 - T0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no DMA may be in flight into LDS when the block retires)
+#if HSTU_TIMING
+  t_dump();
+#endif
+  store_rows(two ? B1 : B0);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Backward (reference: hstu_varlen_bwd -> hstu_bwd.h, core maths :687-729).  With s = alpha <q,k>:
 //   P  = M SiLU(s) / N            dV = P^T dO
 //   dP = dO V^T                   dS = M dP SiLU'(s) alpha / N       dQ = dS K      dK = dS^T Q
@@ -2823,6 +3240,9 @@ __global__ void __launch_bounds__(256, HSTU_XOCC) hstu_bwd_v_p_kernel(BwdAttnArg
 // clock and CU, what L2 + HBM deliver), no staging registers, no commit phase, and a second wave per SIMD to cover the P / dS
 // loads and the fragment reads.
 // ---------------------------------------------------------------------------------------------------
+#ifndef HSTU_KVPC_MIDBAR
+#define HSTU_KVPC_MIDBAR 0   // 1 = a second barrier per step: the S waves arrive after their GEMMs, the K waves after their DMA issue, so the dK GEMM runs under the elementwise phase
+#endif
 #ifndef HSTU_KVPC_PROBE
 #define HSTU_KVPC_PROBE 0   // timing probe (wrong results): 1 = the S waves' GEMMs reuse their first fragment batches (no LDS reads)
 #endif
@@ -3231,7 +3651,7 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
       const bool have = i0 < i_lim;
       prev_valid = have;
       cur = have ? advance(i0) : i0;
-      if (!have || !wave_live) return;
+      if (!have || !wave_live) { if (HSTU_KVPC_MIDBAR) __builtin_amdgcn_s_barrier(); return; }
       const uint16_t* Qs = Qr + PAR * IMG;
       const uint16_t* Ds = dOr + PAR * IMG;
       f32x16_t acc_s, acc_p;
@@ -3262,6 +3682,7 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      if (HSTU_KVPC_MIDBAR) __builtin_amdgcn_s_barrier();   // (no LDS hazard to order: a pure phase alignment)
       TICK(t2);
       TACC(4, t1, t2);
       const bool tail = i0 + BQ > s.L;     // rows past the sequence are clamped copies here (the 4-wave kernel stages zeros): masked
@@ -3360,6 +3781,7 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
     prev_valid = have;
     cur = nxt;
     pin_agpr(acc_dk);
+    if (HSTU_KVPC_MIDBAR) __builtin_amdgcn_s_barrier();
     TICK(t3);
     TACC(2, t2, t3);
     if (!had || !wave_live) return;
@@ -3578,6 +4000,33 @@ static int launch_fwd_pc(const AttnArgs& a, int B, int max_seqlen, hipStream_t s
   // mi355_hstu_attn_fwd_hint_tokens).  On a jagged batch the pairs of a long column are as heavy as before but half as many
   // workgroups share the machine and the tail grows (C4 shape 340 -> 355 us); MI355_HSTU_PAIR = 0 never, 2 always (A/B).
   static const int pair = getenv("MI355_HSTU_PAIR") ? atoi(getenv("MI355_HSTU_PAIR")) : 1;
+  // 64 query rows per wave (two MFMAs per LDS fragment) from 1 025 rows: +4-6 % at L >= 2048, +1-4 % on jagged Zipf-to-4096 batches,
+  // level at 768-1024, -2 % at C3 and -6 % at L = 256 (fewer, larger units per short column); 2 = always, 0 = never (A/B)
+  static const int q2 = getenv("MI355_HSTU_Q2") ? atoi(getenv("MI355_HSTU_Q2")) : 1;
+  if (q2 == 2 || (q2 == 1 && max_seqlen > 1024)) {
+    static bool attr_q2 = false;
+    if (!attr_q2) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_q2_kernel<D, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_q2_kernel<D, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_q2_kernel<D, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_q2_kernel<D, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return MI355_ELAUNCH;
+      attr_q2 = true;
+    }
+    const int nblk = (max_seqlen + kBM - 1) / kBM;
+    const bool win = a.wl >= 0 || a.wr >= 0;
+    if (pair == 2 || (pair == 1 && dense_batch)) {
+      dim3 grid(a.H, B, (nblk + 1) / 2);
+      if (win) hipLaunchKernelGGL((hstu_fwd_q2_kernel<D, true, true>), grid, dim3(512), smem, stream, a);
+      else hipLaunchKernelGGL((hstu_fwd_q2_kernel<D, false, true>), grid, dim3(512), smem, stream, a);
+    } else {
+      dim3 grid(a.H, B, nblk);
+      if (win) hipLaunchKernelGGL((hstu_fwd_q2_kernel<D, true, false>), grid, dim3(512), smem, stream, a);
+      else hipLaunchKernelGGL((hstu_fwd_q2_kernel<D, false, false>), grid, dim3(512), smem, stream, a);
+    }
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+  }
   if (pair == 2 || (pair == 1 && dense_batch)) {
     static bool attr_pair = false;
     if (!attr_pair) {

@@ -432,22 +432,32 @@ def test_rab_without_drab_and_zero_bias():
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("dma", ["1", "0"])
-def test_forward_with_lds_dma_staging(dma):
-    """The d = 256 forward has three kernels: the default since round 4 is the 8-wave S-wave / O-wave kernel
-    (hstu_fwd_pc_kernel, two waves per SIMD); MI355_HSTU_PC=0 falls back to the one-stream kernels -- with MI355_HSTU_DMA=1
-    K / V tiles moved global -> LDS by `global_load_lds_dwordx4` (XOR-swizzled rows, double-buffered, one barrier per tile:
-    hstu_fwd_dma_kernel), with MI355_HSTU_DMA=0 the register-staged hstu_fwd_kernel.  The library reads the switches once,
-    so every d = 256 test of this file (goldens, random jagged batches, contexts / targets, local windows, delta-q) is re-run
-    in a child process with each fallback."""
+_FWD_VARIANTS = {
+    "rows64": {"MI355_HSTU_Q2": "2"},                                    # hstu_fwd_q2_kernel at every length (default: from 1 025 rows)
+    "rows64_pairs": {"MI355_HSTU_Q2": "2", "MI355_HSTU_PAIR": "2"},      # ... with row blocks in pairs on every batch (default: dense ones)
+    "rows32": {"MI355_HSTU_Q2": "0"},                                    # hstu_fwd_pc_kernel / hstu_fwd_pair_kernel at every length
+    "rows32_pairs": {"MI355_HSTU_Q2": "0", "MI355_HSTU_PAIR": "2"},
+    "one_stream_dma": {"MI355_HSTU_PC": "0", "MI355_HSTU_DMA": "1"},     # hstu_fwd_dma_kernel (round 3)
+    "one_stream": {"MI355_HSTU_PC": "0", "MI355_HSTU_DMA": "0"},         # hstu_fwd_kernel, register-staged tiles
+}
+
+
+@pytest.mark.parametrize("variant", list(_FWD_VARIANTS))
+def test_forward_kernel_variants(variant):
+    """The d = 256 forward has five kernels.  Default since round 4: 8-wave workgroups of S waves and O waves (two waves per
+    SIMD) -- hstu_fwd_q2_kernel (64 query rows per wave: two MFMAs per LDS fragment) from 1 025 rows per sequence,
+    hstu_fwd_pc_kernel / hstu_fwd_pair_kernel (32 rows per wave) below; row blocks in (heavy, light) pairs on dense batches.
+    MI355_HSTU_PC=0 falls back to the one-stream kernels (LDS-DMA staged, register staged).  The library reads the switches
+    once, so every d = 256 test of this file (goldens, random jagged batches, contexts / targets, local windows, delta-q) is
+    re-run in a child process with each kernel forced onto every shape."""
     import subprocess
     import sys
 
-    if os.environ.get("MI355_HSTU_PC") == "0":
-        pytest.skip("already a fallback run")
+    if os.environ.get("MI355_HSTU_CHILD"):
+        pytest.skip("already a variant run")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
-                        "256 and not mask_alone and not rab and not lds_dma"],
-                       env=dict(os.environ, MI355_HSTU_PC="0", MI355_HSTU_DMA=dma), capture_output=True, text=True, timeout=900)
+                        "256 and not mask_alone and not rab and not kernel_variants"],
+                       env=dict(os.environ, MI355_HSTU_CHILD="1", **_FWD_VARIANTS[variant]), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout, r.stdout[-500:]
 

@@ -21,7 +21,8 @@ H, d = a.heads, 256
 def shape(name):
     if name == "c3": return [512] * 32
     if name == "d4096": return [4096] * 32
-    if name == "d8x4096": return [4096] * 8
+    if name.startswith("d") and "x" in name:
+        n, l = name[1:].split("x"); return [int(l)] * int(n)
     if name == "d1024": return [1024] * 32
     if name.startswith("jag"):
         rng = np.random.default_rng(int(name[3:]))

@@ -17,14 +17,18 @@ ap.add_argument("--batch", type=int, default=32); ap.add_argument("--seqlen", ty
 ap.add_argument("--heads", type=int, default=4); ap.add_argument("--dim", type=int, default=256)
 ap.add_argument("--dma", action="store_true", help="the LDS-DMA staged forward (sets MI355_HSTU_DMA=1)")
 ap.add_argument("--pc", action="store_true", help="the two-waves-per-SIMD forward (hstu_fwd_pc_kernel: S waves / O waves; the default forward)")
+ap.add_argument("--q2", action="store_true", help="the 64-rows-per-wave forward (hstu_fwd_q2_kernel, the default forward since round 4)")
 ap.add_argument("--bwdpc", action="store_true", help="the S-wave / K-wave dK pass of the backward (hstu_bwd_kv_pc_kernel)")
 ap.add_argument("--bwd", action="store_true", help="the dK pass of the backward (hstu_bwd_kv_kernel, exchange mode) instead of the forward")
 a = ap.parse_args()
 if a.dma:
     os.environ["MI355_HSTU_DMA"] = "1"   # read by the library at its first forward
     os.environ["MI355_HSTU_PC"] = "0"
-if a.pc:
-    os.environ["MI355_HSTU_PC"] = "1"
+if a.q2:
+    a.pc = True
+    os.environ["MI355_HSTU_PC"] = "1"; os.environ["MI355_HSTU_Q2"] = "1"
+elif a.pc:
+    os.environ["MI355_HSTU_PC"] = "1"; os.environ["MI355_HSTU_Q2"] = "0"
     os.environ["MI355_HSTU_PAIR"] = "0"   # the stamps live in the unpaired kernel (hstu_fwd_pc_kernel)
 elif not a.bwd:
     os.environ.setdefault("MI355_HSTU_PC", "0")
@@ -67,7 +71,8 @@ if a.pc:
         d = dd[role_of == role]
         tiles, tot = d[:, 6], d[:, 7]
         print(f"{nm0}: waves {len(d)}  tiles/wave avg {tiles.mean():.2f}  wave lifetime avg {tot.mean():.0f} cyc  max {tot.max():.0f}")
-        names = (["wait own DMA", "barrier", "DMA issue", "gemm1 sub-tile 1 + silu 0", "gemm1 sub-tile 0", "silu sub-tile 1"] if role == 0
+        names = (["barrier .. gemm1 start", "barrier", None, "tile end .. next barrier", "gemm1", "silu + P hand-off"] if role == 0 and a.q2 else
+                 ["wait own DMA", "barrier", "DMA issue", "gemm1 sub-tile 1 + silu 0", "gemm1 sub-tile 0", "silu sub-tile 1"] if role == 0
                  else ["wait own DMA", "barrier", "DMA issue", None, None, "P read + gemm2"])
         for i, nm in enumerate(names):
             if nm is None:
