@@ -1816,6 +1816,9 @@ __global__ void __launch_bounds__(512) hstu_fwd_pair_kernel(AttnArgs a) {
 // LDS traffic per tile: K 64 + V 64 + P 16 written / 32 read + DMA 64 = 240 KB (352 before).  Rings, swizzles, the one barrier
 // per tile, the lag of one tile between the roles and the optional (heavy, light) pairing of row blocks (kPair) are those of
 // the two kernels above; same MFMA order per output element, same roundings: bit-identical output.
+// Measured and rejected: the S waves software-pipelined across tiles (GEMM 1 of tile t between the SiLU groups of tile t - 1, the
+// O waves two tiles behind): Q (128) + two accumulator sets (64) + fragments do not fit 256 registers -- hipcc spills 45 of them and
+// reloads Q fragments from scratch inside the loop: 708-745 TFLOP/s against 866-948 at L = 4096 (same bits).
 // ---------------------------------------------------------------------------------------------------
 #ifndef HSTU_Q2_KBUF
 #define HSTU_Q2_KBUF 3   // S waves: K fragment batches (2 slices = 4 MFMAs) in registers, KBUF - 1 in flight
