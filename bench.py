@@ -405,6 +405,44 @@ def hstu_jagged_section(args, device):
                                    f"H {H}, d {d}, causal"}}
 
 
+def hstu_long_section(args, device):
+    """Path B in its compute-bound regime: 8 dense sequences of 4096 (H 4, d 256, causal) -- the shape the round-3 review set
+    its forward / backward targets on (>= 900 / 750 TFLOP/s).  `sustained_peak` is what tools/ubench_mfma.hip measures for
+    back-to-back 32x32x16 bf16 MFMAs on all 256 CUs (the clock drops from 2.4 to ~1.6-1.9 GHz): profiles/r04_ubench_mfma.txt."""
+    from hstu import hstu_varlen_bwd, hstu_varlen_fwd
+
+    Bq, L, H, d = 8, 4096, args.hstu_heads, args.hstu_dim
+    T = Bq * L
+    cu = torch.arange(0, T + 1, L, dtype=torch.int32, device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(13)
+    q, k, v, do = (torch.empty(T, H, d, device=device).uniform_(-1, 1, generator=g).bfloat16() for _ in range(4))
+    alpha = 1.0 / d ** 0.5
+
+    def timeit(fn, reps):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    tf = timeit(lambda: hstu_varlen_fwd(q, k, v, cu, L, L, None, None, 1, True, alpha), 10)
+    tb = timeit(lambda: hstu_varlen_bwd(do, q, k, v, cu, L, L, None, None, 1, True, alpha), 6)
+    fl = hstu_flops([L] * Bq, H, d)
+    tot = 3.5 * fl / (tf + tb) / 1e9
+    return {"metric": "HSTU attention, dense 8 x 4096", "value": T / (tf + tb) * 1e3, "unit": "tokens/s", "fwd_ms": tf, "bwd_ms": tb,
+            "fwd_TFLOPs": fl / tf / 1e9, "bwd_TFLOPs": 2.5 * fl / tb / 1e9,
+            "roofline": {"bound": "mfma", "achieved": tot, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tot / MFMA_BF16_PEAK_TFLOPS,
+                         "fwd_frac": fl / tf / 1e9 / MFMA_BF16_PEAK_TFLOPS, "sustained_peak": 1900.0,
+                         "sustained_peak_source": "tools/ubench_mfma.hip, profiles/r04_ubench_mfma.txt"},
+            "config": {"workload": f"attention: batch {Bq} x L {L} (dense lengths), H {H}, d {d}, causal, alpha 1/sqrt(d)"}}
+
+
 def c2_16x_section(args, module, device):
     """The bandwidth-regime figure SURVEY 8(d) asks for: the C2 step at 16 x the batch (B = 1,048,576 bags, ~5.8 M keys) on
     the same table: step time and the step-level roofline (minimal bytes / time)."""
@@ -690,6 +728,7 @@ def main():
             result["hstu"] = h
         if rank == 0 and world == 1 and not args.no_extra:
             result["hstu_jagged"] = hstu_jagged_section(args, device)
+            result["hstu_l4096"] = hstu_long_section(args, device)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # keys index host rows directly (the permuted keys are already in [0, rows))

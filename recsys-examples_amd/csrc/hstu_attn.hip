@@ -299,6 +299,9 @@ __device__ __forceinline__ void stage_rows(uint16_t* dst, const uint16_t* src, i
 #ifndef HSTU_TIMING
 #define HSTU_TIMING 0
 #endif
+#ifndef HSTU_X8_PROBE
+#define HSTU_X8_PROBE 0   // timing probes of the one-GEMM passes (results wrong): 1 = no fragment reads after the first batch, 2 = no exchange loads, 4 = no DMA after the first step
+#endif
 #if HSTU_TIMING
 __device__ unsigned long long g_hstu_dbg[8 * 65536];
 __device__ __forceinline__ unsigned tick() {
@@ -3272,7 +3275,11 @@ struct Dma64T {   // LDS-DMA of one 64-row x 256-column bf16 tile by NW waves: 3
       voff[u] = (uint32_t)dr * (uint32_t)row_stride * 2u + 16u * (uint32_t)(dp ^ ((r & 3) << 2));
     }
   }
-  static __device__ __forceinline__ void dma16(const char* sbase, uint32_t vo, uint32_t lds_byte) {
+  static __device__ __forceinline__ void dma16(const char* sbase_any, uint32_t vo, uint32_t lds_byte) {
+    // (the base is an "s" operand: say that it is wave-uniform; the two readfirstlanes fold away where hipcc sees it itself)
+    const uint64_t pa = reinterpret_cast<uintptr_t>(sbase_any);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)pa), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32));
+    const char* sbase = reinterpret_cast<const char*>(((uint64_t)hi32 << 32) | lo);
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(vo), "s"(lds_byte), "s"(sbase) : "memory");
@@ -3326,10 +3333,10 @@ __device__ __forceinline__ void gemm_x8(f32x16_t (&acc)[8], const uint16_t* ring
   for (int bi = 0; bi < NVB - 1; ++bi) load(bi);
 #pragma unroll
   for (int bi = 0; bi < NB; ++bi) {
-    if (bi + NVB - 1 < NB) load(bi + NVB - 1);
+    if (bi + NVB - 1 < NB && !(HSTU_X8_PROBE & 1)) load(bi + NVB - 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) mfma_a(acc[4 * (bi & 1) + u], fr[bi % NVB][u], bf[bi >> 1]);
+    for (int u = 0; u < 4; ++u) mfma_a(acc[4 * (bi & 1) + u], fr[(HSTU_X8_PROBE & 1) ? 0 : bi % NVB][u], bf[bi >> 1]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -3395,7 +3402,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_v_p8_kernel
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int it = i + 32 * t;
-      if (wave_live && visited(it) && !xch_absent(xu, key0 >> 5, it >> 5)) {
+      if (!(HSTU_X8_PROBE & 2) && wave_live && visited(it) && !xch_absent(xu, key0 >> 5, it >> 5)) {
         const u32x4_t* tp = reinterpret_cast<const u32x4_t*>(g.p_ws + xch_tile(xu, key0 >> 5, it >> 5)) + 2 * lane;
         pn0[t] = tp[0]; pn1[t] = tp[1];
       } else {
@@ -3415,7 +3422,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_v_p8_kernel
     __syncthreads();                                    // everyone's have; everyone is done with the other buffer
     {
       const int nx = advance(i0);
-      if (nx < i_lim) { dma.issue(dobase, g.do_row, nx, s.L, smem + (BUF ^ 1) * TILE, lane); fetch_p(nx); }
+      if (nx < i_lim) { if (!(HSTU_X8_PROBE & 4)) dma.issue(dobase, g.do_row, nx, s.L, smem + (BUF ^ 1) * TILE, lane); fetch_p(nx); }
     }
     pin_agpr(acc);
     if (wave_live) gemm_x8<BUF>(acc, smem, pf, lane, hi);
@@ -3491,7 +3498,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_q_ds8_kerne
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int nt = n + 32 * t;
-      if (wave_live && nt < w_end && tile_written(nt) && !xch_absent(xu, nt >> 5, qrow0 >> 5)) {
+      if (!(HSTU_X8_PROBE & 2) && wave_live && nt < w_end && tile_written(nt) && !xch_absent(xu, nt >> 5, qrow0 >> 5)) {
         const u32x4_t* tp = reinterpret_cast<const u32x4_t*>(g.ds_ws + xch_tile(xu, nt >> 5, qrow0 >> 5)) + 2 * lane;
         ds0[t] = tp[0]; ds1[t] = tp[1];
       } else {
@@ -3513,7 +3520,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_q_ds8_kerne
       *reinterpret_cast<u32x4_t*>(dSw + 1024 * t + 16 * lane + 8) = ds1[t];
     }
     __syncthreads();
-    if (n0 + BK < n_end) { dma.issue(kbase, a.k_row, n0 + BK, s.L, smem + (BUF ^ 1) * TILE, lane); fetch_ds(n0 + BK); }
+    if (n0 + BK < n_end) { if (!(HSTU_X8_PROBE & 4)) dma.issue(kbase, a.k_row, n0 + BK, s.L, smem + (BUF ^ 1) * TILE, lane); fetch_ds(n0 + BK); }
     pin_agpr(acc);
     if (wave_live && n0 < w_end && n0 >= w_beg) {
       bf16x8_t sf[2 * NT];
@@ -3541,6 +3548,15 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_q_ds8_kerne
   if (qi < s.L) store_acc_rows<D>(acc, g.dq + ((int64_t)(s.start + qi) * a.H + h) * D, hi);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// What bounds the one-GEMM dV / dQ passes at long sequences (probes of profiles/r04_hstu_bwd_x8_probes.txt, 8 x 4096, one chunk):
+// hstu_bwd_v_p8_kernel 260 us -- 158 without its P loads, 129 without loads and row DMA, 111 without the LDS fragment reads as well
+// (HSTU_X8_PROBE).  The 0.54 GB of P (and of dS) that a pass reads were written by the dK pass and no cache holds them: at the
+// ~5.4 TB/s HBM delivers they are 100 us per pass, and 200 us of writes inside the dK pass -- 0.4 of the backward's 1.02 ms.
+// It is bandwidth, not latency: the same passes with the exchange tiles brought in by LDS-DMA TWO steps ahead (one 8-wave
+// workgroup per CU, a three-slot ring of 96 KB next to the row ring, counted vmcnt, bit-identical results) ran 635-642 TFLOP/s
+// against 662-667 (profiles/r04_hstu_bwd_xe_ab.txt) and were removed again.
+// ---------------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------------
 // The dK pass of the exchange with two waves per SIMD (round 4, head dim 256, no bias): the forward's S-wave / O-wave split
 // applied to the backward.  One workgroup = 128 keys; waves 0-3 ("S waves") hold the K and V fragments of their 32 keys

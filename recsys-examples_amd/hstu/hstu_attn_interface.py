@@ -151,12 +151,15 @@ def append_kvcache(append_key, append_value, batch_indices, positions, seqlen_of
     return kv_cache_table
 
 
-_DS_MAX_BYTES = int(__import__("os").environ.get("MI355_HSTU_DS_MAX_BYTES", str(1 << 30)))
+# Byte cap of the backward's P / dS exchange.  Measured at d = 256, H = 4 (profiles/r04_hstu_exchange_cap.txt): 32 x 4096 backward
+# 581 TFLOP/s at 1 GiB (5 chunks), 640 at 2 GiB, 691 at 4 GiB (2 chunks), 707 at 8 GiB and above (dense layout 8.6 GB: one pass);
+# 8 x 4096 612 / 664 / 671 -- every chunk is three launches whose tails cannot be filled by the next chunk.  4 GiB = 1.4 % of the HBM.
+_DS_MAX_BYTES = int(__import__("os").environ.get("MI355_HSTU_DS_MAX_BYTES", str(4 << 30)))
 
 
 def _bwd_exchange_workspace(q, B, H, D, max_seqlen, plain_causal):
     """Scratch of the backward's P / dS exchange (the dK pass leaves them for the one-GEMM dV / dQ passes): the dense layout
-    B x H x ceil(max_seqlen / 32)^2 tiles when that fits under MI355_HSTU_DS_MAX_BYTES (default 1 GiB), else the jagged,
+    B x H x ceil(max_seqlen / 32)^2 tiles when that fits under MI355_HSTU_DS_MAX_BYTES (default 4 GiB), else the jagged,
     chunked layout of mi355_hstu_attn_bwd_ds_bytes_capped -- sized by the batch's own lengths, never above the cap, walked in
     chunks by the library.  No driver query, no host read of the lengths; the decision depends on the shapes only."""
     L = lib()

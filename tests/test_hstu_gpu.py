@@ -198,10 +198,11 @@ def test_backward_exchange_in_chunks_under_a_cap_is_bit_identical(d, mode, monke
     assert float(g_chunk[0].float().abs().max()) > 0
 
 
-def test_backward_scratch_stays_under_one_gib_at_32x4096():
+def test_backward_scratch_stays_under_one_gib_at_32x4096(monkeypatch):
     """The dense layout of the exchange would take B H ceil(L / 32)^2 x 4 KB = 8.6 GB at 32 sequences x 4096 tokens x 4 heads
-    (d = 256); with the default cap the backward allocates at most 1 GiB of scratch next to its three outputs (peak allocator
-    use checked), and its dq, dk, dv are those of the recomputing passes bit for bit."""
+    (d = 256); under a cap of 1 GiB (MI355_HSTU_DS_MAX_BYTES; the default is 4 GiB, which is 19 % faster here) the backward
+    allocates at most 1 GiB of scratch next to its three outputs (peak allocator use checked), and its dq, dk, dv are those of
+    the recomputing passes bit for bit."""
     import hstu.hstu_attn_interface as hi
 
     Bq, L, H, d = 32, 4096, 4, 256
@@ -211,7 +212,8 @@ def test_backward_scratch_stays_under_one_gib_at_32x4096():
     g.manual_seed(5)
     q, k, v, dout = (torch.empty(T, H, d, device=DEV).uniform_(-1, 1, generator=g).bfloat16() for _ in range(4))
     assert hi.lib().mi355_hstu_attn_bwd_ds_bytes(Bq, H, d, L) >= (8 << 30)
-    assert hi._DS_MAX_BYTES <= (1 << 30)
+    assert hi._DS_MAX_BYTES <= (4 << 30) or "MI355_HSTU_DS_MAX_BYTES" in os.environ      # the default never asks for the dense 8.6 GB
+    monkeypatch.setattr(hi, "_DS_MAX_BYTES", 1 << 30)
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats()
     base = torch.cuda.memory_allocated()
@@ -220,12 +222,11 @@ def test_backward_scratch_stays_under_one_gib_at_32x4096():
     peak = torch.cuda.max_memory_allocated() - base
     outs = 3 * T * H * d * 2
     assert peak <= outs + (1 << 30) + (64 << 20), f"backward peak {peak >> 20} MB for {outs >> 20} MB of outputs"
-    old = hi._DS_MAX_BYTES
-    try:
-        hi._DS_MAX_BYTES = 0      # no scratch at all: the recomputing passes
-        rq, rk, rv = hi.hstu_varlen_bwd(dout, q, k, v, cu, L, L, None, None, 1, True, 1.0 / d ** 0.5)
-    finally:
-        hi._DS_MAX_BYTES = old
+    monkeypatch.setattr(hi, "_DS_MAX_BYTES", 4 << 30)     # the default: two chunks
+    dq4, dk4, dv4 = hi.hstu_varlen_bwd(dout, q, k, v, cu, L, L, None, None, 1, True, 1.0 / d ** 0.5)
+    assert torch.equal(dq, dq4) and torch.equal(dk, dk4) and torch.equal(dv, dv4)
+    monkeypatch.setattr(hi, "_DS_MAX_BYTES", 0)           # no scratch at all: the recomputing passes
+    rq, rk, rv = hi.hstu_varlen_bwd(dout, q, k, v, cu, L, L, None, None, 1, True, 1.0 / d ** 0.5)
     assert torch.equal(dq, rq) and torch.equal(dk, rk) and torch.equal(dv, rv)
 
 
