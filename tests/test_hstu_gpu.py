@@ -463,6 +463,54 @@ def test_forward_kernel_variants(variant):
     assert " passed" in r.stdout, r.stdout[-500:]
 
 
+_LONG_CASES_SCRIPT = r"""
+import hashlib, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(sys.argv[1], "recsys-examples_amd")); sys.path.insert(0, sys.argv[1])
+from hstu import hstu_attn_varlen_func
+dev = torch.device("cuda")
+H, d = 2, 256
+rng = np.random.default_rng(17)
+def run(lengths, ctx, tgt, grp, window, klen_extra=None):
+    lengths = np.asarray(lengths, np.int64)
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    T, N = int(off[-1]), int(lengths.max())
+    g = torch.Generator(device=dev); g.manual_seed(int(lengths.sum()))
+    q, k, v = (torch.empty(T, H, d, device=dev).uniform_(-1, 1, generator=g).bfloat16() for _ in range(3))
+    cu = torch.tensor(off, dtype=torch.int32, device=dev)
+    ti = lambda a: None if a is None else torch.tensor(np.asarray(a), dtype=torch.int32, device=dev)
+    out = hstu_attn_varlen_func(q, k, v, cu, cu, None, None, N, N, N, ti(ctx), ti(tgt), target_group_size=grp, window_size=window, alpha=1.0 / 16)
+    torch.cuda.synchronize()
+    return hashlib.sha1(out.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16]
+L = [1025, 2300, 1, 1536, 64, 1100, 4096, 129]
+print("causal", run(L, None, None, 1, (-1, 0)))
+print("noncausal", run(L, None, None, 1, (-1, -1)))
+print("ctx_tgt", run(L, [3, 70, 0, 128, 5, 0, 200, 1], [100, 64, 0, 7, 3, 500, 1000, 60], 1, (-1, 0)))
+print("tgt_groups", run(L, None, [100, 64, 0, 7, 3, 500, 1000, 60], 4, (-1, 0)))
+print("window", run(L, None, None, 1, (300, 0)))
+print("window2", run(L, None, None, 1, (70, 33)))
+"""
+
+
+def test_forward_64_rows_per_wave_is_bit_identical_on_long_jagged_batches(tmp_path):
+    """From 1 025 rows per sequence the forward runs hstu_fwd_q2_kernel (64 query rows per wave).  Same MFMA order per output
+    element, same roundings as the 32-rows kernels: the outputs of a jagged batch with sequences of 1 .. 4 096 rows must agree
+    bit for bit under every mask rule (causal, none, contexts + targets, target groups, local windows) -- both kernels run in
+    child processes (the library reads MI355_HSTU_Q2 once) and print a hash of the output bits."""
+    import subprocess
+    import sys
+
+    script = tmp_path / "long_cases.py"
+    script.write_text(_LONG_CASES_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for q2 in ("1", "0"):
+        r = subprocess.run([sys.executable, str(script), root], env=dict(os.environ, MI355_HSTU_Q2=q2), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[q2] = [ln for ln in r.stdout.splitlines() if ln and not ln.startswith("/opt")]
+    assert len(outs["1"]) == 6 and outs["1"] == outs["0"], (outs["1"], outs["0"])
+
+
 def test_strided_inputs_and_scaling_seqlen():
     """q/k/v as slices of one fused [T, 3, H, d] tensor (what the fused HSTU layer hands over) and
     scaling_seqlen decoupled from max_seqlen."""
