@@ -181,6 +181,14 @@ class _LookupFunction(torch.autograd.Function):
 
 
 class BatchedDynamicEmbeddingTablesV2(nn.Module):
+    def __new__(cls, table_options=None, *args, **kwargs):
+        # tables backed by a user-supplied store (options.external_storage) are the subclass of external_storage.py
+        if cls is BatchedDynamicEmbeddingTablesV2 and table_options and any(o.external_storage is not None for o in table_options):
+            from .external_storage import ExternalStorageTables
+
+            return super().__new__(ExternalStorageTables)
+        return super().__new__(cls)
+
     def __init__(self, table_options: List[DynamicEmbTableOptions], table_names: Optional[List[str]] = None,
                  feature_table_map: Optional[List[int]] = None, use_index_dedup: bool = False,
                  prefetch_pipeline: bool = False, pooling_mode: DynamicEmbPoolingMode = DynamicEmbPoolingMode.SUM,
@@ -196,8 +204,6 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         opt0 = table_options[0]
         for o in table_options:
             assert opt0 == o, "All tables must match in grouped keys."
-            if o.external_storage is not None:
-                raise NotImplementedError("external storage is a 'next' row (DESIGN.md)")
         self._dynamicemb_options = table_options
         self._table_names = table_names or [f"t{i}" for i in range(len(table_options))]
         self.pooling_mode = pooling_mode

@@ -51,3 +51,27 @@ def get_required_arg(args: Dict[str, Any], key: str) -> Any:
     if key not in args:
         raise ValueError(f"Input args does not contain required optimizer argument: {key}")
     return args[key]
+
+
+class OptimizerView:
+    """What an external `Storage` is told about the optimizer of its tables (the reference constructs it with the
+    BaseDynamicEmbeddingOptimizer object, optimizer.py:118-190; a store only needs the row layout and the checkpoint
+    metadata of it): state columns per embedding dim, their initial value, the hyper-parameters."""
+
+    def __init__(self, module):
+        self._m = module
+
+    def get_state_dim(self, emb_dim: int) -> int:
+        return get_optimizer_state_dim(self._m.optimizer_type, emb_dim, self._m.embedding_dtype)
+
+    def get_ckpt_state_dim(self, emb_dim: int) -> int:
+        return get_optimizer_ckpt_state_dim(self._m.optimizer_type, emb_dim)
+
+    def get_initial_optim_states(self) -> float:
+        return float(self._m.initial_accumulator_value)
+
+    def get_opt_args(self) -> Dict[str, Any]:
+        return self._m._opt_args()
+
+    def set_learning_rate(self, new_lr: float) -> None:
+        self._m.learning_rate = new_lr

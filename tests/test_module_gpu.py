@@ -809,3 +809,130 @@ def test_training_step_is_hipgraph_capturable(B, NK, cap, hi):
     eo, go = torch.argsort(ek), torch.argsort(gk)
     assert torch.equal(ek[eo], gk[go])
     torch.testing.assert_close(ev[eo], gv[go], rtol=1e-5, atol=1e-6)
+
+
+class _DictStore:
+    """A store on the host, written for this test (the role of the reference's PyDictStorage parametrisation,
+    test_batched_dynamic_embedding_tables_v2.py:862-1318): {(table id, key): row}, rows kept on the device."""
+
+    def __new__(cls, options, optimizer):
+        from dynamicemb.types import Storage
+
+        class Impl(Storage):
+            def __init__(self, options, optimizer):
+                self.rows, self.scores = {}, {}
+                self.emb_dim = max(o.dim for o in options)
+                self.value_dim = max(o.dim + optimizer.get_state_dim(o.dim) for o in options)
+                self.dtype = options[0].embedding_dtype
+                self.finds = self.inserts = 0
+
+            def size(self):
+                return len(self.rows)
+
+            def find(self, unique_keys, table_ids, copy_mode, lfu_accumulated_frequency=None):
+                from dynamicemb.types import CopyMode
+
+                self.finds += 1
+                dev = unique_keys.device
+                width = self.emb_dim if copy_mode == CopyMode.EMBEDDING else self.value_dim
+                vals = torch.zeros(unique_keys.numel(), width, dtype=self.dtype, device=dev)
+                ks, ts = unique_keys.cpu().tolist(), table_ids.cpu().tolist()
+                found, miss = [], []
+                for i, (k, t) in enumerate(zip(ks, ts)):
+                    r = self.rows.get((t, k))
+                    found.append(r is not None)
+                    if r is None:
+                        miss.append(i)
+                    else:
+                        vals[i] = r[:width]
+                midx = torch.tensor(miss, dtype=torch.int64, device=dev)
+                return (len(miss), unique_keys[midx], midx, table_ids[midx], None, torch.tensor(found, dtype=torch.bool, device=dev),
+                        torch.zeros(unique_keys.numel(), dtype=torch.int64, device=dev), vals)
+
+            def insert(self, keys, table_ids, values, scores=None, preserve_existing=False):
+                self.inserts += 1
+                sc = scores.cpu().tolist() if scores is not None else None
+                for i, (k, t) in enumerate(zip(keys.cpu().tolist(), table_ids.cpu().tolist())):
+                    if preserve_existing and (t, k) in self.rows:
+                        continue
+                    self.rows[(t, k)] = values[i].clone()
+                    if sc is not None:
+                        self.scores[(t, k)] = sc[i]
+
+        return Impl(options, optimizer)
+
+
+@pytest.mark.parametrize("pooling", ["SUM", "MEAN", "NONE"])
+@pytest.mark.parametrize("optimizer", ["SGD", "ADAM", "EXACT_ADAGRAD", "EXACT_ROWWISE_ADAGRAD"])
+def test_external_storage_is_transparent(pooling, optimizer):
+    """`DynamicEmbTableOptions.external_storage`: the rows live in a user-supplied `dynamicemb.types.Storage` (here a dict on
+    the host); the module de-duplicates, finds, initialises + inserts the unknown keys, pools from the returned buffer, and in
+    the backward reduces, steps the optimizer on the buffer and writes the rows back.  Same outputs and same rows as the
+    HBM-only module on the same key stream (first-touch rows are keyed by the key in both), train and eval."""
+    from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
+    from dynamicemb.dynamicemb_config import (DynamicEmbInitializerArgs, DynamicEmbInitializerMode, DynamicEmbPoolingMode,
+                                              DynamicEmbScoreStrategy, DynamicEmbTableOptions, EmbOptimType)
+    from dynamicemb.external_storage import ExternalStorageTables
+
+    rng = np.random.default_rng(5)
+    dims, F, B = [8, 8], 2, 24
+    pm = getattr(DynamicEmbPoolingMode, pooling)
+    hp = dict(learning_rate=0.05)
+    if optimizer == "ADAM":
+        hp.update(beta1=0.8, beta2=0.9, eps=1e-6, weight_decay=0.01)
+    elif optimizer != "SGD":
+        hp.update(eps=1e-6, initial_accumulator_value=0.1)
+
+    def make(store):
+        opts = [DynamicEmbTableOptions(dim=d, max_capacity=4096, index_type=torch.int64, embedding_dtype=torch.float32,
+                                       score_strategy=DynamicEmbScoreStrategy.STEP, external_storage=store,
+                                       initializer_args=DynamicEmbInitializerArgs(mode=DynamicEmbInitializerMode.UNIFORM, lower=-0.3, upper=0.3))
+                for d in dims]
+        m = BatchedDynamicEmbeddingTablesV2(opts, pooling_mode=pm, output_dtype=torch.float32, optimizer=getattr(EmbOptimType, optimizer),
+                                            device=torch.device("cuda", 0), **hp)
+        m.train()
+        return m
+
+    ref, dut = make(None), make(_DictStore)
+    assert isinstance(dut, ExternalStorageTables) and isinstance(dut, BatchedDynamicEmbeddingTablesV2) and dut.storage_mode == "external"
+    for step in range(6):
+        lens = rng.integers(0, 5, F * B)
+        off = np.zeros(F * B + 1, np.int64)
+        off[1:] = np.cumsum(lens)
+        keys = torch.from_numpy(rng.integers(0, 300, off[-1]).astype(np.int64)).cuda()
+        off_t = torch.from_numpy(off).cuda()
+        o_ref = ref(keys, off_t)
+        o_dut = dut(keys, off_t)
+        torch.testing.assert_close(o_dut, o_ref, rtol=1e-6, atol=1e-6)
+        g = torch.randn_like(o_ref)
+        o_ref.backward(g)
+        o_dut.backward(g)
+    assert dut.storage.finds == 6 and dut.storage.inserts >= 6 and dut.size() == int(ref.size())
+    # every row the store holds equals the HBM module's row (embedding and optimizer state)
+    probe = torch.arange(0, 300, device="cuda", dtype=torch.int64)
+    for t in range(len(dims)):
+        f1, r1 = ref.lookup_rows(probe, t)
+        for k in probe[f1].tolist():
+            torch.testing.assert_close(dut.storage.rows[(t, k)][: r1.size(1)], r1[k], rtol=1e-5, atol=1e-6)
+        assert sum(1 for (tt, _k) in dut.storage.rows if tt == t) == int(f1.sum())
+    # eval: known keys from the store, unknown keys -> the eval initializer (zeros), nothing inserted
+    ref.eval(); dut.eval()
+    ek = torch.from_numpy(rng.integers(0, 600, F * B).astype(np.int64)).cuda()
+    eo = torch.arange(0, F * B + 1, dtype=torch.int64, device="cuda")
+    n_before = dut.size()
+    with torch.no_grad():
+        torch.testing.assert_close(dut(ek, eo), ref(ek, eo), rtol=1e-6, atol=1e-6)
+    assert dut.size() == n_before
+
+
+def test_external_storage_rejects_what_it_cannot_do():
+    from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
+    from dynamicemb.dynamicemb_config import DynamicEmbTableOptions
+
+    mk = lambda **kw: [DynamicEmbTableOptions(dim=8, max_capacity=1024, index_type=torch.int64, embedding_dtype=torch.float32,  # noqa: E731
+                                              external_storage=_DictStore, **kw)]
+    with pytest.raises(NotImplementedError, match="caching"):
+        BatchedDynamicEmbeddingTablesV2(mk(caching=True), device=torch.device("cuda", 0))
+    m = BatchedDynamicEmbeddingTablesV2(mk(), device=torch.device("cuda", 0))
+    with pytest.raises(NotImplementedError, match="prefetch"):
+        m.prefetch(torch.zeros(1, dtype=torch.int64, device="cuda"), torch.tensor([0, 1], device="cuda"))
