@@ -343,8 +343,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         if self._admit_strategy is not None:
             if self._admission_counter is None:
                 raise ValueError("admit_strategy needs an admission_counter (KVCounter) per table")
-            if storage_mode != "hbm":
-                raise NotImplementedError("admission with host / hybrid storage")
+            if storage_mode == "hybrid":    # (HBM-only and host-only tables take the same admission walk: one table, rows by address)
+                raise NotImplementedError("admission with hybrid (HBM + host) storage")
         self.table_ptrs = torch.tensor([v.data_ptr() for v in self.values], dtype=torch.int64, device=self.device_)
         self.table_value_dims = torch.tensor(self.value_dims, dtype=torch.int64, device=self.device_)
         self.table_emb_dims = torch.tensor(self.dims, dtype=torch.int64, device=self.device_)

@@ -577,17 +577,19 @@ def test_c1_matches_torch_embedding_bag():
 
 
 # ------------------------------------------------------------------------------------------ admission
+@pytest.mark.parametrize("storage", ["hbm", "host"])
 @pytest.mark.parametrize("prefetch", [False, True])
 @pytest.mark.parametrize("threshold", [1, 3, 5])
 @pytest.mark.parametrize("pooling", ["SUM", "NONE"])
-def test_frequency_admission_against_dict_twin(threshold, pooling, prefetch):
+def test_frequency_admission_against_dict_twin(threshold, pooling, prefetch, storage):
     """FrequencyAdmissionStrategy + KVCounter (reference test/unit_tests/test_embedding_admission.py: only keys whose
     accumulated frequency reached the threshold are stored).  Stronger than the reference's set invariant: a dict twin
     replays the admission rule step by step (batch frequency of every MISSING unique key is added to its counter; it is
     admitted -- and leaves the counter -- when the sum reaches the threshold; a rejected key is served a constant 0
     row and gets no update), so the stored key set, the counter population, every pooled output and every row after
     SGD must match.  prefetch: batch i + 1 walks the admission path (prefetch()) BEFORE batch i's backward, as the reference's
-    prefetch pipeline does (batched_dynamicemb_function.py:559-696); the stored set, the outputs and the rows are the same."""
+    prefetch pipeline does (batched_dynamicemb_function.py:559-696); the stored set, the outputs and the rows are the same.
+    storage = "host": the table and its rows in pinned host memory (the same walk over the host link)."""
     (B2, IA, IM, PM, SS, TO, OT) = _mods()
     from dynamicemb.embedding_admission import FrequencyAdmissionStrategy, KVCounter
 
@@ -597,8 +599,9 @@ def test_frequency_admission_against_dict_twin(threshold, pooling, prefetch):
                initializer_args=IA(mode=IM.CONSTANT, value=0.25), score_strategy=SS.TIMESTAMP,
                admit_strategy=strategy, admission_counter=KVCounter(capacity=4096, bucket_capacity=128))]
     m = B2(table_options=opts, table_names=["t0"], feature_table_map=[0, 0], pooling_mode=getattr(PM, pooling),
-           optimizer=OT.SGD, learning_rate=lr, output_dtype=torch.float32, device=torch.device(DEV))
+           optimizer=OT.SGD, learning_rate=lr, output_dtype=torch.float32, device=torch.device(DEV), storage_mode=storage)
     m.train()
+    assert m.storage_mode == storage
     rng = np.random.default_rng(threshold * 7 + len(pooling))
     rows, counter = {}, {}
     batches = []
