@@ -581,8 +581,10 @@ def block_bucketize_sparse_features(lengths, indices, bucketize_pos, sequence, d
                                     block_bucketize_pos=None):
     """block_bucketize_sparse_features (sparse_block_bucketize_features.cu:366-830) ->
     (new_lengths, new_indices, new_weights, new_pos, unbucketize_permute)."""
-    if bucketize_pos or block_bucketize_pos is not None or batch_size_per_feature is not None:
-        raise NotImplementedError("positional / variable-batch bucketize is out of scope (DESIGN.md)")
+    if block_bucketize_pos is not None or batch_size_per_feature is not None:
+        raise NotImplementedError("uneven shard boundaries / variable batch size per feature in bucketize (DESIGN.md)")
+    want_perm = sequence
+    sequence = sequence or bucketize_pos      # (the positions travel with the permutation)
     FB = lengths.numel()
     F = block_sizes.numel()
     B = FB // F
@@ -598,7 +600,15 @@ def block_bucketize_sparse_features(lengths, indices, bucketize_pos, sequence, d
     check(lib().mi355_block_bucketize(my_size, FB, B, ptr(offsets), ptr(indices), ptr(block_sizes.to(torch.int64)),
                                       ptr(dist), ptr(weights), ptr(new_lengths), ptr(new_offsets), ptr(new_indices),
                                       ptr(new_w), ptr(perm), stream()), "block_bucketize")
-    return new_lengths.to(lengths.dtype), new_indices, new_w, None, perm
+    new_pos = None
+    if bucketize_pos:
+        # bucketize_pos (sparse_block_bucketize_features.cu:366-830, `new_pos`): the position every value had inside its ORIGINAL
+        # bag, carried to the value's place in the bucketized order (what TorchRec's position-weighted feature processors read)
+        n = indices.numel()
+        bag = torch.repeat_interleave(torch.arange(FB, device=dev), lengths.to(torch.int64), output_size=n)
+        new_pos = torch.empty(n, dtype=indices.dtype, device=dev)
+        new_pos[perm] = (torch.arange(n, device=dev) - offsets[bag]).to(indices.dtype)
+    return new_lengths.to(lengths.dtype), new_indices, new_w, new_pos, (perm if want_perm else None)
 
 
 # ------------------------------------------------------------------------------ value ops ----

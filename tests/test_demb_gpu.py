@@ -330,6 +330,30 @@ def test_expand_table_ids_table_range_compact():
         assert (ca.cpu().numpy() == a[flags]).all() and (cb.cpu().numpy() == b[flags]).all()
 
 
+@pytest.mark.parametrize("W", [1, 3, 8])
+def test_block_bucketize_positions(W):
+    """bucketize_pos=True: new_pos[j] = the position the j-th bucketized value had inside its original bag
+    (reference: block_bucketize_sparse_features, sparse_block_bucketize_features.cu:366-830, called with bucketize_pos by
+    input_dist.py:140-155 for position-weighted features); the permutation is returned only when asked for."""
+    e = ext()
+    rng = np.random.default_rng(W + 40)
+    F, B = 2, 7
+    lens = rng.integers(0, 40, size=F * B)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    idx = rng.integers(0, 1000, size=int(offsets[-1])).astype(np.int64)
+    blk = np.array([1000 // W + 1] * F, np.int64)
+    nl, ni, _, pos, perm = e.block_bucketize_sparse_features(T(lens.astype(np.int64)), T(idx), True, True, T(np.array([0, 1], np.int32)), T(blk), W)
+    nl2, ni2, _, pos2, perm2 = e.block_bucketize_sparse_features(T(lens.astype(np.int64)), T(idx), True, False, T(np.array([0, 1], np.int32)), T(blk), W)
+    assert perm2 is None and torch.equal(pos, pos2) and torch.equal(ni, ni2) and torch.equal(nl, nl2)
+    perm, pos, ni = perm.cpu().numpy(), pos.cpu().numpy(), ni.cpu().numpy()
+    bag = np.repeat(np.arange(F * B), lens)
+    within = np.arange(idx.size) - offsets[bag]
+    assert sorted(perm.tolist()) == list(range(idx.size))   # value j went to place perm[j] (its new value is the shard-local id) ...
+    assert (pos[perm] == within).all()                      # ... and took its in-bag position along
+    with pytest.raises(NotImplementedError):
+        e.block_bucketize_sparse_features(T(lens.astype(np.int64)), T(idx), False, False, None, T(blk), W, batch_size_per_feature=T(np.array([B, B])))
+
+
 @pytest.mark.parametrize("W", [1, 2, 8, 70])
 def test_block_bucketize_exact(W):
     e = ext()
