@@ -53,8 +53,6 @@ class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
                  weight_decay_mode=None, eta=0.001, beta1=0.9, beta2=0.999, counter_based_regularization=None,
                  cowclip_regularization=None, storage_mode=None, *args, **kwargs):
         nn.Module.__init__(self)
-        from itertools import accumulate
-
         from .batched_dynamicemb_tables import _OPT_KIND, EmbOptimType, get_optimizer_state_dim
 
         optimizer = optimizer if optimizer is not None else EmbOptimType.SGD
@@ -191,7 +189,6 @@ class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
         combiner = (0 if self.pooling_mode == DynamicEmbPoolingMode.SUM else 1) if pooled else -1
         g = ext.reduce_grads(st.rev, grads.contiguous(), st.nu, st.batch_size, D, st.offsets if pooled else None, None, combiner,
                              self.total_D)
-        g = g.to(st.values.dtype) if g.dtype != st.values.dtype and self._opt_kind == 1 else g
         vals, tid = st.values, st.tids
         dims_t = torch.tensor(self.dims, dtype=torch.int64, device=self.device_)
         al = D % 4 == 0 and V % 4 == 0
