@@ -299,6 +299,26 @@ __device__ __forceinline__ void stage_rows(uint16_t* dst, const uint16_t* src, i
 #ifndef HSTU_TIMING
 #define HSTU_TIMING 0
 #endif
+#ifndef HSTU_XCH_NT
+#define HSTU_XCH_NT 0   // 1 = P / dS exchange tiles with non-temporal stores (dK pass) and loads (one-GEMM passes): written once, read once,
+                        // 0.5 GB each at 8 x 4096, they evict the Q / dO / K rows the same kernels stream through L2 again and again (TCC
+                        // counters: those rows miss L2 3-7 x, profiles/r04_pmc_hstu_traffic.txt).  Measured: -1..-2 % (8 x 4096 backward 648 against
+                        // 659-666 TFLOP/s, C3 140-149 against 137-144 us): off.
+#endif
+__device__ __forceinline__ void xch_store(u32x4_t* p, const u32x4_t& v) {
+#if HSTU_XCH_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ u32x4_t xch_load(const u32x4_t* p) {
+#if HSTU_XCH_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
 #ifndef HSTU_X8_PROBE
 #define HSTU_X8_PROBE 0   // timing probes of the one-GEMM passes (results wrong): 1 = no fragment reads after the first batch, 2 = no exchange loads, 4 = no DMA after the first step
 #endif
@@ -3404,7 +3424,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_v_p8_kernel
       const int it = i + 32 * t;
       if (!(HSTU_X8_PROBE & 2) && wave_live && visited(it) && !xch_absent(xu, key0 >> 5, it >> 5)) {
         const u32x4_t* tp = reinterpret_cast<const u32x4_t*>(g.p_ws + xch_tile(xu, key0 >> 5, it >> 5)) + 2 * lane;
-        pn0[t] = tp[0]; pn1[t] = tp[1];
+        pn0[t] = xch_load(tp); pn1[t] = xch_load(tp + 1);
       } else {
         pn0[t] = u32x4_t{0u, 0u, 0u, 0u}; pn1[t] = u32x4_t{0u, 0u, 0u, 0u};
       }
@@ -3500,7 +3520,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_q_ds8_kerne
       const int nt = n + 32 * t;
       if (!(HSTU_X8_PROBE & 2) && wave_live && nt < w_end && tile_written(nt) && !xch_absent(xu, nt >> 5, qrow0 >> 5)) {
         const u32x4_t* tp = reinterpret_cast<const u32x4_t*>(g.ds_ws + xch_tile(xu, nt >> 5, qrow0 >> 5)) + 2 * lane;
-        ds0[t] = tp[0]; ds1[t] = tp[1];
+        ds0[t] = xch_load(tp); ds1[t] = xch_load(tp + 1);
       } else {
         ds0[t] = u32x4_t{0u, 0u, 0u, 0u}; ds1[t] = u32x4_t{0u, 0u, 0u, 0u};
       }
@@ -3737,7 +3757,7 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
         hp[0] = y0; hp[64] = y1;                                  // dS -> the K wave of the pair (next step)
         if (i0 < s.L && !xch_absent(xu, key0 >> 5, i0 >> 5)) {    // P and dS -> the one-GEMM dV / dQ passes
           u32x4_t* tp = reinterpret_cast<u32x4_t*>(g.p_ws + xch_tile(xu, key0 >> 5, i0 >> 5)) + 2 * lane;
-          tp[0] = u32x4_t{pk[0], pk[1], pk[2], pk[3]}; tp[1] = u32x4_t{pk[4], pk[5], pk[6], pk[7]};
+          xch_store(tp, u32x4_t{pk[0], pk[1], pk[2], pk[3]}); xch_store(tp + 1, u32x4_t{pk[4], pk[5], pk[6], pk[7]});
         }   // (dS goes to the exchange buffer from the K wave, which has it in registers one step later: two stores fewer here)
       };
       auto ew = [&](auto modec) { if (tail) elementwise(modec, std::true_type{}); else elementwise(modec, std::false_type{}); };
@@ -3816,7 +3836,7 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
     sf[1] = __builtin_bit_cast(bf16x8_t, y1);
     if (ip < s.L && !xch_absent(xu, key0 >> 5, ip >> 5)) {   // dS of that step -> the one-GEMM dQ pass
       u32x4_t* tq = reinterpret_cast<u32x4_t*>(g.ds_ws + xch_tile(xu, key0 >> 5, ip >> 5)) + 2 * lane;
-      tq[0] = y0; tq[1] = y1;
+      xch_store(tq, y0); xch_store(tq + 1, y1);
     }
     const uint16_t* tile = Qt + (PAR ^ 1) * IMG;
     constexpr int NB = 4;
