@@ -3587,6 +3587,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_q_ds8_kerne
 // the S waves) and Q rows once more under the V-style swizzle (transpose reads of the K waves).  One barrier per step,
 // every ring two deep; the step loop is unrolled by two so that every LDS address is a register plus an immediate.
 // Same MFMA order and roundings as hstu_bwd_kv_kernel<256, 32, 2>: bit-identical dK, P and dS.
+// Measured and rejected: the S waves in two types -- wave 2 t holds the K fragments of BOTH key tiles of pair t and computes S for
+// 64 keys, wave 2 t + 1 the V fragments and dP, each hands the other tile's accumulator over through LDS behind a second barrier
+// (every Q / dO fragment read then feeds two MFMAs: 64 KB of LDS reads per step instead of 128).  Same time (8 x 4096 backward
+// 641-644 against 644-646 TFLOP/s, profiles/r04_hstu_bwd_split_ab.txt): the stamps put the S waves' GEMM phase at 1 690 clocks
+// either way -- it is not the fragment reads that pace those 32 MFMAs.
 // ---------------------------------------------------------------------------------------------------
 template <int D>
 __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
