@@ -168,6 +168,20 @@ __device__ __forceinline__ void pin_agpr(f32x16_t (&c)[N]) {
 }
 template <int N> __device__ __forceinline__ void fence_v(f32x16_t (&)[N]) {}   // builtins: the compiler inserts the waits
 template <int N> __device__ __forceinline__ void fence_a(f32x16_t (&c)[N]) { pin_agpr(c); }
+// The kernels that run TWO waves per SIMD (256 registers per wave) must not mention AGPRs at all: one "+a" constraint makes hipcc
+// split the file 128 VGPRs + 128 AGPRs, and every value beyond the 128 -- the K / V / Q fragment sets of the S waves -- is then
+// parked in AGPRs and copied back with four v_accvgpr_read_b32 (+ s_nop) in front of EVERY MFMA that uses it: 50 clocks per MFMA
+// instead of 32 in the dK pass's S waves.  Without the pins the same kernels get up to 242 architectural VGPRs, no AGPRs, no copies.
+#ifndef HSTU_2W_AGPR
+#define HSTU_2W_AGPR 0
+#endif
+template <int N>
+__device__ __forceinline__ void pin_agpr_2w(f32x16_t (&c)[N]) {
+#if HSTU_2W_AGPR
+  pin_agpr(c);
+#endif
+}
+template <int N> __device__ __forceinline__ void fence_a_2w(f32x16_t (&c)[N]) { pin_agpr_2w(c); }
 
 // Row-side mask state of one query (causal case).  M(i, j) of the reference collapses to
 //   j <= jmax  and  (j < hlen  or  j >= jlo)
@@ -1411,9 +1425,9 @@ __global__ void __launch_bounds__(512) hstu_fwd_pc_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc_o[dt][r] = 0.f;
     for (int it = 0; it <= T; ++it) {
-      pin_agpr(acc_o);
+      pin_agpr_2w(acc_o);
       head(it);
-      pin_agpr(acc_o);
+      pin_agpr_2w(acc_o);
       const int tl = it - 1, n0 = n_beg + kBN * tl;
       const bool live = it != 0 && wave_live && n0 < w_end && n0 >= w_beg;
       // HSTU_PC_DSPREAD: this wave's DMA share (K tile it + 1, V tile it) is dealt over the first MFMA batches of GEMM 2
@@ -1449,7 +1463,7 @@ __global__ void __launch_bounds__(512) hstu_fwd_pc_kernel(AttnArgs a) {
         };
 #pragma unroll
         for (int bi = 0; bi < NVB - 1; ++bi) load_v(bi);
-        pin_agpr(acc_o);
+        pin_agpr_2w(acc_o);
 #pragma unroll
         for (int bi = 0; bi < NBAT2; ++bi) {
           const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
@@ -1487,7 +1501,7 @@ __global__ void __launch_bounds__(512) hstu_fwd_pc_kernel(AttnArgs a) {
   t_dump();
 #endif
   {
-    fence_a(acc_o);
+    fence_a_2w(acc_o);
     if (qloc < Lq) {
       uint16_t* op = a.out + (int64_t)(s.start + qloc) * a.o_row + (int64_t)h * a.o_head;
 #pragma unroll
@@ -1756,7 +1770,7 @@ __global__ void __launch_bounds__(512) hstu_fwd_pair_kernel(AttnArgs a) {
       for (int r = 0; r < 16; ++r) acc_o[dt][r] = 0.f;
   };
   auto store_rows = [&](int qloc) {
-    fence_a(acc_o);
+    fence_a_2w(acc_o);
     if (qloc < Lq) {
       uint16_t* op = a.out + (int64_t)(s.start + qloc) * a.o_row + (int64_t)h * a.o_head;
 #pragma unroll
@@ -1773,12 +1787,12 @@ __global__ void __launch_bounds__(512) hstu_fwd_pair_kernel(AttnArgs a) {
   zero_acc();
   if (N > 0) issue_dma(kg, a.k_row, kvoff, Kring, 0);
   auto o_iter = [&](int it) {
-    pin_agpr(acc_o);
+    pin_agpr_2w(acc_o);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces (K item it, V item it - 1) have landed ...
     __syncthreads();                                    // ... everyone's have, P[it - 1] is written, the other buffers are free
     if (it + 1 < N) issue_dma(kg, a.k_row, kvoff, Kring, it + 1);
     if (it < N) issue_dma(vg, a.v_row, vvoff, Vring, it);
-    pin_agpr(acc_o);
+    pin_agpr_2w(acc_o);
     const int tl = it - 1;
     if (tl >= 0) {
       const bool second = tl >= T0;
@@ -1801,7 +1815,7 @@ __global__ void __launch_bounds__(512) hstu_fwd_pair_kernel(AttnArgs a) {
         };
 #pragma unroll
         for (int bi = 0; bi < NVB - 1; ++bi) load_v(bi);
-        pin_agpr(acc_o);
+        pin_agpr_2w(acc_o);
 #pragma unroll
         for (int bi = 0; bi < NBAT2; ++bi) {
           const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
@@ -2160,7 +2174,7 @@ __global__ void __launch_bounds__(512) hstu_fwd_q2_kernel(AttnArgs a) {
       for (int r = 0; r < 16; ++r) acc_o[t][r] = 0.f;
   };
   auto store_rows = [&](const Blk& k) {
-    fence_a(acc_o);
+    fence_a_2w(acc_o);
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       const int qloc = k.hrow0 + 32 * qt + l31;
@@ -2181,7 +2195,7 @@ __global__ void __launch_bounds__(512) hstu_fwd_q2_kernel(AttnArgs a) {
   zero_acc();
   if (N > 0) issue_dma(kg, a.k_row, kvoff, Kring, 0);
   auto o_iter = [&](int it, const Blk& k, int t_in) {     // k, t_in: the block and tile of item it - 1 (t_in < 0: none)
-    pin_agpr(acc_o);
+    pin_agpr_2w(acc_o);
     TICK(t0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces (K item it, V item it - 1) have landed ...
     TICK(t1);
@@ -2189,7 +2203,7 @@ __global__ void __launch_bounds__(512) hstu_fwd_q2_kernel(AttnArgs a) {
     TICK(t2);
     if (it + 1 < N) issue_dma(kg, a.k_row, kvoff, Kring, it + 1);
     if (it < N) issue_dma(vg, a.v_row, vvoff, Vring, it);
-    pin_agpr(acc_o);
+    pin_agpr_2w(acc_o);
     TICK(t3);
     TACC(0, t0, t1); TACC(1, t1, t2); TACC(2, t2, t3);
     const int tl = it - 1;
@@ -2211,7 +2225,7 @@ __global__ void __launch_bounds__(512) hstu_fwd_q2_kernel(AttnArgs a) {
         };
 #pragma unroll
         for (int bi = 0; bi < NVB - 1; ++bi) load_v(bi);
-        pin_agpr(acc_o);
+        pin_agpr_2w(acc_o);
 #pragma unroll
         for (int bi = 0; bi < NBAT2; ++bi) {
           const int ks = bi / (4 / DB), dtl0 = (bi % (4 / DB)) * DB;
@@ -3434,7 +3448,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_v_p8_kernel
   if (i0 < i_lim) { dma.issue(dobase, g.do_row, i0, s.L, smem, lane); fetch_p(i0); }
   auto step = [&](auto bufc) {
     constexpr int BUF = decltype(bufc)::value;
-    pin_agpr(acc);
+    pin_agpr_2w(acc);
     bf16x8_t pf[2 * NT];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the step (and its P words) have arrived
 #pragma unroll
@@ -3444,7 +3458,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_v_p8_kernel
       const int nx = advance(i0);
       if (nx < i_lim) { if (!(HSTU_X8_PROBE & 4)) dma.issue(dobase, g.do_row, nx, s.L, smem + (BUF ^ 1) * TILE, lane); fetch_p(nx); }
     }
-    pin_agpr(acc);
+    pin_agpr_2w(acc);
     if (wave_live) gemm_x8<BUF>(acc, smem, pf, lane, hi);
     i0 = advance(i0);
   };
@@ -3453,7 +3467,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_v_p8_kernel
     if (i0 >= i_lim) break;
     step(std::integral_constant<int, 1>{});
   }
-  fence_a(acc);
+  fence_a_2w(acc);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (kj < s.L) store_acc_rows<D>(acc, g.dv + ((int64_t)(s.start + kj) * a.H + h) * D, hi);
 }
@@ -3530,7 +3544,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_q_ds8_kerne
   int n0 = n_beg;
   auto step = [&](auto bufc) {
     constexpr int BUF = decltype(bufc)::value;
-    pin_agpr(acc);
+    pin_agpr_2w(acc);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the wave's dS sub-tiles of this step -> its private patch (read back transposed below; the previous step's reads of the
     // patch are complete: their MFMAs have been issued)
@@ -3541,7 +3555,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_q_ds8_kerne
     }
     __syncthreads();
     if (n0 + BK < n_end) { if (!(HSTU_X8_PROBE & 4)) dma.issue(kbase, a.k_row, n0 + BK, s.L, smem + (BUF ^ 1) * TILE, lane); fetch_ds(n0 + BK); }
-    pin_agpr(acc);
+    pin_agpr_2w(acc);
     if (wave_live && n0 < w_end && n0 >= w_beg) {
       bf16x8_t sf[2 * NT];
 #pragma unroll
@@ -3563,7 +3577,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_q_ds8_kerne
     if (n0 >= n_end) break;
     step(std::integral_constant<int, 1>{});
   }
-  fence_a(acc);
+  fence_a_2w(acc);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (qi < s.L) store_acc_rows<D>(acc, g.dq + ((int64_t)(s.start + qi) * a.H + h) * D, hi);
 }
@@ -3803,7 +3817,7 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
   int cur = first, prev_valid = 0, prev_i = 0;
   auto step = [&](auto parc) {
     constexpr int PAR = decltype(parc)::value;
-    pin_agpr(acc_dk);
+    pin_agpr_2w(acc_dk);
     TICK(t0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TICK(t1);
@@ -3824,7 +3838,7 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
     }
     prev_valid = have;
     cur = nxt;
-    pin_agpr(acc_dk);
+    pin_agpr_2w(acc_dk);
     if (HSTU_KVPC_MIDBAR) __builtin_amdgcn_s_barrier();
     TICK(t3);
     TACC(2, t2, t3);
@@ -3870,7 +3884,7 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
     if (!(cur < i_lim || prev_valid)) break;
     step(std::integral_constant<int, 1>{});
   }
-  fence_a(acc_dk);
+  fence_a_2w(acc_dk);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if HSTU_TIMING
   t_dump();
