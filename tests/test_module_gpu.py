@@ -852,6 +852,23 @@ class _DictStore:
                 return (len(miss), unique_keys[midx], midx, table_ids[midx], None, torch.tensor(found, dtype=torch.bool, device=dev),
                         torch.zeros(unique_keys.numel(), dtype=torch.int64, device=dev), vals)
 
+            def dump(self, table_id, meta_file_path, emb_key_path, embedding_file_path, score_file_path, opt_file_path, **kw):
+                items = sorted((k, r) for (t, k), r in self.rows.items() if t == table_id)
+                np.asarray([k for k, _ in items], np.int64).tofile(emb_key_path)
+                rows = torch.stack([r for _, r in items]).float().cpu().numpy() if items else np.zeros((0, self.value_dim), np.float32)
+                rows[:, :self.emb_dim].tofile(embedding_file_path)
+                np.asarray([self.scores.get((table_id, k), 0) for k, _ in items], np.int64).tofile(score_file_path)
+                if opt_file_path is not None:
+                    rows[:, self.emb_dim:].tofile(opt_file_path)
+
+            def load(self, table_id, meta_file_path, emb_key_path, embedding_file_path, score_file_path, opt_file_path, **kw):
+                keys = np.fromfile(emb_key_path, np.int64)
+                emb = np.fromfile(embedding_file_path, np.float32).reshape(len(keys), self.emb_dim)
+                opt = (np.fromfile(opt_file_path, np.float32).reshape(len(keys), -1) if opt_file_path is not None
+                       else np.zeros((len(keys), self.value_dim - self.emb_dim), np.float32))
+                for k, e, o in zip(keys.tolist(), emb, opt):
+                    self.rows[(table_id, k)] = torch.from_numpy(np.concatenate([e, o])).to("cuda")
+
             def insert(self, keys, table_ids, values, scores=None, preserve_existing=False):
                 self.inserts += 1
                 sc = scores.cpu().tolist() if scores is not None else None
@@ -926,6 +943,41 @@ def test_external_storage_is_transparent(pooling, optimizer):
     with torch.no_grad():
         torch.testing.assert_close(dut(ek, eo), ref(ek, eo), rtol=1e-6, atol=1e-6)
     assert dut.size() == n_before
+
+
+def test_external_storage_dump_and_load_go_through_the_store(tmp_path):
+    """dump() / load() of a module over an external store hand the reference's per-table file names to Storage.dump / Storage.load
+    (batched_dynamicemb_tables.py:73-92): a second module over a fresh store serves the same rows after load()."""
+    import os
+
+    from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
+    from dynamicemb.dynamicemb_config import DynamicEmbPoolingMode, DynamicEmbTableOptions, EmbOptimType
+
+    def make():
+        opts = [DynamicEmbTableOptions(dim=8, max_capacity=1024, index_type=torch.int64, embedding_dtype=torch.float32,
+                                       external_storage=_DictStore) for _ in range(2)]
+        return BatchedDynamicEmbeddingTablesV2(opts, table_names=["a", "b"], pooling_mode=DynamicEmbPoolingMode.NONE,
+                                               optimizer=EmbOptimType.ADAM, learning_rate=0.1, device=torch.device("cuda", 0))
+
+    m = make()
+    m.train()
+    keys = torch.arange(0, 40, device="cuda", dtype=torch.int64)
+    off = torch.arange(0, 41, device="cuda", dtype=torch.int64)      # 2 features x 20 samples, one key each
+    out = m(keys, off)
+    out.backward(torch.ones_like(out))
+    m.dump(str(tmp_path), optim=True)
+    for name in ("a", "b"):
+        for item in ("keys", "values", "scores", "opt_values"):
+            assert os.path.exists(tmp_path / f"{name}_emb_{item}.rank_0.world_size_1"), (name, item)
+        assert os.path.exists(tmp_path / f"{name}_opt_args.json")
+    m2 = make()
+    m2.load(str(tmp_path), optim=True)
+    assert m2.size() == m.size() == 40
+    m.eval(); m2.eval()
+    with torch.no_grad():
+        assert torch.equal(m2(keys, off), m(keys, off))
+    for kk, r in m.storage.rows.items():
+        assert torch.equal(m2.storage.rows[kk], r)
 
 
 def test_external_storage_rejects_what_it_cannot_do():
