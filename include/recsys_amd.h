@@ -451,6 +451,27 @@ int mi355_hstu_attn_fwd_kv(const void* q, const void* k, const void* v, void* ou
                            const int32_t* page_ids, const int32_t* last_page_lens, int64_t page_size,
                            hipStream_t stream);
 
+/* mi355_hstu_attn_fwd_kv under a local attention window (hstu_attn_varlen_func(window_size=(left, right)) with cu_seqlens_k longer
+ * than cu_seqlens_q and / or kv_cache; the reference composes Is_local with the delta-q offset and Paged_KV, hstu_fwd.h:104-131,
+ * 463-470,516-545): the window runs over absolute positions, query r of a sequence sitting at Lk - Lq + r.  No contextual /
+ * target rows (hstu_attn_interface.py:238-245). */
+int mi355_hstu_attn_fwd_kv_window(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride,
+                                  int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride,
+                                  int64_t k_head_stride, int64_t v_head_stride, int64_t o_head_stride,
+                                  const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int64_t batch, int64_t num_heads,
+                                  int64_t head_dim, int64_t max_seqlen_q, int64_t window_left, int64_t window_right,
+                                  float alpha, float scaling_seqlen, const void* kv_cache, const int32_t* page_offsets,
+                                  const int32_t* page_ids, const int32_t* last_page_lens, int64_t page_size,
+                                  hipStream_t stream);
+int mi355_hstu_attn_fwd_kv_window_f16(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride,
+                                      int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride,
+                                      int64_t k_head_stride, int64_t v_head_stride, int64_t o_head_stride,
+                                      const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int64_t batch, int64_t num_heads,
+                                      int64_t head_dim, int64_t max_seqlen_q, int64_t window_left, int64_t window_right,
+                                      float alpha, float scaling_seqlen, const void* kv_cache, const int32_t* page_offsets,
+                                      const int32_t* page_ids, const int32_t* last_page_lens, int64_t page_size,
+                                      hipStream_t stream);
+
 /* append_kvcache (torch.ops.paged_kvcache_ops.append_kvcache, examples/commons/ops/cuda_ops/csrc/
  * paged_kvcache_ops_kernel.cu:106-140, call site paged_hstu_infer_layer.py:350-364): new-history token i (i < *nnz_dev,
  * or < max_nnz when max_nnz > 0) of sequence batch_indices[i] is written at position positions[i] of that user's

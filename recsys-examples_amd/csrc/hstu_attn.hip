@@ -453,7 +453,10 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
   u32x4_t kreg[KPT], vreg[kVTR ? 1 : VPT][4], vrow[kVTR ? KPT : 1];
   // key j of the sequence: cached token (page table walk) or a token of k / v.  With a cache, k / v hold
   // [new history | candidates] per sequence and only the candidates are read from them (the history is in the cache).
-  const int64_t tok0 = paged ? (int64_t)s.start + (Lq - ntgt) - cachelen : (int64_t)kstart;
+  // (the keys that are not in the cache are the LAST Lk - cachelen rows of the sequence's k / v: key j >= cachelen is row Lq - Lk + j.
+  //  With the candidates as targets that is the former Lq - ntgt - cachelen + j; written this way it also holds without targets,
+  //  e.g. under a local window)
+  const int64_t tok0 = paged ? (int64_t)s.start + Lq - s.L : (int64_t)kstart;
   const uint16_t* kbase = a.k + (int64_t)h * a.k_head;
   const uint16_t* vbase = a.v + (int64_t)h * a.v_head;
   const int64_t pg_slot = (int64_t)a.H * D, pg_kv = (int64_t)a.page_size * pg_slot;
@@ -4431,6 +4434,25 @@ int HSTU_FN(mi355_hstu_attn_fwd_window)(const void* q, const void* k, const void
                                      k_head_stride, v_head_stride, o_head_stride, cu_seqlens, batch, num_heads, head_dim,
                                      max_seqlen, nullptr, nullptr, 1, window_causal(window_left, window_right), alpha,
                                      scaling_seqlen, stream);
+  tl_wl = tl_wr = -1;
+  return rc;
+}
+
+// The inference forward (delta-q keys, paged cache) with a local attention window (hstu_fwd.h:104-131,463-470,516-545 compose
+// Is_local with the query offset and Paged_KV): the window is taken over ABSOLUTE positions -- query r of a sequence sits at Lk - Lq + r.
+int HSTU_FN(mi355_hstu_attn_fwd_kv_window)(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride,
+                                  int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride,
+                                  int64_t k_head_stride, int64_t v_head_stride, int64_t o_head_stride, const int32_t* cu_seqlens_q,
+                                  const int32_t* cu_seqlens_k, int64_t batch, int64_t num_heads, int64_t head_dim,
+                                  int64_t max_seqlen_q, int64_t window_left, int64_t window_right, float alpha,
+                                  float scaling_seqlen, const void* kv_cache, const int32_t* page_offsets,
+                                  const int32_t* page_ids, const int32_t* last_page_lens, int64_t page_size, hipStream_t stream) {
+  MI355_CHECK_ARG(window_left >= -1 && window_right >= -1 && window_left < (1 << 30) && window_right < (1 << 30), "bad window");
+  tl_wl = (int)window_left; tl_wr = window_right == 0 ? -1 : (int)window_right;
+  const int rc = HSTU_FN(mi355_hstu_attn_fwd_kv)(q, k, v, out, q_row_stride, k_row_stride, v_row_stride, o_row_stride, q_head_stride,
+                                        k_head_stride, v_head_stride, o_head_stride, cu_seqlens_q, cu_seqlens_k, batch, num_heads,
+                                        head_dim, max_seqlen_q, nullptr, nullptr, 1, window_causal(window_left, window_right), alpha,
+                                        scaling_seqlen, kv_cache, page_offsets, page_ids, last_page_lens, page_size, stream);
   tl_wl = tl_wr = -1;
   return rc;
 }

@@ -40,13 +40,15 @@ N.register_signatures({
                                    c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_f, c_p, c_i64, c_p],
     "mi355_hstu_attn_fwd_kv": [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64,
                                c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_int, c_f, c_f, c_p, c_p, c_p, c_p, c_i64, c_p],
+    "mi355_hstu_attn_fwd_kv_window": [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64,
+                                      c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_f, c_p, c_p, c_p, c_p, c_i64, c_p],
     "mi355_append_kvcache": [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p,
                              c_i64, c_i64, c_p],
 }, {"mi355_hstu_attn_bwd_workspace_bytes": c_i64, "mi355_hstu_attn_bwd_ds_bytes": c_i64,
     "mi355_hstu_attn_bwd_ds_bytes_capped": c_i64, "mi355_hstu_attn_bwd_hint_tokens": None,
     "mi355_hstu_attn_fwd_hint_tokens": None, "mi355_hstu_attn_fwd_hint_tokens_f16": None})
 # the fp16-operand twins of the seven type-specific entry points (same argument lists)
-_TYPED = ("mi355_hstu_attn_fwd_hint_tokens", "mi355_hstu_attn_fwd", "mi355_hstu_attn_fwd_kv", "mi355_hstu_attn_bwd", "mi355_hstu_attn_fwd_window",
+_TYPED = ("mi355_hstu_attn_fwd_hint_tokens", "mi355_hstu_attn_fwd", "mi355_hstu_attn_fwd_kv", "mi355_hstu_attn_fwd_kv_window", "mi355_hstu_attn_bwd", "mi355_hstu_attn_fwd_window",
           "mi355_hstu_attn_bwd_window", "mi355_hstu_attn_fwd_rab", "mi355_hstu_attn_bwd_rab")
 N.register_signatures({n + "_f16": N.signature_of(n) for n in _TYPED})
 
@@ -87,8 +89,6 @@ def _check_inputs(q, k, v, cu_q, cu_k, num_contexts, num_targets, window_size, r
     if num_targets is not None and (wl, wr) != (-1, 0):
         raise ValueError("AssertError: target is True and causal is not True, this is undefined behavior")
     local = not (wl == -1 and wr in (-1, 0))
-    if local and kv_cache is not None:
-        raise NotImplementedError("local attention windows over a paged KV cache are not supported")
     causal = wr == 0 and not local
     if q.shape[-1] not in (32, 64, 128, 256):
         raise RuntimeError("head_dim must be one of 32, 64, 128, 256")
@@ -111,8 +111,9 @@ def hstu_varlen_fwd(q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_context
 
 def hstu_varlen_fwd_kv(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, scaling_seqlen, num_contexts, num_targets,
                        target_group_size, causal, alpha, kv_cache=None, page_offsets=None, page_ids=None,
-                       last_page_lens=None):
-    """Inference forward: delta-q (cu_seqlens_k) and / or paged KV cache [num_pages, 2, page_size, H, d]."""
+                       last_page_lens=None, window=None):
+    """Inference forward: delta-q (cu_seqlens_k) and / or paged KV cache [num_pages, 2, page_size, H, d]; `window` = (left,
+    right) of a local attention window over absolute positions (then no contextual / target rows)."""
     T, H, D = q.shape
     out = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
     B = cu_seqlens_q.numel() - 1
@@ -127,6 +128,14 @@ def hstu_varlen_fwd_kv(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, scalin
                 raise RuntimeError(f"{name} must be an int32 tensor")
         page_size = kv_cache.size(2)
     _fn("mi355_hstu_attn_fwd_hint_tokens", q)(int(q.shape[0]))   # (dense batches take the paired-row-block kernel)
+    if window is not None:
+        check(_fn("mi355_hstu_attn_fwd_kv_window", q)(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0),
+                                                      out.stride(0), q.stride(1), k.stride(1), v.stride(1), out.stride(1),
+                                                      ptr(cu_seqlens_q), ptr(cu_seqlens_k), B, H, D, int(max_seqlen_q),
+                                                      int(window[0]), int(window[1]), c_f(alpha), c_f(float(scaling_seqlen)),
+                                                      ptr(kv_cache), ptr(page_offsets), ptr(page_ids), ptr(last_page_lens),
+                                                      page_size, stream()), "hstu_attn_fwd_kv_window")
+        return out
     check(_fn("mi355_hstu_attn_fwd_kv", q)(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
                                        q.stride(1), k.stride(1), v.stride(1), out.stride(1), ptr(cu_seqlens_q),
                                        ptr(cu_seqlens_k), B, H, D, int(max_seqlen_q), ptr(num_contexts), ptr(num_targets),
@@ -347,7 +356,11 @@ def hstu_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, seqused_q, sequse
                                      int(target_group_size), wl, wr, float(alpha), bool(has_drab))
     if not (wl == -1 and wr in (-1, 0)):
         if not same:
-            raise NotImplementedError("local attention windows with delta-q keys are not supported")
+            # inference under a local window (delta-q keys and / or the paged cache): forward only, as the plain inference path
+            if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+                raise NotImplementedError("delta-q / paged-KV attention is forward only (as in the reference's inference path)")
+            return hstu_varlen_fwd_kv(q, k, v, cu_seqlens_q, cu_seqlens_k, int(max_seqlen_q), scaling_seqlen, None, None, 1,
+                                      wr == 0, float(alpha), kv_cache, page_offsets, page_ids, last_page_lens, window=(wl, wr))
         return HstuAttnWindowFunc.apply(q, k, v, cu_seqlens_q, int(max_seqlen_k), scaling_seqlen, wl, wr, float(alpha))
     if kv_cache is not None or not same:
         # inference: keys longer than the queries and / or history keys in the paged cache; no backward

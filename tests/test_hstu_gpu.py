@@ -709,6 +709,71 @@ def test_delta_q_and_paged_random_vs_oracle(d):
     assert torch.equal(out_a, out_b)   # same keys, same order of operations -> bit-identical
 
 
+@pytest.mark.parametrize("d", [64, 256])
+@pytest.mark.parametrize("window", [(20, 0), (7, 5), (0, 0), (-1, 9), (300, 0)])
+def test_local_window_over_delta_q_and_paged_keys(d, window):
+    """A local attention window composed with delta-q keys and with the paged cache (inference; the reference composes Is_local
+    with the query offset Lk - Lq and Paged_KV, hstu_fwd.h:104-131,463-470,516-545): the window runs over ABSOLUTE positions.
+    (a) contiguous keys longer than the queries against the oracle, (b) the same keys from a paged cache: bit-identical to (a)."""
+    from hstu import append_kvcache, hstu_attn_varlen_func
+
+    rng = np.random.default_rng(d + 7 * window[0] + window[1])
+    B, H, P = 5, 2, 16
+    new_hist = rng.integers(1, 90, B)
+    num_cand = rng.integers(1, 9, B)
+    old = rng.integers(0, 150, B)
+    old[0] = 0
+    qlen = new_hist + num_cand
+    cachelen = old + new_hist
+    klen = cachelen + num_cand
+    q_off = np.concatenate([[0], np.cumsum(qlen)]).astype(np.int32)
+    k_off = np.concatenate([[0], np.cumsum(klen)]).astype(np.int32)
+    T = int(q_off[-1])
+    mk = lambda n: torch.empty(n, H, d, device=DEV).uniform_(-1, 1).bfloat16()
+    q, k_new, v_new = mk(T), mk(T), mk(T)
+    k_old, v_old = mk(int(old.sum())), mk(int(old.sum()))
+    o_off = np.concatenate([[0], np.cumsum(old)])
+    kf, vf = [], []
+    for b in range(B):
+        kf += [k_old[o_off[b]:o_off[b + 1]], k_new[q_off[b]:q_off[b + 1]]]
+        vf += [v_old[o_off[b]:o_off[b + 1]], v_new[q_off[b]:q_off[b + 1]]]
+    k_full, v_full = torch.cat(kf), torch.cat(vf)
+    alpha, scaling = 1.0 / d ** 0.5, 100.0
+    cuq, cuk = torch.from_numpy(q_off).to(DEV), torch.from_numpy(k_off).to(DEV)
+    ref = ho.hstu_attn_fwd_delta_q(q.float().cpu().numpy(), k_full.float().cpu().numpy(), v_full.float().cpu().numpy(), q_off,
+                                   k_off, alpha, scaling, window=window)
+    out_a = hstu_attn_varlen_func(q, k_full, v_full, cuq, cuk, None, None, int(qlen.max()), int(klen.max()), scaling, None, None,
+                                  window_size=window, alpha=alpha)
+    err = np.abs(out_a.float().cpu().numpy() - ref).max()
+    assert err <= 6e-3 * max(np.abs(ref).max(), 1e-3) + 1e-6, err
+    # (b) the same keys from the paged cache
+    npages = int(((cachelen + P - 1) // P).sum())
+    cache = torch.zeros(npages + 2, 2, P, H, d, dtype=torch.bfloat16, device=DEV)
+    perm = rng.permutation(npages + 2)[:npages]
+    page_ids, page_off, last = [], [0], []
+    cursor = 0
+    for b in range(B):
+        n = int((cachelen[b] + P - 1) // P)
+        pages = perm[cursor:cursor + n]
+        cursor += n
+        page_ids += pages.tolist()
+        page_off.append(len(page_ids))
+        last.append(int(cachelen[b] - (n - 1) * P))
+        for j in range(int(old[b])):
+            cache[pages[j // P], 0, j % P] = k_old[o_off[b] + j]
+            cache[pages[j // P], 1, j % P] = v_old[o_off[b] + j]
+    ti = lambda a: torch.tensor(a, dtype=torch.int32, device=DEV)
+    batch_idx = np.repeat(np.arange(B), new_hist)
+    positions = np.concatenate([old[b] + np.arange(new_hist[b]) for b in range(B)])
+    cand_off = np.concatenate([[0], np.cumsum(num_cand)])
+    append_kvcache(k_new, v_new, ti(batch_idx), ti(positions), ti(cand_off), ti([int(new_hist.sum())]), 0, cache, ti(page_ids),
+                   ti(page_off), ti(last), 0)
+    out_b = hstu_attn_varlen_func(q, k_new, v_new, cuq, cuk, None, None, int(qlen.max()), int(klen.max()), scaling, None, None,
+                                  window_size=window, alpha=alpha, kv_cache=cache, page_offsets=ti(page_off),
+                                  page_ids=ti(page_ids), last_page_lens=ti(last))
+    assert torch.equal(out_a, out_b)
+
+
 def test_paged_kvcache_ops_registration():
     """torch.ops.paged_kvcache_ops.append_kvcache exists with the reference's schema and writes the cache"""
     import paged_kvcache_ops  # noqa: F401
