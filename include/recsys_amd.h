@@ -472,6 +472,31 @@ int mi355_hstu_attn_fwd_kv_window_f16(const void* q, const void* k, const void* 
                                       const int32_t* page_ids, const int32_t* last_page_lens, int64_t page_size,
                                       hipStream_t stream);
 
+/* mi355_hstu_attn_fwd_kv with a relative attention bias (hstu_attn_varlen_func(rab=...) with cu_seqlens_k longer than
+ * cu_seqlens_q and / or kv_cache; hstu_fwd.h:104-131,516-545 with Has_rab): rab [batch][heads or 1][max_seqlen_k][max_seqlen_k]
+ * is indexed by ABSOLUTE positions -- query r of a sequence is row Lk - Lq + r.  Mask as window_size: (-1, 0) causal
+ * (num_contexts / num_targets allowed), (-1, -1) full, otherwise a local window. */
+int mi355_hstu_attn_fwd_kv_rab(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride, int64_t k_row_stride,
+                               int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride, int64_t k_head_stride,
+                               int64_t v_head_stride, int64_t o_head_stride, const int32_t* cu_seqlens_q,
+                               const int32_t* cu_seqlens_k, int64_t batch, int64_t num_heads, int64_t head_dim,
+                               int64_t max_seqlen_q, int64_t max_seqlen_k, const int32_t* num_contexts,
+                               const int32_t* num_targets, int64_t target_group_size, int64_t window_left,
+                               int64_t window_right, float alpha, float scaling_seqlen, const void* rab,
+                               int64_t rab_batch_stride, int64_t rab_head_stride, int64_t rab_row_stride, const void* kv_cache,
+                               const int32_t* page_offsets, const int32_t* page_ids, const int32_t* last_page_lens,
+                               int64_t page_size, hipStream_t stream);
+int mi355_hstu_attn_fwd_kv_rab_f16(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride, int64_t k_row_stride,
+                               int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride, int64_t k_head_stride,
+                               int64_t v_head_stride, int64_t o_head_stride, const int32_t* cu_seqlens_q,
+                               const int32_t* cu_seqlens_k, int64_t batch, int64_t num_heads, int64_t head_dim,
+                               int64_t max_seqlen_q, int64_t max_seqlen_k, const int32_t* num_contexts,
+                               const int32_t* num_targets, int64_t target_group_size, int64_t window_left,
+                               int64_t window_right, float alpha, float scaling_seqlen, const void* rab,
+                               int64_t rab_batch_stride, int64_t rab_head_stride, int64_t rab_row_stride, const void* kv_cache,
+                               const int32_t* page_offsets, const int32_t* page_ids, const int32_t* last_page_lens,
+                               int64_t page_size, hipStream_t stream);
+
 /* append_kvcache (torch.ops.paged_kvcache_ops.append_kvcache, examples/commons/ops/cuda_ops/csrc/
  * paged_kvcache_ops_kernel.cu:106-140, call site paged_hstu_infer_layer.py:350-364): new-history token i (i < *nnz_dev,
  * or < max_nnz when max_nnz > 0) of sequence batch_indices[i] is written at position positions[i] of that user's

@@ -4509,6 +4509,30 @@ int HSTU_FN(mi355_hstu_attn_fwd_rab)(const void* q, const void* k, const void* v
   return rc;
 }
 
+// The inference forward (delta-q keys, paged cache) with a relative attention bias: rab[b][h][i][j] is indexed by ABSOLUTE positions
+// (query r of a sequence is row Lk - Lq + r), max_seqlen = the padded extent of the bias in i and j (>= every Lk).
+int HSTU_FN(mi355_hstu_attn_fwd_kv_rab)(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride, int64_t k_row_stride,
+                               int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride, int64_t k_head_stride,
+                               int64_t v_head_stride, int64_t o_head_stride, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                               int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen_q, int64_t max_seqlen_k,
+                               const int32_t* num_contexts, const int32_t* num_targets, int64_t target_group_size,
+                               int64_t window_left, int64_t window_right, float alpha, float scaling_seqlen, const void* rab,
+                               int64_t rab_batch_stride, int64_t rab_head_stride, int64_t rab_row_stride, const void* kv_cache,
+                               const int32_t* page_offsets, const int32_t* page_ids, const int32_t* last_page_lens,
+                               int64_t page_size, hipStream_t stream) {
+  MI355_CHECK_ARG(rab != nullptr && rab_row_stride >= max_seqlen_k, "rab must be [batch][heads or 1][max_seqlen_k][max_seqlen_k]");
+  int causal = 0;
+  if (const int rc = rab_mask(window_left, window_right, num_contexts, num_targets, &causal)) return rc;
+  tl_rab = RabCall{(const uint16_t*)rab, rab_batch_stride, rab_head_stride, rab_row_stride, nullptr, 0, 0, 0};
+  const int rc = HSTU_FN(mi355_hstu_attn_fwd_kv)(q, k, v, out, q_row_stride, k_row_stride, v_row_stride, o_row_stride, q_head_stride,
+                                        k_head_stride, v_head_stride, o_head_stride, cu_seqlens_q, cu_seqlens_k, batch, num_heads,
+                                        head_dim, max_seqlen_q, num_contexts, num_targets, target_group_size, causal, alpha,
+                                        scaling_seqlen, kv_cache, page_offsets, page_ids, last_page_lens, page_size, stream);
+  tl_rab = RabCall{};
+  tl_wl = tl_wr = -1;
+  return rc;
+}
+
 int HSTU_FN(mi355_hstu_attn_bwd_rab)(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
                             int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t do_row_stride,
                             int64_t q_head_stride, int64_t k_head_stride, int64_t v_head_stride, int64_t do_head_stride,

@@ -42,13 +42,16 @@ N.register_signatures({
                                c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_int, c_f, c_f, c_p, c_p, c_p, c_p, c_i64, c_p],
     "mi355_hstu_attn_fwd_kv_window": [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64,
                                       c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_f, c_p, c_p, c_p, c_p, c_i64, c_p],
+    "mi355_hstu_attn_fwd_kv_rab": [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64,
+                                   c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_f, c_p, c_i64, c_i64, c_i64,
+                                   c_p, c_p, c_p, c_p, c_i64, c_p],
     "mi355_append_kvcache": [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p,
                              c_i64, c_i64, c_p],
 }, {"mi355_hstu_attn_bwd_workspace_bytes": c_i64, "mi355_hstu_attn_bwd_ds_bytes": c_i64,
     "mi355_hstu_attn_bwd_ds_bytes_capped": c_i64, "mi355_hstu_attn_bwd_hint_tokens": None,
     "mi355_hstu_attn_fwd_hint_tokens": None, "mi355_hstu_attn_fwd_hint_tokens_f16": None})
 # the fp16-operand twins of the seven type-specific entry points (same argument lists)
-_TYPED = ("mi355_hstu_attn_fwd_hint_tokens", "mi355_hstu_attn_fwd", "mi355_hstu_attn_fwd_kv", "mi355_hstu_attn_fwd_kv_window", "mi355_hstu_attn_bwd", "mi355_hstu_attn_fwd_window",
+_TYPED = ("mi355_hstu_attn_fwd_hint_tokens", "mi355_hstu_attn_fwd", "mi355_hstu_attn_fwd_kv", "mi355_hstu_attn_fwd_kv_window", "mi355_hstu_attn_fwd_kv_rab", "mi355_hstu_attn_bwd", "mi355_hstu_attn_fwd_window",
           "mi355_hstu_attn_bwd_window", "mi355_hstu_attn_fwd_rab", "mi355_hstu_attn_bwd_rab")
 N.register_signatures({n + "_f16": N.signature_of(n) for n in _TYPED})
 
@@ -66,8 +69,6 @@ def _check_inputs(q, k, v, cu_q, cu_k, num_contexts, num_targets, window_size, r
             raise RuntimeError("rab must be a (batch, nheads or 1, max_seqlen_k, max_seqlen_k) tensor of the dtype of q with a contiguous last dimension")
         if rab.shape[0] != cu_q.numel() - 1 or rab.shape[1] not in (1, q.shape[1]) or rab.shape[2] != rab.shape[3]:
             raise RuntimeError("Number of heads in rab must be 1 or equal to number of heads in query; shape (batch, heads, max_seqlen_k, max_seqlen_k)")
-        if kv_cache is not None:
-            raise NotImplementedError("rab over a paged KV cache is not supported")
     if seqused_q is not None or seqused_k is not None:
         raise NotImplementedError("seqused_q / seqused_k are not supported")
     if q.dtype not in (torch.bfloat16, torch.float16) or k.dtype != q.dtype or v.dtype != q.dtype:
@@ -111,9 +112,10 @@ def hstu_varlen_fwd(q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_context
 
 def hstu_varlen_fwd_kv(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, scaling_seqlen, num_contexts, num_targets,
                        target_group_size, causal, alpha, kv_cache=None, page_offsets=None, page_ids=None,
-                       last_page_lens=None, window=None):
+                       last_page_lens=None, window=None, rab=None, max_seqlen_k=None):
     """Inference forward: delta-q (cu_seqlens_k) and / or paged KV cache [num_pages, 2, page_size, H, d]; `window` = (left,
-    right) of a local attention window over absolute positions (then no contextual / target rows)."""
+    right) of a local attention window over absolute positions (then no contextual / target rows); `rab`: relative attention
+    bias [batch, heads or 1, max_seqlen_k, max_seqlen_k] over absolute positions (with `max_seqlen_k`)."""
     T, H, D = q.shape
     out = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
     B = cu_seqlens_q.numel() - 1
@@ -128,6 +130,17 @@ def hstu_varlen_fwd_kv(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, scalin
                 raise RuntimeError(f"{name} must be an int32 tensor")
         page_size = kv_cache.size(2)
     _fn("mi355_hstu_attn_fwd_hint_tokens", q)(int(q.shape[0]))   # (dense batches take the paired-row-block kernel)
+    if rab is not None:
+        wl_, wr_ = window if window is not None else (-1, 0 if causal else -1)
+        check(_fn("mi355_hstu_attn_fwd_kv_rab", q)(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
+                                                   q.stride(1), k.stride(1), v.stride(1), out.stride(1), ptr(cu_seqlens_q),
+                                                   ptr(cu_seqlens_k), B, H, D, int(max_seqlen_q), int(max_seqlen_k),
+                                                   ptr(num_contexts), ptr(num_targets), int(target_group_size), int(wl_), int(wr_),
+                                                   c_f(alpha), c_f(float(scaling_seqlen)), ptr(rab), rab.stride(0),
+                                                   rab.stride(1) if rab.shape[1] > 1 else 0, rab.stride(2), ptr(kv_cache),
+                                                   ptr(page_offsets), ptr(page_ids), ptr(last_page_lens), page_size, stream()),
+              "hstu_attn_fwd_kv_rab")
+        return out
     if window is not None:
         check(_fn("mi355_hstu_attn_fwd_kv_window", q)(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0),
                                                       out.stride(0), q.stride(1), k.stride(1), v.stride(1), out.stride(1),
@@ -348,8 +361,15 @@ def hstu_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, seqused_q, sequse
     if has_drab and rab is None:   # hstu_attn_interface.py:234-237 of the reference
         raise ValueError("AssertError: rab is None, but has_drab is True, is not allowed in backward")
     if rab is not None:
-        if not same:
-            raise NotImplementedError("rab with delta-q keys is not supported")
+        if rab.shape[-1] != int(max_seqlen_k):
+            raise RuntimeError("rab must be (batch, nheads or 1, max_seqlen_k, max_seqlen_k)")
+        if not same:   # inference (delta-q keys and / or the paged cache) with a bias: forward only
+            if has_drab or (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad or rab.requires_grad)):
+                raise NotImplementedError("delta-q / paged-KV attention is forward only (as in the reference's inference path)")
+            local = not (wl == -1 and wr in (-1, 0))
+            return hstu_varlen_fwd_kv(q, k, v, cu_seqlens_q, cu_seqlens_k, int(max_seqlen_q), scaling_seqlen, num_contexts, num_targets,
+                                      int(target_group_size), causal, float(alpha), kv_cache, page_offsets, page_ids, last_page_lens,
+                                      window=(wl, wr) if local else None, rab=rab, max_seqlen_k=int(max_seqlen_k))
         if rab.shape[-1] != int(max_seqlen_k):
             raise RuntimeError("rab must be (batch, nheads or 1, max_seqlen_k, max_seqlen_k)")
         return HstuAttnRabFunc.apply(q, k, v, rab, cu_seqlens_q, int(max_seqlen_k), scaling_seqlen, num_contexts, num_targets,

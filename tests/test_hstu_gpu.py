@@ -774,6 +774,76 @@ def test_local_window_over_delta_q_and_paged_keys(d, window):
     assert torch.equal(out_a, out_b)
 
 
+@pytest.mark.parametrize("d", [64, 256])
+@pytest.mark.parametrize("mask", ["causal_targets", "window", "full"])
+def test_rab_over_delta_q_and_paged_keys(d, mask):
+    """A relative attention bias composed with delta-q keys and with the paged cache (inference; hstu_fwd.h Has_rab with the
+    sequence offset and Paged_KV): rab[b][h][i][j] is indexed by ABSOLUTE positions.  (a) contiguous keys against the oracle,
+    (b) the same keys from a paged cache: bit-identical to (a)."""
+    from hstu import append_kvcache, hstu_attn_varlen_func
+
+    rng = np.random.default_rng(d + len(mask))
+    B, H, P = 4, 2, 16
+    new_hist = rng.integers(1, 60, B)
+    num_cand = rng.integers(1, 7, B)
+    old = rng.integers(0, 100, B)
+    old[1] = 0
+    qlen, cachelen = new_hist + num_cand, old + new_hist
+    klen = cachelen + num_cand
+    q_off = np.concatenate([[0], np.cumsum(qlen)]).astype(np.int32)
+    k_off = np.concatenate([[0], np.cumsum(klen)]).astype(np.int32)
+    T, Nk = int(q_off[-1]), int(klen.max())
+    mk = lambda n: torch.empty(n, H, d, device=DEV).uniform_(-1, 1).bfloat16()
+    q, k_new, v_new = mk(T), mk(T), mk(T)
+    k_old, v_old = mk(int(old.sum())), mk(int(old.sum()))
+    o_off = np.concatenate([[0], np.cumsum(old)])
+    kf, vf = [], []
+    for b in range(B):
+        kf += [k_old[o_off[b]:o_off[b + 1]], k_new[q_off[b]:q_off[b + 1]]]
+        vf += [v_old[o_off[b]:o_off[b + 1]], v_new[q_off[b]:q_off[b + 1]]]
+    k_full, v_full = torch.cat(kf), torch.cat(vf)
+    rab = (torch.randn(B, H if d == 64 else 1, Nk, Nk, device=DEV) * 2).bfloat16()
+    alpha, scaling = 1.0 / d ** 0.5, 100.0
+    cuq, cuk = torch.from_numpy(q_off).to(DEV), torch.from_numpy(k_off).to(DEV)
+    if mask == "causal_targets":
+        window, tgt_np, causal = (-1, 0), num_cand, True
+    elif mask == "window":
+        window, tgt_np, causal = (25, 3), None, False
+    else:
+        window, tgt_np, causal = (-1, -1), None, False
+    tgt = None if tgt_np is None else torch.from_numpy(tgt_np.astype(np.int32)).to(DEV)
+    ref = ho.hstu_attn_fwd_delta_q(q.float().cpu().numpy(), k_full.float().cpu().numpy(), v_full.float().cpu().numpy(), q_off, k_off,
+                                   alpha, scaling, causal, tgt_np, window=window if mask == "window" else None,
+                                   rab=rab.float().cpu().numpy())
+    out_a = hstu_attn_varlen_func(q, k_full, v_full, cuq, cuk, None, None, int(qlen.max()), Nk, scaling, None, tgt,
+                                  window_size=window, alpha=alpha, rab=rab)
+    err = np.abs(out_a.float().cpu().numpy() - ref).max()
+    assert err <= 6e-3 * max(np.abs(ref).max(), 1e-3) + 1e-6, err
+    if mask == "full":
+        return      # (the paged walk below serves candidates from k_new: same as causal_targets / window)
+    npages = int(((cachelen + P - 1) // P).sum())
+    cache = torch.zeros(npages + 1, 2, P, H, d, dtype=torch.bfloat16, device=DEV)
+    perm = rng.permutation(npages + 1)[:npages]
+    page_ids, page_off, last, cursor = [], [0], [], 0
+    for b in range(B):
+        n = int((cachelen[b] + P - 1) // P)
+        pages = perm[cursor:cursor + n]
+        cursor += n
+        page_ids += pages.tolist()
+        page_off.append(len(page_ids))
+        last.append(int(cachelen[b] - (n - 1) * P))
+        for j in range(int(old[b])):
+            cache[pages[j // P], 0, j % P] = k_old[o_off[b] + j]
+            cache[pages[j // P], 1, j % P] = v_old[o_off[b] + j]
+    ti = lambda a: torch.tensor(a, dtype=torch.int32, device=DEV)
+    append_kvcache(k_new, v_new, ti(np.repeat(np.arange(B), new_hist)), ti(np.concatenate([old[b] + np.arange(new_hist[b]) for b in range(B)])),
+                   ti(np.concatenate([[0], np.cumsum(num_cand)])), ti([int(new_hist.sum())]), 0, cache, ti(page_ids), ti(page_off), ti(last), 0)
+    out_b = hstu_attn_varlen_func(q, k_new, v_new, cuq, cuk, None, None, int(qlen.max()), Nk, scaling, None, tgt,
+                                  window_size=window, alpha=alpha, rab=rab, kv_cache=cache, page_offsets=ti(page_off),
+                                  page_ids=ti(page_ids), last_page_lens=ti(last))
+    assert torch.equal(out_a, out_b)
+
+
 def test_paged_kvcache_ops_registration():
     """torch.ops.paged_kvcache_ops.append_kvcache exists with the reference's schema and writes the cache"""
     import paged_kvcache_ops  # noqa: F401
