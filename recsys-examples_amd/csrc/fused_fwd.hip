@@ -105,6 +105,12 @@ struct FusedArgs {
   int32_t* occ_trank;             // [n] rank of every occurrence among its key's occurrences in the tile (lazy reverse indices)
   uint64_t magic0;                // floor((2^64 - 1) / buckets of table 0): the multiply-high modulus of the one-table paths
   int4* rec_out4;                 // [P * kPartCap] out of path (c): {unique id (~id: row resolved late), rank base, CSR position, 0}
+  // round 4: several tables on path (c).  Partitions are aligned to table boundaries -- table t owns 1 + floor((P - T) n_t / n) of
+  // them (n_t = its keys in this batch), each a range of the table's BUCKETS -- so the unique order stays table-major; one record
+  // list per partition (a table's keys come from a few neighbouring tiles: no same-address chain to split, and a sub-list could
+  // overflow on one tile's records alone)
+  int mt;                         // 1: multi-table partitions
+  int32_t* ptab;                  // [P] table of every partition (written by block 0 of the probe kernel)
 };
 
 __device__ __forceinline__ void store_digest(uint8_t* p, uint8_t d) {
@@ -225,8 +231,13 @@ __device__ __forceinline__ void wave_init_row(const FusedArgs& a, void* rp, uint
 // the offsets, bag starts marked in LDS, max-scan) and groups the bag ids of the keys that occur more than once in the tile --
 // key after key, an exclusive scan over the representatives' counts gives the starts -- into tile_bags; a record carries
 // {position of the representative, bag id | start of the key's list, slot code, occurrences}.
-template <int TILE, int THREADS, bool kTrain, bool kPart = false, bool kFast = false, bool kBags = false>
+// kMT (round 4, with kPart + kBags): table-aligned partitions of a multi-table batch (FusedArgs::mt).
+template <int TILE, int THREADS, bool kTrain, bool kPart = false, bool kFast = false, bool kBags = false, bool kMT = false>
 __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
+  constexpr bool kOne = kPart && !kMT;             // the one-table forms of the partitioned paths keep the table's scalars in registers
+  __shared__ int s_pt[kMT ? kFusedMaxT : 1];       // kMT: partitions of every table
+  __shared__ int s_pb[kMT ? kFusedMaxT + 1 : 1];   //      first partition of every table
+  __shared__ uint64_t s_psc[kMT ? kFusedMaxT : 1]; //      floor(2^32 partitions / buckets) of every table
   __shared__ int s_bag[kBags ? TILE : 1];          // bag of every occurrence of the tile
   __shared__ uint16_t s_sm[kBags ? 2 * TILE : 1];  // per dedup entry: start of the key's list in the tile | multi flag << 15
   __shared__ int s_brange[2], s_wmax[THREADS / 64], s_wsum[THREADS / 64];
@@ -263,11 +274,11 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   // staged through LDS by threads 0 / 1 they were a global round trip in front of the FIRST barrier of every block
   int64_t m_tbo0 = 0, m_tbo1 = 0, m_tptr0 = 0;
   int m_rowb0 = 0;
-  if constexpr (kPart) { m_tbo0 = a.tbo[0]; m_tbo1 = a.tbo[1]; m_tptr0 = a.table_ptrs[0]; m_rowb0 = (int)a.table_value_dims[0] * a.elem_bytes; }
-  auto tbo_of = [&](int t) -> int64_t { if constexpr (kPart) return t == 0 ? m_tbo0 : m_tbo1; else return s_tbo[t]; };
-  auto tptr_of = [&](int t) -> int64_t { if constexpr (kPart) return m_tptr0; else return s_tptr[t]; };
-  auto rowb_of = [&](int t) -> int { if constexpr (kPart) return m_rowb0; else return s_rowb[t]; };
-  for (int t = threadIdx.x; t <= T && !kPart; t += THREADS) {
+  if constexpr (kOne) { m_tbo0 = a.tbo[0]; m_tbo1 = a.tbo[1]; m_tptr0 = a.table_ptrs[0]; m_rowb0 = (int)a.table_value_dims[0] * a.elem_bytes; }
+  auto tbo_of = [&](int t) -> int64_t { if constexpr (kOne) return t == 0 ? m_tbo0 : m_tbo1; else return s_tbo[t]; };
+  auto tptr_of = [&](int t) -> int64_t { if constexpr (kOne) return m_tptr0; else return s_tptr[t]; };
+  auto rowb_of = [&](int t) -> int { if constexpr (kOne) return m_rowb0; else return s_rowb[t]; };
+  for (int t = threadIdx.x; t <= T && !kOne; t += THREADS) {
     s_seg[t] = T == 1 ? (t == 0 ? 0 : a.n) : a.offsets[a.feature_offsets[t] * a.batch];
     s_tbo[t] = a.tbo[t];
     if (t < T) { s_tptr[t] = a.table_ptrs[t]; s_rowb[t] = (int)a.table_value_dims[t] * a.elem_bytes; }
@@ -321,6 +332,12 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     mo0 = a.offsets[bc < 0 ? 0 : bc];
     mo1 = a.offsets[(bc < 0 ? 0 : bc) + 1];
   }
+  if constexpr (kMT) {   // partitions per table: one each, the rest in proportion to the tables' keys in this batch
+    if ((int)threadIdx.x < T) {
+      const uint64_t nt_ = (uint64_t)(s_seg[threadIdx.x + 1] - s_seg[threadIdx.x]);
+      s_pt[threadIdx.x] = 1 + (a.n > 0 ? (int)((uint64_t)(a.P - T) * nt_ / (uint64_t)a.n) : 0);
+    }
+  }
   int hh[PER], rk[PER];
   int64_t bq[PER], hq[PER];      // bucket and hash of my keys (bucket -1: key without a home)
   uint4 dvq[PER];                // first digest vector of the probe
@@ -344,7 +361,7 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     if constexpr (kFast) {
       const uint64_t nb = (uint64_t)(tbo_of(tt + 1) - bb);
       const uint64_t x = (uint64_t)hash >> cshift;
-      uint64_t r = x - __umul64hi(x, kPart ? a.magic0 : s_magic[tt]) * nb;
+      uint64_t r = x - __umul64hi(x, kOne ? a.magic0 : s_magic[tt]) * nb;
       if (r >= nb) r -= nb;
       if (r >= nb) r -= nb;
       ok = i < a.n && is_valid(key) && nb > 0;
@@ -364,6 +381,25 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   PST(2);
   __syncthreads();
   PST(3);
+  if constexpr (kMT) {
+    if (threadIdx.x < 64) {      // (T <= 128: two tables per lane of wave 0)
+      const int l = threadIdx.x;
+      const int v0 = l < T ? s_pt[l] : 0, v1 = l + 64 < T ? s_pt[l + 64] : 0;
+      const int i0 = wave_incl_scan(v0);
+      const int i1 = wave_incl_scan(v1) + __shfl(i0, 63, 64);
+      if (l < T) {
+        s_pb[l] = i0 - v0;
+        const uint64_t nb = (uint64_t)(s_tbo[l + 1] - s_tbo[l]);
+        s_psc[l] = nb ? ((uint64_t)v0 << 32) / nb : 0ull;
+      }
+      if (l + 64 < T) {
+        s_pb[l + 64] = i1 - v1;
+        const uint64_t nb = (uint64_t)(s_tbo[l + 65] - s_tbo[l + 64]);
+        s_psc[l + 64] = nb ? ((uint64_t)v1 << 32) / nb : 0ull;
+      }
+      if (l == 63) s_pb[T] = i1;
+    }
+  }
   if constexpr (kBags) {
     const int bhi = s_brange[1];
     if (mb >= 0 && mb <= bhi && mo1 > mo0) { const int64_t pp = mo0 > tile0 ? mo0 - tile0 : 0; if (pp < TILE) s_bag[pp] = mb; }
@@ -423,7 +459,14 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     for (int q = 0; q < PER; ++q) {
       lpq[q] = 0;
       if (isrep[q]) {
-        const int pk = bq[q] < 0 ? a.P - 1
+        int pk;
+        if constexpr (kMT) {   // the table's partitions split its bucket range evenly; keys without a home: its last partition
+          const int t = s_t[q * THREADS + threadIdx.x];
+          const int p0 = s_pb[t], p1 = s_pb[t + 1];
+          const int x = bq[q] < 0 ? p1 - p0 - 1 : (int)(((uint64_t)(bq[q] - s_tbo[t]) * s_psc[t]) >> 32);
+          pk = p0 + (x < p1 - p0 ? x : p1 - p0 - 1);
+        } else
+        pk = bq[q] < 0 ? a.P - 1
                        : kFast ? (int)((uint32_t)bq[q] / (uint32_t)(a.spp >> cshift)) : (int)(bq[q] * a.t.C / a.spp);
         lpq[q] = pk * 4096 + atomicAdd(&s_hist[pk], 1);
       }
@@ -431,7 +474,14 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     __syncthreads();
     if ((int)threadIdx.x < a.P) {     // (P <= kPartMax = THREADS)
       const int c = s_hist[threadIdx.x];
-      if (c) my_base = atomicAdd(&a.pcount[threadIdx.x * kPartSub + (int)blockIdx.x % kPartSub], c);
+      if (c) my_base = atomicAdd(&a.pcount[threadIdx.x * kPartSub + (kMT ? 0 : (int)blockIdx.x % kPartSub)], c);
+      if constexpr (kMT) {
+        if (blockIdx.x == 0) {   // the partition kernel learns its table from here
+          int t = 0;
+          while (t + 1 < T && s_pb[t + 1] <= (int)threadIdx.x) ++t;
+          a.ptab[threadIdx.x] = t;
+        }
+      }
     }
     if constexpr (kBags) {
       const int w = threadIdx.x >> 6;
@@ -526,7 +576,8 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   __syncthreads();
   PST(9);
   if constexpr (kPart) {
-    const int sub = (int)blockIdx.x % kPartSub;
+    const int sub = kMT ? 0 : (int)blockIdx.x % kPartSub;
+    constexpr int kListCap = kMT ? kPartCap : kSubCap;
     if ((int)threadIdx.x < a.P) s_hist[threadIdx.x] = my_base;
     __syncthreads();
 #pragma unroll
@@ -535,7 +586,7 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
       const int v = s_tab[hh[q]];
       const int pk = v >> 12, idx = s_hist[pk] + (v & 4095);
       int ref = -1;
-      if (idx < kSubCap) {
+      if (idx < kListCap) {
         ref = pk * kPartCap + sub * kSubCap + idx;
         if constexpr (kBags) {
           const int li = q * THREADS + threadIdx.x;
@@ -614,7 +665,7 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     }
   }
   if (blockIdx.x == 0)
-    for (int t = threadIdx.x; t <= T; t += THREADS) a.seg_out[t] = kPart ? (t == 0 ? 0 : a.n) : s_seg[t];
+    for (int t = threadIdx.x; t <= T; t += THREADS) a.seg_out[t] = kOne ? (t == 0 ? 0 : a.n) : s_seg[t];
   PST(11);
 }
 
@@ -1510,8 +1561,12 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
   uint4 rc[kP3Items];
 #pragma unroll
   for (int k = 0; k < kP3Items; ++k) rc[k] = a.rec[(int64_t)p * kPartCap + threadIdx.x + k * kP3Threads];
-  // (rows of the single table of this path: three scalars every output needs, fetched with the records)
-  const int64_t tp0 = a.table_ptrs[0], rowb = a.table_value_dims[0] * a.elem_bytes, s0 = a.tbo[0] * a.t.C;
+  // (rows of the partition's table: three scalars every output needs, fetched with the records; several tables: the probe
+  //  kernel's block 0 left the table of every partition in ptab)
+  int tbl = 0;
+  bool first_of_table = p == 0;
+  if (a.mt) { tbl = a.ptab[p]; first_of_table = p == 0 || a.ptab[p - 1] != tbl; }
+  const int64_t tp0 = a.table_ptrs[tbl], rowb = a.table_value_dims[tbl] * a.elem_bytes, s0 = a.tbo[tbl] * a.t.C;
   for (int i = threadIdx.x; i < kP2Hash; i += kP3Threads) { h_slot[i] = -1; h_cnt[i] = 0; }
   if (threadIdx.x < 256) s_lock[threadIdx.x] = 0;
   if (threadIdx.x < kP2Hash / 32) s_late[threadIdx.x] = 0;
@@ -1527,7 +1582,7 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
   for (int k = 0; k < kP3Items; ++k) {
     const int idx = threadIdx.x + k * kP3Threads;
     const int ms = msub[idx / kSubCap];
-    live[k] = (idx % kSubCap) < (ms < kSubCap ? ms : kSubCap);
+    live[k] = a.mt ? idx < (msub[0] < kPartCap ? msub[0] : kPartCap) : (idx % kSubCap) < (ms < kSubCap ? ms : kSubCap);
     en[k] = -1; bs[k] = 0; dj[k] = -1; mine[k] = false;
     if (!live[k]) continue;
     const int sl = (int)rc[k].z, cn = (int)rc[k].w;
@@ -1645,7 +1700,7 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
               gslot = (int)(bucket * a.t.C + slot);
               if (fresh_row) {
                 void* rp = reinterpret_cast<void*>((uintptr_t)(tp0 + ((int64_t)gslot - s0) * rowb));
-                const int ed = (int)a.table_emb_dims[0], vd = (int)a.table_value_dims[0];
+                const int ed = (int)a.table_emb_dims[tbl], vd = (int)a.table_value_dims[tbl];
                 for (int el = g; el < vd; el += G) {
                   const float v = el < ed ? init_value(a.init, key, (uint32_t)el) : a.init.state_init;
                   if (a.value_dtype == kF32) st1<kF32>(rp, el, v);
@@ -1749,7 +1804,7 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
       o.csr_cnt[uid] = c;
       if (o.freq) o.freq[uid] = c;
       o.row_addr[uid] = gs < a.S ? tp0 + ((int64_t)gs - s0) * rowb : 0;
-      if (o.table_ids) o.table_ids[uid] = 0;
+      if (o.table_ids) o.table_ids[uid] = tbl;
       o.slots[uid] = gs < a.S ? (int64_t)gs - s0 : -1;
       ptr[uid] = pv;
       if (hots && c > hot.khot && c <= hot.kwave) {
@@ -1809,6 +1864,9 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
       for (int j = lane_id(); j < cn; j += 64) csr_src[pos + j] = ~(br + j);
     }
   }
+  // unique rows in front of the partition's table (the first partition of every table; partitions are table-major)
+  if (first_of_table && threadIdx.x == 0)
+    o.table_offsets[tbl] = __hip_atomic_load(&a.hdr[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 0 : upre;
   if (p == (int)a.P - 1 && threadIdx.x == 0) {
     int U = upre + nu;
     const int O = spre + tot2;
@@ -1818,8 +1876,7 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
     // module raises at its next check (the pooled output of the forward is complete: it does not depend on the records).
     if (__hip_atomic_load(&a.hdr[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { U = 0; nh = 0; ntk = 0; nwv = 0; }
     if (hots) { *hot.n_hot = nh; *hot.n_tasks = ntk; *hot.n_wave = nwv; }
-    o.table_offsets[0] = 0;
-    o.table_offsets[1] = U;
+    o.table_offsets[a.T] = U;
     *o.total = O;
     if (U) ptr[U] = O;
   }
@@ -1993,8 +2050,13 @@ static inline int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
 // partitions of the partitioned index stage for a batch of n keys (0: the batch takes the per-slot-counter path)
 static inline int part_count(int64_t n, int64_t num_tables) {
   static const int env = getenv("MI355_FUSED_PART") ? atoi(getenv("MI355_FUSED_PART")) : 2;
-  if (!env || num_tables != 1 || n < (64 << 10) || n > (int64_t)kPartMax * 1024) return 0;
+  // several tables (round 4): path (c) only, with table-aligned partitions -- every table owns at least one, so the batch needs
+  // a few per table (MI355_FUSED_MT=0: multi-table batches keep the per-slot-counter path)
+  static const int mt_env = getenv("MI355_FUSED_MT") ? atoi(getenv("MI355_FUSED_MT")) : 1;
+  if (!env || n < (64 << 10) || n > (int64_t)kPartMax * 1024) return 0;
+  if (num_tables != 1 && (!mt_env || env < 2 || num_tables < 1 || num_tables > kFusedMaxT)) return 0;
   int P = (int)((n + 1023) / 1024);
+  if (num_tables > 1 && P < 4 * num_tables) return 0;
   // the partition kernel of path (c) is one 1024-thread block per partition and per CU: up to 1.5 K keys per partition (about
   // 1.1 K records of the 2 K a partition can hold) the batch gets exactly one block per CU instead of a second, thin generation
   if (env >= 2 && P > 256 && n <= 256 * 1536) P = 256;
@@ -2011,7 +2073,7 @@ int64_t mi355_demb_forward_fused_workspace_bytes(int64_t n, int64_t num_tables) 
   const int64_t nt = (n + 1023) / 1024 + 2;
   return al256(8 * (num_tables + 1)) + al256(8 * n) /*unique keys*/ + al256(8 * n) /*occ_addr*/ + al256(4 * n) /*occ_slot*/ +
          al256(4 * nt) + 256 /*total*/ + al256(8 * n) + 4 * al256(4 * n) /*deferred*/ + al256(16 * nt) /*look-back*/ + 256 +
-         (part_count(n, num_tables) ? 32 * (int64_t)part_count(n, num_tables) * kPartCap + 5 * 256 : 0) /*partition records*/;
+         (part_count(n, num_tables) ? 32 * (int64_t)part_count(n, num_tables) * kPartCap + 5 * 256 + 4 * kPartMax : 0) /*partition records, table of every partition*/;
 }
 
 // The fused forward (see the header of this file).  Persisted outputs as mi355_demb_forward; in eval mode (train == 0)
@@ -2077,6 +2139,7 @@ int mi355_demb_forward_fused(
   a.P = 0; a.spp = 1; a.pcount = aux + 64;
   a.rec = nullptr; a.rec_out = nullptr; a.rec_out4 = nullptr;
   a.tile_bags = nullptr; a.occ_trank = nullptr;
+  a.mt = 0; a.ptab = nullptr;
   a.magic0 = num_buckets > 0 ? ~0ull / (uint64_t)num_buckets : 0ull;   // (one table: its buckets are all the buckets)
   {
     const int P = train ? part_count(n, num_tables) : 0;
@@ -2087,10 +2150,12 @@ int mi355_demb_forward_fused(
         const int64_t nr = (int64_t)P * kPartCap;
         a.rec = (uint4*)w; w += al256(16 * nr);
         a.rec_out = (int2*)w; a.rec_out4 = (int4*)w; w += al256(16 * nr);   // (path (a): 8-byte entries, path (c): 16-byte ones)
+        a.ptab = (int32_t*)w; w += 4 * kPartMax;
+        a.mt = num_tables > 1;
       }
     }
   }
-  const bool part = a.P > 0;
+  bool part = a.P > 0;
   a.csr_rank = csr_rank;
   // backward workspace (row pointers, CSR, hot lists) -- carved before the probe launch, which clears the hot-list header
   int32_t* bptr = nullptr; int32_t* bcsr = nullptr; void* hot_ws = nullptr; int64_t hot_bytes_ = 0;
@@ -2112,6 +2177,7 @@ int mi355_demb_forward_fused(
   while ((4 << lg) < emb_dim && lg < 6) ++lg;
   const bool pathc = part && part_env >= 2 && train && combiner >= 0 && hot_ws && bcsr && aligned16 && emb_dim <= (4 << lg) &&
                      n <= 8 * num_bags && value_dtype <= 1 && out_dtype <= 1 && num_bags < (1ll << 31) - 4096;
+  if (part && a.mt && !pathc) { part = false; a.P = 0; a.mt = 0; }   // several tables: path (c) or the per-slot counters
   if (pathc) {
     a.tile_bags = (int32_t*)((uint8_t*)backward_workspace + al256(4 * (n + 1)) + al256(4 * n));   // head of the grouping workspace
     a.occ_trank = a.d_tid;   // (the deferred-key arrays belong to path (b))
@@ -2161,7 +2227,9 @@ int mi355_demb_forward_fused(
     if (part) {
       const char* fm = getenv("MI355_FUSED_FASTMOD");   // (read per call: A/B inside one process; default on with path (c))
       const bool fast = (fm ? atoi(fm) != 0 : pathc) && (a.t.C & (a.t.C - 1)) == 0 && (a.S >> __builtin_ctzll((unsigned long long)a.t.C)) < (1ll << 31);
-      if (pathc && fast) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
+      if (pathc && a.mt && fast) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, true, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
+      else if (pathc && a.mt) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, false, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
+      else if (pathc && fast) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
       else if (pathc) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, false, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
       else if (fast) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
       else hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
@@ -2189,7 +2257,7 @@ int mi355_demb_forward_fused(
     g.dst = out; g.FB = num_bags; g.n = n; g.B = (int)batch_size; g.D = (int)emb_dim; g.total_D = (int)total_D; g.combiner = combiner;
     LateRefs late; late.occ_slot = a.occ_slot; late.rec = a.rec; late.S = (int)S;
     late.table_ptrs = table_ptrs; late.table_value_dims = table_value_dims; late.tbo = table_bucket_offsets;
-    late.C = bucket_capacity; late.elem_bytes = a.elem_bytes;
+    late.C = bucket_capacity; late.elem_bytes = a.elem_bytes; late.T = (int)num_tables;
     const int nsub = 64 >> lg;
     hipLaunchKernelGGL(fused_part3_kernel, dim3((unsigned)a.P), dim3(kP3Threads), 0, stream, a, o, bptr, bcsr, hot);
     MI355_LAUNCH_CHECK();

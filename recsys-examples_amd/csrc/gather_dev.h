@@ -77,13 +77,16 @@ struct LateRefs {
   int64_t C = 0;
   int elem_bytes = 0;
   int S = 0;
+  int T = 1;                                  // tables (global slots are table-major: tbo[t] C <= slot < tbo[t + 1] C)
 };
 __device__ __forceinline__ uintptr_t late_row(const LateRefs& L, int64_t j) {
   const int ref = L.occ_slot[j];
   if (ref < 0) return 0;
   const int z = (int)L.rec[ref].z;
   if (z < 0 || z >= L.S) return 0;
-  return (uintptr_t)(L.table_ptrs[0] + ((int64_t)z - L.tbo[0] * L.C) * L.table_value_dims[0] * L.elem_bytes);
+  int t = 0;
+  while (t + 1 < L.T && L.tbo[t + 1] * L.C <= (int64_t)z) ++t;   // (rare path: keys that went through an eviction)
+  return (uintptr_t)(L.table_ptrs[t] + ((int64_t)z - L.tbo[t] * L.C) * L.table_value_dims[t] * L.elem_bytes);
 }
 
 // Software-pipelined form for rows of one column group (NCOL == 1, the C2 shape): an LPR-lane group owns KIT

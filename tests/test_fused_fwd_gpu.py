@@ -158,6 +158,122 @@ def test_multi_table_batches_of_a_few_hundred_thousand_keys_against_the_per_op_c
         torch.testing.assert_close(v1[o1], v2[o2], rtol=3e-5, atol=3e-6)
 
 
+@pytest.mark.parametrize("case", ["eight_equal", "skewed", "shared_table_mixed_dims"])
+@pytest.mark.parametrize("pooling,opt,strategy", [("SUM", "SGD", "TIMESTAMP"), ("MEAN", "ADAM", "LFU"), ("SUM", "EXACT_ROWWISE_ADAGRAD", "STEP")])
+def test_multi_table_pooled_batches_take_the_csr_writing_partition_path(case, pooling, opt, strategy, monkeypatch):
+    """round 4: path (c) with TABLE-ALIGNED partitions (every table owns whole partitions, the rest dealt by its share of the
+    batch's keys) against the per-op chain -- eight equal tables (the 8 x 8192-bag shape of tools/bench_model_shapes.py), a skewed
+    batch (one table with nearly all keys, one with a handful, one with NONE), and two features sharing a table with mixed row
+    widths.  Same pooled output, the same unique rows PER TABLE (the unique order stays table-major), reverse indices that point
+    at the key's own table, same stored keys / rows / optimizer state after three steps."""
+    if case == "eight_equal":
+        dims, fmap, B = (16,) * 8, None, 6_000
+        hi = [60_000] * 8
+        maxlen = [9] * 8
+    elif case == "skewed":
+        dims, fmap, B = (16, 16, 16, 16), None, 30_000
+        hi = [300_000, 50, 1_000, 7]
+        maxlen = [9, 2, 0, 2]           # feature 2 has no key at all; features 1 and 3 a few thousand
+    else:
+        dims, fmap, B = (8, 32, 16), [0, 1, 1, 2], 12_000
+        hi = [50_000, 80_000, 80_000, 20_000]
+        maxlen = [9, 9, 5, 9]
+    F = len(hi)
+    ref = _mk(False, dims, cap=1 << 19, pooling=pooling, opt=opt, strategy=strategy, fmap=fmap, learning_rate=0.2, monkeypatch=monkeypatch)
+    dut = _mk(True, dims, cap=1 << 19, pooling=pooling, opt=opt, strategy=strategy, fmap=fmap, learning_rate=0.2, monkeypatch=monkeypatch)
+    fm = fmap or list(range(F))
+    rng = np.random.default_rng(5)
+    ref.train(); dut.train()
+    took_c = 0
+    for it in range(3):
+        lens = np.concatenate([rng.integers(0, m, size=B) if m > 0 else np.zeros(B, np.int64) for m in maxlen])
+        off_np = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        nk = int(off_np[-1])
+        keys_np = np.empty(nk, np.int64)
+        tab_of = np.empty(nk, np.int64)
+        for f in range(F):
+            lo, hi_ = off_np[f * B], off_np[(f + 1) * B]
+            keys_np[lo:hi_] = (rng.zipf(1.2, hi_ - lo) + 5 * it) % (hi[f] + 1000 * it)
+            tab_of[lo:hi_] = fm[f]
+        keys, off = torch.from_numpy(keys_np).to(DEV), torch.from_numpy(off_np).to(DEV)
+        o_ref, s_ref = ref._forward_impl(keys, off, train=True)
+        o_dut, s_dut = dut._forward_impl(keys, off, train=True)
+        took_c += int(bool(getattr(s_dut, "lazy", False)))
+        torch.testing.assert_close(o_ref, o_dut, rtol=1e-5, atol=1e-5, msg=f"step {it} ({nk} keys): forward differs")
+        assert torch.equal(s_ref.uoff.cpu(), s_dut.uoff.cpu()), "unique rows per table differ"
+        nu = int(s_dut.uoff[-1])
+        if it == 1:
+            rev = s_dut.rev
+            assert int(rev.min()) >= 0 and int(rev.max()) < nu
+            tids = s_dut.tids[:nu]
+            assert torch.equal(tids[rev].cpu(), torch.from_numpy(tab_of)), "a reverse index points into another table's unique rows"
+            # table-major unique order: the table ids are non-decreasing and agree with the table offsets
+            uo = s_dut.uoff.cpu().numpy()
+            t_np = tids.cpu().numpy()
+            for t in range(len(dims)):
+                assert (t_np[uo[t]:uo[t + 1]] == t).all()
+            uk = torch.zeros(nu, dtype=torch.int64, device=DEV)
+            uk[rev] = keys
+            assert torch.equal(uk[rev], keys)
+            assert int(torch.unique(rev).numel()) == nu
+        g = torch.rand_like(o_ref) + 0.1
+        ref._backward_impl(s_ref, g)
+        dut._backward_impl(s_dut, g)
+        assert torch.equal(ref.size(), dut.size())
+        assert _counters_clear(dut)
+    assert took_c == 3, "the multi-table batch did not take the CSR-writing partition path"
+    for t in range(len(dims)):
+        k1, v1 = ref.export_keys_values(ref._table_names[t], torch.device(DEV))
+        k2, v2 = dut.export_keys_values(dut._table_names[t], torch.device(DEV))
+        o1, o2 = torch.argsort(k1), torch.argsort(k2)
+        assert k1.numel() == k2.numel() and torch.equal(k1[o1], k2[o2])
+        torch.testing.assert_close(v1[o1], v2[o2], rtol=3e-5, atol=3e-6)
+
+
+def test_multi_table_partition_path_with_full_buckets(monkeypatch):
+    """several small tables whose buckets fill up: the keys without a free slot go through the eviction inside the partition
+    block of THEIR table (row address, table-relative slot and row initialisation all come from the partition's table).  Which
+    of two equal scores is evicted is schedule dependent, so the per-op chain is only held to what is not (unique rows per table,
+    table sizes); the pooled output of every training forward must equal the pooled rows of the module's OWN tables as exported
+    right after it (a late row resolved against the wrong table, or initialised in it, shows up there)."""
+    dims = (16, 16, 16, 16)
+    ref = _mk(False, dims, cap=16_384, pooling="SUM", opt="SGD", strategy="LFU", bucket=16, learning_rate=0.2, monkeypatch=monkeypatch)
+    dut = _mk(True, dims, cap=16_384, pooling="SUM", opt="SGD", strategy="LFU", bucket=16, learning_rate=0.2, monkeypatch=monkeypatch)
+    rng = np.random.default_rng(9)
+    F, B = 4, 8_000
+    ref.train(); dut.train()
+    took_c = 0
+    for it in range(4):
+        lens = rng.integers(1, 6, size=F * B)
+        off = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)).to(DEV)
+        nk = int(off[-1])
+        keys = torch.from_numpy(((rng.zipf(1.3, nk) + 11 * it) % 40_000).astype(np.int64)).to(DEV)
+        o_ref, s_ref = ref._forward_impl(keys, off, train=True)
+        o_dut, s_dut = dut._forward_impl(keys, off, train=True)
+        took_c += int(bool(getattr(s_dut, "lazy", False)))
+        assert torch.equal(s_ref.uoff.cpu(), s_dut.uoff.cpu())
+        bag_of = torch.repeat_interleave(torch.arange(F * B, device=DEV), off[1:] - off[:-1])
+        for f in range(F):
+            ks, vs = dut.export_keys_values(dut._table_names[f], torch.device(DEV))
+            order = torch.argsort(ks)
+            ks, vs = ks[order], vs[order][:, :16].float()
+            lo, hi = int(off[f * B]), int(off[(f + 1) * B])
+            kf = keys[lo:hi]
+            idx = torch.searchsorted(ks, kf).clamp(max=ks.numel() - 1)
+            found = ks[idx] == kf
+            rows = vs[idx] * found[:, None]
+            want = torch.zeros(B, 16, device=DEV).index_add_(0, bag_of[lo:hi] - f * B, rows)
+            torch.testing.assert_close(o_dut[:, 16 * f: 16 * (f + 1)], want, rtol=1e-5, atol=1e-5,
+                                       msg=f"step {it}, table {f}: the pooled output is not the sum of the table's own rows")
+        assert int(found.sum()) > 0
+        g = torch.rand_like(o_ref) + 0.1
+        ref._backward_impl(s_ref, g)
+        dut._backward_impl(s_dut, g)
+        assert torch.equal(ref.size(), dut.size())
+        assert _counters_clear(dut)
+    assert took_c == 4
+
+
 def test_one_new_key_in_every_tile_gets_one_slot(monkeypatch):
     """cold start: the same unseen keys arrive from dozens of tiles at once; every key must end in exactly one slot and
     the reverse indices must group all its occurrences"""
