@@ -232,7 +232,9 @@ __device__ __forceinline__ void wave_init_row(const FusedArgs& a, void* rp, uint
 // key after key, an exclusive scan over the representatives' counts gives the starts -- into tile_bags; a record carries
 // {position of the representative, bag id | start of the key's list, slot code, occurrences}.
 // kMT (round 4, with kPart + kBags): table-aligned partitions of a multi-table batch (FusedArgs::mt).
-template <int TILE, int THREADS, bool kTrain, bool kPart = false, bool kFast = false, bool kBags = false, bool kMT = false>
+// kSeq (round 4, with kBags): sequence lookups -- the "bag" of occurrence j is j itself (the backward's CSR lists gradient rows),
+// so the bag search and the running maximum over the bag marks fall away.
+template <int TILE, int THREADS, bool kTrain, bool kPart = false, bool kFast = false, bool kBags = false, bool kMT = false, bool kSeq = false>
 __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   constexpr bool kOne = kPart && !kMT;             // the one-table forms of the partitioned paths keep the table's scalars in registers
   __shared__ int s_pt[kMT ? kFusedMaxT : 1];       // kMT: partitions of every table
@@ -290,7 +292,7 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   if (blockIdx.x == 0 && kTrain) {
     if (a.hot_counters && threadIdx.x < 3) a.hot_counters[2 * threadIdx.x] = 0;   // n_hot, n_tasks, n_wave
   }
-  if constexpr (kBags) {
+  if constexpr (kBags && !kSeq) {
     for (int k = threadIdx.x; k < TILE; k += THREADS) s_bag[k] = -1;
     if (threadIdx.x < 128) {   // waves 0 / 1: bags of the tile's first / last occurrence (first idx with offsets[idx] > key, minus 1)
       // 64-ary rounds, one probe per lane: three dependent round trips for 64 K bags.  Measured against wider rounds -- 4 probes
@@ -326,7 +328,7 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   // kBags: the offsets of "my" bag of the tile's range are fetched now and used behind the next barrier
   int mb = 0;
   int64_t mo0 = 0, mo1 = 0;
-  if constexpr (kBags) {
+  if constexpr (kBags && !kSeq) {
     mb = s_brange[0] + (int)threadIdx.x;
     const int bc = mb <= s_brange[1] ? mb : s_brange[1];
     mo0 = a.offsets[bc < 0 ? 0 : bc];
@@ -400,7 +402,7 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
       if (l == 63) s_pb[T] = i1;
     }
   }
-  if constexpr (kBags) {
+  if constexpr (kBags && !kSeq) {
     const int bhi = s_brange[1];
     if (mb >= 0 && mb <= bhi && mo1 > mo0) { const int64_t pp = mo0 > tile0 ? mo0 - tile0 : 0; if (pp < TILE) s_bag[pp] = mb; }
     for (int b = mb + THREADS; b <= bhi; b += THREADS) {      // (more bags than threads in the tile's range: empty / one-key bags)
@@ -437,12 +439,14 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   // (thread t owns the occurrences t * PER ..), and the list starts of the keys that occur more than once
   int bagv[PER], bag_incl = -1, mcnt[PER], m_incl = 0, m_mine = 0;
   if constexpr (kBags) {
-    int m = -1;
+    if constexpr (!kSeq) {
+      int m = -1;
 #pragma unroll
-    for (int k = 0; k < PER; ++k) { const int v = s_bag[threadIdx.x * PER + k]; m = v > m ? v : m; bagv[k] = m; }
-    bag_incl = m;
+      for (int k = 0; k < PER; ++k) { const int v = s_bag[threadIdx.x * PER + k]; m = v > m ? v : m; bagv[k] = m; }
+      bag_incl = m;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(bag_incl, off, 64); if (lane_id() >= off) bag_incl = o > bag_incl ? o : bag_incl; }
+      for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(bag_incl, off, 64); if (lane_id() >= off) bag_incl = o > bag_incl ? o : bag_incl; }
+    }
 #pragma unroll
     for (int q = 0; q < PER; ++q) { const int c = isrep[q] ? s_cnt[hh[q]] : 0; mcnt[q] = c > 1 ? c : 0; m_mine += mcnt[q]; }
     m_incl = m_mine;
@@ -487,11 +491,16 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
       const int w = threadIdx.x >> 6;
       int bbase = -1, sbase = 0;
       for (int k = 0; k < w; ++k) { bbase = s_wmax[k] > bbase ? s_wmax[k] : bbase; sbase += s_wsum[k]; }
-      int prev = __shfl_up(bag_incl, 1, 64);
-      if (lane_id() == 0) prev = -1;
-      prev = prev > bbase ? prev : bbase;
+      if constexpr (kSeq) {
 #pragma unroll
-      for (int k = 0; k < PER; ++k) s_bag[threadIdx.x * PER + k] = bagv[k] > prev ? bagv[k] : prev;
+        for (int k = 0; k < PER; ++k) s_bag[threadIdx.x * PER + k] = (int)tile0 + (int)threadIdx.x * PER + k;
+      } else {
+        int prev = __shfl_up(bag_incl, 1, 64);
+        if (lane_id() == 0) prev = -1;
+        prev = prev > bbase ? prev : bbase;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) s_bag[threadIdx.x * PER + k] = bagv[k] > prev ? bagv[k] : prev;
+      }
       int st = sbase + m_incl - m_mine;
 #pragma unroll
       for (int q = 0; q < PER; ++q) {
@@ -1897,6 +1906,27 @@ __global__ void __launch_bounds__(256) gather_pooled_late_kernel(PoolArgs g, Lat
 #endif
 }
 
+// sequence gather of path (c): out[j, :D] = the row of occurrence j, late rows through the key's record (LPR lanes per row;
+// 16-byte aligned rows only -- the path's condition)
+template <int SDT, int DDT>
+__global__ void __launch_bounds__(256)
+gather_rows_late_kernel(const int64_t* __restrict__ occ_addr, LateRefs late, int64_t n, int D, void* dst, int64_t dst_stride, int lpr_log2) {
+  const int lane = lane_id();
+  const int LPR = 1 << lpr_log2, R = 64 >> lpr_log2;
+  const int sub = lane >> lpr_log2, c = lane & (LPR - 1);
+  const int64_t rows_per_block = (int64_t)(blockDim.x >> 6) * R;
+  for (int64_t r0 = (int64_t)blockIdx.x * rows_per_block + (int64_t)(threadIdx.x >> 6) * R; r0 < n; r0 += (int64_t)gridDim.x * rows_per_block) {
+    const int64_t i = r0 + sub;
+    if (i >= n) continue;
+    uintptr_t rp = (uintptr_t)occ_addr[i];
+    if (rp == 1) rp = late_row(late, i);
+    for (int e = 4 * c; e < D; e += 4 * LPR) {
+      const float4 v = rp ? ld4<SDT>(reinterpret_cast<const void*>(rp), e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      st4<DDT>(dst, i * dst_stride + e, v);
+    }
+  }
+}
+
 // eval / inference forward in one launch (gather_dev.h: gather_pooled_eval)
 template <int SDT, int DDT>
 __global__ void __launch_bounds__(256) gather_pooled_eval_kernel(PoolArgs g, ProbeRefs pr, int lpr_log2) {
@@ -2175,8 +2205,13 @@ int mi355_demb_forward_fused(
   static const int part_env = getenv("MI355_FUSED_PART") ? atoi(getenv("MI355_FUSED_PART")) : 2;
   int lg = 3;
   while ((4 << lg) < emb_dim && lg < 6) ++lg;
-  const bool pathc = part && part_env >= 2 && train && combiner >= 0 && hot_ws && bcsr && aligned16 && emb_dim <= (4 << lg) &&
-                     n <= 8 * num_bags && value_dtype <= 1 && out_dtype <= 1 && num_bags < (1ll << 31) - 4096;
+  // sequence lookups (combiner -1, round 4; MI355_FUSED_SEQ=0 keeps them on the probe / partition / scatter chain): occurrence j
+  // is its own bag
+  static const int seq_env = getenv("MI355_FUSED_SEQ") ? atoi(getenv("MI355_FUSED_SEQ")) : 1;
+  const bool seq = combiner == -1;
+  const bool pathc = part && part_env >= 2 && train && (combiner >= 0 || (seq && seq_env)) && hot_ws && bcsr && aligned16 &&
+                     emb_dim <= (4 << lg) && (seq || n <= 8 * num_bags) && value_dtype <= 1 && out_dtype <= 1 &&
+                     num_bags < (1ll << 31) - 4096;
   if (part && a.mt && !pathc) { part = false; a.P = 0; a.mt = 0; }   // several tables: path (c) or the per-slot counters
   if (pathc) {
     a.tile_bags = (int32_t*)((uint8_t*)backward_workspace + al256(4 * (n + 1)) + al256(4 * n));   // head of the grouping workspace
@@ -2227,10 +2262,21 @@ int mi355_demb_forward_fused(
     if (part) {
       const char* fm = getenv("MI355_FUSED_FASTMOD");   // (read per call: A/B inside one process; default on with path (c))
       const bool fast = (fm ? atoi(fm) != 0 : pathc) && (a.t.C & (a.t.C - 1)) == 0 && (a.S >> __builtin_ctzll((unsigned long long)a.t.C)) < (1ll << 31);
-      if (pathc && a.mt && fast) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, true, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
-      else if (pathc && a.mt) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, false, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
-      else if (pathc && fast) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
-      else if (pathc) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, false, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
+      if (pathc) {
+#define LAUNCH_C(FAST, MT, SEQ) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, FAST, true, MT, SEQ>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a)
+        const int v = (fast ? 4 : 0) | (a.mt ? 2 : 0) | (seq ? 1 : 0);
+        switch (v) {
+          case 0: LAUNCH_C(false, false, false); break;
+          case 1: LAUNCH_C(false, false, true); break;
+          case 2: LAUNCH_C(false, true, false); break;
+          case 3: LAUNCH_C(false, true, true); break;
+          case 4: LAUNCH_C(true, false, false); break;
+          case 5: LAUNCH_C(true, false, true); break;
+          case 6: LAUNCH_C(true, true, false); break;
+          default: LAUNCH_C(true, true, true); break;
+        }
+#undef LAUNCH_C
+      }
       else if (fast) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
       else hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
     } else
@@ -2261,7 +2307,17 @@ int mi355_demb_forward_fused(
     const int nsub = 64 >> lg;
     hipLaunchKernelGGL(fused_part3_kernel, dim3((unsigned)a.P), dim3(kP3Threads), 0, stream, a, o, bptr, bcsr, hot);
     MI355_LAUNCH_CHECK();
-    {
+    if (seq) {
+      RoctxRange rg("op:gather_embedding");
+      GatherTimer gt(stream);
+      const unsigned grid = (unsigned)grid_for(n, 4 * nsub, 1 << 20);
+#define LAUNCH_RG(S, D) hipLaunchKernelGGL((gather_rows_late_kernel<S, D>), dim3(grid), dim3(256), 0, stream, a.occ_addr, late, n, (int)emb_dim, out, emb_dim, lg)
+      if (value_dtype == 0 && out_dtype == 0) LAUNCH_RG(kF32, kF32);
+      else if (value_dtype == 0) LAUNCH_RG(kF32, kBF16);
+      else if (out_dtype == 0) LAUNCH_RG(kBF16, kF32);
+      else LAUNCH_RG(kBF16, kBF16);
+#undef LAUNCH_RG
+    } else {
       RoctxRange rg("op:gather_embedding");
       GatherTimer gt(stream);
       const unsigned grid = (unsigned)grid_for(num_bags, 4 * nsub * 4, 1 << 20);

@@ -159,13 +159,17 @@ def test_multi_table_batches_of_a_few_hundred_thousand_keys_against_the_per_op_c
 
 
 @pytest.mark.parametrize("case", ["eight_equal", "skewed", "shared_table_mixed_dims"])
-@pytest.mark.parametrize("pooling,opt,strategy", [("SUM", "SGD", "TIMESTAMP"), ("MEAN", "ADAM", "LFU"), ("SUM", "EXACT_ROWWISE_ADAGRAD", "STEP")])
+@pytest.mark.parametrize("pooling,opt,strategy", [("SUM", "SGD", "TIMESTAMP"), ("MEAN", "ADAM", "LFU"), ("SUM", "EXACT_ROWWISE_ADAGRAD", "STEP"),
+                                                  ("NONE", "SGD", "LFU"), ("NONE", "ADAM", "TIMESTAMP")])
 def test_multi_table_pooled_batches_take_the_csr_writing_partition_path(case, pooling, opt, strategy, monkeypatch):
     """round 4: path (c) with TABLE-ALIGNED partitions (every table owns whole partitions, the rest dealt by its share of the
     batch's keys) against the per-op chain -- eight equal tables (the 8 x 8192-bag shape of tools/bench_model_shapes.py), a skewed
     batch (one table with nearly all keys, one with a handful, one with NONE), and two features sharing a table with mixed row
-    widths.  Same pooled output, the same unique rows PER TABLE (the unique order stays table-major), reverse indices that point
+    widths; pooled (SUM / MEAN) and sequence lookups (NONE: occurrence j is its own bag, rows copied by the late-row variant of the
+    sequence gather).  Same output, the same unique rows PER TABLE (the unique order stays table-major), reverse indices that point
     at the key's own table, same stored keys / rows / optimizer state after three steps."""
+    if pooling == "NONE" and case == "shared_table_mixed_dims":
+        pytest.skip("sequence lookups need one row width")
     if case == "eight_equal":
         dims, fmap, B = (16,) * 8, None, 6_000
         hi = [60_000] * 8
@@ -225,6 +229,61 @@ def test_multi_table_pooled_batches_take_the_csr_writing_partition_path(case, po
     for t in range(len(dims)):
         k1, v1 = ref.export_keys_values(ref._table_names[t], torch.device(DEV))
         k2, v2 = dut.export_keys_values(dut._table_names[t], torch.device(DEV))
+        o1, o2 = torch.argsort(k1), torch.argsort(k2)
+        assert k1.numel() == k2.numel() and torch.equal(k1[o1], k2[o2])
+        torch.testing.assert_close(v1[o1], v2[o2], rtol=3e-5, atol=3e-6)
+
+
+@pytest.mark.parametrize("tokens,opt,strategy,bucket", [(70_000, "SGD", "TIMESTAMP", 128), (131_072, "ADAM", "LFU", 128), (400_000, "SGD", "STEP", 128),
+                                                         (90_000, "SGD", "LFU", 16)])
+def test_sequence_lookups_of_one_table_take_the_csr_writing_partition_path(tokens, opt, strategy, bucket, monkeypatch):
+    """round 4: sequence lookups (pooling NONE) on path (c) -- the probe kernel takes occurrence j as its own bag, the partition
+    kernel writes the backward's CSR over gradient ROWS, the rows are copied by gather_rows_late_kernel -- against the per-op chain
+    over training steps (the last case with 16-slot buckets that fill up: rows that come out of an eviction are resolved late,
+    through the key's record; there only what does not depend on the eviction order is compared)."""
+    cap = 1 << 21 if bucket == 128 else 1 << 15
+    ref = _mk(False, (16,), cap=cap, pooling="NONE", opt=opt, strategy=strategy, bucket=bucket, learning_rate=0.2, monkeypatch=monkeypatch)
+    dut = _mk(True, (16,), cap=cap, pooling="NONE", opt=opt, strategy=strategy, bucket=bucket, learning_rate=0.2, monkeypatch=monkeypatch)
+    rng = np.random.default_rng(tokens)
+    ref.train(); dut.train()
+    took_c = 0
+    exact = bucket == 128
+    for it in range(3):
+        off = torch.arange(tokens + 1, dtype=torch.int64, device=DEV)
+        hi = 300_000 + 100_000 * it if exact else 60_000
+        keys = torch.from_numpy(((rng.zipf(1.15, tokens) + 7 * it) % hi).astype(np.int64)).to(DEV)
+        o_ref, s_ref = ref._forward_impl(keys, off, train=True)
+        o_dut, s_dut = dut._forward_impl(keys, off, train=True)
+        took_c += int(bool(getattr(s_dut, "lazy", False)))
+        # (keys that find no slot at all -- every slot of their bucket is used by this very batch -- are one unique row each on the
+        #  per-op chain and ONE row-less entry per partition here: no row is updated from either)
+        assert int(s_ref.uoff[-1]) == int(s_dut.uoff[-1]) if exact else int(s_dut.uoff[-1]) <= int(s_ref.uoff[-1])
+        if exact:
+            torch.testing.assert_close(o_ref, o_dut, rtol=1e-5, atol=1e-5, msg=f"step {it}: forward differs")
+        else:   # every occurrence of a key got the same row, and it is the row the table holds for the key right now
+            ks, vs = dut.export_keys_values(dut._table_names[0], torch.device(DEV))
+            order = torch.argsort(ks)
+            ks, vs = ks[order], vs[order]
+            idx = torch.searchsorted(ks, keys).clamp(max=ks.numel() - 1)
+            found = ks[idx] == keys
+            torch.testing.assert_close(o_dut, vs[idx] * found[:, None], rtol=1e-6, atol=1e-6)
+            assert int(found.sum()) > tokens // 2
+        if it == 1:
+            nu = int(s_dut.uoff[-1])
+            rev = s_dut.rev
+            uk = torch.zeros(nu, dtype=torch.int64, device=DEV)
+            uk[rev] = keys
+            has_row = torch.ones_like(keys, dtype=torch.bool) if exact else found   # (row-less keys share an entry, see above)
+            assert torch.equal(uk[rev][has_row], keys[has_row]) and int(torch.unique(rev).numel()) == nu
+        g = torch.rand_like(o_ref) + 0.1
+        ref._backward_impl(s_ref, g)
+        dut._backward_impl(s_dut, g)
+        assert torch.equal(ref.size(), dut.size())
+        assert _counters_clear(dut)
+    assert took_c == 3, "the sequence batch did not take the CSR-writing partition path"
+    if exact:
+        k1, v1 = ref.export_keys_values(ref._table_names[0], torch.device(DEV))
+        k2, v2 = dut.export_keys_values(dut._table_names[0], torch.device(DEV))
         o1, o2 = torch.argsort(k1), torch.argsort(k2)
         assert k1.numel() == k2.numel() and torch.equal(k1[o1], k2[o2])
         torch.testing.assert_close(v1[o1], v2[o2], rtol=3e-5, atol=3e-6)

@@ -11,6 +11,7 @@ from dynamicemb.dynamicemb_config import (DynamicEmbInitializerArgs, DynamicEmbI
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=50)
+ap.add_argument("--only", type=int, default=-1, help="run only case N (0-based; for a rocprofv3 kernel trace of one shape)")
 a = ap.parse_args()
 dev = torch.device("cuda")
 
@@ -67,8 +68,11 @@ def case(name, T, rows, tokens, pooling, hot):
     print(f"{name:46s} keys/step {nk:9.0f}  {ms:7.4f} ms/step  {nk / ms / 1e6:7.2f} G lookups/s", flush=True)
 
 
-case("C2: 1 table, pooled SUM, 65536 bags x ~5.5", 1, 10_000_000, 65536, "SUM", 5)
-case("1 table, sequence, 131072 tokens", 1, 10_000_000, 131072, "NONE", 1)
-case("8 tables, sequence, 8 x 16384 tokens", 8, 6_250_000, 16384, "NONE", 1)
-case("8 tables, pooled SUM, 8 x 8192 bags x ~5.5", 8, 6_250_000, 8192, "SUM", 5)
-case("1 table, sequence, 16384 tokens (one feature)", 1, 10_000_000, 16384, "NONE", 1)
+CASES = [("C2: 1 table, pooled SUM, 65536 bags x ~5.5", 1, 10_000_000, 65536, "SUM", 5),
+         ("1 table, sequence, 131072 tokens", 1, 10_000_000, 131072, "NONE", 1),
+         ("8 tables, sequence, 8 x 16384 tokens", 8, 6_250_000, 16384, "NONE", 1),
+         ("8 tables, pooled SUM, 8 x 8192 bags x ~5.5", 8, 6_250_000, 8192, "SUM", 5),
+         ("1 table, sequence, 16384 tokens (one feature)", 1, 10_000_000, 16384, "NONE", 1)]
+for i, c in enumerate(CASES):
+    if a.only < 0 or a.only == i:
+        case(*c)
