@@ -1906,32 +1906,88 @@ __global__ void __launch_bounds__(256) gather_pooled_late_kernel(PoolArgs g, Lat
 #endif
 }
 
-// sequence gather of path (c): out[j, :D] = the row of occurrence j, late rows through the key's record (LPR lanes per row;
-// 16-byte aligned rows only -- the path's condition)
+// A wave copies the 64 rows whose addresses its lanes hold (lane l: row i0 + l; 0 = no row -> zeros): 64 / LPR rows per step,
+// the addresses handed round with shuffles, UN steps' loads issued before their stores -- a wave keeps UN x 64 / LPR rows in flight
+// (one row per lane group and step left the copy latency bound: 2 K waves x 2 rows x 512 B = 2 MB in flight against the ~12 MB
+// that 8 TB/s x 1.5 us asks for).  Rows of one column group (D <= 4 LPR), 16-byte aligned; every load is unconditional (lanes
+// without a row read the zero row, see gather_dev.h).
 template <int SDT, int DDT>
-__global__ void __launch_bounds__(256)
-gather_rows_late_kernel(const int64_t* __restrict__ occ_addr, LateRefs late, int64_t n, int D, void* dst, int64_t dst_stride, int lpr_log2) {
+__device__ __forceinline__ void wave_copy_rows(uintptr_t rp, int64_t i0, int64_t n, int D, void* dst, int64_t dst_stride, int lpr_log2) {
+  constexpr int UN = 8;
+  constexpr int EB = SDT == kF32 ? 4 : 2;
+  const gptr_t zero = (gptr_t)(uintptr_t)g_zero_row;
   const int lane = lane_id();
   const int LPR = 1 << lpr_log2, R = 64 >> lpr_log2;
   const int sub = lane >> lpr_log2, c = lane & (LPR - 1);
-  const int64_t rows_per_block = (int64_t)(blockDim.x >> 6) * R;
-  for (int64_t r0 = (int64_t)blockIdx.x * rows_per_block + (int64_t)(threadIdx.x >> 6) * R; r0 < n; r0 += (int64_t)gridDim.x * rows_per_block) {
-    const int64_t i = r0 + sub;
-    if (i >= n) continue;
-    uintptr_t rp = (uintptr_t)occ_addr[i];
-    if (rp == 1) rp = late_row(late, i);
-    for (int e = 4 * c; e < D; e += 4 * LPR) {
-      const float4 v = rp ? ld4<SDT>(reinterpret_cast<const void*>(rp), e) : make_float4(0.f, 0.f, 0.f, 0.f);
-      st4<DDT>(dst, i * dst_stride + e, v);
+  const int rlo = (int)(rp & 0xffffffffu), rhi = (int)(rp >> 32);
+  const bool col = 4 * c < D;
+  for (int q0 = 0; q0 < 64; q0 += R * UN) {
+    float4 v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int src = (q0 + u * R + sub) & 63;
+      const uintptr_t ad = (uintptr_t)(unsigned)__shfl(rlo, src, 64) | ((uintptr_t)(unsigned)__shfl(rhi, src, 64) << 32);
+      const gptr_t p = (ad != 0 && col) ? (gptr_t)(ad + (uintptr_t)(4 * c * EB)) : zero;
+      v[u] = ld4g<SDT>(p);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int src = q0 + u * R + sub;
+      const int64_t i = i0 + src;
+      if (src < 64 && i < n && col) st4<DDT>(dst, i * dst_stride + 4 * c, v[u]);
     }
   }
 }
 
-// eval / inference forward in one launch (gather_dev.h: gather_pooled_eval)
+// sequence gather of path (c): out[j, :D] = the row of occurrence j, late rows through the key's record.  A wave owns 64
+// consecutive occurrences: one coalesced load of their address words, then wave_copy_rows.
 template <int SDT, int DDT>
+__global__ void __launch_bounds__(256)
+gather_rows_late_kernel(const int64_t* __restrict__ occ_addr, LateRefs late, int64_t n, int D, void* dst, int64_t dst_stride, int lpr_log2) {
+  const int64_t i0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;
+  if (i0 >= n) return;
+  const int64_t j = i0 + lane_id();
+  uintptr_t rp = j < n ? (uintptr_t)occ_addr[j] : 0;
+  if (__ballot(rp == 1)) { if (rp == 1) rp = late_row(late, j); }
+  wave_copy_rows<SDT, DDT>(rp, i0, n, D, dst, dst_stride, lpr_log2);
+}
+
+// eval / inference forward in one launch (gather_dev.h: gather_pooled_eval)
+template <int SDT, int DDT, bool kMT>
 __global__ void __launch_bounds__(256) gather_pooled_eval_kernel(PoolArgs g, ProbeRefs pr, int lpr_log2) {
+  __shared__ EvalTabs tabs;
+  if constexpr (kMT) eval_tabs_load(tabs, pr, g.offsets, g.B, g.n);
   const int64_t sg = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (64 >> lpr_log2) + (lane_id() >> lpr_log2);
-  gather_pooled_eval<SDT, DDT, 4, 4>(g, pr, lpr_log2, sg);
+  gather_pooled_eval<SDT, DDT, 4, 4, kMT>(g, pr, lpr_log2, sg, &tabs);
+}
+
+// eval / inference forward of SEQUENCE lookups in one launch (round 4): lane l of a wave probes key i0 + l (64 independent
+// three-hop chains per wave), then the wave copies the 64 rows, 64 / LPR at a time, the addresses handed round with shuffles;
+// unknown keys give zero rows (batched_dynamicemb_tables.py:1140-1218).  16-byte aligned rows; the conditions of the pooled form.
+template <int SDT, int DDT, bool kMT>
+__global__ void __launch_bounds__(256)
+gather_rows_eval_kernel(ProbeRefs pr, const int64_t* __restrict__ offsets, int B, int64_t n, int D, void* dst, int64_t dst_stride, int lpr_log2) {
+  __shared__ EvalTabs tabs;
+  if constexpr (kMT) eval_tabs_load(tabs, pr, offsets, B, n);
+  EvalTab one{};
+  if constexpr (!kMT) {
+    one.bkt0 = pr.tbo[0];
+    one.nb = (uint64_t)(pr.tbo[1] - one.bkt0);
+    one.tp0 = pr.table_ptrs[0]; one.rowb = pr.table_value_dims[0] * pr.elem_bytes;
+    one.magic = one.nb ? ~0ull / one.nb : 0ull;
+  }
+  if (!pr.timer) pr.timer = device_clock();
+  const int C = (int)pr.t.C;
+  const int cshift = __builtin_ctz((unsigned)C);
+  const int64_t i0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;
+  if (i0 >= n) return;
+  const int64_t j = i0 + lane_id();
+  const int64_t jc = j < n ? j : n - 1;
+  const uint64_t key = pr.keys[jc];
+  uintptr_t rp;
+  if constexpr (kMT) rp = eval_probe_key(pr, eval_tab_of(tabs, pr.T, jc), key, j < n, C, cshift);
+  else rp = eval_probe_key(pr, one, key, j < n, C, cshift);
+  wave_copy_rows<SDT, DDT>(rp, i0, n, D, dst, dst_stride, lpr_log2);
 }
 
 // lazy per-occurrence outputs of path (c): reverse index and full rank of every occurrence from its record, late row addresses
@@ -2220,28 +2276,51 @@ int mi355_demb_forward_fused(
   // ---- eval / inference forward of one table with pooled output: ONE kernel (every lane probes its own keys; no dedup, no
   //      unique numbering, no address array).  MI355_EVAL_FUSED=0 keeps the probe + gather pair.
   static const int eval_env = getenv("MI355_EVAL_FUSED") ? atoi(getenv("MI355_EVAL_FUSED")) : 1;
-  if (!train && eval_env && n > 0 && num_tables == 1 && combiner >= 0 && aligned16 && !use_count &&
+  if (!train && eval_env && n > 0 && num_tables >= 1 && num_tables <= kEvalMaxT && combiner >= -1 && aligned16 && !use_count &&
       (find_policy == kConst || find_policy == kAssign || find_policy == kGlobalTimer) && (bucket_capacity & (bucket_capacity - 1)) == 0 &&
-      value_dtype <= 1 && out_dtype <= 1 && num_buckets < (1ll << 31) && n <= 8 * num_bags) {
+      value_dtype <= 1 && out_dtype <= 1 && num_buckets < (1ll << 31) && (combiner == -1 || n <= 8 * num_bags)) {
     int le = 3;
     while ((4 << le) < emb_dim && le < 6) ++le;
-    if (emb_dim <= (4 << le)) {
+    static const int eval_mt_env = getenv("MI355_EVAL_FUSED_MT") ? atoi(getenv("MI355_EVAL_FUSED_MT")) : 1;   // 0: several tables / sequences keep the probe + gather pair
+    const bool mt = num_tables > 1;
+    if (emb_dim <= (4 << le) && (eval_mt_env || (!mt && combiner >= 0))) {
       RoctxRange rr("op:eval_lookup+gather_embedding");
-      PoolArgs g;
-      g.src = nullptr; g.src_stride = 0; g.row_addr = nullptr; g.rev = nullptr; g.offsets = offsets; g.D_offsets = D_offsets;
-      g.dst = out; g.FB = num_bags; g.n = n; g.B = (int)batch_size; g.D = (int)emb_dim; g.total_D = (int)total_D; g.combiner = combiner;
       ProbeRefs pr;
       pr.keys = (const uint64_t*)keys; pr.t = a.t; pr.tbo = table_bucket_offsets; pr.table_ptrs = table_ptrs;
       pr.table_value_dims = table_value_dims; pr.elem_bytes = a.elem_bytes; pr.find_policy = find_policy;
       pr.score_value = score_value; pr.timer = timer_override;
-      const unsigned grid = (unsigned)grid_for(num_bags, 4 * (64 >> le) * 4, 1 << 20);
+      pr.T = (int)num_tables; pr.feature_offsets = feature_offsets;
       GatherTimer gt(stream);
-#define LAUNCH_EV(S, D) hipLaunchKernelGGL((gather_pooled_eval_kernel<S, D>), dim3(grid), dim3(256), 0, stream, g, pr, le)
-      if (value_dtype == 0 && out_dtype == 0) LAUNCH_EV(kF32, kF32);
-      else if (value_dtype == 0) LAUNCH_EV(kF32, kBF16);
-      else if (out_dtype == 0) LAUNCH_EV(kBF16, kF32);
-      else LAUNCH_EV(kBF16, kBF16);
+      if (combiner == -1) {
+        const unsigned grid = (unsigned)ceil_div(n, 256);
+#define LAUNCH_ER(S, D)                                                                                                                      \
+  do {                                                                                                                                       \
+    if (mt) hipLaunchKernelGGL((gather_rows_eval_kernel<S, D, true>), dim3(grid), dim3(256), 0, stream, pr, offsets, (int)batch_size, n,    \
+                               (int)emb_dim, out, emb_dim, le);                                                                              \
+    else hipLaunchKernelGGL((gather_rows_eval_kernel<S, D, false>), dim3(grid), dim3(256), 0, stream, pr, offsets, (int)batch_size, n,      \
+                            (int)emb_dim, out, emb_dim, le);                                                                                 \
+  } while (0)
+        if (value_dtype == 0 && out_dtype == 0) LAUNCH_ER(kF32, kF32);
+        else if (value_dtype == 0) LAUNCH_ER(kF32, kBF16);
+        else if (out_dtype == 0) LAUNCH_ER(kBF16, kF32);
+        else LAUNCH_ER(kBF16, kBF16);
+#undef LAUNCH_ER
+      } else {
+        PoolArgs g;
+        g.src = nullptr; g.src_stride = 0; g.row_addr = nullptr; g.rev = nullptr; g.offsets = offsets; g.D_offsets = D_offsets;
+        g.dst = out; g.FB = num_bags; g.n = n; g.B = (int)batch_size; g.D = (int)emb_dim; g.total_D = (int)total_D; g.combiner = combiner;
+        const unsigned grid = (unsigned)grid_for(num_bags, 4 * (64 >> le) * 4, 1 << 20);
+#define LAUNCH_EV(S, D)                                                                                                        \
+  do {                                                                                                                         \
+    if (mt) hipLaunchKernelGGL((gather_pooled_eval_kernel<S, D, true>), dim3(grid), dim3(256), 0, stream, g, pr, le);        \
+    else hipLaunchKernelGGL((gather_pooled_eval_kernel<S, D, false>), dim3(grid), dim3(256), 0, stream, g, pr, le);          \
+  } while (0)
+        if (value_dtype == 0 && out_dtype == 0) LAUNCH_EV(kF32, kF32);
+        else if (value_dtype == 0) LAUNCH_EV(kF32, kBF16);
+        else if (out_dtype == 0) LAUNCH_EV(kBF16, kF32);
+        else LAUNCH_EV(kBF16, kBF16);
 #undef LAUNCH_EV
+      }
       MI355_LAUNCH_CHECK();
       return MI355_OK;
     }
@@ -2310,7 +2389,7 @@ int mi355_demb_forward_fused(
     if (seq) {
       RoctxRange rg("op:gather_embedding");
       GatherTimer gt(stream);
-      const unsigned grid = (unsigned)grid_for(n, 4 * nsub, 1 << 20);
+      const unsigned grid = (unsigned)ceil_div(n, 256);
 #define LAUNCH_RG(S, D) hipLaunchKernelGGL((gather_rows_late_kernel<S, D>), dim3(grid), dim3(256), 0, stream, a.occ_addr, late, n, (int)emb_dim, out, emb_dim, lg)
       if (value_dtype == 0 && out_dtype == 0) LAUNCH_RG(kF32, kF32);
       else if (value_dtype == 0) LAUNCH_RG(kF32, kBF16);

@@ -203,20 +203,105 @@ __device__ __forceinline__ void gather_pooled_pipe(const PoolArgs& a, const Late
 struct ProbeRefs {
   const uint64_t* keys = nullptr;
   Table t{};
-  const int64_t* tbo = nullptr;               // [2] bucket range of the table
-  const int64_t* table_ptrs = nullptr;        // [1] rows: base address
-  const int64_t* table_value_dims = nullptr;  // [1] elements per row
+  const int64_t* tbo = nullptr;               // [T + 1] bucket ranges of the tables
+  const int64_t* table_ptrs = nullptr;        // [T] rows: base address
+  const int64_t* table_value_dims = nullptr;  // [T] elements per row
   int elem_bytes = 0;
   int find_policy = 0;                        // kConst / kAssign / kGlobalTimer
   uint64_t score_value = 0, timer = 0;        // timer == 0: the device clock
+  // several tables (round 4): table t owns the keys [offsets[feature_offsets[t] B], offsets[feature_offsets[t + 1] B])
+  int T = 1;
+  const int64_t* feature_offsets = nullptr;   // [T + 1]
 };
+
+// Per-table scalars of the multi-table eval kernels, staged in LDS once per block (one two-hop load, then a barrier): a key's
+// table is a binary search of its position in `seg`, everything else an LDS read -- against three to four more dependent
+// global hops per key if the lanes searched the offsets themselves.
+constexpr int kEvalMaxT = 128;
+struct EvalTabs {
+  int64_t seg[kEvalMaxT + 1];     // first key of every table (seg[T] = n)
+  int64_t tbo[kEvalMaxT + 1];
+  uint64_t magic[kEvalMaxT];      // floor((2^64 - 1) / buckets)
+  int64_t tptr[kEvalMaxT];
+  int rowb[kEvalMaxT];            // bytes per row
+};
+// called by the whole block; ends with a barrier
+__device__ __forceinline__ void eval_tabs_load(EvalTabs& L, const ProbeRefs& pr, const int64_t* offsets, int B, int64_t n) {
+  for (int t = threadIdx.x; t <= pr.T; t += blockDim.x) {
+    L.seg[t] = t == pr.T ? n : offsets[pr.feature_offsets[t] * B];
+    L.tbo[t] = pr.tbo[t];
+    if (t < pr.T) {
+      const uint64_t nb = (uint64_t)(pr.tbo[t + 1] - pr.tbo[t]);
+      L.magic[t] = nb ? ~0ull / nb : 0ull;
+      L.tptr[t] = pr.table_ptrs[t];
+      L.rowb[t] = (int)pr.table_value_dims[t] * pr.elem_bytes;
+    }
+  }
+  __syncthreads();
+}
+
+// the scalars of ONE table a probe needs
+struct EvalTab {
+  int64_t bkt0, tp0, rowb;
+  uint64_t nb, magic;
+};
+__device__ __forceinline__ EvalTab eval_tab_of(const EvalTabs& L, int T, int64_t j) {
+  int lo = 0, hi = T;      // first t with seg[t + 1] > j
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (L.seg[mid + 1] <= j) lo = mid + 1; else hi = mid; }
+  const int t = lo < T ? lo : T - 1;
+  EvalTab e;
+  e.bkt0 = L.tbo[t]; e.nb = (uint64_t)(L.tbo[t + 1] - e.bkt0); e.magic = L.magic[t]; e.tp0 = L.tptr[t]; e.rowb = L.rowb[t];
+  return e;
+}
+
+// Row address of `key` in table `e` (0: unknown key / !have): digest vector, key word, row -- three dependent hops; a found key's
+// score is refreshed (score.cuh:72-96; idempotent across the key's occurrences).
+__device__ __forceinline__ uintptr_t eval_probe_key(const ProbeRefs& pr, const EvalTab& e, uint64_t key, bool have, int C, int cshift) {
+  const int64_t hash = (int64_t)(fmix64(key) & 0x7FFFFFFFFFFFFFFFull);
+  const uint64_t x = (uint64_t)hash >> cshift;
+  uint64_t rr = x - __umul64hi(x, e.magic) * e.nb;
+  if (rr >= e.nb) rr -= e.nb;
+  if (rr >= e.nb) rr -= e.nb;
+  const int b = (int)(e.bkt0 + (int64_t)(e.nb ? rr : 0ull));
+  const int st = (int)((uint64_t)hash & (uint64_t)(C - 1)) & ~15;
+  have = have && is_valid(key) && e.nb > 0;
+  const uint4 dv = *reinterpret_cast<const uint4*>(pr.t.dig(b) + st);
+  const uint32_t m0 = eq_mask16(dv, digest_of(hash));
+  int slot = m0 ? st + __ffs(m0) - 1 : -1;
+  const uint64_t kw = pr.t.keys(b)[slot >= 0 ? slot : 0];
+  slot = (slot >= 0 && kw == key) ? slot : -2;
+  if (__ballot(have && slot == -2)) {   // the first candidate was another key, the key sits beyond the first vector, or is unknown
+    if (have && slot == -2) {
+      slot = -1;
+      const uint32_t d = digest_of(hash);
+      const uint64_t* ks = pr.t.keys(b);
+      const uint8_t* dg = pr.t.dig(b);
+      for (int gi = 0; gi < (C >> 4) && slot < 0; ++gi) {
+        int p0 = st + (gi << 4);
+        if (p0 >= C) p0 -= C;
+        uint32_t m = eq_mask16(*reinterpret_cast<const uint4*>(dg + p0), d);
+        while (m) {
+          const int bit = __ffs(m) - 1;
+          m &= m - 1;
+          if (ks[p0 + bit] == key) { slot = p0 + bit; break; }
+        }
+      }
+    }
+  }
+  if (!have || slot < 0) return 0;
+  uint64_t* sc = pr.t.scores(b) + (int64_t)slot * pr.t.ns;
+  if (pr.find_policy == kGlobalTimer) *sc = pr.timer;
+  else if (pr.find_policy == kAssign) *sc = pr.score_value;
+  return (uintptr_t)(e.tp0 + (((int64_t)b - e.bkt0) * C + slot) * e.rowb);
+}
 
 // one-launch eval forward, lane-group form: the KIT bags of a lane group are ONE contiguous run of keys, so lane c probes the
 // run's key c (one key per lane: ~12 registers of probe state instead of KIT times that) and the bag loop picks its rows'
 // addresses out of the lanes with shuffles.  Keys beyond the first LPR of the run (a few per cent of the groups at C2) are
 // probed when their bag is reached (dependent hops).
-template <int SDT, int DDT, int UNR, int KIT>
-__device__ __forceinline__ void gather_pooled_eval(const PoolArgs& a, ProbeRefs pr, int lpr_log2, int64_t sg) {
+// kMT: several tables -- `tabs` (LDS, eval_tabs_load) holds their scalars, a key's table follows from its position.
+template <int SDT, int DDT, int UNR, int KIT, bool kMT = false>
+__device__ __forceinline__ void gather_pooled_eval(const PoolArgs& a, ProbeRefs pr, int lpr_log2, int64_t sg, const EvalTabs* tabs = nullptr) {
   const int lane = lane_id();
   const int LPR = 1 << lpr_log2;
   const int c = lane & (LPR - 1);
@@ -230,13 +315,16 @@ __device__ __forceinline__ void gather_pooled_eval(const PoolArgs& a, ProbeRefs 
     b = b < a.FB ? b : a.FB;
     myoff = a.offsets[b];
   }
-  const int64_t bkt0 = pr.tbo[0];
-  const uint64_t nb = (uint64_t)(pr.tbo[1] - bkt0);
-  const int64_t tp0 = pr.table_ptrs[0], rowb = pr.table_value_dims[0] * pr.elem_bytes;
+  EvalTab one{};
+  if constexpr (!kMT) {
+    one.bkt0 = pr.tbo[0];
+    one.nb = (uint64_t)(pr.tbo[1] - one.bkt0);
+    one.tp0 = pr.table_ptrs[0]; one.rowb = pr.table_value_dims[0] * pr.elem_bytes;
+    one.magic = one.nb ? ~0ull / one.nb : 0ull;
+  }
   if (!pr.timer) pr.timer = device_clock();
   const int C = (int)pr.t.C;
   const int cshift = __builtin_ctz((unsigned)C);
-  const uint64_t magic = nb ? ~0ull / nb : 0ull;
   const int off_lo = (int)(myoff & 0xffffffff), off_hi = (int)(myoff >> 32);
   auto bag_off = [&](int i) -> int64_t {
     i = i <= KIT ? i : KIT;
@@ -244,47 +332,13 @@ __device__ __forceinline__ void gather_pooled_eval(const PoolArgs& a, ProbeRefs 
   };
   // row address of the key at position j (0: unknown key / j >= jend): three dependent hops
   auto probe = [&](int64_t j, int64_t jend) -> uintptr_t {
-    bool have = j < jend;
+    const bool have = j < jend;
     int64_t jc = have ? j : jend - 1;
     jc = jc < 0 ? 0 : jc;
     jc = jc < a.n ? jc : a.n - 1;
     const uint64_t key = pr.keys[jc];
-    const int64_t hash = (int64_t)(fmix64(key) & 0x7FFFFFFFFFFFFFFFull);
-    const uint64_t x = (uint64_t)hash >> cshift;
-    uint64_t rr = x - __umul64hi(x, magic) * nb;
-    if (rr >= nb) rr -= nb;
-    if (rr >= nb) rr -= nb;
-    const int b = (int)(bkt0 + (int64_t)(nb ? rr : 0ull));
-    const int st = (int)((uint64_t)hash & (uint64_t)(C - 1)) & ~15;
-    have = have && is_valid(key) && nb > 0;
-    const uint4 dv = *reinterpret_cast<const uint4*>(pr.t.dig(b) + st);
-    const uint32_t m0 = eq_mask16(dv, digest_of(hash));
-    int slot = m0 ? st + __ffs(m0) - 1 : -1;
-    const uint64_t kw = pr.t.keys(b)[slot >= 0 ? slot : 0];
-    slot = (slot >= 0 && kw == key) ? slot : -2;
-    if (__ballot(have && slot == -2)) {   // the first candidate was another key, the key sits beyond the first vector, or is unknown
-      if (have && slot == -2) {
-        slot = -1;
-        const uint32_t d = digest_of(hash);
-        const uint64_t* ks = pr.t.keys(b);
-        const uint8_t* dg = pr.t.dig(b);
-        for (int gi = 0; gi < (C >> 4) && slot < 0; ++gi) {
-          int p0 = st + (gi << 4);
-          if (p0 >= C) p0 -= C;
-          uint32_t m = eq_mask16(*reinterpret_cast<const uint4*>(dg + p0), d);
-          while (m) {
-            const int bit = __ffs(m) - 1;
-            m &= m - 1;
-            if (ks[p0 + bit] == key) { slot = p0 + bit; break; }
-          }
-        }
-      }
-    }
-    if (!have || slot < 0) return 0;
-    uint64_t* sc = pr.t.scores(b) + (int64_t)slot * pr.t.ns;
-    if (pr.find_policy == kGlobalTimer) *sc = pr.timer;        // (score.cuh:72-96; idempotent across the key's occurrences)
-    else if (pr.find_policy == kAssign) *sc = pr.score_value;
-    return (uintptr_t)(tp0 + (((int64_t)b - bkt0) * C + slot) * rowb);
+    if constexpr (kMT) return eval_probe_key(pr, eval_tab_of(*tabs, pr.T, jc), key, have, C, cshift);
+    else return eval_probe_key(pr, one, key, have, C, cshift);
   };
   // rows whose addresses sit in lanes base .. base + nq - 1 of `rp`
   auto add_rows = [&](uintptr_t rp, int base, int nq, int Df, float4& acc) {

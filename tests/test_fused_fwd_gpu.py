@@ -232,6 +232,13 @@ def test_multi_table_pooled_batches_take_the_csr_writing_partition_path(case, po
         o1, o2 = torch.argsort(k1), torch.argsort(k2)
         assert k1.numel() == k2.numel() and torch.equal(k1[o1], k2[o2])
         torch.testing.assert_close(v1[o1], v2[o2], rtol=3e-5, atol=3e-6)
+    # eval forward (round 4: ONE kernel for several tables and for sequence lookups too -- every lane probes its own key, the
+    # key's table follows from its position) against the per-op chain; unknown keys (the shifted stream) give zero rows
+    ref.eval(); dut.eval()
+    with torch.no_grad():
+        for kk in (keys, keys + 1_000_003):
+            torch.testing.assert_close(ref._forward_impl(kk, off, train=False)[0], dut._forward_impl(kk, off, train=False)[0],
+                                       rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("tokens,opt,strategy,bucket", [(70_000, "SGD", "TIMESTAMP", 128), (131_072, "ADAM", "LFU", 128), (400_000, "SGD", "STEP", 128),
@@ -281,6 +288,18 @@ def test_sequence_lookups_of_one_table_take_the_csr_writing_partition_path(token
         assert torch.equal(ref.size(), dut.size())
         assert _counters_clear(dut)
     assert took_c == 3, "the sequence batch did not take the CSR-writing partition path"
+    ref.eval(); dut.eval()
+    with torch.no_grad():   # one-kernel sequence eval (gather_rows_eval_kernel): known keys give their rows, unknown ones zeros
+        for kk in (keys, keys + 1_000_003):
+            e_dut = dut._forward_impl(kk, off, train=False)[0]
+            if exact:
+                torch.testing.assert_close(ref._forward_impl(kk, off, train=False)[0], e_dut, rtol=1e-5, atol=1e-5)
+            else:
+                ks, vs = dut.export_keys_values(dut._table_names[0], torch.device(DEV))
+                order = torch.argsort(ks)
+                ks, vs = ks[order], vs[order]
+                idx = torch.searchsorted(ks, kk).clamp(max=ks.numel() - 1)
+                torch.testing.assert_close(e_dut, vs[idx] * (ks[idx] == kk)[:, None], rtol=1e-6, atol=1e-6)
     if exact:
         k1, v1 = ref.export_keys_values(ref._table_names[0], torch.device(DEV))
         k2, v2 = dut.export_keys_values(dut._table_names[0], torch.device(DEV))

@@ -11,6 +11,7 @@ from dynamicemb.dynamicemb_config import (DynamicEmbInitializerArgs, DynamicEmbI
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=50)
+ap.add_argument("--eval", action="store_true", help="time the eval / inference forward of every shape instead of the training step")
 ap.add_argument("--only", type=int, default=-1, help="run only case N (0-based; for a rocprofv3 kernel trace of one shape)")
 a = ap.parse_args()
 dev = torch.device("cuda")
@@ -55,6 +56,14 @@ def case(name, T, rows, tokens, pooling, hot):
         out, st = m._forward_impl(k, o, train=True)
         gg = g if out.shape == g.shape else (torch.zeros_like(out))
         m._backward_impl(st, gg)
+
+    if a.eval:
+        m.eval()
+
+        def step(i):   # noqa: F811
+            k, o = batches[i % len(batches)]
+            with torch.no_grad():
+                m._forward_impl(k, o, train=False)
 
     for i in range(10):
         step(i)
