@@ -320,6 +320,16 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
     const int64_t pt = (int64_t)blockIdx.x * HALVES + threadIdx.x;
     if (pt * 1024 < a.n) { a.tstat[pt] = 0ull; if (kPart) a.tstat[a.P + pt] = 0ull; }
   }
+  if constexpr (kPart && kTrain) {   // more partitions than 1024-key tile halves (small batches with thin partitions): the rest of the 2 P words
+    const int have = (int)((a.n + 1023) >> 10);
+    if (a.P > have && a.tstat) {
+      const int per = (2 * a.P + (int)gridDim.x - 1) / (int)gridDim.x;
+      for (int k = threadIdx.x; k < per; k += THREADS) {
+        const int wd = (int)blockIdx.x * per + k;
+        if (wd < 2 * a.P) a.tstat[wd] = 0ull;
+      }
+    }
+  }
   for (int s = threadIdx.x; s < LDS; s += THREADS) { s_tab[s] = -1; s_cnt[s] = 0; }
   if (threadIdx.x < HALVES) s_nrep[threadIdx.x] = 0;
   if constexpr (kPart) for (int p = threadIdx.x; p < a.P; p += THREADS) s_hist[p] = 0;
@@ -2141,7 +2151,12 @@ static inline int part_count(int64_t n, int64_t num_tables) {
   static const int mt_env = getenv("MI355_FUSED_MT") ? atoi(getenv("MI355_FUSED_MT")) : 1;
   if (!env || n < (64 << 10) || n > (int64_t)kPartMax * 1024) return 0;
   if (num_tables != 1 && (!mt_env || env < 2 || num_tables < 1 || num_tables > kFusedMaxT)) return 0;
+  // keys per partition (MI355_FUSED_KPP, default 1024): the partition kernel is one block per partition and a chain of dependent
+  // phases -- below 256 partitions it leaves CUs idle, so small batches may as well get thinner partitions
+  static const int kpp_env = getenv("MI355_FUSED_KPP") ? atoi(getenv("MI355_FUSED_KPP")) : 1024;
+  const int kpp = kpp_env >= 256 && kpp_env <= 1024 ? kpp_env : 1024;
   int P = (int)((n + 1023) / 1024);
+  if (kpp < 1024 && P < 256) { P = (int)((n + kpp - 1) / kpp); if (P > 256) P = 256; }
   if (num_tables > 1 && P < 4 * num_tables) return 0;
   // the partition kernel of path (c) is one 1024-thread block per partition and per CU: up to 1.5 K keys per partition (about
   // 1.1 K records of the 2 K a partition can hold) the batch gets exactly one block per CU instead of a second, thin generation
@@ -2158,7 +2173,7 @@ int mi355_demb_forward_fused_partitions(int64_t n, int64_t num_tables, int64_t n
 int64_t mi355_demb_forward_fused_workspace_bytes(int64_t n, int64_t num_tables) {
   const int64_t nt = (n + 1023) / 1024 + 2;
   return al256(8 * (num_tables + 1)) + al256(8 * n) /*unique keys*/ + al256(8 * n) /*occ_addr*/ + al256(4 * n) /*occ_slot*/ +
-         al256(4 * nt) + 256 /*total*/ + al256(8 * n) + 4 * al256(4 * n) /*deferred*/ + al256(16 * nt) /*look-back*/ + 256 +
+         al256(4 * nt) + 256 /*total*/ + al256(8 * n) + 4 * al256(4 * n) /*deferred*/ + al256(16 * (nt > 258 ? nt : 258)) /*look-back: two words per 1024 keys, and per partition*/ + 256 +
          (part_count(n, num_tables) ? 32 * (int64_t)part_count(n, num_tables) * kPartCap + 5 * 256 + 4 * kPartMax : 0) /*partition records, table of every partition*/;
 }
 
@@ -2220,7 +2235,7 @@ int mi355_demb_forward_fused(
   a.d_cnt = (int32_t*)w; w += al256(4 * n);
   a.d_slot = (int32_t*)w; w += al256(4 * n);
   a.d_base = (int32_t*)w; w += al256(4 * n);
-  a.tstat = (unsigned long long*)w; w += al256(16 * nt);
+  a.tstat = (unsigned long long*)w; w += al256(16 * (nt > 258 ? nt : 258));
   // partitioned index stage: one table, a batch of 64 K .. 1 M keys, at least 8 buckets per partition, training
   a.P = 0; a.spp = 1; a.pcount = aux + 64;
   a.rec = nullptr; a.rec_out = nullptr; a.rec_out4 = nullptr;
@@ -2500,7 +2515,7 @@ int mi355_demb_fused_materialize(void* workspace, int64_t workspace_bytes, int64
   const int32_t* occ_slot = (const int32_t*)w; w += al256(4 * n);
   w += al256(4 * nt) + 256 + al256(8 * n);
   const int32_t* occ_trank = (const int32_t*)w; w += 4 * al256(4 * n);
-  w += al256(16 * nt);
+  w += al256(16 * (nt > 258 ? nt : 258));
   w += al256(16 * (int64_t)P * kPartCap);
   const int4* rec_out4 = (const int4*)w;
   hipLaunchKernelGGL(occ_from_records_kernel, dim3((unsigned)grid_for(n, 256, 4096)), dim3(256), 0, stream, occ_slot, occ_trank, rec_out4,

@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 4: kernel traces of the 8-table pooled shape (path (c), table-aligned partitions) and of C2 through the same tool
+# round 4: kernel traces of the model shapes (tools/bench_model_shapes.py --only N): args = case numbers
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r4mt; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-for c in 3 0 2; do
+for c in "$@"; do
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace$c -o t -- python $R/tools/bench_model_shapes.py --steps 50 --only $c > $O/trace$c.log 2>&1
-  f=$(ls $O/trace$c/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && head -14 $f | cut -c1-150
+  echo "== case $c"; python $R/tools/rocpd_stats.py $O/trace$c/t_results.db | head -8 | cut -c1-150
 done
