@@ -212,6 +212,17 @@ int mi355_block_bucketize(int64_t world_size, int64_t num_bags, int64_t batch_si
                           const void* indices, const int64_t* block_sizes, const int32_t* dist_type_per_feature,
                           const float* weights, int64_t* new_lengths, int64_t* new_offsets, void* new_indices,
                           float* new_weights, int64_t* unbucketize_permute, hipStream_t stream);
+/* The same op with the two remaining arguments of the reference's signature (sparse_block_bucketize_features.cu:366-380):
+ * `batch_size_per_feature` -- passed as feature_bag_starts [num_features + 1], the first bag of every feature (its exclusive
+ * prefix sum; nullptr: every feature has batch_size bags) -- and `block_bucketize_pos` -- uneven shard boundaries, the sorted
+ * boundaries of all features concatenated plus their offsets [num_features + 1] (:262-292, 341-347: rank = last boundary <= idx,
+ * new index = idx - that boundary; indices outside the boundaries: idx % W, idx / W; the dist types do not apply). */
+int mi355_block_bucketize_ex(int64_t world_size, int64_t num_bags, int64_t batch_size, const int64_t* offsets,
+                             const void* indices, const int64_t* block_sizes, const int32_t* dist_type_per_feature,
+                             const float* weights, int64_t* new_lengths, int64_t* new_offsets, void* new_indices,
+                             float* new_weights, int64_t* unbucketize_permute, const int64_t* feature_bag_starts,
+                             int64_t num_features, const int64_t* block_bucketize_pos_concat,
+                             const int64_t* block_bucketize_pos_offsets, hipStream_t stream);
 
 /* Glue of the row-wise input dist (dynamicemb/input_dist.py :199-285 + TorchRec KJTAllToAll, third party): exclusive
  * offsets of a lengths vector (offsets has n+1 entries); the keys sent to / received from every peer as differences of

@@ -518,6 +518,47 @@ void orc_block_bucketize(int64_t W, int64_t FB, int64_t B, const int64_t *offset
   free(cur);
 }
 
+/* The same op with FBGEMM's two generalisations (sparse_block_bucketize_features.cu:194-211, 228-292, 320-347):
+ * bag_feature [FB] (nullable) = the feature of every bag when the features have DIFFERENT batch sizes (the reference's
+ * length_to_feature_idx); pos_concat / pos_offsets [F + 1] (nullable) = uneven shard boundaries per feature: lb = (index of the
+ * first boundary > idx) - 1, rank = lb < W ? lb : idx % W, new index = lb < W ? idx - boundary[lb] : idx / W (the dist types do
+ * not apply then).  dist_type per feature [F] (nullable: 0). */
+void orc_block_bucketize_ex(int64_t W, int64_t FB, int64_t B, const int64_t *offsets, const uint64_t *indices,
+                            const int64_t *block_sizes, const int32_t *dist_type, const int64_t *bag_feature,
+                            const int64_t *pos_concat, const int64_t *pos_offsets,
+                            int64_t *new_lengths, int64_t *new_offsets, uint64_t *new_indices, int64_t *unbucketize_permute) {
+  for (int64_t i = 0; i < W * FB; ++i) new_lengths[i] = 0;
+  int64_t *cur = malloc(sizeof(int64_t) * (W * FB ? W * FB : 1));
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int64_t bag = 0; bag < FB; ++bag) {
+      int64_t f = bag_feature ? bag_feature[bag] : bag / B;
+      int dist = dist_type ? dist_type[f] : 0;
+      for (int64_t j = offsets[bag]; j < offsets[bag + 1]; ++j) {
+        uint64_t idx = indices[j], nw = idx; int64_t p;
+        if (pos_concat) {
+          int64_t first = pos_offsets[f], last = pos_offsets[f + 1];
+          while (first < last) { int64_t mid = first + (last - first) / 2; if ((uint64_t)pos_concat[mid] <= idx) first = mid + 1; else last = mid; }
+          uint64_t lb = (uint64_t)(first - pos_offsets[f] - 1);
+          if (lb < (uint64_t)W) { p = (int64_t)lb; nw = idx - (uint64_t)pos_concat[pos_offsets[f] + (int64_t)lb]; }
+          else { p = (int64_t)(idx % (uint64_t)W); nw = idx / (uint64_t)W; }
+        } else if (dist == 0) { uint64_t blk = (uint64_t)block_sizes[f];
+          if (idx < blk * (uint64_t)W) { p = (int64_t)(idx / blk); nw = idx % blk; }
+          else { p = (int64_t)(idx % (uint64_t)W); nw = idx / (uint64_t)W; } }
+        else if (dist == 1) p = (int64_t)(idx % (uint64_t)W);
+        else p = (int64_t)(orc_fmix64(idx) % (uint64_t)W);
+        if (pass == 0) new_lengths[p * FB + bag] += 1;
+        else { int64_t dst = cur[p * FB + bag]++; new_indices[dst] = nw; if (unbucketize_permute) unbucketize_permute[j] = dst; }
+      }
+    }
+    if (pass == 0) {
+      new_offsets[0] = 0;
+      for (int64_t i = 0; i < W * FB; ++i) new_offsets[i + 1] = new_offsets[i] + new_lengths[i];
+      memcpy(cur, new_offsets, sizeof(int64_t) * W * FB);
+    }
+  }
+  free(cur);
+}
+
 /* initializer DEBUG mode: src/initializer.cuh:158-176, dynamicemb_config.py:45:
  * every element of the row = float(key % 100000). */
 void orc_debug_init(int64_t n, int64_t dim, int64_t stride, const uint64_t *keys, float *rows) {

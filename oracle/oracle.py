@@ -310,6 +310,30 @@ def block_bucketize(offsets, indices, W, B, block_sizes, dist_type):
     return nl, no, ni, perm
 
 
+def block_bucketize_ex(offsets, indices, W, B, block_sizes, dist_types=None, bag_feature=None, pos=None):
+    """orc_block_bucketize_ex: per-feature dist types, variable batch size per feature (bag_feature [FB]) and uneven shard
+    boundaries (pos: one sorted int64 array of W + 1 boundaries per feature)."""
+    off = np.ascontiguousarray(offsets, dtype=np.int64)
+    idx = _keys(indices)
+    FB = off.size - 1
+    bs = np.ascontiguousarray(block_sizes, dtype=np.int64)
+    dt_ = None if dist_types is None else np.ascontiguousarray(dist_types, dtype=np.int32)
+    bf = None if bag_feature is None else np.ascontiguousarray(bag_feature, dtype=np.int64)
+    pc = po = None
+    if pos is not None:
+        pc = np.ascontiguousarray(np.concatenate([np.asarray(x, np.int64) for x in pos]), dtype=np.int64)
+        po = np.concatenate([[0], np.cumsum([len(x) for x in pos])]).astype(np.int64)
+    nl = np.empty(W * FB, np.int64)
+    no = np.empty(W * FB + 1, np.int64)
+    ni = np.empty(idx.size, np.uint64)
+    perm = np.empty(idx.size, np.int64)
+    none = ctypes.c_void_p(0)
+    lib().orc_block_bucketize_ex(_i64(W), _i64(FB), _i64(B), _p(off), _p(idx), _p(bs), _p(dt_) if dt_ is not None else none,
+                                 _p(bf) if bf is not None else none, _p(pc) if pc is not None else none,
+                                 _p(po) if po is not None else none, _p(nl), _p(no), _p(ni), _p(perm))
+    return nl, no, ni, perm
+
+
 def debug_init(keys, dim):
     keys = _keys(keys)
     out = np.empty((keys.size, dim), np.float32)

@@ -729,14 +729,39 @@ __device__ __forceinline__ void route(uint64_t idx, int dist, uint64_t blk, uint
   else { p = idx % W; nw = idx / W; }
 }
 
+// FBGEMM's two generalisations of the op (sparse_block_bucketize_features.cu:194-211, 262-292, 341-347): features with DIFFERENT
+// batch sizes (fstart [F + 1]: first bag of every feature; the reference materialises a length -> feature array, here a bag
+// finds its feature by a binary search of F + 1 cached words) and uneven shard boundaries (pos / pos_off: the sorted boundaries
+// of every feature, concatenated; the rank is the last boundary <= idx, the dist types do not apply).
+struct BktEx {
+  const int64_t* fstart = nullptr;
+  int F = 0;
+  const int64_t* pos = nullptr;
+  const int64_t* pos_off = nullptr;
+};
+__device__ __forceinline__ int64_t bkt_feature(const BktEx& x, int64_t bag, int64_t B) {
+  if (!x.fstart) return bag / B;
+  int lo = 0, hi = x.F;      // first f with fstart[f + 1] > bag
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (x.fstart[mid + 1] <= bag) lo = mid + 1; else hi = mid; }
+  return lo < x.F ? lo : x.F - 1;
+}
+__device__ __forceinline__ void route_ex(const BktEx& x, int64_t f, uint64_t idx, int dist, uint64_t blk, uint64_t W, uint64_t& p, uint64_t& nw) {
+  if (!x.pos) { route(idx, dist, blk, W, p, nw); return; }
+  int64_t first = x.pos_off[f], last = x.pos_off[f + 1];
+  while (first < last) { const int64_t mid = first + ((last - first) >> 1); if ((uint64_t)x.pos[mid] <= idx) first = mid + 1; else last = mid; }
+  const uint64_t lb = (uint64_t)(first - x.pos_off[f] - 1);
+  if (lb < W) { p = lb; nw = idx - (uint64_t)x.pos[x.pos_off[f] + (int64_t)lb]; }
+  else { p = idx % W; nw = idx / W; }
+}
+
 // one wave per bag (HSTU bags are whole sequences: few bags, thousands of keys each): lane r owns
 // the counter of destination rank r; ranks of a 64-key chunk are tallied with one ballot per rank.
 __global__ void __launch_bounds__(256)
 bucketize_count_kernel(int64_t FB, int64_t B, int W, const int64_t* __restrict__ offsets, const uint64_t* __restrict__ indices,
-                       const int64_t* __restrict__ block_sizes, const int* __restrict__ dist_type, int64_t* __restrict__ new_lengths) {
+                       const int64_t* __restrict__ block_sizes, const int* __restrict__ dist_type, int64_t* __restrict__ new_lengths, BktEx x) {
   const int lane = lane_id();
   for (int64_t bag = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); bag < FB; bag += (int64_t)gridDim.x * (blockDim.x / 64)) {
-    const int64_t f = bag / B;
+    const int64_t f = bkt_feature(x, bag, B);
     const int dist = dist_type ? dist_type[f] : 0;
     const uint64_t blk = (uint64_t)block_sizes[f];
     const int64_t lo = offsets[bag], hi = offsets[bag + 1];
@@ -745,7 +770,7 @@ bucketize_count_kernel(int64_t FB, int64_t B, int W, const int64_t* __restrict__
       for (int64_t j0 = lo; j0 < hi; j0 += 64) {
         const int64_t j = j0 + lane;
         uint64_t p = ~0ull, nw;
-        if (j < hi) route(indices[j], dist, blk, (uint64_t)W, p, nw);
+        if (j < hi) route_ex(x, f, indices[j], dist, blk, (uint64_t)W, p, nw);
         const int nr = W - p0 < 64 ? W - p0 : 64;
         for (int r = 0; r < nr; ++r) {
           int c = __popcll(__ballot(p == (uint64_t)(p0 + r)));
@@ -764,10 +789,10 @@ bucketize_scatter_kernel(int64_t FB, int64_t B, int W, const int64_t* __restrict
                          const int64_t* __restrict__ block_sizes, const int* __restrict__ dist_type,
                          const int64_t* __restrict__ new_offsets, uint64_t* __restrict__ new_indices,
                          int64_t* __restrict__ unbucketize_permute, const float* __restrict__ weights,
-                         float* __restrict__ new_weights) {
+                         float* __restrict__ new_weights, BktEx x) {
   const int lane = lane_id();
   for (int64_t bag = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); bag < FB; bag += (int64_t)gridDim.x * (blockDim.x / 64)) {
-    const int64_t f = bag / B;
+    const int64_t f = bkt_feature(x, bag, B);
     const int dist = dist_type ? dist_type[f] : 0;
     const uint64_t blk = (uint64_t)block_sizes[f];
     const int64_t lo = offsets[bag], hi = offsets[bag + 1];
@@ -777,7 +802,7 @@ bucketize_scatter_kernel(int64_t FB, int64_t B, int W, const int64_t* __restrict
       for (int64_t j0 = lo; j0 < hi; j0 += 64) {
         const int64_t j = j0 + lane;
         uint64_t p = ~0ull, nw = 0;
-        if (j < hi) route(indices[j], dist, blk, (uint64_t)W, p, nw);
+        if (j < hi) route_ex(x, f, indices[j], dist, blk, (uint64_t)W, p, nw);
         int64_t dst = -1;
         for (int r = 0; r < nr; ++r) {
           const uint64_t m = __ballot(p == (uint64_t)(p0 + r));
@@ -803,14 +828,14 @@ template <int GL>
 __global__ void __launch_bounds__(256)
 bucketize_count_short_kernel(int64_t FB, int64_t B, int W, const int64_t* __restrict__ offsets, const uint64_t* __restrict__ indices,
                              const int64_t* __restrict__ block_sizes, const int* __restrict__ dist_type,
-                             int64_t* __restrict__ new_lengths) {
+                             int64_t* __restrict__ new_lengths, BktEx x) {
   constexpr int NG = 64 / GL;
   const int lane = lane_id(), grp = lane / GL, gl = lane % GL;
   const uint64_t gmask = ((1ull << GL) - 1);
   const int64_t bag = ((int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * NG + grp;
   const bool live = bag < FB;
   const int64_t bg = live ? bag : FB - 1;
-  const int64_t f = bg / B;
+  const int64_t f = bkt_feature(x, bg, B);
   const int dist = dist_type ? dist_type[f] : 0;
   const uint64_t blk = (uint64_t)block_sizes[f];
   const int64_t lo = offsets[bg], hi = live ? offsets[bg + 1] : lo;
@@ -822,7 +847,7 @@ bucketize_count_short_kernel(int64_t FB, int64_t B, int W, const int64_t* __rest
     for (int64_t j0 = 0; j0 < maxlen; j0 += GL) {
       const int64_t j = lo + j0 + gl;
       uint64_t p = ~0ull, nw;
-      if (j < hi) route(indices[j], dist, blk, (uint64_t)W, p, nw);
+      if (j < hi) route_ex(x, f, indices[j], dist, blk, (uint64_t)W, p, nw);
       for (int r = 0; r < nr; ++r) {
         const int c = __popcll((__ballot(p == (uint64_t)(p0 + r)) >> (grp * GL)) & gmask);
         if (gl == r) mycnt += c;
@@ -838,14 +863,14 @@ bucketize_scatter_short_kernel(int64_t FB, int64_t B, int W, const int64_t* __re
                                const int64_t* __restrict__ block_sizes, const int* __restrict__ dist_type,
                                const int64_t* __restrict__ new_offsets, uint64_t* __restrict__ new_indices,
                                int64_t* __restrict__ unbucketize_permute, const float* __restrict__ weights,
-                               float* __restrict__ new_weights) {
+                               float* __restrict__ new_weights, BktEx x) {
   constexpr int NG = 64 / GL;
   const int lane = lane_id(), grp = lane / GL, gl = lane % GL;
   const uint64_t gmask = ((1ull << GL) - 1);
   const int64_t bag = ((int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * NG + grp;
   const bool live = bag < FB;
   const int64_t bg = live ? bag : FB - 1;
-  const int64_t f = bg / B;
+  const int64_t f = bkt_feature(x, bg, B);
   const int dist = dist_type ? dist_type[f] : 0;
   const uint64_t blk = (uint64_t)block_sizes[f];
   const int64_t lo = offsets[bg], hi = live ? offsets[bg + 1] : lo;
@@ -857,7 +882,7 @@ bucketize_scatter_short_kernel(int64_t FB, int64_t B, int W, const int64_t* __re
     for (int64_t j0 = 0; j0 < maxlen; j0 += GL) {
       const int64_t j = lo + j0 + gl;
       uint64_t p = ~0ull, nw = 0;
-      if (j < hi) route(indices[j], dist, blk, (uint64_t)W, p, nw);
+      if (j < hi) route_ex(x, f, indices[j], dist, blk, (uint64_t)W, p, nw);
       int64_t dst = -1;
       for (int r = 0; r < nr; ++r) {
         const uint64_t m = (__ballot(p == (uint64_t)(p0 + r)) >> (grp * GL)) & gmask;
@@ -1475,13 +1500,20 @@ int mi355_peer_splits(const int64_t* send_offsets, const int64_t* recv_offsets, 
   return MI355_OK;
 }
 
-int mi355_block_bucketize(int64_t world_size, int64_t num_bags, int64_t batch_size, const int64_t* offsets,
-                          const void* indices, const int64_t* block_sizes, const int32_t* dist_type_per_feature,
-                          const float* weights, int64_t* new_lengths, int64_t* new_offsets, void* new_indices,
-                          float* new_weights, int64_t* unbucketize_permute, hipStream_t stream) {
+int mi355_block_bucketize_ex(int64_t world_size, int64_t num_bags, int64_t batch_size, const int64_t* offsets,
+                             const void* indices, const int64_t* block_sizes, const int32_t* dist_type_per_feature,
+                             const float* weights, int64_t* new_lengths, int64_t* new_offsets, void* new_indices,
+                             float* new_weights, int64_t* unbucketize_permute, const int64_t* feature_bag_starts,
+                             int64_t num_features, const int64_t* block_bucketize_pos_concat,
+                             const int64_t* block_bucketize_pos_offsets, hipStream_t stream) {
   MI355_CHECK_ARG(world_size >= 1 && world_size <= 4096, "bad world size");
+  MI355_CHECK_ARG(!feature_bag_starts || (num_features >= 1 && num_features < (1 << 30)), "feature_bag_starts needs num_features");
+  MI355_CHECK_ARG(feature_bag_starts || batch_size > 0 || num_bags == 0, "batch_size must be positive");
+  MI355_CHECK_ARG((block_bucketize_pos_concat == nullptr) == (block_bucketize_pos_offsets == nullptr), "block_bucketize_pos needs its offsets");
   if (num_bags == 0) return MI355_OK;
   const int W = (int)world_size;
+  BktEx x;
+  x.fstart = feature_bag_starts; x.F = (int)num_features; x.pos = block_bucketize_pos_concat; x.pos_off = block_bucketize_pos_offsets;
   // many bags (embedding-bag batches: tens of thousands of bags of a few keys) -> 8 lanes per bag; few bags (HSTU
   // sequences, the pseudo-bags of the rows-back exchange) -> a wave per bag.  Same results either way.
   const bool short_bags = num_bags >= 8192;
@@ -1489,21 +1521,30 @@ int mi355_block_bucketize(int64_t world_size, int64_t num_bags, int64_t batch_si
   const int grid_s = grid_for(num_bags, 4 * (64 / GL), 1 << 20);
   if (short_bags)
     hipLaunchKernelGGL(bucketize_count_short_kernel<GL>, dim3(grid_s), dim3(256), 0, stream, num_bags, batch_size, W, offsets,
-                       (const uint64_t*)indices, block_sizes, dist_type_per_feature, new_lengths);
+                       (const uint64_t*)indices, block_sizes, dist_type_per_feature, new_lengths, x);
   else
     hipLaunchKernelGGL(bucketize_count_kernel, dim3(grid_for(num_bags, 4)), dim3(256), 0, stream, num_bags, batch_size, W, offsets,
-                       (const uint64_t*)indices, block_sizes, dist_type_per_feature, new_lengths);
+                       (const uint64_t*)indices, block_sizes, dist_type_per_feature, new_lengths, x);
   if (scan_i64(new_lengths, world_size * num_bags, new_offsets, stream) != MI355_OK) return MI355_ELAUNCH;
   if (short_bags)
     hipLaunchKernelGGL(bucketize_scatter_short_kernel<GL>, dim3(grid_s), dim3(256), 0, stream, num_bags, batch_size, W, offsets,
                        (const uint64_t*)indices, block_sizes, dist_type_per_feature, new_offsets, (uint64_t*)new_indices,
-                       unbucketize_permute, weights, new_weights);
+                       unbucketize_permute, weights, new_weights, x);
   else
     hipLaunchKernelGGL(bucketize_scatter_kernel, dim3(grid_for(num_bags, 4)), dim3(256), 0, stream, num_bags, batch_size, W, offsets,
                        (const uint64_t*)indices, block_sizes, dist_type_per_feature, new_offsets, (uint64_t*)new_indices,
-                       unbucketize_permute, weights, new_weights);
+                       unbucketize_permute, weights, new_weights, x);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
+}
+
+int mi355_block_bucketize(int64_t world_size, int64_t num_bags, int64_t batch_size, const int64_t* offsets,
+                          const void* indices, const int64_t* block_sizes, const int32_t* dist_type_per_feature,
+                          const float* weights, int64_t* new_lengths, int64_t* new_offsets, void* new_indices,
+                          float* new_weights, int64_t* unbucketize_permute, hipStream_t stream) {
+  return mi355_block_bucketize_ex(world_size, num_bags, batch_size, offsets, indices, block_sizes, dist_type_per_feature, weights,
+                                  new_lengths, new_offsets, new_indices, new_weights, unbucketize_permute, nullptr, 0, nullptr, nullptr,
+                                  stream);
 }
 
 }  // extern "C"

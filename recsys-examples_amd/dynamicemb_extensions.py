@@ -581,14 +581,31 @@ def block_bucketize_sparse_features(lengths, indices, bucketize_pos, sequence, d
                                     block_bucketize_pos=None):
     """block_bucketize_sparse_features (sparse_block_bucketize_features.cu:366-830) ->
     (new_lengths, new_indices, new_weights, new_pos, unbucketize_permute)."""
-    if block_bucketize_pos is not None or batch_size_per_feature is not None:
-        raise NotImplementedError("uneven shard boundaries / variable batch size per feature in bucketize (DESIGN.md)")
     want_perm = sequence
     sequence = sequence or bucketize_pos      # (the positions travel with the permutation)
     FB = lengths.numel()
     F = block_sizes.numel()
-    B = FB // F
     dev = indices.device
+    # variable batch size per feature (the reference builds length_to_feature_idx from it, :194-211 / :430-470): the bags of
+    # feature f are [starts[f], starts[f + 1])
+    fstart = None
+    if batch_size_per_feature is not None:
+        bspf = torch.as_tensor(batch_size_per_feature, device=dev).to(torch.int64).view(-1)
+        if bspf.numel() != F:
+            raise RuntimeError("batch_size_per_feature must have one entry per feature")
+        fstart = torch.zeros(F + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(bspf, 0, out=fstart[1:])
+        B = 0
+    else:
+        B = FB // F
+    # uneven shard boundaries: one sorted tensor per feature (my_size + 1 boundaries as TorchRec builds them)
+    pos_cat = pos_off = None
+    if block_bucketize_pos is not None:
+        if len(block_bucketize_pos) != F:
+            raise RuntimeError("block_bucketize_pos must have one tensor per feature")
+        pos_cat = torch.cat([torch.as_tensor(x, device=dev).to(torch.int64).view(-1) for x in block_bucketize_pos]).contiguous()
+        sizes = [int(torch.as_tensor(x).numel()) for x in block_bucketize_pos]
+        pos_off = torch.tensor([sum(sizes[:i]) for i in range(F + 1)], dtype=torch.int64, device=dev)
     offsets = torch.zeros(FB + 1, dtype=torch.int64, device=dev)
     torch.cumsum(lengths.to(torch.int64), 0, out=offsets[1:])
     new_lengths = torch.empty(my_size * FB, dtype=torch.int64, device=dev)
@@ -597,9 +614,9 @@ def block_bucketize_sparse_features(lengths, indices, bucketize_pos, sequence, d
     perm = torch.empty(indices.numel(), dtype=torch.int64, device=dev) if sequence else None
     new_w = torch.empty_like(weights) if weights is not None else None
     dist = dist_type_per_feature.to(torch.int32) if dist_type_per_feature is not None else None
-    check(lib().mi355_block_bucketize(my_size, FB, B, ptr(offsets), ptr(indices), ptr(block_sizes.to(torch.int64)),
-                                      ptr(dist), ptr(weights), ptr(new_lengths), ptr(new_offsets), ptr(new_indices),
-                                      ptr(new_w), ptr(perm), stream()), "block_bucketize")
+    check(lib().mi355_block_bucketize_ex(my_size, FB, B, ptr(offsets), ptr(indices), ptr(block_sizes.to(torch.int64)),
+                                         ptr(dist), ptr(weights), ptr(new_lengths), ptr(new_offsets), ptr(new_indices),
+                                         ptr(new_w), ptr(perm), ptr(fstart), F, ptr(pos_cat), ptr(pos_off), stream()), "block_bucketize")
     new_pos = None
     if bucketize_pos:
         # bucketize_pos (sparse_block_bucketize_features.cu:366-830, `new_pos`): the position every value had inside its ORIGINAL

@@ -71,6 +71,7 @@ _SIGS = {
     "mi355_peer_splits": [c_p, c_p, c_i64, c_i64, c_p, c_p],
     "mi355_chunk_bags": [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p],
     "mi355_block_bucketize": [c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "mi355_block_bucketize_ex": [c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_p],
     "mi355_gather_pooled": [c_p, c_i64, c_p, c_int, c_p, c_i64, c_p, c_i64, c_i64, c_int, c_i64, c_p, c_i64, c_p, c_int,
                             c_int, c_p],
     "mi355_gather_rows": [c_p, c_i64, c_p, c_int, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_int, c_int, c_p],

@@ -350,8 +350,54 @@ def test_block_bucketize_positions(W):
     within = np.arange(idx.size) - offsets[bag]
     assert sorted(perm.tolist()) == list(range(idx.size))   # value j went to place perm[j] (its new value is the shard-local id) ...
     assert (pos[perm] == within).all()                      # ... and took its in-bag position along
-    with pytest.raises(NotImplementedError):
-        e.block_bucketize_sparse_features(T(lens.astype(np.int64)), T(idx), False, False, None, T(blk), W, batch_size_per_feature=T(np.array([B, B])))
+
+
+@pytest.mark.parametrize("W", [1, 3, 8, 70])
+@pytest.mark.parametrize("many_bags", [False, True], ids=["wave_per_bag", "lane_group_per_bag"])
+def test_block_bucketize_variable_batch_and_uneven_shard_boundaries(W, many_bags):
+    """the two remaining arguments of the reference's op (sparse_block_bucketize_features.cu:194-211, 262-292, 341-347):
+    batch_size_per_feature (features with different batch sizes: a bag's feature comes from the prefix sum of the sizes) and
+    block_bucketize_pos (uneven shard boundaries: rank = last boundary <= idx, new index = idx - boundary; indices outside the
+    boundaries fall back to idx % W, idx / W) -- each alone and both together, both kernel families, against the oracle;
+    bucketize_pos rides along."""
+    e = ext()
+    rng = np.random.default_rng(W * 2 + int(many_bags))
+    bs = np.array([5, 0, 9, 2], np.int64) * (1200 if many_bags else 1)     # feature 1 has no bag at all
+    F = bs.size
+    FB = int(bs.sum())
+    lens = rng.integers(0, 6 if many_bags else 150, size=FB)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    idx = rng.integers(0, 5000, size=int(offsets[-1])).astype(np.int64)
+    blk = np.array([5000 // W + 1] * F, np.int64)
+    bag_feature = np.repeat(np.arange(F), bs)
+    # boundaries: W + 1 sorted cut points per feature; the first one above 0 and the last below 5000 for features 0 / 2, so that
+    # indices on either side take the fallback
+    pos = []
+    for f in range(F):
+        cuts = np.sort(rng.choice(np.arange(1, 4999), size=W - 1, replace=False)) if W > 1 else np.zeros(0, np.int64)
+        lo, hi = (40, 4900) if f % 2 == 0 else (0, 5000)
+        pos.append(np.concatenate([[lo], np.clip(cuts, lo, hi), [hi]]).astype(np.int64))
+        pos[-1].sort()
+    dist = np.array([0, 1, 2, 0], np.int32)
+    for use_bs, use_pos in ((True, False), (False, True), (True, True)):
+        if not use_bs:      # equal batch sizes: re-draw the bags as F x B
+            B = FB // F
+            lens_c = lens[: F * B]
+            off_c = np.concatenate([[0], np.cumsum(lens_c)]).astype(np.int64)
+            idx_c = idx[: off_c[-1]]
+            bf = None
+        else:
+            B, lens_c, off_c, idx_c, bf = 0, lens, offsets, idx, bag_feature
+        nFB = lens_c.size
+        onl, ono, oni, operm = orc.block_bucketize_ex(off_c, idx_c, W, max(B, 1), blk, dist, bf, pos if use_pos else None)
+        gl, gi, _, gpos, gperm = e.block_bucketize_sparse_features(
+            T(lens_c.astype(np.int64)), T(idx_c), True, True, T(dist), T(blk), W,
+            batch_size_per_feature=T(bs) if use_bs else None, block_bucketize_pos=[T(x) for x in pos] if use_pos else None)
+        assert (gl.cpu().numpy() == onl).all()
+        assert (gi.cpu().numpy() == oni.view(np.int64)).all()
+        assert (gperm.cpu().numpy() == operm).all()
+        bag = np.repeat(np.arange(nFB), lens_c)
+        assert (gpos.cpu().numpy()[operm] == np.arange(idx_c.size) - off_c[bag]).all()
 
 
 @pytest.mark.parametrize("W", [1, 2, 8, 70])

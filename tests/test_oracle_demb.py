@@ -295,6 +295,44 @@ def test_block_bucketize_routing():
                 assert p == k // 250 and ni[perm[j]] == k % 250
 
 
+def test_block_bucketize_variable_batch_and_uneven_boundaries_against_a_loop():
+    """orc_block_bucketize_ex against a plain Python loop that follows the reference kernels line by line
+    (sparse_block_bucketize_features.cu:240-292 lengths, :316-362 scatter)"""
+    rng = np.random.default_rng(5)
+    W = 4
+    bs = [3, 0, 2]
+    F, FB = len(bs), sum(bs)
+    bag_feature = np.repeat(np.arange(F), bs)
+    lens = rng.integers(0, 7, size=FB)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    idx = rng.integers(0, 1000, size=int(offsets[-1])).astype(np.int64)
+    pos = [np.array([10, 200, 400, 800, 990], np.int64), np.array([0, 1, 2, 3, 4], np.int64), np.array([0, 100, 100, 500, 1000], np.int64)]
+    blk = [250, 250, 250]
+    for use_pos in (False, True):
+        for dist in ([0, 0, 0], [1, 2, 0]):
+            nl, no, ni, perm = orc.block_bucketize_ex(offsets, idx, W, 1, blk, dist, bag_feature, pos if use_pos else None)
+            want = [[[] for _ in range(FB)] for _ in range(W)]
+            for b in range(FB):
+                f = bag_feature[b]
+                for j in range(offsets[b], offsets[b + 1]):
+                    k = int(idx[j])
+                    if use_pos:
+                        lb = int(np.searchsorted(pos[f], k, side="right")) - 1
+                        p, nw = (lb, k - int(pos[f][lb])) if 0 <= lb < W else (k % W, k // W)
+                    elif dist[f] == 1:
+                        p, nw = k % W, k
+                    elif dist[f] == 2:
+                        p, nw = orc.fmix64(k) % W, k
+                    else:
+                        p, nw = (k // blk[f], k % blk[f]) if k < blk[f] * W else (k % W, k // W)
+                    want[p][b].append((nw, j))
+            flat = [x for p in range(W) for b in range(FB) for x in want[p][b]]
+            assert [x[0] for x in flat] == ni.view(np.int64).tolist()
+            assert [len(want[p][b]) for p in range(W) for b in range(FB)] == nl.tolist()
+            for dst, (_, j) in enumerate(flat):
+                assert perm[j] == dst
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # pins from the reference's own pure-Python code (tests/golden/gen_demb_flow_golden.py pulls it out of the AST)
 FLOW = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "demb_flow_golden.npz"))
