@@ -7,7 +7,9 @@ examples/hstu/modules/hstu_attention.py:296-314): same argument meaning, same in
 contextual / target masks require causal -- hstu_api.cpp:359-430).
 Inference extensions (forward only): cu_seqlens_k longer than cu_seqlens_q (delta-q) and the paged KV cache
 (kv_cache / page_offsets / page_ids / last_page_lens).
-Not supported (raise): seqused_*, rab or local windows over a KV cache / delta-q.  The raw ops of the fused layer
+Arbitrary mask functions (`func`, hstu_api.cpp:170-180) run as a 0 / -1e9 bias through the biased kernels (func_mask_bias:
+O(batch max_seqlen_k^2) memory), forward and backward, with any other mask except context rows, over delta-q / paged keys too.
+Not supported (raise): seqused_* (no caller of the reference passes them, and its kernels take none).  The raw ops of the fused layer
 (`torch.ops.fbgemm.hstu_varlen_{fwd,bwd}_{80,90}`) are registered by `hstu.hstu_ops_gpu`.
 """
 from __future__ import annotations
@@ -275,6 +277,34 @@ class HstuAttnWindowFunc(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None, None, None
 
 
+_FUNC_NEG = -1.0e9   # bias of a masked (query, key) pair: SiLU(alpha (q.k + bias)) is -0 exactly (the sigmoid underflows to 0;
+                     # so does SiLU', so no gradient crosses the mask) for any alpha above ~1e-7
+
+
+def func_mask_bias(func, cu_seqlens_q, cu_seqlens_k, max_seqlen_k, dtype):
+    """Arbitrary mask functions (`func`, hstu_api.cpp:170-180; applied in hstu_fwd.h:493-556) as an attention bias for the rab
+    kernels: [batch, heads_func, N, N] (N = max_seqlen_k), 0 where query token t may see key column j -- j < func[h, 0, t], or
+    func[h, 2p - 1, t] <= j < func[h, 2p, t] for a p >= 1 -- and -1e9 elsewhere.  Row i of a sequence is the query token
+    i - (Lk - Lq) (delta-q: the queries are the sequence's last rows, corelib/hstu/test.py:122-131).  Built on the device without
+    a host read; O(batch N^2) memory, which is what buys the masks the whole machinery of the biased kernels (any other mask on
+    top, gradients, delta-q / paged keys)."""
+    if func.dtype != torch.int32 or func.dim() != 3 or func.shape[1] % 2 != 1 or func.stride(-1) != 1:
+        raise RuntimeError("func must be an int32 (heads or 1, n_func, >= total_q) tensor with an odd n_func and a contiguous last dimension")
+    dev = func.device
+    N = int(max_seqlen_k)
+    cq, ck = cu_seqlens_q.to(torch.int64), cu_seqlens_k.to(torch.int64)
+    off = (ck[1:] - ck[:-1]) - (cq[1:] - cq[:-1])                               # [B] first query row of every sequence
+    rows = torch.arange(N, device=dev)
+    tok = (cq[:-1, None] + (rows[None, :] - off[:, None])).clamp_(0, func.shape[-1] - 1)   # [B, N] (rows outside a sequence: any token)
+    f = func[:, :, tok].to(torch.int64)                                          # [Hf, n_func, B, N]
+    j = rows.view(1, 1, 1, N)
+    ok = j < f[:, 0, :, :, None]
+    for p in range(1, func.shape[1] // 2 + 1):
+        ok |= (f[:, 2 * p - 1, :, :, None] <= j) & (j < f[:, 2 * p, :, :, None])
+    bias = torch.zeros(ok.shape, dtype=dtype, device=dev).masked_fill_(~ok, _FUNC_NEG)
+    return bias.permute(1, 0, 2, 3).contiguous()                                 # [B, Hf, N, N]
+
+
 def _rab_strides(rab, num_heads):
     """(batch, head, row) strides in elements; one shared bias head is a head stride of 0"""
     return rab.stride(0), (0 if rab.shape[1] == 1 else rab.stride(1)), rab.stride(2)
@@ -360,6 +390,17 @@ def hstu_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, seqused_q, sequse
     wl, wr = (-1 if window_size[0] < 0 else int(window_size[0])), (-1 if window_size[1] < 0 else int(window_size[1]))
     if has_drab and rab is None:   # hstu_attn_interface.py:234-237 of the reference
         raise ValueError("AssertError: rab is None, but has_drab is True, is not allowed in backward")
+    if func is not None:
+        # arbitrary mask: a bias of 0 / -1e9 through the biased kernels (see func_mask_bias); it narrows whatever other mask applies
+        # as in the reference (hstu_fwd.h:519-556) -- except for context rows, which the reference exempts from it
+        if num_contexts is not None:
+            raise NotImplementedError("func together with num_contexts")
+        if func.shape[0] not in (1, q.shape[1]) or func.shape[-1] < q.shape[0]:
+            raise RuntimeError("func must be (heads or 1, n_func, >= total_q)")
+        fb = func_mask_bias(func, cu_seqlens_q, cu_seqlens_k, max_seqlen_k, q.dtype)
+        if rab is not None and rab.shape[-1] != int(max_seqlen_k):
+            raise RuntimeError("rab must be (batch, nheads or 1, max_seqlen_k, max_seqlen_k)")
+        rab = fb if rab is None else rab + fb
     if rab is not None:
         if rab.shape[-1] != int(max_seqlen_k):
             raise RuntimeError("rab must be (batch, nheads or 1, max_seqlen_k, max_seqlen_k)")

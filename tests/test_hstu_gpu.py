@@ -382,6 +382,98 @@ def test_rab_golden(name):
     _assert_drab(drab, g("drab"))
 
 
+# ------------------------------------------------------------------------------------- arbitrary mask functions (func)
+FN = np.load(os.path.join(os.path.dirname(__file__), "golden", "hstu_func_golden.npz"))
+
+
+@pytest.mark.parametrize("name", [str(c) for c in FN["cases"]])
+def test_arbitrary_mask_golden(name):
+    """`func` (hstu_api.cpp:170-180): forward and dq / dk / dv against the reference test's dense statement
+    (tests/golden/gen_hstu_func_golden.py: its random three- / five-bound functions, its causal and local-window emulations)"""
+    from hstu import hstu_attn_varlen_func
+
+    H, d, N = (int(x) for x in FN[f"{name}/meta"])
+    g = lambda k: FN[f"{name}/{k}"]
+    qq, kk, vv = (_bf(g(t)).clone().requires_grad_(True) for t in ("q", "k", "v"))
+    cu = torch.from_numpy(g("off").astype(np.int32)).to(DEV)
+    func = torch.from_numpy(g("func")).to(DEV)
+    out = hstu_attn_varlen_func(qq, kk, vv, cu, cu, None, None, N, N, N, None, None, window_size=(-1, -1), alpha=1.0 / d ** 0.5,
+                                func=func)
+    out.backward(_bf(g("dout")))
+    _assert_vs_oracle(out, (qq.grad, kk.grad, vv.grad), g("out"), g("dq"), g("dk"), g("dv"))
+
+
+@pytest.mark.parametrize("mode", ["per_head", "with_rab", "with_targets_causal", "delta_q", "raw_ops"])
+def test_arbitrary_mask_random_jagged_vs_oracle(mode):
+    """func over several tiles with ragged ends, an empty and a one-token sequence: one mask per head; together with a relative
+    bias (drab flows through the sum, zero where the function masks); narrowing the causal + target mask; over delta-q keys
+    (inference forward: the queries are the last rows of their sequences); through the raw fbgemm ops of the fused layer."""
+    from hstu import hstu_attn_varlen_func
+
+    rng = np.random.default_rng(len(mode))
+    lengths = np.array([300, 1, 0, 129, 64, 77])
+    B, H, d, N = lengths.size, 2, 64, int(lengths.max())
+    off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    T = int(off[-1])
+    mk = lambda lo, hi, *shape: torch.from_numpy(rng.uniform(lo, hi, shape).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    q, k, v, dout = mk(-1, 1, T, H, d), mk(-1, 1, T, H, d), mk(-1, 1, T, H, d), mk(0, 1, T, H, d)
+    HF = H if mode == "per_head" else 1
+    f = np.zeros((HF, 5, T + 64), np.int32)
+    f[:, 0] = rng.integers(0, 40, size=(HF, T + 64))
+    f[:, 1] = rng.integers(30, 120, size=(HF, T + 64)); f[:, 2] = f[:, 1] + rng.integers(0, 90, size=(HF, T + 64))
+    f[:, 3] = rng.integers(200, 260, size=(HF, T + 64)); f[:, 4] = f[:, 3] + rng.integers(0, 60, size=(HF, T + 64))
+    func = torch.from_numpy(f).to(DEV)
+    cu = torch.from_numpy(off.astype(np.int32)).to(DEV)
+    alpha = 1.0 / d ** 0.5
+    qn, kn, vn, dn = (t.float().cpu().numpy() for t in (q, k, v, dout))
+    if mode == "delta_q":
+        # the last min(L, 37) rows of every sequence are the queries; keys = the whole sequence
+        lq = np.minimum(lengths, 37)
+        offq = np.concatenate([[0], np.cumsum(lq)]).astype(np.int64)
+        qsel = np.concatenate([np.arange(off[b + 1] - lq[b], off[b + 1]) for b in range(B)]).astype(np.int64)
+        qd = q[torch.from_numpy(qsel).to(DEV)].contiguous()
+        fd = np.zeros((1, 5, int(offq[-1]) + 8), np.int32)
+        fd[:, :, : int(offq[-1])] = f[:, :, qsel]
+        cuq = torch.from_numpy(offq.astype(np.int32)).to(DEV)
+        with torch.no_grad():
+            out = hstu_attn_varlen_func(qd, k, v, cuq, cu, None, None, int(lq.max()), N, N, None, None, window_size=(-1, -1),
+                                        alpha=alpha, func=torch.from_numpy(fd).to(DEV))
+        full = ho.hstu_attn_fwd(qn, kn, vn, off, alpha, N, causal=False, func=f)    # row r of the sequence = its token: same mask rows
+        ref = full[qsel]
+        err = np.abs(out.float().cpu().numpy() - ref).max()
+        assert err <= 6e-3 * np.abs(ref).max() + 1e-6, f"{err} vs scale {np.abs(ref).max()}"
+        return
+    kw, okw = {}, dict(causal=False)
+    rab = None
+    if mode == "with_rab":
+        rab = mk(-2, 2, B, H, N, N).requires_grad_(True)
+        kw.update(rab=rab, has_drab=True)
+        okw.update(rab=rab.detach().float().cpu().numpy())
+    targets = None
+    if mode == "with_targets_causal":
+        targets = np.minimum(rng.integers(0, 11, size=B), np.maximum(lengths - 1, 0))
+        kw.update(window_size=(-1, 0), target_group_size=2)
+        okw.update(causal=True, num_targets=targets, target_group_size=2)
+    else:
+        kw.update(window_size=(-1, -1))
+    nt = None if targets is None else torch.from_numpy(targets.astype(np.int32)).to(DEV)
+    qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
+    if mode == "raw_ops":
+        import hstu.hstu_ops_gpu  # noqa: F401  (registers torch.ops.fbgemm.hstu_varlen_*)
+        out, _ = torch.ops.fbgemm.hstu_varlen_fwd_80(q, k, v, cu, cu, None, None, N, N, float(N), None, None, 1, -1, -1, alpha, None, func)
+        grads = torch.ops.fbgemm.hstu_varlen_bwd_80(dout, q, k, v, cu, cu, None, None, N, N, float(N), None, None, None, None, None, 1,
+                                                    -1, -1, alpha, None, False, func, False)[:3]
+    else:
+        out = hstu_attn_varlen_func(qq, kk, vv, cu, cu, None, None, N, N, N, None, nt, alpha=alpha, func=func, **kw)
+        out.backward(dout)
+        grads = (qq.grad, kk.grad, vv.grad)
+    ref = ho.hstu_attn_fwd(qn, kn, vn, off, alpha, N, func=f, **okw)
+    res = ho.hstu_attn_bwd(dn, qn, kn, vn, off, alpha, N, func=f, **okw)
+    _assert_vs_oracle(out, grads, ref, res[0], res[1], res[2])
+    if mode == "with_rab":
+        _assert_drab(rab.grad, res[3])
+
+
 @pytest.mark.parametrize("d", [32, 64, 128, 256])
 @pytest.mark.parametrize("mode", ["causal", "ctx_targets", "noncausal", "window", "one_head"])
 def test_rab_random_jagged_vs_oracle(d, mode):
