@@ -327,6 +327,14 @@ int mi355_optimizer_update(int opt_kind, const void* grads, int64_t grad_stride,
                            int weight_dtype, int64_t dim, int64_t state_offset, float lr, float beta1,
                            float beta2, float eps, float weight_decay, int64_t iter_num, int aligned16,
                            hipStream_t stream);
+/* the padded-buffer form over rows of tables with DIFFERENT embedding widths (update4_padded_buffer_kernel,
+ * src/optimizer_kernel.cuh:473-493): row u is table_emb_dims[table_ids[u]] wide, its optimizer state starts at state_offset
+ * (= the widest embedding) whatever its own width; table_ids == nullptr: every row is `dim` wide (the entry above). */
+int mi355_optimizer_update_tables(int opt_kind, const void* grads, int64_t grad_stride, int grad_dtype, int64_t n,
+                                  const int64_t* n_dev, const int64_t* row_addr, void* dense_rows, int64_t dense_stride,
+                                  int weight_dtype, int64_t dim, int64_t state_offset, float lr, float beta1, float beta2,
+                                  float eps, float weight_decay, int64_t iter_num, int aligned16, const int64_t* table_ids,
+                                  const int64_t* table_emb_dims, hipStream_t stream);
 
 /* ---------------------------------------------------------------- growable buffers ---- */
 

@@ -732,7 +732,8 @@ __global__ void __launch_bounds__(256) bwd_kernel(BwdArgs a, OptArgs o, int lpr_
 template <int WDT, int GDT, int NCOL, bool kVec>
 __global__ void __launch_bounds__(256)
 opt_rows_kernel(OptArgs o, const void* grads, int64_t grad_stride, int64_t n, const int64_t* __restrict__ n_dev,
-                const int64_t* __restrict__ row_addr, void* dense_rows, int64_t dense_stride, int D, int lpr_log2) {
+                const int64_t* __restrict__ row_addr, void* dense_rows, int64_t dense_stride, int D, int lpr_log2,
+                const int64_t* __restrict__ table_ids, const int64_t* __restrict__ table_emb_dims) {
   if (n_dev) { int64_t m = *n_dev; n = m < n ? m : n; }
   const int lane = lane_id();
   const int LPR = 1 << lpr_log2;
@@ -742,17 +743,20 @@ opt_rows_kernel(OptArgs o, const void* grads, int64_t grad_stride, int64_t n, co
   for (int64_t u = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); u < n; u += (int64_t)gridDim.x * wpb) {
     void* row = row_addr ? reinterpret_cast<void*>(row_addr[u])
                          : (void*)(reinterpret_cast<typename Elem<WDT>::T*>(dense_rows) + u * dense_stride);
+    // rows of tables with different widths in one padded buffer (update4_padded_buffer_kernel, optimizer.cu:242-280: the row's
+    // own width from table_emb_dims[table_ids[row]], its state behind the WIDEST embedding)
+    const int Dr = table_ids ? (int)table_emb_dims[table_ids[u]] : D;
     float g[NCOL][4];
 #pragma unroll
     for (int k = 0; k < NCOL; ++k) {
       const int e = W * (c + k * LPR);
       g[k][0] = g[k][1] = g[k][2] = g[k][3] = 0.f;
-      if (e < D) {
+      if (e < Dr) {
         if (kVec) { float4 t = ld4<GDT>(grads, u * grad_stride + e); g[k][0] = t.x; g[k][1] = t.y; g[k][2] = t.z; g[k][3] = t.w; }
         else g[k][0] = ld1<GDT>(grads, u * grad_stride + e);
       }
     }
-    apply_sink<WDT, GDT, NCOL, kVec>(o, u, row, D, lpr_log2, false, g, (lane >> lpr_log2) == 0);
+    apply_sink<WDT, GDT, NCOL, kVec>(o, u, row, Dr, lpr_log2, false, g, (lane >> lpr_log2) == 0);
   }
 }
 
@@ -801,14 +805,15 @@ static int launch_bwd(BwdArgs a, OptArgs o, bool vec, hipStream_t stream) {
 
 template <int WDT, int GDT>
 static int launch_opt(OptArgs o, const void* grads, int64_t grad_stride, int64_t n, const int64_t* n_dev,
-                      const int64_t* row_addr, void* dense_rows, int64_t dense_stride, int D, bool vec, hipStream_t stream) {
+                      const int64_t* row_addr, void* dense_rows, int64_t dense_stride, int D, bool vec, hipStream_t stream,
+                      const int64_t* table_ids = nullptr, const int64_t* table_emb_dims = nullptr) {
   const int l = lpr_log2_for(D, vec);
   const int per = vec ? 4 : 1;
   const int ncol = (D + (per << l) - 1) / (per << l);
   const int grid = grid_for(n, 4, 1 << 20);
 #define MI355_OPT_LAUNCH(NC, V)                                                                                    \
   hipLaunchKernelGGL((opt_rows_kernel<WDT, GDT, NC, V>), dim3(grid), dim3(256), 0, stream, o, grads, grad_stride, n, \
-                     n_dev, row_addr, dense_rows, dense_stride, D, l)
+                     n_dev, row_addr, dense_rows, dense_stride, D, l, table_ids, table_emb_dims)
   if (vec) {
     if (ncol <= 1) MI355_OPT_LAUNCH(1, true); else if (ncol <= 2) MI355_OPT_LAUNCH(2, true); else MI355_OPT_LAUNCH(4, true);
   } else {
@@ -880,10 +885,11 @@ int mi355i_backward_fused(const int32_t* ptr, const int32_t* csr_src, int64_t nu
 
 // optimizer step on dense unique gradients [n, grad_stride]; rows by address (flat table) or in a
 // dense padded buffer [n, dense_stride] (update_for_padded_buffer, optimizer.cu:242-413).
-int mi355_optimizer_update(int opt_kind, const void* grads, int64_t grad_stride, int grad_dtype, int64_t n,
-                           const int64_t* n_dev, const int64_t* row_addr, void* dense_rows, int64_t dense_stride,
-                           int weight_dtype, int64_t dim, int64_t state_offset, float lr, float beta1, float beta2,
-                           float eps, float weight_decay, int64_t iter_num, int aligned16, hipStream_t stream) {
+int mi355_optimizer_update_tables(int opt_kind, const void* grads, int64_t grad_stride, int grad_dtype, int64_t n,
+                                  const int64_t* n_dev, const int64_t* row_addr, void* dense_rows, int64_t dense_stride,
+                                  int weight_dtype, int64_t dim, int64_t state_offset, float lr, float beta1, float beta2,
+                                  float eps, float weight_decay, int64_t iter_num, int aligned16, const int64_t* table_ids,
+                                  const int64_t* table_emb_dims, hipStream_t stream) {
   MI355_CHECK_ARG(opt_kind >= 1 && opt_kind <= 4, "bad optimizer kind");
   MI355_CHECK_ARG(row_addr || dense_rows, "row_addr or dense_rows required");
   MI355_CHECK_ARG(dim > 0 && dim <= 1024, "embedding dim must be in (0, 1024]");
@@ -896,9 +902,19 @@ int mi355_optimizer_update(int opt_kind, const void* grads, int64_t grad_stride,
   const bool vec = aligned16 != 0;
   return MI355_DISPATCH_DTYPE(weight_dtype, Wd, [&] {
     return MI355_DISPATCH_DTYPE(grad_dtype, Gd, [&] {
-      return launch_opt<Wd, Gd>(o, grads, grad_stride, n, n_dev, row_addr, dense_rows, dense_stride, (int)dim, vec, stream);
+      return launch_opt<Wd, Gd>(o, grads, grad_stride, n, n_dev, row_addr, dense_rows, dense_stride, (int)dim, vec, stream,
+                                table_ids, table_emb_dims);
     });
   });
+}
+
+int mi355_optimizer_update(int opt_kind, const void* grads, int64_t grad_stride, int grad_dtype, int64_t n,
+                           const int64_t* n_dev, const int64_t* row_addr, void* dense_rows, int64_t dense_stride,
+                           int weight_dtype, int64_t dim, int64_t state_offset, float lr, float beta1, float beta2,
+                           float eps, float weight_decay, int64_t iter_num, int aligned16, hipStream_t stream) {
+  return mi355_optimizer_update_tables(opt_kind, grads, grad_stride, grad_dtype, n, n_dev, row_addr, dense_rows, dense_stride,
+                                       weight_dtype, dim, state_offset, lr, beta1, beta2, eps, weight_decay, iter_num, aligned16,
+                                       nullptr, nullptr, stream);
 }
 
 }  // extern "C"

@@ -6,6 +6,14 @@ for the rows of the unique keys, initialises and inserts the ones it does not ha
 the backward reduces the gradients per unique key, applies the optimizer to the buffer and writes the rows back.
 Everything but `Storage.find` / `Storage.insert` (user code) runs in the HIP kernels of the per-op chain: segmented unique,
 row initialisation, pooled / row gather, gradient reduction, the padded-buffer optimizers.
+
+Value rows travel to and from the store in the reference's PADDED layout (`[embedding | pad to the widest embedding | optimizer
+state]`, key_value_table.py / optimizer_kernel.cuh:28-39), so tables of different widths share one buffer.
+
+`caching=True` (the reference's CACHING_PS layout, batched_dynamicemb_tables.py:694-706): an HBM table of
+`local_hbm_for_values` bytes sits in front of the store.  A key lives in exactly one place: misses are fetched from the store (or
+initialised) and inserted into the cache, what the cache evicts is written back to the store, keys the cache refuses are trained in
+a spill buffer and written back after their backward; `flush()` writes the whole cache back.  Hits never leave the GPU.
 """
 import json
 import os
@@ -17,7 +25,11 @@ from torch import nn
 
 import dynamicemb_extensions as ext
 
-from .batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2, init_dense_rows
+from itertools import accumulate
+
+from mi355_native import check, dt, lib, ptr, stream
+
+from .batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2, _StepCtx, init_dense_rows
 from .dynamicemb_config import DynamicEmbPoolingMode, DynamicEmbScoreStrategy
 from .optimizer import OptimizerView
 from .types import CopyMode
@@ -44,7 +56,7 @@ def _parse_find(r):
 class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
     """BatchedDynamicEmbeddingTablesV2 whose rows live in `table_options[i].external_storage` (a `dynamicemb.types.Storage`
     subclass, constructed here with (options, OptimizerView) as the reference does).  Same forward / backward surface;
-    prefetch, table growth, admission and the HBM cache in front of the store (`caching=True`) are not available."""
+    prefetch, table growth and admission are not available."""
 
     def __init__(self, table_options, table_names=None, feature_table_map=None, use_index_dedup=False, prefetch_pipeline=False,
                  pooling_mode=DynamicEmbPoolingMode.SUM, output_dtype=torch.float32, device=None, enforce_hbm=False,
@@ -59,8 +71,6 @@ class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
         opt0 = table_options[0]
         for o in table_options:
             assert opt0 == o, "All tables must match in grouped keys."
-        if opt0.caching:
-            raise NotImplementedError("an HBM cache in front of an external storage (caching=True) is not supported")
         if opt0.admit_strategy is not None:
             raise NotImplementedError("admission with an external storage")
         self._dynamicemb_options = table_options
@@ -70,14 +80,16 @@ class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
         self.embedding_dtype = opt0.embedding_dtype or torch.float32
         self.device_ = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.dims: List[int] = [o.dim for o in table_options]
-        if len(set(self.dims)) != 1:
-            raise NotImplementedError("external storage with tables of different embedding dims")
+        if pooling_mode == DynamicEmbPoolingMode.NONE:
+            assert all(d == self.dims[0] for d in self.dims), "Sequence mode requires uniform embedding dim"
         T_ = len(table_options)
         self.feature_table_map = feature_table_map if feature_table_map is not None else list(range(T_))
         assert all(any(t == m for m in self.feature_table_map) for t in range(T_)), "Each table must have at least one feature!"
-        self.total_D = sum(self.dims[t] for t in self.feature_table_map)
-        self.max_D, self.mixed_D = self.dims[0], False
-        self.D_offsets_t = None
+        D_offsets = [0] + list(accumulate(self.dims[t] for t in self.feature_table_map))
+        self.total_D = D_offsets[-1]
+        self.max_D = max(self.dims)
+        self.mixed_D = self.max_D > min(self.dims)
+        self.D_offsets_t = torch.tensor(D_offsets, device=self.device_, dtype=torch.int32) if self.mixed_D else None
         self.feature_num = len(self.feature_table_map)
         tof, old = [], -1
         for i, t in enumerate(self.feature_table_map):
@@ -108,6 +120,30 @@ class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
         self._storage = opt0.external_storage(storage_options, OptimizerView(self))
         self._orphan_pins, self._prefetch_states = [], ()
         self.table = self.table_host = None
+        self.dims_t = torch.tensor(self.dims, dtype=torch.int64, device=self.device_)
+        self.max_state = max(v - d for v, d in zip(self.value_dims, self.dims))
+        self.max_V = self.max_D + self.max_state          # width of a padded value row
+        # ---- caching=True: an HBM-only module of the cache's size holds the hot rows (its hash table, its flat value rows, its
+        #      backward); this class walks cache -> store around it
+        self._cache = None
+        if opt0.caching:
+            C = opt0.bucket_capacity
+            eb = torch.empty((), dtype=self.embedding_dtype).element_size()
+            row_bytes = [v * eb for v in self.value_dims]
+            total = sum(o.max_capacity * b for o, b in zip(table_options, row_bytes))
+            cache_opts = deepcopy(list(table_options))
+            for o, b in zip(cache_opts, row_bytes):
+                share = opt0.local_hbm_for_values * (o.max_capacity * b) // max(total, 1) if opt0.local_hbm_for_values > 0 else o.max_capacity * b
+                rows = max(C, (share // b) // C * C)
+                o.max_capacity = min(rows, (o.max_capacity + C - 1) // C * C)
+                o.init_capacity = None
+                o.external_storage, o.caching, o.local_hbm_for_values = None, False, 0
+            self._cache = BatchedDynamicEmbeddingTablesV2(
+                cache_opts, table_names=self._table_names, feature_table_map=self.feature_table_map, pooling_mode=pooling_mode,
+                output_dtype=output_dtype, device=self.device_, optimizer=optimizer, learning_rate=learning_rate, eps=eps,
+                initial_accumulator_value=initial_accumulator_value, weight_decay=weight_decay, beta1=beta1, beta2=beta2,
+                storage_mode="hbm")
+            self._cache._seed = self._seed
 
     # ------------------------------------------------------------------ scores handed to Storage.insert
     def _insert_scores(self, n: int, freq: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -130,9 +166,11 @@ class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
         if indices.dtype != torch.int64:
             indices = indices.to(torch.int64)
         offsets = offsets.to(torch.int64).contiguous()
+        if self._cache is not None:
+            return self._forward_cached(indices, offsets, train)
         n, num_bags = indices.numel(), offsets.numel() - 1
         B = num_bags // self.feature_num
-        T, D, V, dev = self.num_tables, self.dims[0], self.value_dims[0], self.device_
+        T, D, V, dev = self.num_tables, self.max_D, self.max_V, self.device_
         pooled = self.pooling_mode != DynamicEmbPoolingMode.NONE
         lfu = self._score_strategy == DynamicEmbScoreStrategy.LFU
         seg = ext.get_table_range(offsets, self.feature_offsets)
@@ -151,10 +189,7 @@ class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
                     mtids = tids[midx]
                 # first touch: embedding columns by the initializer (keyed by the KEY, as in the HBM tier: the same key draws the
                 # same row in every storage mode), state columns at their initial value -- then the store learns the row
-                mode, p = self._init_params()
-                addr = (values.data_ptr() + midx * (values.stride(0) * values.element_size())).contiguous()
-                ext.init_rows(mode, p, self._seed, float(self.initial_accumulator_value), mkeys.to(torch.int64).contiguous(), addr,
-                              values.dtype, D, values.size(1))
+                self._init_padded_rows(values, midx, mkeys, mtids)
                 sc = self._insert_scores(nu, freq)
                 self._storage.insert(mkeys, mtids, values[midx], sc[midx] if sc is not None else None)
         else:
@@ -168,7 +203,7 @@ class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
             if n == 0 or nu == 0:
                 out.zero_()
             else:
-                ext.gather_embedding_pooled(emb, out, rev, offsets, combiner, self.total_D, B, None, D)
+                ext.gather_embedding_pooled(emb, out, rev, offsets, combiner, self.total_D, B, self.D_offsets_t, D)
         else:
             out = torch.empty(n, D, dtype=self.output_dtype, device=dev)
             if n:
@@ -181,17 +216,36 @@ class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
         self._step += 1
         return out, st
 
+    def _init_padded_rows(self, values: torch.Tensor, midx: torch.Tensor, mkeys: torch.Tensor, mtids: torch.Tensor) -> None:
+        """rows `midx` of the padded buffer `values` <- first-touch rows of the keys `mkeys` (tables `mtids`): the embedding by the
+        initializer, keyed by the key; the state, behind the widest embedding, at its initial value; zeros between"""
+        mode, p = self._init_params()
+        eb = values.element_size()
+        addr = (values.data_ptr() + midx * (values.stride(0) * eb)).contiguous()
+        if not self.mixed_D:
+            ext.init_rows(mode, p, self._seed, float(self.initial_accumulator_value), mkeys.to(torch.int64).contiguous(), addr,
+                          values.dtype, self.max_D, values.size(1))
+            return
+        values[midx] = 0
+        ext.init_rows(mode, p, self._seed, float(self.initial_accumulator_value), mkeys.to(torch.int64).contiguous(), addr,
+                      values.dtype, self.max_D, self.max_D, table_ids=mtids.to(torch.int64).contiguous(),
+                      table_emb_dims=self.dims_t, table_value_dims=self.dims_t)
+        if self.max_state:
+            values[midx, self.max_D:] = float(self.initial_accumulator_value)
+
     def _backward_impl(self, st, grads: torch.Tensor):
+        if self._cache is not None:
+            return self._backward_cached(st, grads)
         if st is None or st.nu == 0:
             return
-        D, V = self.dims[0], self.value_dims[0]
+        D, V = self.max_D, st.values.size(1)
         pooled = self.pooling_mode != DynamicEmbPoolingMode.NONE
         combiner = (0 if self.pooling_mode == DynamicEmbPoolingMode.SUM else 1) if pooled else -1
-        g = ext.reduce_grads(st.rev, grads.contiguous(), st.nu, st.batch_size, D, st.offsets if pooled else None, None, combiner,
-                             self.total_D)
+        g = ext.reduce_grads(st.rev, grads.contiguous(), st.nu, st.batch_size, D, st.offsets if pooled else None, self.D_offsets_t,
+                             combiner, self.total_D)
         vals, tid = st.values, st.tids
-        dims_t = torch.tensor(self.dims, dtype=torch.int64, device=self.device_)
-        al = D % 4 == 0 and V % 4 == 0
+        dims_t = self.dims_t
+        al = all(d % 4 == 0 for d in self.dims) and V % 4 == 0
         self._iter_num += 1
         if self._opt_kind == 1:
             ext.sgd_update_for_padded_buffer(g, vals, tid, dims_t, D, V, al, self.learning_rate)
@@ -204,6 +258,154 @@ class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
             ext.rowwise_adagrad_for_padded_buffer(g, vals, tid, dims_t, D, V, al, self.learning_rate, self.eps)
         self._storage.insert(st.ukeys, tid, vals, self._insert_scores(st.nu, st.freq))
 
+    # ------------------------------------------------------------------ caching=True: HBM cache in front of the store
+    def _sync_cache_hparams(self) -> None:
+        c = self._cache
+        c.learning_rate, c.eps, c.beta1, c.beta2, c.weight_decay = self.learning_rate, self.eps, self.beta1, self.beta2, self.weight_decay
+        c._step, c._custom_score = self._step, self._custom_score
+
+    def _forward_cached(self, indices: torch.Tensor, offsets: torch.Tensor, train: bool):
+        """CACHING_PS forward (batched_dynamicemb_tables.py:694-706; the cache walk of batched_dynamicemb_function.py:298-556 with a
+        `Storage` behind it): find in the HBM cache; misses are fetched from the store (`find`, padded value rows) or initialised,
+        and inserted into the cache, whose evictions are written back (`insert`); a key the cache refuses (its bucket is full of
+        rows this batch uses) is trained in a spill buffer and written back after the backward.  Every unique key ends up with ONE
+        row address on the GPU, so gather and backward are the launches of the HBM-only module."""
+        from .scored_hashtable import ScoreArg
+
+        c = self._cache
+        self._sync_cache_hparams()
+        n, num_bags = indices.numel(), offsets.numel() - 1
+        B = num_bags // self.feature_num
+        T, dev = self.num_tables, self.device_
+        pooled = self.pooling_mode != DynamicEmbPoolingMode.NONE
+        eb = torch.empty((), dtype=self.embedding_dtype).element_size()
+        st = _StepCtx()
+        st.offsets, st.num_keys, st.batch_size, st.num_bags = offsets, n, B, num_bags
+        st.tids = st.slots = None
+        st.pinned, st.event, st.scratch = False, None, None
+        if pooled:
+            out = torch.empty(B, self.total_D, dtype=self.output_dtype, device=dev)
+            combiner = 0 if self.pooling_mode == DynamicEmbPoolingMode.SUM else 1
+        else:
+            out = torch.empty(n, self.dims[0], dtype=self.output_dtype, device=dev)
+            combiner = -1
+        rng = ext.get_table_range(offsets, self.feature_offsets)
+        ukeys, st.rev, st.uoff, st.csr_cnt, st.csr_rank = ext.segmented_unique_csr(indices, rng, T)
+        nu = int(st.uoff[-1].item())
+        st.row_addr = torch.zeros(max(n, 1), dtype=torch.int64, device=dev)
+        keep = []          # buffers the row addresses point into (alive until the gather has been queued / the backward has run)
+        if nu > 0:
+            uk = ukeys[:nu].contiguous()
+            tids = ext.expand_table_ids_cuda(st.uoff, nu)
+            fp, fs, ip, isc, need_freq = c._scores(nu)
+            if need_freq:
+                fs = isc = st.csr_cnt[:nu].to(torch.int64)
+            find = ScoreArg("score", None if fs is None else fs[:nu], fp)
+            addr = st.row_addr[:nu]
+            _, f0, s0 = c.table.lookup(uk, tids, find)
+            hit0 = f0.nonzero().squeeze(1)
+            if hit0.numel():
+                addr[hit0] = ext.row_addresses(s0[hit0], tids[hit0], c.table_ptrs, c.table_value_dims, eb)
+            miss = (~f0).nonzero().squeeze(1)
+            if miss.numel():
+                k1, t1 = uk[miss].contiguous(), tids[miss].contiguous()
+                fr1 = st.csr_cnt[:nu].to(torch.int64)[miss].contiguous() if need_freq else None
+                if train:
+                    nm, mkeys, midx, mtids, _, _, _, vals = _parse_find(self._storage.find(k1, t1, CopyMode.VALUE, fr1))
+                    if vals.size(1) < self.max_V:
+                        raise RuntimeError(f"Storage.find returned rows of {vals.size(1)} values, {self.max_V} expected")
+                    if nm > 0:
+                        midx = midx.to(torch.int64).contiguous()
+                        self._init_padded_rows(vals, midx, mkeys, mtids if mtids is not None else t1[midx])
+                    insn = ScoreArg("score", None if isc is None else isc[:nu][miss].contiguous(), ip)
+                    if hit0.numel():   # rows the batch found in the cache must not be evicted by the batch's own inserts
+                        c.table.increment_counter(s0[hit0].contiguous(), tids[hit0].contiguous())
+                    idxn, h, ek, ei, es, et = c.table.insert_and_evict(k1, t1, insn)
+                    if hit0.numel():
+                        c.table.decrement_counter(s0[hit0].contiguous(), tids[hit0].contiguous())
+                    if h:
+                        ev = (ei >= 0).nonzero().squeeze(1)     # real evictions (negative entries mark refused inputs)
+                        if ev.numel():   # the evicted rows go back to the store before anything overwrites them
+                            e_k, e_s, e_sc, e_t = ek[ev].contiguous(), ei[ev].contiguous(), es[ev].contiguous(), et[ev].contiguous()
+                            buf_ev = torch.zeros(ev.numel(), vals.size(1), dtype=self.embedding_dtype, device=dev)
+                            ext.load_from_flat_table_value(c.table_ptrs, e_s, e_t, buf_ev, c.table_value_dims, c.table_emb_dims,
+                                                           self.max_D, True)
+                            self._storage.insert(e_k, e_t, buf_ev, e_sc.to(torch.int64))
+                    ok = (idxn >= 0).nonzero().squeeze(1)
+                    if ok.numel():
+                        ext.store_to_flat_table_value(c.table_ptrs, idxn[ok].contiguous(), t1[ok].contiguous(), vals[ok].contiguous(),
+                                                      c.table_value_dims, c.table_emb_dims, self.max_D, True)
+                        addr[miss[ok]] = ext.row_addresses(idxn[ok].contiguous(), t1[ok].contiguous(), c.table_ptrs,
+                                                           c.table_value_dims, eb)
+                    bad = (idxn < 0).nonzero().squeeze(1)
+                    if bad.numel():    # refused by the cache: flat rows in a spill buffer for this step, back to the store after it
+                        # the spill buffer is a flat table of its own: the rows of table t, value_dims[t] wide, one after the other
+                        # behind those of the tables before it (unique keys -- hence `bad` -- are table-major)
+                        nb = bad.numel()
+                        tb_ = t1[bad].contiguous()
+                        cnt = torch.bincount(tb_, minlength=T)
+                        first = torch.cumsum(cnt, 0) - cnt                                  # first spilled key of every table
+                        rows = torch.arange(nb, dtype=torch.int64, device=dev) - first[tb_]  # row inside the table's region
+                        elems = cnt * c.table_value_dims
+                        spill = torch.zeros(nb * max(self.value_dims), dtype=self.embedding_dtype, device=dev)
+                        sp_ptrs = (spill.data_ptr() + (torch.cumsum(elems, 0) - elems) * eb).contiguous()
+                        ext.store_to_flat_table_value(sp_ptrs, rows, tb_, vals[bad].contiguous(), c.table_value_dims, c.table_emb_dims,
+                                                      self.max_D, True)
+                        addr[miss[bad]] = sp_ptrs[tb_] + rows * (c.table_value_dims[tb_] * eb)
+                        sc_all = self._insert_scores(nu, fs[:nu] if need_freq else None)
+                        st.scratch = (spill, sp_ptrs, rows, k1[bad].contiguous(), tb_, vals.size(1),
+                                      None if sc_all is None else sc_all[miss][bad].contiguous())
+                else:
+                    nm, _, midx, _, _, _, _, vals = _parse_find(self._storage.find(k1, t1, CopyMode.EMBEDDING, None))
+                    if nm > 0:
+                        init_dense_rows(vals, midx, self._dynamicemb_options[0].eval_initializer_args)
+                    addr[miss] = vals.data_ptr() + torch.arange(miss.numel(), dtype=torch.int64, device=dev) * (vals.stride(0) * eb)
+                    keep.append(vals)
+        al = all(d % 4 == 0 for d in self.dims) and all(v % 4 == 0 for v in self.value_dims) and self.max_V % 4 == 0
+        if pooled:
+            check(lib().mi355_gather_pooled(None, 0, ptr(st.row_addr), dt(self.embedding_dtype), ptr(st.rev), n, ptr(offsets),
+                                            num_bags, B, combiner, self.max_D, ptr(self.D_offsets_t), self.total_D, ptr(out),
+                                            dt(out), int(al), stream()), "gather_pooled")
+        elif n:
+            check(lib().mi355_gather_rows(None, 0, ptr(st.row_addr), dt(self.embedding_dtype), ptr(st.rev), n, None, self.max_D,
+                                          ptr(out), out.stride(0), dt(out), int(al), stream()), "gather_rows")
+        del keep
+        if not train:
+            return out, None
+        self._step += 1
+        return out, st
+
+    def _backward_cached(self, st, grads: torch.Tensor):
+        if st is None:
+            return
+        c = self._cache
+        self._sync_cache_hparams()
+        c._backward_impl_inner(st, grads)
+        self._iter_num = c._iter_num
+        if st.scratch is not None:     # the rows the cache refused: trained in place in the spill buffer, now the store's again
+            spill, sp_ptrs, rows, keys, tids, width, sc = st.scratch
+            st.scratch = None
+            buf = torch.zeros(keys.numel(), width, dtype=self.embedding_dtype, device=self.device_)
+            ext.load_from_flat_table_value(sp_ptrs, rows, tids, buf, c.table_value_dims, c.table_emb_dims, self.max_D, True)
+            self._storage.insert(keys, tids, buf, sc)
+            del spill
+
+    def flush(self) -> None:
+        """write every row of the HBM cache back to the store (the rows stay cached)"""
+        if self._cache is None:
+            return
+        c = self._cache
+        for t in range(self.num_tables):
+            d, s_ = self.dims[t], self.value_dims[t] - self.dims[t]
+            for keys, rows, scores in c._export_table(t, 1 << 16):
+                buf = torch.zeros(keys.numel(), self.max_V, dtype=self.embedding_dtype, device=self.device_)
+                rows = rows.to(self.device_)
+                buf[:, :d] = rows[:, :d]
+                if s_:
+                    buf[:, self.max_D:self.max_D + s_] = rows[:, d:d + s_]
+                self._storage.insert(keys.to(self.device_), torch.full_like(keys, t, device=self.device_), buf,
+                                     scores.to(self.device_).to(torch.int64))
+
     # ------------------------------------------------------------------ the rest of the surface
     def prefetch(self, *args, **kwargs):
         raise NotImplementedError("prefetch with an external storage")
@@ -214,10 +416,8 @@ class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
     def train(self, mode: bool = True):
         return nn.Module.train(self, mode)
 
-    def flush(self) -> None:
-        return
-
     def size(self, table_id: Optional[int] = None):
+        """keys the store holds (with caching=True: after a flush(), which this call does not imply)"""
         return self._storage.size()
 
     @property
@@ -230,6 +430,7 @@ class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
         return os.path.join(save_dir, f"{name}_opt_args.json"), base("keys"), base("values"), base("scores"), base("opt_values")
 
     def dump(self, save_dir: str, optim: bool = False, counter: bool = False, table_names=None, pg=None) -> None:
+        self.flush()
         os.makedirs(save_dir, exist_ok=True)
         names = set(table_names if table_names is not None else self._table_names)
         for t, name in enumerate(self._table_names):
@@ -247,6 +448,9 @@ class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
                 continue
             meta, fk, fv, fs, fo = self._paths(save_dir, name, pg)
             self._storage.load(t, meta, fk, fv, fs, fo if optim else None, include_optim=optim, timestamp=ext.device_timestamp())
+        if self._cache is not None:    # what the cache holds is stale now: the store is the truth again
+            self._cache.table.reset()
 
     def export_keys_values(self, table_name: str, device: torch.device, batch_size: int = 65536):
+        self.flush()
         return self._storage.export_keys_values(device, batch_size, self._table_names.index(table_name))

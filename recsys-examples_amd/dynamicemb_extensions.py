@@ -869,34 +869,43 @@ def rowwise_adagrad_for_flat_table(grads, indices, table_ptrs, table_ids, table_
 rowwise_adagrad_update_for_flat_table = rowwise_adagrad_for_flat_table
 
 
-def _opt_padded(kind, grads, values, emb_dim, state_offset, hp):
+def _opt_padded(kind, grads, values, emb_dim, state_offset, hp, table_ids=None, table_emb_dims=None):
+    """{sgd,adam,adagrad,rowwise_adagrad}_update_for_padded_buffer (optimizer.cu:242-413): row u of `values` is
+    table_emb_dims[table_ids[u]] wide (all `emb_dim` wide when the tables agree), its state starts at `state_offset` = the
+    widest embedding."""
     D = emb_dim
     al = _aligned(D, grads.stride(0), values.stride(0), state_offset)
-    check(lib().mi355_optimizer_update(kind, ptr(grads), grads.stride(0), dt(grads), grads.size(0), None, None,
-                                       ptr(values), values.stride(0), dt(values), D, state_offset,
-                                       c_f(hp.get("lr", 0.0)), c_f(hp.get("beta1", 0.9)), c_f(hp.get("beta2", 0.999)),
-                                       c_f(hp.get("eps", 1e-8)), c_f(hp.get("weight_decay", 0.0)),
-                                       int(hp.get("iter_num", 1)), int(al), stream()), "optimizer_update_padded")
+    mixed = table_ids is not None and table_emb_dims is not None and table_emb_dims.numel() > 1
+    if mixed and al and table_emb_dims.numel() <= 4096:
+        al = int(bool((table_emb_dims % 4 == 0).all().item()))
+    check(lib().mi355_optimizer_update_tables(kind, ptr(grads), grads.stride(0), dt(grads), grads.size(0), None, None,
+                                              ptr(values), values.stride(0), dt(values), D, state_offset,
+                                              c_f(hp.get("lr", 0.0)), c_f(hp.get("beta1", 0.9)), c_f(hp.get("beta2", 0.999)),
+                                              c_f(hp.get("eps", 1e-8)), c_f(hp.get("weight_decay", 0.0)),
+                                              int(hp.get("iter_num", 1)), int(al),
+                                              ptr(table_ids.to(torch.int64).contiguous()) if mixed else None,
+                                              ptr(table_emb_dims.to(torch.int64).contiguous()) if mixed else None, stream()),
+          "optimizer_update_padded")
 
 
 def sgd_update_for_padded_buffer(grads, values, table_ids, table_emb_dims, emb_dim, value_dim, all_dims_vec4, lr):
-    _opt_padded(1, grads, values, emb_dim, emb_dim, dict(lr=lr))
+    _opt_padded(1, grads, values, emb_dim, emb_dim, dict(lr=lr), table_ids, table_emb_dims)
 
 
 def adam_update_for_padded_buffer(grads, values, table_ids, table_emb_dims, emb_dim, value_dim, all_dims_vec4,
                                   lr, beta1, beta2, eps, weight_decay, iter_num):
     _opt_padded(2, grads, values, emb_dim, emb_dim,
-                dict(lr=lr, beta1=beta1, beta2=beta2, eps=eps, weight_decay=weight_decay, iter_num=iter_num))
+                dict(lr=lr, beta1=beta1, beta2=beta2, eps=eps, weight_decay=weight_decay, iter_num=iter_num), table_ids, table_emb_dims)
 
 
 def adagrad_update_for_padded_buffer(grads, values, table_ids, table_emb_dims, emb_dim, value_dim, all_dims_vec4,
                                      lr, eps):
-    _opt_padded(3, grads, values, emb_dim, emb_dim, dict(lr=lr, eps=eps))
+    _opt_padded(3, grads, values, emb_dim, emb_dim, dict(lr=lr, eps=eps), table_ids, table_emb_dims)
 
 
 def rowwise_adagrad_for_padded_buffer(grads, values, table_ids, table_emb_dims, emb_dim, value_dim, all_dims_vec4,
                                       lr, eps):
-    _opt_padded(4, grads, values, emb_dim, emb_dim, dict(lr=lr, eps=eps))
+    _opt_padded(4, grads, values, emb_dim, emb_dim, dict(lr=lr, eps=eps), table_ids, table_emb_dims)
 
 
 rowwise_adagrad_update_for_padded_buffer = rowwise_adagrad_for_padded_buffer

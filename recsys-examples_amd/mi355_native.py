@@ -117,6 +117,8 @@ _SIGS = {
                              c_i64, c_p],
     "mi355_optimizer_update": [c_int, c_p, c_i64, c_int, c_i64, c_p, c_p, c_p, c_i64, c_int, c_i64, c_i64, c_f, c_f,
                                c_f, c_f, c_f, c_i64, c_int, c_p],
+    "mi355_optimizer_update_tables": [c_int, c_p, c_i64, c_int, c_i64, c_p, c_p, c_p, c_i64, c_int, c_i64, c_i64, c_f, c_f,
+                                      c_f, c_f, c_f, c_i64, c_int, c_p, c_p, c_p],
     "mi355_segmented_unique_workspace_bytes": [c_i64],
     "mi355_flagged_compact_workspace_bytes": [c_i64],
     "mi355_group_by_unique_workspace_bytes": [c_i64, c_i64],

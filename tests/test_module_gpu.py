@@ -945,6 +945,79 @@ def test_external_storage_is_transparent(pooling, optimizer):
     assert dut.size() == n_before
 
 
+@pytest.mark.parametrize("caching", [False, True], ids=["store_only", "hbm_cache_in_front"])
+@pytest.mark.parametrize("pooling,optimizer,dims", [("SUM", "SGD", [8, 16, 32]), ("MEAN", "ADAM", [8, 16, 32]),
+                                                    ("SUM", "EXACT_ROWWISE_ADAGRAD", [16, 8, 32]), ("NONE", "EXACT_ADAGRAD", [8, 8, 8])])
+def test_external_storage_mixed_dims_and_hbm_cache(caching, pooling, optimizer, dims):
+    """the two PS layouts of the reference's twin test (test_batched_dynamic_embedding_tables_v2.py:1414-1421, dims [8, 16, 32]):
+    a store alone (HOST_PS) and a store behind an HBM cache (`caching=True`, CACHING_PS) whose 128 rows per table are far fewer
+    than the keys in flight -- so rows are fetched, cached, evicted and written back all the time, and keys the cache refuses are
+    trained in the spill buffer.  Value rows cross the `Storage` interface in the padded layout.  Same outputs as the HBM-only
+    module at every step; after flush() the store holds exactly the HBM module's rows (embedding and optimizer state)."""
+    from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
+    from dynamicemb.dynamicemb_config import (DynamicEmbInitializerArgs, DynamicEmbInitializerMode, DynamicEmbPoolingMode,
+                                              DynamicEmbScoreStrategy, DynamicEmbTableOptions, EmbOptimType)
+    from dynamicemb.external_storage import ExternalStorageTables
+
+    rng = np.random.default_rng(9)
+    fmap = [0, 0, 1, 2]
+    F, B = len(fmap), 40
+    pm = getattr(DynamicEmbPoolingMode, pooling)
+    hp = dict(learning_rate=0.05)
+    if optimizer == "ADAM":
+        hp.update(beta1=0.8, beta2=0.9, eps=1e-6, weight_decay=0.01)
+    elif optimizer != "SGD":
+        hp.update(eps=1e-6, initial_accumulator_value=0.1)
+
+    def make(store):
+        kw = dict(external_storage=store, caching=caching, local_hbm_for_values=1024) if store is not None else {}
+        opts = [DynamicEmbTableOptions(dim=d, max_capacity=4096, index_type=torch.int64, embedding_dtype=torch.float32,
+                                       score_strategy=DynamicEmbScoreStrategy.STEP,
+                                       initializer_args=DynamicEmbInitializerArgs(mode=DynamicEmbInitializerMode.UNIFORM, lower=-0.3, upper=0.3),
+                                       **kw) for d in dims]
+        m = BatchedDynamicEmbeddingTablesV2(opts, feature_table_map=fmap, pooling_mode=pm, output_dtype=torch.float32,
+                                            optimizer=getattr(EmbOptimType, optimizer), device=torch.device("cuda", 0), **hp)
+        m.train()
+        return m
+
+    ref, dut = make(None), make(_DictStore)
+    assert isinstance(dut, ExternalStorageTables) and (dut._cache is not None) == caching
+    if caching:
+        assert all(int(c) == dut._dynamicemb_options[0].bucket_capacity for c in dut._cache.table.per_table_capacity_)   # one bucket per table
+    for step in range(8):
+        lens = rng.integers(0, 6, F * B)
+        off = np.zeros(F * B + 1, np.int64)
+        off[1:] = np.cumsum(lens)
+        keys = torch.from_numpy(rng.integers(0, 500, off[-1]).astype(np.int64)).cuda()
+        off_t = torch.from_numpy(off).cuda()
+        o_ref = ref(keys, off_t)
+        o_dut = dut(keys, off_t)
+        torch.testing.assert_close(o_dut, o_ref, rtol=1e-6, atol=1e-6, msg=f"step {step}")
+        g = torch.randn_like(o_ref)
+        o_ref.backward(g)
+        o_dut.backward(g)
+    if caching:
+        assert dut.storage.inserts > 8, "nothing was ever evicted from the cache"
+    dut.flush()
+    assert dut.size() == int(ref.size())
+    maxD = max(dims)
+    probe = torch.arange(0, 500, device="cuda", dtype=torch.int64)
+    for t, d in enumerate(dims):
+        f1, r1 = ref.lookup_rows(probe, t)
+        sdim = r1.size(1) - d
+        for k in probe[f1].tolist():
+            row = dut.storage.rows[(t, k)]
+            torch.testing.assert_close(row[:d], r1[k][:d], rtol=1e-5, atol=1e-6)
+            if sdim:
+                torch.testing.assert_close(row[maxD:maxD + sdim], r1[k][d:], rtol=1e-5, atol=1e-6)
+        assert sum(1 for (tt, _k) in dut.storage.rows if tt == t) == int(f1.sum())
+    ref.eval(); dut.eval()
+    ek = torch.from_numpy(rng.integers(0, 900, F * B).astype(np.int64)).cuda()
+    eo = torch.arange(0, F * B + 1, dtype=torch.int64, device="cuda")
+    with torch.no_grad():
+        torch.testing.assert_close(dut(ek, eo), ref(ek, eo), rtol=1e-6, atol=1e-6)
+
+
 def test_external_storage_dump_and_load_go_through_the_store(tmp_path):
     """dump() / load() of a module over an external store hand the reference's per-table file names to Storage.dump / Storage.load
     (batched_dynamicemb_tables.py:73-92): a second module over a fresh store serves the same rows after load()."""
@@ -986,8 +1059,6 @@ def test_external_storage_rejects_what_it_cannot_do():
 
     mk = lambda **kw: [DynamicEmbTableOptions(dim=8, max_capacity=1024, index_type=torch.int64, embedding_dtype=torch.float32,  # noqa: E731
                                               external_storage=_DictStore, **kw)]
-    with pytest.raises(NotImplementedError, match="caching"):
-        BatchedDynamicEmbeddingTablesV2(mk(caching=True), device=torch.device("cuda", 0))
     m = BatchedDynamicEmbeddingTablesV2(mk(), device=torch.device("cuda", 0))
     with pytest.raises(NotImplementedError, match="prefetch"):
         m.prefetch(torch.zeros(1, dtype=torch.int64, device="cuda"), torch.tensor([0, 1], device="cuda"))
