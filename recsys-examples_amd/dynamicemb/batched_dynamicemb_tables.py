@@ -343,8 +343,6 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         if self._admit_strategy is not None:
             if self._admission_counter is None:
                 raise ValueError("admit_strategy needs an admission_counter (KVCounter) per table")
-            if storage_mode == "hybrid":    # (HBM-only and host-only tables take the same admission walk: one table, rows by address)
-                raise NotImplementedError("admission with hybrid (HBM + host) storage")
         self.table_ptrs = torch.tensor([v.data_ptr() for v in self.values], dtype=torch.int64, device=self.device_)
         self.table_value_dims = torch.tensor(self.value_dims, dtype=torch.int64, device=self.device_)
         self.table_emb_dims = torch.tensor(self.dims, dtype=torch.int64, device=self.device_)
@@ -741,7 +739,11 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         gather.  Every row it resolved -- in either tier -- is pinned (ref counters of that tier's table) until the batch's
         backward, so the evictions of the batches prefetched after it cannot move it; and while prefetched batches are
         outstanding no key is PROMOTED from the host tier (a promotion moves a row, and an outstanding step may hold its
-        host address): promotion resumes with the first forward that finds the queue empty."""
+        host address): promotion resumes with the first forward that finds the queue empty.
+
+        Admission (round 4: `admit_strategy` over the two tiers, batched_dynamicemb_function.py:559-696): a key missing in BOTH
+        tiers adds its batch frequency to the admission counter; only the admitted ones take the insert walk above, the others are
+        served for this step from scratch rows the initializer fills (not stored, no gradient), as in _forward_admission."""
         from .scored_hashtable import ScoreArg
 
         n = indices.numel()
@@ -767,6 +769,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         ukeys, st.rev, st.uoff, st.csr_cnt, st.csr_rank = ext.segmented_unique_csr(indices, rng, T)
         nu = int(st.uoff[-1].item())
         st.row_addr = torch.zeros(max(n, 1), dtype=torch.int64, device=dev)
+        fwd_addr, scratch = st.row_addr, None      # (admission: the forward also reads scratch rows the backward must not touch)
+        admission = train and self._admit_strategy is not None
         if nu > 0:
             uk = ukeys[:nu].contiguous()
             tids = ext.expand_table_ids_cuda(st.uoff, nu)
@@ -791,6 +795,14 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                 if hit1.numel():
                     addr[miss[hit1]] = ext.row_addresses(s1[hit1], t1[hit1], self.table_ptrs_host, self.table_value_dims, eb)
                 new = miss[(~f1).nonzero().squeeze(1)]
+                rej = new[:0]
+                if admission and new.numel():
+                    km, tm = uk[new].contiguous(), tids[new].contiguous()
+                    acc = self._admission_counter.add(km, tm, st.csr_cnt[:nu].to(torch.int64)[new].contiguous())
+                    admit = self._admit_strategy.admit(km, acc)
+                    rej, new = new[~admit], new[admit]
+                    if new.numel():
+                        self._admission_counter.erase(uk[new].contiguous(), tids[new].contiguous())
                 # cache mode: host-tier hits are promoted into the HBM tier together with the unseen keys (never while a
                 # prefetched batch is outstanding: it may hold the host address of the row a promotion would move)
                 may_promote = train and self._promote and not prefetch_only and self._tier_prefetched == 0
@@ -859,18 +871,31 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                                       self.embedding_dtype, self.max_D, max(self.value_dims), skip=(a_new == 0),
                                       table_ids=tn[:n_new].contiguous(), table_emb_dims=self.table_emb_dims,
                                       table_value_dims=self.table_value_dims)
+                if rej.numel():     # not admitted: scratch rows from the strategy's initializer (None: the table's) for this step only
+                    vmax = max(self.value_dims)
+                    scratch = torch.empty(rej.numel(), vmax, dtype=self.embedding_dtype, device=dev)
+                    a_rej = scratch.data_ptr() + torch.arange(rej.numel(), dtype=torch.int64, device=dev) * (vmax * eb)
+                    mode, p = self._init_params(getattr(self._admit_strategy, "initializer_args", None))
+                    ext.init_rows(mode, p, self._seed, self.initial_accumulator_value, uk[rej].contiguous(), a_rej,
+                                  self.embedding_dtype, self.max_D, vmax, table_ids=tids[rej].contiguous(),
+                                  table_emb_dims=self.table_emb_dims, table_value_dims=self.table_value_dims)
+                    fwd_addr = st.row_addr.clone()
+                    fwd_addr[rej] = a_rej
         if prefetch_only:
+            if admission:
+                st.fwd_addr, st.scratch = fwd_addr, scratch
             self._pin_tier_rows(st, pins)
             self._step += 1
             return None, st
         al = all(d % 4 == 0 for d in self.dims) and all(v % 4 == 0 for v in self.value_dims)
         if pooled:
-            check(lib().mi355_gather_pooled(None, 0, ptr(st.row_addr), dt(self.embedding_dtype), ptr(st.rev), n, ptr(offsets),
+            check(lib().mi355_gather_pooled(None, 0, ptr(fwd_addr), dt(self.embedding_dtype), ptr(st.rev), n, ptr(offsets),
                                             num_bags, B, combiner, self.max_D, ptr(self.D_offsets_t), self.total_D, ptr(out),
                                             dt(out), int(al), stream()), "gather_pooled")
         elif n:
-            check(lib().mi355_gather_rows(None, 0, ptr(st.row_addr), dt(self.embedding_dtype), ptr(st.rev), n, None, self.max_D,
+            check(lib().mi355_gather_rows(None, 0, ptr(fwd_addr), dt(self.embedding_dtype), ptr(st.rev), n, None, self.max_D,
                                           ptr(out), out.stride(0), dt(out), int(al), stream()), "gather_rows")
+        del scratch   # stream-ordered: the gather above is already queued
         if train:
             self._step += 1
         return out, st

@@ -577,7 +577,7 @@ def test_c1_matches_torch_embedding_bag():
 
 
 # ------------------------------------------------------------------------------------------ admission
-@pytest.mark.parametrize("storage", ["hbm", "host"])
+@pytest.mark.parametrize("storage", ["hbm", "host", "hybrid", "cache"])
 @pytest.mark.parametrize("prefetch", [False, True])
 @pytest.mark.parametrize("threshold", [1, 3, 5])
 @pytest.mark.parametrize("pooling", ["SUM", "NONE"])
@@ -589,7 +589,9 @@ def test_frequency_admission_against_dict_twin(threshold, pooling, prefetch, sto
     row and gets no update), so the stored key set, the counter population, every pooled output and every row after
     SGD must match.  prefetch: batch i + 1 walks the admission path (prefetch()) BEFORE batch i's backward, as the reference's
     prefetch pipeline does (batched_dynamicemb_function.py:559-696); the stored set, the outputs and the rows are the same.
-    storage = "host": the table and its rows in pinned host memory (the same walk over the host link)."""
+    storage = "host": the table and its rows in pinned host memory (the same walk over the host link); "hybrid" / "cache"
+    (round 4): a 128-row HBM tier over a host tier, with more keys than the HBM tier holds -- admitted keys take the two-tier
+    insert walk (evictions spill down, "cache" also promotes), rejected ones are served from scratch rows."""
     (B2, IA, IM, PM, SS, TO, OT) = _mods()
     from dynamicemb.embedding_admission import FrequencyAdmissionStrategy, KVCounter
 
@@ -601,14 +603,15 @@ def test_frequency_admission_against_dict_twin(threshold, pooling, prefetch, sto
     m = B2(table_options=opts, table_names=["t0"], feature_table_map=[0, 0], pooling_mode=getattr(PM, pooling),
            optimizer=OT.SGD, learning_rate=lr, output_dtype=torch.float32, device=torch.device(DEV), storage_mode=storage)
     m.train()
-    assert m.storage_mode == storage
+    assert m.storage_mode == ("hybrid" if storage == "cache" else storage)
+    key_hi = 400 if storage in ("hybrid", "cache") else 40
     rng = np.random.default_rng(threshold * 7 + len(pooling))
     rows, counter = {}, {}
     batches = []
     for step in range(steps):
         lens = rng.integers(0, 4, F * B)
         off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-        batches.append((rng.integers(0, 40, int(off[-1])).astype(np.int64), off))
+        batches.append((rng.integers(0, key_hi, int(off[-1])).astype(np.int64), off))
     dev = [(torch.from_numpy(k).to(DEV), torch.from_numpy(o).to(DEV)) for k, o in batches]
     if prefetch:
         m.prefetch(*dev[0])
