@@ -158,7 +158,7 @@ def test_multi_table_batches_of_a_few_hundred_thousand_keys_against_the_per_op_c
         torch.testing.assert_close(v1[o1], v2[o2], rtol=3e-5, atol=3e-6)
 
 
-@pytest.mark.parametrize("case", ["eight_equal", "skewed", "shared_table_mixed_dims"])
+@pytest.mark.parametrize("case", ["eight_equal", "skewed", "shared_table_mixed_dims", "seventy_tables"])
 @pytest.mark.parametrize("pooling,opt,strategy", [("SUM", "SGD", "TIMESTAMP"), ("MEAN", "ADAM", "LFU"), ("SUM", "EXACT_ROWWISE_ADAGRAD", "STEP"),
                                                   ("NONE", "SGD", "LFU"), ("NONE", "ADAM", "TIMESTAMP")])
 def test_multi_table_pooled_batches_take_the_csr_writing_partition_path(case, pooling, opt, strategy, monkeypatch):
@@ -178,13 +178,18 @@ def test_multi_table_pooled_batches_take_the_csr_writing_partition_path(case, po
         dims, fmap, B = (16, 16, 16, 16), None, 30_000
         hi = [300_000, 50, 1_000, 7]
         maxlen = [9, 2, 0, 2]           # feature 2 has no key at all; features 1 and 3 a few thousand
+    elif case == "seventy_tables":     # more tables than a wave has lanes: the partition counts are scanned two per lane
+        dims, fmap, B = (16,) * 70, None, 1_500
+        hi = [4_000 + 50 * t for t in range(70)]
+        maxlen = [9] * 70
     else:
         dims, fmap, B = (8, 32, 16), [0, 1, 1, 2], 12_000
         hi = [50_000, 80_000, 80_000, 20_000]
         maxlen = [9, 9, 5, 9]
     F = len(hi)
-    ref = _mk(False, dims, cap=1 << 19, pooling=pooling, opt=opt, strategy=strategy, fmap=fmap, learning_rate=0.2, monkeypatch=monkeypatch)
-    dut = _mk(True, dims, cap=1 << 19, pooling=pooling, opt=opt, strategy=strategy, fmap=fmap, learning_rate=0.2, monkeypatch=monkeypatch)
+    cap = 1 << 14 if case == "seventy_tables" else 1 << 19
+    ref = _mk(False, dims, cap=cap, pooling=pooling, opt=opt, strategy=strategy, fmap=fmap, learning_rate=0.2, monkeypatch=monkeypatch)
+    dut = _mk(True, dims, cap=cap, pooling=pooling, opt=opt, strategy=strategy, fmap=fmap, learning_rate=0.2, monkeypatch=monkeypatch)
     fm = fmap or list(range(F))
     rng = np.random.default_rng(5)
     ref.train(); dut.train()
