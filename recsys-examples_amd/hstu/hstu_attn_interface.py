@@ -277,14 +277,18 @@ class HstuAttnWindowFunc(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None, None, None
 
 
-_FUNC_NEG = -1.0e9   # bias of a masked (query, key) pair: SiLU(alpha (q.k + bias)) is -0 exactly (the sigmoid underflows to 0;
-                     # so does SiLU', so no gradient crosses the mask) for any alpha above ~1e-7
+def _func_neg(dtype) -> float:
+    """bias of a masked (query, key) pair: SiLU(alpha (q.k + bias)) is -0 exactly (the sigmoid underflows to 0; so does SiLU', so
+    no gradient crosses the mask).  It has to stay FINITE in the operand type (-inf x 0 would be NaN): -1e9 in bf16 (any alpha
+    above ~1e-7), -6e4 in fp16 (alpha above ~2e-3; 1 / sqrt(head_dim) is 0.06 .. 0.18)."""
+    return -6.0e4 if dtype == torch.float16 else -1.0e9
+
 
 
 def func_mask_bias(func, cu_seqlens_q, cu_seqlens_k, max_seqlen_k, dtype):
     """Arbitrary mask functions (`func`, hstu_api.cpp:170-180; applied in hstu_fwd.h:493-556) as an attention bias for the rab
     kernels: [batch, heads_func, N, N] (N = max_seqlen_k), 0 where query token t may see key column j -- j < func[h, 0, t], or
-    func[h, 2p - 1, t] <= j < func[h, 2p, t] for a p >= 1 -- and -1e9 elsewhere.  Row i of a sequence is the query token
+    func[h, 2p - 1, t] <= j < func[h, 2p, t] for a p >= 1 -- and _func_neg(dtype) elsewhere.  Row i of a sequence is the query token
     i - (Lk - Lq) (delta-q: the queries are the sequence's last rows, corelib/hstu/test.py:122-131).  Built on the device without
     a host read; O(batch N^2) memory, which is what buys the masks the whole machinery of the biased kernels (any other mask on
     top, gradients, delta-q / paged keys)."""
@@ -301,7 +305,7 @@ def func_mask_bias(func, cu_seqlens_q, cu_seqlens_k, max_seqlen_k, dtype):
     ok = j < f[:, 0, :, :, None]
     for p in range(1, func.shape[1] // 2 + 1):
         ok |= (f[:, 2 * p - 1, :, :, None] <= j) & (j < f[:, 2 * p, :, :, None])
-    bias = torch.zeros(ok.shape, dtype=dtype, device=dev).masked_fill_(~ok, _FUNC_NEG)
+    bias = torch.zeros(ok.shape, dtype=dtype, device=dev).masked_fill_(~ok, _func_neg(dtype))
     return bias.permute(1, 0, 2, 3).contiguous()                                 # [B, Hf, N, N]
 
 
@@ -400,7 +404,7 @@ def hstu_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, seqused_q, sequse
         fb = func_mask_bias(func, cu_seqlens_q, cu_seqlens_k, max_seqlen_k, q.dtype)
         if rab is not None and rab.shape[-1] != int(max_seqlen_k):
             raise RuntimeError("rab must be (batch, nheads or 1, max_seqlen_k, max_seqlen_k)")
-        rab = fb if rab is None else rab + fb
+        rab = fb if rab is None else (rab + fb).clamp_(min=torch.finfo(q.dtype).min)   # (fp16: the sum must stay finite)
     if rab is not None:
         if rab.shape[-1] != int(max_seqlen_k):
             raise RuntimeError("rab must be (batch, nheads or 1, max_seqlen_k, max_seqlen_k)")

@@ -58,7 +58,7 @@ def _fwd(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, scaling_seqlen
     if func is not None:   # arbitrary mask: a 0 / -1e9 bias through the biased kernels (hstu_attn_interface.func_mask_bias)
         fb = func_mask_bias(func, cu_q, cu_k, int(max_k), q.dtype)
         out = hstu_varlen_fwd_rab(q, k, v, cu_q, int(max_k), scaling_seqlen, num_contexts, num_targets, int(target_group_size),
-                                  max(int(wl), -1), max(int(wr), -1), float(alpha), fb if rab is None else rab + fb)
+                                  max(int(wl), -1), max(int(wr), -1), float(alpha), fb if rab is None else (rab + fb).clamp_(min=torch.finfo(q.dtype).min))
         return out, rab
     if rab is not None:
         return hstu_varlen_fwd_rab(q, k, v, cu_q, int(max_k), scaling_seqlen, num_contexts, num_targets, int(target_group_size),
@@ -81,7 +81,7 @@ def _bwd(dout, q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, scaling_
         fb = func_mask_bias(func, cu_q, cu_k, int(max_k), q.dtype)
         *g, drab = hstu_varlen_bwd_rab(dout, q, k, v, cu_q, int(max_k), scaling_seqlen, num_contexts, num_targets,
                                        int(target_group_size), max(int(wl), -1), max(int(wr), -1), float(alpha),
-                                       fb if rab is None else rab + fb, bool(has_drab))
+                                       fb if rab is None else (rab + fb).clamp_(min=torch.finfo(q.dtype).min), bool(has_drab))
         if drab is not None and rab.shape[1] == 1 and drab.shape[1] > 1:   # (a per-head mask over one shared bias head)
             drab = drab.float().sum(1, keepdim=True).to(q.dtype)
     elif rab is not None:

@@ -403,7 +403,7 @@ def test_arbitrary_mask_golden(name):
     _assert_vs_oracle(out, (qq.grad, kk.grad, vv.grad), g("out"), g("dq"), g("dk"), g("dv"))
 
 
-@pytest.mark.parametrize("mode", ["per_head", "with_rab", "with_targets_causal", "delta_q", "raw_ops"])
+@pytest.mark.parametrize("mode", ["per_head", "with_rab", "with_targets_causal", "delta_q", "raw_ops", "fp16", "fp16_with_rab"])
 def test_arbitrary_mask_random_jagged_vs_oracle(mode):
     """func over several tiles with ragged ends, an empty and a one-token sequence: one mask per head; together with a relative
     bias (drab flows through the sum, zero where the function masks); narrowing the causal + target mask; over delta-q keys
@@ -415,7 +415,8 @@ def test_arbitrary_mask_random_jagged_vs_oracle(mode):
     B, H, d, N = lengths.size, 2, 64, int(lengths.max())
     off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
     T = int(off[-1])
-    mk = lambda lo, hi, *shape: torch.from_numpy(rng.uniform(lo, hi, shape).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    tdt = torch.float16 if mode.startswith("fp16") else torch.bfloat16      # (fp16: the mask bias must stay finite, -6e4)
+    mk = lambda lo, hi, *shape: torch.from_numpy(rng.uniform(lo, hi, shape).astype(np.float32)).to(DEV).to(tdt)
     q, k, v, dout = mk(-1, 1, T, H, d), mk(-1, 1, T, H, d), mk(-1, 1, T, H, d), mk(0, 1, T, H, d)
     HF = H if mode == "per_head" else 1
     f = np.zeros((HF, 5, T + 64), np.int32)
@@ -445,7 +446,7 @@ def test_arbitrary_mask_random_jagged_vs_oracle(mode):
         return
     kw, okw = {}, dict(causal=False)
     rab = None
-    if mode == "with_rab":
+    if mode in ("with_rab", "fp16_with_rab"):
         rab = mk(-2, 2, B, H, N, N).requires_grad_(True)
         kw.update(rab=rab, has_drab=True)
         okw.update(rab=rab.detach().float().cpu().numpy())
@@ -470,7 +471,8 @@ def test_arbitrary_mask_random_jagged_vs_oracle(mode):
     ref = ho.hstu_attn_fwd(qn, kn, vn, off, alpha, N, func=f, **okw)
     res = ho.hstu_attn_bwd(dn, qn, kn, vn, off, alpha, N, func=f, **okw)
     _assert_vs_oracle(out, grads, ref, res[0], res[1], res[2])
-    if mode == "with_rab":
+    assert bool(torch.isfinite(out.float()).all()) and all(bool(torch.isfinite(g_.float()).all()) for g_ in grads)
+    if mode in ("with_rab", "fp16_with_rab"):
         _assert_drab(rab.grad, res[3])
 
 
