@@ -443,6 +443,81 @@ def hstu_long_section(args, device):
             "config": {"workload": f"attention: batch {Bq} x L {L} (dense lengths), H {H}, d {d}, causal, alpha 1/sqrt(d)"}}
 
 
+def model_shapes_section(args, device):
+    """The embedding step at the shapes an HSTU model's embedding collection sends (the round-3 review's item 5):
+    eight tables of 6.25 M rows, (i) pooled SUM, 8 x 8192 bags of ~5.5 keys, (ii) sequence lookups, 8 x 16 384 tokens --
+    fwd + bwd (SGD) per step and the eval forward, Zipf(--alpha) keys per table.  Both take the CSR-writing partition path with
+    table-aligned partitions since round 4 (tools/bench_model_shapes.py has the other shapes and the A/B switches)."""
+    from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
+    from dynamicemb.dynamicemb_config import (DynamicEmbInitializerArgs, DynamicEmbInitializerMode, DynamicEmbPoolingMode,
+                                              DynamicEmbScoreStrategy, DynamicEmbTableOptions, EmbOptimType)
+
+    T, rows = 8, 6_250_000
+    res = {}
+    for name, pooling, bags, hot in (("pooled_8x8192_bags", "SUM", 8192, 5), ("sequence_8x16384_tokens", "NONE", 16384, 1)):
+        opts = [DynamicEmbTableOptions(dim=args.dim, max_capacity=rows, embedding_dtype=torch.float32, index_type=torch.int64,
+                                       score_strategy=DynamicEmbScoreStrategy.TIMESTAMP,
+                                       initializer_args=DynamicEmbInitializerArgs(mode=DynamicEmbInitializerMode.UNIFORM, lower=-0.01, upper=0.01))
+                for _ in range(T)]
+        m = BatchedDynamicEmbeddingTablesV2(opts, feature_table_map=list(range(T)), pooling_mode=getattr(DynamicEmbPoolingMode, pooling),
+                                            output_dtype=torch.bfloat16, optimizer=EmbOptimType.SGD, learning_rate=0.1, device=device)
+        m.train()
+        g = torch.Generator(device=device)
+        g.manual_seed(77)
+        w = torch.arange(1, rows + 1, device=device, dtype=torch.float64).pow_(-args.alpha)
+        cdf = torch.cumsum(w, 0)
+        cdf /= cdf[-1].clone()
+        batches = []
+        for _ in range(6):
+            lens = (torch.ones(T * bags, dtype=torch.int64, device=device) if hot == 1
+                    else torch.randint(1, 2 * hot, (T * bags,), device=device, generator=g))
+            off = torch.zeros(T * bags + 1, dtype=torch.int64, device=device)
+            off[1:] = torch.cumsum(lens, 0)
+            u = torch.rand(int(off[-1].item()), device=device, dtype=torch.float64, generator=g)
+            ranks = torch.searchsorted(cdf, u).clamp_(max=rows - 1)
+            batches.append(((ranks * 2654435761 % rows).contiguous(), off))
+        del w, cdf
+        with torch.no_grad():
+            for k, o in batches:
+                m._forward_impl(k, o, train=True)
+        out, st = m._forward_impl(*batches[0], train=True)
+        grad = (torch.randn_like(out.float()) * 0.01).to(out.dtype)
+        m._backward_impl(st, grad)
+
+        def step(i):
+            k, o = batches[i % len(batches)]
+            out, st = m._forward_impl(k, o, train=True)
+            m._backward_impl(st, grad if out.shape == grad.shape else torch.zeros_like(out))
+
+        def ev(i):
+            k, o = batches[i % len(batches)]
+            m._forward_impl(k, o, train=False)
+
+        def timeit(fn, reps=60):
+            for i in range(8):
+                fn(i)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(reps):
+                fn(i)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        ms = timeit(step)
+        m.eval()
+        with torch.no_grad():
+            ms_eval = timeit(ev)
+        nk = sum(k.numel() for k, _ in batches) / len(batches)
+        res[name] = {"ms_per_step": ms, "eval_forward_ms": ms_eval, "keys_per_step": nk, "lookups_per_s": nk / ms * 1e3,
+                     "path_c": bool(getattr(st, "lazy", False))}
+        del m, batches
+        torch.cuda.empty_cache()
+    res["config"] = {"workload": f"{T} tables x {rows} rows, dim {args.dim}, fp32 rows, SGD, Zipf({args.alpha}) keys per table"}
+    return res
+
+
 def c2_16x_section(args, module, device):
     """The bandwidth-regime figure SURVEY 8(d) asks for: the C2 step at 16 x the batch (B = 1,048,576 bags, ~5.8 M keys) on
     the same table: step time and the step-level roofline (minimal bytes / time)."""
@@ -721,6 +796,7 @@ def main():
 
     if rank == 0 and not sharded_path and not args.no_kernel_timing and not args.no_extra:
         result["c2_16x"] = c2_16x_section(args, module, device)
+        result["model_shapes"] = model_shapes_section(args, device)
 
     if not args.no_hstu:
         h = hstu_section(args, device, world, dist if sharded_path else None)
