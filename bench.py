@@ -480,6 +480,12 @@ def model_shapes_section(args, device):
         with torch.no_grad():
             for k, o in batches:
                 m._forward_impl(k, o, train=True)
+        nus = []
+        for k, o in batches:     # unique rows per step (for the step's algorithmic bytes)
+            out, st = m._forward_impl(k, o, train=True)
+            nus.append(int(st.uoff[-1].item()))
+            grad = (torch.randn_like(out.float()) * 0.01).to(out.dtype)
+            m._backward_impl(st, grad)
         out, st = m._forward_impl(*batches[0], train=True)
         grad = (torch.randn_like(out.float()) * 0.01).to(out.dtype)
         m._backward_impl(st, grad)
@@ -510,8 +516,17 @@ def model_shapes_section(args, device):
         with torch.no_grad():
             ms_eval = timeit(ev)
         nk = sum(k.numel() for k, _ in batches) / len(batches)
-        res[name] = {"ms_per_step": ms, "eval_forward_ms": ms_eval, "keys_per_step": nk, "lookups_per_s": nk / ms * 1e3,
-                     "path_c": bool(getattr(st, "lazy", False))}
+        nu = float(np.mean(nus))
+        D, e, o = args.dim, 4, 2
+        rows_out = T * bags if hot != 1 else nk       # output rows: one per bag (pooled) or per key (sequence)
+        # the byte model of the C2 step (kernel_roofline above): index words per key / bag / unique row, every unique row read
+        # once in the forward and read + written in the backward, the output written, its gradient read
+        step_bytes = (8 * nk + 8 * (T * bags + 1) + 16 * nu + nu * D * e + rows_out * D * o) + (8 * nk + rows_out * D * o + 2 * nu * D * e)
+        gbps = step_bytes / ms / 1e6
+        res[name] = {"ms_per_step": ms, "eval_forward_ms": ms_eval, "keys_per_step": nk, "unique_rows_per_step": nu,
+                     "lookups_per_s": nk / ms * 1e3, "path_c": bool(getattr(st, "lazy", False)),
+                     "step_roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                       "frac": gbps / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": step_bytes}}
         del m, batches
         torch.cuda.empty_cache()
     res["config"] = {"workload": f"{T} tables x {rows} rows, dim {args.dim}, fp32 rows, SGD, Zipf({args.alpha}) keys per table"}
