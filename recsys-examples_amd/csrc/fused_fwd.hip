@@ -111,6 +111,13 @@ struct FusedArgs {
   // overflow on one tile's records alone)
   int mt;                         // 1: multi-table partitions
   int32_t* ptab;                  // [P] table of every partition (written by block 0 of the probe kernel)
+  // opt-in re-run of an overflowed step on the per-slot-counter path inside the same call (MI355_FUSED_OVERFLOW_RERUN=1): the
+  // partitioned probe reports an overflow as hdr[ovf_word] = ovf_val (the call's epoch instead of the sticky 1), and the kernels
+  // of the re-run chain, queued behind the gather on every step, return at once unless *gate == gate_val
+  const int* gate;                // nullable: run only if *gate == gate_val
+  int gate_val;
+  int ovf_word, ovf_val;          // where / what the partitioned probe writes when a record list overflows
+  int* rerun_mark;                // nullable: cleared by block 0 of the partitioned probe, set by the re-run chain's last kernel
 };
 
 __device__ __forceinline__ void store_digest(uint8_t* p, uint8_t d) {
@@ -245,8 +252,10 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   __shared__ int s_brange[2], s_wmax[THREADS / 64], s_wsum[THREADS / 64];
   __shared__ int s_hist[kPart ? kPartMax : 1];    // kPart: records of this tile per partition, then their base in the partition
   __shared__ uint64_t s_magic[kFast ? kFusedMaxT : 1];
+  if (a.gate && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.gate_val) return;   // (block uniform)
   PST(0);
   if (!a.timer) a.timer = device_clock();
+  if (kPart && a.rerun_mark && blockIdx.x == 0 && threadIdx.x == 0) *a.rerun_mark = 0;
   constexpr int PER = TILE / THREADS;
   constexpr int LDS = 2 * TILE;
   constexpr int HALVES = TILE / 1024;
@@ -615,7 +624,7 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
         } else
         a.rec[ref] = make_uint4((uint32_t)kreg[q], (uint32_t)(kreg[q] >> 32), (uint32_t)s_cnt[hh[q]], (uint32_t)cnt_tile[q]);
       } else {
-        a.hdr[5] = 1;     // a partition received more records than it can hold: the step is flagged (see the module)
+        a.hdr[a.ovf_word] = a.ovf_val;     // a partition received more records than it can hold: the step is flagged (see the module)
       }
       s_tab[hh[q]] = ref;
     }
@@ -956,6 +965,7 @@ fused_mid_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, boo
   __shared__ int s_ex[kScanTile + 1];       // exclusive representative count in front of every item of the tile
   __shared__ int64_t s_seg[kFusedMaxT + 1];
   __shared__ int s_hbase[3];
+  if (a.gate && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.gate_val) return;   // (grid uniform)
   const int64_t tile0 = (int64_t)blockIdx.x * kScanTile;
   const int64_t n = a.n;
   const int T = a.T;
@@ -2004,7 +2014,8 @@ gather_rows_eval_kernel(ProbeRefs pr, const int64_t* __restrict__ offsets, int B
 __global__ void __launch_bounds__(256)
 occ_from_records_kernel(const int32_t* __restrict__ occ_slot, const int32_t* __restrict__ occ_trank, const int4* __restrict__ rec_out4,
                         const int64_t* __restrict__ row_addr, int64_t n, int64_t* __restrict__ rev, int32_t* __restrict__ rank,
-                        int64_t* __restrict__ occ_addr) {
+                        int64_t* __restrict__ occ_addr, const int* __restrict__ rerun_mark) {
+  if (*rerun_mark == 1) return;   // the step overflowed and was re-run on the per-slot-counter path: its outputs are already eager
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
     const int ref = occ_slot[j];
     const int4 ro = rec_out4[ref >= 0 ? ref : 0];
@@ -2241,6 +2252,7 @@ int mi355_demb_forward_fused(
   a.rec = nullptr; a.rec_out = nullptr; a.rec_out4 = nullptr;
   a.tile_bags = nullptr; a.occ_trank = nullptr;
   a.mt = 0; a.ptab = nullptr;
+  a.gate = nullptr; a.gate_val = 0; a.ovf_word = 5; a.ovf_val = 1; a.rerun_mark = nullptr;
   a.magic0 = num_buckets > 0 ? ~0ull / (uint64_t)num_buckets : 0ull;   // (one table: its buckets are all the buckets)
   {
     const int P = train ? part_count(n, num_tables) : 0;
@@ -2284,9 +2296,20 @@ int mi355_demb_forward_fused(
                      emb_dim <= (4 << lg) && (seq || n <= 8 * num_bags) && value_dtype <= 1 && out_dtype <= 1 &&
                      num_bags < (1ll << 31) - 4096;
   if (part && a.mt && !pathc) { part = false; a.P = 0; a.mt = 0; }   // several tables: path (c) or the per-slot counters
+  // opt-in: an overflowed step is re-run on the per-slot-counter path inside this call (the reference never skips an update,
+  // unique_op.cu:484-714): three more launches behind the gather that return at once in the steady state
+  static const int rerun_env = getenv("MI355_FUSED_OVERFLOW_RERUN") ? atoi(getenv("MI355_FUSED_OVERFLOW_RERUN")) : 0;
+  static int g_epoch = 0;
+  const bool rerun = pathc && rerun_env != 0;
+  int epoch = 0;
   if (pathc) {
     a.tile_bags = (int32_t*)((uint8_t*)backward_workspace + al256(4 * (n + 1)) + al256(4 * n));   // head of the grouping workspace
     a.occ_trank = a.d_tid;   // (the deferred-key arrays belong to path (b))
+    a.rerun_mark = total + 16;   // cleared by the probe kernel on every step: the lazy materialisation reads it
+    if (rerun) {
+      epoch = (int)(__sync_add_and_fetch(&g_epoch, 1) & 0x3fffffff) + 1;
+      a.ovf_word = 6; a.ovf_val = epoch;
+    }
   }
   // ---- eval / inference forward of one table with pooled output: ONE kernel (every lane probes its own keys; no dedup, no
   //      unique numbering, no address array).  MI355_EVAL_FUSED=0 keeps the probe + gather pair.
@@ -2423,6 +2446,27 @@ int mi355_demb_forward_fused(
 #undef LAUNCH_PG
     }
     MI355_LAUNCH_CHECK();
+    if (rerun) {
+      // the chain of the per-slot-counter path over the same buffers, gated on this call's epoch: probe (keys already inserted are
+      // found; Assign / timer scores are idempotent, counting ones see the step twice), numbering, CSR scatter (eager reverse
+      // indices); the pooled output above is complete either way
+      FusedArgs b = a;
+      b.P = 0; b.spp = 1; b.rec = nullptr; b.rec_out = nullptr; b.rec_out4 = nullptr; b.tile_bags = nullptr; b.occ_trank = nullptr;
+      b.mt = 0; b.ptab = nullptr; b.rerun_mark = nullptr;
+      b.gate = a.hdr + 6; b.gate_val = epoch;
+      hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, b);
+      static int ncu_r = 0;
+      if (!ncu_r) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu_r = prop.multiProcessorCount;
+        if (ncu_r <= 0) ncu_r = 64;
+      }
+      hipLaunchKernelGGL(fused_mid_kernel<true>, dim3((unsigned)ceil_div(n, kScanTile)), dim3(kScanThreads), 0, stream, b, o, bptr, hot, true, ncu_r);
+      MI355_LAUNCH_CHECK();
+      STEP(mi355i_csr_from_slots(csr_rank, b.occ_slot, b.occ + 1, reverse_indices, n, combiner >= 0 ? offsets : nullptr, num_bags,
+                                 bptr, bcsr, hot_ws, hot_bytes_, emb_dim, a.hdr, nullptr, stream, b.gate, epoch, a.rerun_mark));
+    }
     const int64_t* nu_dev = unique_offsets + num_tables;
     if (pin) STEP(mi355_table_update_counter(counter, counter_numel, slots, n, nu_dev, 1, table_ids, table_bucket_offsets,
                                              bucket_capacity, stream));
@@ -2513,13 +2557,15 @@ int mi355_demb_fused_materialize(void* workspace, int64_t workspace_bytes, int64
   w += al256(8 * (num_tables + 1)) + al256(8 * n);
   int64_t* occ_addr = (int64_t*)w; w += al256(8 * n);
   const int32_t* occ_slot = (const int32_t*)w; w += al256(4 * n);
-  w += al256(4 * nt) + 256 + al256(8 * n);
+  w += al256(4 * nt);
+  const int* rerun_mark = (const int*)w + 16;     // (the forward's `total` block: [8] occurrences, [16] the re-run mark)
+  w += 256 + al256(8 * n);
   const int32_t* occ_trank = (const int32_t*)w; w += 4 * al256(4 * n);
   w += al256(16 * (nt > 258 ? nt : 258));
   w += al256(16 * (int64_t)P * kPartCap);
   const int4* rec_out4 = (const int4*)w;
   hipLaunchKernelGGL(occ_from_records_kernel, dim3((unsigned)grid_for(n, 256, 4096)), dim3(256), 0, stream, occ_slot, occ_trank, rec_out4,
-                     row_addr, n, reverse_indices, csr_rank, occ_addr);
+                     row_addr, n, reverse_indices, csr_rank, occ_addr, rerun_mark);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }

@@ -566,12 +566,15 @@ __global__ void __launch_bounds__(256)
 csr_scatter_kernel(const int64_t* __restrict__ rev, int* __restrict__ rank, int64_t n, const int64_t* __restrict__ offsets,
                    int64_t num_bags, const int* __restrict__ ptr, int* __restrict__ csr_src, HotList hot, bool build_hot,
                    const int* __restrict__ slot, const int* __restrict__ uidmap, int64_t* __restrict__ rev_out,
-                   int* __restrict__ hdr_reset = nullptr, PartRefs pr = PartRefs{}) {
+                   int* __restrict__ hdr_reset = nullptr, PartRefs pr = PartRefs{}, const int* __restrict__ gate = nullptr,
+                   int gate_val = 0, int* __restrict__ mark = nullptr) {
   constexpr bool kSlot = kMode == 1;
+  if (gate && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gate_val) return;   // (grid uniform)
+  if (mark && blockIdx.x == 0 && threadIdx.x == 0) *mark = 1;
   SST(0);
   // fused forward: the deferred-key count, barrier words and release flag of the table's aux header are cleared for the
   // next step here, behind the numbering kernel that read them
-  if (hdr_reset && blockIdx.x == 0 && threadIdx.x < 64 && threadIdx.x != 5) hdr_reset[threadIdx.x] = 0;   // ([5]: sticky error flag)
+  if (hdr_reset && blockIdx.x == 0 && threadIdx.x < 64 && threadIdx.x != 5 && threadIdx.x != 6) hdr_reset[threadIdx.x] = 0;   // ([5]: sticky error flag, [6]: epoch of the last overflow under MI355_FUSED_OVERFLOW_RERUN)
   if (build_hot) {
     int nh = *hot.n_hot;
     nh = nh < hot.max_hot ? nh : hot.max_hot;
@@ -700,7 +703,7 @@ csr_scatter_kernel(const int64_t* __restrict__ rev, int* __restrict__ rank, int6
 __global__ void __launch_bounds__(256)
 rev_from_slots_kernel(const int* __restrict__ slot, const int* __restrict__ uidmap, int64_t n, int64_t* __restrict__ rev,
                       int* __restrict__ hdr_reset = nullptr) {
-  if (hdr_reset && blockIdx.x == 0 && threadIdx.x < 64 && threadIdx.x != 5) hdr_reset[threadIdx.x] = 0;   // ([5]: sticky error flag)
+  if (hdr_reset && blockIdx.x == 0 && threadIdx.x < 64 && threadIdx.x != 5 && threadIdx.x != 6) hdr_reset[threadIdx.x] = 0;   // ([5]: sticky error flag, [6]: epoch of the last overflow under MI355_FUSED_OVERFLOW_RERUN)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) rev[i] = uidmap[2 * (int64_t)slot[i]];
 }
 
@@ -708,7 +711,7 @@ rev_from_slots_kernel(const int* __restrict__ slot, const int* __restrict__ uidm
 __global__ void __launch_bounds__(256)
 rev_from_records_kernel(const int* __restrict__ slot, PartRefs pr, int* __restrict__ rank, int64_t n, int64_t* __restrict__ rev,
                         int* __restrict__ hdr_reset) {
-  if (hdr_reset && blockIdx.x == 0 && threadIdx.x < 64 && threadIdx.x != 5) hdr_reset[threadIdx.x] = 0;   // ([5]: sticky error flag)
+  if (hdr_reset && blockIdx.x == 0 && threadIdx.x < 64 && threadIdx.x != 5 && threadIdx.x != 6) hdr_reset[threadIdx.x] = 0;   // ([5]: sticky error flag, [6]: epoch of the last overflow under MI355_FUSED_OVERFLOW_RERUN)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int rc = slot[i];
     if (rc < 0) { rev[i] = -1; continue; }     // (no record: its list overflowed, the step reports no uniques)
@@ -1392,7 +1395,7 @@ int mi355_group_by_unique_csr(const int32_t* csr_cnt, const int32_t* csr_rank, c
 int mi355i_csr_from_slots(const int32_t* csr_rank, const int32_t* occ_slot, const int32_t* uidmap, int64_t* reverse_indices,
                           int64_t n, const int64_t* offsets, int64_t num_bags, int32_t* ptr, int32_t* csr_src,
                           void* hot_workspace, int64_t hot_workspace_bytes, int64_t dim, int32_t* hdr_reset,
-                          const PartRefs* part, hipStream_t stream) {
+                          const PartRefs* part, hipStream_t stream, const int* gate, int gate_val, int* mark) {
   MI355_CHECK_ARG(n < 0x7fffffffLL, "n must be < 2^31");
   if (n == 0) return MI355_OK;
   HotList hot{};
@@ -1408,7 +1411,7 @@ int mi355i_csr_from_slots(const int32_t* csr_rank, const int32_t* occ_slot, cons
     else
       hipLaunchKernelGGL(csr_scatter_kernel<1>, dim3((unsigned)ceil_div(n, kHistTile)), dim3(256), 0, stream, (const int64_t*)nullptr,
                          const_cast<int32_t*>(csr_rank), n, offsets, num_bags, ptr, csr_src, hot, hot_workspace != nullptr, occ_slot,
-                         uidmap, reverse_indices, hdr_reset);
+                         uidmap, reverse_indices, hdr_reset, PartRefs{}, gate, gate_val, mark);
   } else if (part && part->rec_out) {
     hipLaunchKernelGGL(rev_from_records_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, occ_slot, *part,
                        const_cast<int32_t*>(csr_rank), n, reverse_indices, hdr_reset);

@@ -59,7 +59,9 @@ struct PartRefs {
 int mi355i_csr_from_slots(const int32_t* csr_rank, const int32_t* occ_slot, const int32_t* uidmap, int64_t* reverse_indices,
                           int64_t n, const int64_t* offsets, int64_t num_bags, int32_t* ptr, int32_t* csr_src,
                           void* hot_workspace, int64_t hot_workspace_bytes, int64_t dim, int32_t* hdr_reset,
-                          const PartRefs* part, hipStream_t stream);
+                          const PartRefs* part, hipStream_t stream, const int* gate = nullptr, int gate_val = 0, int* mark = nullptr);
+// (gate / gate_val / mark: the opt-in overflow re-run of the fused forward -- the kernel returns at once unless *gate == gate_val
+//  and sets *mark = 1 when it runs)
 
 // mi355_backward_fused with the tile lists that CSR reference entries (< 0: source id = tile_bags[~entry]) point into
 int mi355i_backward_fused(const int32_t* ptr, const int32_t* csr_src, int64_t num_keys, int64_t max_unique,

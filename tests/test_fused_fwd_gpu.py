@@ -563,6 +563,79 @@ np.save(sys.argv[3], out.detach().cpu().numpy()); np.save(sys.argv[4], rows.cpu(
     assert int(a._fused_aux[5]) == 0 and bool(torch.isfinite(out2).all())
 
 
+def test_overflowed_partition_is_rerun_inside_the_call_when_asked(monkeypatch, tmp_path):
+    """MI355_FUSED_OVERFLOW_RERUN=1 (opt-in; the reference never skips an update, unique_op.cu:484-714): a batch whose (tile, key)
+    records flood ONE slot range -- 4 000 distinct keys of partition 0 drawn 80 000 times: ~64 K records for a list of 2 048, but
+    no bucket overfull, so nothing depends on eviction order -- is re-run on the per-slot-counter path inside the same C call:
+    the three gated launches behind the gather find the epoch in aux[6] and redo the numbering and the CSR.  Compared with a process
+    that runs the per-slot-counter path throughout (MI355_FUSED_PART=0): same outputs of the flooded step and of the steps around
+    it, same rows after their backwards, same table size; no sticky flag, nothing raised."""
+    import os
+    import subprocess
+    import sys
+
+    cap, C, n = 1 << 20, 128, 80_000
+    a = _mk(True, (16,), cap=cap, pooling="SUM", learning_rate=0.5, strategy="TIMESTAMP", opt="SGD", monkeypatch=monkeypatch)
+    P = _partitions(a, n)
+    assert P > 0
+    S = a.table.capacity_
+    spp = -(-((S + 1 + P - 1) // P) // C) * C
+    cand = np.arange(1 << 30, (1 << 30) + 6 * 4000 * P, dtype=np.int64)
+    h = _fmix64(cand) & np.uint64(0x7FFFFFFFFFFFFFFF)
+    bucket = (h % np.uint64(S)) // np.uint64(C)
+    pool = cand[(bucket * np.uint64(C)) // np.uint64(spp) == 0][:4000]
+    assert pool.size == 4000
+    rng = np.random.default_rng(3)
+    flood = pool[rng.integers(0, 4000, n)]
+    lens = rng.integers(1, 9, size=n // 4)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    keys = (rng.zipf(1.2, int(off[-1])) % 200_000).astype(np.int64)
+    d = str(tmp_path)
+    np.save(d + "/k.npy", keys); np.save(d + "/o.npy", off); np.save(d + "/f.npy", flood)
+    code = f"""
+import sys, numpy as np, torch
+sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r}); sys.path.insert(0, {os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'recsys-examples_amd')!r})
+from test_fused_fwd_gpu import _mk
+class MP:
+    def setenv(self, k, v):
+        import os; os.environ[k] = v
+d, tag = sys.argv[1], sys.argv[2]
+m = _mk(True, (16,), cap={cap}, pooling="SUM", learning_rate=0.5, strategy="TIMESTAMP", opt="SGD", monkeypatch=MP())
+keys = torch.from_numpy(np.load(d + "/k.npy")).cuda(); off = torch.from_numpy(np.load(d + "/o.npy")).cuda()
+fk = torch.from_numpy(np.load(d + "/f.npy")).cuda(); foff = torch.arange(fk.numel() + 1, dtype=torch.int64, device="cuda")
+m.train()
+outs = []
+lazy = []
+for kk, oo in ((keys, off), (fk, foff), (keys, off)):
+    out, st = m._forward_impl(kk, oo, train=True)
+    lazy.append(bool(getattr(st, "lazy", False)))
+    nu = int(st.uoff[-1])
+    rev = st.rev
+    assert int(rev.min()) >= 0 and int(rev.max()) < nu
+    m._backward_impl(st, torch.ones_like(out))
+    outs.append(out.float().cpu().numpy()); outs.append(np.array([nu]))
+    m._check_partition_flag()
+probe = torch.unique(torch.cat([fk, keys]))
+f, rows = m.lookup_rows(probe, 0)
+torch.cuda.synchronize()
+np.savez(d + "/res_" + tag + ".npz", *outs, found=f.cpu().numpy(), rows=rows.cpu().numpy(), size=int(m.size()), aux5=int(m._fused_aux[5]),
+         aux6=int(m._fused_aux[6]), lazy=np.array(lazy))
+"""
+    res = {}
+    for tag, env in (("rerun", dict(MI355_FUSED_OVERFLOW_RERUN="1")), ("counters", dict(MI355_FUSED_PART="0"))):
+        r = subprocess.run([sys.executable, "-c", code, d, tag], env=dict(os.environ, MI355_FUSED="1", **env), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        res[tag] = np.load(d + "/res_" + tag + ".npz")
+    A, B = res["rerun"], res["counters"]
+    assert A["lazy"].tolist() == [True, True, True] and B["lazy"].tolist() == [False, False, False]
+    assert int(A["aux5"]) == 0 and int(A["aux6"]) != 0, "no overflow was seen (or it left the sticky flag)"
+    for i in range(6):
+        np.testing.assert_allclose(A[f"arr_{i}"], B[f"arr_{i}"], rtol=1e-5, atol=1e-5, err_msg=f"output / unique count {i}")
+    assert int(A["size"]) == int(B["size"]) and bool(A["found"].all()) and bool(B["found"].all())
+    np.testing.assert_allclose(A["rows"], B["rows"], rtol=1e-4, atol=1e-5)
+
+
 def _counters_clear_except_flag(m):
     torch.cuda.synchronize()
     aux = m._fused_aux.clone()
