@@ -416,6 +416,33 @@ int mi355_demb_forward_fused(void* storage, const int64_t* table_bucket_offsets,
                              void* backward_workspace, int64_t backward_workspace_bytes, int use_side_stream,
                              int* join_token, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
+/* Round 5: the pre-bound training step.  Replaces, for the steady-state training step, the per-call argument marshalling of
+ * DynamicEmbeddingFunction.forward / backward (batched_dynamicemb_function.py:1042-1300), which re-reads the constructor state of
+ * BatchedDynamicEmbeddingTablesV2 (batched_dynamicemb_tables.py:462-787, 999-1088) on every step: a plan holds the table, value
+ * buffers, policies, initializer and optimizer of ONE module; a step is then plan_forward(batch, out, step buffer) +
+ * plan_backward(step buffer, grads).  The step buffer holds the persisted arrays of mi355_demb_forward_fused and both
+ * workspaces; mi355_demb_step_layout is the only definition of its layout (13 int64: ten offsets -- rev, tids, slots, row_addr,
+ * freq, csr_cnt, csr_rank, unique_offsets, forward workspace, backward workspace --, total bytes, the two workspace sizes).
+ * plan_forward returns 1 (nothing launched) when the buffer is smaller than mi355_demb_plan_step_bytes(num_keys). */
+void* mi355_demb_plan_create(void* storage, const int64_t* table_bucket_offsets, int64_t bucket_capacity, int64_t num_scores,
+                             int32_t* bucket_sizes, int32_t* counter, int64_t counter_numel, int32_t* aux, int64_t aux_numel,
+                             int64_t num_buckets, const int64_t* table_ptrs, const int64_t* table_value_dims,
+                             const int64_t* table_emb_dims, int value_dtype, int64_t emb_dim, int64_t value_dim,
+                             const int64_t* feature_offsets, int64_t num_tables, int find_policy, int insert_policy,
+                             int use_count, int pin, int init_mode, float p0, float p1, float p2, float p3, uint64_t seed,
+                             float state_init, int combiner, const int32_t* D_offsets, int64_t total_D, int out_dtype,
+                             int aligned16, int opt_kind, float beta1, float beta2, float eps, float weight_decay);
+void mi355_demb_plan_destroy(void* plan);
+void mi355_demb_step_layout(int64_t num_keys, int64_t num_tables, int64_t dim, int train, int64_t* out13);
+int64_t mi355_demb_plan_step_bytes(void* plan, int64_t num_keys);
+int mi355_demb_plan_forward(void* plan, const void* keys, int64_t num_keys, const int64_t* offsets, int64_t num_bags,
+                            int64_t batch_size, uint64_t score_value, uint64_t timer_override, void* out, void* step_buf,
+                            int64_t step_bytes, int* state, hipStream_t stream);
+int mi355_demb_plan_backward(void* plan, void* step_buf, int64_t step_bytes, int64_t num_keys, const int64_t* offsets,
+                             int64_t num_bags, int64_t batch_size, const void* grads, int64_t grad_stride, int grad_dtype,
+                             int grad_aligned16, float lr, float beta1, float beta2, float eps, float weight_decay,
+                             int64_t iter_num, int prepared, hipStream_t stream);
+
 /* hipStream_t of the library's side stream (early CSR build of mi355_demb_forward); NULL if it cannot be created */
 void* mi355_early_csr_stream(void);
 

@@ -697,6 +697,10 @@ __global__ void __launch_bounds__(THREADS) fused_probe_kernel(FusedArgs a) {
   PST(11);
 }
 
+}  // namespace mi355
+#include "probe_c.h"
+namespace mi355 {
+
 // ---- deferred keys: bucket without a free slot -> evict the minimum score (kernels.cuh:226-287, types.cuh:398-512) ----
 // Barrier across a grid whose blocks are all resident.  Two levels -- 16 blocks share a counter, the last arrival of a group
 // bumps the top counter, the last group publishes the generation -- because same-address device atomics serialise at
@@ -1515,8 +1519,8 @@ __device__ __forceinline__ int p2_insert(int* h_slot, int slot, bool* claimed) {
 
 // exclusive scan of five ints per thread across a THREADS-thread block; totals in `tot`.  Two levels: every wave scans its own
 // values, ONE wave scans the wave totals (a thread reading all 16 totals of five values itself was 80 LDS reads per thread).
-template <int THREADS>
-__device__ __forceinline__ void block_scan5(int (&v)[5], int (&tot)[5]) {
+template <int THREADS, typename Publish>
+__device__ __forceinline__ void block_scan5(int (&v)[5], int (&tot)[5], Publish publish) {
   constexpr int NW = THREADS / 64;
   __shared__ int s_w5[5][NW + 1];      // [i][w]: exclusive base of wave w; [i][NW]: total
   const int w = threadIdx.x >> 6;
@@ -1529,13 +1533,18 @@ __device__ __forceinline__ void block_scan5(int (&v)[5], int (&tot)[5]) {
   }
   __syncthreads();
   if (w == 0) {
+    int t5[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const int x = lane_id() < NW ? s_w5[i][lane_id()] : 0;
       const int in2 = wave_incl_scan(x);
       if (lane_id() < NW) s_w5[i][lane_id()] = in2 - x;
       if (lane_id() == NW - 1) s_w5[i][NW] = in2;
+      t5[i] = in2;
     }
+    // round 5: the lane that holds the block totals hands them on at once (the partition kernel publishes its look-back words
+    // from here, one barrier and an LDS read-back earlier than from behind the scan)
+    if (lane_id() == NW - 1) publish(t5);
   }
   __syncthreads();
 #pragma unroll
@@ -1557,13 +1566,11 @@ __device__ __forceinline__ void lookback_sum2_1024(const unsigned long long* ta,
   while ((va & kStatMask) == 0) { __builtin_amdgcn_s_sleep(1); va = stat_load(ta + idx); }
   while ((vb & kStatMask) == 0) { __builtin_amdgcn_s_sleep(1); vb = stat_load(tb + idx); }
   unsigned long long xa = va & ~kStatMask, xb = vb & ~kStatMask;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    uint32_t lo = __shfl_xor((int)(uint32_t)xa, off, 64), hi = __shfl_xor((int)(uint32_t)(xa >> 32), off, 64);
-    xa += ((unsigned long long)hi << 32) | lo;
-    lo = __shfl_xor((int)(uint32_t)xb, off, 64); hi = __shfl_xor((int)(uint32_t)(xb >> 32), off, 64);
-    xb += ((unsigned long long)hi << 32) | lo;
-  }
+  // the five packed fields are summed over the wave on the DPP path (each stays below 2^31 over all partitions)
+  const int f0 = wave_sum((int)(xa & 0x7fffffffull)), f1 = wave_sum((int)(xa >> 31));
+  const int f2 = wave_sum((int)(xb >> 40)), f3 = wave_sum((int)((xb >> 20) & 0xfffff)), f4 = wave_sum((int)(xb & 0xfffff));
+  xa = ((unsigned long long)(unsigned)f1 << 31) + (unsigned long long)(unsigned)f0;
+  xb = ((unsigned long long)(unsigned)f2 << 40) + ((unsigned long long)(unsigned)f3 << 20) + (unsigned long long)(unsigned)f4;
   if (lane_id() == 0) { if (xa) atomicAdd(&s_sa, xa); if (xb) atomicAdd(&s_sb, xb); }
   __syncthreads();
   pre_a = s_sa; pre_b = s_sb;
@@ -1800,13 +1807,14 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
     if (hots && ec[k] > hot.khot && ec[k] <= hot.kwave) ++v5[4];
     else if (hots && ec[k] > hot.khot) { ++v5[2]; v5[3] += (ec[k] + hot.kchunk - 1) / hot.kchunk; }
   }
-  block_scan5<kP3Threads>(v5, tot5);
-  const int nu = tot5[0], tot2 = tot5[1], th = tot5[2], tt = tot5[3], tw = tot5[4];
   unsigned long long* tb = a.tstat + a.P;
-  if (threadIdx.x == 0) {   // the partition's sums go out as early as they are known: the successors' look-back waits for them
-    stat_store(a.tstat + p, kStatAgg | ((unsigned long long)nu << 31) | (unsigned)tot2);
-    stat_store(tb + p, kStatAgg | ((unsigned long long)th << 40) | ((unsigned long long)tt << 20) | (unsigned long long)tw);
-  }
+  // the partition's sums go out as early as they are known -- from inside the scan, by the lane that computes the block totals:
+  // the successors' look-back waits for them
+  block_scan5<kP3Threads>(v5, tot5, [&](const int (&t5)[5]) {
+    stat_store(a.tstat + p, kStatAgg | ((unsigned long long)t5[0] << 31) | (unsigned)t5[1]);
+    stat_store(tb + p, kStatAgg | ((unsigned long long)t5[2] << 40) | ((unsigned long long)t5[3] << 20) | (unsigned long long)t5[4]);
+  });
+  const int nu = tot5[0], tot2 = tot5[1], th = tot5[2], tt = tot5[3], tw = tot5[4];
   {
     int lid = v5[0], pre = v5[1];
 #pragma unroll
@@ -2377,8 +2385,39 @@ int mi355_demb_forward_fused(
     else hipLaunchKernelGGL((fused_probe_kernel<TILE, THREADS, false>), dim3(grid), dim3(THREADS), 0, stream, a);         \
   } while (0)
     if (part) {
-      const char* fm = getenv("MI355_FUSED_FASTMOD");   // (read per call: A/B inside one process; default on with path (c))
-      const bool fast = (fm ? atoi(fm) != 0 : pathc) && (a.t.C & (a.t.C - 1)) == 0 && (a.S >> __builtin_ctzll((unsigned long long)a.t.C)) < (1ll << 31);
+      // (MI355_ENV_LIVE=1 -- the test suite, the A/B tools -- re-reads these two knobs on every call: A/B inside one process;
+      //  otherwise they are read once: getenv walks the whole environment, twice per step adds up on the host)
+      static const bool env_live = getenv("MI355_ENV_LIVE") != nullptr;
+      static int fm_c = -1, pc_c = 1;
+      static bool env_have = false;
+      if (env_live || !env_have) {
+        const char* e1 = getenv("MI355_FUSED_FASTMOD");
+        const char* e2 = getenv("MI355_PROBE_C");
+        fm_c = e1 ? (atoi(e1) != 0) : -1;
+        pc_c = e2 ? atoi(e2) : 1;
+        env_have = true;
+      }
+      const bool fast = (fm_c >= 0 ? fm_c != 0 : pathc) && (a.t.C & (a.t.C - 1)) == 0 && (a.S >> __builtin_ctzll((unsigned long long)a.t.C)) < (1ll << 31);
+      // round 5: the rebuilt probe kernel of path (c) (probe_c.h) -- MI355_PROBE_C: 0 the kernel above, 1 (default) 1024-key tiles
+      // of 1024 threads at two blocks per CU, 2: 1024 / 512, 3: 2048 / 1024, 4: 512 / 512 (read per call: A/B inside one process)
+      const int pcv = pc_c;
+      if (pathc && fast && pcv > 0) {
+#define LAUNCH_PC(TILE, THREADS, WPS)                                                                                                   \
+  do {                                                                                                                                   \
+    const dim3 grid((unsigned)ceil_div(n, TILE)), blk(THREADS);                                                                          \
+    if (a.mt && seq) hipLaunchKernelGGL((probe_c_kernel<TILE, THREADS, WPS, true, true>), grid, blk, 0, stream, a);                     \
+    else if (a.mt) hipLaunchKernelGGL((probe_c_kernel<TILE, THREADS, WPS, true, false>), grid, blk, 0, stream, a);                      \
+    else if (seq) hipLaunchKernelGGL((probe_c_kernel<TILE, THREADS, WPS, false, true>), grid, blk, 0, stream, a);                       \
+    else hipLaunchKernelGGL((probe_c_kernel<TILE, THREADS, WPS, false, false>), grid, blk, 0, stream, a);                               \
+  } while (0)
+        switch (pcv) {
+          case 2: LAUNCH_PC(1024, 512, 6); break;
+          case 3: LAUNCH_PC(2048, 1024, 4); break;
+          case 4: LAUNCH_PC(512, 512, 8); break;
+          default: LAUNCH_PC(1024, 1024, 8); break;
+        }
+#undef LAUNCH_PC
+      } else
       if (pathc) {
 #define LAUNCH_C(FAST, MT, SEQ) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, FAST, true, MT, SEQ>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a)
         const int v = (fast ? 4 : 0) | (a.mt ? 2 : 0) | (seq ? 1 : 0);

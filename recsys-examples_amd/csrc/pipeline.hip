@@ -201,4 +201,107 @@ int mi355_demb_backward(
   return rc;
 }
 
+
+// ---- round 5: the pre-bound training step -------------------------------------------------------------------------------------
+// A module's fused forward takes ~60 arguments of which a handful change from step to step; marshalling them through ctypes on
+// every call (plus the Python that gathers them) was a third of the host time of a step driven through module.forward() +
+// autograd (bench.py step_via_autograd_ms 0.179 vs 0.128 on the driver's box).  A plan holds everything that is constant for a
+// module (table, value buffers, policies, initializer, optimizer); the per-step calls take the batch, the output and ONE step
+// buffer whose layout (the persisted arrays of the step + both workspaces) is computed here -- mi355_demb_step_layout is the
+// single source of it.  Reference counterpart: the constructor state of BatchedDynamicEmbeddingTablesV2
+// (batched_dynamicemb_tables.py:462-787) that DynamicEmbeddingFunction.forward / backward read on every step (:999-1088).
+struct DembPlan {
+  void* storage; const int64_t* tbo; int64_t C, ns; int32_t* bucket_sizes; int32_t* counter; int64_t counter_numel;
+  int32_t* aux; int64_t aux_numel, num_buckets;
+  const int64_t* table_ptrs; const int64_t* table_value_dims; const int64_t* table_emb_dims; int value_dtype; int64_t emb_dim, value_dim;
+  const int64_t* feature_offsets; int64_t T;
+  int find_policy, insert_policy, use_count, pin;
+  int init_mode; float p0, p1, p2, p3; uint64_t seed; float state_init;
+  int combiner; const int32_t* D_offsets; int64_t total_D; int out_dtype, aligned16;
+  int opt_kind; float beta1, beta2, eps, weight_decay;
+};
+
+void* mi355_demb_plan_create(void* storage, const int64_t* table_bucket_offsets, int64_t bucket_capacity, int64_t num_scores,
+                             int32_t* bucket_sizes, int32_t* counter, int64_t counter_numel, int32_t* aux, int64_t aux_numel,
+                             int64_t num_buckets, const int64_t* table_ptrs, const int64_t* table_value_dims,
+                             const int64_t* table_emb_dims, int value_dtype, int64_t emb_dim, int64_t value_dim,
+                             const int64_t* feature_offsets, int64_t num_tables, int find_policy, int insert_policy, int use_count,
+                             int pin, int init_mode, float p0, float p1, float p2, float p3, uint64_t seed, float state_init,
+                             int combiner, const int32_t* D_offsets, int64_t total_D, int out_dtype, int aligned16, int opt_kind,
+                             float beta1, float beta2, float eps, float weight_decay) {
+  DembPlan* p = new DembPlan{storage, table_bucket_offsets, bucket_capacity, num_scores, bucket_sizes, counter, counter_numel,
+                             aux, aux_numel, num_buckets, table_ptrs, table_value_dims, table_emb_dims, value_dtype, emb_dim,
+                             value_dim, feature_offsets, num_tables, find_policy, insert_policy, use_count, pin, init_mode, p0,
+                             p1, p2, p3, seed, state_init, combiner, D_offsets, total_D, out_dtype, aligned16, opt_kind, beta1,
+                             beta2, eps, weight_decay};
+  return p;
+}
+void mi355_demb_plan_destroy(void* plan) { delete (DembPlan*)plan; }
+
+// Byte offsets of the arrays of one step buffer: out[0..9] = rev, tids, slots, row_addr, freq (8 n each), csr_cnt, csr_rank
+// (4 n each), unique_offsets (8 (T + 1)), forward workspace, backward workspace; out[10] = total bytes, out[11] / out[12] = the two
+// workspace sizes.  (dynamicemb/batched_dynamicemb_tables.py: _FusedStep reads its layout from here.)
+void mi355_demb_step_layout(int64_t num_keys, int64_t num_tables, int64_t dim, int train, int64_t* out) {
+  const int64_t n1 = num_keys > 0 ? num_keys : 1;
+  int64_t off = 0;
+  for (int k = 0; k < 5; ++k) { out[k] = off; off += al(8 * n1); }
+  for (int k = 5; k < 7; ++k) { out[k] = off; off += al(4 * n1); }
+  out[7] = off; off += al(8 * (num_tables + 1));
+  const int64_t fwd_b = mi355_demb_forward_fused_workspace_bytes(num_keys, num_tables);
+  const int64_t bwd_b = train ? mi355_demb_backward_workspace_bytes(num_keys, dim) : 0;
+  out[8] = off; off += al(fwd_b);
+  out[9] = off; off += al(bwd_b);
+  out[10] = off; out[11] = fwd_b; out[12] = bwd_b;
+}
+int64_t mi355_demb_plan_step_bytes(void* plan, int64_t num_keys) {
+  const DembPlan* p = (const DembPlan*)plan;
+  int64_t lay[13];
+  mi355_demb_step_layout(num_keys, p->T, p->emb_dim, 1, lay);
+  return lay[10];
+}
+
+// Training forward of one batch through the plan.  Returns MI355_OK, an error, or MI355_ENOSPC (1) when `step_buf` is smaller
+// than mi355_demb_plan_step_bytes(num_keys) (nothing was launched).  *state (out): the join_token of mi355_demb_forward_fused
+// (-2: path (c), lazy reverse indices; -1: everything on `stream`).
+int mi355_demb_plan_forward(void* plan, const void* keys, int64_t num_keys, const int64_t* offsets, int64_t num_bags,
+                            int64_t batch_size, uint64_t score_value, uint64_t timer_override, void* out, void* step_buf,
+                            int64_t step_bytes, int* state, hipStream_t stream) {
+  const DembPlan* p = (const DembPlan*)plan;
+  MI355_CHECK_ARG(p && step_buf, "plan forward: null plan / step buffer");
+  int64_t lay[13];
+  mi355_demb_step_layout(num_keys, p->T, p->emb_dim, 1, lay);
+  if (step_bytes < lay[10]) return 1;
+  uint8_t* b = (uint8_t*)step_buf;
+  return mi355_demb_forward_fused(p->storage, p->tbo, p->C, p->ns, p->bucket_sizes, p->counter, p->counter_numel, p->aux,
+                                  p->aux_numel, p->num_buckets, p->table_ptrs, p->table_value_dims, p->table_emb_dims,
+                                  p->value_dtype, p->emb_dim, p->value_dim, keys, num_keys, offsets, num_bags, batch_size,
+                                  p->feature_offsets, p->T, 1, p->find_policy, p->insert_policy, score_value, p->use_count,
+                                  timer_override, p->pin, p->init_mode, p->p0, p->p1, p->p2, p->p3, p->seed, p->state_init,
+                                  p->combiner, p->D_offsets, p->total_D, out, p->out_dtype, p->aligned16, (int64_t*)(b + lay[0]),
+                                  (int64_t*)(b + lay[7]), (int64_t*)(b + lay[1]), (int64_t*)(b + lay[2]), (int64_t*)(b + lay[3]),
+                                  p->use_count ? (int64_t*)(b + lay[4]) : nullptr, (int32_t*)(b + lay[5]), (int32_t*)(b + lay[6]),
+                                  b + lay[9], lay[12], 0, state, b + lay[8], lay[11], stream);
+}
+
+// Backward of the step whose forward went through mi355_demb_plan_forward on the same buffer (prepared: 1 when that forward
+// left the CSR in the buffer -- any non-empty batch --, 0 to regroup here).  The optimizer's hyper-parameters travel with the
+// call (a learning-rate schedule must not rebuild the plan).
+int mi355_demb_plan_backward(void* plan, void* step_buf, int64_t step_bytes, int64_t num_keys, const int64_t* offsets,
+                             int64_t num_bags, int64_t batch_size, const void* grads, int64_t grad_stride, int grad_dtype,
+                             int grad_aligned16, float lr, float beta1, float beta2, float eps, float weight_decay,
+                             int64_t iter_num, int prepared, hipStream_t stream) {
+  const DembPlan* p = (const DembPlan*)plan;
+  MI355_CHECK_ARG(p && step_buf, "plan backward: null plan / step buffer");
+  int64_t lay[13];
+  mi355_demb_step_layout(num_keys, p->T, p->emb_dim, 1, lay);
+  MI355_CHECK_ARG(step_bytes >= lay[10], "plan backward: step buffer too small");
+  uint8_t* b = (uint8_t*)step_buf;
+  return mi355_demb_backward((const int64_t*)(b + lay[0]), num_keys, (const int64_t*)(b + lay[7]), p->T, offsets, num_bags,
+                             batch_size, grads, grad_stride, grad_dtype, p->D_offsets, p->emb_dim, p->combiner,
+                             (const int64_t*)(b + lay[3]), p->value_dtype, p->opt_kind, lr, beta1, beta2, eps,
+                             weight_decay, iter_num, -1, 1, p->aligned16 && grad_aligned16, p->counter, p->counter_numel,
+                             (const int64_t*)(b + lay[2]), (const int64_t*)(b + lay[1]), p->tbo, p->C, p->pin,
+                             (const int32_t*)(b + lay[5]), (const int32_t*)(b + lay[6]), prepared, b + lay[9], lay[12], stream);
+}
+
 }  // extern "C"

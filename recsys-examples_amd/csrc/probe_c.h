@@ -1,0 +1,415 @@
+// Round 5: the probe kernel of path (c) (fused_fwd.hip), rebuilt around its LATENCY.  Included by fused_fwd.hip behind
+// fused_probe_kernel, whose <kTrain, kPart, kFast, kBags> instantiation it replaces (same inputs, same records / tile lists /
+// per-occurrence arrays; MI355_PROBE_C=0 brings the old kernel back).
+//
+// Restates (reference, corelib/dynamicemb/): segmented_unique_cuda (src/unique_op.cu:484-714), table_lookup_kernel /
+// table_insert_kernel (src/table_operation/kernels.cuh:81-585).
+//
+// What profiles/r03_index_phase_stamps.txt and r05_index_phase_stamps_before.txt show for the old kernel: 176 blocks of 1024
+// threads on 256 CUs (83 KB of LDS and 83 VGPRs: ONE block per CU, 31 % of the CUs idle), a block life of 21 us made of eleven
+// barrier-separated phases, of which
+//   * the first is the 64-ary search of the tile's bag range by waves 0 / 1 -- three dependent loads -- with the other fourteen
+//     waves waiting at the barrier behind it (14 %);
+//   * the probe phase runs a dependent re-probe (digest vector again, then key words one by one) for every key whose first
+//     candidate slot was a digest false positive -- 6 % of the keys, i.e. nearly every wave (18 %);
+//   * the LDS dedup serialises two keys per thread through four dependent LDS operations each (10 %).
+// Here:
+//   * tiles of 1024 keys, ONE key per thread, <= 64 VGPRs and ~37 KB of LDS: 352 blocks, all resident at two per CU, so one
+//     block's barrier waits and round trips run under the other's work;
+//   * the bag search is software-pipelined through the first three phases (round k + 1 is issued when round k is consumed, the
+//     work of the phase in between), so nobody waits for it;
+//   * the key words of the FIRST TWO digest matches are fetched together, before the barrier in front of the probe phase; the
+//     dependent re-probe is left to the ~0.1 % of keys with two false positives in front of them (and to misses);
+//   * six barriers instead of eleven; the dedup hash comes out of the table hash (no second fmix64); the representative of a key
+//     is whichever occurrence claimed the LDS entry (no atomicMin); rows inserted by the block are initialised by the wave that
+//     inserted them, straight from registers.
+#pragma once
+
+namespace mi355 {
+
+template <int TILE, int THREADS, int WPS, bool kMT, bool kSeq>
+__global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
+  constexpr int PER = TILE / THREADS;
+  constexpr int HASH = 2 * TILE;
+  constexpr int NW = THREADS / 64;
+  constexpr int NPB = (kPartMax + THREADS - 1) / THREADS;   // partitions a thread reserves for
+  static_assert(TILE % THREADS == 0 && (TILE & (TILE - 1)) == 0 && TILE <= 4096 && THREADS >= 128, "tile shape");
+  __shared__ uint64_t s_key[TILE];
+  __shared__ int s_tab[HASH];          // dedup: tile position of the key's representative; after the probe: (partition << 12) | position
+  __shared__ int s_cnt[HASH];          // dedup: occurrences inside the tile; after the probe: slot code of the key's record
+  __shared__ uint16_t s_sm[HASH];      // per dedup entry: start of the key's list in the tile | multi flag << 15
+  __shared__ int s_bag[kSeq ? 1 : TILE];
+  __shared__ int s_hist[kPartMax];     // records of this tile per partition, then their base in the partition's list
+  __shared__ int s_brange[2], s_wmax[NW], s_wsum[NW];
+  __shared__ uint16_t s_t[kMT ? TILE : 1];
+  __shared__ int64_t s_seg[kMT ? kFusedMaxT + 1 : 1], s_tbo[kMT ? kFusedMaxT + 1 : 1], s_tptr[kMT ? kFusedMaxT : 1];
+  __shared__ int s_rowb[kMT ? kFusedMaxT : 1];
+  __shared__ uint64_t s_magic[kMT ? kFusedMaxT : 1];
+  __shared__ int s_pt[kMT ? kFusedMaxT : 1], s_pb[kMT ? kFusedMaxT + 1 : 1];
+  __shared__ uint64_t s_psc[kMT ? kFusedMaxT : 1];
+  PST(0);
+  const int T = a.T;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t tile0 = (int64_t)blockIdx.x * TILE;
+  if (!a.timer) a.timer = device_clock();
+  // ---- phase 0: everything that depends on nothing goes out first
+  uint64_t kreg[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int64_t i = tile0 + q * THREADS + tid;
+    kreg[q] = a.keys[i < a.n ? i : a.n - 1];
+  }
+  int64_t m_tbo0 = 0, m_tbo1 = 0, m_tptr0 = 0;
+  int m_rowb0 = 0;
+  if constexpr (!kMT) { m_tbo0 = a.tbo[0]; m_tbo1 = a.tbo[1]; m_tptr0 = a.table_ptrs[0]; m_rowb0 = (int)a.table_value_dims[0] * a.elem_bytes; }
+  auto tbo_of = [&](int t) -> int64_t { if constexpr (!kMT) return t == 0 ? m_tbo0 : m_tbo1; else return s_tbo[t]; };
+  auto tptr_of = [&](int t) -> int64_t { if constexpr (!kMT) return m_tptr0; else return s_tptr[t]; };
+  auto rowb_of = [&](int t) -> int { if constexpr (!kMT) return m_rowb0; else return s_rowb[t]; };
+  // the tile's bag range: waves 0 / 1 find the bags of its first / last occurrence (first idx with offsets[idx] > position, minus
+  // one) by 64-ary rounds, one probe per lane.  A round is issued here and consumed a phase later.
+  const bool searcher = !kSeq && tid < 128;           // (wave uniform)
+  int slo = 0, shi = (int)a.num_bags, sstep = 1;
+  int64_t sval = 0;
+  bool sinf = false;
+  const int64_t tile_end = tile0 + TILE < a.n ? tile0 + TILE : a.n;
+  const int64_t skey = tid < 64 ? tile0 : tile_end - 1;
+  auto s_issue = [&]() {
+    sstep = (shi - slo + 63) >> 6;
+    const int64_t pi = (int64_t)slo + (int64_t)(lane + 1) * sstep - 1;
+    sinf = pi >= shi;
+    const int64_t pc = sinf ? (shi > 0 ? shi - 1 : 0) : pi;
+    sval = a.offsets[pc];
+  };
+  auto s_consume = [&]() {
+    if (shi > slo) {
+      const uint64_t gm = __ballot(sinf || sval > skey);
+      if (!gm) slo = shi;
+      else {
+        const int first = __ffsll((unsigned long long)gm) - 1;
+        const int64_t nhi = (int64_t)slo + (int64_t)(first + 1) * sstep - 1;
+        slo = slo + first * sstep;
+        shi = nhi < shi ? (int)nhi : shi;
+      }
+    }
+  };
+  if (searcher) s_issue();
+  if constexpr (kMT) {
+    for (int t = tid; t <= T; t += THREADS) {
+      s_seg[t] = a.offsets[a.feature_offsets[t] * a.batch];
+      s_tbo[t] = a.tbo[t];
+      if (t < T) {
+        s_tptr[t] = a.table_ptrs[t];
+        s_rowb[t] = (int)a.table_value_dims[t] * a.elem_bytes;
+        const uint64_t nb = (uint64_t)(a.tbo[t + 1] - a.tbo[t]);
+        s_magic[t] = nb ? ~0ull / nb : 0ull;
+      }
+    }
+  }
+  if (blockIdx.x == 0) {
+    if (a.hot_counters && tid < 3) a.hot_counters[2 * tid] = 0;   // n_hot, n_tasks, n_wave
+    if (a.rerun_mark && tid == 0) *a.rerun_mark = 0;
+  }
+  if (a.tstat) {   // the 2 P look-back words of the partition kernel
+    const int per = (2 * a.P + (int)gridDim.x - 1) / (int)gridDim.x;
+    for (int k = tid; k < per; k += THREADS) {
+      const int wd = (int)blockIdx.x * per + k;
+      if (wd < 2 * a.P) a.tstat[wd] = 0ull;
+    }
+  }
+  for (int s = tid; s < HASH; s += THREADS) { s_tab[s] = -1; s_cnt[s] = 0; }
+  for (int p = tid; p < a.P; p += THREADS) s_hist[p] = 0;
+  if constexpr (!kSeq) for (int k = tid; k < TILE; k += THREADS) s_bag[k] = -1;
+  if constexpr (kMT) __syncthreads();                 // the tables' metadata
+  if (searcher) { s_consume(); s_issue(); }           // round 1 -> round 2
+  PST(1);
+  if constexpr (kMT) {   // partitions per table: one each, the rest in proportion to the tables' keys in this batch
+    if (tid < T) {
+      const uint64_t nt_ = (uint64_t)(s_seg[tid + 1] - s_seg[tid]);
+      s_pt[tid] = 1 + (a.n > 0 ? (int)((uint64_t)(a.P - T) * nt_ / (uint64_t)a.n) : 0);
+    }
+  }
+  // ---- phase 1: hash, bucket (division-free: the bucket capacity is a power of two here), first digest vector of EVERY key
+  const int cshift = __builtin_ctzll((unsigned long long)a.t.C);
+  const int Cm = (int)a.t.C - 1;
+  int bq[PER], tq[PER];            // bucket (-1: key without a home), table
+  int64_t hq[PER];
+  uint4 dvq[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int li = q * THREADS + tid;
+    const int64_t i = tile0 + li;
+    int tt = 0;
+    if constexpr (kMT) {
+      int lo = 0, hi = T + 1;      // first t with seg[t] > i
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_seg[mid] <= i) lo = mid + 1; else hi = mid; }
+      tt = lo - 1 < 0 ? 0 : (lo - 1 >= T ? T - 1 : lo - 1);
+      s_t[li] = (uint16_t)tt;
+    }
+    tq[q] = tt;
+    const uint64_t key = kreg[q];
+    s_key[li] = key;
+    const int64_t hash = (int64_t)(fmix64(key) & 0x7FFFFFFFFFFFFFFFull);
+    const int64_t bb = tbo_of(tt);
+    const uint64_t nb = (uint64_t)(tbo_of(tt + 1) - bb);
+    const uint64_t x = (uint64_t)hash >> cshift;
+    uint64_t magic;
+    if constexpr (kMT) magic = s_magic[tt]; else magic = a.magic0;
+    uint64_t r = x - __umul64hi(x, magic) * nb;
+    if (r >= nb) r -= nb;
+    if (r >= nb) r -= nb;
+    const bool ok = i < a.n && is_valid(key) && nb > 0;
+    hq[q] = hash;
+    bq[q] = ok ? (int)(bb + (int64_t)r) : -1;
+    const int start = ((int)hash & Cm) & ~15;
+    dvq[q] = *reinterpret_cast<const uint4*>(a.t.dig(ok ? bq[q] : 0) + start);   // unconditional: bucket 0 for homeless keys
+  }
+  PST(2);
+  __syncthreads();   // A: s_key / s_t, the cleared hash
+  PST(3);
+  if (searcher) { s_consume(); s_issue(); }           // round 2 -> round 3
+  if constexpr (kMT) {
+    if (tid < 64) {      // (T <= 128: two tables per lane of wave 0)
+      const int l = tid;
+      const int v0 = l < T ? s_pt[l] : 0, v1 = l + 64 < T ? s_pt[l + 64] : 0;
+      const int i0 = wave_incl_scan(v0);
+      const int i1 = wave_incl_scan(v1) + __shfl(i0, 63, 64);
+      if (l < T) {
+        s_pb[l] = i0 - v0;
+        const uint64_t nb = (uint64_t)(s_tbo[l + 1] - s_tbo[l]);
+        s_psc[l] = nb ? ((uint64_t)v0 << 32) / nb : 0ull;
+      }
+      if (l + 64 < T) {
+        s_pb[l + 64] = i1 - v1;
+        const uint64_t nb = (uint64_t)(s_tbo[l + 65] - s_tbo[l + 64]);
+        s_psc[l + 64] = nb ? ((uint64_t)v1 << 32) / nb : 0ull;
+      }
+      if (l == 63) s_pb[T] = i1;
+    }
+  }
+  // ---- phase 2: LDS dedup.  The entry's hash comes out of the table hash (bits above the digest); whoever claims the entry
+  //      represents the key.
+  int hh[PER], rk[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int li = q * THREADS + tid;
+    hh[q] = -1;
+    rk[q] = 0;
+    if (tile0 + li < a.n) {
+      const uint64_t key = kreg[q];
+      int h = (int)((uint32_t)((uint64_t)hq[q] >> 40) + (kMT ? (uint32_t)tq[q] * 0x9E3779B1u : 0u)) & (HASH - 1);
+      while (true) {
+        const int cur = atomicCAS(&s_tab[h], -1, li);
+        if (cur == -1) break;
+        bool same = s_key[cur] == key;
+        if constexpr (kMT) same = same && s_t[cur] == (uint16_t)tq[q];
+        if (same) break;
+        h = (h + 1) & (HASH - 1);
+      }
+      hh[q] = h;
+      rk[q] = atomicAdd(&s_cnt[h], 1);
+    }
+  }
+  if (searcher) {                                     // round 3 (and whatever a very long offsets array still needs)
+    s_consume();
+    while (shi > slo) { s_issue(); s_consume(); }
+    if (lane == 0) s_brange[wv] = slo - 1;
+  }
+  PST(4);
+  __syncthreads();   // B: the dedup, the tile's bag range
+  PST(5);
+  // ---- phase 3: offsets of "my" bag of the range; representatives; list starts of the multi-occurrence keys (first half of a
+  //      block scan); the tile's histogram over the partitions; key words of the first two digest matches
+  int mb = 0;
+  int64_t mo0 = 0, mo1 = 0;
+  if constexpr (!kSeq) {
+    mb = s_brange[0] + tid;
+    int bc = mb <= s_brange[1] ? mb : s_brange[1];
+    bc = bc < 0 ? 0 : bc;
+    mo0 = a.offsets[bc];
+    mo1 = a.offsets[bc + 1];
+  }
+  bool isrep[PER];
+  int mcnt[PER], m_mine = 0;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    isrep[q] = hh[q] >= 0 && s_tab[hh[q]] == q * THREADS + tid;
+    const int c = isrep[q] ? s_cnt[hh[q]] : 0;
+    mcnt[q] = c > 1 ? c : 0;
+    m_mine += mcnt[q];
+  }
+  const int m_incl = wave_incl_scan(m_mine);
+  if (lane == 63) s_wsum[wv] = m_incl;
+  int lpq[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    lpq[q] = 0;
+    if (isrep[q]) {
+      int pk;
+      if constexpr (kMT) {   // the table's partitions split its bucket range evenly; keys without a home: its last partition
+        const int t = tq[q];
+        const int p0 = s_pb[t], p1 = s_pb[t + 1];
+        const int x = bq[q] < 0 ? p1 - p0 - 1 : (int)(((uint64_t)((int64_t)bq[q] - s_tbo[t]) * s_psc[t]) >> 32);
+        pk = p0 + (x < p1 - p0 ? x : p1 - p0 - 1);
+      } else {
+        pk = bq[q] < 0 ? a.P - 1 : (int)((uint32_t)bq[q] / (uint32_t)(a.spp >> cshift));
+      }
+      lpq[q] = pk * 4096 + atomicAdd(&s_hist[pk], 1);
+    }
+  }
+  uint64_t kc0[PER], kc1[PER];
+  int c0[PER], c1[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    uint32_t m = eq_mask16(dvq[q], digest_of(hq[q]));
+    const int start = ((int)hq[q] & Cm) & ~15;
+    c0[q] = m ? start + __ffs(m) - 1 : -1;
+    m &= m - 1;
+    c1[q] = m ? start + __ffs(m) - 1 : -1;
+    const uint64_t* ks = a.t.keys(bq[q] >= 0 ? bq[q] : 0);
+    kc0[q] = ks[c0[q] >= 0 ? c0[q] : 0];
+    kc1[q] = ks[c1[q] >= 0 ? c1[q] : (c0[q] >= 0 ? c0[q] : 0)];
+  }
+  PST(6);
+  __syncthreads();   // C: the histogram, the wave sums
+  PST(7);
+  // ---- phase 4: one returning atomic per (tile, partition) reserves the tile's records in the partition's list; list starts;
+  //      bag marks
+  const int sub = kMT ? 0 : (int)blockIdx.x % kPartSub;
+  int my_base[NPB];
+#pragma unroll
+  for (int j = 0; j < NPB; ++j) {
+    const int p = tid + j * THREADS;
+    my_base[j] = 0;
+    if (p < a.P) {
+      const int c = s_hist[p];
+      if (c) my_base[j] = atomicAdd(&a.pcount[p * kPartSub + sub], c);
+      if constexpr (kMT) {
+        if (blockIdx.x == 0) {   // the partition kernel learns its table from here
+          int t = 0;
+          while (t + 1 < T && s_pb[t + 1] <= p) ++t;
+          a.ptab[p] = t;
+        }
+      }
+    }
+  }
+  {
+    int st = m_incl - m_mine;
+    for (int k = 0; k < wv; ++k) st += s_wsum[k];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      if (isrep[q]) s_sm[hh[q]] = (uint16_t)(mcnt[q] ? (st | 0x8000) : 0);
+      st += mcnt[q];
+    }
+  }
+  if constexpr (!kSeq) {
+    const int bhi = s_brange[1];
+    if (mb >= 0 && mb <= bhi && mo1 > mo0) { const int64_t pp = mo0 > tile0 ? mo0 - tile0 : 0; if (pp < TILE) s_bag[pp] = mb; }
+    for (int b = mb + THREADS; b <= bhi; b += THREADS) {      // (more bags than threads in the tile's range: empty / one-key bags)
+      const int64_t o0 = a.offsets[b], o1 = a.offsets[b + 1];
+      if (o1 > o0) { const int64_t pp = o0 > tile0 ? o0 - tile0 : 0; if (pp < TILE) s_bag[pp] = b; }
+    }
+  }
+  PST(8);
+  __syncthreads();   // D: the bag marks (and: everybody has read the dedup's s_tab / s_cnt)
+  // ---- phase 5: running maximum of the bag marks, first half (thread t owns the occurrences t PER ..); the probe itself
+  int bagv[PER], bag_incl = -1;
+  if constexpr (!kSeq) {
+    int m = -1;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { const int v = s_bag[tid * PER + k]; m = v > m ? v : m; bagv[k] = m; }
+    bag_incl = wave_incl_max(m);
+    if (lane == 63) s_wmax[wv] = bag_incl;
+  }
+  int cnt_tile[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    cnt_tile[q] = 0;
+    bool inserted = false;
+    int gslot = (int)a.S;              // default: no slot
+    if (isrep[q]) {
+      const uint64_t key = kreg[q];
+      const int cnt = s_cnt[hh[q]];
+      cnt_tile[q] = cnt;
+      bool defer = false;
+      if (bq[q] >= 0) {
+        const int64_t b = bq[q];
+        int slot;
+        if (c0[q] >= 0 && kc0[q] == key) slot = c0[q];
+        else if (c1[q] >= 0 && kc1[q] == key) slot = c1[q];
+        else slot = thread_probe<true>(a, b, key, hq[q], cnt, inserted);
+        if (slot >= 0) {
+          gslot = (int)(b * a.t.C + slot);
+          // (Assign / timer scores are the same value from every tile: plain stores)
+          if (!inserted) score_found(a, a.t.scores(b) + (int64_t)slot * a.t.ns, cnt);
+        } else if (slot == -2) {
+          defer = true;
+        }
+      }
+      s_tab[hh[q]] = lpq[q];                                // (partition, position among the tile's records of the partition)
+      s_cnt[hh[q]] = defer ? -bq[q] - 2 : gslot;            // slot code of the record
+    }
+    // first-touch initialisation of the rows this wave inserted: the whole wave per row, coalesced stores (steady state: none)
+    uint64_t todo = __ballot(inserted);
+    while (todo) {
+      const int src = __ffsll((unsigned long long)todo) - 1;
+      todo &= todo - 1;
+      const int g = __shfl(gslot, src, 64), t = __shfl(tq[q], src, 64);
+      const uint32_t klo = __shfl((int)(uint32_t)kreg[q], src, 64), khi = __shfl((int)(uint32_t)(kreg[q] >> 32), src, 64);
+      void* rp = reinterpret_cast<void*>((uintptr_t)(tptr_of(t) + ((int64_t)g - tbo_of(t) * a.t.C) * rowb_of(t)));
+      wave_init_row(a, rp, ((uint64_t)khi << 32) | klo, (int)a.table_emb_dims[t], (int)a.table_value_dims[t]);
+    }
+  }
+  PST(9);
+  __syncthreads();   // E: the records' slot codes, the waves' bag maxima
+  // ---- phase 6: bags of all occurrences (second half of the scan); the reserved bases
+  if constexpr (!kSeq) {
+    int bbase = -1;
+    for (int k = 0; k < wv; ++k) bbase = s_wmax[k] > bbase ? s_wmax[k] : bbase;
+    int prev = __shfl_up(bag_incl, 1, 64);
+    if (lane == 0) prev = -1;
+    prev = prev > bbase ? prev : bbase;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) s_bag[tid * PER + k] = bagv[k] > prev ? bagv[k] : prev;
+  }
+#pragma unroll
+  for (int j = 0; j < NPB; ++j) {
+    const int p = tid + j * THREADS;
+    if (p < a.P) s_hist[p] = my_base[j];
+  }
+  __syncthreads();   // F
+  PST(10);
+  // ---- phase 7: records (by the representatives) and the per-occurrence arrays
+  constexpr int kListCap = kMT ? kPartCap : kSubCap;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    if (hh[q] < 0) continue;
+    const int li = q * THREADS + tid;
+    const int64_t i = tile0 + li;
+    const int v = s_tab[hh[q]];
+    const int pk = v >> 12, idx = s_hist[pk] + (v & 4095);
+    const int ref = idx < kListCap ? pk * kPartCap + sub * kSubCap + idx : -1;
+    const int g = s_cnt[hh[q]];
+    const int sm = s_sm[hh[q]];
+    int bag;
+    if constexpr (kSeq) bag = (int)i; else bag = s_bag[li];
+    if (isrep[q]) {
+      if (ref >= 0)
+        a.rec[ref] = make_uint4((uint32_t)i, (uint32_t)((sm & 0x8000) ? (int)tile0 + (sm & 0x7fff) : bag), (uint32_t)g, (uint32_t)cnt_tile[q]);
+      else
+        a.hdr[a.ovf_word] = a.ovf_val;   // a partition received more records than it can hold: the step is flagged (see the module)
+    }
+    a.occ_slot[i] = ref;
+    a.occ_trank[i] = rk[q];
+    if (sm & 0x8000) a.tile_bags[tile0 + (sm & 0x7fff) + rk[q]] = bag;
+    const int t = tq[q];
+    // address word 1: the row comes out of the partition kernel's eviction (gather_dev.h: LateRefs)
+    a.occ_addr[i] = (g >= 0 && g < a.S) ? tptr_of(t) + ((int64_t)g - tbo_of(t) * a.t.C) * rowb_of(t) : (g <= -2 ? 1 : 0);
+  }
+  if (blockIdx.x == 0)
+    for (int t = tid; t <= T; t += THREADS) {
+      if constexpr (kMT) a.seg_out[t] = s_seg[t]; else a.seg_out[t] = t == 0 ? 0 : a.n;
+    }
+  PST(11);
+}
+
+}  // namespace mi355

@@ -8,14 +8,33 @@ constexpr int kScanThreads = 256;
 constexpr int kScanItems = 4;
 constexpr int kScanTile = kScanThreads * kScanItems;  // 1024
 
+// Inclusive scan over the 64 lanes of a wave on the DPP path of the VALU (round 5): row_shr 1 / 2 / 4 / 8 inside the 16-lane rows,
+// then row_bcast:15 / :31 across them -- six v_add_u32_dpp instructions.  The __shfl_up form it replaces compiled to six dependent
+// ds_bpermute_b32 round trips through the LDS crossbar (~100+ cycles each): the block scans of the index kernels were their
+// longest phases (profiles/r03_index_phase_stamps.txt: "entry scan + publish sums" 11 K cycles).
 __device__ __forceinline__ int wave_incl_scan(int v) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    int o = __shfl_up(v, off, 64);
-    if (lane_id() >= off) v += o;
-  }
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1 (lanes without a source add 0)
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
   return v;
 }
+// running maximum over the lanes of a wave, same instruction pattern
+__device__ __forceinline__ int wave_incl_max(int v) {
+  constexpr int kNeg = -2147483647 - 1;
+  int o;
+  o = __builtin_amdgcn_update_dpp(kNeg, v, 0x111, 0xf, 0xf, false); v = o > v ? o : v;
+  o = __builtin_amdgcn_update_dpp(kNeg, v, 0x112, 0xf, 0xf, false); v = o > v ? o : v;
+  o = __builtin_amdgcn_update_dpp(kNeg, v, 0x114, 0xf, 0xf, false); v = o > v ? o : v;
+  o = __builtin_amdgcn_update_dpp(kNeg, v, 0x118, 0xf, 0xf, false); v = o > v ? o : v;
+  o = __builtin_amdgcn_update_dpp(kNeg, v, 0x142, 0xa, 0xf, false); v = o > v ? o : v;
+  o = __builtin_amdgcn_update_dpp(kNeg, v, 0x143, 0xc, 0xf, false); v = o > v ? o : v;
+  return v;
+}
+// sum over the wave, returned to every lane
+__device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_incl_scan(v), 63); }
 
 // exclusive scan of one int per thread across a 256-thread block; returns the block total in `total`
 __device__ __forceinline__ int block_excl_scan(int v, int& total) {

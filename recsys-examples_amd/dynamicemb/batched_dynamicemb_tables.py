@@ -24,6 +24,7 @@ from torch import nn
 import dynamicemb_extensions as ext
 import mi355_native as N
 from mi355_native import c_f, c_p, c_u64, check, current_torch_stream, dt, lib, ptr, stream
+from mi355_native import _DT as _DT_CODE, _cur_device, _raw_stream
 
 from .dynamicemb_config import (DynamicEmbCheckMode, DynamicEmbInitializerMode, DynamicEmbPoolingMode,
                                 DynamicEmbScoreStrategy, DynamicEmbTableOptions, EmbOptimType,
@@ -164,6 +165,36 @@ class _FusedStep:
 
     def __del__(self):
         self.release_ring()
+
+
+class _PlanStep(_FusedStep):
+    """Step context of the pre-bound training step (mi355_demb_plan_forward): the same single buffer as _FusedStep, but nothing is
+    computed on the hot path -- the array offsets come from the library's own layout function the first time somebody asks."""
+
+    def __init__(self, module, buf, n, T, ring, offsets, B, num_bags):   # (no super().__init__: that is the eager layout)
+        self.module, self.buf, self.num_keys, self.T = module, buf, n, T
+        self.ring = ring
+        self.offsets, self.batch_size, self.num_bags = offsets, B, num_bags
+        self.token = -1
+        self.pinned = False
+        self.event = None
+        self.indices = None
+        self.prepared = 0
+        self.lazy = False
+        self.plan_step = True
+
+    def _layout(self):
+        lay = (ctypes.c_int64 * 13)()
+        lib().mi355_demb_step_layout(self.num_keys, self.T, self.module.max_D, 1, lay)
+        names = [f[0] for f in self._FIELDS] + ["uoff", "fwd_ws", "bwd_ws"]
+        self.__dict__["off"] = {nm: int(lay[i]) for i, nm in enumerate(names)}
+        self.__dict__["total"], self.__dict__["fwd_ws_bytes"], self.__dict__["bwd_ws_bytes"] = int(lay[10]), int(lay[11]), int(lay[12])
+
+    def __getattr__(self, name):          # only reached for attributes that are not set yet
+        if name in ("off", "total", "fwd_ws_bytes", "bwd_ws_bytes"):
+            self._layout()
+            return self.__dict__[name]
+        raise AttributeError(name)
 
 
 class _LookupFunction(torch.autograd.Function):
@@ -361,6 +392,10 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         import weakref
         self._live_steps = weakref.WeakSet()   # forward contexts whose backward is still to come
         self._fused_side = os.environ.get("MI355_FUSED_SIDE", "0") != "0"
+        self._plan = None
+        # the pre-bound step (_plan_forward): the steady-state configuration only -- everything else keeps the general path
+        self._plan_ok = (self._fused and not self._growth and not self._fused_side and os.environ.get("MI355_PLAN", "1") != "0"
+                         and opt0.safe_check_mode == DynamicEmbCheckMode.IGNORE and _raw_stream is not None and _cur_device is not None)
         self._step_ring = [None] * 4
         self._bwd_ring = [None] * 4
         self._bwd_busy = [False] * 4
@@ -416,6 +451,10 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
 
     # ---------------------------------------------------------------------------------- forward
     def _forward_impl(self, indices: torch.Tensor, offsets: torch.Tensor, train: bool, prefetch_only: bool = False):
+        if (train and self._plan_ok and not prefetch_only and not self._pin and not self._prefetch_states and not self._orphan_pins
+                and indices.dtype is torch.int64 and offsets.dtype is torch.int64 and indices.is_contiguous()
+                and offsets.is_contiguous() and indices.is_cuda):
+            return self._plan_forward(indices, offsets)
         if self._orphan_pins:
             self._drain_orphan_pins()
         out, st = self._forward_impl_inner(indices, offsets, train, prefetch_only)
@@ -587,6 +626,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         self.table = new_tb
         self.table_ptrs = torch.tensor([v.data_ptr() for v in self.values], dtype=torch.int64, device=self.device_)
         self._fused_aux = None            # sized by the table
+        self._plan_invalidate()
         self._fill_event = None
 
     # ---------------------------------------------------------------------------------- fused forward / backward
@@ -601,6 +641,123 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         if s == DynamicEmbScoreStrategy.LFU:
             return P.ACCUMULATE, P.ASSIGN, 0, 1
         return P.LRU_LFU, P.LRU_LFU, 0, 1
+
+    # ---------------------------------------------------------------------------------- pre-bound training step
+    # Round 5: module.forward() + autograd cost 0.179 ms per C2 step against 0.128 ms of GPU time -- the host
+    # was the bound: ~60 ctypes arguments marshalled per forward, a step object with a dozen fields, size queries, torch.empty
+    # calls.  In the steady-state configuration (HBM storage, fused index stage, no admission / growth / prefetch / pinning /
+    # safe-check) the step now goes through a PLAN (csrc/pipeline.hip: mi355_demb_plan_*): everything constant is bound once,
+    # a step is `torch.empty` for the output + one 13-argument C call, the backward one 19-argument C call.
+    # Reference: DynamicEmbeddingFunction.forward / backward, batched_dynamicemb_function.py:1042-1300.
+    def _plan_invalidate(self):
+        pl = self.__dict__.get("_plan")
+        if pl is not None:
+            lib().mi355_demb_plan_destroy(pl)
+        self._plan = None
+
+    def __del__(self):
+        try:
+            self._plan_invalidate()
+        except Exception:
+            pass
+
+    def _plan_build(self):
+        L = lib()
+        tb = self.table
+        if self._fused_aux is None:
+            self._fused_aux = torch.zeros(L.mi355_demb_aux_numel(tb.capacity_, tb.num_buckets_), dtype=torch.int32, device=self.device_)
+        fp, ip, _sval, use_cnt = self._fused_scores()
+        mode, p = self._init_params()
+        pooled = self.pooling_mode != DynamicEmbPoolingMode.NONE
+        combiner = -1 if not pooled else (0 if self.pooling_mode == DynamicEmbPoolingMode.SUM else 1)
+        al = all(d % 4 == 0 for d in self.dims) and all(v % 4 == 0 for v in self.value_dims)
+        self._plan = L.mi355_demb_plan_create(
+            ptr(tb.table_storage_), ptr(tb.table_bucket_offsets_), tb.bucket_capacity_, tb.num_scores_,
+            ptr(tb.bucket_sizes), ptr(tb._ref_counter), tb._ref_counter.numel(), ptr(self._fused_aux),
+            self._fused_aux.numel(), tb.num_buckets_,
+            ptr(self.table_ptrs), ptr(self.table_value_dims), ptr(self.table_emb_dims), dt(self.embedding_dtype),
+            self.max_D, max(self.value_dims), ptr(self.feature_offsets), self.num_tables,
+            int(fp), int(ip), int(use_cnt), 0,
+            mode, c_f(p[0]), c_f(p[1]), c_f(p[2]), c_f(p[3]), c_u64(self._seed), c_f(self.initial_accumulator_value),
+            combiner, ptr(self.D_offsets_t), self.total_D, dt(self.output_dtype), int(al), self._opt_kind,
+            c_f(self.beta1), c_f(self.beta2), c_f(self.eps), c_f(self.weight_decay))
+        if not self._plan:
+            raise RuntimeError("mi355_demb_plan_create failed")
+        # what the plan froze: anything else that changes rebuilds it (the table objects are replaced by _expand / load)
+        self._plan_key = (id(tb), self._fused_aux.data_ptr(), self.table_ptrs.data_ptr())
+        self._plan_pooled = pooled
+        self._plan_state = ctypes.c_int(-1)
+        self._plan_state_ref = ctypes.byref(self._plan_state)
+        self._plan_step_score = self._score_strategy == DynamicEmbScoreStrategy.STEP
+        self._plan_custom_score = self._score_strategy == DynamicEmbScoreStrategy.CUSTOMIZED
+        self._plan_al_g = al
+        self._plan_fwd = L.mi355_demb_plan_forward
+        self._plan_bwd = L.mi355_demb_plan_backward
+        return self._plan
+
+    def _plan_forward(self, indices, offsets):
+        plan = self._plan
+        if plan is None or self._plan_key[0] != id(self.table):
+            self._plan_invalidate()
+            plan = self._plan_build()
+        n = indices.numel()
+        num_bags = offsets.numel() - 1
+        B = num_bags // self.feature_num
+        buf, ring = None, None
+        if not torch.cuda.is_current_stream_capturing():
+            slot = self._bwd_ring_next % 4
+            if not self._bwd_busy[slot]:
+                object.__setattr__(self, "_bwd_ring_next", self._bwd_ring_next + 1)
+                buf = self._step_ring[slot]
+                self._bwd_busy[slot] = True
+                ring = (self._bwd_busy, slot)
+        if self._plan_pooled:
+            out = torch.empty(B, self.total_D, dtype=self.output_dtype, device=self.device_)
+        else:
+            out = torch.empty(n, self.dims[0], dtype=self.output_dtype, device=self.device_)
+        sval = self._step if self._plan_step_score else (self._custom_score if self._plan_custom_score else 0)
+        s_ = _raw_stream(_cur_device())
+        rc = 1
+        if buf is not None:
+            rc = self._plan_fwd(plan, indices.data_ptr(), n, offsets.data_ptr(), num_bags, B, sval, ext.TIMER_OVERRIDE, out.data_ptr(),
+                                buf.data_ptr(), buf.numel(), self._plan_state_ref, s_)
+        if rc == 1:      # no ring slot free (more steps outstanding than the ring holds), or the slot's buffer is too small
+            need = lib().mi355_demb_plan_step_bytes(plan, n)
+            if ring is not None:
+                buf = self._step_ring[ring[1]] = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=self.device_)
+            else:
+                buf = torch.empty(need, dtype=torch.uint8, device=self.device_)
+            rc = self._plan_fwd(plan, indices.data_ptr(), n, offsets.data_ptr(), num_bags, B, sval, ext.TIMER_OVERRIDE, out.data_ptr(),
+                                buf.data_ptr(), buf.numel(), self._plan_state_ref, s_)
+        if rc != 0:
+            if ring is not None:
+                ring[0][ring[1]] = False
+            check(rc, "demb_plan_forward")
+        st = _PlanStep(self, buf, n, self.num_tables, ring, offsets, B, num_bags)
+        tok = self._plan_state.value
+        st.lazy = tok == -2
+        st.prepared = 1 if n > 0 else 0
+        object.__setattr__(self, "_step", self._step + 1)   # (nn.Module.__setattr__ runs its Parameter / Module checks per assignment)
+        if self._step % 64 == 0 or self.__dict__.get("_part_flag_event") is not None:
+            self._check_partition_flag()
+        return out, st
+
+    def _plan_backward(self, st, grads):
+        if not grads.is_contiguous():
+            grads = grads.contiguous()
+        object.__setattr__(self, "_iter_num", self._iter_num + 1)
+        buf = st.buf
+        rc = self._plan_bwd(self._plan, buf.data_ptr(), buf.numel(), st.num_keys, st.offsets.data_ptr(), st.num_bags, st.batch_size,
+                            grads.data_ptr(), grads.stride(0), _DT_CODE[grads.dtype], int(self._plan_al_g and grads.stride(0) % 4 == 0),
+                            self.learning_rate, self.beta1, self.beta2, self.eps, self.weight_decay, self._iter_num, 1,
+                            _raw_stream(_cur_device()))
+        if rc != 0:
+            check(rc, "demb_plan_backward")
+        st.prepared = 0
+        r = st.ring
+        if r is not None:
+            r[0][r[1]] = False
+            st.ring = None
 
     def _forward_fused(self, indices: torch.Tensor, offsets: torch.Tensor, train: bool, prefetch_only: bool):
         L = lib()
@@ -1151,6 +1308,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             warnings.warn(msg)
 
     def _backward_impl(self, st, grads: torch.Tensor):
+        if getattr(st, "plan_step", False) and st.prepared == 1 and self._plan is not None:
+            return self._plan_backward(st, grads)
         self._live_steps.discard(st)
         self._record_step_on(st, current_torch_stream())   # (prefetched steps only: see _record_step_on)
         try:

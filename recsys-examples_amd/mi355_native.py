@@ -99,6 +99,18 @@ _SIGS = {
                                  c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,  # persisted
                                  c_p, c_i64, c_int, c_p,  # backward workspace, side stream, join token
                                  c_p, c_i64, c_p],
+    "mi355_demb_plan_create": [c_p, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_i64,  # table + aux
+                               c_p, c_p, c_p, c_int, c_i64, c_i64, c_p, c_i64,  # values, feature offsets, tables
+                               c_int, c_int, c_int, c_int,  # policies, pin
+                               c_int, c_f, c_f, c_f, c_f, c_u64, c_f,  # initializer
+                               c_int, c_p, c_i64, c_int, c_int,  # output
+                               c_int, c_f, c_f, c_f, c_f],  # optimizer
+    "mi355_demb_plan_destroy": [c_p],
+    "mi355_demb_step_layout": [c_i64, c_i64, c_i64, c_int, c_p],
+    "mi355_demb_plan_step_bytes": [c_p, c_i64],
+    "mi355_demb_plan_forward": [c_p, c_p, c_i64, c_p, c_i64, c_i64, c_u64, c_u64, c_p, c_p, c_i64, c_p, c_p],
+    "mi355_demb_plan_backward": [c_p, c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_int, c_int,
+                                 c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_p],
     "mi355_demb_aux_numel": [c_i64, c_i64],
     "mi355_demb_forward_fused_workspace_bytes": [c_i64, c_i64],
     "mi355_demb_forward_fused_partitions": [c_i64, c_i64, c_i64],
@@ -144,6 +156,10 @@ _RESTYPES = {
     "mi355_demb_forward_workspace_bytes": c_i64,
     "mi355_demb_backward_workspace_bytes": c_i64,
     "mi355_early_csr_stream": c_p,
+    "mi355_demb_plan_create": c_p,
+    "mi355_demb_plan_destroy": None,
+    "mi355_demb_step_layout": None,
+    "mi355_demb_plan_step_bytes": c_i64,
     "mi355_vmm_data": c_p,
     "mi355_vmm_mapped_bytes": c_i64,
     "mi355_vmm_reserved_bytes": c_i64,
@@ -172,7 +188,7 @@ def _bind(lib, sigs):
     for name, args in sigs.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.argtypes = args
-        fn.restype = _RESTYPES.get(name, c_int)
+        fn.restype = _RESTYPES[name] if name in _RESTYPES else c_int
 
 
 def exported_symbols():

@@ -18,6 +18,11 @@ if STANDINS not in sys.path:
     sys.path.append(STANDINS)
 
 
+# the per-call knobs of the fused forward (MI355_PROBE_C, MI355_FUSED_FASTMOD) are read once per process unless this is set
+# before the library's first call: the suite switches them between tests
+os.environ.setdefault("MI355_ENV_LIVE", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 

@@ -128,6 +128,58 @@ def test_csr_writing_partition_kernel_against_the_per_op_chain_around_its_size_l
                                    rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4"])
+@pytest.mark.parametrize("pooling,bags,bucket", [("SUM", 60_000, 128), ("NONE", 150_000, 128), ("SUM", 40_000, 16)])
+def test_every_tile_shape_of_the_round5_probe_kernel_against_the_per_op_chain(variant, pooling, bags, bucket, monkeypatch):
+    """probe_c_kernel (csrc/probe_c.h; MI355_PROBE_C picks the tile shape, 0 = the round-3 kernel) against the per-op chain:
+    pooled and sequence lookups, steps that insert every key, steps in the steady state, a 16-slot-bucket table that evicts
+    (deferred keys resolved by the partition kernel).  Same outputs, same unique counts, same stored keys and rows."""
+    monkeypatch.setenv("MI355_PROBE_C", variant)
+    cap = 1 << 20 if bucket == 128 else 1 << 16
+    ref = _mk(False, (16,), cap=cap, pooling=pooling, opt="SGD", strategy="STEP" if bucket == 16 else "TIMESTAMP", bucket=bucket,
+              learning_rate=0.2, monkeypatch=monkeypatch)
+    dut = _mk(True, (16,), cap=cap, pooling=pooling, opt="SGD", strategy="STEP" if bucket == 16 else "TIMESTAMP", bucket=bucket,
+              learning_rate=0.2, monkeypatch=monkeypatch)
+    rng = np.random.default_rng(bags + int(variant))
+    ref.train(); dut.train()
+    for it in range(3):
+        if pooling == "NONE":
+            nk = bags
+            off = torch.arange(nk + 1, dtype=torch.int64, device=DEV)
+        else:
+            lens = rng.integers(0, 9, size=bags)          # (empty bags included)
+            off = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)).to(DEV)
+            nk = int(off[-1])
+        hi = (200_000 + 50_000 * it) if bucket == 128 else (30_000 + 20_000 * it)
+        keys = torch.from_numpy(((rng.zipf(1.2, nk) + 11 * it) % hi).astype(np.int64)).to(DEV)
+        o_ref, s_ref = ref._forward_impl(keys, off, train=True)
+        o_dut, s_dut = dut._forward_impl(keys, off, train=True)
+        assert getattr(s_dut, "lazy", False), "the batch did not take the CSR-writing partition path"
+        if bucket == 128:
+            torch.testing.assert_close(o_ref, o_dut, rtol=1e-5, atol=1e-5, msg=f"step {it} ({nk} keys): forward differs")
+        nu_r, nu_d = int(s_ref.uoff[-1]), int(s_dut.uoff[-1])
+        # (keys that find no slot at all in a full 16-slot bucket are one unique row each on the per-op chain and ONE row-less entry
+        #  per partition here: no row is updated from either)
+        assert nu_r == nu_d if bucket == 128 else nu_d <= nu_r
+        rev = s_dut.rev
+        assert int(rev.min()) >= 0 and int(rev.max()) < nu_d and int(torch.unique(rev).numel()) == nu_d
+        if bucket == 128:
+            uk = torch.empty(nu_d, dtype=torch.int64, device=DEV)
+            uk[rev] = keys
+            assert torch.equal(uk[rev], keys)
+        g = torch.rand_like(o_ref) + 0.1
+        ref._backward_impl(s_ref, g)
+        dut._backward_impl(s_dut, g)
+        assert torch.equal(ref.size(), dut.size())
+        assert _counters_clear(dut)
+    if bucket == 128:      # (an evicting table keeps whichever keys its eviction order chose: sizes agree, contents need not)
+        k1, v1 = ref.export_keys_values(ref._table_names[0], torch.device(DEV))
+        k2, v2 = dut.export_keys_values(dut._table_names[0], torch.device(DEV))
+        o1, o2 = torch.argsort(k1), torch.argsort(k2)
+        assert k1.numel() == k2.numel() and torch.equal(k1[o1], k2[o2])
+        torch.testing.assert_close(v1[o1], v2[o2], rtol=3e-5, atol=3e-6)
+
+
 @pytest.mark.parametrize("pooling,opt,strategy", [("NONE", "SGD", "TIMESTAMP"), ("SUM", "ADAM", "LFU"), ("MEAN", "EXACT_ROWWISE_ADAGRAD", "STEP")])
 def test_multi_table_batches_of_a_few_hundred_thousand_keys_against_the_per_op_chain(pooling, opt, strategy, monkeypatch):
     """what the HSTU example's embedding collection sends: several tables, sequence or pooled lookups, 10^5 keys per step --

@@ -14,6 +14,7 @@ torch.cuda.set_device(0)
 NB = 8
 batches = bench.zipf_batches(10_000_000, 0.99, 65536, NB, dev, seed=1234)
 grad = (torch.randn(65536, 128, device=dev) * 0.01).to(torch.bfloat16)
+os.environ["MI355_ENV_LIVE"] = "1"
 os.environ["MI355_FUSED_FASTMOD"] = "1"
 m = bench.build_module(10_000_000, 128, dev)
 m.train()
