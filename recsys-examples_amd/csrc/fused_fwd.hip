@@ -118,6 +118,7 @@ struct FusedArgs {
   int gate_val;
   int ovf_word, ovf_val;          // where / what the partitioned probe writes when a record list overflows
   int* rerun_mark;                // nullable: cleared by block 0 of the partitioned probe, set by the re-run chain's last kernel
+  int tl;                         // probe_c_kernel (round 5): keys of a tile, a run-time value (<= the kernel's capacity, multiple of 64)
 };
 
 __device__ __forceinline__ void store_digest(uint8_t* p, uint8_t d) {
@@ -1591,18 +1592,13 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
   QST(0);
   constexpr int kDefMax = kPartCap / 4;
   const int p = blockIdx.x;
-  int msub[kPartSub];
-#pragma unroll
-  for (int r = 0; r < kPartSub; ++r) msub[r] = a.pcount[p * kPartSub + r];
+  // the sub-list counts come in through the VECTOR memory path (one lane per sub-list, broadcast behind the barrier): as uniform
+  // scalar loads they share the LDS counter of the wave, and the barrier below -- which waits for the LDS initialisation --
+  // waited for their round trip as well (profiles/r05_index_phase_stamps_1024x2.txt: 2 us in front of the first barrier)
+  const int mv = a.pcount[p * kPartSub + ((int)threadIdx.x & (kPartSub - 1))];
   uint4 rc[kP3Items];
 #pragma unroll
   for (int k = 0; k < kP3Items; ++k) rc[k] = a.rec[(int64_t)p * kPartCap + threadIdx.x + k * kP3Threads];
-  // (rows of the partition's table: three scalars every output needs, fetched with the records; several tables: the probe
-  //  kernel's block 0 left the table of every partition in ptab)
-  int tbl = 0;
-  bool first_of_table = p == 0;
-  if (a.mt) { tbl = a.ptab[p]; first_of_table = p == 0 || a.ptab[p - 1] != tbl; }
-  const int64_t tp0 = a.table_ptrs[tbl], rowb = a.table_value_dims[tbl] * a.elem_bytes, s0 = a.tbo[tbl] * a.t.C;
   for (int i = threadIdx.x; i < kP2Hash; i += kP3Threads) { h_slot[i] = -1; h_cnt[i] = 0; }
   if (threadIdx.x < 256) s_lock[threadIdx.x] = 0;
   if (threadIdx.x < kP2Hash / 32) s_late[threadIdx.x] = 0;
@@ -1610,6 +1606,15 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
   QST(1);
   __syncthreads();
   QST(2);
+  int msub[kPartSub];
+#pragma unroll
+  for (int r = 0; r < kPartSub; ++r) msub[r] = __builtin_amdgcn_readlane(mv, r);
+  // (rows of the partition's table: three scalars every output needs -- fetched behind the first barrier, used much later;
+  //  several tables: the probe kernel's block 0 left the table of every partition in ptab)
+  int tbl = 0;
+  bool first_of_table = p == 0;
+  if (a.mt) { tbl = a.ptab[p]; first_of_table = p == 0 || a.ptab[p - 1] != tbl; }
+  const int64_t tp0 = a.table_ptrs[tbl], rowb = a.table_value_dims[tbl] * a.elem_bytes, s0 = a.tbo[tbl] * a.t.C;
   if (threadIdx.x < kPartSub) a.pcount[p * kPartSub + threadIdx.x] = 0;       // clean for the next step
   // ---- merge the records of a slot; the record that creates the entry owns the unique row's key
   int en[kP3Items], bs[kP3Items], dj[kP3Items];
@@ -2260,7 +2265,7 @@ int mi355_demb_forward_fused(
   a.rec = nullptr; a.rec_out = nullptr; a.rec_out4 = nullptr;
   a.tile_bags = nullptr; a.occ_trank = nullptr;
   a.mt = 0; a.ptab = nullptr;
-  a.gate = nullptr; a.gate_val = 0; a.ovf_word = 5; a.ovf_val = 1; a.rerun_mark = nullptr;
+  a.gate = nullptr; a.gate_val = 0; a.ovf_word = 5; a.ovf_val = 1; a.rerun_mark = nullptr; a.tl = 0;
   a.magic0 = num_buckets > 0 ? ~0ull / (uint64_t)num_buckets : 0ull;   // (one table: its buckets are all the buckets)
   {
     const int P = train ? part_count(n, num_tables) : 0;
@@ -2398,24 +2403,35 @@ int mi355_demb_forward_fused(
         env_have = true;
       }
       const bool fast = (fm_c >= 0 ? fm_c != 0 : pathc) && (a.t.C & (a.t.C - 1)) == 0 && (a.S >> __builtin_ctzll((unsigned long long)a.t.C)) < (1ll << 31);
-      // round 5: the rebuilt probe kernel of path (c) (probe_c.h) -- MI355_PROBE_C: 0 the kernel above, 1 (default) 1024-key tiles
-      // of 1024 threads at two blocks per CU, 2: 1024 / 512, 3: 2048 / 1024, 4: 512 / 512 (read per call: A/B inside one process)
+      // round 5: the rebuilt probe kernel of path (c) (probe_c.h); MI355_PROBE_C = 0 keeps the kernel above
       const int pcv = pc_c;
       if (pathc && fast && pcv > 0) {
+        // ONE block per CU in one generation while the batch allows it: tile length = ceil(n / #CUs), rounded to 64, in the kernel
+        // with one key per thread (<= 1 024 keys per tile) or two (<= 2 048); larger batches run full 2 048-key tiles in
+        // generations.  MI355_PROBE_C: 1 this rule, 2 always the two-keys-per-thread kernel, 3 full 1 024-key tiles (two blocks
+        // per CU: the form measured first, profiles/r05_index_phase_stamps_1024x2.txt), 0 the round-3 kernel.
+        static int ncu_p = 0;
+        if (!ncu_p) {
+          int dev = 0;
+          hipDeviceProp_t prop;
+          if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu_p = prop.multiProcessorCount;
+          if (ncu_p <= 0) ncu_p = 256;
+        }
+        const int cap = pcv == 3 ? 1024 : ((pcv == 2 || n > (int64_t)ncu_p * 1024) ? 2048 : 1024);
+        int64_t tlen = pcv == 3 ? cap : (ceil_div(n, ncu_p) + 63) / 64 * 64;
+        if (tlen > cap) tlen = cap;
+        if (tlen < 256) tlen = 256;
+        a.tl = (int)tlen;
 #define LAUNCH_PC(TILE, THREADS, WPS)                                                                                                   \
   do {                                                                                                                                   \
-    const dim3 grid((unsigned)ceil_div(n, TILE)), blk(THREADS);                                                                          \
+    const dim3 grid((unsigned)ceil_div(n, tlen)), blk(THREADS);                                                                          \
     if (a.mt && seq) hipLaunchKernelGGL((probe_c_kernel<TILE, THREADS, WPS, true, true>), grid, blk, 0, stream, a);                     \
     else if (a.mt) hipLaunchKernelGGL((probe_c_kernel<TILE, THREADS, WPS, true, false>), grid, blk, 0, stream, a);                      \
     else if (seq) hipLaunchKernelGGL((probe_c_kernel<TILE, THREADS, WPS, false, true>), grid, blk, 0, stream, a);                       \
     else hipLaunchKernelGGL((probe_c_kernel<TILE, THREADS, WPS, false, false>), grid, blk, 0, stream, a);                               \
   } while (0)
-        switch (pcv) {
-          case 2: LAUNCH_PC(1024, 512, 6); break;
-          case 3: LAUNCH_PC(2048, 1024, 4); break;
-          case 4: LAUNCH_PC(512, 512, 8); break;
-          default: LAUNCH_PC(1024, 1024, 8); break;
-        }
+        if (cap == 2048) LAUNCH_PC(2048, 1024, 4);
+        else LAUNCH_PC(1024, 1024, 8);
 #undef LAUNCH_PC
       } else
       if (pathc) {

@@ -5,22 +5,28 @@
 // Restates (reference, corelib/dynamicemb/): segmented_unique_cuda (src/unique_op.cu:484-714), table_lookup_kernel /
 // table_insert_kernel (src/table_operation/kernels.cuh:81-585).
 //
-// What profiles/r03_index_phase_stamps.txt and r05_index_phase_stamps_before.txt show for the old kernel: 176 blocks of 1024
-// threads on 256 CUs (83 KB of LDS and 83 VGPRs: ONE block per CU, 31 % of the CUs idle), a block life of 21 us made of eleven
-// barrier-separated phases, of which
+// What the phase stamps show for the old kernel (profiles/r03_index_phase_stamps.txt, r05_index_phase_stamps_before.txt): 176
+// blocks of 1024 threads on 256 CUs (one per CU, 31 % of the CUs idle), a block life of 21 us made of eleven barrier-separated
+// phases, of which
 //   * the first is the 64-ary search of the tile's bag range by waves 0 / 1 -- three dependent loads -- with the other fourteen
-//     waves waiting at the barrier behind it (14 %);
+//     waves waiting at the barrier behind it (14-17 %);
 //   * the probe phase runs a dependent re-probe (digest vector again, then key words one by one) for every key whose first
-//     candidate slot was a digest false positive -- 6 % of the keys, i.e. nearly every wave (18 %);
+//     candidate slot was a digest false positive -- 6 % of the keys, i.e. nearly every wave (17 %);
 //   * the LDS dedup serialises two keys per thread through four dependent LDS operations each (10 %).
+// And what the first form of THIS kernel showed (profiles/r05_index_phase_stamps_1024x2.txt): 352 blocks of 1024 keys at two per
+// CU are no faster -- a block that shares its CU takes 22 us, one that has it alone 12.7 us (the kernel is bound by what a CU can
+// issue, not by latency a neighbour could cover), and a search that is pipelined through the phases still gates them, because
+// each round is a full memory round trip for the two waves that run it.
 // Here:
-//   * tiles of 1024 keys, ONE key per thread, <= 64 VGPRs and ~37 KB of LDS: 352 blocks, all resident at two per CU, so one
-//     block's barrier waits and round trips run under the other's work;
-//   * the bag search is software-pipelined through the first three phases (round k + 1 is issued when round k is consumed, the
-//     work of the phase in between), so nobody waits for it;
-//   * the key words of the FIRST TWO digest matches are fetched together, before the barrier in front of the probe phase; the
-//     dependent re-probe is left to the ~0.1 % of keys with two false positives in front of them (and to misses);
-//   * six barriers instead of eleven; the dedup hash comes out of the table hash (no second fmix64); the representative of a key
+//   * ONE block per CU, all in one generation: the tile length is a run-time value, ceil(n / #CUs) rounded to 64 (1 408 keys at
+//     C2), up to the kernel's capacity (1 024 keys, one per thread; 2 048, two per thread); beyond 2 048 x #CUs keys the tiles are
+//     full and the grid runs in generations;
+//   * no search: a block GUESSES its bag range from its position (bag ~ position x bags / keys), loads the offsets of a
+//     2 048-bag window around the guess with the key loads (coalesced, nothing depends on anything), and checks that the window
+//     covers the tile; only a block whose window does not (bag lengths far from uniform) searches;
+//   * the key words of the FIRST TWO digest matches are fetched together, a phase ahead of their use; the dependent re-probe is
+//     left to the ~0.1 % of keys with two false positives in front of them (and to misses);
+//   * five barriers instead of eleven; the dedup hash comes out of the table hash (no second fmix64); the representative of a key
 //     is whichever occurrence claimed the LDS entry (no atomicMin); rows inserted by the block are initialised by the wave that
 //     inserted them, straight from registers.
 #pragma once
@@ -33,6 +39,7 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
   constexpr int HASH = 2 * TILE;
   constexpr int NW = THREADS / 64;
   constexpr int NPB = (kPartMax + THREADS - 1) / THREADS;   // partitions a thread reserves for
+  constexpr int WIN = 2 * THREADS;                          // bags of the guessed window (two per thread)
   static_assert(TILE % THREADS == 0 && (TILE & (TILE - 1)) == 0 && TILE <= 4096 && THREADS >= 128, "tile shape");
   __shared__ uint64_t s_key[TILE];
   __shared__ int s_tab[HASH];          // dedup: tile position of the key's representative; after the probe: (partition << 12) | position
@@ -40,7 +47,7 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
   __shared__ uint16_t s_sm[HASH];      // per dedup entry: start of the key's list in the tile | multi flag << 15
   __shared__ int s_bag[kSeq ? 1 : TILE];
   __shared__ int s_hist[kPartMax];     // records of this tile per partition, then their base in the partition's list
-  __shared__ int s_brange[2], s_wmax[NW], s_wsum[NW];
+  __shared__ int s_brange[2], s_wmax[NW], s_wsum[NW], s_cover;
   __shared__ uint16_t s_t[kMT ? TILE : 1];
   __shared__ int64_t s_seg[kMT ? kFusedMaxT + 1 : 1], s_tbo[kMT ? kFusedMaxT + 1 : 1], s_tptr[kMT ? kFusedMaxT : 1];
   __shared__ int s_rowb[kMT ? kFusedMaxT : 1];
@@ -50,7 +57,9 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
   PST(0);
   const int T = a.T;
   const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int64_t tile0 = (int64_t)blockIdx.x * TILE;
+  const int tl = a.tl;                 // keys of a tile (<= TILE, multiple of 64)
+  const int64_t tile0 = (int64_t)blockIdx.x * tl;
+  const int64_t tile_end = tile0 + tl < a.n ? tile0 + tl : a.n;
   if (!a.timer) a.timer = device_clock();
   // ---- phase 0: everything that depends on nothing goes out first
   uint64_t kreg[PER];
@@ -59,40 +68,31 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
     const int64_t i = tile0 + q * THREADS + tid;
     kreg[q] = a.keys[i < a.n ? i : a.n - 1];
   }
+  // the guessed bag window [wlo, wlo + WIN): bag of a position ~ position * bags / keys; thread t takes the bags wlo + t and
+  // wlo + THREADS + t
+  int wlo = 0;
+  int64_t wo[2][2];
+  if constexpr (!kSeq) {
+    const int64_t nb = a.num_bags;
+    const int64_t g0 = (int64_t)((double)tile0 * (double)nb / (double)a.n), g1 = (int64_t)((double)(tile_end - 1) * (double)nb / (double)a.n);
+    int64_t lo = (g0 + g1) / 2 - WIN / 2;
+    lo = lo + WIN > nb ? nb - WIN : lo;
+    lo = lo < 0 ? 0 : lo;
+    wlo = (int)lo;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t b = lo + h * THREADS + tid;
+      const int64_t bc = b < nb ? b : nb - 1;
+      wo[h][0] = a.offsets[bc];
+      wo[h][1] = a.offsets[bc + 1];
+    }
+  }
   int64_t m_tbo0 = 0, m_tbo1 = 0, m_tptr0 = 0;
   int m_rowb0 = 0;
   if constexpr (!kMT) { m_tbo0 = a.tbo[0]; m_tbo1 = a.tbo[1]; m_tptr0 = a.table_ptrs[0]; m_rowb0 = (int)a.table_value_dims[0] * a.elem_bytes; }
   auto tbo_of = [&](int t) -> int64_t { if constexpr (!kMT) return t == 0 ? m_tbo0 : m_tbo1; else return s_tbo[t]; };
   auto tptr_of = [&](int t) -> int64_t { if constexpr (!kMT) return m_tptr0; else return s_tptr[t]; };
   auto rowb_of = [&](int t) -> int { if constexpr (!kMT) return m_rowb0; else return s_rowb[t]; };
-  // the tile's bag range: waves 0 / 1 find the bags of its first / last occurrence (first idx with offsets[idx] > position, minus
-  // one) by 64-ary rounds, one probe per lane.  A round is issued here and consumed a phase later.
-  const bool searcher = !kSeq && tid < 128;           // (wave uniform)
-  int slo = 0, shi = (int)a.num_bags, sstep = 1;
-  int64_t sval = 0;
-  bool sinf = false;
-  const int64_t tile_end = tile0 + TILE < a.n ? tile0 + TILE : a.n;
-  const int64_t skey = tid < 64 ? tile0 : tile_end - 1;
-  auto s_issue = [&]() {
-    sstep = (shi - slo + 63) >> 6;
-    const int64_t pi = (int64_t)slo + (int64_t)(lane + 1) * sstep - 1;
-    sinf = pi >= shi;
-    const int64_t pc = sinf ? (shi > 0 ? shi - 1 : 0) : pi;
-    sval = a.offsets[pc];
-  };
-  auto s_consume = [&]() {
-    if (shi > slo) {
-      const uint64_t gm = __ballot(sinf || sval > skey);
-      if (!gm) slo = shi;
-      else {
-        const int first = __ffsll((unsigned long long)gm) - 1;
-        const int64_t nhi = (int64_t)slo + (int64_t)(first + 1) * sstep - 1;
-        slo = slo + first * sstep;
-        shi = nhi < shi ? (int)nhi : shi;
-      }
-    }
-  };
-  if (searcher) s_issue();
   if constexpr (kMT) {
     for (int t = tid; t <= T; t += THREADS) {
       s_seg[t] = a.offsets[a.feature_offsets[t] * a.batch];
@@ -119,8 +119,8 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
   for (int s = tid; s < HASH; s += THREADS) { s_tab[s] = -1; s_cnt[s] = 0; }
   for (int p = tid; p < a.P; p += THREADS) s_hist[p] = 0;
   if constexpr (!kSeq) for (int k = tid; k < TILE; k += THREADS) s_bag[k] = -1;
-  if constexpr (kMT) __syncthreads();                 // the tables' metadata
-  if (searcher) { s_consume(); s_issue(); }           // round 1 -> round 2
+  if (tid == 0) s_cover = 1;
+  __syncthreads();   // 0: the cleared LDS (and the tables' metadata); nothing has been waited for yet
   PST(1);
   if constexpr (kMT) {   // partitions per table: one each, the rest in proportion to the tables' keys in this batch
     if (tid < T) {
@@ -128,7 +128,8 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
       s_pt[tid] = 1 + (a.n > 0 ? (int)((uint64_t)(a.P - T) * nt_ / (uint64_t)a.n) : 0);
     }
   }
-  // ---- phase 1: hash, bucket (division-free: the bucket capacity is a power of two here), first digest vector of EVERY key
+  // ---- phase 1: hash, bucket (division-free: the bucket capacity is a power of two here), first digest vector of EVERY key;
+  //      bag marks from the window
   const int cshift = __builtin_ctzll((unsigned long long)a.t.C);
   const int Cm = (int)a.t.C - 1;
   int bq[PER], tq[PER];            // bucket (-1: key without a home), table
@@ -157,16 +158,56 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
     uint64_t r = x - __umul64hi(x, magic) * nb;
     if (r >= nb) r -= nb;
     if (r >= nb) r -= nb;
-    const bool ok = i < a.n && is_valid(key) && nb > 0;
+    const bool ok = li < tl && i < a.n && is_valid(key) && nb > 0;
     hq[q] = hash;
     bq[q] = ok ? (int)(bb + (int64_t)r) : -1;
     const int start = ((int)hash & Cm) & ~15;
     dvq[q] = *reinterpret_cast<const uint4*>(a.t.dig(ok ? bq[q] : 0) + start);   // unconditional: bucket 0 for homeless keys
   }
+  if constexpr (!kSeq) {
+    // a bag marks the tile position of its first key (a bag that began in an earlier tile: position 0); the window covers the
+    // tile iff its first bag starts at or before the tile and its end lies at or behind the tile's end
+    const int64_t nb = a.num_bags;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t b = (int64_t)wlo + h * THREADS + tid;
+      const int64_t o0 = wo[h][0], o1 = wo[h][1];
+      if (b < nb && o1 > o0 && o1 > tile0 && o0 < tile_end) s_bag[o0 > tile0 ? o0 - tile0 : 0] = (int)b;
+      if (h == 0 && tid == 0 && o0 > tile0) s_cover = 0;                                   // (offsets[0] = 0: bag 0 always covers)
+      if (b == (int64_t)wlo + WIN - 1 && b < nb - 1 && o1 < tile_end) s_cover = 0;          // the window ends inside the tile
+    }
+  }
   PST(2);
-  __syncthreads();   // A: s_key / s_t, the cleared hash
+  __syncthreads();   // A: s_key / s_t, the bag marks
   PST(3);
-  if (searcher) { s_consume(); s_issue(); }           // round 2 -> round 3
+  if constexpr (!kSeq) {
+    if (!s_cover) {    // (block uniform, rare) the guess missed: waves 0 / 1 search the tile's bag range, everybody marks from it
+      if (tid < 128) {
+        const int64_t skey = tid < 64 ? tile0 : tile_end - 1;
+        int lo = 0, hi = (int)a.num_bags;
+        while (hi > lo) {
+          const int step = (hi - lo + 63) >> 6;
+          const int64_t pi = (int64_t)lo + (int64_t)(lane + 1) * step - 1;
+          const bool gt = pi >= hi ? true : a.offsets[pi] > skey;
+          const uint64_t gm = __ballot(gt);
+          if (!gm) { lo = hi; break; }
+          const int first = __ffsll((unsigned long long)gm) - 1;
+          const int64_t nhi = (int64_t)lo + (int64_t)(first + 1) * step - 1;
+          lo = lo + first * step;
+          hi = nhi < hi ? (int)nhi : hi;
+        }
+        if (lane == 0) s_brange[wv] = lo - 1;
+      }
+      for (int k = tid; k < TILE; k += THREADS) s_bag[k] = -1;
+      __syncthreads();
+      const int blo = s_brange[0] < 0 ? 0 : s_brange[0], bhi = s_brange[1];
+      for (int b = blo + tid; b <= bhi; b += THREADS) {
+        const int64_t o0 = a.offsets[b], o1 = a.offsets[b + 1];
+        if (o1 > o0 && o1 > tile0 && o0 < tile_end) s_bag[o0 > tile0 ? o0 - tile0 : 0] = b;
+      }
+      __syncthreads();
+    }
+  }
   if constexpr (kMT) {
     if (tid < 64) {      // (T <= 128: two tables per lane of wave 0)
       const int l = tid;
@@ -187,14 +228,14 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
     }
   }
   // ---- phase 2: LDS dedup.  The entry's hash comes out of the table hash (bits above the digest); whoever claims the entry
-  //      represents the key.
+  //      represents the key.  Running maximum of the bag marks, first half (thread t owns the positions t PER ..).
   int hh[PER], rk[PER];
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
     const int li = q * THREADS + tid;
     hh[q] = -1;
     rk[q] = 0;
-    if (tile0 + li < a.n) {
+    if (li < tl && tile0 + li < a.n) {
       const uint64_t key = kreg[q];
       int h = (int)((uint32_t)((uint64_t)hq[q] >> 40) + (kMT ? (uint32_t)tq[q] * 0x9E3779B1u : 0u)) & (HASH - 1);
       while (true) {
@@ -209,25 +250,19 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
       rk[q] = atomicAdd(&s_cnt[h], 1);
     }
   }
-  if (searcher) {                                     // round 3 (and whatever a very long offsets array still needs)
-    s_consume();
-    while (shi > slo) { s_issue(); s_consume(); }
-    if (lane == 0) s_brange[wv] = slo - 1;
+  int bagv[PER], bag_incl = -1;
+  if constexpr (!kSeq) {
+    int m = -1;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { const int v = s_bag[tid * PER + k]; m = v > m ? v : m; bagv[k] = m; }
+    bag_incl = wave_incl_max(m);
+    if (lane == 63) s_wmax[wv] = bag_incl;
   }
   PST(4);
-  __syncthreads();   // B: the dedup, the tile's bag range
+  __syncthreads();   // B: the dedup, the waves' bag maxima
   PST(5);
-  // ---- phase 3: offsets of "my" bag of the range; representatives; list starts of the multi-occurrence keys (first half of a
-  //      block scan); the tile's histogram over the partitions; key words of the first two digest matches
-  int mb = 0;
-  int64_t mo0 = 0, mo1 = 0;
-  if constexpr (!kSeq) {
-    mb = s_brange[0] + tid;
-    int bc = mb <= s_brange[1] ? mb : s_brange[1];
-    bc = bc < 0 ? 0 : bc;
-    mo0 = a.offsets[bc];
-    mo1 = a.offsets[bc + 1];
-  }
+  // ---- phase 3: representatives; list starts of the multi-occurrence keys (first half of a block scan); the tile's histogram
+  //      over the partitions; key words of the first two digest matches; bags of all occurrences (second half of the scan)
   bool isrep[PER];
   int mcnt[PER], m_mine = 0;
 #pragma unroll
@@ -269,11 +304,20 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
     kc0[q] = ks[c0[q] >= 0 ? c0[q] : 0];
     kc1[q] = ks[c1[q] >= 0 ? c1[q] : (c0[q] >= 0 ? c0[q] : 0)];
   }
+  if constexpr (!kSeq) {
+    int bbase = -1;
+    for (int k = 0; k < wv; ++k) bbase = s_wmax[k] > bbase ? s_wmax[k] : bbase;
+    int prev = __shfl_up(bag_incl, 1, 64);
+    if (lane == 0) prev = -1;
+    prev = prev > bbase ? prev : bbase;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) s_bag[tid * PER + k] = bagv[k] > prev ? bagv[k] : prev;
+  }
   PST(6);
-  __syncthreads();   // C: the histogram, the wave sums
+  __syncthreads();   // C: the histogram, the wave sums, the bags; everybody has read the dedup's s_tab / s_cnt
   PST(7);
   // ---- phase 4: one returning atomic per (tile, partition) reserves the tile's records in the partition's list; list starts;
-  //      bag marks
+  //      the probe itself
   const int sub = kMT ? 0 : (int)blockIdx.x % kPartSub;
   int my_base[NPB];
 #pragma unroll
@@ -300,25 +344,6 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
       if (isrep[q]) s_sm[hh[q]] = (uint16_t)(mcnt[q] ? (st | 0x8000) : 0);
       st += mcnt[q];
     }
-  }
-  if constexpr (!kSeq) {
-    const int bhi = s_brange[1];
-    if (mb >= 0 && mb <= bhi && mo1 > mo0) { const int64_t pp = mo0 > tile0 ? mo0 - tile0 : 0; if (pp < TILE) s_bag[pp] = mb; }
-    for (int b = mb + THREADS; b <= bhi; b += THREADS) {      // (more bags than threads in the tile's range: empty / one-key bags)
-      const int64_t o0 = a.offsets[b], o1 = a.offsets[b + 1];
-      if (o1 > o0) { const int64_t pp = o0 > tile0 ? o0 - tile0 : 0; if (pp < TILE) s_bag[pp] = b; }
-    }
-  }
-  PST(8);
-  __syncthreads();   // D: the bag marks (and: everybody has read the dedup's s_tab / s_cnt)
-  // ---- phase 5: running maximum of the bag marks, first half (thread t owns the occurrences t PER ..); the probe itself
-  int bagv[PER], bag_incl = -1;
-  if constexpr (!kSeq) {
-    int m = -1;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) { const int v = s_bag[tid * PER + k]; m = v > m ? v : m; bagv[k] = m; }
-    bag_incl = wave_incl_max(m);
-    if (lane == 63) s_wmax[wv] = bag_incl;
   }
   int cnt_tile[PER];
 #pragma unroll
@@ -359,26 +384,16 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
       wave_init_row(a, rp, ((uint64_t)khi << 32) | klo, (int)a.table_emb_dims[t], (int)a.table_value_dims[t]);
     }
   }
-  PST(9);
-  __syncthreads();   // E: the records' slot codes, the waves' bag maxima
-  // ---- phase 6: bags of all occurrences (second half of the scan); the reserved bases
-  if constexpr (!kSeq) {
-    int bbase = -1;
-    for (int k = 0; k < wv; ++k) bbase = s_wmax[k] > bbase ? s_wmax[k] : bbase;
-    int prev = __shfl_up(bag_incl, 1, 64);
-    if (lane == 0) prev = -1;
-    prev = prev > bbase ? prev : bbase;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) s_bag[tid * PER + k] = bagv[k] > prev ? bagv[k] : prev;
-  }
 #pragma unroll
   for (int j = 0; j < NPB; ++j) {
     const int p = tid + j * THREADS;
     if (p < a.P) s_hist[p] = my_base[j];
   }
-  __syncthreads();   // F
+  PST(8);
+  __syncthreads();   // D: the records' slot codes, the reserved bases
+  PST(9);
   PST(10);
-  // ---- phase 7: records (by the representatives) and the per-occurrence arrays
+  // ---- phase 5: records (by the representatives) and the per-occurrence arrays
   constexpr int kListCap = kMT ? kPartCap : kSubCap;
 #pragma unroll
   for (int q = 0; q < PER; ++q) {

@@ -572,37 +572,69 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         return so
 
     # ---------------------------------------------------------------------------------- table growth
+    def _grow_target(self, incoming: int):
+        """capacities the tables should have for their fill (as of the last completed read-back) + `incoming` keys, or None"""
+        tb = self.table
+        if getattr(self, "_fill_event", None) is None or not self._fill_event.query():
+            return None
+        sizes = self._fill_host.tolist()
+        lf = self._dynamicemb_options[0].max_load_factor
+        caps = list(tb.per_table_capacity_)
+        new_caps = list(caps)
+        per_table_in = incoming / max(self.num_tables, 1)
+        for t in range(self.num_tables):
+            while new_caps[t] < self._max_caps[t] and (sizes[t] + per_table_in) / new_caps[t] > lf:
+                new_caps[t] = min(2 * new_caps[t], self._max_caps[t])
+        return new_caps if new_caps != caps else None
+
     def _maybe_grow(self, incoming: int) -> None:
         """Grow the tables whose fill (as of the previous step: the sizes travel to pinned memory asynchronously, no sync on
-        the step) plus the incoming keys passes max_load_factor: capacity doubles, by rehash, up to max_capacity."""
+        the step) plus the incoming keys passes max_load_factor: capacity doubles, by rehash, up to max_capacity.  A rehash
+        moves every row, so it needs a point where no step holds slots / row addresses of the current table: with steps in
+        flight it is DEFERRED to the first backward that leaves none (_grow_at_safe_point) -- under the prefetch pipeline that
+        point still has the NEXT batch queued, whose prefetch is then dropped and re-resolved against the grown table."""
         tb = self.table
-        if getattr(self, "_fill_event", None) is not None and self._fill_event.query():
-            sizes = self._fill_host.tolist()
-            lf = self._dynamicemb_options[0].max_load_factor
-            caps = list(tb.per_table_capacity_)
-            new_caps = list(caps)
-            per_table_in = incoming / max(self.num_tables, 1)
-            for t in range(self.num_tables):
-                while new_caps[t] < self._max_caps[t] and (sizes[t] + per_table_in) / new_caps[t] > lf:
-                    new_caps[t] = min(2 * new_caps[t], self._max_caps[t])
-            if new_caps != caps:
-                if not self._prefetch_states and len(self._live_steps) == 0:
-                    self._expand(new_caps)
-                    tb = self.table
-                    self._grow_deferred = False
-                else:
-                    if not self._grow_deferred and getattr(self, "_grow_skips", 0) == 64:
-                        import warnings
+        new_caps = self._grow_target(incoming)
+        if new_caps is not None:
+            if not self._prefetch_states and len(self._live_steps) == 0:
+                self._expand(new_caps)
+                tb = self.table
+                self._grow_deferred = False
+                self._grow_skips = 0
+            else:
+                self._grow_skips = getattr(self, "_grow_skips", 0) + 1   # consecutive deferrals (reset by a successful expand)
+                if self._grow_skips == 64:
+                    import warnings
 
-                        warnings.warn("DynamicEmb: table growth has been waiting for live / prefetched steps for 64 steps "
-                                      "(rows evict at max capacity of the current size until a step boundary is free)")
-                    self._grow_skips = getattr(self, "_grow_skips", 0) + 1
-                    self._grow_deferred = True     # retried at the end of the next backward that leaves no step alive
+                    warnings.warn("DynamicEmb: table growth has been waiting for live / prefetched steps for 64 steps "
+                                  "(rows evict at max capacity of the current size until a step boundary is free)")
+                self._grow_deferred = True     # retried at the end of the next backward that leaves no forward alive
         if getattr(self, "_fill_host", None) is None:
             self._fill_host = torch.zeros(self.num_tables, dtype=torch.int64).pin_memory()
         self._fill_host.copy_(ext.segmented_sum_cuda(tb.bucket_sizes, tb.table_bucket_offsets_), non_blocking=True)
         self._fill_event = torch.cuda.Event()
         self._fill_event.record(current_torch_stream())
+
+    def _grow_at_safe_point(self) -> None:
+        """A deferred growth, at the end of a backward that leaves no forward waiting for its backward.  Batches that are only
+        PREFETCHED (queued, not yet forwarded) hold slots of the table that is about to be replaced: they are dropped and
+        prefetched again against the grown table (their keys travel with the state), so the prefetch pipeline -- which always
+        has the next batch queued at this point -- grows too (round-4 advisor finding: it never did)."""
+        if getattr(self, "_fill_event", None) is not None:
+            self._fill_event.synchronize()
+        new_caps = self._grow_target(0)
+        if new_caps is None:
+            self._grow_deferred = False
+            return
+        queued = [(st.indices, st.offsets) for st in self._prefetch_states]
+        if any(ind is None for ind, _ in queued):
+            return                                   # (a state without its keys cannot be re-resolved: keep waiting)
+        self.reset_prefetch()
+        self._expand(new_caps)
+        self._grow_deferred = False
+        self._grow_skips = 0
+        for ind, off in queued:
+            self.prefetch(ind, off)
 
     def _expand(self, new_caps) -> None:
         """rehash into a table of `new_caps` rows per table (key_value_table.py:559-666: export, re-insert with the stored
@@ -1317,8 +1349,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         finally:
             # a growth that had to wait for live / prefetched steps (under the prefetch pipeline one always exists when
             # _maybe_grow runs) is retried at the first safe point: here, when none is left
-            if self._grow_deferred and not self._prefetch_states and len(self._live_steps) == 0:
-                self._maybe_grow(0)
+            if self._grow_deferred and len(self._live_steps - set(self._prefetch_states)) == 0:
+                self._grow_at_safe_point()
 
     def _backward_impl_inner(self, st, grads: torch.Tensor):
         if isinstance(st, _FusedStep):

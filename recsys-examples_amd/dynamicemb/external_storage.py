@@ -294,6 +294,8 @@ class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
         nu = int(st.uoff[-1].item())
         st.row_addr = torch.zeros(max(n, 1), dtype=torch.int64, device=dev)
         keep = []          # buffers the row addresses point into (alive until the gather has been queued / the backward has run)
+        pins = []          # (slots, table ids) of the cache rows this training step holds: pinned until its backward
+        self._drain_cache_orphans()
         if nu > 0:
             uk = ukeys[:nu].contiguous()
             tids = ext.expand_table_ids_cuda(st.uoff, nu)
@@ -307,6 +309,10 @@ class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
             if hit0.numel():
                 addr[hit0] = ext.row_addresses(s0[hit0], tids[hit0], c.table_ptrs, c.table_value_dims, eb)
             miss = (~f0).nonzero().squeeze(1)
+            if train and not miss.numel() and hit0.numel():     # (every key cached: the pins of the step are its hits)
+                hs, ht = s0[hit0].contiguous(), tids[hit0].contiguous()
+                c.table.increment_counter(hs, ht)
+                pins.append((hs, ht))
             if miss.numel():
                 k1, t1 = uk[miss].contiguous(), tids[miss].contiguous()
                 fr1 = st.csr_cnt[:nu].to(torch.int64)[miss].contiguous() if need_freq else None
@@ -318,11 +324,16 @@ class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
                         midx = midx.to(torch.int64).contiguous()
                         self._init_padded_rows(vals, midx, mkeys, mtids if mtids is not None else t1[midx])
                     insn = ScoreArg("score", None if isc is None else isc[:nu][miss].contiguous(), ip)
-                    if hit0.numel():   # rows the batch found in the cache must not be evicted by the batch's own inserts
-                        c.table.increment_counter(s0[hit0].contiguous(), tids[hit0].contiguous())
-                    idxn, h, ek, ei, es, et = c.table.insert_and_evict(k1, t1, insn)
+                    # rows the batch found in the cache must not be evicted by the batch's own inserts -- nor, while this step
+                    # waits for its backward, by a LATER forward's (a shared module called twice, gradient accumulation: the later
+                    # step would evict a row whose address this step still holds, write the stale row back, and this step's
+                    # backward would then update a slot that belongs to another key -- round-4 advisor finding).  The pins taken
+                    # here are kept until _backward_cached (st.cache_pins); the inserted rows join them below.
                     if hit0.numel():
-                        c.table.decrement_counter(s0[hit0].contiguous(), tids[hit0].contiguous())
+                        hs, ht = s0[hit0].contiguous(), tids[hit0].contiguous()
+                        c.table.increment_counter(hs, ht)
+                        pins.append((hs, ht))
+                    idxn, h, ek, ei, es, et = c.table.insert_and_evict(k1, t1, insn)
                     if h:
                         ev = (ei >= 0).nonzero().squeeze(1)     # real evictions (negative entries mark refused inputs)
                         if ev.numel():   # the evicted rows go back to the store before anything overwrites them
@@ -333,6 +344,9 @@ class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
                             self._storage.insert(e_k, e_t, buf_ev, e_sc.to(torch.int64))
                     ok = (idxn >= 0).nonzero().squeeze(1)
                     if ok.numel():
+                        os_, ot_ = idxn[ok].contiguous(), t1[ok].contiguous()
+                        c.table.increment_counter(os_, ot_)
+                        pins.append((os_, ot_))
                         ext.store_to_flat_table_value(c.table_ptrs, idxn[ok].contiguous(), t1[ok].contiguous(), vals[ok].contiguous(),
                                                       c.table_value_dims, c.table_emb_dims, self.max_D, True)
                         addr[miss[ok]] = ext.row_addresses(idxn[ok].contiguous(), t1[ok].contiguous(), c.table_ptrs,
@@ -373,7 +387,28 @@ class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
         if not train:
             return out, None
         self._step += 1
+        if pins:
+            # a step that dies without its backward hands its pins to the module (released at the next forward, on a stream of
+            # ours -- never from the garbage collector)
+            import weakref
+
+            cell = [pins]
+            st.pin_cell = cell
+            weakref.finalize(st, ExternalStorageTables._orphan_cache_step, weakref.ref(self), cell)
         return out, st
+
+    @staticmethod
+    def _orphan_cache_step(module_ref, cell) -> None:
+        m = module_ref()
+        if m is not None and cell[0] is not None:
+            m._cache_orphans.append(cell[0])
+            cell[0] = None
+
+    def _drain_cache_orphans(self) -> None:
+        orphans = self.__dict__.setdefault("_cache_orphans", [])
+        while orphans:
+            for slots, tids in orphans.pop():
+                self._cache.table.decrement_counter(slots, tids)
 
     def _backward_cached(self, st, grads: torch.Tensor):
         if st is None:
@@ -381,6 +416,11 @@ class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
         c = self._cache
         self._sync_cache_hparams()
         c._backward_impl_inner(st, grads)
+        cell = getattr(st, "pin_cell", None)
+        if cell is not None and cell[0] is not None:       # the step's rows may be evicted again
+            for slots, tids in cell[0]:
+                c.table.decrement_counter(slots, tids)
+            cell[0] = None
         self._iter_num = c._iter_num
         if st.scratch is not None:     # the rows the cache refused: trained in place in the spill buffer, now the store's again
             spill, sp_ptrs, rows, keys, tids, width, sc = st.scratch

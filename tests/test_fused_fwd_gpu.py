@@ -128,7 +128,7 @@ def test_csr_writing_partition_kernel_against_the_per_op_chain_around_its_size_l
                                    rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3"])
 @pytest.mark.parametrize("pooling,bags,bucket", [("SUM", 60_000, 128), ("NONE", 150_000, 128), ("SUM", 40_000, 16)])
 def test_every_tile_shape_of_the_round5_probe_kernel_against_the_per_op_chain(variant, pooling, bags, bucket, monkeypatch):
     """probe_c_kernel (csrc/probe_c.h; MI355_PROBE_C picks the tile shape, 0 = the round-3 kernel) against the per-op chain:

@@ -1021,6 +1021,63 @@ def test_external_storage_mixed_dims_and_hbm_cache(caching, pooling, optimizer, 
         torch.testing.assert_close(dut(ek, eo), ref(ek, eo), rtol=1e-6, atol=1e-6)
 
 
+def test_external_storage_cache_keeps_the_rows_of_a_step_until_its_backward():
+    """`caching=True` with TWO training forwards in flight (a shared module called twice / gradient accumulation): the second
+    forward's inserts must not evict a cache row whose address the first step still holds (round-4 advisor finding: the stale
+    row went back to the store and the first backward updated a slot that by then belonged to another key).  The steps' rows
+    stay pinned until their backward; keys the cache then refuses are trained in the spill buffer.  Checked against the HBM-only
+    module driven in the same order: same outputs, same rows in the store after flush()."""
+    from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
+    from dynamicemb.dynamicemb_config import (DynamicEmbInitializerArgs, DynamicEmbInitializerMode, DynamicEmbPoolingMode,
+                                              DynamicEmbScoreStrategy, DynamicEmbTableOptions, EmbOptimType)
+
+    rng = np.random.default_rng(31)
+    dims, fmap = [8], [0]
+    B = 100
+
+    def make(store):
+        kw = dict(external_storage=store, caching=True, local_hbm_for_values=1024) if store is not None else {}
+        opts = [DynamicEmbTableOptions(dim=d, max_capacity=4096, index_type=torch.int64, embedding_dtype=torch.float32,
+                                       score_strategy=DynamicEmbScoreStrategy.STEP,
+                                       initializer_args=DynamicEmbInitializerArgs(mode=DynamicEmbInitializerMode.UNIFORM, lower=-0.3, upper=0.3),
+                                       **kw) for d in dims]
+        m = BatchedDynamicEmbeddingTablesV2(opts, feature_table_map=fmap, pooling_mode=DynamicEmbPoolingMode.SUM,
+                                            output_dtype=torch.float32, optimizer=EmbOptimType.SGD, learning_rate=0.05,
+                                            device=torch.device("cuda", 0))
+        m.train()
+        return m
+
+    ref, dut = make(None), make(_DictStore)
+    cap = int(dut._cache.table.per_table_capacity_[0])       # one 128-row bucket: two batches of ~90 distinct keys do not fit
+
+    def batch(lo):
+        keys = torch.from_numpy(rng.integers(lo, lo + 300, B).astype(np.int64)).cuda()
+        return keys, torch.arange(0, B + 1, dtype=torch.int64, device="cuda")
+
+    for it in range(6):
+        (k1, o1), (k2, o2) = batch(0), batch(150)            # overlapping key ranges: shared rows, plus more rows than the cache holds
+        assert int(torch.unique(torch.cat([k1, k2])).numel()) > cap
+        outs = []
+        for m in (ref, dut):
+            a1 = m(k1, o1)
+            a2 = m(k2, o2)                                   # second forward BEFORE the first backward
+            outs.append((a1, a2))
+        torch.testing.assert_close(outs[1][0], outs[0][0], rtol=1e-6, atol=1e-6, msg=f"iteration {it}, first forward")
+        torch.testing.assert_close(outs[1][1], outs[0][1], rtol=1e-6, atol=1e-6, msg=f"iteration {it}, second forward")
+        g1, g2 = torch.randn_like(outs[0][0]), torch.randn_like(outs[0][1])
+        for a1, a2 in outs:
+            a1.backward(g1)
+            a2.backward(g2)
+        torch.cuda.synchronize()
+        assert int(dut._cache.table._ref_counter.abs().sum()) == 0, "pins left behind after both backwards"
+    dut.flush()
+    assert dut.size() == int(ref.size())
+    probe = torch.arange(0, 450, device="cuda", dtype=torch.int64)
+    f1, r1 = ref.lookup_rows(probe, 0)
+    for k in probe[f1].tolist():
+        torch.testing.assert_close(dut.storage.rows[(0, k)][:dims[0]], r1[k][:dims[0]], rtol=1e-5, atol=1e-6)
+
+
 def test_external_storage_dump_and_load_go_through_the_store(tmp_path):
     """dump() / load() of a module over an external store hand the reference's per-table file names to Storage.dump / Storage.load
     (batched_dynamicemb_tables.py:73-92): a second module over a fresh store serves the same rows after load()."""

@@ -228,6 +228,44 @@ def test_checkpoint_files_against_the_dict_twin(tmp_path, optimizer):
     _check_rows(fresh, twin, hi)
 
 
+def test_table_grows_under_the_prefetch_pipeline_order():
+    """The reference's pipeline order -- prefetch(batch k + 1) before forward / backward of batch k (train_pipeline.py:533-692) --
+    always has a batch queued when a growth is due (round-4 advisor finding: the table then never grew and evicted silently).
+    Now the deferred growth runs at the end of the backward that leaves no forward alive; the queued batch's prefetch is dropped
+    and re-resolved against the grown table.  Checked against the dict twin: nothing is evicted, every key keeps its row."""
+    from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
+    from dynamicemb.dynamicemb_config import (DynamicEmbInitializerArgs, DynamicEmbInitializerMode, DynamicEmbPoolingMode,
+                                              DynamicEmbScoreStrategy, DynamicEmbTableOptions, EmbOptimType)
+
+    dims, fmap, F, B, lr = [8], [0], 1, 96, 0.05
+    opts = [DynamicEmbTableOptions(dim=d, init_capacity=256, max_capacity=16384, max_load_factor=0.5, index_type=torch.int64,
+                                   embedding_dtype=torch.float32, score_strategy=DynamicEmbScoreStrategy.STEP,
+                                   initializer_args=DynamicEmbInitializerArgs(mode=DynamicEmbInitializerMode.DEBUG)) for d in dims]
+    m = BatchedDynamicEmbeddingTablesV2(opts, feature_table_map=fmap, pooling_mode=DynamicEmbPoolingMode.SUM,
+                                        output_dtype=torch.float32, optimizer=EmbOptimType.SGD, learning_rate=lr, device=DEV)
+    m.train()
+    twin = DictEmbeddingTwin(dims, fmap, "SUM", "sgd", lr=lr)
+    rng = np.random.default_rng(21)
+    batches = [_batch(rng, F, B, 150 * (k + 1)) for k in range(26)]
+    dev = [(torch.from_numpy(k).to(DEV), torch.from_numpy(o).to(DEV)) for k, o in batches]
+    m.prefetch(*dev[0])
+    caps_seen = set()
+    for k in range(len(dev)):
+        if k + 1 < len(dev):
+            m.prefetch(*dev[k + 1])
+        out, st = m._forward_impl(*dev[k], train=True)
+        ref = twin.forward(batches[k][0], batches[k][1], True)
+        np.testing.assert_allclose(out.double().cpu().numpy(), ref, rtol=1e-6, atol=1e-3, err_msg=f"step {k}")
+        g = rng.uniform(0.1, 1.1, size=ref.shape).astype(np.float32)
+        m._backward_impl(st, torch.from_numpy(g).to(DEV))
+        twin.backward(g)
+        torch.cuda.synchronize()
+        caps_seen.add(tuple(m.table.per_table_capacity_))
+    assert len(caps_seen) >= 3 and max(caps_seen)[0] >= 2048, caps_seen
+    _check_rows(m, twin, 150 * 26)
+    assert int(m.size()) == sum(len(t) for t in twin.tables)      # nothing evicted on the way
+
+
 def test_table_growth_by_rehash_against_the_dict_twin():
     """init_capacity 256 -> max_capacity 16384 (key_value_table.py:559-666): the table doubles by rehash when its fill
     passes max_load_factor; every key keeps its row and optimizer state across the moves, the value buffer keeps its base

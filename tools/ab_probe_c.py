@@ -1,5 +1,5 @@
 """A/B of the probe kernels of path (c) inside ONE process on the C2 workload (MI355_PROBE_C is read per call under
-MI355_ENV_LIVE=1): 0 = the round-3 kernel, 1..4 = probe_c_kernel tile shapes.  Steps are timed in interleaved rounds; the pooled
+MI355_ENV_LIVE=1): 0 = the round-3 kernel, 1 = probe_c_kernel (one block per CU), 2 = its two-keys-per-thread form, 3 = full 1024-key tiles.  Steps are timed in interleaved rounds; the pooled
 output of every variant must be bit-identical to variant 0's on the same batch.
     python tools/ab_probe_c.py [--rounds 4] [--variants 0,1,2,3,4]"""
 import argparse, os, sys, time
@@ -11,7 +11,7 @@ import bench
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=4)
-ap.add_argument("--variants", default="0,1,2,3,4")
+ap.add_argument("--variants", default="0,1,2,3")
 ap.add_argument("--batch", type=int, default=65536)
 a = ap.parse_args()
 variants = a.variants.split(",")
