@@ -87,9 +87,16 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
       wo[h][1] = a.offsets[bc + 1];
     }
   }
+  // (one table: its scalars come in through the VECTOR memory path -- an index the compiler cannot see is zero --, because as
+  //  uniform scalar loads they share the wave's LDS counter and the first barrier, which waits for the LDS initialisation, waited
+  //  for their round trip as well: 2.6 us in front of barrier 0, profiles/r05_index_phase_stamps_1cu_a.txt)
   int64_t m_tbo0 = 0, m_tbo1 = 0, m_tptr0 = 0;
   int m_rowb0 = 0;
-  if constexpr (!kMT) { m_tbo0 = a.tbo[0]; m_tbo1 = a.tbo[1]; m_tptr0 = a.table_ptrs[0]; m_rowb0 = (int)a.table_value_dims[0] * a.elem_bytes; }
+  if constexpr (!kMT) {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    m_tbo0 = a.tbo[z]; m_tbo1 = a.tbo[z + 1]; m_tptr0 = a.table_ptrs[z]; m_rowb0 = (int)a.table_value_dims[z] * a.elem_bytes;
+  }
   auto tbo_of = [&](int t) -> int64_t { if constexpr (!kMT) return t == 0 ? m_tbo0 : m_tbo1; else return s_tbo[t]; };
   auto tptr_of = [&](int t) -> int64_t { if constexpr (!kMT) return m_tptr0; else return s_tptr[t]; };
   auto rowb_of = [&](int t) -> int { if constexpr (!kMT) return m_rowb0; else return s_rowb[t]; };
@@ -132,7 +139,7 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
   //      bag marks from the window
   const int cshift = __builtin_ctzll((unsigned long long)a.t.C);
   const int Cm = (int)a.t.C - 1;
-  int bq[PER], tq[PER];            // bucket (-1: key without a home), table
+  int bq[PER], tq[PER], pkq[PER];  // bucket (-1: key without a home), table, partition of the key's bucket
   int64_t hq[PER];
   uint4 dvq[PER];
 #pragma unroll
@@ -161,6 +168,7 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
     const bool ok = li < tl && i < a.n && is_valid(key) && nb > 0;
     hq[q] = hash;
     bq[q] = ok ? (int)(bb + (int64_t)r) : -1;
+    if constexpr (!kMT) pkq[q] = bq[q] < 0 ? a.P - 1 : (int)((uint32_t)bq[q] / (uint32_t)(a.spp >> cshift));
     const int start = ((int)hash & Cm) & ~15;
     dvq[q] = *reinterpret_cast<const uint4*>(a.t.dig(ok ? bq[q] : 0) + start);   // unconditional: bucket 0 for homeless keys
   }
@@ -229,18 +237,23 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
   }
   // ---- phase 2: LDS dedup.  The entry's hash comes out of the table hash (bits above the digest); whoever claims the entry
   //      represents the key.  Running maximum of the bag marks, first half (thread t owns the positions t PER ..).
-  int hh[PER], rk[PER];
+  //      The claimer also counts the pair in the tile's histogram over the partitions (the partition follows from the BUCKET,
+  //      known since phase 1): the histogram is complete at barrier B, so the global reservation goes out right behind it and
+  //      its round trip -- 65 K returning device atomics, ~6 us when they all queue at once -- runs under phases 3 and 4.
+  int hh[PER], rk[PER], lpq[PER];
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
     const int li = q * THREADS + tid;
     hh[q] = -1;
     rk[q] = 0;
+    lpq[q] = -1;
     if (li < tl && tile0 + li < a.n) {
       const uint64_t key = kreg[q];
       int h = (int)((uint32_t)((uint64_t)hq[q] >> 40) + (kMT ? (uint32_t)tq[q] * 0x9E3779B1u : 0u)) & (HASH - 1);
+      bool claimed = false;
       while (true) {
         const int cur = atomicCAS(&s_tab[h], -1, li);
-        if (cur == -1) break;
+        if (cur == -1) { claimed = true; break; }
         bool same = s_key[cur] == key;
         if constexpr (kMT) same = same && s_t[cur] == (uint16_t)tq[q];
         if (same) break;
@@ -248,6 +261,7 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
       }
       hh[q] = h;
       rk[q] = atomicAdd(&s_cnt[h], 1);
+      if constexpr (!kMT) { if (claimed) lpq[q] = pkq[q] * 4096 + atomicAdd(&s_hist[pkq[q]], 1); }
     }
   }
   int bagv[PER], bag_incl = -1;
@@ -274,21 +288,37 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
   }
   const int m_incl = wave_incl_scan(m_mine);
   if (lane == 63) s_wsum[wv] = m_incl;
-  int lpq[PER];
+  const int sub = kMT ? 0 : (int)blockIdx.x % kPartSub;
+  int my_base[NPB];
+  auto reserve = [&]() {   // one returning atomic per (tile, partition) reserves the tile's records in the partition's list
 #pragma unroll
-  for (int q = 0; q < PER; ++q) {
-    lpq[q] = 0;
-    if (isrep[q]) {
-      int pk;
-      if constexpr (kMT) {   // the table's partitions split its bucket range evenly; keys without a home: its last partition
+    for (int j = 0; j < NPB; ++j) {
+      const int p = tid + j * THREADS;
+      my_base[j] = 0;
+      if (p < a.P) {
+        const int c = s_hist[p];
+        if (c) my_base[j] = atomicAdd(&a.pcount[p * kPartSub + sub], c);
+        if constexpr (kMT) {
+          if (blockIdx.x == 0) {   // the partition kernel learns its table from here
+            int t = 0;
+            while (t + 1 < T && s_pb[t + 1] <= p) ++t;
+            a.ptab[p] = t;
+          }
+        }
+      }
+    }
+  };
+  if constexpr (!kMT) reserve();
+  if constexpr (kMT) {   // several tables: the partition of a pair needs the tables' partition ranges (wave 0, behind barrier A)
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      if (isrep[q]) {   // the table's partitions split its bucket range evenly; keys without a home: its last partition
         const int t = tq[q];
         const int p0 = s_pb[t], p1 = s_pb[t + 1];
         const int x = bq[q] < 0 ? p1 - p0 - 1 : (int)(((uint64_t)((int64_t)bq[q] - s_tbo[t]) * s_psc[t]) >> 32);
-        pk = p0 + (x < p1 - p0 ? x : p1 - p0 - 1);
-      } else {
-        pk = bq[q] < 0 ? a.P - 1 : (int)((uint32_t)bq[q] / (uint32_t)(a.spp >> cshift));
+        const int pk = p0 + (x < p1 - p0 ? x : p1 - p0 - 1);
+        lpq[q] = pk * 4096 + atomicAdd(&s_hist[pk], 1);
       }
-      lpq[q] = pk * 4096 + atomicAdd(&s_hist[pk], 1);
     }
   }
   uint64_t kc0[PER], kc1[PER];
@@ -316,26 +346,8 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
   PST(6);
   __syncthreads();   // C: the histogram, the wave sums, the bags; everybody has read the dedup's s_tab / s_cnt
   PST(7);
-  // ---- phase 4: one returning atomic per (tile, partition) reserves the tile's records in the partition's list; list starts;
-  //      the probe itself
-  const int sub = kMT ? 0 : (int)blockIdx.x % kPartSub;
-  int my_base[NPB];
-#pragma unroll
-  for (int j = 0; j < NPB; ++j) {
-    const int p = tid + j * THREADS;
-    my_base[j] = 0;
-    if (p < a.P) {
-      const int c = s_hist[p];
-      if (c) my_base[j] = atomicAdd(&a.pcount[p * kPartSub + sub], c);
-      if constexpr (kMT) {
-        if (blockIdx.x == 0) {   // the partition kernel learns its table from here
-          int t = 0;
-          while (t + 1 < T && s_pb[t + 1] <= p) ++t;
-          a.ptab[p] = t;
-        }
-      }
-    }
-  }
+  // ---- phase 4: list starts; the probe itself (several tables: the reservation goes out here)
+  if constexpr (kMT) reserve();
   {
     int st = m_incl - m_mine;
     for (int k = 0; k < wv; ++k) st += s_wsum[k];

@@ -601,6 +601,12 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                 tb = self.table
                 self._grow_deferred = False
                 self._grow_skips = 0
+            elif len(self._live_steps - set(self._prefetch_states)) == 0 and not getattr(self, "_regrowing", False):
+                # only QUEUED prefetches hold the table (the usual state when the pipeline prefetches batch k + 1: batch k is
+                # prefetched, not forwarded yet): grow NOW, before this batch's unseen keys are inserted into a table that is
+                # too small for them (they would evict), and resolve the queued batches again
+                self._grow_at_safe_point(new_caps)
+                tb = self.table
             else:
                 self._grow_skips = getattr(self, "_grow_skips", 0) + 1   # consecutive deferrals (reset by a successful expand)
                 if self._grow_skips == 64:
@@ -615,14 +621,15 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         self._fill_event = torch.cuda.Event()
         self._fill_event.record(current_torch_stream())
 
-    def _grow_at_safe_point(self) -> None:
+    def _grow_at_safe_point(self, new_caps=None) -> None:
         """A deferred growth, at the end of a backward that leaves no forward waiting for its backward.  Batches that are only
         PREFETCHED (queued, not yet forwarded) hold slots of the table that is about to be replaced: they are dropped and
         prefetched again against the grown table (their keys travel with the state), so the prefetch pipeline -- which always
         has the next batch queued at this point -- grows too (round-4 advisor finding: it never did)."""
-        if getattr(self, "_fill_event", None) is not None:
-            self._fill_event.synchronize()
-        new_caps = self._grow_target(0)
+        if new_caps is None:
+            if getattr(self, "_fill_event", None) is not None:
+                self._fill_event.synchronize()
+            new_caps = self._grow_target(0)
         if new_caps is None:
             self._grow_deferred = False
             return
@@ -633,8 +640,12 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         self._expand(new_caps)
         self._grow_deferred = False
         self._grow_skips = 0
-        for ind, off in queued:
-            self.prefetch(ind, off)
+        self._regrowing = True                       # (the re-resolved batches must not start another growth under this one)
+        try:
+            for ind, off in queued:
+                self.prefetch(ind, off)
+        finally:
+            self._regrowing = False
 
     def _expand(self, new_caps) -> None:
         """rehash into a table of `new_caps` rows per table (key_value_table.py:559-666: export, re-insert with the stored

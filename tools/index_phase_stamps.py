@@ -82,10 +82,7 @@ def dump(fn, nblk, nph, names, title, nlive=None):
         print("   end   percentiles (us):", " ".join(f"{np.percentile(en, q):.1f}" for q in qs))
 
 
-PROBE_C = ["start -> loads issued, LDS init, search round 1 consumed", "hash + bucket + digest prefetch issue", "wait: barrier A",
-           "LDS dedup (+ search rounds 2, 3)", "wait: barrier B", "reps, list starts, partition hist, 2 key words issued",
-           "wait: barrier C", "reservation atomic, s_sm, bag marks", "barrier D + bag scan half 1 + probe resolve + scores",
-           "barrier E + bag scan half 2 + bases + barrier F", "records + per-occurrence outputs"]
+PROBE_C = ['start -> loads issued + LDS init + barrier 0', 'hash + bucket + digest prefetch issue + bag marks', 'wait: barrier A', 'LDS dedup (+ pair histogram) + bag scan half 1', 'wait: barrier B', 'reservation issued, reps, list starts, 2 key words issued, bag scan half 2', 'wait: barrier C', 'list starts, probe resolve, scores, reserved bases', 'wait: barrier D', '-', 'records + per-occurrence outputs']
 if os.environ.get("MI355_PROBE_C", "1") != "0":
     dump("mi355_debug_stamps_probe", 1024, 12, PROBE_C, "probe_c_kernel")
 else:
