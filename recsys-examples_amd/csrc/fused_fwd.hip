@@ -53,7 +53,8 @@ constexpr int kPartCap = 2048;      // (tile, key) records per partition
 constexpr int kPartSub = 4;         // sub-lists per partition (tile % kPartSub picks one): same-address atomics serialise at
                                     // ~40 ns each, 176 tiles on ONE counter per partition is a 7 us chain, on four 1.8 us
 constexpr int kSubCap = kPartCap / kPartSub;
-constexpr int kAuxHdr = 64 + kPartMax * 4;   // ints in front of the occ array: [0] deferred keys, [1..] grid barrier, [5] sticky
+constexpr int kAuxHdr = 64 + 4096 * 4;     // (4 096 = kPartMaxBig partitions of the big-batch stage, round 5; 1 024 before)
+// constexpr int kAuxHdr_r4 = 64 + kPartMax * 4;   // ints in front of the occ array: [0] deferred keys, [1..] grid barrier, [5] sticky
                                     // error flag of the partitioned stage, [64 + 4 p + r] records of sub-list r of partition p (zero between steps)
 
 struct FusedArgs {
@@ -119,6 +120,12 @@ struct FusedArgs {
   int ovf_word, ovf_val;          // where / what the partitioned probe writes when a record list overflows
   int* rerun_mark;                // nullable: cleared by block 0 of the partitioned probe, set by the re-run chain's last kernel
   int tl;                         // probe_c_kernel (round 5): keys of a tile, a run-time value (<= the kernel's capacity, multiple of 64)
+  // big-batch stage (round 5, big_index.h): the probe kernel leaves its records TILE-MAJOR -- no reservation at all -- and a split
+  // kernel moves them into the partitions' lists; a per-record forwarding entry keeps the per-occurrence references valid
+  uint4* stage_rec;               // [n] records of tile t at [t * tl, t * tl + tile_cnt[t])
+  int32_t* tile_cnt;              // [tiles]
+  int32_t* fwd;                   // [n] staged record -> its place in `rec` (-1: the partition's list was full)
+  int cap;                        // records per partition of `rec` (kPartCap, or kPartCapBig in the big-batch stage)
 };
 
 __device__ __forceinline__ void store_digest(uint8_t* p, uint8_t d) {
@@ -1490,31 +1497,35 @@ fused_part_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, bo
 //  (Measured and rejected in round 3: the partition blocks riding in the gather's launch.  The gather's throughput is
 //   proportional to its resident waves -- 4.6 us per bag and lane group whatever the occupancy -- and the partition code's 79
 //   registers / 24 KB of LDS take a quarter of them: 54-60 us for the fused launch against 21 + 30 us apart.)
-constexpr int kP2Hash = kPartCap;      // a partition holds at most kPartCap records, hence at most as many distinct slots
+// The partition kernel of path (c) is a template over the record capacity of a partition (round 5): 2 048 for batches up to
+// 1 M keys (the probe kernel's reservation lists), 4 096 for the partitions of the big-batch stage (big_index.h).  A partition
+// holds at most CAP records, hence at most as many distinct slots: the LDS hash has CAP entries.
 constexpr int kP3Threads = 1024;
-constexpr int kP3Items = kPartCap / kP3Threads;
-constexpr int kP3Ent = kP2Hash / kP3Threads;
 constexpr int kRecLate = 1 << 30;      // count word of a record whose key took the eviction path
+constexpr int kPartCapBig = 4096;      // records per partition of the big-batch stage
+constexpr int kPartMaxBig = 4096;      // its partitions
 
-__device__ __forceinline__ int p2_hash(int slot) { return (int)((uint32_t)slot * 2654435761u >> 21) & (kP2Hash - 1); }
+template <int HASH> __device__ __forceinline__ int p2_hash(int slot) { return (int)((uint32_t)slot * 2654435761u >> (32 - __builtin_ctz(HASH))) & (HASH - 1); }
+template <int HASH>
 __device__ __forceinline__ int p2_find(const int* h_slot, int slot) {   // -1: not present
-  int h = p2_hash(slot);
-  for (int n = 0; n < kP2Hash; ++n) {
+  int h = p2_hash<HASH>(slot);
+  for (int n = 0; n < HASH; ++n) {
     const int cur = h_slot[h];
     if (cur == slot) return h;
     if (cur == -1) return -1;
-    h = (h + 1) & (kP2Hash - 1);
+    h = (h + 1) & (HASH - 1);
   }
   return -1;
 }
+template <int HASH>
 __device__ __forceinline__ int p2_insert(int* h_slot, int slot, bool* claimed) {
-  int h = p2_hash(slot);
+  int h = p2_hash<HASH>(slot);
   *claimed = false;
   while (true) {
     const int cur = atomicCAS(&h_slot[h], -1, slot);
     if (cur == -1) { *claimed = true; return h; }
     if (cur == slot) return h;
-    h = (h + 1) & (kP2Hash - 1);
+    h = (h + 1) & (HASH - 1);
   }
 }
 
@@ -1556,17 +1567,22 @@ __device__ __forceinline__ void block_scan5(int (&v)[5], int (&tot)[5], Publish 
   // (no trailing barrier: the one caller uses the staging array once per block)
 }
 
-// sums of two packed words over ALL predecessors of partition t (t < kPartMax = 1024 threads: one word pair per thread)
+// sums of two packed words over ALL predecessors of partition t: one word pair per thread and round of 1 024 (one round for the
+// batches up to 1 M keys; the big-batch stage has up to 4 096 partitions), all of a round polled together
 __device__ __forceinline__ void lookback_sum2_1024(const unsigned long long* ta, const unsigned long long* tb, int t,
                                                    unsigned long long& pre_a, unsigned long long& pre_b) {
   __shared__ unsigned long long s_sa, s_sb;
   if (threadIdx.x == 0) { s_sa = 0; s_sb = 0; }
   __syncthreads();
-  const int idx = t - 1 - (int)threadIdx.x;
-  unsigned long long va = idx >= 0 ? stat_load(ta + idx) : kStatAgg, vb = idx >= 0 ? stat_load(tb + idx) : kStatAgg;
-  while ((va & kStatMask) == 0) { __builtin_amdgcn_s_sleep(1); va = stat_load(ta + idx); }
-  while ((vb & kStatMask) == 0) { __builtin_amdgcn_s_sleep(1); vb = stat_load(tb + idx); }
-  unsigned long long xa = va & ~kStatMask, xb = vb & ~kStatMask;
+  unsigned long long xa = 0, xb = 0;
+  for (int r0 = 0; r0 < t; r0 += kP3Threads) {
+    const int idx = t - 1 - r0 - (int)threadIdx.x;
+    unsigned long long va = idx >= 0 ? stat_load(ta + idx) : kStatAgg, vb = idx >= 0 ? stat_load(tb + idx) : kStatAgg;
+    while ((va & kStatMask) == 0) { __builtin_amdgcn_s_sleep(1); va = stat_load(ta + idx); }
+    while ((vb & kStatMask) == 0) { __builtin_amdgcn_s_sleep(1); vb = stat_load(tb + idx); }
+    xa += va & ~kStatMask;
+    xb += vb & ~kStatMask;
+  }
   // the five packed fields are summed over the wave on the DPP path (each stays below 2^31 over all partitions)
   const int f0 = wave_sum((int)(xa & 0x7fffffffull)), f1 = wave_sum((int)(xa >> 31));
   const int f2 = wave_sum((int)(xb >> 40)), f3 = wave_sum((int)((xb >> 20) & 0xfffff)), f4 = wave_sum((int)(xb & 0xfffff));
@@ -1577,13 +1593,16 @@ __device__ __forceinline__ void lookback_sum2_1024(const unsigned long long* ta,
   pre_a = s_sa; pre_b = s_sb;
 }
 
+template <int CAP>
 __global__ void __launch_bounds__(kP3Threads)
 fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restrict__ csr_src, HotList hot) {
+  constexpr int kPartCap = CAP, kSubCap = CAP / kPartSub, kP2Hash = CAP, kP3Items = CAP / kP3Threads, kP3Ent = CAP / kP3Threads;
   __shared__ int h_slot[kP2Hash];         // slot of the entry (-1: free)
   __shared__ int h_cnt[kP2Hash];          // occurrences of the slot
-  __shared__ int h_pl[kP2Hash];           // (local unique id << 21) | occurrences in front of the entry's row (partition-local)
+  __shared__ int h_pl[kP2Hash];           // occurrences in front of the entry's row (partition-local)
+  __shared__ unsigned short h_lid[kP2Hash];   // local unique id of the entry
   __shared__ short d_rec[kPartCap];       // deferred records (bucket full)
-  __shared__ int d_ent[kPartCap / 4], d_base[kPartCap / 4];   // their hash entry / rank base once resolved (first 512 per step)
+  __shared__ int d_ent[kPartCap / 4], d_base[kPartCap / 4];   // their hash entry / rank base once resolved (first CAP / 4 per step)
   __shared__ int s_lock[256];             // bucket locks of the eviction (hashed)
   __shared__ unsigned s_late[kP2Hash / 32];
   __shared__ int s_nd, s_nbig;
@@ -1629,7 +1648,7 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
     const int sl = (int)rc[k].z, cn = (int)rc[k].w;
     if (sl >= 0) {
       bool cl;
-      en[k] = p2_insert(h_slot, sl, &cl);
+      en[k] = p2_insert<kP2Hash>(h_slot, sl, &cl);
       mine[k] = cl;
       bs[k] = atomicAdd(&h_cnt[en[k]], cn);
     } else {
@@ -1639,7 +1658,7 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
       } else {                           // beyond what one step evicts for: no slot this step (like an insert that returns Busy)
         dj[k] = -2;
         bool cl;
-        en[k] = p2_insert(h_slot, (int)a.S, &cl);
+        en[k] = p2_insert<kP2Hash>(h_slot, (int)a.S, &cl);
         mine[k] = cl;
         bs[k] = atomicAdd(&h_cnt[en[k]], cn);
       }
@@ -1718,7 +1737,7 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
                     const uint64_t k2 = ald64(ks + s2);
                     if (k2 == kLockedKey || k2 == kEmptyKey) continue;
                     if (pin && __hip_atomic_load(pin + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;
-                    if (p2_find(h_slot, (int)(bucket * a.t.C + s2)) >= 0) continue;   // used by this batch
+                    if (p2_find<kP2Hash>(h_slot, (int)(bucket * a.t.C + s2)) >= 0) continue;   // used by this batch
                     best = v; bslot = s2; bkey = k2;
                   }
                 }
@@ -1757,7 +1776,7 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
             if (g == 0) {
               // the slot enters the hash BEFORE the lock is released: that is what protects it from the next eviction
               bool cl;
-              const int ent = p2_insert(h_slot, gslot, &cl);
+              const int ent = p2_insert<kP2Hash>(h_slot, gslot, &cl);
               if (cl) atomicOr(&s_late[ent >> 5], 1u << (ent & 31));
               d_ent[e] = ent; d_base[e] = atomicAdd(&h_cnt[ent], cnt);
               a.rec[r].z = (uint32_t)gslot;
@@ -1769,7 +1788,7 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
           } else if (++guard > (1 << 22)) {
             if (g == 0) {
               bool cl;
-              const int ent = p2_insert(h_slot, (int)a.S, &cl);
+              const int ent = p2_insert<kP2Hash>(h_slot, (int)a.S, &cl);
               if (cl) atomicOr(&s_late[ent >> 5], 1u << (ent & 31));
               d_ent[e] = ent; d_base[e] = atomicAdd(&h_cnt[ent], cnt);
               a.rec[r].z = (uint32_t)a.S;
@@ -1825,7 +1844,8 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
 #pragma unroll
     for (int k = 0; k < kP3Ent; ++k) {
       if (es[k] == -1) continue;
-      h_pl[threadIdx.x * kP3Ent + k] = (lid << 21) | pre;
+      h_pl[threadIdx.x * kP3Ent + k] = pre;
+      h_lid[threadIdx.x * kP3Ent + k] = (unsigned short)lid;
       ++lid; pre += ec[k];
     }
   }
@@ -1883,9 +1903,8 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
   for (int k = 0; k < kP3Items; ++k) {
     if (!live[k]) continue;
     const int idx = threadIdx.x + k * kP3Threads;
-    const int pl = h_pl[en[k]];
-    const int uid = upre + (int)((unsigned)pl >> 21);
-    const int pos = spre + (pl & 0x1fffff) + bs[k];
+    const int uid = upre + (int)h_lid[en[k]];
+    const int pos = spre + h_pl[en[k]] + bs[k];
     const int cn = (int)rc[k].w, br = (int)rc[k].y;
     a.rec_out4[(int64_t)p * kPartCap + idx] = make_int4((int)rc[k].z < 0 ? ~uid : uid, bs[k], pos, 0);
     if (mine[k]) o.unique_keys[uid] = ky[k];
@@ -1925,6 +1944,10 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
   QST(8);
   QST(9);
 }
+
+}  // namespace mi355
+#include "big_index.h"
+namespace mi355 {
 
 // pooled gather of path (c): per-occurrence addresses with late rows (address word 1 -> the slot in the key's record)
 template <int SDT, int DDT>
@@ -2027,10 +2050,11 @@ gather_rows_eval_kernel(ProbeRefs pr, const int64_t* __restrict__ offsets, int B
 __global__ void __launch_bounds__(256)
 occ_from_records_kernel(const int32_t* __restrict__ occ_slot, const int32_t* __restrict__ occ_trank, const int4* __restrict__ rec_out4,
                         const int64_t* __restrict__ row_addr, int64_t n, int64_t* __restrict__ rev, int32_t* __restrict__ rank,
-                        int64_t* __restrict__ occ_addr, const int* __restrict__ rerun_mark) {
+                        int64_t* __restrict__ occ_addr, const int* __restrict__ rerun_mark, const int32_t* __restrict__ fwd) {
   if (*rerun_mark == 1) return;   // the step overflowed and was re-run on the per-slot-counter path: its outputs are already eager
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
-    const int ref = occ_slot[j];
+    int ref = occ_slot[j];
+    if (fwd && ref >= 0) ref = fwd[ref];      // (big-batch stage: the staged record's place in the partitions' lists)
     const int4 ro = rec_out4[ref >= 0 ? ref : 0];
     const bool late = ro.x < 0;
     const int uid = late ? ~ro.x : ro.x;
@@ -2167,13 +2191,28 @@ int64_t mi355_demb_aux_numel(int64_t total_slots, int64_t num_buckets) {
 
 static inline int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
 
+// the big-batch stage (big_index.h): one table, more keys than the reservation lists of path (c) serve (MI355_BIG_MIN, default
+// 1 M; MI355_BIG=0 turns it off: such batches then take the per-slot counters), at most 4 096 partitions of 2 816 keys
+static inline bool big_batch(int64_t n, int64_t num_tables) {
+  static const int on = getenv("MI355_BIG") ? atoi(getenv("MI355_BIG")) : 1;
+  static const int64_t min_keys = getenv("MI355_BIG_MIN") ? atoll(getenv("MI355_BIG_MIN")) : (int64_t)kPartMax * 1024;
+  static const int part_env = getenv("MI355_FUSED_PART") ? atoi(getenv("MI355_FUSED_PART")) : 2;
+  return on && part_env >= 2 && num_tables == 1 && n > min_keys && n <= (int64_t)kPartMaxBig * 2816;
+}
+
 // partitions of the partitioned index stage for a batch of n keys (0: the batch takes the per-slot-counter path)
 static inline int part_count(int64_t n, int64_t num_tables) {
   static const int env = getenv("MI355_FUSED_PART") ? atoi(getenv("MI355_FUSED_PART")) : 2;
   // several tables (round 4): path (c) only, with table-aligned partitions -- every table owns at least one, so the batch needs
   // a few per table (MI355_FUSED_MT=0: multi-table batches keep the per-slot-counter path)
   static const int mt_env = getenv("MI355_FUSED_MT") ? atoi(getenv("MI355_FUSED_MT")) : 1;
-  if (!env || n < (64 << 10) || n > (int64_t)kPartMax * 1024) return 0;
+  if (!env || n < (64 << 10)) return 0;
+  if (big_batch(n, num_tables)) {   // round 5: the big-batch stage (big_index.h): P = keys / 2 816 partitions of up to 4 096 records
+    int Pb = (int)((n + 2815) / 2816);
+    Pb = (Pb + 255) / 256 * 256;
+    return Pb < 256 ? 256 : Pb;
+  }
+  if (n > (int64_t)kPartMax * 1024) return 0;
   if (num_tables != 1 && (!mt_env || env < 2 || num_tables < 1 || num_tables > kFusedMaxT)) return 0;
   // keys per partition (MI355_FUSED_KPP, default 1024): the partition kernel is one block per partition and a chain of dependent
   // phases -- below 256 partitions it leaves CUs idle, so small batches may as well get thinner partitions
@@ -2198,7 +2237,8 @@ int64_t mi355_demb_forward_fused_workspace_bytes(int64_t n, int64_t num_tables) 
   const int64_t nt = (n + 1023) / 1024 + 2;
   return al256(8 * (num_tables + 1)) + al256(8 * n) /*unique keys*/ + al256(8 * n) /*occ_addr*/ + al256(4 * n) /*occ_slot*/ +
          al256(4 * nt) + 256 /*total*/ + al256(8 * n) + 4 * al256(4 * n) /*deferred*/ + al256(16 * (nt > 258 ? nt : 258)) /*look-back: two words per 1024 keys, and per partition*/ + 256 +
-         (part_count(n, num_tables) ? 32 * (int64_t)part_count(n, num_tables) * kPartCap + 5 * 256 + 4 * kPartMax : 0) /*partition records, table of every partition*/;
+         (part_count(n, num_tables) ? 32 * (int64_t)part_count(n, num_tables) * (big_batch(n, num_tables) ? kPartCapBig : kPartCap) + 5 * 256 + 4 * kPartMaxBig : 0) /*partition records, table of every partition*/ +
+         (big_batch(n, num_tables) ? al256(16 * n) + al256(4 * (n / 2048 + 2)) + al256(4 * n) : 0) /*big-batch stage: staged records, tile counts, forwarding entries*/;
 }
 
 // The fused forward (see the header of this file).  Persisted outputs as mi355_demb_forward; in eval mode (train == 0)
@@ -2266,6 +2306,7 @@ int mi355_demb_forward_fused(
   a.tile_bags = nullptr; a.occ_trank = nullptr;
   a.mt = 0; a.ptab = nullptr;
   a.gate = nullptr; a.gate_val = 0; a.ovf_word = 5; a.ovf_val = 1; a.rerun_mark = nullptr; a.tl = 0;
+  a.stage_rec = nullptr; a.tile_cnt = nullptr; a.fwd = nullptr; a.cap = kPartCap;
   a.magic0 = num_buckets > 0 ? ~0ull / (uint64_t)num_buckets : 0ull;   // (one table: its buckets are all the buckets)
   {
     const int P = train ? part_count(n, num_tables) : 0;
@@ -2273,11 +2314,18 @@ int mi355_demb_forward_fused(
       const int64_t per = ((S + 1 + P - 1) / P + bucket_capacity - 1) / bucket_capacity * bucket_capacity;
       if (per < 0x7fffffffLL) {
         a.P = P; a.spp = (int)per;
-        const int64_t nr = (int64_t)P * kPartCap;
+        const bool big = big_batch(n, num_tables);
+        a.cap = big ? kPartCapBig : kPartCap;
+        const int64_t nr = (int64_t)P * a.cap;
         a.rec = (uint4*)w; w += al256(16 * nr);
         a.rec_out = (int2*)w; a.rec_out4 = (int4*)w; w += al256(16 * nr);   // (path (a): 8-byte entries, path (c): 16-byte ones)
-        a.ptab = (int32_t*)w; w += 4 * kPartMax;
+        a.ptab = (int32_t*)w; w += 4 * kPartMaxBig;
         a.mt = num_tables > 1;
+        if (big) {
+          a.stage_rec = (uint4*)w; w += al256(16 * n);
+          a.tile_cnt = (int32_t*)w; w += al256(4 * (n / 2048 + 2));
+          a.fwd = (int32_t*)w; w += al256(4 * n);
+        }
       }
     }
   }
@@ -2305,10 +2353,29 @@ int mi355_demb_forward_fused(
   // is its own bag
   static const int seq_env = getenv("MI355_FUSED_SEQ") ? atoi(getenv("MI355_FUSED_SEQ")) : 1;
   const bool seq = combiner == -1;
-  const bool pathc = part && part_env >= 2 && train && (combiner >= 0 || (seq && seq_env)) && hot_ws && bcsr && aligned16 &&
+  bool pathc = part && part_env >= 2 && train && (combiner >= 0 || (seq && seq_env)) && hot_ws && bcsr && aligned16 &&
                      emb_dim <= (4 << lg) && (seq || n <= 8 * num_bags) && value_dtype <= 1 && out_dtype <= 1 &&
                      num_bags < (1ll << 31) - 4096;
   if (part && a.mt && !pathc) { part = false; a.P = 0; a.mt = 0; }   // several tables: path (c) or the per-slot counters
+  // the two knobs of the probe kernel (MI355_ENV_LIVE=1 -- the test suite, the A/B tools -- re-reads them on every call: A/B inside
+  // one process; otherwise they are read once: getenv walks the whole environment, twice per step adds up on the host)
+  static const bool env_live = getenv("MI355_ENV_LIVE") != nullptr;
+  static int fm_c = -1, pc_c = 1;
+  static bool env_have = false;
+  if (env_live || !env_have) {
+    const char* e1 = getenv("MI355_FUSED_FASTMOD");
+    const char* e2 = getenv("MI355_PROBE_C");
+    fm_c = e1 ? (atoi(e1) != 0) : -1;
+    pc_c = e2 ? atoi(e2) : 1;
+    env_have = true;
+  }
+  const bool fast = part && (fm_c >= 0 ? fm_c != 0 : pathc) && (a.t.C & (a.t.C - 1)) == 0 &&
+                    (a.S >> __builtin_ctzll((unsigned long long)a.t.C)) < (1ll << 31);
+  const int pcv = pc_c;
+  // the big-batch stage needs path (c) and the round-5 probe kernel; anything else: the per-slot counters
+  const bool big = part && a.stage_rec != nullptr && pathc && fast && pcv > 0;
+  if (part && a.stage_rec && !big) { part = false; a.P = 0; a.stage_rec = nullptr; a.cap = kPartCap; }
+  if (!part) pathc = false;
   // opt-in: an overflowed step is re-run on the per-slot-counter path inside this call (the reference never skips an update,
   // unique_op.cu:484-714): three more launches behind the gather that return at once in the steady state
   static const int rerun_env = getenv("MI355_FUSED_OVERFLOW_RERUN") ? atoi(getenv("MI355_FUSED_OVERFLOW_RERUN")) : 0;
@@ -2390,21 +2457,7 @@ int mi355_demb_forward_fused(
     else hipLaunchKernelGGL((fused_probe_kernel<TILE, THREADS, false>), dim3(grid), dim3(THREADS), 0, stream, a);         \
   } while (0)
     if (part) {
-      // (MI355_ENV_LIVE=1 -- the test suite, the A/B tools -- re-reads these two knobs on every call: A/B inside one process;
-      //  otherwise they are read once: getenv walks the whole environment, twice per step adds up on the host)
-      static const bool env_live = getenv("MI355_ENV_LIVE") != nullptr;
-      static int fm_c = -1, pc_c = 1;
-      static bool env_have = false;
-      if (env_live || !env_have) {
-        const char* e1 = getenv("MI355_FUSED_FASTMOD");
-        const char* e2 = getenv("MI355_PROBE_C");
-        fm_c = e1 ? (atoi(e1) != 0) : -1;
-        pc_c = e2 ? atoi(e2) : 1;
-        env_have = true;
-      }
-      const bool fast = (fm_c >= 0 ? fm_c != 0 : pathc) && (a.t.C & (a.t.C - 1)) == 0 && (a.S >> __builtin_ctzll((unsigned long long)a.t.C)) < (1ll << 31);
       // round 5: the rebuilt probe kernel of path (c) (probe_c.h); MI355_PROBE_C = 0 keeps the kernel above
-      const int pcv = pc_c;
       if (pathc && fast && pcv > 0) {
         // ONE block per CU in one generation while the batch allows it: tile length = ceil(n / #CUs), rounded to 64, in the kernel
         // with one key per thread (<= 1 024 keys per tile) or two (<= 2 048); larger batches run full 2 048-key tiles in
@@ -2417,11 +2470,19 @@ int mi355_demb_forward_fused(
           if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu_p = prop.multiProcessorCount;
           if (ncu_p <= 0) ncu_p = 256;
         }
-        const int cap = pcv == 3 ? 1024 : ((pcv == 2 || n > (int64_t)ncu_p * 1024) ? 2048 : 1024);
-        int64_t tlen = pcv == 3 ? cap : (ceil_div(n, ncu_p) + 63) / 64 * 64;
+        const int cap = big ? 2048 : (pcv == 3 ? 1024 : ((pcv == 2 || n > (int64_t)ncu_p * 1024) ? 2048 : 1024));
+        int64_t tlen = (big || pcv == 3) ? cap : (ceil_div(n, ncu_p) + 63) / 64 * 64;
         if (tlen > cap) tlen = cap;
         if (tlen < 256) tlen = 256;
         a.tl = (int)tlen;
+        if (big) {   // tile-major records, then the split into the partitions' lists (big_index.h)
+          const dim3 grid((unsigned)ceil_div(n, tlen)), blk(1024);
+          if (seq) hipLaunchKernelGGL((probe_c_kernel<2048, 1024, 4, false, true, true>), grid, blk, 0, stream, a);
+          else hipLaunchKernelGGL((probe_c_kernel<2048, 1024, 4, false, false, true>), grid, blk, 0, stream, a);
+          const int ntiles = (int)ceil_div(n, tlen);
+          const int tpb = (int)ceil_div(ntiles, ncu_p);
+          hipLaunchKernelGGL(split_records_kernel, dim3((unsigned)ceil_div(ntiles, tpb)), dim3(kSplitThreads), 0, stream, a, tpb, ntiles);
+        } else
 #define LAUNCH_PC(TILE, THREADS, WPS)                                                                                                   \
   do {                                                                                                                                   \
     const dim3 grid((unsigned)ceil_div(n, tlen)), blk(THREADS);                                                                          \
@@ -2432,6 +2493,7 @@ int mi355_demb_forward_fused(
   } while (0)
         if (cap == 2048) LAUNCH_PC(2048, 1024, 4);
         else LAUNCH_PC(1024, 1024, 8);
+        (void)0;
 #undef LAUNCH_PC
       } else
       if (pathc) {
@@ -2473,11 +2535,12 @@ int mi355_demb_forward_fused(
     PoolArgs g;
     g.src = nullptr; g.src_stride = 0; g.row_addr = a.occ_addr; g.rev = nullptr; g.offsets = offsets; g.D_offsets = D_offsets;
     g.dst = out; g.FB = num_bags; g.n = n; g.B = (int)batch_size; g.D = (int)emb_dim; g.total_D = (int)total_D; g.combiner = combiner;
-    LateRefs late; late.occ_slot = a.occ_slot; late.rec = a.rec; late.S = (int)S;
+    LateRefs late; late.occ_slot = a.occ_slot; late.rec = a.rec; late.S = (int)S; late.fwd = a.fwd;
     late.table_ptrs = table_ptrs; late.table_value_dims = table_value_dims; late.tbo = table_bucket_offsets;
     late.C = bucket_capacity; late.elem_bytes = a.elem_bytes; late.T = (int)num_tables;
     const int nsub = 64 >> lg;
-    hipLaunchKernelGGL(fused_part3_kernel, dim3((unsigned)a.P), dim3(kP3Threads), 0, stream, a, o, bptr, bcsr, hot);
+    if (big) hipLaunchKernelGGL(fused_part3_kernel<kPartCapBig>, dim3((unsigned)a.P), dim3(kP3Threads), 0, stream, a, o, bptr, bcsr, hot);
+    else hipLaunchKernelGGL(fused_part3_kernel<kPartCap>, dim3((unsigned)a.P), dim3(kP3Threads), 0, stream, a, o, bptr, bcsr, hot);
     MI355_LAUNCH_CHECK();
     if (seq) {
       RoctxRange rg("op:gather_embedding");
@@ -2617,10 +2680,14 @@ int mi355_demb_fused_materialize(void* workspace, int64_t workspace_bytes, int64
   w += 256 + al256(8 * n);
   const int32_t* occ_trank = (const int32_t*)w; w += 4 * al256(4 * n);
   w += al256(16 * (nt > 258 ? nt : 258));
-  w += al256(16 * (int64_t)P * kPartCap);
+  const bool big = big_batch(n, num_tables);
+  const int64_t nr = (int64_t)P * (big ? kPartCapBig : kPartCap);
+  w += al256(16 * nr);
   const int4* rec_out4 = (const int4*)w;
+  const int32_t* fwd = nullptr;      // big-batch stage: occ_slot names the STAGED record
+  if (big) fwd = (const int32_t*)(w + al256(16 * nr) + 4 * kPartMaxBig + al256(16 * n) + al256(4 * (n / 2048 + 2)));
   hipLaunchKernelGGL(occ_from_records_kernel, dim3((unsigned)grid_for(n, 256, 4096)), dim3(256), 0, stream, occ_slot, occ_trank, rec_out4,
-                     row_addr, n, reverse_indices, csr_rank, occ_addr, rerun_mark);
+                     row_addr, n, reverse_indices, csr_rank, occ_addr, rerun_mark, fwd);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }

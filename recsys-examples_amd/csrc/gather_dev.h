@@ -78,9 +78,11 @@ struct LateRefs {
   int elem_bytes = 0;
   int S = 0;
   int T = 1;                                  // tables (global slots are table-major: tbo[t] C <= slot < tbo[t + 1] C)
+  const int32_t* fwd = nullptr;               // big-batch stage: occ_slot holds the STAGED record, fwd[...] its place in `rec`
 };
 __device__ __forceinline__ uintptr_t late_row(const LateRefs& L, int64_t j) {
-  const int ref = L.occ_slot[j];
+  int ref = L.occ_slot[j];
+  if (ref >= 0 && L.fwd) ref = L.fwd[ref];
   if (ref < 0) return 0;
   const int z = (int)L.rec[ref].z;
   if (z < 0 || z >= L.S) return 0;

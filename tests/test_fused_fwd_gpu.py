@@ -30,8 +30,8 @@ def _counters_clear(m):
     """header + per-slot occurrence counters of the fused forward are all zero between steps (the unique-id map behind
     them is scratch)"""
     torch.cuda.synchronize()
-    cap = m.table.capacity_   # aux = [hdr 64][partition counters 4 x 1024][{occ, uid} x (S + 1)][locks]
-    H = 64 + 4096             # header, partition counters and the occ halves must be zero between steps
+    cap = m.table.capacity_   # aux = [hdr 64][partition counters 4 x 4096][{occ, uid} x (S + 1)][locks]
+    H = 64 + 4 * 4096         # header, partition counters and the occ halves must be zero between steps
     return int(m._fused_aux[:H].abs().sum()) == 0 and int(m._fused_aux[H: H + 2 * (cap + 1): 2].abs().sum()) == 0
 
 
@@ -126,6 +126,52 @@ def test_csr_writing_partition_kernel_against_the_per_op_chain_around_its_size_l
     with torch.no_grad():
         torch.testing.assert_close(ref._forward_impl(keys, off, train=False)[0], dut._forward_impl(keys, off, train=False)[0],
                                    rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("bags,pooling,opt,strategy", [(450_000, "SUM", "SGD", "TIMESTAMP"), (1_350_000, "SUM", "ADAM", "LFU"),
+                                                       (2_300_000, "NONE", "SGD", "STEP")])
+def test_big_batches_take_the_partitioned_stage_against_the_per_op_chain(bags, pooling, opt, strategy, monkeypatch):
+    """Batches beyond 1 M keys (round 5, csrc/big_index.h: tile-major records, one split into the partitions' lists, the partition
+    kernel over 4 096-record lists) against the per-op chain at ~2 M and ~6 M keys (pooled) and 2.3 M tokens (sequence): same
+    outputs, same unique counts, a consistent lazily materialised reverse index, same stored keys and rows after training steps
+    that insert, and steps in the steady state."""
+    cap = 1 << 23
+    ref = _mk(False, (16,), cap=cap, pooling=pooling, opt=opt, strategy=strategy, learning_rate=0.2, monkeypatch=monkeypatch)
+    dut = _mk(True, (16,), cap=cap, pooling=pooling, opt=opt, strategy=strategy, learning_rate=0.2, monkeypatch=monkeypatch)
+    rng = np.random.default_rng(bags)
+    ref.train(); dut.train()
+    for it in range(3):
+        if pooling == "NONE":
+            nk = bags
+            off = torch.arange(nk + 1, dtype=torch.int64, device=DEV)
+        else:
+            lens = rng.integers(0, 9, size=bags)
+            off = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)).to(DEV)
+            nk = int(off[-1])
+        keys = torch.from_numpy(((rng.zipf(1.1, nk) + 13 * it) % (2_500_000 + 500_000 * min(it, 1))).astype(np.int64)).to(DEV)
+        assert nk > (1 << 20)
+        o_ref, s_ref = ref._forward_impl(keys, off, train=True)
+        o_dut, s_dut = dut._forward_impl(keys, off, train=True)
+        assert getattr(s_dut, "lazy", False), "the batch did not take the partitioned stage"
+        torch.testing.assert_close(o_ref, o_dut, rtol=1e-5, atol=1e-5, msg=f"step {it} ({nk} keys): forward differs")
+        nu_r, nu_d = int(s_ref.uoff[-1]), int(s_dut.uoff[-1])
+        assert nu_r == nu_d
+        if it == 1:
+            rev = s_dut.rev
+            assert int(rev.min()) >= 0 and int(rev.max()) < nu_d
+            uk = torch.empty(nu_d, dtype=torch.int64, device=DEV)
+            uk[rev] = keys
+            assert torch.equal(uk[rev], keys) and int(torch.unique(rev).numel()) == nu_d
+        g = torch.rand_like(o_ref) + 0.1
+        ref._backward_impl(s_ref, g)
+        dut._backward_impl(s_dut, g)
+        assert torch.equal(ref.size(), dut.size())
+        assert _counters_clear(dut)
+    k1, v1 = ref.export_keys_values(ref._table_names[0], torch.device(DEV))
+    k2, v2 = dut.export_keys_values(dut._table_names[0], torch.device(DEV))
+    o1, o2 = torch.argsort(k1), torch.argsort(k2)
+    assert k1.numel() == k2.numel() and torch.equal(k1[o1], k2[o2])
+    torch.testing.assert_close(v1[o1], v2[o2], rtol=5e-5, atol=5e-6)
 
 
 @pytest.mark.parametrize("variant", ["0", "1", "2", "3"])
