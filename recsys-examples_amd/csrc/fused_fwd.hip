@@ -1502,7 +1502,7 @@ fused_part_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, bo
 // holds at most CAP records, hence at most as many distinct slots: the LDS hash has CAP entries.
 constexpr int kP3Threads = 1024;
 constexpr int kRecLate = 1 << 30;      // count word of a record whose key took the eviction path
-constexpr int kPartCapBig = 4096;      // records per partition of the big-batch stage
+constexpr int kPartCapBig = 16384;     // records per partition of the big-batch stage (the streaming partition kernel, big_index.h)
 constexpr int kPartMaxBig = 4096;      // its partitions
 
 template <int HASH> __device__ __forceinline__ int p2_hash(int slot) { return (int)((uint32_t)slot * 2654435761u >> (32 - __builtin_ctz(HASH))) & (HASH - 1); }
@@ -1591,6 +1591,129 @@ __device__ __forceinline__ void lookback_sum2_1024(const unsigned long long* ta,
   if (lane_id() == 0) { if (xa) atomicAdd(&s_sa, xa); if (xb) atomicAdd(&s_sb, xb); }
   __syncthreads();
   pre_a = s_sa; pre_b = s_sb;
+}
+
+// ---- deferred keys of a partition: the bucket had no free slot.  Evict the minimum score among the slots this batch does not use
+//      (the partition's LDS hash knows them all: every record of the bucket is in this block) and that nobody pinned
+//      (kernels.cuh:226-287, types.cuh:398-512); 8 lanes per key, a hashed LDS lock per bucket.  The slot goes back into the
+//      record: the gather finds the rows of the key's occurrences there.  Shared by the two partition kernels.
+template <int HASH, typename DRec>
+__device__ __forceinline__ void part_evict(FusedArgs& a, int nd, int64_t rec_base, const DRec* d_rec, int* d_ent, int* d_base, int* s_lock,
+                                           unsigned* s_late, int* h_slot, int* h_cnt, int tbl, int64_t tp0, int64_t rowb, int64_t s0) {
+      if (!a.timer) a.timer = device_clock();
+      const int g = lane_id() & (G - 1);
+      const int gpb = kP3Threads / G;
+      const int C = (int)a.t.C;
+      for (int e0 = 0; e0 < nd; e0 += gpb) {
+        const int e = e0 + (int)threadIdx.x / G;
+        const bool act = e < nd;
+        const int64_t r = rec_base + (act ? (int)d_rec[e] : 0);
+        const uint4 rd = a.rec[r];
+        int64_t kp = (int64_t)rd.x; kp = kp < a.n ? kp : a.n - 1;
+        const uint64_t key = a.keys[kp];
+        const int cnt = (int)rd.w;
+        const int64_t bucket = act ? -(int64_t)(int)rd.z - 2 : 0;
+        const int64_t hash = (int64_t)(fmix64(key) & 0x7FFFFFFFFFFFFFFFull);
+        bool done = !act;
+        int guard = 0;
+        while (__ballot(!done)) {
+          if (!done) {
+            int got = 0;
+            if (g == 0) got = atomicCAS(&s_lock[bucket & 255], 0, 1) == 0 ? 1 : 0;
+            got = group_bcast(got, 0);
+            if (got) {
+              uint64_t* ks = a.t.keys(bucket);
+              int found_slot, empty_slot;
+              group_probe(a.t, bucket, key, hash, true, true, found_slot, empty_slot);
+              int slot = -1;
+              bool fresh_row = false;
+              if (found_slot >= 0) {             // another record of the same key got here first
+                slot = found_slot;
+                if (g == 0) score_found(a, a.t.scores(bucket) + (int64_t)slot * a.t.ns, cnt);
+              } else if (empty_slot >= 0) {      // a slot was freed meanwhile
+                slot = empty_slot;
+                fresh_row = true;
+                if (g == 0) {
+                  store_digest(a.t.dig(bucket) + slot, digest_of(hash));
+                  score_new(a, a.t.scores(bucket) + (int64_t)slot * a.t.ns, cnt);
+                  atomicAdd(&a.bucket_sizes[bucket], 1);
+                }
+              } else {
+                uint64_t best = ~0ull, bkey = 0;
+                int bslot = -1;
+                const uint64_t* sc = a.t.scores(bucket);
+                const int32_t* pin = a.counter ? a.counter + bucket * a.t.C : nullptr;
+                for (int s1 = 2 * g; s1 < C; s1 += 2 * G) {
+  #pragma unroll
+                  for (int u = 0; u < 2; ++u) {
+                    const int s2 = s1 + u;
+                    const uint64_t v = ald64(sc + (int64_t)s2 * a.t.ns + (a.t.ns - 1));
+                    if (v < best) {
+                      const uint64_t k2 = ald64(ks + s2);
+                      if (k2 == kLockedKey || k2 == kEmptyKey) continue;
+                      if (pin && __hip_atomic_load(pin + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;
+                      if (p2_find<HASH>(h_slot, (int)(bucket * a.t.C + s2)) >= 0) continue;   // used by this batch
+                      best = v; bslot = s2; bkey = k2;
+                    }
+                  }
+                }
+                group_argmin(best, bslot, bkey);
+                if (bslot >= 0) {
+                  slot = bslot;
+                  fresh_row = true;
+                  if (g == 0) {
+                    ast64(ks + slot, kLockedKey);
+                    store_digest(a.t.dig(bucket) + slot, digest_of(hash));
+                    for (int64_t w = 0; w < a.t.ns; ++w) ast64((uint64_t*)sc + (int64_t)slot * a.t.ns + w, 0);
+                    score_new(a, a.t.scores(bucket) + (int64_t)slot * a.t.ns, cnt);
+                    if (bkey == kReclaimKey) atomicAdd(&a.bucket_sizes[bucket], 1);
+                  }
+                }
+              }
+              int gslot = (int)a.S;             // no slot could be had: the key is served without a row this step
+              if (slot >= 0) {
+                gslot = (int)(bucket * a.t.C + slot);
+                if (fresh_row) {
+                  void* rp = reinterpret_cast<void*>((uintptr_t)(tp0 + ((int64_t)gslot - s0) * rowb));
+                  const int ed = (int)a.table_emb_dims[tbl], vd = (int)a.table_value_dims[tbl];
+                  for (int el = g; el < vd; el += G) {
+                    const float v = el < ed ? init_value(a.init, key, (uint32_t)el) : a.init.state_init;
+                    if (a.value_dtype == kF32) st1<kF32>(rp, el, v);
+                    else if (a.value_dtype == kBF16) st1<kBF16>(rp, el, v);
+                    else st1<kF16>(rp, el, v);
+                  }
+                  if (g == 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    ast64(ks + slot, key);
+                  }
+                }
+              }
+              if (g == 0) {
+                // the slot enters the hash BEFORE the lock is released: that is what protects it from the next eviction
+                bool cl;
+                const int ent = p2_insert<HASH>(h_slot, gslot, &cl);
+                if (cl) atomicOr(&s_late[ent >> 5], 1u << (ent & 31));
+                d_ent[e] = ent; d_base[e] = atomicAdd(&h_cnt[ent], cnt);
+                a.rec[r].z = (uint32_t)gslot;
+                a.rec[r].w = (uint32_t)(cnt | kRecLate);
+                __threadfence_block();
+                atomicExch(&s_lock[bucket & 255], 0);
+              }
+              done = true;
+            } else if (++guard > (1 << 22)) {
+              if (g == 0) {
+                bool cl;
+                const int ent = p2_insert<HASH>(h_slot, (int)a.S, &cl);
+                if (cl) atomicOr(&s_late[ent >> 5], 1u << (ent & 31));
+                d_ent[e] = ent; d_base[e] = atomicAdd(&h_cnt[ent], cnt);
+                a.rec[r].z = (uint32_t)a.S;
+                a.rec[r].w = (uint32_t)(cnt | kRecLate);
+              }
+              done = true;
+            }
+          }
+        }
+      }
 }
 
 template <int CAP>
@@ -1685,120 +1808,7 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
   const int nd = s_nd < kDefMax ? s_nd : kDefMax;
 #endif
   if (nd > 0) {
-    if (!a.timer) a.timer = device_clock();
-    const int g = lane_id() & (G - 1);
-    const int gpb = kP3Threads / G;
-    const int C = (int)a.t.C;
-    for (int e0 = 0; e0 < nd; e0 += gpb) {
-      const int e = e0 + (int)threadIdx.x / G;
-      const bool act = e < nd;
-      const int64_t r = (int64_t)p * kPartCap + (act ? (int)d_rec[e] : 0);
-      const uint4 rd = a.rec[r];
-      int64_t kp = (int64_t)rd.x; kp = kp < a.n ? kp : a.n - 1;
-      const uint64_t key = a.keys[kp];
-      const int cnt = (int)rd.w;
-      const int64_t bucket = act ? -(int64_t)(int)rd.z - 2 : 0;
-      const int64_t hash = (int64_t)(fmix64(key) & 0x7FFFFFFFFFFFFFFFull);
-      bool done = !act;
-      int guard = 0;
-      while (__ballot(!done)) {
-        if (!done) {
-          int got = 0;
-          if (g == 0) got = atomicCAS(&s_lock[bucket & 255], 0, 1) == 0 ? 1 : 0;
-          got = group_bcast(got, 0);
-          if (got) {
-            uint64_t* ks = a.t.keys(bucket);
-            int found_slot, empty_slot;
-            group_probe(a.t, bucket, key, hash, true, true, found_slot, empty_slot);
-            int slot = -1;
-            bool fresh_row = false;
-            if (found_slot >= 0) {             // another record of the same key got here first
-              slot = found_slot;
-              if (g == 0) score_found(a, a.t.scores(bucket) + (int64_t)slot * a.t.ns, cnt);
-            } else if (empty_slot >= 0) {      // a slot was freed meanwhile
-              slot = empty_slot;
-              fresh_row = true;
-              if (g == 0) {
-                store_digest(a.t.dig(bucket) + slot, digest_of(hash));
-                score_new(a, a.t.scores(bucket) + (int64_t)slot * a.t.ns, cnt);
-                atomicAdd(&a.bucket_sizes[bucket], 1);
-              }
-            } else {
-              uint64_t best = ~0ull, bkey = 0;
-              int bslot = -1;
-              const uint64_t* sc = a.t.scores(bucket);
-              const int32_t* pin = a.counter ? a.counter + bucket * a.t.C : nullptr;
-              for (int s1 = 2 * g; s1 < C; s1 += 2 * G) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                  const int s2 = s1 + u;
-                  const uint64_t v = ald64(sc + (int64_t)s2 * a.t.ns + (a.t.ns - 1));
-                  if (v < best) {
-                    const uint64_t k2 = ald64(ks + s2);
-                    if (k2 == kLockedKey || k2 == kEmptyKey) continue;
-                    if (pin && __hip_atomic_load(pin + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;
-                    if (p2_find<kP2Hash>(h_slot, (int)(bucket * a.t.C + s2)) >= 0) continue;   // used by this batch
-                    best = v; bslot = s2; bkey = k2;
-                  }
-                }
-              }
-              group_argmin(best, bslot, bkey);
-              if (bslot >= 0) {
-                slot = bslot;
-                fresh_row = true;
-                if (g == 0) {
-                  ast64(ks + slot, kLockedKey);
-                  store_digest(a.t.dig(bucket) + slot, digest_of(hash));
-                  for (int64_t w = 0; w < a.t.ns; ++w) ast64((uint64_t*)sc + (int64_t)slot * a.t.ns + w, 0);
-                  score_new(a, a.t.scores(bucket) + (int64_t)slot * a.t.ns, cnt);
-                  if (bkey == kReclaimKey) atomicAdd(&a.bucket_sizes[bucket], 1);
-                }
-              }
-            }
-            int gslot = (int)a.S;             // no slot could be had: the key is served without a row this step
-            if (slot >= 0) {
-              gslot = (int)(bucket * a.t.C + slot);
-              if (fresh_row) {
-                void* rp = reinterpret_cast<void*>((uintptr_t)(tp0 + ((int64_t)gslot - s0) * rowb));
-                const int ed = (int)a.table_emb_dims[tbl], vd = (int)a.table_value_dims[tbl];
-                for (int el = g; el < vd; el += G) {
-                  const float v = el < ed ? init_value(a.init, key, (uint32_t)el) : a.init.state_init;
-                  if (a.value_dtype == kF32) st1<kF32>(rp, el, v);
-                  else if (a.value_dtype == kBF16) st1<kBF16>(rp, el, v);
-                  else st1<kF16>(rp, el, v);
-                }
-                if (g == 0) {
-                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                  ast64(ks + slot, key);
-                }
-              }
-            }
-            if (g == 0) {
-              // the slot enters the hash BEFORE the lock is released: that is what protects it from the next eviction
-              bool cl;
-              const int ent = p2_insert<kP2Hash>(h_slot, gslot, &cl);
-              if (cl) atomicOr(&s_late[ent >> 5], 1u << (ent & 31));
-              d_ent[e] = ent; d_base[e] = atomicAdd(&h_cnt[ent], cnt);
-              a.rec[r].z = (uint32_t)gslot;
-              a.rec[r].w = (uint32_t)(cnt | kRecLate);
-              __threadfence_block();
-              atomicExch(&s_lock[bucket & 255], 0);
-            }
-            done = true;
-          } else if (++guard > (1 << 22)) {
-            if (g == 0) {
-              bool cl;
-              const int ent = p2_insert<kP2Hash>(h_slot, (int)a.S, &cl);
-              if (cl) atomicOr(&s_late[ent >> 5], 1u << (ent & 31));
-              d_ent[e] = ent; d_base[e] = atomicAdd(&h_cnt[ent], cnt);
-              a.rec[r].z = (uint32_t)a.S;
-              a.rec[r].w = (uint32_t)(cnt | kRecLate);
-            }
-            done = true;
-          }
-        }
-      }
-    }
+    part_evict<kP2Hash>(a, nd, (int64_t)p * kPartCap, d_rec, d_ent, d_base, s_lock, s_late, h_slot, h_cnt, tbl, tp0, rowb, s0);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kP3Items; ++k)
@@ -2539,7 +2549,7 @@ int mi355_demb_forward_fused(
     late.table_ptrs = table_ptrs; late.table_value_dims = table_value_dims; late.tbo = table_bucket_offsets;
     late.C = bucket_capacity; late.elem_bytes = a.elem_bytes; late.T = (int)num_tables;
     const int nsub = 64 >> lg;
-    if (big) hipLaunchKernelGGL(fused_part3_kernel<kPartCapBig>, dim3((unsigned)a.P), dim3(kP3Threads), 0, stream, a, o, bptr, bcsr, hot);
+    if (big) hipLaunchKernelGGL(fused_part3s_kernel, dim3((unsigned)a.P), dim3(kP3Threads), 0, stream, a, o, bptr, bcsr, hot);
     else hipLaunchKernelGGL(fused_part3_kernel<kPartCap>, dim3((unsigned)a.P), dim3(kP3Threads), 0, stream, a, o, bptr, bcsr, hot);
     MI355_LAUNCH_CHECK();
     if (seq) {
