@@ -15,7 +15,8 @@
 //   3. fused_part3s_kernel: the partition kernel of path (c) in a STREAMING form.  With thousands of tiles a key of the Zipf head
 //      leaves one record per tile -- 2 816 records of ONE slot at the 16x batch, all in one partition -- so a partition's list is
 //      not bounded by its distinct slots any more (first build, 4 096-record lists: the 16x step overflowed on every batch).  The
-//      lists hold kPartCapBig = 16 384 records; the kernel walks them twice, 1 024 records at a time (merge pass: LDS hash of the
+//      lists hold kPartCapBig = 32 768 records (P = keys / 11 264 partitions: few, large partitions amortise the kernel's fixed round
+//      trips -- at P = keys / 2 816 the 2 048 blocks of the 16x batch took 300 us, 37 us each in eight generations); the kernel walks them twice, 1 024 records at a time (merge pass: LDS hash of the
 //      partition's distinct slots, rank base of every record; output pass: CSR entries), with the per-record state kept in the
 //      record's output entry between the passes -- nothing per record lives in registers.
 #pragma once
@@ -74,7 +75,7 @@ __global__ void __launch_bounds__(kSplitThreads) split_records_kernel(FusedArgs 
 
 
 // The streaming partition kernel (see the header).  Same outputs as fused_part3_kernel; one block per partition.
-constexpr int kP3sHash = 4096;          // hash entries for the distinct slots of a partition (avg ~700 at P = keys / 2 816); past ~3 000 claimed
+constexpr int kP3sHash = 8192;          // hash entries for the distinct slots of a partition (avg ~2 700 at P = keys / 11 264); past ~7 000 claimed
                                         // entries (1 024 threads may claim at once) the step is flagged
 constexpr int kP3sDef = 1024;           // deferred records (bucket full) evicted for per step and partition
 
@@ -104,15 +105,26 @@ fused_part3s_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restri
   if (tid < kPartSub) a.pcount[p * kPartSub + tid] = 0;       // clean for the next step
   const int tbl = 0;
   const int64_t tp0 = a.table_ptrs[tbl], rowb = a.table_value_dims[tbl] * a.elem_bytes, s0 = a.tbo[tbl] * a.t.C;
-  // ---- merge pass: the records of a slot meet in its hash entry; every record learns its entry and the rank base of its tile
-  for (int sl_ = 0; sl_ < kPartSub; ++sl_) {
-    for (int r = tid; r < msub[sl_]; r += kP3Threads) {
-      const int idx = sl_ * subcap + r;
-      const uint4 rc = a.rec[rec_base + idx];
+  // ---- merge pass: the records of a slot meet in its hash entry; every record learns its entry and the rank base of its tile.
+  //      The four sub-lists are walked as ONE index space (flat index -> sub-list by three compares), 1 024 records a round, the
+  //      next round's records in flight while this round's are merged.
+  const int c1 = msub[0], c2 = c1 + msub[1], c3 = c2 + msub[2], total = c3 + msub[3];
+  auto rec_index = [&](int f) -> int {            // flat index -> index inside the partition's list
+    return f < c1 ? f : (f < c2 ? subcap + f - c1 : (f < c3 ? 2 * subcap + f - c2 : 3 * subcap + f - c3));
+  };
+  {
+    uint4 nxt = a.rec[rec_base + rec_index(tid < total ? tid : 0)];
+    for (int f0 = 0; f0 < total; f0 += kP3Threads) {
+      const int f = f0 + tid;
+      const uint4 rc = nxt;
+      const int fn = f + kP3Threads;
+      nxt = a.rec[rec_base + rec_index(fn < total ? fn : 0)];
+      if (f >= total) continue;
+      const int idx = rec_index(f);
       const int sl = (int)rc.z, cn = (int)rc.w;
       int en = -1, bs = 0, mine = 0;
       if (sl >= 0) {
-        // (a table the hash cannot hold -- more distinct slots than entries: the step is flagged, the record joins the row-less entry)
+        // (a partition the hash cannot hold -- more distinct slots than entries: the step is flagged, the record joins the row-less entry)
         int want = sl;
         if (__hip_atomic_load(&s_nclaim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > HASH - 1088 && p2_find<HASH>(h_slot, sl) < 0) {
           want = (int)a.S;
@@ -232,39 +244,42 @@ fused_part3s_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restri
     }
   }
   // ---- output pass: unique id / rank base / CSR position of every record (lazy reverse indices), the unique row's key, the CSR
-  //      entries.  Block-uniform trip count per sub-list: long lists (a hot key's occurrences in one tile) are expanded by whole
-  //      waves behind every round.
-  for (int sl_ = 0; sl_ < kPartSub; ++sl_) {
-    for (int r0 = 0; r0 < msub[sl_]; r0 += kP3Threads) {
-      const int r = r0 + tid;
-      if (r < msub[sl_]) {
-        const int idx = sl_ * subcap + r;
-        const uint4 rc = a.rec[rec_base + idx];
-        const int4 ro = a.rec_out4[rec_base + idx];
-        const int en = ro.x, bs = ro.y;
-        const int uid = upre + (int)h_lid[en];
-        const int pos = spre + h_pl[en] + bs;
-        const int cn = (int)rc.w & ~kRecLate, br = (int)rc.y;
-        a.rec_out4[rec_base + idx] = make_int4(((int)rc.w & kRecLate) ? ~uid : uid, bs, pos, 0);
-        if (ro.z) { int64_t pc = (int64_t)rc.x; pc = pc < a.n ? pc : a.n - 1; o.unique_keys[uid] = a.keys[pc]; }
-        if (cn == 1) csr_src[pos] = br;
-        else if (cn <= 8) {
-          for (int j = 0; j < cn; ++j) csr_src[pos + j] = ~(br + j);
-        } else {
-          const int q = atomicAdd(&s_nbig, 1);
-          if (q < kBigMax) { b_pos[q] = pos; b_ref[q] = br; b_cnt[q] = cn; }
-          else for (int j = 0; j < cn; ++j) csr_src[pos + j] = ~(br + j);
-        }
+  //      entries; the next round's record and state in flight.  Long lists (a hot key's occurrences in one tile) are collected and
+  //      expanded by whole waves behind the loop (beyond 512 of them: by their own thread).
+  {
+    int i0 = rec_index(tid < total ? tid : 0);
+    uint4 nrc = a.rec[rec_base + i0];
+    int4 nro = a.rec_out4[rec_base + i0];
+    for (int f0 = 0; f0 < total; f0 += kP3Threads) {
+      const int f = f0 + tid;
+      const uint4 rc = nrc;
+      const int4 ro = nro;
+      const int idx = i0;
+      const int fn = f + kP3Threads;
+      i0 = rec_index(fn < total ? fn : 0);
+      nrc = a.rec[rec_base + i0];
+      nro = a.rec_out4[rec_base + i0];
+      if (f >= total) continue;
+      const int en = ro.x, bs = ro.y;
+      const int uid = upre + (int)h_lid[en];
+      const int pos = spre + h_pl[en] + bs;
+      const int cn = (int)rc.w & ~kRecLate, br = (int)rc.y;
+      a.rec_out4[rec_base + idx] = make_int4(((int)rc.w & kRecLate) ? ~uid : uid, bs, pos, 0);
+      if (ro.z) { int64_t pc = (int64_t)rc.x; pc = pc < a.n ? pc : a.n - 1; o.unique_keys[uid] = a.keys[pc]; }
+      if (cn == 1) csr_src[pos] = br;
+      else if (cn <= 8) {
+        for (int j = 0; j < cn; ++j) csr_src[pos + j] = ~(br + j);
+      } else {
+        const int q = atomicAdd(&s_nbig, 1);
+        if (q < kBigMax) { b_pos[q] = pos; b_ref[q] = br; b_cnt[q] = cn; }
+        else for (int j = 0; j < cn; ++j) csr_src[pos + j] = ~(br + j);
       }
-      __syncthreads();
-      const int nbig = s_nbig < kBigMax ? s_nbig : kBigMax;
-      for (int q = tid >> 6; q < nbig; q += kP3Threads >> 6) {
-        const int pos = b_pos[q], br = b_ref[q], cn = b_cnt[q];
-        for (int j = lane_id(); j < cn; j += 64) csr_src[pos + j] = ~(br + j);
-      }
-      __syncthreads();
-      if (tid == 0) s_nbig = 0;
-      __syncthreads();
+    }
+    __syncthreads();
+    const int nbig = s_nbig < kBigMax ? s_nbig : kBigMax;
+    for (int q = tid >> 6; q < nbig; q += kP3Threads >> 6) {
+      const int pos = b_pos[q], br = b_ref[q], cn = b_cnt[q];
+      for (int j = lane_id(); j < cn; j += 64) csr_src[pos + j] = ~(br + j);
     }
   }
   if (p == 0 && tid == 0) o.table_offsets[0] = __hip_atomic_load(&a.hdr[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 0 : upre;

@@ -1502,7 +1502,7 @@ fused_part_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, bo
 // holds at most CAP records, hence at most as many distinct slots: the LDS hash has CAP entries.
 constexpr int kP3Threads = 1024;
 constexpr int kRecLate = 1 << 30;      // count word of a record whose key took the eviction path
-constexpr int kPartCapBig = 16384;     // records per partition of the big-batch stage (the streaming partition kernel, big_index.h)
+constexpr int kPartCapBig = 32768;     // records per partition of the big-batch stage (the streaming partition kernel, big_index.h)
 constexpr int kPartMaxBig = 4096;      // its partitions
 
 template <int HASH> __device__ __forceinline__ int p2_hash(int slot) { return (int)((uint32_t)slot * 2654435761u >> (32 - __builtin_ctz(HASH))) & (HASH - 1); }
@@ -2202,12 +2202,12 @@ int64_t mi355_demb_aux_numel(int64_t total_slots, int64_t num_buckets) {
 static inline int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
 
 // the big-batch stage (big_index.h): one table, more keys than the reservation lists of path (c) serve (MI355_BIG_MIN, default
-// 1 M; MI355_BIG=0 turns it off: such batches then take the per-slot counters), at most 4 096 partitions of 2 816 keys
+// 1 M; MI355_BIG=0 turns it off: such batches then take the per-slot counters), at most 4 096 partitions of 11 264 keys
 static inline bool big_batch(int64_t n, int64_t num_tables) {
   static const int on = getenv("MI355_BIG") ? atoi(getenv("MI355_BIG")) : 1;
   static const int64_t min_keys = getenv("MI355_BIG_MIN") ? atoll(getenv("MI355_BIG_MIN")) : (int64_t)kPartMax * 1024;
   static const int part_env = getenv("MI355_FUSED_PART") ? atoi(getenv("MI355_FUSED_PART")) : 2;
-  return on && part_env >= 2 && num_tables == 1 && n > min_keys && n <= (int64_t)kPartMaxBig * 2816;
+  return on && part_env >= 2 && num_tables == 1 && n > min_keys && n <= (int64_t)kPartMaxBig * 11264;
 }
 
 // partitions of the partitioned index stage for a batch of n keys (0: the batch takes the per-slot-counter path)
@@ -2217,9 +2217,9 @@ static inline int part_count(int64_t n, int64_t num_tables) {
   // a few per table (MI355_FUSED_MT=0: multi-table batches keep the per-slot-counter path)
   static const int mt_env = getenv("MI355_FUSED_MT") ? atoi(getenv("MI355_FUSED_MT")) : 1;
   if (!env || n < (64 << 10)) return 0;
-  if (big_batch(n, num_tables)) {   // round 5: the big-batch stage (big_index.h): P = keys / 2 816 partitions of up to 4 096 records
-    int Pb = (int)((n + 2815) / 2816);
-    Pb = (Pb + 255) / 256 * 256;
+  if (big_batch(n, num_tables)) {   // round 5: the big-batch stage (big_index.h): P = keys / 11 264 partitions of up to 32 768 records
+    int Pb = (int)((n + 11263) / 11264);
+    Pb = (Pb + 63) / 64 * 64;
     return Pb < 256 ? 256 : Pb;
   }
   if (n > (int64_t)kPartMax * 1024) return 0;
