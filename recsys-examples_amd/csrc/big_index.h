@@ -92,6 +92,7 @@ fused_part3s_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restri
   __shared__ int b_pos[kBigMax], b_ref[kBigMax], b_cnt[kBigMax];
   const int p = blockIdx.x, tid = (int)threadIdx.x;
   const int cap = a.cap, subcap = a.cap / kPartSub;
+  QST(0);
   const int64_t rec_base = (int64_t)p * cap;
   const int mv = a.pcount[p * kPartSub + (tid & (kPartSub - 1))];
   for (int i = tid; i < HASH; i += kP3Threads) { h_slot[i] = -1; h_cnt[i] = 0; }
@@ -99,6 +100,7 @@ fused_part3s_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restri
   if (tid < HASH / 32) s_late[tid] = 0;
   if (tid == 0) { s_nd = 0; s_nbig = 0; s_nclaim = 0; }
   __syncthreads();
+  QST(1);
   int msub[kPartSub];
 #pragma unroll
   for (int r = 0; r < kPartSub; ++r) { const int m = __builtin_amdgcn_readlane(mv, r); msub[r] = m < subcap ? m : subcap; }
@@ -112,12 +114,21 @@ fused_part3s_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restri
   auto rec_index = [&](int f) -> int {            // flat index -> index inside the partition's list
     return f < c1 ? f : (f < c2 ? subcap + f - c1 : (f < c3 ? 2 * subcap + f - c2 : 3 * subcap + f - c3));
   };
+  //      A record that claims an entry owns the unique row's KEY: the key of every record is fetched a round ahead too (a dependent
+  //      load behind the record's own) and travels in the record's output entry -- fetched in the output pass it was a second memory
+  //      round trip per round (first build: 6 us per 1 024 records, profiles/r05_stamps_16x_a.txt).
   {
-    uint4 nxt = a.rec[rec_base + rec_index(tid < total ? tid : 0)];
+    auto key_pos = [&](const uint4& r) -> int64_t { const int64_t pc = (int64_t)r.x; return pc < a.n ? pc : a.n - 1; };
+    uint4 cur = a.rec[rec_base + rec_index(tid < total ? tid : 0)];
+    uint4 nxt = a.rec[rec_base + rec_index(tid + kP3Threads < total ? tid + kP3Threads : 0)];
+    uint64_t kcur = a.keys[key_pos(cur)];
     for (int f0 = 0; f0 < total; f0 += kP3Threads) {
       const int f = f0 + tid;
-      const uint4 rc = nxt;
-      const int fn = f + kP3Threads;
+      const uint4 rc = cur;
+      const uint64_t key = kcur;
+      cur = nxt;
+      kcur = a.keys[key_pos(cur)];
+      const int fn = f + 2 * kP3Threads;
       nxt = a.rec[rec_base + rec_index(fn < total ? fn : 0)];
       if (f >= total) continue;
       const int idx = rec_index(f);
@@ -139,7 +150,7 @@ fused_part3s_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restri
         const int dj = atomicAdd(&s_nd, 1);
         if (dj < kP3sDef) {
           d_rec[dj] = idx;
-          en = -2 - dj;                            // resolved by the eviction below
+          en = 0;                                  // (entry and rank base come from the eviction below)
         } else {                                   // beyond what one step evicts for: no slot this step (like an insert that returns Busy)
           bool cl;
           en = p2_insert<HASH>(h_slot, (int)a.S, &cl);
@@ -150,10 +161,12 @@ fused_part3s_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restri
           a.rec[rec_base + idx].w = (uint32_t)(cn | kRecLate);
         }
       }
-      a.rec_out4[rec_base + idx] = make_int4(en, bs, mine, 0);
+      a.rec_out4[rec_base + idx] = make_int4(en | (mine << 30), bs, (int)(uint32_t)key, (int)(uint32_t)(key >> 32));
     }
   }
+  QST(2);
   __syncthreads();
+  QST(3);
   const int nd = s_nd < kP3sDef ? s_nd : kP3sDef;
   if (nd > 0) {      // (block uniform)
     part_evict<HASH>(a, nd, rec_base, d_rec, d_ent, d_base, s_lock, s_late, h_slot, h_cnt, tbl, tp0, rowb, s0);
@@ -162,7 +175,9 @@ fused_part3s_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restri
       // the first record (rank base 0) of an entry created by the eviction owns the unique row's key
       const int ent = d_ent[e], bs = d_base[e];
       const int mine = (((s_late[ent >> 5] >> (ent & 31)) & 1u) && bs == 0) ? 1 : 0;
-      a.rec_out4[rec_base + d_rec[e]] = make_int4(ent, bs, mine, 0);
+      int4* ro = &a.rec_out4[rec_base + d_rec[e]];     // (the key words written by the merge pass stay)
+      ro->x = ent | (mine << 30);
+      ro->y = bs;
     }
     __syncthreads();
   }
@@ -197,8 +212,10 @@ fused_part3s_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restri
       ++lid; pre += ec[k];
     }
   }
+  QST(4);
   unsigned long long pre_a = 0, pre_b = 0;
   lookback_sum2_1024(a.tstat, tb, p, pre_a, pre_b);     // (its barriers also publish h_pl / h_lid to the block)
+  QST(5);
   const int upre = (int)(pre_a >> 31), spre = (int)(pre_a & 0x7fffffffull);
   // ---- outputs per unique row: by the thread that owns the entry (consecutive entries -> consecutive unique ids)
   {
@@ -243,6 +260,7 @@ fused_part3s_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restri
       ++uid; pv += c;
     }
   }
+  QST(6);
   // ---- output pass: unique id / rank base / CSR position of every record (lazy reverse indices), the unique row's key, the CSR
   //      entries; the next round's record and state in flight.  Long lists (a hot key's occurrences in one tile) are collected and
   //      expanded by whole waves behind the loop (beyond 512 of them: by their own thread).
@@ -260,12 +278,12 @@ fused_part3s_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restri
       nrc = a.rec[rec_base + i0];
       nro = a.rec_out4[rec_base + i0];
       if (f >= total) continue;
-      const int en = ro.x, bs = ro.y;
+      const int en = ro.x & 0x3fffffff, bs = ro.y;
       const int uid = upre + (int)h_lid[en];
       const int pos = spre + h_pl[en] + bs;
       const int cn = (int)rc.w & ~kRecLate, br = (int)rc.y;
       a.rec_out4[rec_base + idx] = make_int4(((int)rc.w & kRecLate) ? ~uid : uid, bs, pos, 0);
-      if (ro.z) { int64_t pc = (int64_t)rc.x; pc = pc < a.n ? pc : a.n - 1; o.unique_keys[uid] = a.keys[pc]; }
+      if (ro.x & (1 << 30)) o.unique_keys[uid] = ((uint64_t)(uint32_t)ro.w << 32) | (uint64_t)(uint32_t)ro.z;
       if (cn == 1) csr_src[pos] = br;
       else if (cn <= 8) {
         for (int j = 0; j < cn; ++j) csr_src[pos + j] = ~(br + j);
@@ -282,6 +300,7 @@ fused_part3s_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restri
       for (int j = lane_id(); j < cn; j += 64) csr_src[pos + j] = ~(br + j);
     }
   }
+  QST(7);
   if (p == 0 && tid == 0) o.table_offsets[0] = __hip_atomic_load(&a.hdr[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 0 : upre;
   if (p == (int)a.P - 1 && tid == 0) {
     int U = upre + nu;
@@ -294,6 +313,8 @@ fused_part3s_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restri
     *o.total = O;
     if (U) ptr[U] = O;
   }
+  QST(8);
+  QST(9);
 }
 
 }  // namespace mi355

@@ -2248,7 +2248,7 @@ int64_t mi355_demb_forward_fused_workspace_bytes(int64_t n, int64_t num_tables) 
   return al256(8 * (num_tables + 1)) + al256(8 * n) /*unique keys*/ + al256(8 * n) /*occ_addr*/ + al256(4 * n) /*occ_slot*/ +
          al256(4 * nt) + 256 /*total*/ + al256(8 * n) + 4 * al256(4 * n) /*deferred*/ + al256(16 * (nt > 258 ? nt : 258)) /*look-back: two words per 1024 keys, and per partition*/ + 256 +
          (part_count(n, num_tables) ? 32 * (int64_t)part_count(n, num_tables) * (big_batch(n, num_tables) ? kPartCapBig : kPartCap) + 5 * 256 + 4 * kPartMaxBig : 0) /*partition records, table of every partition*/ +
-         (big_batch(n, num_tables) ? al256(16 * n) + al256(4 * (n / 2048 + 2)) + al256(4 * n) : 0) /*big-batch stage: staged records, tile counts, forwarding entries*/;
+         (big_batch(n, num_tables) ? al256(16 * n) + al256(4 * (n / 1024 + 2)) + al256(4 * n) : 0) /*big-batch stage: staged records, tile counts, forwarding entries*/;
 }
 
 // The fused forward (see the header of this file).  Persisted outputs as mi355_demb_forward; in eval mode (train == 0)
@@ -2333,7 +2333,7 @@ int mi355_demb_forward_fused(
         a.mt = num_tables > 1;
         if (big) {
           a.stage_rec = (uint4*)w; w += al256(16 * n);
-          a.tile_cnt = (int32_t*)w; w += al256(4 * (n / 2048 + 2));
+          a.tile_cnt = (int32_t*)w; w += al256(4 * (n / 1024 + 2));
           a.fwd = (int32_t*)w; w += al256(4 * n);
         }
       }
@@ -2480,13 +2480,19 @@ int mi355_demb_forward_fused(
           if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu_p = prop.multiProcessorCount;
           if (ncu_p <= 0) ncu_p = 256;
         }
-        const int cap = big ? 2048 : (pcv == 3 ? 1024 : ((pcv == 2 || n > (int64_t)ncu_p * 1024) ? 2048 : 1024));
+        // (big-batch stage: MI355_BIG_TILE = 1024 runs one-key-per-thread tiles, two blocks per CU -- an A/B knob)
+        static const int big_tile = getenv("MI355_BIG_TILE") ? atoi(getenv("MI355_BIG_TILE")) : 2048;
+        const int cap = big ? (big_tile == 1024 ? 1024 : 2048) : (pcv == 3 ? 1024 : ((pcv == 2 || n > (int64_t)ncu_p * 1024) ? 2048 : 1024));
         int64_t tlen = (big || pcv == 3) ? cap : (ceil_div(n, ncu_p) + 63) / 64 * 64;
         if (tlen > cap) tlen = cap;
         if (tlen < 256) tlen = 256;
         a.tl = (int)tlen;
         if (big) {   // tile-major records, then the split into the partitions' lists (big_index.h)
           const dim3 grid((unsigned)ceil_div(n, tlen)), blk(1024);
+          if (cap == 1024) {
+            if (seq) hipLaunchKernelGGL((probe_c_kernel<1024, 1024, 8, false, true, true>), grid, blk, 0, stream, a);
+            else hipLaunchKernelGGL((probe_c_kernel<1024, 1024, 8, false, false, true>), grid, blk, 0, stream, a);
+          } else
           if (seq) hipLaunchKernelGGL((probe_c_kernel<2048, 1024, 4, false, true, true>), grid, blk, 0, stream, a);
           else hipLaunchKernelGGL((probe_c_kernel<2048, 1024, 4, false, false, true>), grid, blk, 0, stream, a);
           const int ntiles = (int)ceil_div(n, tlen);
@@ -2695,7 +2701,7 @@ int mi355_demb_fused_materialize(void* workspace, int64_t workspace_bytes, int64
   w += al256(16 * nr);
   const int4* rec_out4 = (const int4*)w;
   const int32_t* fwd = nullptr;      // big-batch stage: occ_slot names the STAGED record
-  if (big) fwd = (const int32_t*)(w + al256(16 * nr) + 4 * kPartMaxBig + al256(16 * n) + al256(4 * (n / 2048 + 2)));
+  if (big) fwd = (const int32_t*)(w + al256(16 * nr) + 4 * kPartMaxBig + al256(16 * n) + al256(4 * (n / 1024 + 2)));
   hipLaunchKernelGGL(occ_from_records_kernel, dim3((unsigned)grid_for(n, 256, 4096)), dim3(256), 0, stream, occ_slot, occ_trank, rec_out4,
                      row_addr, n, reverse_indices, csr_rank, occ_addr, rerun_mark, fwd);
   MI355_LAUNCH_CHECK();
