@@ -114,26 +114,21 @@ fused_part3s_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restri
   auto rec_index = [&](int f) -> int {            // flat index -> index inside the partition's list
     return f < c1 ? f : (f < c2 ? subcap + f - c1 : (f < c3 ? 2 * subcap + f - c2 : 3 * subcap + f - c3));
   };
-  //      A record that claims an entry owns the unique row's KEY: the key of every record is fetched a round ahead too (a dependent
-  //      load behind the record's own) and travels in the record's output entry -- fetched in the output pass it was a second memory
-  //      round trip per round (first build: 6 us per 1 024 records, profiles/r05_stamps_16x_a.txt).
+  //      A record that claims an entry owns the unique row's KEY: it leaves the key's position in the entry (h_pl, which the scan
+  //      below overwrites with the occurrence prefix once the owners of the entries have read it).  Fetching the key per RECORD --
+  //      4.2 M random 8-byte loads at the 16x batch, three times the unique rows -- cost 40 K cycles per block wherever it sat
+  //      (profiles/r05_stamps_16x_a.txt, _b.txt); the entries' owners fetch 1.4 M, under the scan and the look-back.
   {
-    auto key_pos = [&](const uint4& r) -> int64_t { const int64_t pc = (int64_t)r.x; return pc < a.n ? pc : a.n - 1; };
-    uint4 cur = a.rec[rec_base + rec_index(tid < total ? tid : 0)];
-    uint4 nxt = a.rec[rec_base + rec_index(tid + kP3Threads < total ? tid + kP3Threads : 0)];
-    uint64_t kcur = a.keys[key_pos(cur)];
+    uint4 nxt = a.rec[rec_base + rec_index(tid < total ? tid : 0)];
     for (int f0 = 0; f0 < total; f0 += kP3Threads) {
       const int f = f0 + tid;
-      const uint4 rc = cur;
-      const uint64_t key = kcur;
-      cur = nxt;
-      kcur = a.keys[key_pos(cur)];
-      const int fn = f + 2 * kP3Threads;
+      const uint4 rc = nxt;
+      const int fn = f + kP3Threads;
       nxt = a.rec[rec_base + rec_index(fn < total ? fn : 0)];
       if (f >= total) continue;
       const int idx = rec_index(f);
       const int sl = (int)rc.z, cn = (int)rc.w;
-      int en = -1, bs = 0, mine = 0;
+      int en = 0, bs = 0;
       if (sl >= 0) {
         // (a partition the hash cannot hold -- more distinct slots than entries: the step is flagged, the record joins the row-less entry)
         int want = sl;
@@ -143,25 +138,22 @@ fused_part3s_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restri
         }
         bool cl;
         en = p2_insert<HASH>(h_slot, want, &cl);
-        if (cl) atomicAdd(&s_nclaim, 1);
-        mine = cl ? 1 : 0;
+        if (cl) { atomicAdd(&s_nclaim, 1); h_pl[en] = (int)rc.x; }
         bs = atomicAdd(&h_cnt[en], cn);
       } else {
         const int dj = atomicAdd(&s_nd, 1);
         if (dj < kP3sDef) {
-          d_rec[dj] = idx;
-          en = 0;                                  // (entry and rank base come from the eviction below)
+          d_rec[dj] = idx;                         // (entry and rank base come from the eviction below)
         } else {                                   // beyond what one step evicts for: no slot this step (like an insert that returns Busy)
           bool cl;
           en = p2_insert<HASH>(h_slot, (int)a.S, &cl);
-          if (cl) atomicAdd(&s_nclaim, 1);
-          mine = cl ? 1 : 0;
+          if (cl) { atomicAdd(&s_nclaim, 1); h_pl[en] = (int)rc.x; }
           bs = atomicAdd(&h_cnt[en], cn);
           a.rec[rec_base + idx].z = (uint32_t)a.S;
           a.rec[rec_base + idx].w = (uint32_t)(cn | kRecLate);
         }
       }
-      a.rec_out4[rec_base + idx] = make_int4(en | (mine << 30), bs, (int)(uint32_t)key, (int)(uint32_t)(key >> 32));
+      a.rec_out4[rec_base + idx] = make_int4(en, bs, 0, 0);
     }
   }
   QST(2);
@@ -174,22 +166,24 @@ fused_part3s_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restri
     for (int e = tid; e < nd; e += kP3Threads) {
       // the first record (rank base 0) of an entry created by the eviction owns the unique row's key
       const int ent = d_ent[e], bs = d_base[e];
-      const int mine = (((s_late[ent >> 5] >> (ent & 31)) & 1u) && bs == 0) ? 1 : 0;
-      int4* ro = &a.rec_out4[rec_base + d_rec[e]];     // (the key words written by the merge pass stay)
-      ro->x = ent | (mine << 30);
-      ro->y = bs;
+      if (((s_late[ent >> 5] >> (ent & 31)) & 1u) && bs == 0) h_pl[ent] = (int)a.rec[rec_base + d_rec[e]].x;
+      a.rec_out4[rec_base + d_rec[e]] = make_int4(ent, bs, 0, 0);
     }
     __syncthreads();
   }
   // ---- one scan over the hash ENTRIES: local unique id, occurrence prefix, hot-list positions (entry order = unique order)
   const bool hots = hot.n_tasks != nullptr;
   int es[kEnt], ec[kEnt];
+  uint64_t uk[kEnt];                      // key of every unique row of mine: in flight under the scan and the look-back
   int v5[5] = {0, 0, 0, 0, 0}, tot5[5];
 #pragma unroll
   for (int k = 0; k < kEnt; ++k) {
     const int e = tid * kEnt + k;
     es[k] = h_slot[e];
     ec[k] = es[k] != -1 ? h_cnt[e] : 0;
+    int64_t kp = es[k] != -1 ? (int64_t)h_pl[e] : 0;
+    kp = kp < a.n ? kp : a.n - 1;
+    uk[k] = a.keys[kp < 0 ? 0 : kp];
     if (es[k] == -1) continue;
     ++v5[0];
     v5[1] += ec[k];
@@ -231,6 +225,7 @@ fused_part3s_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restri
       o.row_addr[uid] = gs < a.S ? tp0 + ((int64_t)gs - s0) * rowb : 0;
       if (o.table_ids) o.table_ids[uid] = tbl;
       o.slots[uid] = gs < a.S ? (int64_t)gs - s0 : -1;
+      o.unique_keys[uid] = uk[k];
       ptr[uid] = pv;
       if (hots && c > hot.khot && c <= hot.kwave) {
         const int w = w_ex++;
@@ -278,12 +273,11 @@ fused_part3s_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restri
       nrc = a.rec[rec_base + i0];
       nro = a.rec_out4[rec_base + i0];
       if (f >= total) continue;
-      const int en = ro.x & 0x3fffffff, bs = ro.y;
+      const int en = ro.x, bs = ro.y;
       const int uid = upre + (int)h_lid[en];
       const int pos = spre + h_pl[en] + bs;
       const int cn = (int)rc.w & ~kRecLate, br = (int)rc.y;
       a.rec_out4[rec_base + idx] = make_int4(((int)rc.w & kRecLate) ? ~uid : uid, bs, pos, 0);
-      if (ro.x & (1 << 30)) o.unique_keys[uid] = ((uint64_t)(uint32_t)ro.w << 32) | (uint64_t)(uint32_t)ro.z;
       if (cn == 1) csr_src[pos] = br;
       else if (cn <= 8) {
         for (int j = 0; j < cn; ++j) csr_src[pos + j] = ~(br + j);
