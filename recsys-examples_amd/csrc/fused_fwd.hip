@@ -2202,12 +2202,15 @@ int64_t mi355_demb_aux_numel(int64_t total_slots, int64_t num_buckets) {
 static inline int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
 
 // the big-batch stage (big_index.h): one table, more keys than the reservation lists of path (c) serve (MI355_BIG_MIN, default
-// 1 M; MI355_BIG=0 turns it off: such batches then take the per-slot counters), at most 4 096 partitions of 11 264 keys
+// 1 M), up to 8 M keys (a hot key leaves one record per 2 048-key tile in ONE partition's list: beyond ~4 000 tiles three such
+// keys in a partition would fill it).  OPT-IN (MI355_BIG=1): measured at parity with the per-slot counters at the 8x / 16x / 32x
+// batches (0.82 / 1.49-1.51 / 2.87 ms against 0.80 / 1.52 / 2.87: profiles/r05_big_stage.txt) for 1.1 GB of step buffer at 16x,
+// and a flooded list flags the step where the per-slot counters cannot fail -- so batches beyond 1 M keys keep path (b) by default.
 static inline bool big_batch(int64_t n, int64_t num_tables) {
-  static const int on = getenv("MI355_BIG") ? atoi(getenv("MI355_BIG")) : 1;
+  static const int on = getenv("MI355_BIG") ? atoi(getenv("MI355_BIG")) : 0;
   static const int64_t min_keys = getenv("MI355_BIG_MIN") ? atoll(getenv("MI355_BIG_MIN")) : (int64_t)kPartMax * 1024;
   static const int part_env = getenv("MI355_FUSED_PART") ? atoi(getenv("MI355_FUSED_PART")) : 2;
-  return on && part_env >= 2 && num_tables == 1 && n > min_keys && n <= (int64_t)kPartMaxBig * 11264;
+  return on && part_env >= 2 && num_tables == 1 && n > min_keys && n <= (8ll << 20);
 }
 
 // partitions of the partitioned index stage for a batch of n keys (0: the batch takes the per-slot-counter path)
@@ -2218,9 +2221,10 @@ static inline int part_count(int64_t n, int64_t num_tables) {
   static const int mt_env = getenv("MI355_FUSED_MT") ? atoi(getenv("MI355_FUSED_MT")) : 1;
   if (!env || n < (64 << 10)) return 0;
   if (big_batch(n, num_tables)) {   // round 5: the big-batch stage (big_index.h): P = keys / 11 264 partitions of up to 32 768 records
-    int Pb = (int)((n + 11263) / 11264);
-    Pb = (Pb + 63) / 64 * 64;
-    return Pb < 256 ? 256 : Pb;
+    // (a multiple of the 256 CUs: the partition kernel runs one block per CU and generation -- 576 partitions at the 16x batch were
+    //  two generations and a quarter, profiles/r05_stamps_16x_c.txt)
+    int Pb = (int)((n / 11264 + 128) / 256 * 256);
+    return Pb < 256 ? 256 : (Pb > kPartMaxBig ? kPartMaxBig : Pb);
   }
   if (n > (int64_t)kPartMax * 1024) return 0;
   if (num_tables != 1 && (!mt_env || env < 2 || num_tables < 1 || num_tables > kFusedMaxT)) return 0;
