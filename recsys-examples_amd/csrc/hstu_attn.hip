@@ -2464,12 +2464,21 @@ __device__ __forceinline__ bool xch_other_chunk(const BwdAttnArgs& g, int b, int
 // long as its longest column of blocks however few units it holds: chunks of (15, 15, 2) units cost three full passes,
 // (11, 11, 10) not much more than one and a half.  A unit = ceil(L_b / 32)^2 tiles of 2 KB (tri: ng (ng + 1) / 2) in each of
 // the dS and P regions.  nchunks_out[0] = chunks used (diagnostics: the host launches its upper bound).
-__global__ void hstu_bwd_plan_kernel(const int* cu, int B, int H, int64_t cap_tiles, int tri, int64_t* base, int32_t* chunk,
-                                     int32_t* nchunks_out) {
-  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+// Round 5: the sequence lengths are staged in LDS by 256 threads first.  Read from global memory inside the 64 lanes' counting loops
+// (three dependent passes over B x H units, one scalar-cache miss per step) the kernel took 34-43 us of every jagged backward
+// (profiles/r04_step_timeline.txt); from LDS it is a few microseconds.
+constexpr int kPlanMaxB = 8192;
+__global__ void __launch_bounds__(256) hstu_bwd_plan_kernel(const int* cu, int B, int H, int64_t cap_tiles, int tri, int64_t* base,
+                                                            int32_t* chunk, int32_t* nchunks_out, int host_chunks, int* host_err) {
+  __shared__ int s_ng[kPlanMaxB];
+  if (blockIdx.x != 0) return;
+  const bool staged = B <= kPlanMaxB;
+  if (staged) for (int b = threadIdx.x; b < B; b += blockDim.x) s_ng[b] = (cu[b + 1] - cu[b] + 31) >> 5;
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
   const int lane = threadIdx.x;
   auto unit = [&](int b) -> int64_t {
-    const int64_t ngb = (cu[b + 1] - cu[b] + 31) >> 5;
+    const int64_t ngb = staged ? (int64_t)s_ng[b] : (int64_t)((cu[b + 1] - cu[b] + 31) >> 5);
     return tri ? ngb * (ngb + 1) / 2 : ngb * ngb;
   };
   auto count = [&](int64_t c) -> int {
@@ -2506,6 +2515,9 @@ __global__ void hstu_bwd_plan_kernel(const int* cu, int B, int H, int64_t cap_ti
     }
   }
   nchunks_out[0] = n + 1;
+  // the host launches `host_chunks` chunk passes from a bound over (T, B, max L); a plan that needs more (a token hint that does not
+  // belong to this batch) would leave units unprocessed: say so where the next call of the library sees it (pinned host word)
+  if (n + 1 > host_chunks && host_err) *host_err = n + 1;
 }
 
 // Query steps (multiples of `bq` rows) the dK pass runs for the key block n0 .. n0 + kBM - 1: [0, c_end) and [jump, lim).
@@ -4337,6 +4349,17 @@ int64_t mi355_hstu_attn_bwd_take_hint_(void) { const int64_t t = tl_bwd_tokens; 
 
 #endif
 
+// pinned host word the plan kernel writes when its plan needs more chunk passes than the host launched (see the kernel)
+static int* plan_err_word() {
+  static int* w = nullptr;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    if (hipHostMalloc((void**)&w, sizeof(int), hipHostMallocMapped) == hipSuccess && w) *w = 0; else w = nullptr;
+  }
+  return w;
+}
+
 // hstu_varlen_bwd (corelib/hstu/csrc/hstu_attn/hstu_api.cpp:525-719).  dq, dk, dv: contiguous bf16 [total, H, d].
 int HSTU_FN(mi355_hstu_attn_bwd)(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
                         int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t do_row_stride,
@@ -4353,6 +4376,14 @@ int HSTU_FN(mi355_hstu_attn_bwd)(const void* dout, const void* q, const void* k,
                       q_head_stride % 8 == 0 && k_head_stride % 8 == 0 && v_head_stride % 8 == 0 && do_head_stride % 8 == 0,
                   "q/k/v/dout strides must be multiples of 8 elements (16-byte rows)");
   if (batch == 0 || max_seqlen == 0) return MI355_OK;
+  if (int* ew = plan_err_word()) {
+    if (*ew) {
+      *ew = 0;
+      mi355_set_error("an earlier hstu backward planned more exchange chunks than were launched (token hint of another batch?): "
+                      "its gradients are incomplete");
+      return MI355_EINVAL;
+    }
+  }
   BwdAttnArgs g{};
   AttnArgs& a = g.f;
   a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v; a.out = nullptr;
@@ -4391,16 +4422,20 @@ int HSTU_FN(mi355_hstu_attn_bwd)(const void* dout, const void* q, const void* k,
       int64_t* base = (int64_t*)w;
       int32_t* chunk = (int32_t*)(w + (units * 8 + 255) / 256 * 256);
       int32_t* nch = (int32_t*)(w + hdr - 256);
-      hipLaunchKernelGGL(hstu_bwd_plan_kernel, dim3(1), dim3(64), 0, stream, cu_seqlens, (int)batch, (int)num_heads, cap_tiles, g.tri,
-                         base, chunk, nch);
       g.plan_base = base; g.plan_chunk = chunk;
       g.ds_ws = (uint16_t*)(w + hdr);
       if (regions == 2) g.p_ws = (uint16_t*)(w + hdr + cap_tiles * 2048);
       // chunks the greedy cut can need at most: every chunk but the last holds more than cap_tiles - umax tiles
       const int64_t bound = xch_tiles_bound(batch, num_heads, g.ng, tokens_hint, g.tri);
       nchunks = (int)((bound + (cap_tiles - umax)) / (cap_tiles - umax + 1));
+      // (round 5) a buffer as large as the bound itself holds every unit in ONE chunk: the formula above, which only knows that a
+      // chunk but the last holds more than cap - umax tiles, still said two -- and every jagged backward under the cap launched a
+      // second, empty set of three kernels (14 + 7 + 7 us at C4, profiles/r04_step_timeline.txt)
+      if (bound <= cap_tiles) nchunks = 1;
       if (nchunks < 1) nchunks = 1;
       if (nchunks > units) nchunks = (int)units;
+      hipLaunchKernelGGL(hstu_bwd_plan_kernel, dim3(1), dim3(256), 0, stream, cu_seqlens, (int)batch, (int)num_heads, cap_tiles, g.tri,
+                         base, chunk, nch, nchunks, plan_err_word());
     }
   }
   for (int c = 0; c < nchunks; ++c) {

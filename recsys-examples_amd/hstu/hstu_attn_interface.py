@@ -190,8 +190,11 @@ def _bwd_exchange_workspace(q, B, H, D, max_seqlen, plain_causal):
     dense = L.mi355_hstu_attn_bwd_ds_bytes(B, H, D, int(max_seqlen))
     n = dense if dense <= _DS_MAX_BYTES else L.mi355_hstu_attn_bwd_ds_bytes_capped(B, H, D, int(max_seqlen), int(q.shape[0]),
                                                                                  _DS_MAX_BYTES, int(bool(plain_causal)))
+    ws = torch.empty(max(int(n), 256), dtype=torch.uint8, device=q.device)
+    # the hint is consumed by the NEXT backward call of this thread: set it last, behind everything here that can raise (an
+    # allocation failure used to leave it behind for a later backward of another batch -- round-4 advisor finding)
     L.mi355_hstu_attn_bwd_hint_tokens(int(q.shape[0]))
-    return torch.empty(max(int(n), 256), dtype=torch.uint8, device=q.device)
+    return ws
 
 
 def hstu_varlen_bwd(dout, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_contexts, num_targets, target_group_size,
