@@ -126,6 +126,8 @@ struct FusedArgs {
   int32_t* tile_cnt;              // [tiles]
   int32_t* fwd;                   // [n] staged record -> its place in `rec` (-1: the partition's list was full)
   int cap;                        // records per partition of `rec` (kPartCap, or kPartCapBig in the big-batch stage)
+  int32_t* part_ready;            // [P] (round 5, the partition blocks riding in the gather's launch): 1 once partition p's deferred keys
+                                  // have their slots in the records (zeroed by the probe kernel; nullable)
 };
 
 __device__ __forceinline__ void store_digest(uint8_t* p, uint8_t d) {
@@ -1569,13 +1571,14 @@ __device__ __forceinline__ void block_scan5(int (&v)[5], int (&tot)[5], Publish 
 
 // sums of two packed words over ALL predecessors of partition t: one word pair per thread and round of 1 024 (one round for the
 // batches up to 1 M keys; the big-batch stage has up to 4 096 partitions), all of a round polled together
+template <int THREADS = kP3Threads>
 __device__ __forceinline__ void lookback_sum2_1024(const unsigned long long* ta, const unsigned long long* tb, int t,
                                                    unsigned long long& pre_a, unsigned long long& pre_b) {
   __shared__ unsigned long long s_sa, s_sb;
   if (threadIdx.x == 0) { s_sa = 0; s_sb = 0; }
   __syncthreads();
   unsigned long long xa = 0, xb = 0;
-  for (int r0 = 0; r0 < t; r0 += kP3Threads) {
+  for (int r0 = 0; r0 < t; r0 += THREADS) {
     const int idx = t - 1 - r0 - (int)threadIdx.x;
     unsigned long long va = idx >= 0 ? stat_load(ta + idx) : kStatAgg, vb = idx >= 0 ? stat_load(tb + idx) : kStatAgg;
     while ((va & kStatMask) == 0) { __builtin_amdgcn_s_sleep(1); va = stat_load(ta + idx); }
@@ -1597,12 +1600,12 @@ __device__ __forceinline__ void lookback_sum2_1024(const unsigned long long* ta,
 //      (the partition's LDS hash knows them all: every record of the bucket is in this block) and that nobody pinned
 //      (kernels.cuh:226-287, types.cuh:398-512); 8 lanes per key, a hashed LDS lock per bucket.  The slot goes back into the
 //      record: the gather finds the rows of the key's occurrences there.  Shared by the two partition kernels.
-template <int HASH, typename DRec>
+template <int HASH, typename DRec, int THREADS = kP3Threads>
 __device__ __forceinline__ void part_evict(FusedArgs& a, int nd, int64_t rec_base, const DRec* d_rec, int* d_ent, int* d_base, int* s_lock,
                                            unsigned* s_late, int* h_slot, int* h_cnt, int tbl, int64_t tp0, int64_t rowb, int64_t s0) {
       if (!a.timer) a.timer = device_clock();
       const int g = lane_id() & (G - 1);
-      const int gpb = kP3Threads / G;
+      const int gpb = THREADS / G;
       const int C = (int)a.t.C;
       for (int e0 = 0; e0 < nd; e0 += gpb) {
         const int e = e0 + (int)threadIdx.x / G;
@@ -2056,6 +2059,10 @@ gather_rows_eval_kernel(ProbeRefs pr, const int64_t* __restrict__ offsets, int B
   wave_copy_rows<SDT, DDT>(rp, i0, n, D, dst, dst_stride, lpr_log2);
 }
 
+}  // namespace mi355
+#include "part3_lean.h"
+namespace mi355 {
+
 // lazy per-occurrence outputs of path (c): reverse index and full rank of every occurrence from its record, late row addresses
 __global__ void __launch_bounds__(256)
 occ_from_records_kernel(const int32_t* __restrict__ occ_slot, const int32_t* __restrict__ occ_trank, const int4* __restrict__ rec_out4,
@@ -2320,7 +2327,7 @@ int mi355_demb_forward_fused(
   a.tile_bags = nullptr; a.occ_trank = nullptr;
   a.mt = 0; a.ptab = nullptr;
   a.gate = nullptr; a.gate_val = 0; a.ovf_word = 5; a.ovf_val = 1; a.rerun_mark = nullptr; a.tl = 0;
-  a.stage_rec = nullptr; a.tile_cnt = nullptr; a.fwd = nullptr; a.cap = kPartCap;
+  a.stage_rec = nullptr; a.tile_cnt = nullptr; a.fwd = nullptr; a.cap = kPartCap; a.part_ready = nullptr;
   a.magic0 = num_buckets > 0 ? ~0ull / (uint64_t)num_buckets : 0ull;   // (one table: its buckets are all the buckets)
   {
     const int P = train ? part_count(n, num_tables) : 0;
@@ -2390,6 +2397,13 @@ int mi355_demb_forward_fused(
   const bool big = part && a.stage_rec != nullptr && pathc && fast && pcv > 0;
   if (part && a.stage_rec && !big) { part = false; a.P = 0; a.stage_rec = nullptr; a.cap = kPartCap; }
   if (!part) pathc = false;
+  // round 5: the partition blocks ride in the gather's launch (part3_lean.h; MI355_PART_FUSED=0: the partition kernel of its own)
+  static const int pf_env = getenv("MI355_PART_FUSED") ? atoi(getenv("MI355_PART_FUSED")) : 1;
+  static int pf_live = 1;
+  if (env_live) { const char* e3 = getenv("MI355_PART_FUSED"); pf_live = e3 ? atoi(e3) : 1; }
+  const int pf_mode = env_live ? pf_live : pf_env;      // 1: the partition role inlined, 2: as a call (A/B)
+  const bool part_fused = pathc && !big && pf_mode != 0;
+  if (part_fused) a.part_ready = (int32_t*)(a.tstat + 2 * a.P);
   // opt-in: an overflowed step is re-run on the per-slot-counter path inside this call (the reference never skips an update,
   // unique_op.cu:484-714): three more launches behind the gather that return at once in the steady state
   static const int rerun_env = getenv("MI355_FUSED_OVERFLOW_RERUN") ? atoi(getenv("MI355_FUSED_OVERFLOW_RERUN")) : 0;
@@ -2559,14 +2573,21 @@ int mi355_demb_forward_fused(
     late.table_ptrs = table_ptrs; late.table_value_dims = table_value_dims; late.tbo = table_bucket_offsets;
     late.C = bucket_capacity; late.elem_bytes = a.elem_bytes; late.T = (int)num_tables;
     const int nsub = 64 >> lg;
-    if (big) hipLaunchKernelGGL(fused_part3s_kernel, dim3((unsigned)a.P), dim3(kP3Threads), 0, stream, a, o, bptr, bcsr, hot);
+    if (part_fused) { late.ready = a.part_ready; late.cap = kPartCap; }
+    else if (big) hipLaunchKernelGGL(fused_part3s_kernel, dim3((unsigned)a.P), dim3(kP3Threads), 0, stream, a, o, bptr, bcsr, hot);
     else hipLaunchKernelGGL(fused_part3_kernel<kPartCap>, dim3((unsigned)a.P), dim3(kP3Threads), 0, stream, a, o, bptr, bcsr, hot);
     MI355_LAUNCH_CHECK();
     if (seq) {
       RoctxRange rg("op:gather_embedding");
       GatherTimer gt(stream);
       const unsigned grid = (unsigned)ceil_div(n, 256);
-#define LAUNCH_RG(S, D) hipLaunchKernelGGL((gather_rows_late_kernel<S, D>), dim3(grid), dim3(256), 0, stream, a.occ_addr, late, n, (int)emb_dim, out, emb_dim, lg)
+#define LAUNCH_RG(S, D)                                                                                                                \
+  do {                                                                                                                                 \
+    if (part_fused) hipLaunchKernelGGL((gather_rows_part_kernel<S, D>), dim3((grid + 1) / 2 + (unsigned)a.P), dim3(kP3lThreads), 0, stream, a, o, bptr,  \
+                                       bcsr, hot, a.occ_addr, late, n, (int)emb_dim, out, emb_dim, lg);                                \
+    else hipLaunchKernelGGL((gather_rows_late_kernel<S, D>), dim3(grid), dim3(256), 0, stream, a.occ_addr, late, n, (int)emb_dim, out, \
+                            emb_dim, lg);                                                                                              \
+  } while (0)
       if (value_dtype == 0 && out_dtype == 0) LAUNCH_RG(kF32, kF32);
       else if (value_dtype == 0) LAUNCH_RG(kF32, kBF16);
       else if (out_dtype == 0) LAUNCH_RG(kBF16, kF32);
@@ -2576,7 +2597,14 @@ int mi355_demb_forward_fused(
       RoctxRange rg("op:gather_embedding");
       GatherTimer gt(stream);
       const unsigned grid = (unsigned)grid_for(num_bags, 4 * nsub * 4, 1 << 20);
-#define LAUNCH_PG(S, D) hipLaunchKernelGGL((gather_pooled_late_kernel<S, D>), dim3(grid), dim3(256), 0, stream, g, late, lg)
+#define LAUNCH_PG(S, D)                                                                                                                \
+  do {                                                                                                                                 \
+    if (part_fused && pf_mode == 2) hipLaunchKernelGGL((gather_pooled_part_kernel<S, D, true>), dim3((grid + 1) / 2 + (unsigned)a.P), dim3(kP3lThreads), 0, stream, a, o, bptr, \
+                                       bcsr, hot, g, late, lg);                                                                        \
+    else if (part_fused) hipLaunchKernelGGL((gather_pooled_part_kernel<S, D, false>), dim3((grid + 1) / 2 + (unsigned)a.P), dim3(kP3lThreads), 0, stream, a, o, bptr, \
+                                       bcsr, hot, g, late, lg);                                                                        \
+    else hipLaunchKernelGGL((gather_pooled_late_kernel<S, D>), dim3(grid), dim3(256), 0, stream, g, late, lg);                         \
+  } while (0)
       if (value_dtype == 0 && out_dtype == 0) LAUNCH_PG(kF32, kF32);
       else if (value_dtype == 0) LAUNCH_PG(kF32, kBF16);
       else if (out_dtype == 0) LAUNCH_PG(kBF16, kF32);

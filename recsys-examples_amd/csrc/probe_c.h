@@ -119,11 +119,12 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
     if (a.hot_counters && tid < 3) a.hot_counters[2 * tid] = 0;   // n_hot, n_tasks, n_wave
     if (a.rerun_mark && tid == 0) *a.rerun_mark = 0;
   }
-  if (a.tstat) {   // the 2 P look-back words of the partition kernel
-    const int per = (2 * a.P + (int)gridDim.x - 1) / (int)gridDim.x;
+  if (a.tstat) {   // the 2 P look-back words of the partition kernel (+ its P ready flags, two per word, behind them)
+    const int nw = 2 * a.P + (a.part_ready ? (a.P + 1) / 2 : 0);
+    const int per = (nw + (int)gridDim.x - 1) / (int)gridDim.x;
     for (int k = tid; k < per; k += THREADS) {
       const int wd = (int)blockIdx.x * per + k;
-      if (wd < 2 * a.P) a.tstat[wd] = 0ull;
+      if (wd < nw) a.tstat[wd] = 0ull;
     }
   }
   for (int s = tid; s < HASH; s += THREADS) { s_tab[s] = -1; s_cnt[s] = 0; }

@@ -124,6 +124,11 @@ int64_t mi355_vmm_reserved_bytes(void* handle) { return handle ? (int64_t)((Vmm*
 int mi355_vmm_destroy(void* handle) {
   if (!handle) return MI355_OK;
   Vmm* v = (Vmm*)handle;
+  // Page-table changes race with work in flight -- not only copies into THIS buffer (see the sync in front of every mapping): a
+  // buffer released by a finalizer while ANOTHER module's forward was running lost that forward's first-touch row stores (round 5:
+  // a growth test that ran right behind another one read zero rows in its first step, and only then).  Unmapping is rare: drain
+  // the device first.
+  (void)hipDeviceSynchronize();
   if (!v->host) {
     if (v->mapped) hipMemUnmap(v->base, v->mapped);
     for (auto h : v->handles) hipMemRelease(h);

@@ -12,6 +12,7 @@ import bench
 ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--variants", default="0,1,2,3")
+ap.add_argument("--var", default="MI355_PROBE_C", help="the per-call knob to switch (any knob the library re-reads under MI355_ENV_LIVE)")
 ap.add_argument("--batch", type=int, default=65536)
 a = ap.parse_args()
 variants = a.variants.split(",")
@@ -26,7 +27,7 @@ with torch.no_grad():
 torch.cuda.synchronize()
 ref_out = {}
 for v in variants:          # identical outputs and unique counts (zero gradient: the rows stay put)
-    os.environ["MI355_PROBE_C"] = v
+    os.environ[a.var] = v
     for bi in (0, 7):
         k, o = batches[bi]
         out, st = module._forward_impl(k, o, train=True)
@@ -42,7 +43,7 @@ print("outputs / unique counts identical over variants", variants)
 times = {v: [] for v in variants}
 for r in range(a.rounds):
     for v in variants:
-        os.environ["MI355_PROBE_C"] = v
+        os.environ[a.var] = v
         for k, o in batches[:5]:
             out, st = module._forward_impl(k, o, train=True); module._backward_impl(st, grad)
         torch.cuda.synchronize()
@@ -53,4 +54,4 @@ for r in range(a.rounds):
         torch.cuda.synchronize()
         times[v].append((time.perf_counter() - t0) / (3 * len(batches)) * 1e3)
 for v in variants:
-    print(f"MI355_PROBE_C={v}: ms/step per round " + " ".join(f"{x:.4f}" for x in times[v]) + f"   median {np.median(times[v]):.4f}")
+    print(f"{a.var}={v}: ms/step per round " + " ".join(f"{x:.4f}" for x in times[v]) + f"   median {np.median(times[v]):.4f}")
