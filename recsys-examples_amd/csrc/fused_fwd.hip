@@ -2257,7 +2257,7 @@ int mi355_demb_forward_fused_partitions(int64_t n, int64_t num_tables, int64_t n
 int64_t mi355_demb_forward_fused_workspace_bytes(int64_t n, int64_t num_tables) {
   const int64_t nt = (n + 1023) / 1024 + 2;
   return al256(8 * (num_tables + 1)) + al256(8 * n) /*unique keys*/ + al256(8 * n) /*occ_addr*/ + al256(4 * n) /*occ_slot*/ +
-         al256(4 * nt) + 256 /*total*/ + al256(8 * n) + 4 * al256(4 * n) /*deferred*/ + al256(16 * (nt > 258 ? nt : 258)) /*look-back: two words per 1024 keys, and per partition*/ + 256 +
+         al256(4 * nt) + 256 /*total*/ + al256(8 * n) + 4 * al256(4 * n) /*deferred*/ + al256(24 * (nt > 258 ? nt : 258)) /*look-back: two words per 1024 keys, and per partition*/ + 256 +
          (part_count(n, num_tables) ? 32 * (int64_t)part_count(n, num_tables) * (big_batch(n, num_tables) ? kPartCapBig : kPartCap) + 5 * 256 + 4 * kPartMaxBig : 0) /*partition records, table of every partition*/ +
          (big_batch(n, num_tables) ? al256(16 * n) + al256(4 * (n / 1024 + 2)) + al256(4 * n) : 0) /*big-batch stage: staged records, tile counts, forwarding entries*/;
 }
@@ -2320,7 +2320,7 @@ int mi355_demb_forward_fused(
   a.d_cnt = (int32_t*)w; w += al256(4 * n);
   a.d_slot = (int32_t*)w; w += al256(4 * n);
   a.d_base = (int32_t*)w; w += al256(4 * n);
-  a.tstat = (unsigned long long*)w; w += al256(16 * (nt > 258 ? nt : 258));
+  a.tstat = (unsigned long long*)w; w += al256(24 * (nt > 258 ? nt : 258));
   // partitioned index stage: one table, a batch of 64 K .. 1 M keys, at least 8 buckets per partition, training
   a.P = 0; a.spp = 1; a.pcount = aux + 64;
   a.rec = nullptr; a.rec_out = nullptr; a.rec_out4 = nullptr;
@@ -2397,13 +2397,14 @@ int mi355_demb_forward_fused(
   const bool big = part && a.stage_rec != nullptr && pathc && fast && pcv > 0;
   if (part && a.stage_rec && !big) { part = false; a.P = 0; a.stage_rec = nullptr; a.cap = kPartCap; }
   if (!part) pathc = false;
-  // round 5: the partition blocks ride in the gather's launch (part3_lean.h; MI355_PART_FUSED=0: the partition kernel of its own)
+  // round 5: the partition blocks ride in the gather's launch (part3_lean.h): sequence lookups by default
   static const int pf_env = getenv("MI355_PART_FUSED") ? atoi(getenv("MI355_PART_FUSED")) : 1;
   static int pf_live = 1;
   if (env_live) { const char* e3 = getenv("MI355_PART_FUSED"); pf_live = e3 ? atoi(e3) : 1; }
-  const int pf_mode = env_live ? pf_live : pf_env;      // 1: the partition role inlined, 2: as a call (A/B)
-  const bool part_fused = pathc && !big && pf_mode != 0;
+  const int pf_mode = env_live ? pf_live : pf_env;      // 0 off, 1 sequence lookups (default: measured gain), 2 pooled batches as well (measured loss)
+  const bool part_fused = pathc && !big && (pf_mode >= 2 || (pf_mode == 1 && seq));
   if (part_fused) a.part_ready = (int32_t*)(a.tstat + 2 * a.P);
+  if (part_fused && env_live) { const char* e4 = getenv("MI355_PART_PRIO"); if (e4 && atoi(e4) == 0) a.dbg |= 4; }
   // opt-in: an overflowed step is re-run on the per-slot-counter path inside this call (the reference never skips an update,
   // unique_op.cu:484-714): three more launches behind the gather that return at once in the steady state
   static const int rerun_env = getenv("MI355_FUSED_OVERFLOW_RERUN") ? atoi(getenv("MI355_FUSED_OVERFLOW_RERUN")) : 0;
@@ -2599,9 +2600,7 @@ int mi355_demb_forward_fused(
       const unsigned grid = (unsigned)grid_for(num_bags, 4 * nsub * 4, 1 << 20);
 #define LAUNCH_PG(S, D)                                                                                                                \
   do {                                                                                                                                 \
-    if (part_fused && pf_mode == 2) hipLaunchKernelGGL((gather_pooled_part_kernel<S, D, true>), dim3((grid + 1) / 2 + (unsigned)a.P), dim3(kP3lThreads), 0, stream, a, o, bptr, \
-                                       bcsr, hot, g, late, lg);                                                                        \
-    else if (part_fused) hipLaunchKernelGGL((gather_pooled_part_kernel<S, D, false>), dim3((grid + 1) / 2 + (unsigned)a.P), dim3(kP3lThreads), 0, stream, a, o, bptr, \
+    if (part_fused) hipLaunchKernelGGL((gather_pooled_part_kernel<S, D>), dim3((grid + 1) / 2 + (unsigned)a.P), dim3(kP3lThreads), 0, stream, a, o, bptr, \
                                        bcsr, hot, g, late, lg);                                                                        \
     else hipLaunchKernelGGL((gather_pooled_late_kernel<S, D>), dim3(grid), dim3(256), 0, stream, g, late, lg);                         \
   } while (0)
@@ -2727,7 +2726,7 @@ int mi355_demb_fused_materialize(void* workspace, int64_t workspace_bytes, int64
   const int* rerun_mark = (const int*)w + 16;     // (the forward's `total` block: [8] occurrences, [16] the re-run mark)
   w += 256 + al256(8 * n);
   const int32_t* occ_trank = (const int32_t*)w; w += 4 * al256(4 * n);
-  w += al256(16 * (nt > 258 ? nt : 258));
+  w += al256(24 * (nt > 258 ? nt : 258));
   const bool big = big_batch(n, num_tables);
   const int64_t nr = (int64_t)P * (big ? kPartCapBig : kPartCap);
   w += al256(16 * nr);

@@ -11,6 +11,12 @@
 // ~45 KB of LDS.  The first P blocks of the grid are partition blocks -- one per CU at P = 256, taking 4 of its 32 wave slots --, the
 // rest the gather's.  The partition work is slower than on 1 024 threads (four rounds of 256 records instead of one) and nobody
 // waits for it: it finishes under the gather.
+// MEASURED (tools/ab_probe_c.py --var MI355_PART_FUSED, profiles/r05_part_fused.txt): sequence lookups gain (8 x 16 K tokens
+// 0.0761 -> 0.0679 ms: the row copy is indifferent to what shares its CU), the POOLED C2 step loses (0.1227 -> 0.1288 ms): next to
+// 24 streaming waves per CU every round trip of the partition block's chain takes 2-3x as long -- its life goes from 12 to 38 us
+// (50 for the slowest block) and the launch ends with it, 54 us against 21 + 30 apart; raising the role's wave priority changes
+// nothing, and with the gather blocks FIRST in the grid a batch whose keys all go through the eviction would deadlock on the
+// ready flags.  Hence: on by default for sequence lookups only (MI355_PART_FUSED: 0 off, 1 sequence, 2 pooled as well).
 // A gather lane that meets an occurrence whose key went through the partition block's eviction (address word 1: bucket full) waits for
 // that partition's ready flag (LateRefs::ready); partition blocks are dispatched ahead of every gather block, so the wait cannot deadlock.
 //
@@ -36,12 +42,16 @@ __device__ __forceinline__ void part3_lean(FusedArgs& a, const EmitOut& o, int* 
   __shared__ int b_pos[kBigMax], b_ref[kBigMax], b_cnt[kBigMax];
   const int tid = (int)threadIdx.x;
   const int64_t rec_base = (int64_t)p * CAP;
+  // a latency chain next to 24 streaming waves of the gather: its few instructions go first (MI355_PART_PRIO=0 in FusedArgs::dbg bit 2 turns it off)
+  if (!(a.dbg & 4)) __builtin_amdgcn_s_setprio(3);
+  QST(0);
   const int mv = a.pcount[p * kPartSub + (tid & (kPartSub - 1))];
   for (int i = tid; i < HASH; i += T) { h_slot[i] = -1; h_cnt[i] = 0; }
   if (tid < 256) s_lock[tid] = 0;
   if (tid < HASH / 32) s_late[tid] = 0;
   if (tid == 0) { s_nd = 0; s_nbig = 0; }
   __syncthreads();
+  QST(1);
   int c1, c2, c3, total;
   {
     const int lim = a.mt ? CAP : kSubCapL;       // (several tables: one list per partition)
@@ -94,7 +104,9 @@ __device__ __forceinline__ void part3_lean(FusedArgs& a, const EmitOut& o, int* 
       a.rec_out4[rec_base + idx] = make_int4(en, bs, 0, 0);
     }
   }
+  QST(2);
   __syncthreads();
+  QST(3);
   const int nd = s_nd < kDefMax ? s_nd : kDefMax;
   if (nd > 0) {      // (block uniform)
     part_evict<HASH, int, T>(a, nd, rec_base, d_rec, d_ent, d_base, s_lock, s_late, h_slot, h_cnt, tbl, tp0, rowb, s0);
@@ -135,8 +147,10 @@ __device__ __forceinline__ void part3_lean(FusedArgs& a, const EmitOut& o, int* 
     stat_store(tb + p, kStatAgg | ((unsigned long long)t5[2] << 40) | ((unsigned long long)t5[3] << 20) | (unsigned long long)t5[4]);
   });
   const int nu = tot5[0], tot2 = tot5[1], th = tot5[2], tt = tot5[3], tw = tot5[4];
+  QST(4);
   unsigned long long pre_a = 0, pre_b = 0;
   lookback_sum2_1024<T>(a.tstat, tb, p, pre_a, pre_b);
+  QST(5);
   const int upre = (int)(pre_a >> 31), spre = (int)(pre_a & 0x7fffffffull);
   // ---- outputs per unique row, and the entry's (local id, occurrence prefix) for the output pass
   {
@@ -188,6 +202,7 @@ __device__ __forceinline__ void part3_lean(FusedArgs& a, const EmitOut& o, int* 
       ++lid; pre += c;
     }
   }
+  QST(6);
   __syncthreads();     // h_pl / h_lid of every entry
   // ---- output pass: unique id / rank base / CSR position of every record (lazy reverse indices) and the CSR entries
   {
@@ -225,6 +240,7 @@ __device__ __forceinline__ void part3_lean(FusedArgs& a, const EmitOut& o, int* 
       for (int j = lane_id(); j < cn; j += 64) csr_src[pos + j] = ~(br + j);
     }
   }
+  QST(7);
   // unique rows in front of the partition's table (the first partition of every table; partitions are table-major)
   if (first_of_table && tid == 0)
     o.table_offsets[tbl] = __hip_atomic_load(&a.hdr[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 0 : upre;
@@ -240,28 +256,25 @@ __device__ __forceinline__ void part3_lean(FusedArgs& a, const EmitOut& o, int* 
     *o.total = O;
     if (U) ptr[U] = O;
   }
-}
-
-// (A/B: the partition role as a real call -- its register pressure and spills then stay out of the gather role's allocation, at the
-//  price of the arguments travelling through scratch memory)
-template <int CAP>
-__device__ __attribute__((noinline)) void part3_lean_call(FusedArgs& a, const EmitOut& o, int* ptr, int* csr_src, const HotList& hot, int p) {
-  part3_lean<CAP>(a, o, ptr, csr_src, hot, p);
+  QST(8);
+  QST(9);
 }
 
 // the pooled gather of path (c) with the partition blocks in front (grid = P + gather blocks)
-template <int SDT, int DDT, bool kCall = false>
+template <int SDT, int DDT>
 __global__ void __launch_bounds__(kP3lThreads, 8)
 gather_pooled_part_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restrict__ csr_src, HotList hot, PoolArgs g, LateRefs late,
                           int lpr_log2) {
-  if ((int)blockIdx.x < a.P) {
-    if constexpr (kCall) part3_lean_call<kPartCap>(a, o, ptr, csr_src, hot, (int)blockIdx.x);
-    else part3_lean<kPartCap>(a, o, ptr, csr_src, hot, (int)blockIdx.x);
-    return;
-  }
+  if ((int)blockIdx.x < a.P) { part3_lean<kPartCap>(a, o, ptr, csr_src, hot, (int)blockIdx.x); return; }
   const int64_t bid = (int64_t)blockIdx.x - a.P;
+#if MI355_STAMPS
+  if (threadIdx.x == 0 && bid < 16384) { g_st_fgather[bid * 4] = __builtin_amdgcn_s_memtime(); g_st_fgather[bid * 4 + 2] = wall_clock64(); }
+#endif
   const int64_t sg = (bid * (kP3lThreads >> 6) + (threadIdx.x >> 6)) * (64 >> lpr_log2) + (lane_id() >> lpr_log2);
   gather_pooled_pipe<SDT, DDT, 3, 4, 4>(g, late, lpr_log2, sg);
+#if MI355_STAMPS
+  if (threadIdx.x == 0 && bid < 16384) { g_st_fgather[bid * 4 + 1] = __builtin_amdgcn_s_memtime(); g_st_fgather[bid * 4 + 3] = wall_clock64(); }
+#endif
 }
 
 // the sequence gather of path (c) with the partition blocks in front

@@ -92,7 +92,11 @@ if os.environ.get("MI355_FUSED_PART", "2") == "1":
     dump("mi355_debug_stamps_scatter", 2048, 6, SCAT, "csr_scatter_kernel")
 PART2 = ["start -> record loads issued + LDS init", "wait: barrier", "merge (LDS hash insert + counts + rank bases out)", "wait: barrier",
          "entry scan + publish sums", "look-back", "outputs per unique row", "outputs per record (CSR entries)", "-"]
-if os.environ.get("MI355_FUSED_PART", "2") != "1":
+PART_L = ["init + barrier", "merge pass", "wait: barrier", "eviction check, entry sums, block scan, publish", "look-back",
+          "unique-row outputs (+ keys)", "wait: barrier", "output pass (CSR entries)", "tail", "-"]
+if os.environ.get("MI355_FUSED_PART", "2") != "1" and os.environ.get("MI355_PART_FUSED", "1") != "0":
+    dump("mi355_debug_stamps_part", 1024, 10, PART_L[:9], "part3_lean (partition role of the gather's launch)")
+elif os.environ.get("MI355_FUSED_PART", "2") != "1":
     dump("mi355_debug_stamps_part", 1024, 10, PART2, "fused_part3_kernel")
     dump("mi355_debug_stamps_fgather", 16384, 2, None, "gather_pooled_late_kernel (thread 0 of each block)")
 dump("mi355_debug_stamps_gather", 16384, 2, None, "gather_pooled_pipe_kernel (thread 0 of each block)")
