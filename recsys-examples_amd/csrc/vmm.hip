@@ -7,6 +7,7 @@
 // What a table gains from the stable address: the flat value buffer of a table that grows by rehash keeps its base pointer
 // (row addresses = base + slot * row_bytes stay computable from one number), and growing costs no copy of the old rows.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/recsys_amd.h"
 #include <sys/mman.h>
 #include <unistd.h>
@@ -59,6 +60,10 @@ int map_more(Vmm* v, size_t new_bytes) {
     }
     v->handles.push_back(h);
     if (!hip_ok(hipMemset(v->base + v->mapped, 0, add), "hipMemset")) return MI355_ELAUNCH;
+    // ... and the fill must have LANDED before anybody writes rows: hipMemset returns before the blit has run, and with RCCL's
+    // queues in the process it was seen to run behind the first forward's first-touch row stores of a fresh module, wiping some of
+    // them (round 5: tools/runs/diag_growth.py -- keys found, rows zero).  Mapping is rare: drain the device.
+    if (!hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize")) return MI355_ELAUNCH;
   } else {
     char* p = v->base + v->mapped;
     if (mprotect(p, add, PROT_READ | PROT_WRITE) != 0) { mi355_set_error("vmm: mprotect failed"); return MI355_ELAUNCH; }
@@ -124,15 +129,18 @@ int64_t mi355_vmm_reserved_bytes(void* handle) { return handle ? (int64_t)((Vmm*
 int mi355_vmm_destroy(void* handle) {
   if (!handle) return MI355_OK;
   Vmm* v = (Vmm*)handle;
-  // Page-table changes race with work in flight -- not only copies into THIS buffer (see the sync in front of every mapping): a
-  // buffer released by a finalizer while ANOTHER module's forward was running lost that forward's first-touch row stores (round 5:
-  // a growth test that ran right behind another one read zero rows in its first step, and only then).  Unmapping is rare: drain
-  // the device first.
+  // Page-table changes race with work in flight (see the sync in front of every mapping); a buffer may be released by a finalizer
+  // while another module's kernels run.  Unmapping is rare: drain the device first.
   (void)hipDeviceSynchronize();
   if (!v->host) {
     if (v->mapped) hipMemUnmap(v->base, v->mapped);
     for (auto h : v->handles) hipMemRelease(h);
-    if (v->base) hipMemAddressFree(v->base, v->reserved);
+    // The address range is NOT handed back (MI355_VMM_FREE_VA=1 does): a later reservation that lands on a freed range was seen
+    // to lose first-touch row stores of its first kernel -- keys found, rows zero, for a third of the rows, only when another
+    // extendable buffer had been destroyed just before (round 5, tools/runs/diag_growth.py; stale translations of the old mapping
+    // is the only reading that fits).  Virtual address space is not a scarce resource; the physical chunks are released above.
+    static const bool free_va = getenv("MI355_VMM_FREE_VA") && atoi(getenv("MI355_VMM_FREE_VA")) != 0;
+    if (v->base && free_va) hipMemAddressFree(v->base, v->reserved);
   } else {
     for (auto& r : v->registered) hipHostUnregister(r.first);
     if (v->base) munmap(v->base, v->reserved);
