@@ -305,7 +305,10 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
       my_base[j] = 0;
       if (p < a.P) {
         const int c = s_hist[p];
-        if (c) my_base[j] = atomicAdd(&a.pcount[p * kPartSub + sub], c);
+        // (FusedArgs::dbg bit 3 skips the reservation -- results wrong, a timing probe: 24.3 -> 19.6 us at C2, the 65 K returning
+        //  atomics of a launch drain for ~5 us.  A layout without them -- every tile owning q slots of every partition's list --
+        //  was built and dropped: profiles/r05_cells_ab.txt)
+        if (c) my_base[j] = (a.dbg & 8) ? 0 : atomicAdd(&a.pcount[p * kPartSub + sub], c);
         if constexpr (kMT) {
           if (blockIdx.x == 0) {   // the partition kernel learns its table from here
             int t = 0;

@@ -457,7 +457,10 @@ class ExternalStorageTables(BatchedDynamicEmbeddingTablesV2):
         return nn.Module.train(self, mode)
 
     def size(self, table_id: Optional[int] = None):
-        """keys the store holds (with caching=True: after a flush(), which this call does not imply)"""
+        """keys the store holds (with caching=True: after a flush(), which this call does not imply).  The `Storage` interface
+        (types.py, as the reference's) counts over all tables: a per-table count is not something it offers"""
+        if table_id is not None:
+            raise NotImplementedError("size(table_id) with an external storage: Storage.size() counts all tables")
         return self._storage.size()
 
     @property

@@ -593,6 +593,13 @@ def block_bucketize_sparse_features(lengths, indices, bucketize_pos, sequence, d
         bspf = torch.as_tensor(batch_size_per_feature, device=dev).to(torch.int64).view(-1)
         if bspf.numel() != F:
             raise RuntimeError("batch_size_per_feature must have one entry per feature")
+        # (round-4 advisor) the bags past the last start would be attributed to feature F - 1, a short sum would misroute them: when
+        # the sizes are host values (a list / tuple / CPU tensor, as TorchRec passes them) the sum is checked here, without a sync
+        if not (isinstance(batch_size_per_feature, torch.Tensor) and batch_size_per_feature.is_cuda):
+            total = int(sum(int(x) for x in (batch_size_per_feature.tolist() if isinstance(batch_size_per_feature, torch.Tensor)
+                                            else batch_size_per_feature)))
+            if total != FB:
+                raise RuntimeError(f"sum(batch_size_per_feature) = {total} does not match lengths.numel() = {FB}")
         fstart = torch.zeros(F + 1, dtype=torch.int64, device=dev)
         torch.cumsum(bspf, 0, out=fstart[1:])
         B = 0
