@@ -256,6 +256,44 @@ int mi355_permute_bags(int64_t num_sources, int64_t num_features, int64_t batch_
                        int64_t num_elements, const int64_t* in_offsets, const int64_t* out_offsets, const void* in_keys,
                        void* out_keys, hipStream_t stream);
 
+/* --------------------------------------------------- exchanges of the row-wise sharded lookup ---- */
+
+/* The collectives of a row-wise (model-parallel) sharded step, driven from INSIDE the library -- one call per stage, RCCL on
+ * the HIP streams the caller names (csrc/exchange.hip).  Replaces, for GPU tensors, the c10d call sequence of
+ * dynamicemb/input_dist.py:199-285 (RwSparseFeaturesDist -> TorchRec KJTAllToAll: lengths all-to-all, keys all-to-all-v, recat)
+ * and of the output dists of planner/rw_sharding.py:85-158 (sequence: rows back), :191-261 (pooled: reduce-scatter of partial
+ * sums, here all-to-all + local sum; backward all-gather).  RCCL is bound at run time from the librccl.so the process already
+ * holds (torch's): mi355_rw_load_rccl(path).  Rank 0 draws two unique ids (128 bytes each) and hands them to every rank by
+ * any means (the module broadcasts them over the existing process group); mi355_rw_create is collective. */
+int mi355_rw_load_rccl(const char* librccl_path);
+int mi355_rw_unique_id(void* out, int64_t bytes);
+int mi355_rw_create(const void* id_input_dist, const void* id_output_dist, int world_size, int rank, void** handle);
+int mi355_rw_destroy(void* handle);
+/* input dist, first half, on `stream` (behind what `producer_stream` holds): block_bucketize -> all-to-all of the lengths
+ * [W][F*B] -> exclusive offsets of the received lengths -> per-peer key counts into pinned memory.  Arrays as
+ * mi355_block_bucketize; recv_lengths [W*F*B], recv_offsets [W*F*B+1].  *ticket names the counts for the second half. */
+int mi355_rw_input_begin(void* handle, int64_t num_features, int64_t batch_size, const int64_t* offsets, const void* keys,
+                         const int64_t* block_sizes, const int32_t* dist_types, int64_t* new_lengths, int64_t* new_offsets,
+                         void* new_keys, int64_t* unbucketize_permute, int64_t* recv_lengths, int64_t* recv_offsets,
+                         hipStream_t producer_stream, hipStream_t stream, int* ticket);
+/* the one host read of the exact exchange: waits for the launch that wrote the counts; send_splits / recv_splits [W] (host),
+ * totals[0] = keys sent, totals[1] = keys received (the size of the buffer mi355_rw_input_keys fills) */
+int mi355_rw_input_counts(void* handle, int ticket, int64_t* send_splits, int64_t* recv_splits, int64_t* totals);
+/* second half on `stream`: all-to-all-v of the 8-byte keys, recat to feature-major when W > 1 and F > 1 (fm_* buffers, else
+ * unused: the received order IS feature-major); `consumer_stream` (if another stream) is ordered behind it */
+int mi355_rw_input_keys(void* handle, int ticket, int64_t num_features, int64_t batch_size, const void* new_keys,
+                        void* recv_keys, const int64_t* recv_lengths, const int64_t* recv_offsets, int64_t* fm_lengths,
+                        int64_t* fm_offsets, void* fm_keys, hipStream_t stream, hipStream_t consumer_stream);
+int mi355_rw_wait_keys(void* handle, int ticket, hipStream_t consumer_stream);
+/* pooled output dist: all-to-all of the W blocks of numel_per_block partial sums (wire_dtype) + their fp32 sum -> out */
+int mi355_rw_output_pooled(void* handle, const void* send, void* recv, int64_t numel_per_block, int wire_dtype, void* out,
+                           int out_dtype, hipStream_t stream);
+/* pooled backward: all-gather of `bytes` bytes per rank */
+int mi355_rw_allgather(void* handle, const void* send, void* recv, int64_t bytes, hipStream_t stream);
+/* sequence output dist / its backward: all-to-all-v of rows; counts in elements of elem_bytes (host arrays [W]) */
+int mi355_rw_alltoallv(void* handle, const void* send, const int64_t* send_counts, void* recv, const int64_t* recv_counts,
+                       int64_t elem_bytes, hipStream_t stream);
+
 /* ------------------------------------------------------------------------ value ops ---- */
 
 /* out[r] = sum_c in[c][r] (fp32 partial pooled sums of the W shards -> output dtype): the local half of the
@@ -266,6 +304,10 @@ int mi355_sum_chunks(const float* in, int64_t chunks, int64_t numel_per_chunk, v
  * fabric in bf16 / fp16, fbgemm_gpu quantize_comm; here the sum reads them directly, fp32 accumulation) */
 int mi355_sum_chunks_typed(const void* in, int in_dtype, int64_t chunks, int64_t numel_per_chunk, void* out, int out_dtype,
                            hipStream_t stream);
+/* the same with chunk `self_index` read from `self_chunk` instead of `in` (the rank's own block stays where the lookup wrote it:
+ * it does not travel through the all-to-all); sum order unchanged */
+int mi355_sum_chunks_self(const void* in, int in_dtype, int64_t chunks, int64_t numel_per_chunk, const void* self_chunk,
+                          int64_t self_index, void* out, int out_dtype, hipStream_t stream);
 
 
 /* gather_embedding_pooled, src/dynamic_emb_op.cu:106-133 (kernels lookup_kernel.cuh:859-998).

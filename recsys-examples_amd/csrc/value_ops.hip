@@ -372,6 +372,19 @@ sum_chunks_typed_kernel(const void* __restrict__ in, int64_t chunks, int64_t n, 
   }
 }
 
+// the same with ONE chunk read in place: the rank's own block of partial sums never goes through the all-to-all (its
+// send buffer IS the chunk); same sum order, chunk 0 .. W-1
+template <int SDT, int DDT>
+__global__ void __launch_bounds__(256)
+sum_chunks_self_kernel(const void* __restrict__ in, int64_t chunks, int64_t n, const void* __restrict__ self_chunk, int64_t self_index,
+                       void* out) {
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t c = 0; c < chunks; ++c) add4(acc, c == self_index ? ld4<SDT>(self_chunk, i) : ld4<SDT>(in, c * n + i));
+    st4<DDT>(out, i, acc);
+  }
+}
+
 }  // namespace mi355
 
 using namespace mi355;
@@ -556,6 +569,21 @@ int mi355_sum_chunks_typed(const void* in, int in_dtype, int64_t chunks, int64_t
     return MI355_DISPATCH_DTYPE(out_dtype, Dd, [&] {
       hipLaunchKernelGGL((sum_chunks_typed_kernel<Sd, Dd>), dim3(grid_for(numel_per_chunk, 1024)), dim3(256), 0, stream, in,
                          chunks, numel_per_chunk, out);
+      MI355_LAUNCH_CHECK();
+      return MI355_OK;
+    });
+  });
+}
+
+int mi355_sum_chunks_self(const void* in, int in_dtype, int64_t chunks, int64_t numel_per_chunk, const void* self_chunk,
+                          int64_t self_index, void* out, int out_dtype, hipStream_t stream) {
+  MI355_CHECK_ARG(numel_per_chunk % 4 == 0, "chunk size must be a multiple of 4 elements");
+  MI355_CHECK_ARG(self_chunk && self_index >= 0 && self_index < chunks, "self chunk");
+  if (numel_per_chunk == 0) return MI355_OK;
+  return MI355_DISPATCH_DTYPE(in_dtype, Sd, [&] {
+    return MI355_DISPATCH_DTYPE(out_dtype, Dd, [&] {
+      hipLaunchKernelGGL((sum_chunks_self_kernel<Sd, Dd>), dim3(grid_for(numel_per_chunk, 1024)), dim3(256), 0, stream, in,
+                         chunks, numel_per_chunk, self_chunk, self_index, out);
       MI355_LAUNCH_CHECK();
       return MI355_OK;
     });

@@ -26,7 +26,7 @@ from typing import List, Optional, Sequence
 import torch
 import torch.distributed as dist
 
-from .input_dist import HipOps, RwSparseFeaturesDist, ShardedKeys
+from .input_dist import DIST_TYPES, HipOps, RwSparseFeaturesDist, ShardedKeys
 
 
 def current_torch_stream():
@@ -51,14 +51,18 @@ class PendingKeys:
     Two-phase form: `state` is what RwSparseFeaturesDist.forward(two_phase=True) left; finish() -- called when the caller
     has queued its other work -- reads the per-peer key counts and sends the keys (still on the exchange stream)."""
 
-    def __init__(self, sk, event=None, dist=None, state=None, comm=None, consumer=None):
+    def __init__(self, sk, event=None, dist=None, state=None, comm=None, consumer=None, native=None):
         self._sk, self._event = sk, event
         self._dist, self._state, self._comm, self._consumer = dist, state, comm, consumer
+        self._native = native        # the in-library exchange (native_exchange.py): state is its input_begin() state
 
     def finish(self):
         if self._state is None:
             return
         state, self._state = self._state, None
+        if self._native is not None:
+            self._sk = self._native.input_finish(state)
+            return
         if self._comm is None:
             self._sk = self._dist.finish(state)
             return
@@ -73,6 +77,12 @@ class PendingKeys:
 
     def wait(self):
         self.finish()
+        if self._native is not None:
+            tk = getattr(self._sk, "_ticket", None)
+            if tk is not None:           # the keys travelled on the exchange stream: the caller's stream waits for them
+                self._native.wait_keys(tk)
+                self._sk._ticket = None
+            return self._sk
         if self._event is not None:
             current_torch_stream().wait_event(self._event)
             self._event = None
@@ -112,12 +122,39 @@ class RowWiseShardedLookup:
                                                is_sequence=not pooled, dist_type_per_feature=dist_type_per_feature,
                                                ops=self.ops, capacity_factor=capacity_factor, expected_keys=expected_keys)
         self.fixed_capacity = capacity_factor is not None
+        self._nx = None               # the in-library exchange (GPU batches; created at the first one)
+        self._nx_off = False
+
+    def _native_for(self, t: torch.Tensor):
+        """the library's own RCCL exchange (native_exchange.py) for GPU batches of the exact exchange; None: the c10d sequence"""
+        if self._nx is not None:
+            return self._nx if t.is_cuda else None
+        if self._nx_off or self.fixed_capacity:
+            return None
+        from .native_exchange import NativeExchange, native_exchange_wanted
+
+        if not native_exchange_wanted(self.pg, t):
+            self._nx_off = t.is_cuda      # (a CPU batch decides nothing: the gloo tests never get a communicator)
+            return None
+        self._nx = NativeExchange(self.pg, t.device)
+        return self._nx
+
+    def _native_begin(self, nx, values, offsets, side):
+        d = self.input_dist
+        if d._dist_codes is None or d._dist_codes.device != values.device:
+            d._dist_codes = torch.tensor([DIST_TYPES[x] for x in d._dist_type_per_feature], dtype=torch.int32,
+                                         device=values.device)
+            d._block_sizes = d._block_sizes.to(values.device)
+        return nx.input_begin(d._num_features, offsets, values, d._block_sizes, d._dist_codes, d._is_sequence, side)
 
     # ------------------------------------------------------------------------------ the three stages of a forward
     # (what TorchRec's ShardedModule calls input_dist / compute / output_dist; forward() below runs them back to back)
     def dist_input(self, values: torch.Tensor, offsets: torch.Tensor, collapse_batch: bool = False,
                    lengths: Optional[torch.Tensor] = None):
         # (the dist only needs the offsets; lengths are derived on the device where a caller has none)
+        nx = None if collapse_batch or offsets is None else self._native_for(values)
+        if nx is not None:
+            return nx.input_finish(self._native_begin(nx, values, offsets, None))
         return self.input_dist(lengths, values, collapse_batch, offsets=offsets)
 
     def dist_input_async(self, values: torch.Tensor, offsets: torch.Tensor, collapse_batch: bool = False,
@@ -135,6 +172,16 @@ class RowWiseShardedLookup:
             return PendingKeys(self.dist_input(values, offsets, collapse_batch, lengths))
         if self._comm is None:
             self._comm = torch.cuda.Stream(device=values.device)
+        nx = None if collapse_batch or offsets is None else self._native_for(values)
+        if nx is not None:
+            # one C call: the exchange stream is ordered behind the caller's inside it.  The second half (the host read of the
+            # key counts, the key exchange) follows in finish() -- at once, or (two_phase) when the caller has queued its work
+            for t in (values, offsets):
+                t.record_stream(self._comm)
+            pend = PendingKeys(None, state=self._native_begin(nx, values, offsets, self._comm), native=nx)
+            if not two_phase:
+                pend.finish()
+            return pend
         cur = current_torch_stream()
         self._comm.wait_stream(cur)       # the batch tensors were produced on the caller's stream
         for t in (values, offsets, lengths):
@@ -164,6 +211,8 @@ class RowWiseShardedLookup:
             assert out_local.size(0) == W * B
             wire = self.wire_dtype or torch.float32
             send = out_local.contiguous() if out_local.dtype == wire else out_local.to(wire)
+            if self._nx is not None and send.is_cuda:
+                return self._nx.output_pooled(send, self.out_dtype)
             recv = torch.empty_like(send)
             dist.all_to_all_single(recv, send, group=self.pg)
             # (the sum reads the chunks in the wire type and accumulates in fp32: no conversion pass on either side)
@@ -171,8 +220,11 @@ class RowWiseShardedLookup:
         D = out_local.size(1)
         # rows come out in (f, src, b) order; send them back in the order they arrived: (src, f, b)
         rows_sfb = self.ops.permute_bags(sk.num_features, W, B, sk.offsets, sk.recv_offsets, out_local.contiguous())
-        back = torch.empty(sum(sk.send_splits), D, dtype=out_local.dtype, device=out_local.device)
-        dist.all_to_all_single(back, rows_sfb, [s for s in sk.send_splits], [r for r in sk.recv_splits], group=self.pg)
+        if self._nx is not None and rows_sfb.is_cuda:
+            back = self._nx.alltoallv_rows(rows_sfb, sk.recv_splits, sk.send_splits)
+        else:
+            back = torch.empty(sum(sk.send_splits), D, dtype=out_local.dtype, device=out_local.device)
+            dist.all_to_all_single(back, rows_sfb, [s for s in sk.send_splits], [r for r in sk.recv_splits], group=self.pg)
         out = back if bucketized else self.ops.gather_rows(back, sk.unbucketize_permute)
         return out if out.dtype == self.out_dtype else out.to(self.out_dtype)
 
@@ -181,6 +233,8 @@ class RowWiseShardedLookup:
         W, B = self.world, sk.batch_size
         grads = grads.contiguous()
         if self.pooled:
+            if self._nx is not None and grads.is_cuda:
+                return self._nx.allgather(grads)
             g_all = torch.empty(W * grads.size(0), grads.size(1), dtype=grads.dtype, device=grads.device)
             dist.all_gather_into_tensor(g_all, grads, group=self.pg)
             return g_all
@@ -195,8 +249,11 @@ class RowWiseShardedLookup:
             inv = torch.empty_like(perm)
             inv[perm] = torch.arange(perm.numel(), dtype=perm.dtype, device=perm.device)
             g_send = self.ops.gather_rows(grads, inv)  # bucketized order
-        g_recv = torch.empty(sum(sk.recv_splits), grads.size(1), dtype=grads.dtype, device=grads.device)
-        dist.all_to_all_single(g_recv, g_send, [r for r in sk.recv_splits], [s for s in sk.send_splits], group=self.pg)
+        if self._nx is not None and g_send.is_cuda:
+            g_recv = self._nx.alltoallv_rows(g_send, sk.send_splits, sk.recv_splits)
+        else:
+            g_recv = torch.empty(sum(sk.recv_splits), grads.size(1), dtype=grads.dtype, device=grads.device)
+            dist.all_to_all_single(g_recv, g_send, [r for r in sk.recv_splits], [s for s in sk.send_splits], group=self.pg)
         return self.ops.permute_bags(W, sk.num_features, B, sk.recv_offsets, sk.offsets, g_recv)
 
     # ------------------------------------------------------------------------------ forward
@@ -239,11 +296,13 @@ class OverlappedSteps:
         pend = self._pending if self._pending is not None else lk.dist_input_async(values, offsets)
         self._pending = None
         sk = pend.wait()
-        out_local, lctx = lk.lookup(sk, train)
         if next_batch is not None:
             # first half only: bucketize, lengths exchange, key counts on their way to pinned memory.  The host read and the
-            # key exchange follow in backward(), when this step's work is queued -- the host never sits waiting for the read
+            # key exchange follow in backward(), when this step's work is queued -- the host never sits waiting for the read.
+            # Issued BEFORE this batch's lookup is queued: the exchange stream is ordered behind what the caller's stream
+            # holds at this point (the next batch was produced there), and that must not include the lookup it is to run under
             self._pending = lk.dist_input_async(*next_batch, two_phase=True)
+        out_local, lctx = lk.lookup(sk, train)
         out = lk.dist_output(sk, out_local)
         return out, _ShardedCtx(sk, lctx, sum(sk.send_splits))
 

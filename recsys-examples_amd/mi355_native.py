@@ -141,6 +141,18 @@ _SIGS = {
     "mi355_vmm_mapped_bytes": [c_p],
     "mi355_vmm_reserved_bytes": [c_p],
     "mi355_vmm_destroy": [c_p],
+    "mi355_sum_chunks_self": [c_p, c_int, c_i64, c_i64, c_p, c_i64, c_p, c_int, c_p],
+    "mi355_rw_load_rccl": [ctypes.c_char_p],
+    "mi355_rw_unique_id": [c_p, c_i64],
+    "mi355_rw_create": [c_p, c_p, c_int, c_int, c_p],
+    "mi355_rw_destroy": [c_p],
+    "mi355_rw_input_begin": [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "mi355_rw_input_counts": [c_p, c_int, c_p, c_p, c_p],
+    "mi355_rw_input_keys": [c_p, c_int, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "mi355_rw_wait_keys": [c_p, c_int, c_p],
+    "mi355_rw_output_pooled": [c_p, c_p, c_p, c_i64, c_int, c_p, c_int, c_p],
+    "mi355_rw_allgather": [c_p, c_p, c_p, c_i64, c_p],
+    "mi355_rw_alltoallv": [c_p, c_p, c_p, c_p, c_p, c_i64, c_p],
     "mi355_abi_version": [],
     "mi355_last_error": [],
 }

@@ -327,3 +327,52 @@ def test_fixed_capacity_exchange_on_the_gpu_matches_the_exact_one(one_rank_group
         f2, r2 = mods[1].lookup_rows(probe, t)
         assert torch.equal(f1, f2) and torch.equal(r1, r2)
         assert int(mods[1].size(t)) == int(mods[0].size(t))      # the padding keys were never stored
+
+
+@pytest.mark.parametrize("pooled", [True, False])
+def test_in_library_exchange_matches_the_c10d_sequence(one_rank_group, pooled, monkeypatch):
+    """GPU batches go through the library's own RCCL calls (csrc/exchange.hip, one C call per stage); MI355_NATIVE_EXCHANGE=0
+    keeps the c10d call sequence.  Same keys / offsets / splits out of the input dist (sync and on the exchange stream), same
+    outputs, same rows after the backward -- bit for bit"""
+    from dynamicemb.sharded import OverlappedSteps, RowWiseShardedLookup, _ModuleLocal
+
+    F, B, dim = 3, 40, 16
+    rng = np.random.default_rng(21)
+    mods = [_module(pooled, F, dim, torch.float32) for _ in range(2)]
+    monkeypatch.setenv("MI355_NATIVE_EXCHANGE", "0")
+    plain = RowWiseShardedLookup(_ModuleLocal(mods[0]), F, [3000] * F, pooled=pooled, device=torch.device("cuda", 0),
+                                 out_dtype=torch.float32, dist_type_per_feature=["roundrobin"] * F)
+    batches = []
+    for _ in range(5):
+        lens = rng.integers(0, 7, F * B)
+        off = np.zeros(F * B + 1, np.int64)
+        off[1:] = np.cumsum(lens)
+        batches.append((torch.from_numpy(rng.integers(0, 3000, off[-1]).astype(np.int64)).cuda(), torch.from_numpy(off).cuda()))
+    sk_p = plain.dist_input(*batches[0])
+    assert plain._nx is None
+    monkeypatch.setenv("MI355_NATIVE_EXCHANGE", "1")
+    nat = RowWiseShardedLookup(_ModuleLocal(mods[1]), F, [3000] * F, pooled=pooled, device=torch.device("cuda", 0),
+                               out_dtype=torch.float32, dist_type_per_feature=["roundrobin"] * F)
+    sk_n = nat.dist_input(*batches[0])
+    assert nat._nx is not None, "the in-library exchange must serve GPU batches by default"
+    sk_a = nat.dist_input_async(*batches[0], two_phase=True).wait()
+    for sk in (sk_n, sk_a):
+        assert torch.equal(sk.values, sk_p.values) and torch.equal(sk.offsets, sk_p.offsets)
+        assert torch.equal(sk.lengths, sk_p.lengths) and torch.equal(sk.recv_offsets, sk_p.recv_offsets)
+        assert sk.send_splits == sk_p.send_splits and sk.recv_splits == sk_p.recv_splits
+        assert (sk.unbucketize_permute is None) == (sk_p.unbucketize_permute is None)
+        if sk_p.unbucketize_permute is not None:
+            assert torch.equal(sk.unbucketize_permute, sk_p.unbucketize_permute)
+    ov = OverlappedSteps(nat)
+    for i, (k, o) in enumerate(batches):
+        o_p, c_p = plain.forward(k, o, True)
+        o_n, c_n = ov.forward(k, o, True, batches[i + 1] if i + 1 < len(batches) else None)
+        assert torch.equal(o_p, o_n)
+        g = torch.randn_like(o_p)
+        plain.backward(c_p, g)
+        ov.backward(c_n, g)
+    probe = torch.arange(0, 3000, device="cuda", dtype=torch.int64)
+    for t in range(F):
+        f1, r1 = mods[0].lookup_rows(probe, t)
+        f2, r2 = mods[1].lookup_rows(probe, t)
+        assert torch.equal(f1, f2) and torch.equal(r1, r2)
