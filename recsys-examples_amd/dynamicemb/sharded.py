@@ -171,7 +171,10 @@ class RowWiseShardedLookup:
                                    state=self.input_dist(lengths, values, collapse_batch, offsets=offsets, two_phase=True))
             return PendingKeys(self.dist_input(values, offsets, collapse_batch, lengths))
         if self._comm is None:
-            self._comm = torch.cuda.Stream(device=values.device)
+            # HIGH priority: the exchange stream's kernels are small (bucketize, two scans, the RCCL copies: ~35 us alone) and
+            # the host read of the step hangs on them -- queued behind the lookup's full-chip kernels they took 140 us and
+            # arrived after the backward (profiles/r05_sharded_w1_timeline_before.txt)
+            self._comm = torch.cuda.Stream(device=values.device, priority=-1)
         nx = None if collapse_batch or offsets is None else self._native_for(values)
         if nx is not None:
             # one C call: the exchange stream is ordered behind the caller's inside it.  The second half (the host read of the
@@ -307,9 +310,15 @@ class OverlappedSteps:
         return out, _ShardedCtx(sk, lctx, sum(sk.send_splits))
 
     def backward(self, ctx: _ShardedCtx, grads: torch.Tensor) -> None:
-        self.lookup.backward(ctx, grads)
+        # second half of the next batch's input dist FIRST: its key counts were launched before this batch's lookup and are
+        # long written; the key exchange then runs on the exchange stream UNDER this backward.  Issued behind it, the small
+        # RCCL kernel waited for a slot among the backward's blocks and the next lookup waited for the keys
+        # (profiles/r05_sharded_w1_timeline_before.txt: 65 us for an 8 us copy, 26 us of idle GPU behind it).
+        # (An exchange THREAD for the input dist was tried as well -- the hand-over between two Python threads cost more
+        #  than the ~80 us of host work it took off this one: 0.21-0.23 ms against 0.19, not kept.)
         if self._pending is not None:
             self._pending.finish()
+        self.lookup.backward(ctx, grads)
 
 
 class RowWiseShardedPooledRows:
