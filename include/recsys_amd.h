@@ -585,6 +585,48 @@ int mi355_hstu_attn_fwd_kv_rab_f16(const void* q, const void* k, const void* v, 
                                const int32_t* page_offsets, const int32_t* page_ids, const int32_t* last_page_lens,
                                int64_t page_size, hipStream_t stream);
 
+/* Arbitrary mask functions (`func` of hstu_attn_varlen_func, hstu_api.cpp:170-180; applied per element inside the reference's
+ * kernels, hstu_fwd.h:139-145, 493-556 / hstu_bwd.h) read INSIDE the kernels: int32 func[heads or 1][n_func][>= total_q] (n_func
+ * odd; head stride 0 = one set for all heads; func_bound_stride = elements between the bounds of a token; last dimension
+ * contiguous).  Query token t sees key position j of its sequence iff j < func[0][t] or func[2p-1][t] <= j < func[2p][t], p >= 1;
+ * a masked pair gets func_neg (< 0, finite in the operand type: -1e9 bf16, -6e4 fp16) added to q.k, so SiLU and SiLU' are exactly
+ * 0 there.  Mask arguments as the *_rab entry points (the other masks apply on top).  Forward: training keys, delta-q keys and
+ * the paged cache; backward: self attention over contiguous keys.  No [batch, heads, N, N] tensor exists anywhere. */
+int mi355_hstu_attn_fwd_kv_func(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride, int64_t k_row_stride,
+                                int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride, int64_t k_head_stride,
+                                int64_t v_head_stride, int64_t o_head_stride, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                                int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen_q, int64_t max_seqlen_k,
+                                const int32_t* num_contexts, const int32_t* num_targets, int64_t target_group_size,
+                                int64_t window_left, int64_t window_right, float alpha, float scaling_seqlen, const int32_t* func,
+                                int64_t func_head_stride, int64_t func_bound_stride, int64_t n_func, float func_neg,
+                                const void* kv_cache, const int32_t* page_offsets, const int32_t* page_ids,
+                                const int32_t* last_page_lens, int64_t page_size, hipStream_t stream);
+int mi355_hstu_attn_fwd_kv_func_f16(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride, int64_t k_row_stride,
+                                int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride, int64_t k_head_stride,
+                                int64_t v_head_stride, int64_t o_head_stride, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                                int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen_q, int64_t max_seqlen_k,
+                                const int32_t* num_contexts, const int32_t* num_targets, int64_t target_group_size,
+                                int64_t window_left, int64_t window_right, float alpha, float scaling_seqlen, const int32_t* func,
+                                int64_t func_head_stride, int64_t func_bound_stride, int64_t n_func, float func_neg,
+                                const void* kv_cache, const int32_t* page_offsets, const int32_t* page_ids,
+                                const int32_t* last_page_lens, int64_t page_size, hipStream_t stream);
+int mi355_hstu_attn_bwd_func(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
+                             int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t do_row_stride,
+                             int64_t q_head_stride, int64_t k_head_stride, int64_t v_head_stride, int64_t do_head_stride,
+                             const int32_t* cu_seqlens, int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen,
+                             const int32_t* num_contexts, const int32_t* num_targets, int64_t target_group_size,
+                             int64_t window_left, int64_t window_right, float alpha, float scaling_seqlen, const int32_t* func,
+                             int64_t func_head_stride, int64_t func_bound_stride, int64_t n_func, float func_neg,
+                             hipStream_t stream);
+int mi355_hstu_attn_bwd_func_f16(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
+                             int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t do_row_stride,
+                             int64_t q_head_stride, int64_t k_head_stride, int64_t v_head_stride, int64_t do_head_stride,
+                             const int32_t* cu_seqlens, int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen,
+                             const int32_t* num_contexts, const int32_t* num_targets, int64_t target_group_size,
+                             int64_t window_left, int64_t window_right, float alpha, float scaling_seqlen, const int32_t* func,
+                             int64_t func_head_stride, int64_t func_bound_stride, int64_t n_func, float func_neg,
+                             hipStream_t stream);
+
 /* append_kvcache (torch.ops.paged_kvcache_ops.append_kvcache, examples/commons/ops/cuda_ops/csrc/
  * paged_kvcache_ops_kernel.cu:106-140, call site paged_hstu_infer_layer.py:350-364): new-history token i (i < *nnz_dev,
  * or < max_nnz when max_nnz > 0) of sequence batch_indices[i] is written at position positions[i] of that user's

@@ -101,6 +101,12 @@ struct AttnArgs {
   // relative attention bias (hstu_api.cpp:100-106,417-430): rab[b][h][i][j] (bf16, padded to max_seqlen_k in i and j) is
   // added to q_i . k_j before alpha and SiLU; head stride 0 = one bias matrix shared by all heads.  NULL: none.
   const uint16_t* rab; int64_t rab_b, rab_h, rab_r;
+  // arbitrary mask functions (`func`, hstu_api.cpp:170-180; applied per element in hstu_fwd.h:139-145, 493-556): int32
+  // func[h][p][t], p < n_func (odd), t = query token (row of q) -- token t sees key column j (position inside its sequence) iff
+  // j < func[h][0][t] or func[h][2p-1][t] <= j < func[h][2p][t] for a p >= 1.  Read where the bias would be added: a masked pair
+  // gets func_neg added to q.k (SiLU and SiLU' underflow to 0 exactly -- the dense-bias statement of the same mask, bit for
+  // bit, without the [batch, heads, N, N] tensor).  Head stride 0: one function set for all heads.  NULL: none.
+  const int32_t* func; int64_t func_h, func_p; int n_func; float func_neg;
   float alpha, inv_scale;
   // ---- inference extensions (forward only; NULL / 0 for training) ----
   const int* cu_seqlens_k;     // [B+1] key offsets when the keys are longer than the queries (delta-q); NULL = same as q
@@ -281,6 +287,47 @@ __device__ __forceinline__ void add_rab_row(f32x16_t (&acc)[NT], const uint16_t*
     for (int rr = 0; rr < 16; ++rr) {
       const int key = n0 + 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
       if (key < L) acc[t][rr] += bf16_bits_to_f32(row[key]);
+    }
+}
+// `func` masks: does query token `tok` see key column j?  (ft = &func[h][0][tok], fp = stride between the bounds)
+__device__ __forceinline__ bool func_sees(const int32_t* ft, int64_t fp, int nf, int j) {
+  bool ok = j < ft[0];
+  for (int p = 1; p + 1 < nf; p += 2) ok |= (ft[p * fp] <= j) & (j < ft[(p + 1) * fp]);
+  return ok;
+}
+// lane = query row (token `tok`), registers = keys as in add_rab_row: masked pairs get `neg` added
+// `free_below`: keys below it are exempt for this row (a contextual row sees the whole history whatever the functions say,
+// hstu_fwd.h:519-524: the context test `continue`s in front of every other mask)
+template <int NT>
+__device__ __forceinline__ void add_func_row(f32x16_t (&acc)[NT], const AttnArgs& a, int h, int64_t tok, bool row_live, int n0, int hi, int L,
+                                             int free_below) {
+  if (!row_live) return;
+  const int32_t* ft = a.func + (int64_t)h * a.func_h + tok;
+  unsigned ok[NT];
+  int f0 = ft[0];
+  f0 = f0 > free_below ? f0 : free_below;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    ok[t] = 0;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) ok[t] |= (unsigned)((n0 + 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * hi) < f0) << rr;
+  }
+  for (int p = 1; p + 1 < a.n_func; p += 2) {
+    const int lo = ft[p * a.func_p], up = ft[(p + 1) * a.func_p];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int key = n0 + 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+        ok[t] |= (unsigned)((lo <= key) & (key < up)) << rr;
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int key = n0 + 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+      if (key < L) acc[t][rr] += ((ok[t] >> rr) & 1u) ? 0.f : a.func_neg;
     }
 }
 // dS = dP * (alpha / N) * SiLU'(x), x = alpha * acc, sg = sigmoid(x).  One statement of the roundings for every kernel that
@@ -670,8 +717,11 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
     }
     fence_v(acc_s);
     if constexpr (kRab) {
+      if (a.func) add_func_row<2>(acc_s, a, h, (int64_t)s.start + qloc, qloc < Lq, n0, hi, s.L, (s.has_ctx && qi < s.c) ? s.hlen : 0);
+      else {
       const uint16_t* row = qi < s.L ? a.rab + (int64_t)b * a.rab_b + (int64_t)h * a.rab_h + (int64_t)qi * a.rab_r : nullptr;
       add_rab_row<2>(acc_s, row, n0, hi, s.L);
+      }
     }
     pin_agpr(acc_o);
     TICK(t6);
@@ -2700,6 +2750,18 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
     TICK(t5);
     TACC(4, t4, t5);
     if constexpr (kRab) {   // lane = key kj, registers = query rows: rab[qi][kj]
+      if (a.func) {         // (the bounds of a query row are the same words for the 32 lanes of a half-wave: one transaction)
+        if (kj < s.L) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+              const int qi = i0 + 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+              if (qi < s.L && !(s.has_ctx && qi < s.c && kj < s.hlen) &&
+                  !func_sees(a.func + (int64_t)h * a.func_h + s.start + qi, a.func_p, a.n_func, kj)) acc_s[t][rr] += a.func_neg;
+            }
+        }
+      } else
       if (kj < s.L) {
         const uint16_t* col = a.rab + (int64_t)b * a.rab_b + (int64_t)h * a.rab_h + kj;
 #pragma unroll
@@ -2971,8 +3033,11 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
     fence_v(acc_s);
     fence_v(acc_p);
     if constexpr (kRab) {
+      if (a.func) add_func_row<NT>(acc_s, a, h, (int64_t)s.start + qi, qi < s.L, n0, hi, s.L, (s.has_ctx && qi < s.c) ? s.hlen : 0);
+      else {
       const uint16_t* row = qi < s.L ? a.rab + (int64_t)b * a.rab_b + (int64_t)h * a.rab_h + (int64_t)qi * a.rab_r : nullptr;
       add_rab_row<NT>(acc_s, row, n0, hi, s.L);
+      }
     }
     pin_agpr(acc_dq);
     bf16x8_t sf[BK / 16];
@@ -3962,7 +4027,7 @@ static void launch_bwd_x8(const BwdAttnArgs& g, int B, int max_seqlen, hipStream
 template <int D>
 static int launch_bwd(BwdAttnArgs g, int B, int max_seqlen, hipStream_t stream) {
   dim3 grid(g.f.H, B, (max_seqlen + kBM - 1) / kBM);   // block rank slowest: see launch_fwd
-  if (g.f.rab) {   // attention bias: the recomputing passes (S needs the bias in every pass), dS doubles as d rab
+  if (g.f.rab || g.f.func) {   // attention bias / mask functions: the recomputing passes (S needs the bias in every pass), dS doubles as d rab
     g.ds_ws = g.p_ws = nullptr;
     g.bq_kv = 64;
     if constexpr (D >= 128) {
@@ -4141,7 +4206,7 @@ static int launch_fwd(const AttnArgs& a, int B, int max_seqlen, hipStream_t stre
   // are handed out first and the light ones fill in behind them.  With the rank in x (per-sequence order 8,6,4,2 key
   // tiles at L = 512) the CUs freed first drew heavy blocks again and the slowest CU did 16 tiles where 10 is the mean.
   dim3 grid(a.H, B, (max_seqlen + kBM - 1) / kBM);
-  if (a.rab) hipLaunchKernelGGL((hstu_fwd_kernel<D, true, true>), grid, dim3(256), smem, stream, a);
+  if (a.rab || a.func) hipLaunchKernelGGL((hstu_fwd_kernel<D, true, true>), grid, dim3(256), smem, stream, a);
   else if (a.wl >= 0 || a.wr >= 0) hipLaunchKernelGGL((hstu_fwd_kernel<D, true>), grid, dim3(256), smem, stream, a);
   else hipLaunchKernelGGL((hstu_fwd_kernel<D, false>), grid, dim3(256), smem, stream, a);
   MI355_LAUNCH_CHECK();
@@ -4158,7 +4223,8 @@ static thread_local int tl_wl = -1, tl_wr = -1;
 // batch, which takes the paired-row-block forward
 static thread_local int64_t tl_fwd_tokens = 0;
 // attention bias of the call in flight on this thread (set by the *_rab entry points)
-struct RabCall { const uint16_t* rab = nullptr; int64_t rb = 0, rh = 0, rr = 0; uint16_t* drab = nullptr; int64_t db = 0, dh = 0, dr = 0; };
+struct RabCall { const uint16_t* rab = nullptr; int64_t rb = 0, rh = 0, rr = 0; uint16_t* drab = nullptr; int64_t db = 0, dh = 0, dr = 0;
+                 const int32_t* func = nullptr; int64_t fh = 0, fp = 0; int nf = 0; float fneg = 0.f; };
 static thread_local RabCall tl_rab;
 static int block_rotation(int heads) {   // MI355_HSTU_ROT (A/B): see seq_head_of_block; default -H = by a sequence per rank, jagged batches only
   static const int v = [] { const char* e = getenv("MI355_HSTU_ROT"); return e ? atoi(e) : 0x7fffffff; }();
@@ -4242,6 +4308,7 @@ int HSTU_FN(mi355_hstu_attn_fwd_kv)(const void* q, const void* k, const void* v,
   a.H = (int)num_heads; a.causal = causal; a.group = (int)target_group_size;
   a.wl = tl_wl; a.wr = tl_wr; a.wskip = window_skip(); a.rot = block_rotation((int)num_heads); a.colmajor = column_major(); a.max_len = (int)max_seqlen_q;
   a.rab = tl_rab.rab; a.rab_b = tl_rab.rb; a.rab_h = tl_rab.rh; a.rab_r = tl_rab.rr;
+  a.func = tl_rab.func; a.func_h = tl_rab.fh; a.func_p = tl_rab.fp; a.n_func = tl_rab.nf; a.func_neg = tl_rab.fneg;
   a.alpha = alpha; a.inv_scale = 1.0f / scaling_seqlen;
   a.cu_seqlens_k = cu_seqlens_k; a.kv_cache = (const uint16_t*)kv_cache; a.page_offsets = page_offsets; a.page_ids = page_ids;
   a.last_page_lens = last_page_lens; a.page_size = (int)page_size;
@@ -4249,9 +4316,9 @@ int HSTU_FN(mi355_hstu_attn_fwd_kv)(const void* q, const void* k, const void* v,
   static const int use_pc = getenv("MI355_HSTU_PC") ? atoi(getenv("MI355_HSTU_PC")) : 1;   // round 4: two waves per SIMD, S waves + O waves
   const int64_t fwd_tokens = tl_fwd_tokens;
   tl_fwd_tokens = 0;
-  if (use_pc && head_dim == 256 && !a.kv_cache && !a.rab)
+  if (use_pc && head_dim == 256 && !a.kv_cache && !a.rab && !a.func)
     return launch_fwd_pc<256>(a, (int)batch, (int)max_seqlen_q, stream, !cu_seqlens_k && fwd_tokens == batch * max_seqlen_q);
-  if (use_dma && head_dim == 256 && !a.kv_cache && !a.rab) return launch_fwd_dma<256>(a, (int)batch, (int)max_seqlen_q, stream);
+  if (use_dma && head_dim == 256 && !a.kv_cache && !a.rab && !a.func) return launch_fwd_dma<256>(a, (int)batch, (int)max_seqlen_q, stream);
   switch (head_dim) {
     case 32: return launch_fwd<32>(a, (int)batch, (int)max_seqlen_q, stream);
     case 64: return launch_fwd<64>(a, (int)batch, (int)max_seqlen_q, stream);
@@ -4393,6 +4460,7 @@ int HSTU_FN(mi355_hstu_attn_bwd)(const void* dout, const void* q, const void* k,
   a.H = (int)num_heads; a.causal = causal; a.group = (int)target_group_size;
   a.wl = tl_wl; a.wr = tl_wr; a.wskip = window_skip(); a.rot = block_rotation((int)num_heads); a.colmajor = column_major(); a.max_len = (int)max_seqlen;
   a.rab = tl_rab.rab; a.rab_b = tl_rab.rb; a.rab_h = tl_rab.rh; a.rab_r = tl_rab.rr;
+  a.func = tl_rab.func; a.func_h = tl_rab.fh; a.func_p = tl_rab.fp; a.n_func = tl_rab.nf; a.func_neg = tl_rab.fneg;
   a.alpha = alpha; a.inv_scale = 1.0f / scaling_seqlen;
   g.dout = (const uint16_t*)dout; g.do_row = do_row_stride; g.do_head = do_head_stride;
   g.dq = (uint16_t*)dq; g.dk = (uint16_t*)dk; g.dv = (uint16_t*)dv;
@@ -4406,7 +4474,7 @@ int HSTU_FN(mi355_hstu_attn_bwd)(const void* dout, const void* q, const void* k,
     const int64_t regions = xch_regions(head_dim), units = batch * num_heads, hdr = xch_plan_header(units);
     const int64_t udense = (int64_t)g.ng * g.ng;
     // plain causal mask: the sub-tiles above the diagonal do not exist in the chunked layout (see BwdAttnArgs::tri)
-    g.tri = (causal && !num_contexts && tl_wl < 0 && tl_wr < 0 && !tl_rab.rab) ? 1 : 0;
+    g.tri = (causal && !num_contexts && tl_wl < 0 && tl_wr < 0 && !tl_rab.rab && !tl_rab.func) ? 1 : 0;
     const int64_t umax = xch_unit_tiles(g.ng, g.tri);
     g.p_ws = nullptr;
     if (need > 0 && workspace && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0) {
@@ -4414,7 +4482,7 @@ int HSTU_FN(mi355_hstu_attn_bwd)(const void* dout, const void* q, const void* k,
       g.ds_ws = (uint16_t*)workspace;
       const int64_t one = batch * num_heads * udense * 2048;
       if (need >= 2 * one && head_dim >= 128) g.p_ws = (uint16_t*)((uint8_t*)workspace + one);
-    } else if (need > 0 && workspace && ((uintptr_t)workspace & 255) == 0 && !tl_rab.rab && workspace_bytes > hdr &&
+    } else if (need > 0 && workspace && ((uintptr_t)workspace & 255) == 0 && !tl_rab.rab && !tl_rab.func && workspace_bytes > hdr &&
                (workspace_bytes - hdr) / regions / 2048 >= 2 * umax) {
       // the jagged, chunked layout: [plan_base | plan_chunk | nchunks | dS region | P region]
       const int64_t cap_tiles = (workspace_bytes - hdr) / regions / 2048;
@@ -4583,6 +4651,59 @@ int HSTU_FN(mi355_hstu_attn_bwd_rab)(const void* dout, const void* q, const void
   if (const int rc = rab_mask(window_left, window_right, num_contexts, num_targets, &causal)) return rc;
   tl_rab = RabCall{(const uint16_t*)rab, rab_batch_stride, rab_head_stride, rab_row_stride,
                    (uint16_t*)drab, drab_batch_stride, drab_head_stride, drab_row_stride};
+  const int rc = HSTU_FN(mi355_hstu_attn_bwd)(dout, q, k, v, dq, dk, dv, q_row_stride, k_row_stride, v_row_stride, do_row_stride,
+                                     q_head_stride, k_head_stride, v_head_stride, do_head_stride, cu_seqlens, batch, num_heads,
+                                     head_dim, max_seqlen, num_contexts, num_targets, target_group_size, causal, alpha,
+                                     scaling_seqlen, nullptr, 0, stream);
+  tl_rab = RabCall{};
+  tl_wl = tl_wr = -1;
+  return rc;
+}
+
+// Arbitrary mask functions (`func` of hstu_attn_varlen_func; hstu_api.cpp:170-180, applied in hstu_fwd.h:139-145, 493-556) read INSIDE
+// the kernels (AttnArgs::func): int32 func[heads or 1][n_func][>= total_q], n_func odd, given by its head stride (0 = one set for
+// all heads) and the stride between the bounds of a token, last dimension contiguous.  Query token t sees key position j of its
+// sequence iff j < func[0][t] or func[2p-1][t] <= j < func[2p][t]; func_neg is what a masked pair gets added to q.k (finite in the
+// operand type: -1e9 bf16, -6e4 fp16).  The other masks apply on top, as for the bias entry points.  Forward: training keys,
+// delta-q keys and the paged cache (as mi355_hstu_attn_fwd_kv); backward: self attention over contiguous keys.
+int HSTU_FN(mi355_hstu_attn_fwd_kv_func)(const void* q, const void* k, const void* v, void* out, int64_t q_row_stride, int64_t k_row_stride,
+                                int64_t v_row_stride, int64_t o_row_stride, int64_t q_head_stride, int64_t k_head_stride,
+                                int64_t v_head_stride, int64_t o_head_stride, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                                int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen_q, int64_t max_seqlen_k,
+                                const int32_t* num_contexts, const int32_t* num_targets, int64_t target_group_size,
+                                int64_t window_left, int64_t window_right, float alpha, float scaling_seqlen, const int32_t* func,
+                                int64_t func_head_stride, int64_t func_bound_stride, int64_t n_func, float func_neg,
+                                const void* kv_cache, const int32_t* page_offsets, const int32_t* page_ids,
+                                const int32_t* last_page_lens, int64_t page_size, hipStream_t stream) {
+  MI355_CHECK_ARG(func != nullptr && n_func >= 1 && (n_func & 1) == 1 && func_bound_stride > 0 && func_neg < 0.f,
+                  "func must be int32 [heads or 1][n_func odd][tokens], func_neg negative");
+  int causal = 0;
+  if (const int rc = rab_mask(window_left, window_right, num_contexts, num_targets, &causal)) return rc;
+  tl_rab = RabCall{};
+  tl_rab.func = func; tl_rab.fh = func_head_stride; tl_rab.fp = func_bound_stride; tl_rab.nf = (int)n_func; tl_rab.fneg = func_neg;
+  const int rc = HSTU_FN(mi355_hstu_attn_fwd_kv)(q, k, v, out, q_row_stride, k_row_stride, v_row_stride, o_row_stride, q_head_stride,
+                                        k_head_stride, v_head_stride, o_head_stride, cu_seqlens_q, cu_seqlens_k, batch, num_heads,
+                                        head_dim, max_seqlen_q, num_contexts, num_targets, target_group_size, causal, alpha,
+                                        scaling_seqlen, kv_cache, page_offsets, page_ids, last_page_lens, page_size, stream);
+  tl_rab = RabCall{};
+  tl_wl = tl_wr = -1;
+  return rc;
+}
+
+int HSTU_FN(mi355_hstu_attn_bwd_func)(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
+                             int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t do_row_stride,
+                             int64_t q_head_stride, int64_t k_head_stride, int64_t v_head_stride, int64_t do_head_stride,
+                             const int32_t* cu_seqlens, int64_t batch, int64_t num_heads, int64_t head_dim, int64_t max_seqlen,
+                             const int32_t* num_contexts, const int32_t* num_targets, int64_t target_group_size,
+                             int64_t window_left, int64_t window_right, float alpha, float scaling_seqlen, const int32_t* func,
+                             int64_t func_head_stride, int64_t func_bound_stride, int64_t n_func, float func_neg,
+                             hipStream_t stream) {
+  MI355_CHECK_ARG(func != nullptr && n_func >= 1 && (n_func & 1) == 1 && func_bound_stride > 0 && func_neg < 0.f,
+                  "func must be int32 [heads or 1][n_func odd][tokens], func_neg negative");
+  int causal = 0;
+  if (const int rc = rab_mask(window_left, window_right, num_contexts, num_targets, &causal)) return rc;
+  tl_rab = RabCall{};
+  tl_rab.func = func; tl_rab.fh = func_head_stride; tl_rab.fp = func_bound_stride; tl_rab.nf = (int)n_func; tl_rab.fneg = func_neg;
   const int rc = HSTU_FN(mi355_hstu_attn_bwd)(dout, q, k, v, dq, dk, dv, q_row_stride, k_row_stride, v_row_stride, do_row_stride,
                                      q_head_stride, k_head_stride, v_head_stride, do_head_stride, cu_seqlens, batch, num_heads,
                                      head_dim, max_seqlen, num_contexts, num_targets, target_group_size, causal, alpha,

@@ -7,8 +7,10 @@ examples/hstu/modules/hstu_attention.py:296-314): same argument meaning, same in
 contextual / target masks require causal -- hstu_api.cpp:359-430).
 Inference extensions (forward only): cu_seqlens_k longer than cu_seqlens_q (delta-q) and the paged KV cache
 (kv_cache / page_offsets / page_ids / last_page_lens).
-Arbitrary mask functions (`func`, hstu_api.cpp:170-180) run as a 0 / -1e9 bias through the biased kernels (func_mask_bias:
-O(batch max_seqlen_k^2) memory), forward and backward, with any other mask except context rows, over delta-q / paged keys too.
+Arbitrary mask functions (`func`, hstu_api.cpp:170-180) are read INSIDE the kernels (mi355_hstu_attn_{fwd_kv,bwd}_func: no mask
+tensor exists), forward and backward, with any other mask -- contextual rows keep their view of the history, as in the
+reference's kernels (hstu_fwd.h:519-524) --, over delta-q / paged keys too.  Next to a relative bias they are added to it as a
+0 / -1e9 bias (func_mask_bias: O(batch max_seqlen_k^2) memory, like the bias itself).
 Not supported (raise): seqused_* (no caller of the reference passes them, and its kernels take none).  The raw ops of the fused layer
 (`torch.ops.fbgemm.hstu_varlen_{fwd,bwd}_{80,90}`) are registered by `hstu.hstu_ops_gpu`.
 """
@@ -47,6 +49,12 @@ N.register_signatures({
     "mi355_hstu_attn_fwd_kv_rab": [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64,
                                    c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_f, c_p, c_i64, c_i64, c_i64,
                                    c_p, c_p, c_p, c_p, c_i64, c_p],
+    "mi355_hstu_attn_fwd_kv_func": [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64,
+                                    c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_f, c_p, c_i64, c_i64, c_i64,
+                                    c_f, c_p, c_p, c_p, c_p, c_i64, c_p],
+    "mi355_hstu_attn_bwd_func": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p,
+                                 c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_f, c_p, c_i64, c_i64, c_i64,
+                                 c_f, c_p],
     "mi355_append_kvcache": [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p,
                              c_i64, c_i64, c_p],
 }, {"mi355_hstu_attn_bwd_workspace_bytes": c_i64, "mi355_hstu_attn_bwd_ds_bytes": c_i64,
@@ -54,7 +62,8 @@ N.register_signatures({
     "mi355_hstu_attn_fwd_hint_tokens": None, "mi355_hstu_attn_fwd_hint_tokens_f16": None})
 # the fp16-operand twins of the seven type-specific entry points (same argument lists)
 _TYPED = ("mi355_hstu_attn_fwd_hint_tokens", "mi355_hstu_attn_fwd", "mi355_hstu_attn_fwd_kv", "mi355_hstu_attn_fwd_kv_window", "mi355_hstu_attn_fwd_kv_rab", "mi355_hstu_attn_bwd", "mi355_hstu_attn_fwd_window",
-          "mi355_hstu_attn_bwd_window", "mi355_hstu_attn_fwd_rab", "mi355_hstu_attn_bwd_rab")
+          "mi355_hstu_attn_bwd_window", "mi355_hstu_attn_fwd_rab", "mi355_hstu_attn_bwd_rab", "mi355_hstu_attn_fwd_kv_func",
+          "mi355_hstu_attn_bwd_func")
 N.register_signatures({n + "_f16": N.signature_of(n) for n in _TYPED})
 
 
@@ -356,6 +365,81 @@ def hstu_varlen_bwd_rab(dout, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, n
     return dq, dk, dv, drab
 
 
+_FUNC_NEG = {}
+_FUNC_DENSE = __import__("os").environ.get("MI355_HSTU_FUNC_DENSE", "0") == "1"
+
+
+def _func_neg_value(dtype) -> float:
+    """_func_neg(dtype) as the operand type holds it (what the dense-bias statement of the mask adds)"""
+    v = _FUNC_NEG.get(dtype)
+    if v is None:
+        v = _FUNC_NEG[dtype] = float(torch.tensor(_func_neg(dtype), dtype=dtype))
+    return v
+
+
+def _check_func(func, q):
+    if func.dtype != torch.int32 or func.dim() != 3 or func.shape[1] % 2 != 1 or func.stride(-1) != 1:
+        raise RuntimeError("func must be an int32 (heads or 1, n_func, >= total_q) tensor with an odd n_func and a contiguous last dimension")
+    if func.shape[0] not in (1, q.shape[1]) or func.shape[-1] < q.shape[0]:
+        raise RuntimeError("func must be (heads or 1, n_func, >= total_q)")
+
+
+def hstu_varlen_fwd_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, scaling_seqlen, num_contexts, num_targets,
+                         target_group_size, wl, wr, alpha, func, kv_cache=None, page_offsets=None, page_ids=None, last_page_lens=None):
+    """Raw forward with arbitrary mask functions read inside the kernel (mi355_hstu_attn_fwd_kv_func): no dense bias.
+    cu_seqlens_k None = the keys are the queries' tokens (training)."""
+    T, H, D = q.shape
+    out = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
+    B = cu_seqlens_q.numel() - 1
+    page_size = kv_cache.size(2) if kv_cache is not None else 0
+    check(_fn("mi355_hstu_attn_fwd_kv_func", q)(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
+                                                q.stride(1), k.stride(1), v.stride(1), out.stride(1), ptr(cu_seqlens_q),
+                                                ptr(cu_seqlens_k), B, H, D, int(max_seqlen_q), int(max_seqlen_k),
+                                                ptr(num_contexts), ptr(num_targets), int(target_group_size), int(wl), int(wr),
+                                                c_f(alpha), c_f(float(scaling_seqlen)), ptr(func),
+                                                func.stride(0) if func.shape[0] > 1 else 0, func.stride(1), func.shape[1],
+                                                c_f(_func_neg_value(q.dtype)), ptr(kv_cache), ptr(page_offsets), ptr(page_ids),
+                                                ptr(last_page_lens), page_size, stream()), "hstu_attn_fwd_kv_func")
+    return out
+
+
+def hstu_varlen_bwd_func(dout, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, num_contexts, num_targets, target_group_size, wl, wr,
+                         alpha, func):
+    """Raw backward with arbitrary mask functions read inside the kernels: (dq, dk, dv)"""
+    T, H, D = q.shape
+    dout = dout.contiguous() if dout.stride(-1) != 1 else dout
+    dq = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
+    dk, dv = torch.empty_like(dq), torch.empty_like(dq)
+    B = cu_seqlens.numel() - 1
+    check(_fn("mi355_hstu_attn_bwd_func", q)(ptr(dout), ptr(q), ptr(k), ptr(v), ptr(dq), ptr(dk), ptr(dv), q.stride(0), k.stride(0),
+                                             v.stride(0), dout.stride(0), q.stride(1), k.stride(1), v.stride(1), dout.stride(1),
+                                             ptr(cu_seqlens), B, H, D, int(max_seqlen), ptr(num_contexts), ptr(num_targets),
+                                             int(target_group_size), int(wl), int(wr), c_f(alpha), c_f(float(scaling_seqlen)),
+                                             ptr(func), func.stride(0) if func.shape[0] > 1 else 0, func.stride(1), func.shape[1],
+                                             c_f(_func_neg_value(q.dtype)), stream()), "hstu_attn_bwd_func")
+    return dq, dk, dv
+
+
+class HstuAttnFuncFunc(torch.autograd.Function):
+    """attention under arbitrary mask functions, the functions read inside the kernels (hstu_fwd.h:139-145, 493-556)"""
+
+    @staticmethod
+    def forward(ctx, q, k, v, func, cu_seqlens, max_seqlen, scaling_seqlen, num_contexts, num_targets, target_group_size, wl, wr,
+                alpha):
+        out = hstu_varlen_fwd_func(q, k, v, cu_seqlens, None, max_seqlen, max_seqlen, scaling_seqlen, num_contexts, num_targets,
+                                   target_group_size, wl, wr, alpha, func)
+        ctx.save_for_backward(q, k, v, func, cu_seqlens, num_contexts, num_targets)
+        ctx.meta = (max_seqlen, scaling_seqlen, target_group_size, wl, wr, alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, func, cu, nc, nt = ctx.saved_tensors
+        max_seqlen, scaling, g, wl, wr, alpha = ctx.meta
+        dq, dk, dv = hstu_varlen_bwd_func(dout, q, k, v, cu, max_seqlen, scaling, nc, nt, g, wl, wr, alpha, func)
+        return dq, dk, dv, None, None, None, None, None, None, None, None, None, None
+
+
 class HstuAttnRabFunc(torch.autograd.Function):
     """attention with a relative bias; rab receives a gradient when has_drab (hstu_attn_interface.py:23-183 of the reference)"""
 
@@ -397,13 +481,25 @@ def hstu_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, seqused_q, sequse
     wl, wr = (-1 if window_size[0] < 0 else int(window_size[0])), (-1 if window_size[1] < 0 else int(window_size[1]))
     if has_drab and rab is None:   # hstu_attn_interface.py:234-237 of the reference
         raise ValueError("AssertError: rab is None, but has_drab is True, is not allowed in backward")
+    if func is not None and rab is None:
+        # arbitrary mask functions, read inside the kernels (round 5; MI355_HSTU_FUNC_DENSE=1 keeps the dense-bias statement below,
+        # the two agree bit for bit): they narrow whatever other mask applies, as in the reference (hstu_fwd.h:519-556) -- except
+        # for the history columns of contextual rows, which its context test exempts
+        _check_func(func, q)
+        if not _FUNC_DENSE:
+            if not same:   # inference (delta-q keys and / or the paged cache): forward only
+                if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+                    raise NotImplementedError("delta-q / paged-KV attention is forward only (as in the reference's inference path)")
+                return hstu_varlen_fwd_func(q, k, v, cu_seqlens_q, cu_seqlens_k, int(max_seqlen_q), int(max_seqlen_k), scaling_seqlen,
+                                            num_contexts, num_targets, int(target_group_size), wl, wr, float(alpha), func, kv_cache,
+                                            page_offsets, page_ids, last_page_lens)
+            return HstuAttnFuncFunc.apply(q, k, v, func, cu_seqlens_q, int(max_seqlen_k), scaling_seqlen, num_contexts, num_targets,
+                                          int(target_group_size), wl, wr, float(alpha))
     if func is not None:
-        # arbitrary mask: a bias of 0 / -1e9 through the biased kernels (see func_mask_bias); it narrows whatever other mask applies
-        # as in the reference (hstu_fwd.h:519-556) -- except for context rows, which the reference exempts from it
+        # with a relative bias as well (or MI355_HSTU_FUNC_DENSE=1): a bias of 0 / -1e9 through the biased kernels (func_mask_bias)
         if num_contexts is not None:
-            raise NotImplementedError("func together with num_contexts")
-        if func.shape[0] not in (1, q.shape[1]) or func.shape[-1] < q.shape[0]:
-            raise RuntimeError("func must be (heads or 1, n_func, >= total_q)")
+            raise NotImplementedError("func together with num_contexts needs the in-kernel mask functions (no rab)")
+        _check_func(func, q)
         fb = func_mask_bias(func, cu_seqlens_q, cu_seqlens_k, max_seqlen_k, q.dtype)
         if rab is not None and rab.shape[-1] != int(max_seqlen_k):
             raise RuntimeError("rab must be (batch, nheads or 1, max_seqlen_k, max_seqlen_k)")

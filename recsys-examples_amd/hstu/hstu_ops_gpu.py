@@ -6,11 +6,12 @@ The reference's fused HSTU layer does not go through `hstu_attn_varlen_func`: it
 Importing this module (the example does: `import hstu.hstu_ops_gpu`, fused_hstu_op.py:19-20) defines all four ops with the
 positional order of those call sites, backed by the gfx950 kernels, plus Meta kernels for export.  Arguments this build has
 no kernel for (seqused, fp8 quantisation) must be None / default; the ops raise otherwise.  `func` (arbitrary mask functions)
-runs as a 0 / -1e9 bias through the bias kernel (hstu_attn_interface.func_mask_bias).
+is read inside the kernels (mi355_hstu_attn_{fwd_kv,bwd}_func); next to a relative bias it is added to it as a 0 / -1e9 bias
+(hstu_attn_interface.func_mask_bias).
 `window_size_left / right` with a finite side run the local-window kernels, `rab` / `has_drab` the bias kernels."""
 import torch
 
-from .hstu_attn_interface import (func_mask_bias, hstu_varlen_bwd, hstu_varlen_bwd_rab, hstu_varlen_bwd_window, hstu_varlen_fwd,
+from .hstu_attn_interface import (_check_func, func_mask_bias, hstu_varlen_bwd_func, hstu_varlen_fwd_func, hstu_varlen_bwd, hstu_varlen_bwd_rab, hstu_varlen_bwd_window, hstu_varlen_fwd,
                                   hstu_varlen_fwd_rab, hstu_varlen_fwd_window)
 
 _T = "Tensor"
@@ -29,8 +30,8 @@ def _check(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, wl, wr, rab,
            num_contexts=None, num_targets=None):
     if seqused_q is not None or seqused_k is not None:
         raise NotImplementedError("seqused_q / seqused_k are not supported")
-    if func is not None and num_contexts is not None:
-        raise NotImplementedError("func together with num_contexts")
+    if func is not None and num_contexts is not None and rab is not None:
+        raise NotImplementedError("func together with num_contexts needs the in-kernel mask functions (no rab)")
     if rab is not None and (rab.dim() != 4 or rab.shape[1] not in (1, q.shape[1]) or rab.shape[-1] != max_k or rab.stride(-1) != 1):
         raise RuntimeError("rab must be (batch, nheads or 1, max_seqlen_k, max_seqlen_k) with a contiguous last dimension")
     if quant_mode not in (-1, None) or any(e is not None for e in extra):
@@ -55,7 +56,11 @@ def _fwd(q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, scaling_seqlen
                             num_contexts=num_contexts, num_targets=num_targets)
     if output_dtype not in (0, None):
         raise NotImplementedError("output_dtype must be 0 (bf16)")
-    if func is not None:   # arbitrary mask: a 0 / -1e9 bias through the biased kernels (hstu_attn_interface.func_mask_bias)
+    if func is not None and rab is None:   # arbitrary mask functions, read inside the kernel
+        _check_func(func, q)
+        return hstu_varlen_fwd_func(q, k, v, cu_q, None, int(max_q), int(max_k), scaling_seqlen, num_contexts, num_targets,
+                                    int(target_group_size), max(int(wl), -1), max(int(wr), -1), float(alpha), func), None
+    if func is not None:   # ... next to a relative bias: a 0 / -1e9 bias added to it (hstu_attn_interface.func_mask_bias)
         fb = func_mask_bias(func, cu_q, cu_k, int(max_k), q.dtype)
         out = hstu_varlen_fwd_rab(q, k, v, cu_q, int(max_k), scaling_seqlen, num_contexts, num_targets, int(target_group_size),
                                   max(int(wl), -1), max(int(wr), -1), float(alpha), fb if rab is None else (rab + fb).clamp_(min=torch.finfo(q.dtype).min))
@@ -77,7 +82,11 @@ def _bwd(dout, q, k, v, cu_q, cu_k, seqused_q, seqused_k, max_q, max_k, scaling_
     if has_drab and rab is None:
         raise RuntimeError("rab must exist when using has_drab")   # hstu_api.cpp:660
     drab = None
-    if func is not None:
+    if func is not None and rab is None:
+        _check_func(func, q)
+        g = hstu_varlen_bwd_func(dout, q, k, v, cu_q, int(max_k), scaling_seqlen, num_contexts, num_targets, int(target_group_size),
+                                 max(int(wl), -1), max(int(wr), -1), float(alpha), func)
+    elif func is not None:
         fb = func_mask_bias(func, cu_q, cu_k, int(max_k), q.dtype)
         *g, drab = hstu_varlen_bwd_rab(dout, q, k, v, cu_q, int(max_k), scaling_seqlen, num_contexts, num_targets,
                                        int(target_group_size), max(int(wl), -1), max(int(wr), -1), float(alpha),

@@ -476,6 +476,105 @@ def test_arbitrary_mask_random_jagged_vs_oracle(mode):
         _assert_drab(rab.grad, res[3])
 
 
+def _func_case(rng, lengths, H, d, tdt, per_head=True, slack=64):
+    off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    T = int(off[-1])
+    mk = lambda lo, hi, *shape: torch.from_numpy(rng.uniform(lo, hi, shape).astype(np.float32)).to(DEV).to(tdt)
+    q, k, v, dout = mk(-1, 1, T, H, d), mk(-1, 1, T, H, d), mk(-1, 1, T, H, d), mk(0, 1, T, H, d)
+    HF = H if per_head else 1
+    f = np.zeros((HF, 5, T + slack), np.int32)
+    f[:, 0] = rng.integers(0, 40, size=(HF, T + slack))
+    f[:, 1] = rng.integers(30, 120, size=(HF, T + slack)); f[:, 2] = f[:, 1] + rng.integers(0, 90, size=(HF, T + slack))
+    f[:, 3] = rng.integers(200, 260, size=(HF, T + slack)); f[:, 4] = f[:, 3] + rng.integers(0, 60, size=(HF, T + slack))
+    return off, q, k, v, dout, f
+
+
+@pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("d", [64, 256])
+def test_mask_functions_inside_the_kernels_match_their_dense_bias_statement_bit_for_bit(tdt, d):
+    """round 5: `func` is read inside the forward / dK+dV / dQ kernels (mi355_hstu_attn_{fwd_kv,bwd}_func) instead of being expanded
+    into a [batch, heads, N, N] bias of 0 / -1e9 for the biased kernels.  The two statements of the mask agree bit for bit:
+    output, dq, dk, dv; full, causal + targets, and a local window on top."""
+    from hstu.hstu_attn_interface import HstuAttnFuncFunc, HstuAttnRabFunc, func_mask_bias
+
+    rng = np.random.default_rng(7 + d)
+    lengths = np.array([300, 1, 0, 129, 64, 77])
+    off, q, k, v, dout, f = _func_case(rng, lengths, 2, d, tdt)
+    B, N = lengths.size, int(lengths.max())
+    cu = torch.from_numpy(off.astype(np.int32)).to(DEV)
+    func = torch.from_numpy(f).to(DEV)
+    nt = torch.from_numpy(np.minimum(rng.integers(0, 11, size=B), np.maximum(lengths - 1, 0)).astype(np.int32)).to(DEV)
+    alpha = 1.0 / d ** 0.5
+    for wl, wr, targets in ((-1, -1, None), (-1, 0, nt), (40, 25, None)):
+        res = []
+        for kind in ("kernel", "dense"):
+            qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
+            if kind == "kernel":
+                out = HstuAttnFuncFunc.apply(qq, kk, vv, func, cu, N, float(N), None, targets, 2, wl, wr, alpha)
+            else:
+                out = HstuAttnRabFunc.apply(qq, kk, vv, func_mask_bias(func, cu, cu, N, tdt), cu, N, float(N), None, targets, 2, wl,
+                                            wr, alpha, False)
+            out.backward(dout)
+            res.append((out.detach(), qq.grad, kk.grad, vv.grad))
+        for a_, b_ in zip(*res):
+            assert torch.equal(a_, b_), f"window ({wl}, {wr}): the in-kernel mask functions differ from the dense bias"
+
+
+def test_mask_functions_with_contextual_rows_vs_oracle():
+    """`func` together with num_contexts (refused while the functions were a bias): contextual rows see the whole history whatever
+    the functions say -- the reference's context test `continue`s in front of every other mask (hstu_fwd.h:519-524)"""
+    from hstu import hstu_attn_varlen_func
+
+    rng = np.random.default_rng(33)
+    lengths = np.array([200, 3, 0, 129, 70])
+    off, q, k, v, dout, f = _func_case(rng, lengths, 2, 64, torch.bfloat16)
+    B, N = lengths.size, int(lengths.max())
+    f[:, 0] = rng.integers(0, 6, size=f[:, 0].shape)          # narrow first intervals: the exemption is what lets context rows see
+    ctx = np.minimum(np.array([5, 2, 0, 9, 1]), lengths)
+    tgt = np.minimum(np.array([7, 0, 0, 20, 3]), np.maximum(lengths - ctx, 0))
+    cu = torch.from_numpy(off.astype(np.int32)).to(DEV)
+    ti = lambda a: torch.from_numpy(a.astype(np.int32)).to(DEV)
+    qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
+    alpha = 1.0 / 8
+    out = hstu_attn_varlen_func(qq, kk, vv, cu, cu, None, None, N, N, N, ti(ctx), ti(tgt), target_group_size=2, window_size=(-1, 0),
+                                alpha=alpha, func=torch.from_numpy(f).to(DEV))
+    out.backward(dout)
+    qn, kn, vn, dn = (t.float().cpu().numpy() for t in (q, k, v, dout))
+    okw = dict(causal=True, num_targets=tgt, num_contextuals=ctx, target_group_size=2, func=f)
+    ref = ho.hstu_attn_fwd(qn, kn, vn, off, alpha, N, **okw)
+    res = ho.hstu_attn_bwd(dn, qn, kn, vn, off, alpha, N, **okw)
+    _assert_vs_oracle(out, (qq.grad, kk.grad, vv.grad), ref, res[0], res[1], res[2])
+    # and the exemption matters in this case: without it the context rows' outputs differ
+    ref_no = ho.hstu_attn_fwd(qn, kn, vn, off, alpha, N, causal=True, num_targets=tgt, target_group_size=2, func=f)
+    assert np.abs(ref_no - ref).max() > 1e-2
+
+
+def test_mask_functions_allocate_no_mask_tensor():
+    """2 x 4096 tokens: the forward under `func` allocates its output and nothing else (the dense statement of the same mask is a
+    [2, 2, 4096, 4096] bias: 128 MB here, 1 GB at batch 32)"""
+    from hstu import hstu_attn_varlen_func
+
+    rng = np.random.default_rng(5)
+    lengths = np.array([4096, 4096])
+    off, q, k, v, dout, f = _func_case(rng, lengths, 2, 64, torch.bfloat16, per_head=False, slack=0)
+    f[:, 3] = rng.integers(2000, 3000, size=f[:, 3].shape); f[:, 4] = f[:, 3] + rng.integers(0, 900, size=f[:, 3].shape)
+    cu = torch.from_numpy(off.astype(np.int32)).to(DEV)
+    func = torch.from_numpy(f).to(DEV)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    with torch.no_grad():
+        out = hstu_attn_varlen_func(q, k, v, cu, cu, None, None, 4096, 4096, 4096, None, None, window_size=(-1, -1), alpha=0.125,
+                                    func=func)
+    torch.cuda.synchronize()
+    assert torch.cuda.max_memory_allocated() - base < 2 * q.numel() * q.element_size()
+    sel = np.r_[0:40, 4000:4096, 4096:4130, 8100:8192]          # a few hundred rows against the oracle (the whole batch takes minutes)
+    qn, kn, vn = (t.float().cpu().numpy() for t in (q, k, v))
+    ref = ho.hstu_attn_fwd(qn, kn, vn, off, 0.125, 4096, causal=False, func=f)
+    err = np.abs(out.float().cpu().numpy()[sel] - ref[sel]).max()
+    assert err <= 6e-3 * np.abs(ref).max() + 1e-6
+
+
 @pytest.mark.parametrize("d", [32, 64, 128, 256])
 @pytest.mark.parametrize("mode", ["causal", "ctx_targets", "noncausal", "window", "one_head"])
 def test_rab_random_jagged_vs_oracle(d, mode):
