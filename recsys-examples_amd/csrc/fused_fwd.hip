@@ -1602,7 +1602,10 @@ __device__ __forceinline__ void lookback_sum2_1024(const unsigned long long* ta,
 //      record: the gather finds the rows of the key's occurrences there.  Shared by the two partition kernels.
 template <int HASH, typename DRec, int THREADS = kP3Threads>
 __device__ __forceinline__ void part_evict(FusedArgs& a, int nd, int64_t rec_base, const DRec* d_rec, int* d_ent, int* d_base, int* s_lock,
-                                           unsigned* s_late, int* h_slot, int* h_cnt, int tbl, int64_t tp0, int64_t rowb, int64_t s0) {
+                                           unsigned* s_late, int* h_slot, int* h_cnt, int tbl, int64_t tp0, int64_t rowb, int64_t s0,
+                                           const uint64_t* d_key = nullptr, const int2* d_zw = nullptr) {
+      // d_key / d_zw (optional, LDS): key and (slot code, count) of every deferred record, left by the thread that held the
+      // record in registers -- two dependent round trips (record, key) off the front of the chain
       if (!a.timer) a.timer = device_clock();
       const int g = lane_id() & (G - 1);
       const int gpb = THREADS / G;
@@ -1611,11 +1614,19 @@ __device__ __forceinline__ void part_evict(FusedArgs& a, int nd, int64_t rec_bas
         const int e = e0 + (int)threadIdx.x / G;
         const bool act = e < nd;
         const int64_t r = rec_base + (act ? (int)d_rec[e] : 0);
-        const uint4 rd = a.rec[r];
-        int64_t kp = (int64_t)rd.x; kp = kp < a.n ? kp : a.n - 1;
-        const uint64_t key = a.keys[kp];
-        const int cnt = (int)rd.w;
-        const int64_t bucket = act ? -(int64_t)(int)rd.z - 2 : 0;
+        uint64_t key;
+        int cnt, zc;
+        if (d_key) {
+          key = d_key[act ? e : 0];
+          const int2 zw = d_zw[act ? e : 0];
+          zc = zw.x; cnt = zw.y;
+        } else {
+          const uint4 rd = a.rec[r];
+          int64_t kp = (int64_t)rd.x; kp = kp < a.n ? kp : a.n - 1;
+          key = a.keys[kp];
+          cnt = (int)rd.w; zc = (int)rd.z;
+        }
+        const int64_t bucket = act ? -(int64_t)zc - 2 : 0;
         const int64_t hash = (int64_t)(fmix64(key) & 0x7FFFFFFFFFFFFFFFull);
         bool done = !act;
         int guard = 0;
@@ -1642,23 +1653,43 @@ __device__ __forceinline__ void part_evict(FusedArgs& a, int nd, int64_t rec_bas
                   atomicAdd(&a.bucket_sizes[bucket], 1);
                 }
               } else {
+                // The lane's minimum FIRST, its eligibility second (round 5).  The scan used to test every slot that beat the
+                // running minimum as it went -- score, then key, then pin counter, three dependent round trips, up to 16 times per
+                // lane: ~25 us for one key, and a partition kernel that evicts for a single key holds up every partition behind
+                // it in the look-back (table at 75 % load: 19.8 -> 48 us, profiles/r05_eviction_regime.txt).  Now the lane's 16
+                // scores are fetched eight at a time, the smallest (score, slot) is tested, and only a refused one (locked, pinned, in
+                // use by this batch: rare) sends the lane round again for the next smallest.
                 uint64_t best = ~0ull, bkey = 0;
                 int bslot = -1;
                 const uint64_t* sc = a.t.scores(bucket);
                 const int32_t* pin = a.counter ? a.counter + bucket * a.t.C : nullptr;
-                for (int s1 = 2 * g; s1 < C; s1 += 2 * G) {
+                uint64_t lo_s = 0;
+                int lo_slot = -1;                  // candidates are (score, slot) > (lo_s, lo_slot), lexicographically
+                for (int tries = 0; tries < C; ++tries) {
+                  uint64_t cs = ~0ull;
+                  int cslot = -1;
+                  for (int s1 = 2 * g; s1 < C; s1 += 8 * G) {    // (two passes at the usual 128 slots per bucket, 8 loads in flight: 16 -- or these 8 issued in front of the probe -- spill)
+                    uint64_t v[8];
   #pragma unroll
-                  for (int u = 0; u < 2; ++u) {
-                    const int s2 = s1 + u;
-                    const uint64_t v = ald64(sc + (int64_t)s2 * a.t.ns + (a.t.ns - 1));
-                    if (v < best) {
-                      const uint64_t k2 = ald64(ks + s2);
-                      if (k2 == kLockedKey || k2 == kEmptyKey) continue;
-                      if (pin && __hip_atomic_load(pin + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;
-                      if (p2_find<HASH>(h_slot, (int)(bucket * a.t.C + s2)) >= 0) continue;   // used by this batch
-                      best = v; bslot = s2; bkey = k2;
+                    for (int u = 0; u < 8; ++u) {
+                      const int s2 = s1 + (u >> 1) * 2 * G + (u & 1);
+                      v[u] = s2 < C ? ald64(sc + (int64_t)s2 * a.t.ns + (a.t.ns - 1)) : ~0ull;
+                    }
+  #pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                      const int s2 = s1 + (u >> 1) * 2 * G + (u & 1);
+                      const bool above = v[u] > lo_s || (v[u] == lo_s && s2 > lo_slot);
+                      if (s2 < C && above && (v[u] < cs || cslot < 0)) { cs = v[u]; cslot = s2; }   // (ascending slots: ties keep the lower one)
                     }
                   }
+                  if (cslot < 0) break;
+                  const uint64_t k2 = ald64(ks + cslot);
+                  const int pv = pin ? __hip_atomic_load(pin + cslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                  if (k2 != kLockedKey && k2 != kEmptyKey && pv <= 0 && p2_find<HASH>(h_slot, (int)(bucket * a.t.C + cslot)) < 0) {
+                    best = cs; bslot = cslot; bkey = k2;
+                    break;
+                  }
+                  lo_s = cs; lo_slot = cslot;
                 }
                 group_argmin(best, bslot, bkey);
                 if (bslot >= 0) {
@@ -1729,6 +1760,8 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
   __shared__ unsigned short h_lid[kP2Hash];   // local unique id of the entry
   __shared__ short d_rec[kPartCap];       // deferred records (bucket full)
   __shared__ int d_ent[kPartCap / 4], d_base[kPartCap / 4];   // their hash entry / rank base once resolved (first CAP / 4 per step)
+  __shared__ uint64_t d_key[kPartCap / 4];                    // ... their keys and (slot code, count): see part_evict
+  __shared__ int2 d_zw[kPartCap / 4];
   __shared__ int s_lock[256];             // bucket locks of the eviction (hashed)
   __shared__ unsigned s_late[kP2Hash / 32];
   __shared__ int s_nd, s_nbig;
@@ -1798,6 +1831,9 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
     pc = pc < a.n ? pc : a.n - 1;
     ky[k] = a.keys[pc];
   }
+#pragma unroll
+  for (int k = 0; k < kP3Items; ++k)
+    if (dj[k] >= 0) { d_key[dj[k]] = ky[k]; d_zw[dj[k]] = make_int2((int)rc[k].z, (int)rc[k].w); }
   QST(3);
   __syncthreads();
   QST(4);
@@ -1811,7 +1847,7 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
   const int nd = s_nd < kDefMax ? s_nd : kDefMax;
 #endif
   if (nd > 0) {
-    part_evict<kP2Hash>(a, nd, (int64_t)p * kPartCap, d_rec, d_ent, d_base, s_lock, s_late, h_slot, h_cnt, tbl, tp0, rowb, s0);
+    part_evict<kP2Hash>(a, nd, (int64_t)p * kPartCap, d_rec, d_ent, d_base, s_lock, s_late, h_slot, h_cnt, tbl, tp0, rowb, s0, d_key, d_zw);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kP3Items; ++k)
@@ -2407,6 +2443,9 @@ int mi355_demb_forward_fused(
   if (part_fused && env_live) { const char* e4 = getenv("MI355_PART_PRIO"); if (e4 && atoi(e4) == 0) a.dbg |= 4; }
   // opt-in: an overflowed step is re-run on the per-slot-counter path inside this call (the reference never skips an update,
   // unique_op.cu:484-714): three more launches behind the gather that return at once in the steady state
+  // (round 5: the chain on the SIDE stream, forked in front of the gather -- its head kernel holding it back in a flagged step until
+  //  every wave of the gather's launch had counted itself done -- was built, passed the flood tests, and cost 0.252 ms per C2 step
+  //  against 0.169 in line and 0.162 without: the fork / join event pair across two queues is far dearer than three empty launches)
   static const int rerun_env = getenv("MI355_FUSED_OVERFLOW_RERUN") ? atoi(getenv("MI355_FUSED_OVERFLOW_RERUN")) : 0;
   static int g_epoch = 0;
   const bool rerun = pathc && rerun_env != 0;

@@ -661,8 +661,10 @@ np.save(sys.argv[3], out.detach().cpu().numpy()); np.save(sys.argv[4], rows.cpu(
     assert int(a._fused_aux[5]) == 0 and bool(torch.isfinite(out2).all())
 
 
-def test_overflowed_partition_is_rerun_inside_the_call_when_asked(monkeypatch, tmp_path):
-    """MI355_FUSED_OVERFLOW_RERUN=1 (opt-in; the reference never skips an update, unique_op.cu:484-714): a batch whose (tile, key)
+@pytest.mark.parametrize("mode,pooling", [("1", "SUM"), ("1", "NONE")])
+def test_overflowed_partition_is_rerun_inside_the_call_when_asked(monkeypatch, tmp_path, mode, pooling):
+    """(sequence lookups -- pooling NONE -- since round 5: the partition blocks ride in the gather's launch there.)
+    MI355_FUSED_OVERFLOW_RERUN=1 (opt-in; the reference never skips an update, unique_op.cu:484-714): a batch whose (tile, key)
     records flood ONE slot range -- 4 000 distinct keys of partition 0 drawn 80 000 times: ~64 K records for a list of 2 048, but
     no bucket overfull, so nothing depends on eviction order -- is re-run on the per-slot-counter path inside the same C call:
     the three gated launches behind the gather find the epoch in aux[6] and redo the numbering and the CSR.  Compared with a process
@@ -673,7 +675,7 @@ def test_overflowed_partition_is_rerun_inside_the_call_when_asked(monkeypatch, t
     import sys
 
     cap, C, n = 1 << 20, 128, 80_000
-    a = _mk(True, (16,), cap=cap, pooling="SUM", learning_rate=0.5, strategy="TIMESTAMP", opt="SGD", monkeypatch=monkeypatch)
+    a = _mk(True, (16,), cap=cap, pooling=pooling, learning_rate=0.5, strategy="TIMESTAMP", opt="SGD", monkeypatch=monkeypatch)
     P = _partitions(a, n)
     assert P > 0
     S = a.table.capacity_
@@ -698,7 +700,7 @@ class MP:
     def setenv(self, k, v):
         import os; os.environ[k] = v
 d, tag = sys.argv[1], sys.argv[2]
-m = _mk(True, (16,), cap={cap}, pooling="SUM", learning_rate=0.5, strategy="TIMESTAMP", opt="SGD", monkeypatch=MP())
+m = _mk(True, (16,), cap={cap}, pooling={pooling!r}, learning_rate=0.5, strategy="TIMESTAMP", opt="SGD", monkeypatch=MP())
 keys = torch.from_numpy(np.load(d + "/k.npy")).cuda(); off = torch.from_numpy(np.load(d + "/o.npy")).cuda()
 fk = torch.from_numpy(np.load(d + "/f.npy")).cuda(); foff = torch.arange(fk.numel() + 1, dtype=torch.int64, device="cuda")
 m.train()
@@ -720,7 +722,7 @@ np.savez(d + "/res_" + tag + ".npz", *outs, found=f.cpu().numpy(), rows=rows.cpu
          aux6=int(m._fused_aux[6]), lazy=np.array(lazy))
 """
     res = {}
-    for tag, env in (("rerun", dict(MI355_FUSED_OVERFLOW_RERUN="1")), ("counters", dict(MI355_FUSED_PART="0"))):
+    for tag, env in (("rerun", dict(MI355_FUSED_OVERFLOW_RERUN=mode)), ("counters", dict(MI355_FUSED_PART="0"))):
         r = subprocess.run([sys.executable, "-c", code, d, tag], env=dict(os.environ, MI355_FUSED="1", **env), capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]

@@ -16,15 +16,18 @@ import mi355_native
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=65536)
 ap.add_argument("--rows", type=int, default=10_000_000)
+ap.add_argument("--batches", type=int, default=6, help="distinct batches run before the stamped step (300: the table is 3/4 full, "
+                "new keys meet full buckets: the eviction regime)")
 a = ap.parse_args()
 dev = torch.device("cuda")
-batches = bench.zipf_batches(a.rows, 0.99, a.batch, 6, dev)
+batches = bench.zipf_batches(a.rows, 0.99, a.batch, a.batches, dev)
 module = bench.build_module(a.rows, 128, dev)
 module.train()
 grad = (torch.randn(a.batch, 128, device=dev) * 0.01).to(torch.bfloat16)
-with torch.no_grad():
-    for k, o in batches:
-        module._forward_impl(k, o, train=True)
+if a.batches <= 6:
+    with torch.no_grad():
+        for k, o in batches:
+            module._forward_impl(k, o, train=True)
 for k, o in batches:
     out, st = module._forward_impl(k, o, train=True)
     module._backward_impl(st, grad)
