@@ -2517,18 +2517,126 @@ __device__ __forceinline__ bool xch_other_chunk(const BwdAttnArgs& g, int b, int
 // Round 5: the sequence lengths are staged in LDS by 256 threads first.  Read from global memory inside the 64 lanes' counting loops
 // (three dependent passes over B x H units, one scalar-cache miss per step) the kernel took 34-43 us of every jagged backward
 // (profiles/r04_step_timeline.txt); from LDS it is a few microseconds.
-constexpr int kPlanMaxB = 8192;
+constexpr int kPlanMaxU = 4096;        // (sequence, head) units whose tile prefix is staged in LDS (more: the serial form)
+constexpr int kPlanMaxChunks = 2048;   // chunk starts kept in LDS for the parallel assignment (more: the serial form)
+// The greedy cut of the (sequence, head) units into chunks of at most c tiles -- `if (cur + need > c && cur > 0) new chunk` over the
+// units in order -- without walking the units (round 5: the walk, once per lane for its trial capacity and once more by lane 0 with
+// two global stores per unit, was 34-43 us of ONE wave in front of every jagged backward, profiles/r04_step_timeline.txt).
+// F[u] = tiles in front of unit u (a prefix array in LDS, built by all threads); a chunk that starts at unit s ends in front of
+// e = L(F[s] + c), L(x) = the largest e with F[e] <= x (binary search) -- or, when not even the first unit with tiles fits
+// (z = L(F[s]) is that unit: the units s .. z - 1 have none), in front of z + 1: exactly the walk's `cur > 0` rule
+// (tests/test_hstu_plan_cpu.py holds the equivalence).  A trial capacity costs chunks x log U LDS reads instead of U dependent
+// steps; the assignment (base, chunk of every unit) is done by all 256 threads from the list of chunk starts.
+struct PlanView {
+  const int64_t* F; int U;
+  __device__ __forceinline__ int L(int64_t x) const {      // largest e in [0, U] with F[e] <= x   (F[0] = 0 <= x)
+    int lo = 0, hi = U;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (F[mid] <= x) lo = mid; else hi = mid - 1; }
+    return lo;
+  }
+  __device__ __forceinline__ int next(int s, int64_t c) const {   // first unit of the chunk behind the one that starts at s
+    const int64_t fs = F[s];
+    const int z = L(fs), e = L(fs + c);
+    return e > z ? e : (z + 1 < U ? z + 1 : U);
+  }
+  __device__ __forceinline__ int count(int64_t c) const {
+    int n = 0;
+    for (int s = 0; s < U; s = next(s, c)) ++n;
+    return n > 0 ? n : 1;
+  }
+};
 __global__ void __launch_bounds__(256) hstu_bwd_plan_kernel(const int* cu, int B, int H, int64_t cap_tiles, int tri, int64_t* base,
                                                             int32_t* chunk, int32_t* nchunks_out, int host_chunks, int* host_err) {
-  __shared__ int s_ng[kPlanMaxB];
+  __shared__ int64_t s_F[kPlanMaxU + 1];
+  __shared__ int64_t s_part[256];
+  __shared__ int s_start[kPlanMaxChunks + 1];
+  __shared__ int64_t s_umax;
+  __shared__ int s_n;
+  __shared__ int64_t s_c;
   if (blockIdx.x != 0) return;
-  const bool staged = B <= kPlanMaxB;
-  if (staged) for (int b = threadIdx.x; b < B; b += blockDim.x) s_ng[b] = (cu[b + 1] - cu[b] + 31) >> 5;
-  __syncthreads();
-  if (threadIdx.x >= 64) return;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int64_t U64 = (int64_t)B * H;
+  const bool staged = U64 <= kPlanMaxU;
+  if (staged) {
+    const int U = (int)U64;
+    // ---- tiles of every unit, their prefix (256 threads: a slice of units each, the slices' sums scanned by wave 0)
+    const int per = (U + 255) / 256, u0 = tid * per < U ? tid * per : U, u1 = u0 + per < U ? u0 + per : U;
+    int64_t sum = 0, mx = 1;
+    {
+      int b = u0 / H, h = u0 - b * H;
+      int64_t nd = 0;
+      for (int u = u0; u < u1; ++u) {
+        if (u == u0 || h == 0) { const int64_t n = (cu[b + 1] - cu[b] + 31) >> 5; nd = tri ? n * (n + 1) / 2 : n * n; }
+        s_F[u] = nd;                   // (the unit's own tiles for now)
+        sum += nd;
+        mx = nd > mx ? nd : mx;
+        if (++h == H) { h = 0; ++b; }
+      }
+    }
+    s_part[tid] = sum;
+    if (tid == 0) s_umax = 1;
+    __syncthreads();
+    atomicMax((unsigned long long*)&s_umax, (unsigned long long)mx);
+    if (tid < 64) {                    // exclusive scan of the 256 slice sums: four per lane, then across the wave
+      int64_t v[4], run = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[k] = s_part[4 * tid + k]; run += v[k]; }
+      int64_t inc = run;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int64_t o = ((int64_t)__shfl_up((int)(inc >> 32), off, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)inc, off, 64);
+        if (tid >= off) inc += o;
+      }
+      int64_t ex = inc - run;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { s_part[4 * tid + k] = ex; ex += v[k]; }
+    }
+    __syncthreads();
+    {
+      int64_t run = s_part[tid];
+      for (int u = u0; u < u1; ++u) { const int64_t nd = s_F[u]; s_F[u] = run; run += nd; }
+      if (u1 == U) s_F[U] = run;       // (the thread whose slice ends the units; empty slices behind it hold the same total)
+    }
+    __syncthreads();
+    const PlanView v{s_F, U};
+    if (tid < 64) {
+      const int64_t umax = s_umax;
+      const int best = v.count(cap_tiles);
+      const int64_t lo = umax < cap_tiles ? umax : cap_tiles;
+      const int64_t mine = lo + (cap_tiles - lo) * (tid + 1) / 64;                     // lane 63 tries the cap itself
+      const bool ok = v.count(mine) <= best;
+      const unsigned long long okm = __ballot(ok);
+      const int pick = __ffsll(okm) - 1;                                               // the smallest capacity that still needs `best` chunks
+      if (tid == 0) {
+        const int64_t c = lo + (cap_tiles - lo) * (pick + 1) / 64;
+        int n = 0;
+        for (int s0 = 0; s0 < U; s0 = v.next(s0, c)) { if (n < kPlanMaxChunks) s_start[n] = s0; ++n; }
+        if (n == 0) { s_start[0] = 0; n = 1; }
+        s_n = n; s_c = c;
+        nchunks_out[0] = n;
+        // the host launches `host_chunks` chunk passes from a bound over (T, B, max L); a plan that needs more (a token hint that
+        // does not belong to this batch) would leave units unprocessed: say so where the next call of the library sees it
+        if (n > host_chunks && host_err) *host_err = n;
+      }
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (n <= kPlanMaxChunks) {
+      for (int u = tid; u < U; u += 256) {
+        int lo = 0, hi = n - 1;                    // the chunk of unit u: the last start <= u
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_start[mid] <= u) lo = mid; else hi = mid - 1; }
+        base[u] = s_F[u] - s_F[s_start[lo]];
+        chunk[u] = lo;
+      }
+      return;
+    }
+    // (more chunks than the list holds: lane 0 walks them below with the capacity chosen above)
+  }
+  // ---- the serial form: one lane walks the units (more than kPlanMaxU units / more than kPlanMaxChunks chunks)
+  if (tid >= 64) return;
+  const int lane = tid;
   auto unit = [&](int b) -> int64_t {
-    const int64_t ngb = staged ? (int64_t)s_ng[b] : (int64_t)((cu[b + 1] - cu[b] + 31) >> 5);
+    const int64_t ngb = (int64_t)((cu[b + 1] - cu[b] + 31) >> 5);
     return tri ? ngb * (ngb + 1) / 2 : ngb * ngb;
   };
   auto count = [&](int64_t c) -> int {
@@ -2543,15 +2651,19 @@ __global__ void __launch_bounds__(256) hstu_bwd_plan_kernel(const int* cu, int B
     }
     return n;
   };
-  int64_t umax = 1;
-  for (int b = 0; b < B; ++b) { const int64_t u = unit(b); umax = u > umax ? u : umax; }
-  const int best = count(cap_tiles);
-  const int64_t lo = umax < cap_tiles ? umax : cap_tiles;
-  const int64_t mine = lo + (cap_tiles - lo) * (lane + 1) / 64;                     // lane 63 tries the cap itself
-  const bool ok = count(mine) <= best;
-  const unsigned long long okm = __ballot(ok);
-  const int pick = __ffsll(okm) - 1;                                                 // the smallest capacity that still needs `best` chunks
-  const int64_t c = lo + (cap_tiles - lo) * (pick + 1) / 64;
+  int64_t c;
+  if (staged) c = s_c;
+  else {
+    int64_t umax = 1;
+    for (int b = 0; b < B; ++b) { const int64_t u = unit(b); umax = u > umax ? u : umax; }
+    const int best = count(cap_tiles);
+    const int64_t lo = umax < cap_tiles ? umax : cap_tiles;
+    const int64_t mine = lo + (cap_tiles - lo) * (lane + 1) / 64;
+    const bool ok = count(mine) <= best;
+    const unsigned long long okm = __ballot(ok);
+    const int pick = __ffsll(okm) - 1;
+    c = lo + (cap_tiles - lo) * (pick + 1) / 64;
+  }
   if (lane != 0) return;
   int64_t cur = 0;
   int n = 0;
@@ -2565,8 +2677,6 @@ __global__ void __launch_bounds__(256) hstu_bwd_plan_kernel(const int* cu, int B
     }
   }
   nchunks_out[0] = n + 1;
-  // the host launches `host_chunks` chunk passes from a bound over (T, B, max L); a plan that needs more (a token hint that does not
-  // belong to this batch) would leave units unprocessed: say so where the next call of the library sees it (pinned host word)
   if (n + 1 > host_chunks && host_err) *host_err = n + 1;
 }
 
