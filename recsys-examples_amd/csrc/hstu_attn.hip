@@ -2598,6 +2598,11 @@ __global__ void __launch_bounds__(256) hstu_bwd_plan_kernel(const int* cu, int B
       if (u1 == U) s_F[U] = run;       // (the thread whose slice ends the units; empty slices behind it hold the same total)
     }
     __syncthreads();
+    if (s_F[U] <= cap_tiles) {          // everything fits one chunk (the usual case under the default cap): no capacity search
+      for (int u = tid; u < U; u += 256) { base[u] = s_F[u]; chunk[u] = 0; }
+      if (tid == 0) nchunks_out[0] = 1;
+      return;
+    }
     const PlanView v{s_F, U};
     if (tid < 64) {
       const int64_t umax = s_umax;
