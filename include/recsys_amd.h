@@ -279,6 +279,8 @@ int mi355_rw_input_begin(void* handle, int64_t num_features, int64_t batch_size,
 /* the one host read of the exact exchange: waits for the launch that wrote the counts; send_splits / recv_splits [W] (host),
  * totals[0] = keys sent, totals[1] = keys received (the size of the buffer mi355_rw_input_keys fills) */
 int mi355_rw_input_counts(void* handle, int ticket, int64_t* send_splits, int64_t* recv_splits, int64_t* totals);
+/* 1 when mi355_rw_input_counts(ticket) would not wait (the launch that writes the counts has completed), else 0 */
+int mi355_rw_input_counts_ready(void* handle, int ticket);
 /* second half on `stream`: all-to-all-v of the 8-byte keys, recat to feature-major when W > 1 and F > 1 (fm_* buffers, else
  * unused: the received order IS feature-major); `consumer_stream` (if another stream) is ordered behind it */
 int mi355_rw_input_keys(void* handle, int ticket, int64_t num_features, int64_t batch_size, const void* new_keys,

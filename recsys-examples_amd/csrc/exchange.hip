@@ -200,6 +200,13 @@ int mi355_rw_input_begin(void* handle, int64_t num_features, int64_t batch_size,
   return 0;
 }
 
+// 1: the key counts of `ticket` have been written (mi355_rw_input_counts will not wait), 0: not yet
+int mi355_rw_input_counts_ready(void* handle, int ticket) {
+  RwExchange* x = (RwExchange*)handle;
+  if (!x || ticket < 0 || ticket >= kRing) return 0;
+  return hipEventQuery(x->ev_counts[ticket]) == hipSuccess ? 1 : 0;
+}
+
 int mi355_rw_input_counts(void* handle, int ticket, int64_t* send_splits, int64_t* recv_splits, int64_t* totals) {
   RwExchange* x = (RwExchange*)handle;
   MI355_CHECK_ARG(x && ticket >= 0 && ticket < kRing && send_splits && recv_splits && totals, "bad arguments");

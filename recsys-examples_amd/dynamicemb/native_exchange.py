@@ -105,6 +105,10 @@ class NativeExchange:
         return (buf, self._ticket.value, F, B, n, nl, o_new_val, o_perm if sequence else -1, o_recv_len, o_recv_off, side,
                 values.dtype)
 
+    def counts_ready(self, state) -> bool:
+        """True when input_finish(state) would not wait for the key counts"""
+        return bool(self._lib.mi355_rw_input_counts_ready(self._h, state[1]))
+
     def input_finish(self, state) -> ShardedKeys:
         """the host reads the key counts, the keys travel; the consumer orders itself behind them with wait_keys()"""
         from mi355_native import check, stream

@@ -148,6 +148,7 @@ _SIGS = {
     "mi355_rw_destroy": [c_p],
     "mi355_rw_input_begin": [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "mi355_rw_input_counts": [c_p, c_int, c_p, c_p, c_p],
+    "mi355_rw_input_counts_ready": [c_p, c_int],
     "mi355_rw_input_keys": [c_p, c_int, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "mi355_rw_wait_keys": [c_p, c_int, c_p],
     "mi355_rw_output_pooled": [c_p, c_p, c_p, c_i64, c_int, c_p, c_int, c_p],
