@@ -376,3 +376,37 @@ def test_in_library_exchange_matches_the_c10d_sequence(one_rank_group, pooled, m
         f1, r1 = mods[0].lookup_rows(probe, t)
         f2, r2 = mods[1].lookup_rows(probe, t)
         assert torch.equal(f1, f2) and torch.equal(r1, r2)
+
+
+@pytest.mark.parametrize("pooled", [True, False])
+def test_in_library_exchange_with_empty_batches_and_empty_bags(one_rank_group, pooled):
+    """a batch without a single key, then one whose bags are mostly empty, through the library's own collectives (zero-byte sends,
+    zero-row receive buffers), forward and backward; outputs against the bare module"""
+    from dynamicemb.sharded import OverlappedSteps, RowWiseShardedLookup, _ModuleLocal
+
+    F, B, dim = 2, 12, 16
+    rng = np.random.default_rng(77)
+    ref = _module(pooled, F, dim, torch.float32)
+    loc = _module(pooled, F, dim, torch.float32)
+    sh = RowWiseShardedLookup(_ModuleLocal(loc), F, [500] * F, pooled=pooled, device=torch.device("cuda", 0), out_dtype=torch.float32,
+                              dist_type_per_feature=["roundrobin"] * F)
+    ov = OverlappedSteps(sh)
+    batches = []
+    for lens in (np.zeros(F * B, np.int64), (rng.random(F * B) < 0.2).astype(np.int64) * 3, np.zeros(F * B, np.int64),
+                 rng.integers(0, 4, F * B)):
+        off = np.zeros(F * B + 1, np.int64)
+        off[1:] = np.cumsum(lens)
+        batches.append((torch.from_numpy(rng.integers(0, 500, off[-1]).astype(np.int64)).cuda(), torch.from_numpy(off).cuda()))
+    for i, (k, o) in enumerate(batches):
+        o_ref, st = ref._forward_impl(k, o, train=True)
+        o_sh, ctx = ov.forward(k, o, True, batches[i + 1] if i + 1 < len(batches) else None)
+        assert sh._nx is not None
+        assert o_ref.shape == o_sh.shape and torch.equal(o_ref, o_sh)
+        g = torch.randn_like(o_ref)
+        ref._backward_impl(st, g)
+        ov.backward(ctx, g)
+    probe = torch.arange(0, 500, device="cuda", dtype=torch.int64)
+    for t in range(F):
+        f1, r1 = ref.lookup_rows(probe, t)
+        f2, r2 = loc.lookup_rows(probe, t)
+        assert torch.equal(f1, f2) and torch.equal(r1, r2)
