@@ -64,3 +64,19 @@ def test_table_partition_views_cpu():
     assert keys.shape == (nb, C) and dig.shape == (nb, C) and sc.shape == (nb, C)
     assert dig[1, 2].item() == st[17 * C + 8 * C + 2].item()
     assert keys.stride() == (17 * C // 8, 1)
+
+
+def test_exchange_entry_points_reject_use_before_rccl_is_bound():
+    """csrc/exchange.hip binds RCCL at run time; before that (and with a bad path) every entry point answers with an error code"""
+    import mi355_native as N
+
+    lib = N.lib()
+    buf = (ctypes.c_uint8 * 128)()
+    if lib.mi355_rw_unique_id(ctypes.addressof(buf), 128) == 0:
+        pytest.skip("RCCL already bound in this process")
+    assert b"mi355_rw_load_rccl" in lib.mi355_last_error()
+    assert lib.mi355_rw_load_rccl(b"/nonexistent/librccl.so") == -1 and lib.mi355_last_error()
+    h = ctypes.c_void_p()
+    assert lib.mi355_rw_create(ctypes.addressof(buf), ctypes.addressof(buf), 1, 0, ctypes.byref(h)) == -1
+    assert lib.mi355_rw_input_counts_ready(None, 0) == 0
+    assert lib.mi355_rw_allgather(None, None, None, 0, None) == -1
