@@ -571,6 +571,32 @@ def c2_16x_section(args, module, device):
                               "algorithmic_bytes_per_step": step_bytes}}
 
 
+def c2_filling_section(args, device, fill=300, window=40):
+    """The C2 step while the table FILLS UP: `fill` distinct batches into an empty table -- at 300 the 10 M-row table is ~3/4 full and a
+    few new keys per step meet a full bucket, so the partition kernel evicts for them -- and the time of the last `window` of them.
+    Every batch here is new (inserts in every step), unlike the headline's steady state over pre-inserted batches; found in round 5
+    (`bench.py --steps 300`, profiles/r05_eviction_regime.txt): the regime a long training run with a full table lives in."""
+    batches = zipf_batches(args.rows, args.alpha, args.batch, fill, device, seed=4321)
+    m = build_module(args.rows, args.dim, device)
+    m.train()
+    grad = (torch.randn(args.batch, args.dim, device=device) * 0.01).to(torch.bfloat16)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for i, (keys, offsets) in enumerate(batches):
+        if i == fill - window:
+            e0.record()
+        out, st = m._forward_impl(keys, offsets, train=True)
+        m._backward_impl(st, grad)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / window
+    size = int(m.size())
+    nt = float(np.mean([k.numel() for k, _ in batches[fill - window:]]))
+    del batches, m, grad
+    torch.cuda.empty_cache()
+    return {"ms_per_step": ms, "lookups_per_s": nt / ms * 1e3, "distinct_batches": fill, "timed_last": window, "table_rows": size,
+            "load": size / args.rows, "note": "every batch new (inserts each step; full buckets evict)"}
+
+
 def sharded_stage_times(sharded, batches, grad, dist, device, world, step_ms):
     """Where a sharded step's time goes, so that a scaling curve explains itself: the four stages of one step run back to
     back WITHOUT overlap (plain schedule), each bracketed by HIP events on the launch stream -- input_dist (bucketize + the
@@ -822,6 +848,7 @@ def main():
     if rank == 0 and not sharded_path and not args.no_kernel_timing and not args.no_extra:
         result["c2_16x"] = c2_16x_section(args, module, device)
         result["model_shapes"] = model_shapes_section(args, device)
+        result["c2_table_filling"] = c2_filling_section(args, device)
 
     if not args.no_hstu:
         h = hstu_section(args, device, world, dist if sharded_path else None)

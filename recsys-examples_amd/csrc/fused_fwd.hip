@@ -43,9 +43,11 @@ namespace mi355 {
 
 STAMP_ARRAY(g_st_probe, 1024, 12)
 STAMP_ARRAY(g_st_part, 1024, 10)
+STAMP_ARRAY(g_st_evict, 1024, 10)
 STAMP_ARRAY(g_st_fgather, 16384, 2)
 #define PST(ph) STAMP(g_st_probe, 1024, 12, ph)
 #define QST(ph) STAMP(g_st_part, 1024, 10, ph)
+#define EST(ph) STAMP(g_st_evict, 1024, 10, ph)      // the first deferred key of a partition block (thread 0 leads its lane group)
 
 constexpr int kFusedMaxT = 128;     // tables per fused launch (per-table metadata lives in LDS)
 constexpr int kPartMax = 1024;      // partitions of the partitioned index stage (their counters live in the aux header)
@@ -1603,9 +1605,13 @@ __device__ __forceinline__ void lookback_sum2_1024(const unsigned long long* ta,
 template <int HASH, typename DRec, int THREADS = kP3Threads>
 __device__ __forceinline__ void part_evict(FusedArgs& a, int nd, int64_t rec_base, const DRec* d_rec, int* d_ent, int* d_base, int* s_lock,
                                            unsigned* s_late, int* h_slot, int* h_cnt, int tbl, int64_t tp0, int64_t rowb, int64_t s0,
-                                           const uint64_t* d_key = nullptr, const int2* d_zw = nullptr) {
+                                           const uint64_t* d_key = nullptr, const int2* d_zw = nullptr, unsigned* s_fresh = nullptr) {
+      // s_fresh (optional, LDS, one bit per deferred record, zeroed by the caller; needs d_key): rows of freshly taken slots are NOT
+      // initialised by the 8 lanes that evicted for them (16 Philox draws each in a row: 12.5 K of the 27.8 K cycles one eviction
+      // took, profiles/r05_eviction_stamps.txt) but by the whole block behind the pass, one element per thread
       // d_key / d_zw (optional, LDS): key and (slot code, count) of every deferred record, left by the thread that held the
       // record in registers -- two dependent round trips (record, key) off the front of the chain
+      EST(0);
       if (!a.timer) a.timer = device_clock();
       const int g = lane_id() & (G - 1);
       const int gpb = THREADS / G;
@@ -1632,13 +1638,19 @@ __device__ __forceinline__ void part_evict(FusedArgs& a, int nd, int64_t rec_bas
         int guard = 0;
         while (__ballot(!done)) {
           if (!done) {
-            int got = 0;
-            if (g == 0) got = atomicCAS(&s_lock[bucket & 255], 0, 1) == 0 ? 1 : 0;
+            // lock word of the bucket (hashed): bit 0 held, bit 1 "an eviction of this block has been through here".  Until then the
+            // bucket is as the probe kernel left it -- full, the key absent: every record of the bucket is in THIS block and nothing
+            // else writes the table inside a step -- and the re-probe (digest row, key words: two dependent round trips) is skipped
+            int got = 0, seen = 0;
+            if (g == 0) { const int old = atomicOr(&s_lock[bucket & 255], 1); got = (old & 1) == 0 ? 1 : 0; seen = (old >> 1) & 1; }
             got = group_bcast(got, 0);
+            seen = group_bcast(seen, 0);
             if (got) {
+              EST(1);
               uint64_t* ks = a.t.keys(bucket);
-              int found_slot, empty_slot;
-              group_probe(a.t, bucket, key, hash, true, true, found_slot, empty_slot);
+              int found_slot = -1, empty_slot = -1;
+              if (seen) group_probe(a.t, bucket, key, hash, true, true, found_slot, empty_slot);
+              EST(2);
               int slot = -1;
               bool fresh_row = false;
               if (found_slot >= 0) {             // another record of the same key got here first
@@ -1691,6 +1703,7 @@ __device__ __forceinline__ void part_evict(FusedArgs& a, int nd, int64_t rec_bas
                   }
                   lo_s = cs; lo_slot = cslot;
                 }
+                EST(3);
                 group_argmin(best, bslot, bkey);
                 if (bslot >= 0) {
                   slot = bslot;
@@ -1704,10 +1717,13 @@ __device__ __forceinline__ void part_evict(FusedArgs& a, int nd, int64_t rec_bas
                   }
                 }
               }
+              EST(4);
               int gslot = (int)a.S;             // no slot could be had: the key is served without a row this step
               if (slot >= 0) {
                 gslot = (int)(bucket * a.t.C + slot);
-                if (fresh_row) {
+                if (fresh_row && s_fresh) {
+                  if (g == 0) { atomicOr(&s_fresh[e >> 5], 1u << (e & 31)); ast64(ks + slot, key); }
+                } else if (fresh_row) {
                   void* rp = reinterpret_cast<void*>((uintptr_t)(tp0 + ((int64_t)gslot - s0) * rowb));
                   const int ed = (int)a.table_emb_dims[tbl], vd = (int)a.table_value_dims[tbl];
                   for (int el = g; el < vd; el += G) {
@@ -1716,12 +1732,16 @@ __device__ __forceinline__ void part_evict(FusedArgs& a, int nd, int64_t rec_bas
                     else if (a.value_dtype == kBF16) st1<kBF16>(rp, el, v);
                     else st1<kF16>(rp, el, v);
                   }
+                  EST(5);
                   if (g == 0) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    // the row is complete before its key can be seen -- needed only where somebody reads rows while this kernel
+                    // runs: the gather blocks of the fused launch (part3_lean.h) behind the partition's ready flag
+                    if (a.part_ready) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     ast64(ks + slot, key);
                   }
                 }
               }
+              EST(6);
               if (g == 0) {
                 // the slot enters the hash BEFORE the lock is released: that is what protects it from the next eviction
                 bool cl;
@@ -1731,8 +1751,9 @@ __device__ __forceinline__ void part_evict(FusedArgs& a, int nd, int64_t rec_bas
                 a.rec[r].z = (uint32_t)gslot;
                 a.rec[r].w = (uint32_t)(cnt | kRecLate);
                 __threadfence_block();
-                atomicExch(&s_lock[bucket & 255], 0);
+                atomicExch(&s_lock[bucket & 255], 2);
               }
+              EST(7);
               done = true;
             } else if (++guard > (1 << 22)) {
               if (g == 0) {
@@ -1748,6 +1769,25 @@ __device__ __forceinline__ void part_evict(FusedArgs& a, int nd, int64_t rec_bas
           }
         }
       }
+      EST(8);
+      if (s_fresh) {     // rows of the freshly taken slots: every thread of the block draws its elements
+        __syncthreads();
+        const int ed = (int)a.table_emb_dims[tbl], vd = (int)a.table_value_dims[tbl];
+        for (int item = (int)threadIdx.x; item < nd * vd; item += THREADS) {
+          const int e = item / vd, el = item - e * vd;
+          if (!((s_fresh[e >> 5] >> (e & 31)) & 1u)) continue;
+          const int gslot = h_slot[d_ent[e]];
+          void* rp = reinterpret_cast<void*>((uintptr_t)(tp0 + ((int64_t)gslot - s0) * rowb));
+          const float v = el < ed ? init_value(a.init, d_key[e], (uint32_t)el) : a.init.state_init;
+          if (a.value_dtype == kF32) st1<kF32>(rp, el, v);
+          else if (a.value_dtype == kBF16) st1<kBF16>(rp, el, v);
+          else st1<kF16>(rp, el, v);
+        }
+        // (rows read while this kernel runs -- the gather blocks of the fused launch behind the partition's ready flag -- must be
+        //  complete before the caller's barrier lets thread 0 publish the flag)
+        if (a.part_ready) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      EST(9);
 }
 
 template <int CAP>
@@ -1762,6 +1802,7 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
   __shared__ int d_ent[kPartCap / 4], d_base[kPartCap / 4];   // their hash entry / rank base once resolved (first CAP / 4 per step)
   __shared__ uint64_t d_key[kPartCap / 4];                    // ... their keys and (slot code, count): see part_evict
   __shared__ int2 d_zw[kPartCap / 4];
+  __shared__ unsigned s_fresh[kPartCap / 4 / 32];            // ... and which of them took a fresh slot (row initialised by the block)
   __shared__ int s_lock[256];             // bucket locks of the eviction (hashed)
   __shared__ unsigned s_late[kP2Hash / 32];
   __shared__ int s_nd, s_nbig;
@@ -1780,6 +1821,7 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
   for (int i = threadIdx.x; i < kP2Hash; i += kP3Threads) { h_slot[i] = -1; h_cnt[i] = 0; }
   if (threadIdx.x < 256) s_lock[threadIdx.x] = 0;
   if (threadIdx.x < kP2Hash / 32) s_late[threadIdx.x] = 0;
+  if (threadIdx.x < kPartCap / 4 / 32) s_fresh[threadIdx.x] = 0;
   if (threadIdx.x == 0) { s_nd = 0; s_nbig = 0; }
   QST(1);
   __syncthreads();
@@ -1847,7 +1889,7 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
   const int nd = s_nd < kDefMax ? s_nd : kDefMax;
 #endif
   if (nd > 0) {
-    part_evict<kP2Hash>(a, nd, (int64_t)p * kPartCap, d_rec, d_ent, d_base, s_lock, s_late, h_slot, h_cnt, tbl, tp0, rowb, s0, d_key, d_zw);
+    part_evict<kP2Hash>(a, nd, (int64_t)p * kPartCap, d_rec, d_ent, d_base, s_lock, s_late, h_slot, h_cnt, tbl, tp0, rowb, s0, d_key, d_zw, s_fresh);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kP3Items; ++k)
@@ -2147,6 +2189,7 @@ __global__ void __launch_bounds__(kScanThreads) fused_scan_partials_kernel(int* 
 using namespace mi355;
 STAMP_EXPORT(mi355_debug_stamps_probe, g_st_probe)
 STAMP_EXPORT(mi355_debug_stamps_part, g_st_part)
+STAMP_EXPORT(mi355_debug_stamps_evict, g_st_evict)
 STAMP_EXPORT(mi355_debug_stamps_fgather, g_st_fgather)
 
 // Side stream on which the forward numbers the uniques and builds the backward's CSR while its own gather runs.

@@ -97,7 +97,12 @@ PART2 = ["start -> record loads issued + LDS init", "wait: barrier", "merge (LDS
          "entry scan + publish sums", "look-back", "outputs per unique row", "outputs per record (CSR entries)", "-"]
 PART_L = ["init + barrier", "merge pass", "wait: barrier", "eviction check, entry sums, block scan, publish", "look-back",
           "unique-row outputs (+ keys)", "wait: barrier", "output pass (CSR entries)", "tail", "-"]
-if os.environ.get("MI355_FUSED_PART", "2") != "1" and os.environ.get("MI355_PART_FUSED", "1") != "0":
+EVICT = ["entry -> bucket lock taken", "re-probe (only behind an earlier eviction)", "score scan: the lane's minimum + its eligibility",
+         "group arg-min, lock / digest / score stores", "row initialisation issued", "(drain) + key published", "LDS hash insert, record, unlock",
+         "rest of the pass (other keys)", "-"]
+if os.environ.get("MI355_FUSED_PART", "2") != "1":
+    dump("mi355_debug_stamps_evict", 1024, 10, EVICT, "part_evict: FIRST deferred key of every partition block that had one (any step so far)")
+if os.environ.get("MI355_FUSED_PART", "2") != "1" and os.environ.get("MI355_PART_FUSED", "1") == "2":
     dump("mi355_debug_stamps_part", 1024, 10, PART_L[:9], "part3_lean (partition role of the gather's launch)")
 elif os.environ.get("MI355_FUSED_PART", "2") != "1":
     dump("mi355_debug_stamps_part", 1024, 10, PART2, "fused_part3_kernel")
