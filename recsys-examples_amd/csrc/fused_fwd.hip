@@ -1606,7 +1606,7 @@ template <int HASH, typename DRec, int THREADS = kP3Threads>
 __device__ __forceinline__ void part_evict(FusedArgs& a, int nd, int64_t rec_base, const DRec* d_rec, int* d_ent, int* d_base, int* s_lock,
                                            unsigned* s_late, int* h_slot, int* h_cnt, int tbl, int64_t tp0, int64_t rowb, int64_t s0,
                                            const uint64_t* d_key = nullptr, const int2* d_zw = nullptr, unsigned* s_fresh = nullptr) {
-      // s_fresh (optional, LDS, one bit per deferred record, zeroed by the caller; needs d_key): rows of freshly taken slots are NOT
+      // s_fresh (optional, LDS, one bit per deferred record, zeroed by the caller): rows of freshly taken slots are NOT
       // initialised by the 8 lanes that evicted for them (16 Philox draws each in a row: 12.5 K of the 27.8 K cycles one eviction
       // took, profiles/r05_eviction_stamps.txt) but by the whole block behind the pass, one element per thread
       // d_key / d_zw (optional, LDS): key and (slot code, count) of every deferred record, left by the thread that held the
@@ -1778,7 +1778,14 @@ __device__ __forceinline__ void part_evict(FusedArgs& a, int nd, int64_t rec_bas
           if (!((s_fresh[e >> 5] >> (e & 31)) & 1u)) continue;
           const int gslot = h_slot[d_ent[e]];
           void* rp = reinterpret_cast<void*>((uintptr_t)(tp0 + ((int64_t)gslot - s0) * rowb));
-          const float v = el < ed ? init_value(a.init, d_key[e], (uint32_t)el) : a.init.state_init;
+          uint64_t key;
+          if (d_key) key = d_key[e];
+          else {                       // (callers without the LDS copy: through the record)
+            int64_t kp = (int64_t)a.rec[rec_base + (int)d_rec[e]].x;
+            kp = kp < a.n ? kp : a.n - 1;
+            key = a.keys[kp];
+          }
+          const float v = el < ed ? init_value(a.init, key, (uint32_t)el) : a.init.state_init;
           if (a.value_dtype == kF32) st1<kF32>(rp, el, v);
           else if (a.value_dtype == kBF16) st1<kBF16>(rp, el, v);
           else st1<kF16>(rp, el, v);

@@ -38,6 +38,7 @@ __device__ __forceinline__ void part3_lean(FusedArgs& a, const EmitOut& o, int* 
   __shared__ int s_lock[256];
   __shared__ unsigned s_late[HASH / 32];
   __shared__ int s_nd, s_nbig;
+  __shared__ unsigned s_fresh[kDefMax / 32];          // deferred records that took a fresh slot (row initialised by the block, part_evict)
   constexpr int kBigMax = 256;
   __shared__ int b_pos[kBigMax], b_ref[kBigMax], b_cnt[kBigMax];
   const int tid = (int)threadIdx.x;
@@ -50,6 +51,7 @@ __device__ __forceinline__ void part3_lean(FusedArgs& a, const EmitOut& o, int* 
   if (tid < 256) s_lock[tid] = 0;
   if (tid < HASH / 32) s_late[tid] = 0;
   if (tid == 0) { s_nd = 0; s_nbig = 0; }
+  if (tid < kDefMax / 32) s_fresh[tid] = 0;
   __syncthreads();
   QST(1);
   int c1, c2, c3, total;
@@ -109,7 +111,7 @@ __device__ __forceinline__ void part3_lean(FusedArgs& a, const EmitOut& o, int* 
   QST(3);
   const int nd = s_nd < kDefMax ? s_nd : kDefMax;
   if (nd > 0) {      // (block uniform)
-    part_evict<HASH, int, T>(a, nd, rec_base, d_rec, d_ent, d_base, s_lock, s_late, h_slot, h_cnt, tbl, tp0, rowb, s0);
+    part_evict<HASH, int, T>(a, nd, rec_base, d_rec, d_ent, d_base, s_lock, s_late, h_slot, h_cnt, tbl, tp0, rowb, s0, nullptr, nullptr, s_fresh);
     __syncthreads();
     for (int e = tid; e < nd; e += T) {
       // the first record (rank base 0) of an entry created by the eviction owns the unique row's key
