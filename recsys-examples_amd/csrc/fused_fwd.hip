@@ -198,11 +198,12 @@ __device__ __forceinline__ int thread_probe(const FusedArgs& a, int64_t b, uint6
       while (me) {
         const int bit = __ffs(me) - 1;
         me &= me - 1;
-        const uint64_t k = fresh ? ald64(ks + p0 + bit) : ks[p0 + bit];
-        if (k == kEmptyKey) {
-          if (!kInsert) return -1;
-          uint64_t e = kEmptyKey;
-          if (cas64(ks + p0 + bit, e, kLockedKey)) {
+        uint64_t k;
+        if constexpr (kInsert) {
+          // (round 5) the compare-and-swap IS the look at the slot: it takes an Empty word, and says what is there otherwise -- one
+          // dependent round trip instead of load-then-CAS on the path every new key of a step goes down
+          k = kEmptyKey;
+          if (cas64(ks + p0 + bit, k, kLockedKey)) {
             store_digest(dg + p0 + bit, (uint8_t)d);
             score_new(a, t.scores(b) + (int64_t)(p0 + bit) * t.ns, cnt);
             atomicAdd(&a.bucket_sizes[b], 1);
@@ -211,8 +212,9 @@ __device__ __forceinline__ int thread_probe(const FusedArgs& a, int64_t b, uint6
             inserted = true;
             return p0 + bit;
           }
-          again = true;                    // lost the slot: look at this vector again
-          break;
+        } else {
+          k = fresh ? ald64(ks + p0 + bit) : ks[p0 + bit];
+          if (k == kEmptyKey) return -1;
         }
         if (k == key) return p0 + bit;     // published after the digest snapshot was taken
         if (kInsert && k == kLockedKey) { again = true; break; }

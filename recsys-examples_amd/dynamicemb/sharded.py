@@ -329,10 +329,15 @@ class OverlappedSteps:
         # ... but only when that does not make the host WAIT for the counts (the exchange stream may be behind): asked again
         # behind the backward's launches, and at the latest the next forward finishes it (PendingKeys.wait) -- a host that
         # blocked here cost more than the late key exchange does (0.190 vs 0.179 ms per forced-W=1 step)
-        done = self._pending is None or self._pending.try_finish()
+        # (the c10d sequence -- CPU tensors, MI355_NATIVE_EXCHANGE=0 -- has no such query: its host read stays behind the backward)
+        pend = self._pending
+        early = pend is not None and pend._native is not None and pend.try_finish()
         self.lookup.backward(ctx, grads)
-        if not done:
-            self._pending.try_finish()
+        if pend is not None and not early:
+            if pend._native is not None:
+                pend.try_finish()
+            else:
+                pend.finish()
 
 
 class RowWiseShardedPooledRows:
