@@ -902,252 +902,8 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
 typedef __attribute__((address_space(3))) void* lds_void_t;
 typedef __attribute__((address_space(1))) const void* glb_void_t;
 
-template <int D, bool kWin>
-__global__ void __launch_bounds__(256) hstu_fwd_dma_kernel(AttnArgs a) {
-  static_assert(D == 256 || D == 128, "rows of 16 or 32 chunks");
-  constexpr int CPR = D / 8;            // 16-byte chunks per row
-  constexpr int RPI = 64 / CPR;         // rows per DMA wave-instruction (1 KB)
-  constexpr int ROWB = D;               // row stride in LDS (elements): unpadded
-  constexpr int TENS = kBN * ROWB;      // elements of one K (or V) tile
-  constexpr int IPW = (kBN / RPI) / 4;  // DMA instructions per wave and tensor
-  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [2 buffers][K tile | V tile]
-
-  const BlockSeq bs = seq_head_of_block(a);
-  const int b = bs.b, h = bs.h;
-  SeqInfo s;
-  s.start = bs.start;
-  const int Lq = bs.end - s.start;
-  const int kstart = a.cu_seqlens_k ? a.cu_seqlens_k[b] : s.start;
-  s.L = a.cu_seqlens_k ? a.cu_seqlens_k[b + 1] - kstart : Lq;
-  const int dq = s.L - Lq;
-  const int nblk = (Lq + kBM - 1) / kBM;
-  if (bs.z >= nblk || dq < 0) return;
-  const int m0 = row_block_of_rank(bs.z, nblk, a, b) * kBM;
-  s.has_ctx = a.num_contexts != nullptr;
-  s.has_tgt = a.num_targets != nullptr;
-  s.c = s.has_ctx ? a.num_contexts[b] : 0;
-  s.hlen = s.L - (s.has_tgt ? a.num_targets[b] : 0);
-  s.wl = kWin ? a.wl : -1; s.wr = kWin ? a.wr : -1;
-
-  const int lane = lane_id(), wv = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
-  const int qrow0 = m0 + 32 * wv, qloc = qrow0 + l31, qi = dq + qloc;
-  const bool wave_live = qrow0 < Lq;
-  int last_row = dq + (m0 + kBM - 1 < Lq - 1 ? m0 + kBM - 1 : Lq - 1);
-  int n_end = s.L;
-  if (a.causal) {
-    n_end = last_row + 1;
-    if (s.has_ctx && dq + m0 < s.c && s.hlen > n_end) n_end = s.hlen;
-  }
-  if (kWin) n_end = band_key_end(a, last_row, n_end);
-  const int n_beg = kWin ? band_key_begin(a, dq + m0, kBN) : 0;
-  int w_last = dq + (qrow0 + 31 < Lq - 1 ? qrow0 + 31 : Lq - 1);
-  int w_end = s.L;
-  if (a.causal) {
-    w_end = w_last + 1;
-    if (s.has_ctx && dq + qrow0 < s.c && s.hlen > w_end) w_end = s.hlen;
-  }
-  if (kWin) w_end = band_key_end(a, w_last, w_end);
-  const int w_beg = kWin ? band_key_begin(a, dq + qrow0, kBN) : 0;
-
-  // ---- Q fragments in registers (as hstu_fwd_kernel)
-  bf16x8_t qf[D / 16];
-  {
-    const uint16_t* qp = a.q + (int64_t)(s.start + (qloc < Lq ? qloc : 0)) * a.q_row + (int64_t)h * a.q_head + 8 * hi;
-#pragma unroll
-    for (int sl = 0; sl < D / 16; ++sl) {
-      uint4 t = make_uint4(0, 0, 0, 0);
-      if (qloc < Lq) t = *reinterpret_cast<const uint4*>(qp + 16 * sl);
-      qf[sl] = *reinterpret_cast<bf16x8_t*>(&t);
-    }
-  }
-  f32x16_t acc_o[D / 32];
-#pragma unroll
-  for (int dt = 0; dt < D / 32; ++dt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc_o[dt][r] = 0.f;
-  const float nal2e = -a.alpha * 1.44269504088896f, ais = a.alpha * a.inv_scale;
-  const RowMask rm = row_mask(qi < s.L ? qi : s.L - 1, s, a.causal, a.group);
-
-  // ---- the DMA of one tile: wave w moves rows [16 w, 16 w + 16) of K and of V, RPI rows per instruction.  Lane -> (row
-  // inside the instruction, LDS chunk slot p); the lane fetches global chunk p ^ swizzle(row).  Rows past the sequence end
-  // are read clamped to its last row (their P is masked to zero).
-  const uint16_t* kg = a.k + (int64_t)kstart * a.k_row + (int64_t)h * a.k_head;
-  const uint16_t* vg = a.v + (int64_t)kstart * a.v_row + (int64_t)h * a.v_head;
-  const int dma_r = lane / CPR, dma_p = lane % CPR;
-  auto issue_dma = [&](int n0, int buf) {
-    uint16_t* kd = smem + buf * 2 * TENS;
-    uint16_t* vd = kd + TENS;
-#pragma unroll
-    for (int j = 0; j < IPW; ++j) {
-      const int r = (kBN / 4) * wv + RPI * j + dma_r;           // row of the tile
-      const int row = n0 + r < s.L ? n0 + r : s.L - 1;
-      const uint16_t* ksrc = kg + (int64_t)row * a.k_row + 8 * (dma_p ^ (r & 15));
-      const uint16_t* vsrc = vg + (int64_t)row * a.v_row + 8 * (dma_p ^ ((r & 3) << 2));
-      const int base = ((kBN / 4) * wv + RPI * j) * ROWB;       // wave-uniform LDS offset (elements) of the instruction's 1 KB
-      __builtin_amdgcn_global_load_lds((glb_void_t)ksrc, (lds_void_t)(kd + base), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void_t)vsrc, (lds_void_t)(vd + base), 16, 0, 0);
-    }
-  };
-
-  // ---- fragment addresses under the swizzles
-  // K (B... A operand of GEMM 1): lane (row 32 t + l31, k half hi) reads chunk (2 sl + hi) ^ (l31 & 15) of its row
-  const int kx = l31 & 15;
-  // V^T (A operand of GEMM 2) through two transpose reads: within a 16-lane group lane i points at the 8-byte half
-  // (i & 1) of chunk 4 dt + 2 g1 + ((i & 3) >> 1) of row 16 ks + 4 hi + (i >> 2) (+ 8); chunk' = chunk ^ ((row & 3) << 2)
-  const int il = lane & 15, g1 = (lane >> 4) & 1, vq = il >> 2;
-  const int v_row_off = (4 * hi + vq) * ROWB + 4 * (il & 1);          // elements
-  const int v_chunk_lo = 2 * g1 + ((il & 3) >> 1);
-  auto v_frag = [&](const uint16_t* Vb, int dt, int ks) -> bf16x8_t {
-    typedef short v4s_t __attribute__((ext_vector_type(4)));
-    typedef short v8s_t __attribute__((ext_vector_type(8)));
-    typedef __attribute__((address_space(3))) v4s_t* lds_v4s_t;
-    const uint16_t* p0 = Vb + (16 * ks) * ROWB + v_row_off + 8 * ((4 * (dt ^ vq)) + v_chunk_lo);
-    const v4s_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(p0));
-    const v4s_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(p0 + 8 * ROWB));
-    const v8s_t r = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-    return __builtin_bit_cast(bf16x8_t, r);
-  };
-
-  if (n_end > n_beg) issue_dma(n_beg, 0);
-  int it = 0;
-#if HSTU_TIMING
-  unsigned tsum[7] = {0, 0, 0, 0, 0, 0, 0};   // wait for own DMA, barrier, DMA issue, -, GEMM 1, SiLU + GEMM 2, tiles
-  const unsigned t_start = tick();
-#endif
-  for (int n0 = n_beg; n0 < n_end; n0 += kBN, ++it) {
-    pin_agpr(acc_o);
-    TICK(t0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile n0 have landed ...
-    TICK(t1);
-    __syncthreads();                                    // ... everyone's have, and everyone is done reading the other buffer
-    TICK(t2);
-    if (n0 + kBN < n_end) issue_dma(n0 + kBN, (it + 1) & 1);
-    TICK(t3);
-    TACC(0, t0, t1); TACC(1, t1, t2); TACC(2, t2, t3);
-    const uint16_t* Ks = smem + (it & 1) * 2 * TENS;
-    const uint16_t* Vt = Ks + TENS;
-    pin_agpr(acc_o);
-    if (!wave_live || n0 >= w_end || n0 < w_beg) continue;
-    TICK(t5);
-
-    // ---- GEMM 1: S^T[64 keys x 32 q] = K Q^T (two 32-key tiles), fragment batches double-buffered
-    f32x16_t acc_s[2];
-    {
-      constexpr int SLB = 4, NBAT = (D / 16) / SLB;
-      bf16x8_t kfr[2][SLB][2];
-      auto load_b = [&](int bi, int buf) {
-#pragma unroll
-        for (int u = 0; u < SLB; ++u) {
-          const int sl = SLB * bi + u;
-          const int ch = ((2 * sl) ^ (kx & 14)) + (hi ^ (kx & 1));
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-            kfr[buf][u][t] = *reinterpret_cast<const bf16x8_t*>(Ks + (32 * t + l31) * ROWB + 8 * ch);
-        }
-      };
-      load_b(0, 0);
-#pragma unroll
-      for (int bi = 0; bi < NBAT; ++bi) {
-        if (bi + 1 < NBAT) load_b(bi + 1, (bi + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < SLB; ++u)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            if (bi == 0 && u == 0) mfma_v0(acc_s[t], kfr[bi & 1][u][t], qf[SLB * bi + u]);
-            else mfma_v(acc_s[t], kfr[bi & 1][u][t], qf[SLB * bi + u]);
-          }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    fence_v(acc_s);
-    pin_agpr(acc_o);
-    TICK(t6);
-    TACC(4, t5, t6);
-    const bool full = a.causal && s.wl < 0 && (n0 + kBN - 1 <= dq + qrow0) && (!s.has_ctx || dq + qrow0 >= s.c) && (!s.has_tgt || n0 + kBN - 1 < s.hlen);
-    // ---- GEMM 2: O^T[D x 32 q] += V^T[D x 64 keys] P^T, pipelined with the SiLU of the next 16-key slice
-    constexpr int NDT = D / 32;
-    constexpr int DB = NDT < 8 ? NDT : 8;
-    auto gemm2 = [&](auto fullc) {
-      constexpr bool kFull = decltype(fullc)::value;
-      auto ew = [&](int ks) -> bf16x8_t {
-        const int t = ks >> 1, r0 = (ks & 1) * 8;
-        uint32_t pk[4];
-#pragma unroll
-        for (int r = 0; r < 8; r += 2) {
-          float p2[2];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int rr = r0 + r + u;
-            const float pv = silu_scaled(acc_s[t][rr], nal2e, ais);
-            if (kFull) p2[u] = pv;
-            else {
-              const int key = n0 + 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
-              p2[u] = key_ok(key, rm) ? pv : 0.f;
-            }
-          }
-          pk[r >> 1] = pack_bf16(p2[0], p2[1]);
-        }
-        const u32x4_t x = {pk[0], pk[1], pk[2], pk[3]};
-        return __builtin_bit_cast(bf16x8_t, x);
-      };
-      constexpr int NBAT2 = 4 * (NDT / DB);
-      bf16x8_t vfr[2][DB];
-      auto load_v = [&](int bi, int buf) {
-        const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
-#pragma unroll
-        for (int u = 0; u < DB; ++u) vfr[buf][u] = v_frag(Vt, dt0 + u, ks);
-      };
-      load_v(0, 0);
-      bf16x8_t pf[4];
-      pf[0] = ew(0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int bi = 0; bi < NBAT2; ++bi) {
-        const int ks = bi / (NDT / DB), dt0 = (bi % (NDT / DB)) * DB;
-        const bool last_of_ks = (bi % (NDT / DB)) == (NDT / DB) - 1;
-        if (bi + 1 < NBAT2) load_v(bi + 1, (bi + 1) & 1);
-        if (last_of_ks && ks + 1 < 4) pf[ks + 1] = ew(ks + 1);
-#pragma unroll
-        for (int u = 0; u < DB; ++u) mfma_a(acc_o[dt0 + u], vfr[bi & 1][u], pf[ks]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    pin_agpr(acc_o);
-    if (full) gemm2(std::true_type{}); else gemm2(std::false_type{});
-    TICK(t7);
-    TACC(5, t6, t7);
-#if HSTU_TIMING
-    tsum[6] += 1;
-#endif
-  }
-  fence_a(acc_o);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no DMA may be in flight into LDS when the block retires)
-#if HSTU_TIMING
-  {
-    const unsigned t_end = tick();
-    if (lane == 0) {
-      const int blk = ((int)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-      unsigned long long* d = g_hstu_dbg + ((size_t)(blk * 4 + wv) % 65536) * 8;
-      for (int i = 0; i < 7; ++i) d[i] = tsum[i];
-      d[7] = t_end - t_start;
-    }
-  }
-#endif
-
-  if (qloc < Lq) {
-    uint16_t* op = a.out + (int64_t)(s.start + qloc) * a.o_row + (int64_t)h * a.o_head;
-#pragma unroll
-    for (int dt = 0; dt < D / 32; ++dt)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        uint2 o;
-        o.x = pack_bf16(acc_o[dt][4 * g4 + 0], acc_o[dt][4 * g4 + 1]);
-        o.y = pack_bf16(acc_o[dt][4 * g4 + 2], acc_o[dt][4 * g4 + 3]);
-        *reinterpret_cast<uint2*>(op + 32 * dt + 8 * g4 + 4 * hi) = o;
-      }
-  }
-}
+// (hstu_fwd_dma_kernel, the one-kind forward with these images -- round 3's default at head dim 256 -- was removed in round 5: the
+//  two-waves-per-SIMD kernels below win on every shape, profiles/r04_hstu_fwd_variants_a.txt; the images and swizzles live on in them)
 
 // ---------------------------------------------------------------------------------------------------
 // Forward with TWO waves per SIMD (round 4; head dim 256, contiguous keys, no bias): an 8-wave workgroup whose waves are
@@ -1163,7 +919,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_dma_kernel(AttnArgs a) {
 // the other, and neither wave needs more than ~200 registers (the one-stream kernel: 222 + 160).  The O wave runs ONE tile
 // behind its S wave: iteration i = { S wave: tile i -> P[i & 1] | O wave: P[(i - 1) & 1], V tile i - 1 }, one barrier per
 // iteration.  LDS = K ring 2 x 32 KB + V ring 2 x 32 KB + P ring 2 x 4 x 4 KB = 160 KB, all of it.
-// The K / V images and swizzles are those of hstu_fwd_dma_kernel.
+// The K / V images and swizzles are the ones described above.
 // ---------------------------------------------------------------------------------------------------
 #ifndef HSTU_PC_SDMA
 #define HSTU_PC_SDMA 0   // LDS-DMA instructions per tile and tensor issued by each S wave (of 32; the O waves issue the rest)
@@ -1259,7 +1015,7 @@ __global__ void __launch_bounds__(512) hstu_fwd_pc_kernel(AttnArgs a) {
     vvoff[u] = (uint32_t)dma_r * (uint32_t)a.v_row * 2u + 16u * (uint32_t)(dma_p ^ ((r & 3) << 2));
   }
   // The DMA instruction is issued from inline asm: hipcc models the builtin as an LDS store in flight and puts a
-  // vmcnt(0) in front of the next transpose read of ANY LDS address (seen in hstu_fwd_dma_kernel's GEMM 2: the prefetch
+  // vmcnt(0) in front of the next transpose read of ANY LDS address (seen in the removed one-kind DMA forward's GEMM 2: the prefetch
   // it was meant to overlap is drained first).  Here the completion is counted by hand: vmcnt(0) + barrier at the loop head.
   bool dma_on = true;
   auto dma16 = [&](const char* sbase, uint32_t voff, uint32_t lds_byte) {
@@ -1300,7 +1056,7 @@ __global__ void __launch_bounds__(512) hstu_fwd_pc_kernel(AttnArgs a) {
   if (T > 0) issue_dma(kg, a.k_row, kvoff, Kring, 0, 0, NMY);
   if (HSTU_PC_PRIO != 0 && role == (HSTU_PC_PRIO == 1 ? 1 : 0)) __builtin_amdgcn_s_setprio(1);
 
-  // fragment addresses under the swizzles (as hstu_fwd_dma_kernel)
+  // fragment addresses under the swizzles described above
   const int kx = l31 & 15;
   const int il = lane & 15, g1 = (lane >> 4) & 1, vq = il >> 2;
   const int v_row_off = (4 * hi + vq) * ROWB + 4 * (il & 1);
@@ -4218,26 +3974,7 @@ static int launch_bwd(BwdAttnArgs g, int B, int max_seqlen, hipStream_t stream) 
   return MI355_OK;
 }
 
-// the LDS-DMA staged forward (default; MI355_HSTU_DMA=0 = register-staged): head dim 256, contiguous keys, no bias
-template <int D>
-static int launch_fwd_dma(const AttnArgs& a, int B, int max_seqlen, hipStream_t stream) {
-  const size_t smem = (size_t)2 * 2 * kBN * D * sizeof(uint16_t);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_dma_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)smem) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_dma_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)smem) != hipSuccess) return MI355_ELAUNCH;
-    attr_set = true;
-  }
-  dim3 grid(a.H, B, (max_seqlen + kBM - 1) / kBM);
-  if (a.wl >= 0 || a.wr >= 0) hipLaunchKernelGGL((hstu_fwd_dma_kernel<D, true>), grid, dim3(256), smem, stream, a);
-  else hipLaunchKernelGGL((hstu_fwd_dma_kernel<D, false>), grid, dim3(256), smem, stream, a);
-  MI355_LAUNCH_CHECK();
-  return MI355_OK;
-}
-
-// the two-waves-per-SIMD forward (default at head dim 256; MI355_HSTU_PC=0 = the one-stream LDS-DMA kernel)
+// the two-waves-per-SIMD forward (default at head dim 256; MI355_HSTU_PC=0 = the one-kind register-staged kernel)
 template <int D>
 static int launch_fwd_pc(const AttnArgs& a, int B, int max_seqlen, hipStream_t stream, bool dense_batch) {
   const size_t smem = (size_t)(4 * kBN * D + 2 * 4 * 4 * 64 * 8) * sizeof(uint16_t);   // K ring + V ring + P ring = 160 KB
@@ -4427,13 +4164,11 @@ int HSTU_FN(mi355_hstu_attn_fwd_kv)(const void* q, const void* k, const void* v,
   a.alpha = alpha; a.inv_scale = 1.0f / scaling_seqlen;
   a.cu_seqlens_k = cu_seqlens_k; a.kv_cache = (const uint16_t*)kv_cache; a.page_offsets = page_offsets; a.page_ids = page_ids;
   a.last_page_lens = last_page_lens; a.page_size = (int)page_size;
-  static const int use_dma = getenv("MI355_HSTU_DMA") ? atoi(getenv("MI355_HSTU_DMA")) : 1;   // default since round 3: +4..9 % on every d = 256 shape measured
   static const int use_pc = getenv("MI355_HSTU_PC") ? atoi(getenv("MI355_HSTU_PC")) : 1;   // round 4: two waves per SIMD, S waves + O waves
   const int64_t fwd_tokens = tl_fwd_tokens;
   tl_fwd_tokens = 0;
   if (use_pc && head_dim == 256 && !a.kv_cache && !a.rab && !a.func)
     return launch_fwd_pc<256>(a, (int)batch, (int)max_seqlen_q, stream, !cu_seqlens_k && fwd_tokens == batch * max_seqlen_q);
-  if (use_dma && head_dim == 256 && !a.kv_cache && !a.rab && !a.func) return launch_fwd_dma<256>(a, (int)batch, (int)max_seqlen_q, stream);
   switch (head_dim) {
     case 32: return launch_fwd<32>(a, (int)batch, (int)max_seqlen_q, stream);
     case 64: return launch_fwd<64>(a, (int)batch, (int)max_seqlen_q, stream);

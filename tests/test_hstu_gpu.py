@@ -631,17 +631,16 @@ _FWD_VARIANTS = {
     "rows64_pairs": {"MI355_HSTU_Q2": "2", "MI355_HSTU_PAIR": "2"},      # ... with row blocks in pairs on every batch (default: dense ones)
     "rows32": {"MI355_HSTU_Q2": "0"},                                    # hstu_fwd_pc_kernel / hstu_fwd_pair_kernel at every length
     "rows32_pairs": {"MI355_HSTU_Q2": "0", "MI355_HSTU_PAIR": "2"},
-    "one_stream_dma": {"MI355_HSTU_PC": "0", "MI355_HSTU_DMA": "1"},     # hstu_fwd_dma_kernel (round 3)
-    "one_stream": {"MI355_HSTU_PC": "0", "MI355_HSTU_DMA": "0"},         # hstu_fwd_kernel, register-staged tiles
+    "one_stream": {"MI355_HSTU_PC": "0"},                               # hstu_fwd_kernel, register-staged tiles
 }
 
 
 @pytest.mark.parametrize("variant", list(_FWD_VARIANTS))
 def test_forward_kernel_variants(variant):
-    """The d = 256 forward has five kernels.  Default since round 4: 8-wave workgroups of S waves and O waves (two waves per
+    """The d = 256 forward has four kernels (the one-kind LDS-DMA kernel of round 3 won on no shape and was removed in round 5).  Default since round 4: 8-wave workgroups of S waves and O waves (two waves per
     SIMD) -- hstu_fwd_q2_kernel (64 query rows per wave: two MFMAs per LDS fragment) from 1 025 rows per sequence,
     hstu_fwd_pc_kernel / hstu_fwd_pair_kernel (32 rows per wave) below; row blocks in (heavy, light) pairs on dense batches.
-    MI355_HSTU_PC=0 falls back to the one-stream kernels (LDS-DMA staged, register staged).  The library reads the switches
+    MI355_HSTU_PC=0 falls back to the one-kind register-staged kernel.  The library reads the switches
     once, so every d = 256 test of this file (goldens, random jagged batches, contexts / targets, local windows, delta-q) is
     re-run in a child process with each kernel forced onto every shape."""
     import subprocess

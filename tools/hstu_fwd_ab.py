@@ -1,5 +1,5 @@
 """Forward-only A/B of the d = 256 attention kernels over a few shapes, one process per library / environment variant
-(MI355_LIB, MI355_HSTU_PC, MI355_HSTU_DMA are read once per process).  Prints the time and a checksum of the output bits --
+(MI355_LIB, MI355_HSTU_PC are read once per process).  Prints the time and a checksum of the output bits --
 variants of one algorithm (same MFMA order, same roundings) must print the same checksum.
     python tools/hstu_fwd_ab.py [--shapes c3,d4096,d8x4096,jag1,jag2] [--reps N]"""
 import argparse, os, sys
@@ -31,7 +31,7 @@ def shape(name):
     raise SystemExit(name)
 
 
-tag = f"lib={os.path.basename(os.environ.get('MI355_LIB', 'default'))} PC={os.environ.get('MI355_HSTU_PC', '-')} DMA={os.environ.get('MI355_HSTU_DMA', '-')}"
+tag = f"lib={os.path.basename(os.environ.get('MI355_LIB', 'default'))} PC={os.environ.get('MI355_HSTU_PC', '-')}"
 for name in a.shapes.split(","):
     lengths = np.asarray(shape(name), np.int64)
     cu = torch.tensor(np.concatenate([[0], np.cumsum(lengths)]), dtype=torch.int32, device=dev)

@@ -1,4 +1,4 @@
-"""Per-phase cycle breakdown of the d = 256 attention kernels -- hstu_fwd_kernel, hstu_fwd_dma_kernel (--dma), the dK pass of
+"""Per-phase cycle breakdown of the d = 256 attention kernels -- hstu_fwd_kernel (the one-kind LDS-DMA forward of round 3 was removed in round 5), the dK pass of
 the backward (--bwd).  Needs a library whose hstu_attn.hip was compiled with -DHSTU_TIMING=1:
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DHSTU_TIMING=1 -c recsys-examples_amd/csrc/hstu_attn.hip -o /tmp/h.o
@@ -15,15 +15,11 @@ import mi355_native
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32); ap.add_argument("--seqlen", type=int, default=512)
 ap.add_argument("--heads", type=int, default=4); ap.add_argument("--dim", type=int, default=256)
-ap.add_argument("--dma", action="store_true", help="the LDS-DMA staged forward (sets MI355_HSTU_DMA=1)")
 ap.add_argument("--pc", action="store_true", help="the two-waves-per-SIMD forward (hstu_fwd_pc_kernel: S waves / O waves; the default forward)")
 ap.add_argument("--q2", action="store_true", help="the 64-rows-per-wave forward (hstu_fwd_q2_kernel, the default forward since round 4)")
 ap.add_argument("--bwdpc", action="store_true", help="the S-wave / K-wave dK pass of the backward (hstu_bwd_kv_pc_kernel)")
 ap.add_argument("--bwd", action="store_true", help="the dK pass of the backward (hstu_bwd_kv_kernel, exchange mode) instead of the forward")
 a = ap.parse_args()
-if a.dma:
-    os.environ["MI355_HSTU_DMA"] = "1"   # read by the library at its first forward
-    os.environ["MI355_HSTU_PC"] = "0"
 if a.q2:
     a.pc = True
     os.environ["MI355_HSTU_PC"] = "1"; os.environ["MI355_HSTU_Q2"] = "1"
@@ -84,7 +80,6 @@ if a.pc:
 d = buf[:n].astype(np.float64)
 tiles = d[:, 6]
 names = (["barrier1", "fetch (load + wait)", "commit x2 images", "barrier2", "gemm S + dP", "silu' + P/dS stores"] if a.bwd
-         else ["wait own DMA", "barrier", "DMA issue (next tile)", "-", "gemm1", "silu+gemm2"] if a.dma
          else ["barrier1", "commit", "barrier2", "fetch-issue", "gemm1", "silu+gemm2"])
 tot = d[:, 7]
 print(f"waves {n}  tiles/wave avg {tiles.mean():.2f}  wave lifetime avg {tot.mean():.0f} cyc  max {tot.max():.0f}")
