@@ -1604,8 +1604,13 @@ __device__ __forceinline__ void lookback_sum2_1024(const unsigned long long* ta,
 //      (the partition's LDS hash knows them all: every record of the bucket is in this block) and that nobody pinned
 //      (kernels.cuh:226-287, types.cuh:398-512); 8 lanes per key, a hashed LDS lock per bucket.  The slot goes back into the
 //      record: the gather finds the rows of the key's occurrences there.  Shared by the two partition kernels.
+#ifdef P3_EVICT_NOINLINE
+#define P3_EVICT_ATTR __attribute__((noinline))
+#else
+#define P3_EVICT_ATTR __forceinline__
+#endif
 template <int HASH, typename DRec, int THREADS = kP3Threads>
-__device__ __forceinline__ void part_evict(FusedArgs& a, int nd, int64_t rec_base, const DRec* d_rec, int* d_ent, int* d_base, int* s_lock,
+__device__ P3_EVICT_ATTR void part_evict(FusedArgs& a, int nd, int64_t rec_base, const DRec* d_rec, int* d_ent, int* d_base, int* s_lock,
                                            unsigned* s_late, int* h_slot, int* h_cnt, int tbl, int64_t tp0, int64_t rowb, int64_t s0,
                                            const uint64_t* d_key = nullptr, const int2* d_zw = nullptr, unsigned* s_fresh = nullptr) {
       // s_fresh (optional, LDS, one bit per deferred record, zeroed by the caller): rows of freshly taken slots are NOT
@@ -1640,18 +1645,17 @@ __device__ __forceinline__ void part_evict(FusedArgs& a, int nd, int64_t rec_bas
         int guard = 0;
         while (__ballot(!done)) {
           if (!done) {
-            // lock word of the bucket (hashed): bit 0 held, bit 1 "an eviction of this block has been through here".  Until then the
-            // bucket is as the probe kernel left it -- full, the key absent: every record of the bucket is in THIS block and nothing
-            // else writes the table inside a step -- and the re-probe (digest row, key words: two dependent round trips) is skipped
-            int got = 0, seen = 0;
-            if (g == 0) { const int old = atomicOr(&s_lock[bucket & 255], 1); got = (old & 1) == 0 ? 1 : 0; seen = (old >> 1) & 1; }
+            int got = 0;
+            if (g == 0) got = atomicCAS(&s_lock[bucket & 255], 0, 1) == 0 ? 1 : 0;
             got = group_bcast(got, 0);
-            seen = group_bcast(seen, 0);
             if (got) {
               EST(1);
               uint64_t* ks = a.t.keys(bucket);
-              int found_slot = -1, empty_slot = -1;
-              if (seen) group_probe(a.t, bucket, key, hash, true, true, found_slot, empty_slot);
+              int found_slot, empty_slot;
+              // (the re-probe stays even for the first eviction a bucket sees in this block: skipping it -- "the bucket is as the
+              //  probe kernel left it" -- measured nothing (36.4 us either way) and is wrong for a key the probe kernel gave up on
+              //  behind a stuck Locked word, which may be in the bucket by now)
+              group_probe(a.t, bucket, key, hash, true, true, found_slot, empty_slot);
               EST(2);
               int slot = -1;
               bool fresh_row = false;
@@ -1671,7 +1675,7 @@ __device__ __forceinline__ void part_evict(FusedArgs& a, int nd, int64_t rec_bas
                 // running minimum as it went -- score, then key, then pin counter, three dependent round trips, up to 16 times per
                 // lane: ~25 us for one key, and a partition kernel that evicts for a single key holds up every partition behind
                 // it in the look-back (table at 75 % load: 19.8 -> 48 us, profiles/r05_eviction_regime.txt).  Now the lane's 16
-                // scores are fetched eight at a time, the smallest (score, slot) is tested, and only a refused one (locked, pinned, in
+                // scores are fetched six at a time, the smallest (score, slot) is tested, and only a refused one (locked, pinned, in
                 // use by this batch: rare) sends the lane round again for the next smallest.
                 uint64_t best = ~0ull, bkey = 0;
                 int bslot = -1;
@@ -1682,15 +1686,15 @@ __device__ __forceinline__ void part_evict(FusedArgs& a, int nd, int64_t rec_bas
                 for (int tries = 0; tries < C; ++tries) {
                   uint64_t cs = ~0ull;
                   int cslot = -1;
-                  for (int s1 = 2 * g; s1 < C; s1 += 8 * G) {    // (two passes at the usual 128 slots per bucket, 8 loads in flight: 16 -- or these 8 issued in front of the probe -- spill)
-                    uint64_t v[8];
+                  for (int s1 = 2 * g; s1 < C; s1 += 6 * G) {    // (three passes at the usual 128 slots per bucket, 6 loads in flight: 8 leave 20 bytes
+                    uint64_t v[6];                                 //  of scratch in the kernel's steady path (+1.2 us), 16 -- or 8 in front of the probe -- more)
   #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < 6; ++u) {
                       const int s2 = s1 + (u >> 1) * 2 * G + (u & 1);
                       v[u] = s2 < C ? ald64(sc + (int64_t)s2 * a.t.ns + (a.t.ns - 1)) : ~0ull;
                     }
   #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < 6; ++u) {
                       const int s2 = s1 + (u >> 1) * 2 * G + (u & 1);
                       const bool above = v[u] > lo_s || (v[u] == lo_s && s2 > lo_slot);
                       if (s2 < C && above && (v[u] < cs || cslot < 0)) { cs = v[u]; cslot = s2; }   // (ascending slots: ties keep the lower one)
@@ -1753,7 +1757,7 @@ __device__ __forceinline__ void part_evict(FusedArgs& a, int nd, int64_t rec_bas
                 a.rec[r].z = (uint32_t)gslot;
                 a.rec[r].w = (uint32_t)(cnt | kRecLate);
                 __threadfence_block();
-                atomicExch(&s_lock[bucket & 255], 2);
+                atomicExch(&s_lock[bucket & 255], 0);
               }
               EST(7);
               done = true;
@@ -1882,9 +1886,6 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
     pc = pc < a.n ? pc : a.n - 1;
     ky[k] = a.keys[pc];
   }
-#pragma unroll
-  for (int k = 0; k < kP3Items; ++k)
-    if (dj[k] >= 0) { d_key[dj[k]] = ky[k]; d_zw[dj[k]] = make_int2((int)rc[k].z, (int)rc[k].w); }
   QST(3);
   __syncthreads();
   QST(4);
@@ -1898,7 +1899,19 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
   const int nd = s_nd < kDefMax ? s_nd : kDefMax;
 #endif
   if (nd > 0) {
-    part_evict<kP2Hash>(a, nd, (int64_t)p * kPartCap, d_rec, d_ent, d_base, s_lock, s_late, h_slot, h_cnt, tbl, tp0, rowb, s0, d_key, d_zw, s_fresh);
+    // (key and (slot code, count) of the deferred records go to LDS here, behind the barrier and only in a block that evicts: in
+    //  front of it the stores made every block wait for its key loads -- +1.2 us on the steady-state kernel)
+#pragma unroll
+    for (int k = 0; k < kP3Items; ++k)
+      if (dj[k] >= 0) { d_key[dj[k]] = ky[k]; d_zw[dj[k]] = make_int2((int)rc[k].z, (int)rc[k].w); }
+    __syncthreads();
+    part_evict<kP2Hash>(a, nd, (int64_t)p * kPartCap, d_rec, d_ent, d_base, s_lock, s_late, h_slot, h_cnt, tbl, tp0, rowb, s0, d_key, d_zw,
+#ifdef P3_NO_FRESH
+                        nullptr
+#else
+                        s_fresh
+#endif
+                        );
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kP3Items; ++k)

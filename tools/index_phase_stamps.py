@@ -97,7 +97,7 @@ PART2 = ["start -> record loads issued + LDS init", "wait: barrier", "merge (LDS
          "entry scan + publish sums", "look-back", "outputs per unique row", "outputs per record (CSR entries)", "-"]
 PART_L = ["init + barrier", "merge pass", "wait: barrier", "eviction check, entry sums, block scan, publish", "look-back",
           "unique-row outputs (+ keys)", "wait: barrier", "output pass (CSR entries)", "tail", "-"]
-EVICT = ["entry -> bucket lock taken", "re-probe (only behind an earlier eviction)", "score scan: the lane's minimum + its eligibility",
+EVICT = ["entry -> bucket lock taken", "re-probe of the bucket", "score scan: the lane's minimum + its eligibility",
          "group arg-min, lock / digest / score stores", "row initialisation issued", "(drain) + key published", "LDS hash insert, record, unlock",
          "rest of the pass (other keys)", "-"]
 if os.environ.get("MI355_FUSED_PART", "2") != "1":
