@@ -286,6 +286,18 @@ def kernel_roofline(module, batches, grad, batch, D, e=4, o=2):
     # HBM traffic of the dominant kernel per launch: PMC counters cannot be read from inside this process; the figure is
     # the one of the committed separate rocprofv3 --pmc passes over THIS command (tools/pmc_run.sh, C2 batch size only)
     traffic, src = None, None
+    if batch == 16 * 65536:      # the 16 x batch of tools/bench_extended.py: its own PMC passes (round 5)
+        for tag in ("r05",):
+            for suffix in ("", "_before"):
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic_16x{suffix}.json")))["kernels"]
+                    key = dom[0] if dom[0] in pmc else dom[0].replace("late", "pipe")
+                    traffic, src = pmc[key]["traffic_bytes"], f"profiles/{tag}_pmc_traffic_16x{suffix}.json"
+                    break
+                except Exception:
+                    continue
+            if traffic is not None:
+                break
     if batch == 65536:
         for tag in ("r05", "r04", "r03", "r02", "r01"):
             try:
