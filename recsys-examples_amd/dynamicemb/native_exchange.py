@@ -83,6 +83,10 @@ class NativeExchange:
 
         W = self.W
         FB = offsets.numel() - 1
+        if FB % F:
+            raise ValueError(f"{FB} bags do not divide into {F} features")
+        if values.element_size() != 8:
+            raise ValueError("the in-library exchange moves 8-byte keys")
         B = FB // F
         n = values.numel()
         nl = W * FB
