@@ -820,8 +820,17 @@ def main():
                            "value": keys_total / args.steps * sus_steps / sus, "unit": "lookups/s"}
 
     if sharded_path:
-        result["stages_ms"] = sharded_stage_times(sharded, batches[args.warmup:], grad, dist, device, world,
-                                                  result["sustained"]["ms_per_step"])
+        # which exchange moved the bytes of the timed steps: "native" = the library's own RCCL calls (csrc/exchange.hip: created,
+        # agreed on by all ranks and, at W > 1, checked once against the c10d sequence on the first batch), "c10d" = the
+        # torch.distributed call sequence (the fallback every failure of the former lands on)
+        lk = getattr(sharded.impl, "inner", sharded.impl)
+        result["exchange"] = lk.exchange
+        result["exchange_selfchecked"] = bool(getattr(lk, "exchange_selfchecked", False))
+        try:
+            result["stages_ms"] = sharded_stage_times(sharded, batches[args.warmup:], grad, dist, device, world,
+                                                      result["sustained"]["ms_per_step"])
+        except Exception as e:      # noqa: BLE001 -- a diagnostic must not cost the headline line
+            result["stages_ms"] = {"error": repr(e)}
 
     if rank == 0 and not sharded_path:
         # the same step through the module's internal entry points (_forward_impl / _backward_impl: no autograd function, no
@@ -863,7 +872,12 @@ def main():
         result["c2_table_filling"] = c2_filling_section(args, device)
 
     if not args.no_hstu:
-        h = hstu_section(args, device, world, dist if sharded_path else None)
+        try:
+            h = hstu_section(args, device, world, dist if sharded_path else None)
+        except Exception as e:      # noqa: BLE001
+            if world == 1:
+                raise
+            h = {"error": repr(e)}
         if rank == 0:
             result["hstu"] = h
         if rank == 0 and world == 1 and not args.no_extra:

@@ -269,6 +269,10 @@ int mi355_rw_load_rccl(const char* librccl_path);
 int mi355_rw_unique_id(void* out, int64_t bytes);
 int mi355_rw_create(const void* id_input_dist, const void* id_output_dist, int world_size, int rank, void** handle);
 int mi355_rw_destroy(void* handle);
+/* hang guard of the caller's one-time self-check: aborts both communicators (ncclCommAbort: a collective kernel waiting for a
+ * peer that never came returns) and frees the handle without a device synchronisation; the caller continues on the c10d
+ * sequence.  No reference counterpart (TorchRec relies on ProcessGroupNCCL's watchdog for the same purpose). */
+int mi355_rw_abort(void* handle);
 /* input dist, first half, on `stream` (behind what `producer_stream` holds): block_bucketize -> all-to-all of the lengths
  * [W][F*B] -> exclusive offsets of the received lengths -> per-peer key counts into pinned memory.  Arrays as
  * mi355_block_bucketize; recv_lengths [W*F*B], recv_offsets [W*F*B+1].  *ticket names the counts for the second half. */
@@ -287,6 +291,11 @@ int mi355_rw_input_keys(void* handle, int ticket, int64_t num_features, int64_t 
                         void* recv_keys, const int64_t* recv_lengths, const int64_t* recv_offsets, int64_t* fm_lengths,
                         int64_t* fm_offsets, void* fm_keys, hipStream_t stream, hipStream_t consumer_stream);
 int mi355_rw_wait_keys(void* handle, int ticket, hipStream_t consumer_stream);
+/* 1 when the key exchange of `ticket` has completed on the device, else 0 (an event query, never waits) */
+int mi355_rw_keys_ready(void* handle, int ticket);
+/* gives a ticket back whose second half will not run (at most 8 input dists may be in flight: a 9th mi355_rw_input_begin
+ * before the oldest mi355_rw_input_keys is refused) */
+int mi355_rw_input_cancel(void* handle, int ticket);
 /* pooled output dist: all-to-all of the W blocks of numel_per_block partial sums (wire_dtype) + their fp32 sum -> out */
 int mi355_rw_output_pooled(void* handle, const void* send, void* recv, int64_t numel_per_block, int wire_dtype, void* out,
                            int out_dtype, hipStream_t stream);

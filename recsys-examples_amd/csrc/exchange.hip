@@ -40,6 +40,7 @@ struct Rccl {
   int (*GetUniqueId)(NcclId*) = nullptr;
   int (*CommInitRank)(Comm*, int, NcclId, int) = nullptr;
   int (*CommDestroy)(Comm) = nullptr;
+  int (*CommAbort)(Comm) = nullptr;          // optional: the hang guard of the one-time self-check (mi355_rw_abort)
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   int (*Send)(const void*, size_t, int, int, Comm, hipStream_t) = nullptr;
@@ -56,8 +57,24 @@ struct RwExchange {
   int64_t* splits[kRing] = {};      // pinned host [2 W]: keys sent to / received from every peer
   hipEvent_t ev_counts[kRing] = {}, ev_keys[kRing] = {};
   hipEvent_t ev_fork = nullptr;
+  bool live[kRing] = {};            // ticket handed out by input_begin and not yet consumed by input_keys
   int next = 0;
 };
+
+void free_exchange(RwExchange* x, bool abort) {
+  if (!x) return;
+  if (x->comm_in) { if (abort && g_rccl.CommAbort) g_rccl.CommAbort(x->comm_in); else g_rccl.CommDestroy(x->comm_in); }
+  if (x->comm_out) { if (abort && g_rccl.CommAbort) g_rccl.CommAbort(x->comm_out); else g_rccl.CommDestroy(x->comm_out); }
+  x->comm_in = x->comm_out = nullptr;
+  for (int i = 0; i < kRing; ++i) {
+    if (x->splits[i]) (void)hipHostFree(x->splits[i]);
+    if (x->ev_counts[i]) (void)hipEventDestroy(x->ev_counts[i]);
+    if (x->ev_keys[i]) (void)hipEventDestroy(x->ev_keys[i]);
+    x->splits[i] = nullptr; x->ev_counts[i] = x->ev_keys[i] = nullptr;
+  }
+  if (x->ev_fork) (void)hipEventDestroy(x->ev_fork);
+  x->ev_fork = nullptr;
+}
 
 int nccl_fail(int rc, const char* what) {
   std::string m = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
@@ -115,10 +132,16 @@ int mi355_rw_load_rccl(const char* path) {
   MI355_CHECK_ARG(path != nullptr, "path of librccl.so required");
   void* so = dlopen(path, RTLD_NOW | RTLD_LOCAL);
   if (!so) { mi355_set_error(dlerror()); return MI355_EINVAL; }
+  // a partial bind leaves nothing behind: the handle is closed and every pointer reset before the error goes out
 #define RW_SYM(field, name)                                                                      \
   do {                                                                                           \
     *(void**)(&g_rccl.field) = dlsym(so, name);                                                  \
-    if (!g_rccl.field) { mi355_set_error("librccl.so: symbol " name " missing"); return MI355_EINVAL; } \
+    if (!g_rccl.field) {                                                                         \
+      g_rccl = Rccl();                                                                           \
+      dlclose(so);                                                                               \
+      mi355_set_error("librccl.so: symbol " name " missing");                                    \
+      return MI355_EINVAL;                                                                       \
+    }                                                                                            \
   } while (0)
   RW_SYM(GetUniqueId, "ncclGetUniqueId");
   RW_SYM(CommInitRank, "ncclCommInitRank");
@@ -130,6 +153,7 @@ int mi355_rw_load_rccl(const char* path) {
   RW_SYM(AllGather, "ncclAllGather");
   RW_SYM(GetErrorString, "ncclGetErrorString");
 #undef RW_SYM
+  *(void**)(&g_rccl.CommAbort) = dlsym(so, "ncclCommAbort");
   g_rccl.so = so;
   return 0;
 }
@@ -143,20 +167,27 @@ int mi355_rw_unique_id(void* out, int64_t bytes) {
 
 int mi355_rw_create(const void* id_in, const void* id_out, int world, int rank, void** handle) {
   MI355_CHECK_ARG(g_rccl.so, "mi355_rw_load_rccl first");
-  MI355_CHECK_ARG(id_in && id_out && handle && world >= 1 && rank >= 0 && rank < world, "bad arguments");
+  MI355_CHECK_ARG(id_in && id_out && handle && world >= 1 && world <= 512 && rank >= 0 && rank < world, "bad arguments");
   RwExchange* x = new RwExchange();
   x->world = world; x->rank = rank;
   NcclId a, b;
   memcpy(&a, id_in, sizeof(a)); memcpy(&b, id_out, sizeof(b));
   int rc = g_rccl.CommInitRank(&x->comm_in, world, a, rank);
   if (rc == 0) rc = g_rccl.CommInitRank(&x->comm_out, world, b, rank);
-  if (rc != 0) { delete x; return nccl_fail(rc, "ncclCommInitRank"); }
-  for (int i = 0; i < kRing; ++i) {
-    RW_HIP(hipHostMalloc((void**)&x->splits[i], 2 * sizeof(int64_t) * world, hipHostMallocDefault));
-    RW_HIP(hipEventCreateWithFlags(&x->ev_counts[i], hipEventDisableTiming));
-    RW_HIP(hipEventCreateWithFlags(&x->ev_keys[i], hipEventDisableTiming));
+  if (rc != 0) { free_exchange(x, false); delete x; return nccl_fail(rc, "ncclCommInitRank"); }
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < kRing && e == hipSuccess; ++i) {
+    e = hipHostMalloc((void**)&x->splits[i], 2 * sizeof(int64_t) * world, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_counts[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_keys[i], hipEventDisableTiming);
   }
-  RW_HIP(hipEventCreateWithFlags(&x->ev_fork, hipEventDisableTiming));
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_fork, hipEventDisableTiming);
+  if (e != hipSuccess) {   // nothing of a half-built exchange survives (communicators included)
+    free_exchange(x, false);
+    delete x;
+    mi355_set_error(hipGetErrorString(e));
+    return MI355_ELAUNCH;
+  }
   *handle = x;
   return 0;
 }
@@ -165,14 +196,17 @@ int mi355_rw_destroy(void* handle) {
   RwExchange* x = (RwExchange*)handle;
   if (!x) return 0;
   (void)hipDeviceSynchronize();
-  if (x->comm_in) g_rccl.CommDestroy(x->comm_in);
-  if (x->comm_out) g_rccl.CommDestroy(x->comm_out);
-  for (int i = 0; i < kRing; ++i) {
-    if (x->splits[i]) (void)hipHostFree(x->splits[i]);
-    if (x->ev_counts[i]) (void)hipEventDestroy(x->ev_counts[i]);
-    if (x->ev_keys[i]) (void)hipEventDestroy(x->ev_keys[i]);
-  }
-  if (x->ev_fork) (void)hipEventDestroy(x->ev_fork);
+  free_exchange(x, false);
+  delete x;
+  return 0;
+}
+
+// the hang guard: both communicators are aborted (a collective kernel stuck on a peer that never came returns), the handle is
+// freed without a device synchronisation.  After this the caller uses the c10d sequence.
+int mi355_rw_abort(void* handle) {
+  RwExchange* x = (RwExchange*)handle;
+  if (!x) return 0;
+  free_exchange(x, true);
   delete x;
   return 0;
 }
@@ -185,6 +219,11 @@ int mi355_rw_input_begin(void* handle, int64_t num_features, int64_t batch_size,
   MI355_CHECK_ARG(x && ticket && num_features >= 1 && batch_size >= 0, "bad arguments");
   const int W = x->world;
   const int64_t FB = num_features * batch_size;
+  const int slot = x->next % kRing;
+  if (x->live[slot]) {     // kRing input dists in flight: the oldest ticket's pinned counts and events are still owed to its finish
+    mi355_set_error("mi355_rw_input_begin: every ticket of the ring is in flight (finish the oldest input dist first)");
+    return MI355_EINVAL;
+  }
   if (producer_stream != stream) {      // the batch was produced on the caller's compute stream
     RW_HIP(hipEventRecord(x->ev_fork, producer_stream));
     RW_HIP(hipStreamWaitEvent(stream, x->ev_fork, 0));
@@ -193,9 +232,10 @@ int mi355_rw_input_begin(void* handle, int64_t num_features, int64_t batch_size,
                               new_keys, nullptr, unbucketize_permute, stream));
   RW_RC(all_to_all_equal(x->comm_in, W, new_lengths, recv_lengths, FB * (int64_t)sizeof(int64_t), stream));
   RW_RC(mi355_exclusive_offsets(recv_lengths, W * FB, recv_offsets, stream));
-  const int slot = x->next++ % kRing;
   RW_RC(mi355_peer_splits(new_offsets, recv_offsets, FB, W, x->splits[slot], stream));
   RW_HIP(hipEventRecord(x->ev_counts[slot], stream));
+  x->live[slot] = true;
+  x->next++;
   *ticket = slot;
   return 0;
 }
@@ -243,7 +283,23 @@ int mi355_rw_input_keys(void* handle, int ticket, int64_t num_features, int64_t 
     RW_RC(mi355_permute_bags(W, num_features, batch_size, 8, r / 8, recv_offsets, fm_offsets, recv_keys, fm_keys, stream));
   }
   RW_HIP(hipEventRecord(x->ev_keys[ticket], stream));
+  x->live[ticket] = false;
   if (consumer_stream != stream) RW_HIP(hipStreamWaitEvent(consumer_stream, x->ev_keys[ticket], 0));
+  return 0;
+}
+
+// 1: the key exchange of `ticket` (mi355_rw_input_keys) has completed on the device, 0: not yet
+int mi355_rw_keys_ready(void* handle, int ticket) {
+  RwExchange* x = (RwExchange*)handle;
+  if (!x || ticket < 0 || ticket >= kRing) return 0;
+  return hipEventQuery(x->ev_keys[ticket]) == hipSuccess ? 1 : 0;
+}
+
+// drops a ticket whose second half will never run (the caller fell back to the c10d sequence)
+int mi355_rw_input_cancel(void* handle, int ticket) {
+  RwExchange* x = (RwExchange*)handle;
+  MI355_CHECK_ARG(x && ticket >= 0 && ticket < kRing, "bad arguments");
+  x->live[ticket] = false;
   return 0;
 }
 

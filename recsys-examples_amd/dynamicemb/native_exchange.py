@@ -11,8 +11,10 @@ planner/rw_sharding.py:85-158, 191-261 (the output dists).
 from __future__ import annotations
 
 import ctypes
+import logging
 import math
 import os
+import time
 from typing import Optional
 
 import torch
@@ -30,26 +32,113 @@ def native_exchange_wanted(pg, t: torch.Tensor) -> bool:
         return False
 
 
+_log = logging.getLogger("dynamicemb.native_exchange")
+
+
+def _rccl_candidates():
+    """the librccl.so this process already maps (torch.distributed's "nccl" backend IS RCCL), then the usual places"""
+    paths = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "librccl" in line:
+                    q = line.split()[-1]
+                    if q not in paths:
+                        paths.append(q)
+    except OSError:
+        pass
+    paths.append(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+    paths += ["librccl.so", "librccl.so.1"]
+    return paths
+
+
+def all_ranks_ok(pg, ok: bool, device) -> bool:
+    """ONE decision for all ranks: a rank that fell back alone would leave the others inside a collective"""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=pg)
+    return bool(flag.item())
+
+
+def bounded_wait(ready, seconds: Optional[float] = None) -> bool:
+    """polls `ready()` (an event query) for at most `seconds`: the hang guard of the self-check"""
+    if seconds is None:
+        seconds = float(os.environ.get("MI355_EXCHANGE_TIMEOUT_S", "30"))
+    end = time.monotonic() + seconds
+    while not ready():
+        if time.monotonic() > end:
+            return False
+        time.sleep(0.0005)
+    return True
+
+
 class NativeExchange:
     """Two RCCL communicators over the ranks of `pg` (input dist / output dist), created from unique ids that rank 0 draws and
-    the existing process group broadcasts."""
+    the existing process group broadcasts.
+
+    Construction never leaves a rank alone: every step that can fail on one rank only (binding librccl.so, drawing the ids,
+    ncclCommInitRank) ends in a MIN all-reduce of an ok flag over `pg`; `create()` returns None on EVERY rank if any rank
+    failed, and the caller keeps the c10d call sequence (input_dist.py)."""
+
+    @classmethod
+    def create(cls, pg, device) -> Optional["NativeExchange"]:
+        x = cls.__new__(cls)
+        x._h = None
+        x.dead = False
+        why = None
+        try:
+            x._bind(pg)
+            raw = x._draw_ids()
+        except Exception as e:       # noqa: BLE001 -- whatever went wrong, the step continues on the c10d sequence
+            why, raw = e, None
+        if not all_ranks_ok(pg, why is None, device):
+            _log.warning("in-library RCCL exchange unavailable (%s): using the c10d sequence", why or "another rank failed")
+            return None
+        try:
+            x._init_comms(pg, device, raw)
+        except Exception as e:       # noqa: BLE001
+            why = e
+        if not all_ranks_ok(pg, why is None, device):
+            _log.warning("in-library RCCL exchange: communicator creation failed (%s): using the c10d sequence",
+                         why or "another rank failed")
+            x.abort()
+            return None
+        return x
 
     def __init__(self, pg, device):
-        from mi355_native import check, lib
+        """raises on failure (single-process use and tests); `create()` is the form that agrees across ranks"""
+        self._h = None
+        self.dead = False
+        self._bind(pg)
+        self._init_comms(pg, device, self._draw_ids())
+
+    def _bind(self, pg):
+        from mi355_native import NativeError, lib
 
         self.pg = pg
         self.W = dist.get_world_size(pg)
         self.rank = dist.get_rank(pg)
         self._lib = lib()
-        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        check(self._lib.mi355_rw_load_rccl(path.encode()), "rw_load_rccl")
-        ids = torch.zeros(256, dtype=torch.uint8)
+        errs = []
+        for path in _rccl_candidates():
+            if self._lib.mi355_rw_load_rccl(path.encode()) == 0:
+                return
+            msg = self._lib.mi355_last_error()
+            errs.append(f"{path}: {msg.decode() if msg else '?'}")
+        raise NativeError("librccl.so could not be bound: " + "; ".join(errs))
+
+    def _draw_ids(self):
+        from mi355_native import check
+
+        raw = (ctypes.c_uint8 * 256)()
         if self.rank == 0:
-            raw = (ctypes.c_uint8 * 256)()
             check(self._lib.mi355_rw_unique_id(ctypes.addressof(raw), 128), "rw_unique_id")
             check(self._lib.mi355_rw_unique_id(ctypes.addressof(raw) + 128, 128), "rw_unique_id")
-            ids = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone()
-        ids = ids.to(device)
+        return raw
+
+    def _init_comms(self, pg, device, raw):
+        from mi355_native import check
+
+        ids = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone().to(device)
         dist.broadcast(ids, src=dist.get_global_rank(pg, 0) if pg is not dist.group.WORLD else 0, group=pg)
         host = (ctypes.c_uint8 * 256).from_buffer_copy(bytes(ids.cpu().numpy().tobytes()))
         torch.cuda.synchronize(device)
@@ -64,9 +153,21 @@ class NativeExchange:
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
+        self.dead = True
         if h is not None:
             try:
                 self._lib.mi355_rw_destroy(h)
+            except Exception:
+                pass
+
+    def abort(self):
+        """the hang guard: ncclCommAbort on both communicators (a collective kernel waiting for a peer that never came
+        returns); the handle is gone afterwards"""
+        h, self._h = getattr(self, "_h", None), None
+        self.dead = True
+        if h is not None:
+            try:
+                self._lib.mi355_rw_abort(h)
             except Exception:
                 pass
 
@@ -123,11 +224,20 @@ class NativeExchange:
         n_send, n_recv = self._tot[0], self._tot[1]
         send_splits, recv_splits = list(self._ss), list(self._rs)
         recat = W > 1 and F > 1
-        rbuf = torch.empty(n_recv * 2 + 2 * nl + 1 if recat else n_recv, dtype=torch.int64, device=buf.device)
+        rnum = n_recv * 2 + 2 * nl + 1 if recat else n_recv
         st = stream()
         if side is not None:
-            rbuf.record_stream(side)
+            # allocated ON the exchange stream: a block of the caller's stream may have been freed by a tensor whose kernels
+            # are still queued there (nothing orders `side` behind them -- the fork event exists only in input_begin), and
+            # the key exchange would write into it early.  The consumer (the caller's stream, behind wait_keys) is recorded.
+            from mi355_native import current_torch_stream, on_stream
+
+            with on_stream(side):
+                rbuf = torch.empty(rnum, dtype=torch.int64, device=buf.device)
+            rbuf.record_stream(current_torch_stream())
             st = ctypes.c_void_p(side.cuda_stream)
+        else:
+            rbuf = torch.empty(rnum, dtype=torch.int64, device=buf.device)
         base, rbase = buf.data_ptr(), rbuf.data_ptr()
         check(self._lib.mi355_rw_input_keys(self._h, ticket, F, B, base + 8 * o_new_val, rbase, base + 8 * o_recv_len,
                                             base + 8 * o_recv_off,
@@ -148,7 +258,11 @@ class NativeExchange:
         perm = buf[o_perm:o_perm + n_send] if o_perm >= 0 else None
         sk = ShardedKeys(lengths, offs, vals, recv_offsets, send_splits, recv_splits, perm, B, F)
         sk._ticket = ticket if side is not None else None
+        sk._last_ticket = ticket
         return sk
+
+    def keys_ready(self, ticket: int) -> bool:
+        return bool(self._lib.mi355_rw_keys_ready(self._h, ticket))
 
     def wait_keys(self, ticket: int) -> None:
         from mi355_native import check, stream

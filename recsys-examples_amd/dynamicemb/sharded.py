@@ -134,20 +134,107 @@ class RowWiseShardedLookup:
         self.fixed_capacity = capacity_factor is not None
         self._nx = None               # the in-library exchange (GPU batches; created at the first one)
         self._nx_off = False
+        self.exchange_selfchecked = False
 
-    def _native_for(self, t: torch.Tensor):
-        """the library's own RCCL exchange (native_exchange.py) for GPU batches of the exact exchange; None: the c10d sequence"""
+    def _native_for(self, t: torch.Tensor, offsets: Optional[torch.Tensor] = None):
+        """the library's own RCCL exchange (native_exchange.py) for GPU batches of the exact exchange; None: the c10d sequence.
+        Never raises and never leaves a rank alone: creation agrees across ranks (NativeExchange.create), and at W > 1 the
+        first batch goes through BOTH exchanges once (`_selftest_native`) before the in-library one is trusted."""
         if self._nx is not None:
+            if self._nx.dead:
+                self._nx, self._nx_off = None, True
+                return None
             return self._nx if t.is_cuda else None
         if self._nx_off or self.fixed_capacity:
             return None
-        from .native_exchange import NativeExchange, native_exchange_wanted
+        from .native_exchange import NativeExchange, all_ranks_ok, native_exchange_wanted
 
         if not native_exchange_wanted(self.pg, t):
             self._nx_off = t.is_cuda      # (a CPU batch decides nothing: the gloo tests never get a communicator)
             return None
-        self._nx = NativeExchange(self.pg, t.device)
+        nx = NativeExchange.create(self.pg, t.device)
+        if nx is None:
+            self._nx_off = True
+            return None
+        if (self.world > 1 or os.environ.get("MI355_EXCHANGE_SELFCHECK", "") == "1") and offsets is not None:
+            why = None
+            try:
+                self._selftest_native(nx, t, offsets)
+            except Exception as e:      # noqa: BLE001 -- a wrong or hung exchange must not end the run: c10d takes over
+                why = e
+            if not all_ranks_ok(self.pg, why is None, t.device):
+                import logging
+
+                logging.getLogger("dynamicemb.native_exchange").warning(
+                    "in-library RCCL exchange failed its self-check (%s): using the c10d sequence", why or "another rank failed")
+                nx.abort()
+                self._nx_off = True
+                return None
+        self._nx = nx
+        self.exchange_selfchecked = self.world > 1 or os.environ.get("MI355_EXCHANGE_SELFCHECK", "") == "1"
         return self._nx
+
+    @property
+    def exchange(self) -> str:
+        """which exchange moves this lookup's GPU batches: "native" (csrc/exchange.hip) or "c10d" (torch.distributed calls)"""
+        return "native" if self._nx is not None and not self._nx.dead else "c10d"
+
+    def _selftest_native(self, nx, values, offsets) -> None:
+        """One-time check of the in-library exchange against the c10d sequence, every wait bounded (MI355_EXCHANGE_TIMEOUT_S):
+        the input dist of THIS batch through both (received keys / offsets / lengths / splits must be equal), then the three
+        output collectives on small rank-dependent blocks.  Raises on any difference or timeout."""
+        from .native_exchange import bounded_wait
+
+        def fence(what):
+            ev = torch.cuda.Event()
+            ev.record(current_torch_stream())
+            if not bounded_wait(ev.query):
+                raise TimeoutError(f"in-library exchange: {what} did not complete")
+
+        W, dev = self.world, values.device
+        # --- input dist of the real batch
+        state = self._native_begin(nx, values, offsets, None)
+        if not bounded_wait(lambda: nx.counts_ready(state)):
+            raise TimeoutError("in-library exchange: lengths all-to-all did not complete")
+        sk_n = nx.input_finish(state)
+        if not bounded_wait(lambda: nx.keys_ready(sk_n._last_ticket)):
+            raise TimeoutError("in-library exchange: key all-to-all did not complete")
+        sk_c = self.input_dist(None, values, False, offsets=offsets)
+        same = (sk_n.send_splits == sk_c.send_splits and sk_n.recv_splits == sk_c.recv_splits
+                and torch.equal(sk_n.values, sk_c.values) and torch.equal(sk_n.offsets, sk_c.offsets)
+                and torch.equal(sk_n.lengths, sk_c.lengths) and torch.equal(sk_n.recv_offsets, sk_c.recv_offsets)
+                and (sk_n.unbucketize_permute is None) == (sk_c.unbucketize_permute is None)
+                and (sk_c.unbucketize_permute is None or torch.equal(sk_n.unbucketize_permute, sk_c.unbucketize_permute)))
+        if not same:
+            raise RuntimeError("in-library input dist differs from the c10d sequence")
+        # --- output collectives on small blocks that differ per rank and per destination
+        g = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
+        Bt, Dt = 8, 16
+        for wire in (torch.float32, torch.bfloat16):
+            send = torch.randn(W * Bt, Dt, generator=g).to(dev).to(wire)
+            out_n = nx.output_pooled(send, torch.float32)
+            fence("partial-sum all-to-all")
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send, group=self.pg)
+            out_c = self.ops.sum_chunks(recv.view(W, Bt * Dt), torch.float32).view(Bt, Dt)
+            if not torch.equal(out_n, out_c):
+                raise RuntimeError("in-library pooled output dist differs from the c10d sequence")
+        blk = torch.randn(Bt, Dt, generator=g).to(dev)
+        ga_n = nx.allgather(blk)
+        fence("all-gather")
+        ga_c = torch.empty(W * Bt, Dt, dtype=blk.dtype, device=dev)
+        dist.all_gather_into_tensor(ga_c, blk, group=self.pg)
+        if not torch.equal(ga_n, ga_c):
+            raise RuntimeError("in-library all-gather differs from the c10d one")
+        sc = [1 + (self.rank + p) % 3 for p in range(W)]          # rows this rank sends to peer p
+        rc = [1 + (p + self.rank) % 3 for p in range(W)]          # ... and receives from peer p (the peer's sc[self.rank])
+        rows = torch.randn(sum(sc), Dt, generator=g).to(dev)
+        rv_n = nx.alltoallv_rows(rows, sc, rc)
+        fence("row all-to-all-v")
+        rv_c = torch.empty(sum(rc), Dt, dtype=rows.dtype, device=dev)
+        dist.all_to_all_single(rv_c, rows, rc, sc, group=self.pg)
+        if not torch.equal(rv_n, rv_c):
+            raise RuntimeError("in-library row all-to-all-v differs from the c10d one")
 
     def _native_begin(self, nx, values, offsets, side):
         d = self.input_dist
@@ -162,7 +249,7 @@ class RowWiseShardedLookup:
     def dist_input(self, values: torch.Tensor, offsets: torch.Tensor, collapse_batch: bool = False,
                    lengths: Optional[torch.Tensor] = None):
         # (the dist only needs the offsets; lengths are derived on the device where a caller has none)
-        nx = None if collapse_batch or offsets is None else self._native_for(values)
+        nx = None if collapse_batch or offsets is None else self._native_for(values, offsets)
         if nx is not None:
             return nx.input_finish(self._native_begin(nx, values, offsets, None))
         return self.input_dist(lengths, values, collapse_batch, offsets=offsets)
@@ -185,7 +272,7 @@ class RowWiseShardedLookup:
             # the host read of the step hangs on them -- queued behind the lookup's full-chip kernels they took 140 us and
             # arrived after the backward (profiles/r05_sharded_w1_timeline_before.txt)
             self._comm = torch.cuda.Stream(device=values.device, priority=-1)
-        nx = None if collapse_batch or offsets is None else self._native_for(values)
+        nx = None if collapse_batch or offsets is None else self._native_for(values, offsets)
         if nx is not None:
             # one C call: the exchange stream is ordered behind the caller's inside it.  The second half (the host read of the
             # key counts, the key exchange) follows in finish() -- at once, or (two_phase) when the caller has queued its work
@@ -330,7 +417,16 @@ class OverlappedSteps:
         # behind the backward's launches, and at the latest the next forward finishes it (PendingKeys.wait) -- a host that
         # blocked here cost more than the late key exchange does (0.190 vs 0.179 ms per forced-W=1 step)
         # (the c10d sequence -- CPU tensors, MI355_NATIVE_EXCHANGE=0 -- has no such query: its host read stays behind the backward)
+        # W > 1: the issue point must be the SAME on every rank.  The key exchange runs on the input communicator, the
+        # backward's all-gather on the output communicator; ranks that enqueue the two in different relative orders (an
+        # event query answers differently per rank) can deadlock when both streams drain through one hardware queue.  So
+        # with peers the second half always goes out HERE, before the backward, whatever the query says (the host may wait
+        # for the counts: they were launched before this batch's lookup); the opportunistic form is the one-rank path only.
         pend = self._pending
+        if pend is not None and pend._native is not None and self.lookup.world > 1:
+            pend.finish()
+            self.lookup.backward(ctx, grads)
+            return
         early = pend is not None and pend._native is not None and pend.try_finish()
         self.lookup.backward(ctx, grads)
         if pend is not None and not early:

@@ -146,6 +146,9 @@ _SIGS = {
     "mi355_rw_unique_id": [c_p, c_i64],
     "mi355_rw_create": [c_p, c_p, c_int, c_int, c_p],
     "mi355_rw_destroy": [c_p],
+    "mi355_rw_abort": [c_p],
+    "mi355_rw_keys_ready": [c_p, c_int],
+    "mi355_rw_input_cancel": [c_p, c_int],
     "mi355_rw_input_begin": [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "mi355_rw_input_counts": [c_p, c_int, c_p, c_p, c_p],
     "mi355_rw_input_counts_ready": [c_p, c_int],

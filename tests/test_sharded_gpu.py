@@ -410,3 +410,155 @@ def test_in_library_exchange_with_empty_batches_and_empty_bags(one_rank_group, p
         f1, r1 = ref.lookup_rows(probe, t)
         f2, r2 = loc.lookup_rows(probe, t)
         assert torch.equal(f1, f2) and torch.equal(r1, r2)
+
+
+def test_the_self_check_of_the_in_library_exchange_passes_and_a_wrong_exchange_falls_back(one_rank_group, monkeypatch):
+    """What a W > 1 job does on its first batch, forced here on one rank (MI355_EXCHANGE_SELFCHECK=1): the batch goes through
+    BOTH exchanges and the output collectives are compared on small blocks; then the same with a corrupted in-library
+    all-to-all-v: the lookup logs, aborts its communicators and serves every batch through the c10d sequence -- same results."""
+    from dynamicemb import native_exchange as ne
+    from dynamicemb.sharded import RowWiseShardedLookup, _ModuleLocal
+
+    F, B, dim = 2, 24, 16
+    rng = np.random.default_rng(5)
+    lens = rng.integers(0, 6, F * B)
+    off = np.zeros(F * B + 1, np.int64)
+    off[1:] = np.cumsum(lens)
+    keys = torch.from_numpy(rng.integers(0, 2000, off[-1]).astype(np.int64)).cuda()
+    offs = torch.from_numpy(off).cuda()
+    monkeypatch.setenv("MI355_EXCHANGE_SELFCHECK", "1")
+    monkeypatch.setenv("MI355_EXCHANGE_TIMEOUT_S", "20")
+    mods = [_module(True, F, dim, torch.float32) for _ in range(3)]
+    mk = lambda m: RowWiseShardedLookup(_ModuleLocal(m), F, [2000] * F, pooled=True, device=torch.device("cuda", 0),
+                                        out_dtype=torch.float32, dist_type_per_feature=["roundrobin"] * F)
+    good = mk(mods[0])
+    o_good, _ = good.forward(keys, offs, True)
+    assert good.exchange == "native" and good.exchange_selfchecked
+
+    real = ne.NativeExchange.alltoallv_rows
+
+    def broken(self, send, sc, rc):
+        out = real(self, send, sc, rc)
+        out[0, 0] += 1.0
+        return out
+
+    monkeypatch.setattr(ne.NativeExchange, "alltoallv_rows", broken)
+    bad = mk(mods[1])
+    o_bad, _ = bad.forward(keys, offs, True)
+    assert bad.exchange == "c10d" and bad._nx is None and bad._nx_off
+    assert torch.equal(o_good, o_bad)
+    o_again, _ = bad.forward(keys, offs, True)         # stays on the c10d sequence
+    assert torch.equal(o_good, o_again)
+
+    # a librccl.so that cannot be bound: creation fails on "every" rank, c10d from the first batch
+    monkeypatch.setattr(ne.NativeExchange, "alltoallv_rows", real)
+    monkeypatch.setattr(ne.NativeExchange, "_bind", lambda self, pg: (_ for _ in ()).throw(OSError("no librccl.so")))
+    none = mk(mods[2])
+    o_none, _ = none.forward(keys, offs, True)
+    assert none.exchange == "c10d" and torch.equal(o_good, o_none)
+
+
+def test_input_dists_in_flight_are_bounded_by_the_ticket_ring(one_rank_group):
+    """eight input dists may be in flight; a ninth begin before the oldest finish is refused instead of overwriting the pinned
+    counts and events of a live ticket"""
+    from mi355_native import NativeError
+    from dynamicemb.sharded import RowWiseShardedLookup, _ModuleLocal
+
+    F, B = 1, 16
+    m = _module(True, F, 16, torch.float32)
+    sh = RowWiseShardedLookup(_ModuleLocal(m), F, [500], pooled=True, device=torch.device("cuda", 0), out_dtype=torch.float32,
+                              dist_type_per_feature=["roundrobin"])
+    keys = torch.arange(0, 2 * B, dtype=torch.int64, device="cuda")
+    offs = torch.arange(0, 2 * B + 1, 2, dtype=torch.int64, device="cuda")
+    pend = [sh.dist_input_async(keys, offs, two_phase=True) for _ in range(8)]
+    with pytest.raises(NativeError, match="ticket"):
+        sh.dist_input_async(keys, offs, two_phase=True)
+    first = pend[0].wait()
+    assert torch.equal(first.values, keys)
+    pend.append(sh.dist_input_async(keys, offs, two_phase=True))      # a slot is free again
+    for p in pend[1:]:
+        assert torch.equal(p.wait().values, keys)
+
+
+def _two_rank_worker(rank, world, port, pooled, fail):
+    """one process per GPU: the in-library exchange against the c10d sequence at W = 2, forward and backward, overlapped
+    schedule; any assertion ends the rank with a traceback (spawn turns it into a failure of the test)"""
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
+        from dynamicemb.dynamicemb_config import (DynamicEmbInitializerArgs, DynamicEmbInitializerMode, DynamicEmbPoolingMode,
+                                                  DynamicEmbScoreStrategy, DynamicEmbTableOptions, EmbOptimType)
+        from dynamicemb.sharded import OverlappedSteps, RowWiseShardedLookup, _ModuleLocal
+
+        F, B, dim = 3, 40, 16
+
+        def module():
+            opts = [DynamicEmbTableOptions(dim=dim, max_capacity=4096, index_type=torch.int64, embedding_dtype=torch.float32,
+                                           score_strategy=DynamicEmbScoreStrategy.STEP,
+                                           initializer_args=DynamicEmbInitializerArgs(mode=DynamicEmbInitializerMode.DEBUG))
+                    for _ in range(F)]
+            m = BatchedDynamicEmbeddingTablesV2(opts, pooling_mode=DynamicEmbPoolingMode.SUM if pooled else DynamicEmbPoolingMode.NONE,
+                                                output_dtype=torch.float32, optimizer=EmbOptimType.SGD, learning_rate=0.25, device=dev)
+            m.train()
+            return m
+
+        mods = [module(), module()]
+        rng = np.random.default_rng(100 + rank)
+        batches = []
+        for _ in range(5):
+            lens = rng.integers(0, 7, F * B)
+            off = np.zeros(F * B + 1, np.int64)
+            off[1:] = np.cumsum(lens)
+            batches.append((torch.from_numpy(rng.integers(0, 3000, off[-1]).astype(np.int64)).to(dev), torch.from_numpy(off).to(dev)))
+        os.environ["MI355_NATIVE_EXCHANGE"] = "0"
+        plain = RowWiseShardedLookup(_ModuleLocal(mods[0]), F, [3000] * F, pooled=pooled, device=dev, out_dtype=torch.float32,
+                                     dist_type_per_feature=["roundrobin"] * F)
+        sk_p = plain.dist_input(*batches[0])
+        assert plain.exchange == "c10d"
+        os.environ["MI355_NATIVE_EXCHANGE"] = "1"
+        if fail:     # rank 1 cannot bind RCCL: BOTH ranks must land on the c10d sequence (nobody is left inside a collective)
+            from dynamicemb import native_exchange as ne
+
+            if rank == 1:
+                ne.NativeExchange._bind = lambda self, pg: (_ for _ in ()).throw(OSError("no librccl.so on this rank"))
+        nat = RowWiseShardedLookup(_ModuleLocal(mods[1]), F, [3000] * F, pooled=pooled, device=dev, out_dtype=torch.float32,
+                                   dist_type_per_feature=["roundrobin"] * F)
+        sk_n = nat.dist_input(*batches[0])
+        assert nat.exchange == ("c10d" if fail else "native"), nat.exchange
+        assert fail or nat.exchange_selfchecked
+        assert torch.equal(sk_n.values, sk_p.values) and torch.equal(sk_n.offsets, sk_p.offsets)
+        assert sk_n.send_splits == sk_p.send_splits and sk_n.recv_splits == sk_p.recv_splits
+        ov = OverlappedSteps(nat)
+        for i, (k, o) in enumerate(batches):
+            o_p, c_p = plain.forward(k, o, True)
+            o_n, c_n = ov.forward(k, o, True, batches[i + 1] if i + 1 < len(batches) else None)
+            assert torch.equal(o_p, o_n)
+            g = torch.randn_like(o_p)
+            plain.backward(c_p, g)
+            ov.backward(c_n, g)
+        probe = torch.arange(0, 3000, device=dev, dtype=torch.int64)
+        for t in range(F):
+            f1, r1 = mods[0].lookup_rows(probe, t)
+            f2, r2 = mods[1].lookup_rows(probe, t)
+            assert torch.equal(f1, f2) and torch.equal(r1, r2)
+        torch.cuda.synchronize()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail", [False, True])
+@pytest.mark.parametrize("pooled", [True, False])
+def test_two_ranks_in_library_exchange_matches_the_c10d_sequence(pooled, fail):
+    """The W = 2 run of `test_in_library_exchange_matches_the_c10d_sequence` -- one process per GPU over RCCL.  Skipped on a
+    one-GPU box (two ranks cannot share a device under RCCL); on any box with two GPUs it is part of `-m gpu`."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (one rank per device)")
+    import torch.multiprocessing as mp
+
+    mp.spawn(_two_rank_worker, args=(2, _free_port(), pooled, fail), nprocs=2, join=True)
