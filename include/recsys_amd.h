@@ -468,6 +468,32 @@ int mi355_demb_forward_fused(void* storage, const int64_t* table_bucket_offsets,
                              int64_t* slots, int64_t* row_addr, int64_t* freq, int32_t* csr_cnt, int32_t* csr_rank,
                              void* backward_workspace, int64_t backward_workspace_bytes, int use_side_stream,
                              int* join_token, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+/* Round 6: no step ever loses its update (the reference's unique op serves any key stream in one pass, src/unique_op.cu:484-714;
+ * DynamicEmbeddingFunction.backward updates every unique row of every step, batched_dynamicemb_function.py:1193-1300).  Path (c)
+ * gives every slot-range partition a fixed record list; a key stream that defeats the hash can flood one.  Such a step's FORWARD
+ * output is complete, its CSR is not.  A path-(c) training forward therefore returns *join_token = -(2 + epoch), epoch > 0: its
+ * partition kernel stores {epoch, flooded} into pinned host memory as its first action, and the caller asks
+ * mi355_demb_fused_step_flooded(epoch, wait_ms) before it uses the step's CSR or unique numbering: 0 = complete; 1 (or 2: the
+ * notice was overwritten 64 steps later, treated alike) = flooded: run mi355_demb_forward_fused_rerun (the arguments of the step's
+ * forward call + its epoch; `out` untouched), which regroups the step on the per-slot-counter path over the same buffers, then
+ * the backward as usual; -1 = the forward has not reached its partition kernel within wait_ms.  The steady state pays one host
+ * read of pinned memory per step and no launch.  *join_token == -2 (a forward captured into a hipGraph, pin != 0, or
+ * MI355_FUSED_OVERFLOW_RERUN=1): the re-run chain rode behind the gather in the same call, gated on the device; nothing to ask. */
+int mi355_demb_fused_step_flooded(int epoch, int wait_ms);
+int mi355_demb_forward_fused_rerun(void* storage, const int64_t* table_bucket_offsets, int64_t bucket_capacity,
+                                   int64_t num_scores, int32_t* bucket_sizes, int32_t* counter, int64_t counter_numel,
+                                   int32_t* aux, int64_t aux_numel, int64_t num_buckets, const int64_t* table_ptrs,
+                                   const int64_t* table_value_dims, const int64_t* table_emb_dims, int value_dtype,
+                                   int64_t emb_dim, int64_t value_dim, const void* keys, int64_t num_keys,
+                                   const int64_t* offsets, int64_t num_bags, int64_t batch_size,
+                                   const int64_t* feature_offsets, int64_t num_tables, int train, int find_policy,
+                                   int insert_policy, uint64_t score_value, int use_count, uint64_t timer_override, int pin,
+                                   int init_mode, float p0, float p1, float p2, float p3, uint64_t seed, float state_init,
+                                   int combiner, const int32_t* D_offsets, int64_t total_D, void* out, int out_dtype,
+                                   int aligned16, int64_t* reverse_indices, int64_t* unique_offsets, int64_t* table_ids,
+                                   int64_t* slots, int64_t* row_addr, int64_t* freq, int32_t* csr_cnt, int32_t* csr_rank,
+                                   void* backward_workspace, int64_t backward_workspace_bytes, int use_side_stream,
+                                   int epoch, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* Round 5: the pre-bound training step.  Replaces, for the steady-state training step, the per-call argument marshalling of
  * DynamicEmbeddingFunction.forward / backward (batched_dynamicemb_function.py:1042-1300), which re-reads the constructor state of
@@ -494,7 +520,12 @@ int mi355_demb_plan_forward(void* plan, const void* keys, int64_t num_keys, cons
 int mi355_demb_plan_backward(void* plan, void* step_buf, int64_t step_bytes, int64_t num_keys, const int64_t* offsets,
                              int64_t num_bags, int64_t batch_size, const void* grads, int64_t grad_stride, int grad_dtype,
                              int grad_aligned16, float lr, float beta1, float beta2, float eps, float weight_decay,
-                             int64_t iter_num, int prepared, hipStream_t stream);
+                             int64_t iter_num, int prepared, int epoch, hipStream_t stream);
+/* (epoch > 0: the step's overflow notice is read first; a flooded step returns 2 with nothing launched -- call
+ *  mi355_demb_plan_rerun(the batch of the step's plan_forward call, its epoch = -2 - *state) and then plan_backward with epoch 0) */
+int mi355_demb_plan_rerun(void* plan, const void* keys, int64_t num_keys, const int64_t* offsets, int64_t num_bags,
+                          int64_t batch_size, uint64_t score_value, uint64_t timer_override, void* step_buf,
+                          int64_t step_bytes, int epoch, hipStream_t stream);
 
 /* hipStream_t of the library's side stream (early CSR build of mi355_demb_forward); NULL if it cannot be created */
 void* mi355_early_csr_stream(void);

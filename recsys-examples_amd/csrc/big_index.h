@@ -93,6 +93,7 @@ fused_part3s_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restri
   const int p = blockIdx.x, tid = (int)threadIdx.x;
   const int cap = a.cap, subcap = a.cap / kPartSub;
   QST(0);
+  if (a.notice && p == 0 && tid == 0) publish_notice(a);
   const int64_t rec_base = (int64_t)p * cap;
   const int mv = a.pcount[p * kPartSub + (tid & (kPartSub - 1))];
   for (int i = tid; i < HASH; i += kP3Threads) { h_slot[i] = -1; h_cnt[i] = 0; }

@@ -37,6 +37,7 @@
 #include "stamps.h"
 #include "gather_dev.h"
 #include <pthread.h>
+#include <chrono>
 #include <stdlib.h>
 
 namespace mi355 {
@@ -121,6 +122,11 @@ struct FusedArgs {
   int gate_val;
   int ovf_word, ovf_val;          // where / what the partitioned probe writes when a record list overflows
   int* rerun_mark;                // nullable: cleared by block 0 of the partitioned probe, set by the re-run chain's last kernel
+  // round 6 (the default): the partition kernel's first block tells the HOST whether a record list of this step overflowed -- one
+  // 8-byte system-scope store {epoch, flooded} into pinned memory -- and the step's backward (or whoever reads its unique
+  // numbering first) re-runs the index stage on the per-slot-counter path before it uses the CSR (mi355_demb_fused_step_flooded,
+  // mi355_demb_forward_fused_rerun): no update is ever skipped and the steady state pays no launch for it
+  unsigned long long* notice;     // nullable: pinned, host-coherent
   int tl;                         // probe_c_kernel (round 5): keys of a tile, a run-time value (<= the kernel's capacity, multiple of 64)
   // big-batch stage (round 5, big_index.h): the probe kernel leaves its records TILE-MAJOR -- no reservation at all -- and a split
   // kernel moves them into the partitions' lists; a per-record forwarding entry keeps the per-occurrence references valid
@@ -1803,6 +1809,12 @@ __device__ P3_EVICT_ATTR void part_evict(FusedArgs& a, int nd, int64_t rec_base,
       EST(9);
 }
 
+// every block of the probe kernel has retired when a partition block starts: the overflow word of this step is final
+__device__ __forceinline__ void publish_notice(const FusedArgs& a) {
+  const unsigned long long f = __hip_atomic_load(&a.hdr[a.ovf_word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.ovf_val ? 1ull : 0ull;
+  __hip_atomic_store(a.notice, (unsigned long long)(unsigned)a.ovf_val | (f << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <int CAP>
 __global__ void __launch_bounds__(kP3Threads)
 fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restrict__ csr_src, HotList hot) {
@@ -1824,6 +1836,7 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
   QST(0);
   constexpr int kDefMax = kPartCap / 4;
   const int p = blockIdx.x;
+  if (a.notice && p == 0 && threadIdx.x == 0) publish_notice(a);
   // the sub-list counts come in through the VECTOR memory path (one lane per sub-list, broadcast behind the barrier): as uniform
   // scalar loads they share the LDS counter of the wave, and the barrier below -- which waits for the LDS initialisation --
   // waited for their round trip as well (profiles/r05_index_phase_stamps_1024x2.txt: 2 us in front of the first barrier)
@@ -2303,6 +2316,47 @@ int mi355_side_join(int token, hipStream_t stream) {
   return rc;
 }
 
+// ---- round 6: the overflow notice of path (c).  64 pinned, host-coherent words {epoch (low 32), flooded (bit 32)}: slot epoch % 64
+// is written by the partition kernel of the step with that epoch (publish_notice) and read by the host when the step's
+// backward is issued.  Epochs are process-wide and never zero.
+static constexpr int kNoticeRing = 64;
+static unsigned long long* notice_ring() {
+  static unsigned long long* ring = [] {
+    unsigned long long* r = nullptr;
+    if (hipHostMalloc((void**)&r, kNoticeRing * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess)
+      return (unsigned long long*)nullptr;
+    for (int i = 0; i < kNoticeRing; ++i) r[i] = 0;
+    return r;
+  }();
+  return ring;
+}
+static int g_epoch = 0;
+// mi355_demb_forward_fused_rerun: the epoch of the step being regrouped (0: an ordinary forward)
+static thread_local int t_rerun_epoch = 0;
+
+// Has the forward with this epoch flooded a partition's record list?  0: no (its CSR is complete), 1: yes (re-run its index stage
+// with mi355_demb_forward_fused_rerun / mi355_demb_plan_rerun before its backward), -1: not known within wait_ms milliseconds
+// (the forward has not reached its partition kernel: a stuck GPU), 2: the notice was overwritten by a step 64 epochs later --
+// treat as flooded (a re-run of a clean step is harmless).  The wait spins on pinned memory; with a dense model between forward
+// and backward the word has long been written.
+int mi355_demb_fused_step_flooded(int epoch, int wait_ms) {
+  if (epoch <= 0) return 0;
+  volatile unsigned long long* slot = notice_ring();
+  if (!slot) return 2;
+  slot += epoch % kNoticeRing;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 0;; ++spin) {
+    const unsigned long long v = *slot;
+    const int e = (int)(unsigned)(v & 0xffffffffull);
+    if (e == epoch) return (int)((v >> 32) & 1ull);
+    if (e > epoch) return 2;   // a later epoch owns the slot (64 forwards were issued before this step's backward)
+    if ((spin & 1023) == 1023 &&
+        std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > wait_ms)
+      return -1;
+    __builtin_ia32_pause();
+  }
+}
+
 int64_t mi355_demb_aux_numel(int64_t total_slots, int64_t num_buckets) {
   return kAuxHdr + 2 * (total_slots + 1) + num_buckets;
 }
@@ -2478,7 +2532,10 @@ int mi355_demb_forward_fused(
   bool pathc = part && part_env >= 2 && train && (combiner >= 0 || (seq && seq_env)) && hot_ws && bcsr && aligned16 &&
                      emb_dim <= (4 << lg) && (seq || n <= 8 * num_bags) && value_dtype <= 1 && out_dtype <= 1 &&
                      num_bags < (1ll << 31) - 4096;
-  if (part && a.mt && !pathc) { part = false; a.P = 0; a.mt = 0; }   // several tables: path (c) or the per-slot counters
+  // round 6: the partitioned stage is path (c) or nothing.  Round 2's form (a) -- the same record lists, merged by fused_part_kernel
+  // and scattered by a third kernel -- reported a flooded list through a sticky flag and skipped the step's update; what is not
+  // eligible for path (c) (long bags, fp16 rows, unaligned rows, MI355_FUSED_PART=1) takes the per-slot counters, which cannot flood
+  if (part && !pathc) { part = false; a.P = 0; a.mt = 0; }
   // the two knobs of the probe kernel (MI355_ENV_LIVE=1 -- the test suite, the A/B tools -- re-reads them on every call: A/B inside
   // one process; otherwise they are read once: getenv walks the whole environment, twice per step adds up on the host)
   static const bool env_live = getenv("MI355_ENV_LIVE") != nullptr;
@@ -2511,18 +2568,34 @@ int mi355_demb_forward_fused(
   // (round 5: the chain on the SIDE stream, forked in front of the gather -- its head kernel holding it back in a flagged step until
   //  every wave of the gather's launch had counted itself done -- was built, passed the flood tests, and cost 0.252 ms per C2 step
   //  against 0.169 in line and 0.162 without: the fork / join event pair across two queues is far dearer than three empty launches)
+  // round 6: no update is ever lost, and the steady state pays nothing for it.  Default = the NOTICE: the partition kernel's
+  // first block stores {epoch, flooded} into pinned memory, the host reads it when the step's backward is issued and re-runs the
+  // index stage on the per-slot-counter path first if it has to (mi355_demb_forward_fused_rerun).  Where the host cannot wait
+  // for a word -- the forward is being CAPTURED into a graph -- or where the step's pin counters are taken from the numbering
+  // (pin != 0), the chain runs IN LINE instead: three launches behind the gather, gated on the epoch, that return at once in the
+  // steady state (MI355_FUSED_OVERFLOW_RERUN=1 forces this form: the round-5 behaviour, kept for A/B).
   static const int rerun_env = getenv("MI355_FUSED_OVERFLOW_RERUN") ? atoi(getenv("MI355_FUSED_OVERFLOW_RERUN")) : 0;
-  static int g_epoch = 0;
-  const bool rerun = pathc && rerun_env != 0;
+  const int rerun_only = t_rerun_epoch;
+  bool capturing = false;
+  if (pathc && !rerun_only) {
+    hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cst) == hipSuccess) capturing = cst != hipStreamCaptureStatusNone;
+  }
+  unsigned long long* ring = pathc ? notice_ring() : nullptr;
+  const bool notice_mode = pathc && !rerun_only && !pin && !capturing && rerun_env != 1 && ring != nullptr;
+  const bool rerun = pathc && (rerun_only || !notice_mode);
   int epoch = 0;
+  a.notice = nullptr;
   if (pathc) {
     a.tile_bags = (int32_t*)((uint8_t*)backward_workspace + al256(4 * (n + 1)) + al256(4 * n));   // head of the grouping workspace
     a.occ_trank = a.d_tid;   // (the deferred-key arrays belong to path (b))
     a.rerun_mark = total + 16;   // cleared by the probe kernel on every step: the lazy materialisation reads it
-    if (rerun) {
-      epoch = (int)(__sync_add_and_fetch(&g_epoch, 1) & 0x3fffffff) + 1;
-      a.ovf_word = 6; a.ovf_val = epoch;
-    }
+    epoch = rerun_only ? rerun_only : (int)(__sync_add_and_fetch(&g_epoch, 1) & 0x3fffffff) + 1;
+    a.ovf_word = 6; a.ovf_val = epoch;
+    if (notice_mode) a.notice = ring + epoch % kNoticeRing;
+  } else if (rerun_only) {
+    mi355_set_error("mi355_demb_forward_fused_rerun: not a path-(c) step (nothing to re-run)");
+    return MI355_EINVAL;
   }
   // ---- eval / inference forward of one table with pooled output: ONE kernel (every lane probes its own keys; no dedup, no
   //      unique numbering, no address array).  MI355_EVAL_FUSED=0 keeps the probe + gather pair.
@@ -2576,7 +2649,7 @@ int mi355_demb_forward_fused(
       return MI355_OK;
     }
   }
-  if (n > 0) {
+  if (n > 0 && !rerun_only) {
     RoctxRange rr("op:fused_index(segmented_unique+storage_find+storage_insert+initializer)");
     // keys per tile / threads per block: one key per thread keeps every probe chain (digest vector -> key -> slot counter)
     // in flight at once; larger tiles cost fewer (tile, key) pairs = fewer device-scope atomics
@@ -2678,6 +2751,7 @@ int mi355_demb_forward_fused(
     late.table_ptrs = table_ptrs; late.table_value_dims = table_value_dims; late.tbo = table_bucket_offsets;
     late.C = bucket_capacity; late.elem_bytes = a.elem_bytes; late.T = (int)num_tables;
     const int nsub = 64 >> lg;
+    if (rerun_only) goto rerun_chain;      // (a flooded step: its forward ran, only the index stage is redone)
     if (part_fused) { late.ready = a.part_ready; late.cap = kPartCap; }
     else if (big) hipLaunchKernelGGL(fused_part3s_kernel, dim3((unsigned)a.P), dim3(kP3Threads), 0, stream, a, o, bptr, bcsr, hot);
     else hipLaunchKernelGGL(fused_part3_kernel<kPartCap>, dim3((unsigned)a.P), dim3(kP3Threads), 0, stream, a, o, bptr, bcsr, hot);
@@ -2715,6 +2789,7 @@ int mi355_demb_forward_fused(
 #undef LAUNCH_PG
     }
     MI355_LAUNCH_CHECK();
+  rerun_chain:
     if (rerun) {
       // the chain of the per-slot-counter path over the same buffers, gated on this call's epoch: probe (keys already inserted are
       // found; Assign / timer scores are idempotent, counting ones see the step twice), numbering, CSR scatter (eager reverse
@@ -2722,7 +2797,8 @@ int mi355_demb_forward_fused(
       FusedArgs b = a;
       b.P = 0; b.spp = 1; b.rec = nullptr; b.rec_out = nullptr; b.rec_out4 = nullptr; b.tile_bags = nullptr; b.occ_trank = nullptr;
       b.mt = 0; b.ptab = nullptr; b.rerun_mark = nullptr;
-      b.gate = a.hdr + 6; b.gate_val = epoch;
+      b.notice = nullptr;
+      if (!rerun_only) { b.gate = a.hdr + 6; b.gate_val = epoch; }      // in line: gated on this call's epoch; re-run: the host knows
       hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, b);
       static int ncu_r = 0;
       if (!ncu_r) {
@@ -2737,9 +2813,11 @@ int mi355_demb_forward_fused(
                                  bptr, bcsr, hot_ws, hot_bytes_, emb_dim, a.hdr, nullptr, stream, b.gate, epoch, a.rerun_mark));
     }
     const int64_t* nu_dev = unique_offsets + num_tables;
-    if (pin) STEP(mi355_table_update_counter(counter, counter_numel, slots, n, nu_dev, 1, table_ids, table_bucket_offsets,
-                                             bucket_capacity, stream));
-    if (join_token) *join_token = -2;   // reverse indices / full ranks: on demand (mi355_demb_fused_materialize)
+    if (pin && !rerun_only) STEP(mi355_table_update_counter(counter, counter_numel, slots, n, nu_dev, 1, table_ids, table_bucket_offsets,
+                                                            bucket_capacity, stream));
+    // reverse indices / full ranks: on demand (mi355_demb_fused_materialize).  -2: the CSR is final (a flooded step was re-run in
+    // line); -(2 + epoch): ask mi355_demb_fused_step_flooded(epoch) before the CSR or the unique numbering is used
+    if (join_token) *join_token = notice_mode ? -(2 + epoch) : -2;
     return MI355_OK;
   }
   hipStream_t cs = stream;
@@ -2809,6 +2887,42 @@ int mi355_demb_forward_fused(
   return MI355_OK;
 }
 
+
+// The index stage of a path-(c) step whose partition lists flooded (mi355_demb_fused_step_flooded(epoch) == 1), redone on the
+// per-slot-counter path over the SAME buffers: probe (the step's keys are in the table by now: found; Assign / timer scores are
+// idempotent, counting ones see the step twice), unique numbering, CSR of the backward, eager reverse indices.  Arguments: exactly
+// those of the step's mi355_demb_forward_fused call (`out` is not written: the forward's output stands), plus its epoch.  After it
+// the step's backward runs with prepared = 1 as usual.  Reference: the reference's unique op serves any key stream in one pass
+// (unique_op.cu:484-714) -- this is what keeps that promise for a stream that defeats the slot-range partition.
+int mi355_demb_forward_fused_rerun(
+    void* storage, const int64_t* table_bucket_offsets, int64_t bucket_capacity, int64_t num_scores,
+    int32_t* bucket_sizes, int32_t* counter, int64_t counter_numel, int32_t* aux, int64_t aux_numel, int64_t num_buckets,
+    const int64_t* table_ptrs, const int64_t* table_value_dims, const int64_t* table_emb_dims,
+    int value_dtype, int64_t emb_dim, int64_t value_dim,
+    const void* keys, int64_t num_keys, const int64_t* offsets, int64_t num_bags, int64_t batch_size,
+    const int64_t* feature_offsets, int64_t num_tables,
+    int train, int find_policy, int insert_policy, uint64_t score_value, int use_count,
+    uint64_t timer_override, int pin,
+    int init_mode, float p0, float p1, float p2, float p3, uint64_t seed, float state_init,
+    int combiner, const int32_t* D_offsets, int64_t total_D, void* out, int out_dtype, int aligned16,
+    int64_t* reverse_indices, int64_t* unique_offsets, int64_t* table_ids, int64_t* slots,
+    int64_t* row_addr, int64_t* freq, int32_t* csr_cnt, int32_t* csr_rank,
+    void* backward_workspace, int64_t backward_workspace_bytes, int use_side_stream,
+    int epoch,
+    void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  MI355_CHECK_ARG(epoch > 0 && train && num_keys > 0, "rerun: the epoch of a training step required");
+  t_rerun_epoch = epoch;
+  int tok = 0;
+  const int rc = mi355_demb_forward_fused(storage, table_bucket_offsets, bucket_capacity, num_scores, bucket_sizes, counter, counter_numel, aux,
+                                          aux_numel, num_buckets, table_ptrs, table_value_dims, table_emb_dims, value_dtype, emb_dim, value_dim,
+                                          keys, num_keys, offsets, num_bags, batch_size, feature_offsets, num_tables, train, find_policy,
+                                          insert_policy, score_value, use_count, timer_override, pin, init_mode, p0, p1, p2, p3, seed,
+                                          state_init, combiner, D_offsets, total_D, out, out_dtype, aligned16, reverse_indices, unique_offsets,
+                                          table_ids, slots, row_addr, freq, csr_cnt, csr_rank, backward_workspace, backward_workspace_bytes,
+                                          use_side_stream, &tok, workspace, workspace_bytes, stream);
+  t_rerun_epoch = 0;
+  return rc;
+}
 
 // Per-occurrence outputs of a path-(c) forward that nothing on the training path reads (reference: the `inverse` of
 // segmented_unique_cuda, unique_op.cu:484-714): reverse_indices [num_keys] and the rank of every occurrence inside its unique

@@ -46,6 +46,7 @@ __device__ __forceinline__ void part3_lean(FusedArgs& a, const EmitOut& o, int* 
   // a latency chain next to 24 streaming waves of the gather: its few instructions go first (MI355_PART_PRIO=0 in FusedArgs::dbg bit 2 turns it off)
   if (!(a.dbg & 4)) __builtin_amdgcn_s_setprio(3);
   QST(0);
+  if (a.notice && p == 0 && tid == 0) publish_notice(a);
   const int mv = a.pcount[p * kPartSub + (tid & (kPartSub - 1))];
   for (int i = tid; i < HASH; i += T) { h_slot[i] = -1; h_cnt[i] = 0; }
   if (tid < 256) s_lock[tid] = 0;

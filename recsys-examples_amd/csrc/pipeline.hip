@@ -262,7 +262,8 @@ int64_t mi355_demb_plan_step_bytes(void* plan, int64_t num_keys) {
 
 // Training forward of one batch through the plan.  Returns MI355_OK, an error, or MI355_ENOSPC (1) when `step_buf` is smaller
 // than mi355_demb_plan_step_bytes(num_keys) (nothing was launched).  *state (out): the join_token of mi355_demb_forward_fused
-// (-2: path (c), lazy reverse indices; -1: everything on `stream`).
+// (<= -2: path (c), lazy reverse indices -- -2 - *state = the step's epoch for mi355_demb_plan_backward, 0: nothing to ask;
+// -1: everything on `stream`).
 int mi355_demb_plan_forward(void* plan, const void* keys, int64_t num_keys, const int64_t* offsets, int64_t num_bags,
                             int64_t batch_size, uint64_t score_value, uint64_t timer_override, void* out, void* step_buf,
                             int64_t step_bytes, int* state, hipStream_t stream) {
@@ -289,9 +290,14 @@ int mi355_demb_plan_forward(void* plan, const void* keys, int64_t num_keys, cons
 int mi355_demb_plan_backward(void* plan, void* step_buf, int64_t step_bytes, int64_t num_keys, const int64_t* offsets,
                              int64_t num_bags, int64_t batch_size, const void* grads, int64_t grad_stride, int grad_dtype,
                              int grad_aligned16, float lr, float beta1, float beta2, float eps, float weight_decay,
-                             int64_t iter_num, int prepared, hipStream_t stream) {
+                             int64_t iter_num, int prepared, int epoch, hipStream_t stream) {
   const DembPlan* p = (const DembPlan*)plan;
   MI355_CHECK_ARG(p && step_buf, "plan backward: null plan / step buffer");
+  if (epoch > 0) {      // a path-(c) step: did its partition lists hold every record?  (one read of pinned memory)
+    const int f = mi355_demb_fused_step_flooded(epoch, 20000);
+    if (f < 0) { mi355_set_error("plan backward: the forward of this step never reported (GPU stuck?)"); return MI355_ELAUNCH; }
+    if (f > 0) return 2;   // nothing launched: mi355_demb_plan_rerun first, then this call again with epoch = 0
+  }
   int64_t lay[13];
   mi355_demb_step_layout(num_keys, p->T, p->emb_dim, 1, lay);
   MI355_CHECK_ARG(step_bytes >= lay[10], "plan backward: step buffer too small");
@@ -302,6 +308,30 @@ int mi355_demb_plan_backward(void* plan, void* step_buf, int64_t step_bytes, int
                              weight_decay, iter_num, -1, 1, p->aligned16 && grad_aligned16, p->counter, p->counter_numel,
                              (const int64_t*)(b + lay[2]), (const int64_t*)(b + lay[1]), p->tbo, p->C, p->pin,
                              (const int32_t*)(b + lay[5]), (const int32_t*)(b + lay[6]), prepared, b + lay[9], lay[12], stream);
+}
+
+
+// Regroups a flooded step (mi355_demb_plan_backward returned 2) on the per-slot-counter path: the batch arguments of the step's
+// mi355_demb_plan_forward call again, plus its epoch (-2 - *state of that call).
+int mi355_demb_plan_rerun(void* plan, const void* keys, int64_t num_keys, const int64_t* offsets, int64_t num_bags,
+                          int64_t batch_size, uint64_t score_value, uint64_t timer_override, void* step_buf,
+                          int64_t step_bytes, int epoch, hipStream_t stream) {
+  const DembPlan* p = (const DembPlan*)plan;
+  MI355_CHECK_ARG(p && step_buf, "plan rerun: null plan / step buffer");
+  int64_t lay[13];
+  mi355_demb_step_layout(num_keys, p->T, p->emb_dim, 1, lay);
+  MI355_CHECK_ARG(step_bytes >= lay[10], "plan rerun: step buffer too small");
+  uint8_t* b = (uint8_t*)step_buf;
+  return mi355_demb_forward_fused_rerun(p->storage, p->tbo, p->C, p->ns, p->bucket_sizes, p->counter, p->counter_numel, p->aux,
+                                        p->aux_numel, p->num_buckets, p->table_ptrs, p->table_value_dims, p->table_emb_dims,
+                                        p->value_dtype, p->emb_dim, p->value_dim, keys, num_keys, offsets, num_bags, batch_size,
+                                        p->feature_offsets, p->T, 1, p->find_policy, p->insert_policy, score_value, p->use_count,
+                                        timer_override, p->pin, p->init_mode, p->p0, p->p1, p->p2, p->p3, p->seed, p->state_init,
+                                        p->combiner, p->D_offsets, p->total_D, nullptr, p->out_dtype, p->aligned16,
+                                        (int64_t*)(b + lay[0]), (int64_t*)(b + lay[7]), (int64_t*)(b + lay[1]), (int64_t*)(b + lay[2]),
+                                        (int64_t*)(b + lay[3]), p->use_count ? (int64_t*)(b + lay[4]) : nullptr,
+                                        (int32_t*)(b + lay[5]), (int32_t*)(b + lay[6]), b + lay[9], lay[12], 0, epoch, b + lay[8],
+                                        lay[11], stream);
 }
 
 }  // extern "C"

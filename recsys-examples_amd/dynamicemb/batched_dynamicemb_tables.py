@@ -112,9 +112,27 @@ class _FusedStep:
         self.offsets = None
         self.prepared = 0
         self.lazy = False      # reverse indices / ranks not produced yet (mi355_demb_fused_materialize on first use)
+        self.epoch = 0         # path (c): the step's overflow notice has not been read yet (settle())
+        self.rerun_args = None
+
+    def settle(self):
+        """A path-(c) step gave every slot-range partition a fixed record list.  Before anybody uses its CSR or unique numbering
+        the library is asked whether every list held its records (one read of pinned memory, written by the step's partition
+        kernel); a flooded step is regrouped on the per-slot-counter path first.  No step ever skips its update (reference:
+        batched_dynamicemb_function.py:1042-1191, the unique op serves any key stream)."""
+        ep = self.epoch
+        if ep:
+            self.epoch = 0
+            f = lib().mi355_demb_fused_step_flooded(ep, 20000)
+            if f < 0:
+                raise RuntimeError("fused forward: the step never reported its partition state (GPU stuck?)")
+            if f:
+                self.module._rerun_step(self, ep)
 
     def materialize(self):
-        """per-occurrence outputs of a forward whose partition blocks wrote the CSR themselves (join_token == -2)"""
+        """per-occurrence outputs of a forward whose partition blocks wrote the CSR themselves (join_token <= -2)"""
+        if self.epoch:
+            self.settle()
         if self.lazy:
             self.lazy = False
             check(lib().mi355_demb_fused_materialize(self.p("fwd_ws"), self.fwd_ws_bytes, self.num_keys, self.T, self.p("row_addr"),
@@ -129,7 +147,9 @@ class _FusedStep:
         return c_p(self.buf.data_ptr() + self.off[name])
 
     def join(self):
-        """make the current stream wait for the side-stream half of this step's forward"""
+        """make the current stream wait for the side-stream half of this step's forward (and settle a path-(c) step)"""
+        if self.epoch:
+            self.settle()
         if self.token >= 0:
             check(lib().mi355_side_join(self.token, stream()), "side join")
             self.token = -1
@@ -181,6 +201,8 @@ class _PlanStep(_FusedStep):
         self.indices = None
         self.prepared = 0
         self.lazy = False
+        self.epoch = 0
+        self.rerun_args = None
         self.plan_step = True
 
     def _layout(self):
@@ -778,11 +800,12 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             check(rc, "demb_plan_forward")
         st = _PlanStep(self, buf, n, self.num_tables, ring, offsets, B, num_bags)
         tok = self._plan_state.value
-        st.lazy = tok == -2
+        if tok <= -2:            # path (c): lazy reverse indices; -(2 + epoch) names the step's overflow notice (settle())
+            st.lazy = True
+            st.epoch = -2 - tok
+            st.indices, st.sval = indices, sval
         st.prepared = 1 if n > 0 else 0
         object.__setattr__(self, "_step", self._step + 1)   # (nn.Module.__setattr__ runs its Parameter / Module checks per assignment)
-        if self._step % 64 == 0 or self.__dict__.get("_part_flag_event") is not None:
-            self._check_partition_flag()
         return out, st
 
     def _plan_backward(self, st, grads):
@@ -790,10 +813,19 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             grads = grads.contiguous()
         object.__setattr__(self, "_iter_num", self._iter_num + 1)
         buf = st.buf
+        s_ = _raw_stream(_cur_device())
+        # (the step's overflow notice is read inside the call: st.epoch > 0 unless somebody looked at the step already)
         rc = self._plan_bwd(self._plan, buf.data_ptr(), buf.numel(), st.num_keys, st.offsets.data_ptr(), st.num_bags, st.batch_size,
                             grads.data_ptr(), grads.stride(0), _DT_CODE[grads.dtype], int(self._plan_al_g and grads.stride(0) % 4 == 0),
-                            self.learning_rate, self.beta1, self.beta2, self.eps, self.weight_decay, self._iter_num, 1,
-                            _raw_stream(_cur_device()))
+                            self.learning_rate, self.beta1, self.beta2, self.eps, self.weight_decay, self._iter_num, 1, st.epoch, s_)
+        if rc == 2:      # a flooded partition: regroup the step on the per-slot-counter path, then the backward (nothing is skipped)
+            ep, st.epoch = st.epoch, 0
+            self._rerun_step(st, ep)
+            rc = self._plan_bwd(self._plan, buf.data_ptr(), buf.numel(), st.num_keys, st.offsets.data_ptr(), st.num_bags,
+                                st.batch_size, grads.data_ptr(), grads.stride(0), _DT_CODE[grads.dtype],
+                                int(self._plan_al_g and grads.stride(0) % 4 == 0), self.learning_rate, self.beta1, self.beta2,
+                                self.eps, self.weight_decay, self._iter_num, 1, 0, s_)
+        st.epoch = 0
         if rc != 0:
             check(rc, "demb_plan_backward")
         st.prepared = 0
@@ -850,7 +882,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         al = all(d % 4 == 0 for d in self.dims) and all(v % 4 == 0 for v in self.value_dims)
         tok = ctypes.c_int(-1)
         need_freq = use_cnt
-        check(L.mi355_demb_forward_fused(
+        head = (
             ptr(tb.table_storage_), ptr(tb.table_bucket_offsets_), tb.bucket_capacity_, tb.num_scores_,
             ptr(tb.bucket_sizes), ptr(tb._ref_counter), tb._ref_counter.numel(), ptr(self._fused_aux),
             self._fused_aux.numel(), tb.num_buckets_,
@@ -861,41 +893,41 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             mode, c_f(p[0]), c_f(p[1]), c_f(p[2]), c_f(p[3]), c_u64(self._seed), c_f(self.initial_accumulator_value),
             combiner, ptr(self.D_offsets_t), self.total_D, ptr(out), dt(out) if out is not None else 0, int(al),
             st.p("rev"), st.p("uoff"), st.p("tids"), st.p("slots"), st.p("row_addr"), st.p("freq") if need_freq else None,
-            st.p("csr_cnt"), st.p("csr_rank"), st.p("bwd_ws") if bwd_b else None, bwd_b, use_side, ctypes.byref(tok),
-            st.p("fwd_ws"), fwd_b, stream()), "demb_forward_fused")
-        st.lazy = tok.value == -2
+            st.p("csr_cnt"), st.p("csr_rank"), st.p("bwd_ws") if bwd_b else None, bwd_b, use_side)
+        tail = (st.p("fwd_ws"), fwd_b)
+        check(L.mi355_demb_forward_fused(*head, ctypes.byref(tok), *tail, stream()), "demb_forward_fused")
+        st.lazy = tok.value <= -2
+        if tok.value < -2:       # path (c): the step's overflow notice is read before its CSR is used (_FusedStep.settle)
+            st.epoch = -2 - tok.value
+            st.rerun_args = (head, tail)
+            st.indices = indices     # (the re-run reads the batch again)
         st.token = tok.value if tok.value >= 0 else -1
         st.prepared = (2 + tok.value) if tok.value >= 0 else (1 if bwd_b and n > 0 else 0)
         if train:
-            self._check_partition_flag()
             self._step += 1
             if self._dynamicemb_options[0].safe_check_mode != DynamicEmbCheckMode.IGNORE:
                 self._safe_check(st)
         return out, st
 
-    def _check_partition_flag(self):
-        """The partitioned index stage gives every slot range a fixed number of (tile, key) records per step; if a range ever
-        receives more (a key stream that defeats the hash: never seen with real keys), that step reported zero unique rows --
-        its forward output is complete, its backward updated NO row -- and the kernel left a sticky flag in the aux header.  Read without a sync (the flag travels to
-        pinned memory every 64 steps) and reported as an error: the remedy is MI355_FUSED_PART=0."""
-        if torch.cuda.is_current_stream_capturing():
-            return
-        ev = getattr(self, "_part_flag_event", None)
-        if ev is not None and ev.query():
-            self._part_flag_event = None
-            if int(self._part_flag_host.item()) != 0:
-                self._fused_aux[5:6].zero_()
-                raise RuntimeError("fused forward: a slot-range partition overflowed its record list in an earlier step "
-                                   "(that step's backward updated no row); set MI355_FUSED_PART=0")
-        if ev is None and self._step % 64 == 0:
-            if getattr(self, "_part_flag_host", None) is None:
-                self._part_flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-            self._part_flag_host.copy_(self._fused_aux[5:6], non_blocking=True)
-            self._part_flag_event = torch.cuda.Event()
-            self._part_flag_event.record(current_torch_stream())
+    def _rerun_step(self, st, epoch: int) -> None:
+        """a partition's record list flooded in this step's forward (a key stream that defeats the hash: never seen with real keys):
+        its index stage is redone on the per-slot-counter path over the step's own buffers (csrc/fused_fwd.hip:
+        mi355_demb_forward_fused_rerun); the forward's output stands, the backward that follows updates every row"""
+        self.overflow_reruns = getattr(self, "overflow_reruns", 0) + 1
+        if getattr(st, "plan_step", False):
+            buf = st.buf
+            check(lib().mi355_demb_plan_rerun(self._plan, st.indices.data_ptr(), st.num_keys, st.offsets.data_ptr(), st.num_bags,
+                                              st.batch_size, st.sval, ext.TIMER_OVERRIDE, buf.data_ptr(), buf.numel(), epoch,
+                                              stream()), "demb_plan_rerun")
+        else:
+            head, tail = st.rerun_args
+            check(lib().mi355_demb_forward_fused_rerun(*head, epoch, *tail, stream()), "demb_forward_fused_rerun")
+        st.lazy = False          # the re-run left reverse indices and ranks eagerly
 
     def _backward_fused(self, st, grads: torch.Tensor):
         grads = grads.contiguous()
+        if st.epoch:
+            st.settle()
         self._iter_num += 1
         pooled = self.pooling_mode != DynamicEmbPoolingMode.NONE
         combiner = -1 if not pooled else (0 if self.pooling_mode == DynamicEmbPoolingMode.SUM else 1)

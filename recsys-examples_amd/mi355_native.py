@@ -99,6 +99,15 @@ _SIGS = {
                                  c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,  # persisted
                                  c_p, c_i64, c_int, c_p,  # backward workspace, side stream, join token
                                  c_p, c_i64, c_p],
+    "mi355_demb_forward_fused_rerun": [c_p, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_i64,  # table + aux
+                                 c_p, c_p, c_p, c_int, c_i64, c_i64,  # values
+                                 c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i64,  # batch
+                                 c_int, c_int, c_int, c_u64, c_int, c_u64, c_int,  # policies
+                                 c_int, c_f, c_f, c_f, c_f, c_u64, c_f,  # initializer
+                                 c_int, c_p, c_i64, c_p, c_int, c_int,  # output
+                                 c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,  # persisted
+                                 c_p, c_i64, c_int, c_int,  # backward workspace, side stream, epoch
+                                 c_p, c_i64, c_p],
     "mi355_demb_plan_create": [c_p, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_i64,  # table + aux
                                c_p, c_p, c_p, c_int, c_i64, c_i64, c_p, c_i64,  # values, feature offsets, tables
                                c_int, c_int, c_int, c_int,  # policies, pin
@@ -110,7 +119,9 @@ _SIGS = {
     "mi355_demb_plan_step_bytes": [c_p, c_i64],
     "mi355_demb_plan_forward": [c_p, c_p, c_i64, c_p, c_i64, c_i64, c_u64, c_u64, c_p, c_p, c_i64, c_p, c_p],
     "mi355_demb_plan_backward": [c_p, c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_int, c_int,
-                                 c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_p],
+                                 c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_p],
+    "mi355_demb_plan_rerun": [c_p, c_p, c_i64, c_p, c_i64, c_i64, c_u64, c_u64, c_p, c_i64, c_int, c_p],
+    "mi355_demb_fused_step_flooded": [c_int, c_int],
     "mi355_demb_aux_numel": [c_i64, c_i64],
     "mi355_demb_forward_fused_workspace_bytes": [c_i64, c_i64],
     "mi355_demb_forward_fused_partitions": [c_i64, c_i64, c_i64],
