@@ -111,6 +111,35 @@ def build_module(rows, dim, device):
                                            device=device)
 
 
+def timed_loop(fn, steps, warm=20):
+    fn(warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn(steps)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def pipelined_ms(module, batches, grad, steps):
+    """The reference's prefetch-pipeline order (PrefetchTrainPipelineSparseDist, examples/commons/pipeline/train_pipeline.py:
+    533-692) through the module's PUBLIC calls: prefetch_async(batch k + 1) -- the index stage on the module's prefetch stream,
+    ordered behind what the main stream holds, i.e. behind the gather of batch k -- then backward(batch k) on the main stream;
+    forward(k + 1) only gathers.  The index stage of the next batch runs under the backward of this one."""
+    nb = len(batches)
+
+    def run(n):
+        module.prefetch_async(*batches[0])
+        for i in range(n):
+            k, o = batches[i % nb]
+            out = module(k, o)                       # consumes the prefetched state: waits for its mark, gathers
+            module.prefetch_async(*batches[(i + 1) % nb])
+            out.backward(grad)
+        out = module(*batches[n % nb])               # drain the last prefetched state
+        out.backward(grad)
+
+    return timed_loop(run, steps)
+
+
 def _cpu_model() -> str:
     try:
         for line in open("/proc/cpuinfo"):
@@ -856,6 +885,18 @@ def main():
         result["step_via_autograd_ms"] = result["sustained"]["ms_per_step"]
         result["step_via_autograd_note"] = ("the timed region IS module.forward(keys, offsets) + out.backward(grad) since round 5; "
                                             "step_via_impl_ms = the same batches through _forward_impl / _backward_impl")
+
+    if rank == 0 and not sharded_path and not args.no_extra:
+        # the reference's prefetch-pipeline order on the same module and batches (round 6: prefetch_async runs the index stage of
+        # batch k + 1 on the partitioned path under the backward of batch k).  NOT the headline: on one GPU without a dense model
+        # the latency-bound index kernels and the bandwidth-bound backward slow each other down (profiles/r06_pipelined_timeline.txt)
+        try:
+            result["pipelined_ms_per_step"] = pipelined_ms(module, batches[args.warmup:], grad, max(args.steps, 100))
+            result["pipelined_note"] = ("prefetch_async(batch k+1) before backward(batch k), public calls; serial headline above. "
+                                        "Pinning prefetch of rounds 1-5 on the same loop: MI355_PREFETCH_C=0")
+        except Exception as e:      # noqa: BLE001
+            result["pipelined_ms_per_step"] = None
+            result["pipelined_note"] = repr(e)
 
     if rank == 0 and not sharded_path and not args.no_kernel_timing:
         roof, step_bytes = kernel_roofline(module, batches[args.warmup:], grad, args.batch, args.dim)

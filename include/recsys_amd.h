@@ -517,6 +517,17 @@ int64_t mi355_demb_plan_step_bytes(void* plan, int64_t num_keys);
 int mi355_demb_plan_forward(void* plan, const void* keys, int64_t num_keys, const int64_t* offsets, int64_t num_bags,
                             int64_t batch_size, uint64_t score_value, uint64_t timer_override, void* out, void* step_buf,
                             int64_t step_bytes, int* state, hipStream_t stream);
+/* Round 6: the forward in two halves -- the reference's prefetch pipeline (BatchedDynamicEmbeddingTablesV2.prefetch,
+ * batched_dynamicemb_tables.py:1090-1137; PrefetchTrainPipelineSparseDist, train_pipeline.py:533-692) on the fast index path.
+ * stage 1 = index stage only (issued for batch k + 1 on a side stream under the backward of batch k), stage 2 = the gather of a
+ * step whose stage 1 ran earlier, stage 0 = mi355_demb_plan_forward.  protect_score: evictions of this call spare every slot whose
+ * score is >= it (what the reference's ref-counter pins achieve; exact for the recency policies STEP / TIMESTAMP).  Returns 3 with
+ * nothing launched when the batch is not eligible for the partitioned index path. */
+int mi355_demb_plan_stage(void* plan, int stage, uint64_t protect_score, const void* keys, int64_t num_keys, const int64_t* offsets,
+                          int64_t num_bags, int64_t batch_size, uint64_t score_value, uint64_t timer_override, void* out,
+                          void* step_buf, int64_t step_bytes, int* state, hipStream_t fork_from, int slot, hipStream_t stream);
+/* (slot 0..3: the stream order of the staged step is kept by the library -- stage 1 on `stream` starts behind what `fork_from`
+ *  holds at the call and marks its end, stage 2 waits for the mark; slot -1: the caller orders its streams itself) */
 int mi355_demb_plan_backward(void* plan, void* step_buf, int64_t step_bytes, int64_t num_keys, const int64_t* offsets,
                              int64_t num_bags, int64_t batch_size, const void* grads, int64_t grad_stride, int grad_dtype,
                              int grad_aligned16, float lr, float beta1, float beta2, float eps, float weight_decay,

@@ -127,6 +127,11 @@ struct FusedArgs {
   // numbering first) re-runs the index stage on the per-slot-counter path before it uses the CSR (mi355_demb_fused_step_flooded,
   // mi355_demb_forward_fused_rerun): no update is ever skipped and the steady state pays no launch for it
   unsigned long long* notice;     // nullable: pinned, host-coherent
+  // round 6, the prefetch pipeline on path (c): the index stage of batch k + 1 runs under the backward of batch k, so an eviction
+  // must not take a slot an in-flight step uses.  With recency scores (STEP, TIMESTAMP) every key of an in-flight step carries a
+  // score >= the score of the oldest of them: victims must score BELOW `protect` (~0: no limit) -- the pin of the reference's
+  // prefetch (increment_counter, batched_dynamicemb_function.py:559-696) without a counter atomic per key
+  uint64_t protect;
   int tl;                         // probe_c_kernel (round 5): keys of a tile, a run-time value (<= the kernel's capacity, multiple of 64)
   // big-batch stage (round 5, big_index.h): the probe kernel leaves its records TILE-MAJOR -- no reservation at all -- and a split
   // kernel moves them into the partitions' lists; a per-record forwarding entry keeps the per-occurrence references valid
@@ -1707,6 +1712,7 @@ __device__ P3_EVICT_ATTR void part_evict(FusedArgs& a, int nd, int64_t rec_base,
                     }
                   }
                   if (cslot < 0) break;
+                  if (cs >= a.protect) { cslot = -1; break; }     // everything from here up belongs to a step in flight (ascending order)
                   const uint64_t k2 = ald64(ks + cslot);
                   const int pv = pin ? __hip_atomic_load(pin + cslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
                   if (k2 != kLockedKey && k2 != kEmptyKey && pv <= 0 && p2_find<HASH>(h_slot, (int)(bucket * a.t.C + cslot)) < 0) {
@@ -2333,6 +2339,12 @@ static unsigned long long* notice_ring() {
 static int g_epoch = 0;
 // mi355_demb_forward_fused_rerun: the epoch of the step being regrouped (0: an ordinary forward)
 static thread_local int t_rerun_epoch = 0;
+// stages of a path-(c) forward (mi355_demb_plan_stage): 0 the whole forward, 1 the index stage only (probe + partition kernel:
+// everything the backward needs and the per-occurrence row addresses), 2 the gather only (of a step whose stage 1 ran earlier,
+// typically on another stream).  t_protect: FusedArgs::protect of the call.
+static thread_local int t_stage = 0;
+static thread_local uint64_t t_protect = ~0ull;
+void mi355i_fused_stage(int stage, uint64_t protect) { t_stage = stage; t_protect = protect; }
 
 // Has the forward with this epoch flooded a partition's record list?  0: no (its CSR is complete), 1: yes (re-run its index stage
 // with mi355_demb_forward_fused_rerun / mi355_demb_plan_rerun before its backward), -1: not known within wait_ms milliseconds
@@ -2482,6 +2494,7 @@ int mi355_demb_forward_fused(
   a.tile_bags = nullptr; a.occ_trank = nullptr;
   a.mt = 0; a.ptab = nullptr;
   a.gate = nullptr; a.gate_val = 0; a.ovf_word = 5; a.ovf_val = 1; a.rerun_mark = nullptr; a.tl = 0;
+  a.protect = t_protect;
   a.stage_rec = nullptr; a.tile_cnt = nullptr; a.fwd = nullptr; a.cap = kPartCap; a.part_ready = nullptr;
   a.magic0 = num_buckets > 0 ? ~0ull / (uint64_t)num_buckets : 0ull;   // (one table: its buckets are all the buckets)
   {
@@ -2560,7 +2573,7 @@ int mi355_demb_forward_fused(
   static int pf_live = 1;
   if (env_live) { const char* e3 = getenv("MI355_PART_FUSED"); pf_live = e3 ? atoi(e3) : 1; }
   const int pf_mode = env_live ? pf_live : pf_env;      // 0 off, 1 sequence lookups (default: measured gain), 2 pooled batches as well (measured loss)
-  const bool part_fused = pathc && !big && (pf_mode >= 2 || (pf_mode == 1 && seq));
+  const bool part_fused = pathc && !big && t_stage == 0 && (pf_mode >= 2 || (pf_mode == 1 && seq));   // (staged forwards: two launches)
   if (part_fused) a.part_ready = (int32_t*)(a.tstat + 2 * a.P);
   if (part_fused && env_live) { const char* e4 = getenv("MI355_PART_PRIO"); if (e4 && atoi(e4) == 0) a.dbg |= 4; }
   // opt-in: an overflowed step is re-run on the per-slot-counter path inside this call (the reference never skips an update,
@@ -2576,6 +2589,8 @@ int mi355_demb_forward_fused(
   // steady state (MI355_FUSED_OVERFLOW_RERUN=1 forces this form: the round-5 behaviour, kept for A/B).
   static const int rerun_env = getenv("MI355_FUSED_OVERFLOW_RERUN") ? atoi(getenv("MI355_FUSED_OVERFLOW_RERUN")) : 0;
   const int rerun_only = t_rerun_epoch;
+  const int stage = rerun_only ? 0 : t_stage;
+  if (stage && !pathc) return 3;     // (nothing launched) not a path-(c) batch: the caller keeps its one-call forward
   bool capturing = false;
   if (pathc && !rerun_only) {
     hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
@@ -2583,16 +2598,16 @@ int mi355_demb_forward_fused(
   }
   unsigned long long* ring = pathc ? notice_ring() : nullptr;
   const bool notice_mode = pathc && !rerun_only && !pin && !capturing && rerun_env != 1 && ring != nullptr;
-  const bool rerun = pathc && (rerun_only || !notice_mode);
+  const bool rerun = pathc && stage != 2 && (rerun_only || !notice_mode);
   int epoch = 0;
   a.notice = nullptr;
   if (pathc) {
     a.tile_bags = (int32_t*)((uint8_t*)backward_workspace + al256(4 * (n + 1)) + al256(4 * n));   // head of the grouping workspace
     a.occ_trank = a.d_tid;   // (the deferred-key arrays belong to path (b))
     a.rerun_mark = total + 16;   // cleared by the probe kernel on every step: the lazy materialisation reads it
-    epoch = rerun_only ? rerun_only : (int)(__sync_add_and_fetch(&g_epoch, 1) & 0x3fffffff) + 1;
+    epoch = rerun_only ? rerun_only : (stage == 2 ? 0 : (int)(__sync_add_and_fetch(&g_epoch, 1) & 0x3fffffff) + 1);
     a.ovf_word = 6; a.ovf_val = epoch;
-    if (notice_mode) a.notice = ring + epoch % kNoticeRing;
+    if (notice_mode && stage != 2) a.notice = ring + epoch % kNoticeRing;
   } else if (rerun_only) {
     mi355_set_error("mi355_demb_forward_fused_rerun: not a path-(c) step (nothing to re-run)");
     return MI355_EINVAL;
@@ -2649,7 +2664,7 @@ int mi355_demb_forward_fused(
       return MI355_OK;
     }
   }
-  if (n > 0 && !rerun_only) {
+  if (n > 0 && !rerun_only && stage != 2) {
     RoctxRange rr("op:fused_index(segmented_unique+storage_find+storage_insert+initializer)");
     // keys per tile / threads per block: one key per thread keeps every probe chain (digest vector -> key -> slot counter)
     // in flight at once; larger tiles cost fewer (tile, key) pairs = fewer device-scope atomics
@@ -2753,9 +2768,11 @@ int mi355_demb_forward_fused(
     const int nsub = 64 >> lg;
     if (rerun_only) goto rerun_chain;      // (a flooded step: its forward ran, only the index stage is redone)
     if (part_fused) { late.ready = a.part_ready; late.cap = kPartCap; }
+    else if (stage == 2) { }               // (the partition kernel ran with the step's index stage)
     else if (big) hipLaunchKernelGGL(fused_part3s_kernel, dim3((unsigned)a.P), dim3(kP3Threads), 0, stream, a, o, bptr, bcsr, hot);
     else hipLaunchKernelGGL(fused_part3_kernel<kPartCap>, dim3((unsigned)a.P), dim3(kP3Threads), 0, stream, a, o, bptr, bcsr, hot);
     MI355_LAUNCH_CHECK();
+    if (stage == 1) goto rerun_chain;      // index stage only: the gather follows in a stage-2 call
     if (seq) {
       RoctxRange rg("op:gather_embedding");
       GatherTimer gt(stream);
@@ -2813,11 +2830,11 @@ int mi355_demb_forward_fused(
                                  bptr, bcsr, hot_ws, hot_bytes_, emb_dim, a.hdr, nullptr, stream, b.gate, epoch, a.rerun_mark));
     }
     const int64_t* nu_dev = unique_offsets + num_tables;
-    if (pin && !rerun_only) STEP(mi355_table_update_counter(counter, counter_numel, slots, n, nu_dev, 1, table_ids, table_bucket_offsets,
+    if (pin && !rerun_only && stage != 2) STEP(mi355_table_update_counter(counter, counter_numel, slots, n, nu_dev, 1, table_ids, table_bucket_offsets,
                                                             bucket_capacity, stream));
     // reverse indices / full ranks: on demand (mi355_demb_fused_materialize).  -2: the CSR is final (a flooded step was re-run in
     // line); -(2 + epoch): ask mi355_demb_fused_step_flooded(epoch) before the CSR or the unique numbering is used
-    if (join_token) *join_token = notice_mode ? -(2 + epoch) : -2;
+    if (join_token) *join_token = (notice_mode && stage != 2) ? -(2 + epoch) : -2;
     return MI355_OK;
   }
   hipStream_t cs = stream;

@@ -72,6 +72,10 @@ int mi355i_backward_fused(const int32_t* ptr, const int32_t* csr_src, int64_t nu
                           void* out, int64_t out_stride, int aligned16, void* workspace, int64_t workspace_bytes,
                           const int32_t* tile_bags, int one_feature, hipStream_t stream);
 
+// stage (0 whole forward, 1 index stage only, 2 gather only) and eviction limit of the NEXT mi355_demb_forward_fused call of this
+// thread (fused_fwd.hip; mi355_demb_plan_stage brackets its call with it)
+void mi355i_fused_stage(int stage, uint64_t protect);
+
 // bench.py's live kernel timing (err.hip): event of slot (0 gather, 1 backward kernel), end 0 / 1
 void mi355i_prof_mark(int slot, int end, hipStream_t stream);
 

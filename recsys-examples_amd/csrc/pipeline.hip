@@ -219,6 +219,8 @@ struct DembPlan {
   int init_mode; float p0, p1, p2, p3; uint64_t seed; float state_init;
   int combiner; const int32_t* D_offsets; int64_t total_D; int out_dtype, aligned16;
   int opt_kind; float beta1, beta2, eps, weight_decay;
+  // staged forwards (mi355_demb_plan_stage): per step-ring slot, the fork point of a prefetch and the end of its index stage
+  hipEvent_t ev_fork[4] = {}, ev_done[4] = {};
 };
 
 void* mi355_demb_plan_create(void* storage, const int64_t* table_bucket_offsets, int64_t bucket_capacity, int64_t num_scores,
@@ -236,7 +238,15 @@ void* mi355_demb_plan_create(void* storage, const int64_t* table_bucket_offsets,
                              beta2, eps, weight_decay};
   return p;
 }
-void mi355_demb_plan_destroy(void* plan) { delete (DembPlan*)plan; }
+void mi355_demb_plan_destroy(void* plan) {
+  DembPlan* p = (DembPlan*)plan;
+  if (!p) return;
+  for (int i = 0; i < 4; ++i) {
+    if (p->ev_fork[i]) (void)hipEventDestroy(p->ev_fork[i]);
+    if (p->ev_done[i]) (void)hipEventDestroy(p->ev_done[i]);
+  }
+  delete p;
+}
 
 // Byte offsets of the arrays of one step buffer: out[0..9] = rev, tids, slots, row_addr, freq (8 n each), csr_cnt, csr_rank
 // (4 n each), unique_offsets (8 (T + 1)), forward workspace, backward workspace; out[10] = total bytes, out[11] / out[12] = the two
@@ -282,6 +292,53 @@ int mi355_demb_plan_forward(void* plan, const void* keys, int64_t num_keys, cons
                                   (int64_t*)(b + lay[7]), (int64_t*)(b + lay[1]), (int64_t*)(b + lay[2]), (int64_t*)(b + lay[3]),
                                   p->use_count ? (int64_t*)(b + lay[4]) : nullptr, (int32_t*)(b + lay[5]), (int32_t*)(b + lay[6]),
                                   b + lay[9], lay[12], 0, state, b + lay[8], lay[11], stream);
+}
+
+// The same forward in two halves (round 6: the reference's prefetch pipeline -- BatchedDynamicEmbeddingTablesV2.prefetch,
+// batched_dynamicemb_tables.py:1090-1137, PrefetchTrainPipelineSparseDist, train_pipeline.py:533-692 -- on path (c)).  stage 1: the
+// index stage only (probe + partition kernel: every table mutation of the step, the per-occurrence row addresses, the backward's
+// CSR) -- `out` unused; issued for batch k + 1 on a side stream, it runs under the backward of batch k.  stage 2: the gather of a
+// step whose stage 1 ran earlier (same batch arguments, same step buffer), on the stream that needs the output.  stage 0 =
+// mi355_demb_plan_forward.  protect_score: an eviction of this call takes no slot whose score is >= it (recency scores: the score
+// of the oldest step still in flight keeps every row of every in-flight step where it is; ~0: no limit).  Returns 3, nothing
+// launched, when the batch is not eligible for path (c) (the caller uses its one-call forward / the pinning prefetch).
+// Stream order of a staged step, kept inside the library (an event pair per slot, slot in 0..3, -1: the caller orders the streams
+// itself): stage 1 with fork_from != stream -- `stream` first waits for what `fork_from` holds at this point (the batch was
+// produced there, and the rows the previous backward writes must be final before an eviction may re-initialise one), and the end
+// of the index stage is marked; stage 2 -- `stream` waits for that mark before it gathers.
+int mi355_demb_plan_stage(void* plan, int stage, uint64_t protect_score, const void* keys, int64_t num_keys, const int64_t* offsets,
+                          int64_t num_bags, int64_t batch_size, uint64_t score_value, uint64_t timer_override, void* out,
+                          void* step_buf, int64_t step_bytes, int* state, hipStream_t fork_from, int slot, hipStream_t stream) {
+  DembPlan* p = (DembPlan*)plan;
+  MI355_CHECK_ARG(p && stage >= 0 && stage <= 2 && slot >= -1 && slot < 4, "plan stage: stage 0..2, slot -1..3");
+  if (slot >= 0 && stage != 0) {
+    if (!p->ev_fork[slot]) {
+      if (hipEventCreateWithFlags(&p->ev_fork[slot], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&p->ev_done[slot], hipEventDisableTiming) != hipSuccess) {
+        mi355_set_error("plan stage: event creation failed");
+        return MI355_ELAUNCH;
+      }
+    }
+    if (stage == 1 && fork_from != stream) {
+      if (hipEventRecord(p->ev_fork[slot], fork_from) != hipSuccess || hipStreamWaitEvent(stream, p->ev_fork[slot], 0) != hipSuccess) {
+        mi355_set_error("plan stage: fork failed");
+        return MI355_ELAUNCH;
+      }
+    }
+    if (stage == 2 && hipStreamWaitEvent(stream, p->ev_done[slot], 0) != hipSuccess) {
+      mi355_set_error("plan stage: join failed");
+      return MI355_ELAUNCH;
+    }
+  }
+  mi355i_fused_stage(stage, protect_score);
+  const int rc = mi355_demb_plan_forward(plan, keys, num_keys, offsets, num_bags, batch_size, score_value, timer_override, out, step_buf,
+                                         step_bytes, state, stream);
+  mi355i_fused_stage(0, ~0ull);
+  if (rc == 0 && stage == 1 && slot >= 0 && hipEventRecord(p->ev_done[slot], stream) != hipSuccess) {
+    mi355_set_error("plan stage: mark failed");
+    return MI355_ELAUNCH;
+  }
+  return rc;
 }
 
 // Backward of the step whose forward went through mi355_demb_plan_forward on the same buffer (prepared: 1 when that forward

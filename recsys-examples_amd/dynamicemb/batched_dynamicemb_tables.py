@@ -425,6 +425,11 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         from collections import deque
 
         self._prefetch_states = deque()
+        # round 6: prefetch on the partitioned index path (mi355_demb_plan_stage).  Scores of the steps in flight (forward or
+        # prefetch issued, backward not yet): an eviction spares every slot that scores at least the smallest of them
+        self._inflight = weakref.WeakKeyDictionary()
+        self._pf_c_used = False
+        self._clock0 = None
         self._tier_prefetched = 0      # prefetched batches of the tier / admission paths whose backward has not run yet
         self._orphan_pins = []         # pins of steps that died without a backward (released at the next call)
         self._grow_deferred = False    # a growth that had to wait for live / prefetched steps (retried after a backward)
@@ -495,6 +500,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             st = self._prefetch_states.popleft()
             if st.num_keys != indices.numel() or st.num_bags != offsets.numel() - 1:
                 raise RuntimeError("forward() received a batch that was not the oldest prefetched one")
+            if getattr(st, "staged", False):
+                return self._plan_gather_staged(st), st
             return self._gather_prefetched(st), st
         if self.storage_mode == "hybrid":
             return self._forward_hybrid(indices, offsets, train, prefetch_only)
@@ -757,6 +764,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         self._plan_custom_score = self._score_strategy == DynamicEmbScoreStrategy.CUSTOMIZED
         self._plan_al_g = al
         self._plan_fwd = L.mi355_demb_plan_forward
+        self._plan_stage = L.mi355_demb_plan_stage
+        self._plan_recency = self._score_strategy in (DynamicEmbScoreStrategy.STEP, DynamicEmbScoreStrategy.TIMESTAMP)
         self._plan_bwd = L.mi355_demb_plan_backward
         return self._plan
 
@@ -783,22 +792,31 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         sval = self._step if self._plan_step_score else (self._custom_score if self._plan_custom_score else 0)
         s_ = _raw_stream(_cur_device())
         rc = 1
-        if buf is not None:
-            rc = self._plan_fwd(plan, indices.data_ptr(), n, offsets.data_ptr(), num_bags, B, sval, ext.TIMER_OVERRIDE, out.data_ptr(),
-                                buf.data_ptr(), buf.numel(), self._plan_state_ref, s_)
-        if rc == 1:      # no ring slot free (more steps outstanding than the ring holds), or the slot's buffer is too small
-            need = lib().mi355_demb_plan_step_bytes(plan, n)
-            if ring is not None:
-                buf = self._step_ring[ring[1]] = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=self.device_)
-            else:
-                buf = torch.empty(need, dtype=torch.uint8, device=self.device_)
-            rc = self._plan_fwd(plan, indices.data_ptr(), n, offsets.data_ptr(), num_bags, B, sval, ext.TIMER_OVERRIDE, out.data_ptr(),
-                                buf.data_ptr(), buf.numel(), self._plan_state_ref, s_)
+        if not self._pf_c_used:
+            if buf is not None:
+                rc = self._plan_fwd(plan, indices.data_ptr(), n, offsets.data_ptr(), num_bags, B, sval, ext.TIMER_OVERRIDE,
+                                    out.data_ptr(), buf.data_ptr(), buf.numel(), self._plan_state_ref, s_)
+            if rc == 1:      # no ring slot free (more steps outstanding than the ring holds), or the slot's buffer is too small
+                need = lib().mi355_demb_plan_step_bytes(plan, n)
+                if ring is not None:
+                    buf = self._step_ring[ring[1]] = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=self.device_)
+                else:
+                    buf = torch.empty(need, dtype=torch.uint8, device=self.device_)
+                rc = self._plan_fwd(plan, indices.data_ptr(), n, offsets.data_ptr(), num_bags, B, sval, ext.TIMER_OVERRIDE,
+                                    out.data_ptr(), buf.data_ptr(), buf.numel(), self._plan_state_ref, s_)
+            score = None
+        else:
+            # this module prefetches on the partitioned path: a plain forward between prefetched ones takes part in the eviction
+            # limit like them (its keys score >= `score`; its own evictions spare the steps in flight)
+            score, timer = self._step_score(sval, exact=False)
+            buf, rc = self._plan_stage_call(plan, 0, indices, n, offsets, num_bags, B, sval, ext.TIMER_OVERRIDE, out, buf, ring, s_)
         if rc != 0:
             if ring is not None:
                 ring[0][ring[1]] = False
             check(rc, "demb_plan_forward")
         st = _PlanStep(self, buf, n, self.num_tables, ring, offsets, B, num_bags)
+        if score is not None:
+            self._inflight[st] = score
         tok = self._plan_state.value
         if tok <= -2:            # path (c): lazy reverse indices; -(2 + epoch) names the step's overflow notice (settle())
             st.lazy = True
@@ -807,6 +825,122 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         st.prepared = 1 if n > 0 else 0
         object.__setattr__(self, "_step", self._step + 1)   # (nn.Module.__setattr__ runs its Parameter / Module checks per assignment)
         return out, st
+
+    # ---- round 6: the prefetch pipeline on the partitioned index path (reference: BatchedDynamicEmbeddingTablesV2.prefetch,
+    # batched_dynamicemb_tables.py:1090-1137, driven by PrefetchTrainPipelineSparseDist, train_pipeline.py:533-692).  prefetch(k+1)
+    # runs the INDEX STAGE of batch k+1 (probe + partition kernel: table mutations, row addresses, the backward's CSR) on the
+    # caller's side stream under the backward of batch k; forward(k+1) is the gather alone.  The reference pins the rows of a
+    # prefetched batch with a ref-counter atomic per key so that a later prefetch cannot evict them; with recency scores (STEP,
+    # TIMESTAMP) the same guarantee costs nothing: every key of a step in flight scores at least that step's score, and an
+    # eviction takes only slots that score below the oldest of them (FusedArgs::protect).  Other score policies, tiny batches
+    # and every non-default configuration keep the pinning prefetch.
+    def _device_clock_now(self) -> int:
+        """the device's score clock (100 MHz ticks) estimated on the host: read once with a sync, then extrapolated"""
+        import time
+
+        if self._clock0 is None:
+            self._clock0 = (ext.device_timestamp(), time.monotonic_ns())
+        d0, h0 = self._clock0
+        return d0 + (time.monotonic_ns() - h0) // 10
+
+    def _step_score(self, sval, exact: bool):
+        """-> (score every key of the step is guaranteed to reach, timer override for the step's kernels).  STEP: the step number.
+        TIMESTAMP: a staged step stamps its keys with the host's estimate of the device clock (exact); a plain forward reads the
+        clock on the device when it runs -- not before the estimate taken now, minus a margin for the calibration (1 ms)."""
+        if self._plan_step_score:
+            return sval, ext.TIMER_OVERRIDE
+        if ext.TIMER_OVERRIDE:
+            return ext.TIMER_OVERRIDE, ext.TIMER_OVERRIDE
+        now = self._device_clock_now()
+        return (now, now) if exact else (now - 100_000, 0)
+
+    def _plan_stage_call(self, plan, stage, indices, n, offsets, num_bags, B, sval, timer, out, buf, ring, s_, fork_from=None, slot=-1):
+        protect = min(self._inflight.values(), default=0xFFFFFFFFFFFFFFFF)
+        op = out.data_ptr() if out is not None else None
+        rc = 1
+        if buf is not None:
+            rc = self._plan_stage(plan, stage, protect, indices.data_ptr(), n, offsets.data_ptr(), num_bags, B, sval, timer, op,
+                                  buf.data_ptr(), buf.numel(), self._plan_state_ref, fork_from, slot, s_)
+        if rc == 1:
+            need = lib().mi355_demb_plan_step_bytes(plan, n)
+            if ring is not None:
+                buf = self._step_ring[ring[1]] = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=self.device_)
+            else:
+                buf = torch.empty(need, dtype=torch.uint8, device=self.device_)
+            rc = self._plan_stage(plan, stage, protect, indices.data_ptr(), n, offsets.data_ptr(), num_bags, B, sval, timer, op,
+                                  buf.data_ptr(), buf.numel(), self._plan_state_ref, fork_from, slot, s_)
+        return buf, rc
+
+    def _plan_prefetch(self, indices, offsets, side=None):
+        """index stage of a later batch on the current stream -- or, side given, on that stream behind what the current one
+        holds, ordered by the library's own events --; None: not a batch of the partitioned path"""
+        plan = self._plan
+        if plan is None or self._plan_key[0] != id(self.table):
+            self._plan_invalidate()
+            plan = self._plan_build()
+        if not self._plan_recency:
+            return None
+        n = indices.numel()
+        num_bags = offsets.numel() - 1
+        B = num_bags // self.feature_num
+        if lib().mi355_demb_forward_fused_partitions(n, self.num_tables, self.table.num_buckets_) <= 0:
+            return None
+        buf, ring = None, None
+        slot = self._bwd_ring_next % 4
+        if not self._bwd_busy[slot]:
+            object.__setattr__(self, "_bwd_ring_next", self._bwd_ring_next + 1)
+            buf = self._step_ring[slot]
+            self._bwd_busy[slot] = True
+            ring = (self._bwd_busy, slot)
+        sval = self._step if self._plan_step_score else 0
+        score, timer = self._step_score(sval, exact=True)
+        if side is not None and ring is None:
+            return None                  # (more steps outstanding than the ring holds: the caller's stream-managed prefetch)
+        self._pf_c_used = True
+        cur = _raw_stream(_cur_device())
+        if side is None:
+            buf, rc = self._plan_stage_call(plan, 1, indices, n, offsets, num_bags, B, sval, timer, None, buf, ring, cur)
+        else:
+            if buf is None:              # first use of the slot: allocate here, on the caller's stream, not inside the staged call
+                need = lib().mi355_demb_plan_step_bytes(plan, n)
+                buf = self._step_ring[ring[1]] = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=self.device_)
+            buf, rc = self._plan_stage_call(plan, 1, indices, n, offsets, num_bags, B, sval, timer, None, buf, ring, side.cuda_stream,
+                                            fork_from=cur, slot=ring[1])
+        if rc != 0:
+            if ring is not None:
+                ring[0][ring[1]] = False
+            if rc == 3:          # nothing was launched: not eligible after all (long bags, fp16 rows ...)
+                return None
+            check(rc, "demb_plan_stage")
+        st = _PlanStep(self, buf, n, self.num_tables, ring, offsets, B, num_bags)
+        tok = self._plan_state.value
+        st.lazy = True
+        st.epoch = -2 - tok if tok < -2 else 0
+        st.indices, st.sval, st.timer = indices, sval, timer
+        st.staged = True
+        st.ev_slot = ring[1] if side is not None else -1
+        st.prepared = 1 if n > 0 else 0
+        self._inflight[st] = score
+        object.__setattr__(self, "_step", self._step + 1)
+        return st
+
+    def _plan_gather_staged(self, st):
+        """forward of a batch whose index stage ran in prefetch(): the gather alone, on the current stream"""
+        if st.event is not None:
+            current_torch_stream().wait_event(st.event)
+        if st.ring is None and st.event is not None:
+            st.buf.record_stream(current_torch_stream())      # (a buffer outside the module's ring: allocated under the prefetch stream)
+        n = st.num_keys
+        if self._plan_pooled:
+            out = torch.empty(st.batch_size, self.total_D, dtype=self.output_dtype, device=self.device_)
+        else:
+            out = torch.empty(n, self.dims[0], dtype=self.output_dtype, device=self.device_)
+        rc = self._plan_stage(self._plan, 2, 0xFFFFFFFFFFFFFFFF, st.indices.data_ptr(), n, st.offsets.data_ptr(), st.num_bags,
+                              st.batch_size, st.sval, st.timer, out.data_ptr(), st.buf.data_ptr(), st.buf.numel(),
+                              self._plan_state_ref, None, st.ev_slot, _raw_stream(_cur_device()))
+        if rc != 0:
+            check(rc, "demb_plan_stage(gather)")
+        return out
 
     def _plan_backward(self, st, grads):
         if not grads.is_contiguous():
@@ -826,6 +960,8 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
                                 int(self._plan_al_g and grads.stride(0) % 4 == 0), self.learning_rate, self.beta1, self.beta2,
                                 self.eps, self.weight_decay, self._iter_num, 1, 0, s_)
         st.epoch = 0
+        if self._pf_c_used:
+            self._inflight.pop(st, None)
         if rc != 0:
             check(rc, "demb_plan_backward")
         st.prepared = 0
@@ -1329,7 +1465,13 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         only gathers."""
         if not self.training:
             return
-        _, st = self._forward_impl(indices, offsets, train=True, prefetch_only=True)
+        st = None
+        if (self._plan_ok and not self._pin and not self._orphan_pins and indices.dtype is torch.int64
+                and offsets.dtype is torch.int64 and indices.is_contiguous() and offsets.is_contiguous() and indices.is_cuda
+                and os.environ.get("MI355_PREFETCH_C", "1") != "0"):
+            st = self._plan_prefetch(indices, offsets)
+        if st is None:
+            _, st = self._forward_impl(indices, offsets, train=True, prefetch_only=True)
         st.event = torch.cuda.Event()
         st.event.record(current_torch_stream())
         st.indices = indices   # keeps the key tensor alive until the forward
@@ -1340,6 +1482,31 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
             self._record_step_on(st, forward_stream)
             if isinstance(indices, torch.Tensor) and indices.is_cuda:
                 indices.record_stream(forward_stream)
+        self._prefetch_states.append(st)
+
+    def prefetch_async(self, indices: torch.Tensor, offsets: torch.Tensor) -> None:
+        """prefetch() on the module's own prefetch stream, ordered behind what the CURRENT stream holds at the call (the batch,
+        and the backward whose rows must be final before an eviction may recycle one) -- the fork, the end-of-stage mark and the
+        wait of the later forward are library-owned events, no stream context is switched on the host.  Call it where the
+        reference's pipeline calls prefetch: after forward(batch k) has been issued, before backward(batch k)."""
+        if not self.training:
+            return
+        side = self.__dict__.get("_pf_stream")
+        if side is None:
+            side = torch.cuda.Stream(device=self.device_)
+            object.__setattr__(self, "_pf_stream", side)
+        st = None
+        if (self._plan_ok and not self._pin and not self._orphan_pins and indices.dtype is torch.int64
+                and offsets.dtype is torch.int64 and indices.is_contiguous() and offsets.is_contiguous() and indices.is_cuda
+                and os.environ.get("MI355_PREFETCH_C", "1") != "0"):
+            st = self._plan_prefetch(indices, offsets, side)
+        if st is None:                  # not a batch of the partitioned path: the stream-managed form
+            cur = current_torch_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self.prefetch(indices, offsets, forward_stream=cur)
+            return
+        st.event = None
         self._prefetch_states.append(st)
 
     def _gather_prefetched(self, st):

@@ -118,6 +118,7 @@ _SIGS = {
     "mi355_demb_step_layout": [c_i64, c_i64, c_i64, c_int, c_p],
     "mi355_demb_plan_step_bytes": [c_p, c_i64],
     "mi355_demb_plan_forward": [c_p, c_p, c_i64, c_p, c_i64, c_i64, c_u64, c_u64, c_p, c_p, c_i64, c_p, c_p],
+    "mi355_demb_plan_stage": [c_p, c_int, c_u64, c_p, c_i64, c_p, c_i64, c_i64, c_u64, c_u64, c_p, c_p, c_i64, c_p, c_p, c_int, c_p],
     "mi355_demb_plan_backward": [c_p, c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_int, c_int,
                                  c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_p],
     "mi355_demb_plan_rerun": [c_p, c_p, c_i64, c_p, c_i64, c_i64, c_u64, c_u64, c_p, c_i64, c_int, c_p],

@@ -406,6 +406,91 @@ def test_dump_load_wire_format_roundtrip(tmp_path, optimizer, strategy):
     torch.testing.assert_close(r1[sel][:, :dims[0]], r2[sel][:, :dims[0]], rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("api", ["prefetch", "prefetch_async"])
+@pytest.mark.parametrize("strategy,pooling,cap", [("STEP", "SUM", 1 << 20), ("TIMESTAMP", "SUM", 1 << 20), ("STEP", "NONE", 1 << 20),
+                                                   ("STEP", "SUM", 1 << 17)])
+def test_prefetch_one_batch_ahead_on_the_partitioned_index_path_matches_plain_training(api, strategy, pooling, cap):
+    """Round 6: batches of the partitioned index path (>= 64 K keys, one table) are prefetched on it -- stage 1 (probe + partition
+    kernel) in prefetch(), the gather alone in forward(); no ref-counter pin: evictions spare every slot that scores at least the
+    oldest step in flight.  Same order as the test above (prefetch(k + 1) before backward(k)): outputs and final rows equal plain
+    forward / backward; `prefetch_async` is the form with library-owned stream ordering.  cap = 1 << 17: the table is smaller than
+    the key space, buckets fill up and the partition kernel evicts while batches are in flight."""
+    from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
+    from dynamicemb.dynamicemb_config import (DynamicEmbInitializerArgs, DynamicEmbInitializerMode, DynamicEmbPoolingMode,
+                                              DynamicEmbScoreStrategy, DynamicEmbTableOptions, EmbOptimType)
+
+    rng = np.random.default_rng(5)
+    torch.manual_seed(5)
+    pm = DynamicEmbPoolingMode.SUM if pooling == "SUM" else DynamicEmbPoolingMode.NONE
+    hi = 150_000 if cap == 1 << 20 else 400_000
+
+    def make():
+        opt = DynamicEmbTableOptions(dim=16, max_capacity=cap, index_type=torch.int64, embedding_dtype=torch.float32,
+                                     score_strategy=getattr(DynamicEmbScoreStrategy, strategy),
+                                     initializer_args=DynamicEmbInitializerArgs(mode=DynamicEmbInitializerMode.DEBUG))
+        m = BatchedDynamicEmbeddingTablesV2([opt], pooling_mode=pm, output_dtype=torch.float32, optimizer=EmbOptimType.SGD,
+                                            learning_rate=0.05, device=torch.device("cuda", 0))
+        m.train()
+        return m
+
+    batches = []
+    for _ in range(5):
+        lens = rng.integers(1, 8, 20_000)
+        off = np.zeros(lens.size + 1, np.int64)
+        off[1:] = np.cumsum(lens)
+        keys = (rng.zipf(1.3, off[-1]) % hi).astype(np.int64)
+        if pooling == "NONE":
+            off = np.arange(off[-1] + 1, dtype=np.int64)
+        batches.append((torch.from_numpy(keys).cuda(), torch.from_numpy(off).cuda()))
+    assert all(k.numel() >= 65_536 for k, _ in batches)
+    plain, piped = make(), make()
+    grads, outs_plain = [], []
+    for k, o in batches:
+        out, st = plain._forward_impl(k, o, train=True)
+        g = torch.randn_like(out)
+        grads.append(g)
+        outs_plain.append(out)
+        plain._backward_impl(st, g)
+    side = torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+
+    def pf(i):
+        if api == "prefetch_async":
+            piped.prefetch_async(*batches[i])
+        else:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                piped.prefetch(*batches[i], forward_stream=main)
+
+    pf(0)
+    for i, (k, o) in enumerate(batches):
+        assert getattr(piped._prefetch_states[0], "staged", False), "the batch was not prefetched on the partitioned path"
+        out, st = piped._forward_impl(k, o, train=True)       # consumes the prefetched state: the gather alone
+        if i + 1 < len(batches):
+            pf(i + 1)                                          # runs ahead of this batch's backward
+        # (two runs of the partitioned path sum a row's gradients in the order their records were reserved: fp32 rows differ
+        #  by an ulp or two between ANY two runs, the rows here are as large as 1e5)
+        torch.testing.assert_close(out, outs_plain[i], rtol=1e-5, atol=1e-4)
+        piped._backward_impl(st, grads[i])
+        main.wait_stream(side)
+    torch.cuda.synchronize()
+    assert piped._pf_c_used and not piped._prefetch_states and len(piped._inflight) == 0
+    assert int(piped.size()) == int(plain.size())
+    probe = torch.arange(0, hi, device="cuda", dtype=torch.int64)
+    f1, r1 = plain.lookup_rows(probe, 0)
+    f2, r2 = piped.lookup_rows(probe, 0)
+    if cap == 1 << 20:
+        assert torch.equal(f1, f2)
+        torch.testing.assert_close(r2, r1, rtol=1e-5, atol=1e-4)
+    else:
+        # evictions: which of two equal-score victims goes may differ between the schedules (the prefetch spares the rows of
+        # the step in flight); every key both tables hold has the same row
+        both = f1 & f2
+        assert int(both.sum()) > 0.8 * min(int(f1.sum()), int(f2.sum()))
+        torch.testing.assert_close(r2[both], r1[both], rtol=1e-5, atol=1e-4)
+    assert int(piped.table._ref_counter.abs().sum()) == 0
+
+
 @pytest.mark.parametrize("pooling", ["SUM", "NONE"])
 def test_prefetch_one_batch_ahead_matches_plain_training(pooling):
     """prefetch(batch i+1) on a side stream before backward(batch i) (PrefetchTrainPipelineSparseDist's order,

@@ -1,6 +1,7 @@
 """C2 step with the prefetch pipeline (the reference's PrefetchTrainPipelineSparseDist order: the index stage of batch k + 1
 is issued on a side stream before the backward of batch k) against the serial step, same module, same batches.
-    python tools/pipeline_step.py [--steps 200]"""
+    python tools/pipeline_step.py [--steps 200]
+MI355_PREFETCH_C=0 keeps the pinning prefetch (per-slot counters + ref-counter atomics) for comparison."""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "recsys-examples_amd")); sys.path.insert(0, ROOT)
@@ -26,35 +27,10 @@ nb = len(batches)
 def serial(steps):
     for i in range(steps):
         k, o = batches[i % nb]
-        out, st = module._forward_impl(k, o, train=True)
-        module._backward_impl(st, grad)
+        out = module(k, o)
+        out.backward(grad)
 
 
-def pipelined(steps, side):
-    main = torch.cuda.current_stream()
-    module.prefetch(*batches[0])
-    for i in range(steps):
-        k, o = batches[i % nb]
-        out, st = module._forward_impl(k, o, train=True)      # consumes the prefetched state: gather only
-        side.wait_stream(main)                                 # the side stream sees the table as of this point
-        with torch.cuda.stream(side):
-            module.prefetch(*batches[(i + 1) % nb])
-        module._backward_impl(st, grad)
-    # drain the last prefetched state
-    out, st = module._forward_impl(*batches[steps % nb], train=True)
-    module._backward_impl(st, grad)
-
-
-def timeit(fn, steps, *args):
-    fn(20, *args)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    fn(steps, *args)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps * 1e3
-
-
-print("serial    %.4f ms/step" % timeit(serial, a.steps))
-side = torch.cuda.Stream()
-print("pipelined %.4f ms/step" % timeit(pipelined, a.steps, side))
-print("serial    %.4f ms/step" % timeit(serial, a.steps))
+print("serial    %.4f ms/step" % bench.timed_loop(serial, a.steps))
+print("pipelined %.4f ms/step  (staged on the partitioned path: %s)" % (bench.pipelined_ms(module, batches, grad, a.steps), module._pf_c_used))
+print("serial    %.4f ms/step" % bench.timed_loop(serial, a.steps))
