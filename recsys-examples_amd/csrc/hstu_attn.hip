@@ -330,6 +330,96 @@ __device__ __forceinline__ void add_func_row(f32x16_t (&acc)[NT], const AttnArgs
       if (key < L) acc[t][rr] += ((ok[t] >> rr) & 1u) ? 0.f : a.func_neg;
     }
 }
+// ---- `func` masks: tile skipping (round 6).  The reference derives the key blocks a query block can reach from the extents of
+// its rows' functions before the tile loop and visits only those (hstu_fwd.h:80-83, 139-151, 228-291, 411-412: sValidBlockIds /
+// sn_valid_block_max).  Here: what a group of query rows reaches = the prefix [0, f0) (largest first bound of the group) and the
+// hull [lo, hi) of every band of every row; a key tile that meets neither is skipped.  Conservative (a hull may cover a gap
+// between two bands) and exact in its effect: a skipped tile's P is all zero.
+struct FuncExt { int f0, lo, hi, f0min; };   // lo >= hi: no band; f0min: the SMALLEST prefix of the group -- keys below it are seen by every row
+__device__ __forceinline__ FuncExt func_ext_row(const AttnArgs& a, int h, int64_t tok, bool live, int free_below) {
+  FuncExt e{0, 0x7fffffff, 0, 0x7fffffff};
+  if (!live) return e;
+  const int32_t* ft = a.func + (int64_t)h * a.func_h + tok;
+  const int f0 = ft[0];
+  e.f0 = f0 > free_below ? f0 : free_below;
+  e.f0min = e.f0;
+  for (int p = 1; p + 1 < a.n_func; p += 2) {
+    const int lo = ft[p * a.func_p], up = ft[(p + 1) * a.func_p];
+    if (lo < up) { e.lo = lo < e.lo ? lo : e.lo; e.hi = up > e.hi ? up : e.hi; }
+  }
+  return e;
+}
+__device__ __forceinline__ FuncExt func_ext_merge(const FuncExt& x, const FuncExt& y) {
+  return FuncExt{x.f0 > y.f0 ? x.f0 : y.f0, x.lo < y.lo ? x.lo : y.lo, x.hi > y.hi ? x.hi : y.hi, x.f0min < y.f0min ? x.f0min : y.f0min};
+}
+// over the 32 rows of a wave (lane & 31 = row, both halves hold the same rows)
+__device__ __forceinline__ FuncExt func_ext_wave(FuncExt e) {
+#pragma unroll
+  for (int off = 1; off < 32; off <<= 1) {
+    FuncExt o{__shfl_xor(e.f0, off, 64), __shfl_xor(e.lo, off, 64), __shfl_xor(e.hi, off, 64), __shfl_xor(e.f0min, off, 64)};
+    e = func_ext_merge(e, o);
+  }
+  return e;
+}
+__device__ __forceinline__ bool func_ext_hits(const FuncExt& e, int n0, int n1) { return n0 < e.f0 || (e.lo < n1 && e.hi > n0); }
+__device__ __forceinline__ int func_ext_end(const FuncExt& e) { return e.f0 > e.hi ? e.f0 : e.hi; }                    // keys from here on: unseen
+__device__ __forceinline__ int func_ext_begin(const FuncExt& e) { return e.f0 > 0 ? 0 : (e.lo < e.hi ? e.lo : 0x7fffffff); }   // keys below: unseen
+// block-wide merge of the waves' extents (NW waves; one barrier; `slot` = 3 * NW ints of LDS)
+template <int NW>
+__device__ __forceinline__ FuncExt func_ext_block(const FuncExt& wx, int wv, int lane, int* slot) {
+  if (lane == 0) { slot[3 * wv] = wx.f0; slot[3 * wv + 1] = wx.lo; slot[3 * wv + 2] = wx.hi; }
+  __syncthreads();
+  FuncExt bx{slot[0], slot[1], slot[2], 0};
+#pragma unroll
+  for (int w = 1; w < NW; ++w) bx = func_ext_merge(bx, FuncExt{slot[3 * w], slot[3 * w + 1], slot[3 * w + 2], 0});
+  return bx;
+}
+// index of key block n0 / 128 of sequence b in the per-key-block table of the backward (hstu_func_kvis_kernel): sequences start at
+// arbitrary tokens, floor(start / 128) + b leaves every sequence ceil(L / 128) slots of its own
+__device__ __forceinline__ int64_t func_kvis_index(int start, int b, int n0) { return (int64_t)(start >> 7) + b + (n0 >> 7); }
+
+// For the key-major passes of the backward: per (function set, sequence, 128-key block) the range of query rows [first, last) that
+// reach the block (multiples of 32; first >= last: nobody does).  One block per (sequence, function set): the extents of the
+// sequence's 32-row groups in LDS, then one thread per key block walks them.
+// gext (second table, 4 x as many entries): the extents {smallest prefix, largest prefix, band hull lo, hi} of every 32-row group,
+// entry floor(start / 32) + b + group -- a key-major step asks it whether its tile needs the per-element test at all.
+__device__ __forceinline__ int64_t func_gext_index(int start, int b, int row) { return (int64_t)(start >> 5) + b + (row >> 5); }
+__global__ void __launch_bounds__(256)
+hstu_func_kvis_kernel(AttnArgs a, int nfh, int2* __restrict__ kvis, int64_t kvis_h, int4* __restrict__ gext) {
+  extern __shared__ int s_ext[];      // [4][ng]
+  const int b = blockIdx.x, fh = blockIdx.y;
+  const int start = a.cu_seqlens[b], L = a.cu_seqlens[b + 1] - start;
+  const int ng = (L + 31) >> 5, nkb = (L + 127) >> 7;
+  int* e_f0 = s_ext; int* e_lo = s_ext + ng; int* e_hi = s_ext + 2 * ng; int* e_fm = s_ext + 3 * ng;
+  for (int g = threadIdx.x; g < ng; g += blockDim.x) { e_f0[g] = 0; e_lo[g] = 0x7fffffff; e_hi[g] = 0; e_fm[g] = 0x7fffffff; }
+  __syncthreads();
+  const int c = a.num_contexts ? a.num_contexts[b] : 0;
+  const int hlen = L - (a.num_targets ? a.num_targets[b] : 0);
+  for (int r = threadIdx.x; r < L; r += blockDim.x) {
+    const FuncExt e = func_ext_row(a, fh, (int64_t)start + r, true, (a.num_contexts && r < c) ? hlen : 0);
+    atomicMax(&e_f0[r >> 5], e.f0);
+    atomicMin(&e_lo[r >> 5], e.lo);
+    atomicMax(&e_hi[r >> 5], e.hi);
+    atomicMin(&e_fm[r >> 5], e.f0min);
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < ng; g += blockDim.x) {
+    const int64_t idx = func_gext_index(start, b, g << 5);
+    if (idx < 4 * kvis_h) gext[(int64_t)fh * 4 * kvis_h + idx] = make_int4(e_fm[g], e_f0[g], e_lo[g], e_hi[g]);
+  }
+  for (int kb = threadIdx.x; kb < nkb; kb += blockDim.x) {
+    const int k0 = kb << 7, k1 = k0 + 128;
+    int first = 0x7fffffff, last = 0;
+    for (int g = 0; g < ng; ++g) {
+      const FuncExt e{e_f0[g], e_lo[g], e_hi[g], 0};
+      if (func_ext_hits(e, k0, k1)) { first = first < (g << 5) ? first : (g << 5); last = (g + 1) << 5; }
+    }
+    const int64_t idx = func_kvis_index(start, b, k0);
+    if (idx < kvis_h) kvis[(int64_t)fh * kvis_h + idx] = make_int2(first, last);
+  }
+  (void)nfh;
+}
+
 // dS = dP * (alpha / N) * SiLU'(x), x = alpha * acc, sg = sigmoid(x).  One statement of the roundings for every kernel that
 // forms dS (the dK pass and the recomputing dQ pass must agree bit for bit with each other and with the exchanged dS):
 // contraction is switched off and the one fused step is spelled out, so that the code around a call site cannot change it.
@@ -458,7 +548,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
     if (s.has_ctx && dq + m0 < s.c && s.hlen > n_end) n_end = s.hlen;
   }
   if (kWin) n_end = band_key_end(a, last_row, n_end);
-  const int n_beg = kWin ? band_key_begin(a, dq + m0, kBN) : 0;
+  int n_beg = kWin ? band_key_begin(a, dq + m0, kBN) : 0;
   // the wave's own reach (skips MFMA work on tiles past it)
   int w_last = dq + (qrow0 + 31 < Lq - 1 ? qrow0 + 31 : Lq - 1);
   int w_end = s.L;
@@ -467,7 +557,21 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
     if (s.has_ctx && dq + qrow0 < s.c && s.hlen > w_end) w_end = s.hlen;
   }
   if (kWin) w_end = band_key_end(a, w_last, w_end);
-  const int w_beg = kWin ? band_key_begin(a, dq + qrow0, kBN) : 0;
+  int w_beg = kWin ? band_key_begin(a, dq + qrow0, kBN) : 0;
+  // `func` masks: the key tiles the block / the wave can reach at all, from the extents of their rows' functions
+  FuncExt wx{0x7fffffff, 0, 0x7fffffff, 0};       // (no functions: every tile "hits"; with functions and no skipping: no tile is "full")
+  if constexpr (kRab) {
+    if (a.func && a.wskip) {
+      __shared__ int s_fx[3 * 4];
+      wx = func_ext_wave(func_ext_row(a, h, (int64_t)s.start + qloc, qloc < Lq, (s.has_ctx && qi < s.c) ? s.hlen : 0));
+      const FuncExt bx = func_ext_block<4>(wx, wv, lane, s_fx);
+      const int be = func_ext_end(bx), bb = func_ext_begin(bx), we = func_ext_end(wx), wb = func_ext_begin(wx);
+      if (be < n_end) n_end = be;
+      if (we < w_end) w_end = we;
+      if (bb > n_beg) n_beg = bb >= n_end ? n_end : (bb / kBN) * kBN;
+      if (wb > w_beg) w_beg = wb >= 0x7fffff00 ? 0x7fffff00 : (wb / kBN) * kBN;
+    }
+  }
 
   // ---- Q fragments (B operand of GEMM 1): lane = (query l31, k half hi), 8 consecutive d per 16-slice
   bf16x8_t qf[QLDS ? 1 : D / 16];
@@ -678,6 +782,7 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
     }
     pin_agpr(acc_o);
     if (!wave_live || n0 >= w_end || n0 < w_beg) continue;
+    if constexpr (kRab) { if (!func_ext_hits(wx, n0, n0 + kBN)) continue; }     // (a gap between the prefix and the bands)
     TICK(t5);
 
     // ---- GEMM 1: S^T[64 keys x 32 q] = K Q^T, two 32-key tiles.  Operand fragments are fetched from LDS
@@ -717,8 +822,9 @@ __global__ void __launch_bounds__(256) hstu_fwd_kernel(AttnArgs a) {
     }
     fence_v(acc_s);
     if constexpr (kRab) {
-      if (a.func) add_func_row<2>(acc_s, a, h, (int64_t)s.start + qloc, qloc < Lq, n0, hi, s.L, (s.has_ctx && qi < s.c) ? s.hlen : 0);
-      else {
+      if (a.func) {     // (a tile below the smallest prefix of the wave's rows is seen by all of them: nothing to test)
+        if (n0 + kBN > wx.f0min) add_func_row<2>(acc_s, a, h, (int64_t)s.start + qloc, qloc < Lq, n0, hi, s.L, (s.has_ctx && qi < s.c) ? s.hlen : 0);
+      } else {
       const uint16_t* row = qi < s.L ? a.rab + (int64_t)b * a.rab_b + (int64_t)h * a.rab_h + (int64_t)qi * a.rab_r : nullptr;
       add_rab_row<2>(acc_s, row, n0, hi, s.L);
       }
@@ -2247,6 +2353,10 @@ struct BwdAttnArgs {
                                // are all zero, never written and never read (xch_absent)
   // d loss / d rab (hstu_api.cpp:659-667): [b][h][i][j] bf16, zero-filled by the caller; the dK pass writes dS there
   uint16_t* drab; int64_t drab_b, drab_h, drab_r;
+  // `func` masks (round 6): per (function set, 128-key block) the query rows [first, last) that reach the block
+  // (hstu_func_kvis_kernel, launched in front of the passes); NULL: every query tile is visited
+  const int2* func_kvis; int64_t func_kvis_h;
+  const int4* func_gext;       // per 32-row group: {smallest prefix, largest prefix, band hull}; 4 func_kvis_h entries per function set
 };
 // where a (sequence, head) unit's sub-tiles live: read ONCE per block (inside the step loops a load of the plan could not be
 // hoisted over the stores and cost a scalar-load latency per step: +27 % on a jagged batch)
@@ -2526,7 +2636,17 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
   // query tiles that can see this key block: the tiles holding contextual rows (they see all history keys), then
   // from the tile containing row n0 on (causal); everything (non causal)
   const KvSpan span = kv_span(a, s, n0, BQ);
-  const int jump = span.jump, c_end = span.c_end, i_lim = span.lim;
+  int jump = span.jump, c_end = span.c_end, i_lim = span.lim;
+  if constexpr (kRab) {
+    const int64_t kidx = func_kvis_index(s.start, b, n0);
+    if (a.func && g.func_kvis && kidx < g.func_kvis_h) {   // `func` masks: only the query tiles between the first and the last row that reach this key block
+      const int2 vis = g.func_kvis[(int64_t)(a.func_h ? h : 0) * g.func_kvis_h + kidx];
+      const int first = vis.x < vis.y ? (vis.x / BQ) * BQ : 0x7fffff00;
+      if (first > jump) jump = first;
+      if (vis.y < i_lim) i_lim = vis.y;
+      if (c_end > i_lim) c_end = i_lim;
+    }
+  }
   auto advance = [&](int i) { i += BQ; return (i >= c_end && i < jump) ? jump : i; };
   int i0 = c_end > 0 ? 0 : jump;
 
@@ -2622,7 +2742,21 @@ __global__ void __launch_bounds__(256) hstu_bwd_kv_kernel(BwdAttnArgs g) {
     TACC(4, t4, t5);
     if constexpr (kRab) {   // lane = key kj, registers = query rows: rab[qi][kj]
       if (a.func) {         // (the bounds of a query row are the same words for the 32 lanes of a half-wave: one transaction)
-        if (kj < s.L) {
+        // a step whose query rows all see every key of the block (the block lies below their smallest prefix) needs no test
+        bool func_full = false;
+        if (g.func_gext) {
+          const int64_t gi = func_gext_index(s.start, b, i0);
+          if (gi + NT <= 4 * g.func_kvis_h) {
+            int fmin = 0x7fffffff;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const int f = g.func_gext[(int64_t)(a.func_h ? h : 0) * 4 * g.func_kvis_h + gi + t].x;
+              fmin = f < fmin ? f : fmin;
+            }
+            func_full = n0 + kBM <= fmin;
+          }
+        }
+        if (kj < s.L && !func_full) {
 #pragma unroll
           for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -2833,7 +2967,20 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
   if (a.causal) { w_end = w_last + 1; if (s.has_ctx && qrow0 < s.c && s.hlen > w_end) w_end = s.hlen; }
   n_end = band_key_end(a, last_row, n_end);
   w_end = band_key_end(a, w_last, w_end);
-  const int n_beg = band_key_begin(a, m0, BK), w_beg = band_key_begin(a, qrow0, BK);
+  int n_beg = band_key_begin(a, m0, BK), w_beg = band_key_begin(a, qrow0, BK);
+  FuncExt wx{0x7fffffff, 0, 0x7fffffff, 0};       // (no functions: every tile "hits"; with functions and no skipping: no tile is "full")
+  if constexpr (kRab) {
+    if (a.func && a.wskip) {        // key tiles the block / the wave can reach, from the extents of their rows' functions (as in the forward)
+      __shared__ int s_fx[3 * 4];
+      wx = func_ext_wave(func_ext_row(a, h, (int64_t)s.start + qi, qi < s.L, (s.has_ctx && qi < s.c) ? s.hlen : 0));
+      const FuncExt bx = func_ext_block<4>(wx, wv, lane, s_fx);
+      const int be = func_ext_end(bx), bb = func_ext_begin(bx), we = func_ext_end(wx), wb = func_ext_begin(wx);
+      if (be < n_end) n_end = be;
+      if (we < w_end) w_end = we;
+      if (bb > n_beg) n_beg = bb >= n_end ? n_end : (bb / BK) * BK;
+      if (wb > w_beg) w_beg = wb >= 0x7fffff00 ? 0x7fffff00 : (wb / BK) * BK;
+    }
+  }
 
   // Q / dO fragments of the wave's 32 queries; rows beyond the sequence read a clamped row and are never stored
   bf16x8_t qf[D / 16], dof[D / 16];
@@ -2870,6 +3017,7 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
     if (kPre && n0 + BK < n_end) fetch_all(n0 + BK);
     pin_agpr(acc_dq);
     if (!wave_live || n0 >= w_end || n0 < w_beg) continue;
+    if constexpr (kRab) { if (!func_ext_hits(wx, n0, n0 + BK)) continue; }
     f32x16_t acc_s[NT], acc_p[NT];   // S^T, dP^T [keys x q]
     {
       constexpr int SLB = 4 / NT < D / 16 ? 4 / NT : D / 16;
@@ -2904,7 +3052,7 @@ __global__ void __launch_bounds__(256) hstu_bwd_q_kernel(BwdAttnArgs g) {
     fence_v(acc_s);
     fence_v(acc_p);
     if constexpr (kRab) {
-      if (a.func) add_func_row<NT>(acc_s, a, h, (int64_t)s.start + qi, qi < s.L, n0, hi, s.L, (s.has_ctx && qi < s.c) ? s.hlen : 0);
+      if (a.func) { if (n0 + BK > wx.f0min) add_func_row<NT>(acc_s, a, h, (int64_t)s.start + qi, qi < s.L, n0, hi, s.L, (s.has_ctx && qi < s.c) ? s.hlen : 0); }
       else {
       const uint16_t* row = qi < s.L ? a.rab + (int64_t)b * a.rab_b + (int64_t)h * a.rab_h + (int64_t)qi * a.rab_r : nullptr;
       add_rab_row<NT>(acc_s, row, n0, hi, s.L);
@@ -4076,7 +4224,8 @@ static thread_local int tl_wl = -1, tl_wr = -1;
 static thread_local int64_t tl_fwd_tokens = 0;
 // attention bias of the call in flight on this thread (set by the *_rab entry points)
 struct RabCall { const uint16_t* rab = nullptr; int64_t rb = 0, rh = 0, rr = 0; uint16_t* drab = nullptr; int64_t db = 0, dh = 0, dr = 0;
-                 const int32_t* func = nullptr; int64_t fh = 0, fp = 0; int nf = 0; float fneg = 0.f; };
+                 const int32_t* func = nullptr; int64_t fh = 0, fp = 0; int nf = 0; float fneg = 0.f;
+                 void* kvis = nullptr; int64_t kvis_bytes = 0; };   // (backward: room for the key-block table of the func masks)
 static thread_local RabCall tl_rab;
 static int block_rotation(int heads) {   // MI355_HSTU_ROT (A/B): see seq_head_of_block; default -H = by a sequence per rank, jagged batches only
   static const int v = [] { const char* e = getenv("MI355_HSTU_ROT"); return e ? atoi(e) : 0x7fffffff; }();
@@ -4317,7 +4466,23 @@ int HSTU_FN(mi355_hstu_attn_bwd)(const void* dout, const void* q, const void* k,
   g.ds_ws = nullptr; g.ng = (int)((max_seqlen + 31) / 32); g.bq_kv = 32;
   g.drab = tl_rab.drab; g.drab_b = tl_rab.db; g.drab_h = tl_rab.dh; g.drab_r = tl_rab.dr;
   g.plan_base = nullptr; g.plan_chunk = nullptr; g.chunk = 0;
+  g.func_kvis = nullptr; g.func_kvis_h = 0; g.func_gext = nullptr;
   const int64_t tokens_hint = mi355_hstu_attn_bwd_take_hint_();
+  if (a.func && tl_rab.kvis && a.wskip) {
+    // the query rows that reach every 128-key block, for the key-major passes (the query-major pass derives its reach in place)
+    // (table of total_tokens / 128 + batch + 1 entries per function set; a key block whose entry lies beyond the buffer is simply
+    //  not clipped -- both kernels check the index)
+    // layout: [gext: nfh x 4 slots int4 | kvis: nfh x slots int2] = 72 bytes per slot and function set
+    const int64_t nfh = a.func_h ? num_heads : 1;
+    const int64_t slots = tl_rab.kvis_bytes / 72 / nfh;
+    if (slots > 0 && ((uintptr_t)tl_rab.kvis & 15) == 0) {
+      const size_t sm = 4 * (size_t)((max_seqlen + 31) / 32) * sizeof(int);
+      int4* gext = (int4*)tl_rab.kvis;
+      int2* kvis = (int2*)(gext + nfh * 4 * slots);
+      hipLaunchKernelGGL(hstu_func_kvis_kernel, dim3((unsigned)batch, (unsigned)nfh), dim3(256), sm, stream, a, (int)nfh, kvis, slots, gext);
+      g.func_kvis = kvis; g.func_kvis_h = slots; g.func_gext = gext;
+    }
+  }
   int nchunks = 1;
   {
     const int64_t need = mi355_hstu_attn_bwd_ds_bytes(batch, num_heads, head_dim, max_seqlen);
@@ -4547,13 +4712,14 @@ int HSTU_FN(mi355_hstu_attn_bwd_func)(const void* dout, const void* q, const voi
                              const int32_t* num_contexts, const int32_t* num_targets, int64_t target_group_size,
                              int64_t window_left, int64_t window_right, float alpha, float scaling_seqlen, const int32_t* func,
                              int64_t func_head_stride, int64_t func_bound_stride, int64_t n_func, float func_neg,
-                             hipStream_t stream) {
+                             void* func_workspace, int64_t func_workspace_bytes, hipStream_t stream) {
   MI355_CHECK_ARG(func != nullptr && n_func >= 1 && (n_func & 1) == 1 && func_bound_stride > 0 && func_neg < 0.f,
                   "func must be int32 [heads or 1][n_func odd][tokens], func_neg negative");
   int causal = 0;
   if (const int rc = rab_mask(window_left, window_right, num_contexts, num_targets, &causal)) return rc;
   tl_rab = RabCall{};
   tl_rab.func = func; tl_rab.fh = func_head_stride; tl_rab.fp = func_bound_stride; tl_rab.nf = (int)n_func; tl_rab.fneg = func_neg;
+  tl_rab.kvis = func_workspace; tl_rab.kvis_bytes = func_workspace_bytes;
   const int rc = HSTU_FN(mi355_hstu_attn_bwd)(dout, q, k, v, dq, dk, dv, q_row_stride, k_row_stride, v_row_stride, do_row_stride,
                                      q_head_stride, k_head_stride, v_head_stride, do_head_stride, cu_seqlens, batch, num_heads,
                                      head_dim, max_seqlen, num_contexts, num_targets, target_group_size, causal, alpha,
