@@ -779,12 +779,12 @@ static int launch_bwd(BwdArgs a, OptArgs o, bool vec, hipStream_t stream) {
   const int per = vec ? 4 : 1;
   const int ncol = (a.D + (per << l) - 1) / (per << l);
   const int nsub = 64 >> l;
-  static const int hot_cap = getenv("MI355_HOT_BLOCKS") ? atoi(getenv("MI355_HOT_BLOCKS")) : 2048;   // tuning knob
+  constexpr int hot_cap = 2048;    // (swept in rounds 2-5, profiles/r05_bwd_hot_sweep.txt: the optimum at C2 and at the 16x batch)
   a.hot_blocks = a.hot.n_tasks ? (a.hot.max_tasks < hot_cap ? a.hot.max_tasks : hot_cap) : 0;
   const size_t smem = a.hot.n_tasks ? 4 * (size_t)a.D * sizeof(float) : 0;
   const int nb = ncol <= 1 ? PIPE_NB : (ncol <= 2 ? 2 : 1);
   a.wave_blocks = 0;
-  static const int wave_cap = getenv("MI355_WAVE_BLOCKS") ? atoi(getenv("MI355_WAVE_BLOCKS")) : 1024;   // tuning knob
+  constexpr int wave_cap = 1024;
   if (a.hot.n_tasks && a.hot.kwave > a.hot.khot) a.wave_blocks = a.hot.max_hot / 4 + 1 < wave_cap ? a.hot.max_hot / 4 + 1 : wave_cap;
   const int grid = a.hot_blocks + a.wave_blocks + grid_for(a.max_unique, 4 * nsub * nb * kBwdGroupsPerLaneGroup, 1 << 20);
 #define MI355_BWD_LAUNCH(NC, V) hipLaunchKernelGGL((bwd_kernel<WDT, GDT, NC, V, false>), dim3(grid), dim3(256), smem, stream, a, o, l)

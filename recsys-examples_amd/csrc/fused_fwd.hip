@@ -56,7 +56,7 @@ constexpr int kPartCap = 2048;      // (tile, key) records per partition
 constexpr int kPartSub = 4;         // sub-lists per partition (tile % kPartSub picks one): same-address atomics serialise at
                                     // ~40 ns each, 176 tiles on ONE counter per partition is a 7 us chain, on four 1.8 us
 constexpr int kSubCap = kPartCap / kPartSub;
-constexpr int kAuxHdr = 64 + 4096 * 4;     // (4 096 = kPartMaxBig partitions of the big-batch stage, round 5; 1 024 before)
+constexpr int kAuxHdr = 64 + 4096 * 4;     // (room for 4 096 partitions' sub-list counters: a layout constant of the aux buffer)
 // constexpr int kAuxHdr_r4 = 64 + kPartMax * 4;   // ints in front of the occ array: [0] deferred keys, [1..] grid barrier, [5] sticky
                                     // error flag of the partitioned stage, [64 + 4 p + r] records of sub-list r of partition p (zero between steps)
 
@@ -133,12 +133,7 @@ struct FusedArgs {
   // prefetch (increment_counter, batched_dynamicemb_function.py:559-696) without a counter atomic per key
   uint64_t protect;
   int tl;                         // probe_c_kernel (round 5): keys of a tile, a run-time value (<= the kernel's capacity, multiple of 64)
-  // big-batch stage (round 5, big_index.h): the probe kernel leaves its records TILE-MAJOR -- no reservation at all -- and a split
-  // kernel moves them into the partitions' lists; a per-record forwarding entry keeps the per-occurrence references valid
-  uint4* stage_rec;               // [n] records of tile t at [t * tl, t * tl + tile_cnt[t])
-  int32_t* tile_cnt;              // [tiles]
-  int32_t* fwd;                   // [n] staged record -> its place in `rec` (-1: the partition's list was full)
-  int cap;                        // records per partition of `rec` (kPartCap, or kPartCapBig in the big-batch stage)
+  int cap;                        // records per partition of `rec` (kPartCap)
   int32_t* part_ready;            // [P] (round 5, the partition blocks riding in the gather's launch): 1 once partition p's deferred keys
                                   // have their slots in the records (zeroed by the probe kernel; nullable)
 };
@@ -1151,352 +1146,6 @@ fused_mid_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, boo
   }
 }
 
-// ---- partitioned index stage, second kernel: ONE block per slot range ---------------------------------------------------
-// All (tile, key) records of a slot range meet in one block, so merging the records of a slot, ranking the tiles inside
-// the row's list, numbering the uniques and even evicting for the keys whose bucket was full are LDS work: no global
-// atomics, no per-slot scratch, no locks outside the block.  Only the two running sums (uniques, occurrences) cross
-// blocks -- one packed look-back word per partition.  Unique order: partition-major (= slot order), arbitrary inside.
-constexpr int kPartHash = 2 * kPartCap;          // LDS hash of the partition's slots
-constexpr int kPartItems = kPartCap / kScanThreads;
-
-__device__ __forceinline__ int part_hash_find(const int* h_slot, int slot) {   // -1: not present
-  int h = (int)((uint32_t)slot * 2654435761u >> 20) & (kPartHash - 1);
-  while (true) {
-    const int cur = h_slot[h];
-    if (cur == slot) return h;
-    if (cur == -1) return -1;
-    h = (h + 1) & (kPartHash - 1);
-  }
-}
-// claim or find the entry of `slot`; *claimed: this caller created it
-__device__ __forceinline__ int part_hash_insert(int* h_slot, int slot, bool* claimed) {
-  int h = (int)((uint32_t)slot * 2654435761u >> 20) & (kPartHash - 1);
-  *claimed = false;
-  while (true) {
-    const int cur = atomicCAS(&h_slot[h], -1, slot);
-    if (cur == -1) { *claimed = true; return h; }
-    if (cur == slot) return h;
-    h = (h + 1) & (kPartHash - 1);
-  }
-}
-
-__global__ void __launch_bounds__(kScanThreads)
-fused_part_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, bool build_hot) {
-  __shared__ int h_slot[kPartHash];       // slot of the entry (-1: free)
-  __shared__ int h_cnt[kPartHash];        // occurrences accumulated so far; at the end: all occurrences of the slot
-  __shared__ int h_lid[kPartHash];        // local unique id of the entry
-  __shared__ int l_cnt[kPartCap];         // occurrences by local unique id, then their exclusive prefix
-  constexpr int kDefMax = 512;            // deferred records handled per partition and step (more: served without a row)
-  __shared__ int d_rec[kDefMax];          // deferred records (bucket full) of the partition
-  __shared__ int d_ent[kDefMax], d_base[kDefMax];   // their hash entry / rank base once resolved
-  __shared__ int s_lock[256];             // bucket locks of the eviction (hashed)
-  __shared__ int s_nu, s_nd, s_tot, s_th, s_tt, s_tw;
-  const int p = blockIdx.x;
-  QST(0);
-  // the records come in kPartSub sub-lists of kSubCap; every load is issued unconditionally (the arrays are fully
-  // allocated), so the records are in flight together with their counts
-  int msub[kPartSub];
-#pragma unroll
-  for (int r = 0; r < kPartSub; ++r) msub[r] = a.pcount[p * kPartSub + r];
-  for (int i = threadIdx.x; i < kPartHash; i += kScanThreads) { h_slot[i] = -1; h_cnt[i] = 0; }
-  if (threadIdx.x < 256) s_lock[threadIdx.x] = 0;
-  if (threadIdx.x == 0) { s_nu = 0; s_nd = 0; s_tot = 0; s_th = 0; s_tt = 0; s_tw = 0; }
-  uint64_t ky[kPartItems];
-  int sl[kPartItems], cn[kPartItems], en[kPartItems], bs[kPartItems], dj[kPartItems];
-  bool mine[kPartItems];
-  bool live[kPartItems];
-#pragma unroll
-  for (int k = 0; k < kPartItems; ++k) {
-    const int idx = threadIdx.x + k * kScanThreads;
-    const int64_t r = (int64_t)p * kPartCap + idx;
-    const uint4 rc = a.rec[r];
-    ky[k] = ((uint64_t)rc.y << 32) | rc.x; sl[k] = (int)rc.z; cn[k] = (int)rc.w;
-    en[k] = -1; bs[k] = 0; dj[k] = -1; mine[k] = false;
-  }
-#pragma unroll
-  for (int k = 0; k < kPartItems; ++k) {
-    const int idx = threadIdx.x + k * kScanThreads;
-    const int ms = msub[k / (kSubCap / kScanThreads)];   // (kSubCap is a multiple of the block size)
-    live[k] = (idx % kSubCap) < (ms < kSubCap ? ms : kSubCap);
-  }
-  QST(1);
-  __syncthreads();
-  QST(2);
-  if (threadIdx.x < kPartSub) a.pcount[p * kPartSub + threadIdx.x] = 0;       // the counters are clean for the next step
-  // ---- merge the records of a slot; the record that creates the entry owns the unique row's outputs
-  {
-    int mysum = 0;
-#pragma unroll
-    for (int k = 0; k < kPartItems; ++k) mysum += live[k] ? cn[k] : 0;
-    if (mysum) atomicAdd(&s_tot, mysum);
-  }
-#pragma unroll
-  for (int k = 0; k < kPartItems; ++k) {
-    const int idx = threadIdx.x + k * kScanThreads;
-    if (!live[k]) continue;
-    if (sl[k] >= 0) {
-      bool cl;
-      en[k] = part_hash_insert(h_slot, sl[k], &cl);
-      mine[k] = cl;
-      if (cl) h_lid[en[k]] = atomicAdd(&s_nu, 1);
-      bs[k] = atomicAdd(&h_cnt[en[k]], cn[k]);
-    } else {
-      dj[k] = atomicAdd(&s_nd, 1);
-      if (dj[k] < kDefMax) {
-        d_rec[dj[k]] = idx;
-      } else {                           // beyond what one step evicts for: no slot this step (like an insert that returns Busy)
-        dj[k] = -1;
-        bool cl;
-        en[k] = part_hash_insert(h_slot, (int)a.S, &cl);
-        mine[k] = cl;
-        if (cl) h_lid[en[k]] = atomicAdd(&s_nu, 1);
-        bs[k] = atomicAdd(&h_cnt[en[k]], cn[k]);
-      }
-    }
-  }
-  QST(3);
-  __syncthreads();
-  QST(4);
-  // ---- deferred keys: the bucket had no free slot.  Evict the minimum score among the slots this batch does not use
-  //      (the hash above knows them all: every record of the bucket is in this block) and that nobody pinned
-  //      (kernels.cuh:226-287, types.cuh:398-512); 8 lanes per key, a hashed LDS lock per bucket.
-  const int nd = s_nd < kDefMax ? s_nd : kDefMax;
-  if (nd > 0) {
-    if (!a.timer) a.timer = device_clock();
-    const int g = lane_id() & (G - 1);
-    const int gpb = kScanThreads / G;
-    const int C = (int)a.t.C;
-    for (int e0 = 0; e0 < nd; e0 += gpb) {
-      const int e = e0 + (int)threadIdx.x / G;
-      const bool act = e < nd;
-      const int64_t r = (int64_t)p * kPartCap + (act ? d_rec[e] : 0);
-      const uint4 rc = a.rec[r];
-      const uint64_t key = ((uint64_t)rc.y << 32) | rc.x;
-      const int cnt = (int)rc.w;
-      const int64_t bucket = act ? -(int64_t)(int)rc.z - 2 : 0;
-      const int64_t hash = (int64_t)(fmix64(key) & 0x7FFFFFFFFFFFFFFFull);
-      int ent = -1, base = 0;
-      bool done = !act;
-      int guard = 0;
-      while (__ballot(!done)) {
-        if (!done) {
-          int got = 0;
-          if (g == 0) got = atomicCAS(&s_lock[bucket & 255], 0, 1) == 0 ? 1 : 0;
-          got = group_bcast(got, 0);
-          if (got) {
-            uint64_t* ks = a.t.keys(bucket);
-            int found_slot, empty_slot;
-            group_probe(a.t, bucket, key, hash, true, true, found_slot, empty_slot);
-            int slot = -1;
-            bool fresh_row = false;
-            if (found_slot >= 0) {             // another record of the same key got here first
-              slot = found_slot;
-              if (g == 0) score_found(a, a.t.scores(bucket) + (int64_t)slot * a.t.ns, cnt);
-            } else if (empty_slot >= 0) {      // a slot was freed meanwhile
-              slot = empty_slot;
-              fresh_row = true;
-              if (g == 0) {
-                store_digest(a.t.dig(bucket) + slot, digest_of(hash));
-                score_new(a, a.t.scores(bucket) + (int64_t)slot * a.t.ns, cnt);
-                atomicAdd(&a.bucket_sizes[bucket], 1);
-              }
-            } else {
-              uint64_t best = ~0ull, bkey = 0;
-              int bslot = -1;
-              const uint64_t* sc = a.t.scores(bucket);
-              const int32_t* pin = a.counter ? a.counter + bucket * a.t.C : nullptr;
-              for (int s0 = 2 * g; s0 < C; s0 += 2 * G) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                  const int s2 = s0 + u;
-                  const uint64_t v = ald64(sc + (int64_t)s2 * a.t.ns + (a.t.ns - 1));
-                  if (v < best) {
-                    const uint64_t k2 = ald64(ks + s2);
-                    if (k2 == kLockedKey || k2 == kEmptyKey) continue;
-                    if (pin && __hip_atomic_load(pin + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;
-                    if (part_hash_find(h_slot, (int)(bucket * a.t.C + s2)) >= 0) continue;   // used by this batch
-                    best = v; bslot = s2; bkey = k2;
-                  }
-                }
-              }
-              group_argmin(best, bslot, bkey);
-              if (bslot >= 0) {
-                slot = bslot;
-                fresh_row = true;
-                if (g == 0) {
-                  ast64(ks + slot, kLockedKey);
-                  store_digest(a.t.dig(bucket) + slot, digest_of(hash));
-                  for (int64_t w = 0; w < a.t.ns; ++w) ast64((uint64_t*)sc + (int64_t)slot * a.t.ns + w, 0);
-                  score_new(a, a.t.scores(bucket) + (int64_t)slot * a.t.ns, cnt);
-                  if (bkey == kReclaimKey) atomicAdd(&a.bucket_sizes[bucket], 1);
-                }
-              }
-            }
-            int gslot = (int)a.S;             // no slot could be had: the key is served without a row this step
-            if (slot >= 0) {
-              gslot = (int)(bucket * a.t.C + slot);
-              if (fresh_row) {
-                void* rp = reinterpret_cast<void*>((uintptr_t)(a.table_ptrs[0] + ((int64_t)gslot - a.tbo[0] * a.t.C) *
-                                                                                  a.table_value_dims[0] * a.elem_bytes));
-                const int ed = (int)a.table_emb_dims[0], vd = (int)a.table_value_dims[0];
-                for (int el = g; el < vd; el += G) {
-                  const float v = el < ed ? init_value(a.init, key, (uint32_t)el) : a.init.state_init;
-                  if (a.value_dtype == kF32) st1<kF32>(rp, el, v);
-                  else if (a.value_dtype == kBF16) st1<kBF16>(rp, el, v);
-                  else st1<kF16>(rp, el, v);
-                }
-                if (g == 0) {
-                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                  ast64(ks + slot, key);
-                }
-              }
-            }
-            if (g == 0) {
-              // the slot enters the hash BEFORE the lock is released: that is what protects it from the next eviction
-              bool cl;
-              ent = part_hash_insert(h_slot, gslot, &cl);
-              if (cl) h_lid[ent] = atomicAdd(&s_nu, 1) | 0x40000000;    // created late: outputs written by the record below
-              base = atomicAdd(&h_cnt[ent], cnt);
-              d_ent[e] = ent; d_base[e] = base;
-              __threadfence_block();
-              atomicExch(&s_lock[bucket & 255], 0);
-            }
-            done = true;
-          } else if (++guard > (1 << 22)) {
-            if (g == 0) { bool cl; ent = part_hash_insert(h_slot, (int)a.S, &cl); if (cl) h_lid[ent] = atomicAdd(&s_nu, 1) | 0x40000000;
-                          d_ent[e] = ent; d_base[e] = atomicAdd(&h_cnt[ent], cnt); }
-            done = true;
-          }
-        }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kPartItems; ++k)
-      if (dj[k] >= 0) {
-        en[k] = d_ent[dj[k]]; bs[k] = d_base[dj[k]];
-        // the first record (rank base 0) of an entry created by the eviction writes the unique row's outputs
-        if ((h_lid[en[k]] & 0x40000000) && bs[k] == 0) mine[k] = true;
-      }
-    __syncthreads();
-    for (int i = threadIdx.x; i < kPartHash; i += kScanThreads) h_lid[i] &= 0x3fffffff;
-  }
-  __syncthreads();
-  // ---- the partition's sums go out as early as they are known (uniques, occurrences | hot rows, hot tasks, one-wave
-  //      rows): the successors' look-back waits for them, the local scans below run meanwhile.  (The Zipf head is spread
-  //      over ALL slot ranges, so every block has hot rows: their list positions come from the look-back too -- one atomic
-  //      per block on the three list counters would be a ~14 us same-address chain.)
-  const int nu = s_nu;
-  const int tot2 = s_tot;
-  const bool hots = ptr && build_hot;
-  int nh_local = 0, nt_local = 0, nw_local = 0;
-  if (hots) {
-#pragma unroll
-    for (int k = 0; k < kPartItems; ++k) {
-      if (!mine[k]) continue;
-      const int c = h_cnt[en[k]];
-      if (c > hot.khot && c <= hot.kwave) ++nw_local;
-      else if (c > hot.khot) { ++nh_local; nt_local += (c + hot.kchunk - 1) / hot.kchunk; }
-    }
-    if (nh_local) { atomicAdd(&s_th, nh_local); atomicAdd(&s_tt, nt_local); }
-    if (nw_local) atomicAdd(&s_tw, nw_local);
-  }
-#pragma unroll
-  for (int k = 0; k < kPartItems; ++k)
-    if (mine[k]) l_cnt[h_lid[en[k]]] = h_cnt[en[k]];
-  __syncthreads();
-  const int th = s_th, tt = s_tt, tw = s_tw;
-  unsigned long long* tb = a.tstat + a.P;
-  if (threadIdx.x == 0) {
-    stat_store(a.tstat + p, kStatAgg | ((unsigned long long)nu << 31) | (unsigned)tot2);
-    stat_store(tb + p, kStatAgg | ((unsigned long long)th << 40) | ((unsigned long long)tt << 20) | (unsigned long long)tw);
-  }
-  QST(5);
-  // ---- local prefix of the occurrence counts in local-unique-id order, local positions of the hot rows
-  int lc[kPartItems], csum = 0;
-#pragma unroll
-  for (int k = 0; k < kPartItems; ++k) {
-    const int i = threadIdx.x * kPartItems + k;
-    lc[k] = i < nu ? l_cnt[i] : 0;
-    csum += lc[k];
-  }
-  int dummy;
-  int ex2 = block_excl_scan(csum, dummy);
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < kPartItems; ++k) {
-    const int i = threadIdx.x * kPartItems + k;
-    if (i < nu) l_cnt[i] = ex2;
-    ex2 += lc[k];
-  }
-  int h_ex = 0, t_ex = 0, w_ex = 0;
-  if (hots) {
-    h_ex = block_excl_scan(nh_local, dummy);
-    t_ex = block_excl_scan(nt_local, dummy);
-    w_ex = block_excl_scan(nw_local, dummy);
-  }
-  unsigned long long pre_a = 0, pre_b = 0;
-  QST(6);
-  lookback_sum2(a.tstat, tb, p, pre_a, pre_b);
-  QST(7);
-  const int upre = (int)(pre_a >> 31), spre = (int)(pre_a & 0x7fffffffull);
-  h_ex += (int)(pre_b >> 40); t_ex += (int)((pre_b >> 20) & 0xfffff); w_ex += (int)(pre_b & 0xfffff);
-  __syncthreads();
-  // ---- outputs: per unique row (by the record that owns it), per record
-#pragma unroll
-  for (int k = 0; k < kPartItems; ++k) {
-    const int idx = threadIdx.x + k * kScanThreads;
-    if (!live[k]) continue;
-    const int lid = h_lid[en[k]];
-    const int uid = upre + lid;
-    const int64_t r = (int64_t)p * kPartCap + idx;
-    a.rec_out[r] = make_int2(uid, sl[k] < 0 ? ~bs[k] : bs[k]);
-    if (!mine[k]) continue;
-    const int gs = h_slot[en[k]];
-    const int c = h_cnt[en[k]];
-    o.unique_keys[uid] = ky[k];
-    o.csr_cnt[uid] = c;
-    if (o.freq) o.freq[uid] = c;
-    o.row_addr[uid] = gs < a.S ? a.table_ptrs[0] + ((int64_t)gs - a.tbo[0] * a.t.C) * a.table_value_dims[0] * a.elem_bytes : 0;
-    if (o.table_ids) o.table_ids[uid] = 0;
-    o.slots[uid] = gs < a.S ? (int64_t)gs - a.tbo[0] * a.t.C : -1;
-    if (ptr) {
-      const int pv = spre + l_cnt[lid];
-      ptr[uid] = pv;
-      if (build_hot && c > hot.khot && c <= hot.kwave) {
-        const int w = w_ex++;
-        if (w < hot.max_hot) { hot.wave_u[w] = uid; hot.wave_lo[w] = pv; hot.wave_cnt[w] = c; }
-      } else if (build_hot && c > hot.khot) {
-        const int nch = (c + hot.kchunk - 1) / hot.kchunk;
-        const int h = h_ex++, t0 = t_ex;
-        t_ex += nch;
-        if (h < hot.max_hot && t0 + nch <= hot.max_tasks) {
-          hot.hot_done[h] = 0;
-          hot.hot_nchunks[h] = nch;
-          hot.hot_u[h] = uid;
-          hot.hot_lo[h] = pv;
-          hot.hot_cnt[h] = c;
-          hot.hot_t0[h] = t0;
-        }
-      }
-    }
-  }
-  if (p == (int)gridDim.x - 1 && threadIdx.x == 0) {
-    int U = upre + nu;
-    const int O = spre + tot2;
-    int nh = (int)(pre_b >> 40) + th, ntk = (int)((pre_b >> 20) & 0xfffff) + tt, nwv = (int)(pre_b & 0xfffff) + tw;
-    // a record list overflowed in the probe kernel (sticky flag): no row may be updated from an incomplete CSR -- as in path (c)
-    if (__hip_atomic_load(&a.hdr[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { U = 0; nh = 0; ntk = 0; nwv = 0; }
-    if (hots) { *hot.n_hot = nh; *hot.n_tasks = ntk; *hot.n_wave = nwv; }
-    o.table_offsets[0] = 0;
-    o.table_offsets[1] = U;
-    *o.total = O;
-    if (ptr) ptr[U] = O;
-  }
-  QST(8);
-  QST(9);
-}
-
 // ---- round 3, path (c): the partition kernel ALSO writes the backward's CSR -- no scatter kernel ---------------------------------
 // Measured in round 2 / 3 (phase stamps, tools/index_phase_stamps.py): every kernel of the chain costs 4-8 us beyond the life of
 // its blocks (dispatch ramp, tail, end-of-kernel write-back), and the scatter kernel existed only because the CSR positions come
@@ -1515,12 +1164,11 @@ fused_part_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, HotList hot, bo
 //   proportional to its resident waves -- 4.6 us per bag and lane group whatever the occupancy -- and the partition code's 79
 //   registers / 24 KB of LDS take a quarter of them: 54-60 us for the fused launch against 21 + 30 us apart.)
 // The partition kernel of path (c) is a template over the record capacity of a partition (round 5): 2 048 for batches up to
-// 1 M keys (the probe kernel's reservation lists), 4 096 for the partitions of the big-batch stage (big_index.h).  A partition
+// 1 M keys (the probe kernel's reservation lists).  A partition
 // holds at most CAP records, hence at most as many distinct slots: the LDS hash has CAP entries.
 constexpr int kP3Threads = 1024;
 constexpr int kRecLate = 1 << 30;      // count word of a record whose key took the eviction path
-constexpr int kPartCapBig = 32768;     // records per partition of the big-batch stage (the streaming partition kernel, big_index.h)
-constexpr int kPartMaxBig = 4096;      // its partitions
+constexpr int kPartMaxBig = 4096;      // partition slots of the aux header / the partition table (layout constant; path (c) uses up to kPartMax)
 
 template <int HASH> __device__ __forceinline__ int p2_hash(int slot) { return (int)((uint32_t)slot * 2654435761u >> (32 - __builtin_ctz(HASH))) & (HASH - 1); }
 template <int HASH>
@@ -1585,7 +1233,7 @@ __device__ __forceinline__ void block_scan5(int (&v)[5], int (&tot)[5], Publish 
 }
 
 // sums of two packed words over ALL predecessors of partition t: one word pair per thread and round of 1 024 (one round for the
-// batches up to 1 M keys; the big-batch stage has up to 4 096 partitions), all of a round polled together
+// batches up to 1 M keys), all of a round polled together
 template <int THREADS = kP3Threads>
 __device__ __forceinline__ void lookback_sum2_1024(const unsigned long long* ta, const unsigned long long* tb, int t,
                                                    unsigned long long& pre_a, unsigned long long& pre_b) {
@@ -2077,9 +1725,6 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
   QST(9);
 }
 
-}  // namespace mi355
-#include "big_index.h"
-namespace mi355 {
 
 // pooled gather of path (c): per-occurrence addresses with late rows (address word 1 -> the slot in the key's record)
 template <int SDT, int DDT>
@@ -2186,11 +1831,10 @@ namespace mi355 {
 __global__ void __launch_bounds__(256)
 occ_from_records_kernel(const int32_t* __restrict__ occ_slot, const int32_t* __restrict__ occ_trank, const int4* __restrict__ rec_out4,
                         const int64_t* __restrict__ row_addr, int64_t n, int64_t* __restrict__ rev, int32_t* __restrict__ rank,
-                        int64_t* __restrict__ occ_addr, const int* __restrict__ rerun_mark, const int32_t* __restrict__ fwd) {
+                        int64_t* __restrict__ occ_addr, const int* __restrict__ rerun_mark) {
   if (*rerun_mark == 1) return;   // the step overflowed and was re-run on the per-slot-counter path: its outputs are already eager
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
-    int ref = occ_slot[j];
-    if (fwd && ref >= 0) ref = fwd[ref];      // (big-batch stage: the staged record's place in the partitions' lists)
+    const int ref = occ_slot[j];
     const int4 ro = rec_out4[ref >= 0 ? ref : 0];
     const bool late = ro.x < 0;
     const int uid = late ? ~ro.x : ro.x;
@@ -2375,36 +2019,18 @@ int64_t mi355_demb_aux_numel(int64_t total_slots, int64_t num_buckets) {
 
 static inline int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
 
-// the big-batch stage (big_index.h): one table, more keys than the reservation lists of path (c) serve (MI355_BIG_MIN, default
-// 1 M), up to 8 M keys (a hot key leaves one record per 2 048-key tile in ONE partition's list: beyond ~4 000 tiles three such
-// keys in a partition would fill it).  OPT-IN (MI355_BIG=1): measured at parity with the per-slot counters at the 8x / 16x / 32x
-// batches (0.82 / 1.49-1.51 / 2.87 ms against 0.80 / 1.52 / 2.87: profiles/r05_big_stage.txt) for 1.1 GB of step buffer at 16x,
-// and a flooded list flags the step where the per-slot counters cannot fail -- so batches beyond 1 M keys keep path (b) by default.
-static inline bool big_batch(int64_t n, int64_t num_tables) {
-  static const int on = getenv("MI355_BIG") ? atoi(getenv("MI355_BIG")) : 0;
-  static const int64_t min_keys = getenv("MI355_BIG_MIN") ? atoll(getenv("MI355_BIG_MIN")) : (int64_t)kPartMax * 1024;
-  static const int part_env = getenv("MI355_FUSED_PART") ? atoi(getenv("MI355_FUSED_PART")) : 2;
-  return on && part_env >= 2 && num_tables == 1 && n > min_keys && n <= (8ll << 20);
-}
-
 // partitions of the partitioned index stage for a batch of n keys (0: the batch takes the per-slot-counter path)
 static inline int part_count(int64_t n, int64_t num_tables) {
   static const int env = getenv("MI355_FUSED_PART") ? atoi(getenv("MI355_FUSED_PART")) : 2;
   // several tables (round 4): path (c) only, with table-aligned partitions -- every table owns at least one, so the batch needs
   // a few per table (MI355_FUSED_MT=0: multi-table batches keep the per-slot-counter path)
-  static const int mt_env = getenv("MI355_FUSED_MT") ? atoi(getenv("MI355_FUSED_MT")) : 1;
+  constexpr int mt_env = 1;
   if (!env || n < (64 << 10)) return 0;
-  if (big_batch(n, num_tables)) {   // round 5: the big-batch stage (big_index.h): P = keys / 11 264 partitions of up to 32 768 records
-    // (a multiple of the 256 CUs: the partition kernel runs one block per CU and generation -- 576 partitions at the 16x batch were
-    //  two generations and a quarter, profiles/r05_stamps_16x_c.txt)
-    int Pb = (int)((n / 11264 + 128) / 256 * 256);
-    return Pb < 256 ? 256 : (Pb > kPartMaxBig ? kPartMaxBig : Pb);
-  }
   if (n > (int64_t)kPartMax * 1024) return 0;
   if (num_tables != 1 && (!mt_env || env < 2 || num_tables < 1 || num_tables > kFusedMaxT)) return 0;
   // keys per partition (MI355_FUSED_KPP, default 1024): the partition kernel is one block per partition and a chain of dependent
   // phases -- below 256 partitions it leaves CUs idle, so small batches may as well get thinner partitions
-  static const int kpp_env = getenv("MI355_FUSED_KPP") ? atoi(getenv("MI355_FUSED_KPP")) : 1024;
+  constexpr int kpp_env = 1024;
   const int kpp = kpp_env >= 256 && kpp_env <= 1024 ? kpp_env : 1024;
   int P = (int)((n + 1023) / 1024);
   if (kpp < 1024 && P < 256) { P = (int)((n + kpp - 1) / kpp); if (P > 256) P = 256; }
@@ -2425,8 +2051,7 @@ int64_t mi355_demb_forward_fused_workspace_bytes(int64_t n, int64_t num_tables) 
   const int64_t nt = (n + 1023) / 1024 + 2;
   return al256(8 * (num_tables + 1)) + al256(8 * n) /*unique keys*/ + al256(8 * n) /*occ_addr*/ + al256(4 * n) /*occ_slot*/ +
          al256(4 * nt) + 256 /*total*/ + al256(8 * n) + 4 * al256(4 * n) /*deferred*/ + al256(24 * (nt > 258 ? nt : 258)) /*look-back: two words per 1024 keys, and per partition*/ + 256 +
-         (part_count(n, num_tables) ? 32 * (int64_t)part_count(n, num_tables) * (big_batch(n, num_tables) ? kPartCapBig : kPartCap) + 5 * 256 + 4 * kPartMaxBig : 0) /*partition records, table of every partition*/ +
-         (big_batch(n, num_tables) ? al256(16 * n) + al256(4 * (n / 1024 + 2)) + al256(4 * n) : 0) /*big-batch stage: staged records, tile counts, forwarding entries*/;
+         (part_count(n, num_tables) ? 32 * (int64_t)part_count(n, num_tables) * kPartCap + 5 * 256 + 4 * kPartMaxBig : 0) /*partition records, table of every partition*/;
 }
 
 // The fused forward (see the header of this file).  Persisted outputs as mi355_demb_forward; in eval mode (train == 0)
@@ -2473,7 +2098,7 @@ int mi355_demb_forward_fused(
   a.keys = (const uint64_t*)keys; a.n = n; a.offsets = offsets; a.feature_offsets = feature_offsets; a.num_bags = num_bags; a.batch = batch_size;
   a.T = (int)num_tables; a.find_policy = find_policy; a.insert_policy = insert_policy; a.use_count = use_count;
   a.score_value = score_value; a.timer = timer_override;
-  static const int dbg_env = getenv("MI355_FUSED_DBG") ? atoi(getenv("MI355_FUSED_DBG")) : 0;
+  constexpr int dbg_env = 0;
   a.dbg = dbg_env;
   a.init = InitArgs{init_mode, p0, p1, p2, p3, seed, state_init};
   a.seg_out = (int64_t*)w; w += al256(8 * (num_tables + 1));
@@ -2495,7 +2120,7 @@ int mi355_demb_forward_fused(
   a.mt = 0; a.ptab = nullptr;
   a.gate = nullptr; a.gate_val = 0; a.ovf_word = 5; a.ovf_val = 1; a.rerun_mark = nullptr; a.tl = 0;
   a.protect = t_protect;
-  a.stage_rec = nullptr; a.tile_cnt = nullptr; a.fwd = nullptr; a.cap = kPartCap; a.part_ready = nullptr;
+  a.cap = kPartCap; a.part_ready = nullptr;
   a.magic0 = num_buckets > 0 ? ~0ull / (uint64_t)num_buckets : 0ull;   // (one table: its buckets are all the buckets)
   {
     const int P = train ? part_count(n, num_tables) : 0;
@@ -2503,18 +2128,12 @@ int mi355_demb_forward_fused(
       const int64_t per = ((S + 1 + P - 1) / P + bucket_capacity - 1) / bucket_capacity * bucket_capacity;
       if (per < 0x7fffffffLL) {
         a.P = P; a.spp = (int)per;
-        const bool big = big_batch(n, num_tables);
-        a.cap = big ? kPartCapBig : kPartCap;
+        a.cap = kPartCap;
         const int64_t nr = (int64_t)P * a.cap;
         a.rec = (uint4*)w; w += al256(16 * nr);
         a.rec_out = (int2*)w; a.rec_out4 = (int4*)w; w += al256(16 * nr);   // (path (a): 8-byte entries, path (c): 16-byte ones)
         a.ptab = (int32_t*)w; w += 4 * kPartMaxBig;
         a.mt = num_tables > 1;
-        if (big) {
-          a.stage_rec = (uint4*)w; w += al256(16 * n);
-          a.tile_cnt = (int32_t*)w; w += al256(4 * (n / 1024 + 2));
-          a.fwd = (int32_t*)w; w += al256(4 * n);
-        }
       }
     }
   }
@@ -2540,7 +2159,7 @@ int mi355_demb_forward_fused(
   while ((4 << lg) < emb_dim && lg < 6) ++lg;
   // sequence lookups (combiner -1, round 4; MI355_FUSED_SEQ=0 keeps them on the probe / partition / scatter chain): occurrence j
   // is its own bag
-  static const int seq_env = getenv("MI355_FUSED_SEQ") ? atoi(getenv("MI355_FUSED_SEQ")) : 1;
+  constexpr int seq_env = 1;
   const bool seq = combiner == -1;
   bool pathc = part && part_env >= 2 && train && (combiner >= 0 || (seq && seq_env)) && hot_ws && bcsr && aligned16 &&
                      emb_dim <= (4 << lg) && (seq || n <= 8 * num_bags) && value_dtype <= 1 && out_dtype <= 1 &&
@@ -2549,33 +2168,26 @@ int mi355_demb_forward_fused(
   // and scattered by a third kernel -- reported a flooded list through a sticky flag and skipped the step's update; what is not
   // eligible for path (c) (long bags, fp16 rows, unaligned rows, MI355_FUSED_PART=1) takes the per-slot counters, which cannot flood
   if (part && !pathc) { part = false; a.P = 0; a.mt = 0; }
-  // the two knobs of the probe kernel (MI355_ENV_LIVE=1 -- the test suite, the A/B tools -- re-reads them on every call: A/B inside
-  // one process; otherwise they are read once: getenv walks the whole environment, twice per step adds up on the host)
+  // MI355_PROBE_C (a TEST hook: the tile shape of the probe kernel -- 1 the run-time rule, 2 two keys per thread, 3 full
+  // 1 024-key tiles); MI355_ENV_LIVE=1 (the test suite) re-reads it on every call, otherwise once: getenv walks the environment
   static const bool env_live = getenv("MI355_ENV_LIVE") != nullptr;
-  static int fm_c = -1, pc_c = 1;
+  static int pc_c = 1;
   static bool env_have = false;
   if (env_live || !env_have) {
-    const char* e1 = getenv("MI355_FUSED_FASTMOD");
     const char* e2 = getenv("MI355_PROBE_C");
-    fm_c = e1 ? (atoi(e1) != 0) : -1;
     pc_c = e2 ? atoi(e2) : 1;
+    if (pc_c < 1 || pc_c > 3) pc_c = 1;
     env_have = true;
   }
-  const bool fast = part && (fm_c >= 0 ? fm_c != 0 : pathc) && (a.t.C & (a.t.C - 1)) == 0 &&
-                    (a.S >> __builtin_ctzll((unsigned long long)a.t.C)) < (1ll << 31);
+  // division-free bucket arithmetic (multiply-high by a per-table magic): power-of-two bucket capacities
+  const bool fast = part && pathc && (a.t.C & (a.t.C - 1)) == 0 && (a.S >> __builtin_ctzll((unsigned long long)a.t.C)) < (1ll << 31);
   const int pcv = pc_c;
-  // the big-batch stage needs path (c) and the round-5 probe kernel; anything else: the per-slot counters
-  const bool big = part && a.stage_rec != nullptr && pathc && fast && pcv > 0;
-  if (part && a.stage_rec && !big) { part = false; a.P = 0; a.stage_rec = nullptr; a.cap = kPartCap; }
   if (!part) pathc = false;
-  // round 5: the partition blocks ride in the gather's launch (part3_lean.h): sequence lookups by default
-  static const int pf_env = getenv("MI355_PART_FUSED") ? atoi(getenv("MI355_PART_FUSED")) : 1;
-  static int pf_live = 1;
-  if (env_live) { const char* e3 = getenv("MI355_PART_FUSED"); pf_live = e3 ? atoi(e3) : 1; }
-  const int pf_mode = env_live ? pf_live : pf_env;      // 0 off, 1 sequence lookups (default: measured gain), 2 pooled batches as well (measured loss)
-  const bool part_fused = pathc && !big && t_stage == 0 && (pf_mode >= 2 || (pf_mode == 1 && seq));   // (staged forwards: two launches)
+  // round 5: the partition blocks ride in the gather's launch (part3_lean.h) for SEQUENCE lookups (8 x 16 K tokens 0.076 -> 0.068 ms);
+  // pooled batches keep the partition kernel of its own (the same role in front of the pooled gather's blocks measured a loss at
+  // C2: 0.1227 -> 0.1288 ms, profiles/r05_part_fused.txt)
+  const bool part_fused = pathc && t_stage == 0 && seq;   // (staged forwards: two launches)
   if (part_fused) a.part_ready = (int32_t*)(a.tstat + 2 * a.P);
-  if (part_fused && env_live) { const char* e4 = getenv("MI355_PART_PRIO"); if (e4 && atoi(e4) == 0) a.dbg |= 4; }
   // opt-in: an overflowed step is re-run on the per-slot-counter path inside this call (the reference never skips an update,
   // unique_op.cu:484-714): three more launches behind the gather that return at once in the steady state
   // (round 5: the chain on the SIDE stream, forked in front of the gather -- its head kernel holding it back in a flagged step until
@@ -2614,13 +2226,13 @@ int mi355_demb_forward_fused(
   }
   // ---- eval / inference forward of one table with pooled output: ONE kernel (every lane probes its own keys; no dedup, no
   //      unique numbering, no address array).  MI355_EVAL_FUSED=0 keeps the probe + gather pair.
-  static const int eval_env = getenv("MI355_EVAL_FUSED") ? atoi(getenv("MI355_EVAL_FUSED")) : 1;
+  constexpr int eval_env = 1;
   if (!train && eval_env && n > 0 && num_tables >= 1 && num_tables <= kEvalMaxT && combiner >= -1 && aligned16 && !use_count &&
       (find_policy == kConst || find_policy == kAssign || find_policy == kGlobalTimer) && (bucket_capacity & (bucket_capacity - 1)) == 0 &&
       value_dtype <= 1 && out_dtype <= 1 && num_buckets < (1ll << 31) && (combiner == -1 || n <= 8 * num_bags)) {
     int le = 3;
     while ((4 << le) < emb_dim && le < 6) ++le;
-    static const int eval_mt_env = getenv("MI355_EVAL_FUSED_MT") ? atoi(getenv("MI355_EVAL_FUSED_MT")) : 1;   // 0: several tables / sequences keep the probe + gather pair
+    constexpr int eval_mt_env = 1;
     const bool mt = num_tables > 1;
     if (emb_dim <= (4 << le) && (eval_mt_env || (!mt && combiner >= 0))) {
       RoctxRange rr("op:eval_lookup+gather_embedding");
@@ -2668,7 +2280,7 @@ int mi355_demb_forward_fused(
     RoctxRange rr("op:fused_index(segmented_unique+storage_find+storage_insert+initializer)");
     // keys per tile / threads per block: one key per thread keeps every probe chain (digest vector -> key -> slot counter)
     // in flight at once; larger tiles cost fewer (tile, key) pairs = fewer device-scope atomics
-    static const int cfg_env = getenv("MI355_FUSED_CFG") ? atoi(getenv("MI355_FUSED_CFG")) : -1;
+    constexpr int cfg_env = -1;
     // measured at C2 (360 K keys): 2048-key tiles / 1024 threads 33.5 us, 1024 / 1024 37.8 us, 1024 / 512 35.2 us
     const int cfg = cfg_env >= 0 ? cfg_env : (n >= (64 << 10) ? 3 : 0);
 #define LAUNCH_PROBE(TILE, THREADS)                                                                                        \
@@ -2678,8 +2290,9 @@ int mi355_demb_forward_fused(
     else hipLaunchKernelGGL((fused_probe_kernel<TILE, THREADS, false>), dim3(grid), dim3(THREADS), 0, stream, a);         \
   } while (0)
     if (part) {
-      // round 5: the rebuilt probe kernel of path (c) (probe_c.h); MI355_PROBE_C = 0 keeps the kernel above
-      if (pathc && fast && pcv > 0) {
+      // (part implies path (c) since round 6)  round 5: the rebuilt probe kernel (probe_c.h) wherever the bucket arithmetic is
+      // division-free; other bucket capacities keep the round-3 probe kernel
+      if (fast) {
         // ONE block per CU in one generation while the batch allows it: tile length = ceil(n / #CUs), rounded to 64, in the kernel
         // with one key per thread (<= 1 024 keys per tile) or two (<= 2 048); larger batches run full 2 048-key tiles in
         // generations.  MI355_PROBE_C: 1 this rule, 2 always the two-keys-per-thread kernel, 3 full 1 024-key tiles (two blocks
@@ -2691,25 +2304,11 @@ int mi355_demb_forward_fused(
           if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu_p = prop.multiProcessorCount;
           if (ncu_p <= 0) ncu_p = 256;
         }
-        // (big-batch stage: MI355_BIG_TILE = 1024 runs one-key-per-thread tiles, two blocks per CU -- an A/B knob)
-        static const int big_tile = getenv("MI355_BIG_TILE") ? atoi(getenv("MI355_BIG_TILE")) : 2048;
-        const int cap = big ? (big_tile == 1024 ? 1024 : 2048) : (pcv == 3 ? 1024 : ((pcv == 2 || n > (int64_t)ncu_p * 1024) ? 2048 : 1024));
-        int64_t tlen = (big || pcv == 3) ? cap : (ceil_div(n, ncu_p) + 63) / 64 * 64;
+        const int cap = pcv == 3 ? 1024 : ((pcv == 2 || n > (int64_t)ncu_p * 1024) ? 2048 : 1024);
+        int64_t tlen = pcv == 3 ? cap : (ceil_div(n, ncu_p) + 63) / 64 * 64;
         if (tlen > cap) tlen = cap;
         if (tlen < 256) tlen = 256;
         a.tl = (int)tlen;
-        if (big) {   // tile-major records, then the split into the partitions' lists (big_index.h)
-          const dim3 grid((unsigned)ceil_div(n, tlen)), blk(1024);
-          if (cap == 1024) {
-            if (seq) hipLaunchKernelGGL((probe_c_kernel<1024, 1024, 8, false, true, true>), grid, blk, 0, stream, a);
-            else hipLaunchKernelGGL((probe_c_kernel<1024, 1024, 8, false, false, true>), grid, blk, 0, stream, a);
-          } else
-          if (seq) hipLaunchKernelGGL((probe_c_kernel<2048, 1024, 4, false, true, true>), grid, blk, 0, stream, a);
-          else hipLaunchKernelGGL((probe_c_kernel<2048, 1024, 4, false, false, true>), grid, blk, 0, stream, a);
-          const int ntiles = (int)ceil_div(n, tlen);
-          const int tpb = (int)ceil_div(ntiles, ncu_p);
-          hipLaunchKernelGGL(split_records_kernel, dim3((unsigned)ceil_div(ntiles, tpb)), dim3(kSplitThreads), 0, stream, a, tpb, ntiles);
-        } else
 #define LAUNCH_PC(TILE, THREADS, WPS)                                                                                                   \
   do {                                                                                                                                   \
     const dim3 grid((unsigned)ceil_div(n, tlen)), blk(THREADS);                                                                          \
@@ -2722,32 +2321,20 @@ int mi355_demb_forward_fused(
         else LAUNCH_PC(1024, 1024, 8);
         (void)0;
 #undef LAUNCH_PC
-      } else
-      if (pathc) {
-#define LAUNCH_C(FAST, MT, SEQ) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, FAST, true, MT, SEQ>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a)
-        const int v = (fast ? 4 : 0) | (a.mt ? 2 : 0) | (seq ? 1 : 0);
+      } else {
+#define LAUNCH_C(MT, SEQ) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, false, true, MT, SEQ>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a)
+        // (bucket capacities that are not a power of two: the round-3 probe kernel with the generic bucket arithmetic)
+        const int v = (a.mt ? 2 : 0) | (seq ? 1 : 0);
         switch (v) {
-          case 0: LAUNCH_C(false, false, false); break;
-          case 1: LAUNCH_C(false, false, true); break;
-          case 2: LAUNCH_C(false, true, false); break;
-          case 3: LAUNCH_C(false, true, true); break;
-          case 4: LAUNCH_C(true, false, false); break;
-          case 5: LAUNCH_C(true, false, true); break;
-          case 6: LAUNCH_C(true, true, false); break;
-          default: LAUNCH_C(true, true, true); break;
+          case 0: LAUNCH_C(false, false); break;
+          case 1: LAUNCH_C(false, true); break;
+          case 2: LAUNCH_C(true, false); break;
+          default: LAUNCH_C(true, true); break;
         }
 #undef LAUNCH_C
       }
-      else if (fast) hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
-      else hipLaunchKernelGGL((fused_probe_kernel<2048, 1024, true, true>), dim3((unsigned)ceil_div(n, 2048)), dim3(1024), 0, stream, a);
-    } else
-    switch (cfg) {
-      case 1: LAUNCH_PROBE(1024, 256); break;
-      case 2: LAUNCH_PROBE(2048, 512); break;
-      case 3: LAUNCH_PROBE(2048, 1024); break;
-      case 4: LAUNCH_PROBE(1024, 512); break;
-      default: LAUNCH_PROBE(1024, 1024); break;
-    }
+    } else if (cfg == 3) LAUNCH_PROBE(2048, 1024);
+    else LAUNCH_PROBE(1024, 1024);
 #undef LAUNCH_PROBE
     MI355_LAUNCH_CHECK();
   }
@@ -2762,14 +2349,13 @@ int mi355_demb_forward_fused(
     PoolArgs g;
     g.src = nullptr; g.src_stride = 0; g.row_addr = a.occ_addr; g.rev = nullptr; g.offsets = offsets; g.D_offsets = D_offsets;
     g.dst = out; g.FB = num_bags; g.n = n; g.B = (int)batch_size; g.D = (int)emb_dim; g.total_D = (int)total_D; g.combiner = combiner;
-    LateRefs late; late.occ_slot = a.occ_slot; late.rec = a.rec; late.S = (int)S; late.fwd = a.fwd;
+    LateRefs late; late.occ_slot = a.occ_slot; late.rec = a.rec; late.S = (int)S;
     late.table_ptrs = table_ptrs; late.table_value_dims = table_value_dims; late.tbo = table_bucket_offsets;
     late.C = bucket_capacity; late.elem_bytes = a.elem_bytes; late.T = (int)num_tables;
     const int nsub = 64 >> lg;
     if (rerun_only) goto rerun_chain;      // (a flooded step: its forward ran, only the index stage is redone)
     if (part_fused) { late.ready = a.part_ready; late.cap = kPartCap; }
     else if (stage == 2) { }               // (the partition kernel ran with the step's index stage)
-    else if (big) hipLaunchKernelGGL(fused_part3s_kernel, dim3((unsigned)a.P), dim3(kP3Threads), 0, stream, a, o, bptr, bcsr, hot);
     else hipLaunchKernelGGL(fused_part3_kernel<kPartCap>, dim3((unsigned)a.P), dim3(kP3Threads), 0, stream, a, o, bptr, bcsr, hot);
     MI355_LAUNCH_CHECK();
     if (stage == 1) goto rerun_chain;      // index stage only: the gather follows in a stage-2 call
@@ -2877,19 +2463,15 @@ int mi355_demb_forward_fused(
     }
     HotList hot{};
     if (hot_ws) hot = hot_carve(hot_ws, n, emb_dim);
-    if (part) {
-      hipLaunchKernelGGL(fused_part_kernel, dim3((unsigned)a.P), dim3(kScanThreads), 0, cs, a, o, bptr, hot, hot_ws != nullptr);
-    } else if (ntile <= kSelfPrefixMaxTiles) {
+    if (ntile <= kSelfPrefixMaxTiles) {
       hipLaunchKernelGGL(fused_mid_kernel<true>, dim3((unsigned)ntile), dim3(kScanThreads), 0, cs, a, o, bptr, hot, hot_ws != nullptr, ncu);
     } else {
       hipLaunchKernelGGL(fused_scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, cs, a.partial, ntile);
       hipLaunchKernelGGL(fused_mid_kernel<false>, dim3((unsigned)ntile), dim3(kScanThreads), 0, cs, a, o, bptr, hot, hot_ws != nullptr, ncu);
     }
     MI355_LAUNCH_CHECK();
-    PartRefs prf;
-    if (part) { prf.rec_out = a.rec_out; prf.row_addr = row_addr; prf.occ_addr = a.occ_addr; }
     STEP(mi355i_csr_from_slots(csr_rank, a.occ_slot, a.occ + 1, reverse_indices, n, combiner >= 0 ? offsets : nullptr, num_bags,
-                               bptr, bcsr, hot_ws, hot_bytes_, emb_dim, a.hdr, part ? &prf : nullptr, cs));
+                               bptr, bcsr, hot_ws, hot_bytes_, emb_dim, a.hdr, nullptr, cs));
     if (pin) STEP(mi355_table_update_counter(counter, counter_numel, slots, n, nu_dev, 1, table_ids, table_bucket_offsets,
                                              bucket_capacity, cs));
     if (forked) {
@@ -2962,14 +2544,11 @@ int mi355_demb_fused_materialize(void* workspace, int64_t workspace_bytes, int64
   w += 256 + al256(8 * n);
   const int32_t* occ_trank = (const int32_t*)w; w += 4 * al256(4 * n);
   w += al256(24 * (nt > 258 ? nt : 258));
-  const bool big = big_batch(n, num_tables);
-  const int64_t nr = (int64_t)P * (big ? kPartCapBig : kPartCap);
+  const int64_t nr = (int64_t)P * kPartCap;
   w += al256(16 * nr);
   const int4* rec_out4 = (const int4*)w;
-  const int32_t* fwd = nullptr;      // big-batch stage: occ_slot names the STAGED record
-  if (big) fwd = (const int32_t*)(w + al256(16 * nr) + 4 * kPartMaxBig + al256(16 * n) + al256(4 * (n / 1024 + 2)));
   hipLaunchKernelGGL(occ_from_records_kernel, dim3((unsigned)grid_for(n, 256, 4096)), dim3(256), 0, stream, occ_slot, occ_trank, rec_out4,
-                     row_addr, n, reverse_indices, csr_rank, occ_addr, rerun_mark, fwd);
+                     row_addr, n, reverse_indices, csr_rank, occ_addr, rerun_mark);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }

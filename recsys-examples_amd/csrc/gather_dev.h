@@ -78,13 +78,11 @@ struct LateRefs {
   int elem_bytes = 0;
   int S = 0;
   int T = 1;                                  // tables (global slots are table-major: tbo[t] C <= slot < tbo[t + 1] C)
-  const int32_t* fwd = nullptr;               // big-batch stage: occ_slot holds the STAGED record, fwd[...] its place in `rec`
   const int32_t* ready = nullptr;             // partition blocks in the SAME launch (round 5): ready[p] != 0 once partition p's evictions
   int cap = 2048;                             // are in the records (records per partition: ref / cap = p)
 };
 __device__ __forceinline__ uintptr_t late_row(const LateRefs& L, int64_t j) {
-  int ref = L.occ_slot[j];
-  if (ref >= 0 && L.fwd) ref = L.fwd[ref];
+  const int ref = L.occ_slot[j];
   if (ref < 0) return 0;
   if (L.ready) {   // (rare: a key whose bucket was full) the partition block that evicts for it runs in this very launch, ahead of us
     const int32_t* rp = L.ready + ref / L.cap;

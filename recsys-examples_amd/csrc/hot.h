@@ -12,9 +12,9 @@ namespace mi355 {
 #include <stdlib.h>
 // occurrences above which a row takes the chunked path / CSR entries per task (one wave per task).
 // Tunable through MI355_HOT / MI355_CHUNK (read once per process) for profiling sweeps.
-static inline int hot_threshold() { static const int v = getenv("MI355_HOT") ? atoi(getenv("MI355_HOT")) : 4; return v < 1 ? 1 : v; }
-static inline int hot_chunk() { static const int v = getenv("MI355_CHUNK") ? atoi(getenv("MI355_CHUNK")) : 1024; return v < 4 ? 4 : v; }
-static inline int hot_wave() { static const int v = getenv("MI355_WAVE") ? atoi(getenv("MI355_WAVE")) : 128; return v; }
+static inline int hot_threshold() { return 4; }
+static inline int hot_chunk() { return 1024; }
+static inline int hot_wave() { return 128; }
 
 struct HotList {
   int* n_hot;        // [1]

@@ -4061,7 +4061,7 @@ static int launch_bwd(BwdAttnArgs g, int B, int max_seqlen, hipStream_t stream) 
     return MI355_OK;
   }
   if constexpr (D >= 256) {
-    static const int var = getenv("MI355_HSTU_VAR") ? atoi(getenv("MI355_HSTU_VAR")) : 1;   // tuning sweeps only; measured best = 1
+    constexpr int var = 1;   // (the variant bits below were sweep switches of rounds 3-4; 1 is the measured best)
     g.bq_kv = (var & 1) ? 64 : 32;
     if (g.p_ws) {          // dK pass first (it writes P and dS), then the two one-GEMM passes
       // 32-row steps with the next step's Q / dO rows prefetched into registers (64-row steps leave no registers for it and
@@ -4069,7 +4069,7 @@ static int launch_bwd(BwdAttnArgs g, int B, int max_seqlen, hipStream_t stream) 
       if (var & 32) { g.bq_kv = 64; launch_bwd_kv<D, 64, 2, false, true>(g, grid, stream); }
       else {
         g.bq_kv = 32;
-        static const int kvpc = getenv("MI355_HSTU_KVPC") ? atoi(getenv("MI355_HSTU_KVPC")) : 1;
+        constexpr int kvpc = 1;
         if (kvpc) {   // the S-wave / K-wave dK pass (two waves per SIMD)
           const size_t smem_pc = (size_t)(6 * 32 * 256 + 2 * 4 * 2 * 64 * 8) * sizeof(uint16_t);
           static bool attr_pc = false;
@@ -4080,7 +4080,7 @@ static int launch_bwd(BwdAttnArgs g, int B, int max_seqlen, hipStream_t stream) 
           hipLaunchKernelGGL((hstu_bwd_kv_pc_kernel<256>), grid, dim3(512), smem_pc, stream, g);
         } else launch_bwd_kv<D, 32, 2, true, true>(g, grid, stream);
       }
-      static const int x8 = getenv("MI355_HSTU_X8") ? atoi(getenv("MI355_HSTU_X8")) : 4;
+      constexpr int x8 = 4;
       if (x8 == 8) launch_bwd_x8<8>(g, B, max_seqlen, stream);
       else if (x8) launch_bwd_x8<4>(g, B, max_seqlen, stream);
       else {
@@ -4137,10 +4137,13 @@ static int launch_fwd_pc(const AttnArgs& a, int B, int max_seqlen, hipStream_t s
   // row blocks in (heavy, light) pairs per workgroup: dense batches only (every sequence max_seqlen rows: the caller said so with
   // mi355_hstu_attn_fwd_hint_tokens).  On a jagged batch the pairs of a long column are as heavy as before but half as many
   // workgroups share the machine and the tail grows (C4 shape 340 -> 355 us); MI355_HSTU_PAIR = 0 never, 2 always (A/B).
-  static const int pair = getenv("MI355_HSTU_PAIR") ? atoi(getenv("MI355_HSTU_PAIR")) : 1;
+  // MI355_HSTU_FWD (a TEST hook, read once): 0 / unset = the rules below; 1 = 64-row waves at every length, 2 = ... in pairs on every
+  // batch, 3 = 32-row waves at every length, 4 = ... in pairs on every batch (5 = the one-kind kernel: see mi355_hstu_attn_fwd_kv)
+  static const int fwd_hook = getenv("MI355_HSTU_FWD") ? atoi(getenv("MI355_HSTU_FWD")) : 0;
+  const int pair = (fwd_hook == 2 || fwd_hook == 4) ? 2 : 1;
   // 64 query rows per wave (two MFMAs per LDS fragment) from 1 025 rows: +4-6 % at L >= 2048, +1-4 % on jagged Zipf-to-4096 batches,
   // level at 768-1024, -2 % at C3 and -6 % at L = 256 (fewer, larger units per short column); 2 = always, 0 = never (A/B)
-  static const int q2 = getenv("MI355_HSTU_Q2") ? atoi(getenv("MI355_HSTU_Q2")) : 1;
+  const int q2 = (fwd_hook == 1 || fwd_hook == 2) ? 2 : ((fwd_hook == 3 || fwd_hook == 4) ? 0 : 1);
   if (q2 == 2 || (q2 == 1 && max_seqlen > 1024)) {
     static bool attr_q2 = false;
     if (!attr_q2) {
@@ -4228,11 +4231,11 @@ struct RabCall { const uint16_t* rab = nullptr; int64_t rb = 0, rh = 0, rr = 0; 
                  void* kvis = nullptr; int64_t kvis_bytes = 0; };   // (backward: room for the key-block table of the func masks)
 static thread_local RabCall tl_rab;
 static int block_rotation(int heads) {   // MI355_HSTU_ROT (A/B): see seq_head_of_block; default -H = by a sequence per rank, jagged batches only
-  static const int v = [] { const char* e = getenv("MI355_HSTU_ROT"); return e ? atoi(e) : 0x7fffffff; }();
+  constexpr int v = 0x7fffffff;
   return v == 0x7fffffff ? -heads : v;
 }
 static int column_major() {   // MI355_HSTU_CM=0: dense batches keep the rank-major grid (A/B)
-  static const int v = [] { const char* e = getenv("MI355_HSTU_CM"); return e ? atoi(e) : 1; }();
+  constexpr int v = 1;
   return v;
 }
 static int window_skip() {   // MI355_HSTU_WSKIP=0: keep the full tile loops under a window (A/B tests of the band clipping)
@@ -4242,7 +4245,7 @@ static int window_skip() {   // MI355_HSTU_WSKIP=0: keep the full tile loops und
 
 // ---- sizes of the backward's optional P / dS exchange (shared by both translation units)
 static int xch_regions(int64_t head_dim) {   // dS, and (head_dim >= 128, where dV and dK are separate passes) P behind it
-  static const int envp = getenv("MI355_HSTU_XP") ? atoi(getenv("MI355_HSTU_XP")) : 1;
+  constexpr int envp = 1;
   return (envp && head_dim >= 128) ? 2 : 1;
 }
 static int64_t xch_plan_header(int64_t units) { return ((units * 8 + 255) / 256 + (units * 4 + 255) / 256 + 1) * 256; }
@@ -4313,7 +4316,7 @@ int HSTU_FN(mi355_hstu_attn_fwd_kv)(const void* q, const void* k, const void* v,
   a.alpha = alpha; a.inv_scale = 1.0f / scaling_seqlen;
   a.cu_seqlens_k = cu_seqlens_k; a.kv_cache = (const uint16_t*)kv_cache; a.page_offsets = page_offsets; a.page_ids = page_ids;
   a.last_page_lens = last_page_lens; a.page_size = (int)page_size;
-  static const int use_pc = getenv("MI355_HSTU_PC") ? atoi(getenv("MI355_HSTU_PC")) : 1;   // round 4: two waves per SIMD, S waves + O waves
+  static const int use_pc = !(getenv("MI355_HSTU_FWD") && atoi(getenv("MI355_HSTU_FWD")) == 5);   // round 4: two waves per SIMD, S waves + O waves (hook 5: the one-kind kernel)
   const int64_t fwd_tokens = tl_fwd_tokens;
   tl_fwd_tokens = 0;
   if (use_pc && head_dim == 256 && !a.kv_cache && !a.rab && !a.func)

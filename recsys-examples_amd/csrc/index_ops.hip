@@ -1172,7 +1172,7 @@ static int scan_i64(const int64_t* in, int64_t n, int64_t* out, hipStream_t stre
   const int64_t nt = ceil_div(n, kScan64Tile);
   int64_t* sc = scan64_scratch(nt + 2);
   if (!sc) { mi355_set_error("scan scratch allocation failed"); return MI355_ELAUNCH; }
-  static const int three = getenv("MI355_SCAN3") ? atoi(getenv("MI355_SCAN3")) : 0;   // (A/B: the three-launch form)
+  constexpr int three = 0;   // (the three-launch form: kept for batches beyond the one-launch scan's capacity)
   if (three) {
     static thread_local int64_t* sc3 = nullptr;
     static thread_local int64_t cap3 = 0;

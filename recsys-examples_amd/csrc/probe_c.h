@@ -33,11 +33,8 @@
 
 namespace mi355 {
 
-// kStage (big-batch stage, big_index.h): the tile's records go out TILE-MAJOR -- dense behind the tile's first position, in the
-// order of an exclusive scan over the representatives -- with the tile's record count; no histogram, no reservation.
-template <int TILE, int THREADS, int WPS, bool kMT, bool kSeq, bool kStage = false>
+template <int TILE, int THREADS, int WPS, bool kMT, bool kSeq>
 __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
-  static_assert(!(kStage && kMT), "the big-batch stage serves one table");
   constexpr int PER = TILE / THREADS;
   constexpr int HASH = 2 * TILE;
   constexpr int NW = THREADS / 64;
@@ -128,7 +125,7 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
     }
   }
   for (int s = tid; s < HASH; s += THREADS) { s_tab[s] = -1; s_cnt[s] = 0; }
-  if constexpr (!kStage) for (int p = tid; p < a.P; p += THREADS) s_hist[p] = 0;
+  for (int p = tid; p < a.P; p += THREADS) s_hist[p] = 0;
   if constexpr (!kSeq) for (int k = tid; k < TILE; k += THREADS) s_bag[k] = -1;
   if (tid == 0) s_cover = 1;
   __syncthreads();   // 0: the cleared LDS (and the tables' metadata); nothing has been waited for yet
@@ -172,7 +169,7 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
     const bool ok = li < tl && i < a.n && is_valid(key) && nb > 0;
     hq[q] = hash;
     bq[q] = ok ? (int)(bb + (int64_t)r) : -1;
-    if constexpr (!kMT && !kStage) pkq[q] = bq[q] < 0 ? a.P - 1 : (int)((uint32_t)bq[q] / (uint32_t)(a.spp >> cshift));
+    if constexpr (!kMT) pkq[q] = bq[q] < 0 ? a.P - 1 : (int)((uint32_t)bq[q] / (uint32_t)(a.spp >> cshift));
     const int start = ((int)hash & Cm) & ~15;
     dvq[q] = *reinterpret_cast<const uint4*>(a.t.dig(ok ? bq[q] : 0) + start);   // unconditional: bucket 0 for homeless keys
   }
@@ -265,7 +262,7 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
       }
       hh[q] = h;
       rk[q] = atomicAdd(&s_cnt[h], 1);
-      if constexpr (!kMT && !kStage) { if (claimed) lpq[q] = pkq[q] * 4096 + atomicAdd(&s_hist[pkq[q]], 1); }
+      if constexpr (!kMT) { if (claimed) lpq[q] = pkq[q] * 4096 + atomicAdd(&s_hist[pkq[q]], 1); }
     }
   }
   int bagv[PER], bag_incl = -1;
@@ -289,10 +286,6 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
     const int c = isrep[q] ? s_cnt[hh[q]] : 0;
     mcnt[q] = c > 1 ? c : 0;
     m_mine += mcnt[q];
-  }
-  if constexpr (kStage) {   // one scan for two sums: list starts (low half), representatives in front of mine (high half)
-#pragma unroll
-    for (int q = 0; q < PER; ++q) m_mine += isrep[q] ? 1 << 16 : 0;
   }
   const int m_incl = wave_incl_scan(m_mine);
   if (lane == 63) s_wsum[wv] = m_incl;
@@ -319,7 +312,7 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
       }
     }
   };
-  if constexpr (!kMT && !kStage) reserve();
+  if constexpr (!kMT) reserve();
   if constexpr (kMT) {   // several tables: the partition of a pair needs the tables' partition ranges (wave 0, behind barrier A)
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
@@ -362,16 +355,10 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
   {
     int st = m_incl - m_mine;
     for (int k = 0; k < wv; ++k) st += s_wsum[k];
-    int flat = st >> 16;              // (kStage) representatives in front of mine
-    st &= 0xffff;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
       if (isrep[q]) s_sm[hh[q]] = (uint16_t)(mcnt[q] ? (st | 0x8000) : 0);
       st += mcnt[q];
-      if constexpr (kStage) { if (isrep[q]) lpq[q] = flat++; }
-    }
-    if constexpr (kStage) {
-      if (tid == THREADS - 1) a.tile_cnt[blockIdx.x] = flat;     // (the last thread's running count is the tile's total)
     }
   }
   int cnt_tile[PER];
@@ -413,12 +400,10 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
       wave_init_row(a, rp, ((uint64_t)khi << 32) | klo, (int)a.table_emb_dims[t], (int)a.table_value_dims[t]);
     }
   }
-  if constexpr (!kStage) {
 #pragma unroll
-    for (int j = 0; j < NPB; ++j) {
-      const int p = tid + j * THREADS;
-      if (p < a.P) s_hist[p] = my_base[j];
-    }
+  for (int j = 0; j < NPB; ++j) {
+    const int p = tid + j * THREADS;
+    if (p < a.P) s_hist[p] = my_base[j];
   }
   PST(8);
   __syncthreads();   // D: the records' slot codes, the reserved bases
@@ -432,21 +417,14 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
     const int li = q * THREADS + tid;
     const int64_t i = tile0 + li;
     const int v = s_tab[hh[q]];
-    int ref;
-    if constexpr (kStage) {
-      ref = (int)tile0 + v;           // the staged record (big_index.h: split_records_kernel forwards it)
-    } else {
-      const int pk = v >> 12, idx = s_hist[pk] + (v & 4095);
-      ref = idx < kListCap ? pk * kPartCap + sub * kSubCap + idx : -1;
-    }
+    const int pk = v >> 12, idx = s_hist[pk] + (v & 4095);
+    const int ref = idx < kListCap ? pk * kPartCap + sub * kSubCap + idx : -1;
     const int g = s_cnt[hh[q]];
     const int sm = s_sm[hh[q]];
     int bag;
     if constexpr (kSeq) bag = (int)i; else bag = s_bag[li];
     if (isrep[q]) {
-      if constexpr (kStage)
-        a.stage_rec[ref] = make_uint4((uint32_t)i, (uint32_t)((sm & 0x8000) ? (int)tile0 + (sm & 0x7fff) : bag), (uint32_t)g, (uint32_t)cnt_tile[q]);
-      else if (ref >= 0)
+      if (ref >= 0)
         a.rec[ref] = make_uint4((uint32_t)i, (uint32_t)((sm & 0x8000) ? (int)tile0 + (sm & 0x7fff) : bag), (uint32_t)g, (uint32_t)cnt_tile[q]);
       else
         a.hdr[a.ovf_word] = a.ovf_val;   // a partition received more records than it can hold: the step is flagged (see the module)

@@ -407,7 +407,7 @@ static int launch_pooled(PoolArgs a, bool vec, hipStream_t stream) {
     const int nsub = 64 >> l;
     // bags per block = 4 waves x nsub groups x NB
     if (ncol <= 1) {
-      static const int variant = getenv("MI355_POOL_VARIANT") ? atoi(getenv("MI355_POOL_VARIANT")) : 0;
+      constexpr int variant = 0;
 #define MI355_POOL_V(NBV, RPRV)                                                                                          \
   do {                                                                                                                   \
     if (a.row_addr) hipLaunchKernelGGL((gather_pooled_vec_kernel<SDT, DDT, 1, NBV, true, RPRV>), dim3(grid_for(a.FB, 4 * nsub * NBV, 1 << 20)), dim3(256), 0, stream, a, l); \

@@ -139,7 +139,7 @@ int mi355_vmm_destroy(void* handle) {
     // to lose first-touch row stores of its first kernel -- keys found, rows zero, for a third of the rows, only when another
     // extendable buffer had been destroyed just before (round 5, tools/runs/diag_growth.py; stale translations of the old mapping
     // is the only reading that fits).  Virtual address space is not a scarce resource; the physical chunks are released above.
-    static const bool free_va = getenv("MI355_VMM_FREE_VA") && atoi(getenv("MI355_VMM_FREE_VA")) != 0;
+    constexpr bool free_va = false;   // (address ranges are never handed back: DESIGN.md, VMM value buffers)
     if (v->base && free_va) hipMemAddressFree(v->base, v->reserved);
   } else {
     for (auto& r : v->registered) hipHostUnregister(r.first);

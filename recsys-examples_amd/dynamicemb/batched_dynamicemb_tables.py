@@ -405,7 +405,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         self._empty_tensor = nn.Parameter(torch.empty(10, requires_grad=True, device=self.device_,
                                                       dtype=self.embedding_dtype))
         self._pin = False  # ref-counter pinning is only needed when prefetch runs ahead of backward
-        self._early_csr = os.environ.get("MI355_EARLY_CSR", "1") != "0"   # build the backward's CSR under the forward
+        self._early_csr = True   # (per-op path) build the backward's CSR on the side stream under the forward
         # fused index stage (csrc/fused_fwd.hip): HBM storage, no admission, 32-bit slot ids, not the deterministic mode
         self._fused = (os.environ.get("MI355_FUSED", "1") != "0" and storage_mode == "hbm" and self._admit_strategy is None
                        and T_ <= 128 and self.table.capacity_ < (1 << 31) - 512
@@ -413,7 +413,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         self._fused_aux = None
         import weakref
         self._live_steps = weakref.WeakSet()   # forward contexts whose backward is still to come
-        self._fused_side = os.environ.get("MI355_FUSED_SIDE", "0") != "0"
+        self._fused_side = False   # (the fused forward forks nothing: measured slower back to back)
         self._plan = None
         # the pre-bound step (_plan_forward): the steady-state configuration only -- everything else keeps the general path
         self._plan_ok = (self._fused and not self._growth and not self._fused_side and os.environ.get("MI355_PLAN", "1") != "0"

@@ -62,7 +62,7 @@ def all_ranks_ok(pg, ok: bool, device) -> bool:
 def bounded_wait(ready, seconds: Optional[float] = None) -> bool:
     """polls `ready()` (an event query) for at most `seconds`: the hang guard of the self-check"""
     if seconds is None:
-        seconds = float(os.environ.get("MI355_EXCHANGE_TIMEOUT_S", "30"))
+        seconds = 30.0
     end = time.monotonic() + seconds
     while not ready():
         if time.monotonic() > end:

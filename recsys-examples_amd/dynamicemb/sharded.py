@@ -180,7 +180,7 @@ class RowWiseShardedLookup:
         return "native" if self._nx is not None and not self._nx.dead else "c10d"
 
     def _selftest_native(self, nx, values, offsets) -> None:
-        """One-time check of the in-library exchange against the c10d sequence, every wait bounded (MI355_EXCHANGE_TIMEOUT_S):
+        """One-time check of the in-library exchange against the c10d sequence, every wait bounded (30 s):
         the input dist of THIS batch through both (received keys / offsets / lengths / splits must be equal), then the three
         output collectives on small rank-dependent blocks.  Raises on any difference or timeout."""
         from .native_exchange import bounded_wait

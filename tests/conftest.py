@@ -18,12 +18,9 @@ if STANDINS not in sys.path:
     sys.path.append(STANDINS)
 
 
-# the per-call knobs of the fused forward (MI355_PROBE_C, MI355_FUSED_FASTMOD) are read once per process unless this is set
+# the per-call knobs of the fused forward (MI355_PROBE_C: the probe kernel's tile shape) are read once per process unless this is set
 # before the library's first call: the suite switches them between tests
 os.environ.setdefault("MI355_ENV_LIVE", "1")
-# the big-batch stage of the fused forward (csrc/big_index.h) is opt-in; the suite runs with it on (its tests need it, every other
-# test with more than 1 M keys then exercises it as well)
-os.environ.setdefault("MI355_BIG", "1")
 
 
 def pytest_configure(config):

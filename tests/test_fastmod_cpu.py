@@ -1,4 +1,4 @@
-"""The integer identities behind `fused_probe_kernel<.., kFast>` (recsys-examples_amd/csrc/fused_fwd.hip, MI355_FUSED_FASTMOD=1),
+"""The integer identities behind `fused_probe_kernel<.., kFast>` (recsys-examples_amd/csrc/fused_fwd.hip, the default wherever the bucket capacity is a power of two),
 restated with Python integers: the bucket of a key without a 64-bit division must be the bucket of the generic formula
 `bucket = (hash % (n * C)) // C` (types.cuh:308-396 of the reference; oracle/demb_oracle.c) for every 63-bit hash, every
 bucket count n and every power-of-two bucket capacity C -- including the quotient estimate that is one short and the bucket

@@ -130,11 +130,11 @@ def test_csr_writing_partition_kernel_against_the_per_op_chain_around_its_size_l
 
 @pytest.mark.parametrize("bags,pooling,opt,strategy", [(450_000, "SUM", "SGD", "TIMESTAMP"), (1_350_000, "SUM", "ADAM", "LFU"),
                                                        (2_300_000, "NONE", "SGD", "STEP")])
-def test_big_batches_take_the_partitioned_stage_against_the_per_op_chain(bags, pooling, opt, strategy, monkeypatch):
-    """Batches beyond 1 M keys (round 5, csrc/big_index.h: tile-major records, one split into the partitions' lists, the partition
-    kernel over 4 096-record lists) against the per-op chain at ~2 M and ~6 M keys (pooled) and 2.3 M tokens (sequence): same
-    outputs, same unique counts, a consistent lazily materialised reverse index, same stored keys and rows after training steps
-    that insert, and steps in the steady state."""
+def test_batches_beyond_a_million_keys_against_the_per_op_chain(bags, pooling, opt, strategy, monkeypatch):
+    """Batches beyond 1 M keys (the per-slot-counter index path: the partitioned stage serves 64 K .. 1 M keys; round 5's opt-in
+    stage for larger batches measured at parity with this path and was removed in round 6) against the per-op chain at ~2 M and
+    ~6 M keys (pooled) and 2.3 M tokens (sequence): same outputs, same unique counts, a consistent reverse index, same stored keys
+    and rows after training steps that insert, and steps in the steady state."""
     cap = 1 << 23
     ref = _mk(False, (16,), cap=cap, pooling=pooling, opt=opt, strategy=strategy, learning_rate=0.2, monkeypatch=monkeypatch)
     dut = _mk(True, (16,), cap=cap, pooling=pooling, opt=opt, strategy=strategy, learning_rate=0.2, monkeypatch=monkeypatch)
@@ -152,7 +152,6 @@ def test_big_batches_take_the_partitioned_stage_against_the_per_op_chain(bags, p
         assert nk > (1 << 20)
         o_ref, s_ref = ref._forward_impl(keys, off, train=True)
         o_dut, s_dut = dut._forward_impl(keys, off, train=True)
-        assert getattr(s_dut, "lazy", False), "the batch did not take the partitioned stage"
         torch.testing.assert_close(o_ref, o_dut, rtol=1e-5, atol=1e-5, msg=f"step {it} ({nk} keys): forward differs")
         nu_r, nu_d = int(s_ref.uoff[-1]), int(s_dut.uoff[-1])
         assert nu_r == nu_d
@@ -174,14 +173,15 @@ def test_big_batches_take_the_partitioned_stage_against_the_per_op_chain(bags, p
     torch.testing.assert_close(v1[o1], v2[o2], rtol=5e-5, atol=5e-6)
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3"])
-@pytest.mark.parametrize("pooling,bags,bucket", [("SUM", 60_000, 128), ("NONE", 150_000, 128), ("SUM", 40_000, 16)])
+@pytest.mark.parametrize("variant", ["1", "2", "3"])
+@pytest.mark.parametrize("pooling,bags,bucket", [("SUM", 60_000, 128), ("NONE", 150_000, 128), ("SUM", 40_000, 16), ("SUM", 60_000, 48)])
 def test_every_tile_shape_of_the_round5_probe_kernel_against_the_per_op_chain(variant, pooling, bags, bucket, monkeypatch):
-    """probe_c_kernel (csrc/probe_c.h; MI355_PROBE_C picks the tile shape, 0 = the round-3 kernel) against the per-op chain:
-    pooled and sequence lookups, steps that insert every key, steps in the steady state, a 16-slot-bucket table that evicts
-    (deferred keys resolved by the partition kernel).  Same outputs, same unique counts, same stored keys and rows."""
+    """probe_c_kernel (csrc/probe_c.h; MI355_PROBE_C, a test hook, picks the tile shape) against the per-op chain: pooled and
+    sequence lookups, steps that insert every key, steps in the steady state, a 16-slot-bucket table that evicts (deferred keys
+    resolved by the partition kernel); 48-slot buckets (not a power of two) take the round-3 probe kernel with the generic bucket
+    arithmetic.  Same outputs, same unique counts, same stored keys and rows."""
     monkeypatch.setenv("MI355_PROBE_C", variant)
-    cap = 1 << 20 if bucket == 128 else 1 << 16
+    cap = 1 << 20 if bucket == 128 else (1 << 16 if bucket == 16 else 48 << 14)
     ref = _mk(False, (16,), cap=cap, pooling=pooling, opt="SGD", strategy="STEP" if bucket == 16 else "TIMESTAMP", bucket=bucket,
               learning_rate=0.2, monkeypatch=monkeypatch)
     dut = _mk(True, (16,), cap=cap, pooling=pooling, opt="SGD", strategy="STEP" if bucket == 16 else "TIMESTAMP", bucket=bucket,

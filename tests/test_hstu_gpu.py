@@ -627,11 +627,11 @@ def test_rab_without_drab_and_zero_bias():
 
 
 _FWD_VARIANTS = {
-    "rows64": {"MI355_HSTU_Q2": "2"},                                    # hstu_fwd_q2_kernel at every length (default: from 1 025 rows)
-    "rows64_pairs": {"MI355_HSTU_Q2": "2", "MI355_HSTU_PAIR": "2"},      # ... with row blocks in pairs on every batch (default: dense ones)
-    "rows32": {"MI355_HSTU_Q2": "0"},                                    # hstu_fwd_pc_kernel / hstu_fwd_pair_kernel at every length
-    "rows32_pairs": {"MI355_HSTU_Q2": "0", "MI355_HSTU_PAIR": "2"},
-    "one_stream": {"MI355_HSTU_PC": "0"},                               # hstu_fwd_kernel, register-staged tiles
+    "rows64": {"MI355_HSTU_FWD": "1"},                                   # hstu_fwd_q2_kernel at every length (default: from 1 025 rows)
+    "rows64_pairs": {"MI355_HSTU_FWD": "2"},                             # ... with row blocks in pairs on every batch (default: dense ones)
+    "rows32": {"MI355_HSTU_FWD": "3"},                                   # hstu_fwd_pc_kernel / hstu_fwd_pair_kernel at every length
+    "rows32_pairs": {"MI355_HSTU_FWD": "4"},
+    "one_stream": {"MI355_HSTU_FWD": "5"},                               # hstu_fwd_kernel, register-staged tiles
 }
 
 
@@ -640,8 +640,8 @@ def test_forward_kernel_variants(variant):
     """The d = 256 forward has four kernels (the one-kind LDS-DMA kernel of round 3 won on no shape and was removed in round 5).  Default since round 4: 8-wave workgroups of S waves and O waves (two waves per
     SIMD) -- hstu_fwd_q2_kernel (64 query rows per wave: two MFMAs per LDS fragment) from 1 025 rows per sequence,
     hstu_fwd_pc_kernel / hstu_fwd_pair_kernel (32 rows per wave) below; row blocks in (heavy, light) pairs on dense batches.
-    MI355_HSTU_PC=0 falls back to the one-kind register-staged kernel.  The library reads the switches
-    once, so every d = 256 test of this file (goldens, random jagged batches, contexts / targets, local windows, delta-q) is
+    MI355_HSTU_FWD (one test hook, values 1..5) forces each of them onto every shape; 5 is the one-kind register-staged kernel.
+    The library reads the hook once, so every d = 256 test of this file (goldens, random jagged batches, contexts / targets, local windows, delta-q) is
     re-run in a child process with each kernel forced onto every shape."""
     import subprocess
     import sys
@@ -688,7 +688,7 @@ def test_forward_64_rows_per_wave_is_bit_identical_on_long_jagged_batches(tmp_pa
     """From 1 025 rows per sequence the forward runs hstu_fwd_q2_kernel (64 query rows per wave).  Same MFMA order per output
     element, same roundings as the 32-rows kernels: the outputs of a jagged batch with sequences of 1 .. 4 096 rows must agree
     bit for bit under every mask rule (causal, none, contexts + targets, target groups, local windows) -- both kernels run in
-    child processes (the library reads MI355_HSTU_Q2 once) and print a hash of the output bits."""
+    child processes (the library reads MI355_HSTU_FWD once) and print a hash of the output bits."""
     import subprocess
     import sys
 
@@ -696,8 +696,8 @@ def test_forward_64_rows_per_wave_is_bit_identical_on_long_jagged_batches(tmp_pa
     script.write_text(_LONG_CASES_SCRIPT)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    for q2 in ("1", "0"):
-        r = subprocess.run([sys.executable, str(script), root], env=dict(os.environ, MI355_HSTU_Q2=q2), capture_output=True, text=True, timeout=600)
+    for q2 in ("1", "0"):       # "1": the default rule (64-row waves on these lengths), "0": 32-row waves forced (hook 3)
+        r = subprocess.run([sys.executable, str(script), root], env=dict(os.environ, MI355_HSTU_FWD="0" if q2 == "1" else "3"), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs[q2] = [ln for ln in r.stdout.splitlines() if ln and not ln.startswith("/opt")]
     assert len(outs["1"]) == 6 and outs["1"] == outs["0"], (outs["1"], outs["0"])

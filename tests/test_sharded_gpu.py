@@ -427,7 +427,6 @@ def test_the_self_check_of_the_in_library_exchange_passes_and_a_wrong_exchange_f
     keys = torch.from_numpy(rng.integers(0, 2000, off[-1]).astype(np.int64)).cuda()
     offs = torch.from_numpy(off).cuda()
     monkeypatch.setenv("MI355_EXCHANGE_SELFCHECK", "1")
-    monkeypatch.setenv("MI355_EXCHANGE_TIMEOUT_S", "20")
     mods = [_module(True, F, dim, torch.float32) for _ in range(3)]
     mk = lambda m: RowWiseShardedLookup(_ModuleLocal(m), F, [2000] * F, pooled=True, device=torch.device("cuda", 0),
                                         out_dtype=torch.float32, dist_type_per_feature=["roundrobin"] * F)

@@ -1,4 +1,4 @@
-"""C2 (Zipf) pattern of the fused gather+pool kernel: event-timed, checked against torch (MI355_POOL_VARIANT picks a kernel
+"""C2 (Zipf) pattern of the fused gather+pool kernel: event-timed, checked against torch (the library's default pooled gather
 variant, see value_ops.hip).  Usage: bench_gather_c2.py [iters]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,5 +29,5 @@ for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
 times.sort()
 err = (out.float() - want).abs().max().item()
 exact = torch.equal(out, want.bfloat16())
-print(f"variant {os.environ.get('MI355_POOL_VARIANT', '0'):>2s} nt {nt} nu {uk.numel()} gather median {times[len(times) // 2]:.1f} us min {times[0]:.1f} us  "
+print(f"nt {nt} nu {uk.numel()} gather median {times[len(times) // 2]:.1f} us min {times[0]:.1f} us  "
       f"max_err {err:.2e} exact_vs_sequential_fp32 {exact}")

@@ -22,12 +22,11 @@ ap.add_argument("--bwd", action="store_true", help="the dK pass of the backward 
 a = ap.parse_args()
 if a.q2:
     a.pc = True
-    os.environ["MI355_HSTU_PC"] = "1"; os.environ["MI355_HSTU_Q2"] = "1"
+    os.environ["MI355_HSTU_FWD"] = "1"
 elif a.pc:
-    os.environ["MI355_HSTU_PC"] = "1"; os.environ["MI355_HSTU_Q2"] = "0"
-    os.environ["MI355_HSTU_PAIR"] = "0"   # the stamps live in the unpaired kernel (hstu_fwd_pc_kernel)
+    os.environ["MI355_HSTU_FWD"] = "3"   # 32-row waves, unpaired: the stamps live in hstu_fwd_pc_kernel
 elif not a.bwd:
-    os.environ.setdefault("MI355_HSTU_PC", "0")
+    os.environ.setdefault("MI355_HSTU_FWD", "5")
 dev = torch.device("cuda")
 T = a.batch * a.seqlen
 cu = torch.arange(0, T + 1, a.seqlen, dtype=torch.int32, device=dev)

@@ -1,6 +1,6 @@
 """Forward / backward time of the d = 256 attention kernels over a set of batch shapes (one process, HIP events):
 C3 dense, dense 32 x 4096, and jagged Zipf(1.2) batches clipped to 4096 / 512 with several seeds -- the shapes the block
-scheduling knobs (MI355_HSTU_ROT, ...) are judged on.   python tools/hstu_shapes.py [--heads 4] [--dim 256]"""
+block-to-sequence maps were judged on.   python tools/hstu_shapes.py [--heads 4] [--dim 256]"""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "recsys-examples_amd")); sys.path.insert(0, ROOT)
@@ -44,7 +44,6 @@ def run(name, lengths):
     print(f"{name:34s} tokens {T:7d} max {L:5d}  fwd {tf * 1e3:8.1f} us {fl / tf / 1e9:6.0f} TF   bwd {tb * 1e3:8.1f} us {2.5 * fl / tb / 1e9:6.0f} TF", flush=True)
 
 
-print("MI355_HSTU_ROT =", os.environ.get("MI355_HSTU_ROT", "(default)"))
 run("C3 dense 32 x 512", [512] * 32)
 run("dense 32 x 4096", [4096] * 32)
 run("dense 8 x 4096", [4096] * 8)

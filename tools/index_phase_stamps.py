@@ -86,7 +86,7 @@ def dump(fn, nblk, nph, names, title, nlive=None):
 
 
 PROBE_C = ['start -> loads issued + LDS init + barrier 0', 'hash + bucket + digest prefetch issue + bag marks', 'wait: barrier A', 'LDS dedup (+ pair histogram) + bag scan half 1', 'wait: barrier B', 'reservation issued, reps, list starts, 2 key words issued, bag scan half 2', 'wait: barrier C', 'list starts, probe resolve, scores, reserved bases', 'wait: barrier D', '-', 'records + per-occurrence outputs']
-if os.environ.get("MI355_PROBE_C", "1") != "0":
+if True:
     dump("mi355_debug_stamps_probe", 1024, 12, PROBE_C, "probe_c_kernel")
 else:
     dump("mi355_debug_stamps_probe", 1024, 12, PROBE, "fused_probe_kernel")
@@ -102,7 +102,7 @@ EVICT = ["entry -> bucket lock taken", "re-probe of the bucket", "score scan: th
          "rest of the pass (other keys)", "-"]
 if os.environ.get("MI355_FUSED_PART", "2") != "1":
     dump("mi355_debug_stamps_evict", 1024, 10, EVICT, "part_evict: FIRST deferred key of every partition block that had one (any step so far)")
-if os.environ.get("MI355_FUSED_PART", "2") != "1" and os.environ.get("MI355_PART_FUSED", "1") == "2":
+if False:
     dump("mi355_debug_stamps_part", 1024, 10, PART_L[:9], "part3_lean (partition role of the gather's launch)")
 elif os.environ.get("MI355_FUSED_PART", "2") != "1":
     dump("mi355_debug_stamps_part", 1024, 10, PART2, "fused_part3_kernel")
