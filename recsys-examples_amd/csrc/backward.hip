@@ -78,8 +78,8 @@ __device__ __forceinline__ int entry_src(const BwdArgs& a, int sv) {
 #define HOT_UNR 8
 #endif
 #ifndef PIPE_KIT
-#define PIPE_KIT 4
-#endif
+#define PIPE_KIT 2      // round 6 (profiles/r06_bwd_variants.txt): 2 groups per lane group beat 4 by 1.5 us at C2 (twice the blocks, half the
+#endif                  // tail); 1 and 3 lose, and so do 1 or 3 entries per round and 1, 3 or 4 rows per group
 constexpr int kBwdGroupsPerLaneGroup = PIPE_KIT;  // consecutive row groups walked by one lane group (regular rows)
 
 __device__ __attribute__((aligned(16))) float g_zero_grad[1024];  // see g_zero_row in value_ops.hip

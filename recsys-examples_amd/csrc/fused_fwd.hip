@@ -1727,13 +1727,21 @@ fused_part3_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restric
 
 
 // pooled gather of path (c): per-occurrence addresses with late rows (address word 1 -> the slot in the key's record)
+#ifndef LATE_UNR
+#define LATE_UNR 2      // rows of a bag loaded per round.  Round 6 (profiles/r06_gather_variants.txt): 2 beats 4 by 1.6-1.7 us at C2 (bags of 1..10
+                        // rows: a round of 4 points up to 3 loads at the zero row, and those requests are what the kernel is short of); 1 and 3
+                        // lose, 8 loses; exec-masked loads instead of zero-row loads lose at every width
+#endif
+#ifndef LATE_KIT
+#define LATE_KIT 4      // consecutive bags per lane group
+#endif
 template <int SDT, int DDT>
 __global__ void __launch_bounds__(256) gather_pooled_late_kernel(PoolArgs g, LateRefs late, int lpr_log2) {
 #if MI355_STAMPS
   if (threadIdx.x == 0 && blockIdx.x < 16384) { g_st_fgather[blockIdx.x * 4] = __builtin_amdgcn_s_memtime(); g_st_fgather[blockIdx.x * 4 + 2] = wall_clock64(); }
 #endif
   const int64_t sg = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (64 >> lpr_log2) + (lane_id() >> lpr_log2);
-  gather_pooled_pipe<SDT, DDT, 3, 4, 4>(g, late, lpr_log2, sg);
+  gather_pooled_pipe<SDT, DDT, 3, LATE_UNR, LATE_KIT>(g, late, lpr_log2, sg);
 #if MI355_STAMPS
   if (threadIdx.x == 0 && blockIdx.x < 16384) { g_st_fgather[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime(); g_st_fgather[blockIdx.x * 4 + 3] = wall_clock64(); }
 #endif
@@ -2378,7 +2386,7 @@ int mi355_demb_forward_fused(
     } else {
       RoctxRange rg("op:gather_embedding");
       GatherTimer gt(stream);
-      const unsigned grid = (unsigned)grid_for(num_bags, 4 * nsub * 4, 1 << 20);
+      const unsigned grid = (unsigned)grid_for(num_bags, 4 * nsub * LATE_KIT, 1 << 20);
 #define LAUNCH_PG(S, D)                                                                                                                \
   do {                                                                                                                                 \
     if (part_fused) hipLaunchKernelGGL((gather_pooled_part_kernel<S, D>), dim3((grid + 1) / 2 + (unsigned)a.P), dim3(kP3lThreads), 0, stream, a, o, bptr, \
