@@ -733,6 +733,15 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         except Exception:
             pass
 
+    def _plan_key_now(self):
+        """everything a plan froze that somebody may replace or mutate later: the table objects (_expand / load), the scratch and
+        value-pointer tensors, and the hyper-parameters bound at creation (initializer seed and parameters, the optimizer state's
+        initial value, the score policy) -- a change rebuilds the plan at the next step"""
+        ia = self.initializer_args
+        return (id(self.table), self._fused_aux.data_ptr() if self._fused_aux is not None else 0, self.table_ptrs.data_ptr(),
+                self._seed, self.initial_accumulator_value, self._score_strategy, ia.mode, ia.mean, ia.std_dev, ia.lower, ia.upper,
+                ia.value)
+
     def _plan_build(self):
         L = lib()
         tb = self.table
@@ -756,7 +765,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         if not self._plan:
             raise RuntimeError("mi355_demb_plan_create failed")
         # what the plan froze: anything else that changes rebuilds it (the table objects are replaced by _expand / load)
-        self._plan_key = (id(tb), self._fused_aux.data_ptr(), self.table_ptrs.data_ptr())
+        self._plan_key = self._plan_key_now()
         self._plan_pooled = pooled
         self._plan_state = ctypes.c_int(-1)
         self._plan_state_ref = ctypes.byref(self._plan_state)
@@ -771,7 +780,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
 
     def _plan_forward(self, indices, offsets):
         plan = self._plan
-        if plan is None or self._plan_key[0] != id(self.table):
+        if plan is None or self._plan_key != self._plan_key_now():
             self._plan_invalidate()
             plan = self._plan_build()
         n = indices.numel()
@@ -875,7 +884,7 @@ class BatchedDynamicEmbeddingTablesV2(nn.Module):
         """index stage of a later batch on the current stream -- or, side given, on that stream behind what the current one
         holds, ordered by the library's own events --; None: not a batch of the partitioned path"""
         plan = self._plan
-        if plan is None or self._plan_key[0] != id(self.table):
+        if plan is None or self._plan_key != self._plan_key_now():
             self._plan_invalidate()
             plan = self._plan_build()
         if not self._plan_recency:

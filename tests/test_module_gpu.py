@@ -1207,3 +1207,39 @@ def test_external_storage_rejects_what_it_cannot_do():
     m = BatchedDynamicEmbeddingTablesV2(mk(), device=torch.device("cuda", 0))
     with pytest.raises(NotImplementedError, match="prefetch"):
         m.prefetch(torch.zeros(1, dtype=torch.int64, device="cuda"), torch.tensor([0, 1], device="cuda"))
+
+
+def test_the_prebound_plan_follows_the_hyper_parameters_it_froze():
+    """the pre-bound training step (mi355_demb_plan_*) binds the initializer, the optimizer state's initial value and the score
+    policy once; changing one of them later must reach the kernels (the plan is rebuilt at the next step), as it does on the
+    general path"""
+    from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
+    from dynamicemb.dynamicemb_config import (DynamicEmbInitializerArgs, DynamicEmbInitializerMode, DynamicEmbPoolingMode,
+                                              DynamicEmbScoreStrategy, DynamicEmbTableOptions, EmbOptimType)
+
+    def make():
+        opt = DynamicEmbTableOptions(dim=8, max_capacity=4096, index_type=torch.int64, embedding_dtype=torch.float32,
+                                     score_strategy=DynamicEmbScoreStrategy.STEP,
+                                     initializer_args=DynamicEmbInitializerArgs(mode=DynamicEmbInitializerMode.CONSTANT, value=1.5))
+        m = BatchedDynamicEmbeddingTablesV2([opt], pooling_mode=DynamicEmbPoolingMode.NONE, output_dtype=torch.float32,
+                                            optimizer=EmbOptimType.SGD, learning_rate=0.5, device=torch.device("cuda", 0))
+        m.train()
+        return m
+
+    m = make()
+    if not m._plan_ok:
+        pytest.skip("the pre-bound step is not in use in this configuration")
+    off = lambda n: torch.arange(n + 1, dtype=torch.int64, device="cuda")
+    a = torch.arange(0, 50, dtype=torch.int64, device="cuda")
+    out, st = m._forward_impl(a, off(50), train=True)
+    assert getattr(st, "plan_step", False) and bool((out == 1.5).all())
+    m._backward_impl(st, torch.zeros_like(out))
+    key0 = m._plan_key
+    m.initializer_args.value = -2.0                 # mutated in place: new keys must be initialised with it
+    b = torch.arange(100, 150, dtype=torch.int64, device="cuda")
+    out, st = m._forward_impl(b, off(50), train=True)
+    assert m._plan_key != key0 and bool((out == -2.0).all())
+    m._backward_impl(st, torch.zeros_like(out))
+    out, st = m._forward_impl(a, off(50), train=True)    # keys of the first step keep their rows
+    assert bool((out == 1.5).all())
+    m._backward_impl(st, torch.zeros_like(out))
