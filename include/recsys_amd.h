@@ -476,7 +476,8 @@ int mi355_demb_forward_fused(void* storage, const int64_t* table_bucket_offsets,
  * mi355_demb_fused_step_flooded(epoch, wait_ms) before it uses the step's CSR or unique numbering: 0 = complete; 1 (or 2: the
  * notice was overwritten 64 steps later, treated alike) = flooded: run mi355_demb_forward_fused_rerun (the arguments of the step's
  * forward call + its epoch; `out` untouched), which regroups the step on the per-slot-counter path over the same buffers, then
- * the backward as usual; -1 = the forward has not reached its partition kernel within wait_ms.  The steady state pays one host
+ * the backward as usual; -1 = the forward has not reached its partition kernel within wait_ms; 3 = a gather block of a
+ * sequence lookup abandoned its bounded wait for a partition block of the same launch (the output lacks rows: an error).  The steady state pays one host
  * read of pinned memory per step and no launch.  *join_token == -2 (a forward captured into a hipGraph, pin != 0, or
  * MI355_FUSED_OVERFLOW_RERUN=1): the re-run chain rode behind the gather in the same call, gated on the device; nothing to ask. */
 int mi355_demb_fused_step_flooded(int epoch, int wait_ms);

@@ -1789,7 +1789,7 @@ gather_rows_late_kernel(const int64_t* __restrict__ occ_addr, LateRefs late, int
   if (i0 >= n) return;
   const int64_t j = i0 + lane_id();
   uintptr_t rp = j < n ? (uintptr_t)occ_addr[j] : 0;
-  if (__ballot(rp == 1)) { if (rp == 1) rp = late_row(late, j); }
+  if (__ballot(rp == 1)) { if (rp == 1) rp = late_row<false>(late, j); }
   wave_copy_rows<SDT, DDT>(rp, i0, n, D, dst, dst_stride, lpr_log2);
 }
 
@@ -2001,7 +2001,8 @@ void mi355i_fused_stage(int stage, uint64_t protect) { t_stage = stage; t_protec
 // Has the forward with this epoch flooded a partition's record list?  0: no (its CSR is complete), 1: yes (re-run its index stage
 // with mi355_demb_forward_fused_rerun / mi355_demb_plan_rerun before its backward), -1: not known within wait_ms milliseconds
 // (the forward has not reached its partition kernel: a stuck GPU), 2: the notice was overwritten by a step 64 epochs later --
-// treat as flooded (a re-run of a clean step is harmless).  The wait spins on pinned memory; with a dense model between forward
+// treat as flooded (a re-run of a clean step is harmless), 3: a gather block of the step abandoned its bounded wait for a partition
+// block of the same launch (sequence lookups; gather_dev.h: late_row) -- the step's OUTPUT lacks rows: an error.  The wait spins on pinned memory; with a dense model between forward
 // and backward the word has long been written.
 int mi355_demb_fused_step_flooded(int epoch, int wait_ms) {
   if (epoch <= 0) return 0;
@@ -2012,7 +2013,7 @@ int mi355_demb_fused_step_flooded(int epoch, int wait_ms) {
   for (unsigned spin = 0;; ++spin) {
     const unsigned long long v = *slot;
     const int e = (int)(unsigned)(v & 0xffffffffull);
-    if (e == epoch) return (int)((v >> 32) & 1ull);
+    if (e == epoch) return ((v >> 33) & 1ull) ? 3 : (int)((v >> 32) & 1ull);   // 3: a gather block gave up waiting for its partition block
     if (e > epoch) return 2;   // a later epoch owns the slot (64 forwards were issued before this step's backward)
     if ((spin & 1023) == 1023 &&
         std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > wait_ms)
@@ -2362,7 +2363,7 @@ int mi355_demb_forward_fused(
     late.C = bucket_capacity; late.elem_bytes = a.elem_bytes; late.T = (int)num_tables;
     const int nsub = 64 >> lg;
     if (rerun_only) goto rerun_chain;      // (a flooded step: its forward ran, only the index stage is redone)
-    if (part_fused) { late.ready = a.part_ready; late.cap = kPartCap; }
+    if (part_fused) { late.ready = a.part_ready; late.cap = kPartCap; late.notice = a.notice; }
     else if (stage == 2) { }               // (the partition kernel ran with the step's index stage)
     else hipLaunchKernelGGL(fused_part3_kernel<kPartCap>, dim3((unsigned)a.P), dim3(kP3Threads), 0, stream, a, o, bptr, bcsr, hot);
     MI355_LAUNCH_CHECK();
@@ -2389,9 +2390,7 @@ int mi355_demb_forward_fused(
       const unsigned grid = (unsigned)grid_for(num_bags, 4 * nsub * LATE_KIT, 1 << 20);
 #define LAUNCH_PG(S, D)                                                                                                                \
   do {                                                                                                                                 \
-    if (part_fused) hipLaunchKernelGGL((gather_pooled_part_kernel<S, D>), dim3((grid + 1) / 2 + (unsigned)a.P), dim3(kP3lThreads), 0, stream, a, o, bptr, \
-                                       bcsr, hot, g, late, lg);                                                                        \
-    else hipLaunchKernelGGL((gather_pooled_late_kernel<S, D>), dim3(grid), dim3(256), 0, stream, g, late, lg);                         \
+    hipLaunchKernelGGL((gather_pooled_late_kernel<S, D>), dim3(grid), dim3(256), 0, stream, g, late, lg);                              \
   } while (0)
       if (value_dtype == 0 && out_dtype == 0) LAUNCH_PG(kF32, kF32);
       else if (value_dtype == 0) LAUNCH_PG(kF32, kBF16);

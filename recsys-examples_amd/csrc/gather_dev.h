@@ -80,13 +80,30 @@ struct LateRefs {
   int T = 1;                                  // tables (global slots are table-major: tbo[t] C <= slot < tbo[t + 1] C)
   const int32_t* ready = nullptr;             // partition blocks in the SAME launch (round 5): ready[p] != 0 once partition p's evictions
   int cap = 2048;                             // are in the records (records per partition: ref / cap = p)
+  unsigned long long* notice = nullptr;       // the step's host-visible notice word (fused_fwd.hip): bit 33 = a wait on `ready` was abandoned
 };
+// kReady: the caller's launch holds the partition blocks itself (part3_lean.h) and the lane waits for its partition's flag.  A
+// template parameter on purpose: compiled into the pooled gather -- where the flag is never set -- the rarely taken spin loop
+// cost the kernel's hot path 3.5 us in round 5 (28.9 -> 32.4 us) and 9 us once the wait was bounded (round 6: 31 -> 40 us).  What is
+// left of the rare path costs nothing (a stub in its place: same time) and must stay inlined (noinline: 31.6 -> 42 us;
+// profiles/r06_gather_variants.txt).
+template <bool kReady>
 __device__ __forceinline__ uintptr_t late_row(const LateRefs& L, int64_t j) {
   const int ref = L.occ_slot[j];
   if (ref < 0) return 0;
-  if (L.ready) {   // (rare: a key whose bucket was full) the partition block that evicts for it runs in this very launch, ahead of us
+  if constexpr (kReady) {   // (rare: a key whose bucket was full) the partition block that evicts for it runs in this very launch, ahead of us
+    // The partition blocks have the lowest block ids of the launch and are dispatched first -- in practice, not by any guarantee
+    // of the programming model (CU masks, a pre-empting queue, a serialising profiler): the wait is BOUNDED (~0.5 s).  Abandoned,
+    // the occurrence gets a zero row and the step's notice word says so: the host raises when it settles the step.
     const int32_t* rp = L.ready + ref / L.cap;
-    while (__hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+    unsigned spins = 0;
+    while (__hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 22)) {
+        if (L.notice) __hip_atomic_fetch_or(L.notice, 1ull << 33, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return 0;
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   const int z = (int)L.rec[ref].z;
@@ -178,12 +195,12 @@ __device__ __forceinline__ void gather_pooled_pipe(const PoolArgs& a, const Late
     if (a.D_offsets) { d0 = a.D_offsets[f]; Df = a.D_offsets[f + 1] - d0; }
     const int64_t L = hi_c - lo_c;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (kAddr == 3) { if (__ballot(rp_c == 1)) { if (rp_c == 1) rp_c = late_row(late, lo_c + c); } }
+    if constexpr (kAddr == 3) { if (__ballot(rp_c == 1)) { if (rp_c == 1) rp_c = late_row<false>(late, lo_c + c); } }
     add_rows(rp_c, (int)(L < LPR ? L : LPR), Df, acc);
     for (int64_t r = LPR; __ballot(r < L) != 0; r += LPR) {   // bags longer than a lane group: dependent hops
       const int64_t u = my_index(lo_c, hi_c, r);
       uintptr_t rp = my_row(u, lo_c, hi_c, r);
-      if constexpr (kAddr == 3) { if (__ballot(rp == 1)) { if (rp == 1) rp = late_row(late, lo_c + r + c); } }
+      if constexpr (kAddr == 3) { if (__ballot(rp == 1)) { if (rp == 1) rp = late_row<false>(late, lo_c + r + c); } }
       const int64_t left = L - r;
       add_rows(rp, (int)(left < 0 ? 0 : (left < LPR ? left : LPR)), Df, acc);
     }

@@ -263,23 +263,8 @@ __device__ __forceinline__ void part3_lean(FusedArgs& a, const EmitOut& o, int* 
   QST(9);
 }
 
-// the pooled gather of path (c) with the partition blocks in front (grid = P + gather blocks)
-template <int SDT, int DDT>
-__global__ void __launch_bounds__(kP3lThreads, 8)
-gather_pooled_part_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __restrict__ csr_src, HotList hot, PoolArgs g, LateRefs late,
-                          int lpr_log2) {
-  if ((int)blockIdx.x < a.P) { part3_lean<kPartCap>(a, o, ptr, csr_src, hot, (int)blockIdx.x); return; }
-  const int64_t bid = (int64_t)blockIdx.x - a.P;
-#if MI355_STAMPS
-  if (threadIdx.x == 0 && bid < 16384) { g_st_fgather[bid * 4] = __builtin_amdgcn_s_memtime(); g_st_fgather[bid * 4 + 2] = wall_clock64(); }
-#endif
-  const int64_t sg = (bid * (kP3lThreads >> 6) + (threadIdx.x >> 6)) * (64 >> lpr_log2) + (lane_id() >> lpr_log2);
-  gather_pooled_pipe<SDT, DDT, 3, 4, 4>(g, late, lpr_log2, sg);
-#if MI355_STAMPS
-  if (threadIdx.x == 0 && bid < 16384) { g_st_fgather[bid * 4 + 1] = __builtin_amdgcn_s_memtime(); g_st_fgather[bid * 4 + 3] = wall_clock64(); }
-#endif
-}
-
+// (the POOLED gather with the partition blocks in front was measured a loss at C2 -- 0.1227 -> 0.1288 ms, profiles/r05_part_fused.txt --
+//  and removed in round 6: pooled batches keep the partition kernel of their own)
 // the sequence gather of path (c) with the partition blocks in front
 template <int SDT, int DDT>
 __global__ void __launch_bounds__(kP3lThreads, 8)
@@ -291,7 +276,7 @@ gather_rows_part_kernel(FusedArgs a, EmitOut o, int* __restrict__ ptr, int* __re
   if (i0 >= n) return;
   const int64_t j = i0 + lane_id();
   uintptr_t rp = j < n ? (uintptr_t)occ_addr[j] : 0;
-  if (__ballot(rp == 1)) { if (rp == 1) rp = late_row(late, j); }
+  if (__ballot(rp == 1)) { if (rp == 1) rp = late_row<true>(late, j); }
   wave_copy_rows<SDT, DDT>(rp, i0, n, D, dst, dst_stride, lpr_log2);
 }
 

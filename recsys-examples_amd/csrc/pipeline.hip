@@ -353,6 +353,7 @@ int mi355_demb_plan_backward(void* plan, void* step_buf, int64_t step_bytes, int
   if (epoch > 0) {      // a path-(c) step: did its partition lists hold every record?  (one read of pinned memory)
     const int f = mi355_demb_fused_step_flooded(epoch, 20000);
     if (f < 0) { mi355_set_error("plan backward: the forward of this step never reported (GPU stuck?)"); return MI355_ELAUNCH; }
+    if (f == 3) { mi355_set_error("plan backward: a gather block of this step's forward gave up waiting for its partition block: the step's output lacks rows"); return MI355_ELAUNCH; }
     if (f > 0) return 2;   // nothing launched: mi355_demb_plan_rerun first, then this call again with epoch = 0
   }
   int64_t lay[13];

@@ -126,6 +126,9 @@ class _FusedStep:
             f = lib().mi355_demb_fused_step_flooded(ep, 20000)
             if f < 0:
                 raise RuntimeError("fused forward: the step never reported its partition state (GPU stuck?)")
+            if f == 3:
+                raise RuntimeError("fused forward: a gather block gave up waiting for the partition block of its own launch "
+                                   "(blocks were not dispatched in id order); the step's output lacks rows")
             if f:
                 self.module._rerun_step(self, ep)
 
