@@ -56,6 +56,11 @@ struct BwdArgs {
   HotList hot;              // hot-row task list built by mi355_group_by_unique (hot.n_tasks == nullptr: none)
   int hot_blocks;           // leading blocks of the launch that serve the hot tasks
   int wave_blocks;          // blocks after them whose waves serve the one-wave rows (hot.wave_*)
+  // consecutive row groups one lane group walks (<= PIPE_KIT).  Round 6 (profiles/r06_bwd_variants.txt): the walk COMPILED for 2 groups
+  // beats the one for 4 by 1.5 us at C2 (47.7 -> 46.1 us; the 4-group code stopped after 2 groups at run time does not: 47.5), 4 beat
+  // 2 by 1-1.5 % from the 4x batch on (fewer, longer walks keep more index loads ahead of the rows); 1 and 3 lose at C2, and so do
+  // 1 or 3 entries per round and 1, 3 or 4 rows per group.  Hence two instantiations of the SGD kernel, chosen by the batch size.
+  int kit;
   int one_feature;          // pooled, one feature (num_bags == batch): a source id IS the gradient row -- no division by the batch
   const int32_t* tile_bags; // nullable.  Round 3 (fused forward, csrc/fused_fwd.hip): a CSR entry e < 0 is a REFERENCE -- the
                             // source id is tile_bags[~e] (occurrences of one key inside one 2048-key tile are listed there by
@@ -78,8 +83,8 @@ __device__ __forceinline__ int entry_src(const BwdArgs& a, int sv) {
 #define HOT_UNR 8
 #endif
 #ifndef PIPE_KIT
-#define PIPE_KIT 2      // round 6 (profiles/r06_bwd_variants.txt): 2 groups per lane group beat 4 by 1.5 us at C2 (twice the blocks, half the
-#endif                  // tail); 1 and 3 lose, and so do 1 or 3 entries per round and 1, 3 or 4 rows per group
+#define PIPE_KIT 4      // groups per lane group the walk is compiled for; BwdArgs::kit says how many a launch uses
+#endif
 constexpr int kBwdGroupsPerLaneGroup = PIPE_KIT;  // consecutive row groups walked by one lane group (regular rows)
 
 __device__ __attribute__((aligned(16))) float g_zero_grad[1024];  // see g_zero_row in value_ops.hip
@@ -376,7 +381,8 @@ __device__ __forceinline__ void rows_pipelined(const BwdArgs& a, const OptArgs& 
   constexpr int WB = WDT == kF32 ? 4 : 2;
   const gptr_t zero = (gptr_t)(uintptr_t)g_zero_grad;
   const bool hot_on = a.hot.n_tasks != nullptr;
-  const int64_t ubase = sg * (int64_t)(KIT * NB);
+  const int kit = a.kit < KIT ? a.kit : KIT;
+  const int64_t ubase = sg * (int64_t)(kit * NB);
   if (ubase >= nu) return;  // no cross-lane operation below
   int pA[NB + 1];
   int64_t rA[NB];
@@ -456,7 +462,7 @@ __device__ __forceinline__ void rows_pipelined(const BwdArgs& a, const OptArgs& 
   stageP(1);
 #pragma unroll
   for (int it = 0; it < KIT; ++it) {
-    if (ubase + (int64_t)it * NB >= nu) break;
+    if (it >= kit || ubase + (int64_t)it * NB >= nu) break;
     stageS(nxt);       // CSR entries of group it+1 (its ptr / row_addr arrived with the previous wait)
     stageP(it + 2);    // ptr / row_addr of group it+2
     if (a.tile_bags) {   // reference entries (two occurrences of a cold key in one tile: ~1 % of these rows): a rare dependent hop
@@ -548,7 +554,7 @@ STAMP_ARRAY(g_st_bwd, 16384, 2)
 #if MI355_STAMPS
 struct BwdEndStamp { __device__ ~BwdEndStamp() { STAMP(g_st_bwd, 16384, 2, 1); } };
 #endif
-template <int WDT, int GDT, int NCOL, bool kVec, bool kSgd>
+template <int WDT, int GDT, int NCOL, bool kVec, bool kSgd, int KITT = kBwdGroupsPerLaneGroup>
 __global__ void __launch_bounds__(256) bwd_kernel(BwdArgs a, OptArgs o, int lpr_log2) {
   STAMP(g_st_bwd, 16384, 2, 0);
 #if MI355_STAMPS
@@ -680,7 +686,7 @@ __global__ void __launch_bounds__(256) bwd_kernel(BwdArgs a, OptArgs o, int lpr_
   // the table rows themselves are fetched up front (SGD) since their address only needs row_addr[u].
   constexpr int NB = NCOL == 1 ? PIPE_NB : (NCOL == 2 ? 2 : 1);
   constexpr int RPR = 2;
-  constexpr int KIT = kBwdGroupsPerLaneGroup;
+  constexpr int KIT = KITT;      // (the SGD walk of one-column-group rows is also compiled for 2 groups: see BwdArgs::kit)
   int64_t nu = a.max_unique;
   if (a.nu_dev) { int64_t m = *a.nu_dev; nu = m < nu ? m : nu; }
   const int64_t sg = ((int64_t)(blockIdx.x - a.hot_blocks - a.wave_blocks) * wpb + (threadIdx.x >> 6)) * NSUB + sub;
@@ -693,8 +699,9 @@ __global__ void __launch_bounds__(256) bwd_kernel(BwdArgs a, OptArgs o, int lpr_
       return;
     }
   }
-  for (int it = 0; it < KIT; ++it) {   // wave-uniform trip count (apply_sink shuffles inside)
-    const int64_t u0 = (sg * KIT + it) * NB;
+  const int kit_g = a.kit < KIT ? a.kit : KIT;
+  for (int it = 0; it < kit_g; ++it) {   // wave-uniform trip count (apply_sink shuffles inside)
+    const int64_t u0 = (sg * kit_g + it) * NB;
     int lo[NB], hi[NB];
     bool work[NB], have[NB], hotrow[NB];
     uintptr_t rowp[NB];
@@ -786,11 +793,15 @@ static int launch_bwd(BwdArgs a, OptArgs o, bool vec, hipStream_t stream) {
   a.wave_blocks = 0;
   constexpr int wave_cap = 1024;
   if (a.hot.n_tasks && a.hot.kwave > a.hot.khot) a.wave_blocks = a.hot.max_hot / 4 + 1 < wave_cap ? a.hot.max_hot / 4 + 1 : wave_cap;
-  const int grid = a.hot_blocks + a.wave_blocks + grid_for(a.max_unique, 4 * nsub * nb * kBwdGroupsPerLaneGroup, 1 << 20);
+  // (max_unique = the key count of the batch: C2 360 K, its 4x batch 1.44 M)
+  a.kit = (a.max_unique <= 720 * 1024 && vec && o.kind == kOptSgd && a.D_offsets == nullptr && ncol <= 1) ? 2 : kBwdGroupsPerLaneGroup;
+  const int grid = a.hot_blocks + a.wave_blocks + grid_for(a.max_unique, 4 * nsub * nb * a.kit, 1 << 20);
 #define MI355_BWD_LAUNCH(NC, V) hipLaunchKernelGGL((bwd_kernel<WDT, GDT, NC, V, false>), dim3(grid), dim3(256), smem, stream, a, o, l)
 #define MI355_BWD_LAUNCH_SGD(NC) hipLaunchKernelGGL((bwd_kernel<WDT, GDT, NC, true, true>), dim3(grid), dim3(256), smem, stream, a, o, l)
+#define MI355_BWD_LAUNCH_SGD2() hipLaunchKernelGGL((bwd_kernel<WDT, GDT, 1, true, true, 2>), dim3(grid), dim3(256), smem, stream, a, o, l)
   if (vec && o.kind == kOptSgd && a.D_offsets == nullptr) {
-    if (ncol <= 1) MI355_BWD_LAUNCH_SGD(1); else if (ncol <= 2) MI355_BWD_LAUNCH_SGD(2); else MI355_BWD_LAUNCH_SGD(4);
+    if (ncol <= 1 && a.kit == 2) MI355_BWD_LAUNCH_SGD2();
+    else if (ncol <= 1) MI355_BWD_LAUNCH_SGD(1); else if (ncol <= 2) MI355_BWD_LAUNCH_SGD(2); else MI355_BWD_LAUNCH_SGD(4);
   } else if (vec) {
     if (ncol <= 1) MI355_BWD_LAUNCH(1, true); else if (ncol <= 2) MI355_BWD_LAUNCH(2, true); else MI355_BWD_LAUNCH(4, true);
   } else {
@@ -799,6 +810,7 @@ static int launch_bwd(BwdArgs a, OptArgs o, bool vec, hipStream_t stream) {
   }
 #undef MI355_BWD_LAUNCH
 #undef MI355_BWD_LAUNCH_SGD
+#undef MI355_BWD_LAUNCH_SGD2
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }
