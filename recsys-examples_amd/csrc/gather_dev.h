@@ -418,112 +418,5 @@ __device__ __forceinline__ void gather_pooled_eval(const PoolArgs& a, ProbeRefs 
   }
 }
 
-// Flat-stream pooled gather of the bags [b0, b0 + bn) by ONE lane group of LPR = 1 << lpr_log2 lanes (rows of one column
-// group: D <= 4 * LPR; uniform D: a.D_offsets == nullptr; bn <= KB < LPR).  Called by whole lane groups; groups of a wave are
-// independent (shuffles stay inside the group).
-// kAddr: 0 dense source through rev, 1 row addresses per UNIQUE key through rev (one more index hop, one more pipeline stage),
-//        2 row addresses per OCCURRENCE (fused forward).
-template <int SDT, int DDT, int kAddr, int U, int KB>
-__device__ __forceinline__ void gather_pooled_flat(const PoolArgs& a, int lpr_log2, int64_t b0) {
-  const int LPR = 1 << lpr_log2;
-  const int c = lane_id() & (LPR - 1);
-  const gptr_t zero = (gptr_t)(uintptr_t)g_zero_row;
-  constexpr int EB = SDT == kF32 ? 4 : 2;
-  constexpr bool kTwoHop = kAddr == 1;
-  int bn = (int)(a.FB - b0 < (int64_t)KB ? a.FB - b0 : (int64_t)KB);
-  // offsets of my bags: lane i of the group holds offsets[b0 + i], i <= bn (KB < LPR)
-  const int64_t myoff = a.offsets[b0 + (c <= bn ? c : bn)];
-  const int olo = (int)(myoff & 0xffffffff), ohi = (int)(myoff >> 32);
-  auto off = [&](int i) -> int64_t {
-    i = i <= bn ? i : bn;
-    return (int64_t)(((uint64_t)(unsigned)__shfl(ohi, i, LPR) << 32) | (uint64_t)(unsigned)__shfl(olo, i, LPR));
-  };
-  const int64_t lo = off(0);
-  int64_t hi = off(bn);
-  hi = hi < a.n ? hi : a.n;
-  // index word of MY row (lane c < U) of the chunk at r: the per-occurrence row address (kAddr 2) or the reverse index
-  auto pre = [&](int64_t r) -> int64_t {
-    int64_t j = r + c;
-    j = j < hi ? j : hi - 1;
-    j = j < 0 ? 0 : j;
-    if constexpr (kAddr == 2) return a.row_addr[j]; else return a.rev[j];
-  };
-  // ... to the row address (0: no such row in this chunk / missing row)
-  auto fin = [&](int64_t w, int64_t r) -> uintptr_t {
-    uintptr_t p;
-    if constexpr (kAddr == 2) p = (uintptr_t)w;
-    else if constexpr (kAddr == 1) p = (uintptr_t)a.row_addr[w];
-    else p = (uintptr_t)a.src + (uintptr_t)(w * a.src_stride * EB);
-    return (r + c < hi && c < U) ? p : 0;
-  };
-  const bool col = 4 * c < a.D;
-  auto issue = [&](uintptr_t ad, float4 (&v)[U]) {
-    const int alo = (int)(ad & 0xffffffffu), ahi = (int)(ad >> 32);
-#pragma unroll
-    for (int q = 0; q < U; ++q) {
-      const uintptr_t base = (uintptr_t)(unsigned)__shfl(alo, q, LPR) | ((uintptr_t)(unsigned)__shfl(ahi, q, LPR) << 32);
-      const gptr_t p = (base != 0 && col) ? (gptr_t)(base + (uintptr_t)(4 * c * EB)) : zero;
-      v[q] = ld4g<SDT>(p);
-    }
-  };
-  // consume cursor: current bag (relative), its first row and the row behind its last
-  int b = 0;
-  int64_t bbeg = lo, bend = off(1);
-  // (feature, sample) of the current bag, advanced incrementally (one 32-bit division per lane group)
-  int f = (int)((uint32_t)b0 / (uint32_t)a.B), bb = (int)((uint32_t)b0 - (uint32_t)f * (uint32_t)a.B);
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto flush = [&]() {   // store the current bag's sum and move to the next bag
-    const int64_t L = bend - bbeg;
-    if (a.combiner == 1 && L > 0) { const float fl = (float)L; acc.x /= fl; acc.y /= fl; acc.z /= fl; acc.w /= fl; }
-    if (col) st4<DDT>(a.dst, (int64_t)bb * a.total_D + (int64_t)f * a.D + 4 * c, acc);
-    acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    ++b;
-    if (++bb == a.B) { bb = 0; ++f; }
-    bbeg = bend;
-    bend = off(b + 1);
-  };
-  auto consume = [&](int64_t r, const float4 (&v)[U]) {
-#pragma unroll
-    for (int q = 0; q < U; ++q) {
-      const int64_t j = r + q;
-      if (j < hi) {
-        add4(acc, v[q]);
-        while (b < bn && j + 1 >= bend) flush();    // (>=: empty bags behind this row are flushed as zeros)
-      }
-    }
-  };
-  while (b < bn && bend <= lo) flush();              // leading empty bags
-  if (lo >= hi) {                                    // no rows at all (every bag empty, or offsets beyond n)
-    while (b < bn) flush();
-    return;
-  }
-  float4 va[U], vb[U];
-  uintptr_t a1;
-  int64_t w2 = 0;
-  if constexpr (kTwoHop) {
-    const int64_t w0 = pre(lo), w1 = pre(lo + U);
-    w2 = pre(lo + 2 * U);
-    const uintptr_t a0 = fin(w0, lo);
-    a1 = fin(w1, lo + U);
-    issue(a0, va);
-  } else {
-    const uintptr_t a0 = fin(pre(lo), lo);
-    a1 = fin(pre(lo + U), lo + U);
-    issue(a0, va);
-  }
-  for (int64_t r = lo; r < hi; r += 2 * U) {
-    uintptr_t a2, a3;
-    int64_t w3 = 0, w4 = 0;
-    if constexpr (kTwoHop) { w3 = pre(r + 3 * U); a2 = fin(w2, r + 2 * U); } else { a2 = fin(pre(r + 2 * U), r + 2 * U); }
-    issue(a1, vb);
-    consume(r, va);
-    if (__ballot(r + U < hi) == 0) break;            // wave uniform: the other lane group of the wave may still have rows
-    if constexpr (kTwoHop) { w4 = pre(r + 4 * U); a3 = fin(w3, r + 3 * U); } else { a3 = fin(pre(r + 3 * U), r + 3 * U); }
-    issue(a2, va);
-    consume(r + U, vb);
-    a1 = a3; w2 = w4;
-  }
-  while (b < bn) flush();                             // trailing empty bags (and nothing else: every row has been consumed)
-}
 
 }  // namespace mi355

@@ -149,16 +149,6 @@ __global__ void __launch_bounds__(256) gather_pooled_pipe_kernel(PoolArgs a, int
   STAMP(g_st_gather, 16384, 2, 1);
 }
 
-// flat-stream form (gather_dev.h): a lane group owns KB consecutive bags and keeps U .. 2U rows in flight for its whole life
-template <int SDT, int DDT, int kAddr, int U, int KB>
-__global__ void __launch_bounds__(256) gather_pooled_flat_kernel(PoolArgs a, int lpr_log2) {
-  STAMP(g_st_gather, 16384, 2, 0);
-  const int NSUB = 64 >> lpr_log2;
-  const int64_t sg = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * NSUB + (lane_id() >> lpr_log2);
-  const int64_t b0 = sg * KB;
-  if (b0 < a.FB) gather_pooled_flat<SDT, DDT, kAddr, U, KB>(a, lpr_log2, b0);
-  STAMP(g_st_gather, 16384, 2, 1);
-}
 
 // scalar fallback (odd dims such as 7 / 11 / 13): lane handles elements lane, lane+64, ...
 template <int SDT, int DDT>
@@ -407,61 +397,20 @@ static int launch_pooled(PoolArgs a, bool vec, hipStream_t stream) {
     const int nsub = 64 >> l;
     // bags per block = 4 waves x nsub groups x NB
     if (ncol <= 1) {
-      constexpr int variant = 0;
-#define MI355_POOL_V(NBV, RPRV)                                                                                          \
-  do {                                                                                                                   \
-    if (a.row_addr) hipLaunchKernelGGL((gather_pooled_vec_kernel<SDT, DDT, 1, NBV, true, RPRV>), dim3(grid_for(a.FB, 4 * nsub * NBV, 1 << 20)), dim3(256), 0, stream, a, l); \
-    else hipLaunchKernelGGL((gather_pooled_vec_kernel<SDT, DDT, 1, NBV, false, RPRV>), dim3(grid_for(a.FB, 4 * nsub * NBV, 1 << 20)), dim3(256), 0, stream, a, l); \
-  } while (0)
-      // MI355_POOL_VARIANT=31: the flat-stream kernel of gather_dev.h (uniform D).  Measured equal to the pipelined kernel below
-      // on C2 (30.2 vs 29.7 us under rocprofv3 in the real step; 29.0 vs 27.9 us standalone on tools/ubench_gather.hip's data):
-      // both keep ~U rows per lane group in flight all the time; what is left is the imbalance of the bag lengths
-#ifndef POOL_FLAT_U
-#define POOL_FLAT_U 4
-#endif
-      if (variant == 31 && a.D_offsets == nullptr && a.FB < (1ll << 31) - 64) {
-#define MI355_POOL_F(KBV)                                                                                                          \
-  do {                                                                                                                             \
-    const int64_t groups = ceil_div(a.FB, KBV);                                                                                    \
-    const int grid = (int)ceil_div(groups, 4 * nsub);                                                                              \
-    if (a.row_addr && !a.rev) hipLaunchKernelGGL((gather_pooled_flat_kernel<SDT, DDT, 2, POOL_FLAT_U, KBV>), dim3(grid), dim3(256), 0, stream, a, l); \
-    else if (a.row_addr) hipLaunchKernelGGL((gather_pooled_flat_kernel<SDT, DDT, 1, POOL_FLAT_U, KBV>), dim3(grid), dim3(256), 0, stream, a, l);      \
-    else hipLaunchKernelGGL((gather_pooled_flat_kernel<SDT, DDT, 0, POOL_FLAT_U, KBV>), dim3(grid), dim3(256), 0, stream, a, l);  \
-  } while (0)
-        if (l == 3) MI355_POOL_F(4); else MI355_POOL_F(8);
-#undef MI355_POOL_F
-      } else if (variant <= 0 || variant >= 20) {
-#ifndef POOL_KIT
-#define POOL_KIT 4
-#endif
-        constexpr int KIT = POOL_KIT;
-        const int grid = grid_for(a.FB, 4 * nsub * KIT, 1 << 20);
+      // the software-pipelined kernel (gather_dev.h: gather_pooled_pipe).  Rounds 1-3 kept eight lock-step variants and a flat
+      // double-buffered stream next to it (measured equal at best: 30.2 vs 29.7 us at C2); removed in round 6 with their knob.
+      constexpr int KIT = 4;
+      const int grid = grid_for(a.FB, 4 * nsub * KIT, 1 << 20);
 #define MI355_POOL_P(UNRV)                                                                                                   \
   do {                                                                                                                       \
     if (a.row_addr && !a.rev) hipLaunchKernelGGL((gather_pooled_pipe_kernel<SDT, DDT, 2, UNRV, KIT>), dim3(grid), dim3(256), 0, stream, a, l); \
     else if (a.row_addr) hipLaunchKernelGGL((gather_pooled_pipe_kernel<SDT, DDT, 1, UNRV, KIT>), dim3(grid), dim3(256), 0, stream, a, l); \
     else hipLaunchKernelGGL((gather_pooled_pipe_kernel<SDT, DDT, 0, UNRV, KIT>), dim3(grid), dim3(256), 0, stream, a, l); \
   } while (0)
-        // rows per load batch: short bags (C2: 1..10 keys) run best with 4 (8 waves / SIMD), long bags with 8
-        const bool small = variant == 20 || (variant != 21 && a.n <= 8 * a.FB);
-        if (small) MI355_POOL_P(4); else MI355_POOL_P(8);
+      // rows per load batch: short bags (C2: 1..10 keys) run best with 4 (8 waves / SIMD), long bags with 8 (2, the optimum of the
+      // late-row gather of path (c) at C2, loses 0.5-1 % here at the 4x / 16x batches: profiles/r06_gather_variants.txt)
+      if (a.n <= 8 * a.FB) MI355_POOL_P(4); else MI355_POOL_P(8);
 #undef MI355_POOL_P
-      } else if (SDT == kF32 && DDT == kBF16) {
-        switch (variant) {
-          case 1: MI355_POOL_V(1, 4); break;
-          case 2: MI355_POOL_V(4, 2); break;
-          case 3: MI355_POOL_V(4, 4); break;
-          case 4: MI355_POOL_V(2, 2); break;
-          case 5: MI355_POOL_V(1, 8); break;
-          case 6: MI355_POOL_V(8, 1); break;
-          case 7: MI355_POOL_V(4, 1); break;
-          case 8: MI355_POOL_V(2, 4); break;
-          default: MI355_POOL_V(1, 4); break;  // measured best on C2 (rocprofv3: 36-38 us vs 40-51 us)
-        }
-      } else {
-        MI355_POOL_V(1, 4);
-      }
-#undef MI355_POOL_V
     } else if (ncol <= 2) {
       constexpr int NB = 2;
       if (a.row_addr) hipLaunchKernelGGL((gather_pooled_vec_kernel<SDT, DDT, 2, NB, true>), dim3(grid_for(a.FB, 4 * nsub * NB, 1 << 20)), dim3(256), 0, stream, a, l);
