@@ -98,11 +98,16 @@ int nccl_fail(int rc, const char* what) {
     if (rc2__ != 0) return rc2__;  \
   } while (0)
 
-// all-to-all of byte ranges: peer p gets send[soff[p] .. + scnt[p]), its bytes land at recv[roff[p] .. + rcnt[p])
-int all_to_all_bytes(Comm comm, int world, const char* send, const int64_t* soff, const int64_t* scnt, char* recv,
+// all-to-all of byte ranges: peer p gets send[soff[p] .. + scnt[p]), its bytes land at recv[roff[p] .. + rcnt[p]).
+// The rank's OWN range never goes through RCCL (round 6): a send / receive pair to oneself is a copy kernel plus ~15 us of host
+// time per call -- a stream-ordered device copy instead; with one rank no RCCL call is made at all.
+int all_to_all_bytes(Comm comm, int world, int rank, const char* send, const int64_t* soff, const int64_t* scnt, char* recv,
                      const int64_t* roff, const int64_t* rcnt, hipStream_t stream) {
+  if (scnt[rank] > 0) RW_HIP(hipMemcpyAsync(recv + roff[rank], send + soff[rank], (size_t)scnt[rank], hipMemcpyDeviceToDevice, stream));
+  if (world == 1) return 0;
   RW_NCCL(g_rccl.GroupStart(), "ncclGroupStart");
   for (int p = 0; p < world; ++p) {
+    if (p == rank) continue;
     RW_NCCL(g_rccl.Send(send + soff[p], (size_t)scnt[p], kNcclInt8, p, comm, stream), "ncclSend");
     RW_NCCL(g_rccl.Recv(recv + roff[p], (size_t)rcnt[p], kNcclInt8, p, comm, stream), "ncclRecv");
   }
@@ -110,12 +115,16 @@ int all_to_all_bytes(Comm comm, int world, const char* send, const int64_t* soff
   return 0;
 }
 
-// skip: a rank whose block does not travel (-1: none) -- the caller reads its own block in place
-int all_to_all_equal(Comm comm, int world, const void* send, void* recv, int64_t bytes_per_peer, hipStream_t stream, int skip = -1) {
-  if (world == 1 && skip == 0) return 0;
+// skip_self: the rank's own block does not travel at all -- the caller reads it in place (else it is copied on the stream)
+int all_to_all_equal(Comm comm, int world, int rank, const void* send, void* recv, int64_t bytes_per_peer, hipStream_t stream,
+                     bool skip_self = false) {
+  if (!skip_self && bytes_per_peer > 0)
+    RW_HIP(hipMemcpyAsync((char*)recv + rank * bytes_per_peer, (const char*)send + rank * bytes_per_peer, (size_t)bytes_per_peer,
+                          hipMemcpyDeviceToDevice, stream));
+  if (world == 1) return 0;
   RW_NCCL(g_rccl.GroupStart(), "ncclGroupStart");
   for (int p = 0; p < world; ++p) {
-    if (p == skip) continue;
+    if (p == rank) continue;
     RW_NCCL(g_rccl.Send((const char*)send + p * bytes_per_peer, (size_t)bytes_per_peer, kNcclInt8, p, comm, stream), "ncclSend");
     RW_NCCL(g_rccl.Recv((char*)recv + p * bytes_per_peer, (size_t)bytes_per_peer, kNcclInt8, p, comm, stream), "ncclRecv");
   }
@@ -230,7 +239,7 @@ int mi355_rw_input_begin(void* handle, int64_t num_features, int64_t batch_size,
   }
   RW_RC(mi355_block_bucketize(W, FB, batch_size, offsets, keys, block_sizes, dist_types, nullptr, new_lengths, new_offsets,
                               new_keys, nullptr, unbucketize_permute, stream));
-  RW_RC(all_to_all_equal(x->comm_in, W, new_lengths, recv_lengths, FB * (int64_t)sizeof(int64_t), stream));
+  RW_RC(all_to_all_equal(x->comm_in, W, x->rank, new_lengths, recv_lengths, FB * (int64_t)sizeof(int64_t), stream));
   RW_RC(mi355_exclusive_offsets(recv_lengths, W * FB, recv_offsets, stream));
   RW_RC(mi355_peer_splits(new_offsets, recv_offsets, FB, W, x->splits[slot], stream));
   RW_HIP(hipEventRecord(x->ev_counts[slot], stream));
@@ -275,7 +284,7 @@ int mi355_rw_input_keys(void* handle, int ticket, int64_t num_features, int64_t 
     soff[p] = s; roff[p] = r;
     s += scnt[p]; r += rcnt[p];
   }
-  RW_RC(all_to_all_bytes(x->comm_in, W, (const char*)new_keys, soff, scnt, (char*)recv_keys, roff, rcnt, stream));
+  RW_RC(all_to_all_bytes(x->comm_in, W, x->rank, (const char*)new_keys, soff, scnt, (char*)recv_keys, roff, rcnt, stream));
   if (W > 1 && num_features > 1) {   // recat (src, f, b) -> (f, src, b)
     MI355_CHECK_ARG(fm_lengths && fm_offsets && fm_keys, "recat buffers required");
     RW_RC(mi355_permute_lengths(W, num_features, batch_size, recv_lengths, fm_lengths, stream));
@@ -316,7 +325,7 @@ int mi355_rw_output_pooled(void* handle, const void* send, void* recv, int64_t n
   MI355_CHECK_ARG(x && send && recv && out, "bad arguments");
   const int64_t eb = wire_dtype == 0 /*float32*/ ? 4 : 2;
   // the rank's own block stays where the lookup wrote it: W - 1 blocks travel, the sum reads block `rank` from `send`
-  RW_RC(all_to_all_equal(x->comm_out, x->world, send, recv, numel_per_block * eb, stream, x->rank));
+  RW_RC(all_to_all_equal(x->comm_out, x->world, x->rank, send, recv, numel_per_block * eb, stream, true));
   return mi355_sum_chunks_self(recv, wire_dtype, x->world, numel_per_block, (const char*)send + x->rank * numel_per_block * eb,
                                x->rank, out, out_dtype, stream);
 }
@@ -339,7 +348,7 @@ int mi355_rw_alltoallv(void* handle, const void* send, const int64_t* send_count
     soff[p] = s; roff[p] = r;
     s += scnt[p]; r += rcnt[p];
   }
-  return all_to_all_bytes(x->comm_out, x->world, (const char*)send, soff, scnt, (char*)recv, roff, rcnt, stream);
+  return all_to_all_bytes(x->comm_out, x->world, x->rank, (const char*)send, soff, scnt, (char*)recv, roff, rcnt, stream);
 }
 
 }  // extern "C"
