@@ -241,19 +241,21 @@ struct BlockSeq { int b, h, start, end, z; };   // z: the block's rank inside it
 // column after another, heaviest first -- an XCD's 32 CUs then walk a column's key tiles in step and all but the first
 // reader hit that XCD's L2.  Needs B * H to be a multiple of 8 (else the plain grid).  Measured: dense 32 x 4096 forward 1.71 ->
 // 1.66 ms, backward 5.11 -> 4.94 ms; 8 x 4096 unchanged; C3 (4 blocks per column) 48 -> 58 us, hence columns of >= 16 blocks only.
-__device__ __forceinline__ BlockSeq seq_head_of_block(const AttnArgs& a) {
-  const int b0 = blockIdx.y, h0 = blockIdx.x, z0 = blockIdx.z;
+// (bz, nz): the block's rank and the ranks of its launch -- blockIdx.z / gridDim.z, or a role's share of them where two passes
+// ride in ONE launch (hstu_bwd_vq8_kernel)
+__device__ __forceinline__ BlockSeq seq_head_of_block(const AttnArgs& a, unsigned bz, unsigned nz) {
+  const int b0 = blockIdx.y, h0 = blockIdx.x, z0 = (int)bz;
   if (a.rot == 0 && a.colmajor == 0) return {b0, h0, a.cu_seqlens[b0], a.cu_seqlens[b0 + 1], z0};
   const unsigned bh = gridDim.x * gridDim.y;
   const unsigned step = (unsigned)(a.rot < 0 ? -a.rot : a.rot);
   const unsigned lin0 = blockIdx.x + gridDim.x * blockIdx.y;
-  const unsigned slot = (lin0 + step * blockIdx.z) % bh;
+  const unsigned slot = (lin0 + step * bz) % bh;
   const int b1 = (int)(slot / gridDim.x), h1 = (int)(slot - (unsigned)b1 * gridDim.x);
   // column-major candidate
-  const unsigned lin = lin0 + bh * blockIdx.z, xcd = lin & 7u, k = lin >> 3;
-  const unsigned col = xcd + 8u * (k / gridDim.z);
-  const int z2 = (int)(k % gridDim.z);
-  const bool cm_ok = a.colmajor != 0 && (bh & 7u) == 0 && gridDim.z >= 16;   // (long columns only: at 4 blocks per column it costs 20 %)
+  const unsigned lin = lin0 + bh * bz, xcd = lin & 7u, k = lin >> 3;
+  const unsigned col = xcd + 8u * (k / nz);
+  const int z2 = (int)(k % nz);
+  const bool cm_ok = a.colmajor != 0 && (bh & 7u) == 0 && nz >= 16;   // (long columns only: at 4 blocks per column it costs 20 %)
   const int b2 = cm_ok ? (int)(col / gridDim.x) : b0, h2 = cm_ok ? (int)(col % gridDim.x) : h0;
   const int t0 = a.cu_seqlens[0], t1 = a.cu_seqlens[gridDim.y];
   const int s0 = a.cu_seqlens[b0], e0 = a.cu_seqlens[b0 + 1], s1 = a.cu_seqlens[b1], e1 = a.cu_seqlens[b1 + 1];
@@ -263,6 +265,7 @@ __device__ __forceinline__ BlockSeq seq_head_of_block(const AttnArgs& a) {
   if (a.rot > 0 || a.rot < 0) return BlockSeq{b1, h1, s1, e1, z0};
   return BlockSeq{b0, h0, s0, e0, z0};
 }
+__device__ __forceinline__ BlockSeq seq_head_of_block(const AttnArgs& a) { return seq_head_of_block(a, blockIdx.z, gridDim.z); }
 // Row block a query-block owner of dispatch rank `rank` takes: heaviest first = the latest rows first (causal).  With contextual
 // rows the FIRST block is the heaviest of all -- its contextual rows reach every history key -- and goes first: left at the
 // end of the order it was a 8-tile tail behind a CU's other blocks (C3 shape with 4 contextual rows: forward 66 -> 5x us).
@@ -3489,13 +3492,13 @@ __device__ __forceinline__ void store_acc_rows(const f32x16_t (&acc)[D / 32], ui
 // dV from the stored P, 256 keys per workgroup.  The query steps are the union of what the dK pass ran for the block's two
 // 128-key halves (its blocks are kBM keys); a wave consults the span of ITS half to tell which sub-tiles exist.
 template <int D, int NW>
-__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_v_p8_kernel(BwdAttnArgs g) {
+__device__ __forceinline__ void hstu_bwd_v_p8_body(const BwdAttnArgs& g, unsigned bz, unsigned nz) {
   constexpr int kBM8 = 32 * NW;   // keys per workgroup
   static_assert(D == 256, "DMA rows of 32 chunks");
   const AttnArgs& a = g.f;
   constexpr int BQ = 64, NT = 2, TILE = BQ * D;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [2][64][256] dO tiles
-  const BlockSeq bs = seq_head_of_block(a);
+  const BlockSeq bs = seq_head_of_block(a, bz, nz);
   const int b = bs.b, h = bs.h;
   SeqInfo s;
   s.start = bs.start;
@@ -3574,13 +3577,18 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_v_p8_kernel
 // dQ from the stored dS, 256 query rows per workgroup (the layout juggling of hstu_bwd_q_ds_kernel: the 2 KB sub-tile goes
 // through a wave-private LDS patch and comes back through transpose reads)
 template <int D, int NW>
-__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_q_ds8_kernel(BwdAttnArgs g) {
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_v_p8_kernel(BwdAttnArgs g) {
+  hstu_bwd_v_p8_body<D, NW>(g, blockIdx.z, gridDim.z);
+}
+
+template <int D, int NW>
+__device__ __forceinline__ void hstu_bwd_q_ds8_body(const BwdAttnArgs& g, unsigned bz, unsigned nz) {
   constexpr int kBM8 = 32 * NW;   // query rows per workgroup
   static_assert(D == 256, "DMA rows of 32 chunks");
   const AttnArgs& a = g.f;
   constexpr int BK = 64, NT = 2, TILE = BK * D;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [2][64][256] K tiles | 8 waves x 2 x 2 KB dS patches
-  const BlockSeq bs = seq_head_of_block(a);
+  const BlockSeq bs = seq_head_of_block(a, bz, nz);
   const int b = bs.b, h = bs.h;
   SeqInfo s;
   s.start = bs.start;
@@ -3679,6 +3687,21 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_q_ds8_kerne
   fence_a_2w(acc);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (qi < s.L) store_acc_rows<D>(acc, g.dq + ((int64_t)(s.start + qi) * a.H + h) * D, hi);
+}
+
+template <int D, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_q_ds8_kernel(BwdAttnArgs g) {
+  hstu_bwd_q_ds8_body<D, NW>(g, blockIdx.z, gridDim.z);
+}
+
+// Round 6: the two one-GEMM passes in ONE launch -- they are independent (dV reads P, dQ reads dS, both written by the dK pass) and
+// at C3's 512 rows each is a single generation of blocks whose launch ramp and tail the other can fill: the first half of the
+// block ranks takes the dV role, the second the dQ role (LDS = the larger of the two: 80 KB, two workgroups per CU as before).
+template <int D, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_vq8_kernel(BwdAttnArgs g) {
+  const unsigned nz = gridDim.z >> 1;
+  if (blockIdx.z < nz) hstu_bwd_v_p8_body<D, NW>(g, blockIdx.z, nz);
+  else hstu_bwd_q_ds8_body<D, NW>(g, blockIdx.z - nz, nz);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -4039,6 +4062,18 @@ static void launch_bwd_x8(const BwdAttnArgs& g, int B, int max_seqlen, hipStream
     attr_set = true;
   }
   dim3 grid(g.f.H, B, (max_seqlen + 32 * NW - 1) / (32 * NW));
+#ifndef HSTU_VQ_MERGED
+#define HSTU_VQ_MERGED 1
+#endif
+  if (HSTU_VQ_MERGED && NW == 4) {
+    static bool attr_m = false;
+    if (!attr_m) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_vq8_kernel<256, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_q);
+      attr_m = true;
+    }
+    hipLaunchKernelGGL((hstu_bwd_vq8_kernel<256, NW>), dim3(grid.x, grid.y, 2 * grid.z), dim3(64 * NW), smem_q, stream, g);
+    return;
+  }
   hipLaunchKernelGGL((hstu_bwd_v_p8_kernel<256, NW>), grid, dim3(64 * NW), smem_v, stream, g);
   hipLaunchKernelGGL((hstu_bwd_q_ds8_kernel<256, NW>), grid, dim3(64 * NW), smem_q, stream, g);
 }
