@@ -2327,7 +2327,7 @@ int mi355_demb_forward_fused(
     else hipLaunchKernelGGL((probe_c_kernel<TILE, THREADS, WPS, false, false>), grid, blk, 0, stream, a);                               \
   } while (0)
         if (cap == 2048) LAUNCH_PC(2048, 1024, 4);
-        else LAUNCH_PC(1024, 1024, 8);
+        else LAUNCH_PC(1024, 1024, 4);      // (one block per CU by construction: the register budget of four waves per SIMD)
         (void)0;
 #undef LAUNCH_PC
       } else {

@@ -24,8 +24,10 @@
 //   * no search: a block GUESSES its bag range from its position (bag ~ position x bags / keys), loads the offsets of a
 //     2 048-bag window around the guess with the key loads (coalesced, nothing depends on anything), and checks that the window
 //     covers the tile; only a block whose window does not (bag lengths far from uniform) searches;
-//   * the key words of the FIRST TWO digest matches are fetched together, a phase ahead of their use; the dependent re-probe is
-//     left to the ~0.1 % of keys with two false positives in front of them (and to misses);
+//   * (round 6) no digest vector at all on the fast path: the key's HOME GROUP -- the 16 key words its probe starts in, one aligned
+//     128-byte line at the usual 128-slot buckets -- is fetched by 8 lanes and compared directly: one random line per key
+//     instead of two dependent ones (round 5: digest vector, then the key words of the first two digest matches); keys that
+//     are not in their home group (and misses) take the full probe (thread_probe), as before;
 //   * five barriers instead of eleven; the dedup hash comes out of the table hash (no second fmix64); the representative of a key
 //     is whichever occurrence claimed the LDS entry (no atomicMin); rows inserted by the block are initialised by the wave that
 //     inserted them, straight from registers.
@@ -48,6 +50,12 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
   __shared__ int s_bag[kSeq ? 1 : TILE];
   __shared__ int s_hist[kPartMax];     // records of this tile per partition, then their base in the partition's list
   __shared__ int s_brange[2], s_wmax[NW], s_wsum[NW], s_cover;
+  // round 6: the HOME GROUP of a key -- the 16 key words its probe starts in, one aligned 128-byte line at the usual 128-slot
+  // buckets -- is fetched by 8 lanes (16 bytes each) and compared directly: one random line per key instead of two dependent ones
+  // (16-byte digest vector, then the key words of the digest matches).  s_grp: the line of every key (bucket * groups per
+  // bucket + group; -1: none), s_pos: position of the key inside its group (-1: not there -> the full probe)
+  __shared__ int s_grp[TILE];
+  __shared__ signed char s_pos[TILE];
   __shared__ uint16_t s_t[kMT ? TILE : 1];
   __shared__ int64_t s_seg[kMT ? kFusedMaxT + 1 : 1], s_tbo[kMT ? kFusedMaxT + 1 : 1], s_tptr[kMT ? kFusedMaxT : 1];
   __shared__ int s_rowb[kMT ? kFusedMaxT : 1];
@@ -142,7 +150,6 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
   const int Cm = (int)a.t.C - 1;
   int bq[PER], tq[PER], pkq[PER];  // bucket (-1: key without a home), table, partition of the key's bucket
   int64_t hq[PER];
-  uint4 dvq[PER];
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
     const int li = q * THREADS + tid;
@@ -171,7 +178,7 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
     bq[q] = ok ? (int)(bb + (int64_t)r) : -1;
     if constexpr (!kMT) pkq[q] = bq[q] < 0 ? a.P - 1 : (int)((uint32_t)bq[q] / (uint32_t)(a.spp >> cshift));
     const int start = ((int)hash & Cm) & ~15;
-    dvq[q] = *reinterpret_cast<const uint4*>(a.t.dig(ok ? bq[q] : 0) + start);   // unconditional: bucket 0 for homeless keys
+    s_grp[li] = ok ? (int)(((int64_t)bq[q] << (cshift - 4)) + (start >> 4)) : -1;
   }
   if constexpr (!kSeq) {
     // a bag marks the tile position of its first key (a bag that began in an earlier tile: position 0); the window covers the
@@ -236,6 +243,38 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
       if (l == 63) s_pb[T] = i1;
     }
   }
+  // the home groups of the wave's 64 PER keys: 8 keys per load instruction, lane = (key, 16-byte chunk); issued here, behind
+  // barrier A and in front of the dedup, for EVERY occurrence (for the representatives only, behind the dedup: slower, the batch
+  // no longer runs under the dedup -- profiles/r06_probe_keyline.txt)
+  constexpr int NLN = 8 * PER;
+  uint4 lnq[NLN];
+  auto issue_lines = [&]() {
+    const int gsh = cshift - 4, gmask = (1 << gsh) - 1;
+#pragma unroll
+    for (int j = 0; j < NLN; ++j) {
+      const int k = (j >> 3) * THREADS + wv * 64 + (j & 7) * 8 + (lane >> 3);
+      const int grp = s_grp[k];
+      const int gb = grp < 0 ? 0 : grp >> gsh, gg = grp < 0 ? 0 : grp & gmask;
+      lnq[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(a.t.keys(gb)) + gg * 128 + (lane & 7) * 16);
+    }
+  };
+  auto compare_lines = [&]() {   // a lane holds two key words of key k; the octet's match (keys are unique: at most one) -> s_pos[k]
+#pragma unroll
+    for (int j = 0; j < NLN; ++j) {
+      const int k = (j >> 3) * THREADS + wv * 64 + (j & 7) * 8 + (lane >> 3);
+      const uint64_t key = s_key[k];
+      const uint64_t w0 = ((uint64_t)lnq[j].y << 32) | lnq[j].x, w1 = ((uint64_t)lnq[j].w << 32) | lnq[j].z;
+      const bool live = s_grp[k] >= 0;
+      const uint64_t b0 = __ballot(live && w0 == key), b1 = __ballot(live && w1 == key);
+      const int sh = lane & ~7;
+      const uint32_t x0 = (uint32_t)(b0 >> sh) & 0xffu, x1 = (uint32_t)(b1 >> sh) & 0xffu;
+      int pos = -1;
+      if (x0) pos = 2 * (__ffs(x0) - 1);
+      else if (x1) pos = 2 * (__ffs(x1) - 1) + 1;
+      if ((lane & 7) == 0) s_pos[k] = (signed char)pos;
+    }
+  };
+  issue_lines();
   // ---- phase 2: LDS dedup.  The entry's hash comes out of the table hash (bits above the digest); whoever claims the entry
   //      represents the key.  Running maximum of the bag marks, first half (thread t owns the positions t PER ..).
   //      The claimer also counts the pair in the tile's histogram over the partitions (the partition follows from the BUCKET,
@@ -325,19 +364,7 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
       }
     }
   }
-  uint64_t kc0[PER], kc1[PER];
-  int c0[PER], c1[PER];
-#pragma unroll
-  for (int q = 0; q < PER; ++q) {
-    uint32_t m = eq_mask16(dvq[q], digest_of(hq[q]));
-    const int start = ((int)hq[q] & Cm) & ~15;
-    c0[q] = m ? start + __ffs(m) - 1 : -1;
-    m &= m - 1;
-    c1[q] = m ? start + __ffs(m) - 1 : -1;
-    const uint64_t* ks = a.t.keys(bq[q] >= 0 ? bq[q] : 0);
-    kc0[q] = ks[c0[q] >= 0 ? c0[q] : 0];
-    kc1[q] = ks[c1[q] >= 0 ? c1[q] : (c0[q] >= 0 ? c0[q] : 0)];
-  }
+  compare_lines();
   if constexpr (!kSeq) {
     int bbase = -1;
     for (int k = 0; k < wv; ++k) bbase = s_wmax[k] > bbase ? s_wmax[k] : bbase;
@@ -375,8 +402,8 @@ __global__ void __launch_bounds__(THREADS, WPS) probe_c_kernel(FusedArgs a) {
       if (bq[q] >= 0) {
         const int64_t b = bq[q];
         int slot;
-        if (c0[q] >= 0 && kc0[q] == key) slot = c0[q];
-        else if (c1[q] >= 0 && kc1[q] == key) slot = c1[q];
+        const int gpos = s_pos[q * THREADS + tid];
+        if (gpos >= 0) slot = (((int)hq[q] & Cm) & ~15) + gpos;
         else slot = thread_probe<true>(a, b, key, hq[q], cnt, inserted);
         if (slot >= 0) {
           gslot = (int)(b * a.t.C + slot);
