@@ -328,7 +328,7 @@ def kernel_roofline(module, batches, grad, batch, D, e=4, o=2):
             if traffic is not None:
                 break
     if batch == 65536:
-        for tag in ("r05", "r04", "r03", "r02", "r01"):
+        for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")))["kernels"]
                 key = dom[0] if dom[0] in pmc else dom[0].replace("late", "pipe")
