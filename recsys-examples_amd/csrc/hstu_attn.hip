@@ -364,6 +364,12 @@ __device__ __forceinline__ FuncExt func_ext_wave(FuncExt e) {
   }
   return e;
 }
+// over the 64 rows of a wave whose lanes hold one row each
+__device__ __forceinline__ FuncExt func_ext_wave64(FuncExt e) {
+  e = func_ext_wave(e);
+  const FuncExt o{__shfl_xor(e.f0, 32, 64), __shfl_xor(e.lo, 32, 64), __shfl_xor(e.hi, 32, 64), __shfl_xor(e.f0min, 32, 64)};
+  return func_ext_merge(e, o);
+}
 __device__ __forceinline__ bool func_ext_hits(const FuncExt& e, int n0, int n1) { return n0 < e.f0 || (e.lo < n1 && e.hi > n0); }
 __device__ __forceinline__ int func_ext_end(const FuncExt& e) { return e.f0 > e.hi ? e.f0 : e.hi; }                    // keys from here on: unseen
 __device__ __forceinline__ int func_ext_begin(const FuncExt& e) { return e.f0 > 0 ? 0 : (e.lo < e.hi ? e.lo : 0x7fffffff); }   // keys below: unseen
@@ -1784,7 +1790,10 @@ __global__ void __launch_bounds__(512) hstu_fwd_pair_kernel(AttnArgs a) {
 #ifndef HSTU_Q2_VBUF
 #define HSTU_Q2_VBUF 3   // O waves: V^T fragment batches (2 fragments = 4 MFMAs) likewise
 #endif
-template <int D, bool kWin, bool kPair>
+// kFunc (round 6): `func` masks of up to two bands (n_func <= 5) -- the rows' bounds live in registers of the S waves, the tile stream is
+// clipped to what the block's functions reach, a half skips the tiles in the gap between its prefix and its bands, and the tiles
+// below every row's prefix take the mask-free path
+template <int D, bool kWin, bool kPair, bool kFunc = false>
 __global__ void __launch_bounds__(512) hstu_fwd_q2_kernel(AttnArgs a) {
   static_assert(D == 256, "rows of 32 chunks");
   constexpr int CPR = D / 8, RPI = 64 / CPR, ROWB = D, TENS = kBN * ROWB, NINS = kBN / RPI;
@@ -1817,12 +1826,13 @@ __global__ void __launch_bounds__(512) hstu_fwd_q2_kernel(AttnArgs a) {
   // ---- one row block of the stream, seen from this wave's 64-row half
   // t_lo .. t_hi: the tiles that reach the half's rows; S waves: tiles below tf need no mask (a prefix of the stream under every
   // mask rule), tile t_dead has this wave's 32 keys past every row's reach (its P is zero, the O waves read the whole tile)
-  struct Blk { int m0, hrow0, n_beg, T, t_lo, t_hi, tf, t_dead; };
+  struct Blk { int m0, hrow0, n_beg, T, t_lo, t_hi, tf, t_dead, g_lo, g_hi; };   // g_lo .. g_hi (kFunc): tiles in the half's gap
   auto setup = [&](int rank) -> Blk {
     Blk k;
     k.m0 = row_block_of_rank(rank, nblk, a, b) * kBM;
     k.hrow0 = k.m0 + 64 * half;
-    const bool half_live = k.hrow0 < Lq;
+    bool half_live = k.hrow0 < Lq;
+    k.g_lo = k.g_hi = 0;
     const int last_row = dq + (k.m0 + kBM - 1 < Lq - 1 ? k.m0 + kBM - 1 : Lq - 1);
     int n_end = s.L;
     if (a.causal) {
@@ -1838,7 +1848,29 @@ __global__ void __launch_bounds__(512) hstu_fwd_q2_kernel(AttnArgs a) {
       if (s.has_ctx && dq + k.hrow0 < s.c && s.hlen > h_end) h_end = s.hlen;
     }
     if (kWin) h_end = band_key_end(a, h_last, h_end);
-    const int h_beg = kWin ? band_key_begin(a, dq + k.hrow0, kBN) : 0;     // (a multiple of the tile, >= n_beg)
+    int h_beg = kWin ? band_key_begin(a, dq + k.hrow0, kBN) : 0;     // (a multiple of the tile, >= n_beg)
+    FuncExt hx{0x7fffffff, 0, 0x7fffffff, 0};
+    if constexpr (kFunc) {
+      if (a.wskip) {     // extents of the half's 64 rows and of the block's 128: one row per lane, no barrier
+        auto ext64 = [&](int row0) {
+          const int r = row0 + lane;
+          return func_ext_wave64(func_ext_row(a, h, (int64_t)s.start + r, r < Lq, (s.has_ctx && dq + r < s.c) ? s.hlen : 0));
+        };
+        hx = ext64(k.hrow0);
+        const FuncExt bx = func_ext_merge(hx, ext64(k.m0 + 64 * (1 - half)));
+        const int be = func_ext_end(bx), bb = func_ext_begin(bx), he = func_ext_end(hx), hb = func_ext_begin(hx);
+        if (be < n_end) n_end = be;
+        if (he < h_end) h_end = he;
+        if (bb > k.n_beg) k.n_beg = bb >= n_end ? n_end : (bb / kBN) * kBN;
+        if (hb >= h_end) half_live = false;
+        else if (hb > h_beg) h_beg = (hb / kBN) * kBN;
+        if (h_beg < k.n_beg) h_beg = k.n_beg;
+        if (half_live && hx.lo < hx.hi && hx.lo > hx.f0) {     // the tiles wholly between the prefix and the bands' hull
+          const int g0 = hx.f0 > k.n_beg ? (hx.f0 - k.n_beg + kBN - 1) / kBN : 0, g1 = hx.lo > k.n_beg ? (hx.lo - k.n_beg) / kBN : 0;
+          if (g0 < g1) { k.g_lo = g0; k.g_hi = g1; }
+        }
+      }
+    }
     k.T = n_end > k.n_beg ? (n_end - k.n_beg + kBN - 1) / kBN : 0;
     k.t_lo = (h_beg - k.n_beg) / kBN;
     k.t_hi = h_end > k.n_beg ? (h_end - k.n_beg + kBN - 1) / kBN : 0;
@@ -1851,6 +1883,11 @@ __global__ void __launch_bounds__(512) hstu_fwd_q2_kernel(AttnArgs a) {
     if (a.causal && s.has_tgt && s.hlen - 1 < lim) lim = s.hlen - 1;
     const int num = lim - 31 - 32 * sub - k.n_beg;
     k.tf = (fc && num >= 0) ? num / kBN + 1 : 0;
+    if constexpr (kFunc) {     // ... and below every row's prefix
+      const int num2 = hx.f0min - 32 - 32 * sub - k.n_beg;
+      const int tf2 = (a.wskip && half_live && num2 >= 0) ? num2 / kBN + 1 : 0;
+      if (tf2 < k.tf) k.tf = tf2;
+    }
     k.t_dead = (sub == 1 && k.t_hi > k.t_lo && k.n_beg + kBN * (k.t_hi - 1) + 32 >= h_end) ? k.t_hi - 1 : -1;
     return k;
   };
@@ -1878,10 +1915,25 @@ __global__ void __launch_bounds__(512) hstu_fwd_q2_kernel(AttnArgs a) {
     // =========================== S waves: item `it` -> P ring slot it & 1 ===========================
     bf16x8_t qf[2][D / 16];
     RowMask rm[2];
+    int f_pre[2], f_lo[2][2], f_len[2][2];     // kFunc: the row sees key j iff j < f_pre or (unsigned)(j - f_lo[b]) < f_len[b]
     auto load_q = [&](const Blk& k) {
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
         const int qloc = k.hrow0 + 32 * qt + l31;
+        if constexpr (kFunc) {
+          const int32_t* ft = a.func + (int64_t)h * a.func_h + s.start + (qloc < Lq ? qloc : 0);
+          const int free_below = (s.has_ctx && dq + qloc < s.c) ? s.hlen : 0;
+          const int f0 = qloc < Lq ? ft[0] : 0;
+          f_pre[qt] = f0 > free_below ? f0 : free_below;
+#pragma unroll
+          for (int bnd = 0; bnd < 2; ++bnd) {
+            int lo = 0, up = 0;
+            if (qloc < Lq && 2 * bnd + 2 < a.n_func) { lo = ft[(int64_t)(2 * bnd + 1) * a.func_p]; up = ft[(int64_t)(2 * bnd + 2) * a.func_p]; }
+            lo = lo > 0 ? lo : 0;
+            f_lo[qt][bnd] = lo;
+            f_len[qt][bnd] = up > lo ? up - lo : 0;
+          }
+        }
         const uint16_t* qp = a.q + (int64_t)(s.start + (qloc < Lq ? qloc : 0)) * a.q_row + (int64_t)h * a.q_head + 8 * hi;
 #pragma unroll
         for (int sl = 0; sl < D / 16; ++sl) {
@@ -1909,6 +1961,7 @@ __global__ void __launch_bounds__(512) hstu_fwd_q2_kernel(AttnArgs a) {
       TICK(t1);
       TACC(1, t0, t1);
       if (t_in < k.t_lo || t_in >= k.t_hi) return;
+      if constexpr (kFunc) { if (t_in >= k.g_lo && t_in < k.g_hi) return; }
       u32x4_t* pdst = Pring + ((((it & 1) * 2 + half) * 2) * 4 + 2 * sub) * 64 + lane;   // q tile qt: + 256 qt, second key slice: + 64
       if (t_in == k.t_dead) {
         const u32x4_t z = {0u, 0u, 0u, 0u};
@@ -1986,10 +2039,14 @@ __global__ void __launch_bounds__(512) hstu_fwd_q2_kernel(AttnArgs a) {
 #endif
           if (kMode != 0) {
             const int th = rm[qt].jmax - k0 - 4 * hi;     // kMode 1: element rr is visible iff (rr & 3) + 8 (rr >> 2) <= th
+            const int kb = k0 + 4 * hi;                   // kMode 3: the general rule and the row's functions
+            const int fa = kFunc ? f_pre[qt] - kb : 0, fb0 = kFunc ? kb - f_lo[qt][0] : 0, fb1 = kFunc ? kb - f_lo[qt][1] : 0;
 #pragma unroll
             for (int i = 0; i < NE; ++i) {
               const int rr = r0 + i, off = (rr & 3) + 8 * (rr >> 2);
-              const bool ok = kMode == 1 ? off <= th : key_ok(k0 + off + 4 * hi, rm[qt]);
+              bool ok = kMode == 1 ? off <= th : key_ok(k0 + off + 4 * hi, rm[qt]);
+              if constexpr (kFunc && kMode == 3)
+                ok = ok & ((off < fa) | ((unsigned)(off + fb0) < (unsigned)f_len[qt][0]) | ((unsigned)(off + fb1) < (unsigned)f_len[qt][1]));
               y[i] = ok ? y[i] : 0.f;
             }
           }
@@ -2011,9 +2068,14 @@ __global__ void __launch_bounds__(512) hstu_fwd_q2_kernel(AttnArgs a) {
         t_prev = t7;
 #endif
       };
-      if (t_in < k.tf) tile(std::integral_constant<int, 0>{});
-      else if (m12 == 1) tile(std::integral_constant<int, 1>{});
-      else tile(std::integral_constant<int, 2>{});
+      if constexpr (kFunc) {
+        if (t_in < k.tf) tile(std::integral_constant<int, 0>{});
+        else tile(std::integral_constant<int, 3>{});
+      } else {
+        if (t_in < k.tf) tile(std::integral_constant<int, 0>{});
+        else if (m12 == 1) tile(std::integral_constant<int, 1>{});
+        else tile(std::integral_constant<int, 2>{});
+      }
     };
     // Two loops over ONE stream of iterations (as hstu_fwd_pair_kernel): block B's queries are loaded at the switch
     load_q(B0);
@@ -2126,7 +2188,7 @@ __global__ void __launch_bounds__(512) hstu_fwd_q2_kernel(AttnArgs a) {
     TACC(0, t0, t1); TACC(1, t1, t2); TACC(2, t2, t3);
     const int tl = it - 1;
     {
-      if (t_in >= k.t_lo && t_in < k.t_hi) {
+      if (t_in >= k.t_lo && t_in < k.t_hi && !(kFunc && t_in >= k.g_lo && t_in < k.g_hi)) {
         const uint16_t* Vt = Vring + (tl & 1) * TENS;
         const u32x4_t* psrc = Pring + (((tl & 1) * 2 + half) * 2 * 4) * 64 + lane;
         bf16x8_t pf[2][4];
@@ -4179,7 +4241,7 @@ static int launch_fwd_pc(const AttnArgs& a, int B, int max_seqlen, hipStream_t s
   // 64 query rows per wave (two MFMAs per LDS fragment) from 1 025 rows: +4-6 % at L >= 2048, +1-4 % on jagged Zipf-to-4096 batches,
   // level at 768-1024, -2 % at C3 and -6 % at L = 256 (fewer, larger units per short column); 2 = always, 0 = never (A/B)
   const int q2 = (fwd_hook == 1 || fwd_hook == 2) ? 2 : ((fwd_hook == 3 || fwd_hook == 4) ? 0 : 1);
-  if (q2 == 2 || (q2 == 1 && max_seqlen > 1024)) {
+  if (q2 == 2 || (q2 == 1 && max_seqlen > 1024) || a.func) {
     static bool attr_q2 = false;
     if (!attr_q2) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_q2_kernel<D, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
@@ -4191,6 +4253,19 @@ static int launch_fwd_pc(const AttnArgs& a, int B, int max_seqlen, hipStream_t s
     }
     const int nblk = (max_seqlen + kBM - 1) / kBM;
     const bool win = a.wl >= 0 || a.wr >= 0;
+    if (a.func) {     // mask functions: the window-capable variants + the functions
+      static bool attr_fn = false;
+      if (!attr_fn) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_q2_kernel<D, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_fwd_q2_kernel<D, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+          return MI355_ELAUNCH;
+        attr_fn = true;
+      }
+      if (pair == 2 || (pair == 1 && dense_batch)) hipLaunchKernelGGL((hstu_fwd_q2_kernel<D, true, true, true>), dim3(a.H, B, (nblk + 1) / 2), dim3(512), smem, stream, a);
+      else hipLaunchKernelGGL((hstu_fwd_q2_kernel<D, true, false, true>), dim3(a.H, B, nblk), dim3(512), smem, stream, a);
+      MI355_LAUNCH_CHECK();
+      return MI355_OK;
+    }
     if (pair == 2 || (pair == 1 && dense_batch)) {
       dim3 grid(a.H, B, (nblk + 1) / 2);
       if (win) hipLaunchKernelGGL((hstu_fwd_q2_kernel<D, true, true>), grid, dim3(512), smem, stream, a);
@@ -4354,7 +4429,8 @@ int HSTU_FN(mi355_hstu_attn_fwd_kv)(const void* q, const void* k, const void* v,
   static const int use_pc = !(getenv("MI355_HSTU_FWD") && atoi(getenv("MI355_HSTU_FWD")) == 5);   // round 4: two waves per SIMD, S waves + O waves (hook 5: the one-kind kernel)
   const int64_t fwd_tokens = tl_fwd_tokens;
   tl_fwd_tokens = 0;
-  if (use_pc && head_dim == 256 && !a.kv_cache && !a.rab && !a.func)
+  // (`func` masks of up to two bands ride the 64-rows-per-wave forward at every length; longer function lists keep the one-kind kernel)
+  if (use_pc && head_dim == 256 && !a.kv_cache && !a.rab && (!a.func || a.n_func <= 5))
     return launch_fwd_pc<256>(a, (int)batch, (int)max_seqlen_q, stream, !cu_seqlens_k && fwd_tokens == batch * max_seqlen_q);
   switch (head_dim) {
     case 32: return launch_fwd<32>(a, (int)batch, (int)max_seqlen_q, stream);

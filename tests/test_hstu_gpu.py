@@ -520,6 +520,57 @@ def test_mask_functions_inside_the_kernels_match_their_dense_bias_statement_bit_
             assert torch.equal(a_, b_), f"window ({wl}, {wr}): the in-kernel mask functions differ from the dense bias"
 
 
+@pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", ["prefix_gap_band", "causal_like", "bands_only", "three_bounds", "one_bound", "blind_rows", "dense_pairs"])
+def test_mask_functions_on_the_two_wave_kind_forward_match_the_dense_bias_statement(shape, tdt):
+    """round 6: at head dim 256 functions of up to two bands ride the 64-rows-per-wave forward (hstu_fwd_q2_kernel<.., kFunc>): tile
+    stream clipped to the block's extents, a half skipping the gap between its prefix and its bands, mask-free tiles below every
+    row's prefix.  Against the dense 0 / -1e9 bias statement of the same mask through the one-kind kernel, bit for bit
+    (forward and the three gradients), over sequences of several row blocks with ragged ends."""
+    from hstu.hstu_attn_interface import HstuAttnFuncFunc, HstuAttnRabFunc, func_mask_bias
+
+    rng = np.random.default_rng(len(shape))
+    lengths = np.array([1024, 1024, 1024]) if shape == "dense_pairs" else np.array([1500, 0, 700, 1, 130, 257])
+    H, d = 2, 256
+    off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    T, B, N = int(off[-1]), lengths.size, int(lengths.max())
+    mk = lambda lo, hi, *sh: torch.from_numpy(rng.uniform(lo, hi, sh).astype(np.float32)).to(DEV).to(tdt)
+    q, k, v, dout = mk(-1, 1, T, H, d), mk(-1, 1, T, H, d), mk(-1, 1, T, H, d), mk(0, 1, T, H, d)
+    pos = np.concatenate([np.arange(n) for n in lengths]).astype(np.int64)
+    nb = {"three_bounds": 3, "one_bound": 1}.get(shape, 5)
+    f = np.zeros((H, nb, T), np.int64)
+    r = lambda lo, hi: rng.integers(lo, hi, size=(H, T))
+    if shape == "prefix_gap_band":            # a short prefix, two bands far to the right: whole tiles between them see nothing
+        f[:, 0] = r(0, 100); f[:, 1] = r(900, 1000); f[:, 2] = f[:, 1] + r(0, 200); f[:, 3] = r(1250, 1300); f[:, 4] = f[:, 3] + r(0, 150)
+    elif shape in ("causal_like", "dense_pairs"):   # j <= i and a band inside it, a second one to the right of the diagonal
+        f[:, 0] = pos + 1; f[:, 1] = np.maximum(pos - 300, 0); f[:, 2] = np.maximum(pos - 200, 0); f[:, 3] = pos + 100; f[:, 4] = pos + 140
+    elif shape == "bands_only":               # no prefix: a sliding window and a sink, as bands
+        f[:, 1] = 0; f[:, 2] = r(0, 20); f[:, 3] = np.maximum(pos - r(100, 200), 0); f[:, 4] = pos + r(0, 3)
+    elif shape == "three_bounds":
+        f[:, 0] = r(0, 300); f[:, 1] = r(400, 600); f[:, 2] = f[:, 1] + r(0, 500)
+    elif shape == "one_bound":
+        f[:, 0] = np.where(r(0, 4) == 0, 0, pos + 1 - r(0, 2))
+    elif shape == "blind_rows":               # half of the 64-row groups see nothing at all, the others a band
+        blind = ((pos // 64) % 2 == 0)[None, :]
+        f[:, 1] = np.where(blind, 0, r(500, 520)); f[:, 2] = np.where(blind, 0, f[:, 1] + r(1, 90)); f[:, 3] = f[:, 4] = 0
+    func = torch.from_numpy(f.astype(np.int32)).to(DEV)
+    cu = torch.from_numpy(off.astype(np.int32)).to(DEV)
+    alpha = 1.0 / d ** 0.5
+    for wl, wr in ((-1, -1), (-1, 0), (450, 60)):
+        res = []
+        for kind in ("kernel", "dense"):
+            qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
+            if kind == "kernel":
+                out = HstuAttnFuncFunc.apply(qq, kk, vv, func, cu, N, float(N), None, None, 1, wl, wr, alpha)
+            else:
+                out = HstuAttnRabFunc.apply(qq, kk, vv, func_mask_bias(func, cu, cu, N, tdt), cu, N, float(N), None, None, 1, wl, wr, alpha, False)
+            out.backward(dout)
+            res.append((out.detach(), qq.grad, kk.grad, vv.grad))
+        for name, a_, b_ in zip(("out", "dq", "dk", "dv"), *res):
+            assert torch.equal(a_, b_), f"{shape}, window ({wl}, {wr}): {name} differs from the dense bias statement"
+        assert float(res[0][0].float().abs().sum()) > 0
+
+
 def test_mask_functions_with_contextual_rows_vs_oracle():
     """`func` together with num_contexts (refused while the functions were a bias): contextual rows see the whole history whatever
     the functions say -- the reference's context test `continue`s in front of every other mask (hstu_fwd.h:519-524)"""
