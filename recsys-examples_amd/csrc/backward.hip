@@ -85,6 +85,9 @@ __device__ __forceinline__ int entry_src(const BwdArgs& a, int sv) {
 #ifndef PIPE_KIT
 #define PIPE_KIT 4      // groups per lane group the walk is compiled for; BwdArgs::kit says how many a launch uses
 #endif
+#ifndef BWD_KIT_SMALL
+#define BWD_KIT_SMALL 2  // ... and for batches of <= 720 K keys (SGD, one column group)
+#endif
 constexpr int kBwdGroupsPerLaneGroup = PIPE_KIT;  // consecutive row groups walked by one lane group (regular rows)
 
 __device__ __attribute__((aligned(16))) float g_zero_grad[1024];  // see g_zero_row in value_ops.hip
@@ -794,13 +797,13 @@ static int launch_bwd(BwdArgs a, OptArgs o, bool vec, hipStream_t stream) {
   constexpr int wave_cap = 1024;
   if (a.hot.n_tasks && a.hot.kwave > a.hot.khot) a.wave_blocks = a.hot.max_hot / 4 + 1 < wave_cap ? a.hot.max_hot / 4 + 1 : wave_cap;
   // (max_unique = the key count of the batch: C2 360 K, its 4x batch 1.44 M)
-  a.kit = (a.max_unique <= 720 * 1024 && vec && o.kind == kOptSgd && a.D_offsets == nullptr && ncol <= 1) ? 2 : kBwdGroupsPerLaneGroup;
+  a.kit = (a.max_unique <= 720 * 1024 && vec && o.kind == kOptSgd && a.D_offsets == nullptr && ncol <= 1) ? BWD_KIT_SMALL : kBwdGroupsPerLaneGroup;
   const int grid = a.hot_blocks + a.wave_blocks + grid_for(a.max_unique, 4 * nsub * nb * a.kit, 1 << 20);
 #define MI355_BWD_LAUNCH(NC, V) hipLaunchKernelGGL((bwd_kernel<WDT, GDT, NC, V, false>), dim3(grid), dim3(256), smem, stream, a, o, l)
 #define MI355_BWD_LAUNCH_SGD(NC) hipLaunchKernelGGL((bwd_kernel<WDT, GDT, NC, true, true>), dim3(grid), dim3(256), smem, stream, a, o, l)
-#define MI355_BWD_LAUNCH_SGD2() hipLaunchKernelGGL((bwd_kernel<WDT, GDT, 1, true, true, 2>), dim3(grid), dim3(256), smem, stream, a, o, l)
+#define MI355_BWD_LAUNCH_SGD2() hipLaunchKernelGGL((bwd_kernel<WDT, GDT, 1, true, true, BWD_KIT_SMALL>), dim3(grid), dim3(256), smem, stream, a, o, l)
   if (vec && o.kind == kOptSgd && a.D_offsets == nullptr) {
-    if (ncol <= 1 && a.kit == 2) MI355_BWD_LAUNCH_SGD2();
+    if (ncol <= 1 && a.kit == BWD_KIT_SMALL) MI355_BWD_LAUNCH_SGD2();
     else if (ncol <= 1) MI355_BWD_LAUNCH_SGD(1); else if (ncol <= 2) MI355_BWD_LAUNCH_SGD(2); else MI355_BWD_LAUNCH_SGD(4);
   } else if (vec) {
     if (ncol <= 1) MI355_BWD_LAUNCH(1, true); else if (ncol <= 2) MI355_BWD_LAUNCH(2, true); else MI355_BWD_LAUNCH(4, true);
