@@ -666,7 +666,9 @@ int mi355_hstu_attn_fwd_kv_func_f16(const void* q, const void* k, const void* v,
                                 const int32_t* last_page_lens, int64_t page_size, hipStream_t stream);
 /* (round 6) func_workspace (nullable): room for the tables of the tile skipping -- 72 bytes x (total_tokens / 128 + batch + 1)
  * per function set (heads, or 1 when the head stride is 0); the reference derives the valid key blocks from the func extents the
- * same way (hstu_fwd.h:80-83, 139-151, 228-291, 411-412).  NULL / too small: the key-major passes visit every query tile. */
+ * same way (hstu_fwd.h:80-83, 139-151, 228-291, 411-412).  NULL / too small: the key-major passes visit every query tile.
+ * workspace / workspace_bytes (nullable): the P / dS exchange scratch of mi355_hstu_attn_bwd (same sizing calls); used for functions
+ * of up to two bands (n_func <= 5) at head_dim 256 when func_workspace is given, otherwise the recomputing passes run. */
 int mi355_hstu_attn_bwd_func(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
                              int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t do_row_stride,
                              int64_t q_head_stride, int64_t k_head_stride, int64_t v_head_stride, int64_t do_head_stride,
@@ -674,7 +676,8 @@ int mi355_hstu_attn_bwd_func(const void* dout, const void* q, const void* k, con
                              const int32_t* num_contexts, const int32_t* num_targets, int64_t target_group_size,
                              int64_t window_left, int64_t window_right, float alpha, float scaling_seqlen, const int32_t* func,
                              int64_t func_head_stride, int64_t func_bound_stride, int64_t n_func, float func_neg,
-                             void* func_workspace, int64_t func_workspace_bytes, hipStream_t stream);
+                             void* func_workspace, int64_t func_workspace_bytes, void* workspace, int64_t workspace_bytes,
+                             hipStream_t stream);
 int mi355_hstu_attn_bwd_func_f16(const void* dout, const void* q, const void* k, const void* v, void* dq, void* dk, void* dv,
                              int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t do_row_stride,
                              int64_t q_head_stride, int64_t k_head_stride, int64_t v_head_stride, int64_t do_head_stride,
@@ -682,7 +685,8 @@ int mi355_hstu_attn_bwd_func_f16(const void* dout, const void* q, const void* k,
                              const int32_t* num_contexts, const int32_t* num_targets, int64_t target_group_size,
                              int64_t window_left, int64_t window_right, float alpha, float scaling_seqlen, const int32_t* func,
                              int64_t func_head_stride, int64_t func_bound_stride, int64_t n_func, float func_neg,
-                             void* func_workspace, int64_t func_workspace_bytes, hipStream_t stream);
+                             void* func_workspace, int64_t func_workspace_bytes, void* workspace, int64_t workspace_bytes,
+                             hipStream_t stream);
 
 /* append_kvcache (torch.ops.paged_kvcache_ops.append_kvcache, examples/commons/ops/cuda_ops/csrc/
  * paged_kvcache_ops_kernel.cu:106-140, call site paged_hstu_infer_layer.py:350-364): new-history token i (i < *nnz_dev,

@@ -2633,6 +2633,20 @@ __device__ __forceinline__ KvSpan kv_span(const AttnArgs& a, const SeqInfo& s, i
   return v;
 }
 __device__ __forceinline__ bool kv_visited(const KvSpan& v, int step) { return (step < v.c_end || step >= v.jump) && step < v.lim; }
+// `func` masks: the span narrowed to the query rows [vis.x, vis.y) that reach the key block at all (hstu_func_kvis_kernel's table).
+// ONE statement of the rule for the pass that writes the exchanged sub-tiles and the passes that read them.
+__device__ __forceinline__ KvSpan kv_span_clip(KvSpan v, int2 vis, int bq) {
+  const int first = vis.x < vis.y ? (vis.x / bq) * bq : 0x7fffff00;
+  if (first > v.jump) v.jump = first;
+  if (vis.y < v.lim) v.lim = vis.y;
+  if (v.c_end > v.lim) v.c_end = v.lim;
+  return v;
+}
+__device__ __forceinline__ int2 func_kvis_of(const BwdAttnArgs& g, int start, int b, int h, int n0) {
+  const int64_t kidx = func_kvis_index(start, b, n0);
+  if (g.f.func && g.func_kvis && kidx < g.func_kvis_h) return g.func_kvis[(int64_t)(g.f.func_h ? h : 0) * g.func_kvis_h + kidx];
+  return make_int2(0, 0x7fffffff);
+}
 
 // pass A: one workgroup = 128 keys (32 per wave) of one (sequence, head); loops over query tiles of BQ rows.
 // MODE 0: dV and dK together (d <= 64).  Larger d: the two output accumulators plus the S / dP accumulators and the
@@ -3553,7 +3567,7 @@ __device__ __forceinline__ void store_acc_rows(const f32x16_t (&acc)[D / 32], ui
 
 // dV from the stored P, 256 keys per workgroup.  The query steps are the union of what the dK pass ran for the block's two
 // 128-key halves (its blocks are kBM keys); a wave consults the span of ITS half to tell which sub-tiles exist.
-template <int D, int NW>
+template <int D, int NW, bool kFunc = false>
 __device__ __forceinline__ void hstu_bwd_v_p8_body(const BwdAttnArgs& g, unsigned bz, unsigned nz) {
   constexpr int kBM8 = 32 * NW;   // keys per workgroup
   static_assert(D == 256, "DMA rows of 32 chunks");
@@ -3583,7 +3597,8 @@ __device__ __forceinline__ void hstu_bwd_v_p8_body(const BwdAttnArgs& g, unsigne
   for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
-  const KvSpan sp0 = kv_span(a, s, n0, g.bq_kv);
+  KvSpan sp0 = kv_span(a, s, n0, g.bq_kv);
+  if constexpr (kFunc) { static_assert(NW == 4, "one key block of the dK pass per workgroup"); sp0 = kv_span_clip(sp0, func_kvis_of(g, s.start, b, h, n0), g.bq_kv); }
   const KvSpan sp1 = (NW == 8 && n0 + kBM < s.L) ? kv_span(a, s, n0 + kBM, g.bq_kv) : sp0;
   const KvSpan mine = wv < 4 ? sp0 : sp1;
   const int jump = sp0.jump < sp1.jump ? sp0.jump : sp1.jump, c_end = sp0.c_end > sp1.c_end ? sp0.c_end : sp1.c_end;
@@ -3643,7 +3658,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_v_p8_kernel
   hstu_bwd_v_p8_body<D, NW>(g, blockIdx.z, gridDim.z);
 }
 
-template <int D, int NW>
+template <int D, int NW, bool kFunc = false>
 __device__ __forceinline__ void hstu_bwd_q_ds8_body(const BwdAttnArgs& g, unsigned bz, unsigned nz) {
   constexpr int kBM8 = 32 * NW;   // query rows per workgroup
   static_assert(D == 256, "DMA rows of 32 chunks");
@@ -3677,8 +3692,32 @@ __device__ __forceinline__ void hstu_bwd_q_ds8_body(const BwdAttnArgs& g, unsign
   if (a.causal) { w_end = w_last + 1; if (s.has_ctx && qrow0 < s.c && s.hlen > w_end) w_end = s.hlen; }
   n_end = band_key_end(a, last_row, n_end);
   w_end = band_key_end(a, w_last, w_end);
-  const int n_beg = band_key_begin(a, m0, BK), w_beg = band_key_begin(a, qrow0, BK);
+  int n_beg = band_key_begin(a, m0, BK), w_beg = band_key_begin(a, qrow0, BK);
   const int it_kv = (qrow0 / g.bq_kv) * g.bq_kv;   // query tile of the dK pass that holds this wave's rows
+  // kFunc: lane l holds the table entry of key block l (the query rows that reach it: which sub-tiles the dK pass wrote); the key
+  // loop is clipped to what the block's / the wave's row groups reach (their extents: hstu_func_kvis_kernel's second table)
+  int2 vis_all = make_int2(0, 0x7fffffff);
+  if constexpr (kFunc) {
+    if (kBM * lane < s.L) vis_all = func_kvis_of(g, s.start, b, h, kBM * lane);
+    if (g.func_gext && a.wskip) {
+      FuncExt bx{0, 0x7fffffff, 0, 0x7fffffff}, wx = bx;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const int row = m0 + 32 * w;
+        const int64_t gi = func_gext_index(s.start, b, row);
+        FuncExt e{0x7fffffff, 0, 0x7fffffff, 0};     // (no entry: everything reachable)
+        if (row >= s.L) e = FuncExt{0, 0x7fffffff, 0, 0x7fffffff};
+        else if (gi < 4 * g.func_kvis_h) { const int4 t = g.func_gext[(int64_t)(a.func_h ? h : 0) * 4 * g.func_kvis_h + gi]; e = FuncExt{t.y, t.z, t.w, t.x}; }
+        bx = func_ext_merge(bx, e);
+        if (w == wv) wx = e;
+      }
+      const int be = func_ext_end(bx), bb = func_ext_begin(bx), we = func_ext_end(wx), wb = func_ext_begin(wx);
+      if (be < n_end) n_end = be;
+      if (we < w_end) w_end = we;
+      if (bb > n_beg) n_beg = bb >= n_end ? n_end : (bb / BK) * BK;
+      if (wb > w_beg) w_beg = wb >= 0x7fffff00 ? 0x7fffff00 : (wb / BK) * BK;
+    }
+  }
   f32x16_t acc[D / 32];
 #pragma unroll
   for (int dt = 0; dt < D / 32; ++dt)
@@ -3695,7 +3734,15 @@ __device__ __forceinline__ void hstu_bwd_q_ds8_body(const BwdAttnArgs& g, unsign
   u32x4_t ds0[NT], ds1[NT];
   auto tile_written = [&](int n0) -> bool {
     if (n0 >= s.L) return false;
-    return kv_visited(kv_span(a, s, (n0 / kBM) * kBM, g.bq_kv), it_kv);
+    KvSpan sp = kv_span(a, s, (n0 / kBM) * kBM, g.bq_kv);
+    if constexpr (kFunc) {
+      const int kb = __builtin_amdgcn_readfirstlane(n0 / kBM);
+      int2 vis;
+      if (kb < 64) { vis.x = __builtin_amdgcn_readlane(vis_all.x, kb); vis.y = __builtin_amdgcn_readlane(vis_all.y, kb); }
+      else vis = func_kvis_of(g, s.start, b, h, kb * kBM);
+      sp = kv_span_clip(sp, vis, g.bq_kv);
+    }
+    return kv_visited(sp, it_kv);
   };
   auto fetch_ds = [&](int n) {
 #pragma unroll
@@ -3759,11 +3806,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_q_ds8_kerne
 // Round 6: the two one-GEMM passes in ONE launch -- they are independent (dV reads P, dQ reads dS, both written by the dK pass) and
 // at C3's 512 rows each is a single generation of blocks whose launch ramp and tail the other can fill: the first half of the
 // block ranks takes the dV role, the second the dQ role (LDS = the larger of the two: 80 KB, two workgroups per CU as before).
-template <int D, int NW>
+template <int D, int NW, bool kFunc = false>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_vq8_kernel(BwdAttnArgs g) {
   const unsigned nz = gridDim.z >> 1;
-  if (blockIdx.z < nz) hstu_bwd_v_p8_body<D, NW>(g, blockIdx.z, nz);
-  else hstu_bwd_q_ds8_body<D, NW>(g, blockIdx.z - nz, nz);
+  if (blockIdx.z < nz) hstu_bwd_v_p8_body<D, NW, kFunc>(g, blockIdx.z, nz);
+  else hstu_bwd_q_ds8_body<D, NW, kFunc>(g, blockIdx.z - nz, nz);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -3791,7 +3838,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) hstu_bwd_vq8_kernel(
 // 641-644 against 644-646 TFLOP/s, profiles/r04_hstu_bwd_split_ab.txt): the stamps put the S waves' GEMM phase at 1 690 clocks
 // either way -- it is not the fragment reads that pace those 32 MFMAs.
 // ---------------------------------------------------------------------------------------------------
-template <int D>
+// kFunc (round 6): `func` masks of up to two bands (n_func <= 5) on the exchange backward.  The K waves stage, one step ahead and
+// next to the step's images, the bounds of its 32 query rows and the extents of that row group ([2][6][32] ints of LDS); an S wave
+// whose 32 keys lie below every row's prefix takes the plain paths, otherwise the general rule and the rows' functions per element.
+// The steps follow kv_span_clip -- the one-GEMM passes replay the same span and find exactly the sub-tiles written here.
+template <int D, bool kFunc = false>
 __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
   static_assert(D == 256, "DMA rows of 32 chunks");
   const AttnArgs& a = g.f;
@@ -3801,6 +3852,7 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
   uint16_t* const dOr = smem + 2 * IMG;              // [2][32][256] dO rows, K-style swizzle
   uint16_t* const Qt = smem + 4 * IMG;               // [2][32][256] Q rows, V-style swizzle (read transposed)
   uint16_t* const Hs = smem + 6 * IMG;               // [2][4 pairs][2 slices][64 lanes] x 16 B: dS hand-off
+  int* const Fs = reinterpret_cast<int*>(smem + 6 * IMG + 2 * 4 * 2 * 64 * 8);   // kFunc: [2][6][32] row bounds (5) + group extents
 
   const BlockSeq bs = seq_head_of_block(a);
   const int b = bs.b, h = bs.h;
@@ -3828,7 +3880,8 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
   const uint16_t* dobase = g.dout + (int64_t)s.start * g.do_row + (int64_t)h * g.do_head;
   const float neg_alpha_log2e = -a.alpha * 1.4426950408889634f;
   const float c_p = a.alpha * a.inv_scale, c_ds = a.alpha * a.inv_scale;
-  const KvSpan span = kv_span(a, s, n0, BQ);
+  KvSpan span = kv_span(a, s, n0, BQ);
+  if constexpr (kFunc) span = kv_span_clip(span, func_kvis_of(g, s.start, b, h, n0), BQ);
   const int jump = span.jump, c_end = span.c_end, i_lim = span.lim;
   auto advance = [&](int i) { i += BQ; return (i >= c_end && i < jump) ? jump : i; };
   const int first = c_end > 0 ? 0 : jump;
@@ -3932,9 +3985,20 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
         constexpr int kMask = decltype(modec)::value;
         constexpr bool kTail = decltype(tailc)::value;
         uint32_t pk[8], sk[8];
+        int fb[5][4];      // kMask 5: bounds of the four rows 8 (r >> 2) + 4 hi + 0 .. 3, reloaded per group of four registers
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           float p2[2], s2[2];
+          if constexpr (kMask == 5) {
+            if ((r & 3) == 0) {
+              const int* fs = Fs + PAR * 192 + 4 * hi + 8 * (r >> 2);
+#pragma unroll
+              for (int pb = 0; pb < 5; ++pb) {
+                const int4 t4 = *reinterpret_cast<const int4*>(fs + 32 * pb);
+                fb[pb][0] = t4.x; fb[pb][1] = t4.y; fb[pb][2] = t4.z; fb[pb][3] = t4.w;
+              }
+            }
+          }
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const int rr = r + u;
@@ -3945,6 +4009,13 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
             else if constexpr (kMask == 3) ok = (qi < ctx_end ? key_hist : ((kj <= qi) & key_in)) & (key_hist | (qi < key_iend));
             else if constexpr (kMask == 4)
               ok = key_in & ((s.wl < 0) | (kj >= qi - s.wl)) & (a.causal ? (kj <= qi) : ((s.wr < 0) | (kj <= qi + s.wr)));
+            else if constexpr (kMask == 5) {     // every rule at once, and the row's functions
+              const bool c1 = a.causal ? (kj <= qi) : ((s.wr < 0) | (kj <= qi + s.wr));
+              const bool c2 = (s.wl < 0) | (kj >= qi - s.wl);
+              ok = key_in & (qi < ctx_end ? key_hist : (c1 & c2)) & (key_hist | (qi < key_iend));
+              const int e = rr & 3;
+              ok = ok & ((kj < fb[0][e]) | ((fb[1][e] <= kj) & (kj < fb[2][e])) | ((fb[3][e] <= kj) & (kj < fb[4][e])));
+            }
             if constexpr (kTail) ok = ok & (qi < s.L);
             const float acc = acc_s[rr];
             const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc * neg_alpha_log2e));
@@ -3964,7 +4035,10 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
         }   // (dS goes to the exchange buffer from the K wave, which has it in registers one step later: two stores fewer here)
       };
       auto ew = [&](auto modec) { if (tail) elementwise(modec, std::true_type{}); else elementwise(modec, std::false_type{}); };
-      if (!plain) {
+      bool func_test = false;
+      if constexpr (kFunc) func_test = !(key0 + 32 <= Fs[PAR * 192 + 160]);    // (the group's smallest prefix: below it every row sees every key)
+      if (func_test) ew(std::integral_constant<int, 5>{});
+      else if (!plain) {
         if (s.wl >= 0 || s.wr >= 0) ew(std::integral_constant<int, 4>{}); else ew(std::integral_constant<int, 3>{});
       } else if (a.causal) {
         if (key0 + 31 <= i0) ew(std::integral_constant<int, 0>{}); else ew(std::integral_constant<int, 1>{});
@@ -3994,9 +4068,32 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
   for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_dk[dt][r] = 0.f;
+  // kFunc: thread (pw, lane) of the K waves fetches ONE word of a step's bounds: p = (64 pw + lane) / 32 (0 .. 4: the row's bounds,
+  // 5: the extents of the row group, lanes 0 .. 3), r = lane & 31 -- written to LDS behind the next step's vmcnt wait
+  int fword = 0;
+  auto fetch_func = [&](int i) {
+    if constexpr (kFunc) {
+      const int pb = 2 * pw + (lane >> 5), r = lane & 31, qi = i + r;
+      int v = 0;
+      if (pb < 5) {
+        if (qi < s.L && pb < a.n_func) v = a.func[(int64_t)h * a.func_h + (int64_t)pb * a.func_p + s.start + qi];
+        if (pb == 0 && s.has_ctx && qi < s.c && s.hlen > v) v = s.hlen;      // a contextual row sees the whole history
+      } else if (pb == 5) {
+        v = r == 0 ? 0 : (r == 1 ? 0x7fffffff : (r == 2 ? 0 : 0x7fffffff));   // (no table: never "all visible")
+        const int64_t gi = func_gext_index(s.start, b, i);
+        if (g.func_gext && gi < 4 * g.func_kvis_h && r < 4)
+          v = reinterpret_cast<const int*>(g.func_gext + (int64_t)(a.func_h ? h : 0) * 4 * g.func_kvis_h + gi)[r];
+      }
+      fword = v;
+    }
+  };
+  auto commit_func = [&](int par) {
+    if constexpr (kFunc) { const int pb = 2 * pw + (lane >> 5); if (pb < 6) Fs[par * 192 + 32 * pb + (lane & 31)] = fword; }
+  };
   if (first < i_lim) {
     issue_img(qbase, a.q_row, vq_k, first, Qr);
     issue_img(dobase, g.do_row, vdo_k, first, dOr);
+    fetch_func(first);
   }
   int cur = first, prev_valid = 0, prev_i = 0;
   auto step = [&](auto parc) {
@@ -4004,6 +4101,7 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
     pin_agpr_2w(acc_dk);
     TICK(t0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    commit_func(PAR);                // (the bounds of THIS step's rows, fetched one step ago)
     TICK(t1);
     __syncthreads();
     TICK(t2);
@@ -4017,6 +4115,7 @@ __global__ void __launch_bounds__(512) hstu_bwd_kv_pc_kernel(BwdAttnArgs g) {
       if (nxt < i_lim) {
         issue_img(qbase, a.q_row, vq_k, nxt, Qr + (PAR ^ 1) * IMG);
         issue_img(dobase, g.do_row, vdo_k, nxt, dOr + (PAR ^ 1) * IMG);
+        fetch_func(nxt);
       }
       issue_img(qbase, a.q_row, vq_v, i0, Qt + PAR * IMG);      // read by the K waves in the NEXT step
     }
@@ -4114,7 +4213,7 @@ static void launch_bwd_q_ds(const BwdAttnArgs& g, dim3 grid, hipStream_t stream)
 // the DMA-staged one-GEMM passes (head dim 256): MI355_HSTU_X8 = 8: one 8-wave workgroup of 256 rows per CU; 4 (default):
 // 4-wave workgroups of 128 rows, TWO per CU -- the same two waves per SIMD, twice the blocks (causal work balances over the
 // CUs: a chunk of the capped exchange may hold only one 256-row block per CU); 0: the register-staged 4-wave kernels
-template <int NW>
+template <int NW, bool kFunc = false>
 static void launch_bwd_x8(const BwdAttnArgs& g, int B, int max_seqlen, hipStream_t stream) {
   const size_t smem_v = (size_t)2 * 64 * 256 * sizeof(uint16_t), smem_q = smem_v + (size_t)NW * 2 * 1024 * sizeof(uint16_t);
   static bool attr_set = false;
@@ -4127,13 +4226,13 @@ static void launch_bwd_x8(const BwdAttnArgs& g, int B, int max_seqlen, hipStream
 #ifndef HSTU_VQ_MERGED
 #define HSTU_VQ_MERGED 1
 #endif
-  if (HSTU_VQ_MERGED && NW == 4) {
+  if ((HSTU_VQ_MERGED || kFunc) && NW == 4) {
     static bool attr_m = false;
     if (!attr_m) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_vq8_kernel<256, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_q);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_vq8_kernel<256, NW, kFunc>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_q);
       attr_m = true;
     }
-    hipLaunchKernelGGL((hstu_bwd_vq8_kernel<256, NW>), dim3(grid.x, grid.y, 2 * grid.z), dim3(64 * NW), smem_q, stream, g);
+    hipLaunchKernelGGL((hstu_bwd_vq8_kernel<256, NW, kFunc>), dim3(grid.x, grid.y, 2 * grid.z), dim3(64 * NW), smem_q, stream, g);
     return;
   }
   hipLaunchKernelGGL((hstu_bwd_v_p8_kernel<256, NW>), grid, dim3(64 * NW), smem_v, stream, g);
@@ -4143,6 +4242,23 @@ static void launch_bwd_x8(const BwdAttnArgs& g, int B, int max_seqlen, hipStream
 template <int D>
 static int launch_bwd(BwdAttnArgs g, int B, int max_seqlen, hipStream_t stream) {
   dim3 grid(g.f.H, B, (max_seqlen + kBM - 1) / kBM);   // block rank slowest: see launch_fwd
+  // (round 6) mask functions of up to two bands take the exchange backward at head dim 256 when the caller brought the scratch
+  const bool func_x = D == 256 && g.f.func && !g.f.rab && g.f.n_func <= 5 && g.p_ws && g.ds_ws;
+  if constexpr (D == 256) {
+    if (func_x) {
+      g.bq_kv = 32;
+      const size_t smem_pc = (size_t)(6 * 32 * 256 + 2 * 4 * 2 * 64 * 8) * sizeof(uint16_t) + 2 * 192 * sizeof(int);
+      static bool attr_pcf = false;
+      if (!attr_pcf) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hstu_bwd_kv_pc_kernel<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_pc);
+        attr_pcf = true;
+      }
+      hipLaunchKernelGGL((hstu_bwd_kv_pc_kernel<256, true>), grid, dim3(512), smem_pc, stream, g);
+      launch_bwd_x8<4, true>(g, B, max_seqlen, stream);
+      MI355_LAUNCH_CHECK();
+      return MI355_OK;
+    }
+  }
   if (g.f.rab || g.f.func) {   // attention bias / mask functions: the recomputing passes (S needs the bias in every pass), dS doubles as d rab
     g.ds_ws = g.p_ws = nullptr;
     g.bq_kv = 64;
@@ -4611,7 +4727,8 @@ int HSTU_FN(mi355_hstu_attn_bwd)(const void* dout, const void* q, const void* k,
       g.ds_ws = (uint16_t*)workspace;
       const int64_t one = batch * num_heads * udense * 2048;
       if (need >= 2 * one && head_dim >= 128) g.p_ws = (uint16_t*)((uint8_t*)workspace + one);
-    } else if (need > 0 && workspace && ((uintptr_t)workspace & 255) == 0 && !tl_rab.rab && !tl_rab.func && workspace_bytes > hdr &&
+    } else if (need > 0 && workspace && ((uintptr_t)workspace & 255) == 0 && !tl_rab.rab &&
+               (!tl_rab.func || (head_dim == 256 && tl_rab.nf <= 5)) && workspace_bytes > hdr &&
                (workspace_bytes - hdr) / regions / 2048 >= 2 * umax) {
       // the jagged, chunked layout: [plan_base | plan_chunk | nchunks | dS region | P region]
       const int64_t cap_tiles = (workspace_bytes - hdr) / regions / 2048;
@@ -4826,7 +4943,8 @@ int HSTU_FN(mi355_hstu_attn_bwd_func)(const void* dout, const void* q, const voi
                              const int32_t* num_contexts, const int32_t* num_targets, int64_t target_group_size,
                              int64_t window_left, int64_t window_right, float alpha, float scaling_seqlen, const int32_t* func,
                              int64_t func_head_stride, int64_t func_bound_stride, int64_t n_func, float func_neg,
-                             void* func_workspace, int64_t func_workspace_bytes, hipStream_t stream) {
+                             void* func_workspace, int64_t func_workspace_bytes, void* workspace, int64_t workspace_bytes,
+                             hipStream_t stream) {
   MI355_CHECK_ARG(func != nullptr && n_func >= 1 && (n_func & 1) == 1 && func_bound_stride > 0 && func_neg < 0.f,
                   "func must be int32 [heads or 1][n_func odd][tokens], func_neg negative");
   int causal = 0;
@@ -4834,10 +4952,13 @@ int HSTU_FN(mi355_hstu_attn_bwd_func)(const void* dout, const void* q, const voi
   tl_rab = RabCall{};
   tl_rab.func = func; tl_rab.fh = func_head_stride; tl_rab.fp = func_bound_stride; tl_rab.nf = (int)n_func; tl_rab.fneg = func_neg;
   tl_rab.kvis = func_workspace; tl_rab.kvis_bytes = func_workspace_bytes;
+  // the P / dS exchange (as mi355_hstu_attn_bwd's workspace) serves functions of up to two bands at head dim 256 when the tables
+  // above are there (the passes that read the exchange replay the table to know which sub-tiles exist); otherwise: the recomputing passes
+  const bool xch = head_dim == 256 && n_func <= 5 && func_workspace != nullptr && window_skip();
   const int rc = HSTU_FN(mi355_hstu_attn_bwd)(dout, q, k, v, dq, dk, dv, q_row_stride, k_row_stride, v_row_stride, do_row_stride,
                                      q_head_stride, k_head_stride, v_head_stride, do_head_stride, cu_seqlens, batch, num_heads,
                                      head_dim, max_seqlen, num_contexts, num_targets, target_group_size, causal, alpha,
-                                     scaling_seqlen, nullptr, 0, stream);
+                                     scaling_seqlen, xch ? workspace : nullptr, xch ? workspace_bytes : 0, stream);
   tl_rab = RabCall{};
   tl_wl = tl_wr = -1;
   return rc;

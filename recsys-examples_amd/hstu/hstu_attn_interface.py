@@ -56,7 +56,7 @@ N.register_signatures({
                                     c_f, c_p, c_p, c_p, c_p, c_i64, c_p],
     "mi355_hstu_attn_bwd_func": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p,
                                  c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_f, c_p, c_i64, c_i64, c_i64,
-                                 c_f, c_p, c_i64, c_p],
+                                 c_f, c_p, c_i64, c_p, c_i64, c_p],
     "mi355_append_kvcache": [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p,
                              c_i64, c_i64, c_p],
 }, {"mi355_hstu_attn_bwd_workspace_bytes": c_i64, "mi355_hstu_attn_bwd_ds_bytes": c_i64,
@@ -416,16 +416,16 @@ def hstu_varlen_bwd_func(dout, q, k, v, cu_seqlens, max_seqlen, scaling_seqlen, 
     # tile skipping (round 6): room for the key-block table the backward fills in front of its passes -- which query rows reach
     # every 128-key block, derived from the extents of the functions (72 bytes per key block and function set: the block's query range + the extents of its four 32-row groups; MI355_HSTU_WSKIP=0, the
     # A/B switch of every tile-range clipping, turns it off in the library)
-    fws = None
-    if True:
-        fws = torch.empty((func.shape[0] if func.shape[0] > 1 else 1) * (T // 128 + B + 1) * 18, dtype=torch.int32, device=q.device)
+    fws = torch.empty((func.shape[0] if func.shape[0] > 1 else 1) * (T // 128 + B + 1) * 18, dtype=torch.int32, device=q.device)
+    # functions of up to two bands take the P / dS exchange backward at head dim 256 (the scratch of hstu_varlen_bwd)
+    ws = _bwd_exchange_workspace(q, B, H, D, max_seqlen, False) if (D == 256 and func.shape[1] <= 5) else None
     check(_fn("mi355_hstu_attn_bwd_func", q)(ptr(dout), ptr(q), ptr(k), ptr(v), ptr(dq), ptr(dk), ptr(dv), q.stride(0), k.stride(0),
                                              v.stride(0), dout.stride(0), q.stride(1), k.stride(1), v.stride(1), dout.stride(1),
                                              ptr(cu_seqlens), B, H, D, int(max_seqlen), ptr(num_contexts), ptr(num_targets),
                                              int(target_group_size), int(wl), int(wr), c_f(alpha), c_f(float(scaling_seqlen)),
                                              ptr(func), func.stride(0) if func.shape[0] > 1 else 0, func.stride(1), func.shape[1],
                                              c_f(_func_neg_value(q.dtype)), ptr(fws), fws.numel() * 4 if fws is not None else 0,
-                                             stream()), "hstu_attn_bwd_func")
+                                             ptr(ws), ws.numel() if ws is not None else 0, stream()), "hstu_attn_bwd_func")
     return dq, dk, dv
 
 

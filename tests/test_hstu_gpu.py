@@ -571,14 +571,67 @@ def test_mask_functions_on_the_two_wave_kind_forward_match_the_dense_bias_statem
         assert float(res[0][0].float().abs().sum()) > 0
 
 
-def test_mask_functions_with_contextual_rows_vs_oracle():
+@pytest.mark.parametrize("mode", ["full", "causal_targets", "contexts", "window"])
+def test_mask_functions_on_the_exchange_backward_match_the_recomputing_passes_bit_for_bit(mode, monkeypatch):
+    """round 6: at head dim 256 functions of up to two bands take the P / dS exchange backward (hstu_bwd_kv_pc_kernel<.., kFunc> writes
+    the sub-tiles of the steps its key block's table entry names, the one-GEMM passes replay the entry).  dq, dk, dv agree bit for bit
+    with the recomputing passes (no scratch: _DS_MAX_BYTES = 0) and with the jagged, chunked layout of the exchange under a cap."""
+    import hstu.hstu_attn_interface as hi
+    from hstu.hstu_attn_interface import HstuAttnFuncFunc
+
+    rng = np.random.default_rng(len(mode) + 3)
+    lengths = np.array([700, 1, 0, 333, 129, 64, 257, 31])
+    H, d = 2, 256
+    off, q, k, v, dout, f = _func_case(rng, lengths, H, d, torch.bfloat16)
+    T, B, N = int(off[-1]), lengths.size, int(lengths.max())
+    pos = np.concatenate([np.arange(n) for n in lengths])
+    f[:, 0, :T] = np.where(rng.integers(0, 3, size=(H, T)) == 0, pos + 1, f[:, 0, :T])      # a third of the rows: a causal prefix
+    f[:, 3, :T] = rng.integers(400, 500, size=(H, T)); f[:, 4, :T] = f[:, 3, :T] + rng.integers(0, 200, size=(H, T))
+    cu = torch.from_numpy(off.astype(np.int32)).to(DEV)
+    func = torch.from_numpy(f).to(DEV)
+    ti = lambda a: torch.from_numpy(a.astype(np.int32)).to(DEV)
+    ctx = tgt = None
+    wl, wr = -1, -1
+    if mode == "causal_targets":
+        tgt = ti(np.minimum(rng.integers(0, 30, size=B), np.maximum(lengths - 1, 0))); wr = 0
+    elif mode == "contexts":
+        cx = np.minimum(rng.integers(0, 12, size=B), lengths)
+        ctx = ti(cx); tgt = ti(np.minimum(rng.integers(0, 20, size=B), lengths - cx)); wr = 0
+    elif mode == "window":
+        wl, wr = 350, 40
+    alpha = 1.0 / d ** 0.5
+
+    def grads():
+        qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
+        out = HstuAttnFuncFunc.apply(qq, kk, vv, func, cu, N, float(N), ctx, tgt, 2, wl, wr, alpha)
+        out.backward(dout)
+        return out.detach(), qq.grad, kk.grad, vv.grad
+
+    ref = None
+    ng = (N + 31) // 32
+    cap = 4096 + 2 * int(2.3 * ng * ng) * 2048
+    assert cap < hi.lib().mi355_hstu_attn_bwd_ds_bytes(B, H, d, N)
+    for label, limit in (("recompute", 0), ("dense exchange", 4 << 30), ("chunked exchange", cap)):
+        monkeypatch.setattr(hi, "_DS_MAX_BYTES", limit)
+        got = grads()
+        if ref is None:
+            ref = got
+            assert float(ref[1].float().abs().max()) > 0
+            continue
+        for name, a_, b_ in zip(("out", "dq", "dk", "dv"), got, ref):
+            assert torch.equal(a_, b_), f"{mode}, {label}: {name} differs from the recomputing passes by {(a_.float() - b_.float()).abs().max().item()}"
+
+
+@pytest.mark.parametrize("d", [64, 256])
+def test_mask_functions_with_contextual_rows_vs_oracle(d):
     """`func` together with num_contexts (refused while the functions were a bias): contextual rows see the whole history whatever
-    the functions say -- the reference's context test `continue`s in front of every other mask (hstu_fwd.h:519-524)"""
+    the functions say -- the reference's context test `continue`s in front of every other mask (hstu_fwd.h:519-524).  (d = 256: the
+    two-wave-kind forward and the exchange backward)"""
     from hstu import hstu_attn_varlen_func
 
     rng = np.random.default_rng(33)
     lengths = np.array([200, 3, 0, 129, 70])
-    off, q, k, v, dout, f = _func_case(rng, lengths, 2, 64, torch.bfloat16)
+    off, q, k, v, dout, f = _func_case(rng, lengths, 2, d, torch.bfloat16)
     B, N = lengths.size, int(lengths.max())
     f[:, 0] = rng.integers(0, 6, size=f[:, 0].shape)          # narrow first intervals: the exemption is what lets context rows see
     ctx = np.minimum(np.array([5, 2, 0, 9, 1]), lengths)
