@@ -17,7 +17,7 @@ timeout 600 python bench.py --force-sharded --no-hstu --no-cpu-baseline --no-ext
 )
 timeout 900 bash tools/pmc_hstu_traffic.sh 8 4096 gpurun_out/r06_pmc_hstu_traffic.txt > /dev/null 2>&1
 timeout 300 python tools/pipeline_step.py > $O/r06_pipeline_step.txt 2>&1
-{ python tools/bench_hstu_func.py; python tools/bench_hstu_func.py --batch 32 --seqlen 512; } 2>&1 | grep "func in" > $O/r06_hstu_func_final.txt
+{ python tools/bench_hstu_func.py; python tools/bench_hstu_func.py --batch 32 --seqlen 512; MI355_HSTU_DS_MAX_BYTES=0 MI355_HSTU_FWD=5 python tools/bench_hstu_func.py; } 2>&1 | grep "func in" > $O/r06_hstu_func_final.txt
 timeout 300 python tools/bench_model_shapes.py > $O/r06_model_shapes.txt 2>&1
 timeout 1800 python -m pytest tests -q -m gpu > $O/r06_pytest_gpu.txt 2>&1; grep "passed\|failed" $O/r06_pytest_gpu.txt
 ls -la $O/r06_* | awk '{print $5, $9}'
