@@ -726,9 +726,14 @@ def main():
     if sharded_path:
         import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if world == 1 and "MASTER_PORT" not in os.environ:    # --force-sharded on one GPU: no TCP port to collide on
+            import tempfile, uuid
+            dist.init_process_group("nccl", init_method="file://" + os.path.join(tempfile.gettempdir(), "mi355_bench_pg_" + uuid.uuid4().hex),
+                                    rank=0, world_size=1, device_id=device)
+        else:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 

@@ -57,3 +57,10 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     for kind in sorted(HSTU_TOL_USAGE):
         ratio, test = HSTU_TOL_USAGE[kind]
         terminalreporter.write_line(f"hstu_tolerance_used {kind:14s} {ratio:6.3f}   ({test})")
+
+
+def rendezvous_file():
+    """init_method of a process group WITHOUT a TCP port: a fresh file:// store.  (A port found free by bind(0) and closed again can be
+    taken by any outgoing connection before the TCPStore listens on it -- one GPU-suite run of round 6 lost 14 tests to EADDRINUSE.)"""
+    import os, tempfile, uuid
+    return "file://" + os.path.join(tempfile.gettempdir(), "mi355_pg_" + uuid.uuid4().hex)

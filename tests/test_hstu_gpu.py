@@ -403,7 +403,8 @@ def test_arbitrary_mask_golden(name):
     _assert_vs_oracle(out, (qq.grad, kk.grad, vv.grad), g("out"), g("dq"), g("dk"), g("dv"))
 
 
-@pytest.mark.parametrize("mode", ["per_head", "with_rab", "with_targets_causal", "delta_q", "raw_ops", "fp16", "fp16_with_rab"])
+@pytest.mark.parametrize("mode", ["per_head", "with_rab", "with_targets_causal", "delta_q", "delta_q_d256", "per_head_d256", "raw_ops", "fp16",
+                                  "fp16_with_rab"])
 def test_arbitrary_mask_random_jagged_vs_oracle(mode):
     """func over several tiles with ragged ends, an empty and a one-token sequence: one mask per head; together with a relative
     bias (drab flows through the sum, zero where the function masks); narrowing the causal + target mask; over delta-q keys
@@ -412,7 +413,8 @@ def test_arbitrary_mask_random_jagged_vs_oracle(mode):
 
     rng = np.random.default_rng(len(mode))
     lengths = np.array([300, 1, 0, 129, 64, 77])
-    B, H, d, N = lengths.size, 2, 64, int(lengths.max())
+    B, H, d, N = lengths.size, 2, (256 if mode.endswith("_d256") else 64), int(lengths.max())   # (d = 256: the two-wave-kind forward, the exchange backward)
+    mode = mode[:-5] if mode.endswith("_d256") else mode
     off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
     T = int(off[-1])
     tdt = torch.float16 if mode.startswith("fp16") else torch.bfloat16      # (fp16: the mask bias must stay finite, -6e4)

@@ -6,7 +6,6 @@ BatchedDynamicEmbeddingTablesV2 with the same options (the first-touch initialis
 same row), and the DynamicEmbDump / DynamicEmbLoad round trip.  Mirrors the shape of the reference's distributed tests
 (corelib/dynamicemb/test/unit_tests/test_sequence_embedding.sh / test_pooled_embedding.sh: DMP + known-answer rows)."""
 import os
-import socket
 
 import numpy as np
 import pytest
@@ -16,18 +15,12 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
 @pytest.fixture(scope="module")
 def pg():
     import torch.distributed as dist
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=DEV)
+    from conftest import rendezvous_file
+    dist.init_process_group("nccl", init_method=rendezvous_file(), rank=0, world_size=1, device_id=DEV)
     yield dist.group.WORLD
     dist.destroy_process_group()
 

@@ -6,7 +6,6 @@ element work is injected: a numpy `ops` backend built on the oracle's block_buck
 local table.  Expected results come from ONE process doing the global batch on one dict table.
 """
 import os
-import socket
 import sys
 
 import numpy as np
@@ -172,17 +171,8 @@ def grads_for(rank, shape, seed):
     return torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-def _worker(rank, W, port, F, B, pooled, dist_type, steps, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=W)
+def _worker(rank, W, store, F, B, pooled, dist_type, steps, q):
+    dist.init_process_group("gloo", init_method=store, rank=rank, world_size=W)
     try:
         from dynamicemb.sharded import RowWiseShardedLookup, RowWiseShardedPooledRows
 
@@ -307,8 +297,9 @@ def _run_and_compare(W, F, B, pooled, dist_type, out_rtol=1e-5, out_atol=1e-6):
     steps = 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, W, port, F, B, pooled, dist_type, steps, q)) for r in range(W)]
+    from conftest import rendezvous_file
+    store = rendezvous_file()
+    procs = [ctx.Process(target=_worker, args=(r, W, store, F, B, pooled, dist_type, steps, q)) for r in range(W)]
     for p in procs:
         p.start()
     got = {}
@@ -360,8 +351,8 @@ def test_fixed_capacity_overflow_is_reported():
     """one rank, capacity far below the batch: the overflow flag turns into an error at the next exchange"""
     from dynamicemb.input_dist import RwSparseFeaturesDist
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    dist.init_process_group("gloo", rank=0, world_size=1)
+    from conftest import rendezvous_file
+    dist.init_process_group("gloo", init_method=rendezvous_file(), rank=0, world_size=1)
     try:
         d = RwSparseFeaturesDist(dist.group.WORLD, 1, [200], "cpu", is_sequence=True, dist_type_per_feature=["roundrobin"],
                                  ops=NumpyOps(), capacity_factor=0.25, expected_keys=8)   # slot of 8 keys

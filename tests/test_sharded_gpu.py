@@ -2,7 +2,6 @@
 RowWiseShardedLookup with the HIP backend on a 1-rank RCCL group (the W>1 routing is covered on CPU over
 gloo in test_sharded_cpu.py; two ranks cannot share the single GPU of the test box)."""
 import os
-import socket
 
 import numpy as np
 import pytest
@@ -120,20 +119,12 @@ def test_sum_chunks_reads_the_wire_type(wire):
         assert torch.equal(out, ref.to(dtype))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
 @pytest.fixture(scope="module")
 def one_rank_group():
     import torch.distributed as dist
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from conftest import rendezvous_file
+    dist.init_process_group("nccl", init_method=rendezvous_file(), rank=0, world_size=1, device_id=torch.device("cuda", 0))
     yield
     dist.destroy_process_group()
 
@@ -479,15 +470,15 @@ def test_input_dists_in_flight_are_bounded_by_the_ticket_ring(one_rank_group):
         assert torch.equal(p.wait().values, keys)
 
 
-def _two_rank_worker(rank, world, port, pooled, fail):
+def _two_rank_worker(rank, world, store, pooled, fail):
     """one process per GPU: the in-library exchange against the c10d sequence at W = 2, forward and backward, overlapped
     schedule; any assertion ends the rank with a traceback (spawn turns it into a failure of the test)"""
     import torch.distributed as dist
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(rank)
     dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    dist.init_process_group("nccl", init_method=store, rank=rank, world_size=world, device_id=dev)
     try:
         from dynamicemb.batched_dynamicemb_tables import BatchedDynamicEmbeddingTablesV2
         from dynamicemb.dynamicemb_config import (DynamicEmbInitializerArgs, DynamicEmbInitializerMode, DynamicEmbPoolingMode,
@@ -560,4 +551,5 @@ def test_two_ranks_in_library_exchange_matches_the_c10d_sequence(pooled, fail):
         pytest.skip("needs two GPUs (one rank per device)")
     import torch.multiprocessing as mp
 
-    mp.spawn(_two_rank_worker, args=(2, _free_port(), pooled, fail), nprocs=2, join=True)
+    from conftest import rendezvous_file
+    mp.spawn(_two_rank_worker, args=(2, rendezvous_file(), pooled, fail), nprocs=2, join=True)

@@ -5,7 +5,6 @@ of the sharded pooled path (shard/embedding.py:183-275) and the checkpoint wire 
 :73-92,1262-1409) read back by an independent numpy reader."""
 import json
 import os
-import socket
 
 import numpy as np
 import pytest
@@ -143,18 +142,12 @@ def test_prefetch_pipeline_through_the_tiers_against_the_dict_twin(mode, pooling
     np.testing.assert_allclose(out.double().cpu().numpy(), twin.forward(keys, off, train=True), rtol=1e-6, atol=1e-3)
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
 @pytest.fixture(scope="module")
 def pg():
     import torch.distributed as dist
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=DEV)
+    from conftest import rendezvous_file
+    dist.init_process_group("nccl", init_method=rendezvous_file(), rank=0, world_size=1, device_id=DEV)
     yield dist.group.WORLD
     dist.destroy_process_group()
 
