@@ -797,7 +797,9 @@ static int launch_bwd(BwdArgs a, OptArgs o, bool vec, hipStream_t stream) {
   constexpr int wave_cap = 1024;
   if (a.hot.n_tasks && a.hot.kwave > a.hot.khot) a.wave_blocks = a.hot.max_hot / 4 + 1 < wave_cap ? a.hot.max_hot / 4 + 1 : wave_cap;
   // (max_unique = the key count of the batch: C2 360 K, its 4x batch 1.44 M)
-  a.kit = (a.max_unique <= 720 * 1024 && vec && o.kind == kOptSgd && a.D_offsets == nullptr && ncol <= 1) ? BWD_KIT_SMALL : kBwdGroupsPerLaneGroup;
+  // (round 6, stateful optimizers: the same rule -- C2 with Adam 0.212 -> 0.198 ms per step with the walk compiled for 2 groups, 1 the same,
+  //  3 and 4 slower, one block per CU slower; profiles/r06_bwd_variants.txt)
+  a.kit = (a.max_unique <= 720 * 1024 && vec && a.D_offsets == nullptr && ncol <= 1) ? BWD_KIT_SMALL : kBwdGroupsPerLaneGroup;
   const int grid = a.hot_blocks + a.wave_blocks + grid_for(a.max_unique, 4 * nsub * nb * a.kit, 1 << 20);
 #define MI355_BWD_LAUNCH(NC, V) hipLaunchKernelGGL((bwd_kernel<WDT, GDT, NC, V, false>), dim3(grid), dim3(256), smem, stream, a, o, l)
 #define MI355_BWD_LAUNCH_SGD(NC) hipLaunchKernelGGL((bwd_kernel<WDT, GDT, NC, true, true>), dim3(grid), dim3(256), smem, stream, a, o, l)
@@ -806,7 +808,8 @@ static int launch_bwd(BwdArgs a, OptArgs o, bool vec, hipStream_t stream) {
     if (ncol <= 1 && a.kit == BWD_KIT_SMALL) MI355_BWD_LAUNCH_SGD2();
     else if (ncol <= 1) MI355_BWD_LAUNCH_SGD(1); else if (ncol <= 2) MI355_BWD_LAUNCH_SGD(2); else MI355_BWD_LAUNCH_SGD(4);
   } else if (vec) {
-    if (ncol <= 1) MI355_BWD_LAUNCH(1, true); else if (ncol <= 2) MI355_BWD_LAUNCH(2, true); else MI355_BWD_LAUNCH(4, true);
+    if (ncol <= 1 && a.kit == BWD_KIT_SMALL) hipLaunchKernelGGL((bwd_kernel<WDT, GDT, 1, true, false, BWD_KIT_SMALL>), dim3(grid), dim3(256), smem, stream, a, o, l);
+    else if (ncol <= 1) MI355_BWD_LAUNCH(1, true); else if (ncol <= 2) MI355_BWD_LAUNCH(2, true); else MI355_BWD_LAUNCH(4, true);
   } else {
     if (ncol <= 1) MI355_BWD_LAUNCH(1, false); else if (ncol <= 2) MI355_BWD_LAUNCH(2, false);
     else if (ncol <= 4) MI355_BWD_LAUNCH(4, false); else MI355_BWD_LAUNCH(16, false);
