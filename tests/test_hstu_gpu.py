@@ -624,6 +624,39 @@ def test_mask_functions_on_the_exchange_backward_match_the_recomputing_passes_bi
             assert torch.equal(a_, b_), f"{mode}, {label}: {name} differs from the recomputing passes by {(a_.float() - b_.float()).abs().max().item()}"
 
 
+@pytest.mark.parametrize("rule", ["causal", "window"])
+def test_a_built_in_mask_written_as_functions_is_bit_identical_to_the_built_in_kernels(rule):
+    """A size-independent property at 4 x 2048 (the oracle takes minutes there): the causal mask written as a prefix function
+    (key j < i + 1) and a local window written as one band (i - wl <= j < i + wr + 1) give the outputs and gradients of the causal /
+    window kernels bit for bit -- same tiles, same MFMA order, the masked elements exact zeros either way (d = 256: two-wave-kind
+    forward, exchange backward on both sides; the function side in the dense exchange layout, the causal side in the triangular one)."""
+    from hstu import hstu_attn_varlen_func
+
+    rng = np.random.default_rng(11)
+    B, L, H, d = 4, 2048, 2, 256
+    T = B * L
+    mk = lambda lo, hi: torch.from_numpy(rng.uniform(lo, hi, (T, H, d)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    q, k, v, dout = mk(-1, 1), mk(-1, 1), mk(-1, 1), mk(0, 1)
+    cu = torch.arange(0, T + 1, L, dtype=torch.int32, device=DEV)
+    pos = (torch.arange(T, device=DEV) % L).to(torch.int32)
+    if rule == "causal":
+        f = (pos + 1).view(1, 1, T).contiguous()
+        window = (-1, 0)
+    else:
+        wl, wr = 700, 90
+        f = torch.stack([torch.zeros_like(pos), (pos - wl).clamp(min=0), pos + wr + 1]).view(1, 3, T).contiguous()
+        window = (wl, wr)
+    res = []
+    for kw in (dict(window_size=(-1, -1), func=f), dict(window_size=window)):
+        qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
+        out = hstu_attn_varlen_func(qq, kk, vv, cu, cu, None, None, L, L, L, None, None, alpha=1.0 / d ** 0.5, **kw)
+        out.backward(dout)
+        res.append((out.detach(), qq.grad, kk.grad, vv.grad))
+    for name, a_, b_ in zip(("out", "dq", "dk", "dv"), *res):
+        assert torch.equal(a_, b_), f"{rule}: {name} differs by {(a_.float() - b_.float()).abs().max().item()}"
+    assert float(res[0][1].float().abs().max()) > 0
+
+
 @pytest.mark.parametrize("d", [64, 256])
 def test_mask_functions_with_contextual_rows_vs_oracle(d):
     """`func` together with num_contexts (refused while the functions were a bias): contextual rows see the whole history whatever
