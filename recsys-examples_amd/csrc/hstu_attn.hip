@@ -1826,13 +1826,16 @@ __global__ void __launch_bounds__(512) hstu_fwd_q2_kernel(AttnArgs a) {
   // ---- one row block of the stream, seen from this wave's 64-row half
   // t_lo .. t_hi: the tiles that reach the half's rows; S waves: tiles below tf need no mask (a prefix of the stream under every
   // mask rule), tile t_dead has this wave's 32 keys past every row's reach (its P is zero, the O waves read the whole tile)
-  struct Blk { int m0, hrow0, n_beg, T, t_lo, t_hi, tf, t_dead, g_lo, g_hi; };   // g_lo .. g_hi (kFunc): tiles in the half's gap
+  // g_lo .. g_hi (kFunc): tiles in the half's gap; jt / js (kFunc): the BLOCK's gap -- from tile jt on the stream continues js keys
+  // further right (the tiles wholly between the block's prefix and its bands are not part of the stream: no DMA, no barrier)
+  struct Blk { int m0, hrow0, n_beg, T, t_lo, t_hi, tf, t_dead, g_lo, g_hi, jt, js; };
+  auto tile_n0 = [&](const Blk& k, int t) { int n = k.n_beg + kBN * t; if constexpr (kFunc) n += t >= k.jt ? k.js : 0; return n; };
   auto setup = [&](int rank) -> Blk {
     Blk k;
     k.m0 = row_block_of_rank(rank, nblk, a, b) * kBM;
     k.hrow0 = k.m0 + 64 * half;
     bool half_live = k.hrow0 < Lq;
-    k.g_lo = k.g_hi = 0;
+    k.g_lo = k.g_hi = 0; k.jt = 0x7fffffff; k.js = 0;
     const int last_row = dq + (k.m0 + kBM - 1 < Lq - 1 ? k.m0 + kBM - 1 : Lq - 1);
     int n_end = s.L;
     if (a.causal) {
@@ -1850,6 +1853,7 @@ __global__ void __launch_bounds__(512) hstu_fwd_q2_kernel(AttnArgs a) {
     if (kWin) h_end = band_key_end(a, h_last, h_end);
     int h_beg = kWin ? band_key_begin(a, dq + k.hrow0, kBN) : 0;     // (a multiple of the tile, >= n_beg)
     FuncExt hx{0x7fffffff, 0, 0x7fffffff, 0};
+    bool gap_half = false;
     if constexpr (kFunc) {
       if (a.wskip) {     // extents of the half's 64 rows and of the block's 128: one row per lane, no barrier
         auto ext64 = [&](int row0) {
@@ -1865,15 +1869,31 @@ __global__ void __launch_bounds__(512) hstu_fwd_q2_kernel(AttnArgs a) {
         if (hb >= h_end) half_live = false;
         else if (hb > h_beg) h_beg = (hb / kBN) * kBN;
         if (h_beg < k.n_beg) h_beg = k.n_beg;
-        if (half_live && hx.lo < hx.hi && hx.lo > hx.f0) {     // the tiles wholly between the prefix and the bands' hull
-          const int g0 = hx.f0 > k.n_beg ? (hx.f0 - k.n_beg + kBN - 1) / kBN : 0, g1 = hx.lo > k.n_beg ? (hx.lo - k.n_beg) / kBN : 0;
-          if (g0 < g1) { k.g_lo = g0; k.g_hi = g1; }
+        if (bx.lo < bx.hi && bx.lo > bx.f0) {     // the block's gap: tiles wholly inside [bx.f0, min(bx.lo, n_end)) leave the stream
+          const int lo_c = bx.lo < n_end ? bx.lo : n_end;
+          const int gs = bx.f0 > k.n_beg ? (bx.f0 - k.n_beg + kBN - 1) / kBN : 0, ge = lo_c > k.n_beg ? (lo_c - k.n_beg) / kBN : 0;
+          if (gs < ge) { k.jt = gs; k.js = (ge - gs) * kBN; }
         }
+        gap_half = half_live && hx.lo < hx.hi && hx.lo > hx.f0;
       }
     }
-    k.T = n_end > k.n_beg ? (n_end - k.n_beg + kBN - 1) / kBN : 0;
-    k.t_lo = (h_beg - k.n_beg) / kBN;
-    k.t_hi = h_end > k.n_beg ? (h_end - k.n_beg + kBN - 1) / kBN : 0;
+    if constexpr (!kFunc) {
+      k.T = n_end > k.n_beg ? (n_end - k.n_beg + kBN - 1) / kBN : 0;
+      k.t_lo = (h_beg - k.n_beg) / kBN;
+      k.t_hi = h_end > k.n_beg ? (h_end - k.n_beg + kBN - 1) / kBN : 0;
+    } else {
+      // key position -> tile index of the stream (a key inside the block's gap: the first tile behind it)
+      const int GA = k.n_beg + kBN * (k.jt < 0x7fffffff ? k.jt : 0), GB = GA + k.js;
+      auto t_floor = [&](int key) { if (k.js > 0 && key > GA) { if (key < GB) return k.jt; key -= k.js; } return (key - k.n_beg) / kBN; };
+      auto t_ceil = [&](int key) { if (k.js > 0 && key > GA) { if (key < GB) return k.jt; key -= k.js; } return (key - k.n_beg + kBN - 1) / kBN; };
+      k.T = n_end > k.n_beg ? t_ceil(n_end) : 0;
+      k.t_lo = t_floor(h_beg);
+      k.t_hi = h_end > k.n_beg ? t_ceil(h_end) : 0;
+      if (gap_half) {     // the tiles wholly between the HALF's prefix and its bands' hull that are still in the stream
+        const int g0 = hx.f0 > k.n_beg ? t_ceil(hx.f0) : 0, g1 = hx.lo > k.n_beg ? t_floor(hx.lo) : 0;
+        if (g0 < g1) { k.g_lo = g0; k.g_hi = g1; }
+      }
+    }
     if (k.t_hi > k.T) k.t_hi = k.T;
     if (!half_live || k.t_hi < k.t_lo) k.t_hi = k.t_lo;
     // mode 0 (no mask): causal -- no window, the half holds no contextual row, the wave's last key <= the half's first row and
@@ -1888,14 +1908,19 @@ __global__ void __launch_bounds__(512) hstu_fwd_q2_kernel(AttnArgs a) {
       const int tf2 = (a.wskip && half_live && num2 >= 0) ? num2 / kBN + 1 : 0;
       if (tf2 < k.tf) k.tf = tf2;
     }
-    k.t_dead = (sub == 1 && k.t_hi > k.t_lo && k.n_beg + kBN * (k.t_hi - 1) + 32 >= h_end) ? k.t_hi - 1 : -1;
+    if constexpr (kFunc) { if (k.tf > k.jt) k.tf = k.jt; }
+    if constexpr (kFunc) k.t_dead = (sub == 1 && k.t_hi > k.t_lo && tile_n0(k, k.t_hi - 1) + 32 >= h_end) ? k.t_hi - 1 : -1;
+    else k.t_dead = (sub == 1 && k.t_hi > k.t_lo && k.n_beg + kBN * (k.t_hi - 1) + 32 >= h_end) ? k.t_hi - 1 : -1;
     return k;
   };
   const Blk B0 = setup(rank0);
   Blk B1 = B0;
   if (two) B1 = setup(rank1);
   const int T0 = B0.T, T1 = two ? B1.T : 0, N = T0 + T1;     // items of the tile stream: block A's tiles, then block B's
-  auto item_n0 = [&](int i) { return i < T0 ? B0.n_beg + kBN * i : B1.n_beg + kBN * (i - T0); };
+  auto item_n0 = [&](int i) {
+    if constexpr (kFunc) return i < T0 ? tile_n0(B0, i) : tile_n0(B1, i - T0);
+    else return i < T0 ? B0.n_beg + kBN * i : B1.n_beg + kBN * (i - T0);
+  };
 #if HSTU_TIMING
   unsigned tsum[7] = {0, 0, 0, 0, 0, 0, 0};   // O: wait for own DMA | barrier | O: DMA issue | - | S: GEMM 1 | S: SiLU + hand-off, O: GEMM 2 | tiles
   const unsigned t_start = tick();
@@ -1968,7 +1993,8 @@ __global__ void __launch_bounds__(512) hstu_fwd_q2_kernel(AttnArgs a) {
         pdst[0] = z; pdst[64] = z; pdst[256] = z; pdst[320] = z;
         return;
       }
-      const int k0 = k.n_beg + kBN * t_in + 32 * sub;        // this wave's 32 keys
+      int k0 = k.n_beg + kBN * t_in + 32 * sub;        // this wave's 32 keys
+      if constexpr (kFunc) k0 = tile_n0(k, t_in) + 32 * sub;
       const uint16_t* Ks = Kring + (it & 1) * TENS + (32 * sub + l31) * ROWB;
       auto tile = [&](auto modec) {
         constexpr int kMode = decltype(modec)::value;
@@ -3697,6 +3723,8 @@ __device__ __forceinline__ void hstu_bwd_q_ds8_body(const BwdAttnArgs& g, unsign
   // kFunc: lane l holds the table entry of key block l (the query rows that reach it: which sub-tiles the dK pass wrote); the key
   // loop is clipped to what the block's / the wave's row groups reach (their extents: hstu_func_kvis_kernel's second table)
   int2 vis_all = make_int2(0, 0x7fffffff);
+  int gap_a = 0x7fffffff, gap_b = 0x7fffffff;     // kFunc: the key steps in [gap_a, gap_b) lie wholly between the block's prefix and its bands: not visited
+  int wgap_a = 0x7fffffff, wgap_b = 0x7fffffff;   // ... and the wave's own (its MFMAs skip them)
   if constexpr (kFunc) {
     if (kBM * lane < s.L) vis_all = func_kvis_of(g, s.start, b, h, kBM * lane);
     if (g.func_gext && a.wskip) {
@@ -3716,8 +3744,18 @@ __device__ __forceinline__ void hstu_bwd_q_ds8_body(const BwdAttnArgs& g, unsign
       if (we < w_end) w_end = we;
       if (bb > n_beg) n_beg = bb >= n_end ? n_end : (bb / BK) * BK;
       if (wb > w_beg) w_beg = wb >= 0x7fffff00 ? 0x7fffff00 : (wb / BK) * BK;
+      if (bx.lo < bx.hi && bx.lo > bx.f0) {
+        const int ga = ((bx.f0 + BK - 1) / BK) * BK, gb = (bx.lo / BK) * BK;
+        if (ga < gb) { gap_a = ga; gap_b = gb; }
+      }
+      if (wx.lo < wx.hi && wx.lo > wx.f0) {
+        const int ga = ((wx.f0 + BK - 1) / BK) * BK, gb = (wx.lo / BK) * BK;
+        if (ga < gb) { wgap_a = ga; wgap_b = gb; }
+      }
+      if (n_beg >= gap_a && n_beg < gap_b) n_beg = gap_b;
     }
   }
+  auto next_step = [&](int n) { n += BK; if constexpr (kFunc) { if (n >= gap_a && n < gap_b) n = gap_b; } return n; };
   f32x16_t acc[D / 32];
 #pragma unroll
   for (int dt = 0; dt < D / 32; ++dt)
@@ -3770,9 +3808,9 @@ __device__ __forceinline__ void hstu_bwd_q_ds8_body(const BwdAttnArgs& g, unsign
       *reinterpret_cast<u32x4_t*>(dSw + 1024 * t + 16 * lane + 8) = ds1[t];
     }
     __syncthreads();
-    if (n0 + BK < n_end) { if (!(HSTU_X8_PROBE & 4)) dma.issue(kbase, a.k_row, n0 + BK, s.L, smem + (BUF ^ 1) * TILE, lane); fetch_ds(n0 + BK); }
+    { const int nx = next_step(n0); if (nx < n_end) { if (!(HSTU_X8_PROBE & 4)) dma.issue(kbase, a.k_row, nx, s.L, smem + (BUF ^ 1) * TILE, lane); fetch_ds(nx); } }
     pin_agpr_2w(acc);
-    if (wave_live && n0 < w_end && n0 >= w_beg) {
+    if (wave_live && n0 < w_end && n0 >= w_beg && !(kFunc && n0 >= wgap_a && n0 < wgap_b)) {
       bf16x8_t sf[2 * NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -3786,7 +3824,7 @@ __device__ __forceinline__ void hstu_bwd_q_ds8_body(const BwdAttnArgs& g, unsign
         }
       gemm_x8<BUF>(acc, smem, sf, lane, hi);
     }
-    n0 += BK;
+    n0 = next_step(n0);
   };
   while (n0 < n_end) {
     step(std::integral_constant<int, 0>{});

@@ -523,16 +523,17 @@ def test_mask_functions_inside_the_kernels_match_their_dense_bias_statement_bit_
 
 
 @pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("shape", ["prefix_gap_band", "causal_like", "bands_only", "three_bounds", "one_bound", "blind_rows", "dense_pairs"])
+@pytest.mark.parametrize("shape", ["prefix_gap_band", "causal_like", "bands_only", "three_bounds", "one_bound", "blind_rows", "dense_pairs", "sink_window",
+                                   "sink_window_dense"])
 def test_mask_functions_on_the_two_wave_kind_forward_match_the_dense_bias_statement(shape, tdt):
     """round 6: at head dim 256 functions of up to two bands ride the 64-rows-per-wave forward (hstu_fwd_q2_kernel<.., kFunc>): tile
-    stream clipped to the block's extents, a half skipping the gap between its prefix and its bands, mask-free tiles below every
-    row's prefix.  Against the dense 0 / -1e9 bias statement of the same mask through the one-kind kernel, bit for bit
+    stream clipped to the block's extents and jumping over the tiles between the block's prefix and its bands, a half skipping what is
+    left of its own gap, mask-free tiles below every row's prefix; the backward on the P / dS exchange, its dQ pass with the same jump.  Against the dense 0 / -1e9 bias statement of the same mask through the one-kind kernel, bit for bit
     (forward and the three gradients), over sequences of several row blocks with ragged ends."""
     from hstu.hstu_attn_interface import HstuAttnFuncFunc, HstuAttnRabFunc, func_mask_bias
 
     rng = np.random.default_rng(len(shape))
-    lengths = np.array([1024, 1024, 1024]) if shape == "dense_pairs" else np.array([1500, 0, 700, 1, 130, 257])
+    lengths = np.array([1024, 1024, 1024]) if shape in ("dense_pairs", "sink_window_dense") else np.array([1500, 0, 700, 1, 130, 257])
     H, d = 2, 256
     off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
     T, B, N = int(off[-1]), lengths.size, int(lengths.max())
@@ -548,6 +549,8 @@ def test_mask_functions_on_the_two_wave_kind_forward_match_the_dense_bias_statem
         f[:, 0] = pos + 1; f[:, 1] = np.maximum(pos - 300, 0); f[:, 2] = np.maximum(pos - 200, 0); f[:, 3] = pos + 100; f[:, 4] = pos + 140
     elif shape == "bands_only":               # no prefix: a sliding window and a sink, as bands
         f[:, 1] = 0; f[:, 2] = r(0, 20); f[:, 3] = np.maximum(pos - r(100, 200), 0); f[:, 4] = pos + r(0, 3)
+    elif shape in ("sink_window", "sink_window_dense"):   # the first keys and a causal window: whole tiles between them leave the block's stream (the gap jump)
+        f[:, 0] = np.minimum(pos + 1, r(40, 70)); f[:, 1] = np.maximum(pos - r(150, 260), 0); f[:, 2] = pos + 1; f[:, 3] = f[:, 4] = 0
     elif shape == "three_bounds":
         f[:, 0] = r(0, 300); f[:, 1] = r(400, 600); f[:, 2] = f[:, 1] + r(0, 500)
     elif shape == "one_bound":

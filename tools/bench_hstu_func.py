@@ -10,6 +10,8 @@ from hstu import hstu_attn_varlen_func
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8); ap.add_argument("--seqlen", type=int, default=4096)
 ap.add_argument("--heads", type=int, default=4); ap.add_argument("--dim", type=int, default=256); ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--mask", default="causal_band", help="causal_band: j <= i plus a band further left (= the causal mask); sink_window: the first 64 keys + "
+                "a causal window of 256 (a gap of whole tiles between the two for most rows)")
 a = ap.parse_args()
 dev = torch.device("cuda")
 B, L, H, d = a.batch, a.seqlen, a.heads, a.dim
@@ -20,7 +22,10 @@ dout = torch.randn(T, H, d, device=dev, generator=g).to(torch.bfloat16)
 cu = torch.arange(0, T + 1, L, dtype=torch.int32, device=dev)
 pos = torch.arange(T, device=dev) % L
 f = torch.zeros(1, 3, T, dtype=torch.int32, device=dev)       # a causal prefix + one band further left: j <= i, or i - 1536 <= j < i - 1024
-f[0, 0] = (pos + 1).to(torch.int32); f[0, 1] = (pos - 1536).clamp(min=0).to(torch.int32); f[0, 2] = (pos - 1024).clamp(min=0).to(torch.int32)
+if a.mask == "sink_window":
+    f[0, 0] = torch.minimum(pos + 1, torch.full_like(pos, 64)).to(torch.int32); f[0, 1] = (pos - 255).clamp(min=0).to(torch.int32); f[0, 2] = (pos + 1).to(torch.int32)
+else:
+    f[0, 0] = (pos + 1).to(torch.int32); f[0, 1] = (pos - 1536).clamp(min=0).to(torch.int32); f[0, 2] = (pos - 1024).clamp(min=0).to(torch.int32)
 def step():
     out = hstu_attn_varlen_func(q, k, v, cu, cu, None, None, L, L, L, None, None, window_size=(-1, -1), alpha=1.0 / d ** 0.5, func=f)
     out.backward(dout)
@@ -39,5 +44,5 @@ for _ in range(a.reps):
     e[2].record(); torch.cuda.synchronize()
     tf += e[0].elapsed_time(e[1]); tb += e[1].elapsed_time(e[2])
 mode = "dense bias" if os.environ.get("MI355_HSTU_FUNC_DENSE") == "1" else "in the kernels"
-print(f"func {mode}: batch {B} x L {L}, H {H}, d {d}: forward {tf / a.reps:.3f} ms, backward {tb / a.reps:.3f} ms, peak extra memory of a step {peak / 2**20:.0f} MiB "
+print(f"func {mode} [{a.mask}]: batch {B} x L {L}, H {H}, d {d}: forward {tf / a.reps:.3f} ms, backward {tb / a.reps:.3f} ms, peak extra memory of a step {peak / 2**20:.0f} MiB "
       f"(q + k + v + dout = {4 * T * H * d * 2 / 2**20:.0f} MiB), checksum {float(out.float().abs().sum()):.6e}")
