@@ -22,7 +22,11 @@ dout = torch.randn(T, H, d, device=dev, generator=g).to(torch.bfloat16)
 cu = torch.arange(0, T + 1, L, dtype=torch.int32, device=dev)
 pos = torch.arange(T, device=dev) % L
 f = torch.zeros(1, 3, T, dtype=torch.int32, device=dev)       # a causal prefix + one band further left: j <= i, or i - 1536 <= j < i - 1024
-if a.mask == "sink_window":
+if a.mask == "sink":
+    f[0, 0] = torch.minimum(pos + 1, torch.full_like(pos, 64)).to(torch.int32)
+elif a.mask == "window_band":
+    f[0, 1] = (pos - 255).clamp(min=0).to(torch.int32); f[0, 2] = (pos + 1).to(torch.int32)
+elif a.mask == "sink_window":
     f[0, 0] = torch.minimum(pos + 1, torch.full_like(pos, 64)).to(torch.int32); f[0, 1] = (pos - 255).clamp(min=0).to(torch.int32); f[0, 2] = (pos + 1).to(torch.int32)
 else:
     f[0, 0] = (pos + 1).to(torch.int32); f[0, 1] = (pos - 1536).clamp(min=0).to(torch.int32); f[0, 2] = (pos - 1024).clamp(min=0).to(torch.int32)
