@@ -394,6 +394,7 @@ def hstu_varlen_fwd_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_
     out = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
     B = cu_seqlens_q.numel() - 1
     page_size = kv_cache.size(2) if kv_cache is not None else 0
+    _fn("mi355_hstu_attn_fwd_hint_tokens", q)(int(q.shape[0]))   # (dense batches take the paired-row-block kernel)
     check(_fn("mi355_hstu_attn_fwd_kv_func", q)(ptr(q), ptr(k), ptr(v), ptr(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
                                                 q.stride(1), k.stride(1), v.stride(1), out.stride(1), ptr(cu_seqlens_q),
                                                 ptr(cu_seqlens_k), B, H, D, int(max_seqlen_q), int(max_seqlen_k),
