@@ -64,3 +64,19 @@ def rendezvous_file():
     taken by any outgoing connection before the TCPStore listens on it -- one GPU-suite run of round 6 lost 14 tests to EADDRINUSE.)"""
     import os, tempfile, uuid
     return "file://" + os.path.join(tempfile.gettempdir(), "mi355_pg_" + uuid.uuid4().hex)
+
+
+import zlib
+
+import pytest
+
+
+@pytest.fixture(autouse=True)
+def _seed_torch_per_test(request):
+    """Every test starts from a torch RNG state derived from its own name (CPU and, where there is one, the GPU): tests that draw
+    their inputs with torch's global generator see the same data in every run and in every order (round 6: one full-suite run in
+    ~15 lost a window test whose unseeded inputs landed 0.1 % past its tolerance)."""
+    import torch
+
+    torch.manual_seed(zlib.crc32(request.node.nodeid.encode()) & 0x7fffffff)
+    yield

@@ -1079,7 +1079,7 @@ def test_local_window_over_delta_q_and_paged_keys(d, window):
     out_a = hstu_attn_varlen_func(q, k_full, v_full, cuq, cuk, None, None, int(qlen.max()), int(klen.max()), scaling, None, None,
                                   window_size=window, alpha=alpha)
     err = np.abs(out_a.float().cpu().numpy() - ref).max()
-    assert err <= 6e-3 * max(np.abs(ref).max(), 1e-3) + 1e-6, err
+    assert err <= 8e-3 * max(np.abs(ref).max(), 1e-3) + 1e-6, err     # (two bf16 roundings -- P and the output -- of values near the maximum)
     # (b) the same keys from the paged cache
     npages = int(((cachelen + P - 1) // P).sum())
     cache = torch.zeros(npages + 2, 2, P, H, d, dtype=torch.bfloat16, device=DEV)
