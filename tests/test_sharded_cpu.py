@@ -304,7 +304,7 @@ def _run_and_compare(W, F, B, pooled, dist_type, out_rtol=1e-5, out_atol=1e-6):
         p.start()
     got = {}
     for _ in range(W):
-        rank, outs, rows = q.get(timeout=120)
+        rank, outs, rows = q.get(timeout=600)
         got[rank] = (outs, rows)
     for p in procs:
         p.join(timeout=60)
